@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""
+make_golden.py -- regenerate tests/golden/ in the BUILD container (needs /root/reference).
+
+What it does, per case:
+  1. copies the reference's test FASTA inputs (data files) into tests/golden/fasta/ ;
+  2. sketches them with the C oracle (oracle/_build/mx_oracle, `--pos --seq`) into
+     tests/golden/cases/<case>/<fasta>.k<k>.w<w>.tsv ;
+  3. imports the reference's OWN bin/ntjoin_utils.py and bin/ntjoin.py from /root/reference/bin (with a
+     small stand-in for the python-igraph container, which is not installed here), runs
+     read_minimizers -> filter_minimizers -> build_graph -> print_graph on those TSVs in the
+     reference's call order (bin/ntjoin.py:178-204, bin/ntjoin_assemble.py:799-807), and dumps what they
+     return to tests/golden/cases/<case>/reference.json and reference.mx.dot .
+
+The reference's source never enters this repository: only its outputs do.  Nothing in tests/, bench.py
+or the package reads /root/reference at run time; this script is the only place that does.
+"""
+import contextlib
+import io
+import json
+import os
+import shutil
+import subprocess
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+ORACLE_BIN = os.path.join(REPO, "oracle", "_build", "mx_oracle")
+
+# (case name, k, w, variant, [(ref fasta, weight)...], (target fasta, weight))
+CASES = [
+    ("f-f_w1000", 32, 1000, "v2", [("ref.fa", 2)], ("scaf.f-f.fa", 1)),
+    ("f-f_w1000_v1", 32, 1000, "v1", [("ref.fa", 2)], ("scaf.f-f.fa", 1)),
+    ("f-f_w100_config1", 32, 100, "v2", [("ref.fa", 2)], ("scaf.f-f.fa", 1)),
+    ("f-f_termN_w1000", 32, 1000, "v2", [("ref.fa", 2)], ("scaf.f-f.termN.fa", 1)),
+    ("f-f_termN_unassigned_w1000", 32, 1000, "v2", [("ref.fa", 2)], ("scaf.f-f.termN.unassigned.fa", 1)),
+    ("f-r_w1000", 32, 1000, "v2", [("ref.fa", 2)], ("scaf.f-r.fa", 1)),
+    ("r-f_w1000", 32, 1000, "v2", [("ref.fa", 2)], ("scaf.r-f.fa", 1)),
+    ("r-r_w1000", 32, 1000, "v2", [("ref.fa", 2)], ("scaf.r-r.fa", 1)),
+    ("gap-dist_w500", 32, 500, "v2", [("ref.multiple.fa", 2)], ("scaf.multiple.fa", 1)),
+    ("regions-ff-rr_w500", 32, 500, "v2", [("ref.multiple.fa", 2)], ("scaf.misassembled.f-f.r-r.fa", 1)),
+    ("regions-fr-rf_w500", 32, 500, "v2", [("ref.multiple.fa", 2)], ("scaf.misassembled.f-r.r-f.fa", 1)),
+    ("f-f-f_w1000", 32, 1000, "v2", [("ref.fa", 2), ("scaf.f-f.copy.fa", 2)], ("scaf.f-f.fa", 1)),
+    ("f-f-f_w100_weights", 32, 100, "v2", [("ref.fa", 0.1), ("scaf.f-f.copy.fa", 0.2)], ("scaf.f-f.fa", 1.5)),
+    ("overlap_k15_w10", 15, 10, "v2", [("ref.fa", 1)], ("scaf.f-f.overlapping.fa", 1)),
+    ("more_seqs_pieces_w500", 32, 500, "v2", [("scaf.more_seqs.fa", 2)], ("more_seqs.pieces.fa", 1)),
+    ("synth_w100", 32, 100, "v2", [("synth.ref.fa", 2)], ("synth.tgt.fa", 1)),
+    ("synth_w1000", 32, 1000, "v2", [("synth.ref.fa", 2)], ("synth.tgt.fa", 1)),
+    ("synth3_w50", 32, 50, "v2", [("synth.ref.fa", 2), ("synth.ref2.fa", 1.5)], ("synth.tgt.fa", 1)),
+    ("synth_k15_w60", 15, 60, "v2", [("synth.ref.fa", 1)], ("synth.tgt.fa", 1)),
+    ("synth_v1_w200", 32, 200, "v1", [("synth.ref2.fa", 3)], ("synth.ref.fa", 1)),
+]
+
+
+def install_igraph_standin():
+    """python-igraph is not installed here.  The reference only uses it as a container on this path
+    (Graph(), add_vertices, add_edges, get_eid, es()[attr]=list, iteration over vs()/es())."""
+    class _Vertex(dict):
+        def __init__(self, index, name):
+            super().__init__(name=name)
+            self.index = index
+
+    class _Edge(dict):
+        def __init__(self, index, source, target):
+            super().__init__()
+            self.index, self.source, self.target = index, source, target
+
+    class _EdgeSeq(list):
+        def __setitem__(self, key, values):
+            if isinstance(key, str):
+                assert len(values) == len(self)
+                for e, v in zip(self, values):
+                    dict.__setitem__(e, key, v)
+            else:
+                list.__setitem__(self, key, values)
+
+    class _VertexSeq(list):
+        def find(self, name):
+            return next(v for v in self if v["name"] == name)
+
+    class Graph:
+        def __init__(self):
+            self._vs, self._es, self._idx, self._eid = _VertexSeq(), _EdgeSeq(), {}, {}
+
+        def add_vertices(self, names):
+            for n in names:
+                self._idx[n] = len(self._vs)
+                self._vs.append(_Vertex(len(self._vs), n))
+
+        def add_edges(self, pairs):
+            for s, t in pairs:
+                a, b = self._idx[s], self._idx[t]
+                lo, hi = min(a, b), max(a, b)  # igraph reports an undirected edge as (lower id, higher id)
+                self._eid[(lo, hi)] = len(self._es)
+                self._es.append(_Edge(len(self._es), lo, hi))
+
+        def get_eid(self, s, t):
+            a, b = self._idx[s], self._idx[t]
+            return self._eid[(min(a, b), max(a, b))]
+
+    # `graph.vs[index]['name']` and `graph.vs.find(name)` are attribute-style accesses in ntjoin_utils
+    Graph.vs = property(lambda self: _CallableSeq(self._vs))
+    Graph.es = property(lambda self: _CallableSeq(self._es))
+
+    class _CallableSeq:
+        def __init__(self, seq):
+            self._seq = seq
+
+        def __call__(self):
+            return self._seq
+
+        def __getitem__(self, i):
+            return self._seq[i]
+
+        def __iter__(self):
+            return iter(self._seq)
+
+        def find(self, name):
+            return self._seq.find(name)
+
+    mod = types.ModuleType("igraph")
+    mod.Graph = Graph
+    sys.modules["igraph"] = mod
+
+
+def run_reference(case_dir, ref_tsvs, ref_weights, target_tsv, target_weight, prefix):
+    sys.path.insert(0, os.path.join(REF, "bin"))
+    import ntjoin_utils  # noqa: the reference's own module
+    import ntjoin        # noqa: the reference's own module
+    cwd = os.getcwd()
+    os.chdir(case_dir)
+    try:
+        args = types.SimpleNamespace(p=prefix, FILES=list(ref_tsvs), t=1, s=target_tsv, l=float(target_weight))
+        nj = ntjoin.Ntjoin(args)
+        nj.weights_list = [float(x) for x in ref_weights]            # ntjoin_assemble.py:788-797,811
+        with contextlib.redirect_stdout(io.StringIO()):
+            nj.load_minimizers()                                     # ntjoin.py:178-186
+            # the four lines of ntjoin_assemble.py:803-807 (that module is not importable here:
+            # it needs pybedtools / pymannkendall / btllib)
+            info, mxs = ntjoin_utils.read_minimizers(args.s)
+            nj.list_mx_info[args.s] = info
+            nj.list_mxs[args.s] = mxs
+            nj.weights[args.s] = args.l
+            filtered = ntjoin_utils.filter_minimizers(nj.list_mxs)   # ntjoin.py:198
+            nj.make_minimizer_graph()                                # ntjoin.py:189-204 (writes <prefix>.mx.dot)
+        g = nj.graph
+        names = [v["name"] for v in g.vs()]
+        edges = []
+        for e in g.es():
+            edges.append([names[e.source], names[e.target], list(e["support"]), e["weight"]])
+        return {
+            "assemblies": list(nj.list_mx_info.keys()),
+            "weights": nj.weights,
+            "mx_info": {a: {mx: [c, p] for mx, (c, p) in d.items()} for a, d in nj.list_mx_info.items()},
+            "mxs": nj.list_mxs,
+            "filtered": filtered,
+            "vertices": sorted(names, key=int),
+            "edges": edges,
+        }
+    finally:
+        os.chdir(cwd)
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("make_golden.py needs /root/reference (build container only)")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle")])
+    install_igraph_standin()
+    fasta_dir = os.path.join(HERE, "fasta")
+    os.makedirs(fasta_dir, exist_ok=True)
+    # the reference's own expected outputs for this path (data files its tests hold)
+    exp_dir = os.path.join(HERE, "reference_expected_outputs")
+    os.makedirs(exp_dir, exist_ok=True)
+    for f in ("ref.fa.k32.w1000.tsv", "scaf.f-f.fa.k32.w1000.tsv", "f-f_test.mx.dot"):
+        shutil.copyfile(os.path.join(REF, "tests", "expected_outputs", f), os.path.join(exp_dir, f))
+    # synthetic fixtures (ours) need scaf.more_seqs.fa in place first
+    src = os.path.join(fasta_dir, "scaf.more_seqs.fa")
+    if not os.path.exists(src):
+        shutil.copyfile(os.path.join(REF, "tests", "scaf.more_seqs.fa"), src)
+    subprocess.check_call([sys.executable, os.path.join(HERE, "make_synth_fasta.py")])
+    index = []
+    for name, k, w, variant, refs, target in CASES:
+        case_dir = os.path.join(HERE, "cases", name)
+        shutil.rmtree(case_dir, ignore_errors=True)
+        os.makedirs(case_dir)
+        tsvs = []
+        for fa, _ in refs + [target]:
+            dst = os.path.join(fasta_dir, fa)
+            if not os.path.exists(dst):
+                shutil.copyfile(os.path.join(REF, "tests", fa), dst)  # a data file the reference's tests hold
+            tsv = f"{fa}.k{k}.w{w}.tsv"
+            subprocess.check_call([ORACLE_BIN, "-k", str(k), "-w", str(w), "--variant", variant,
+                                   "--pos", "--seq", "-o", os.path.join(case_dir, tsv), dst])
+            tsvs.append(tsv)
+        prefix = "out"
+        result = run_reference(case_dir, tsvs[:-1], [wt for _, wt in refs], tsvs[-1], target[1], prefix)
+        os.replace(os.path.join(case_dir, prefix + ".mx.dot"), os.path.join(case_dir, "reference.mx.dot"))
+        meta = {"name": name, "k": k, "w": w, "variant": variant,
+                "refs": [{"fasta": fa, "weight": wt, "tsv": t} for (fa, wt), t in zip(refs, tsvs[:-1])],
+                "target": {"fasta": target[0], "weight": target[1], "tsv": tsvs[-1]}}
+        with open(os.path.join(case_dir, "reference.json"), "w", encoding="utf-8") as fh:
+            json.dump({"meta": meta, "reference": result}, fh, indent=0, sort_keys=True)
+        index.append(meta)
+        print(f"{name}: |V|={len(result['vertices'])} |E|={len(result['edges'])}")
+    with open(os.path.join(HERE, "cases", "index.json"), "w", encoding="utf-8") as fh:
+        json.dump(index, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
