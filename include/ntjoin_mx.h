@@ -1,0 +1,195 @@
+/*
+ * ntjoin_mx.h -- C-ABI of libntjoin_mx.so: the MI355X-native minimizer-sketch + minimizer-graph engine
+ * that drops in for ntJoin's hot path (sketch -> uniqueness -> intersection -> adjacency edges).
+ *
+ * Plain C linkage, plain pointers and sizes; no C++/torch types cross this boundary.  Every function
+ * returns 0 on success or a negative MXG_E* code; mxg_last_error(h) then holds a message.  The library
+ * owns every buffer it returns (valid until the next call that recomputes it, or mxg_destroy);
+ * a handle is not thread-safe, distinct handles are.  All device work runs on the handle's HIP stream
+ * and each call blocks until its results are usable.  There is NO CPU fallback: without a usable HIP
+ * device every compute entry point fails with MXG_EDEVICE.
+ *
+ * Reference interfaces replaced (file:line under the reference tree):
+ *   mxg_add_assembly_fasta + mxg_sketch + mxg_write_tsv
+ *        = `indexlr --seq --long --pos -k K -w W -t T X.fa > X.fa.kK.wW.tsv`          ntJoin:204-205
+ *          (and its twin run_indexlr()                                                  bin/ntjoin_utils.py:195-202)
+ *   mxg_add_assembly_tsv            = the parse half of read_minimizers()               bin/ntjoin_utils.py:167-185
+ *   mxg_build_graph (uniqueness)    = the dup_mxs logic of read_minimizers()            bin/ntjoin_utils.py:182-193
+ *   mxg_build_graph (intersection)  = filter_minimizers()                               bin/ntjoin_utils.py:152-165
+ *   mxg_build_graph (edges/weights) = build_graph(), calc_total_weight()                bin/ntjoin_utils.py:83-141,54-56
+ *   assembly order = refs (CLI order) then target, weights as double                    bin/ntjoin.py:178-186,
+ *                                                                                       bin/ntjoin_assemble.py:788-807
+ *   mxg_write_dot                   = Ntjoin.print_graph()                              bin/ntjoin.py:25-62
+ */
+#ifndef NTJOIN_MX_H
+#define NTJOIN_MX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MXG_ABI_VERSION 1
+
+/* error codes */
+#define MXG_OK 0
+#define MXG_EINVAL (-1)   /* bad argument / bad state                                   */
+#define MXG_EIO (-2)      /* file could not be read / written / parsed                  */
+#define MXG_ENOMEM (-3)   /* host or device allocation failed                           */
+#define MXG_EDEVICE (-4)  /* no usable HIP device, or a HIP call / kernel failed        */
+#define MXG_ELIMIT (-5)   /* an engine limit was exceeded (see mxg_last_error)          */
+
+/* canonical-hash variant */
+#define MXG_VARIANT_V2_SUM 0 /* min_hash = fwd+rev: current btllib; default                */
+#define MXG_VARIANT_V1_MIN 1 /* min_hash = min(fwd,rev): what the reference's stale golden TSVs hold */
+
+/* mxg_config.flags */
+#define MXG_FLAG_DENSE_ONLY 0x1u  /* disable the sparse-candidate fast path (every k-mer is a candidate) */
+#define MXG_FLAG_DROP_SEQ 0x2u    /* do not keep FASTA text on the host (mxg_write_tsv then decodes k-mers from the packed bases: upper-case) */
+#define MXG_FLAG_TIMING 0x4u      /* bracket each kernel family with HIP events (read back through mxg_stats) */
+
+#define MXG_MAX_ASSEMBLIES 32
+
+typedef struct mxg_handle mxg_handle;
+
+typedef struct mxg_config {
+    uint32_t struct_size;  /* = sizeof(mxg_config); lets the struct grow compatibly          */
+    uint32_t k;            /* k-mer size, 1..1024  (ntJoin: k=32, ntJoin:36)                 */
+    uint32_t w;            /* window size in k-mers, >= 1 (ntJoin: w=1000, ntJoin:33)        */
+    uint32_t variant;      /* MXG_VARIANT_*                                                   */
+    int32_t device;        /* HIP device ordinal, -1 = current device                         */
+    uint32_t flags;        /* MXG_FLAG_*                                                      */
+    void *stream;          /* hipStream_t to launch on; NULL = the library creates its own    */
+    uint32_t cand_per_window; /* sparse path: expected candidates per window (0 = default 12) */
+    uint32_t reserved[5];
+} mxg_config;
+
+/* host view of one assembly's ordered sketch: minimizer i is (out_hash[i], pos[i], record[i], strand[i]);
+   entries are sorted by (record, pos); record indexes the assembly's FASTA records in input order. */
+typedef struct mxg_sketch_view {
+    uint64_t n;
+    const uint64_t *out_hash;
+    const uint32_t *pos;
+    const uint32_t *record;
+    const uint8_t *forward;      /* 1 = forward hash <= reverse hash ('+' under --strand) */
+    uint64_t n_records;
+    const uint64_t *record_first; /* n_records+1 offsets into the arrays above (CSR by record) */
+} mxg_sketch_view;
+
+/* device view (HBM pointers) of the same arrays, for collectives run by the caller (RCCL all-gather) */
+typedef struct mxg_sketch_dview {
+    uint64_t n;
+    const void *out_hash; /* uint64[n] */
+    const void *pos;      /* uint32[n] */
+    const void *record;   /* uint32[n] */
+    const void *forward;  /* uint8[n]  */
+} mxg_sketch_dview;
+
+/* per-minimizer classification after mxg_build_graph (parallel to mxg_sketch_view arrays) */
+#define MXG_MX_UNIQUE 0x1u /* hash occurs exactly once in its assembly  -> key of mx_info (ntjoin_utils.py:187)  */
+#define MXG_MX_SHARED 0x2u /* ... and exactly once in EVERY assembly    -> vertex of the minimizer graph          */
+#define MXG_MX_INALL 0x4u  /* hash occurs (any number of times) in EVERY assembly: filter_minimizers' set rule (:152-165) */
+
+typedef struct mxg_graph_view {
+    uint32_t n_assemblies;
+    uint64_t n_vertices;          /* |intersection|                                                     */
+    const uint64_t *vertex_hash;  /* [n_vertices] out_hash = igraph vertex `name` (decimal string there) */
+    /* [a * n_vertices + v]: where vertex v lies in assembly a  (= list_mx_info[a][name], ntjoin.py:183)  */
+    const uint32_t *vertex_pos;
+    const uint32_t *vertex_record;
+    uint64_t n_edges;
+    const uint32_t *edge_u;       /* [n_edges] vertex index, first-seen orientation (ntjoin_utils.py:101-108) */
+    const uint32_t *edge_v;
+    const uint32_t *edge_support; /* bit a set = assembly a (order of mxg_add_*) supports the edge      */
+    const double *edge_weight;    /* sum of weights over support, in assembly order (ntjoin_utils.py:54-56) */
+} mxg_graph_view;
+
+typedef struct mxg_stats {
+    uint32_t struct_size;
+    uint32_t n_assemblies;
+    uint64_t bases;            /* sum of record lengths over all assemblies                     */
+    uint64_t kmers;            /* valid k-mers hashed (records with >= w valid k-mers)          */
+    uint64_t minimizers;       /* sum of sketch sizes                                           */
+    uint64_t candidates;       /* sparse path: candidates that reached the resolve kernel       */
+    uint64_t dense_kmers;      /* k-mers re-processed by the dense (gap / fallback) path        */
+    uint64_t unique;           /* minimizers flagged MXG_MX_UNIQUE                              */
+    uint64_t vertices, edges;
+    /* HIP-event times in ms, accumulated since mxg_create / mxg_reset_timers (MXG_FLAG_TIMING)  */
+    double ms_hash;            /* hash + candidate kernels (the dominant kernel family)         */
+    double ms_resolve;         /* window arg-min resolve + compaction + emit                    */
+    double ms_graph;           /* uniqueness, intersection, vertex ids, edges                   */
+    uint64_t launches_hash;    /* number of hash-kernel launches in ms_hash                     */
+    uint64_t hash_kernel_bases;/* bases covered by those launches                               */
+    double reserved[8];
+} mxg_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+int mxg_abi_version(void);
+int mxg_create(const mxg_config *cfg, mxg_handle **out);
+void mxg_destroy(mxg_handle *h);
+const char *mxg_last_error(const mxg_handle *h); /* h may be NULL: error of the last failed mxg_create */
+
+/* ---- assemblies: call in the reference's order, references first (CLI order), target last -----
+   every mxg_add_assembly_* returns the new assembly's index (>= 0) on success, a negative code on failure */
+/* FASTA file (plain text; `>id comment`, multi-line, any case; non-ACGTU bytes invalidate k-mers). */
+int mxg_add_assembly_fasta(mxg_handle *h, const char *name, double weight, const char *fasta_path);
+/* Records already in host memory: record r is ascii[offsets[r] .. offsets[r+1]) with id ids[r]. */
+int mxg_add_assembly_buffers(mxg_handle *h, const char *name, double weight, const uint8_t *ascii,
+                             const uint64_t *offsets, const char *const *ids, uint64_t n_records);
+/* Bases already resident in HBM, 2-bit packed (A=0,C=1,G=2,T=3; base i in bits 2*(i%16).. of 32-bit word
+   i/16), no invalid bases.  record r starts at base rec_start[r] (a multiple of 16) and has rec_len[r]
+   bases; the buffer must be readable 1 KiB past the last base.  d_packed is borrowed, not copied.
+   ids may be NULL (records are then named "0","1",...). */
+int mxg_add_assembly_packed_device(mxg_handle *h, const char *name, double weight, const void *d_packed,
+                                   const uint64_t *rec_start, const uint64_t *rec_len,
+                                   const char *const *ids, uint64_t n_records);
+/* A sketch computed elsewhere: an indexlr TSV (`id \t hash:pos[:seq] ...`), parsed as read_minimizers does. */
+int mxg_add_assembly_tsv(mxg_handle *h, const char *name, double weight, const char *tsv_path);
+/* ... or arrays (sorted by record, then pos); record_ids has n_records entries. */
+int mxg_add_assembly_minimizers(mxg_handle *h, const char *name, double weight, const uint64_t *out_hash,
+                                const uint32_t *pos, const uint32_t *record, uint64_t n,
+                                const char *const *record_ids, uint64_t n_records);
+int mxg_num_assemblies(const mxg_handle *h);
+const char *mxg_assembly_name(const mxg_handle *h, int assembly);
+/* id of record r of an assembly (first whitespace-delimited token of the FASTA header) */
+const char *mxg_record_id(const mxg_handle *h, int assembly, uint64_t record);
+uint64_t mxg_record_length(const mxg_handle *h, int assembly, uint64_t record);
+
+/* ---- sketch stage (replaces indexlr) --------------------------------------------------------- */
+int mxg_sketch(mxg_handle *h, int assembly /* -1 = every assembly that has bases and no sketch yet */);
+int mxg_get_sketch(mxg_handle *h, int assembly, mxg_sketch_view *out);
+int mxg_get_sketch_device(mxg_handle *h, int assembly, mxg_sketch_dview *out);
+/* Replace an assembly's sketch by device arrays (e.g. the concatenation an all-gather produced);
+   entries must be sorted by (record, pos).  The arrays are copied. */
+int mxg_set_sketch_device(mxg_handle *h, int assembly, const void *d_out_hash, const void *d_pos,
+                          const void *d_record, const void *d_forward, uint64_t n);
+/* indexlr TSV: `id \t out_hash[:pos][:+|-][:kmer] ( out_hash...)* \n`, one line per record, input order.
+   path "-" = stdout. */
+int mxg_write_tsv(mxg_handle *h, int assembly, const char *path, int with_pos, int with_strand,
+                  int with_seq);
+
+/* ---- graph stage (replaces read_minimizers' uniqueness, filter_minimizers, build_graph) -------- */
+int mxg_build_graph(mxg_handle *h);
+/* flags[i] (MXG_MX_*) for minimizer i of the assembly's sketch */
+int mxg_get_mx_flags(mxg_handle *h, int assembly, const uint8_t **flags, uint64_t *n);
+int mxg_get_graph(mxg_handle *h, mxg_graph_view *out);
+/* `.mx.dot` as Ntjoin.print_graph writes it (HEAD syntax); vertex/edge line order: vertices in first-assembly
+   order, edges in first-seen order (the reference's own order is unspecified: python set order). */
+int mxg_write_dot(mxg_handle *h, const char *path);
+
+/* ---- text helpers used by the writers (host only; usable without a device) --------------------- */
+/* python repr() of a float / of a str, as Ntjoin.print_graph's f-strings produce them.  Returns the length
+   written (excluding the NUL), or the length needed if it exceeds cap. */
+size_t mxg_py_repr_double(double v, char *buf, size_t cap);
+size_t mxg_py_repr_str(const char *s, char *buf, size_t cap);
+
+/* ---- introspection ----------------------------------------------------------------------------- */
+int mxg_get_stats(mxg_handle *h, mxg_stats *out);
+int mxg_reset_timers(mxg_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTJOIN_MX_H */

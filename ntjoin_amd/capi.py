@@ -1,0 +1,114 @@
+"""ctypes binding of libntjoin_mx.so (C-ABI: include/ntjoin_mx.h).  No compute happens in Python."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libntjoin_mx.so")
+
+MXG_OK, MXG_EINVAL, MXG_EIO, MXG_ENOMEM, MXG_EDEVICE, MXG_ELIMIT = 0, -1, -2, -3, -4, -5
+VARIANT_V2_SUM, VARIANT_V1_MIN = 0, 1
+FLAG_DENSE_ONLY, FLAG_DROP_SEQ, FLAG_TIMING = 0x1, 0x2, 0x4
+MX_UNIQUE, MX_SHARED, MX_INALL = 0x1, 0x2, 0x4
+ABI_VERSION = 1
+
+SYMBOLS = [
+    "mxg_abi_version", "mxg_create", "mxg_destroy", "mxg_last_error",
+    "mxg_add_assembly_fasta", "mxg_add_assembly_buffers", "mxg_add_assembly_packed_device",
+    "mxg_add_assembly_tsv", "mxg_add_assembly_minimizers", "mxg_num_assemblies", "mxg_assembly_name",
+    "mxg_record_id", "mxg_record_length",
+    "mxg_sketch", "mxg_get_sketch", "mxg_get_sketch_device", "mxg_set_sketch_device", "mxg_write_tsv",
+    "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_write_dot",
+    "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("k", C.c_uint32), ("w", C.c_uint32), ("variant", C.c_uint32),
+                ("device", C.c_int32), ("flags", C.c_uint32), ("stream", C.c_void_p),
+                ("cand_per_window", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+
+
+class SketchView(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("out_hash", C.POINTER(C.c_uint64)), ("pos", C.POINTER(C.c_uint32)),
+                ("record", C.POINTER(C.c_uint32)), ("forward", C.POINTER(C.c_uint8)),
+                ("n_records", C.c_uint64), ("record_first", C.POINTER(C.c_uint64))]
+
+
+class SketchDView(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("out_hash", C.c_void_p), ("pos", C.c_void_p), ("record", C.c_void_p),
+                ("forward", C.c_void_p)]
+
+
+class GraphView(C.Structure):
+    _fields_ = [("n_assemblies", C.c_uint32), ("n_vertices", C.c_uint64),
+                ("vertex_hash", C.POINTER(C.c_uint64)), ("vertex_pos", C.POINTER(C.c_uint32)),
+                ("vertex_record", C.POINTER(C.c_uint32)), ("n_edges", C.c_uint64),
+                ("edge_u", C.POINTER(C.c_uint32)), ("edge_v", C.POINTER(C.c_uint32)),
+                ("edge_support", C.POINTER(C.c_uint32)), ("edge_weight", C.POINTER(C.c_double))]
+
+
+class Stats(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_assemblies", C.c_uint32), ("bases", C.c_uint64),
+                ("kmers", C.c_uint64), ("minimizers", C.c_uint64), ("candidates", C.c_uint64),
+                ("dense_kmers", C.c_uint64), ("unique", C.c_uint64), ("vertices", C.c_uint64),
+                ("edges", C.c_uint64), ("ms_hash", C.c_double), ("ms_resolve", C.c_double),
+                ("ms_graph", C.c_double), ("launches_hash", C.c_uint64), ("hash_kernel_bases", C.c_uint64),
+                ("reserved", C.c_double * 8)]
+
+
+_lib = None
+
+
+def load():
+    """Load libntjoin_mx.so.  There is no fallback: a missing/unloadable library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C ntjoin_amd/csrc`). ntjoin_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, cp, u64, i32 = C.c_void_p, C.c_char_p, C.c_uint64, C.c_int
+    L.mxg_abi_version.restype = i32
+    L.mxg_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.mxg_destroy.argtypes = [vp]
+    L.mxg_destroy.restype = None
+    L.mxg_last_error.argtypes = [vp]
+    L.mxg_last_error.restype = cp
+    L.mxg_add_assembly_fasta.argtypes = [vp, cp, C.c_double, cp]
+    L.mxg_add_assembly_buffers.argtypes = [vp, cp, C.c_double, vp, C.POINTER(u64), C.POINTER(cp), u64]
+    L.mxg_add_assembly_packed_device.argtypes = [vp, cp, C.c_double, vp, C.POINTER(u64), C.POINTER(u64),
+                                                 C.POINTER(cp), u64]
+    L.mxg_add_assembly_tsv.argtypes = [vp, cp, C.c_double, cp]
+    L.mxg_add_assembly_minimizers.argtypes = [vp, cp, C.c_double, vp, vp, vp, u64, C.POINTER(cp), u64]
+    L.mxg_num_assemblies.argtypes = [vp]
+    L.mxg_assembly_name.argtypes = [vp, i32]
+    L.mxg_assembly_name.restype = cp
+    L.mxg_record_id.argtypes = [vp, i32, u64]
+    L.mxg_record_id.restype = cp
+    L.mxg_record_length.argtypes = [vp, i32, u64]
+    L.mxg_record_length.restype = u64
+    L.mxg_sketch.argtypes = [vp, i32]
+    L.mxg_get_sketch.argtypes = [vp, i32, C.POINTER(SketchView)]
+    L.mxg_get_sketch_device.argtypes = [vp, i32, C.POINTER(SketchDView)]
+    L.mxg_set_sketch_device.argtypes = [vp, i32, vp, vp, vp, vp, u64]
+    L.mxg_write_tsv.argtypes = [vp, i32, cp, i32, i32, i32]
+    L.mxg_build_graph.argtypes = [vp]
+    L.mxg_get_mx_flags.argtypes = [vp, i32, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(u64)]
+    L.mxg_get_graph.argtypes = [vp, C.POINTER(GraphView)]
+    L.mxg_write_dot.argtypes = [vp, cp]
+    L.mxg_py_repr_double.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
+    L.mxg_py_repr_double.restype = C.c_size_t
+    L.mxg_py_repr_str.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.mxg_py_repr_str.restype = C.c_size_t
+    L.mxg_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.mxg_reset_timers.argtypes = [vp]
+    for name in SYMBOLS:
+        fn = getattr(L, name)  # raises AttributeError if the symbol is not exported
+        if fn.restype is C.c_int and name not in ("mxg_abi_version",):
+            fn.restype = i32
+    if L.mxg_abi_version() != ABI_VERSION:
+        raise RuntimeError("libntjoin_mx.so ABI version mismatch")
+    _lib = L
+    return L

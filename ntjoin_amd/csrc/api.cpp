@@ -1,0 +1,459 @@
+// api.cpp -- extern "C" entry points of libntjoin_mx.so (declared in include/ntjoin_mx.h).
+#include <algorithm>
+#include <new>
+
+#include "mxg_internal.h"
+
+using namespace mxg;
+
+static thread_local std::string g_create_err;
+
+extern "C" {
+
+int mxg_abi_version(void) { return MXG_ABI_VERSION; }
+
+const char *mxg_last_error(const mxg_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int mxg_create(const mxg_config *cfg, mxg_handle **out)
+{
+    if (out) *out = nullptr;
+    if (!cfg || !out) {
+        g_create_err = "mxg_create: null argument";
+        return MXG_EINVAL;
+    }
+    if (cfg->struct_size != sizeof(mxg_config)) {
+        g_create_err = "mxg_create: mxg_config.struct_size does not match this library (ABI mismatch)";
+        return MXG_EINVAL;
+    }
+    if (cfg->k < 1 || cfg->k > 1024 || cfg->w < 1 || cfg->w > (1u << 24) || cfg->variant > MXG_VARIANT_V1_MIN) {
+        g_create_err = "mxg_create: need 1 <= k <= 1024, 1 <= w <= 2^24, variant in {0,1}";
+        return MXG_EINVAL;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("mxg_create: no usable HIP device (") + hipGetErrorString(e) +
+                       "); this engine has no CPU fallback";
+        return MXG_EDEVICE;
+    }
+    int dev = cfg->device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev) {
+        g_create_err = "mxg_create: device ordinal out of range";
+        return MXG_EINVAL;
+    }
+    mxg_handle *h = new (std::nothrow) mxg_handle();
+    if (!h) {
+        g_create_err = "mxg_create: out of memory";
+        return MXG_ENOMEM;
+    }
+    h->cfg = *cfg;
+    h->device = dev;
+    auto fail = [&](hipError_t er, const char *what) {
+        g_create_err = std::string("mxg_create: ") + what + ": " + hipGetErrorString(er);
+        mxg_destroy(h);
+        return MXG_EDEVICE;
+    };
+    if ((e = hipSetDevice(dev)) != hipSuccess) return fail(e, "hipSetDevice");
+    if (cfg->stream) {
+        h->stream = (hipStream_t)cfg->stream;
+    } else {
+        if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess)
+            return fail(e, "hipStreamCreate");
+        h->own_stream = true;
+    }
+    if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
+    make_hash_tab(cfg->k, &h->tab);
+    *out = h;
+    return MXG_OK;
+}
+
+void mxg_destroy(mxg_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto *a : h->asms) delete a;
+    h->asms.clear();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int new_assembly(mxg_handle *h, const char *name, double weight, Assembly **out)
+{
+    if (!h) return MXG_EINVAL;
+    if (!name) return set_err(h, MXG_EINVAL, "assembly name is NULL");
+    if (h->asms.size() >= MXG_MAX_ASSEMBLIES) return set_err(h, MXG_ELIMIT, "at most %d assemblies", MXG_MAX_ASSEMBLIES);
+    for (auto *a : h->asms)
+        if (a->name == name)
+            return set_err(h, MXG_EINVAL, "assembly name '%s' already used (names key the graph's support lists)", name);
+    Assembly *a = new (std::nothrow) Assembly();
+    if (!a) return set_err(h, MXG_ENOMEM, "out of memory");
+    a->name = name;
+    a->weight = weight;
+    *out = a;
+    return MXG_OK;
+}
+
+static int commit(mxg_handle *h, Assembly *a, int rc)
+{
+    if (rc != MXG_OK) {
+        delete a;
+        return rc;
+    }
+    h->asms.push_back(a);
+    h->graph.valid = false;
+    return (int)h->asms.size() - 1;
+}
+
+int mxg_add_assembly_fasta(mxg_handle *h, const char *name, double weight, const char *fasta_path)
+{
+    Assembly *a;
+    int rc = new_assembly(h, name, weight, &a);
+    if (rc != MXG_OK) return rc;
+    if (!fasta_path) return commit(h, a, set_err(h, MXG_EINVAL, "fasta_path is NULL"));
+    try {
+        rc = load_fasta(h, a, fasta_path);
+    } catch (const std::bad_alloc &) {
+        rc = set_err(h, MXG_ENOMEM, "out of host memory reading '%s'", fasta_path);
+    }
+    return commit(h, a, rc);
+}
+
+int mxg_add_assembly_buffers(mxg_handle *h, const char *name, double weight, const uint8_t *ascii,
+                             const uint64_t *offsets, const char *const *ids, uint64_t n_records)
+{
+    Assembly *a;
+    int rc = new_assembly(h, name, weight, &a);
+    if (rc != MXG_OK) return rc;
+    if ((!ascii || !offsets) && n_records) return commit(h, a, set_err(h, MXG_EINVAL, "ascii/offsets is NULL"));
+    try {
+        rc = load_buffers(h, a, ascii, offsets, ids, n_records);
+    } catch (const std::bad_alloc &) {
+        rc = set_err(h, MXG_ENOMEM, "out of host memory");
+    }
+    return commit(h, a, rc);
+}
+
+int mxg_add_assembly_packed_device(mxg_handle *h, const char *name, double weight, const void *d_packed,
+                                   const uint64_t *rec_start, const uint64_t *rec_len,
+                                   const char *const *ids, uint64_t n_records)
+{
+    Assembly *a;
+    int rc = new_assembly(h, name, weight, &a);
+    if (rc != MXG_OK) return rc;
+    if (!d_packed || !rec_start || !rec_len) return commit(h, a, set_err(h, MXG_EINVAL, "null argument"));
+    uint64_t end = 0;
+    for (uint64_t r = 0; r < n_records && rc == MXG_OK; ++r) {
+        if (rec_start[r] & 15) rc = set_err(h, MXG_EINVAL, "rec_start[%llu] is not a multiple of 16", (unsigned long long)r);
+        if (rec_len[r] >= (1ull << 32)) rc = set_err(h, MXG_ELIMIT, "record %llu too long", (unsigned long long)r);
+        Record rec;
+        rec.id = (ids && ids[r]) ? std::string(ids[r]) : std::to_string(r);
+        rec.len = rec_len[r];
+        rec.base_off = rec_start[r];
+        a->recs.push_back(rec);
+        end = std::max(end, rec_start[r] + rec_len[r]);
+    }
+    if (rc == MXG_OK) {
+        a->d_packed = static_cast<const uint32_t *>(d_packed);
+        a->packed_words = (end + 15) / 16 + 1;
+        build_runs_from_lengths(h, a);
+    }
+    return commit(h, a, rc);
+}
+
+static int adopt_host_sketch(mxg_handle *h, Assembly *a, const std::vector<uint64_t> &hash,
+                             const std::vector<uint32_t> &pos, const std::vector<uint32_t> &rec)
+{
+    const uint64_t n = hash.size();
+    for (uint64_t i = 0; i < n; ++i)
+        if (rec[i] >= a->recs.size()) return set_err(h, MXG_EINVAL, "record index out of range at minimizer %llu", (unsigned long long)i);
+    MXG_HIP(h, hipSetDevice(h->device));
+    MXG_HIP(h, a->d_hash.ensure(std::max<uint64_t>(n * 8, 16)));
+    MXG_HIP(h, a->d_pos.ensure(std::max<uint64_t>(n * 4, 16)));
+    MXG_HIP(h, a->d_rec.ensure(std::max<uint64_t>(n * 4, 16)));
+    MXG_HIP(h, a->d_fwd.ensure(std::max<uint64_t>(n, 16)));
+    if (n) {
+        MXG_HIP(h, hipMemcpyAsync(a->d_hash.p, hash.data(), n * 8, hipMemcpyHostToDevice, h->stream));
+        MXG_HIP(h, hipMemcpyAsync(a->d_pos.p, pos.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+        MXG_HIP(h, hipMemcpyAsync(a->d_rec.p, rec.data(), n * 4, hipMemcpyHostToDevice, h->stream));
+        MXG_HIP(h, hipMemsetAsync(a->d_fwd.p, 1, n, h->stream));
+        MXG_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    a->n_mx = n;
+    a->h_hash = hash;
+    a->h_pos = pos;
+    a->h_rec = rec;
+    a->h_fwd.assign(n, 1);
+    build_rec_first(a);
+    a->host_valid = true;
+    a->has_sketch = true;
+    return MXG_OK;
+}
+
+int mxg_add_assembly_tsv(mxg_handle *h, const char *name, double weight, const char *tsv_path)
+{
+    Assembly *a;
+    int rc = new_assembly(h, name, weight, &a);
+    if (rc != MXG_OK) return rc;
+    if (!tsv_path) return commit(h, a, set_err(h, MXG_EINVAL, "tsv_path is NULL"));
+    std::vector<uint64_t> hash;
+    std::vector<uint32_t> pos, rec;
+    try {
+        rc = load_tsv(h, a, tsv_path, hash, pos, rec);
+        if (rc == MXG_OK) rc = adopt_host_sketch(h, a, hash, pos, rec);
+    } catch (const std::bad_alloc &) {
+        rc = set_err(h, MXG_ENOMEM, "out of host memory reading '%s'", tsv_path);
+    }
+    return commit(h, a, rc);
+}
+
+int mxg_add_assembly_minimizers(mxg_handle *h, const char *name, double weight, const uint64_t *out_hash,
+                                const uint32_t *pos, const uint32_t *record, uint64_t n,
+                                const char *const *record_ids, uint64_t n_records)
+{
+    Assembly *a;
+    int rc = new_assembly(h, name, weight, &a);
+    if (rc != MXG_OK) return rc;
+    if (n && (!out_hash || !pos || !record)) return commit(h, a, set_err(h, MXG_EINVAL, "null argument"));
+    for (uint64_t r = 0; r < n_records; ++r) {
+        Record rec;
+        rec.id = (record_ids && record_ids[r]) ? std::string(record_ids[r]) : std::to_string(r);
+        a->recs.push_back(rec);
+    }
+    std::vector<uint64_t> hv(out_hash, out_hash + n);
+    std::vector<uint32_t> pv(pos, pos + n), rv(record, record + n);
+    for (uint64_t i = 1; i < n && rc == MXG_OK; ++i)
+        if (rv[i] < rv[i - 1]) rc = set_err(h, MXG_EINVAL, "minimizers must be grouped by non-decreasing record index");
+    if (rc == MXG_OK) rc = adopt_host_sketch(h, a, hv, pv, rv);
+    return commit(h, a, rc);
+}
+
+int mxg_num_assemblies(const mxg_handle *h) { return h ? (int)h->asms.size() : MXG_EINVAL; }
+
+static Assembly *get_asm(mxg_handle *h, int assembly)
+{
+    if (!h || assembly < 0 || (size_t)assembly >= h->asms.size()) {
+        if (h) set_err(h, MXG_EINVAL, "assembly index %d out of range", assembly);
+        return nullptr;
+    }
+    return h->asms[assembly];
+}
+
+const char *mxg_assembly_name(const mxg_handle *h, int assembly)
+{
+    if (!h || assembly < 0 || (size_t)assembly >= h->asms.size()) return nullptr;
+    return h->asms[assembly]->name.c_str();
+}
+
+const char *mxg_record_id(const mxg_handle *h, int assembly, uint64_t record)
+{
+    if (!h || assembly < 0 || (size_t)assembly >= h->asms.size()) return nullptr;
+    const Assembly *a = h->asms[assembly];
+    if (record >= a->recs.size()) return nullptr;
+    return a->recs[record].id.c_str();
+}
+
+uint64_t mxg_record_length(const mxg_handle *h, int assembly, uint64_t record)
+{
+    if (!h || assembly < 0 || (size_t)assembly >= h->asms.size()) return 0;
+    const Assembly *a = h->asms[assembly];
+    return record < a->recs.size() ? a->recs[record].len : 0;
+}
+
+int mxg_sketch(mxg_handle *h, int assembly)
+{
+    if (!h) return MXG_EINVAL;
+    try {
+        if (assembly >= 0) {
+            Assembly *a = get_asm(h, assembly);
+            if (!a) return MXG_EINVAL;
+            return sketch_assembly(h, a);
+        }
+        for (auto *a : h->asms) {
+            if (a->has_bases && !a->has_sketch) {
+                int rc = sketch_assembly(h, a);
+                if (rc != MXG_OK) return rc;
+            }
+        }
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_sketch");
+    }
+    return MXG_OK;
+}
+
+int mxg_get_sketch(mxg_handle *h, int assembly, mxg_sketch_view *out)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !out) return MXG_EINVAL;
+    int rc = sync_sketch_to_host(h, a);
+    if (rc != MXG_OK) return rc;
+    out->n = a->n_mx;
+    out->out_hash = a->h_hash.data();
+    out->pos = a->h_pos.data();
+    out->record = a->h_rec.data();
+    out->forward = a->h_fwd.data();
+    out->n_records = a->recs.size();
+    out->record_first = a->rec_first.data();
+    return MXG_OK;
+}
+
+int mxg_get_sketch_device(mxg_handle *h, int assembly, mxg_sketch_dview *out)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !out) return MXG_EINVAL;
+    if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch yet", a->name.c_str());
+    out->n = a->n_mx;
+    out->out_hash = a->d_hash.p;
+    out->pos = a->d_pos.p;
+    out->record = a->d_rec.p;
+    out->forward = a->d_fwd.p;
+    return MXG_OK;
+}
+
+int mxg_set_sketch_device(mxg_handle *h, int assembly, const void *d_out_hash, const void *d_pos,
+                          const void *d_record, const void *d_forward, uint64_t n)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a) return MXG_EINVAL;
+    if (n && (!d_out_hash || !d_pos || !d_record)) return set_err(h, MXG_EINVAL, "null device pointer");
+    MXG_HIP(h, hipSetDevice(h->device));
+    // copy into fresh buffers first: the sources may alias the current sketch
+    DevBuf nh, np, nr, nf;
+    MXG_HIP(h, nh.ensure(std::max<uint64_t>(n * 8, 16)));
+    MXG_HIP(h, np.ensure(std::max<uint64_t>(n * 4, 16)));
+    MXG_HIP(h, nr.ensure(std::max<uint64_t>(n * 4, 16)));
+    MXG_HIP(h, nf.ensure(std::max<uint64_t>(n, 16)));
+    if (n) {
+        MXG_HIP(h, hipMemcpyAsync(nh.p, d_out_hash, n * 8, hipMemcpyDeviceToDevice, h->stream));
+        MXG_HIP(h, hipMemcpyAsync(np.p, d_pos, n * 4, hipMemcpyDeviceToDevice, h->stream));
+        MXG_HIP(h, hipMemcpyAsync(nr.p, d_record, n * 4, hipMemcpyDeviceToDevice, h->stream));
+        if (d_forward) MXG_HIP(h, hipMemcpyAsync(nf.p, d_forward, n, hipMemcpyDeviceToDevice, h->stream));
+        else MXG_HIP(h, hipMemsetAsync(nf.p, 1, n, h->stream));
+        MXG_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    std::swap(a->d_hash.p, nh.p); std::swap(a->d_hash.bytes, nh.bytes);
+    std::swap(a->d_pos.p, np.p);  std::swap(a->d_pos.bytes, np.bytes);
+    std::swap(a->d_rec.p, nr.p);  std::swap(a->d_rec.bytes, nr.bytes);
+    std::swap(a->d_fwd.p, nf.p);  std::swap(a->d_fwd.bytes, nf.bytes);
+    a->n_mx = n;
+    a->has_sketch = true;
+    a->host_valid = false;
+    a->flags_valid = false;
+    h->graph.valid = false;
+    return MXG_OK;
+}
+
+int mxg_write_tsv(mxg_handle *h, int assembly, const char *path, int with_pos, int with_strand, int with_seq)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !path) return MXG_EINVAL;
+    try {
+        return write_tsv(h, a, path, with_pos, with_strand, with_seq);
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_write_tsv");
+    }
+}
+
+int mxg_build_graph(mxg_handle *h)
+{
+    if (!h) return MXG_EINVAL;
+    try {
+        return build_graph(h);
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_build_graph");
+    }
+}
+
+int mxg_get_mx_flags(mxg_handle *h, int assembly, const uint8_t **flags, uint64_t *n)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !flags || !n) return MXG_EINVAL;
+    if (!h->graph.valid || !a->flags_valid) return set_err(h, MXG_EINVAL, "call mxg_build_graph first");
+    *flags = a->h_flags.data();
+    *n = a->n_mx;
+    return MXG_OK;
+}
+
+int mxg_get_graph(mxg_handle *h, mxg_graph_view *out)
+{
+    if (!h || !out) return MXG_EINVAL;
+    const Graph &g = h->graph;
+    if (!g.valid) return set_err(h, MXG_EINVAL, "call mxg_build_graph first");
+    out->n_assemblies = g.n_asm;
+    out->n_vertices = g.nv;
+    out->vertex_hash = g.vhash.data();
+    out->vertex_pos = g.vpos.data();
+    out->vertex_record = g.vrec.data();
+    out->n_edges = g.ne;
+    out->edge_u = g.eu.data();
+    out->edge_v = g.ev.data();
+    out->edge_support = g.esup.data();
+    out->edge_weight = g.ew.data();
+    return MXG_OK;
+}
+
+int mxg_write_dot(mxg_handle *h, const char *path)
+{
+    if (!h || !path) return MXG_EINVAL;
+    try {
+        return write_dot(h, path);
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_write_dot");
+    }
+}
+
+static size_t copy_out(const std::string &r, char *buf, size_t cap)
+{
+    if (buf && cap) {
+        size_t n = std::min(r.size(), cap - 1);
+        memcpy(buf, r.data(), n);
+        buf[n] = 0;
+    }
+    return r.size();
+}
+
+size_t mxg_py_repr_double(double v, char *buf, size_t cap) { return copy_out(py_repr_float(v), buf, cap); }
+
+size_t mxg_py_repr_str(const char *s, char *buf, size_t cap) { return copy_out(py_repr_str(s ? s : ""), buf, cap); }
+
+int mxg_get_stats(mxg_handle *h, mxg_stats *out)
+{
+    if (!h || !out) return MXG_EINVAL;
+    if (out->struct_size != sizeof(mxg_stats)) return set_err(h, MXG_EINVAL, "mxg_stats.struct_size mismatch");
+    mxg_stats s{};
+    s.struct_size = sizeof(mxg_stats);
+    s.n_assemblies = (uint32_t)h->asms.size();
+    for (auto *a : h->asms) {
+        s.bases += a->total_bases;
+        s.kmers += a->total_kmers;
+        if (a->has_sketch) s.minimizers += a->n_mx;
+    }
+    s.candidates = h->stat_candidates;
+    s.dense_kmers = h->stat_dense_kmers;
+    s.unique = h->stat_unique;
+    s.vertices = h->graph.valid ? h->graph.nv : 0;
+    s.edges = h->graph.valid ? h->graph.ne : 0;
+    s.ms_hash = h->tm.ms_hash;
+    s.ms_resolve = h->tm.ms_resolve;
+    s.ms_graph = h->tm.ms_graph;
+    s.launches_hash = h->tm.launches_hash;
+    s.hash_kernel_bases = h->tm.hash_bases;
+    *out = s;
+    return MXG_OK;
+}
+
+int mxg_reset_timers(mxg_handle *h)
+{
+    if (!h) return MXG_EINVAL;
+    h->tm = Timers();
+    h->stat_candidates = h->stat_dense_kmers = 0;
+    return MXG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,387 @@
+// graph.hip -- the minimizer-graph stage on gfx950: per-assembly uniqueness, cross-assembly intersection,
+// adjacency edges with support masks and weights.  Replaces (reference file:line):
+//   read_minimizers' duplicate removal      bin/ntjoin_utils.py:182-193  (hash seen >= 2x in an assembly is dropped everywhere in it)
+//   filter_minimizers                        bin/ntjoin_utils.py:152-165  (keep hashes present in every assembly)
+//   build_graph + calc_total_weight          bin/ntjoin_utils.py:83-115,132-137,54-56
+//
+// Design (no sort needed): one open-addressing table in HBM keyed by the 64-bit out_hash holds, per key,
+// a `seen` and a `dup` bit per assembly.  A hash survives iff seen == all assemblies and dup == 0, i.e. it
+// occurs exactly once in every assembly.  Survivors get dense vertex ids (rank in the first assembly's
+// order).  Because each survivor occurs once per assembly, a vertex has at most one successor and one
+// predecessor per assembly: adjacency is two dense arrays nxt[a][v], prv[a][v]; the support mask of edge
+// {u,v} is read off those arrays and the edge is emitted once, by the first assembly (reference order:
+// refs in CLI order, then target) that contains it, in that assembly's first-seen orientation --
+// the same (s,t) the reference's `edges[s][t]` dictionary keeps (bin/ntjoin_utils.py:101-108).
+#include <algorithm>
+
+#include "mxg_internal.h"
+#include "scan_kernels.h"
+
+namespace mxg {
+
+static constexpr uint64_t HT_EMPTY = 0xFFFFFFFFFFFFFFFFull;
+static constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t ht_slot(unsigned long long *keys, uint32_t mask, uint32_t cap, uint64_t key)
+{
+    if (key == HT_EMPTY) return cap;  // the sentinel value itself lives in the extra slot [cap]
+    uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+    while (true) {
+        unsigned long long cur = keys[s];
+        if (cur == key) return s;
+        if (cur == HT_EMPTY) {
+            unsigned long long old = atomicCAS(&keys[s], (unsigned long long)HT_EMPTY, (unsigned long long)key);
+            if (old == HT_EMPTY || old == key) return s;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+// insert every minimizer of one assembly; remember its slot
+__global__ __launch_bounds__(256) void k_insert(const uint64_t *__restrict__ hash, uint32_t n, uint32_t bit,
+                                                unsigned long long *keys, uint32_t mask, uint32_t cap,
+                                                uint32_t *seen, uint32_t *dup, uint32_t *__restrict__ slot_out)
+{
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = ht_slot(keys, mask, cap, hash[i]);
+    uint32_t old = atomicOr(&seen[s], bit);
+    if (old & bit) atomicOr(&dup[s], bit);
+    slot_out[i] = s;
+}
+
+__global__ __launch_bounds__(256) void k_flags(const uint32_t *__restrict__ slot, uint32_t n, uint32_t bit,
+                                               uint32_t full, const uint32_t *__restrict__ seen,
+                                               const uint32_t *__restrict__ dup, uint8_t *__restrict__ flags,
+                                               uint8_t *__restrict__ shared)
+{
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = slot[i];
+    uint32_t d = dup[s];
+    bool uniq = !(d & bit);
+    bool inall = seen[s] == full;
+    bool sh = inall && d == 0;
+    flags[i] = (uint8_t)((uniq ? MXG_MX_UNIQUE : 0) | (sh ? MXG_MX_SHARED : 0) | (inall ? MXG_MX_INALL : 0));
+    shared[i] = sh ? 1 : 0;
+}
+
+struct VertexParams {
+    const uint8_t *shared;
+    const uint32_t *bsum;
+    const uint32_t *slot;
+    const uint64_t *hash;
+    const uint32_t *pos, *rec;
+    uint32_t n;
+    uint32_t first;   // 1: this is assembly 0 -> assign vertex ids
+    uint32_t *vid;    // [cap+1] slot -> vertex id
+    uint64_t *vhash;  // [nv]
+    uint32_t *vpos, *vrec;  // this assembly's slice [nv]
+    uint32_t *fv, *frec;    // this assembly's filtered order -> vertex id / record
+};
+
+// ordered compaction of the shared minimizers of one assembly; rank r in filtered order
+__global__ __launch_bounds__(256) void k_vertices(const VertexParams p)
+{
+    __shared__ uint32_t sh[256];
+    uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
+    uint32_t c = 0;
+    for (int u = 0; u < TILE_PER_THREAD; ++u)
+        if (base + u < p.n) c += p.shared[base + u];
+    uint32_t r = p.bsum[blockIdx.x] + block_exclusive_256(c, sh);
+    if (c == 0) return;
+    for (int u = 0; u < TILE_PER_THREAD; ++u) {
+        uint32_t i = base + u;
+        if (i < p.n && p.shared[i]) {
+            uint32_t s = p.slot[i];
+            uint32_t v;
+            if (p.first) {
+                v = r;
+                p.vid[s] = v;
+                p.vhash[v] = p.hash[i];
+            } else {
+                v = p.vid[s];
+            }
+            p.vpos[v] = p.pos[i];
+            p.vrec[v] = p.rec[i];
+            p.fv[r] = v;
+            p.frec[r] = p.rec[i];
+            ++r;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_adjacency(const uint32_t *__restrict__ fv, const uint32_t *__restrict__ frec,
+                                                   uint32_t nv, uint32_t *__restrict__ nxt, uint32_t *__restrict__ prv)
+{
+    uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r + 1 >= nv) return;
+    if (frec[r] == frec[r + 1]) {  // consecutive surviving minimizers of the same contig (ntjoin_utils.py:98-99)
+        uint32_t u = fv[r], v = fv[r + 1];
+        nxt[u] = v;
+        prv[v] = u;
+    }
+}
+
+struct EdgeParams {
+    const uint32_t *fv;   // [A][nv]
+    const uint32_t *nxt;  // [A][nv]
+    const uint32_t *prv;  // [A][nv]
+    uint32_t nv, n_asm;
+    uint8_t *eflag;       // [A*nv]
+    const uint32_t *bsum;
+    uint32_t *eu, *ev, *esup;
+    double *ew;
+    double weights[MXG_MAX_ASSEMBLIES];
+};
+
+__device__ __forceinline__ uint32_t edge_mask(const EdgeParams &p, uint32_t u, uint32_t v)
+{
+    uint32_t m = 0;
+    for (uint32_t b = 0; b < p.n_asm; ++b) {
+        size_t o = (size_t)b * p.nv + u;
+        if (p.nxt[o] == v || p.prv[o] == v) m |= 1u << b;
+    }
+    return m;
+}
+
+// item = a*nv + r : the pair (filtered[a][r], filtered[a][r+1]); flagged iff assembly a is the first supporter
+__global__ __launch_bounds__(256) void k_edge_flags(const EdgeParams p)
+{
+    uint64_t item = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (item >= (uint64_t)p.n_asm * p.nv) return;
+    uint32_t a = (uint32_t)(item / p.nv);
+    uint32_t r = (uint32_t)(item % p.nv);
+    uint32_t u = p.fv[(size_t)a * p.nv + r];
+    uint32_t v = p.nxt[(size_t)a * p.nv + u];
+    uint8_t f = 0;
+    if (v != NONE32) {
+        uint32_t m = edge_mask(p, u, v);
+        f = ((uint32_t)__builtin_ctz(m) == a) ? 1 : 0;
+    }
+    p.eflag[item] = f;
+}
+
+__global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_items)
+{
+    __shared__ uint32_t sh[256];
+    uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
+    uint32_t c = 0;
+    for (int t = 0; t < TILE_PER_THREAD; ++t)
+        if (base + t < n_items) c += p.eflag[base + t];
+    uint32_t e = p.bsum[blockIdx.x] + block_exclusive_256(c, sh);
+    if (c == 0) return;
+    for (int t = 0; t < TILE_PER_THREAD; ++t) {
+        uint32_t item = base + t;
+        if (item < n_items && p.eflag[item]) {
+            uint32_t a = item / p.nv, r = item % p.nv;
+            uint32_t u = p.fv[(size_t)a * p.nv + r];
+            uint32_t v = p.nxt[(size_t)a * p.nv + u];
+            uint32_t m = edge_mask(p, u, v);
+            // python: sum(weights[f] for f in support) -- int 0 start, then float adds in support (= assembly) order
+            double wsum = 0.0;
+            for (uint32_t b = 0; b < p.n_asm; ++b)
+                if (m & (1u << b)) wsum = wsum + p.weights[b];
+            p.eu[e] = u;
+            p.ev[e] = v;
+            p.esup[e] = m;
+            p.ew[e] = wsum;
+            ++e;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+template <class T>
+static int d2h(mxg_handle *h, std::vector<T> &dst, const void *src, size_t n)
+{
+    dst.resize(n);
+    if (n) MXG_HIP(h, hipMemcpyAsync(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    return MXG_OK;
+}
+
+int build_graph(mxg_handle *h)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    const uint32_t A = (uint32_t)h->asms.size();
+    if (A == 0) return set_err(h, MXG_EINVAL, "mxg_build_graph: no assemblies");
+    if (A > MXG_MAX_ASSEMBLIES) return set_err(h, MXG_ELIMIT, "at most %d assemblies", MXG_MAX_ASSEMBLIES);
+    uint64_t N = 0, nmax = 0;
+    for (auto *a : h->asms) {
+        if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch (call mxg_sketch)", a->name.c_str());
+        N += a->n_mx;
+        nmax = std::max(nmax, a->n_mx);
+    }
+    if (N >= (1ull << 30)) return set_err(h, MXG_ELIMIT, "too many minimizers for one table (%llu)", (unsigned long long)N);
+    Graph &g = h->graph;
+    g = Graph();
+    g.n_asm = A;
+    const bool timing = (h->cfg.flags & MXG_FLAG_TIMING) != 0;
+    if (timing) MXG_HIP(h, hipEventRecord(h->ev0, h->stream));
+
+    uint32_t cap = 1024;
+    while (cap < 2 * N) cap <<= 1;
+    const uint32_t mask = cap - 1;
+    const uint32_t full = (A == 32) ? 0xFFFFFFFFu : ((1u << A) - 1u);
+
+    DevBuf d_keys, d_seen, d_dup, d_vid, d_shared, d_bsum, d_total;
+    std::vector<DevBuf> d_slot(A);
+    MXG_HIP(h, d_keys.ensure(((size_t)cap + 1) * 8));
+    MXG_HIP(h, d_seen.ensure(((size_t)cap + 1) * 4));
+    MXG_HIP(h, d_dup.ensure(((size_t)cap + 1) * 4));
+    MXG_HIP(h, d_vid.ensure(((size_t)cap + 1) * 4));
+    MXG_HIP(h, hipMemsetAsync(d_keys.p, 0xFF, ((size_t)cap + 1) * 8, h->stream));
+    MXG_HIP(h, hipMemsetAsync(d_seen.p, 0, ((size_t)cap + 1) * 4, h->stream));
+    MXG_HIP(h, hipMemsetAsync(d_dup.p, 0, ((size_t)cap + 1) * 4, h->stream));
+    MXG_HIP(h, d_shared.ensure(std::max<uint64_t>(nmax, 16)));
+    MXG_HIP(h, d_total.ensure(64));
+
+    for (uint32_t a = 0; a < A; ++a) {
+        Assembly *as = h->asms[a];
+        MXG_HIP(h, d_slot[a].ensure(std::max<uint64_t>(as->n_mx * 4, 16)));
+        MXG_HIP(h, as->d_flags.ensure(std::max<uint64_t>(as->n_mx, 16)));
+        if (as->n_mx)
+            hipLaunchKernelGGL(k_insert, dim3((uint32_t)((as->n_mx + 255) / 256)), dim3(256), 0, h->stream,
+                               as->d_hash.as<uint64_t>(), (uint32_t)as->n_mx, 1u << a,
+                               d_keys.as<unsigned long long>(), mask, cap, d_seen.as<uint32_t>(),
+                               d_dup.as<uint32_t>(), d_slot[a].as<uint32_t>());
+    }
+    MXG_HIP(h, hipGetLastError());
+
+    // flags + shared count per assembly (identical across assemblies by construction)
+    std::vector<std::vector<uint32_t>> bsums_host;  // not needed on host; per-assembly device bsum kept
+    std::vector<DevBuf> d_bs(A);
+    std::vector<DevBuf> d_sh(A);
+    std::vector<uint64_t> totals(A, 0);
+    for (uint32_t a = 0; a < A; ++a) {
+        Assembly *as = h->asms[a];
+        uint32_t n = (uint32_t)as->n_mx;
+        uint32_t n_tiles = (n + TILE - 1) / TILE;
+        MXG_HIP(h, d_sh[a].ensure(std::max<uint32_t>(n, 16)));
+        MXG_HIP(h, d_bs[a].ensure((size_t)n_tiles * 4 + 16));
+        if (n) {
+            hipLaunchKernelGGL(k_flags, dim3((n + 255) / 256), dim3(256), 0, h->stream, d_slot[a].as<uint32_t>(), n,
+                               1u << a, full, d_seen.as<uint32_t>(), d_dup.as<uint32_t>(), as->d_flags.as<uint8_t>(),
+                               d_sh[a].as<uint8_t>());
+            hipLaunchKernelGGL(k_count, dim3(n_tiles), dim3(256), 0, h->stream, d_sh[a].as<uint8_t>(), n,
+                               d_bs[a].as<uint32_t>());
+        }
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, d_bs[a].as<uint32_t>(), n_tiles,
+                           d_total.as<uint64_t>());
+        MXG_HIP(h, hipGetLastError());
+        MXG_HIP(h, hipMemcpyAsync(&totals[a], d_total.p, 8, hipMemcpyDeviceToHost, h->stream));
+        MXG_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    const uint64_t nv = totals[0];
+    for (uint32_t a = 1; a < A; ++a)
+        if (totals[a] != nv)
+            return set_err(h, MXG_EDEVICE, "internal error: shared-minimizer counts differ between assemblies (%llu vs %llu)",
+                           (unsigned long long)totals[a], (unsigned long long)nv);
+    g.nv = nv;
+
+    DevBuf d_vhash, d_vpos, d_vrec, d_fv, d_frec, d_nxt, d_prv, d_eflag, d_ebs, d_eu, d_ev, d_esup, d_ew;
+    uint64_t ne = 0;
+    if (nv > 0) {
+        if ((uint64_t)A * nv >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "graph too large for 32-bit item indices");
+        MXG_HIP(h, d_vhash.ensure(nv * 8));
+        MXG_HIP(h, d_vpos.ensure((size_t)A * nv * 4));
+        MXG_HIP(h, d_vrec.ensure((size_t)A * nv * 4));
+        MXG_HIP(h, d_fv.ensure((size_t)A * nv * 4));
+        MXG_HIP(h, d_frec.ensure((size_t)A * nv * 4));
+        MXG_HIP(h, d_nxt.ensure((size_t)A * nv * 4));
+        MXG_HIP(h, d_prv.ensure((size_t)A * nv * 4));
+        MXG_HIP(h, hipMemsetAsync(d_nxt.p, 0xFF, (size_t)A * nv * 4, h->stream));
+        MXG_HIP(h, hipMemsetAsync(d_prv.p, 0xFF, (size_t)A * nv * 4, h->stream));
+        for (uint32_t a = 0; a < A; ++a) {
+            Assembly *as = h->asms[a];
+            uint32_t n = (uint32_t)as->n_mx;
+            VertexParams vp;
+            vp.shared = d_sh[a].as<uint8_t>();
+            vp.bsum = d_bs[a].as<uint32_t>();
+            vp.slot = d_slot[a].as<uint32_t>();
+            vp.hash = as->d_hash.as<uint64_t>();
+            vp.pos = as->d_pos.as<uint32_t>();
+            vp.rec = as->d_rec.as<uint32_t>();
+            vp.n = n;
+            vp.first = a == 0;
+            vp.vid = d_vid.as<uint32_t>();
+            vp.vhash = d_vhash.as<uint64_t>();
+            vp.vpos = d_vpos.as<uint32_t>() + (size_t)a * nv;
+            vp.vrec = d_vrec.as<uint32_t>() + (size_t)a * nv;
+            vp.fv = d_fv.as<uint32_t>() + (size_t)a * nv;
+            vp.frec = d_frec.as<uint32_t>() + (size_t)a * nv;
+            hipLaunchKernelGGL(k_vertices, dim3((n + TILE - 1) / TILE), dim3(256), 0, h->stream, vp);
+            hipLaunchKernelGGL(k_adjacency, dim3((uint32_t)((nv + 255) / 256)), dim3(256), 0, h->stream,
+                               d_fv.as<uint32_t>() + (size_t)a * nv, d_frec.as<uint32_t>() + (size_t)a * nv,
+                               (uint32_t)nv, d_nxt.as<uint32_t>() + (size_t)a * nv,
+                               d_prv.as<uint32_t>() + (size_t)a * nv);
+        }
+        MXG_HIP(h, hipGetLastError());
+        const uint32_t n_items = (uint32_t)((uint64_t)A * nv);
+        const uint32_t e_tiles = (n_items + TILE - 1) / TILE;
+        MXG_HIP(h, d_eflag.ensure(n_items));
+        MXG_HIP(h, d_ebs.ensure((size_t)e_tiles * 4 + 16));
+        EdgeParams ep;
+        ep.fv = d_fv.as<uint32_t>();
+        ep.nxt = d_nxt.as<uint32_t>();
+        ep.prv = d_prv.as<uint32_t>();
+        ep.nv = (uint32_t)nv;
+        ep.n_asm = A;
+        ep.eflag = d_eflag.as<uint8_t>();
+        ep.bsum = d_ebs.as<uint32_t>();
+        ep.eu = ep.ev = ep.esup = nullptr;
+        ep.ew = nullptr;
+        for (uint32_t a = 0; a < MXG_MAX_ASSEMBLIES; ++a) ep.weights[a] = a < A ? h->asms[a]->weight : 0.0;
+        hipLaunchKernelGGL(k_edge_flags, dim3((n_items + 255) / 256), dim3(256), 0, h->stream, ep);
+        hipLaunchKernelGGL(k_count, dim3(e_tiles), dim3(256), 0, h->stream, d_eflag.as<uint8_t>(), n_items,
+                           d_ebs.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, d_ebs.as<uint32_t>(), e_tiles,
+                           d_total.as<uint64_t>());
+        MXG_HIP(h, hipGetLastError());
+        MXG_HIP(h, hipMemcpyAsync(&ne, d_total.p, 8, hipMemcpyDeviceToHost, h->stream));
+        MXG_HIP(h, hipStreamSynchronize(h->stream));
+        MXG_HIP(h, d_eu.ensure(std::max<uint64_t>(ne * 4, 16)));
+        MXG_HIP(h, d_ev.ensure(std::max<uint64_t>(ne * 4, 16)));
+        MXG_HIP(h, d_esup.ensure(std::max<uint64_t>(ne * 4, 16)));
+        MXG_HIP(h, d_ew.ensure(std::max<uint64_t>(ne * 8, 16)));
+        ep.eu = d_eu.as<uint32_t>();
+        ep.ev = d_ev.as<uint32_t>();
+        ep.esup = d_esup.as<uint32_t>();
+        ep.ew = d_ew.as<double>();
+        hipLaunchKernelGGL(k_edges, dim3(e_tiles), dim3(256), 0, h->stream, ep, n_items);
+        MXG_HIP(h, hipGetLastError());
+    }
+    g.ne = ne;
+    if (timing) {
+        MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
+        MXG_HIP(h, hipStreamSynchronize(h->stream));
+        float ms = 0;
+        MXG_HIP(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        h->tm.ms_graph += ms;
+    }
+    // results to the host (the boundary hands out host views)
+    int rc;
+    if ((rc = d2h(h, g.vhash, d_vhash.p, nv)) != MXG_OK) return rc;
+    if ((rc = d2h(h, g.vpos, d_vpos.p, (size_t)A * nv)) != MXG_OK) return rc;
+    if ((rc = d2h(h, g.vrec, d_vrec.p, (size_t)A * nv)) != MXG_OK) return rc;
+    if ((rc = d2h(h, g.eu, d_eu.p, ne)) != MXG_OK) return rc;
+    if ((rc = d2h(h, g.ev, d_ev.p, ne)) != MXG_OK) return rc;
+    if ((rc = d2h(h, g.esup, d_esup.p, ne)) != MXG_OK) return rc;
+    if ((rc = d2h(h, g.ew, d_ew.p, ne)) != MXG_OK) return rc;
+    uint64_t uniq = 0;
+    for (uint32_t a = 0; a < A; ++a) {
+        Assembly *as = h->asms[a];
+        if ((rc = d2h(h, as->h_flags, as->d_flags.p, as->n_mx)) != MXG_OK) return rc;
+    }
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    for (uint32_t a = 0; a < A; ++a) {
+        Assembly *as = h->asms[a];
+        for (uint8_t f : as->h_flags) uniq += (f & MXG_MX_UNIQUE) ? 1 : 0;
+        as->flags_valid = true;
+    }
+    h->stat_unique = uniq;
+    g.valid = true;
+    return MXG_OK;
+}
+
+}  // namespace mxg

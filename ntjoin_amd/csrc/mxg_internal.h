@@ -1,0 +1,173 @@
+// mxg_internal.h -- internal structures of libntjoin_mx.so (not part of the C-ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ntjoin_mx.h"
+
+namespace mxg {
+
+// ---- device-side tables ------------------------------------------------------------------------
+// One maximal run of valid (ACGTU) bases that holds at least one k-mer, inside an ELIGIBLE contig
+// (a record with >= w valid k-mers; shorter records have no window and yield no minimizer,
+// SURVEY.md A.3).  Windows are taken over the concatenation of a contig's runs (valid k-mers only).
+struct Run {
+    uint64_t base_off;  // global base index (into the packed array) of the run's first base
+    uint32_t n_kmers;   // run_len - k + 1
+    uint32_t contig;    // eligible-contig index
+    uint32_t kidx0;     // contig-local valid-k-mer index of the run's first k-mer
+    uint32_t pos0;      // contig-local base position of the run's first base
+};
+
+struct HashTab {  // ntHash step table, entry (out*4+in), out==4: warm-up step with no outgoing base
+    // x,y = low/high word of  srol^k(SEED[out]) ^ SEED[in]            (forward update term)
+    // z,w = low/high word of  SEED[comp(out)] ^ srol^k(SEED[comp(in)]) (reverse update term, before sror)
+    uint4 e[20];
+};
+
+// ---- host-side helpers ---------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    // grow-only; contents are NOT preserved
+    hipError_t ensure(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        release();
+        size_t want = need + need / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        bytes = want;
+        return hipSuccess;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct Record {
+    std::string id;
+    uint64_t len = 0;       // bases in the record
+    uint64_t base_off = 0;  // global base offset in the packed array (multiple of 16)
+    uint64_t text_off = 0;  // offset of the record's text in Assembly::text (if kept)
+};
+
+struct Assembly {
+    std::string name;
+    double weight = 0.0;
+    std::vector<Record> recs;
+    uint64_t total_bases = 0;
+    // bases
+    bool has_bases = false;
+    std::string text;                // concatenated record text as read (kept unless MXG_FLAG_DROP_SEQ)
+    bool has_text = false;
+    std::vector<uint32_t> h_packed;  // host 2-bit packing (dropped after upload)
+    DevBuf d_packed_own;
+    const uint32_t *d_packed = nullptr;  // owned (above) or borrowed
+    uint64_t packed_words = 0;
+    // eligibility tables (host), uploaded by the sketch driver
+    std::vector<Run> runs;
+    std::vector<uint32_t> ctg_rec;   // eligible contig -> record index
+    std::vector<uint32_t> ctg_nk;    // eligible contig -> valid k-mer count
+    std::vector<uint32_t> ctg_run0;  // eligible contig -> first run (size n+1)
+    uint64_t total_kmers = 0;        // over eligible contigs
+    // sketch (device, ordered by (record,pos)) + lazily filled host mirror
+    bool has_sketch = false;
+    uint64_t n_mx = 0;
+    DevBuf d_hash, d_pos, d_rec, d_fwd;
+    bool host_valid = false;
+    std::vector<uint64_t> h_hash;
+    std::vector<uint32_t> h_pos, h_rec;
+    std::vector<uint8_t> h_fwd;
+    std::vector<uint64_t> rec_first;
+    // graph stage
+    DevBuf d_flags;
+    std::vector<uint8_t> h_flags;
+    bool flags_valid = false;
+};
+
+struct Graph {
+    bool valid = false;
+    uint32_t n_asm = 0;
+    uint64_t nv = 0, ne = 0;
+    std::vector<uint64_t> vhash;
+    std::vector<uint32_t> vpos, vrec;  // [a*nv+v]
+    std::vector<uint32_t> eu, ev, esup;
+    std::vector<double> ew;
+};
+
+struct Timers {
+    double ms_hash = 0, ms_resolve = 0, ms_graph = 0;
+    uint64_t launches_hash = 0, hash_bases = 0;
+};
+
+}  // namespace mxg
+
+struct mxg_handle {
+    mxg_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    std::vector<mxg::Assembly *> asms;
+    mxg::Graph graph;
+    mxg::Timers tm;
+    mxg::HashTab tab{};
+    uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
+    // scratch reused across calls
+    mxg::DevBuf s_runs, s_strip0, s_g0, s_ctg_nk, s_ctg_rec, s_ctg_run0;
+    mxg::DevBuf s_cand_h, s_cand_k, s_cand_c, s_sel, s_bsum, s_total, s_misc;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace mxg {
+
+int set_err(mxg_handle *h, int code, const char *fmt, ...);
+#define MXG_HIP(h, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return mxg::set_err((h), e_ == hipErrorOutOfMemory ? MXG_ENOMEM : MXG_EDEVICE,      \
+                                "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                                __LINE__);                                                       \
+    } while (0)
+
+// host_io.cpp
+int load_fasta(mxg_handle *h, Assembly *a, const char *path);
+int load_buffers(mxg_handle *h, Assembly *a, const uint8_t *ascii, const uint64_t *offsets,
+                 const char *const *ids, uint64_t n_records);
+int load_tsv(mxg_handle *h, Assembly *a, const char *path, std::vector<uint64_t> &hash,
+             std::vector<uint32_t> &pos, std::vector<uint32_t> &rec);
+void build_runs_from_lengths(mxg_handle *h, Assembly *a);  // N-free packed-device input
+int write_tsv(mxg_handle *h, Assembly *a, const char *path, int with_pos, int with_strand, int with_seq);
+int write_dot(mxg_handle *h, const char *path);
+void build_rec_first(Assembly *a);
+std::string py_repr_str(const std::string &s);
+std::string py_repr_float(double v);
+void make_hash_tab(uint32_t k, HashTab *t);
+
+// sketch.hip
+int sketch_assembly(mxg_handle *h, Assembly *a);
+int sync_sketch_to_host(mxg_handle *h, Assembly *a);
+// graph.hip
+int build_graph(mxg_handle *h);
+
+}  // namespace mxg

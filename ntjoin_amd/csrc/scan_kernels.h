@@ -1,0 +1,71 @@
+// scan_kernels.h -- ordered stream-compaction building blocks shared by sketch.hip and graph.hip.
+// Pattern: k_count (flags -> per-tile counts) ; k_scan_sums (exclusive scan of tile counts, one block) ;
+// then a consumer kernel re-scans its tile in LDS (tile_exclusive_rank) and writes in order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mxg {
+
+constexpr int TILE_PER_THREAD = 16;
+constexpr int TILE = 256 * TILE_PER_THREAD;
+
+static __global__ __launch_bounds__(256) void k_count(const uint8_t *__restrict__ sel, uint32_t n, uint32_t *__restrict__ bsum)
+{
+    __shared__ uint32_t sh[256];
+    uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
+    uint32_t c = 0;
+    for (int u = 0; u < TILE_PER_THREAD; ++u)
+        if (base + u < n) c += sel[base + u];
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
+}
+
+// exclusive scan of bsum[0..n) in place by ONE block; total -> *total
+static __global__ __launch_bounds__(1024) void k_scan_sums(uint32_t *__restrict__ bsum, uint32_t n, uint64_t *__restrict__ total)
+{
+    __shared__ uint32_t sh[1024];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < n ? bsum[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint32_t t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint32_t carry = carry_s;
+        if (i < n) bsum[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+
+// inside a 256-thread block: exclusive prefix of per-thread counts `c` (uses sh[256]); all threads must call
+__device__ __forceinline__ uint32_t block_exclusive_256(uint32_t c, uint32_t *sh)
+{
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    return sh[threadIdx.x] - c;
+}
+
+}  // namespace mxg

@@ -1,0 +1,193 @@
+"""
+MxEngine -- Python face of one libntjoin_mx handle (one k, w, hash variant, one GPU).
+
+Order of use mirrors the reference pipeline:
+    eng = MxEngine(k=32, w=1000)
+    eng.add_fasta("ref.fa.k32.w1000.tsv", 2.0, "ref.fa")        # references first, CLI order
+    eng.add_fasta("scaf.fa.k32.w1000.tsv", 1.0, "scaf.fa")      # target last
+    eng.sketch()                                                # = indexlr              ntJoin:204-205
+    eng.write_tsv(0, "ref.fa.k32.w1000.tsv")
+    eng.build_graph()                                           # = read_minimizers' uniqueness + filter_minimizers + build_graph
+    eng.write_dot("prefix.mx.dot")                              # = Ntjoin.print_graph   bin/ntjoin.py:25-62
+All arrays returned are numpy COPIES (the library owns its buffers), hence picklable.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class MxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libntjoin_mx error {code}: {msg}")
+        self.code = code
+
+
+def _np(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(int(n),)).astype(dtype, copy=True)
+
+
+class MxEngine:
+    def __init__(self, k=32, w=1000, variant="v2", device=-1, stream=None, dense_only=False, drop_seq=False,
+                 timing=False, cand_per_window=0):
+        self._lib = capi.load()
+        self._h = C.c_void_p()
+        cfg = capi.Config()
+        cfg.struct_size = C.sizeof(capi.Config)
+        cfg.k, cfg.w = int(k), int(w)
+        cfg.variant = capi.VARIANT_V1_MIN if str(variant).lower() in ("v1", "min", "1") else capi.VARIANT_V2_SUM
+        cfg.device = int(device)
+        cfg.flags = ((capi.FLAG_DENSE_ONLY if dense_only else 0) | (capi.FLAG_DROP_SEQ if drop_seq else 0) |
+                     (capi.FLAG_TIMING if timing else 0))
+        cfg.stream = C.c_void_p(stream) if stream else None
+        cfg.cand_per_window = int(cand_per_window)
+        rc = self._lib.mxg_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise MxError(rc, (self._lib.mxg_last_error(None) or b"").decode())
+        self.k, self.w = int(k), int(w)
+        self._keep = []  # objects that must outlive the handle (borrowed device buffers)
+
+    # -- plumbing -------------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc < 0:
+            raise MxError(rc, (self._lib.mxg_last_error(self._h) or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.mxg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- assemblies -------------------------------------------------------------------------------------
+    def add_fasta(self, name, weight, fasta_path):
+        return self._check(self._lib.mxg_add_assembly_fasta(self._h, str(name).encode(), float(weight),
+                                                            str(fasta_path).encode()))
+
+    def add_records(self, name, weight, records):
+        """records: iterable of (id, sequence str/bytes)."""
+        ids, seqs = [], []
+        for rid, s in records:
+            ids.append(str(rid).encode())
+            seqs.append(s.encode("ascii") if isinstance(s, str) else bytes(s))
+        blob = b"".join(seqs)
+        offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        if seqs:
+            offs[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+        arr_ids = (C.c_char_p * max(len(ids), 1))(*ids)
+        buf = C.create_string_buffer(blob, len(blob) + 1)
+        return self._check(self._lib.mxg_add_assembly_buffers(
+            self._h, str(name).encode(), float(weight), C.cast(buf, C.c_void_p),
+            offs.ctypes.data_as(C.POINTER(C.c_uint64)), arr_ids, len(seqs)))
+
+    def add_packed_device(self, name, weight, d_ptr, rec_start, rec_len, ids=None, keepalive=None):
+        """2-bit packed bases already in HBM (see include/ntjoin_mx.h); d_ptr is borrowed."""
+        rs = np.ascontiguousarray(rec_start, dtype=np.uint64)
+        rl = np.ascontiguousarray(rec_len, dtype=np.uint64)
+        arr_ids = None
+        if ids is not None:
+            arr_ids = (C.c_char_p * len(ids))(*[str(i).encode() for i in ids])
+        if keepalive is not None:
+            self._keep.append(keepalive)
+        return self._check(self._lib.mxg_add_assembly_packed_device(
+            self._h, str(name).encode(), float(weight), C.c_void_p(int(d_ptr)),
+            rs.ctypes.data_as(C.POINTER(C.c_uint64)), rl.ctypes.data_as(C.POINTER(C.c_uint64)), arr_ids, len(rs)))
+
+    def add_tsv(self, name, weight, tsv_path):
+        return self._check(self._lib.mxg_add_assembly_tsv(self._h, str(name).encode(), float(weight),
+                                                          str(tsv_path).encode()))
+
+    def add_minimizers(self, name, weight, out_hash, pos, record, record_ids):
+        hh = np.ascontiguousarray(out_hash, dtype=np.uint64)
+        pp = np.ascontiguousarray(pos, dtype=np.uint32)
+        rr = np.ascontiguousarray(record, dtype=np.uint32)
+        ids = (C.c_char_p * max(len(record_ids), 1))(*[str(i).encode() for i in record_ids])
+        return self._check(self._lib.mxg_add_assembly_minimizers(
+            self._h, str(name).encode(), float(weight), hh.ctypes.data, pp.ctypes.data, rr.ctypes.data,
+            len(hh), ids, len(record_ids)))
+
+    @property
+    def n_assemblies(self):
+        return self._lib.mxg_num_assemblies(self._h)
+
+    def assembly_name(self, a):
+        return self._lib.mxg_assembly_name(self._h, a).decode()
+
+    def record_ids(self, a, n_records):
+        return [self._lib.mxg_record_id(self._h, a, r).decode() for r in range(int(n_records))]
+
+    # -- sketch stage -------------------------------------------------------------------------------------
+    def sketch(self, assembly=-1):
+        self._check(self._lib.mxg_sketch(self._h, int(assembly)))
+
+    def get_sketch(self, a):
+        v = capi.SketchView()
+        self._check(self._lib.mxg_get_sketch(self._h, int(a), C.byref(v)))
+        return {"out_hash": _np(v.out_hash, v.n, np.uint64), "pos": _np(v.pos, v.n, np.uint32),
+                "record": _np(v.record, v.n, np.uint32), "forward": _np(v.forward, v.n, np.uint8),
+                "record_first": _np(v.record_first, v.n_records + 1, np.uint64),
+                "record_ids": self.record_ids(a, v.n_records)}
+
+    def get_sketch_device(self, a):
+        v = capi.SketchDView()
+        self._check(self._lib.mxg_get_sketch_device(self._h, int(a), C.byref(v)))
+        return {"n": int(v.n), "out_hash": v.out_hash or 0, "pos": v.pos or 0, "record": v.record or 0,
+                "forward": v.forward or 0}
+
+    def set_sketch_device(self, a, d_hash, d_pos, d_record, d_forward, n):
+        self._check(self._lib.mxg_set_sketch_device(self._h, int(a), C.c_void_p(int(d_hash)), C.c_void_p(int(d_pos)),
+                                                    C.c_void_p(int(d_record)),
+                                                    C.c_void_p(int(d_forward)) if d_forward else None, int(n)))
+
+    def write_tsv(self, a, path, with_pos=True, with_strand=False, with_seq=True):
+        self._check(self._lib.mxg_write_tsv(self._h, int(a), str(path).encode(), int(with_pos), int(with_strand),
+                                            int(with_seq)))
+
+    # -- graph stage ----------------------------------------------------------------------------------------
+    def build_graph(self):
+        self._check(self._lib.mxg_build_graph(self._h))
+
+    def get_mx_flags(self, a):
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_uint64()
+        self._check(self._lib.mxg_get_mx_flags(self._h, int(a), C.byref(p), C.byref(n)))
+        return _np(p, n.value, np.uint8)
+
+    def get_graph(self):
+        g = capi.GraphView()
+        self._check(self._lib.mxg_get_graph(self._h, C.byref(g)))
+        A, nv, ne = int(g.n_assemblies), int(g.n_vertices), int(g.n_edges)
+        return {"n_assemblies": A,
+                "vertex_hash": _np(g.vertex_hash, nv, np.uint64),
+                "vertex_pos": _np(g.vertex_pos, A * nv, np.uint32).reshape(A, nv),
+                "vertex_record": _np(g.vertex_record, A * nv, np.uint32).reshape(A, nv),
+                "edge_u": _np(g.edge_u, ne, np.uint32), "edge_v": _np(g.edge_v, ne, np.uint32),
+                "edge_support": _np(g.edge_support, ne, np.uint32),
+                "edge_weight": _np(g.edge_weight, ne, np.float64)}
+
+    def write_dot(self, path):
+        self._check(self._lib.mxg_write_dot(self._h, str(path).encode()))
+
+    # -- stats ------------------------------------------------------------------------------------------------
+    def stats(self):
+        s = capi.Stats()
+        s.struct_size = C.sizeof(capi.Stats)
+        self._check(self._lib.mxg_get_stats(self._h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in capi.Stats._fields_ if f not in ("struct_size", "reserved")}
+
+    def reset_timers(self):
+        self._check(self._lib.mxg_reset_timers(self._h))

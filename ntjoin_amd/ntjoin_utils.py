@@ -1,0 +1,179 @@
+"""
+Drop-in counterparts of the reference's hot-path helpers (same names, argument meaning and error
+behaviour), computing on the GPU through libntjoin_mx:
+
+    read_minimizers(tsv_filename, repeat_bf=False) -> (mx_info, mxs)     reference bin/ntjoin_utils.py:167-193
+    filter_minimizers(list_mxs) -> dict                                   reference bin/ntjoin_utils.py:152-165
+    build_graph(list_mxs, weights, graph=None, black_list=None) -> MxGraph   reference bin/ntjoin_utils.py:83-141
+    calc_total_weight(list_files, weights)                                reference bin/ntjoin_utils.py:54-56
+    run_indexlr(assembly, k, w, t, **kwargs) -> tsv name                  reference bin/ntjoin_utils.py:195-202
+
+Hashes stay decimal strings at this boundary, exactly as in the reference (its vertex `name`s).  These
+functions convert between Python containers and arrays and therefore pay Python costs per minimizer;
+the fused path (ntjoin_amd.ntjoin.Ntjoin, which keeps everything in HBM between the stages) is the fast one.
+python-igraph is not a dependency: build_graph returns an MxGraph (struct-of-arrays + name index) that
+offers the small part of the igraph API the reference touches on this path.
+"""
+import datetime
+import sys
+
+import numpy as np
+
+from .engine import MxEngine, MxError
+from . import capi
+
+
+class MxGraph:
+    """Undirected minimizer graph: vertices = decimal-string hashes, edge attributes support / weight."""
+
+    def __init__(self, names, edges, support, weight):
+        self.names = list(names)                  # vertex id -> name
+        self._index = {n: i for i, n in enumerate(self.names)}
+        self.edges = [(int(s), int(t)) for s, t in edges]  # (source id, target id), first-seen orientation
+        self.support = [list(s) for s in support]  # per edge: assembly names in load order
+        self.weight = [float(x) for x in weight]
+        self._eid = {}
+        for e, (s, t) in enumerate(self.edges):
+            self._eid[(min(s, t), max(s, t))] = e
+
+    def vcount(self):
+        return len(self.names)
+
+    def ecount(self):
+        return len(self.edges)
+
+    def vertex_index(self, name):
+        return self._index[name]
+
+    def get_eid(self, source, target):
+        s = source if isinstance(source, int) else self._index[source]
+        t = target if isinstance(target, int) else self._index[target]
+        return self._eid[(min(s, t), max(s, t))]
+
+    def edge_list_named(self):
+        """[(source name, target name, support list, weight)] in edge-id order."""
+        return [(self.names[s], self.names[t], sup, w) for (s, t), sup, w in zip(self.edges, self.support, self.weight)]
+
+    def degree(self):
+        deg = [0] * len(self.names)
+        for s, t in self.edges:
+            deg[s] += 1
+            deg[t] += 1
+        return deg
+
+    def to_igraph(self):
+        import igraph as ig  # optional
+        g = ig.Graph()
+        g.add_vertices(self.names)
+        g.add_edges(self.edges)
+        g.es["support"] = self.support
+        g.es["weight"] = self.weight
+        return g
+
+
+def calc_total_weight(list_files, weights):
+    "Calculate the total weight of an edge given the assembly support"
+    return sum((weights[f] for f in list_files))
+
+
+def _lists_from_sketch(sk, keep):
+    out = []
+    first = sk["record_first"]
+    hashes = sk["out_hash"]
+    for r in range(len(sk["record_ids"])):
+        lo, hi = int(first[r]), int(first[r + 1])
+        if hi > lo:  # only records with at least one entry appear in the reference's `mxs` (:176)
+            sel = keep[lo:hi]
+            out.append([str(x) for x in hashes[lo:hi][sel].tolist()])
+    return out
+
+
+def read_minimizers(tsv_filename, repeat_bf=False, k=32):
+    "Read the minimizers from a file, removing duplicate minimizers"
+    print(datetime.datetime.today(), ": Reading minimizers", tsv_filename, file=sys.stdout)
+    if repeat_bf:
+        raise NotImplementedError("repeat_bf is never supplied on ntJoin's own path (bin/ntjoin.py:178)")
+    try:
+        with MxEngine(k=k, w=1) as eng:
+            eng.add_tsv(tsv_filename, 1.0, tsv_filename)
+            eng.build_graph()  # one assembly: MXG_MX_UNIQUE = "seen exactly once in this assembly"
+            sk = eng.get_sketch(0)
+            flags = eng.get_mx_flags(0)
+    except MxError as e:
+        if e.code == capi.MXG_EIO and "three" in str(e):
+            raise ValueError(str(e)) from None  # the reference's tuple-unpack ValueError (:181)
+        if e.code == capi.MXG_EIO:
+            raise FileNotFoundError(str(e)) from None
+        raise
+    uniq = (flags & capi.MX_UNIQUE) != 0
+    ids = sk["record_ids"]
+    mx_info = {str(h): (ids[r], int(p)) for h, p, r in
+               zip(sk["out_hash"][uniq].tolist(), sk["pos"][uniq].tolist(), sk["record"][uniq].tolist())}
+    return mx_info, _lists_from_sketch(sk, uniq)
+
+
+def _engine_from_lists(list_mxs, weights=None):
+    eng = MxEngine(k=32, w=1)
+    for assembly in list_mxs:
+        lists = list_mxs[assembly]
+        hashes = np.fromiter((int(mx) for lst in lists for mx in lst), dtype=np.uint64)
+        rec = np.repeat(np.arange(len(lists), dtype=np.uint32), [len(lst) for lst in lists]) if lists else \
+            np.zeros(0, dtype=np.uint32)
+        pos = np.zeros(len(hashes), dtype=np.uint32)
+        eng.add_minimizers(str(assembly), 1.0 if weights is None else weights[assembly], hashes, pos, rec,
+                           [str(i) for i in range(len(lists))])
+    return eng
+
+
+def filter_minimizers(list_mxs):
+    "Filters out minimizers that are not found in all assemblies"
+    print(datetime.datetime.today(), ": Filtering minimizers", file=sys.stdout)
+    if not list_mxs:
+        raise TypeError("unbound method set.intersection() needs an argument")  # what the reference raises
+    return_mxs = {}
+    with _engine_from_lists(list_mxs) as eng:
+        eng.build_graph()
+        for a, assembly in enumerate(list_mxs):
+            flags = eng.get_mx_flags(a)
+            keep = (flags & capi.MX_INALL) != 0
+            out, i = [], 0
+            for lst in list_mxs[assembly]:
+                n = len(lst)
+                out.append([mx for mx, kf in zip(lst, keep[i:i + n].tolist()) if kf])
+                i += n
+            return_mxs[assembly] = out
+    return return_mxs
+
+
+def build_graph(list_mxs, weights, graph=None, black_list=None):
+    "Builds an undirected graph: nodes=minimizers; edges=between adjacent minimizers"
+    print(datetime.datetime.today(), ": Building graph", file=sys.stdout)
+    if graph is not None or black_list is not None:
+        raise NotImplementedError("incremental build_graph (graph=/black_list=) is not used by ntJoin's CLI "
+                                  "(bin/ntjoin.py:201) and is out of scope")
+    names_in_order = list(list_mxs.keys())
+    with _engine_from_lists(list_mxs, weights) as eng:
+        eng.build_graph()
+        for a in range(len(names_in_order)):
+            flags = eng.get_mx_flags(a)
+            if not np.all((flags & capi.MX_SHARED) != 0):
+                raise ValueError("build_graph on the GPU expects filter_minimizers' output: every minimizer exactly "
+                                 "once in every assembly (the reference's call site, bin/ntjoin.py:198-201)")
+        g = eng.get_graph()
+    print(datetime.datetime.today(), ": Adding vertices", file=sys.stdout)
+    print(datetime.datetime.today(), ": Adding edges", file=sys.stdout)
+    print(datetime.datetime.today(), ": Adding attributes", file=sys.stdout)
+    names = [str(h) for h in g["vertex_hash"].tolist()]
+    support = [[names_in_order[b] for b in range(len(names_in_order)) if m >> b & 1]
+               for m in g["edge_support"].tolist()]
+    return MxGraph(names, zip(g["edge_u"].tolist(), g["edge_v"].tolist()), support, g["edge_weight"].tolist())
+
+
+def run_indexlr(assembly, k, w, t, **kwargs):
+    "Run indexlr on the given assembly with the specified k and w"
+    out = f"{assembly}.k{k}.w{w}.tsv"
+    with MxEngine(k=int(k), w=int(w)) as eng:
+        eng.add_fasta(out, 1.0, assembly)
+        eng.sketch()
+        eng.write_tsv(0, out, with_pos=True, with_strand=False, with_seq=True)
+    return out

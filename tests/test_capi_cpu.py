@@ -1,0 +1,79 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every declared symbol, formats text like
+python's repr(), and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import random
+import re
+
+import pytest
+
+from tests.conftest import REPO
+
+
+def _lib():
+    from ntjoin_amd import capi
+    if not os.path.exists(capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return capi, capi.load()
+
+
+def test_every_declared_symbol_is_exported():
+    capi, lib = _lib()
+    header = open(os.path.join(REPO, "include", "ntjoin_mx.h"), encoding="utf-8").read()
+    declared = set(re.findall(r"\b(mxg_[a-z_0-9]+)\s*\(", header))
+    declared -= {"mxg_create"} if False else set()
+    assert declared, "no declarations found"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ntjoin_mx.h but not exported"
+    assert set(capi.SYMBOLS) == declared
+    assert lib.mxg_abi_version() == capi.ABI_VERSION
+
+
+def test_struct_sizes_match_header():
+    capi, _ = _lib()
+    # mxg_config: 6*u32 + ptr + u32 + 5*u32 (with natural alignment) ; mxg_stats layout is mirrored field by field
+    assert C.sizeof(capi.Config) == 56
+    assert C.sizeof(capi.Stats) == 8 + 8 * 8 + 3 * 8 + 2 * 8 + 8 * 8
+
+
+def test_py_repr_double_matches_python():
+    _, lib = _lib()
+    rng = random.Random(9)
+    vals = [0.0, 1.0, 2.0, 3.0, 1.5, 0.1, 0.2, 0.1 + 0.2, 0.30000000000000004, 100000.0, 1e15, 1e16, 1e17, 1.5e16,
+            123456789012345680.0, 1e-4, 1e-5, 0.0001234, 5e-324, 1.7976931348623157e308, -2.5, 1e22, 1e21, 2.0 ** 53,
+            0.1 + 0.2 + 1.5, 3.3000000000000003, float("inf")]
+    vals += [rng.uniform(-10, 10) for _ in range(200)] + [rng.random() * 10 ** rng.randint(-10, 25) for _ in range(200)]
+    vals += [float(rng.randint(0, 50)) / 4 for _ in range(50)]
+    buf = C.create_string_buffer(64)
+    for v in vals:
+        n = lib.mxg_py_repr_double(v, buf, 64)
+        assert buf.value.decode() == repr(v) and n == len(repr(v)), v
+
+
+def test_py_repr_str_matches_python():
+    _, lib = _lib()
+    buf = C.create_string_buffer(256)
+    for s in ["test", "1_f", "chr'1", 'chr"1', "a'b\"c", "back\\slash", "tab\there", "", "ctgA0_f", "naïve", "x\x01y"]:
+        lib.mxg_py_repr_str(s.encode("utf-8"), buf, 256)
+        assert buf.value.decode("utf-8") == repr(s), s
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK), reason="a GPU is visible")
+def test_no_cpu_fallback():
+    """without a HIP device the engine refuses to start: nothing silently routes to a CPU path"""
+    from ntjoin_amd.engine import MxEngine, MxError
+    from ntjoin_amd import capi
+    with pytest.raises(MxError) as ei:
+        MxEngine(k=32, w=100)
+    assert ei.value.code == capi.MXG_EDEVICE
+
+
+def test_product_does_not_import_oracle():
+    """the package never references oracle/ (the oracle is the checker, never the shipped path)"""
+    pkg = os.path.join(REPO, "ntjoin_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(root, f), encoding="utf-8").read()
+                assert "mx_oracle" not in text and "graph_oracle" not in text and "import oracle" not in text, f
