@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mbp M]
+
+One STEP = one pass of the whole hot path over one batch of synthetic input already resident in HBM:
+sketch every assembly (ntHash + window arg-min) -> uniqueness -> intersection -> adjacency edges, results
+handed back through the C-ABI.  Workload = BASELINE.json configs[1]: 1 x 100 Mbp reference (weight 2) +
+a target derived from it (weight 1), k=32, w=1000.  metric = Gbp/s = (sum of bases over all assemblies) / time.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank sketches its own
+100 Mbp + 100 Mbp shard of an N-times larger genome, the per-assembly sketches are exchanged with ONE RCCL
+all-gather each (the path's only exchange step), and every rank builds the graph of the union.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+K, W = 32, 1000
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+ALG_BYTES_PER_BASE_HASH = 0.25  # hash kernel: one 2-bit packed base read per base
+
+
+def cpu_baseline(ref, tgt):
+    """The oracle (scalar C port of indexlr + Python port of the graph stage) on the SAME workload, 1 core.
+    Checker/baseline only: nothing here is on the product path."""
+    from ntjoin_amd import synth
+    from oracle import graph_oracle
+    from tests import _oracle
+    orc = _oracle.load()
+    warm = synth.to_ascii(ref[0][:2_000_000])
+    orc.sketch(warm, K, W)  # fault the allocator's pages in once
+    t0 = time.perf_counter()
+    sketches = []
+    for recs in (ref, tgt):
+        out = []
+        for codes in recs:
+            out.append(orc.sketch(synth.to_ascii(codes), K, W))
+        sketches.append(out)
+    t_sketch = time.perf_counter() - t0
+    with tempfile.TemporaryDirectory() as td:
+        names = [os.path.join(td, "ref.k32.w1000.tsv"), os.path.join(td, "tgt.k32.w1000.tsv")]
+        for path, out in zip(names, sketches):
+            with open(path, "w", encoding="ascii") as fh:
+                for r, mxs in enumerate(out):
+                    fh.write(f"{r}\t" + " ".join(f"{h}:{p}:N" for h, p, _, _ in mxs) + "\n")
+        t1 = time.perf_counter()
+        state = graph_oracle.load_and_build([names[0]], [2.0], names[1], 1.0)
+        t_graph = time.perf_counter() - t1
+    bases = sum(len(c) for c in ref) + sum(len(c) for c in tgt)
+    n_mx = sum(len(m) for out in sketches for m in out)
+    return {"seconds": t_sketch + t_graph, "t_sketch": t_sketch, "t_graph": t_graph, "bases": bases,
+            "minimizers": n_mx, "vertices": len(state["vertices"]), "edges": len(state["edges"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mbp", type=float, default=100.0, help="reference size per rank in Mbp (configs[1]: 100)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N ...")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ntjoin_amd import synth
+    from ntjoin_amd.engine import MxEngine
+    from ntjoin_amd.dist import allgather_union_graph
+
+    n_bases = int(args.mbp * 1e6)
+    ref, tgt = synth.config2(seed=1 + 100 * rank, n_bases=n_bases)
+    bases_rank = sum(len(c) for c in ref) + sum(len(c) for c in tgt)
+    keep = []
+    eng = MxEngine(k=K, w=W, device=local_rank, timing=True)
+    for name, weight, recs in (("ref.fa.k32.w1000.tsv", 2.0, ref), ("tgt.fa.k32.w1000.tsv", 1.0, tgt)):
+        words, starts, lens = synth.pack_records(recs)
+        d = torch.from_numpy(words.view(np.int32)).cuda()  # bases resident in HBM before the timed region
+        keep.append(d)
+        eng.add_packed_device(name, weight, d.data_ptr(), starts, lens)
+    union = None
+
+    def step():
+        nonlocal union
+        eng.sketch(0)
+        eng.sketch(1)
+        if world > 1:
+            union = allgather_union_graph(eng, K, W, local_rank, union)
+        else:
+            eng.build_graph()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.reset_timers()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt, float(bases_rank)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, bases_total = float(tmax[0]), float(t[1])
+    else:
+        bases_total = float(bases_rank)
+
+    st = eng.stats()
+    gst = (union.stats() if union is not None else st)
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = bases_total * args.steps / dt / 1e9
+        # dominant kernel = the ntHash/candidate kernel; HIP events recorded by the library on ITS launch stream
+        launches = max(st["launches_hash"], 1)
+        avg_ms = st["ms_hash"] / launches
+        bytes_per_launch = ALG_BYTES_PER_BASE_HASH * st["hash_kernel_bases"] / launches
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_hash_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Gbp/s minimizer-sketch+graph-build (k=32,w=1000)", "value": round(value, 4), "unit": "Gbp/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: synthetic 1x{args.mbp:g} Mbp reference + derived target per GPU, "
+                                   "k=32 w=1000, weights 2/1, bases resident in HBM (2-bit packed)",
+                       "k": K, "w": W, "bases_per_step": int(bases_total), "minimizers": int(st["minimizers"]),
+                       "vertices": int(gst["vertices"]), "edges": int(gst["edges"]),
+                       "parallelism": f"contig-sharded x{world}, RCCL all-gather of sketches" if world > 1 else "1 GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_hash (ntHash fwd/rc rolling + candidate filter)",
+                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "alg_bytes_per_base": ALG_BYTES_PER_BASE_HASH,
+                         "avg_launch_ms": round(avg_ms, 4), "launches": int(st["launches_hash"]),
+                         "bases_per_launch": int(st["hash_kernel_bases"] / launches)},
+            "stage_ms_per_step": {"hash": round(st["ms_hash"] / args.steps, 4),
+                                  "graph": round(gst["ms_graph"] / args.steps, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(ref, tgt)
+            out["cpu_baseline"] = {
+                "value": round(cb["bases"] / cb["seconds"] / 1e9, 5), "unit": "Gbp/s", "cores": 1, "kind": "port",
+                "sample": f"the whole step workload ({cb['bases'] / 1e6:.0f} Mbp): scalar C port of indexlr "
+                          f"({cb['t_sketch']:.1f} s) + Python port of read/filter/build_graph ({cb['t_graph']:.1f} s)",
+            }
+            # same inputs -> same counts (full bit-exact parity lives in tests/)
+            out["parity_counts_match_cpu"] = bool(cb["minimizers"] == st["minimizers"] and
+                                                  cb["vertices"] == st["vertices"] and cb["edges"] == st["edges"])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -156,6 +156,8 @@ const char *mxg_assembly_name(const mxg_handle *h, int assembly);
 /* id of record r of an assembly (first whitespace-delimited token of the FASTA header) */
 const char *mxg_record_id(const mxg_handle *h, int assembly, uint64_t record);
 uint64_t mxg_record_length(const mxg_handle *h, int assembly, uint64_t record);
+uint64_t mxg_num_records(const mxg_handle *h, int assembly);
+double mxg_assembly_weight(const mxg_handle *h, int assembly);
 
 /* ---- sketch stage (replaces indexlr) --------------------------------------------------------- */
 int mxg_sketch(mxg_handle *h, int assembly /* -1 = every assembly that has bases and no sketch yet */);

@@ -15,7 +15,7 @@ SYMBOLS = [
     "mxg_abi_version", "mxg_create", "mxg_destroy", "mxg_last_error",
     "mxg_add_assembly_fasta", "mxg_add_assembly_buffers", "mxg_add_assembly_packed_device",
     "mxg_add_assembly_tsv", "mxg_add_assembly_minimizers", "mxg_num_assemblies", "mxg_assembly_name",
-    "mxg_record_id", "mxg_record_length",
+    "mxg_record_id", "mxg_record_length", "mxg_num_records", "mxg_assembly_weight",
     "mxg_sketch", "mxg_get_sketch", "mxg_get_sketch_device", "mxg_set_sketch_device", "mxg_write_tsv",
     "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_write_dot",
     "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers",
@@ -89,6 +89,10 @@ def load():
     L.mxg_record_id.restype = cp
     L.mxg_record_length.argtypes = [vp, i32, u64]
     L.mxg_record_length.restype = u64
+    L.mxg_num_records.argtypes = [vp, i32]
+    L.mxg_num_records.restype = u64
+    L.mxg_assembly_weight.argtypes = [vp, i32]
+    L.mxg_assembly_weight.restype = C.c_double
     L.mxg_sketch.argtypes = [vp, i32]
     L.mxg_get_sketch.argtypes = [vp, i32, C.POINTER(SketchView)]
     L.mxg_get_sketch_device.argtypes = [vp, i32, C.POINTER(SketchDView)]

@@ -266,6 +266,18 @@ uint64_t mxg_record_length(const mxg_handle *h, int assembly, uint64_t record)
     return record < a->recs.size() ? a->recs[record].len : 0;
 }
 
+uint64_t mxg_num_records(const mxg_handle *h, int assembly)
+{
+    if (!h || assembly < 0 || (size_t)assembly >= h->asms.size()) return 0;
+    return h->asms[assembly]->recs.size();
+}
+
+double mxg_assembly_weight(const mxg_handle *h, int assembly)
+{
+    if (!h || assembly < 0 || (size_t)assembly >= h->asms.size()) return 0.0;
+    return h->asms[assembly]->weight;
+}
+
 int mxg_sketch(mxg_handle *h, int assembly)
 {
     if (!h) return MXG_EINVAL;

@@ -89,6 +89,11 @@ struct Assembly {
     std::vector<uint32_t> ctg_nk;    // eligible contig -> valid k-mer count
     std::vector<uint32_t> ctg_run0;  // eligible contig -> first run (size n+1)
     uint64_t total_kmers = 0;        // over eligible contigs
+    // device copies of the tables above + strip / k-mer prefix tables (built once, by the first sketch)
+    bool tables_ready = false;
+    std::vector<uint32_t> strip0_dense, strip0_sparse;  // [n_runs+1] exclusive prefix of strips per run
+    std::vector<uint64_t> g0;                           // [n_runs+1] exclusive prefix of k-mers per run
+    DevBuf d_runs, d_strip0_dense, d_strip0_sparse, d_g0, d_ctg_nk, d_ctg_rec, d_ctg_run0;
     // sketch (device, ordered by (record,pos)) + lazily filled host mirror
     bool has_sketch = false;
     uint64_t n_mx = 0;
@@ -133,8 +138,8 @@ struct mxg_handle {
     mxg::HashTab tab{};
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
     // scratch reused across calls
-    mxg::DevBuf s_runs, s_strip0, s_g0, s_ctg_nk, s_ctg_rec, s_ctg_run0;
-    mxg::DevBuf s_cand_h, s_cand_k, s_cand_c, s_sel, s_bsum, s_total, s_misc;
+    mxg::DevBuf scratch[40];  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
+    uint64_t arena_cap_hint = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 

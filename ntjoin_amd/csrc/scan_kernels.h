@@ -68,4 +68,40 @@ __device__ __forceinline__ uint32_t block_exclusive_256(uint32_t c, uint32_t *sh
     return sh[threadIdx.x] - c;
 }
 
+// ---- u32 array exclusive scan (tile sums -> k_scan_sums -> downsweep) -------------------------------
+static __global__ __launch_bounds__(256) void k_tile_sum_u32(const uint32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ bsum)
+{
+    __shared__ uint32_t sh[256];
+    uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
+    uint32_t c = 0;
+    for (int u = 0; u < TILE_PER_THREAD; ++u)
+        if (base + u < n) c += in[base + u];
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
+}
+
+// out[i] = exclusive prefix of in[0..i)   (bsum already exclusive-scanned)
+static __global__ __launch_bounds__(256) void k_tile_excl_u32(const uint32_t *__restrict__ in, uint32_t n,
+                                                               const uint32_t *__restrict__ bsum, uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t sh[256];
+    uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
+    uint32_t v[TILE_PER_THREAD];
+    uint32_t c = 0;
+    for (int u = 0; u < TILE_PER_THREAD; ++u) {
+        v[u] = base + u < n ? in[base + u] : 0;
+        c += v[u];
+    }
+    uint32_t run = bsum[blockIdx.x] + block_exclusive_256(c, sh);
+    for (int u = 0; u < TILE_PER_THREAD; ++u) {
+        if (base + u < n) out[base + u] = run;
+        run += v[u];
+    }
+}
+
 }  // namespace mxg

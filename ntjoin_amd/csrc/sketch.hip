@@ -4,27 +4,43 @@
 // arg-min of canonical ntHash in every window of w consecutive valid k-mers; distinct arg-mins in
 // position order; printed hash = second ntHash value ext(min_hash).
 //
-// Stateless, data-parallel formulation used here (equivalent to the stateful ring-buffer loop, proved
-// in DESIGN.md and checked against the oracle): k-mer p (contig-local valid-k-mer index) is a
-// minimizer iff  L(p) + R(p) + 1 >= w  where
+// Stateless, data-parallel formulation (equivalent to btllib's stateful ring-buffer loop; argued in
+// DESIGN.md, checked against the oracle): k-mer p (contig-local valid-k-mer index) is a minimizer iff
+//     L(p) + R(p) + 1 >= w
 //     L(p) = number of consecutive k-mers left of p with hash >= h(p)   (capped by p and w-1)
 //     R(p) = number of consecutive k-mers right of p with hash >  h(p)  (capped by n-1-p and w-1)
 // i.e. there is room for a window of w k-mers around p in which p is the rightmost minimum.
 //
+// Fast path (sparse candidates): only k-mers with min_hash < tau (tau = 2^64 * c / w, c ~ 12 expected per
+// window) can be the minimum of a window that contains at least one of them, and k-mers >= tau never block
+// a candidate.  So the window logic runs on ~1.2 % of the k-mers.  Windows that contain NO candidate lie
+// inside a candidate-free stretch ("gap") of >= w k-mers; those stretches are detected exactly and re-done
+// by the dense path (every k-mer a candidate) as stand-alone ranges; the two result sets are disjoint and
+// their union is the exact sketch (low-complexity sequence simply degrades to the dense path).
+//
 // Kernels:
-//   k_hash<S,...>   one lane per strip of S consecutive k-mers inside one valid run: k warm-up steps, then
-//                   rolling forward / reverse-complement ntHash (split-rotate done on 32-bit halves),
-//                   table-driven (LDS, one ds_read_b128 per base).  Emits CANDIDATES (min_hash, contig-local
-//                   k-mer index, contig|strand).  Dense mode: every k-mer is a candidate.
-//   k_resolve       one lane per candidate: scan neighbouring candidates left/right for a blocker.
-//   k_count/k_emit  ordered stream compaction of the selected candidates into the sketch arrays
-//                   (out_hash = ext(min_hash), pos from the run table, record index, strand).
+//   k_hash_sparse  one lane per strip of S consecutive k-mers of one valid run: k warm-up steps then rolling
+//                  fwd/rc ntHash (split-rotate on 32-bit halves; one ds_read_b128 of the 20-entry step table per
+//                  base).  Candidates are staged per WAVE in LDS (ballot/mbcnt slot allocation, no atomics) and
+//                  flushed to an HBM arena with ONE atomic bump per flush, coalesced 16 B entries.
+//   k_reorder      arena entry -> its ordered slot (exclusive scan of per-strip counts + rank inside the strip)
+//   k_hash_dense   every k-mer is a candidate, written at its own index (DENSE_ONLY mode and gap fix-up)
+//   k_resolve      one lane per candidate: nearest smaller / smaller-or-equal neighbour scan; gap detection
+//   k_count/k_scan_sums/k_emit   ordered stream compaction into the sketch arrays
+//   k_merge        merge of the (small) gap sketch into the batch sketch by (record,pos)
 #include <algorithm>
 
 #include "mxg_internal.h"
 #include "scan_kernels.h"
 
 namespace mxg {
+
+enum Scratch {
+    SC_CAND_H, SC_CAND_K, SC_CAND_C, SC_SEL, SC_BSUM, SC_CTRL, SC_ARENA, SC_STRIP_CNT, SC_STRIP_META,
+    SC_STRIP_PREF, SC_SBSUM, SC_GAPS, SC_ST_HASH, SC_ST_POS, SC_ST_REC, SC_ST_FWD, SC_G_HASH, SC_G_POS,
+    SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_COUNT
+};
+static_assert(SC_COUNT <= 40, "scratch pool too small");
 
 // ------------------------------------------------------------------------------------------------------
 // device helpers
@@ -57,12 +73,17 @@ __device__ __forceinline__ uint32_t fetch16(const uint32_t *__restrict__ packed,
 }
 
 template <int VARIANT>
-__device__ __forceinline__ uint64_t canonical(const H2 &h, bool &forward)
+__device__ __forceinline__ uint64_t canonical(const H2 &h)
 {
     uint64_t f = ((uint64_t)h.fhi << 32) | h.flo, r = ((uint64_t)h.rhi << 32) | h.rlo;
-    forward = f <= r;
-    if (VARIANT == MXG_VARIANT_V1_MIN) return forward ? f : r;
+    if (VARIANT == MXG_VARIANT_V1_MIN) return f <= r ? f : r;
     return f + r;
+}
+
+__device__ __forceinline__ bool is_forward(const H2 &h)
+{
+    uint64_t f = ((uint64_t)h.fhi << 32) | h.flo, r = ((uint64_t)h.rhi << 32) | h.rlo;
+    return f <= r;
 }
 
 __device__ __forceinline__ uint64_t ext_hash(uint64_t h0, uint64_t mult)
@@ -71,7 +92,33 @@ __device__ __forceinline__ uint64_t ext_hash(uint64_t h0, uint64_t mult)
     return t ^ (t >> 27);
 }
 
-struct HashParams {
+// locate strip s: run index lo with run_strip0[lo] <= s < run_strip0[lo+1]
+__device__ __forceinline__ uint32_t find_run(const uint32_t *__restrict__ run_strip0, uint32_t lo, uint32_t hi, uint32_t s)
+{
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (run_strip0[mid] <= s) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <class T>
+__device__ __forceinline__ void warm_up(H2 &h, const uint32_t *__restrict__ packed, uint64_t b, uint32_t k, const T *tab)
+{
+    for (uint32_t t = 0; t < k; t += 16) {  // k steps with no outgoing base
+        uint32_t chunk = fetch16(packed, b + t);
+        uint32_t n = min(16u, k - t);
+        for (uint32_t u = 0; u < n; ++u) {
+            nt_step(h, tab[16 + (chunk & 3u)]);
+            chunk >>= 2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// dense hash kernel
+// ------------------------------------------------------------------------------------------------------
+struct DenseParams {
     const uint32_t *packed;
     const Run *runs;
     const uint32_t *run_strip0;  // [n_runs+1] exclusive prefix of strips per run
@@ -86,20 +133,15 @@ struct HashParams {
     HashTab tab;
 };
 
-// Dense mode: every valid k-mer becomes a candidate at arena slot (its global k-mer index - g_base).
 template <int S, int VARIANT>
-__global__ __launch_bounds__(256) void k_hash_dense(const HashParams p)
+__global__ __launch_bounds__(256) void k_hash_dense(const DenseParams p)
 {
     __shared__ uint4 tab[20];
     if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
     __syncthreads();
     const uint32_t s = p.strip_lo + blockIdx.x * 256u + threadIdx.x;
     if (s >= p.strip_hi) return;
-    uint32_t lo = p.run_lo, hi = p.run_hi;  // run_strip0[lo] <= s < run_strip0[hi]
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (p.run_strip0[mid] <= s) lo = mid; else hi = mid;
-    }
+    const uint32_t lo = find_run(p.run_strip0, p.run_lo, p.run_hi, s);
     const Run run = p.runs[lo];
     const uint32_t j0 = (s - p.run_strip0[lo]) * (uint32_t)S;
     const uint32_t len = min((uint32_t)S, run.n_kmers - j0);
@@ -109,21 +151,10 @@ __global__ __launch_bounds__(256) void k_hash_dense(const HashParams p)
     const uint32_t k = p.k;
 
     H2 h = {0u, 0u, 0u, 0u};
-    for (uint32_t t = 0; t < k; t += 16) {  // warm-up: k steps with no outgoing base
-        uint32_t chunk = fetch16(p.packed, b + t);
-        uint32_t n = min(16u, k - t);
-        for (uint32_t u = 0; u < n; ++u) {
-            nt_step(h, tab[16 + (chunk & 3u)]);
-            chunk >>= 2;
-        }
-    }
-    {
-        bool fw;
-        uint64_t h0 = canonical<VARIANT>(h, fw);
-        p.cand_h[gi] = h0;
-        p.cand_k[gi] = kidx;
-        p.cand_c[gi] = run.contig | (fw ? 0u : 0x80000000u);
-    }
+    warm_up(h, p.packed, b, k, tab);
+    p.cand_h[gi] = canonical<VARIANT>(h);
+    p.cand_k[gi] = kidx;
+    p.cand_c[gi] = run.contig | (is_forward(h) ? 0u : 0x80000000u);
 #pragma unroll 1
     for (uint32_t blk = 0; blk < (uint32_t)S / 16; ++blk) {
         uint32_t cout = fetch16(p.packed, b + 16u * blk);
@@ -134,35 +165,176 @@ __global__ __launch_bounds__(256) void k_hash_dense(const HashParams p)
             nt_step(h, tab[idx]);
             uint32_t j = 1u + 16u * blk + u;
             if (j < len) {
-                bool fw;
-                uint64_t h0 = canonical<VARIANT>(h, fw);
-                p.cand_h[gi + j] = h0;
+                p.cand_h[gi + j] = canonical<VARIANT>(h);
                 p.cand_k[gi + j] = kidx + j;
-                p.cand_c[gi + j] = run.contig | (fw ? 0u : 0x80000000u);
+                p.cand_c[gi + j] = run.contig | (is_forward(h) ? 0u : 0x80000000u);
             }
         }
     }
 }
 
-// One lane per candidate.  sel[i] = 1 iff candidate i is a minimizer (see file header).
-__global__ __launch_bounds__(256) void k_resolve(const uint64_t *__restrict__ ch, const uint32_t *__restrict__ ck,
-                                                 const uint32_t *__restrict__ cc, uint32_t n,
-                                                 const uint32_t *__restrict__ ctg_nk, uint32_t w,
-                                                 uint8_t *__restrict__ sel)
+// ------------------------------------------------------------------------------------------------------
+// sparse hash kernel
+// ------------------------------------------------------------------------------------------------------
+constexpr int WCAP = 256;  // LDS candidate slots per wave (flushed when fewer than 64 remain)
+
+struct SparseParams {
+    const uint32_t *packed;
+    const Run *runs;
+    const uint32_t *run_strip0;
+    uint32_t run_lo, run_hi;
+    uint32_t strip_lo, strip_hi;
+    uint32_t k;
+    uint32_t tau_hi;      // candidate iff high word of min_hash < tau_hi
+    uint4 *arena;         // {hash lo, hash hi, strip (relative to strip_lo), j | seq<<10 | fw<<20}
+    uint32_t arena_cap;
+    uint32_t *ctrl;       // [0] arena counter
+    uint32_t *strip_cnt;  // [n_strips] candidates per strip
+    uint2 *strip_meta;    // [n_strips] {contig, kidx of the strip's first k-mer}
+    HashTab tab;
+};
+
+template <int S, int VARIANT>
+__global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
 {
+    static_assert(S % 16 == 0 && S <= 1024, "strip length");
+    __shared__ uint4 tab[20];
+    __shared__ uint64_t bh[4][WCAP];
+    __shared__ uint32_t bm[4][WCAP];
+    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t srel = blockIdx.x * 256u + threadIdx.x;        // strip index relative to strip_lo
+    const uint32_t s = p.strip_lo + srel;
+    const bool active = s < p.strip_hi;                          // inactive lanes stay alive (wave-wide flush)
+    uint32_t len = 0, contig = 0, kidx = 0;
+    uint64_t b = 0;
+    if (active) {
+        const uint32_t lo = find_run(p.run_strip0, p.run_lo, p.run_hi, s);
+        const Run run = p.runs[lo];
+        const uint32_t j0 = (s - p.run_strip0[lo]) * (uint32_t)S;
+        len = min((uint32_t)S, run.n_kmers - j0);
+        b = run.base_off + j0;
+        contig = run.contig;
+        kidx = run.kidx0 + j0;
+        p.strip_meta[srel] = make_uint2(contig, kidx);
+    }
+    const uint32_t k = p.k;
+    const uint32_t tau_hi = p.tau_hi;
+    uint32_t cnt_w = 0;  // wave-uniform: entries staged in this wave's LDS buffer
+    uint32_t seq = 0;    // this lane's candidates so far
+    const uint32_t wave_srel0 = blockIdx.x * 256u + wv * 64u;
+
+    auto flush = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        uint32_t m = cnt_w, base = 0;
+        if (lane == 0) base = atomicAdd(&p.ctrl[0], m);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (uint32_t i = lane; i < m; i += 64) {
+            if (base + i < p.arena_cap) {
+                uint64_t hh = bh[wv][i];
+                uint32_t mt = bm[wv][i];
+                p.arena[base + i] = make_uint4((uint32_t)hh, (uint32_t)(hh >> 32), wave_srel0 + (mt & 63u), mt >> 6);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        cnt_w = 0;
+    };
+    auto visit = [&](const H2 &h, uint32_t j) {
+        uint64_t h0 = canonical<VARIANT>(h);
+        bool c = (j < len) && ((uint32_t)(h0 >> 32) < tau_hi);
+        uint64_t mask = __ballot(c);
+        if (mask) {  // wave-uniform
+            if (c) {
+                uint32_t slot = cnt_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                bh[wv][slot] = h0;
+                bm[wv][slot] = lane | (j << 6) | (seq << 16) | ((is_forward(h) ? 1u : 0u) << 26);
+                ++seq;
+            }
+            cnt_w += (uint32_t)__popcll(mask);
+            if (cnt_w > WCAP - 64) flush();
+        }
+    };
+
+    H2 h = {0u, 0u, 0u, 0u};
+    warm_up(h, p.packed, b, k, tab);
+    visit(h, 0);
+#pragma unroll 1
+    for (uint32_t blk = 0; blk < (uint32_t)S / 16; ++blk) {
+        uint32_t cout = fetch16(p.packed, b + 16u * blk);
+        uint32_t cin = fetch16(p.packed, b + k + 16u * blk);
+#pragma unroll
+        for (uint32_t u = 0; u < 16; ++u) {
+            uint32_t idx = ((cout >> (2 * u)) & 3u) * 4u + ((cin >> (2 * u)) & 3u);
+            nt_step(h, tab[idx]);
+            visit(h, 1u + 16u * blk + u);
+        }
+    }
+    if (cnt_w) flush();
+    if (active) p.strip_cnt[srel] = seq;
+}
+
+// arena entry -> ordered candidate slot
+__global__ __launch_bounds__(256) void k_reorder(const uint4 *__restrict__ arena, const uint32_t *__restrict__ ctrl,
+                                                 uint32_t arena_cap, const uint32_t *__restrict__ strip_pref,
+                                                 const uint2 *__restrict__ strip_meta, uint64_t *__restrict__ ch,
+                                                 uint32_t *__restrict__ ck, uint32_t *__restrict__ cc)
+{
+    const uint32_t n = min(ctrl[0], arena_cap);
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= n) return;
+    const uint4 a = arena[e];
+    const uint32_t j = a.w & 1023u, seq = (a.w >> 10) & 1023u, fw = (a.w >> 20) & 1u;
+    const uint32_t dst = strip_pref[a.z] + seq;
+    const uint2 sm = strip_meta[a.z];
+    ch[dst] = ((uint64_t)a.y << 32) | a.x;
+    ck[dst] = sm.y + j;
+    cc[dst] = sm.x | (fw ? 0u : 0x80000000u);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// resolve
+// ------------------------------------------------------------------------------------------------------
+struct ResolveParams {
+    const uint64_t *ch;
+    const uint32_t *ck, *cc;
+    const uint32_t *n_ptr;  // number of candidates (device), clamped to n_cap
+    uint32_t n_cap;
+    const uint32_t *ctg_nk;
+    uint32_t w;
+    uint8_t *sel;
+    // gap detection (sparse mode)
+    uint32_t ctg_lo, ctg_hi;  // contigs of this batch
+    uint4 *gaps;              // {contig, k_lo, k_hi, 0}
+    uint32_t gap_cap;
+    uint32_t *gap_count;
+};
+
+__device__ __forceinline__ void push_gap(const ResolveParams &p, uint32_t c, uint32_t lo, uint32_t hi)
+{
+    uint32_t idx = atomicAdd(p.gap_count, 1u);
+    if (idx < p.gap_cap) p.gaps[idx] = make_uint4(c, lo, hi, 0u);
+}
+
+// One lane per candidate.  sel[i] = 1 iff candidate i is a minimizer (see file header).
+template <bool GAPS>
+__global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
+{
+    const uint32_t n = min(*p.n_ptr, p.n_cap);
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    const uint64_t h = ch[i];
-    const uint32_t kx = ck[i];
-    const uint32_t c = cc[i] & 0x7FFFFFFFu;
-    const uint32_t nk = ctg_nk[c];
-    const uint32_t wm1 = w - 1;
+    const uint64_t h = p.ch[i];
+    const uint32_t kx = p.ck[i];
+    const uint32_t c = p.cc[i] & 0x7FFFFFFFu;
+    const uint32_t nk = p.ctg_nk[c];
+    const uint32_t w = p.w, wm1 = w - 1;
     uint32_t L = min(kx, wm1);
     for (uint32_t j = i; j-- > 0;) {
-        if ((cc[j] & 0x7FFFFFFFu) != c) break;
-        uint32_t d = kx - ck[j];
+        if ((p.cc[j] & 0x7FFFFFFFu) != c) break;
+        uint32_t d = kx - p.ck[j];
         if (d > wm1) break;
-        if (ch[j] < h) {  // strictly smaller on the left blocks (ties: rightmost wins)
+        if (p.ch[j] < h) {  // strictly smaller on the left blocks (ties: rightmost wins)
             L = d - 1;
             break;
         }
@@ -170,26 +342,64 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *__restrict__ ch
     uint32_t R = min(nk - 1 - kx, wm1);
     bool s = (L + R + 1 >= w);  // enough room if nothing blocks on the right
     if (s && L < wm1) {
-        // need R >= w-1-L : look at candidates up to that distance only
-        const uint32_t need = wm1 - L;
+        const uint32_t need = wm1 - L;  // need R >= need: no blocker within that distance
         for (uint32_t j = i + 1; j < n; ++j) {
-            if ((cc[j] & 0x7FFFFFFFu) != c) break;
-            uint32_t d = ck[j] - kx;
+            if ((p.cc[j] & 0x7FFFFFFFu) != c) break;
+            uint32_t d = p.ck[j] - kx;
             if (d > need) break;
-            if (ch[j] <= h) {  // smaller-or-equal on the right blocks
+            if (p.ch[j] <= h) {  // smaller-or-equal on the right blocks
                 s = false;
                 break;
             }
         }
     }
-    sel[i] = (s && h != 0xFFFFFFFFFFFFFFFFull) ? 1 : 0;  // btllib never reports min_hash == 2^64-1
+    p.sel[i] = (s && h != 0xFFFFFFFFFFFFFFFFull) ? 1 : 0;  // btllib never reports min_hash == 2^64-1
+
+    if (GAPS) {
+        // candidate-free stretches of >= w k-mers hold windows whose minimum is not a candidate
+        const bool first = (i == 0) || ((p.cc[i - 1] & 0x7FFFFFFFu) != c);
+        if (first) {
+            uint32_t pc = (i == 0) ? p.ctg_lo : (p.cc[i - 1] & 0x7FFFFFFFu) + 1;
+            for (; pc < c; ++pc) push_gap(p, pc, 0, p.ctg_nk[pc] - 1);  // contigs without any candidate
+            if (kx >= w) push_gap(p, c, 0, kx - 1);
+        }
+        const bool last = (i + 1 >= n) || ((p.cc[i + 1] & 0x7FFFFFFFu) != c);
+        if (!last) {
+            uint32_t nx = p.ck[i + 1];
+            if (nx - kx - 1 >= w) push_gap(p, c, kx + 1, nx - 1);
+        } else {
+            if (nk - 1 - kx >= w) push_gap(p, c, kx + 1, nk - 1);
+            if (i + 1 >= n)
+                for (uint32_t nc = c + 1; nc < p.ctg_hi; ++nc) push_gap(p, nc, 0, p.ctg_nk[nc] - 1);
+        }
+    }
+}
+
+// k_count with the element count read from device memory
+__global__ __launch_bounds__(256) void k_count_n(const uint8_t *__restrict__ sel, const uint32_t *__restrict__ n_ptr,
+                                                 uint32_t n_cap, uint32_t *__restrict__ bsum)
+{
+    __shared__ uint32_t sh[256];
+    const uint32_t n = min(*n_ptr, n_cap);
+    uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
+    uint32_t c = 0;
+    for (int u = 0; u < TILE_PER_THREAD; ++u)
+        if (base + u < n) c += sel[base + u];
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
 }
 
 struct EmitParams {
     const uint8_t *sel;
     const uint64_t *ch;
     const uint32_t *ck, *cc;
-    uint32_t n;
+    const uint32_t *n_ptr;
+    uint32_t n_cap;
     const uint32_t *bsum;  // exclusive block offsets
     const Run *runs;
     const uint32_t *ctg_run0, *ctg_rec;
@@ -203,23 +413,16 @@ struct EmitParams {
 __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
 {
     __shared__ uint32_t sh[256];
+    const uint32_t n = min(*p.n_ptr, p.n_cap);
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
     uint32_t c = 0;
     for (int u = 0; u < TILE_PER_THREAD; ++u)
-        if (base + u < p.n) c += p.sel[base + u];
-    sh[threadIdx.x] = c;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
-    }
-    uint64_t o = p.out_base + p.bsum[blockIdx.x] + sh[threadIdx.x] - c;
+        if (base + u < n) c += p.sel[base + u];
+    uint64_t o = p.out_base + p.bsum[blockIdx.x] + block_exclusive_256(c, sh);
     if (c == 0) return;
     for (int u = 0; u < TILE_PER_THREAD; ++u) {
         uint32_t i = base + u;
-        if (i < p.n && p.sel[i]) {
+        if (i < n && p.sel[i]) {
             uint32_t cs = p.cc[i], ctg = cs & 0x7FFFFFFFu, kx = p.ck[i];
             // contig-local valid-k-mer index -> base position, through the contig's run table
             uint32_t lo = p.ctg_run0[ctg], hi = p.ctg_run0[ctg + 1];
@@ -236,9 +439,48 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     }
 }
 
+// merge two (record,pos)-sorted sketches A (nA) and B (nB) with disjoint keys into O
+struct MergeParams {
+    const uint64_t *a_hash; const uint32_t *a_pos, *a_rec; const uint8_t *a_fwd; uint32_t nA;
+    const uint64_t *b_hash; const uint32_t *b_pos, *b_rec; const uint8_t *b_fwd; uint32_t nB;
+    uint64_t *o_hash; uint32_t *o_pos, *o_rec; uint8_t *o_fwd;
+};
+
+__device__ __forceinline__ uint32_t lower_bound_key(const uint32_t *rec, const uint32_t *pos, uint32_t n, uint64_t key)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        uint64_t km = ((uint64_t)rec[mid] << 32) | pos[mid];
+        if (km < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_merge(const MergeParams p)
+{
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < p.nA) {
+        uint64_t key = ((uint64_t)p.a_rec[t] << 32) | p.a_pos[t];
+        uint32_t d = t + lower_bound_key(p.b_rec, p.b_pos, p.nB, key);
+        p.o_hash[d] = p.a_hash[t]; p.o_pos[d] = p.a_pos[t]; p.o_rec[d] = p.a_rec[t]; p.o_fwd[d] = p.a_fwd[t];
+    } else if (t < p.nA + p.nB) {
+        uint32_t u = t - p.nA;
+        uint64_t key = ((uint64_t)p.b_rec[u] << 32) | p.b_pos[u];
+        uint32_t d = u + lower_bound_key(p.a_rec, p.a_pos, p.nA, key);
+        p.o_hash[d] = p.b_hash[u]; p.o_pos[d] = p.b_pos[u]; p.o_rec[d] = p.b_rec[u]; p.o_fwd[d] = p.b_fwd[u];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------------------
+constexpr int S_DENSE = 128;
+constexpr int S_SPARSE = 256;
+constexpr uint64_t DENSE_BATCH_KMERS = 96ull << 20;   // dense arena = 16 B per k-mer
+constexpr uint64_t SPARSE_BATCH_KMERS = 2040ull << 20; // < 2^31 k-mers and < 2^32 strips per batch
+constexpr uint32_t GAP_CAP = 1u << 20;
+
 static hipError_t grow_preserve(DevBuf &b, size_t used_bytes, size_t need_bytes, hipStream_t st)
 {
     if (need_bytes <= b.bytes) return hipSuccess;
@@ -269,173 +511,525 @@ static int upload(mxg_handle *h, DevBuf &b, const std::vector<T> &v)
     return MXG_OK;
 }
 
-constexpr int S_DENSE = 128;
-constexpr uint64_t DENSE_BATCH_KMERS = 96ull << 20;  // arena = 16 B per k-mer
+// a set of contigs/runs to sketch: host vectors + their device copies
+struct Tables {
+    const std::vector<Run> *runs;
+    const std::vector<uint32_t> *ctg_nk, *ctg_rec, *ctg_run0;
+    const std::vector<uint32_t> *strip0_dense, *strip0_sparse;  // sparse may be null
+    const std::vector<uint64_t> *g0;
+    const Run *d_runs;
+    const uint32_t *d_strip0_dense, *d_strip0_sparse, *d_ctg_nk, *d_ctg_rec, *d_ctg_run0;
+    const uint64_t *d_g0;
+    const std::vector<Record> *recs;  // for base accounting (may be null)
+};
 
-template <int S>
-static void launch_hash_dense(mxg_handle *h, const HashParams &p, uint32_t n_strips)
+struct OutArrays {
+    DevBuf *hash, *pos, *rec, *fwd;
+    uint64_t n = 0;
+    uint64_t cap() const { return std::min<uint64_t>({hash->bytes / 8, pos->bytes / 4, rec->bytes / 4, fwd->bytes}); }
+};
+
+static int out_reserve(mxg_handle *h, OutArrays &o, uint64_t need)
 {
-    dim3 grid((n_strips + 255) / 256), block(256);
-    if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-        hipLaunchKernelGGL((k_hash_dense<S, MXG_VARIANT_V1_MIN>), grid, block, 0, h->stream, p);
-    else
-        hipLaunchKernelGGL((k_hash_dense<S, MXG_VARIANT_V2_SUM>), grid, block, 0, h->stream, p);
+    if (need <= o.cap()) return MXG_OK;
+    MXG_HIP(h, grow_preserve(*o.hash, o.n * 8, need * 8, h->stream));
+    MXG_HIP(h, grow_preserve(*o.pos, o.n * 4, need * 4, h->stream));
+    MXG_HIP(h, grow_preserve(*o.rec, o.n * 4, need * 4, h->stream));
+    MXG_HIP(h, grow_preserve(*o.fwd, o.n, need, h->stream));
+    return MXG_OK;
+}
+
+static void build_strip_tables(const std::vector<Run> &runs, int S, std::vector<uint32_t> &strip0, bool *overflow)
+{
+    strip0.resize(runs.size() + 1);
+    uint64_t s = 0;
+    for (size_t r = 0; r < runs.size(); ++r) {
+        strip0[r] = (uint32_t)s;
+        s += (runs[r].n_kmers + S - 1) / S;
+    }
+    strip0[runs.size()] = (uint32_t)s;
+    if (s >= (1ull << 32)) *overflow = true;
+}
+
+struct EventPair {
+    hipEvent_t a, b;
+    uint64_t bases;
+    bool is_hash;
+};
+
+struct Driver {
+    mxg_handle *h;
+    std::vector<EventPair> evs;
+    bool timing;
+    explicit Driver(mxg_handle *h_) : h(h_), timing((h_->cfg.flags & MXG_FLAG_TIMING) != 0) {}
+    ~Driver()
+    {
+        for (auto &e : evs) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+    }
+    DevBuf &sc(int i) { return h->scratch[i]; }
+
+    int ev_begin(uint64_t bases, bool is_hash)
+    {
+        if (!timing) return MXG_OK;
+        EventPair e;
+        MXG_HIP(h, hipEventCreate(&e.a));
+        MXG_HIP(h, hipEventCreate(&e.b));
+        e.bases = bases;
+        e.is_hash = is_hash;
+        MXG_HIP(h, hipEventRecord(e.a, h->stream));
+        evs.push_back(e);
+        return MXG_OK;
+    }
+    int ev_end()
+    {
+        if (!timing) return MXG_OK;
+        MXG_HIP(h, hipEventRecord(evs.back().b, h->stream));
+        return MXG_OK;
+    }
+    int collect()
+    {
+        if (!timing) return MXG_OK;
+        MXG_HIP(h, hipStreamSynchronize(h->stream));
+        for (auto &e : evs) {
+            float ms = 0;
+            MXG_HIP(h, hipEventElapsedTime(&ms, e.a, e.b));
+            if (e.is_hash) {
+                h->tm.ms_hash += ms;
+                h->tm.launches_hash += 1;
+                h->tm.hash_bases += e.bases;
+            } else {
+                h->tm.ms_resolve += ms;
+            }
+        }
+        return MXG_OK;
+    }
+
+    uint64_t batch_bases(const Tables &T, size_t c0, size_t c1) const
+    {
+        uint64_t b = 0;
+        if (T.recs)
+            for (size_t c = c0; c < c1; ++c) b += (*T.recs)[(*T.ctg_rec)[c]].len;
+        return b;
+    }
+
+    // resolve -> count -> scan over candidates already in SC_CAND_*; n candidates read from ctrl[0] (<= n_cap)
+    template <bool GAPS>
+    int resolve_and_count(const Tables &T, uint32_t n_cap, uint32_t ctg_lo, uint32_t ctg_hi)
+    {
+        const uint32_t n_tiles = (n_cap + TILE - 1) / TILE;
+        MXG_HIP(h, sc(SC_SEL).ensure(std::max<uint32_t>(n_cap, 16)));
+        MXG_HIP(h, sc(SC_BSUM).ensure((size_t)n_tiles * 4 + 16));
+        uint32_t *ctrl = sc(SC_CTRL).as<uint32_t>();
+        ResolveParams rp;
+        rp.ch = sc(SC_CAND_H).as<uint64_t>();
+        rp.ck = sc(SC_CAND_K).as<uint32_t>();
+        rp.cc = sc(SC_CAND_C).as<uint32_t>();
+        rp.n_ptr = ctrl;
+        rp.n_cap = n_cap;
+        rp.ctg_nk = T.d_ctg_nk;
+        rp.w = h->cfg.w;
+        rp.sel = sc(SC_SEL).as<uint8_t>();
+        rp.ctg_lo = ctg_lo;
+        rp.ctg_hi = ctg_hi;
+        rp.gaps = sc(SC_GAPS).as<uint4>();
+        rp.gap_cap = GAP_CAP;
+        rp.gap_count = ctrl + 1;
+        if (n_cap) {
+            hipLaunchKernelGGL(k_resolve<GAPS>, dim3((n_cap + 255) / 256), dim3(256), 0, h->stream, rp);
+            hipLaunchKernelGGL(k_count_n, dim3(n_tiles), dim3(256), 0, h->stream, rp.sel, rp.n_ptr, n_cap,
+                               sc(SC_BSUM).as<uint32_t>());
+        }
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, sc(SC_BSUM).as<uint32_t>(), n_tiles,
+                           reinterpret_cast<uint64_t *>(ctrl + 2));
+        MXG_HIP(h, hipGetLastError());
+        return MXG_OK;
+    }
+
+    int emit(const Tables &T, uint32_t n_cap, DevBuf &oh, DevBuf &op, DevBuf &orc, DevBuf &of, uint64_t out_base)
+    {
+        if (!n_cap) return MXG_OK;
+        EmitParams ep;
+        ep.sel = sc(SC_SEL).as<uint8_t>();
+        ep.ch = sc(SC_CAND_H).as<uint64_t>();
+        ep.ck = sc(SC_CAND_K).as<uint32_t>();
+        ep.cc = sc(SC_CAND_C).as<uint32_t>();
+        ep.n_ptr = sc(SC_CTRL).as<uint32_t>();
+        ep.n_cap = n_cap;
+        ep.bsum = sc(SC_BSUM).as<uint32_t>();
+        ep.runs = T.d_runs;
+        ep.ctg_run0 = T.d_ctg_run0;
+        ep.ctg_rec = T.d_ctg_rec;
+        ep.mult = 1ull ^ ((uint64_t)h->cfg.k * 0x90b45d39fb6da1faull);
+        ep.out_base = out_base;
+        ep.o_hash = oh.as<uint64_t>();
+        ep.o_pos = op.as<uint32_t>();
+        ep.o_rec = orc.as<uint32_t>();
+        ep.o_fwd = of.as<uint8_t>();
+        hipLaunchKernelGGL(k_emit, dim3((n_cap + TILE - 1) / TILE), dim3(256), 0, h->stream, ep);
+        MXG_HIP(h, hipGetLastError());
+        return MXG_OK;
+    }
+
+    // ---- dense pipeline over every contig of T, appended to `out` ------------------------------------
+    int dense_all(const uint32_t *d_packed, const Tables &T, OutArrays &out, bool count_as_hash)
+    {
+        const size_t n_ctg = T.ctg_rec->size();
+        MXG_HIP(h, sc(SC_CTRL).ensure(64));
+        size_t c0 = 0;
+        while (c0 < n_ctg) {
+            size_t c1 = c0;
+            uint64_t nk = 0;
+            while (c1 < n_ctg && (c1 == c0 || nk + (*T.ctg_nk)[c1] <= DENSE_BATCH_KMERS)) nk += (*T.ctg_nk)[c1++];
+            if (nk >= (1ull << 31))
+                return set_err(h, MXG_ELIMIT, "a candidate-free stretch / record of %llu k-mers exceeds the dense path's 2^31 limit",
+                               (unsigned long long)nk);
+            const uint32_t r_lo = (*T.ctg_run0)[c0], r_hi = (*T.ctg_run0)[c1];
+            MXG_HIP(h, sc(SC_CAND_H).ensure(nk * 8));
+            MXG_HIP(h, sc(SC_CAND_K).ensure(nk * 4));
+            MXG_HIP(h, sc(SC_CAND_C).ensure(nk * 4));
+            const uint32_t n_cand = (uint32_t)nk;
+            uint32_t ctrl_init[4] = {n_cand, 0, 0, 0};
+            MXG_HIP(h, hipMemcpyAsync(sc(SC_CTRL).p, ctrl_init, 16, hipMemcpyHostToDevice, h->stream));
+            DenseParams hp;
+            hp.packed = d_packed;
+            hp.runs = T.d_runs;
+            hp.run_strip0 = T.d_strip0_dense;
+            hp.run_g0 = T.d_g0;
+            hp.run_lo = r_lo;
+            hp.run_hi = r_hi;
+            hp.strip_lo = (*T.strip0_dense)[r_lo];
+            hp.strip_hi = (*T.strip0_dense)[r_hi];
+            hp.g_base = (*T.g0)[r_lo];
+            hp.k = h->cfg.k;
+            hp.cand_h = sc(SC_CAND_H).as<uint64_t>();
+            hp.cand_k = sc(SC_CAND_K).as<uint32_t>();
+            hp.cand_c = sc(SC_CAND_C).as<uint32_t>();
+            hp.tab = h->tab;
+            int rc = ev_begin(count_as_hash ? batch_bases(T, c0, c1) : 0, count_as_hash);
+            if (rc != MXG_OK) return rc;
+            const uint32_t n_strips = hp.strip_hi - hp.strip_lo;
+            dim3 grid((n_strips + 255) / 256), block(256);
+            if (h->cfg.variant == MXG_VARIANT_V1_MIN)
+                hipLaunchKernelGGL((k_hash_dense<S_DENSE, MXG_VARIANT_V1_MIN>), grid, block, 0, h->stream, hp);
+            else
+                hipLaunchKernelGGL((k_hash_dense<S_DENSE, MXG_VARIANT_V2_SUM>), grid, block, 0, h->stream, hp);
+            if (count_as_hash && (rc = ev_end()) != MXG_OK) return rc;
+            MXG_HIP(h, hipGetLastError());
+            if ((rc = resolve_and_count<false>(T, n_cand, (uint32_t)c0, (uint32_t)c1)) != MXG_OK) return rc;
+            if (!count_as_hash && (rc = ev_end()) != MXG_OK) return rc;
+            uint32_t ctrl[4];
+            MXG_HIP(h, hipMemcpyAsync(ctrl, sc(SC_CTRL).p, 16, hipMemcpyDeviceToHost, h->stream));
+            MXG_HIP(h, hipStreamSynchronize(h->stream));
+            const uint64_t total = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
+            if ((rc = out_reserve(h, out, out.n + total)) != MXG_OK) return rc;
+            if ((rc = emit(T, n_cand, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
+            out.n += total;
+            h->stat_dense_kmers += nk;
+            c0 = c1;
+        }
+        return MXG_OK;
+    }
+
+    // ---- gap fix-up: dense pipeline over candidate-free stretches, result in SC_G_* ---------------------
+    int process_gaps(Assembly *a, const Tables &T, std::vector<uint4> &gaps, uint64_t *n_gap_mx)
+    {
+        std::sort(gaps.begin(), gaps.end(), [](const uint4 &x, const uint4 &y) {
+            return x.x != y.x ? x.x < y.x : x.y < y.y;
+        });
+        // every stretch becomes a stand-alone virtual contig made of pieces of the real contig's runs
+        std::vector<Run> vruns;
+        std::vector<uint32_t> v_nk, v_rec, v_run0;
+        for (size_t v = 0; v < gaps.size(); ++v) {
+            const uint32_t c = gaps[v].x, klo = gaps[v].y, khi = gaps[v].z;
+            v_run0.push_back((uint32_t)vruns.size());
+            v_nk.push_back(khi - klo + 1);
+            v_rec.push_back((*T.ctg_rec)[c]);
+            for (uint32_t r = (*T.ctg_run0)[c]; r < (*T.ctg_run0)[c + 1]; ++r) {
+                const Run &run = (*T.runs)[r];
+                uint64_t lo = std::max<uint64_t>(run.kidx0, klo);
+                uint64_t hi = std::min<uint64_t>((uint64_t)run.kidx0 + run.n_kmers, (uint64_t)khi + 1);
+                if (lo >= hi) continue;
+                Run vr;
+                vr.base_off = run.base_off + (lo - run.kidx0);
+                vr.n_kmers = (uint32_t)(hi - lo);
+                vr.contig = (uint32_t)v;
+                vr.kidx0 = (uint32_t)(lo - klo);
+                vr.pos0 = run.pos0 + (uint32_t)(lo - run.kidx0);
+                vruns.push_back(vr);
+            }
+        }
+        v_run0.push_back((uint32_t)vruns.size());
+        std::vector<uint32_t> vstrip0;
+        std::vector<uint64_t> vg0(vruns.size() + 1);
+        bool ovf = false;
+        build_strip_tables(vruns, S_DENSE, vstrip0, &ovf);
+        if (ovf) return set_err(h, MXG_ELIMIT, "too many strips in gap fix-up");
+        uint64_t g = 0;
+        for (size_t r = 0; r < vruns.size(); ++r) {
+            vg0[r] = g;
+            g += vruns[r].n_kmers;
+        }
+        vg0[vruns.size()] = g;
+        int rc;
+        if ((rc = upload(h, sc(SC_V_RUNS), vruns)) != MXG_OK) return rc;
+        if ((rc = upload(h, sc(SC_V_STRIP0), vstrip0)) != MXG_OK) return rc;
+        if ((rc = upload(h, sc(SC_V_G0), vg0)) != MXG_OK) return rc;
+        if ((rc = upload(h, sc(SC_V_NK), v_nk)) != MXG_OK) return rc;
+        if ((rc = upload(h, sc(SC_V_REC), v_rec)) != MXG_OK) return rc;
+        if ((rc = upload(h, sc(SC_V_RUN0), v_run0)) != MXG_OK) return rc;
+        Tables V;
+        V.runs = &vruns;
+        V.ctg_nk = &v_nk;
+        V.ctg_rec = &v_rec;
+        V.ctg_run0 = &v_run0;
+        V.strip0_dense = &vstrip0;
+        V.strip0_sparse = nullptr;
+        V.g0 = &vg0;
+        V.d_runs = sc(SC_V_RUNS).as<Run>();
+        V.d_strip0_dense = sc(SC_V_STRIP0).as<uint32_t>();
+        V.d_strip0_sparse = nullptr;
+        V.d_ctg_nk = sc(SC_V_NK).as<uint32_t>();
+        V.d_ctg_rec = sc(SC_V_REC).as<uint32_t>();
+        V.d_ctg_run0 = sc(SC_V_RUN0).as<uint32_t>();
+        V.d_g0 = sc(SC_V_G0).as<uint64_t>();
+        V.recs = nullptr;
+        OutArrays og{&sc(SC_G_HASH), &sc(SC_G_POS), &sc(SC_G_REC), &sc(SC_G_FWD), 0};
+        MXG_HIP(h, og.hash->ensure(1024 * 8));
+        MXG_HIP(h, og.pos->ensure(1024 * 4));
+        MXG_HIP(h, og.rec->ensure(1024 * 4));
+        MXG_HIP(h, og.fwd->ensure(1024));
+        if ((rc = dense_all(a->d_packed, V, og, false)) != MXG_OK) return rc;
+        *n_gap_mx = og.n;
+        return MXG_OK;
+    }
+
+    // ---- sparse pipeline over every contig of T, appended to `out` ------------------------------------
+    int sparse_all(Assembly *a, const Tables &T, OutArrays &out, uint32_t tau_hi, double cand_frac)
+    {
+        const size_t n_ctg = T.ctg_rec->size();
+        MXG_HIP(h, sc(SC_CTRL).ensure(64));
+        MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
+        size_t c0 = 0;
+        while (c0 < n_ctg) {
+            size_t c1 = c0;
+            uint64_t nk = 0;
+            while (c1 < n_ctg && (c1 == c0 || nk + (*T.ctg_nk)[c1] <= SPARSE_BATCH_KMERS)) nk += (*T.ctg_nk)[c1++];
+            const uint32_t r_lo = (*T.ctg_run0)[c0], r_hi = (*T.ctg_run0)[c1];
+            const uint32_t strip_lo = (*T.strip0_sparse)[r_lo], strip_hi = (*T.strip0_sparse)[r_hi];
+            const uint32_t n_strips = strip_hi - strip_lo;
+            const uint32_t s_tiles = (n_strips + TILE - 1) / TILE;
+            MXG_HIP(h, sc(SC_STRIP_CNT).ensure((size_t)n_strips * 4 + 16));
+            MXG_HIP(h, sc(SC_STRIP_PREF).ensure((size_t)n_strips * 4 + 16));
+            MXG_HIP(h, sc(SC_STRIP_META).ensure((size_t)n_strips * 8 + 16));
+            MXG_HIP(h, sc(SC_SBSUM).ensure((size_t)s_tiles * 4 + 16));
+            uint64_t want = (uint64_t)((double)nk * cand_frac * 1.5) + 65536;
+            want = std::max<uint64_t>(want, h->arena_cap_hint);
+            uint32_t ctrl[4];
+            for (int attempt = 0;; ++attempt) {
+                if (want >= (1ull << 32))
+                    return set_err(h, MXG_ELIMIT, "candidate arena would exceed 2^32 entries; use MXG_FLAG_DENSE_ONLY or a smaller cand_per_window");
+                const uint32_t arena_cap = (uint32_t)want;
+                MXG_HIP(h, sc(SC_ARENA).ensure((size_t)arena_cap * 16));
+                MXG_HIP(h, sc(SC_CAND_H).ensure((size_t)arena_cap * 8));
+                MXG_HIP(h, sc(SC_CAND_K).ensure((size_t)arena_cap * 4));
+                MXG_HIP(h, sc(SC_CAND_C).ensure((size_t)arena_cap * 4));
+                MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, 16, h->stream));
+                SparseParams sp;
+                sp.packed = a->d_packed;
+                sp.runs = T.d_runs;
+                sp.run_strip0 = T.d_strip0_sparse;
+                sp.run_lo = r_lo;
+                sp.run_hi = r_hi;
+                sp.strip_lo = strip_lo;
+                sp.strip_hi = strip_hi;
+                sp.k = h->cfg.k;
+                sp.tau_hi = tau_hi;
+                sp.arena = sc(SC_ARENA).as<uint4>();
+                sp.arena_cap = arena_cap;
+                sp.ctrl = sc(SC_CTRL).as<uint32_t>();
+                sp.strip_cnt = sc(SC_STRIP_CNT).as<uint32_t>();
+                sp.strip_meta = sc(SC_STRIP_META).as<uint2>();
+                sp.tab = h->tab;
+                int rc = ev_begin(batch_bases(T, c0, c1), true);
+                if (rc != MXG_OK) return rc;
+                dim3 grid((n_strips + 255) / 256), block(256);
+                if (h->cfg.variant == MXG_VARIANT_V1_MIN)
+                    hipLaunchKernelGGL((k_hash_sparse<S_SPARSE, MXG_VARIANT_V1_MIN>), grid, block, 0, h->stream, sp);
+                else
+                    hipLaunchKernelGGL((k_hash_sparse<S_SPARSE, MXG_VARIANT_V2_SUM>), grid, block, 0, h->stream, sp);
+                if ((rc = ev_end()) != MXG_OK) return rc;
+                MXG_HIP(h, hipGetLastError());
+                // order the candidates: exclusive scan of per-strip counts, then scatter
+                if ((rc = ev_begin(0, false)) != MXG_OK) return rc;
+                hipLaunchKernelGGL(k_tile_sum_u32, dim3(s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, n_strips,
+                                   sc(SC_SBSUM).as<uint32_t>());
+                hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, sc(SC_SBSUM).as<uint32_t>(), s_tiles,
+                                   reinterpret_cast<uint64_t *>(sp.ctrl + 2));
+                hipLaunchKernelGGL(k_tile_excl_u32, dim3(s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, n_strips,
+                                   sc(SC_SBSUM).as<uint32_t>(), sc(SC_STRIP_PREF).as<uint32_t>());
+                hipLaunchKernelGGL(k_reorder, dim3((arena_cap + 255) / 256), dim3(256), 0, h->stream, sp.arena, sp.ctrl,
+                                   arena_cap, sc(SC_STRIP_PREF).as<uint32_t>(), sp.strip_meta,
+                                   sc(SC_CAND_H).as<uint64_t>(), sc(SC_CAND_K).as<uint32_t>(),
+                                   sc(SC_CAND_C).as<uint32_t>());
+                MXG_HIP(h, hipGetLastError());
+                if ((rc = resolve_and_count<true>(T, arena_cap, (uint32_t)c0, (uint32_t)c1)) != MXG_OK) return rc;
+                if ((rc = ev_end()) != MXG_OK) return rc;
+                MXG_HIP(h, hipMemcpyAsync(ctrl, sc(SC_CTRL).p, 16, hipMemcpyDeviceToHost, h->stream));
+                MXG_HIP(h, hipStreamSynchronize(h->stream));
+                if (ctrl[0] <= arena_cap) break;
+                if (attempt >= 2) return set_err(h, MXG_EDEVICE, "internal error: candidate arena keeps overflowing");
+                want = (uint64_t)ctrl[0] + ctrl[0] / 8 + 65536;  // exact need is known now: redo the batch
+                h->arena_cap_hint = want;
+            }
+            const uint32_t n_cand = ctrl[0];
+            const uint32_t arena_cap = (uint32_t)want;
+            uint32_t n_gaps = ctrl[1];
+            const uint64_t total = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
+            h->stat_candidates += n_cand;
+            int rc;
+            std::vector<uint4> gaps;
+            if (n_cand == 0) {  // no candidate at all: every contig of the batch is one stretch
+                for (size_t c = c0; c < c1; ++c) gaps.push_back(make_uint4((uint32_t)c, 0, (*T.ctg_nk)[c] - 1, 0));
+                n_gaps = (uint32_t)gaps.size();
+            } else if (n_gaps > GAP_CAP) {
+                // pathological input: fall back to the dense path for the whole batch
+                return set_err(h, MXG_ELIMIT, "more than %u candidate-free stretches in one batch; rerun with MXG_FLAG_DENSE_ONLY", GAP_CAP);
+            } else if (n_gaps) {
+                gaps.resize(n_gaps);
+                MXG_HIP(h, hipMemcpyAsync(gaps.data(), sc(SC_GAPS).p, (size_t)n_gaps * 16, hipMemcpyDeviceToHost, h->stream));
+                MXG_HIP(h, hipStreamSynchronize(h->stream));
+            }
+            if (n_gaps == 0) {
+                if ((rc = out_reserve(h, out, out.n + total)) != MXG_OK) return rc;
+                if ((rc = emit(T, arena_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
+                out.n += total;
+            } else {
+                // main result to staging (before the candidate scratch is reused by the gap pass)
+                MXG_HIP(h, sc(SC_ST_HASH).ensure(std::max<uint64_t>(total * 8, 16)));
+                MXG_HIP(h, sc(SC_ST_POS).ensure(std::max<uint64_t>(total * 4, 16)));
+                MXG_HIP(h, sc(SC_ST_REC).ensure(std::max<uint64_t>(total * 4, 16)));
+                MXG_HIP(h, sc(SC_ST_FWD).ensure(std::max<uint64_t>(total, 16)));
+                if ((rc = emit(T, arena_cap, sc(SC_ST_HASH), sc(SC_ST_POS), sc(SC_ST_REC), sc(SC_ST_FWD), 0)) != MXG_OK) return rc;
+                uint64_t n_gap_mx = 0;
+                if ((rc = process_gaps(a, T, gaps, &n_gap_mx)) != MXG_OK) return rc;
+                if (total + n_gap_mx >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "batch sketch too large to merge");
+                if ((rc = out_reserve(h, out, out.n + total + n_gap_mx)) != MXG_OK) return rc;
+                MergeParams mp;
+                mp.a_hash = sc(SC_ST_HASH).as<uint64_t>(); mp.a_pos = sc(SC_ST_POS).as<uint32_t>();
+                mp.a_rec = sc(SC_ST_REC).as<uint32_t>(); mp.a_fwd = sc(SC_ST_FWD).as<uint8_t>(); mp.nA = (uint32_t)total;
+                mp.b_hash = sc(SC_G_HASH).as<uint64_t>(); mp.b_pos = sc(SC_G_POS).as<uint32_t>();
+                mp.b_rec = sc(SC_G_REC).as<uint32_t>(); mp.b_fwd = sc(SC_G_FWD).as<uint8_t>(); mp.nB = (uint32_t)n_gap_mx;
+                mp.o_hash = out.hash->as<uint64_t>() + out.n; mp.o_pos = out.pos->as<uint32_t>() + out.n;
+                mp.o_rec = out.rec->as<uint32_t>() + out.n; mp.o_fwd = out.fwd->as<uint8_t>() + out.n;
+                const uint32_t nt = mp.nA + mp.nB;
+                if (nt) hipLaunchKernelGGL(k_merge, dim3((nt + 255) / 256), dim3(256), 0, h->stream, mp);
+                MXG_HIP(h, hipGetLastError());
+                out.n += total + n_gap_mx;
+            }
+            c0 = c1;
+        }
+        return MXG_OK;
+    }
+};
+
+static int prepare_tables(mxg_handle *h, Assembly *a)
+{
+    if (a->tables_ready) return MXG_OK;
+    const size_t n_runs = a->runs.size();
+    if (n_runs >= (1ull << 31)) return set_err(h, MXG_ELIMIT, "too many valid runs (%zu)", n_runs);
+    bool ovf = false;
+    build_strip_tables(a->runs, S_DENSE, a->strip0_dense, &ovf);
+    build_strip_tables(a->runs, S_SPARSE, a->strip0_sparse, &ovf);
+    if (ovf) return set_err(h, MXG_ELIMIT, "too many strips");
+    a->g0.resize(n_runs + 1);
+    uint64_t g = 0;
+    for (size_t r = 0; r < n_runs; ++r) {
+        a->g0[r] = g;
+        g += a->runs[r].n_kmers;
+    }
+    a->g0[n_runs] = g;
+    int rc;
+    if ((rc = upload(h, a->d_runs, a->runs)) != MXG_OK) return rc;
+    if ((rc = upload(h, a->d_strip0_dense, a->strip0_dense)) != MXG_OK) return rc;
+    if ((rc = upload(h, a->d_strip0_sparse, a->strip0_sparse)) != MXG_OK) return rc;
+    if ((rc = upload(h, a->d_g0, a->g0)) != MXG_OK) return rc;
+    if ((rc = upload(h, a->d_ctg_nk, a->ctg_nk)) != MXG_OK) return rc;
+    if ((rc = upload(h, a->d_ctg_rec, a->ctg_rec)) != MXG_OK) return rc;
+    if ((rc = upload(h, a->d_ctg_run0, a->ctg_run0)) != MXG_OK) return rc;
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    a->tables_ready = true;
+    return MXG_OK;
 }
 
 int sketch_assembly(mxg_handle *h, Assembly *a)
 {
     if (!a->has_bases) return set_err(h, MXG_EINVAL, "assembly '%s' has no bases to sketch", a->name.c_str());
     MXG_HIP(h, hipSetDevice(h->device));
-    const uint32_t k = h->cfg.k, w = h->cfg.w;
+    const uint32_t w = h->cfg.w;
     a->has_sketch = false;
     a->host_valid = false;
     a->flags_valid = false;
     h->graph.valid = false;
     a->n_mx = 0;
 
-    // bases to HBM
-    if (!a->d_packed) {
+    if (!a->d_packed) {  // bases to HBM
         MXG_HIP(h, a->d_packed_own.ensure(a->h_packed.size() * 4));
         MXG_HIP(h, hipMemcpyAsync(a->d_packed_own.p, a->h_packed.data(), a->h_packed.size() * 4,
                                   hipMemcpyHostToDevice, h->stream));
         MXG_HIP(h, hipStreamSynchronize(h->stream));
         a->d_packed = a->d_packed_own.as<uint32_t>();
-        if (a->has_text || !(h->cfg.flags & MXG_FLAG_DROP_SEQ)) {
-            std::vector<uint32_t>().swap(a->h_packed);  // text (if any) serves --seq; otherwise refetched on demand
-        }
+        std::vector<uint32_t>().swap(a->h_packed);  // refetched from HBM on demand (mxg_write_tsv without text)
     }
-    const size_t n_runs = a->runs.size();
-    if (n_runs == 0) {  // nothing eligible: empty sketch
+    if (a->runs.empty()) {  // nothing eligible: empty sketch
         a->has_sketch = true;
         return MXG_OK;
     }
-    if (n_runs >= (1ull << 31)) return set_err(h, MXG_ELIMIT, "too many valid runs (%zu)", n_runs);
+    int rc = prepare_tables(h, a);
+    if (rc != MXG_OK) return rc;
 
-    const int S = S_DENSE;
-    std::vector<uint32_t> strip0(n_runs + 1);
-    std::vector<uint64_t> g0(n_runs + 1);
-    {
-        uint64_t s = 0, g = 0;
-        for (size_t r = 0; r < n_runs; ++r) {
-            strip0[r] = (uint32_t)s;
-            g0[r] = g;
-            s += (a->runs[r].n_kmers + S - 1) / S;
-            g += a->runs[r].n_kmers;
-            if (s >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "too many strips");
-        }
-        strip0[n_runs] = (uint32_t)s;
-        g0[n_runs] = g;
-    }
-    int rc;
-    if ((rc = upload(h, h->s_runs, a->runs)) != MXG_OK) return rc;
-    if ((rc = upload(h, h->s_strip0, strip0)) != MXG_OK) return rc;
-    if ((rc = upload(h, h->s_g0, g0)) != MXG_OK) return rc;
-    if ((rc = upload(h, h->s_ctg_nk, a->ctg_nk)) != MXG_OK) return rc;
-    if ((rc = upload(h, h->s_ctg_rec, a->ctg_rec)) != MXG_OK) return rc;
-    if ((rc = upload(h, h->s_ctg_run0, a->ctg_run0)) != MXG_OK) return rc;
-    MXG_HIP(h, h->s_total.ensure(64));
+    Tables T;
+    T.runs = &a->runs;
+    T.ctg_nk = &a->ctg_nk;
+    T.ctg_rec = &a->ctg_rec;
+    T.ctg_run0 = &a->ctg_run0;
+    T.strip0_dense = &a->strip0_dense;
+    T.strip0_sparse = &a->strip0_sparse;
+    T.g0 = &a->g0;
+    T.d_runs = a->d_runs.as<Run>();
+    T.d_strip0_dense = a->d_strip0_dense.as<uint32_t>();
+    T.d_strip0_sparse = a->d_strip0_sparse.as<uint32_t>();
+    T.d_ctg_nk = a->d_ctg_nk.as<uint32_t>();
+    T.d_ctg_rec = a->d_ctg_rec.as<uint32_t>();
+    T.d_ctg_run0 = a->d_ctg_run0.as<uint32_t>();
+    T.d_g0 = a->d_g0.as<uint64_t>();
+    T.recs = &a->recs;
 
-    // output capacity estimate: density 2/(w+1) per k-mer, generous slack; grown on demand
+    // output capacity estimate: density 2/(w+1) per k-mer plus slack; grown on demand
+    OutArrays out{&a->d_hash, &a->d_pos, &a->d_rec, &a->d_fwd, 0};
     uint64_t cap = (uint64_t)(3.0 * (double)a->total_kmers / (double)(w + 1)) + 4096;
     MXG_HIP(h, a->d_hash.ensure(cap * 8));
     MXG_HIP(h, a->d_pos.ensure(cap * 4));
     MXG_HIP(h, a->d_rec.ensure(cap * 4));
     MXG_HIP(h, a->d_fwd.ensure(cap));
-    cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
 
-    const uint64_t mult = 1ull ^ ((uint64_t)k * 0x90b45d39fb6da1faull);
-    const size_t n_ctg = a->ctg_rec.size();
-    uint64_t n_out = 0;
-    size_t c0 = 0;
-    while (c0 < n_ctg) {
-        // batch = whole contigs [c0, c1)
-        size_t c1 = c0;
-        uint64_t nk = 0;
-        while (c1 < n_ctg && (c1 == c0 || nk + a->ctg_nk[c1] <= DENSE_BATCH_KMERS)) nk += a->ctg_nk[c1++];
-        if (nk >= (1ull << 31))
-            return set_err(h, MXG_ELIMIT, "record '%s' has %llu valid k-mers; the dense path handles < 2^31 per record",
-                           a->recs[a->ctg_rec[c0]].id.c_str(), (unsigned long long)nk);
-        const uint32_t r_lo = a->ctg_run0[c0], r_hi = a->ctg_run0[c1];
-        MXG_HIP(h, h->s_cand_h.ensure(nk * 8));
-        MXG_HIP(h, h->s_cand_k.ensure(nk * 4));
-        MXG_HIP(h, h->s_cand_c.ensure(nk * 4));
-        MXG_HIP(h, h->s_sel.ensure(nk));
-        const uint32_t n_cand = (uint32_t)nk;
-        const uint32_t n_tiles = (n_cand + TILE - 1) / TILE;
-        MXG_HIP(h, h->s_bsum.ensure((size_t)n_tiles * 4 + 16));
-
-        HashParams hp;
-        hp.packed = a->d_packed;
-        hp.runs = h->s_runs.as<Run>();
-        hp.run_strip0 = h->s_strip0.as<uint32_t>();
-        hp.run_g0 = h->s_g0.as<uint64_t>();
-        hp.run_lo = r_lo;
-        hp.run_hi = r_hi;
-        hp.strip_lo = strip0[r_lo];
-        hp.strip_hi = strip0[r_hi];
-        hp.g_base = g0[r_lo];
-        hp.k = k;
-        hp.cand_h = h->s_cand_h.as<uint64_t>();
-        hp.cand_k = h->s_cand_k.as<uint32_t>();
-        hp.cand_c = h->s_cand_c.as<uint32_t>();
-        hp.tab = h->tab;
-        const bool timing = (h->cfg.flags & MXG_FLAG_TIMING) != 0;
-        if (timing) MXG_HIP(h, hipEventRecord(h->ev0, h->stream));
-        launch_hash_dense<S_DENSE>(h, hp, hp.strip_hi - hp.strip_lo);
-        if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
-        MXG_HIP(h, hipGetLastError());
-
-        hipLaunchKernelGGL(k_resolve, dim3((n_cand + 255) / 256), dim3(256), 0, h->stream, hp.cand_h, hp.cand_k,
-                           hp.cand_c, n_cand, h->s_ctg_nk.as<uint32_t>(), w, h->s_sel.as<uint8_t>());
-        hipLaunchKernelGGL(k_count, dim3(n_tiles), dim3(256), 0, h->stream, h->s_sel.as<uint8_t>(), n_cand,
-                           h->s_bsum.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, h->s_bsum.as<uint32_t>(), n_tiles,
-                           h->s_total.as<uint64_t>());
-        MXG_HIP(h, hipGetLastError());
-        uint64_t total = 0;
-        MXG_HIP(h, hipMemcpyAsync(&total, h->s_total.p, 8, hipMemcpyDeviceToHost, h->stream));
-        MXG_HIP(h, hipStreamSynchronize(h->stream));
-        if (timing) {
-            float ms = 0;
-            MXG_HIP(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-            h->tm.ms_hash += ms;
-            h->tm.launches_hash += 1;
-            uint64_t bases = 0;
-            for (size_t c = c0; c < c1; ++c) bases += a->recs[a->ctg_rec[c]].len;
-            h->tm.hash_bases += bases;
-        }
-        if (n_out + total > cap) {
-            uint64_t need = n_out + total;
-            MXG_HIP(h, grow_preserve(a->d_hash, n_out * 8, need * 8, h->stream));
-            MXG_HIP(h, grow_preserve(a->d_pos, n_out * 4, need * 4, h->stream));
-            MXG_HIP(h, grow_preserve(a->d_rec, n_out * 4, need * 4, h->stream));
-            MXG_HIP(h, grow_preserve(a->d_fwd, n_out, need, h->stream));
-            cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
-        }
-        EmitParams ep;
-        ep.sel = h->s_sel.as<uint8_t>();
-        ep.ch = hp.cand_h;
-        ep.ck = hp.cand_k;
-        ep.cc = hp.cand_c;
-        ep.n = n_cand;
-        ep.bsum = h->s_bsum.as<uint32_t>();
-        ep.runs = hp.runs;
-        ep.ctg_run0 = h->s_ctg_run0.as<uint32_t>();
-        ep.ctg_rec = h->s_ctg_rec.as<uint32_t>();
-        ep.mult = mult;
-        ep.out_base = n_out;
-        ep.o_hash = a->d_hash.as<uint64_t>();
-        ep.o_pos = a->d_pos.as<uint32_t>();
-        ep.o_rec = a->d_rec.as<uint32_t>();
-        ep.o_fwd = a->d_fwd.as<uint8_t>();
-        hipLaunchKernelGGL(k_emit, dim3(n_tiles), dim3(256), 0, h->stream, ep);
-        MXG_HIP(h, hipGetLastError());
-        n_out += total;
-        h->stat_dense_kmers += nk;
-        c0 = c1;
+    Driver drv(h);
+    // sparse path: expected c candidates per window; it pays while candidates are a small fraction of k-mers
+    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : 12;
+    const double frac = (double)c / (double)w;
+    const bool sparse = !(h->cfg.flags & MXG_FLAG_DENSE_ONLY) && frac <= 0.125;
+    if (sparse) {
+        uint32_t tau_hi = (uint32_t)std::min<double>(4294967295.0, frac * 4294967296.0);
+        rc = drv.sparse_all(a, T, out, tau_hi, frac);
+    } else {
+        rc = drv.dense_all(a->d_packed, T, out, true);
     }
+    if (rc != MXG_OK) return rc;
     MXG_HIP(h, hipStreamSynchronize(h->stream));
-    a->n_mx = n_out;
+    if ((rc = drv.collect()) != MXG_OK) return rc;
+    a->n_mx = out.n;
     a->has_sketch = true;
     return MXG_OK;
 }

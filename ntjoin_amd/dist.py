@@ -1,0 +1,123 @@
+"""
+Multi-GPU path: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm).
+
+The hot path shards by contig: every rank sketches its own records of EVERY assembly (the sketch is >95 % of
+the work and needs no communication).  Uniqueness and intersection need each assembly's complete hash multiset,
+so the path has exactly one exchange step per assembly: an all-gather of the rank-local sketches
+(out_hash u64, pos u32, record u32, strand u8 = 17 B per minimizer; <= a few hundred MB even at 20 Gbp).  The four
+arrays travel as ONE byte buffer per assembly (one collective, fixed rank order => deterministic
+concatenation => results identical for any number of ranks).  Every rank then builds the graph of the union
+(replicated: cheaper than a distributed table at these sizes).
+
+gather_sketches() is device-agnostic (tensors in, tensors out) so the same code is exercised on CPU with gloo
+in tests/test_dist_cpu.py.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class _DevArray:
+    """Expose a raw HBM pointer to torch (zero-copy) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def wrap_device(ptr, n, typestr, device):
+    if n == 0:
+        dt = {"<i8": torch.int64, "<i4": torch.int32, "|u1": torch.uint8}[typestr]
+        return torch.empty(0, dtype=dt, device=device)
+    return torch.as_tensor(_DevArray(ptr, n, typestr), device=device)
+
+
+def gather_sketches(local, n_records_local, group=None):
+    """local: {"out_hash": int64[n], "pos": int32[n], "record": int32[n], "forward": uint8[n]} on any device.
+    Returns the same dict for the UNION in rank order, record indices shifted by the number of records held by
+    lower ranks, plus "n_records" (total) and "record_offset" (this rank's shift)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local["out_hash"].device
+    n = int(local["out_hash"].numel())
+    meta = torch.tensor([n, int(n_records_local)], dtype=torch.int64, device=dev)
+    metas = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(metas, meta, group=group)
+    metas = metas.view(world, 2).cpu()
+    counts = metas[:, 0].tolist()
+    nrecs = metas[:, 1].tolist()
+    nmax = (max(max(counts), 1) + 7) // 8 * 8  # keeps every sub-array 8-byte aligned inside the byte buffer
+    # one byte buffer per rank: [hash 8*nmax | pos 4*nmax | record 4*nmax | forward nmax]
+    buf = torch.zeros(17 * nmax, dtype=torch.uint8, device=dev)
+    if n:
+        buf[0:8 * n] = local["out_hash"].contiguous().view(torch.uint8)
+        buf[8 * nmax:8 * nmax + 4 * n] = local["pos"].contiguous().view(torch.uint8)
+        buf[12 * nmax:12 * nmax + 4 * n] = local["record"].contiguous().view(torch.uint8)
+        buf[16 * nmax:16 * nmax + n] = local["forward"].contiguous()
+    allbuf = torch.empty(world * 17 * nmax, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(allbuf, buf, group=group)
+    allbuf = allbuf.view(world, 17 * nmax)
+    hs, ps, rs, fs = [], [], [], []
+    rec_off = 0
+    my_off = 0
+    for r in range(world):
+        c = counts[r]
+        row = allbuf[r]
+        if r == rank:
+            my_off = rec_off
+        if c:
+            hs.append(row[0:8 * c].view(torch.int64))
+            ps.append(row[8 * nmax:8 * nmax + 4 * c].view(torch.int32))
+            rs.append(row[12 * nmax:12 * nmax + 4 * c].view(torch.int32) + rec_off)
+            fs.append(row[16 * nmax:16 * nmax + c])
+        rec_off += nrecs[r]
+    def cat(parts, dt):
+        return torch.cat(parts).contiguous() if parts else torch.empty(0, dtype=dt, device=dev)
+    return {"out_hash": cat(hs, torch.int64), "pos": cat(ps, torch.int32), "record": cat(rs, torch.int32),
+            "forward": cat(fs, torch.uint8), "n_records": rec_off, "record_offset": my_off, "counts": counts}
+
+
+def shard_records(lengths, world):
+    """Greedy longest-processing-time assignment of records (by base count) to ranks, then restored to input
+    order inside each rank: returns a list (per rank) of record indices.  Contigs shard naturally."""
+    order = np.argsort(-np.asarray(lengths, dtype=np.int64), kind="stable")
+    load = np.zeros(world, dtype=np.int64)
+    out = [[] for _ in range(world)]
+    for i in order.tolist():
+        r = int(np.argmin(load))
+        out[r].append(i)
+        load[r] += int(lengths[i])
+    return [sorted(x) for x in out]
+
+
+def allgather_union_graph(eng, k, w, device, union=None, group=None):
+    """All-gather every assembly's sketch from `eng` (this rank's shard) and build the graph of the union on this
+    rank.  `union` (an MxEngine holding the union's record tables) is created on first use and reused."""
+    from .engine import MxEngine
+    A = eng.n_assemblies
+    dev = torch.device("cuda", device)
+    gathered = []
+    for a in range(A):
+        dv = eng.get_sketch_device(a)
+        n = dv["n"]
+        local = {"out_hash": wrap_device(dv["out_hash"], n, "<i8", dev), "pos": wrap_device(dv["pos"], n, "<i4", dev),
+                 "record": wrap_device(dv["record"], n, "<i4", dev), "forward": wrap_device(dv["forward"], n, "|u1", dev)}
+        nrec = eng.n_records(a)
+        gathered.append(gather_sketches(local, nrec, group))
+    if union is None:
+        union = MxEngine(k=k, w=w, device=device, timing=True)
+        rank = dist.get_rank(group)
+        for a in range(A):
+            ids_local = [f"r{rank}:{x}" for x in eng.record_ids(a, eng.n_records(a))]
+            all_ids = [None] * dist.get_world_size(group)
+            dist.all_gather_object(all_ids, ids_local, group=group)
+            flat = [x for part in all_ids for x in part]
+            union.add_minimizers(eng.assembly_name(a), eng.assembly_weight(a), np.zeros(0, np.uint64),
+                                 np.zeros(0, np.uint32), np.zeros(0, np.uint32), flat)
+    torch.cuda.current_stream().synchronize()
+    for a, g in enumerate(gathered):
+        n = int(g["out_hash"].numel())
+        union.set_sketch_device(a, g["out_hash"].data_ptr() if n else 0, g["pos"].data_ptr() if n else 0,
+                                g["record"].data_ptr() if n else 0, g["forward"].data_ptr() if n else 0, n)
+    union.build_graph()
+    return union

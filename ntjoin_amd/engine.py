@@ -127,6 +127,12 @@ class MxEngine:
     def assembly_name(self, a):
         return self._lib.mxg_assembly_name(self._h, a).decode()
 
+    def n_records(self, a):
+        return int(self._lib.mxg_num_records(self._h, int(a)))
+
+    def assembly_weight(self, a):
+        return float(self._lib.mxg_assembly_weight(self._h, int(a)))
+
     def record_ids(self, a, n_records):
         return [self._lib.mxg_record_id(self._h, a, r).decode() for r in range(int(n_records))]
 

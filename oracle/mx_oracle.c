@@ -101,17 +101,26 @@ size_t mxo_kmer_hashes(const char *seq, size_t len, unsigned k, int variant, uin
     size_t run = 0; /* consecutive valid bases ending at the base just consumed */
     uint64_t f = 0, r = 0;
     int have_prev = 0; /* k-mer at i-1 was valid -> f,r hold its hashes */
-    for (size_t j = 0; j + 1 < k; ++j) run = mxo_seed((unsigned char)seq[j]) ? run + 1 : 0;
+    /* per-byte tables of the four terms of the rolling update (A.1), built once per call */
+    uint64_t t_in_f[256], t_out_f[256], t_in_r[256], t_out_r[256];
+    for (unsigned c = 0; c < 256; ++c) {
+        uint64_t s = mxo_seed((unsigned char)c), sc = mxo_seed_comp((unsigned char)c);
+        t_in_f[c] = s;                   /* SEED[in]                 */
+        t_out_f[c] = mxo_srol_n(s, k);   /* srol^k(SEED[out])        */
+        t_out_r[c] = sc;                 /* SEED[comp(out)]          */
+        t_in_r[c] = mxo_srol_n(sc, k);   /* srol^k(SEED[comp(in)])   */
+    }
+    for (size_t j = 0; j + 1 < k; ++j) run = t_in_f[(unsigned char)seq[j]] ? run + 1 : 0;
     for (size_t i = 0; i < n; ++i) {
         unsigned char cin = (unsigned char)seq[i + k - 1];
-        run = mxo_seed(cin) ? run + 1 : 0;
+        run = t_in_f[cin] ? run + 1 : 0;
         int ok = run >= k;
         if (ok) {
             if (have_prev) {
                 unsigned char cout = (unsigned char)seq[i - 1];
                 /* rolling update (A.1) */
-                f = mxo_srol(f) ^ mxo_srol_n(mxo_seed(cout), k) ^ mxo_seed(cin);
-                r = mxo_sror(r ^ mxo_seed_comp(cout) ^ mxo_srol_n(mxo_seed_comp(cin), k));
+                f = mxo_srol(f) ^ t_out_f[cout] ^ t_in_f[cin];
+                r = mxo_sror(r ^ t_out_r[cout] ^ t_in_r[cin]);
             } else {
                 mxo_nthash_direct(seq + i, k, &f, &r);
             }

@@ -1,0 +1,81 @@
+"""CPU test of the N>1 exchange step: world_size-2 gloo processes run ntjoin_amd.dist.gather_sketches and must
+produce the rank-ordered concatenation with shifted record indices (what the union graph is built from)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.conftest import REPO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _local(rank):
+    rng = np.random.default_rng(100 + rank)
+    n = [5, 0, 9][rank % 3] if rank < 3 else 4
+    nrec = rank + 2
+    rec = np.sort(rng.integers(0, nrec, size=n)).astype(np.int32)
+    return {"out_hash": torch.from_numpy(rng.integers(-2**62, 2**62, size=n, dtype=np.int64)),
+            "pos": torch.from_numpy(rng.integers(0, 10**6, size=n).astype(np.int32)),
+            "record": torch.from_numpy(rec),
+            "forward": torch.from_numpy(rng.integers(0, 2, size=n).astype(np.uint8))}, nrec
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ntjoin_amd.dist import gather_sketches
+    local, nrec = _local(rank)
+    g = gather_sketches(local, nrec)
+    q.put((rank, {k: (v.numpy().copy() if torch.is_tensor(v) else v) for k, v in g.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_sketches_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    locs = [_local(r) for r in range(world)]
+    off = np.cumsum([0] + [nrec for _, nrec in locs])
+    want = {k: np.concatenate([l[k].numpy() + (off[r] if k == "record" else 0) for r, (l, _) in enumerate(locs)])
+            for k in ("out_hash", "pos", "record", "forward")}
+    for r in range(world):
+        g = results[r]
+        for k in want:
+            assert np.array_equal(g[k], want[k]), (r, k)
+        assert g["n_records"] == off[-1] and g["record_offset"] == off[r]
+        assert g["counts"] == [l["out_hash"].numel() for l, _ in locs]
+
+
+def test_shard_records_balanced():
+    from ntjoin_amd.dist import shard_records
+    rng = np.random.default_rng(0)
+    lens = np.exp(rng.uniform(np.log(1e4), np.log(2e6), size=500)).astype(np.int64)
+    for world in (1, 2, 4, 8):
+        shards = shard_records(lens, world)
+        assert sorted(i for s in shards for i in s) == list(range(500))
+        loads = [int(lens[s].sum()) for s in shards]
+        assert max(loads) - min(loads) <= lens.max()
+        assert all(s == sorted(s) for s in shards)
