@@ -386,7 +386,8 @@ int mxg_get_mx_flags(mxg_handle *h, int assembly, const uint8_t **flags, uint64_
 {
     Assembly *a = get_asm(h, assembly);
     if (!a || !flags || !n) return MXG_EINVAL;
-    if (!h->graph.valid || !a->flags_valid) return set_err(h, MXG_EINVAL, "call mxg_build_graph first");
+    int rc = flags_to_host(h, a);
+    if (rc != MXG_OK) return rc;
     *flags = a->h_flags.data();
     *n = a->n_mx;
     return MXG_OK;
@@ -395,8 +396,9 @@ int mxg_get_mx_flags(mxg_handle *h, int assembly, const uint8_t **flags, uint64_
 int mxg_get_graph(mxg_handle *h, mxg_graph_view *out)
 {
     if (!h || !out) return MXG_EINVAL;
+    int rc = graph_to_host(h);
+    if (rc != MXG_OK) return rc;
     const Graph &g = h->graph;
-    if (!g.valid) return set_err(h, MXG_EINVAL, "call mxg_build_graph first");
     out->n_assemblies = g.n_asm;
     out->n_vertices = g.nv;
     out->vertex_hash = g.vhash.data();
@@ -414,6 +416,8 @@ int mxg_write_dot(mxg_handle *h, const char *path)
 {
     if (!h || !path) return MXG_EINVAL;
     try {
+        int rc = graph_to_host(h);
+        if (rc != MXG_OK) return rc;
         return write_dot(h, path);
     } catch (const std::bad_alloc &) {
         return set_err(h, MXG_ENOMEM, "out of host memory in mxg_write_dot");
@@ -446,9 +450,17 @@ int mxg_get_stats(mxg_handle *h, mxg_stats *out)
         s.kmers += a->total_kmers;
         if (a->has_sketch) s.minimizers += a->n_mx;
     }
+    if (h->graph.valid && h->stat_unique == ~0ull) {  // lazily: needs the per-minimizer flags on the host
+        uint64_t u = 0;
+        for (auto *a : h->asms) {
+            if (flags_to_host(h, a) != MXG_OK) return MXG_EDEVICE;
+            for (uint8_t f : a->h_flags) u += (f & MXG_MX_UNIQUE) ? 1 : 0;
+        }
+        h->stat_unique = u;
+    }
     s.candidates = h->stat_candidates;
     s.dense_kmers = h->stat_dense_kmers;
-    s.unique = h->stat_unique;
+    s.unique = h->graph.valid ? h->stat_unique : 0;
     s.vertices = h->graph.valid ? h->graph.nv : 0;
     s.edges = h->graph.valid ? h->graph.ne : 0;
     s.ms_hash = h->tm.ms_hash;

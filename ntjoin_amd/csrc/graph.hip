@@ -200,17 +200,29 @@ static int d2h(mxg_handle *h, std::vector<T> &dst, const void *src, size_t n)
     return MXG_OK;
 }
 
+// control block g_ctl (u64 words): [0..A) shared count per assembly, [32] edge count, [33] unique count
+static constexpr int CTL_EDGES = 32, CTL_WORDS = 40;
+
+__global__ __launch_bounds__(256) void k_count_unique(const uint8_t *__restrict__ flags, uint32_t n, unsigned long long *counter)
+{
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool u = i < n && (flags[i] & MXG_MX_UNIQUE);
+    uint64_t m = __ballot(u);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(counter, (unsigned long long)__popcll(m));
+}
+
 int build_graph(mxg_handle *h)
 {
     MXG_HIP(h, hipSetDevice(h->device));
     const uint32_t A = (uint32_t)h->asms.size();
     if (A == 0) return set_err(h, MXG_EINVAL, "mxg_build_graph: no assemblies");
     if (A > MXG_MAX_ASSEMBLIES) return set_err(h, MXG_ELIMIT, "at most %d assemblies", MXG_MAX_ASSEMBLIES);
-    uint64_t N = 0, nmax = 0;
+    uint64_t N = 0, nmin = ~0ull;
     for (auto *a : h->asms) {
         if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch (call mxg_sketch)", a->name.c_str());
         N += a->n_mx;
-        nmax = std::max(nmax, a->n_mx);
+        nmin = std::min(nmin, a->n_mx);
+        a->flags_valid = a->flags_on_host = false;
     }
     if (N >= (1ull << 30)) return set_err(h, MXG_ELIMIT, "too many minimizers for one table (%llu)", (unsigned long long)N);
     Graph &g = h->graph;
@@ -224,163 +236,172 @@ int build_graph(mxg_handle *h)
     const uint32_t mask = cap - 1;
     const uint32_t full = (A == 32) ? 0xFFFFFFFFu : ((1u << A) - 1u);
 
-    DevBuf d_keys, d_seen, d_dup, d_vid, d_shared, d_bsum, d_total;
-    std::vector<DevBuf> d_slot(A);
-    MXG_HIP(h, d_keys.ensure(((size_t)cap + 1) * 8));
-    MXG_HIP(h, d_seen.ensure(((size_t)cap + 1) * 4));
-    MXG_HIP(h, d_dup.ensure(((size_t)cap + 1) * 4));
-    MXG_HIP(h, d_vid.ensure(((size_t)cap + 1) * 4));
-    MXG_HIP(h, hipMemsetAsync(d_keys.p, 0xFF, ((size_t)cap + 1) * 8, h->stream));
-    MXG_HIP(h, hipMemsetAsync(d_seen.p, 0, ((size_t)cap + 1) * 4, h->stream));
-    MXG_HIP(h, hipMemsetAsync(d_dup.p, 0, ((size_t)cap + 1) * 4, h->stream));
-    MXG_HIP(h, d_shared.ensure(std::max<uint64_t>(nmax, 16)));
-    MXG_HIP(h, d_total.ensure(64));
+    MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * 8));
+    MXG_HIP(h, h->g_seen.ensure(((size_t)cap + 1) * 4));
+    MXG_HIP(h, h->g_dup.ensure(((size_t)cap + 1) * 4));
+    MXG_HIP(h, h->g_vid.ensure(((size_t)cap + 1) * 4));
+    MXG_HIP(h, h->g_ctl.ensure(CTL_WORDS * 8));
+    MXG_HIP(h, hipMemsetAsync(h->g_keys.p, 0xFF, ((size_t)cap + 1) * 8, h->stream));
+    MXG_HIP(h, hipMemsetAsync(h->g_seen.p, 0, ((size_t)cap + 1) * 4, h->stream));
+    MXG_HIP(h, hipMemsetAsync(h->g_dup.p, 0, ((size_t)cap + 1) * 4, h->stream));
+    MXG_HIP(h, hipMemsetAsync(h->g_ctl.p, 0, CTL_WORDS * 8, h->stream));
+    uint64_t *ctl = h->g_ctl.as<uint64_t>();
 
     for (uint32_t a = 0; a < A; ++a) {
         Assembly *as = h->asms[a];
-        MXG_HIP(h, d_slot[a].ensure(std::max<uint64_t>(as->n_mx * 4, 16)));
+        MXG_HIP(h, as->d_slot.ensure(std::max<uint64_t>(as->n_mx * 4, 16)));
         MXG_HIP(h, as->d_flags.ensure(std::max<uint64_t>(as->n_mx, 16)));
         if (as->n_mx)
             hipLaunchKernelGGL(k_insert, dim3((uint32_t)((as->n_mx + 255) / 256)), dim3(256), 0, h->stream,
                                as->d_hash.as<uint64_t>(), (uint32_t)as->n_mx, 1u << a,
-                               d_keys.as<unsigned long long>(), mask, cap, d_seen.as<uint32_t>(),
-                               d_dup.as<uint32_t>(), d_slot[a].as<uint32_t>());
+                               h->g_keys.as<unsigned long long>(), mask, cap, h->g_seen.as<uint32_t>(),
+                               h->g_dup.as<uint32_t>(), as->d_slot.as<uint32_t>());
     }
     MXG_HIP(h, hipGetLastError());
-
-    // flags + shared count per assembly (identical across assemblies by construction)
-    std::vector<std::vector<uint32_t>> bsums_host;  // not needed on host; per-assembly device bsum kept
-    std::vector<DevBuf> d_bs(A);
-    std::vector<DevBuf> d_sh(A);
-    std::vector<uint64_t> totals(A, 0);
+    // flags + number of shared minimizers per assembly (equal across assemblies by construction)
     for (uint32_t a = 0; a < A; ++a) {
         Assembly *as = h->asms[a];
-        uint32_t n = (uint32_t)as->n_mx;
-        uint32_t n_tiles = (n + TILE - 1) / TILE;
-        MXG_HIP(h, d_sh[a].ensure(std::max<uint32_t>(n, 16)));
-        MXG_HIP(h, d_bs[a].ensure((size_t)n_tiles * 4 + 16));
+        const uint32_t n = (uint32_t)as->n_mx;
+        const uint32_t n_tiles = (n + TILE - 1) / TILE;
+        MXG_HIP(h, as->d_shared.ensure(std::max<uint32_t>(n, 16)));
+        MXG_HIP(h, as->d_bs.ensure((size_t)n_tiles * 4 + 16));
         if (n) {
-            hipLaunchKernelGGL(k_flags, dim3((n + 255) / 256), dim3(256), 0, h->stream, d_slot[a].as<uint32_t>(), n,
-                               1u << a, full, d_seen.as<uint32_t>(), d_dup.as<uint32_t>(), as->d_flags.as<uint8_t>(),
-                               d_sh[a].as<uint8_t>());
-            hipLaunchKernelGGL(k_count, dim3(n_tiles), dim3(256), 0, h->stream, d_sh[a].as<uint8_t>(), n,
-                               d_bs[a].as<uint32_t>());
+            hipLaunchKernelGGL(k_flags, dim3((n + 255) / 256), dim3(256), 0, h->stream, as->d_slot.as<uint32_t>(), n,
+                               1u << a, full, h->g_seen.as<uint32_t>(), h->g_dup.as<uint32_t>(), as->d_flags.as<uint8_t>(),
+                               as->d_shared.as<uint8_t>());
+            hipLaunchKernelGGL(k_count, dim3(n_tiles), dim3(256), 0, h->stream, as->d_shared.as<uint8_t>(), n,
+                               as->d_bs.as<uint32_t>());
         }
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, d_bs[a].as<uint32_t>(), n_tiles,
-                           d_total.as<uint64_t>());
-        MXG_HIP(h, hipGetLastError());
-        MXG_HIP(h, hipMemcpyAsync(&totals[a], d_total.p, 8, hipMemcpyDeviceToHost, h->stream));
-        MXG_HIP(h, hipStreamSynchronize(h->stream));
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, as->d_bs.as<uint32_t>(), n_tiles, ctl + a);
+        as->flags_valid = true;
     }
-    const uint64_t nv = totals[0];
+    MXG_HIP(h, hipGetLastError());
+    uint64_t hctl[CTL_WORDS];
+    MXG_HIP(h, hipMemcpyAsync(hctl, h->g_ctl.p, CTL_WORDS * 8, hipMemcpyDeviceToHost, h->stream));
+    MXG_HIP(h, hipStreamSynchronize(h->stream));  // sync 1 of 2: |intersection|
+    const uint64_t nv = hctl[0];
     for (uint32_t a = 1; a < A; ++a)
-        if (totals[a] != nv)
+        if (hctl[a] != nv)
             return set_err(h, MXG_EDEVICE, "internal error: shared-minimizer counts differ between assemblies (%llu vs %llu)",
-                           (unsigned long long)totals[a], (unsigned long long)nv);
+                           (unsigned long long)hctl[a], (unsigned long long)nv);
     g.nv = nv;
+    h->stat_unique = ~0ull;  // counted lazily from the flags (mxg_get_stats)
 
-    DevBuf d_vhash, d_vpos, d_vrec, d_fv, d_frec, d_nxt, d_prv, d_eflag, d_ebs, d_eu, d_ev, d_esup, d_ew;
     uint64_t ne = 0;
     if (nv > 0) {
         if ((uint64_t)A * nv >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "graph too large for 32-bit item indices");
-        MXG_HIP(h, d_vhash.ensure(nv * 8));
-        MXG_HIP(h, d_vpos.ensure((size_t)A * nv * 4));
-        MXG_HIP(h, d_vrec.ensure((size_t)A * nv * 4));
-        MXG_HIP(h, d_fv.ensure((size_t)A * nv * 4));
-        MXG_HIP(h, d_frec.ensure((size_t)A * nv * 4));
-        MXG_HIP(h, d_nxt.ensure((size_t)A * nv * 4));
-        MXG_HIP(h, d_prv.ensure((size_t)A * nv * 4));
-        MXG_HIP(h, hipMemsetAsync(d_nxt.p, 0xFF, (size_t)A * nv * 4, h->stream));
-        MXG_HIP(h, hipMemsetAsync(d_prv.p, 0xFF, (size_t)A * nv * 4, h->stream));
+        const size_t anv = (size_t)A * nv;
+        MXG_HIP(h, h->g_vhash.ensure(nv * 8));
+        MXG_HIP(h, h->g_vpos.ensure(anv * 4));
+        MXG_HIP(h, h->g_vrec.ensure(anv * 4));
+        MXG_HIP(h, h->g_fv.ensure(anv * 4));
+        MXG_HIP(h, h->g_frec.ensure(anv * 4));
+        MXG_HIP(h, h->g_nxt.ensure(anv * 4));
+        MXG_HIP(h, h->g_prv.ensure(anv * 4));
+        MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, anv * 4, h->stream));
+        MXG_HIP(h, hipMemsetAsync(h->g_prv.p, 0xFF, anv * 4, h->stream));
         for (uint32_t a = 0; a < A; ++a) {
             Assembly *as = h->asms[a];
-            uint32_t n = (uint32_t)as->n_mx;
+            const uint32_t n = (uint32_t)as->n_mx;
             VertexParams vp;
-            vp.shared = d_sh[a].as<uint8_t>();
-            vp.bsum = d_bs[a].as<uint32_t>();
-            vp.slot = d_slot[a].as<uint32_t>();
+            vp.shared = as->d_shared.as<uint8_t>();
+            vp.bsum = as->d_bs.as<uint32_t>();
+            vp.slot = as->d_slot.as<uint32_t>();
             vp.hash = as->d_hash.as<uint64_t>();
             vp.pos = as->d_pos.as<uint32_t>();
             vp.rec = as->d_rec.as<uint32_t>();
             vp.n = n;
             vp.first = a == 0;
-            vp.vid = d_vid.as<uint32_t>();
-            vp.vhash = d_vhash.as<uint64_t>();
-            vp.vpos = d_vpos.as<uint32_t>() + (size_t)a * nv;
-            vp.vrec = d_vrec.as<uint32_t>() + (size_t)a * nv;
-            vp.fv = d_fv.as<uint32_t>() + (size_t)a * nv;
-            vp.frec = d_frec.as<uint32_t>() + (size_t)a * nv;
+            vp.vid = h->g_vid.as<uint32_t>();
+            vp.vhash = h->g_vhash.as<uint64_t>();
+            vp.vpos = h->g_vpos.as<uint32_t>() + (size_t)a * nv;
+            vp.vrec = h->g_vrec.as<uint32_t>() + (size_t)a * nv;
+            vp.fv = h->g_fv.as<uint32_t>() + (size_t)a * nv;
+            vp.frec = h->g_frec.as<uint32_t>() + (size_t)a * nv;
             hipLaunchKernelGGL(k_vertices, dim3((n + TILE - 1) / TILE), dim3(256), 0, h->stream, vp);
             hipLaunchKernelGGL(k_adjacency, dim3((uint32_t)((nv + 255) / 256)), dim3(256), 0, h->stream,
-                               d_fv.as<uint32_t>() + (size_t)a * nv, d_frec.as<uint32_t>() + (size_t)a * nv,
-                               (uint32_t)nv, d_nxt.as<uint32_t>() + (size_t)a * nv,
-                               d_prv.as<uint32_t>() + (size_t)a * nv);
+                               h->g_fv.as<uint32_t>() + (size_t)a * nv, h->g_frec.as<uint32_t>() + (size_t)a * nv,
+                               (uint32_t)nv, h->g_nxt.as<uint32_t>() + (size_t)a * nv,
+                               h->g_prv.as<uint32_t>() + (size_t)a * nv);
         }
         MXG_HIP(h, hipGetLastError());
-        const uint32_t n_items = (uint32_t)((uint64_t)A * nv);
+        const uint32_t n_items = (uint32_t)anv;
         const uint32_t e_tiles = (n_items + TILE - 1) / TILE;
-        MXG_HIP(h, d_eflag.ensure(n_items));
-        MXG_HIP(h, d_ebs.ensure((size_t)e_tiles * 4 + 16));
+        MXG_HIP(h, h->g_eflag.ensure(n_items));
+        MXG_HIP(h, h->g_ebs.ensure((size_t)e_tiles * 4 + 16));
+        // every item yields at most one edge: size the edge arrays by that bound, no sync needed before k_edges
+        MXG_HIP(h, h->g_eu.ensure((size_t)n_items * 4));
+        MXG_HIP(h, h->g_ev.ensure((size_t)n_items * 4));
+        MXG_HIP(h, h->g_esup.ensure((size_t)n_items * 4));
+        MXG_HIP(h, h->g_ew.ensure((size_t)n_items * 8));
         EdgeParams ep;
-        ep.fv = d_fv.as<uint32_t>();
-        ep.nxt = d_nxt.as<uint32_t>();
-        ep.prv = d_prv.as<uint32_t>();
+        ep.fv = h->g_fv.as<uint32_t>();
+        ep.nxt = h->g_nxt.as<uint32_t>();
+        ep.prv = h->g_prv.as<uint32_t>();
         ep.nv = (uint32_t)nv;
         ep.n_asm = A;
-        ep.eflag = d_eflag.as<uint8_t>();
-        ep.bsum = d_ebs.as<uint32_t>();
-        ep.eu = ep.ev = ep.esup = nullptr;
-        ep.ew = nullptr;
+        ep.eflag = h->g_eflag.as<uint8_t>();
+        ep.bsum = h->g_ebs.as<uint32_t>();
+        ep.eu = h->g_eu.as<uint32_t>();
+        ep.ev = h->g_ev.as<uint32_t>();
+        ep.esup = h->g_esup.as<uint32_t>();
+        ep.ew = h->g_ew.as<double>();
         for (uint32_t a = 0; a < MXG_MAX_ASSEMBLIES; ++a) ep.weights[a] = a < A ? h->asms[a]->weight : 0.0;
         hipLaunchKernelGGL(k_edge_flags, dim3((n_items + 255) / 256), dim3(256), 0, h->stream, ep);
-        hipLaunchKernelGGL(k_count, dim3(e_tiles), dim3(256), 0, h->stream, d_eflag.as<uint8_t>(), n_items,
-                           d_ebs.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, d_ebs.as<uint32_t>(), e_tiles,
-                           d_total.as<uint64_t>());
-        MXG_HIP(h, hipGetLastError());
-        MXG_HIP(h, hipMemcpyAsync(&ne, d_total.p, 8, hipMemcpyDeviceToHost, h->stream));
-        MXG_HIP(h, hipStreamSynchronize(h->stream));
-        MXG_HIP(h, d_eu.ensure(std::max<uint64_t>(ne * 4, 16)));
-        MXG_HIP(h, d_ev.ensure(std::max<uint64_t>(ne * 4, 16)));
-        MXG_HIP(h, d_esup.ensure(std::max<uint64_t>(ne * 4, 16)));
-        MXG_HIP(h, d_ew.ensure(std::max<uint64_t>(ne * 8, 16)));
-        ep.eu = d_eu.as<uint32_t>();
-        ep.ev = d_ev.as<uint32_t>();
-        ep.esup = d_esup.as<uint32_t>();
-        ep.ew = d_ew.as<double>();
+        hipLaunchKernelGGL(k_count, dim3(e_tiles), dim3(256), 0, h->stream, h->g_eflag.as<uint8_t>(), n_items,
+                           h->g_ebs.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, h->g_ebs.as<uint32_t>(), e_tiles,
+                           ctl + CTL_EDGES);
         hipLaunchKernelGGL(k_edges, dim3(e_tiles), dim3(256), 0, h->stream, ep, n_items);
         MXG_HIP(h, hipGetLastError());
+        if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
+        MXG_HIP(h, hipMemcpyAsync(&ne, ctl + CTL_EDGES, 8, hipMemcpyDeviceToHost, h->stream));
+        MXG_HIP(h, hipStreamSynchronize(h->stream));  // sync 2 of 2: edge count; results stay in HBM
+    } else {
+        if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
+        MXG_HIP(h, hipStreamSynchronize(h->stream));
     }
     g.ne = ne;
     if (timing) {
-        MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
-        MXG_HIP(h, hipStreamSynchronize(h->stream));
         float ms = 0;
         MXG_HIP(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
         h->tm.ms_graph += ms;
     }
-    // results to the host (the boundary hands out host views)
-    int rc;
-    if ((rc = d2h(h, g.vhash, d_vhash.p, nv)) != MXG_OK) return rc;
-    if ((rc = d2h(h, g.vpos, d_vpos.p, (size_t)A * nv)) != MXG_OK) return rc;
-    if ((rc = d2h(h, g.vrec, d_vrec.p, (size_t)A * nv)) != MXG_OK) return rc;
-    if ((rc = d2h(h, g.eu, d_eu.p, ne)) != MXG_OK) return rc;
-    if ((rc = d2h(h, g.ev, d_ev.p, ne)) != MXG_OK) return rc;
-    if ((rc = d2h(h, g.esup, d_esup.p, ne)) != MXG_OK) return rc;
-    if ((rc = d2h(h, g.ew, d_ew.p, ne)) != MXG_OK) return rc;
-    uint64_t uniq = 0;
-    for (uint32_t a = 0; a < A; ++a) {
-        Assembly *as = h->asms[a];
-        if ((rc = d2h(h, as->h_flags, as->d_flags.p, as->n_mx)) != MXG_OK) return rc;
-    }
-    MXG_HIP(h, hipStreamSynchronize(h->stream));
-    for (uint32_t a = 0; a < A; ++a) {
-        Assembly *as = h->asms[a];
-        for (uint8_t f : as->h_flags) uniq += (f & MXG_MX_UNIQUE) ? 1 : 0;
-        as->flags_valid = true;
-    }
-    h->stat_unique = uniq;
     g.valid = true;
+    g.host_valid = false;
+    return MXG_OK;
+}
+
+// host mirrors are filled on demand (mxg_get_graph, mxg_write_dot, mxg_get_mx_flags)
+int graph_to_host(mxg_handle *h)
+{
+    Graph &g = h->graph;
+    if (!g.valid) return set_err(h, MXG_EINVAL, "call mxg_build_graph first");
+    if (g.host_valid) return MXG_OK;
+    MXG_HIP(h, hipSetDevice(h->device));
+    const size_t anv = (size_t)g.n_asm * g.nv;
+    int rc;
+    if ((rc = d2h(h, g.vhash, h->g_vhash.p, g.nv)) != MXG_OK) return rc;
+    if ((rc = d2h(h, g.vpos, h->g_vpos.p, anv)) != MXG_OK) return rc;
+    if ((rc = d2h(h, g.vrec, h->g_vrec.p, anv)) != MXG_OK) return rc;
+    if ((rc = d2h(h, g.eu, h->g_eu.p, g.ne)) != MXG_OK) return rc;
+    if ((rc = d2h(h, g.ev, h->g_ev.p, g.ne)) != MXG_OK) return rc;
+    if ((rc = d2h(h, g.esup, h->g_esup.p, g.ne)) != MXG_OK) return rc;
+    if ((rc = d2h(h, g.ew, h->g_ew.p, g.ne)) != MXG_OK) return rc;
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    g.host_valid = true;
+    return MXG_OK;
+}
+
+int flags_to_host(mxg_handle *h, Assembly *a)
+{
+    if (!h->graph.valid || !a->flags_valid) return set_err(h, MXG_EINVAL, "call mxg_build_graph first");
+    if (a->flags_on_host) return MXG_OK;
+    MXG_HIP(h, hipSetDevice(h->device));
+    int rc = d2h(h, a->h_flags, a->d_flags.p, a->n_mx);
+    if (rc != MXG_OK) return rc;
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    a->flags_on_host = true;
     return MXG_OK;
 }
 

@@ -91,6 +91,7 @@ struct Assembly {
     uint64_t total_kmers = 0;        // over eligible contigs
     // device copies of the tables above + strip / k-mer prefix tables (built once, by the first sketch)
     bool tables_ready = false;
+    uint32_t S_sparse = 256;  // strip length chosen for the sparse hash kernel
     std::vector<uint32_t> strip0_dense, strip0_sparse;  // [n_runs+1] exclusive prefix of strips per run
     std::vector<uint64_t> g0;                           // [n_runs+1] exclusive prefix of k-mers per run
     DevBuf d_runs, d_strip0_dense, d_strip0_sparse, d_g0, d_ctg_nk, d_ctg_rec, d_ctg_run0;
@@ -104,13 +105,15 @@ struct Assembly {
     std::vector<uint8_t> h_fwd;
     std::vector<uint64_t> rec_first;
     // graph stage
-    DevBuf d_flags;
+    DevBuf d_flags, d_slot, d_shared, d_bs;
     std::vector<uint8_t> h_flags;
-    bool flags_valid = false;
+    bool flags_valid = false;   // device flags computed
+    bool flags_on_host = false; // h_flags mirrors d_flags
 };
 
 struct Graph {
-    bool valid = false;
+    bool valid = false;       // device results computed
+    bool host_valid = false;  // host mirrors below filled (lazily, by graph_to_host)
     uint32_t n_asm = 0;
     uint64_t nv = 0, ne = 0;
     std::vector<uint64_t> vhash;
@@ -138,7 +141,9 @@ struct mxg_handle {
     mxg::HashTab tab{};
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
     // scratch reused across calls
-    mxg::DevBuf scratch[40];  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
+    mxg::DevBuf scratch[40];
+    mxg::DevBuf g_keys, g_seen, g_dup, g_vid, g_ctl, g_vhash, g_vpos, g_vrec, g_fv, g_frec, g_nxt, g_prv, g_eflag,
+        g_ebs, g_eu, g_ev, g_esup, g_ew;  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
     uint64_t arena_cap_hint = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -174,5 +179,7 @@ int sketch_assembly(mxg_handle *h, Assembly *a);
 int sync_sketch_to_host(mxg_handle *h, Assembly *a);
 // graph.hip
 int build_graph(mxg_handle *h);
+int graph_to_host(mxg_handle *h);
+int flags_to_host(mxg_handle *h, Assembly *a);
 
 }  // namespace mxg

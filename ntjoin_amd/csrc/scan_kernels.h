@@ -7,7 +7,7 @@
 
 namespace mxg {
 
-constexpr int TILE_PER_THREAD = 16;
+constexpr int TILE_PER_THREAD = 4;
 constexpr int TILE = 256 * TILE_PER_THREAD;
 
 static __global__ __launch_bounds__(256) void k_count(const uint8_t *__restrict__ sel, uint32_t n, uint32_t *__restrict__ bsum)

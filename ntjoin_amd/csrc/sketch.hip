@@ -29,6 +29,7 @@
 //   k_count/k_scan_sums/k_emit   ordered stream compaction into the sketch arrays
 //   k_merge        merge of the (small) gap sketch into the batch sketch by (record,pos)
 #include <algorithm>
+#include <cstdlib>
 
 #include "mxg_internal.h"
 #include "scan_kernels.h"
@@ -185,6 +186,7 @@ struct SparseParams {
     uint32_t run_lo, run_hi;
     uint32_t strip_lo, strip_hi;
     uint32_t k;
+    uint32_t S;           // k-mers per strip (multiple of 16, <= 1024)
     uint32_t tau_hi;      // candidate iff high word of min_hash < tau_hi
     uint4 *arena;         // {hash lo, hash hi, strip (relative to strip_lo), j | seq<<10 | fw<<20}
     uint32_t arena_cap;
@@ -194,16 +196,19 @@ struct SparseParams {
     HashTab tab;
 };
 
-template <int S, int VARIANT>
+// Packed bases are read straight from HBM/L2 by each lane (one 32-bit word per 16 steps per stream).  Staging the
+// wave's strips through LDS with coalesced row loads was measured (profiles/r01_notes.md) and does not pay: the
+// kernel is VALU/issue-bound, not memory-bound (SQ_WAIT on the loads is hidden by 4-6 waves per SIMD).
+template <int VARIANT>
 __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
 {
-    static_assert(S % 16 == 0 && S <= 1024, "strip length");
     __shared__ uint4 tab[20];
-    __shared__ uint64_t bh[4][WCAP];
-    __shared__ uint32_t bm[4][WCAP];
+    __shared__ uint4 buf[4][WCAP];  // per-wave candidate staging: {hash lo, hash hi, meta, -}
     if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
     __syncthreads();
+    const uint32_t S = p.S;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint4 *wbuf = buf[wv];
     const uint32_t srel = blockIdx.x * 256u + threadIdx.x;        // strip index relative to strip_lo
     const uint32_t s = p.strip_lo + srel;
     const bool active = s < p.strip_hi;                          // inactive lanes stay alive (wave-wide flush)
@@ -212,8 +217,8 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     if (active) {
         const uint32_t lo = find_run(p.run_strip0, p.run_lo, p.run_hi, s);
         const Run run = p.runs[lo];
-        const uint32_t j0 = (s - p.run_strip0[lo]) * (uint32_t)S;
-        len = min((uint32_t)S, run.n_kmers - j0);
+        const uint32_t j0 = (s - p.run_strip0[lo]) * S;
+        len = min(S, run.n_kmers - j0);
         b = run.base_off + j0;
         contig = run.contig;
         kidx = run.kidx0 + j0;
@@ -221,8 +226,8 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     }
     const uint32_t k = p.k;
     const uint32_t tau_hi = p.tau_hi;
-    uint32_t cnt_w = 0;  // wave-uniform: entries staged in this wave's LDS buffer
-    uint32_t seq = 0;    // this lane's candidates so far
+    uint32_t cnt_w = 0;    // wave-uniform: entries staged in this wave's LDS buffer
+    uint32_t seq16 = lane; // (this lane's candidates so far) << 16 | lane
     const uint32_t wave_srel0 = blockIdx.x * 256u + wv * 64u;
 
     auto flush = [&]() {
@@ -232,25 +237,26 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
         base = __builtin_amdgcn_readfirstlane(base);
         for (uint32_t i = lane; i < m; i += 64) {
             if (base + i < p.arena_cap) {
-                uint64_t hh = bh[wv][i];
-                uint32_t mt = bm[wv][i];
-                p.arena[base + i] = make_uint4((uint32_t)hh, (uint32_t)(hh >> 32), wave_srel0 + (mt & 63u), mt >> 6);
+                uint4 e = wbuf[i];
+                p.arena[base + i] = make_uint4(e.x, e.y, wave_srel0 + (e.z & 63u), e.z >> 6);
             }
         }
         __builtin_amdgcn_wave_barrier();
         cnt_w = 0;
     };
-    auto visit = [&](const H2 &h, uint32_t j) {
-        uint64_t h0 = canonical<VARIANT>(h);
-        bool c = (j < len) && ((uint32_t)(h0 >> 32) < tau_hi);
-        uint64_t mask = __ballot(c);
+    // meta layout in LDS: lane[0..5] | j[6..15] | seq[16..25] | fw[26]  -> arena.w = meta >> 6
+    auto visit = [&](const H2 &h, uint32_t j, bool check_len) {
+        const uint64_t h0 = canonical<VARIANT>(h);
+        bool c = (uint32_t)(h0 >> 32) < tau_hi;
+        if (check_len) c = c && (j < len);
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(c);
         if (mask) {  // wave-uniform
             if (c) {
-                uint32_t slot = cnt_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                bh[wv][slot] = h0;
-                bm[wv][slot] = lane | (j << 6) | (seq << 16) | ((is_forward(h) ? 1u : 0u) << 26);
-                ++seq;
+                const uint32_t slot = cnt_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                wbuf[slot] = make_uint4((uint32_t)h0, (uint32_t)(h0 >> 32),
+                                        seq16 | (j << 6) | (is_forward(h) ? (1u << 26) : 0u), 0u);
+                seq16 += 1u << 16;
             }
             cnt_w += (uint32_t)__popcll(mask);
             if (cnt_w > WCAP - 64) flush();
@@ -259,20 +265,40 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
 
     H2 h = {0u, 0u, 0u, 0u};
     warm_up(h, p.packed, b, k, tab);
-    visit(h, 0);
+    visit(h, 0, true);
+    // strips shorter than S only occur at the end of a run: when every lane of the wave owns a full strip the
+    // per-step length test is dropped (wave-uniform loop versioning)
+    const bool all_full = __builtin_amdgcn_ballot_w64(len != S) == 0;
+    if (all_full) {
 #pragma unroll 1
-    for (uint32_t blk = 0; blk < (uint32_t)S / 16; ++blk) {
-        uint32_t cout = fetch16(p.packed, b + 16u * blk);
-        uint32_t cin = fetch16(p.packed, b + k + 16u * blk);
+        for (uint32_t blk = 0; blk < S / 16; ++blk) {
+            const uint32_t cout = fetch16(p.packed, b + 16u * blk);
+            const uint32_t cin = fetch16(p.packed, b + k + 16u * blk);
+            const uint32_t jb = 1u + 16u * blk;
 #pragma unroll
-        for (uint32_t u = 0; u < 16; ++u) {
-            uint32_t idx = ((cout >> (2 * u)) & 3u) * 4u + ((cin >> (2 * u)) & 3u);
-            nt_step(h, tab[idx]);
-            visit(h, 1u + 16u * blk + u);
+            for (uint32_t u = 0; u < 16; ++u) {
+                const uint32_t idx = ((cout >> (2 * u)) & 3u) * 4u + ((cin >> (2 * u)) & 3u);
+                nt_step(h, tab[idx]);
+                if (u == 15 && blk + 1 == S / 16) break;  // j == S: beyond the strip
+                visit(h, jb + u, false);
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t blk = 0; blk < S / 16; ++blk) {
+            const uint32_t cout = fetch16(p.packed, b + 16u * blk);
+            const uint32_t cin = fetch16(p.packed, b + k + 16u * blk);
+            const uint32_t jb = 1u + 16u * blk;
+#pragma unroll
+            for (uint32_t u = 0; u < 16; ++u) {
+                const uint32_t idx = ((cout >> (2 * u)) & 3u) * 4u + ((cin >> (2 * u)) & 3u);
+                nt_step(h, tab[idx]);
+                visit(h, jb + u, true);
+            }
         }
     }
     if (cnt_w) flush();
-    if (active) p.strip_cnt[srel] = seq;
+    if (active) p.strip_cnt[srel] = seq16 >> 16;
 }
 
 // arena entry -> ordered candidate slot
@@ -317,42 +343,149 @@ __device__ __forceinline__ void push_gap(const ResolveParams &p, uint32_t c, uin
     if (idx < p.gap_cap) p.gaps[idx] = make_uint4(c, lo, hi, 0u);
 }
 
-// One lane per candidate.  sel[i] = 1 iff candidate i is a minimizer (see file header).
+// One lane per candidate, wave-cooperative for long scans.  sel[i] = 1 iff candidate i is a minimizer.
+// Phase 1: each lane looks at its T1 nearest neighbours on its own (decides most candidates: for random
+// hashes the nearest smaller element is O(1) away).  Phase 2: candidates still undecided are served one at
+// a time by the whole wave, 64 neighbours per step (ballot + first set bit = nearest event), so a true
+// minimizer's scan over up to w-1 k-mers costs ceil(w/64) steps instead of w dependent loads.
+
+struct CoopCtx {
+    const uint64_t *ch;
+    const uint32_t *ck, *cc;
+    uint32_t n, wm1;
+};
+
+// nearest event to the LEFT of candidate (bi,bh,bkx,bc) beyond distance-in-index `start`:
+// returns (distance in k-mers of the nearest strictly-smaller element) or 0xFFFFFFFF if the scan ran out
+__device__ __forceinline__ uint32_t coop_left(const CoopCtx &q, uint32_t lane, uint32_t bi, uint64_t bh, uint32_t bkx,
+                                              uint32_t bc, uint32_t start)
+{
+    for (uint32_t base = start;; base += 64) {
+        const uint32_t off = base + lane;
+        bool inr = off <= bi;  // j = bi - off >= 0
+        uint32_t dist = 0xFFFFFFFFu;
+        if (inr) {
+            const uint32_t j = bi - off;
+            inr = (q.cc[j] & 0x7FFFFFFFu) == bc;
+            if (inr) {
+                dist = bkx - q.ck[j];
+                inr = dist <= q.wm1;
+            }
+        }
+        const bool blk = inr && q.ch[inr ? bi - off : 0] < bh;
+        const uint64_t bm = __ballot(blk), sm = __ballot(!inr);
+        const uint64_t ev = bm | sm;
+        if (ev) {
+            const int first = __builtin_ctzll(ev);
+            if ((bm >> first) & 1ull) return (uint32_t)__builtin_amdgcn_readlane((int)dist, first);
+            return 0xFFFFFFFFu;
+        }
+    }
+}
+
+// is there an element <= bh to the RIGHT within k-mer distance `need`, beyond distance-in-index `start`?
+__device__ __forceinline__ bool coop_right_blocked(const CoopCtx &q, uint32_t lane, uint32_t bi, uint64_t bh, uint32_t bkx,
+                                                   uint32_t bc, uint32_t start, uint32_t need)
+{
+    for (uint32_t base = start;; base += 64) {
+        const uint32_t off = base + lane;
+        const uint64_t j64 = (uint64_t)bi + off;
+        bool inr = j64 < q.n;
+        if (inr) {
+            const uint32_t j = (uint32_t)j64;
+            inr = (q.cc[j] & 0x7FFFFFFFu) == bc;
+            if (inr) inr = (q.ck[j] - bkx) <= need;
+        }
+        const bool blk = inr && q.ch[inr ? (uint32_t)j64 : 0] <= bh;
+        const uint64_t bm = __ballot(blk), sm = __ballot(!inr);
+        const uint64_t ev = bm | sm;
+        if (ev) {
+            const int first = __builtin_ctzll(ev);
+            return ((bm >> first) & 1ull) != 0;
+        }
+    }
+}
+
+constexpr int RH = 128;  // halo (candidates) staged on each side of a block's 256 candidates
+
 template <bool GAPS>
 __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
 {
+    __shared__ uint64_t lh[256 + 2 * RH];
+    __shared__ uint2 lkc[256 + 2 * RH];  // {k-mer index, contig (strand bit cleared); contig = ~0 outside the array}
     const uint32_t n = min(*p.n_ptr, p.n_cap);
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t h = p.ch[i];
-    const uint32_t kx = p.ck[i];
-    const uint32_t c = p.cc[i] & 0x7FFFFFFFu;
+    const uint32_t i0 = blockIdx.x * 256u;
+    if (i0 >= n) return;
+    for (uint32_t e = threadIdx.x; e < 256 + 2 * RH; e += 256) {
+        const int64_t g = (int64_t)i0 - RH + e;
+        if (g >= 0 && g < (int64_t)n) {
+            lh[e] = p.ch[g];
+            lkc[e] = make_uint2(p.ck[g], p.cc[g] & 0x7FFFFFFFu);
+        } else {
+            lh[e] = 0;
+            lkc[e] = make_uint2(0u, 0xFFFFFFFFu);
+        }
+    }
+    __syncthreads();
+    const uint32_t i = i0 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool live = i < n;
+    const uint32_t li = RH + threadIdx.x;
+    const uint64_t h = lh[li];
+    const uint32_t kx = lkc[li].x;
+    const uint32_t c = live ? lkc[li].y : 0u;
     const uint32_t nk = p.ctg_nk[c];
     const uint32_t w = p.w, wm1 = w - 1;
+    CoopCtx q{p.ch, p.ck, p.cc, n, wm1};
+
+    // ---- left: nearest strictly smaller (ties: rightmost wins) ----
     uint32_t L = min(kx, wm1);
-    for (uint32_t j = i; j-- > 0;) {
-        if ((p.cc[j] & 0x7FFFFFFFu) != c) break;
-        uint32_t d = kx - p.ck[j];
-        if (d > wm1) break;
-        if (p.ch[j] < h) {  // strictly smaller on the left blocks (ties: rightmost wins)
-            L = d - 1;
-            break;
+    bool ldone = !live;
+    if (live) {
+        for (uint32_t t = 1; t <= (uint32_t)RH; ++t) {
+            const uint2 kc = lkc[li - t];
+            if (kc.y != c) { ldone = true; break; }
+            const uint32_t d = kx - kc.x;
+            if (d > wm1) { ldone = true; break; }
+            if (lh[li - t] < h) { L = d - 1; ldone = true; break; }
         }
     }
-    uint32_t R = min(nk - 1 - kx, wm1);
-    bool s = (L + R + 1 >= w);  // enough room if nothing blocks on the right
-    if (s && L < wm1) {
-        const uint32_t need = wm1 - L;  // need R >= need: no blocker within that distance
-        for (uint32_t j = i + 1; j < n; ++j) {
-            if ((p.cc[j] & 0x7FFFFFFFu) != c) break;
-            uint32_t d = p.ck[j] - kx;
-            if (d > need) break;
-            if (p.ch[j] <= h) {  // smaller-or-equal on the right blocks
-                s = false;
-                break;
-            }
+    for (uint64_t todo = __ballot(!ldone); todo; todo &= todo - 1) {
+        const int src = __builtin_ctzll(todo);
+        const uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)i, src);
+        const uint32_t bkx = (uint32_t)__builtin_amdgcn_readlane((int)kx, src);
+        const uint32_t bc = (uint32_t)__builtin_amdgcn_readlane((int)c, src);
+        const uint64_t bh = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), src) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, src);
+        const uint32_t d = coop_left(q, lane, bi, bh, bkx, bc, RH + 1);
+        if ((int)lane == src && d != 0xFFFFFFFFu) L = d - 1;
+    }
+    // ---- right: any smaller-or-equal within the distance still needed ----
+    const uint32_t R = min(nk - 1 - kx, wm1);
+    bool s = live && (L + R + 1 >= w);  // enough room if nothing blocks on the right
+    const uint32_t need = wm1 - min(L, wm1);  // need R >= need
+    bool rdone = !(s && need > 0);
+    if (!rdone) {
+        for (uint32_t t = 1; t <= (uint32_t)RH; ++t) {
+            const uint2 kc = lkc[li + t];
+            if (kc.y != c) { rdone = true; break; }
+            const uint32_t d = kc.x - kx;
+            if (d > need) { rdone = true; break; }
+            if (lh[li + t] <= h) { s = false; rdone = true; break; }
         }
     }
+    for (uint64_t todo = __ballot(!rdone); todo; todo &= todo - 1) {
+        const int src = __builtin_ctzll(todo);
+        const uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)i, src);
+        const uint32_t bkx = (uint32_t)__builtin_amdgcn_readlane((int)kx, src);
+        const uint32_t bc = (uint32_t)__builtin_amdgcn_readlane((int)c, src);
+        const uint32_t bneed = (uint32_t)__builtin_amdgcn_readlane((int)need, src);
+        const uint64_t bh = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), src) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, src);
+        const bool blocked = coop_right_blocked(q, lane, bi, bh, bkx, bc, RH + 1, bneed);
+        if ((int)lane == src && blocked) s = false;
+    }
+    if (!live) return;
     p.sel[i] = (s && h != 0xFFFFFFFFFFFFFFFFull) ? 1 : 0;  // btllib never reports min_hash == 2^64-1
 
     if (GAPS) {
@@ -405,6 +538,7 @@ struct EmitParams {
     const uint32_t *ctg_run0, *ctg_rec;
     uint64_t mult;         // 1 ^ (k * MULTISEED)
     uint64_t out_base;     // where this batch starts in the output arrays
+    uint64_t out_limit;    // capacity of the output arrays (entries at or beyond it are dropped: speculative emit)
     uint64_t *o_hash;
     uint32_t *o_pos, *o_rec;
     uint8_t *o_fwd;
@@ -430,10 +564,12 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
                 uint32_t mid = (lo + hi) >> 1;
                 if (p.runs[mid].kidx0 <= kx) lo = mid; else hi = mid;
             }
-            p.o_hash[o] = ext_hash(p.ch[i], p.mult);
-            p.o_pos[o] = p.runs[lo].pos0 + (kx - p.runs[lo].kidx0);
-            p.o_rec[o] = p.ctg_rec[ctg];
-            p.o_fwd[o] = (cs >> 31) ? 0 : 1;
+            if (o < p.out_limit) {
+                p.o_hash[o] = ext_hash(p.ch[i], p.mult);
+                p.o_pos[o] = p.runs[lo].pos0 + (kx - p.runs[lo].kidx0);
+                p.o_rec[o] = p.ctg_rec[ctg];
+                p.o_fwd[o] = (cs >> 31) ? 0 : 1;
+            }
             ++o;
         }
     }
@@ -476,7 +612,23 @@ __global__ __launch_bounds__(256) void k_merge(const MergeParams p)
 // host driver
 // ------------------------------------------------------------------------------------------------------
 constexpr int S_DENSE = 128;
-constexpr int S_SPARSE = 256;
+
+// MXG_SPARSE_S=<n> (environment) forces the strip length instead of the occupancy-balanced choice
+// Strip length for the sparse kernel: one lane hashes S consecutive k-mers after a k-step warm-up, so S should be
+// long (warm-up overhead k/S) but the launch should still fill the chip evenly: MI355X has 256 CUs x 4 SIMDs;
+// aim for a whole number of waves per SIMD (>= 4 for latency hiding) in a single round when the input is small.
+static uint32_t choose_sparse_S(uint64_t total_kmers)
+{
+    const char *e = getenv("MXG_SPARSE_S");
+    if (e && atoi(e) >= 16) return std::min(1024, (atoi(e) + 15) / 16 * 16);
+    const uint64_t lanes = 1024ull * 64;  // SIMDs x lanes
+    for (uint32_t m = 4; m <= 8; ++m) {    // waves per SIMD
+        uint64_t S = (total_kmers + lanes * m - 1) / (lanes * m);
+        S = (S + 15) / 16 * 16;
+        if (S <= 512) return (uint32_t)std::max<uint64_t>(S, 128);
+    }
+    return 512;  // large inputs: many rounds anyway; warm-up overhead k/512
+}
 constexpr uint64_t DENSE_BATCH_KMERS = 96ull << 20;   // dense arena = 16 B per k-mer
 constexpr uint64_t SPARSE_BATCH_KMERS = 2040ull << 20; // < 2^31 k-mers and < 2^32 strips per batch
 constexpr uint32_t GAP_CAP = 1u << 20;
@@ -650,6 +802,7 @@ struct Driver {
 
     int emit(const Tables &T, uint32_t n_cap, DevBuf &oh, DevBuf &op, DevBuf &orc, DevBuf &of, uint64_t out_base)
     {
+        const uint64_t limit = std::min<uint64_t>({oh.bytes / 8, op.bytes / 4, orc.bytes / 4, of.bytes});
         if (!n_cap) return MXG_OK;
         EmitParams ep;
         ep.sel = sc(SC_SEL).as<uint8_t>();
@@ -664,6 +817,7 @@ struct Driver {
         ep.ctg_rec = T.d_ctg_rec;
         ep.mult = 1ull ^ ((uint64_t)h->cfg.k * 0x90b45d39fb6da1faull);
         ep.out_base = out_base;
+        ep.out_limit = limit;
         ep.o_hash = oh.as<uint64_t>();
         ep.o_pos = op.as<uint32_t>();
         ep.o_rec = orc.as<uint32_t>();
@@ -846,6 +1000,7 @@ struct Driver {
                 sp.strip_lo = strip_lo;
                 sp.strip_hi = strip_hi;
                 sp.k = h->cfg.k;
+                sp.S = a->S_sparse;
                 sp.tau_hi = tau_hi;
                 sp.arena = sc(SC_ARENA).as<uint4>();
                 sp.arena_cap = arena_cap;
@@ -857,9 +1012,9 @@ struct Driver {
                 if (rc != MXG_OK) return rc;
                 dim3 grid((n_strips + 255) / 256), block(256);
                 if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-                    hipLaunchKernelGGL((k_hash_sparse<S_SPARSE, MXG_VARIANT_V1_MIN>), grid, block, 0, h->stream, sp);
+                    hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V1_MIN>), grid, block, 0, h->stream, sp);
                 else
-                    hipLaunchKernelGGL((k_hash_sparse<S_SPARSE, MXG_VARIANT_V2_SUM>), grid, block, 0, h->stream, sp);
+                    hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), grid, block, 0, h->stream, sp);
                 if ((rc = ev_end()) != MXG_OK) return rc;
                 MXG_HIP(h, hipGetLastError());
                 // order the candidates: exclusive scan of per-strip counts, then scatter
@@ -876,6 +1031,9 @@ struct Driver {
                                    sc(SC_CAND_C).as<uint32_t>());
                 MXG_HIP(h, hipGetLastError());
                 if ((rc = resolve_and_count<true>(T, arena_cap, (uint32_t)c0, (uint32_t)c1)) != MXG_OK) return rc;
+                // speculative emit straight into the output arrays (guarded by their capacity): on the common
+                // path (no gap, no overflow) the batch then needs a single host sync
+                if ((rc = emit(T, arena_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
                 if ((rc = ev_end()) != MXG_OK) return rc;
                 MXG_HIP(h, hipMemcpyAsync(ctrl, sc(SC_CTRL).p, 16, hipMemcpyDeviceToHost, h->stream));
                 MXG_HIP(h, hipStreamSynchronize(h->stream));
@@ -903,8 +1061,10 @@ struct Driver {
                 MXG_HIP(h, hipStreamSynchronize(h->stream));
             }
             if (n_gaps == 0) {
-                if ((rc = out_reserve(h, out, out.n + total)) != MXG_OK) return rc;
-                if ((rc = emit(T, arena_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
+                if (out.n + total > out.cap()) {  // the speculative emit did not fit: grow, emit again
+                    if ((rc = out_reserve(h, out, out.n + total)) != MXG_OK) return rc;
+                    if ((rc = emit(T, arena_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
+                }
                 out.n += total;
             } else {
                 // main result to staging (before the candidate scratch is reused by the gap pass)
@@ -942,7 +1102,8 @@ static int prepare_tables(mxg_handle *h, Assembly *a)
     if (n_runs >= (1ull << 31)) return set_err(h, MXG_ELIMIT, "too many valid runs (%zu)", n_runs);
     bool ovf = false;
     build_strip_tables(a->runs, S_DENSE, a->strip0_dense, &ovf);
-    build_strip_tables(a->runs, S_SPARSE, a->strip0_sparse, &ovf);
+    a->S_sparse = choose_sparse_S(a->total_kmers);
+    build_strip_tables(a->runs, (int)a->S_sparse, a->strip0_sparse, &ovf);
     if (ovf) return set_err(h, MXG_ELIMIT, "too many strips");
     a->g0.resize(n_runs + 1);
     uint64_t g = 0;
@@ -1017,7 +1178,7 @@ int sketch_assembly(mxg_handle *h, Assembly *a)
 
     Driver drv(h);
     // sparse path: expected c candidates per window; it pays while candidates are a small fraction of k-mers
-    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : 12;
+    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : 16;
     const double frac = (double)c / (double)w;
     const bool sparse = !(h->cfg.flags & MXG_FLAG_DENSE_ONLY) && frac <= 0.125;
     if (sparse) {
