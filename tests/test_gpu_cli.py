@@ -1,0 +1,94 @@
+"""GPU tests of the process boundary: the indexlr-compatible binary and the make front-end."""
+import filecmp
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from oracle import graph_oracle as go
+from tests.conftest import GOLDEN, REPO, load_case
+
+pytestmark = pytest.mark.gpu
+INDEXLR = os.path.join(REPO, "ntjoin_amd", "bin", "indexlr")
+FASTA = os.path.join(GOLDEN, "fasta")
+
+
+def test_indexlr_stdout_matches_golden_tsv(tmp_path):
+    """the reference recipe, verbatim: indexlr --seq --long --pos -k K -w W -t T X.fa > X.fa.kK.wW.tsv"""
+    case = load_case("synth_w100")["meta"]
+    for a in case["refs"] + [case["target"]]:
+        out = tmp_path / a["tsv"]
+        with open(out, "wb") as fh:
+            subprocess.check_call([INDEXLR, "--seq", "--long", "--pos", "-k", "32", "-w", "100", "-t", "4",
+                                   os.path.join(FASTA, a["fasta"])], stdout=fh)
+        assert filecmp.cmp(str(out), os.path.join(GOLDEN, "cases", "synth_w100", a["tsv"]), shallow=False)
+
+
+def test_indexlr_glued_options_and_o(tmp_path):
+    """run_indexlr()'s spelling (reference bin/ntjoin_utils.py:198): -k32 -w100 -t4 ... -o file"""
+    out = tmp_path / "o.tsv"
+    subprocess.check_call([INDEXLR, os.path.join(FASTA, "ref.fa"), "--seq", "--long", "--pos", "-k32", "-w100", "-t4",
+                           "-o", str(out)])
+    assert filecmp.cmp(str(out), os.path.join(GOLDEN, "cases", "f-f_w100_config1", "ref.fa.k32.w100.tsv"), shallow=False)
+    # hash-only and strand columns
+    r = subprocess.run([INDEXLR, "-k", "32", "-w", "1000", "--variant", "v1", "--pos", os.path.join(FASTA, "ref.fa")],
+                       check=True, capture_output=True)
+    want = open(os.path.join(GOLDEN, "reference_expected_outputs", "ref.fa.k32.w1000.tsv"), "rb").read()
+    assert r.stdout == want  # the reference's own (stale-format) golden file, bit for bit
+    r = subprocess.run([INDEXLR, "-k", "32", "-w", "1000", "--pos", "--strand", os.path.join(FASTA, "ref.fa")],
+                       check=True, capture_output=True)
+    fields = r.stdout.decode().split("\t")[1].split()[0].split(":")
+    assert len(fields) == 3 and fields[2] in "+-"
+
+
+def test_indexlr_failure_is_loud(tmp_path):
+    r = subprocess.run([INDEXLR, "-k", "32", "-w", "100", str(tmp_path / "missing.fa")], capture_output=True)
+    assert r.returncode != 0 and r.stdout == b"" and b"cannot open" in r.stderr
+    r = subprocess.run([INDEXLR, "-w", "100", os.path.join(FASTA, "ref.fa")], capture_output=True)
+    assert r.returncode == 2 and r.stdout == b""
+
+
+def test_make_front_end_mxgraph(tmp_path):
+    """ntJoin's variable surface: target= references= reference_weights= k= w= prefix= ; same file naming"""
+    case = load_case("f-f-f_w100_weights")
+    meta = case["meta"]
+    for a in meta["refs"] + [meta["target"]]:
+        shutil.copy(os.path.join(FASTA, a["fasta"]), tmp_path / a["fasta"])
+    refs = " ".join(a["fasta"] for a in meta["refs"])
+    wts = " ".join(str(a["weight"]) for a in meta["refs"])
+    subprocess.check_call(["make", "-f", os.path.join(REPO, "ntJoin-mx"), "mxgraph", f"target={meta['target']['fasta']}",
+                           f"target_weight={meta['target']['weight']}", f"references={refs}",
+                           f"reference_weights={wts}", "k=32", "w=100", "prefix=out"], cwd=tmp_path)
+    for a in meta["refs"] + [meta["target"]]:
+        assert filecmp.cmp(str(tmp_path / a["tsv"]), os.path.join(GOLDEN, "cases", meta["name"], a["tsv"]), shallow=False)
+    with open(os.path.join(GOLDEN, "cases", meta["name"], "reference.mx.dot"), encoding="utf-8") as fh:
+        want = go.canonical_dot_from_text(fh.read())
+    assert go.canonical_dot_from_text((tmp_path / "out.mx.dot").read_text(encoding="utf-8")) == want
+
+
+def test_python_mirror_functions(tmp_path):
+    """read_minimizers / filter_minimizers / build_graph counterparts return what the reference's returned"""
+    from ntjoin_amd import ntjoin_utils as nu
+    case = load_case("gap-dist_w500")
+    meta, ref = case["meta"], case["reference"]
+    cdir = os.path.join(GOLDEN, "cases", meta["name"])
+    os.chdir(cdir)
+    list_mxs, weights = {}, {}
+    for a in meta["refs"] + [meta["target"]]:
+        info, mxs = nu.read_minimizers(a["tsv"])
+        assert {m: list(v) for m, v in info.items()} == ref["mx_info"][a["tsv"]]
+        assert mxs == ref["mxs"][a["tsv"]]
+        list_mxs[a["tsv"]] = mxs
+        weights[a["tsv"]] = float(a["weight"])
+    filt = nu.filter_minimizers(list_mxs)
+    assert filt == ref["filtered"]
+    g = nu.build_graph(filt, weights)
+    mine = {frozenset((s, t)): (sup, w) for s, t, sup, w in g.edge_list_named()}
+    theirs = {frozenset((s, t)): (sup, w) for s, t, sup, w in ref["edges"]}
+    assert mine == theirs and sorted(g.names, key=int) == ref["vertices"]
+    # error behaviour: an entry without exactly three fields raises ValueError, as the reference's unpack does
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("ctg\t123:45\n")
+    with pytest.raises(ValueError):
+        nu.read_minimizers(str(bad))
