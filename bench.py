@@ -83,9 +83,12 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("MXG_BENCH_FORCE_DIST") == "1"  # exercise the N>1 path with one rank (testing)
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from ntjoin_amd import synth
     from ntjoin_amd.engine import MxEngine
@@ -107,7 +110,7 @@ def main():
         nonlocal union
         eng.sketch(0)
         eng.sketch(1)
-        if world > 1:
+        if world > 1 or force_dist:
             union = allgather_union_graph(eng, K, W, local_rank, union)
         else:
             eng.build_graph()
@@ -182,7 +185,7 @@ def main():
             out["parity_counts_match_cpu"] = bool(cb["minimizers"] == st["minimizers"] and
                                                   cb["vertices"] == st["vertices"] and cb["edges"] == st["edges"])
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -59,6 +59,29 @@ class Stats(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime.  PyTorch wheels bundle their own libamdhip64; if this library were
+    loaded first it would bind /opt/rocm's copy and a later `import torch` would initialise a second runtime that
+    sees no GPU.  When torch is installed, map its bundled runtime first (without importing torch): the loader
+    then resolves our DT_NEEDED libamdhip64.so.N to the copy already in the process, whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load():
     """Load libntjoin_mx.so.  There is no fallback: a missing/unloadable library is an error."""
     global _lib
@@ -68,6 +91,7 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C ntjoin_amd/csrc`). ntjoin_amd has no CPU fallback.")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, cp, u64, i32 = C.c_void_p, C.c_char_p, C.c_uint64, C.c_int
     L.mxg_abi_version.restype = i32
