@@ -29,7 +29,9 @@
 //   k_count/k_scan_sums/k_emit   ordered stream compaction into the sketch arrays
 //   k_merge        merge of the (small) gap sketch into the batch sketch by (record,pos)
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "mxg_internal.h"
 #include "scan_kernels.h"
@@ -38,7 +40,7 @@ namespace mxg {
 
 enum Scratch {
     SC_CAND_H, SC_CAND_K, SC_CAND_C, SC_SEL, SC_BSUM, SC_CTRL, SC_ARENA, SC_STRIP_CNT, SC_STRIP_META,
-    SC_STRIP_PREF, SC_SBSUM, SC_GAPS, SC_ST_HASH, SC_ST_POS, SC_ST_REC, SC_ST_FWD, SC_G_HASH, SC_G_POS,
+    SC_STRIP_PREF, SC_SBSUM, SC_GAPS, SC_WAVE_CNT, SC_ST_HASH, SC_ST_POS, SC_ST_REC, SC_ST_FWD, SC_G_HASH, SC_G_POS,
     SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_COUNT
 };
 static_assert(SC_COUNT <= 40, "scratch pool too small");
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void k_hash_dense(const DenseParams p)
     warm_up(h, p.packed, b, k, tab);
     p.cand_h[gi] = canonical<VARIANT>(h);
     p.cand_k[gi] = kidx;
-    p.cand_c[gi] = run.contig | (is_forward(h) ? 0u : 0x80000000u);
+    p.cand_c[gi] = run.contig;
 #pragma unroll 1
     for (uint32_t blk = 0; blk < (uint32_t)S / 16; ++blk) {
         uint32_t cout = fetch16(p.packed, b + 16u * blk);
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void k_hash_dense(const DenseParams p)
             if (j < len) {
                 p.cand_h[gi + j] = canonical<VARIANT>(h);
                 p.cand_k[gi + j] = kidx + j;
-                p.cand_c[gi + j] = run.contig | (is_forward(h) ? 0u : 0x80000000u);
+                p.cand_c[gi + j] = run.contig;
             }
         }
     }
@@ -177,8 +179,6 @@ __global__ __launch_bounds__(256) void k_hash_dense(const DenseParams p)
 // ------------------------------------------------------------------------------------------------------
 // sparse hash kernel
 // ------------------------------------------------------------------------------------------------------
-constexpr int WCAP = 256;  // LDS candidate slots per wave (flushed when fewer than 64 remain)
-
 struct SparseParams {
     const uint32_t *packed;
     const Run *runs;
@@ -188,30 +188,29 @@ struct SparseParams {
     uint32_t k;
     uint32_t S;           // k-mers per strip (multiple of 16, <= 1024)
     uint32_t tau_hi;      // candidate iff high word of min_hash < tau_hi
-    uint4 *arena;         // {hash lo, hash hi, strip (relative to strip_lo), j | seq<<10 | fw<<20}
-    uint32_t arena_cap;
-    uint32_t *ctrl;       // [0] arena counter
+    uint4 *arena;         // wave w owns entries [w*wave_cap, (w+1)*wave_cap): {hash lo, hash hi, strip (rel.), j | seq<<10}
+    uint32_t wave_cap;
+    uint32_t *wave_cnt;   // [n_waves] candidates each wave produced (may exceed wave_cap: overflow, batch is redone)
+    uint32_t *ctrl;       // [0] max over waves of wave_cnt (atomicMax, only written on overflow)
     uint32_t *strip_cnt;  // [n_strips] candidates per strip
     uint2 *strip_meta;    // [n_strips] {contig, kidx of the strip's first k-mer}
     HashTab tab;
 };
 
-// Packed bases are read straight from HBM/L2 by each lane (one 32-bit word per 16 steps per stream).  Staging the
-// wave's strips through LDS with coalesced row loads was measured (profiles/r01_notes.md) and does not pay: the
-// kernel is VALU/issue-bound, not memory-bound (SQ_WAIT on the loads is hidden by 4-6 waves per SIMD).
-template <int VARIANT>
+// Packed bases are read straight from HBM/L2 by each lane (one 32-bit word per 16 steps per stream, requested one
+// block ahead).  Staging the wave's strips through LDS with coalesced row loads was measured and does not pay
+// (profiles/r01_notes.md): the kernel is bound by VALU issue and by what the candidate capture costs, not by memory.
+template <int VARIANT, int ABL = 0>
 __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
 {
     __shared__ uint4 tab[20];
-    __shared__ uint4 buf[4][WCAP];  // per-wave candidate staging: {hash lo, hash hi, meta, -}
     if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
     __syncthreads();
     const uint32_t S = p.S;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    uint4 *wbuf = buf[wv];
     const uint32_t srel = blockIdx.x * 256u + threadIdx.x;        // strip index relative to strip_lo
     const uint32_t s = p.strip_lo + srel;
-    const bool active = s < p.strip_hi;                          // inactive lanes stay alive (wave-wide flush)
+    const bool active = s < p.strip_hi;                          // inactive lanes stay alive (wave-wide steps)
     uint32_t len = 0, contig = 0, kidx = 0;
     uint64_t b = 0;
     if (active) {
@@ -226,41 +225,44 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     }
     const uint32_t k = p.k;
     const uint32_t tau_hi = p.tau_hi;
-    uint32_t cnt_w = 0;    // wave-uniform: entries staged in this wave's LDS buffer
-    uint32_t seq16 = lane; // (this lane's candidates so far) << 16 | lane
-    const uint32_t wave_srel0 = blockIdx.x * 256u + wv * 64u;
+    const uint32_t wave_id = blockIdx.x * 4u + wv;
+    uint4 *const region = p.arena + (size_t)wave_id * p.wave_cap;  // this wave's private slice of the arena
+    const uint32_t wave_cap = p.wave_cap;
+    uint32_t cnt_w = 0;  // wave-uniform: candidates this wave has written
+    uint32_t seq = 0;    // this lane's candidates so far (rank inside its strip)
 
-    auto flush = [&]() {
-        __builtin_amdgcn_wave_barrier();
-        uint32_t m = cnt_w, base = 0;
-        if (lane == 0) base = atomicAdd(&p.ctrl[0], m);
-        base = __builtin_amdgcn_readfirstlane(base);
-        for (uint32_t i = lane; i < m; i += 64) {
-            if (base + i < p.arena_cap) {
-                uint4 e = wbuf[i];
-                p.arena[base + i] = make_uint4(e.x, e.y, wave_srel0 + (e.z & 63u), e.z >> 6);
-            }
+    // Candidate capture is branch-free per step: a lane keeps at most ONE pending candidate in registers
+    // (hash lo/hi, step j), selected with v_cndmask.  Every 8 steps the pending lanes store theirs to the wave's
+    // arena slice with fire-and-forget 16 B global stores (slot = running count + rank among pending lanes: no
+    // atomics, no LDS staging, nothing waits on the stores).  A second candidate in a lane that still holds one
+    // forces an early drain (rare).  Ablation (profiles/r01_notes.md): an exec-masked capture body executed in
+    // 64 % of the steps cost as much as the hashing itself; LDS staging + atomic flush cost ~40 us of 140.
+    uint32_t pend_lo = 0, pend_hi = 0, pend_j = 0;
+    uint64_t pend_mask = 0;  // wave-uniform: lanes holding a pending candidate
+    uint32_t abl_acc = 0;    // (profiling builds only)
+    auto drain = [&]() {
+        if (ABL == 4) { abl_acc += pend_lo ^ pend_hi ^ pend_j; pend_mask = 0; return; }
+        if ((pend_mask >> lane) & 1ull) {  // this lane holds a pending candidate
+            const uint32_t slot = cnt_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(pend_mask >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)pend_mask, 0u));
+            if (slot < wave_cap) region[slot] = make_uint4(pend_lo, pend_hi, srel, pend_j | (seq << 10));
+            ++seq;
         }
-        __builtin_amdgcn_wave_barrier();
-        cnt_w = 0;
+        cnt_w += (uint32_t)__popcll(pend_mask);
+        pend_mask = 0;
     };
-    // meta layout in LDS: lane[0..5] | j[6..15] | seq[16..25] | fw[26]  -> arena.w = meta >> 6
     auto visit = [&](const H2 &h, uint32_t j, bool check_len) {
         const uint64_t h0 = canonical<VARIANT>(h);
+        if (ABL == 1) { abl_acc ^= (uint32_t)(h0 >> 32); return; }
         bool c = (uint32_t)(h0 >> 32) < tau_hi;
         if (check_len) c = c && (j < len);
         const uint64_t mask = __builtin_amdgcn_ballot_w64(c);
-        if (mask) {  // wave-uniform
-            if (c) {
-                const uint32_t slot = cnt_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                wbuf[slot] = make_uint4((uint32_t)h0, (uint32_t)(h0 >> 32),
-                                        seq16 | (j << 6) | (is_forward(h) ? (1u << 26) : 0u), 0u);
-                seq16 += 1u << 16;
-            }
-            cnt_w += (uint32_t)__popcll(mask);
-            if (cnt_w > WCAP - 64) flush();
-        }
+        if (ABL == 2) { if (mask) abl_acc += 1; return; }
+        if (mask & pend_mask) drain();  // wave-uniform, rare
+        pend_lo = c ? (uint32_t)h0 : pend_lo;
+        pend_hi = c ? (uint32_t)(h0 >> 32) : pend_hi;
+        pend_j = c ? j : pend_j;
+        pend_mask |= mask;
     };
 
     H2 h = {0u, 0u, 0u, 0u};
@@ -269,54 +271,60 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     // strips shorter than S only occur at the end of a run: when every lane of the wave owns a full strip the
     // per-step length test is dropped (wave-uniform loop versioning)
     const bool all_full = __builtin_amdgcn_ballot_w64(len != S) == 0;
-    if (all_full) {
+    // table index of step u of a block: (out_u << 2 | in_u) << 4 (byte offset of a 16-byte entry), from the two
+    // 16-base words; the words of block blk+1 are requested before block blk is hashed (software prefetch)
+    const unsigned char *tabb = reinterpret_cast<const unsigned char *>(tab);
+    uint32_t cout = fetch16(p.packed, b);
+    uint32_t cin = fetch16(p.packed, b + k);
+    const uint32_t nblk = S / 16;
+    auto run = [&](auto chk) {
+        constexpr bool CHECK_LEN = decltype(chk)::value;
 #pragma unroll 1
-        for (uint32_t blk = 0; blk < S / 16; ++blk) {
-            const uint32_t cout = fetch16(p.packed, b + 16u * blk);
-            const uint32_t cin = fetch16(p.packed, b + k + 16u * blk);
+        for (uint32_t blk = 0; blk < nblk; ++blk) {
+            const uint32_t ncout = fetch16(p.packed, b + 16u * (blk + 1));  // reads stay inside the padded buffer
+            const uint32_t ncin = fetch16(p.packed, b + k + 16u * (blk + 1));
             const uint32_t jb = 1u + 16u * blk;
+            const bool last_blk = blk + 1 == nblk;
 #pragma unroll
             for (uint32_t u = 0; u < 16; ++u) {
-                const uint32_t idx = ((cout >> (2 * u)) & 3u) * 4u + ((cin >> (2 * u)) & 3u);
-                nt_step(h, tab[idx]);
-                if (u == 15 && blk + 1 == S / 16) break;  // j == S: beyond the strip
-                visit(h, jb + u, false);
+                // (cout >> 2u & 3) << 6 | (cin >> 2u & 3) << 4 with constant shifts: two shift-and-mask + one or
+                const uint32_t o6 = (2 * u >= 6 ? cout >> (2 * u - 6) : cout << (6 - 2 * u)) & 0xC0u;
+                const uint32_t i4 = (2 * u >= 4 ? cin >> (2 * u - 4) : cin << (4 - 2 * u)) & 0x30u;
+                nt_step(h, *reinterpret_cast<const uint4 *>(tabb + (o6 | i4)));
+                if (u == 15 && last_blk) break;  // j == S: beyond the strip
+                visit(h, jb + u, CHECK_LEN);
+                if ((u & 7u) == 7u && (ABL == 0 || ABL >= 3) && pend_mask) drain();
             }
+            cout = ncout;
+            cin = ncin;
         }
-    } else {
-#pragma unroll 1
-        for (uint32_t blk = 0; blk < S / 16; ++blk) {
-            const uint32_t cout = fetch16(p.packed, b + 16u * blk);
-            const uint32_t cin = fetch16(p.packed, b + k + 16u * blk);
-            const uint32_t jb = 1u + 16u * blk;
-#pragma unroll
-            for (uint32_t u = 0; u < 16; ++u) {
-                const uint32_t idx = ((cout >> (2 * u)) & 3u) * 4u + ((cin >> (2 * u)) & 3u);
-                nt_step(h, tab[idx]);
-                visit(h, jb + u, true);
-            }
-        }
+    };
+    if (all_full) run(std::false_type{}); else run(std::true_type{});
+    if (pend_mask) drain();
+    if (ABL != 0 && abl_acc == 0x12345u) p.ctrl[3] = abl_acc;  // keep the ablated work alive
+    if (active) p.strip_cnt[srel] = seq;
+    if (lane == 0) {
+        p.wave_cnt[wave_id] = cnt_w;
+        if (cnt_w > wave_cap) atomicMax(&p.ctrl[0], cnt_w);  // overflow: the host redoes the batch with this capacity
     }
-    if (cnt_w) flush();
-    if (active) p.strip_cnt[srel] = seq16 >> 16;
 }
 
-// arena entry -> ordered candidate slot
-__global__ __launch_bounds__(256) void k_reorder(const uint4 *__restrict__ arena, const uint32_t *__restrict__ ctrl,
-                                                 uint32_t arena_cap, const uint32_t *__restrict__ strip_pref,
+// arena entry -> ordered candidate slot: one thread per (wave, slot)
+__global__ __launch_bounds__(256) void k_reorder(const uint4 *__restrict__ arena, const uint32_t *__restrict__ wave_cnt,
+                                                 uint32_t wave_cap, uint32_t n_waves, const uint32_t *__restrict__ strip_pref,
                                                  const uint2 *__restrict__ strip_meta, uint64_t *__restrict__ ch,
                                                  uint32_t *__restrict__ ck, uint32_t *__restrict__ cc)
 {
-    const uint32_t n = min(ctrl[0], arena_cap);
-    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
-    if (e >= n) return;
-    const uint4 a = arena[e];
-    const uint32_t j = a.w & 1023u, seq = (a.w >> 10) & 1023u, fw = (a.w >> 20) & 1u;
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t wv = (uint32_t)(t / wave_cap), i = (uint32_t)(t % wave_cap);
+    if (wv >= n_waves || i >= min(wave_cnt[wv], wave_cap)) return;
+    const uint4 a = arena[t];
+    const uint32_t j = a.w & 1023u, seq = a.w >> 10;
     const uint32_t dst = strip_pref[a.z] + seq;
     const uint2 sm = strip_meta[a.z];
     ch[dst] = ((uint64_t)a.y << 32) | a.x;
     ck[dst] = sm.y + j;
-    cc[dst] = sm.x | (fw ? 0u : 0x80000000u);
+    cc[dst] = sm.x;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -537,6 +545,9 @@ struct EmitParams {
     const Run *runs;
     const uint32_t *ctg_run0, *ctg_rec;
     uint64_t mult;         // 1 ^ (k * MULTISEED)
+    const uint32_t *packed; // the strand bit is recomputed here from the bases (k steps, only for minimizers)
+    uint32_t k;
+    HashTab tab;
     uint64_t out_base;     // where this batch starts in the output arrays
     uint64_t out_limit;    // capacity of the output arrays (entries at or beyond it are dropped: speculative emit)
     uint64_t *o_hash;
@@ -547,6 +558,8 @@ struct EmitParams {
 __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
 {
     __shared__ uint32_t sh[256];
+    __shared__ uint4 tab[20];
+    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
     const uint32_t n = min(*p.n_ptr, p.n_cap);
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
     uint32_t c = 0;
@@ -565,10 +578,13 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
                 if (p.runs[mid].kidx0 <= kx) lo = mid; else hi = mid;
             }
             if (o < p.out_limit) {
+                const uint32_t off = kx - p.runs[lo].kidx0;
+                H2 hh = {0u, 0u, 0u, 0u};
+                warm_up(hh, p.packed, p.runs[lo].base_off + off, p.k, tab);  // forward = fwd_hash <= rev_hash
                 p.o_hash[o] = ext_hash(p.ch[i], p.mult);
-                p.o_pos[o] = p.runs[lo].pos0 + (kx - p.runs[lo].kidx0);
+                p.o_pos[o] = p.runs[lo].pos0 + off;
                 p.o_rec[o] = p.ctg_rec[ctg];
-                p.o_fwd[o] = (cs >> 31) ? 0 : 1;
+                p.o_fwd[o] = is_forward(hh) ? 1 : 0;
             }
             ++o;
         }
@@ -767,7 +783,7 @@ struct Driver {
         return b;
     }
 
-    // resolve -> count -> scan over candidates already in SC_CAND_*; n candidates read from ctrl[0] (<= n_cap)
+    // resolve -> count -> scan over candidates already in SC_CAND_*; n candidates read from ctrl[4] (<= n_cap)
     template <bool GAPS>
     int resolve_and_count(const Tables &T, uint32_t n_cap, uint32_t ctg_lo, uint32_t ctg_hi)
     {
@@ -779,7 +795,7 @@ struct Driver {
         rp.ch = sc(SC_CAND_H).as<uint64_t>();
         rp.ck = sc(SC_CAND_K).as<uint32_t>();
         rp.cc = sc(SC_CAND_C).as<uint32_t>();
-        rp.n_ptr = ctrl;
+        rp.n_ptr = ctrl + 4;
         rp.n_cap = n_cap;
         rp.ctg_nk = T.d_ctg_nk;
         rp.w = h->cfg.w;
@@ -800,7 +816,8 @@ struct Driver {
         return MXG_OK;
     }
 
-    int emit(const Tables &T, uint32_t n_cap, DevBuf &oh, DevBuf &op, DevBuf &orc, DevBuf &of, uint64_t out_base)
+    int emit(const uint32_t *d_packed, const Tables &T, uint32_t n_cap, DevBuf &oh, DevBuf &op, DevBuf &orc, DevBuf &of,
+             uint64_t out_base)
     {
         const uint64_t limit = std::min<uint64_t>({oh.bytes / 8, op.bytes / 4, orc.bytes / 4, of.bytes});
         if (!n_cap) return MXG_OK;
@@ -809,13 +826,16 @@ struct Driver {
         ep.ch = sc(SC_CAND_H).as<uint64_t>();
         ep.ck = sc(SC_CAND_K).as<uint32_t>();
         ep.cc = sc(SC_CAND_C).as<uint32_t>();
-        ep.n_ptr = sc(SC_CTRL).as<uint32_t>();
+        ep.n_ptr = sc(SC_CTRL).as<uint32_t>() + 4;
         ep.n_cap = n_cap;
         ep.bsum = sc(SC_BSUM).as<uint32_t>();
         ep.runs = T.d_runs;
         ep.ctg_run0 = T.d_ctg_run0;
         ep.ctg_rec = T.d_ctg_rec;
         ep.mult = 1ull ^ ((uint64_t)h->cfg.k * 0x90b45d39fb6da1faull);
+        ep.packed = d_packed;
+        ep.k = h->cfg.k;
+        ep.tab = h->tab;
         ep.out_base = out_base;
         ep.out_limit = limit;
         ep.o_hash = oh.as<uint64_t>();
@@ -845,8 +865,8 @@ struct Driver {
             MXG_HIP(h, sc(SC_CAND_K).ensure(nk * 4));
             MXG_HIP(h, sc(SC_CAND_C).ensure(nk * 4));
             const uint32_t n_cand = (uint32_t)nk;
-            uint32_t ctrl_init[4] = {n_cand, 0, 0, 0};
-            MXG_HIP(h, hipMemcpyAsync(sc(SC_CTRL).p, ctrl_init, 16, hipMemcpyHostToDevice, h->stream));
+            uint32_t ctrl_init[8] = {0, 0, 0, 0, n_cand, 0, 0, 0};
+            MXG_HIP(h, hipMemcpyAsync(sc(SC_CTRL).p, ctrl_init, 32, hipMemcpyHostToDevice, h->stream));
             DenseParams hp;
             hp.packed = d_packed;
             hp.runs = T.d_runs;
@@ -879,7 +899,7 @@ struct Driver {
             MXG_HIP(h, hipStreamSynchronize(h->stream));
             const uint64_t total = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
             if ((rc = out_reserve(h, out, out.n + total)) != MXG_OK) return rc;
-            if ((rc = emit(T, n_cand, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
+            if ((rc = emit(d_packed, T, n_cand, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
             out.n += total;
             h->stat_dense_kmers += nk;
             c0 = c1;
@@ -961,11 +981,14 @@ struct Driver {
     }
 
     // ---- sparse pipeline over every contig of T, appended to `out` ------------------------------------
+    // control block (u32 words): [0] max wave count if a wave overflowed its arena slice, [1] gap count,
+    // [2..3] number of selected candidates (u64), [4..5] number of candidates (u64)
     int sparse_all(Assembly *a, const Tables &T, OutArrays &out, uint32_t tau_hi, double cand_frac)
     {
         const size_t n_ctg = T.ctg_rec->size();
         MXG_HIP(h, sc(SC_CTRL).ensure(64));
         MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
+        const uint32_t S = a->S_sparse;
         size_t c0 = 0;
         while (c0 < n_ctg) {
             size_t c1 = c0;
@@ -974,23 +997,30 @@ struct Driver {
             const uint32_t r_lo = (*T.ctg_run0)[c0], r_hi = (*T.ctg_run0)[c1];
             const uint32_t strip_lo = (*T.strip0_sparse)[r_lo], strip_hi = (*T.strip0_sparse)[r_hi];
             const uint32_t n_strips = strip_hi - strip_lo;
+            const uint32_t n_blocks = (n_strips + 255) / 256, n_waves = n_blocks * 4;
             const uint32_t s_tiles = (n_strips + TILE - 1) / TILE;
             MXG_HIP(h, sc(SC_STRIP_CNT).ensure((size_t)n_strips * 4 + 16));
             MXG_HIP(h, sc(SC_STRIP_PREF).ensure((size_t)n_strips * 4 + 16));
             MXG_HIP(h, sc(SC_STRIP_META).ensure((size_t)n_strips * 8 + 16));
             MXG_HIP(h, sc(SC_SBSUM).ensure((size_t)s_tiles * 4 + 16));
-            uint64_t want = (uint64_t)((double)nk * cand_frac * 1.5) + 65536;
-            want = std::max<uint64_t>(want, h->arena_cap_hint);
-            uint32_t ctrl[4];
+            MXG_HIP(h, sc(SC_WAVE_CNT).ensure((size_t)n_waves * 4 + 16));
+            // every wave owns a slice of the arena: twice the expected candidates of 64 strips plus 6 sigma
+            const double expect = 64.0 * S * cand_frac;
+            uint64_t wave_cap = (uint64_t)(2.0 * expect + 6.0 * std::sqrt(expect)) + 64;
+            wave_cap = std::max<uint64_t>(wave_cap, h->arena_cap_hint);
+            wave_cap = std::min<uint64_t>(wave_cap, 64ull * S);  // a wave can never produce more
+            uint32_t ctrl[8];
+            uint64_t n_cap64 = 0;
             for (int attempt = 0;; ++attempt) {
-                if (want >= (1ull << 32))
-                    return set_err(h, MXG_ELIMIT, "candidate arena would exceed 2^32 entries; use MXG_FLAG_DENSE_ONLY or a smaller cand_per_window");
-                const uint32_t arena_cap = (uint32_t)want;
-                MXG_HIP(h, sc(SC_ARENA).ensure((size_t)arena_cap * 16));
-                MXG_HIP(h, sc(SC_CAND_H).ensure((size_t)arena_cap * 8));
-                MXG_HIP(h, sc(SC_CAND_K).ensure((size_t)arena_cap * 4));
-                MXG_HIP(h, sc(SC_CAND_C).ensure((size_t)arena_cap * 4));
-                MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, 16, h->stream));
+                n_cap64 = (uint64_t)n_waves * wave_cap;
+                if (n_cap64 >= (1ull << 32))
+                    return set_err(h, MXG_ELIMIT, "candidate arena would exceed 2^32 entries; use MXG_FLAG_DENSE_ONLY");
+                const uint32_t n_cap = (uint32_t)n_cap64;
+                MXG_HIP(h, sc(SC_ARENA).ensure((size_t)n_cap * 16));
+                MXG_HIP(h, sc(SC_CAND_H).ensure((size_t)n_cap * 8));
+                MXG_HIP(h, sc(SC_CAND_K).ensure((size_t)n_cap * 4));
+                MXG_HIP(h, sc(SC_CAND_C).ensure((size_t)n_cap * 4));
+                MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, 32, h->stream));
                 SparseParams sp;
                 sp.packed = a->d_packed;
                 sp.runs = T.d_runs;
@@ -1000,50 +1030,58 @@ struct Driver {
                 sp.strip_lo = strip_lo;
                 sp.strip_hi = strip_hi;
                 sp.k = h->cfg.k;
-                sp.S = a->S_sparse;
+                sp.S = S;
                 sp.tau_hi = tau_hi;
                 sp.arena = sc(SC_ARENA).as<uint4>();
-                sp.arena_cap = arena_cap;
+                sp.wave_cap = (uint32_t)wave_cap;
+                sp.wave_cnt = sc(SC_WAVE_CNT).as<uint32_t>();
                 sp.ctrl = sc(SC_CTRL).as<uint32_t>();
                 sp.strip_cnt = sc(SC_STRIP_CNT).as<uint32_t>();
                 sp.strip_meta = sc(SC_STRIP_META).as<uint2>();
                 sp.tab = h->tab;
                 int rc = ev_begin(batch_bases(T, c0, c1), true);
                 if (rc != MXG_OK) return rc;
-                dim3 grid((n_strips + 255) / 256), block(256);
+                dim3 grid(n_blocks), block(256);
+                static const int abl = getenv("MXG_ABLATE") ? atoi(getenv("MXG_ABLATE")) : 0;  // profiling only
                 if (h->cfg.variant == MXG_VARIANT_V1_MIN)
                     hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V1_MIN>), grid, block, 0, h->stream, sp);
+                else if (abl == 1)
+                    hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 1>), grid, block, 0, h->stream, sp);
+                else if (abl == 2)
+                    hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 2>), grid, block, 0, h->stream, sp);
+                else if (abl == 4)
+                    hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 4>), grid, block, 0, h->stream, sp);
                 else
                     hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), grid, block, 0, h->stream, sp);
                 if ((rc = ev_end()) != MXG_OK) return rc;
                 MXG_HIP(h, hipGetLastError());
-                // order the candidates: exclusive scan of per-strip counts, then scatter
+                // order the candidates: exclusive scan of per-strip counts (total = number of candidates), then scatter
                 if ((rc = ev_begin(0, false)) != MXG_OK) return rc;
                 hipLaunchKernelGGL(k_tile_sum_u32, dim3(s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, n_strips,
                                    sc(SC_SBSUM).as<uint32_t>());
                 hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, sc(SC_SBSUM).as<uint32_t>(), s_tiles,
-                                   reinterpret_cast<uint64_t *>(sp.ctrl + 2));
+                                   reinterpret_cast<uint64_t *>(sp.ctrl + 4));
                 hipLaunchKernelGGL(k_tile_excl_u32, dim3(s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, n_strips,
                                    sc(SC_SBSUM).as<uint32_t>(), sc(SC_STRIP_PREF).as<uint32_t>());
-                hipLaunchKernelGGL(k_reorder, dim3((arena_cap + 255) / 256), dim3(256), 0, h->stream, sp.arena, sp.ctrl,
-                                   arena_cap, sc(SC_STRIP_PREF).as<uint32_t>(), sp.strip_meta,
+                hipLaunchKernelGGL(k_reorder, dim3((n_cap + 255) / 256), dim3(256), 0, h->stream, sp.arena, sp.wave_cnt,
+                                   sp.wave_cap, n_waves, sc(SC_STRIP_PREF).as<uint32_t>(), sp.strip_meta,
                                    sc(SC_CAND_H).as<uint64_t>(), sc(SC_CAND_K).as<uint32_t>(),
                                    sc(SC_CAND_C).as<uint32_t>());
                 MXG_HIP(h, hipGetLastError());
-                if ((rc = resolve_and_count<true>(T, arena_cap, (uint32_t)c0, (uint32_t)c1)) != MXG_OK) return rc;
+                if ((rc = resolve_and_count<true>(T, n_cap, (uint32_t)c0, (uint32_t)c1)) != MXG_OK) return rc;
                 // speculative emit straight into the output arrays (guarded by their capacity): on the common
                 // path (no gap, no overflow) the batch then needs a single host sync
-                if ((rc = emit(T, arena_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
+                if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
                 if ((rc = ev_end()) != MXG_OK) return rc;
-                MXG_HIP(h, hipMemcpyAsync(ctrl, sc(SC_CTRL).p, 16, hipMemcpyDeviceToHost, h->stream));
+                MXG_HIP(h, hipMemcpyAsync(ctrl, sc(SC_CTRL).p, 32, hipMemcpyDeviceToHost, h->stream));
                 MXG_HIP(h, hipStreamSynchronize(h->stream));
-                if (ctrl[0] <= arena_cap) break;
+                if (ctrl[0] == 0) break;  // no wave overflowed its slice
                 if (attempt >= 2) return set_err(h, MXG_EDEVICE, "internal error: candidate arena keeps overflowing");
-                want = (uint64_t)ctrl[0] + ctrl[0] / 8 + 65536;  // exact need is known now: redo the batch
-                h->arena_cap_hint = want;
+                wave_cap = std::min<uint64_t>((uint64_t)ctrl[0] + 64, 64ull * S);  // exact need is known: redo the batch
+                h->arena_cap_hint = wave_cap;
             }
-            const uint32_t n_cand = ctrl[0];
-            const uint32_t arena_cap = (uint32_t)want;
+            const uint32_t n_cap = (uint32_t)n_cap64;
+            const uint64_t n_cand = (uint64_t)ctrl[4] | ((uint64_t)ctrl[5] << 32);
             uint32_t n_gaps = ctrl[1];
             const uint64_t total = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
             h->stat_candidates += n_cand;
@@ -1053,7 +1091,6 @@ struct Driver {
                 for (size_t c = c0; c < c1; ++c) gaps.push_back(make_uint4((uint32_t)c, 0, (*T.ctg_nk)[c] - 1, 0));
                 n_gaps = (uint32_t)gaps.size();
             } else if (n_gaps > GAP_CAP) {
-                // pathological input: fall back to the dense path for the whole batch
                 return set_err(h, MXG_ELIMIT, "more than %u candidate-free stretches in one batch; rerun with MXG_FLAG_DENSE_ONLY", GAP_CAP);
             } else if (n_gaps) {
                 gaps.resize(n_gaps);
@@ -1063,7 +1100,7 @@ struct Driver {
             if (n_gaps == 0) {
                 if (out.n + total > out.cap()) {  // the speculative emit did not fit: grow, emit again
                     if ((rc = out_reserve(h, out, out.n + total)) != MXG_OK) return rc;
-                    if ((rc = emit(T, arena_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
+                    if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
                 }
                 out.n += total;
             } else {
@@ -1072,7 +1109,7 @@ struct Driver {
                 MXG_HIP(h, sc(SC_ST_POS).ensure(std::max<uint64_t>(total * 4, 16)));
                 MXG_HIP(h, sc(SC_ST_REC).ensure(std::max<uint64_t>(total * 4, 16)));
                 MXG_HIP(h, sc(SC_ST_FWD).ensure(std::max<uint64_t>(total, 16)));
-                if ((rc = emit(T, arena_cap, sc(SC_ST_HASH), sc(SC_ST_POS), sc(SC_ST_REC), sc(SC_ST_FWD), 0)) != MXG_OK) return rc;
+                if ((rc = emit(a->d_packed, T, n_cap, sc(SC_ST_HASH), sc(SC_ST_POS), sc(SC_ST_REC), sc(SC_ST_FWD), 0)) != MXG_OK) return rc;
                 uint64_t n_gap_mx = 0;
                 if ((rc = process_gaps(a, T, gaps, &n_gap_mx)) != MXG_OK) return rc;
                 if (total + n_gap_mx >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "batch sketch too large to merge");
