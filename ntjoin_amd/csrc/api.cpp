@@ -192,6 +192,7 @@ static int adopt_host_sketch(mxg_handle *h, Assembly *a, const std::vector<uint6
     a->h_fwd.assign(n, 1);
     build_rec_first(a);
     a->host_valid = true;
+    a->fwd_valid = true;
     a->has_sketch = true;
     return MXG_OK;
 }
@@ -320,6 +321,8 @@ int mxg_get_sketch_device(mxg_handle *h, int assembly, mxg_sketch_dview *out)
     Assembly *a = get_asm(h, assembly);
     if (!a || !out) return MXG_EINVAL;
     if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch yet", a->name.c_str());
+    int rc = ensure_strand(h, a);
+    if (rc != MXG_OK) return rc;
     out->n = a->n_mx;
     out->out_hash = a->d_hash.p;
     out->pos = a->d_pos.p;
@@ -355,6 +358,7 @@ int mxg_set_sketch_device(mxg_handle *h, int assembly, const void *d_out_hash, c
     std::swap(a->d_fwd.p, nf.p);  std::swap(a->d_fwd.bytes, nf.bytes);
     a->n_mx = n;
     a->has_sketch = true;
+    a->fwd_valid = true;
     a->host_valid = false;
     a->flags_valid = false;
     h->graph.valid = false;

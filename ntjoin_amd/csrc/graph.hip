@@ -272,7 +272,7 @@ int build_graph(mxg_handle *h)
             hipLaunchKernelGGL(k_count, dim3(n_tiles), dim3(256), 0, h->stream, as->d_shared.as<uint8_t>(), n,
                                as->d_bs.as<uint32_t>());
         }
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, as->d_bs.as<uint32_t>(), n_tiles, ctl + a);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, h->stream, as->d_bs.as<uint32_t>(), n_tiles, ctl + a);
         as->flags_valid = true;
     }
     MXG_HIP(h, hipGetLastError());
@@ -350,7 +350,7 @@ int build_graph(mxg_handle *h)
         hipLaunchKernelGGL(k_edge_flags, dim3((n_items + 255) / 256), dim3(256), 0, h->stream, ep);
         hipLaunchKernelGGL(k_count, dim3(e_tiles), dim3(256), 0, h->stream, h->g_eflag.as<uint8_t>(), n_items,
                            h->g_ebs.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, h->g_ebs.as<uint32_t>(), e_tiles,
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, h->stream, h->g_ebs.as<uint32_t>(), e_tiles,
                            ctl + CTL_EDGES);
         hipLaunchKernelGGL(k_edges, dim3(e_tiles), dim3(256), 0, h->stream, ep, n_items);
         MXG_HIP(h, hipGetLastError());

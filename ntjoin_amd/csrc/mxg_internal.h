@@ -98,7 +98,8 @@ struct Assembly {
     // sketch (device, ordered by (record,pos)) + lazily filled host mirror
     bool has_sketch = false;
     uint64_t n_mx = 0;
-    DevBuf d_hash, d_pos, d_rec, d_fwd;
+    DevBuf d_hash, d_pos, d_rec, d_fwd, d_rec_base;
+    bool fwd_valid = false;  // d_fwd filled (lazily: k_strand)
     bool host_valid = false;
     std::vector<uint64_t> h_hash;
     std::vector<uint32_t> h_pos, h_rec;
@@ -177,6 +178,7 @@ void make_hash_tab(uint32_t k, HashTab *t);
 // sketch.hip
 int sketch_assembly(mxg_handle *h, Assembly *a);
 int sync_sketch_to_host(mxg_handle *h, Assembly *a);
+int ensure_strand(mxg_handle *h, Assembly *a);
 // graph.hip
 int build_graph(mxg_handle *h);
 int graph_to_host(mxg_handle *h);

@@ -26,34 +26,6 @@ static __global__ __launch_bounds__(256) void k_count(const uint8_t *__restrict_
     if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
 }
 
-// exclusive scan of bsum[0..n) in place by ONE block; total -> *total
-static __global__ __launch_bounds__(1024) void k_scan_sums(uint32_t *__restrict__ bsum, uint32_t n, uint64_t *__restrict__ total)
-{
-    __shared__ uint32_t sh[1024];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < n ? bsum[i] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            uint32_t t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        uint32_t carry = carry_s;
-        if (i < n) bsum[i] = carry + sh[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + sh[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = carry_s;
-}
-
-
 // inside a 256-thread block: exclusive prefix of per-thread counts `c` (uses sh[256]); all threads must call
 __device__ __forceinline__ uint32_t block_exclusive_256(uint32_t c, uint32_t *sh)
 {
@@ -66,6 +38,33 @@ __device__ __forceinline__ uint32_t block_exclusive_256(uint32_t c, uint32_t *sh
         __syncthreads();
     }
     return sh[threadIdx.x] - c;
+}
+
+// exclusive scan of bsum[0..n) in place by ONE 256-thread block (16 elements per thread per pass); total -> *total
+static __global__ __launch_bounds__(256) void k_scan_sums(uint32_t *__restrict__ bsum, uint32_t n, uint64_t *__restrict__ total)
+{
+    __shared__ uint32_t sh[256];
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 4096) {
+        const uint32_t i0 = base + threadIdx.x * 16u;
+        uint32_t v[16];
+        uint32_t c = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            v[u] = i0 + u < n ? bsum[i0 + u] : 0;
+            c += v[u];
+        }
+        uint32_t run = (uint32_t)carry + block_exclusive_256(c, sh);
+        const uint32_t tile_total = sh[255];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (i0 + u < n) bsum[i0 + u] = run;
+            run += v[u];
+        }
+        carry += tile_total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
 }
 
 // ---- u32 array exclusive scan (tile sums -> k_scan_sums -> downsweep) -------------------------------

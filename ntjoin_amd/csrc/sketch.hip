@@ -415,17 +415,18 @@ __device__ __forceinline__ bool coop_right_blocked(const CoopCtx &q, uint32_t la
 }
 
 constexpr int RH = 128;  // halo (candidates) staged on each side of a block's 256 candidates
+constexpr int RP = 4;    // padding entries so that 4-wide neighbour groups never index outside the arrays
 
 template <bool GAPS>
 __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
 {
-    __shared__ uint64_t lh[256 + 2 * RH];
-    __shared__ uint2 lkc[256 + 2 * RH];  // {k-mer index, contig (strand bit cleared); contig = ~0 outside the array}
+    __shared__ uint64_t lh[256 + 2 * RH + 2 * RP];
+    __shared__ uint2 lkc[256 + 2 * RH + 2 * RP];  // {k-mer index, contig}; contig = ~0 outside the candidate array
     const uint32_t n = min(*p.n_ptr, p.n_cap);
     const uint32_t i0 = blockIdx.x * 256u;
     if (i0 >= n) return;
-    for (uint32_t e = threadIdx.x; e < 256 + 2 * RH; e += 256) {
-        const int64_t g = (int64_t)i0 - RH + e;
+    for (uint32_t e = threadIdx.x; e < 256 + 2 * RH + 2 * RP; e += 256) {
+        const int64_t g = (int64_t)i0 - RH - RP + e;
         if (g >= 0 && g < (int64_t)n) {
             lh[e] = p.ch[g];
             lkc[e] = make_uint2(p.ck[g], p.cc[g] & 0x7FFFFFFFu);
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
     const uint32_t i = i0 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const bool live = i < n;
-    const uint32_t li = RH + threadIdx.x;
+    const uint32_t li = RH + RP + threadIdx.x;
     const uint64_t h = lh[li];
     const uint32_t kx = lkc[li].x;
     const uint32_t c = live ? lkc[li].y : 0u;
@@ -446,16 +447,24 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
     const uint32_t w = p.w, wm1 = w - 1;
     CoopCtx q{p.ch, p.ck, p.cc, n, wm1};
 
+    // The per-lane scans look at 4 neighbours per iteration with predicated selects: the loop control of a
+    // one-neighbour-per-iteration divergent loop (exec-mask bookkeeping, ~535 SALU per wave) dominated this kernel.
     // ---- left: nearest strictly smaller (ties: rightmost wins) ----
     uint32_t L = min(kx, wm1);
     bool ldone = !live;
     if (live) {
-        for (uint32_t t = 1; t <= (uint32_t)RH; ++t) {
-            const uint2 kc = lkc[li - t];
-            if (kc.y != c) { ldone = true; break; }
-            const uint32_t d = kx - kc.x;
-            if (d > wm1) { ldone = true; break; }
-            if (lh[li - t] < h) { L = d - 1; ldone = true; break; }
+        for (uint32_t t = 1; t <= (uint32_t)RH; t += 4) {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint2 kc = lkc[li - t - u];
+                const uint64_t hn = lh[li - t - u];
+                const uint32_t d = kx - kc.x;
+                const bool stop = (kc.y != c) || (d > wm1);
+                const bool hit = !stop && (hn < h);
+                L = (!ldone && hit) ? d - 1 : L;
+                ldone = ldone || stop || hit;
+            }
+            if (ldone) break;
         }
     }
     for (uint64_t todo = __ballot(!ldone); todo; todo &= todo - 1) {
@@ -474,12 +483,18 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
     const uint32_t need = wm1 - min(L, wm1);  // need R >= need
     bool rdone = !(s && need > 0);
     if (!rdone) {
-        for (uint32_t t = 1; t <= (uint32_t)RH; ++t) {
-            const uint2 kc = lkc[li + t];
-            if (kc.y != c) { rdone = true; break; }
-            const uint32_t d = kc.x - kx;
-            if (d > need) { rdone = true; break; }
-            if (lh[li + t] <= h) { s = false; rdone = true; break; }
+        for (uint32_t t = 1; t <= (uint32_t)RH; t += 4) {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint2 kc = lkc[li + t + u];
+                const uint64_t hn = lh[li + t + u];
+                const uint32_t d = kc.x - kx;
+                const bool stop = (kc.y != c) || (d > need);
+                const bool hit = !stop && (hn <= h);
+                s = (!rdone && hit) ? false : s;
+                rdone = rdone || stop || hit;
+            }
+            if (rdone) break;
         }
     }
     for (uint64_t todo = __ballot(!rdone); todo; todo &= todo - 1) {
@@ -545,9 +560,6 @@ struct EmitParams {
     const Run *runs;
     const uint32_t *ctg_run0, *ctg_rec;
     uint64_t mult;         // 1 ^ (k * MULTISEED)
-    const uint32_t *packed; // the strand bit is recomputed here from the bases (k steps, only for minimizers)
-    uint32_t k;
-    HashTab tab;
     uint64_t out_base;     // where this batch starts in the output arrays
     uint64_t out_limit;    // capacity of the output arrays (entries at or beyond it are dropped: speculative emit)
     uint64_t *o_hash;
@@ -558,8 +570,6 @@ struct EmitParams {
 __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
 {
     __shared__ uint32_t sh[256];
-    __shared__ uint4 tab[20];
-    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
     const uint32_t n = min(*p.n_ptr, p.n_cap);
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
     uint32_t c = 0;
@@ -577,18 +587,30 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
                 uint32_t mid = (lo + hi) >> 1;
                 if (p.runs[mid].kidx0 <= kx) lo = mid; else hi = mid;
             }
-            if (o < p.out_limit) {
-                const uint32_t off = kx - p.runs[lo].kidx0;
-                H2 hh = {0u, 0u, 0u, 0u};
-                warm_up(hh, p.packed, p.runs[lo].base_off + off, p.k, tab);  // forward = fwd_hash <= rev_hash
+            if (o < p.out_limit) {  // (the strand byte is filled lazily by k_strand, only when somebody asks for it)
                 p.o_hash[o] = ext_hash(p.ch[i], p.mult);
-                p.o_pos[o] = p.runs[lo].pos0 + off;
+                p.o_pos[o] = p.runs[lo].pos0 + (kx - p.runs[lo].kidx0);
                 p.o_rec[o] = p.ctg_rec[ctg];
-                p.o_fwd[o] = is_forward(hh) ? 1 : 0;
             }
             ++o;
         }
     }
+}
+
+// forward[i] = (forward hash <= reverse-complement hash) of minimizer i's k-mer, recomputed from the bases with the
+// k-step direct formula.  Only `--strand` output and host/device sketch views need it, so it runs on demand.
+__global__ __launch_bounds__(256) void k_strand(const uint32_t *__restrict__ packed, const uint64_t *__restrict__ rec_base,
+                                                const uint32_t *__restrict__ pos, const uint32_t *__restrict__ rec,
+                                                uint64_t n, uint32_t k, const HashTab t, uint8_t *__restrict__ fwd)
+{
+    __shared__ uint4 tab[20];
+    if (threadIdx.x < 20) tab[threadIdx.x] = t.e[threadIdx.x];
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    H2 h = {0u, 0u, 0u, 0u};
+    warm_up(h, packed, rec_base[rec[i]] + pos[i], k, tab);
+    fwd[i] = is_forward(h) ? 1 : 0;
 }
 
 // merge two (record,pos)-sorted sketches A (nA) and B (nB) with disjoint keys into O
@@ -810,7 +832,7 @@ struct Driver {
             hipLaunchKernelGGL(k_count_n, dim3(n_tiles), dim3(256), 0, h->stream, rp.sel, rp.n_ptr, n_cap,
                                sc(SC_BSUM).as<uint32_t>());
         }
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, sc(SC_BSUM).as<uint32_t>(), n_tiles,
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, h->stream, sc(SC_BSUM).as<uint32_t>(), n_tiles,
                            reinterpret_cast<uint64_t *>(ctrl + 2));
         MXG_HIP(h, hipGetLastError());
         return MXG_OK;
@@ -833,9 +855,7 @@ struct Driver {
         ep.ctg_run0 = T.d_ctg_run0;
         ep.ctg_rec = T.d_ctg_rec;
         ep.mult = 1ull ^ ((uint64_t)h->cfg.k * 0x90b45d39fb6da1faull);
-        ep.packed = d_packed;
-        ep.k = h->cfg.k;
-        ep.tab = h->tab;
+        (void)d_packed;
         ep.out_base = out_base;
         ep.out_limit = limit;
         ep.o_hash = oh.as<uint64_t>();
@@ -1059,7 +1079,7 @@ struct Driver {
                 if ((rc = ev_begin(0, false)) != MXG_OK) return rc;
                 hipLaunchKernelGGL(k_tile_sum_u32, dim3(s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, n_strips,
                                    sc(SC_SBSUM).as<uint32_t>());
-                hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, sc(SC_SBSUM).as<uint32_t>(), s_tiles,
+                hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, h->stream, sc(SC_SBSUM).as<uint32_t>(), s_tiles,
                                    reinterpret_cast<uint64_t *>(sp.ctrl + 4));
                 hipLaunchKernelGGL(k_tile_excl_u32, dim3(s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, n_strips,
                                    sc(SC_SBSUM).as<uint32_t>(), sc(SC_STRIP_PREF).as<uint32_t>());
@@ -1169,6 +1189,7 @@ int sketch_assembly(mxg_handle *h, Assembly *a)
     const uint32_t w = h->cfg.w;
     a->has_sketch = false;
     a->host_valid = false;
+    a->fwd_valid = false;
     a->flags_valid = false;
     h->graph.valid = false;
     a->n_mx = 0;
@@ -1232,10 +1253,37 @@ int sketch_assembly(mxg_handle *h, Assembly *a)
     return MXG_OK;
 }
 
+int ensure_strand(mxg_handle *h, Assembly *a)
+{
+    if (a->fwd_valid || !a->has_sketch) return MXG_OK;
+    MXG_HIP(h, hipSetDevice(h->device));
+    MXG_HIP(h, a->d_fwd.ensure(std::max<uint64_t>(a->n_mx, 16)));
+    if (a->has_bases && a->d_packed && a->n_mx) {
+        if (!a->d_rec_base.p) {
+            std::vector<uint64_t> rb(a->recs.size());
+            for (size_t r = 0; r < rb.size(); ++r) rb[r] = a->recs[r].base_off;
+            int rc = upload(h, a->d_rec_base, rb);
+            if (rc != MXG_OK) return rc;
+            MXG_HIP(h, hipStreamSynchronize(h->stream));
+        }
+        hipLaunchKernelGGL(k_strand, dim3((uint32_t)((a->n_mx + 255) / 256)), dim3(256), 0, h->stream, a->d_packed,
+                           a->d_rec_base.as<uint64_t>(), a->d_pos.as<uint32_t>(), a->d_rec.as<uint32_t>(), a->n_mx,
+                           h->cfg.k, h->tab, a->d_fwd.as<uint8_t>());
+        MXG_HIP(h, hipGetLastError());
+    } else if (a->n_mx) {  // a sketch imported without bases and without strands: reported as forward
+        MXG_HIP(h, hipMemsetAsync(a->d_fwd.p, 1, a->n_mx, h->stream));
+    }
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    a->fwd_valid = true;
+    return MXG_OK;
+}
+
 int sync_sketch_to_host(mxg_handle *h, Assembly *a)
 {
     if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch yet (call mxg_sketch)", a->name.c_str());
     if (a->host_valid) return MXG_OK;
+    int rcs = ensure_strand(h, a);
+    if (rcs != MXG_OK) return rcs;
     MXG_HIP(h, hipSetDevice(h->device));
     a->h_hash.resize(a->n_mx);
     a->h_pos.resize(a->n_mx);
