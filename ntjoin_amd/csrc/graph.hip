@@ -22,15 +22,22 @@ namespace mxg {
 static constexpr uint64_t HT_EMPTY = 0xFFFFFFFFFFFFFFFFull;
 static constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 
-__device__ __forceinline__ uint32_t ht_slot(unsigned long long *keys, uint32_t mask, uint32_t cap, uint64_t key)
+// One table slot (16 B): {key, ~seen mask, ~dup mask}.  The masks are stored INVERTED so that a single 0xFF fill
+// initialises a slot completely (key = empty sentinel, nothing seen, nothing duplicated).
+struct Slot {
+    unsigned long long key;
+    uint32_t nseen, ndup;
+};
+
+__device__ __forceinline__ uint32_t ht_slot(Slot *tab, uint32_t mask, uint32_t cap, uint64_t key)
 {
     if (key == HT_EMPTY) return cap;  // the sentinel value itself lives in the extra slot [cap]
     uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & mask;
     while (true) {
-        unsigned long long cur = keys[s];
+        unsigned long long cur = tab[s].key;
         if (cur == key) return s;
         if (cur == HT_EMPTY) {
-            unsigned long long old = atomicCAS(&keys[s], (unsigned long long)HT_EMPTY, (unsigned long long)key);
+            unsigned long long old = atomicCAS(&tab[s].key, (unsigned long long)HT_EMPTY, (unsigned long long)key);
             if (old == HT_EMPTY || old == key) return s;
         }
         s = (s + 1) & mask;
@@ -38,29 +45,27 @@ __device__ __forceinline__ uint32_t ht_slot(unsigned long long *keys, uint32_t m
 }
 
 // insert every minimizer of one assembly; remember its slot
-__global__ __launch_bounds__(256) void k_insert(const uint64_t *__restrict__ hash, uint32_t n, uint32_t bit,
-                                                unsigned long long *keys, uint32_t mask, uint32_t cap,
-                                                uint32_t *seen, uint32_t *dup, uint32_t *__restrict__ slot_out)
+__global__ __launch_bounds__(256) void k_insert(const uint64_t *__restrict__ hash, uint32_t n, uint32_t bit, Slot *tab,
+                                                uint32_t mask, uint32_t cap, uint32_t *__restrict__ slot_out)
 {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    uint32_t s = ht_slot(keys, mask, cap, hash[i]);
-    uint32_t old = atomicOr(&seen[s], bit);
-    if (old & bit) atomicOr(&dup[s], bit);
+    uint32_t s = ht_slot(tab, mask, cap, hash[i]);
+    uint32_t old = atomicAnd(&tab[s].nseen, ~bit);
+    if (!(old & bit)) atomicAnd(&tab[s].ndup, ~bit);  // bit already cleared: second occurrence in this assembly
     slot_out[i] = s;
 }
 
 __global__ __launch_bounds__(256) void k_flags(const uint32_t *__restrict__ slot, uint32_t n, uint32_t bit,
-                                               uint32_t full, const uint32_t *__restrict__ seen,
-                                               const uint32_t *__restrict__ dup, uint8_t *__restrict__ flags,
+                                               uint32_t full, const Slot *__restrict__ tab, uint8_t *__restrict__ flags,
                                                uint8_t *__restrict__ shared)
 {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    uint32_t s = slot[i];
-    uint32_t d = dup[s];
+    const Slot sl = tab[slot[i]];
+    const uint32_t seen = ~sl.nseen & full, d = ~sl.ndup & full;
     bool uniq = !(d & bit);
-    bool inall = seen[s] == full;
+    bool inall = seen == full;
     bool sh = inall && d == 0;
     flags[i] = (uint8_t)((uniq ? MXG_MX_UNIQUE : 0) | (sh ? MXG_MX_SHARED : 0) | (inall ? MXG_MX_INALL : 0));
     shared[i] = sh ? 1 : 0;
@@ -236,14 +241,10 @@ int build_graph(mxg_handle *h)
     const uint32_t mask = cap - 1;
     const uint32_t full = (A == 32) ? 0xFFFFFFFFu : ((1u << A) - 1u);
 
-    MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * 8));
-    MXG_HIP(h, h->g_seen.ensure(((size_t)cap + 1) * 4));
-    MXG_HIP(h, h->g_dup.ensure(((size_t)cap + 1) * 4));
+    MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * sizeof(Slot)));
     MXG_HIP(h, h->g_vid.ensure(((size_t)cap + 1) * 4));
     MXG_HIP(h, h->g_ctl.ensure(CTL_WORDS * 8));
-    MXG_HIP(h, hipMemsetAsync(h->g_keys.p, 0xFF, ((size_t)cap + 1) * 8, h->stream));
-    MXG_HIP(h, hipMemsetAsync(h->g_seen.p, 0, ((size_t)cap + 1) * 4, h->stream));
-    MXG_HIP(h, hipMemsetAsync(h->g_dup.p, 0, ((size_t)cap + 1) * 4, h->stream));
+    MXG_HIP(h, hipMemsetAsync(h->g_keys.p, 0xFF, ((size_t)cap + 1) * sizeof(Slot), h->stream));  // one fill: see Slot
     MXG_HIP(h, hipMemsetAsync(h->g_ctl.p, 0, CTL_WORDS * 8, h->stream));
     uint64_t *ctl = h->g_ctl.as<uint64_t>();
 
@@ -253,9 +254,8 @@ int build_graph(mxg_handle *h)
         MXG_HIP(h, as->d_flags.ensure(std::max<uint64_t>(as->n_mx, 16)));
         if (as->n_mx)
             hipLaunchKernelGGL(k_insert, dim3((uint32_t)((as->n_mx + 255) / 256)), dim3(256), 0, h->stream,
-                               as->d_hash.as<uint64_t>(), (uint32_t)as->n_mx, 1u << a,
-                               h->g_keys.as<unsigned long long>(), mask, cap, h->g_seen.as<uint32_t>(),
-                               h->g_dup.as<uint32_t>(), as->d_slot.as<uint32_t>());
+                               as->d_hash.as<uint64_t>(), (uint32_t)as->n_mx, 1u << a, h->g_keys.as<Slot>(), mask, cap,
+                               as->d_slot.as<uint32_t>());
     }
     MXG_HIP(h, hipGetLastError());
     // flags + number of shared minimizers per assembly (equal across assemblies by construction)
@@ -267,8 +267,7 @@ int build_graph(mxg_handle *h)
         MXG_HIP(h, as->d_bs.ensure((size_t)n_tiles * 4 + 16));
         if (n) {
             hipLaunchKernelGGL(k_flags, dim3((n + 255) / 256), dim3(256), 0, h->stream, as->d_slot.as<uint32_t>(), n,
-                               1u << a, full, h->g_seen.as<uint32_t>(), h->g_dup.as<uint32_t>(), as->d_flags.as<uint8_t>(),
-                               as->d_shared.as<uint8_t>());
+                               1u << a, full, h->g_keys.as<Slot>(), as->d_flags.as<uint8_t>(), as->d_shared.as<uint8_t>());
             hipLaunchKernelGGL(k_count, dim3(n_tiles), dim3(256), 0, h->stream, as->d_shared.as<uint8_t>(), n,
                                as->d_bs.as<uint32_t>());
         }
@@ -296,10 +295,9 @@ int build_graph(mxg_handle *h)
         MXG_HIP(h, h->g_vrec.ensure(anv * 4));
         MXG_HIP(h, h->g_fv.ensure(anv * 4));
         MXG_HIP(h, h->g_frec.ensure(anv * 4));
-        MXG_HIP(h, h->g_nxt.ensure(anv * 4));
-        MXG_HIP(h, h->g_prv.ensure(anv * 4));
-        MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, anv * 4, h->stream));
-        MXG_HIP(h, hipMemsetAsync(h->g_prv.p, 0xFF, anv * 4, h->stream));
+        MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4));  // nxt[A][nv] followed by prv[A][nv]: one fill
+        MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));
+        uint32_t *const d_prv = h->g_nxt.as<uint32_t>() + anv;
         for (uint32_t a = 0; a < A; ++a) {
             Assembly *as = h->asms[a];
             const uint32_t n = (uint32_t)as->n_mx;
@@ -321,8 +319,7 @@ int build_graph(mxg_handle *h)
             hipLaunchKernelGGL(k_vertices, dim3((n + TILE - 1) / TILE), dim3(256), 0, h->stream, vp);
             hipLaunchKernelGGL(k_adjacency, dim3((uint32_t)((nv + 255) / 256)), dim3(256), 0, h->stream,
                                h->g_fv.as<uint32_t>() + (size_t)a * nv, h->g_frec.as<uint32_t>() + (size_t)a * nv,
-                               (uint32_t)nv, h->g_nxt.as<uint32_t>() + (size_t)a * nv,
-                               h->g_prv.as<uint32_t>() + (size_t)a * nv);
+                               (uint32_t)nv, h->g_nxt.as<uint32_t>() + (size_t)a * nv, d_prv + (size_t)a * nv);
         }
         MXG_HIP(h, hipGetLastError());
         const uint32_t n_items = (uint32_t)anv;
@@ -337,7 +334,7 @@ int build_graph(mxg_handle *h)
         EdgeParams ep;
         ep.fv = h->g_fv.as<uint32_t>();
         ep.nxt = h->g_nxt.as<uint32_t>();
-        ep.prv = h->g_prv.as<uint32_t>();
+        ep.prv = d_prv;
         ep.nv = (uint32_t)nv;
         ep.n_asm = A;
         ep.eflag = h->g_eflag.as<uint8_t>();

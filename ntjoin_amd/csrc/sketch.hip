@@ -309,22 +309,24 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     }
 }
 
-// arena entry -> ordered candidate slot: one thread per (wave, slot)
+// arena entry -> ordered candidate slot: one block per wave slice
 __global__ __launch_bounds__(256) void k_reorder(const uint4 *__restrict__ arena, const uint32_t *__restrict__ wave_cnt,
-                                                 uint32_t wave_cap, uint32_t n_waves, const uint32_t *__restrict__ strip_pref,
+                                                 uint32_t wave_cap, const uint32_t *__restrict__ strip_pref,
                                                  const uint2 *__restrict__ strip_meta, uint64_t *__restrict__ ch,
                                                  uint32_t *__restrict__ ck, uint32_t *__restrict__ cc)
 {
-    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    const uint32_t wv = (uint32_t)(t / wave_cap), i = (uint32_t)(t % wave_cap);
-    if (wv >= n_waves || i >= min(wave_cnt[wv], wave_cap)) return;
-    const uint4 a = arena[t];
-    const uint32_t j = a.w & 1023u, seq = a.w >> 10;
-    const uint32_t dst = strip_pref[a.z] + seq;
-    const uint2 sm = strip_meta[a.z];
-    ch[dst] = ((uint64_t)a.y << 32) | a.x;
-    ck[dst] = sm.y + j;
-    cc[dst] = sm.x;
+    const uint32_t wv = blockIdx.x;
+    const uint32_t cnt = min(wave_cnt[wv], wave_cap);
+    const uint4 *src = arena + (size_t)wv * wave_cap;
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+        const uint4 a = src[i];
+        const uint32_t j = a.w & 1023u, seq = a.w >> 10;
+        const uint32_t dst = strip_pref[a.z] + seq;
+        const uint2 sm = strip_meta[a.z];
+        ch[dst] = ((uint64_t)a.y << 32) | a.x;
+        ck[dst] = sm.y + j;
+        cc[dst] = sm.x;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1083,8 +1085,8 @@ struct Driver {
                                    reinterpret_cast<uint64_t *>(sp.ctrl + 4));
                 hipLaunchKernelGGL(k_tile_excl_u32, dim3(s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, n_strips,
                                    sc(SC_SBSUM).as<uint32_t>(), sc(SC_STRIP_PREF).as<uint32_t>());
-                hipLaunchKernelGGL(k_reorder, dim3((n_cap + 255) / 256), dim3(256), 0, h->stream, sp.arena, sp.wave_cnt,
-                                   sp.wave_cap, n_waves, sc(SC_STRIP_PREF).as<uint32_t>(), sp.strip_meta,
+                hipLaunchKernelGGL(k_reorder, dim3(n_waves), dim3(256), 0, h->stream, sp.arena, sp.wave_cnt,
+                                   sp.wave_cap, sc(SC_STRIP_PREF).as<uint32_t>(), sp.strip_meta,
                                    sc(SC_CAND_H).as<uint64_t>(), sc(SC_CAND_K).as<uint32_t>(),
                                    sc(SC_CAND_C).as<uint32_t>());
                 MXG_HIP(h, hipGetLastError());
