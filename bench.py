@@ -184,10 +184,19 @@ def main():
             # same inputs -> same counts (full bit-exact parity lives in tests/)
             out["parity_counts_match_cpu"] = bool(cb["minimizers"] == st["minimizers"] and
                                                   cb["vertices"] == st["vertices"] and cb["edges"] == st["edges"])
-        print(json.dumps(out), flush=True)
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes its banner through C stdio, which is flushed at exit: flush it first so that the JSON line is
+    # the LAST line on stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if result_line is not None:
+        print(result_line, flush=True)
+
 
 
 if __name__ == "__main__":

@@ -162,11 +162,21 @@ double mxg_assembly_weight(const mxg_handle *h, int assembly);
 /* ---- sketch stage (replaces indexlr) --------------------------------------------------------- */
 int mxg_sketch(mxg_handle *h, int assembly /* -1 = every assembly that has bases and no sketch yet */);
 int mxg_get_sketch(mxg_handle *h, int assembly, mxg_sketch_view *out);
+/* (forward is NULL until the strands have been computed: mxg_get_sketch, mxg_write_tsv or mxg_compute_strands) */
 int mxg_get_sketch_device(mxg_handle *h, int assembly, mxg_sketch_dview *out);
+int mxg_compute_strands(mxg_handle *h, int assembly);
 /* Replace an assembly's sketch by device arrays (e.g. the concatenation an all-gather produced);
    entries must be sorted by (record, pos).  The arrays are copied. */
 int mxg_set_sketch_device(mxg_handle *h, int assembly, const void *d_out_hash, const void *d_pos,
                           const void *d_record, const void *d_forward, uint64_t n);
+/* Exchange step of the multi-GPU path (one all-gather per assembly).  Every rank packs its sketch into
+   one byte buffer of 16*nmax bytes laid out [out_hash u64 x nmax | pos u32 x nmax | record u32 x nmax] (nmax >= n,
+   a multiple of 8), the caller all-gathers the buffers (RCCL), and mxg_set_sketch_gathered unpacks the `world`
+   buffers in rank order -- counts[r] minimizers from rank r, record indices shifted by rec_offsets[r] -- straight into
+   the assembly's sketch.  Strands do not travel (they are recomputed from bases on demand, or reported as '+'). */
+int mxg_pack_sketch_device(mxg_handle *h, int assembly, void *d_buf, uint64_t nmax);
+int mxg_set_sketch_gathered(mxg_handle *h, int assembly, const void *d_allbuf, uint32_t world, uint64_t nmax,
+                            const uint64_t *counts, const uint64_t *rec_offsets);
 /* indexlr TSV: `id \t out_hash[:pos][:+|-][:kmer] ( out_hash...)* \n`, one line per record, input order.
    path "-" = stdout. */
 int mxg_write_tsv(mxg_handle *h, int assembly, const char *path, int with_pos, int with_strand,

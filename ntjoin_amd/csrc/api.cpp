@@ -321,14 +321,35 @@ int mxg_get_sketch_device(mxg_handle *h, int assembly, mxg_sketch_dview *out)
     Assembly *a = get_asm(h, assembly);
     if (!a || !out) return MXG_EINVAL;
     if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch yet", a->name.c_str());
-    int rc = ensure_strand(h, a);
-    if (rc != MXG_OK) return rc;
     out->n = a->n_mx;
     out->out_hash = a->d_hash.p;
     out->pos = a->d_pos.p;
     out->record = a->d_rec.p;
-    out->forward = a->d_fwd.p;
+    out->forward = a->fwd_valid ? a->d_fwd.p : nullptr;
     return MXG_OK;
+}
+
+int mxg_compute_strands(mxg_handle *h, int assembly)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a) return MXG_EINVAL;
+    if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch yet", a->name.c_str());
+    return ensure_strand(h, a);
+}
+
+int mxg_pack_sketch_device(mxg_handle *h, int assembly, void *d_buf, uint64_t nmax)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !d_buf) return MXG_EINVAL;
+    return pack_sketch(h, a, d_buf, nmax);
+}
+
+int mxg_set_sketch_gathered(mxg_handle *h, int assembly, const void *d_allbuf, uint32_t world, uint64_t nmax,
+                            const uint64_t *counts, const uint64_t *rec_offsets)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !d_allbuf || !counts || !rec_offsets) return MXG_EINVAL;
+    return unpack_gathered(h, a, d_allbuf, world, nmax, counts, rec_offsets);
 }
 
 int mxg_set_sketch_device(mxg_handle *h, int assembly, const void *d_out_hash, const void *d_pos,
@@ -338,24 +359,26 @@ int mxg_set_sketch_device(mxg_handle *h, int assembly, const void *d_out_hash, c
     if (!a) return MXG_EINVAL;
     if (n && (!d_out_hash || !d_pos || !d_record)) return set_err(h, MXG_EINVAL, "null device pointer");
     MXG_HIP(h, hipSetDevice(h->device));
-    // copy into fresh buffers first: the sources may alias the current sketch
-    DevBuf nh, np, nr, nf;
-    MXG_HIP(h, nh.ensure(std::max<uint64_t>(n * 8, 16)));
-    MXG_HIP(h, np.ensure(std::max<uint64_t>(n * 4, 16)));
-    MXG_HIP(h, nr.ensure(std::max<uint64_t>(n * 4, 16)));
-    MXG_HIP(h, nf.ensure(std::max<uint64_t>(n, 16)));
+    // the sources must not alias this assembly's own sketch buffers (they are overwritten in place)
+    const char *own[4] = {(const char *)a->d_hash.p, (const char *)a->d_pos.p, (const char *)a->d_rec.p, (const char *)a->d_fwd.p};
+    const size_t own_sz[4] = {a->d_hash.bytes, a->d_pos.bytes, a->d_rec.bytes, a->d_fwd.bytes};
+    const char *src[4] = {(const char *)d_out_hash, (const char *)d_pos, (const char *)d_record, (const char *)d_forward};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (src[i] && own[j] && src[i] >= own[j] && src[i] < own[j] + own_sz[j])
+                return set_err(h, MXG_EINVAL, "mxg_set_sketch_device: source arrays alias the assembly's own sketch");
+    MXG_HIP(h, a->d_hash.ensure(std::max<uint64_t>(n * 8, 16)));
+    MXG_HIP(h, a->d_pos.ensure(std::max<uint64_t>(n * 4, 16)));
+    MXG_HIP(h, a->d_rec.ensure(std::max<uint64_t>(n * 4, 16)));
+    MXG_HIP(h, a->d_fwd.ensure(std::max<uint64_t>(n, 16)));
     if (n) {
-        MXG_HIP(h, hipMemcpyAsync(nh.p, d_out_hash, n * 8, hipMemcpyDeviceToDevice, h->stream));
-        MXG_HIP(h, hipMemcpyAsync(np.p, d_pos, n * 4, hipMemcpyDeviceToDevice, h->stream));
-        MXG_HIP(h, hipMemcpyAsync(nr.p, d_record, n * 4, hipMemcpyDeviceToDevice, h->stream));
-        if (d_forward) MXG_HIP(h, hipMemcpyAsync(nf.p, d_forward, n, hipMemcpyDeviceToDevice, h->stream));
-        else MXG_HIP(h, hipMemsetAsync(nf.p, 1, n, h->stream));
-        MXG_HIP(h, hipStreamSynchronize(h->stream));
+        MXG_HIP(h, hipMemcpyAsync(a->d_hash.p, d_out_hash, n * 8, hipMemcpyDeviceToDevice, h->stream));
+        MXG_HIP(h, hipMemcpyAsync(a->d_pos.p, d_pos, n * 4, hipMemcpyDeviceToDevice, h->stream));
+        MXG_HIP(h, hipMemcpyAsync(a->d_rec.p, d_record, n * 4, hipMemcpyDeviceToDevice, h->stream));
+        if (d_forward) MXG_HIP(h, hipMemcpyAsync(a->d_fwd.p, d_forward, n, hipMemcpyDeviceToDevice, h->stream));
+        else MXG_HIP(h, hipMemsetAsync(a->d_fwd.p, 1, n, h->stream));
+        MXG_HIP(h, hipStreamSynchronize(h->stream));  // the caller may release its arrays as soon as this returns
     }
-    std::swap(a->d_hash.p, nh.p); std::swap(a->d_hash.bytes, nh.bytes);
-    std::swap(a->d_pos.p, np.p);  std::swap(a->d_pos.bytes, np.bytes);
-    std::swap(a->d_rec.p, nr.p);  std::swap(a->d_rec.bytes, nr.bytes);
-    std::swap(a->d_fwd.p, nf.p);  std::swap(a->d_fwd.bytes, nf.bytes);
     a->n_mx = n;
     a->has_sketch = true;
     a->fwd_valid = true;

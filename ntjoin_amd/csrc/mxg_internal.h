@@ -179,6 +179,9 @@ void make_hash_tab(uint32_t k, HashTab *t);
 int sketch_assembly(mxg_handle *h, Assembly *a);
 int sync_sketch_to_host(mxg_handle *h, Assembly *a);
 int ensure_strand(mxg_handle *h, Assembly *a);
+int pack_sketch(mxg_handle *h, Assembly *a, void *d_buf, uint64_t nmax);
+int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t world, uint64_t nmax,
+                    const uint64_t *counts, const uint64_t *rec_offsets);
 // graph.hip
 int build_graph(mxg_handle *h);
 int graph_to_host(mxg_handle *h);

@@ -662,7 +662,7 @@ static uint32_t choose_sparse_S(uint64_t total_kmers)
     const char *e = getenv("MXG_SPARSE_S");
     if (e && atoi(e) >= 16) return std::min(1024, (atoi(e) + 15) / 16 * 16);
     const uint64_t lanes = 1024ull * 64;  // SIMDs x lanes
-    for (uint32_t m = 4; m <= 8; ++m) {    // waves per SIMD
+    for (uint32_t m : {6u, 7u, 8u}) {      // waves per SIMD (measured: 6 waves of S=256 beat 4 waves of S=384)
         uint64_t S = (total_kmers + lanes * m - 1) / (lanes * m);
         S = (S + 15) / 16 * 16;
         if (S <= 512) return (uint32_t)std::max<uint64_t>(S, 128);
@@ -1277,6 +1277,89 @@ int ensure_strand(mxg_handle *h, Assembly *a)
     }
     MXG_HIP(h, hipStreamSynchronize(h->stream));
     a->fwd_valid = true;
+    return MXG_OK;
+}
+
+// ---- exchange step of the multi-GPU path: pack / unpack of the all-gather buffer ---------------------------------
+__global__ __launch_bounds__(256) void k_pack(const uint64_t *__restrict__ hash, const uint32_t *__restrict__ pos,
+                                              const uint32_t *__restrict__ rec, uint64_t n, uint64_t nmax,
+                                              unsigned char *__restrict__ buf)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    reinterpret_cast<uint64_t *>(buf)[i] = hash[i];
+    reinterpret_cast<uint32_t *>(buf + 8 * nmax)[i] = pos[i];
+    reinterpret_cast<uint32_t *>(buf + 12 * nmax)[i] = rec[i];
+}
+
+struct UnpackParams {
+    const unsigned char *all;
+    uint64_t nmax;
+    uint32_t world;
+    uint64_t start[65];    // exclusive prefix of counts (world <= 64)
+    uint32_t rec_off[64];
+    uint64_t *hash;
+    uint32_t *pos, *rec;
+};
+
+__global__ __launch_bounds__(256) void k_unpack(const UnpackParams p)
+{
+    const uint64_t o = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (o >= p.start[p.world]) return;
+    uint32_t r = 0;
+    while (o >= p.start[r + 1]) ++r;  // world is small
+    const uint64_t i = o - p.start[r];
+    const unsigned char *buf = p.all + (size_t)r * 16 * p.nmax;
+    p.hash[o] = reinterpret_cast<const uint64_t *>(buf)[i];
+    p.pos[o] = reinterpret_cast<const uint32_t *>(buf + 8 * p.nmax)[i];
+    p.rec[o] = reinterpret_cast<const uint32_t *>(buf + 12 * p.nmax)[i] + p.rec_off[r];
+}
+
+int pack_sketch(mxg_handle *h, Assembly *a, void *d_buf, uint64_t nmax)
+{
+    if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch yet", a->name.c_str());
+    if (nmax < a->n_mx || (nmax & 7)) return set_err(h, MXG_EINVAL, "nmax must be >= n and a multiple of 8");
+    MXG_HIP(h, hipSetDevice(h->device));
+    if (a->n_mx)
+        hipLaunchKernelGGL(k_pack, dim3((uint32_t)((a->n_mx + 255) / 256)), dim3(256), 0, h->stream,
+                           a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(), a->d_rec.as<uint32_t>(), a->n_mx, nmax,
+                           static_cast<unsigned char *>(d_buf));
+    MXG_HIP(h, hipGetLastError());
+    MXG_HIP(h, hipStreamSynchronize(h->stream));  // the caller hands the buffer to a collective on another stream
+    return MXG_OK;
+}
+
+int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t world, uint64_t nmax,
+                    const uint64_t *counts, const uint64_t *rec_offsets)
+{
+    if (world == 0 || world > 64) return set_err(h, MXG_ELIMIT, "world size must be 1..64");
+    MXG_HIP(h, hipSetDevice(h->device));
+    UnpackParams up;
+    up.all = static_cast<const unsigned char *>(d_allbuf);
+    up.nmax = nmax;
+    up.world = world;
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+        if (counts[r] > nmax) return set_err(h, MXG_EINVAL, "counts[%u] exceeds nmax", r);
+        up.start[r] = total;
+        up.rec_off[r] = (uint32_t)rec_offsets[r];
+        total += counts[r];
+    }
+    up.start[world] = total;
+    MXG_HIP(h, a->d_hash.ensure(std::max<uint64_t>(total * 8, 16)));
+    MXG_HIP(h, a->d_pos.ensure(std::max<uint64_t>(total * 4, 16)));
+    MXG_HIP(h, a->d_rec.ensure(std::max<uint64_t>(total * 4, 16)));
+    up.hash = a->d_hash.as<uint64_t>();
+    up.pos = a->d_pos.as<uint32_t>();
+    up.rec = a->d_rec.as<uint32_t>();
+    if (total) hipLaunchKernelGGL(k_unpack, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, h->stream, up);
+    MXG_HIP(h, hipGetLastError());
+    a->n_mx = total;
+    a->has_sketch = true;
+    a->fwd_valid = false;   // strands do not travel; an assembly without bases reports '+'
+    a->host_valid = false;
+    a->flags_valid = false;
+    h->graph.valid = false;
     return MXG_OK;
 }
 

@@ -91,33 +91,42 @@ def shard_records(lengths, world):
 
 
 def allgather_union_graph(eng, k, w, device, union=None, group=None):
-    """All-gather every assembly's sketch from `eng` (this rank's shard) and build the graph of the union on this
-    rank.  `union` (an MxEngine holding the union's record tables) is created on first use and reused."""
+    """The exchange step + graph of the union.  Per step: ONE small all-gather with every assembly's (count, records)
+    and ONE all-gather per assembly of its packed sketch (16 B per minimizer: out_hash, pos, record); packing and
+    unpacking (rank-order concatenation, record-index shift) are library kernels (mxg_pack_sketch_device /
+    mxg_set_sketch_gathered).  `union` (an MxEngine holding the union's record tables) is created on first use."""
     from .engine import MxEngine
     A = eng.n_assemblies
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", device)
-    gathered = []
-    for a in range(A):
-        dv = eng.get_sketch_device(a)
-        n = dv["n"]
-        local = {"out_hash": wrap_device(dv["out_hash"], n, "<i8", dev), "pos": wrap_device(dv["pos"], n, "<i4", dev),
-                 "record": wrap_device(dv["record"], n, "<i4", dev), "forward": wrap_device(dv["forward"], n, "|u1", dev)}
-        nrec = eng.n_records(a)
-        gathered.append(gather_sketches(local, nrec, group))
+    meta = torch.tensor([[eng.sketch_size(a), eng.n_records(a)] for a in range(A)], dtype=torch.int64, device=dev)
+    metas = torch.empty((world, A, 2), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(metas.view(-1), meta.view(-1), group=group)
+    metas = metas.cpu().numpy()  # the one host sync of the exchange: sizes of what follows
     if union is None:
         union = MxEngine(k=k, w=w, device=device, timing=True)
-        rank = dist.get_rank(group)
         for a in range(A):
             ids_local = [f"r{rank}:{x}" for x in eng.record_ids(a, eng.n_records(a))]
-            all_ids = [None] * dist.get_world_size(group)
+            all_ids = [None] * world
             dist.all_gather_object(all_ids, ids_local, group=group)
             flat = [x for part in all_ids for x in part]
             union.add_minimizers(eng.assembly_name(a), eng.assembly_weight(a), np.zeros(0, np.uint64),
                                  np.zeros(0, np.uint32), np.zeros(0, np.uint32), flat)
-    torch.cuda.current_stream().synchronize()
-    for a, g in enumerate(gathered):
-        n = int(g["out_hash"].numel())
-        union.set_sketch_device(a, g["out_hash"].data_ptr() if n else 0, g["pos"].data_ptr() if n else 0,
-                                g["record"].data_ptr() if n else 0, g["forward"].data_ptr() if n else 0, n)
+        union._xbuf = {}
+    for a in range(A):
+        counts = metas[:, a, 0].astype(np.uint64)
+        nrecs = metas[:, a, 1].astype(np.uint64)
+        rec_off = np.concatenate([[0], np.cumsum(nrecs)[:-1]]).astype(np.uint64)
+        nmax = (max(int(counts.max()), 1) + 7) // 8 * 8
+        bufs = union._xbuf.get(a)
+        if bufs is None or bufs[0].numel() < 16 * nmax:  # exchange buffers are kept across steps
+            cap = 16 * (nmax + nmax // 4 + 8)
+            bufs = (torch.empty(cap, dtype=torch.uint8, device=dev), torch.empty(world * cap, dtype=torch.uint8, device=dev))
+            union._xbuf[a] = bufs
+        send, recv = bufs[0][:16 * nmax], bufs[1][:world * 16 * nmax]
+        eng.pack_sketch_device(a, send.data_ptr(), nmax)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        torch.cuda.current_stream().synchronize()
+        union.set_sketch_gathered(a, recv.data_ptr(), nmax, counts, rec_off)
     union.build_graph()
     return union

@@ -154,6 +154,24 @@ class MxEngine:
         return {"n": int(v.n), "out_hash": v.out_hash or 0, "pos": v.pos or 0, "record": v.record or 0,
                 "forward": v.forward or 0}
 
+    def compute_strands(self, a):
+        self._check(self._lib.mxg_compute_strands(self._h, int(a)))
+
+    def sketch_size(self, a):
+        v = capi.SketchDView()
+        self._check(self._lib.mxg_get_sketch_device(self._h, int(a), C.byref(v)))
+        return int(v.n)
+
+    def pack_sketch_device(self, a, d_buf, nmax):
+        self._check(self._lib.mxg_pack_sketch_device(self._h, int(a), C.c_void_p(int(d_buf)), int(nmax)))
+
+    def set_sketch_gathered(self, a, d_allbuf, nmax, counts, rec_offsets):
+        cc = np.ascontiguousarray(counts, dtype=np.uint64)
+        ro = np.ascontiguousarray(rec_offsets, dtype=np.uint64)
+        self._check(self._lib.mxg_set_sketch_gathered(self._h, int(a), C.c_void_p(int(d_allbuf)), len(cc), int(nmax),
+                                                      cc.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                      ro.ctypes.data_as(C.POINTER(C.c_uint64))))
+
     def set_sketch_device(self, a, d_hash, d_pos, d_record, d_forward, n):
         self._check(self._lib.mxg_set_sketch_device(self._h, int(a), C.c_void_p(int(d_hash)), C.c_void_p(int(d_pos)),
                                                     C.c_void_p(int(d_record)),
