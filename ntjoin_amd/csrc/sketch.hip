@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
 
 // arena entry -> ordered candidate slot: one block per wave slice
 __global__ __launch_bounds__(256) void k_reorder(const uint4 *__restrict__ arena, const uint32_t *__restrict__ wave_cnt,
-                                                 uint32_t wave_cap, const uint32_t *__restrict__ strip_pref,
+                                                 uint32_t wave_cap, uint32_t n_cap, const uint32_t *__restrict__ strip_pref,
                                                  const uint2 *__restrict__ strip_meta, uint64_t *__restrict__ ch,
                                                  uint32_t *__restrict__ ck, uint32_t *__restrict__ cc)
 {
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(256) void k_reorder(const uint4 *__restrict__ arena
         const uint4 a = src[i];
         const uint32_t j = a.w & 1023u, seq = a.w >> 10;
         const uint32_t dst = strip_pref[a.z] + seq;
+        if (dst >= n_cap) continue;  // only when a wave overflowed its slice: the host redoes the batch
         const uint2 sm = strip_meta[a.z];
         ch[dst] = ((uint64_t)a.y << 32) | a.x;
         ck[dst] = sm.y + j;
@@ -337,6 +338,7 @@ struct ResolveParams {
     const uint32_t *ck, *cc;
     const uint32_t *n_ptr;  // number of candidates (device), clamped to n_cap
     uint32_t n_cap;
+    const uint32_t *ovf;    // != 0: a wave overflowed its arena slice, candidate arrays are incomplete -> do nothing
     const uint32_t *ctg_nk;
     uint32_t w;
     uint8_t *sel;
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
     __shared__ uint2 lkc[256 + 2 * RH + 2 * RP];  // {k-mer index, contig}; contig = ~0 outside the candidate array
     const uint32_t n = min(*p.n_ptr, p.n_cap);
     const uint32_t i0 = blockIdx.x * 256u;
-    if (i0 >= n) return;
+    if (i0 >= n || *p.ovf) return;
     for (uint32_t e = threadIdx.x; e < 256 + 2 * RH + 2 * RP; e += 256) {
         const int64_t g = (int64_t)i0 - RH - RP + e;
         if (g >= 0 && g < (int64_t)n) {
@@ -558,6 +560,7 @@ struct EmitParams {
     const uint32_t *ck, *cc;
     const uint32_t *n_ptr;
     uint32_t n_cap;
+    const uint32_t *ovf;   // see ResolveParams
     const uint32_t *bsum;  // exclusive block offsets
     const Run *runs;
     const uint32_t *ctg_run0, *ctg_rec;
@@ -572,6 +575,7 @@ struct EmitParams {
 __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
 {
     __shared__ uint32_t sh[256];
+    if (*p.ovf) return;
     const uint32_t n = min(*p.n_ptr, p.n_cap);
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
     uint32_t c = 0;
@@ -669,8 +673,15 @@ static uint32_t choose_sparse_S(uint64_t total_kmers)
     }
     return 512;  // large inputs: many rounds anyway; warm-up overhead k/512
 }
-constexpr uint64_t DENSE_BATCH_KMERS = 96ull << 20;   // dense arena = 16 B per k-mer
-constexpr uint64_t SPARSE_BATCH_KMERS = 2040ull << 20; // < 2^31 k-mers and < 2^32 strips per batch
+// batch sizes (whole records; a single record may exceed them).  Test knobs (environment, read per call):
+// MXG_DENSE_BATCH_KMERS / MXG_SPARSE_BATCH_KMERS shrink the batches, MXG_WAVE_CAP forces the arena-overflow retry.
+static uint64_t env_u64(const char *name, uint64_t dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? strtoull(e, nullptr, 10) : dflt;
+}
+#define DENSE_BATCH_KMERS env_u64("MXG_DENSE_BATCH_KMERS", 96ull << 20)    /* dense arena = 16 B per k-mer */
+#define SPARSE_BATCH_KMERS env_u64("MXG_SPARSE_BATCH_KMERS", 2040ull << 20) /* < 2^31 k-mers per batch */
 constexpr uint32_t GAP_CAP = 1u << 20;
 
 static hipError_t grow_preserve(DevBuf &b, size_t used_bytes, size_t need_bytes, hipStream_t st)
@@ -821,6 +832,7 @@ struct Driver {
         rp.cc = sc(SC_CAND_C).as<uint32_t>();
         rp.n_ptr = ctrl + 4;
         rp.n_cap = n_cap;
+        rp.ovf = ctrl;
         rp.ctg_nk = T.d_ctg_nk;
         rp.w = h->cfg.w;
         rp.sel = sc(SC_SEL).as<uint8_t>();
@@ -851,6 +863,7 @@ struct Driver {
         ep.ck = sc(SC_CAND_K).as<uint32_t>();
         ep.cc = sc(SC_CAND_C).as<uint32_t>();
         ep.n_ptr = sc(SC_CTRL).as<uint32_t>() + 4;
+        ep.ovf = sc(SC_CTRL).as<uint32_t>();
         ep.n_cap = n_cap;
         ep.bsum = sc(SC_BSUM).as<uint32_t>();
         ep.runs = T.d_runs;
@@ -1031,6 +1044,7 @@ struct Driver {
             uint64_t wave_cap = (uint64_t)(2.0 * expect + 6.0 * std::sqrt(expect)) + 64;
             wave_cap = std::max<uint64_t>(wave_cap, h->arena_cap_hint);
             wave_cap = std::min<uint64_t>(wave_cap, 64ull * S);  // a wave can never produce more
+            if (h->arena_cap_hint == 0) wave_cap = env_u64("MXG_WAVE_CAP", wave_cap);  // test knob
             uint32_t ctrl[8];
             uint64_t n_cap64 = 0;
             for (int attempt = 0;; ++attempt) {
@@ -1086,7 +1100,7 @@ struct Driver {
                 hipLaunchKernelGGL(k_tile_excl_u32, dim3(s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, n_strips,
                                    sc(SC_SBSUM).as<uint32_t>(), sc(SC_STRIP_PREF).as<uint32_t>());
                 hipLaunchKernelGGL(k_reorder, dim3(n_waves), dim3(256), 0, h->stream, sp.arena, sp.wave_cnt,
-                                   sp.wave_cap, sc(SC_STRIP_PREF).as<uint32_t>(), sp.strip_meta,
+                                   sp.wave_cap, n_cap, sc(SC_STRIP_PREF).as<uint32_t>(), sp.strip_meta,
                                    sc(SC_CAND_H).as<uint64_t>(), sc(SC_CAND_K).as<uint32_t>(),
                                    sc(SC_CAND_C).as<uint32_t>());
                 MXG_HIP(h, hipGetLastError());
