@@ -153,7 +153,8 @@ def main():
         tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_hash_bytes_per_launch")
+                # measured on the 100 Mbp launch of configs[1]; the kernel's traffic is linear in the bases of a launch
+                traffic = round(json.load(open(tpath)).get("k_hash_bytes_per_base") * st["hash_kernel_bases"] / launches)
             except Exception:
                 traffic = None
         out = {
@@ -168,7 +169,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_hash (ntHash fwd/rc rolling + candidate filter)",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "alg_bytes_per_base": ALG_BYTES_PER_BASE_HASH,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/hbm_traffic.json)",
+                         "alg_bytes_per_base": ALG_BYTES_PER_BASE_HASH, "alg_bytes_per_launch": int(bytes_per_launch),
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(st["launches_hash"]),
                          "bases_per_launch": int(st["hash_kernel_bases"] / launches)},
             "stage_ms_per_step": {"hash": round(st["ms_hash"] / args.steps, 4),

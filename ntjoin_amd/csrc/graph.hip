@@ -90,14 +90,13 @@ __global__ __launch_bounds__(256) void k_vertices(const VertexParams p)
 {
     __shared__ uint32_t sh[256];
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
-    uint32_t c = 0;
-    for (int u = 0; u < TILE_PER_THREAD; ++u)
-        if (base + u < p.n) c += p.shared[base + u];
+    const uint32_t fl = load_flags4(p.shared, base, p.n);
+    uint32_t c = count_flags4(fl);
     uint32_t r = p.bsum[blockIdx.x] + block_exclusive_256(c, sh);
     if (c == 0) return;
     for (int u = 0; u < TILE_PER_THREAD; ++u) {
         uint32_t i = base + u;
-        if (i < p.n && p.shared[i]) {
+        if ((fl >> (8 * u)) & 1u) {
             uint32_t s = p.slot[i];
             uint32_t v;
             if (p.first) {
@@ -171,14 +170,13 @@ __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_it
 {
     __shared__ uint32_t sh[256];
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
-    uint32_t c = 0;
-    for (int t = 0; t < TILE_PER_THREAD; ++t)
-        if (base + t < n_items) c += p.eflag[base + t];
+    const uint32_t fl = load_flags4(p.eflag, base, n_items);
+    uint32_t c = count_flags4(fl);
     uint32_t e = p.bsum[blockIdx.x] + block_exclusive_256(c, sh);
     if (c == 0) return;
     for (int t = 0; t < TILE_PER_THREAD; ++t) {
         uint32_t item = base + t;
-        if (item < n_items && p.eflag[item]) {
+        if ((fl >> (8 * t)) & 1u) {
             uint32_t a = item / p.nv, r = item % p.nv;
             uint32_t u = p.fv[(size_t)a * p.nv + r];
             uint32_t v = p.nxt[(size_t)a * p.nv + u];

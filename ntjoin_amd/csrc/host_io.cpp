@@ -49,6 +49,26 @@ void make_hash_tab(uint32_t k, HashTab *t)
         }
 }
 
+// Direct-initialisation table for the sketch kernel: the "warm-up state" after the first m = 4*(k/4) bases of a
+// strip is  F = XOR_j srol^{m-1-j}(seed[c_j]),  R = XOR_j srol^{k-m+j}(seed'[c_j]);  entry [b][v] holds the XOR of the
+// four terms of byte position b (bases 4b..4b+3, base i in bits 2i..2i+1 of v), so the state is the XOR of k/4 lookups;
+// the remaining k%4 bases are stepped as usual.
+void make_init_tab(uint32_t k, std::vector<uint4> &out)
+{
+    const uint32_t P = k / 4, m = 4 * P;
+    out.assign((size_t)P * 256, make_uint4(0, 0, 0, 0));
+    for (uint32_t b = 0; b < P; ++b)
+        for (uint32_t v = 0; v < 256; ++v) {
+            uint64_t f = 0, r = 0;
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t c = (v >> (2 * i)) & 3u, j = 4 * b + i;
+                f ^= srol_n(SEED[c], m - 1 - j);
+                r ^= srol_n(SEED[3 - c], k - m + j);
+            }
+            out[(size_t)b * 256 + v] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+        }
+}
+
 // ---- base code table -------------------------------------------------------------------------------
 static const uint8_t *code_lut()
 {

@@ -140,6 +140,7 @@ struct mxg_handle {
     mxg::Graph graph;
     mxg::Timers tm;
     mxg::HashTab tab{};
+    mxg::DevBuf d_init_tab;  // direct-initialisation table (k/4 x 256 x 16 B), built by the first sketch
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
     // scratch reused across calls
     mxg::DevBuf scratch[40];
@@ -174,6 +175,7 @@ void build_rec_first(Assembly *a);
 std::string py_repr_str(const std::string &s);
 std::string py_repr_float(double v);
 void make_hash_tab(uint32_t k, HashTab *t);
+void make_init_tab(uint32_t k, std::vector<uint4> &out);
 
 // sketch.hip
 int sketch_assembly(mxg_handle *h, Assembly *a);

@@ -9,14 +9,25 @@ namespace mxg {
 
 constexpr int TILE_PER_THREAD = 4;
 constexpr int TILE = 256 * TILE_PER_THREAD;
+static_assert(TILE_PER_THREAD == 4, "flag loads below fetch one 32-bit word per thread");
+
+// the thread's four flag bytes [base, base+4) as one word (base is a multiple of 4; bytes at or beyond n read as 0).
+// The flag arrays are allocated with >= 16 bytes of slack, so the word load never leaves the allocation.
+__device__ __forceinline__ uint32_t load_flags4(const uint8_t *__restrict__ flags, uint32_t base, uint32_t n)
+{
+    if (base >= n) return 0u;
+    uint32_t v = *reinterpret_cast<const uint32_t *>(flags + base);
+    const uint32_t valid = n - base;
+    if (valid < 4) v &= (1u << (8 * valid)) - 1u;
+    return v;
+}
+__device__ __forceinline__ uint32_t count_flags4(uint32_t v) { return (v & 1u) + ((v >> 8) & 1u) + ((v >> 16) & 1u) + ((v >> 24) & 1u); }
 
 static __global__ __launch_bounds__(256) void k_count(const uint8_t *__restrict__ sel, uint32_t n, uint32_t *__restrict__ bsum)
 {
     __shared__ uint32_t sh[256];
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
-    uint32_t c = 0;
-    for (int u = 0; u < TILE_PER_THREAD; ++u)
-        if (base + u < n) c += sel[base + u];
+    uint32_t c = count_flags4(load_flags4(sel, base, n));
     sh[threadIdx.x] = c;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {

@@ -118,6 +118,31 @@ __device__ __forceinline__ void warm_up(H2 &h, const uint32_t *__restrict__ pack
     }
 }
 
+// Hash state of the first k-mer of a strip without k rolling steps: XOR of k/4 table lookups (one per byte of
+// packed bases; table built by make_init_tab), then k%4 ordinary warm-up steps.
+template <class T>
+__device__ __forceinline__ void init_direct(H2 &h, const uint32_t *__restrict__ packed, uint64_t b, uint32_t k,
+                                            const uint4 *__restrict__ init_tab, const T *tab)
+{
+    const uint32_t P = k / 4;
+    for (uint32_t q = 0; q < P; q += 4) {  // 16 bases = 4 table bytes per fetch
+        const uint32_t word = fetch16(packed, b + 4u * q);
+        const uint32_t nb = min(4u, P - q);
+        for (uint32_t u = 0; u < nb; ++u) {
+            const uint4 e = init_tab[(size_t)(q + u) * 256u + ((word >> (8 * u)) & 255u)];
+            h.flo ^= e.x; h.fhi ^= e.y; h.rlo ^= e.z; h.rhi ^= e.w;
+        }
+    }
+    const uint32_t rem = k - 4 * P;
+    if (rem) {
+        uint32_t chunk = fetch16(packed, b + 4u * P);
+        for (uint32_t u = 0; u < rem; ++u) {
+            nt_step(h, tab[16 + (chunk & 3u)]);
+            chunk >>= 2;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // dense hash kernel
 // ------------------------------------------------------------------------------------------------------
@@ -194,6 +219,7 @@ struct SparseParams {
     uint32_t *ctrl;       // [0] max over waves of wave_cnt (atomicMax, only written on overflow)
     uint32_t *strip_cnt;  // [n_strips] candidates per strip
     uint2 *strip_meta;    // [n_strips] {contig, kidx of the strip's first k-mer}
+    const uint4 *init_tab; // direct-initialisation table (make_init_tab)
     HashTab tab;
 };
 
@@ -266,7 +292,7 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     };
 
     H2 h = {0u, 0u, 0u, 0u};
-    warm_up(h, p.packed, b, k, tab);
+    init_direct(h, p.packed, b, k, p.init_tab, tab);  // replaces k rolling warm-up steps per strip
     visit(h, 0, true);
     // strips shorter than S only occur at the end of a run: when every lane of the wave owns a full strip the
     // per-step length test is dropped (wave-uniform loop versioning)
@@ -542,9 +568,11 @@ __global__ __launch_bounds__(256) void k_count_n(const uint8_t *__restrict__ sel
     __shared__ uint32_t sh[256];
     const uint32_t n = min(*n_ptr, n_cap);
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
-    uint32_t c = 0;
-    for (int u = 0; u < TILE_PER_THREAD; ++u)
-        if (base + u < n) c += sel[base + u];
+    if (blockIdx.x * TILE >= n) {  // whole tile beyond the candidates
+        if (threadIdx.x == 0) bsum[blockIdx.x] = 0;
+        return;
+    }
+    uint32_t c = count_flags4(load_flags4(sel, base, n));
     sh[threadIdx.x] = c;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -577,15 +605,15 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     __shared__ uint32_t sh[256];
     if (*p.ovf) return;
     const uint32_t n = min(*p.n_ptr, p.n_cap);
+    if (blockIdx.x * TILE >= n) return;  // whole tile beyond the candidates
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
-    uint32_t c = 0;
-    for (int u = 0; u < TILE_PER_THREAD; ++u)
-        if (base + u < n) c += p.sel[base + u];
+    const uint32_t fl = load_flags4(p.sel, base, n);
+    uint32_t c = count_flags4(fl);
     uint64_t o = p.out_base + p.bsum[blockIdx.x] + block_exclusive_256(c, sh);
     if (c == 0) return;
     for (int u = 0; u < TILE_PER_THREAD; ++u) {
         uint32_t i = base + u;
-        if (i < n && p.sel[i]) {
+        if ((fl >> (8 * u)) & 1u) {
             uint32_t cs = p.cc[i], ctg = cs & 0x7FFFFFFFu, kx = p.ck[i];
             // contig-local valid-k-mer index -> base position, through the contig's run table
             uint32_t lo = p.ctg_run0[ctg], hi = p.ctg_run0[ctg + 1];
@@ -666,8 +694,10 @@ static uint32_t choose_sparse_S(uint64_t total_kmers)
     const char *e = getenv("MXG_SPARSE_S");
     if (e && atoi(e) >= 16) return std::min(1024, (atoi(e) + 15) / 16 * 16);
     const uint64_t lanes = 1024ull * 64;  // SIMDs x lanes
-    for (uint32_t m : {6u, 7u, 8u}) {      // waves per SIMD (measured: 6 waves of S=256 beat 4 waves of S=384)
-        uint64_t S = (total_kmers + lanes * m - 1) / (lanes * m);
+    // with the table-driven initialisation a strip has no warm-up cost, so short strips are fine: aim for ~12 waves per
+    // SIMD (measured 88 us at S=128 vs 94 us at S=256 for 100 Mbp), at least 128 k-mers per strip
+    {
+        uint64_t S = (total_kmers + lanes * 12 - 1) / (lanes * 12);
         S = (S + 15) / 16 * 16;
         if (S <= 512) return (uint32_t)std::max<uint64_t>(S, 128);
     }
@@ -1074,6 +1104,7 @@ struct Driver {
                 sp.ctrl = sc(SC_CTRL).as<uint32_t>();
                 sp.strip_cnt = sc(SC_STRIP_CNT).as<uint32_t>();
                 sp.strip_meta = sc(SC_STRIP_META).as<uint2>();
+                sp.init_tab = h->d_init_tab.as<uint4>();
                 sp.tab = h->tab;
                 int rc = ev_begin(batch_bases(T, c0, c1), true);
                 if (rc != MXG_OK) return rc;
@@ -1224,6 +1255,13 @@ int sketch_assembly(mxg_handle *h, Assembly *a)
     }
     int rc = prepare_tables(h, a);
     if (rc != MXG_OK) return rc;
+    if (!h->d_init_tab.p) {
+        std::vector<uint4> it;
+        make_init_tab(h->cfg.k, it);
+        if (it.empty()) it.push_back(make_uint4(0, 0, 0, 0));
+        if ((rc = upload(h, h->d_init_tab, it)) != MXG_OK) return rc;
+        MXG_HIP(h, hipStreamSynchronize(h->stream));
+    }
 
     Tables T;
     T.runs = &a->runs;
