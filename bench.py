@@ -108,8 +108,7 @@ def main():
 
     def step():
         nonlocal union
-        eng.sketch(0)
-        eng.sketch(1)
+        eng.sketch(-2)  # MXG_SKETCH_ALL: both assemblies enqueued back to back, one host sync
         if world > 1 or force_dist:
             union = allgather_union_graph(eng, K, W, local_rank, union)
         else:

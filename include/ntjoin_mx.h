@@ -160,7 +160,9 @@ uint64_t mxg_num_records(const mxg_handle *h, int assembly);
 double mxg_assembly_weight(const mxg_handle *h, int assembly);
 
 /* ---- sketch stage (replaces indexlr) --------------------------------------------------------- */
-int mxg_sketch(mxg_handle *h, int assembly /* -1 = every assembly that has bases and no sketch yet */);
+#define MXG_SKETCH_PENDING (-1) /* every assembly that has bases and no sketch yet                         */
+#define MXG_SKETCH_ALL (-2)     /* every assembly that has bases (re-sketch); pipelined: one host sync for all */
+int mxg_sketch(mxg_handle *h, int assembly /* index, MXG_SKETCH_PENDING or MXG_SKETCH_ALL */);
 int mxg_get_sketch(mxg_handle *h, int assembly, mxg_sketch_view *out);
 /* (forward is NULL until the strands have been computed: mxg_get_sketch, mxg_write_tsv or mxg_compute_strands) */
 int mxg_get_sketch_device(mxg_handle *h, int assembly, mxg_sketch_dview *out);

@@ -80,6 +80,7 @@ void mxg_destroy(mxg_handle *h)
     h->asms.clear();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->pinned_ctrl) (void)hipHostFree(h->pinned_ctrl);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -288,12 +289,10 @@ int mxg_sketch(mxg_handle *h, int assembly)
             if (!a) return MXG_EINVAL;
             return sketch_assembly(h, a);
         }
-        for (auto *a : h->asms) {
-            if (a->has_bases && !a->has_sketch) {
-                int rc = sketch_assembly(h, a);
-                if (rc != MXG_OK) return rc;
-            }
-        }
+        std::vector<Assembly *> todo;
+        for (auto *a : h->asms)
+            if (a->has_bases && (assembly == MXG_SKETCH_ALL || !a->has_sketch)) todo.push_back(a);
+        if (!todo.empty()) return sketch_assemblies(h, todo.data(), todo.size());
     } catch (const std::bad_alloc &) {
         return set_err(h, MXG_ENOMEM, "out of host memory in mxg_sketch");
     }

@@ -116,8 +116,10 @@ __global__ __launch_bounds__(256) void k_vertices(const VertexParams p)
 }
 
 __global__ __launch_bounds__(256) void k_adjacency(const uint32_t *__restrict__ fv, const uint32_t *__restrict__ frec,
-                                                   uint32_t nv, uint32_t *__restrict__ nxt, uint32_t *__restrict__ prv)
+                                                   const uint64_t *__restrict__ nv_ptr, uint32_t *__restrict__ nxt,
+                                                   uint32_t *__restrict__ prv)
 {
+    const uint32_t nv = (uint32_t)*nv_ptr;  // number of shared minimizers, still in HBM (no host sync before this stage)
     uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r + 1 >= nv) return;
     if (frec[r] == frec[r + 1]) {  // consecutive surviving minimizers of the same contig (ntjoin_utils.py:98-99)
@@ -128,9 +130,10 @@ __global__ __launch_bounds__(256) void k_adjacency(const uint32_t *__restrict__ 
 }
 
 struct EdgeParams {
-    const uint32_t *fv;   // [A][nv]
+    const uint32_t *fv;   // [A][nv]   (nv = stride = upper bound of the vertex count; the count itself is *nv_ptr)
     const uint32_t *nxt;  // [A][nv]
     const uint32_t *prv;  // [A][nv]
+    const uint64_t *nv_ptr;
     uint32_t nv, n_asm;
     uint8_t *eflag;       // [A*nv]
     const uint32_t *bsum;
@@ -156,6 +159,10 @@ __global__ __launch_bounds__(256) void k_edge_flags(const EdgeParams p)
     if (item >= (uint64_t)p.n_asm * p.nv) return;
     uint32_t a = (uint32_t)(item / p.nv);
     uint32_t r = (uint32_t)(item % p.nv);
+    if (r >= (uint32_t)*p.nv_ptr) {  // beyond the actual vertex count
+        p.eflag[item] = 0;
+        return;
+    }
     uint32_t u = p.fv[(size_t)a * p.nv + r];
     uint32_t v = p.nxt[(size_t)a * p.nv + u];
     uint8_t f = 0;
@@ -273,27 +280,19 @@ int build_graph(mxg_handle *h)
         as->flags_valid = true;
     }
     MXG_HIP(h, hipGetLastError());
-    uint64_t hctl[CTL_WORDS];
-    MXG_HIP(h, hipMemcpyAsync(hctl, h->g_ctl.p, CTL_WORDS * 8, hipMemcpyDeviceToHost, h->stream));
-    MXG_HIP(h, hipStreamSynchronize(h->stream));  // sync 1 of 2: |intersection|
-    const uint64_t nv = hctl[0];
-    for (uint32_t a = 1; a < A; ++a)
-        if (hctl[a] != nv)
-            return set_err(h, MXG_EDEVICE, "internal error: shared-minimizer counts differ between assemblies (%llu vs %llu)",
-                           (unsigned long long)hctl[a], (unsigned long long)nv);
-    g.nv = nv;
-    h->stat_unique = ~0ull;  // counted lazily from the flags (mxg_get_stats)
-
-    uint64_t ne = 0;
-    if (nv > 0) {
-        if ((uint64_t)A * nv >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "graph too large for 32-bit item indices");
-        const size_t anv = (size_t)A * nv;
-        MXG_HIP(h, h->g_vhash.ensure(nv * 8));
+    // vertex arrays are strided by an upper bound of the vertex count (every vertex occurs once in every assembly), so
+    // this stage needs no host sync before its kernels: they read the counts from the control block in HBM
+    const uint64_t nvs = nmin;  // stride
+    uint64_t hctl[CTL_WORDS] = {0};
+    if (nvs > 0) {
+        if ((uint64_t)A * nvs >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "graph too large for 32-bit item indices");
+        const size_t anv = (size_t)A * nvs;
+        MXG_HIP(h, h->g_vhash.ensure(nvs * 8));
         MXG_HIP(h, h->g_vpos.ensure(anv * 4));
         MXG_HIP(h, h->g_vrec.ensure(anv * 4));
         MXG_HIP(h, h->g_fv.ensure(anv * 4));
         MXG_HIP(h, h->g_frec.ensure(anv * 4));
-        MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4));  // nxt[A][nv] followed by prv[A][nv]: one fill
+        MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4));  // nxt[A][nvs] followed by prv[A][nvs]: one fill
         MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));
         uint32_t *const d_prv = h->g_nxt.as<uint32_t>() + anv;
         for (uint32_t a = 0; a < A; ++a) {
@@ -310,21 +309,21 @@ int build_graph(mxg_handle *h)
             vp.first = a == 0;
             vp.vid = h->g_vid.as<uint32_t>();
             vp.vhash = h->g_vhash.as<uint64_t>();
-            vp.vpos = h->g_vpos.as<uint32_t>() + (size_t)a * nv;
-            vp.vrec = h->g_vrec.as<uint32_t>() + (size_t)a * nv;
-            vp.fv = h->g_fv.as<uint32_t>() + (size_t)a * nv;
-            vp.frec = h->g_frec.as<uint32_t>() + (size_t)a * nv;
+            vp.vpos = h->g_vpos.as<uint32_t>() + (size_t)a * nvs;
+            vp.vrec = h->g_vrec.as<uint32_t>() + (size_t)a * nvs;
+            vp.fv = h->g_fv.as<uint32_t>() + (size_t)a * nvs;
+            vp.frec = h->g_frec.as<uint32_t>() + (size_t)a * nvs;
             hipLaunchKernelGGL(k_vertices, dim3((n + TILE - 1) / TILE), dim3(256), 0, h->stream, vp);
-            hipLaunchKernelGGL(k_adjacency, dim3((uint32_t)((nv + 255) / 256)), dim3(256), 0, h->stream,
-                               h->g_fv.as<uint32_t>() + (size_t)a * nv, h->g_frec.as<uint32_t>() + (size_t)a * nv,
-                               (uint32_t)nv, h->g_nxt.as<uint32_t>() + (size_t)a * nv, d_prv + (size_t)a * nv);
+            hipLaunchKernelGGL(k_adjacency, dim3((uint32_t)((nvs + 255) / 256)), dim3(256), 0, h->stream,
+                               h->g_fv.as<uint32_t>() + (size_t)a * nvs, h->g_frec.as<uint32_t>() + (size_t)a * nvs,
+                               ctl + a, h->g_nxt.as<uint32_t>() + (size_t)a * nvs, d_prv + (size_t)a * nvs);
         }
         MXG_HIP(h, hipGetLastError());
         const uint32_t n_items = (uint32_t)anv;
         const uint32_t e_tiles = (n_items + TILE - 1) / TILE;
         MXG_HIP(h, h->g_eflag.ensure(n_items));
         MXG_HIP(h, h->g_ebs.ensure((size_t)e_tiles * 4 + 16));
-        // every item yields at most one edge: size the edge arrays by that bound, no sync needed before k_edges
+        // every item yields at most one edge: size the edge arrays by that bound
         MXG_HIP(h, h->g_eu.ensure((size_t)n_items * 4));
         MXG_HIP(h, h->g_ev.ensure((size_t)n_items * 4));
         MXG_HIP(h, h->g_esup.ensure((size_t)n_items * 4));
@@ -333,7 +332,8 @@ int build_graph(mxg_handle *h)
         ep.fv = h->g_fv.as<uint32_t>();
         ep.nxt = h->g_nxt.as<uint32_t>();
         ep.prv = d_prv;
-        ep.nv = (uint32_t)nv;
+        ep.nv_ptr = ctl;
+        ep.nv = (uint32_t)nvs;
         ep.n_asm = A;
         ep.eflag = h->g_eflag.as<uint8_t>();
         ep.bsum = h->g_ebs.as<uint32_t>();
@@ -349,14 +349,19 @@ int build_graph(mxg_handle *h)
                            ctl + CTL_EDGES);
         hipLaunchKernelGGL(k_edges, dim3(e_tiles), dim3(256), 0, h->stream, ep, n_items);
         MXG_HIP(h, hipGetLastError());
-        if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
-        MXG_HIP(h, hipMemcpyAsync(&ne, ctl + CTL_EDGES, 8, hipMemcpyDeviceToHost, h->stream));
-        MXG_HIP(h, hipStreamSynchronize(h->stream));  // sync 2 of 2: edge count; results stay in HBM
-    } else {
-        if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
-        MXG_HIP(h, hipStreamSynchronize(h->stream));
     }
-    g.ne = ne;
+    if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
+    MXG_HIP(h, hipMemcpyAsync(hctl, h->g_ctl.p, CTL_WORDS * 8, hipMemcpyDeviceToHost, h->stream));
+    MXG_HIP(h, hipStreamSynchronize(h->stream));  // the stage's only sync; results stay in HBM
+    const uint64_t nv = hctl[0];
+    for (uint32_t a = 1; a < A; ++a)
+        if (hctl[a] != nv)
+            return set_err(h, MXG_EDEVICE, "internal error: shared-minimizer counts differ between assemblies (%llu vs %llu)",
+                           (unsigned long long)hctl[a], (unsigned long long)nv);
+    g.nv = nv;
+    g.nv_stride = nvs;
+    g.ne = nvs > 0 ? hctl[CTL_EDGES] : 0;
+    h->stat_unique = ~0ull;  // counted lazily from the flags (mxg_get_stats)
     if (timing) {
         float ms = 0;
         MXG_HIP(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -377,8 +382,14 @@ int graph_to_host(mxg_handle *h)
     const size_t anv = (size_t)g.n_asm * g.nv;
     int rc;
     if ((rc = d2h(h, g.vhash, h->g_vhash.p, g.nv)) != MXG_OK) return rc;
-    if ((rc = d2h(h, g.vpos, h->g_vpos.p, anv)) != MXG_OK) return rc;
-    if ((rc = d2h(h, g.vrec, h->g_vrec.p, anv)) != MXG_OK) return rc;
+    g.vpos.resize(anv);
+    g.vrec.resize(anv);
+    for (uint32_t a = 0; a < g.n_asm && g.nv; ++a) {  // device arrays are strided by nv_stride, host mirrors are compact
+        MXG_HIP(h, hipMemcpyAsync(g.vpos.data() + (size_t)a * g.nv, h->g_vpos.as<uint32_t>() + (size_t)a * g.nv_stride,
+                                  g.nv * 4, hipMemcpyDeviceToHost, h->stream));
+        MXG_HIP(h, hipMemcpyAsync(g.vrec.data() + (size_t)a * g.nv, h->g_vrec.as<uint32_t>() + (size_t)a * g.nv_stride,
+                                  g.nv * 4, hipMemcpyDeviceToHost, h->stream));
+    }
     if ((rc = d2h(h, g.eu, h->g_eu.p, g.ne)) != MXG_OK) return rc;
     if ((rc = d2h(h, g.ev, h->g_ev.p, g.ne)) != MXG_OK) return rc;
     if ((rc = d2h(h, g.esup, h->g_esup.p, g.ne)) != MXG_OK) return rc;

@@ -116,7 +116,7 @@ struct Graph {
     bool valid = false;       // device results computed
     bool host_valid = false;  // host mirrors below filled (lazily, by graph_to_host)
     uint32_t n_asm = 0;
-    uint64_t nv = 0, ne = 0;
+    uint64_t nv = 0, ne = 0, nv_stride = 0;
     std::vector<uint64_t> vhash;
     std::vector<uint32_t> vpos, vrec;  // [a*nv+v]
     std::vector<uint32_t> eu, ev, esup;
@@ -148,6 +148,7 @@ struct mxg_handle {
         g_ebs, g_eu, g_ev, g_esup, g_ew;  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
     uint64_t arena_cap_hint = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t *pinned_ctrl = nullptr;  // pinned host copies of per-assembly control blocks (pipelined sketch)
 };
 
 namespace mxg {
@@ -179,6 +180,7 @@ void make_init_tab(uint32_t k, std::vector<uint4> &out);
 
 // sketch.hip
 int sketch_assembly(mxg_handle *h, Assembly *a);
+int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n);
 int sync_sketch_to_host(mxg_handle *h, Assembly *a);
 int ensure_strand(mxg_handle *h, Assembly *a);
 int pack_sketch(mxg_handle *h, Assembly *a, void *d_buf, uint64_t nmax);

@@ -1045,102 +1045,137 @@ struct Driver {
         return MXG_OK;
     }
 
-    // ---- sparse pipeline over every contig of T, appended to `out` ------------------------------------
+    // ---- sparse pipeline -------------------------------------------------------------------------------------
     // control block (u32 words): [0] max wave count if a wave overflowed its arena slice, [1] gap count,
     // [2..3] number of selected candidates (u64), [4..5] number of candidates (u64)
+    struct BatchGeom {
+        size_t c0, c1;
+        uint64_t nk;
+        uint32_t r_lo, r_hi, strip_lo, strip_hi, n_strips, n_blocks, n_waves, s_tiles;
+    };
+    void batch_geom(const Tables &T, size_t c0, BatchGeom &g) const
+    {
+        const size_t n_ctg = T.ctg_rec->size();
+        g.c0 = c0;
+        g.c1 = c0;
+        g.nk = 0;
+        while (g.c1 < n_ctg && (g.c1 == c0 || g.nk + (*T.ctg_nk)[g.c1] <= SPARSE_BATCH_KMERS)) g.nk += (*T.ctg_nk)[g.c1++];
+        g.r_lo = (*T.ctg_run0)[g.c0];
+        g.r_hi = (*T.ctg_run0)[g.c1];
+        g.strip_lo = (*T.strip0_sparse)[g.r_lo];
+        g.strip_hi = (*T.strip0_sparse)[g.r_hi];
+        g.n_strips = g.strip_hi - g.strip_lo;
+        g.n_blocks = (g.n_strips + 255) / 256;
+        g.n_waves = g.n_blocks * 4;
+        g.s_tiles = (g.n_strips + TILE - 1) / TILE;
+    }
+    uint64_t default_wave_cap(uint32_t S, double cand_frac) const
+    {
+        // every wave owns a slice of the arena: twice the expected candidates of 64 strips plus 6 sigma
+        const double expect = 64.0 * S * cand_frac;
+        uint64_t wave_cap = (uint64_t)(2.0 * expect + 6.0 * std::sqrt(expect)) + 64;
+        wave_cap = std::max<uint64_t>(wave_cap, h->arena_cap_hint);
+        wave_cap = std::min<uint64_t>(wave_cap, 64ull * S);  // a wave can never produce more
+        if (h->arena_cap_hint == 0) wave_cap = env_u64("MXG_WAVE_CAP", wave_cap);  // test knob
+        return wave_cap;
+    }
+    // Enqueue one batch completely (hash -> order -> resolve -> count -> speculative emit at out.n) and an async copy
+    // of the control block to `ctrl_host`; NO host sync.  *n_cap_out = capacity the candidate arrays were sized for.
+    int enqueue_sparse(Assembly *a, const Tables &T, const BatchGeom &g, uint64_t wave_cap, uint32_t tau_hi,
+                       OutArrays &out, uint32_t *ctrl_host, uint32_t *n_cap_out)
+    {
+        const uint32_t S = a->S_sparse;
+        MXG_HIP(h, sc(SC_CTRL).ensure(64));
+        MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
+        MXG_HIP(h, sc(SC_STRIP_CNT).ensure((size_t)g.n_strips * 4 + 16));
+        MXG_HIP(h, sc(SC_STRIP_PREF).ensure((size_t)g.n_strips * 4 + 16));
+        MXG_HIP(h, sc(SC_STRIP_META).ensure((size_t)g.n_strips * 8 + 16));
+        MXG_HIP(h, sc(SC_SBSUM).ensure((size_t)g.s_tiles * 4 + 16));
+        MXG_HIP(h, sc(SC_WAVE_CNT).ensure((size_t)g.n_waves * 4 + 16));
+        const uint64_t n_cap64 = (uint64_t)g.n_waves * wave_cap;
+        if (n_cap64 >= (1ull << 32))
+            return set_err(h, MXG_ELIMIT, "candidate arena would exceed 2^32 entries; use MXG_FLAG_DENSE_ONLY");
+        const uint32_t n_cap = (uint32_t)n_cap64;
+        *n_cap_out = n_cap;
+        MXG_HIP(h, sc(SC_ARENA).ensure((size_t)n_cap * 16));
+        MXG_HIP(h, sc(SC_CAND_H).ensure((size_t)n_cap * 8));
+        MXG_HIP(h, sc(SC_CAND_K).ensure((size_t)n_cap * 4));
+        MXG_HIP(h, sc(SC_CAND_C).ensure((size_t)n_cap * 4));
+        MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, 32, h->stream));
+        SparseParams sp;
+        sp.packed = a->d_packed;
+        sp.runs = T.d_runs;
+        sp.run_strip0 = T.d_strip0_sparse;
+        sp.run_lo = g.r_lo;
+        sp.run_hi = g.r_hi;
+        sp.strip_lo = g.strip_lo;
+        sp.strip_hi = g.strip_hi;
+        sp.k = h->cfg.k;
+        sp.S = S;
+        sp.tau_hi = tau_hi;
+        sp.arena = sc(SC_ARENA).as<uint4>();
+        sp.wave_cap = (uint32_t)wave_cap;
+        sp.wave_cnt = sc(SC_WAVE_CNT).as<uint32_t>();
+        sp.ctrl = sc(SC_CTRL).as<uint32_t>();
+        sp.strip_cnt = sc(SC_STRIP_CNT).as<uint32_t>();
+        sp.strip_meta = sc(SC_STRIP_META).as<uint2>();
+        sp.init_tab = h->d_init_tab.as<uint4>();
+        sp.tab = h->tab;
+        int rc = ev_begin(batch_bases(T, g.c0, g.c1), true);
+        if (rc != MXG_OK) return rc;
+        dim3 grid(g.n_blocks), block(256);
+        static const int abl = getenv("MXG_ABLATE") ? atoi(getenv("MXG_ABLATE")) : 0;  // profiling only
+        if (h->cfg.variant == MXG_VARIANT_V1_MIN)
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V1_MIN>), grid, block, 0, h->stream, sp);
+        else if (abl == 1)
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 1>), grid, block, 0, h->stream, sp);
+        else if (abl == 2)
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 2>), grid, block, 0, h->stream, sp);
+        else if (abl == 4)
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 4>), grid, block, 0, h->stream, sp);
+        else
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), grid, block, 0, h->stream, sp);
+        if ((rc = ev_end()) != MXG_OK) return rc;
+        MXG_HIP(h, hipGetLastError());
+        // order the candidates: exclusive scan of per-strip counts (total = number of candidates), then scatter
+        if ((rc = ev_begin(0, false)) != MXG_OK) return rc;
+        hipLaunchKernelGGL(k_tile_sum_u32, dim3(g.s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, g.n_strips,
+                           sc(SC_SBSUM).as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, h->stream, sc(SC_SBSUM).as<uint32_t>(), g.s_tiles,
+                           reinterpret_cast<uint64_t *>(sp.ctrl + 4));
+        hipLaunchKernelGGL(k_tile_excl_u32, dim3(g.s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, g.n_strips,
+                           sc(SC_SBSUM).as<uint32_t>(), sc(SC_STRIP_PREF).as<uint32_t>());
+        hipLaunchKernelGGL(k_reorder, dim3(g.n_waves), dim3(256), 0, h->stream, sp.arena, sp.wave_cnt, sp.wave_cap, n_cap,
+                           sc(SC_STRIP_PREF).as<uint32_t>(), sp.strip_meta, sc(SC_CAND_H).as<uint64_t>(),
+                           sc(SC_CAND_K).as<uint32_t>(), sc(SC_CAND_C).as<uint32_t>());
+        MXG_HIP(h, hipGetLastError());
+        if ((rc = resolve_and_count<true>(T, n_cap, (uint32_t)g.c0, (uint32_t)g.c1)) != MXG_OK) return rc;
+        // speculative emit straight into the output arrays (guarded by their capacity): on the common path
+        // (no gap, no overflow) the batch then needs a single host sync
+        if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
+        if ((rc = ev_end()) != MXG_OK) return rc;
+        MXG_HIP(h, hipMemcpyAsync(ctrl_host, sc(SC_CTRL).p, 32, hipMemcpyDeviceToHost, h->stream));
+        return MXG_OK;
+    }
+
+    // every contig of T, appended to `out` (synchronous: one sync per batch, retries and gap fix-ups inline)
     int sparse_all(Assembly *a, const Tables &T, OutArrays &out, uint32_t tau_hi, double cand_frac)
     {
         const size_t n_ctg = T.ctg_rec->size();
-        MXG_HIP(h, sc(SC_CTRL).ensure(64));
-        MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
         const uint32_t S = a->S_sparse;
         size_t c0 = 0;
         while (c0 < n_ctg) {
-            size_t c1 = c0;
-            uint64_t nk = 0;
-            while (c1 < n_ctg && (c1 == c0 || nk + (*T.ctg_nk)[c1] <= SPARSE_BATCH_KMERS)) nk += (*T.ctg_nk)[c1++];
-            const uint32_t r_lo = (*T.ctg_run0)[c0], r_hi = (*T.ctg_run0)[c1];
-            const uint32_t strip_lo = (*T.strip0_sparse)[r_lo], strip_hi = (*T.strip0_sparse)[r_hi];
-            const uint32_t n_strips = strip_hi - strip_lo;
-            const uint32_t n_blocks = (n_strips + 255) / 256, n_waves = n_blocks * 4;
-            const uint32_t s_tiles = (n_strips + TILE - 1) / TILE;
-            MXG_HIP(h, sc(SC_STRIP_CNT).ensure((size_t)n_strips * 4 + 16));
-            MXG_HIP(h, sc(SC_STRIP_PREF).ensure((size_t)n_strips * 4 + 16));
-            MXG_HIP(h, sc(SC_STRIP_META).ensure((size_t)n_strips * 8 + 16));
-            MXG_HIP(h, sc(SC_SBSUM).ensure((size_t)s_tiles * 4 + 16));
-            MXG_HIP(h, sc(SC_WAVE_CNT).ensure((size_t)n_waves * 4 + 16));
-            // every wave owns a slice of the arena: twice the expected candidates of 64 strips plus 6 sigma
-            const double expect = 64.0 * S * cand_frac;
-            uint64_t wave_cap = (uint64_t)(2.0 * expect + 6.0 * std::sqrt(expect)) + 64;
-            wave_cap = std::max<uint64_t>(wave_cap, h->arena_cap_hint);
-            wave_cap = std::min<uint64_t>(wave_cap, 64ull * S);  // a wave can never produce more
-            if (h->arena_cap_hint == 0) wave_cap = env_u64("MXG_WAVE_CAP", wave_cap);  // test knob
+            BatchGeom g;
+            batch_geom(T, c0, g);
+            const size_t c1 = g.c1;
+            uint64_t wave_cap = default_wave_cap(S, cand_frac);
             uint32_t ctrl[8];
             uint64_t n_cap64 = 0;
             for (int attempt = 0;; ++attempt) {
-                n_cap64 = (uint64_t)n_waves * wave_cap;
-                if (n_cap64 >= (1ull << 32))
-                    return set_err(h, MXG_ELIMIT, "candidate arena would exceed 2^32 entries; use MXG_FLAG_DENSE_ONLY");
-                const uint32_t n_cap = (uint32_t)n_cap64;
-                MXG_HIP(h, sc(SC_ARENA).ensure((size_t)n_cap * 16));
-                MXG_HIP(h, sc(SC_CAND_H).ensure((size_t)n_cap * 8));
-                MXG_HIP(h, sc(SC_CAND_K).ensure((size_t)n_cap * 4));
-                MXG_HIP(h, sc(SC_CAND_C).ensure((size_t)n_cap * 4));
-                MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, 32, h->stream));
-                SparseParams sp;
-                sp.packed = a->d_packed;
-                sp.runs = T.d_runs;
-                sp.run_strip0 = T.d_strip0_sparse;
-                sp.run_lo = r_lo;
-                sp.run_hi = r_hi;
-                sp.strip_lo = strip_lo;
-                sp.strip_hi = strip_hi;
-                sp.k = h->cfg.k;
-                sp.S = S;
-                sp.tau_hi = tau_hi;
-                sp.arena = sc(SC_ARENA).as<uint4>();
-                sp.wave_cap = (uint32_t)wave_cap;
-                sp.wave_cnt = sc(SC_WAVE_CNT).as<uint32_t>();
-                sp.ctrl = sc(SC_CTRL).as<uint32_t>();
-                sp.strip_cnt = sc(SC_STRIP_CNT).as<uint32_t>();
-                sp.strip_meta = sc(SC_STRIP_META).as<uint2>();
-                sp.init_tab = h->d_init_tab.as<uint4>();
-                sp.tab = h->tab;
-                int rc = ev_begin(batch_bases(T, c0, c1), true);
+                uint32_t n_cap_now = 0;
+                int rc = enqueue_sparse(a, T, g, wave_cap, tau_hi, out, ctrl, &n_cap_now);
                 if (rc != MXG_OK) return rc;
-                dim3 grid(n_blocks), block(256);
-                static const int abl = getenv("MXG_ABLATE") ? atoi(getenv("MXG_ABLATE")) : 0;  // profiling only
-                if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-                    hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V1_MIN>), grid, block, 0, h->stream, sp);
-                else if (abl == 1)
-                    hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 1>), grid, block, 0, h->stream, sp);
-                else if (abl == 2)
-                    hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 2>), grid, block, 0, h->stream, sp);
-                else if (abl == 4)
-                    hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 4>), grid, block, 0, h->stream, sp);
-                else
-                    hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), grid, block, 0, h->stream, sp);
-                if ((rc = ev_end()) != MXG_OK) return rc;
-                MXG_HIP(h, hipGetLastError());
-                // order the candidates: exclusive scan of per-strip counts (total = number of candidates), then scatter
-                if ((rc = ev_begin(0, false)) != MXG_OK) return rc;
-                hipLaunchKernelGGL(k_tile_sum_u32, dim3(s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, n_strips,
-                                   sc(SC_SBSUM).as<uint32_t>());
-                hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, h->stream, sc(SC_SBSUM).as<uint32_t>(), s_tiles,
-                                   reinterpret_cast<uint64_t *>(sp.ctrl + 4));
-                hipLaunchKernelGGL(k_tile_excl_u32, dim3(s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, n_strips,
-                                   sc(SC_SBSUM).as<uint32_t>(), sc(SC_STRIP_PREF).as<uint32_t>());
-                hipLaunchKernelGGL(k_reorder, dim3(n_waves), dim3(256), 0, h->stream, sp.arena, sp.wave_cnt,
-                                   sp.wave_cap, n_cap, sc(SC_STRIP_PREF).as<uint32_t>(), sp.strip_meta,
-                                   sc(SC_CAND_H).as<uint64_t>(), sc(SC_CAND_K).as<uint32_t>(),
-                                   sc(SC_CAND_C).as<uint32_t>());
-                MXG_HIP(h, hipGetLastError());
-                if ((rc = resolve_and_count<true>(T, n_cap, (uint32_t)c0, (uint32_t)c1)) != MXG_OK) return rc;
-                // speculative emit straight into the output arrays (guarded by their capacity): on the common
-                // path (no gap, no overflow) the batch then needs a single host sync
-                if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
-                if ((rc = ev_end()) != MXG_OK) return rc;
-                MXG_HIP(h, hipMemcpyAsync(ctrl, sc(SC_CTRL).p, 32, hipMemcpyDeviceToHost, h->stream));
+                n_cap64 = n_cap_now;
                 MXG_HIP(h, hipStreamSynchronize(h->stream));
                 if (ctrl[0] == 0) break;  // no wave overflowed its slice
                 if (attempt >= 2) return set_err(h, MXG_EDEVICE, "internal error: candidate arena keeps overflowing");
@@ -1229,7 +1264,8 @@ static int prepare_tables(mxg_handle *h, Assembly *a)
     return MXG_OK;
 }
 
-int sketch_assembly(mxg_handle *h, Assembly *a)
+// uploads / tables / output capacity for one assembly; *empty = nothing eligible (the sketch is empty)
+static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
 {
     if (!a->has_bases) return set_err(h, MXG_EINVAL, "assembly '%s' has no bases to sketch", a->name.c_str());
     MXG_HIP(h, hipSetDevice(h->device));
@@ -1240,6 +1276,7 @@ int sketch_assembly(mxg_handle *h, Assembly *a)
     a->flags_valid = false;
     h->graph.valid = false;
     a->n_mx = 0;
+    *empty = false;
 
     if (!a->d_packed) {  // bases to HBM
         MXG_HIP(h, a->d_packed_own.ensure(a->h_packed.size() * 4));
@@ -1251,6 +1288,7 @@ int sketch_assembly(mxg_handle *h, Assembly *a)
     }
     if (a->runs.empty()) {  // nothing eligible: empty sketch
         a->has_sketch = true;
+        *empty = true;
         return MXG_OK;
     }
     int rc = prepare_tables(h, a);
@@ -1262,8 +1300,6 @@ int sketch_assembly(mxg_handle *h, Assembly *a)
         if ((rc = upload(h, h->d_init_tab, it)) != MXG_OK) return rc;
         MXG_HIP(h, hipStreamSynchronize(h->stream));
     }
-
-    Tables T;
     T.runs = &a->runs;
     T.ctg_nk = &a->ctg_nk;
     T.ctg_rec = &a->ctg_rec;
@@ -1279,32 +1315,103 @@ int sketch_assembly(mxg_handle *h, Assembly *a)
     T.d_ctg_run0 = a->d_ctg_run0.as<uint32_t>();
     T.d_g0 = a->d_g0.as<uint64_t>();
     T.recs = &a->recs;
-
     // output capacity estimate: density 2/(w+1) per k-mer plus slack; grown on demand
-    OutArrays out{&a->d_hash, &a->d_pos, &a->d_rec, &a->d_fwd, 0};
     uint64_t cap = (uint64_t)(3.0 * (double)a->total_kmers / (double)(w + 1)) + 4096;
     MXG_HIP(h, a->d_hash.ensure(cap * 8));
     MXG_HIP(h, a->d_pos.ensure(cap * 4));
     MXG_HIP(h, a->d_rec.ensure(cap * 4));
     MXG_HIP(h, a->d_fwd.ensure(cap));
+    return MXG_OK;
+}
 
-    Driver drv(h);
-    // sparse path: expected c candidates per window; it pays while candidates are a small fraction of k-mers
+// sparse path: expected c candidates per window; it pays while candidates are a small fraction of k-mers
+static bool sparse_mode(const mxg_handle *h, double *frac, uint32_t *tau_hi)
+{
     const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : 16;
-    const double frac = (double)c / (double)w;
-    const bool sparse = !(h->cfg.flags & MXG_FLAG_DENSE_ONLY) && frac <= 0.125;
-    if (sparse) {
-        uint32_t tau_hi = (uint32_t)std::min<double>(4294967295.0, frac * 4294967296.0);
-        rc = drv.sparse_all(a, T, out, tau_hi, frac);
-    } else {
-        rc = drv.dense_all(a->d_packed, T, out, true);
-    }
+    *frac = (double)c / (double)h->cfg.w;
+    *tau_hi = (uint32_t)std::min<double>(4294967295.0, *frac * 4294967296.0);
+    return !(h->cfg.flags & MXG_FLAG_DENSE_ONLY) && *frac <= 0.125;
+}
+
+static int run_sketch_sync(mxg_handle *h, Assembly *a, const Tables &T, Driver &drv)
+{
+    OutArrays out{&a->d_hash, &a->d_pos, &a->d_rec, &a->d_fwd, 0};
+    double frac;
+    uint32_t tau_hi;
+    int rc = sparse_mode(h, &frac, &tau_hi) ? drv.sparse_all(a, T, out, tau_hi, frac) : drv.dense_all(a->d_packed, T, out, true);
     if (rc != MXG_OK) return rc;
     MXG_HIP(h, hipStreamSynchronize(h->stream));
-    if ((rc = drv.collect()) != MXG_OK) return rc;
     a->n_mx = out.n;
     a->has_sketch = true;
     return MXG_OK;
+}
+
+int sketch_assembly(mxg_handle *h, Assembly *a)
+{
+    Tables T;
+    bool empty = false;
+    int rc = prepare_sketch(h, a, T, &empty);
+    if (rc != MXG_OK || empty) return rc;
+    Driver drv(h);
+    if ((rc = run_sketch_sync(h, a, T, drv)) != MXG_OK) return rc;
+    return drv.collect();
+}
+
+// Several assemblies: every assembly whose work is one sparse batch is ENQUEUED completely (its pipeline ends with
+// a speculative emit into its own sketch arrays and an async copy of its control block), then ONE host sync covers
+// them all.  An assembly that turns out to need more (arena overflow, candidate-free stretches, output growth)
+// is simply redone through the synchronous path -- rare, and nothing of it was kept.
+int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
+{
+    if (n == 1) return sketch_assembly(h, list[0]);
+    MXG_HIP(h, hipSetDevice(h->device));
+    if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, MXG_MAX_ASSEMBLIES * 32));
+    double frac;
+    uint32_t tau_hi;
+    const bool sparse = sparse_mode(h, &frac, &tau_hi);
+    Driver drv(h);
+    std::vector<Tables> tabs(n);
+    std::vector<int> state(n, 0);  // 0 = synchronous path, 1 = enqueued, 2 = done (empty)
+    std::vector<uint32_t> ncap(n, 0);
+    int rc;
+    for (size_t i = 0; i < n; ++i) {
+        bool empty = false;
+        if ((rc = prepare_sketch(h, list[i], tabs[i], &empty)) != MXG_OK) return rc;
+        if (empty) {
+            state[i] = 2;
+            continue;
+        }
+        if (!sparse || i >= MXG_MAX_ASSEMBLIES) continue;
+        Driver::BatchGeom g;
+        drv.batch_geom(tabs[i], 0, g);
+        if (g.c1 != tabs[i].ctg_rec->size()) continue;  // more than one batch: synchronous path
+        OutArrays out{&list[i]->d_hash, &list[i]->d_pos, &list[i]->d_rec, &list[i]->d_fwd, 0};
+        uint32_t *slot = h->pinned_ctrl + 8 * i;
+        memset(slot, 0xFF, 32);
+        if ((rc = drv.enqueue_sparse(list[i], tabs[i], g, drv.default_wave_cap(list[i]->S_sparse, frac), tau_hi, out, slot,
+                                     &ncap[i])) != MXG_OK)
+            return rc;
+        state[i] = 1;
+    }
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < n; ++i) {
+        if (state[i] != 1) continue;
+        Assembly *a = list[i];
+        const uint32_t *c = h->pinned_ctrl + 8 * i;
+        const uint64_t total = (uint64_t)c[2] | ((uint64_t)c[3] << 32), n_cand = (uint64_t)c[4] | ((uint64_t)c[5] << 32);
+        const uint64_t cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
+        if (c[0] == 0 && c[1] == 0 && n_cand > 0 && total <= cap) {
+            a->n_mx = total;
+            a->has_sketch = true;
+            h->stat_candidates += n_cand;
+            state[i] = 2;
+        } else {
+            state[i] = 0;  // redo synchronously
+        }
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (state[i] == 0 && (rc = run_sketch_sync(h, list[i], tabs[i], drv)) != MXG_OK) return rc;
+    return drv.collect();
 }
 
 int ensure_strand(mxg_handle *h, Assembly *a)
