@@ -135,6 +135,18 @@ const char *mxg_last_error(const mxg_handle *h); /* h may be NULL: error of the 
    every mxg_add_assembly_* returns the new assembly's index (>= 0) on success, a negative code on failure */
 /* FASTA file (plain text; `>id comment`, multi-line, any case; non-ACGTU bytes invalidate k-mers). */
 int mxg_add_assembly_fasta(mxg_handle *h, const char *name, double weight, const char *fasta_path);
+/* Contig sharding for one-process-per-GPU runs: the same FASTA is opened by every rank; ALL records are registered
+   (ids, lengths: record indices are global) but only the records of shard `shard` of `n_shards` are packed and
+   sketched.  Shards are contiguous record ranges balanced by base count (mxg_shard_range), so concatenating the ranks'
+   sketches in rank order yields the globally (record,pos)-sorted sketch. */
+int mxg_add_assembly_fasta_shard(mxg_handle *h, const char *name, double weight, const char *fasta_path,
+                                 uint32_t shard, uint32_t n_shards);
+/* records [*lo,*hi) of shard `shard`: cut points at multiples of total/n_shards of the cumulative base count
+   (a record belongs to the shard its midpoint falls in).  Host only; usable without a device. */
+int mxg_shard_range(const uint64_t *lengths, uint64_t n_records, uint32_t shard, uint32_t n_shards, uint64_t *lo,
+                    uint64_t *hi);
+/* the record range this handle sketches for an assembly ([0,n_records) unless added with ..._fasta_shard) */
+int mxg_assembly_shard(const mxg_handle *h, int assembly, uint64_t *lo, uint64_t *hi);
 /* Records already in host memory: record r is ascii[offsets[r] .. offsets[r+1]) with id ids[r]. */
 int mxg_add_assembly_buffers(mxg_handle *h, const char *name, double weight, const uint8_t *ascii,
                              const uint64_t *offsets, const char *const *ids, uint64_t n_records);

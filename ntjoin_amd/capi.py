@@ -13,7 +13,8 @@ ABI_VERSION = 1
 
 SYMBOLS = [
     "mxg_abi_version", "mxg_create", "mxg_destroy", "mxg_last_error",
-    "mxg_add_assembly_fasta", "mxg_add_assembly_buffers", "mxg_add_assembly_packed_device",
+    "mxg_add_assembly_fasta", "mxg_add_assembly_fasta_shard", "mxg_shard_range", "mxg_assembly_shard",
+    "mxg_add_assembly_buffers", "mxg_add_assembly_packed_device",
     "mxg_add_assembly_tsv", "mxg_add_assembly_minimizers", "mxg_num_assemblies", "mxg_assembly_name",
     "mxg_record_id", "mxg_record_length", "mxg_num_records", "mxg_assembly_weight",
     "mxg_sketch", "mxg_get_sketch", "mxg_get_sketch_device", "mxg_compute_strands", "mxg_set_sketch_device",
@@ -102,6 +103,9 @@ def load():
     L.mxg_last_error.argtypes = [vp]
     L.mxg_last_error.restype = cp
     L.mxg_add_assembly_fasta.argtypes = [vp, cp, C.c_double, cp]
+    L.mxg_add_assembly_fasta_shard.argtypes = [vp, cp, C.c_double, cp, C.c_uint32, C.c_uint32]
+    L.mxg_shard_range.argtypes = [C.POINTER(u64), u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
+    L.mxg_assembly_shard.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(u64)]
     L.mxg_add_assembly_buffers.argtypes = [vp, cp, C.c_double, vp, C.POINTER(u64), C.POINTER(cp), u64]
     L.mxg_add_assembly_packed_device.argtypes = [vp, cp, C.c_double, vp, C.POINTER(u64), C.POINTER(u64),
                                                  C.POINTER(cp), u64]

@@ -126,6 +126,39 @@ int mxg_add_assembly_fasta(mxg_handle *h, const char *name, double weight, const
     return commit(h, a, rc);
 }
 
+int mxg_add_assembly_fasta_shard(mxg_handle *h, const char *name, double weight, const char *fasta_path,
+                                 uint32_t shard, uint32_t n_shards)
+{
+    Assembly *a;
+    int rc = new_assembly(h, name, weight, &a);
+    if (rc != MXG_OK) return rc;
+    if (!fasta_path || n_shards == 0 || shard >= n_shards)
+        return commit(h, a, set_err(h, MXG_EINVAL, "need fasta_path and shard < n_shards"));
+    try {
+        rc = load_fasta(h, a, fasta_path, shard, n_shards);
+    } catch (const std::bad_alloc &) {
+        rc = set_err(h, MXG_ENOMEM, "out of host memory reading '%s'", fasta_path);
+    }
+    return commit(h, a, rc);
+}
+
+int mxg_shard_range(const uint64_t *lengths, uint64_t n_records, uint32_t shard, uint32_t n_shards, uint64_t *lo,
+                    uint64_t *hi)
+{
+    if ((!lengths && n_records) || !lo || !hi || n_shards == 0 || shard >= n_shards) return MXG_EINVAL;
+    shard_range(lengths, n_records, shard, n_shards, lo, hi);
+    return MXG_OK;
+}
+
+int mxg_assembly_shard(const mxg_handle *h, int assembly, uint64_t *lo, uint64_t *hi)
+{
+    if (!h || !lo || !hi || assembly < 0 || (size_t)assembly >= h->asms.size()) return MXG_EINVAL;
+    const Assembly *a = h->asms[assembly];
+    *lo = std::min<uint64_t>(a->shard_lo, a->recs.size());
+    *hi = std::min<uint64_t>(a->shard_hi, a->recs.size());
+    return MXG_OK;
+}
+
 int mxg_add_assembly_buffers(mxg_handle *h, const char *name, double weight, const uint8_t *ascii,
                              const uint64_t *offsets, const char *const *ids, uint64_t n_records)
 {
@@ -381,6 +414,7 @@ int mxg_set_sketch_device(mxg_handle *h, int assembly, const void *d_out_hash, c
     a->n_mx = n;
     a->has_sketch = true;
     a->fwd_valid = true;
+    a->foreign_sketch = true;
     a->host_valid = false;
     a->flags_valid = false;
     h->graph.valid = false;

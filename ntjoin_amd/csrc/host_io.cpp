@@ -95,11 +95,23 @@ struct Ingest {
     uint64_t rec_start = 0, rec_pos = 0, run_len = 0;
     std::vector<std::pair<uint32_t, uint32_t>> rec_runs;  // (pos0, n_kmers) of the open record
     uint32_t cur_word = 0;
+    bool skip = false;        // current record is outside this handle's shard: only its length is recorded
+    bool lengths_only = false;  // first pass of a sharded load: record nothing but lengths
+    uint64_t keep_lo = 0, keep_hi = ~0ull;
+    std::vector<uint64_t> lengths;
 
     Ingest(mxg_handle *h_, Assembly *a_) : h(h_), a(a_), k(h_->cfg.k), w(h_->cfg.w) {}
 
     void begin_record(const std::string &id)
     {
+        if (lengths_only) {
+            lengths.push_back(0);
+            rec_pos = 0;
+            skip = true;
+            return;
+        }
+        const uint64_t ridx = a->recs.size();
+        skip = ridx < keep_lo || ridx >= keep_hi;
         cur_base = (cur_base + 15) & ~uint64_t(15);
         Record r;
         r.id = id;
@@ -119,6 +131,10 @@ struct Ingest {
     }
     void add_bases(const uint8_t *s, size_t n, bool keep_text)
     {
+        if (skip) {
+            rec_pos += n;
+            return;
+        }
         const uint8_t *lut = code_lut();
         if (keep_text) a->text.append(reinterpret_cast<const char *>(s), n);
         for (size_t i = 0; i < n; ++i) {
@@ -139,6 +155,19 @@ struct Ingest {
     }
     int end_record()
     {
+        if (lengths_only) {
+            lengths.back() = rec_pos;
+            return MXG_OK;
+        }
+        if (skip) {  // registered (global record index, id, length) but neither packed nor sketched here
+            Record &r = a->recs.back();
+            r.len = rec_pos;
+            if (r.len >= (uint64_t(1) << 32))
+                return set_err(h, MXG_ELIMIT, "record '%s' has %llu bases; the engine indexes positions with 32 bits",
+                               r.id.c_str(), (unsigned long long)r.len);
+            a->total_bases += 0;
+            return MXG_OK;
+        }
         close_run();
         if (rec_pos & 15) a->h_packed.push_back(cur_word);
         cur_word = 0;
@@ -189,12 +218,35 @@ static std::string header_id(const char *p, size_t n)
     return std::string(p, e);
 }
 
-int load_fasta(mxg_handle *h, Assembly *a, const char *path)
+void shard_range(const uint64_t *lengths, uint64_t n, uint32_t shard, uint32_t n_shards, uint64_t *lo, uint64_t *hi)
 {
-    FILE *f = fopen(path, "rb");
-    if (!f) return set_err(h, MXG_EIO, "cannot open FASTA '%s'", path);
-    const bool keep = !(h->cfg.flags & MXG_FLAG_DROP_SEQ);
-    Ingest in(h, a);
+    // a record belongs to the shard that the midpoint of its base range falls in (cumulative over the file)
+    long double total = 0;
+    for (uint64_t r = 0; r < n; ++r) total += (long double)lengths[r];
+    uint64_t l = n, hgh = n;
+    bool have_lo = false;
+    long double cum = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+        const long double mid = cum + (long double)lengths[r] / 2;
+        uint32_t s = total > 0 ? (uint32_t)std::min<long double>((long double)n_shards - 1, mid * n_shards / total) : 0;
+        if (!have_lo && s >= shard) {
+            l = r;
+            have_lo = true;
+        }
+        if (s > shard) {
+            hgh = r;
+            break;
+        }
+        cum += (long double)lengths[r];
+    }
+    if (!have_lo) l = n;
+    if (hgh < l) hgh = l;
+    *lo = l;
+    *hi = hgh;
+}
+
+static int parse_fasta_stream(mxg_handle *h, FILE *f, const char *path, Ingest &in, bool keep)
+{
     std::vector<char> buf(1 << 22);
     std::string carry;  // partial header line across buffer boundaries
     bool in_header = false, have_rec = false, at_line_start = true;
@@ -232,7 +284,6 @@ int load_fasta(mxg_handle *h, Assembly *a, const char *path)
         }
     }
     if (ferror(f)) rc = set_err(h, MXG_EIO, "read error on '%s'", path);
-    fclose(f);
     if (rc != MXG_OK) return rc;
     if (in_header) {  // header without trailing newline at EOF
         if (have_rec) rc = in.end_record();
@@ -240,6 +291,29 @@ int load_fasta(mxg_handle *h, Assembly *a, const char *path)
         have_rec = true;
     }
     if (rc == MXG_OK && have_rec) rc = in.end_record();
+    return rc;
+}
+
+int load_fasta(mxg_handle *h, Assembly *a, const char *path, uint32_t shard, uint32_t n_shards)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return set_err(h, MXG_EIO, "cannot open FASTA '%s'", path);
+    const bool keep = !(h->cfg.flags & MXG_FLAG_DROP_SEQ);
+    Ingest in(h, a);
+    int rc = MXG_OK;
+    if (n_shards > 1) {  // pass 1: record lengths -> this rank's contiguous record range (same on every rank)
+        in.lengths_only = true;
+        rc = parse_fasta_stream(h, f, path, in, false);
+        if (rc == MXG_OK) {
+            shard_range(in.lengths.data(), in.lengths.size(), shard, n_shards, &in.keep_lo, &in.keep_hi);
+            a->shard_lo = in.keep_lo;
+            a->shard_hi = in.keep_hi;
+            in.lengths_only = false;
+            rewind(f);
+        }
+    }
+    if (rc == MXG_OK) rc = parse_fasta_stream(h, f, path, in, keep);
+    fclose(f);
     if (rc != MXG_OK) return rc;
     in.finish();
     a->has_text = keep;
@@ -481,6 +555,7 @@ int write_tsv(mxg_handle *h, Assembly *a, const char *path, int with_pos, int wi
     OutBuf o(f);
     std::string kmer(k, 'N');
     for (size_t r = 0; r < a->recs.size(); ++r) {
+        if (r < a->shard_lo || r >= a->shard_hi) continue;  // sharded load: this rank prints its own records (rank-ordered parts concatenate to the full file)
         const Record &rec = a->recs[r];
         o.put(rec.id);
         o.put('\t');

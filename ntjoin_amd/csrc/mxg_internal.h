@@ -75,6 +75,7 @@ struct Assembly {
     double weight = 0.0;
     std::vector<Record> recs;
     uint64_t total_bases = 0;
+    uint64_t shard_lo = 0, shard_hi = ~0ull;  // records this handle holds bases for (fasta_shard); others: id + length only
     // bases
     bool has_bases = false;
     std::string text;                // concatenated record text as read (kept unless MXG_FLAG_DROP_SEQ)
@@ -100,6 +101,7 @@ struct Assembly {
     uint64_t n_mx = 0;
     DevBuf d_hash, d_pos, d_rec, d_fwd, d_rec_base;
     bool fwd_valid = false;  // d_fwd filled (lazily: k_strand)
+    bool foreign_sketch = false;  // sketch holds minimizers of records this handle has no bases for (gathered / imported)
     bool host_valid = false;
     std::vector<uint64_t> h_hash;
     std::vector<uint32_t> h_pos, h_rec;
@@ -164,7 +166,8 @@ int set_err(mxg_handle *h, int code, const char *fmt, ...);
     } while (0)
 
 // host_io.cpp
-int load_fasta(mxg_handle *h, Assembly *a, const char *path);
+int load_fasta(mxg_handle *h, Assembly *a, const char *path, uint32_t shard = 0, uint32_t n_shards = 1);
+void shard_range(const uint64_t *lengths, uint64_t n, uint32_t shard, uint32_t n_shards, uint64_t *lo, uint64_t *hi);
 int load_buffers(mxg_handle *h, Assembly *a, const uint8_t *ascii, const uint64_t *offsets,
                  const char *const *ids, uint64_t n_records);
 int load_tsv(mxg_handle *h, Assembly *a, const char *path, std::vector<uint64_t> &hash,

@@ -1273,6 +1273,7 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
     a->has_sketch = false;
     a->host_valid = false;
     a->fwd_valid = false;
+    a->foreign_sketch = false;
     a->flags_valid = false;
     h->graph.valid = false;
     a->n_mx = 0;
@@ -1419,7 +1420,7 @@ int ensure_strand(mxg_handle *h, Assembly *a)
     if (a->fwd_valid || !a->has_sketch) return MXG_OK;
     MXG_HIP(h, hipSetDevice(h->device));
     MXG_HIP(h, a->d_fwd.ensure(std::max<uint64_t>(a->n_mx, 16)));
-    if (a->has_bases && a->d_packed && a->n_mx) {
+    if (a->has_bases && a->d_packed && a->n_mx && !a->foreign_sketch) {
         if (!a->d_rec_base.p) {
             std::vector<uint64_t> rb(a->recs.size());
             for (size_t r = 0; r < rb.size(); ++r) rb[r] = a->recs[r].base_off;
@@ -1515,7 +1516,8 @@ int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t w
     MXG_HIP(h, hipGetLastError());
     a->n_mx = total;
     a->has_sketch = true;
-    a->fwd_valid = false;   // strands do not travel; an assembly without bases reports '+'
+    a->fwd_valid = false;   // strands do not travel; a gathered sketch reports '+'
+    a->foreign_sketch = true;
     a->host_valid = false;
     a->flags_valid = false;
     h->graph.valid = false;

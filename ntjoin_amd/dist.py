@@ -130,3 +130,41 @@ def allgather_union_graph(eng, k, w, device, union=None, group=None):
         union.set_sketch_gathered(a, recv.data_ptr(), nmax, counts, rec_off)
     union.build_graph()
     return union
+
+
+def shard_range(lengths, shard, n_shards):
+    """[lo, hi) of the records shard `shard` owns: contiguous, balanced by base count (the library's rule)."""
+    import ctypes as C
+    from . import capi
+    lib = capi.load()
+    arr = np.ascontiguousarray(lengths, dtype=np.uint64)
+    lo, hi = C.c_uint64(), C.c_uint64()
+    rc = lib.mxg_shard_range(arr.ctypes.data_as(C.POINTER(C.c_uint64)), len(arr), int(shard), int(n_shards),
+                             C.byref(lo), C.byref(hi))
+    if rc != 0:
+        raise ValueError("mxg_shard_range: bad arguments")
+    return int(lo.value), int(hi.value)
+
+
+def allgather_inplace(eng, device, group=None):
+    """Exchange step for engines whose assemblies were added with add_fasta_shard (global record indices, contiguous
+    record ranges per rank): every assembly's rank-local sketch is replaced by the union, in rank order = global
+    (record,pos) order.  One small all-gather of counts, one all-gather per assembly."""
+    A = eng.n_assemblies
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", device)
+    meta = torch.tensor([eng.sketch_size(a) for a in range(A)], dtype=torch.int64, device=dev)
+    metas = torch.empty((world, A), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(metas.view(-1), meta, group=group)
+    metas = metas.cpu().numpy()
+    zeros = np.zeros(world, dtype=np.uint64)
+    for a in range(A):
+        counts = metas[:, a].astype(np.uint64)
+        nmax = (max(int(counts.max()), 1) + 7) // 8 * 8
+        send = torch.empty(16 * nmax, dtype=torch.uint8, device=dev)
+        recv = torch.empty(world * 16 * nmax, dtype=torch.uint8, device=dev)
+        eng.pack_sketch_device(a, send.data_ptr(), nmax)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        torch.cuda.current_stream().synchronize()
+        eng.set_sketch_gathered(a, recv.data_ptr(), nmax, counts, zeros)
+    return metas

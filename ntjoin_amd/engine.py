@@ -78,6 +78,16 @@ class MxEngine:
         return self._check(self._lib.mxg_add_assembly_fasta(self._h, str(name).encode(), float(weight),
                                                             str(fasta_path).encode()))
 
+    def add_fasta_shard(self, name, weight, fasta_path, shard, n_shards):
+        """every record is registered (global indices) but only shard `shard` of `n_shards` is packed and sketched"""
+        return self._check(self._lib.mxg_add_assembly_fasta_shard(self._h, str(name).encode(), float(weight),
+                                                                  str(fasta_path).encode(), int(shard), int(n_shards)))
+
+    def assembly_shard(self, a):
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.mxg_assembly_shard(self._h, int(a), C.byref(lo), C.byref(hi)))
+        return int(lo.value), int(hi.value)
+
     def add_records(self, name, weight, records):
         """records: iterable of (id, sequence str/bytes)."""
         ids, seqs = [], []

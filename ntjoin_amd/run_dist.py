@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""
+Multi-GPU driver of the hot path, one process per GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        -m ntjoin_amd.run_dist -k 32 -w 1000 -p out --target scaf.fa --target_weight 1 \
+        --references ref1.fa ref2.fa --reference_weights 2 2
+
+Every rank opens every FASTA, keeps the records of its shard (contiguous record ranges balanced by bases; record
+indices are global), sketches them, and writes its part of `<fasta>.k<k>.w<w>.tsv` (rank 0 concatenates the parts in
+rank order = input order).  The sketches are exchanged with one RCCL all-gather per assembly; every rank then holds
+the full sketches and builds the minimizer graph; rank 0 writes `<prefix>.mx.dot`.  Same file names as ntJoin
+(reference ntJoin:26,204 and bin/ntjoin.py:28).
+"""
+import argparse
+import os
+import shutil
+import sys
+
+import torch
+import torch.distributed as dist
+
+from .dist import allgather_inplace
+from .engine import MxEngine
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="ntJoin hot path on N GPUs: FASTA -> .tsv sketches + <prefix>.mx.dot")
+    ap.add_argument("-k", type=int, default=32)
+    ap.add_argument("-w", type=int, default=1000)
+    ap.add_argument("-p", "--prefix", default="out")
+    ap.add_argument("--target", required=True)
+    ap.add_argument("--target_weight", type=float, default=1.0)
+    ap.add_argument("--references", nargs="+", required=True)
+    ap.add_argument("--reference_weights", nargs="+", type=float, required=True)
+    ap.add_argument("--variant", default="v2")
+    args = ap.parse_args(argv)
+    if len(args.references) != len(args.reference_weights):
+        sys.exit("ERROR: The length of supplied reference weights and number of references must be equal.")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    try:
+        fastas = list(args.references) + [args.target]          # references first (CLI order), target last
+        weights = list(args.reference_weights) + [args.target_weight]
+        tsvs = [f"{fa}.k{args.k}.w{args.w}.tsv" for fa in fastas]
+        with MxEngine(k=args.k, w=args.w, variant=args.variant, device=local_rank) as eng:
+            for fa, wt, tsv in zip(fastas, weights, tsvs):
+                eng.add_fasta_shard(tsv, wt, fa, rank, world)
+            eng.sketch()
+            for a, tsv in enumerate(tsvs):                       # this rank's records only
+                eng.write_tsv(a, f"{tsv}.part{rank}", with_pos=True, with_strand=False, with_seq=True)
+            dist.barrier()
+            if rank == 0:
+                for tsv in tsvs:
+                    with open(tsv, "wb") as out:
+                        for r in range(world):
+                            with open(f"{tsv}.part{r}", "rb") as part:
+                                shutil.copyfileobj(part, out)
+                            os.remove(f"{tsv}.part{r}")
+            allgather_inplace(eng, local_rank)
+            eng.build_graph()
+            if rank == 0:
+                eng.write_dot(args.prefix + ".mx.dot")
+                st = eng.stats()
+                print(f"ntjoin_amd.run_dist: {world} GPU(s), {st['minimizers']} minimizers, {st['vertices']} vertices, "
+                      f"{st['edges']} edges -> {args.prefix}.mx.dot", flush=True)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

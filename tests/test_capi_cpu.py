@@ -77,3 +77,20 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(root, f), encoding="utf-8").read()
                 assert "mx_oracle" not in text and "graph_oracle" not in text and "import oracle" not in text, f
+
+
+def test_shard_range_partitions_records():
+    """contig sharding rule (host only): contiguous ranges, every record in exactly one shard, balanced by bases"""
+    import numpy as np
+    from ntjoin_amd.dist import shard_range
+    rng = np.random.default_rng(5)
+    for lens in ([10], [5, 5], [0, 0, 7], list(rng.integers(1, 10**6, size=200)),
+                 [250_000_000, 50_000_000, 240_000_000, 60_000_000] * 6, []):
+        for world in (1, 2, 3, 8):
+            ranges = [shard_range(lens, s, world) for s in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == len(lens)
+            for (lo, hi), (lo2, _) in zip(ranges, ranges[1:]):
+                assert lo <= hi == lo2
+            if len(lens) >= 50 * world:
+                loads = [sum(int(x) for x in lens[lo:hi]) for lo, hi in ranges]
+                assert max(loads) <= sum(loads) / world + max(int(x) for x in lens)

@@ -45,3 +45,56 @@ def test_union_graph_single_rank_nccl():
             union.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_run_dist_single_rank(tmp_path):
+    """the torchrun-able FASTA driver with one rank: TSVs byte-identical to the committed sketches, canonical
+    .mx.dot identical to the reference's (sharding with world=1 is the identity; world>1 differs only in who holds
+    which contiguous record range, covered by test_shard_range_partitions_records + the gloo exchange tests)"""
+    import shutil
+    import subprocess
+    import sys
+    from oracle import graph_oracle as go
+    from tests.conftest import REPO
+    meta = load_case("synth3_w50")["meta"]
+    asms = meta["refs"] + [meta["target"]]
+    for a in asms:
+        shutil.copy(os.path.join(FASTA, a["fasta"]), tmp_path / a["fasta"])
+    env = dict(os.environ, PYTHONPATH=REPO, MASTER_PORT="29577")
+    cmd = [sys.executable, "-m", "ntjoin_amd.run_dist", "-k", str(meta["k"]), "-w", str(meta["w"]), "-p", "out",
+           "--target", meta["target"]["fasta"], "--target_weight", str(meta["target"]["weight"]),
+           "--references"] + [a["fasta"] for a in meta["refs"]] + ["--reference_weights"] + \
+          [str(a["weight"]) for a in meta["refs"]]
+    subprocess.check_call(cmd, cwd=tmp_path, env=env)
+    import filecmp
+    for a in asms:
+        assert filecmp.cmp(str(tmp_path / a["tsv"]), os.path.join(GOLDEN, "cases", meta["name"], a["tsv"]), shallow=False)
+    with open(os.path.join(GOLDEN, "cases", meta["name"], "reference.mx.dot"), encoding="utf-8") as fh:
+        want = go.canonical_dot_from_text(fh.read())
+    assert go.canonical_dot_from_text((tmp_path / "out.mx.dot").read_text(encoding="utf-8")) == want
+
+
+def test_sharded_load_equals_full_load():
+    """add_fasta_shard(s, n) for all s, concatenated in shard order, equals add_fasta (sketch arrays, global records)"""
+    from ntjoin_amd.engine import MxEngine
+    fa = os.path.join(FASTA, "scaf.more_seqs.fa")
+    with MxEngine(k=32, w=100) as eng:
+        eng.add_fasta("x", 1.0, fa)
+        eng.sketch()
+        full = eng.get_sketch(0)
+    for world in (2, 3):
+        parts = []
+        covered = []
+        for s in range(world):
+            with MxEngine(k=32, w=100) as eng:
+                eng.add_fasta_shard("x", 1.0, fa, s, world)
+                eng.sketch()
+                sk = eng.get_sketch(0)
+                lo, hi = eng.assembly_shard(0)
+                covered.append((lo, hi))
+                assert sk["record_ids"] == full["record_ids"]
+                assert all(lo <= r < hi for r in sk["record"].tolist())
+                parts.append(sk)
+        assert covered[0][0] == 0 and covered[-1][1] == len(full["record_ids"])
+        for key in ("out_hash", "pos", "record", "forward"):
+            assert np.array_equal(np.concatenate([p[key] for p in parts]), full[key]), (world, key)
