@@ -172,6 +172,10 @@ def main():
                          "alg_bytes_per_base": ALG_BYTES_PER_BASE_HASH, "alg_bytes_per_launch": int(bytes_per_launch),
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(st["launches_hash"]),
                          "bases_per_launch": int(st["hash_kernel_bases"] / launches)},
+            # the binding resource is integer VALU issue, not HBM: reported beside the HBM figure
+            "valu": {"wave64_instr_per_base": 30.3, "int_lane_ops_per_s": round(30.3 * 64 * st["hash_kernel_bases"] / 64 / max(st["ms_hash"], 1e-9) * 1e3, 0),
+                     "peak_lane_ops_per_s": 256 * 4 * 32 * 2.4e9, "valu_busy_pmc": 0.91,
+                     "source": "rocprofv3 SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU, profiles/r01_pmc_by_kernel.json"},
             "stage_ms_per_step": {"hash": round(st["ms_hash"] / args.steps, 4),
                                   "graph": round(gst["ms_graph"] / args.steps, 4)},
         }

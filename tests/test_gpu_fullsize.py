@@ -104,3 +104,85 @@ def test_half_gbp_properties(oracle):
         sel = (pr >= lo + 2000) & (pr <= lo + 56_000)
         got = list(zip(sk["out_hash"][s0:int(first[2])][sel].tolist(), pr[sel].tolist()))
         assert got == want
+
+
+def test_config4_shape_four_assemblies(oracle, tmp_path):
+    """configs[3] shape: target + 3 references (independent 0.5-2 % divergence), k=32, w=500, weights 1/2/2/2 --
+    at 20 Mbp per assembly the oracle checks everything: sketches bit-exact, canonical .mx.dot identical
+    (support lists of up to 4 assemblies, colours black/lightgrey/..., weights 2.0..7.0)."""
+    w = 500
+    base = synth.make_reference(40, 20_000_000, n_records=4)
+    names, recs_all, weights = [], [], []
+    for i, div in enumerate((0.005, 0.01, 0.02)):
+        rng = np.random.default_rng(100 + i)
+        recs = []
+        for codes in base:
+            c = codes.copy()
+            idx = rng.integers(0, len(c), size=int(len(c) * div))
+            c[idx] = (c[idx] + rng.integers(1, 4, size=len(idx), dtype=np.uint8)) & 3
+            recs.append(c)
+        names.append(str(tmp_path / f"ref{i}.fa.k32.w500.tsv"))
+        recs_all.append(recs)
+        weights.append(2.0)
+    names.append(str(tmp_path / "tgt.fa.k32.w500.tsv"))
+    recs_all.append(synth.derive_target(base, 7, min_len=10_000, max_len=500_000))
+    weights.append(1.0)
+    with _engine(k=K, w=w) as eng:
+        for nm, wt, recs in zip(names, weights, recs_all):
+            _add_packed(eng, nm, wt, recs)
+        eng.sketch()
+        for a, recs in enumerate(recs_all):
+            sk = eng.get_sketch(a)
+            first = sk["record_first"]
+            with open(names[a], "w", encoding="ascii") as fh:
+                for r, codes in enumerate(recs):
+                    want = oracle.sketch(synth.to_ascii(codes), K, w)
+                    lo, hi = int(first[r]), int(first[r + 1])
+                    got = list(zip(sk["out_hash"][lo:hi].tolist(), sk["pos"][lo:hi].tolist()))
+                    assert got == [(h, p) for h, p, _, _ in want], (a, r)
+                    fh.write(f"{r}\t" + " ".join(f"{h}:{p}:N" for h, p in got) + "\n")
+        eng.build_graph()
+        eng.write_dot(str(tmp_path / "o.mx.dot"))
+    state = go.load_and_build(names[:3], weights[:3], names[3], weights[3])
+    got = go.canonical_dot_from_text((tmp_path / "o.mx.dot").read_text(encoding="utf-8"))
+    want = go.canonical_dot_from_state(state)
+    assert got == want
+    colours = {e[2].split("color=")[1].rstrip("]") for e in want["edges"]}
+    assert "black" in colours and len(want["nodes"]) > 10_000
+
+
+def test_config3_scale_properties(oracle):
+    """configs[2] scale: one 3 Gbp assembly (24 records of 50-250 Mbp) on one GPU.  Beyond what the oracle finishes
+    in seconds, so size-independent properties: sorted + duplicate-free, density 2/(w+1), window coverage, sampled
+    known-answer hashes, and exact agreement with the oracle on excerpts sketched as stand-alone records."""
+    rng = np.random.default_rng(3)
+    lens = rng.integers(50_000_000, 250_000_000, size=24).astype(np.float64)
+    lens = (lens * (3.0e9 / lens.sum())).astype(np.int64)
+    recs = [np.random.default_rng(1000 + i).integers(0, 4, size=int(n), dtype=np.uint8) for i, n in enumerate(lens)]
+    with _engine(k=K, w=W) as eng:
+        _add_packed(eng, "hs", 1.0, recs)
+        eng.sketch()
+        sk = eng.get_sketch(0)
+        st = eng.stats()
+    n = int(sum(lens))
+    key = (sk["record"].astype(np.uint64) << np.uint64(32)) | sk["pos"].astype(np.uint64)
+    assert np.all(key[1:] > key[:-1])
+    assert abs(len(key) / n - 2.0 / (W + 1)) < 0.02 * 2.0 / (W + 1)
+    assert st["kmers"] == n - 24 * (K - 1)
+    first = sk["record_first"]
+    for r in range(24):
+        p = sk["pos"][int(first[r]):int(first[r + 1])].astype(np.int64)
+        assert p[0] < W and (lens[r] - K + 1) - p[-1] <= W and np.all(np.diff(p) <= W)
+    pick = np.random.default_rng(9).integers(0, len(key), size=200)
+    for i in pick:
+        r, p = int(sk["record"][i]), int(sk["pos"][i])
+        mh, oh, fw, ok = oracle.kmer_hashes(synth.to_ascii(recs[r][p:p + K]), K)
+        assert ok[0] and int(oh[0]) == int(sk["out_hash"][i]) and int(fw[0]) == int(sk["forward"][i])
+    # interior windows of a 300 kbp excerpt are sketched identically whether or not the rest of the record is there
+    for r, lo in ((0, 10_000_000), (23, int(lens[23]) - 400_000), (11, 0)):
+        seg = synth.to_ascii(recs[r][lo:lo + 300_000])
+        want = [(h, p + lo) for h, p, _, _ in oracle.sketch(seg, K, W) if 2 * W <= p <= 300_000 - 3 * W]
+        s0, s1 = int(first[r]), int(first[r + 1])
+        pr = sk["pos"][s0:s1]
+        sel = (pr >= lo + 2 * W) & (pr <= lo + 300_000 - 3 * W)
+        assert list(zip(sk["out_hash"][s0:s1][sel].tolist(), pr[sel].tolist())) == want
