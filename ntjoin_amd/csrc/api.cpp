@@ -64,6 +64,7 @@ int mxg_create(const mxg_config *cfg, mxg_handle **out)
             return fail(e, "hipStreamCreate");
         h->own_stream = true;
     }
+    if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
     make_hash_tab(cfg->k, &h->tab);
@@ -76,6 +77,10 @@ void mxg_destroy(mxg_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) {
+        (void)hipStreamSynchronize(h->stream2);
+        (void)hipStreamDestroy(h->stream2);
+    }
     for (auto *a : h->asms) delete a;
     h->asms.clear();
     if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -136,6 +136,7 @@ struct mxg_handle {
     mxg_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // second stream of the pipelined multi-assembly sketch (always library-owned)
     bool own_stream = false;
     std::string err;
     std::vector<mxg::Assembly *> asms;
@@ -145,7 +146,7 @@ struct mxg_handle {
     mxg::DevBuf d_init_tab;  // direct-initialisation table (k/4 x 256 x 16 B), built by the first sketch
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
     // scratch reused across calls
-    mxg::DevBuf scratch[40];
+    mxg::DevBuf scratch[2][40];  // two sets, indexed by mxg::Scratch (sketch.hip): one per in-flight sketch driver
     mxg::DevBuf g_keys, g_seen, g_dup, g_vid, g_ctl, g_vhash, g_vpos, g_vrec, g_fv, g_frec, g_nxt, g_prv, g_eflag,
         g_ebs, g_eu, g_ev, g_esup, g_ew;  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
     uint64_t arena_cap_hint = 0;

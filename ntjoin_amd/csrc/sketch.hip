@@ -736,11 +736,11 @@ static hipError_t grow_preserve(DevBuf &b, size_t used_bytes, size_t need_bytes,
 }
 
 template <class T>
-static int upload(mxg_handle *h, DevBuf &b, const std::vector<T> &v)
+static int upload(mxg_handle *h, DevBuf &b, const std::vector<T> &v, hipStream_t st = nullptr)
 {
     MXG_HIP(h, b.ensure(std::max<size_t>(v.size() * sizeof(T), 16)));
     if (!v.empty())
-        MXG_HIP(h, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+        MXG_HIP(h, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st ? st : h->stream));
     return MXG_OK;
 }
 
@@ -762,13 +762,13 @@ struct OutArrays {
     uint64_t cap() const { return std::min<uint64_t>({hash->bytes / 8, pos->bytes / 4, rec->bytes / 4, fwd->bytes}); }
 };
 
-static int out_reserve(mxg_handle *h, OutArrays &o, uint64_t need)
+static int out_reserve(mxg_handle *h, OutArrays &o, uint64_t need, hipStream_t st)
 {
     if (need <= o.cap()) return MXG_OK;
-    MXG_HIP(h, grow_preserve(*o.hash, o.n * 8, need * 8, h->stream));
-    MXG_HIP(h, grow_preserve(*o.pos, o.n * 4, need * 4, h->stream));
-    MXG_HIP(h, grow_preserve(*o.rec, o.n * 4, need * 4, h->stream));
-    MXG_HIP(h, grow_preserve(*o.fwd, o.n, need, h->stream));
+    MXG_HIP(h, grow_preserve(*o.hash, o.n * 8, need * 8, st));
+    MXG_HIP(h, grow_preserve(*o.pos, o.n * 4, need * 4, st));
+    MXG_HIP(h, grow_preserve(*o.rec, o.n * 4, need * 4, st));
+    MXG_HIP(h, grow_preserve(*o.fwd, o.n, need, st));
     return MXG_OK;
 }
 
@@ -794,7 +794,12 @@ struct Driver {
     mxg_handle *h;
     std::vector<EventPair> evs;
     bool timing;
-    explicit Driver(mxg_handle *h_) : h(h_), timing((h_->cfg.flags & MXG_FLAG_TIMING) != 0) {}
+    hipStream_t st;   // stream this driver enqueues on
+    int slot;         // which of the handle's two scratch sets it uses (two drivers can be in flight at once)
+    explicit Driver(mxg_handle *h_, int slot_ = 0)
+        : h(h_), timing((h_->cfg.flags & MXG_FLAG_TIMING) != 0), st(slot_ == 0 ? h_->stream : h_->stream2), slot(slot_)
+    {
+    }
     ~Driver()
     {
         for (auto &e : evs) {
@@ -802,7 +807,7 @@ struct Driver {
             (void)hipEventDestroy(e.b);
         }
     }
-    DevBuf &sc(int i) { return h->scratch[i]; }
+    DevBuf &sc(int i) { return h->scratch[slot][i]; }
 
     int ev_begin(uint64_t bases, bool is_hash)
     {
@@ -812,20 +817,20 @@ struct Driver {
         MXG_HIP(h, hipEventCreate(&e.b));
         e.bases = bases;
         e.is_hash = is_hash;
-        MXG_HIP(h, hipEventRecord(e.a, h->stream));
+        MXG_HIP(h, hipEventRecord(e.a, st));
         evs.push_back(e);
         return MXG_OK;
     }
     int ev_end()
     {
         if (!timing) return MXG_OK;
-        MXG_HIP(h, hipEventRecord(evs.back().b, h->stream));
+        MXG_HIP(h, hipEventRecord(evs.back().b, st));
         return MXG_OK;
     }
     int collect()
     {
         if (!timing) return MXG_OK;
-        MXG_HIP(h, hipStreamSynchronize(h->stream));
+        MXG_HIP(h, hipStreamSynchronize(st));
         for (auto &e : evs) {
             float ms = 0;
             MXG_HIP(h, hipEventElapsedTime(&ms, e.a, e.b));
@@ -872,11 +877,11 @@ struct Driver {
         rp.gap_cap = GAP_CAP;
         rp.gap_count = ctrl + 1;
         if (n_cap) {
-            hipLaunchKernelGGL(k_resolve<GAPS>, dim3((n_cap + 255) / 256), dim3(256), 0, h->stream, rp);
-            hipLaunchKernelGGL(k_count_n, dim3(n_tiles), dim3(256), 0, h->stream, rp.sel, rp.n_ptr, n_cap,
+            hipLaunchKernelGGL(k_resolve<GAPS>, dim3((n_cap + 255) / 256), dim3(256), 0, st, rp);
+            hipLaunchKernelGGL(k_count_n, dim3(n_tiles), dim3(256), 0, st, rp.sel, rp.n_ptr, n_cap,
                                sc(SC_BSUM).as<uint32_t>());
         }
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, h->stream, sc(SC_BSUM).as<uint32_t>(), n_tiles,
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, sc(SC_BSUM).as<uint32_t>(), n_tiles,
                            reinterpret_cast<uint64_t *>(ctrl + 2));
         MXG_HIP(h, hipGetLastError());
         return MXG_OK;
@@ -907,7 +912,7 @@ struct Driver {
         ep.o_pos = op.as<uint32_t>();
         ep.o_rec = orc.as<uint32_t>();
         ep.o_fwd = of.as<uint8_t>();
-        hipLaunchKernelGGL(k_emit, dim3((n_cap + TILE - 1) / TILE), dim3(256), 0, h->stream, ep);
+        hipLaunchKernelGGL(k_emit, dim3((n_cap + TILE - 1) / TILE), dim3(256), 0, st, ep);
         MXG_HIP(h, hipGetLastError());
         return MXG_OK;
     }
@@ -931,7 +936,7 @@ struct Driver {
             MXG_HIP(h, sc(SC_CAND_C).ensure(nk * 4));
             const uint32_t n_cand = (uint32_t)nk;
             uint32_t ctrl_init[8] = {0, 0, 0, 0, n_cand, 0, 0, 0};
-            MXG_HIP(h, hipMemcpyAsync(sc(SC_CTRL).p, ctrl_init, 32, hipMemcpyHostToDevice, h->stream));
+            MXG_HIP(h, hipMemcpyAsync(sc(SC_CTRL).p, ctrl_init, 32, hipMemcpyHostToDevice, st));
             DenseParams hp;
             hp.packed = d_packed;
             hp.runs = T.d_runs;
@@ -952,18 +957,18 @@ struct Driver {
             const uint32_t n_strips = hp.strip_hi - hp.strip_lo;
             dim3 grid((n_strips + 255) / 256), block(256);
             if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-                hipLaunchKernelGGL((k_hash_dense<S_DENSE, MXG_VARIANT_V1_MIN>), grid, block, 0, h->stream, hp);
+                hipLaunchKernelGGL((k_hash_dense<S_DENSE, MXG_VARIANT_V1_MIN>), grid, block, 0, st, hp);
             else
-                hipLaunchKernelGGL((k_hash_dense<S_DENSE, MXG_VARIANT_V2_SUM>), grid, block, 0, h->stream, hp);
+                hipLaunchKernelGGL((k_hash_dense<S_DENSE, MXG_VARIANT_V2_SUM>), grid, block, 0, st, hp);
             if (count_as_hash && (rc = ev_end()) != MXG_OK) return rc;
             MXG_HIP(h, hipGetLastError());
             if ((rc = resolve_and_count<false>(T, n_cand, (uint32_t)c0, (uint32_t)c1)) != MXG_OK) return rc;
             if (!count_as_hash && (rc = ev_end()) != MXG_OK) return rc;
             uint32_t ctrl[4];
-            MXG_HIP(h, hipMemcpyAsync(ctrl, sc(SC_CTRL).p, 16, hipMemcpyDeviceToHost, h->stream));
-            MXG_HIP(h, hipStreamSynchronize(h->stream));
+            MXG_HIP(h, hipMemcpyAsync(ctrl, sc(SC_CTRL).p, 16, hipMemcpyDeviceToHost, st));
+            MXG_HIP(h, hipStreamSynchronize(st));
             const uint64_t total = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
-            if ((rc = out_reserve(h, out, out.n + total)) != MXG_OK) return rc;
+            if ((rc = out_reserve(h, out, out.n + total, st)) != MXG_OK) return rc;
             if ((rc = emit(d_packed, T, n_cand, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
             out.n += total;
             h->stat_dense_kmers += nk;
@@ -1013,12 +1018,12 @@ struct Driver {
         }
         vg0[vruns.size()] = g;
         int rc;
-        if ((rc = upload(h, sc(SC_V_RUNS), vruns)) != MXG_OK) return rc;
-        if ((rc = upload(h, sc(SC_V_STRIP0), vstrip0)) != MXG_OK) return rc;
-        if ((rc = upload(h, sc(SC_V_G0), vg0)) != MXG_OK) return rc;
-        if ((rc = upload(h, sc(SC_V_NK), v_nk)) != MXG_OK) return rc;
-        if ((rc = upload(h, sc(SC_V_REC), v_rec)) != MXG_OK) return rc;
-        if ((rc = upload(h, sc(SC_V_RUN0), v_run0)) != MXG_OK) return rc;
+        if ((rc = upload(h, sc(SC_V_RUNS), vruns, st)) != MXG_OK) return rc;
+        if ((rc = upload(h, sc(SC_V_STRIP0), vstrip0, st)) != MXG_OK) return rc;
+        if ((rc = upload(h, sc(SC_V_G0), vg0, st)) != MXG_OK) return rc;
+        if ((rc = upload(h, sc(SC_V_NK), v_nk, st)) != MXG_OK) return rc;
+        if ((rc = upload(h, sc(SC_V_REC), v_rec, st)) != MXG_OK) return rc;
+        if ((rc = upload(h, sc(SC_V_RUN0), v_run0, st)) != MXG_OK) return rc;
         Tables V;
         V.runs = &vruns;
         V.ctg_nk = &v_nk;
@@ -1101,7 +1106,7 @@ struct Driver {
         MXG_HIP(h, sc(SC_CAND_H).ensure((size_t)n_cap * 8));
         MXG_HIP(h, sc(SC_CAND_K).ensure((size_t)n_cap * 4));
         MXG_HIP(h, sc(SC_CAND_C).ensure((size_t)n_cap * 4));
-        MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, 32, h->stream));
+        MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, 32, st));
         SparseParams sp;
         sp.packed = a->d_packed;
         sp.runs = T.d_runs;
@@ -1126,26 +1131,26 @@ struct Driver {
         dim3 grid(g.n_blocks), block(256);
         static const int abl = getenv("MXG_ABLATE") ? atoi(getenv("MXG_ABLATE")) : 0;  // profiling only
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V1_MIN>), grid, block, 0, h->stream, sp);
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V1_MIN>), grid, block, 0, st, sp);
         else if (abl == 1)
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 1>), grid, block, 0, h->stream, sp);
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 1>), grid, block, 0, st, sp);
         else if (abl == 2)
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 2>), grid, block, 0, h->stream, sp);
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 2>), grid, block, 0, st, sp);
         else if (abl == 4)
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 4>), grid, block, 0, h->stream, sp);
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 4>), grid, block, 0, st, sp);
         else
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), grid, block, 0, h->stream, sp);
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), grid, block, 0, st, sp);
         if ((rc = ev_end()) != MXG_OK) return rc;
         MXG_HIP(h, hipGetLastError());
         // order the candidates: exclusive scan of per-strip counts (total = number of candidates), then scatter
         if ((rc = ev_begin(0, false)) != MXG_OK) return rc;
-        hipLaunchKernelGGL(k_tile_sum_u32, dim3(g.s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, g.n_strips,
+        hipLaunchKernelGGL(k_tile_sum_u32, dim3(g.s_tiles), dim3(256), 0, st, sp.strip_cnt, g.n_strips,
                            sc(SC_SBSUM).as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, h->stream, sc(SC_SBSUM).as<uint32_t>(), g.s_tiles,
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, sc(SC_SBSUM).as<uint32_t>(), g.s_tiles,
                            reinterpret_cast<uint64_t *>(sp.ctrl + 4));
-        hipLaunchKernelGGL(k_tile_excl_u32, dim3(g.s_tiles), dim3(256), 0, h->stream, sp.strip_cnt, g.n_strips,
+        hipLaunchKernelGGL(k_tile_excl_u32, dim3(g.s_tiles), dim3(256), 0, st, sp.strip_cnt, g.n_strips,
                            sc(SC_SBSUM).as<uint32_t>(), sc(SC_STRIP_PREF).as<uint32_t>());
-        hipLaunchKernelGGL(k_reorder, dim3(g.n_waves), dim3(256), 0, h->stream, sp.arena, sp.wave_cnt, sp.wave_cap, n_cap,
+        hipLaunchKernelGGL(k_reorder, dim3(g.n_waves), dim3(256), 0, st, sp.arena, sp.wave_cnt, sp.wave_cap, n_cap,
                            sc(SC_STRIP_PREF).as<uint32_t>(), sp.strip_meta, sc(SC_CAND_H).as<uint64_t>(),
                            sc(SC_CAND_K).as<uint32_t>(), sc(SC_CAND_C).as<uint32_t>());
         MXG_HIP(h, hipGetLastError());
@@ -1154,7 +1159,7 @@ struct Driver {
         // (no gap, no overflow) the batch then needs a single host sync
         if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
         if ((rc = ev_end()) != MXG_OK) return rc;
-        MXG_HIP(h, hipMemcpyAsync(ctrl_host, sc(SC_CTRL).p, 32, hipMemcpyDeviceToHost, h->stream));
+        MXG_HIP(h, hipMemcpyAsync(ctrl_host, sc(SC_CTRL).p, 32, hipMemcpyDeviceToHost, st));
         return MXG_OK;
     }
 
@@ -1176,7 +1181,7 @@ struct Driver {
                 int rc = enqueue_sparse(a, T, g, wave_cap, tau_hi, out, ctrl, &n_cap_now);
                 if (rc != MXG_OK) return rc;
                 n_cap64 = n_cap_now;
-                MXG_HIP(h, hipStreamSynchronize(h->stream));
+                MXG_HIP(h, hipStreamSynchronize(st));
                 if (ctrl[0] == 0) break;  // no wave overflowed its slice
                 if (attempt >= 2) return set_err(h, MXG_EDEVICE, "internal error: candidate arena keeps overflowing");
                 wave_cap = std::min<uint64_t>((uint64_t)ctrl[0] + 64, 64ull * S);  // exact need is known: redo the batch
@@ -1196,12 +1201,12 @@ struct Driver {
                 return set_err(h, MXG_ELIMIT, "more than %u candidate-free stretches in one batch; rerun with MXG_FLAG_DENSE_ONLY", GAP_CAP);
             } else if (n_gaps) {
                 gaps.resize(n_gaps);
-                MXG_HIP(h, hipMemcpyAsync(gaps.data(), sc(SC_GAPS).p, (size_t)n_gaps * 16, hipMemcpyDeviceToHost, h->stream));
-                MXG_HIP(h, hipStreamSynchronize(h->stream));
+                MXG_HIP(h, hipMemcpyAsync(gaps.data(), sc(SC_GAPS).p, (size_t)n_gaps * 16, hipMemcpyDeviceToHost, st));
+                MXG_HIP(h, hipStreamSynchronize(st));
             }
             if (n_gaps == 0) {
                 if (out.n + total > out.cap()) {  // the speculative emit did not fit: grow, emit again
-                    if ((rc = out_reserve(h, out, out.n + total)) != MXG_OK) return rc;
+                    if ((rc = out_reserve(h, out, out.n + total, st)) != MXG_OK) return rc;
                     if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
                 }
                 out.n += total;
@@ -1215,7 +1220,7 @@ struct Driver {
                 uint64_t n_gap_mx = 0;
                 if ((rc = process_gaps(a, T, gaps, &n_gap_mx)) != MXG_OK) return rc;
                 if (total + n_gap_mx >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "batch sketch too large to merge");
-                if ((rc = out_reserve(h, out, out.n + total + n_gap_mx)) != MXG_OK) return rc;
+                if ((rc = out_reserve(h, out, out.n + total + n_gap_mx, st)) != MXG_OK) return rc;
                 MergeParams mp;
                 mp.a_hash = sc(SC_ST_HASH).as<uint64_t>(); mp.a_pos = sc(SC_ST_POS).as<uint32_t>();
                 mp.a_rec = sc(SC_ST_REC).as<uint32_t>(); mp.a_fwd = sc(SC_ST_FWD).as<uint8_t>(); mp.nA = (uint32_t)total;
@@ -1224,7 +1229,7 @@ struct Driver {
                 mp.o_hash = out.hash->as<uint64_t>() + out.n; mp.o_pos = out.pos->as<uint32_t>() + out.n;
                 mp.o_rec = out.rec->as<uint32_t>() + out.n; mp.o_fwd = out.fwd->as<uint8_t>() + out.n;
                 const uint32_t nt = mp.nA + mp.nB;
-                if (nt) hipLaunchKernelGGL(k_merge, dim3((nt + 255) / 256), dim3(256), 0, h->stream, mp);
+                if (nt) hipLaunchKernelGGL(k_merge, dim3((nt + 255) / 256), dim3(256), 0, st, mp);
                 MXG_HIP(h, hipGetLastError());
                 out.n += total + n_gap_mx;
             }
@@ -1341,7 +1346,7 @@ static int run_sketch_sync(mxg_handle *h, Assembly *a, const Tables &T, Driver &
     uint32_t tau_hi;
     int rc = sparse_mode(h, &frac, &tau_hi) ? drv.sparse_all(a, T, out, tau_hi, frac) : drv.dense_all(a->d_packed, T, out, true);
     if (rc != MXG_OK) return rc;
-    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    MXG_HIP(h, hipStreamSynchronize(drv.st));
     a->n_mx = out.n;
     a->has_sketch = true;
     return MXG_OK;
@@ -1370,11 +1375,15 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
     double frac;
     uint32_t tau_hi;
     const bool sparse = sparse_mode(h, &frac, &tau_hi);
-    Driver drv(h);
+    // two drivers = two streams with their own scratch: assembly i+1's hash kernel overlaps the small, latency-bound
+    // kernels (ordering, resolve, compaction) that follow assembly i's hash kernel
+    Driver drv0(h, 0), drv1(h, 1);
+    Driver *drvs[2] = {&drv0, &drv1};
     std::vector<Tables> tabs(n);
     std::vector<int> state(n, 0);  // 0 = synchronous path, 1 = enqueued, 2 = done (empty)
     std::vector<uint32_t> ncap(n, 0);
     int rc;
+    size_t n_enq = 0;
     for (size_t i = 0; i < n; ++i) {
         bool empty = false;
         if ((rc = prepare_sketch(h, list[i], tabs[i], &empty)) != MXG_OK) return rc;
@@ -1383,6 +1392,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
             continue;
         }
         if (!sparse || i >= MXG_MAX_ASSEMBLIES) continue;
+        Driver &drv = *drvs[n_enq & 1];
         Driver::BatchGeom g;
         drv.batch_geom(tabs[i], 0, g);
         if (g.c1 != tabs[i].ctg_rec->size()) continue;  // more than one batch: synchronous path
@@ -1393,8 +1403,10 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
                                      &ncap[i])) != MXG_OK)
             return rc;
         state[i] = 1;
+        ++n_enq;
     }
     MXG_HIP(h, hipStreamSynchronize(h->stream));
+    MXG_HIP(h, hipStreamSynchronize(h->stream2));
     for (size_t i = 0; i < n; ++i) {
         if (state[i] != 1) continue;
         Assembly *a = list[i];
@@ -1411,8 +1423,9 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
         }
     }
     for (size_t i = 0; i < n; ++i)
-        if (state[i] == 0 && (rc = run_sketch_sync(h, list[i], tabs[i], drv)) != MXG_OK) return rc;
-    return drv.collect();
+        if (state[i] == 0 && (rc = run_sketch_sync(h, list[i], tabs[i], drv0)) != MXG_OK) return rc;
+    if ((rc = drv0.collect()) != MXG_OK) return rc;
+    return drv1.collect();
 }
 
 int ensure_strand(mxg_handle *h, Assembly *a)
