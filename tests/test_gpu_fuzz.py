@@ -1,0 +1,100 @@
+"""GPU differential fuzz: random (k, w, variant, candidates-per-window, strip length) x random ragged / N-heavy /
+low-complexity records, sparse path vs the CPU oracle, bit for bit.  MXG_FUZZ_TRIALS raises the trial count."""
+import os
+import random
+
+import pytest
+
+from tests import _oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_record(rng, n):
+    kind = rng.random()
+    if kind < 0.5:
+        return "".join(rng.choice("ACGT") for _ in range(n))
+    if kind < 0.65:
+        unit = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 9)))
+        return (unit * (n // len(unit) + 1))[:n]
+    if kind < 0.85:
+        s = [rng.choice("ACGT") for _ in range(n)]
+        for _ in range(rng.randint(1, 6)):
+            p = rng.randrange(max(n, 1))
+            ln = rng.choice([1, 1, 3, 40, 700])
+            s[p:p + ln] = "N" * len(s[p:p + ln])
+        return "".join(s)
+    s = [rng.choice("ACGT") for _ in range(n)]
+    p = rng.randrange(max(n, 1))
+    ln = rng.randint(0, n)
+    s[p:p + ln] = [rng.choice("Aa") for _ in s[p:p + ln]]
+    return "".join(s)
+
+
+def test_fuzz_sparse_path_vs_oracle(oracle):
+    from ntjoin_amd.engine import MxEngine
+    trials = int(os.environ.get("MXG_FUZZ_TRIALS", "60"))
+    rng = random.Random(int(os.environ.get("MXG_FUZZ_SEED", "2024")))
+    saved = os.environ.get("MXG_SPARSE_S")
+    try:
+        for t in range(trials):
+            k = rng.choice([4, 11, 15, 16, 21, 31, 32, 33, 47, 64])
+            w = rng.choice([16, 50, 100, 200, 333, 1000, 2000])
+            variant = rng.choice(["v2", "v2", "v1"])
+            c = rng.choice([1, 2, 4, 8, 16, 16, 24]) if w >= 200 else rng.choice([1, 2])
+            os.environ["MXG_SPARSE_S"] = str(rng.choice([16, 32, 64, 128, 256, 512]))
+            recs = [(f"r{i}", _rand_record(rng, rng.choice([0, 5, k + w - 2, k + w - 1, 500, 3000, 9000, 40000])))
+                    for i in range(rng.randint(1, 8))]
+            with MxEngine(k=k, w=w, variant=variant, cand_per_window=c) as eng:
+                eng.add_records("x", 1.0, recs)
+                eng.sketch()
+                sk = eng.get_sketch(0)
+            ov = _oracle.V1_MIN if variant == "v1" else _oracle.V2_SUM
+            for r, (rid, seq) in enumerate(recs):
+                lo, hi = int(sk["record_first"][r]), int(sk["record_first"][r + 1])
+                want = oracle.sketch(seq, k, w, ov)
+                got = list(zip(sk["out_hash"][lo:hi].tolist(), sk["pos"][lo:hi].tolist(), sk["forward"][lo:hi].tolist()))
+                assert got == [(h, p, f) for h, p, f, _ in want], (t, k, w, variant, c, os.environ["MXG_SPARSE_S"], rid)
+    finally:
+        if saved is None:
+            os.environ.pop("MXG_SPARSE_S", None)
+        else:
+            os.environ["MXG_SPARSE_S"] = saved
+
+
+def test_fuzz_graph_stage_vs_oracle(tmp_path):
+    """random sketches fed through mxg_add_assembly_tsv: duplicates inside and across assemblies, empty records,
+    1-6 assemblies, fractional weights -> flags, filtered lists, edges, weights and canonical .mx.dot vs the oracle"""
+    from ntjoin_amd.engine import MxEngine
+    from oracle import graph_oracle as go
+    trials = int(os.environ.get("MXG_FUZZ_TRIALS", "60"))
+    rng = random.Random(77)
+    os.chdir(tmp_path)
+    for t in range(trials):
+        A = rng.randint(1, 6)
+        universe = [rng.getrandbits(64) for _ in range(rng.choice([5, 30, 200, 2000]))]
+        names, weights = [], []
+        for a in range(A):
+            name = f"t{t}_asm{a}.k32.w10.tsv"
+            with open(name, "w", encoding="ascii") as fh:
+                for r in range(rng.randint(1, 12)):
+                    n = rng.choice([0, 0, 1, 2, 5, 40, 300])
+                    picks = [rng.choice(universe) for _ in range(n)] if rng.random() < 0.5 else \
+                        rng.sample(universe, min(n, len(universe)))
+                    pos = sorted(rng.sample(range(10 ** 6), len(picks)))
+                    fh.write(f"ctg{r}\t" + " ".join(f"{h}:{p}:ACGT" for h, p in zip(picks, pos)) + "\n")
+            names.append(name)
+            weights.append(rng.choice([1, 2, 0.5, 1.5, 0.1, 3]))
+        with MxEngine(k=32, w=10) as eng:
+            for nm, wt in zip(names, weights):
+                eng.add_tsv(nm, wt, nm)
+            eng.build_graph()
+            eng.write_dot(f"t{t}.mx.dot")
+            flags = [eng.get_mx_flags(a) for a in range(A)]
+            sks = [eng.get_sketch(a) for a in range(A)]
+        state = go.load_and_build(names[:-1], weights[:-1], names[-1], weights[-1])
+        got = go.canonical_dot_from_text(open(f"t{t}.mx.dot", encoding="utf-8").read())
+        assert got == go.canonical_dot_from_state(state), t
+        for a, nm in enumerate(names):
+            uniq = {str(h) for h, f in zip(sks[a]["out_hash"].tolist(), flags[a].tolist()) if f & 1}
+            assert uniq == set(state["list_mx_info"][nm].keys()), (t, a)
