@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mbp", type=float, default=100.0, help="reference size per rank in Mbp (configs[1]: 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cand", type=int, default=0, help="candidates per window for the sparse path (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -98,7 +99,7 @@ def main():
     ref, tgt = synth.config2(seed=1 + 100 * rank, n_bases=n_bases)
     bases_rank = sum(len(c) for c in ref) + sum(len(c) for c in tgt)
     keep = []
-    eng = MxEngine(k=K, w=W, device=local_rank, timing=True)
+    eng = MxEngine(k=K, w=W, device=local_rank, timing=True, cand_per_window=args.cand)
     for name, weight, recs in (("ref.fa.k32.w1000.tsv", 2.0, ref), ("tgt.fa.k32.w1000.tsv", 1.0, tgt)):
         words, starts, lens = synth.pack_records(recs)
         d = torch.from_numpy(words.view(np.int32)).cuda()  # bases resident in HBM before the timed region

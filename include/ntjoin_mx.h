@@ -62,7 +62,7 @@ typedef struct mxg_config {
     int32_t device;        /* HIP device ordinal, -1 = current device                         */
     uint32_t flags;        /* MXG_FLAG_*                                                      */
     void *stream;          /* hipStream_t to launch on; NULL = the library creates its own    */
-    uint32_t cand_per_window; /* sparse path: expected candidates per window (0 = default 16) */
+    uint32_t cand_per_window; /* sparse path: expected candidates per window (0 = default 18) */
     uint32_t reserved[5];
 } mxg_config;
 

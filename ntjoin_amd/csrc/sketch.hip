@@ -1163,6 +1163,60 @@ struct Driver {
         return MXG_OK;
     }
 
+    // Second half of a sparse batch, after the host has read the control block `ctrl` of a run that did not overflow:
+    // accept the speculative emit, or (candidate-free stretches) emit to staging, run the dense fix-up, merge.
+    // The candidate arrays of that run must still be intact in this driver's scratch.
+    int complete_batch(Assembly *a, const Tables &T, const BatchGeom &g, OutArrays &out, const uint32_t *ctrl, uint32_t n_cap)
+    {
+        const size_t c0 = g.c0, c1 = g.c1;
+                const uint64_t n_cand = (uint64_t)ctrl[4] | ((uint64_t)ctrl[5] << 32);
+        uint32_t n_gaps = ctrl[1];
+        const uint64_t total = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
+        h->stat_candidates += n_cand;
+        int rc;
+        std::vector<uint4> gaps;
+        if (n_cand == 0) {  // no candidate at all: every contig of the batch is one stretch
+            for (size_t c = c0; c < c1; ++c) gaps.push_back(make_uint4((uint32_t)c, 0, (*T.ctg_nk)[c] - 1, 0));
+            n_gaps = (uint32_t)gaps.size();
+        } else if (n_gaps > GAP_CAP) {
+            return set_err(h, MXG_ELIMIT, "more than %u candidate-free stretches in one batch; rerun with MXG_FLAG_DENSE_ONLY", GAP_CAP);
+        } else if (n_gaps) {
+            gaps.resize(n_gaps);
+            MXG_HIP(h, hipMemcpyAsync(gaps.data(), sc(SC_GAPS).p, (size_t)n_gaps * 16, hipMemcpyDeviceToHost, st));
+            MXG_HIP(h, hipStreamSynchronize(st));
+        }
+        if (n_gaps == 0) {
+            if (out.n + total > out.cap()) {  // the speculative emit did not fit: grow, emit again
+                if ((rc = out_reserve(h, out, out.n + total, st)) != MXG_OK) return rc;
+                if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
+            }
+            out.n += total;
+        } else {
+            // main result to staging (before the candidate scratch is reused by the gap pass)
+            MXG_HIP(h, sc(SC_ST_HASH).ensure(std::max<uint64_t>(total * 8, 16)));
+            MXG_HIP(h, sc(SC_ST_POS).ensure(std::max<uint64_t>(total * 4, 16)));
+            MXG_HIP(h, sc(SC_ST_REC).ensure(std::max<uint64_t>(total * 4, 16)));
+            MXG_HIP(h, sc(SC_ST_FWD).ensure(std::max<uint64_t>(total, 16)));
+            if ((rc = emit(a->d_packed, T, n_cap, sc(SC_ST_HASH), sc(SC_ST_POS), sc(SC_ST_REC), sc(SC_ST_FWD), 0)) != MXG_OK) return rc;
+            uint64_t n_gap_mx = 0;
+            if ((rc = process_gaps(a, T, gaps, &n_gap_mx)) != MXG_OK) return rc;
+            if (total + n_gap_mx >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "batch sketch too large to merge");
+            if ((rc = out_reserve(h, out, out.n + total + n_gap_mx, st)) != MXG_OK) return rc;
+            MergeParams mp;
+            mp.a_hash = sc(SC_ST_HASH).as<uint64_t>(); mp.a_pos = sc(SC_ST_POS).as<uint32_t>();
+            mp.a_rec = sc(SC_ST_REC).as<uint32_t>(); mp.a_fwd = sc(SC_ST_FWD).as<uint8_t>(); mp.nA = (uint32_t)total;
+            mp.b_hash = sc(SC_G_HASH).as<uint64_t>(); mp.b_pos = sc(SC_G_POS).as<uint32_t>();
+            mp.b_rec = sc(SC_G_REC).as<uint32_t>(); mp.b_fwd = sc(SC_G_FWD).as<uint8_t>(); mp.nB = (uint32_t)n_gap_mx;
+            mp.o_hash = out.hash->as<uint64_t>() + out.n; mp.o_pos = out.pos->as<uint32_t>() + out.n;
+            mp.o_rec = out.rec->as<uint32_t>() + out.n; mp.o_fwd = out.fwd->as<uint8_t>() + out.n;
+            const uint32_t nt = mp.nA + mp.nB;
+            if (nt) hipLaunchKernelGGL(k_merge, dim3((nt + 255) / 256), dim3(256), 0, st, mp);
+            MXG_HIP(h, hipGetLastError());
+            out.n += total + n_gap_mx;
+        }
+        return MXG_OK;
+    }
+
     // every contig of T, appended to `out` (synchronous: one sync per batch, retries and gap fix-ups inline)
     int sparse_all(Assembly *a, const Tables &T, OutArrays &out, uint32_t tau_hi, double cand_frac)
     {
@@ -1187,52 +1241,8 @@ struct Driver {
                 wave_cap = std::min<uint64_t>((uint64_t)ctrl[0] + 64, 64ull * S);  // exact need is known: redo the batch
                 h->arena_cap_hint = wave_cap;
             }
-            const uint32_t n_cap = (uint32_t)n_cap64;
-            const uint64_t n_cand = (uint64_t)ctrl[4] | ((uint64_t)ctrl[5] << 32);
-            uint32_t n_gaps = ctrl[1];
-            const uint64_t total = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
-            h->stat_candidates += n_cand;
-            int rc;
-            std::vector<uint4> gaps;
-            if (n_cand == 0) {  // no candidate at all: every contig of the batch is one stretch
-                for (size_t c = c0; c < c1; ++c) gaps.push_back(make_uint4((uint32_t)c, 0, (*T.ctg_nk)[c] - 1, 0));
-                n_gaps = (uint32_t)gaps.size();
-            } else if (n_gaps > GAP_CAP) {
-                return set_err(h, MXG_ELIMIT, "more than %u candidate-free stretches in one batch; rerun with MXG_FLAG_DENSE_ONLY", GAP_CAP);
-            } else if (n_gaps) {
-                gaps.resize(n_gaps);
-                MXG_HIP(h, hipMemcpyAsync(gaps.data(), sc(SC_GAPS).p, (size_t)n_gaps * 16, hipMemcpyDeviceToHost, st));
-                MXG_HIP(h, hipStreamSynchronize(st));
-            }
-            if (n_gaps == 0) {
-                if (out.n + total > out.cap()) {  // the speculative emit did not fit: grow, emit again
-                    if ((rc = out_reserve(h, out, out.n + total, st)) != MXG_OK) return rc;
-                    if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
-                }
-                out.n += total;
-            } else {
-                // main result to staging (before the candidate scratch is reused by the gap pass)
-                MXG_HIP(h, sc(SC_ST_HASH).ensure(std::max<uint64_t>(total * 8, 16)));
-                MXG_HIP(h, sc(SC_ST_POS).ensure(std::max<uint64_t>(total * 4, 16)));
-                MXG_HIP(h, sc(SC_ST_REC).ensure(std::max<uint64_t>(total * 4, 16)));
-                MXG_HIP(h, sc(SC_ST_FWD).ensure(std::max<uint64_t>(total, 16)));
-                if ((rc = emit(a->d_packed, T, n_cap, sc(SC_ST_HASH), sc(SC_ST_POS), sc(SC_ST_REC), sc(SC_ST_FWD), 0)) != MXG_OK) return rc;
-                uint64_t n_gap_mx = 0;
-                if ((rc = process_gaps(a, T, gaps, &n_gap_mx)) != MXG_OK) return rc;
-                if (total + n_gap_mx >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "batch sketch too large to merge");
-                if ((rc = out_reserve(h, out, out.n + total + n_gap_mx, st)) != MXG_OK) return rc;
-                MergeParams mp;
-                mp.a_hash = sc(SC_ST_HASH).as<uint64_t>(); mp.a_pos = sc(SC_ST_POS).as<uint32_t>();
-                mp.a_rec = sc(SC_ST_REC).as<uint32_t>(); mp.a_fwd = sc(SC_ST_FWD).as<uint8_t>(); mp.nA = (uint32_t)total;
-                mp.b_hash = sc(SC_G_HASH).as<uint64_t>(); mp.b_pos = sc(SC_G_POS).as<uint32_t>();
-                mp.b_rec = sc(SC_G_REC).as<uint32_t>(); mp.b_fwd = sc(SC_G_FWD).as<uint8_t>(); mp.nB = (uint32_t)n_gap_mx;
-                mp.o_hash = out.hash->as<uint64_t>() + out.n; mp.o_pos = out.pos->as<uint32_t>() + out.n;
-                mp.o_rec = out.rec->as<uint32_t>() + out.n; mp.o_fwd = out.fwd->as<uint8_t>() + out.n;
-                const uint32_t nt = mp.nA + mp.nB;
-                if (nt) hipLaunchKernelGGL(k_merge, dim3((nt + 255) / 256), dim3(256), 0, st, mp);
-                MXG_HIP(h, hipGetLastError());
-                out.n += total + n_gap_mx;
-            }
+            int rcb = complete_batch(a, T, g, out, ctrl, (uint32_t)n_cap64);
+            if (rcb != MXG_OK) return rcb;
             c0 = c1;
         }
         return MXG_OK;
@@ -1333,7 +1343,7 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
 // sparse path: expected c candidates per window; it pays while candidates are a small fraction of k-mers
 static bool sparse_mode(const mxg_handle *h, double *frac, uint32_t *tau_hi)
 {
-    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : 16;
+    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : 18;
     *frac = (double)c / (double)h->cfg.w;
     *tau_hi = (uint32_t)std::min<double>(4294967295.0, *frac * 4294967296.0);
     return !(h->cfg.flags & MXG_FLAG_DENSE_ONLY) && *frac <= 0.125;
@@ -1382,6 +1392,9 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
     std::vector<Tables> tabs(n);
     std::vector<int> state(n, 0);  // 0 = synchronous path, 1 = enqueued, 2 = done (empty)
     std::vector<uint32_t> ncap(n, 0);
+    std::vector<Driver::BatchGeom> geoms(n);
+    std::vector<int> slot_of(n, 0);
+    size_t last_on_slot[2] = {(size_t)-1, (size_t)-1};
     int rc;
     size_t n_enq = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -1393,7 +1406,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
         }
         if (!sparse || i >= MXG_MAX_ASSEMBLIES) continue;
         Driver &drv = *drvs[n_enq & 1];
-        Driver::BatchGeom g;
+        Driver::BatchGeom &g = geoms[i];
         drv.batch_geom(tabs[i], 0, g);
         if (g.c1 != tabs[i].ctg_rec->size()) continue;  // more than one batch: synchronous path
         OutArrays out{&list[i]->d_hash, &list[i]->d_pos, &list[i]->d_rec, &list[i]->d_fwd, 0};
@@ -1403,6 +1416,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
                                      &ncap[i])) != MXG_OK)
             return rc;
         state[i] = 1;
+        slot_of[i] = (int)(n_enq & 1);
+        last_on_slot[n_enq & 1] = i;
         ++n_enq;
     }
     MXG_HIP(h, hipStreamSynchronize(h->stream));
@@ -1418,8 +1433,20 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
             a->has_sketch = true;
             h->stat_candidates += n_cand;
             state[i] = 2;
+        } else if (c[0] == 0 && last_on_slot[slot_of[i]] == i) {
+            // candidate-free stretches (or an output that outgrew its estimate) and the run's candidate arrays are still
+            // intact in its driver's scratch: finish from there (staging emit, dense fix-up, merge) instead of redoing it
+            Driver &drv = *drvs[slot_of[i]];
+            OutArrays out{&a->d_hash, &a->d_pos, &a->d_rec, &a->d_fwd, 0};
+            uint32_t ctrl_copy[8];
+            memcpy(ctrl_copy, c, 32);
+            if ((rc = drv.complete_batch(a, tabs[i], geoms[i], out, ctrl_copy, ncap[i])) != MXG_OK) return rc;
+            MXG_HIP(h, hipStreamSynchronize(drv.st));
+            a->n_mx = out.n;
+            a->has_sketch = true;
+            state[i] = 2;
         } else {
-            state[i] = 0;  // redo synchronously
+            state[i] = 0;  // a wave overflowed its arena slice (or the scratch was reused): redo synchronously
         }
     }
     for (size_t i = 0; i < n; ++i)
