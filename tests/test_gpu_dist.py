@@ -98,3 +98,46 @@ def test_sharded_load_equals_full_load():
         assert covered[0][0] == 0 and covered[-1][1] == len(full["record_ids"])
         for key in ("out_hash", "pos", "record", "forward"):
             assert np.array_equal(np.concatenate([p[key] for p in parts]), full[key]), (world, key)
+
+
+def test_pack_unpack_two_ranks_on_one_gpu():
+    """the exchange kernels with world=2 without a second GPU: two engines play the ranks (disjoint record sets of
+    every assembly), their packed buffers are laid side by side as an all-gather would, and mxg_set_sketch_gathered
+    unpacks them (rank order, record indices shifted) into a union engine; the union graph must equal the graph of
+    one engine that holds everything."""
+    import torch
+    from ntjoin_amd.engine import MxEngine
+    from tests import _oracle
+    meta = load_case("synth3_w50")["meta"]
+    asms = meta["refs"] + [meta["target"]]
+    k, w = meta["k"], meta["w"]
+    all_recs = [_oracle.read_fasta(os.path.join(FASTA, a["fasta"])) for a in asms]
+    with MxEngine(k=k, w=w) as full, MxEngine(k=k, w=w) as r0, MxEngine(k=k, w=w) as r1, MxEngine(k=k, w=w) as union:
+        splits = []
+        for a, recs in zip(asms, all_recs):
+            cut = max(1, len(recs) // 2)
+            splits.append(cut)
+            full.add_records(a["tsv"], a["weight"], recs)
+            r0.add_records(a["tsv"], a["weight"], recs[:cut])
+            r1.add_records(a["tsv"], a["weight"], recs[cut:])
+            union.add_minimizers(a["tsv"], a["weight"], np.zeros(0, np.uint64), np.zeros(0, np.uint32),
+                                 np.zeros(0, np.uint32), [rid for rid, _ in recs])
+        for e in (full, r0, r1):
+            e.sketch()
+        for a in range(len(asms)):
+            counts = np.array([r0.sketch_size(a), r1.sketch_size(a)], dtype=np.uint64)
+            nmax = (max(int(counts.max()), 1) + 7) // 8 * 8
+            recv = torch.zeros(2 * 16 * nmax, dtype=torch.uint8, device="cuda")
+            r0.pack_sketch_device(a, recv[:16 * nmax].data_ptr(), nmax)
+            r1.pack_sketch_device(a, recv[16 * nmax:].data_ptr(), nmax)
+            union.set_sketch_gathered(a, recv.data_ptr(), nmax, counts, np.array([0, splits[a]], dtype=np.uint64))
+        full.build_graph()
+        union.build_graph()
+        for a in range(len(asms)):
+            s0, s1 = full.get_sketch(a), union.get_sketch(a)
+            for key in ("out_hash", "pos", "record", "record_first"):
+                assert np.array_equal(s0[key], s1[key]), (a, key)
+            assert np.array_equal(full.get_mx_flags(a), union.get_mx_flags(a))
+        g0, g1 = full.get_graph(), union.get_graph()
+        for key in g0:
+            assert np.array_equal(np.asarray(g0[key]), np.asarray(g1[key])), key
