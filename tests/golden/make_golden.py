@@ -55,74 +55,11 @@ CASES = [
 
 
 def install_igraph_standin():
-    """python-igraph is not installed here.  The reference only uses it as a container on this path
-    (Graph(), add_vertices, add_edges, get_eid, es()[attr]=list, iteration over vs()/es())."""
-    class _Vertex(dict):
-        def __init__(self, index, name):
-            super().__init__(name=name)
-            self.index = index
-
-    class _Edge(dict):
-        def __init__(self, index, source, target):
-            super().__init__()
-            self.index, self.source, self.target = index, source, target
-
-    class _EdgeSeq(list):
-        def __setitem__(self, key, values):
-            if isinstance(key, str):
-                assert len(values) == len(self)
-                for e, v in zip(self, values):
-                    dict.__setitem__(e, key, v)
-            else:
-                list.__setitem__(self, key, values)
-
-    class _VertexSeq(list):
-        def find(self, name):
-            return next(v for v in self if v["name"] == name)
-
-    class Graph:
-        def __init__(self):
-            self._vs, self._es, self._idx, self._eid = _VertexSeq(), _EdgeSeq(), {}, {}
-
-        def add_vertices(self, names):
-            for n in names:
-                self._idx[n] = len(self._vs)
-                self._vs.append(_Vertex(len(self._vs), n))
-
-        def add_edges(self, pairs):
-            for s, t in pairs:
-                a, b = self._idx[s], self._idx[t]
-                lo, hi = min(a, b), max(a, b)  # igraph reports an undirected edge as (lower id, higher id)
-                self._eid[(lo, hi)] = len(self._es)
-                self._es.append(_Edge(len(self._es), lo, hi))
-
-        def get_eid(self, s, t):
-            a, b = self._idx[s], self._idx[t]
-            return self._eid[(min(a, b), max(a, b))]
-
-    # `graph.vs[index]['name']` and `graph.vs.find(name)` are attribute-style accesses in ntjoin_utils
-    Graph.vs = property(lambda self: _CallableSeq(self._vs))
-    Graph.es = property(lambda self: _CallableSeq(self._es))
-
-    class _CallableSeq:
-        def __init__(self, seq):
-            self._seq = seq
-
-        def __call__(self):
-            return self._seq
-
-        def __getitem__(self, i):
-            return self._seq[i]
-
-        def __iter__(self):
-            return iter(self._seq)
-
-        def find(self, name):
-            return self._seq.find(name)
-
-    mod = types.ModuleType("igraph")
-    mod.Graph = Graph
-    sys.modules["igraph"] = mod
+    """python-igraph is not installed here: tests/golden/igraph_standin.py provides the container API the reference
+    uses on this path (and on the path-extraction step that follows it)."""
+    sys.path.insert(0, HERE)
+    import igraph_standin
+    igraph_standin.install()
 
 
 def run_reference(case_dir, ref_tsvs, ref_weights, target_tsv, target_weight, prefix):
@@ -146,6 +83,17 @@ def run_reference(case_dir, ref_tsvs, ref_weights, target_tsv, target_weight, pr
             filtered = ntjoin_utils.filter_minimizers(nj.list_mxs)   # ntjoin.py:198
             nj.make_minimizer_graph()                                # ntjoin.py:189-204 (writes <prefix>.mx.dot)
         g = nj.graph
+        # next row: the reference's own global filter + path extraction, for several -n values
+        # (reference bin/ntjoin.py:80-89,137-176; called at bin/ntjoin_assemble.py:759,779)
+        paths_by_n = {}
+        total_w = sum(nj.weights.values())
+        for n_min in sorted({1, 2, 3, int(total_w), int(total_w) + 1}):
+            nj.args.n = n_min
+            nj.graph = nj.filter_graph_global(g.copy())
+            with contextlib.redirect_stdout(io.StringIO()):
+                found = nj.find_paths()
+            paths_by_n[str(n_min)] = [[list(path) for path, _sub in comp] for comp in found]
+        nj.graph = g
         names = [v["name"] for v in g.vs()]
         edges = []
         for e in g.es():
@@ -158,6 +106,7 @@ def run_reference(case_dir, ref_tsvs, ref_weights, target_tsv, target_weight, pr
             "filtered": filtered,
             "vertices": sorted(names, key=int),
             "edges": edges,
+            "paths_by_n": paths_by_n,
         }
     finally:
         os.chdir(cwd)
