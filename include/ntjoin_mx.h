@@ -205,6 +205,20 @@ int mxg_get_graph(mxg_handle *h, mxg_graph_view *out);
    order, edges in first-seen order (the reference's own order is unspecified: python set order). */
 int mxg_write_dot(mxg_handle *h, const char *path);
 
+/* ---- next row: linear paths through the minimizer graph -------------------------------------------
+   What the reference computes with igraph right after the graph (bin/ntjoin_assemble.py:759,779): filter_graph_global
+   with minimum edge weight n (bin/ntjoin.py:80-89), then per component the branch filtering with rising thresholds
+   (filter_graph :69-77, find_paths_process :137-161), circular components opened (check_circularity :113-135), source
+   and target chosen by position in the highest-weight assembly (determine_source_vertex :91-103); a sub-component yields
+   a path iff it is a simple chain.  Vertices are indices into mxg_graph_view; paths are ordered by source vertex. */
+typedef struct mxg_paths_view {
+    uint64_t n_paths;
+    const uint64_t *path_first;      /* [n_paths+1] offsets into path_vertex                                     */
+    const uint32_t *path_vertex;     /* vertex indices, source -> target                                          */
+    const uint32_t *path_component;  /* [n_paths] id of the component of the globally filtered graph it came from */
+} mxg_paths_view;
+int mxg_find_paths(mxg_handle *h, int64_t min_edge_weight /* ntJoin's n */, mxg_paths_view *out);
+
 /* ---- text helpers used by the writers (host only; usable without a device) --------------------- */
 /* python repr() of a float / of a str, as Ntjoin.print_graph's f-strings produce them.  Returns the length
    written (excluding the NUL), or the length needed if it exceeds cap. */

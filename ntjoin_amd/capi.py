@@ -19,7 +19,7 @@ SYMBOLS = [
     "mxg_record_id", "mxg_record_length", "mxg_num_records", "mxg_assembly_weight",
     "mxg_sketch", "mxg_get_sketch", "mxg_get_sketch_device", "mxg_compute_strands", "mxg_set_sketch_device",
     "mxg_pack_sketch_device", "mxg_set_sketch_gathered", "mxg_write_tsv",
-    "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_write_dot",
+    "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_write_dot",
     "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers",
 ]
 
@@ -47,6 +47,11 @@ class GraphView(C.Structure):
                 ("vertex_record", C.POINTER(C.c_uint32)), ("n_edges", C.c_uint64),
                 ("edge_u", C.POINTER(C.c_uint32)), ("edge_v", C.POINTER(C.c_uint32)),
                 ("edge_support", C.POINTER(C.c_uint32)), ("edge_weight", C.POINTER(C.c_double))]
+
+
+class PathsView(C.Structure):
+    _fields_ = [("n_paths", C.c_uint64), ("path_first", C.POINTER(C.c_uint64)), ("path_vertex", C.POINTER(C.c_uint32)),
+                ("path_component", C.POINTER(C.c_uint32))]
 
 
 class Stats(C.Structure):
@@ -133,6 +138,7 @@ def load():
     L.mxg_build_graph.argtypes = [vp]
     L.mxg_get_mx_flags.argtypes = [vp, i32, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(u64)]
     L.mxg_get_graph.argtypes = [vp, C.POINTER(GraphView)]
+    L.mxg_find_paths.argtypes = [vp, C.c_int64, C.POINTER(PathsView)]
     L.mxg_write_dot.argtypes = [vp, cp]
     L.mxg_py_repr_double.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
     L.mxg_py_repr_double.restype = C.c_size_t

@@ -477,6 +477,23 @@ int mxg_get_graph(mxg_handle *h, mxg_graph_view *out)
     return MXG_OK;
 }
 
+int mxg_find_paths(mxg_handle *h, int64_t min_edge_weight, mxg_paths_view *out)
+{
+    if (!h || !out) return MXG_EINVAL;
+    try {
+        int rc = find_paths(h, min_edge_weight);
+        if (rc != MXG_OK) return rc;
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_find_paths");
+    }
+    const Paths &P = h->paths;
+    out->n_paths = P.component.size();
+    out->path_first = P.first.data();
+    out->path_vertex = P.vertex.data();
+    out->path_component = P.component.data();
+    return MXG_OK;
+}
+
 int mxg_write_dot(mxg_handle *h, const char *path)
 {
     if (!h || !path) return MXG_EINVAL;

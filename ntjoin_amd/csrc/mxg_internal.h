@@ -125,6 +125,13 @@ struct Graph {
     std::vector<double> ew;
 };
 
+struct Paths {  // result of mxg_find_paths (host copies)
+    bool valid = false;
+    std::vector<uint32_t> vertex;     // concatenated paths, vertex indices of the graph, source -> target
+    std::vector<uint64_t> first;      // [n_paths+1]
+    std::vector<uint32_t> component;  // [n_paths] component (root vertex index) of the globally filtered graph
+};
+
 struct Timers {
     double ms_hash = 0, ms_resolve = 0, ms_graph = 0;
     uint64_t launches_hash = 0, hash_bases = 0;
@@ -141,6 +148,8 @@ struct mxg_handle {
     std::string err;
     std::vector<mxg::Assembly *> asms;
     mxg::Graph graph;
+    mxg::Paths paths;
+    mxg::DevBuf pbuf[32];  // scratch of paths.hip
     mxg::Timers tm;
     mxg::HashTab tab{};
     mxg::DevBuf d_init_tab;  // direct-initialisation table (k/4 x 256 x 16 B), built by the first sketch
@@ -193,6 +202,7 @@ int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t w
 // graph.hip
 int build_graph(mxg_handle *h);
 int graph_to_host(mxg_handle *h);
+int find_paths(mxg_handle *h, int64_t n_min);  // paths.hip
 int flags_to_host(mxg_handle *h, Assembly *a);
 
 }  // namespace mxg

@@ -213,6 +213,16 @@ class MxEngine:
                 "edge_support": _np(g.edge_support, ne, np.uint32),
                 "edge_weight": _np(g.edge_weight, ne, np.float64)}
 
+    def find_paths(self, n=1):
+        """linear paths through the graph (ntJoin's -n = minimum edge weight): list of (component id, [vertex indices])"""
+        v = capi.PathsView()
+        self._check(self._lib.mxg_find_paths(self._h, int(n), C.byref(v)))
+        npaths = int(v.n_paths)
+        first = _np(v.path_first, npaths + 1, np.uint64)
+        verts = _np(v.path_vertex, int(first[-1]) if npaths else 0, np.uint32)
+        comp = _np(v.path_component, npaths, np.uint32)
+        return [(int(comp[i]), verts[int(first[i]):int(first[i + 1])].tolist()) for i in range(npaths)]
+
     def write_dot(self, path):
         self._check(self._lib.mxg_write_dot(self._h, str(path).encode()))
 

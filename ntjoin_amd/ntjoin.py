@@ -98,6 +98,16 @@ class Ntjoin:
                 self.list_mxs[assembly] = lists
         self.print_graph(self.graph)
 
+    def find_paths(self):
+        "Finds paths through the minimizer graph (global filter with args.n, branch filtering, linear paths)"
+        print(datetime.datetime.today(), ": Finding paths", file=sys.stdout)
+        found = self._engine.find_paths(int(getattr(self.args, "n", 1)))
+        by_comp = {}
+        for comp, verts in found:
+            by_comp.setdefault(comp, []).append(([self.graph.names[v] for v in verts], None))
+        print("\nTotal number of components in graph:", len(by_comp), "\n", sep=" ", file=sys.stdout, flush=True)
+        return list(by_comp.values())
+
     def print_graph(self, graph, out_prefix=None):
         "Prints the minimizer graph in dot format"
         out_graph = (self.args.p + ".mx.dot") if out_prefix is None else (out_prefix + "mx.dot")
