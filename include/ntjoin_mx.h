@@ -212,6 +212,7 @@ int mxg_write_dot(mxg_handle *h, const char *path);
    and target chosen by position in the highest-weight assembly (determine_source_vertex :91-103); a sub-component yields
    a path iff it is a simple chain.  Vertices are indices into mxg_graph_view; paths are ordered by source vertex. */
 typedef struct mxg_paths_view {
+    uint64_t n_components;           /* components of the globally filtered graph (bin/ntjoin.py:166-167)         */
     uint64_t n_paths;
     const uint64_t *path_first;      /* [n_paths+1] offsets into path_vertex                                     */
     const uint32_t *path_vertex;     /* vertex indices, source -> target                                          */

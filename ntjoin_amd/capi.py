@@ -50,7 +50,7 @@ class GraphView(C.Structure):
 
 
 class PathsView(C.Structure):
-    _fields_ = [("n_paths", C.c_uint64), ("path_first", C.POINTER(C.c_uint64)), ("path_vertex", C.POINTER(C.c_uint32)),
+    _fields_ = [("n_components", C.c_uint64), ("n_paths", C.c_uint64), ("path_first", C.POINTER(C.c_uint64)), ("path_vertex", C.POINTER(C.c_uint32)),
                 ("path_component", C.POINTER(C.c_uint32))]
 
 

@@ -487,6 +487,7 @@ int mxg_find_paths(mxg_handle *h, int64_t min_edge_weight, mxg_paths_view *out)
         return set_err(h, MXG_ENOMEM, "out of host memory in mxg_find_paths");
     }
     const Paths &P = h->paths;
+    out->n_components = P.n_components;
     out->n_paths = P.component.size();
     out->path_first = P.first.data();
     out->path_vertex = P.vertex.data();

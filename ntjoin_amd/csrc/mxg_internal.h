@@ -127,6 +127,7 @@ struct Graph {
 
 struct Paths {  // result of mxg_find_paths (host copies)
     bool valid = false;
+    uint64_t n_components = 0;        // components of the globally filtered graph (singletons included)
     std::vector<uint32_t> vertex;     // concatenated paths, vertex indices of the graph, source -> target
     std::vector<uint64_t> first;      // [n_paths+1]
     std::vector<uint32_t> component;  // [n_paths] component (root vertex index) of the globally filtered graph

@@ -82,6 +82,20 @@ __global__ __launch_bounds__(256) void kp_compress(uint32_t *parent, uint32_t n)
     parent[v] = r;
 }
 
+// number of components = number of roots (block-reduced, one atomic per block)
+__global__ __launch_bounds__(256) void kp_count_roots(const uint32_t *__restrict__ parent, uint32_t n, uint32_t *count)
+{
+    __shared__ uint32_t sh[256];
+    uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    sh[threadIdx.x] = (v < n && parent[v] == v) ? 1u : 0u;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && sh[0]) atomicAdd(count, sh[0]);
+}
+
 __global__ __launch_bounds__(256) void kp_degree(const uint32_t *__restrict__ eu, const uint32_t *__restrict__ ev,
                                                  const uint8_t *__restrict__ alive, uint32_t ne, uint32_t *deg)
 {
@@ -385,6 +399,10 @@ int find_paths(mxg_handle *h, int64_t n_min)
     if (ne) hipLaunchKernelGGL(kp_alive, ge, b, 0, h->stream, ew, ne, (double)n_min, do_filter, alive);
     int rc = components(h, eu, ev, alive, ne, nv, comp, d_flag);
     if (rc != MXG_OK) return rc;
+    MXG_HIP(h, hipMemsetAsync(d_flag + 1, 0, 4, h->stream));
+    hipLaunchKernelGGL(kp_count_roots, gv, b, 0, h->stream, comp, nv, d_flag + 1);
+    uint32_t n_comp = 0;
+    MXG_HIP(h, hipMemcpyAsync(&n_comp, d_flag + 1, 4, hipMemcpyDeviceToHost, h->stream));  // read at the next sync
 
     // branch filtering, all components at once: thresholds n, n+1, ... while some component still has a branch node
     for (double t = (double)n_min; t <= wsum; t += 1.0) {
@@ -487,6 +505,7 @@ int find_paths(mxg_handle *h, int64_t n_min)
     }
     MXG_HIP(h, hipStreamSynchronize(h->stream));
     P.first[n_paths] = n_pv;
+    P.n_components = n_comp;
     P.valid = true;
     return MXG_OK;
 }

@@ -221,6 +221,7 @@ class MxEngine:
         first = _np(v.path_first, npaths + 1, np.uint64)
         verts = _np(v.path_vertex, int(first[-1]) if npaths else 0, np.uint32)
         comp = _np(v.path_component, npaths, np.uint32)
+        self.n_components = int(v.n_components)
         return [(int(comp[i]), verts[int(first[i]):int(first[i + 1])].tolist()) for i in range(npaths)]
 
     def write_dot(self, path):

@@ -105,8 +105,10 @@ class Ntjoin:
         by_comp = {}
         for comp, verts in found:
             by_comp.setdefault(comp, []).append(([self.graph.names[v] for v in verts], None))
-        print("\nTotal number of components in graph:", len(by_comp), "\n", sep=" ", file=sys.stdout, flush=True)
-        return list(by_comp.values())
+        n_comp = self._engine.n_components
+        print("\nTotal number of components in graph:", n_comp, "\n", sep=" ", file=sys.stdout, flush=True)
+        # one list per component, as the reference returns (components without an accepted path give [])
+        return list(by_comp.values()) + [[] for _ in range(n_comp - len(by_comp))]
 
     def print_graph(self, graph, out_prefix=None):
         "Prints the minimizer graph in dot format"

@@ -35,6 +35,7 @@ def test_paths_match_reference_goldens(name):
         eng.build_graph()
         for n, ref_paths in ref["paths_by_n"].items():
             assert _canonical_gpu(eng, int(n)) == po.canonical(ref_paths), (name, n)
+            assert eng.n_components == len(ref_paths), (name, n)   # the reference returns one entry per component
 
 
 def test_paths_orientation_and_order():
@@ -207,3 +208,26 @@ def test_long_and_many_chains(length, n_chains):
             got = sorted((vh[np.array(p)].tolist() for _c, p in found), key=lambda p: p[0])
             want = sorted((hs[i * length:(i + 1) * length].tolist() for i in range(n_chains)), key=lambda p: p[0])
             assert got == want
+
+
+def test_ntjoin_class_find_paths(tmp_path, capsys):
+    """the Ntjoin counterpart class: load -> graph -> find_paths returns one list per component of (path, _) tuples with
+    vertex NAMES, as bin/ntjoin.py:137-176 does, and prints the component count"""
+    import argparse
+    from ntjoin_amd.ntjoin import Ntjoin
+    name = "f-f_w1000"
+    meta, ref = load_case(name)["meta"], load_case(name)["reference"]
+    os.chdir(os.path.join(GOLDEN, "cases", name))
+    args = argparse.Namespace(FILES=[r["tsv"] for r in meta["refs"]], s=meta["target"]["tsv"], l=meta["target"]["weight"],
+                              p=str(tmp_path / "out"), k=meta["k"], n=2, t=1)
+    nj = Ntjoin(args)
+    try:
+        nj.weights_list = [r["weight"] for r in meta["refs"]]
+        nj.load_minimizers_scaffold()
+        nj.make_minimizer_graph()
+        paths = nj.find_paths()
+    finally:
+        nj.close()
+    assert po.canonical([[p for p, _g in comp] for comp in paths]) == po.canonical(ref["paths_by_n"]["2"])
+    assert len(paths) == len(ref["paths_by_n"]["2"])      # one entry per component, empty ones included
+    assert f"Total number of components in graph: {len(paths)}" in capsys.readouterr().out
