@@ -19,11 +19,15 @@
 // their union is the exact sketch (low-complexity sequence simply degrades to the dense path).
 //
 // Kernels:
-//   k_hash_sparse  one lane per strip of S consecutive k-mers of one valid run: k warm-up steps then rolling
-//                  fwd/rc ntHash (split-rotate on 32-bit halves; one ds_read_b128 of the 20-entry step table per
-//                  base).  Candidates are staged per WAVE in LDS (ballot/mbcnt slot allocation, no atomics) and
-//                  flushed to an HBM arena with ONE atomic bump per flush, coalesced 16 B entries.
-//   k_reorder      arena entry -> its ordered slot (exclusive scan of per-strip counts + rank inside the strip)
+//   k_hash_sparse  one lane per strip of S consecutive k-mers of one valid run.  ntHash's split rotation never mixes
+//                  the top 31 bits of a hash with its low 33, so the candidate filter rolls ONLY the two 31-bit rings
+//                  (forward and reverse-complement): 3 VALU per ring per base, one ds_read_b64 of the 20-entry step
+//                  table, and "is (fwd+rev) below tau" decided from the rings up to the unknown carry out of the low
+//                  33 bits (a superset, exact for the min(fwd,rev) variant).  Captured k-mer indices go to the wave's
+//                  own arena slice (8 B entries, no atomics).
+//   k_reorder      arena entry -> full 64-bit hash of that k-mer (table-driven direct formula) -> its ordered slot
+//                  (exclusive scan of per-strip counts + rank inside the strip); entries whose exact hash turns out
+//                  >= tau stay in the list and are skipped by k_resolve
 //   k_hash_dense   every k-mer is a candidate, written at its own index (DENSE_ONLY mode and gap fix-up)
 //   k_resolve      one lane per candidate: nearest smaller / smaller-or-equal neighbour scan; gap detection
 //   k_count/k_scan_sums/k_emit   ordered stream compaction into the sketch arrays
@@ -41,7 +45,7 @@ namespace mxg {
 enum Scratch {
     SC_CAND_H, SC_CAND_K, SC_CAND_C, SC_SEL, SC_BSUM, SC_CTRL, SC_ARENA, SC_STRIP_CNT, SC_STRIP_META,
     SC_STRIP_PREF, SC_SBSUM, SC_GAPS, SC_WAVE_CNT, SC_ST_HASH, SC_ST_POS, SC_ST_REC, SC_ST_FWD, SC_G_HASH, SC_G_POS,
-    SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_COUNT
+    SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_TICKETS_HASH, SC_TICKETS_RESOLVE, SC_OFF256, SC_WAVE_PREF, SC_COUNT
 };
 static_assert(SC_COUNT <= 40, "scratch pool too small");
 
@@ -212,147 +216,205 @@ struct SparseParams {
     uint32_t strip_lo, strip_hi;
     uint32_t k;
     uint32_t S;           // k-mers per strip (multiple of 16, <= 1024)
-    uint32_t tau_hi;      // candidate iff high word of min_hash < tau_hi
-    uint4 *arena;         // wave w owns entries [w*wave_cap, (w+1)*wave_cap): {hash lo, hash hi, strip (rel.), j | seq<<10}
+    uint32_t tau_hi;      // candidate iff high word of min_hash < tau_hi (EVEN: tau_hi = 2T, T on the top 31 bits)
+    uint2 *arena;         // wave w owns entries [w*wave_cap, (w+1)*wave_cap): {strip (rel.), j | seq<<10}
     uint32_t wave_cap;
     uint32_t *wave_cnt;   // [n_waves] candidates each wave produced (may exceed wave_cap: overflow, batch is redone)
     uint32_t *ctrl;       // [0] max over waves of wave_cnt (atomicMax, only written on overflow)
     uint32_t *strip_cnt;  // [n_strips] candidates per strip
-    uint2 *strip_meta;    // [n_strips] {contig, kidx of the strip's first k-mer}
+    uint32_t *wave_pref;  // [n_waves] candidates per wave; the block that finishes last scans it in place (exclusive)
+    uint32_t n_waves;
+    uint32_t *done;       // ticket counters of last_block_ticket
+    uint4 *strip_meta;    // [n_strips] {contig, kidx of the strip's first k-mer, base offset of it lo, hi}
     const uint4 *init_tab; // direct-initialisation table (make_init_tab)
     HashTab tab;
 };
 
+// The top-31 rings.  A 64-bit ntHash value is two rings that srol/sror rotate separately: bits 0..32 and bits 33..63.
+// With F, R the 31-bit top rings of the forward and reverse-complement hashes,
+//     F' = rotl31(F) ^ Tf        R' = rotr31(R ^ Tr)            (Tf, Tr: top rings of the step-table entry)
+// and the top 31 bits of fwd+rev are (F + R + c) mod 2^31 with c the (unknown here) carry out of the low 33 bits.
+// For tau = T * 2^33:  fwd+rev < tau  =>  (F+R) mod 2^31 in {-1, 0, .., T-1}.  The kernel keeps the COMPLEMENTED rings
+// (same recurrences: rotation and xor commute with complement), x = ~F in bits 30..0 and y = ~R in bits 31..1, because
+// then that interval test is a single unsigned compare:  (x<<1) + y  >=  2^32 - 2T - 2.  (Bit 31 of x and bit 0 of y
+// are don't-cares that the updates never propagate into the rings.)  min(fwd,rev) < tau is exactly F < T or R < T.
+// (min variant: max(x<<1, y) >= 2^32 - 2T.)
+__device__ __forceinline__ void ring_step(uint32_t &x, uint32_t &y, const uint2 t)
+{
+    x = ((x << 1) | ((x >> 30) & 1u)) ^ t.x;                      // v_bfe, v_lshl_or, v_xor
+    const uint32_t u = y ^ t.y;
+    y = __builtin_amdgcn_alignbit(u >> 1, u, 1);                  // (u >> 1) | (u[1] << 31)
+}
+
 // Packed bases are read straight from HBM/L2 by each lane (one 32-bit word per 16 steps per stream, requested one
 // block ahead).  Staging the wave's strips through LDS with coalesced row loads was measured and does not pay
-// (profiles/r01_notes.md): the kernel is bound by VALU issue and by what the candidate capture costs, not by memory.
+// (profiles/r01_notes.md): the kernel is bound by VALU issue, not by memory.
+//
+// Capture: the 16 test results of a block are shifted into one register per lane (v_addc with the compare's carry:
+// one VALU per step, no branch, no scalar mask bookkeeping, so a block is one straight-line basic block whose table
+// reads the compiler can hoist).  Once per block the lanes with a non-zero history store ONE 8-byte entry
+// {strip, bits | block<<16 | rank<<22} to the wave's own arena slice (slot = running count + rank among the storing
+// lanes: no atomics, no LDS staging, nothing waits on the stores).  k_reorder expands the bits.
+// ABL (profiling builds only): 1 = ring updates only, 2 = + test and history, 0 = full.
 template <int VARIANT, int ABL = 0>
 __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
 {
-    __shared__ uint4 tab[20];
-    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
+    __shared__ uint4 tab[20];    // full step table: only init_direct's k%4 remainder uses it
+    __shared__ uint2 ring[16];   // top rings of the rolling entries (out<<2 | in): {Tf, Tr<<1}
+    if (threadIdx.x < 20) {
+        const uint4 e = p.tab.e[threadIdx.x];
+        tab[threadIdx.x] = e;
+        if (threadIdx.x < 16) ring[threadIdx.x] = make_uint2(e.y >> 1, e.w & ~1u);
+    }
     __syncthreads();
     const uint32_t S = p.S;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t srel = blockIdx.x * 256u + threadIdx.x;        // strip index relative to strip_lo
     const uint32_t s = p.strip_lo + srel;
-    const bool active = s < p.strip_hi;                          // inactive lanes stay alive (wave-wide steps)
-    uint32_t len = 0, contig = 0, kidx = 0;
-    uint64_t b = 0;
-    if (active) {
+    uint32_t len = 0;                                            // 0 for lanes beyond the batch: they stay alive
+    uint64_t b = 0;                                              // (wave-wide steps) and never capture anything
+    if (s < p.strip_hi) {
         const uint32_t lo = find_run(p.run_strip0, p.run_lo, p.run_hi, s);
         const Run run = p.runs[lo];
         const uint32_t j0 = (s - p.run_strip0[lo]) * S;
         len = min(S, run.n_kmers - j0);
         b = run.base_off + j0;
-        contig = run.contig;
-        kidx = run.kidx0 + j0;
-        p.strip_meta[srel] = make_uint2(contig, kidx);
+        p.strip_meta[srel] = make_uint4(run.contig, run.kidx0 + j0, (uint32_t)b, (uint32_t)(b >> 32));
     }
     const uint32_t k = p.k;
-    const uint32_t tau_hi = p.tau_hi;
+    const uint32_t thr = 0u - p.tau_hi - (VARIANT == MXG_VARIANT_V1_MIN ? 0u : 2u);
     const uint32_t wave_id = blockIdx.x * 4u + wv;
-    uint4 *const region = p.arena + (size_t)wave_id * p.wave_cap;  // this wave's private slice of the arena
+    uint2 *const region = p.arena + (size_t)wave_id * p.wave_cap;  // this wave's private slice of the arena
     const uint32_t wave_cap = p.wave_cap;
-    uint32_t cnt_w = 0;  // wave-uniform: candidates this wave has written
+    uint32_t cnt_w = 0;  // wave-uniform: entries this wave has written
     uint32_t seq = 0;    // this lane's candidates so far (rank inside its strip)
+    uint32_t abl_acc = 0;  // (profiling builds only)
 
-    // Candidate capture is branch-free per step: a lane keeps at most ONE pending candidate in registers
-    // (hash lo/hi, step j), selected with v_cndmask.  Every 8 steps the pending lanes store theirs to the wave's
-    // arena slice with fire-and-forget 16 B global stores (slot = running count + rank among pending lanes: no
-    // atomics, no LDS staging, nothing waits on the stores).  A second candidate in a lane that still holds one
-    // forces an early drain (rare).  Ablation (profiles/r01_notes.md): an exec-masked capture body executed in
-    // 64 % of the steps cost as much as the hashing itself; LDS staging + atomic flush cost ~40 us of 140.
-    uint32_t pend_lo = 0, pend_hi = 0, pend_j = 0;
-    uint64_t pend_mask = 0;  // wave-uniform: lanes holding a pending candidate
-    uint32_t abl_acc = 0;    // (profiling builds only)
-    auto drain = [&]() {
-        if (ABL == 4) { abl_acc += pend_lo ^ pend_hi ^ pend_j; pend_mask = 0; return; }
-        if ((pend_mask >> lane) & 1ull) {  // this lane holds a pending candidate
-            const uint32_t slot = cnt_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(pend_mask >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)pend_mask, 0u));
-            if (slot < wave_cap) region[slot] = make_uint4(pend_lo, pend_hi, srel, pend_j | (seq << 10));
-            ++seq;
-        }
-        cnt_w += (uint32_t)__popcll(pend_mask);
-        pend_mask = 0;
-    };
-    auto visit = [&](const H2 &h, uint32_t j, bool check_len) {
-        const uint64_t h0 = canonical<VARIANT>(h);
-        if (ABL == 1) { abl_acc ^= (uint32_t)(h0 >> 32); return; }
-        bool c = (uint32_t)(h0 >> 32) < tau_hi;
-        if (check_len) c = c && (j < len);
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(c);
-        if (ABL == 2) { if (mask) abl_acc += 1; return; }
-        if (mask & pend_mask) drain();  // wave-uniform, rare
-        pend_lo = c ? (uint32_t)h0 : pend_lo;
-        pend_hi = c ? (uint32_t)(h0 >> 32) : pend_hi;
-        pend_j = c ? j : pend_j;
-        pend_mask |= mask;
-    };
-
-    H2 h = {0u, 0u, 0u, 0u};
-    init_direct(h, p.packed, b, k, p.init_tab, tab);  // replaces k rolling warm-up steps per strip
-    visit(h, 0, true);
-    // strips shorter than S only occur at the end of a run: when every lane of the wave owns a full strip the
-    // per-step length test is dropped (wave-uniform loop versioning)
-    const bool all_full = __builtin_amdgcn_ballot_w64(len != S) == 0;
-    // table index of step u of a block: (out_u << 2 | in_u) << 4 (byte offset of a 16-byte entry), from the two
-    // 16-base words; the words of block blk+1 are requested before block blk is hashed (software prefetch)
-    const unsigned char *tabb = reinterpret_cast<const unsigned char *>(tab);
-    uint32_t cout = fetch16(p.packed, b);
-    uint32_t cin = fetch16(p.packed, b + k);
+    uint32_t x, y;
+    {
+        H2 h = {0u, 0u, 0u, 0u};
+        init_direct(h, p.packed, b, k, p.init_tab, tab);  // replaces k rolling warm-up steps per strip
+        x = ~(h.fhi >> 1);
+        y = ~h.rhi;
+    }
+    // byte offset of step u's ring entry = (out_u << 2 | in_u) << 3.  The two 16-base words of a block are interleaved
+    // once into nibble streams (even steps, odd steps), so a step costs one shift and one mask.  The words of block
+    // blk+1 are requested before block blk is hashed (software prefetch).
+    const unsigned char *ringb = reinterpret_cast<const unsigned char *>(ring);
+    const uint32_t *po = p.packed + (b >> 4), *pi = p.packed + ((b + k) >> 4);
+    const uint32_t so = ((uint32_t)b & 15u) * 2u, si = ((uint32_t)(b + k) & 15u) * 2u;
+    uint32_t o0 = po[0], o1 = po[1], i0 = pi[0], i1 = pi[1];
     const uint32_t nblk = S / 16;
-    auto run = [&](auto chk) {
-        constexpr bool CHECK_LEN = decltype(chk)::value;
 #pragma unroll 1
-        for (uint32_t blk = 0; blk < nblk; ++blk) {
-            const uint32_t ncout = fetch16(p.packed, b + 16u * (blk + 1));  // reads stay inside the padded buffer
-            const uint32_t ncin = fetch16(p.packed, b + k + 16u * (blk + 1));
-            const uint32_t jb = 1u + 16u * blk;
-            const bool last_blk = blk + 1 == nblk;
+    for (uint32_t blk = 0; blk < nblk; ++blk) {
+        const uint32_t o2 = po[blk + 2], i2 = pi[blk + 2];       // next block's words; reads stay inside the padding
+        const uint32_t cout = __builtin_amdgcn_alignbit(o1, o0, so);
+        const uint32_t cin = __builtin_amdgcn_alignbit(i1, i0, si);
+        o0 = o1; o1 = o2; i0 = i1; i1 = i2;
+        constexpr uint32_t M = 0x33333333u;
+        const uint32_t ze = ((cout & M) << 2) | (cin & M);        // nibble v = (out, in) of step 2v
+        const uint32_t zo = (cout & ~M) | ((cin >> 2) & M);       // nibble v = (out, in) of step 2v+1
+        uint32_t bits = 0;                                       // bit 15-u: k-mer 16*blk+u passed the ring test
 #pragma unroll
-            for (uint32_t u = 0; u < 16; ++u) {
-                // (cout >> 2u & 3) << 6 | (cin >> 2u & 3) << 4 with constant shifts: two shift-and-mask + one or
-                const uint32_t o6 = (2 * u >= 6 ? cout >> (2 * u - 6) : cout << (6 - 2 * u)) & 0xC0u;
-                const uint32_t i4 = (2 * u >= 4 ? cin >> (2 * u - 4) : cin << (4 - 2 * u)) & 0x30u;
-                nt_step(h, *reinterpret_cast<const uint4 *>(tabb + (o6 | i4)));
-                if (u == 15 && last_blk) break;  // j == S: beyond the strip
-                visit(h, jb + u, CHECK_LEN);
-                if ((u & 7u) == 7u && (ABL == 0 || ABL >= 3) && pend_mask) drain();
+        for (uint32_t u = 0; u < 16; ++u) {
+            // k-mer j = 16*blk + u is in (x, y): test, then roll to j+1 (the last roll of a strip is never looked at)
+            if (ABL != 1) {
+                const uint32_t v = VARIANT == MXG_VARIANT_V1_MIN ? max(x << 1, y) : (x << 1) + y;
+                // bits = 2*bits + (v >= thr): the compare's carry goes straight into the add
+                asm("v_cmp_le_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v), "s"(thr) : "vcc");
             }
-            cout = ncout;
-            cin = ncin;
+            const uint32_t z = (u & 1u) ? zo : ze;
+            const uint32_t sh = 4u * (u >> 1);
+            const uint32_t off = (sh >= 3u ? z >> (sh - 3u) : z << (3u - sh)) & 0x78u;
+            ring_step(x, y, *reinterpret_cast<const uint2 *>(ringb + off));
         }
-    };
-    if (all_full) run(std::false_type{}); else run(std::true_type{});
-    if (pend_mask) drain();
-    if (ABL != 0 && abl_acc == 0x12345u) p.ctrl[3] = abl_acc;  // keep the ablated work alive
-    if (active) p.strip_cnt[srel] = seq;
+        if (ABL == 1) { abl_acc ^= x + y; continue; }
+        if (ABL == 2) { abl_acc += bits; continue; }
+        // k-mers at or beyond the strip's length (end of a run, lanes beyond the batch) do not count
+        const uint32_t j0 = 16u * blk;
+        const uint32_t nvalid = len > j0 ? min(len - j0, 16u) : 0u;
+        bits &= 0xFFFFu & ~(0xFFFFu >> nvalid);
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(bits != 0u);
+        if (mask) {  // wave-uniform; almost always taken (64 lanes x 16 k-mers at ~1.8 %)
+            if (bits) {
+                const uint32_t slot = cnt_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (slot < wave_cap) region[slot] = make_uint2(srel, bits | (blk << 16) | (seq << 22));
+                seq += (uint32_t)__popc(bits);
+            }
+            cnt_w += (uint32_t)__popcll(mask);
+        }
+    }
+    if (ABL != 0) {
+        if (abl_acc == 0x12345u) p.ctrl[3] = abl_acc;  // keep the ablated work alive
+        return;
+    }
+    if (s < p.strip_hi) p.strip_cnt[srel] = seq;
+    // candidates of the whole wave (the ordered arrays hold wave_cap per wave)
+    const uint32_t tot = wave_sum_u32(seq);
     if (lane == 0) {
         p.wave_cnt[wave_id] = cnt_w;
-        if (cnt_w > wave_cap) atomicMax(&p.ctrl[0], cnt_w);  // overflow: the host redoes the batch with this capacity
+        publish_u32(&p.wave_pref[wave_id], tot);
+        if (tot > wave_cap) atomicMax(&p.ctrl[0], tot);  // overflow: the host redoes the batch with this capacity
     }
+    // the block that finishes last turns the per-wave counts into each wave's first ordered slot (+ the total)
+    if (last_block_ticket(p.done, blockIdx.x, gridDim.x)) block_scan_counts(p.wave_pref, p.wave_pref, p.n_waves, p.ctrl + 4);
 }
 
-// arena entry -> ordered candidate slot: one block per wave slice
-__global__ __launch_bounds__(256) void k_reorder(const uint4 *__restrict__ arena, const uint32_t *__restrict__ wave_cnt,
-                                                 uint32_t wave_cap, uint32_t n_cap, const uint32_t *__restrict__ strip_pref,
-                                                 const uint2 *__restrict__ strip_meta, uint64_t *__restrict__ ch,
-                                                 uint32_t *__restrict__ ck, uint32_t *__restrict__ cc)
+// arena entry -> full hashes -> ordered candidate slots: one block per wave slice, one thread per entry (1.15
+// candidates per entry on average).  The 64-bit canonical hash of each captured k-mer comes from the direct formula
+// (k/4 table lookups on the packed bases, which this block's 64 strips keep hot in L2).  An entry whose exact hash is
+// >= tau (the ring test cannot see the carry out of the low 33 bits) keeps its slot; k_resolve treats it as absent.
+struct ReorderParams {
+    const uint2 *arena;
+    const uint32_t *wave_cnt;
+    uint32_t wave_cap, n_cap;
+    const uint32_t *strip_cnt;   // [n_strips] candidates per strip
+    uint32_t n_strips;
+    const uint32_t *wave_pref;   // [n_waves] ordered slot of each wave's first candidate (scanned by k_hash_sparse)
+    const uint4 *strip_meta;
+    const uint32_t *packed;
+    const uint4 *init_tab;
+    uint32_t k;
+    uint64_t *ch;
+    uint32_t *ck, *cc;
+    HashTab tab;
+};
+
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_reorder(const ReorderParams p)
 {
+    __shared__ uint4 tab[20];
+    __shared__ uint32_t spref[64];  // ordered slot of the first candidate of each of this wave's 64 strips
+    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
     const uint32_t wv = blockIdx.x;
-    const uint32_t cnt = min(wave_cnt[wv], wave_cap);
-    const uint4 *src = arena + (size_t)wv * wave_cap;
+    if (threadIdx.x < 64) {  // exclusive scan over the strips: the wave's first slot + prefix inside the wave
+        const uint32_t s = wv * 64u + threadIdx.x;
+        const uint32_t c = s < p.n_strips ? p.strip_cnt[s] : 0u;
+        spref[threadIdx.x] = p.wave_pref[wv] + wave_inclusive_u32(c, threadIdx.x) - c;
+    }
+    __syncthreads();
+    const uint32_t cnt = min(p.wave_cnt[wv], p.wave_cap);
+    const uint2 *src = p.arena + (size_t)wv * p.wave_cap;
     for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-        const uint4 a = src[i];
-        const uint32_t j = a.w & 1023u, seq = a.w >> 10;
-        const uint32_t dst = strip_pref[a.z] + seq;
-        if (dst >= n_cap) continue;  // only when a wave overflowed its slice: the host redoes the batch
-        const uint2 sm = strip_meta[a.z];
-        ch[dst] = ((uint64_t)a.y << 32) | a.x;
-        ck[dst] = sm.y + j;
-        cc[dst] = sm.x;
+        const uint2 a = src[i];
+        uint32_t bits = a.y & 0xFFFFu;
+        const uint32_t j0 = ((a.y >> 16) & 63u) * 16u;
+        uint32_t dst = spref[a.x & 63u] + (a.y >> 22);
+        const uint4 sm = p.strip_meta[a.x];
+        const uint64_t b0 = (((uint64_t)sm.w << 32) | sm.z) + j0;
+        while (bits) {  // most significant bit = first k-mer of the block
+            const uint32_t u = (uint32_t)__clz((int)bits) - 16u;
+            bits &= ~(0x8000u >> u);
+            if (dst < p.n_cap) {  // beyond it only when a wave overflowed: the host redoes the batch
+                H2 h = {0u, 0u, 0u, 0u};
+                init_direct(h, p.packed, b0 + u, p.k, p.init_tab, tab);
+                p.ch[dst] = canonical<VARIANT>(h);
+                p.ck[dst] = sm.y + j0 + u;
+                p.cc[dst] = sm.x;
+            }
+            ++dst;
+        }
     }
 }
 
@@ -365,6 +427,7 @@ struct ResolveParams {
     const uint32_t *n_ptr;  // number of candidates (device), clamped to n_cap
     uint32_t n_cap;
     const uint32_t *ovf;    // != 0: a wave overflowed its arena slice, candidate arrays are incomplete -> do nothing
+    uint64_t tau;           // entries with hash >= tau are not candidates (ring-test false positives); dense: 2^64-1
     const uint32_t *ctg_nk;
     uint32_t w;
     uint8_t *sel;
@@ -373,6 +436,10 @@ struct ResolveParams {
     uint4 *gaps;              // {contig, k_lo, k_hi, 0}
     uint32_t gap_cap;
     uint32_t *gap_count;
+    // fused count + scan (COUNT): minimizers per block of 256 candidates; the block that finishes last scans them
+    uint32_t *off256;         // [gridDim.x] -> exclusive offsets
+    uint32_t *n_sel;          // ctrl[2..3]: number of selected candidates
+    uint32_t *done;           // ticket counters of last_block_ticket
 };
 
 __device__ __forceinline__ void push_gap(const ResolveParams &p, uint32_t c, uint32_t lo, uint32_t hi)
@@ -447,7 +514,16 @@ __device__ __forceinline__ bool coop_right_blocked(const CoopCtx &q, uint32_t la
 constexpr int RH = 128;  // halo (candidates) staged on each side of a block's 256 candidates
 constexpr int RP = 4;    // padding entries so that 4-wide neighbour groups never index outside the arrays
 
-template <bool GAPS>
+// the last thing a block of k_resolve<.., COUNT> that holds candidates does: its count, and the scan if it is the last
+// one out (blocks beyond the n candidates take no part)
+__device__ __forceinline__ void resolve_finish(const ResolveParams &p, uint32_t n, uint32_t block_count)
+{
+    const uint32_t n_blocks = (n + 255u) / 256u;
+    if (threadIdx.x == 0) publish_u32(&p.off256[blockIdx.x], block_count);
+    if (last_block_ticket(p.done, blockIdx.x, n_blocks)) block_scan_counts(p.off256, p.off256, n_blocks, p.n_sel);
+}
+
+template <bool GAPS, bool COUNT>
 __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
 {
     __shared__ uint64_t lh[256 + 2 * RH + 2 * RP];
@@ -538,27 +614,49 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
         const bool blocked = coop_right_blocked(q, lane, bi, bh, bkx, bc, RH + 1, bneed);
         if ((int)lane == src && blocked) s = false;
     }
-    if (!live) return;
-    p.sel[i] = (s && h != 0xFFFFFFFFFFFFFFFFull) ? 1 : 0;  // btllib never reports min_hash == 2^64-1
+    // An entry >= tau is not a candidate at all (it never blocks anybody: every real candidate is < tau <= it).
+    // btllib never reports min_hash == 2^64-1.
+    const uint64_t tau = p.tau;
+    const bool absent = h >= tau;
+    const bool chosen = live && s && !absent && h != 0xFFFFFFFFFFFFFFFFull;
+    if (live) p.sel[i] = chosen ? 1 : 0;
 
-    if (GAPS) {
-        // candidate-free stretches of >= w k-mers hold windows whose minimum is not a candidate
-        const bool first = (i == 0) || ((p.cc[i - 1] & 0x7FFFFFFFu) != c);
-        if (first) {
-            uint32_t pc = (i == 0) ? p.ctg_lo : (p.cc[i - 1] & 0x7FFFFFFFu) + 1;
-            for (; pc < c; ++pc) push_gap(p, pc, 0, p.ctg_nk[pc] - 1);  // contigs without any candidate
-            if (kx >= w) push_gap(p, c, 0, kx - 1);
-        }
-        const bool last = (i + 1 >= n) || ((p.cc[i + 1] & 0x7FFFFFFFu) != c);
-        if (!last) {
-            uint32_t nx = p.ck[i + 1];
-            if (nx - kx - 1 >= w) push_gap(p, c, kx + 1, nx - 1);
-        } else {
-            if (nk - 1 - kx >= w) push_gap(p, c, kx + 1, nk - 1);
-            if (i + 1 >= n)
-                for (uint32_t nc = c + 1; nc < p.ctg_hi; ++nc) push_gap(p, nc, 0, p.ctg_nk[nc] - 1);
+    if (GAPS && live) {
+        // candidate-free stretches of >= w k-mers hold windows whose minimum is not a candidate.  Every real candidate
+        // reports the stretch up to the next real one (and the first reports what precedes it); absent entries
+        // (about one in 10^9) are stepped over.  lh[] outside the candidate array is 0, i.e. "not absent".
+        if (!absent) {
+            int64_t jp = (int64_t)i - 1;
+            if (lh[li - 1] >= tau) {
+                do --jp; while (jp >= 0 && p.ch[jp] >= tau);
+            }
+            const bool first = (jp < 0) || ((p.cc[jp] & 0x7FFFFFFFu) != c);
+            if (first) {
+                uint32_t pc = (jp < 0) ? p.ctg_lo : (p.cc[jp] & 0x7FFFFFFFu) + 1;
+                for (; pc < c; ++pc) push_gap(p, pc, 0, p.ctg_nk[pc] - 1);  // contigs without any candidate
+                if (kx >= w) push_gap(p, c, 0, kx - 1);
+            }
+            uint32_t jn = i + 1;
+            if (lh[li + 1] >= tau) {
+                do ++jn; while (jn < n && p.ch[jn] >= tau);
+            }
+            const bool last = (jn >= n) || ((p.cc[jn] & 0x7FFFFFFFu) != c);
+            if (!last) {
+                uint32_t nx = p.ck[jn];
+                if (nx - kx - 1 >= w) push_gap(p, c, kx + 1, nx - 1);
+            } else {
+                if (nk - 1 - kx >= w) push_gap(p, c, kx + 1, nk - 1);
+                if (jn >= n)
+                    for (uint32_t nc = c + 1; nc < p.ctg_hi; ++nc) push_gap(p, nc, 0, p.ctg_nk[nc] - 1);
+            }
+        } else if (i == 0) {  // nobody else speaks for a batch whose every entry is absent
+            uint32_t jn = 1;
+            while (jn < n && p.ch[jn] >= tau) ++jn;
+            if (jn >= n)
+                for (uint32_t pc = p.ctg_lo; pc < p.ctg_hi; ++pc) push_gap(p, pc, 0, p.ctg_nk[pc] - 1);
         }
     }
+    if (COUNT) resolve_finish(p, n, (uint32_t)__syncthreads_count(chosen ? 1 : 0));
 }
 
 // k_count with the element count read from device memory
@@ -589,7 +687,8 @@ struct EmitParams {
     const uint32_t *n_ptr;
     uint32_t n_cap;
     const uint32_t *ovf;   // see ResolveParams
-    const uint32_t *bsum;  // exclusive block offsets
+    const uint32_t *bsum;  // exclusive offsets: tile t starts at bsum[t * bsum_stride]
+    uint32_t bsum_stride;  // 1: per 1024-tile (k_count_n + k_scan_sums), 4: per 256 candidates (k_resolve's fused scan)
     const Run *runs;
     const uint32_t *ctg_run0, *ctg_rec;
     uint64_t mult;         // 1 ^ (k * MULTISEED)
@@ -609,7 +708,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
     const uint32_t fl = load_flags4(p.sel, base, n);
     uint32_t c = count_flags4(fl);
-    uint64_t o = p.out_base + p.bsum[blockIdx.x] + block_exclusive_256(c, sh);
+    uint64_t o = p.out_base + p.bsum[blockIdx.x * p.bsum_stride] + block_exclusive_256(c, sh);
     if (c == 0) return;
     for (int u = 0; u < TILE_PER_THREAD; ++u) {
         uint32_t i = base + u;
@@ -809,6 +908,19 @@ struct Driver {
     }
     DevBuf &sc(int i) { return h->scratch[slot][i]; }
 
+    // ticket counters of a fused "last block scans" launch (scan_kernels.h): zeroed at allocation, self-resetting
+    int tickets(int which, uint32_t grid_blocks, uint32_t **counters)
+    {
+        DevBuf &b = sc(which);
+        const size_t need = ((size_t)grid_blocks / 64 + 4) * LB_STRIDE * 4;
+        if (need > b.bytes) {
+            MXG_HIP(h, b.ensure(need));
+            MXG_HIP(h, hipMemsetAsync(b.p, 0, b.bytes, st));
+        }
+        *counters = b.as<uint32_t>();
+        return MXG_OK;
+    }
+
     int ev_begin(uint64_t bases, bool is_hash)
     {
         if (!timing) return MXG_OK;
@@ -853,9 +965,43 @@ struct Driver {
         return b;
     }
 
+    // sparse path: resolve + gap detection + per-256 counts + their scan in ONE launch (offsets in SC_OFF256, total
+    // in ctrl[2..3]); emit(..., true) then places the minimizers
+    int resolve_count(const Tables &T, uint32_t n_cap, uint32_t ctg_lo, uint32_t ctg_hi, uint64_t tau)
+    {
+        if (!n_cap) return MXG_OK;
+        MXG_HIP(h, sc(SC_SEL).ensure(std::max<uint32_t>(n_cap, 16)));
+        const uint32_t blocks = (n_cap + 255) / 256;
+        MXG_HIP(h, sc(SC_OFF256).ensure((size_t)blocks * 4 + 64));
+        uint32_t *ctrl = sc(SC_CTRL).as<uint32_t>();
+        ResolveParams rp;
+        rp.ch = sc(SC_CAND_H).as<uint64_t>();
+        rp.ck = sc(SC_CAND_K).as<uint32_t>();
+        rp.cc = sc(SC_CAND_C).as<uint32_t>();
+        rp.n_ptr = ctrl + 4;
+        rp.n_cap = n_cap;
+        rp.ovf = ctrl;
+        rp.tau = tau;
+        rp.ctg_nk = T.d_ctg_nk;
+        rp.w = h->cfg.w;
+        rp.sel = sc(SC_SEL).as<uint8_t>();
+        rp.ctg_lo = ctg_lo;
+        rp.ctg_hi = ctg_hi;
+        rp.gaps = sc(SC_GAPS).as<uint4>();
+        rp.gap_cap = GAP_CAP;
+        rp.gap_count = ctrl + 1;
+        rp.off256 = sc(SC_OFF256).as<uint32_t>();
+        rp.n_sel = ctrl + 2;
+        int rc = tickets(SC_TICKETS_RESOLVE, blocks, &rp.done);
+        if (rc != MXG_OK) return rc;
+        hipLaunchKernelGGL((k_resolve<true, true>), dim3(blocks), dim3(256), 0, st, rp);
+        MXG_HIP(h, hipGetLastError());
+        return MXG_OK;
+    }
+
     // resolve -> count -> scan over candidates already in SC_CAND_*; n candidates read from ctrl[4] (<= n_cap)
     template <bool GAPS>
-    int resolve_and_count(const Tables &T, uint32_t n_cap, uint32_t ctg_lo, uint32_t ctg_hi)
+    int resolve_and_count(const Tables &T, uint32_t n_cap, uint32_t ctg_lo, uint32_t ctg_hi, uint64_t tau)
     {
         const uint32_t n_tiles = (n_cap + TILE - 1) / TILE;
         MXG_HIP(h, sc(SC_SEL).ensure(std::max<uint32_t>(n_cap, 16)));
@@ -868,6 +1014,7 @@ struct Driver {
         rp.n_ptr = ctrl + 4;
         rp.n_cap = n_cap;
         rp.ovf = ctrl;
+        rp.tau = tau;
         rp.ctg_nk = T.d_ctg_nk;
         rp.w = h->cfg.w;
         rp.sel = sc(SC_SEL).as<uint8_t>();
@@ -876,8 +1023,11 @@ struct Driver {
         rp.gaps = sc(SC_GAPS).as<uint4>();
         rp.gap_cap = GAP_CAP;
         rp.gap_count = ctrl + 1;
+        rp.off256 = nullptr;
+        rp.n_sel = nullptr;
+        rp.done = nullptr;
         if (n_cap) {
-            hipLaunchKernelGGL(k_resolve<GAPS>, dim3((n_cap + 255) / 256), dim3(256), 0, st, rp);
+            hipLaunchKernelGGL((k_resolve<GAPS, false>), dim3((n_cap + 255) / 256), dim3(256), 0, st, rp);
             hipLaunchKernelGGL(k_count_n, dim3(n_tiles), dim3(256), 0, st, rp.sel, rp.n_ptr, n_cap,
                                sc(SC_BSUM).as<uint32_t>());
         }
@@ -887,8 +1037,9 @@ struct Driver {
         return MXG_OK;
     }
 
+    // offsets: SC_BSUM per 1024-tile (after resolve_and_count / recount) or, fused = true, SC_OFF256 (after resolve_count)
     int emit(const uint32_t *d_packed, const Tables &T, uint32_t n_cap, DevBuf &oh, DevBuf &op, DevBuf &orc, DevBuf &of,
-             uint64_t out_base)
+             uint64_t out_base, bool fused = false)
     {
         const uint64_t limit = std::min<uint64_t>({oh.bytes / 8, op.bytes / 4, orc.bytes / 4, of.bytes});
         if (!n_cap) return MXG_OK;
@@ -900,7 +1051,8 @@ struct Driver {
         ep.n_ptr = sc(SC_CTRL).as<uint32_t>() + 4;
         ep.ovf = sc(SC_CTRL).as<uint32_t>();
         ep.n_cap = n_cap;
-        ep.bsum = sc(SC_BSUM).as<uint32_t>();
+        ep.bsum = fused ? sc(SC_OFF256).as<uint32_t>() : sc(SC_BSUM).as<uint32_t>();
+        ep.bsum_stride = fused ? TILE / 256 : 1;
         ep.runs = T.d_runs;
         ep.ctg_run0 = T.d_ctg_run0;
         ep.ctg_rec = T.d_ctg_rec;
@@ -962,7 +1114,7 @@ struct Driver {
                 hipLaunchKernelGGL((k_hash_dense<S_DENSE, MXG_VARIANT_V2_SUM>), grid, block, 0, st, hp);
             if (count_as_hash && (rc = ev_end()) != MXG_OK) return rc;
             MXG_HIP(h, hipGetLastError());
-            if ((rc = resolve_and_count<false>(T, n_cand, (uint32_t)c0, (uint32_t)c1)) != MXG_OK) return rc;
+            if ((rc = resolve_and_count<false>(T, n_cand, (uint32_t)c0, (uint32_t)c1, ~0ull)) != MXG_OK) return rc;
             if (!count_as_hash && (rc = ev_end()) != MXG_OK) return rc;
             uint32_t ctrl[4];
             MXG_HIP(h, hipMemcpyAsync(ctrl, sc(SC_CTRL).p, 16, hipMemcpyDeviceToHost, st));
@@ -1093,16 +1245,15 @@ struct Driver {
         MXG_HIP(h, sc(SC_CTRL).ensure(64));
         MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
         MXG_HIP(h, sc(SC_STRIP_CNT).ensure((size_t)g.n_strips * 4 + 16));
-        MXG_HIP(h, sc(SC_STRIP_PREF).ensure((size_t)g.n_strips * 4 + 16));
-        MXG_HIP(h, sc(SC_STRIP_META).ensure((size_t)g.n_strips * 8 + 16));
-        MXG_HIP(h, sc(SC_SBSUM).ensure((size_t)g.s_tiles * 4 + 16));
+        MXG_HIP(h, sc(SC_STRIP_META).ensure((size_t)g.n_strips * 16 + 16));
         MXG_HIP(h, sc(SC_WAVE_CNT).ensure((size_t)g.n_waves * 4 + 16));
+        MXG_HIP(h, sc(SC_WAVE_PREF).ensure((size_t)g.n_waves * 4 + 16));
         const uint64_t n_cap64 = (uint64_t)g.n_waves * wave_cap;
         if (n_cap64 >= (1ull << 32))
             return set_err(h, MXG_ELIMIT, "candidate arena would exceed 2^32 entries; use MXG_FLAG_DENSE_ONLY");
         const uint32_t n_cap = (uint32_t)n_cap64;
         *n_cap_out = n_cap;
-        MXG_HIP(h, sc(SC_ARENA).ensure((size_t)n_cap * 16));
+        MXG_HIP(h, sc(SC_ARENA).ensure((size_t)n_cap * 8));
         MXG_HIP(h, sc(SC_CAND_H).ensure((size_t)n_cap * 8));
         MXG_HIP(h, sc(SC_CAND_K).ensure((size_t)n_cap * 4));
         MXG_HIP(h, sc(SC_CAND_C).ensure((size_t)n_cap * 4));
@@ -1118,16 +1269,19 @@ struct Driver {
         sp.k = h->cfg.k;
         sp.S = S;
         sp.tau_hi = tau_hi;
-        sp.arena = sc(SC_ARENA).as<uint4>();
+        sp.arena = sc(SC_ARENA).as<uint2>();
         sp.wave_cap = (uint32_t)wave_cap;
         sp.wave_cnt = sc(SC_WAVE_CNT).as<uint32_t>();
         sp.ctrl = sc(SC_CTRL).as<uint32_t>();
         sp.strip_cnt = sc(SC_STRIP_CNT).as<uint32_t>();
-        sp.strip_meta = sc(SC_STRIP_META).as<uint2>();
+        sp.strip_meta = sc(SC_STRIP_META).as<uint4>();
+        sp.wave_pref = sc(SC_WAVE_PREF).as<uint32_t>();
+        sp.n_waves = g.n_waves;
+        int rc = tickets(SC_TICKETS_HASH, g.n_blocks, &sp.done);
+        if (rc != MXG_OK) return rc;
         sp.init_tab = h->d_init_tab.as<uint4>();
         sp.tab = h->tab;
-        int rc = ev_begin(batch_bases(T, g.c0, g.c1), true);
-        if (rc != MXG_OK) return rc;
+        if ((rc = ev_begin(batch_bases(T, g.c0, g.c1), true)) != MXG_OK) return rc;
         dim3 grid(g.n_blocks), block(256);
         static const int abl = getenv("MXG_ABLATE") ? atoi(getenv("MXG_ABLATE")) : 0;  // profiling only
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
@@ -1136,28 +1290,37 @@ struct Driver {
             hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 1>), grid, block, 0, st, sp);
         else if (abl == 2)
             hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 2>), grid, block, 0, st, sp);
-        else if (abl == 4)
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 4>), grid, block, 0, st, sp);
         else
             hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), grid, block, 0, st, sp);
         if ((rc = ev_end()) != MXG_OK) return rc;
         MXG_HIP(h, hipGetLastError());
         // order the candidates: exclusive scan of per-strip counts (total = number of candidates), then scatter
         if ((rc = ev_begin(0, false)) != MXG_OK) return rc;
-        hipLaunchKernelGGL(k_tile_sum_u32, dim3(g.s_tiles), dim3(256), 0, st, sp.strip_cnt, g.n_strips,
-                           sc(SC_SBSUM).as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, sc(SC_SBSUM).as<uint32_t>(), g.s_tiles,
-                           reinterpret_cast<uint64_t *>(sp.ctrl + 4));
-        hipLaunchKernelGGL(k_tile_excl_u32, dim3(g.s_tiles), dim3(256), 0, st, sp.strip_cnt, g.n_strips,
-                           sc(SC_SBSUM).as<uint32_t>(), sc(SC_STRIP_PREF).as<uint32_t>());
-        hipLaunchKernelGGL(k_reorder, dim3(g.n_waves), dim3(256), 0, st, sp.arena, sp.wave_cnt, sp.wave_cap, n_cap,
-                           sc(SC_STRIP_PREF).as<uint32_t>(), sp.strip_meta, sc(SC_CAND_H).as<uint64_t>(),
-                           sc(SC_CAND_K).as<uint32_t>(), sc(SC_CAND_C).as<uint32_t>());
+        ReorderParams op;
+        op.arena = sp.arena;
+        op.wave_cnt = sp.wave_cnt;
+        op.wave_cap = sp.wave_cap;
+        op.n_cap = n_cap;
+        op.strip_cnt = sp.strip_cnt;
+        op.n_strips = g.n_strips;
+        op.wave_pref = sp.wave_pref;
+        op.strip_meta = sp.strip_meta;
+        op.packed = sp.packed;
+        op.init_tab = sp.init_tab;
+        op.k = sp.k;
+        op.ch = sc(SC_CAND_H).as<uint64_t>();
+        op.ck = sc(SC_CAND_K).as<uint32_t>();
+        op.cc = sc(SC_CAND_C).as<uint32_t>();
+        op.tab = h->tab;
+        if (h->cfg.variant == MXG_VARIANT_V1_MIN)
+            hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V1_MIN>, dim3(g.n_waves), dim3(256), 0, st, op);
+        else
+            hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V2_SUM>, dim3(g.n_waves), dim3(256), 0, st, op);
         MXG_HIP(h, hipGetLastError());
-        if ((rc = resolve_and_count<true>(T, n_cap, (uint32_t)g.c0, (uint32_t)g.c1)) != MXG_OK) return rc;
-        // speculative emit straight into the output arrays (guarded by their capacity): on the common path
+        // resolve + speculative emit straight into the output arrays (guarded by their capacity): on the common path
         // (no gap, no overflow) the batch then needs a single host sync
-        if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
+        if ((rc = resolve_count(T, n_cap, (uint32_t)g.c0, (uint32_t)g.c1, (uint64_t)tau_hi << 32)) != MXG_OK) return rc;
+        if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true)) != MXG_OK) return rc;
         if ((rc = ev_end()) != MXG_OK) return rc;
         MXG_HIP(h, hipMemcpyAsync(ctrl_host, sc(SC_CTRL).p, 32, hipMemcpyDeviceToHost, st));
         return MXG_OK;
@@ -1188,7 +1351,7 @@ struct Driver {
         if (n_gaps == 0) {
             if (out.n + total > out.cap()) {  // the speculative emit did not fit: grow, emit again
                 if ((rc = out_reserve(h, out, out.n + total, st)) != MXG_OK) return rc;
-                if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n)) != MXG_OK) return rc;
+                if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true)) != MXG_OK) return rc;
             }
             out.n += total;
         } else {
@@ -1197,7 +1360,7 @@ struct Driver {
             MXG_HIP(h, sc(SC_ST_POS).ensure(std::max<uint64_t>(total * 4, 16)));
             MXG_HIP(h, sc(SC_ST_REC).ensure(std::max<uint64_t>(total * 4, 16)));
             MXG_HIP(h, sc(SC_ST_FWD).ensure(std::max<uint64_t>(total, 16)));
-            if ((rc = emit(a->d_packed, T, n_cap, sc(SC_ST_HASH), sc(SC_ST_POS), sc(SC_ST_REC), sc(SC_ST_FWD), 0)) != MXG_OK) return rc;
+            if ((rc = emit(a->d_packed, T, n_cap, sc(SC_ST_HASH), sc(SC_ST_POS), sc(SC_ST_REC), sc(SC_ST_FWD), 0, true)) != MXG_OK) return rc;
             uint64_t n_gap_mx = 0;
             if ((rc = process_gaps(a, T, gaps, &n_gap_mx)) != MXG_OK) return rc;
             if (total + n_gap_mx >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "batch sketch too large to merge");
@@ -1345,7 +1508,8 @@ static bool sparse_mode(const mxg_handle *h, double *frac, uint32_t *tau_hi)
 {
     const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : 18;
     *frac = (double)c / (double)h->cfg.w;
-    *tau_hi = (uint32_t)std::min<double>(4294967295.0, *frac * 4294967296.0);
+    // even: the threshold then falls on the top 31-bit ring of the hash, which is all the sparse kernel rolls
+    *tau_hi = std::max(2u, (uint32_t)std::min<double>(4294967294.0, *frac * 4294967296.0) & ~1u);
     return !(h->cfg.flags & MXG_FLAG_DENSE_ONLY) && *frac <= 0.125;
 }
 
@@ -1388,7 +1552,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
     // two drivers = two streams with their own scratch: assembly i+1's hash kernel overlaps the small, latency-bound
     // kernels (ordering, resolve, compaction) that follow assembly i's hash kernel
     Driver drv0(h, 0), drv1(h, 1);
-    Driver *drvs[2] = {&drv0, &drv1};
+    static const bool one_stream = getenv("MXG_ONE_STREAM") != nullptr;  // profiling: kernels of the two assemblies do not overlap
+    Driver *drvs[2] = {&drv0, one_stream ? &drv0 : &drv1};
     std::vector<Tables> tabs(n);
     std::vector<int> state(n, 0);  // 0 = synchronous path, 1 = enqueued, 2 = done (empty)
     std::vector<uint32_t> ncap(n, 0);
