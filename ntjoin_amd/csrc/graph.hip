@@ -13,6 +13,7 @@
 // refs in CLI order, then target) that contains it, in that assembly's first-seen orientation --
 // the same (s,t) the reference's `edges[s][t]` dictionary keeps (bin/ntjoin_utils.py:101-108).
 #include <algorithm>
+#include <cstring>
 
 #include "mxg_internal.h"
 #include "scan_kernels.h"
@@ -44,36 +45,67 @@ __device__ __forceinline__ uint32_t ht_slot(Slot *tab, uint32_t mask, uint32_t c
     }
 }
 
-// insert every minimizer of one assembly; remember its slot
-__global__ __launch_bounds__(256) void k_insert(const uint64_t *__restrict__ hash, uint32_t n, uint32_t bit, Slot *tab,
-                                                uint32_t mask, uint32_t cap, uint32_t *__restrict__ slot_out)
+// all assemblies of the handle in one launch: block b works on 256 minimizers of assembly a, bstart[a] <= b < bstart[a+1]
+struct AsmSet {
+    uint32_t n_asm;
+    uint32_t full;                              // mask with one bit per assembly
+    uint32_t n[MXG_MAX_ASSEMBLIES];             // minimizers per assembly
+    uint32_t bstart[MXG_MAX_ASSEMBLIES + 1];    // exclusive prefix of 256-element blocks
+    const uint64_t *hash[MXG_MAX_ASSEMBLIES];
+    uint32_t *slot[MXG_MAX_ASSEMBLIES];
+    uint8_t *flags[MXG_MAX_ASSEMBLIES];
+    uint8_t *shared[MXG_MAX_ASSEMBLIES];
+};
+
+__device__ __forceinline__ uint32_t asm_of_block(const AsmSet &p, uint32_t b)
 {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    uint32_t s = ht_slot(tab, mask, cap, hash[i]);
-    uint32_t old = atomicAnd(&tab[s].nseen, ~bit);
-    if (!(old & bit)) atomicAnd(&tab[s].ndup, ~bit);  // bit already cleared: second occurrence in this assembly
-    slot_out[i] = s;
+    uint32_t a = 0;
+    while (a + 1 < p.n_asm && b >= p.bstart[a + 1]) ++a;  // block-uniform, <= 32 steps
+    return a;
 }
 
-__global__ __launch_bounds__(256) void k_flags(const uint32_t *__restrict__ slot, uint32_t n, uint32_t bit,
-                                               uint32_t full, const Slot *__restrict__ tab, uint8_t *__restrict__ flags,
-                                               uint8_t *__restrict__ shared)
+// insert every minimizer of every assembly; remember its slot
+__global__ __launch_bounds__(256) void k_insert(const AsmSet p, Slot *tab, uint32_t mask, uint32_t cap)
 {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const Slot sl = tab[slot[i]];
-    const uint32_t seen = ~sl.nseen & full, d = ~sl.ndup & full;
-    bool uniq = !(d & bit);
-    bool inall = seen == full;
-    bool sh = inall && d == 0;
-    flags[i] = (uint8_t)((uniq ? MXG_MX_UNIQUE : 0) | (sh ? MXG_MX_SHARED : 0) | (inall ? MXG_MX_INALL : 0));
-    shared[i] = sh ? 1 : 0;
+    const uint32_t a = asm_of_block(p, blockIdx.x);
+    const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
+    if (i >= p.n[a]) return;
+    const uint32_t bit = 1u << a;
+    uint32_t s = ht_slot(tab, mask, cap, p.hash[a][i]);
+    uint32_t old = atomicAnd(&tab[s].nseen, ~bit);
+    if (!(old & bit)) atomicAnd(&tab[s].ndup, ~bit);  // bit already cleared: second occurrence in this assembly
+    p.slot[a][i] = s;
+}
+
+// flags of every minimizer + number of shared ones per block of 256; the block that finishes last turns each assembly's
+// counts into exclusive offsets (cnt[bstart[a]..)) and its total (ctl[a])
+__global__ __launch_bounds__(256) void k_flags(const AsmSet p, const Slot *__restrict__ tab, uint32_t *cnt, uint32_t *tickets,
+                                               uint64_t *ctl)
+{
+    const uint32_t a = asm_of_block(p, blockIdx.x);
+    const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
+    bool sh = false;
+    if (i < p.n[a]) {
+        const uint32_t bit = 1u << a, full = p.full;
+        const Slot sl = tab[p.slot[a][i]];
+        const uint32_t seen = ~sl.nseen & full, d = ~sl.ndup & full;
+        const bool uniq = !(d & bit);
+        const bool inall = seen == full;
+        sh = inall && d == 0;
+        p.flags[a][i] = (uint8_t)((uniq ? MXG_MX_UNIQUE : 0) | (sh ? MXG_MX_SHARED : 0) | (inall ? MXG_MX_INALL : 0));
+        p.shared[a][i] = sh ? 1 : 0;
+    }
+    const uint32_t c = (uint32_t)__syncthreads_count(sh ? 1 : 0);
+    if (threadIdx.x == 0) publish_u32(&cnt[blockIdx.x], c);
+    if (last_block_ticket(tickets, blockIdx.x, gridDim.x))
+        for (uint32_t q = 0; q < p.n_asm; ++q)
+            block_scan_counts(cnt + p.bstart[q], cnt + p.bstart[q], p.bstart[q + 1] - p.bstart[q],
+                              reinterpret_cast<uint32_t *>(ctl + q));
 }
 
 struct VertexParams {
     const uint8_t *shared;
-    const uint32_t *bsum;
+    const uint32_t *bsum;   // exclusive offsets per 256 elements (k_flags): tile t starts at bsum[4 t]
     const uint32_t *slot;
     const uint64_t *hash;
     const uint32_t *pos, *rec;
@@ -92,7 +124,7 @@ __global__ __launch_bounds__(256) void k_vertices(const VertexParams p)
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
     const uint32_t fl = load_flags4(p.shared, base, p.n);
     uint32_t c = count_flags4(fl);
-    uint32_t r = p.bsum[blockIdx.x] + block_exclusive_256(c, sh);
+    uint32_t r = p.bsum[blockIdx.x * (TILE / 256)] + block_exclusive_256(c, sh);
     if (c == 0) return;
     for (int u = 0; u < TILE_PER_THREAD; ++u) {
         uint32_t i = base + u;
@@ -115,11 +147,15 @@ __global__ __launch_bounds__(256) void k_vertices(const VertexParams p)
     }
 }
 
-__global__ __launch_bounds__(256) void k_adjacency(const uint32_t *__restrict__ fv, const uint32_t *__restrict__ frec,
-                                                   const uint64_t *__restrict__ nv_ptr, uint32_t *__restrict__ nxt,
-                                                   uint32_t *__restrict__ prv)
+// blockIdx.y = assembly; all arrays are [A][stride]
+__global__ __launch_bounds__(256) void k_adjacency(const uint32_t *__restrict__ fv0, const uint32_t *__restrict__ frec0,
+                                                   const uint64_t *__restrict__ nv_ptr, uint32_t *__restrict__ nxt0,
+                                                   uint32_t *__restrict__ prv0, uint32_t stride)
 {
     const uint32_t nv = (uint32_t)*nv_ptr;  // number of shared minimizers, still in HBM (no host sync before this stage)
+    const size_t o = (size_t)blockIdx.y * stride;
+    const uint32_t *fv = fv0 + o, *frec = frec0 + o;
+    uint32_t *nxt = nxt0 + o, *prv = prv0 + o;
     uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r + 1 >= nv) return;
     if (frec[r] == frec[r + 1]) {  // consecutive surviving minimizers of the same contig (ntjoin_utils.py:98-99)
@@ -136,7 +172,9 @@ struct EdgeParams {
     const uint64_t *nv_ptr;
     uint32_t nv, n_asm;
     uint8_t *eflag;       // [A*nv]
-    const uint32_t *bsum;
+    uint32_t *bsum;       // edges per 256 items -> exclusive offsets (scanned by the last block of k_edge_flags)
+    uint32_t *tickets;
+    uint32_t *n_edges;    // ctl[CTL_EDGES] (2 words)
     uint32_t *eu, *ev, *esup;
     double *ew;
     double weights[MXG_MAX_ASSEMBLIES];
@@ -156,21 +194,23 @@ __device__ __forceinline__ uint32_t edge_mask(const EdgeParams &p, uint32_t u, u
 __global__ __launch_bounds__(256) void k_edge_flags(const EdgeParams p)
 {
     uint64_t item = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (item >= (uint64_t)p.n_asm * p.nv) return;
-    uint32_t a = (uint32_t)(item / p.nv);
-    uint32_t r = (uint32_t)(item % p.nv);
-    if (r >= (uint32_t)*p.nv_ptr) {  // beyond the actual vertex count
-        p.eflag[item] = 0;
-        return;
-    }
-    uint32_t u = p.fv[(size_t)a * p.nv + r];
-    uint32_t v = p.nxt[(size_t)a * p.nv + u];
     uint8_t f = 0;
-    if (v != NONE32) {
-        uint32_t m = edge_mask(p, u, v);
-        f = ((uint32_t)__builtin_ctz(m) == a) ? 1 : 0;
+    if (item < (uint64_t)p.n_asm * p.nv) {
+        uint32_t a = (uint32_t)(item / p.nv);
+        uint32_t r = (uint32_t)(item % p.nv);
+        if (r < (uint32_t)*p.nv_ptr) {  // (beyond it: not a vertex)
+            uint32_t u = p.fv[(size_t)a * p.nv + r];
+            uint32_t v = p.nxt[(size_t)a * p.nv + u];
+            if (v != NONE32) {
+                uint32_t m = edge_mask(p, u, v);
+                f = ((uint32_t)__builtin_ctz(m) == a) ? 1 : 0;
+            }
+        }
+        p.eflag[item] = f;
     }
-    p.eflag[item] = f;
+    const uint32_t c = (uint32_t)__syncthreads_count(f);
+    if (threadIdx.x == 0) publish_u32(&p.bsum[blockIdx.x], c);
+    if (last_block_ticket(p.tickets, blockIdx.x, gridDim.x)) block_scan_counts(p.bsum, p.bsum, gridDim.x, p.n_edges);
 }
 
 __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_items)
@@ -179,7 +219,7 @@ __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_it
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
     const uint32_t fl = load_flags4(p.eflag, base, n_items);
     uint32_t c = count_flags4(fl);
-    uint32_t e = p.bsum[blockIdx.x] + block_exclusive_256(c, sh);
+    uint32_t e = p.bsum[blockIdx.x * (TILE / 256)] + block_exclusive_256(c, sh);
     if (c == 0) return;
     for (int t = 0; t < TILE_PER_THREAD; ++t) {
         uint32_t item = base + t;
@@ -250,43 +290,60 @@ int build_graph(mxg_handle *h)
     MXG_HIP(h, h->g_vid.ensure(((size_t)cap + 1) * 4));
     MXG_HIP(h, h->g_ctl.ensure(CTL_WORDS * 8));
     MXG_HIP(h, hipMemsetAsync(h->g_keys.p, 0xFF, ((size_t)cap + 1) * sizeof(Slot), h->stream));  // one fill: see Slot
-    MXG_HIP(h, hipMemsetAsync(h->g_ctl.p, 0, CTL_WORDS * 8, h->stream));
-    uint64_t *ctl = h->g_ctl.as<uint64_t>();
+    uint64_t *ctl = h->g_ctl.as<uint64_t>();  // every word the host reads below is written by a kernel of this call
 
+    AsmSet as_all;
+    as_all.n_asm = A;
+    as_all.full = full;
+    uint32_t nb = 0;
     for (uint32_t a = 0; a < A; ++a) {
         Assembly *as = h->asms[a];
         MXG_HIP(h, as->d_slot.ensure(std::max<uint64_t>(as->n_mx * 4, 16)));
         MXG_HIP(h, as->d_flags.ensure(std::max<uint64_t>(as->n_mx, 16)));
-        if (as->n_mx)
-            hipLaunchKernelGGL(k_insert, dim3((uint32_t)((as->n_mx + 255) / 256)), dim3(256), 0, h->stream,
-                               as->d_hash.as<uint64_t>(), (uint32_t)as->n_mx, 1u << a, h->g_keys.as<Slot>(), mask, cap,
-                               as->d_slot.as<uint32_t>());
-    }
-    MXG_HIP(h, hipGetLastError());
-    // flags + number of shared minimizers per assembly (equal across assemblies by construction)
-    for (uint32_t a = 0; a < A; ++a) {
-        Assembly *as = h->asms[a];
-        const uint32_t n = (uint32_t)as->n_mx;
-        const uint32_t n_tiles = (n + TILE - 1) / TILE;
-        MXG_HIP(h, as->d_shared.ensure(std::max<uint32_t>(n, 16)));
-        MXG_HIP(h, as->d_bs.ensure((size_t)n_tiles * 4 + 16));
-        if (n) {
-            hipLaunchKernelGGL(k_flags, dim3((n + 255) / 256), dim3(256), 0, h->stream, as->d_slot.as<uint32_t>(), n,
-                               1u << a, full, h->g_keys.as<Slot>(), as->d_flags.as<uint8_t>(), as->d_shared.as<uint8_t>());
-            hipLaunchKernelGGL(k_count, dim3(n_tiles), dim3(256), 0, h->stream, as->d_shared.as<uint8_t>(), n,
-                               as->d_bs.as<uint32_t>());
-        }
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, h->stream, as->d_bs.as<uint32_t>(), n_tiles, ctl + a);
+        MXG_HIP(h, as->d_shared.ensure(std::max<uint64_t>(as->n_mx, 16)));
+        as_all.n[a] = (uint32_t)as->n_mx;
+        as_all.bstart[a] = nb;
+        nb += (uint32_t)((as->n_mx + 255) / 256);
+        as_all.hash[a] = as->d_hash.as<uint64_t>();
+        as_all.slot[a] = as->d_slot.as<uint32_t>();
+        as_all.flags[a] = as->d_flags.as<uint8_t>();
+        as_all.shared[a] = as->d_shared.as<uint8_t>();
         as->flags_valid = true;
     }
-    MXG_HIP(h, hipGetLastError());
+    as_all.bstart[A] = nb;
+    for (uint32_t a = A; a < MXG_MAX_ASSEMBLIES; ++a) {
+        as_all.n[a] = 0;
+        as_all.bstart[a + 1] = nb;
+        as_all.hash[a] = nullptr;
+        as_all.slot[a] = nullptr;
+        as_all.flags[a] = as_all.shared[a] = nullptr;
+    }
     // vertex arrays are strided by an upper bound of the vertex count (every vertex occurs once in every assembly), so
     // this stage needs no host sync before its kernels: they read the counts from the control block in HBM
     const uint64_t nvs = nmin;  // stride
     uint64_t hctl[CTL_WORDS] = {0};
+    if (nvs > 0 && (uint64_t)A * nvs >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "graph too large for 32-bit item indices");
+    const size_t anv = (size_t)A * nvs;
+    const uint32_t n_items = (uint32_t)anv;
+    const uint32_t e_blocks = (n_items + 255) / 256;
+    // ticket counters of the two fused count+scan kernels (scan_kernels.h): zeroed when allocated, self-resetting
+    {
+        const size_t need = ((size_t)std::max(nb, e_blocks) / 64 + 4) * LB_STRIDE * 4;
+        if (need > h->g_tickets.bytes) {
+            MXG_HIP(h, h->g_tickets.ensure(need));
+            MXG_HIP(h, hipMemsetAsync(h->g_tickets.p, 0, h->g_tickets.bytes, h->stream));
+        }
+    }
+    uint32_t *tickets = h->g_tickets.as<uint32_t>();
+    MXG_HIP(h, h->g_cnt.ensure((size_t)nb * 4 + 64));  // shared minimizers per 256 -> offsets, all assemblies
+    uint32_t *cnt = h->g_cnt.as<uint32_t>();
+    if (nb) {
+        hipLaunchKernelGGL(k_insert, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), mask, cap);
+        // flags + number of shared minimizers per assembly (equal across assemblies by construction) -> ctl[a]
+        hipLaunchKernelGGL(k_flags, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), cnt, tickets, ctl);
+    }
+    MXG_HIP(h, hipGetLastError());
     if (nvs > 0) {
-        if ((uint64_t)A * nvs >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "graph too large for 32-bit item indices");
-        const size_t anv = (size_t)A * nvs;
         MXG_HIP(h, h->g_vhash.ensure(nvs * 8));
         MXG_HIP(h, h->g_vpos.ensure(anv * 4));
         MXG_HIP(h, h->g_vrec.ensure(anv * 4));
@@ -295,12 +352,12 @@ int build_graph(mxg_handle *h)
         MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4));  // nxt[A][nvs] followed by prv[A][nvs]: one fill
         MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));
         uint32_t *const d_prv = h->g_nxt.as<uint32_t>() + anv;
-        for (uint32_t a = 0; a < A; ++a) {
+        for (uint32_t a = 0; a < A; ++a) {  // assembly 0 assigns the vertex ids the others look up: one launch each
             Assembly *as = h->asms[a];
             const uint32_t n = (uint32_t)as->n_mx;
             VertexParams vp;
             vp.shared = as->d_shared.as<uint8_t>();
-            vp.bsum = as->d_bs.as<uint32_t>();
+            vp.bsum = cnt + as_all.bstart[a];
             vp.slot = as->d_slot.as<uint32_t>();
             vp.hash = as->d_hash.as<uint64_t>();
             vp.pos = as->d_pos.as<uint32_t>();
@@ -314,15 +371,13 @@ int build_graph(mxg_handle *h)
             vp.fv = h->g_fv.as<uint32_t>() + (size_t)a * nvs;
             vp.frec = h->g_frec.as<uint32_t>() + (size_t)a * nvs;
             hipLaunchKernelGGL(k_vertices, dim3((n + TILE - 1) / TILE), dim3(256), 0, h->stream, vp);
-            hipLaunchKernelGGL(k_adjacency, dim3((uint32_t)((nvs + 255) / 256)), dim3(256), 0, h->stream,
-                               h->g_fv.as<uint32_t>() + (size_t)a * nvs, h->g_frec.as<uint32_t>() + (size_t)a * nvs,
-                               ctl + a, h->g_nxt.as<uint32_t>() + (size_t)a * nvs, d_prv + (size_t)a * nvs);
         }
+        hipLaunchKernelGGL(k_adjacency, dim3((uint32_t)((nvs + 255) / 256), A), dim3(256), 0, h->stream, h->g_fv.as<uint32_t>(),
+                           h->g_frec.as<uint32_t>(), ctl, h->g_nxt.as<uint32_t>(), d_prv, (uint32_t)nvs);
         MXG_HIP(h, hipGetLastError());
-        const uint32_t n_items = (uint32_t)anv;
         const uint32_t e_tiles = (n_items + TILE - 1) / TILE;
         MXG_HIP(h, h->g_eflag.ensure(n_items));
-        MXG_HIP(h, h->g_ebs.ensure((size_t)e_tiles * 4 + 16));
+        MXG_HIP(h, h->g_ebs.ensure((size_t)e_blocks * 4 + 64));
         // every item yields at most one edge: size the edge arrays by that bound
         MXG_HIP(h, h->g_eu.ensure((size_t)n_items * 4));
         MXG_HIP(h, h->g_ev.ensure((size_t)n_items * 4));
@@ -337,22 +392,21 @@ int build_graph(mxg_handle *h)
         ep.n_asm = A;
         ep.eflag = h->g_eflag.as<uint8_t>();
         ep.bsum = h->g_ebs.as<uint32_t>();
+        ep.tickets = tickets;
+        ep.n_edges = reinterpret_cast<uint32_t *>(ctl + CTL_EDGES);
         ep.eu = h->g_eu.as<uint32_t>();
         ep.ev = h->g_ev.as<uint32_t>();
         ep.esup = h->g_esup.as<uint32_t>();
         ep.ew = h->g_ew.as<double>();
         for (uint32_t a = 0; a < MXG_MAX_ASSEMBLIES; ++a) ep.weights[a] = a < A ? h->asms[a]->weight : 0.0;
-        hipLaunchKernelGGL(k_edge_flags, dim3((n_items + 255) / 256), dim3(256), 0, h->stream, ep);
-        hipLaunchKernelGGL(k_count, dim3(e_tiles), dim3(256), 0, h->stream, h->g_eflag.as<uint8_t>(), n_items,
-                           h->g_ebs.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, h->stream, h->g_ebs.as<uint32_t>(), e_tiles,
-                           ctl + CTL_EDGES);
+        hipLaunchKernelGGL(k_edge_flags, dim3(e_blocks), dim3(256), 0, h->stream, ep);  // + per-256 counts + their scan
         hipLaunchKernelGGL(k_edges, dim3(e_tiles), dim3(256), 0, h->stream, ep, n_items);
         MXG_HIP(h, hipGetLastError());
     }
     if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
     MXG_HIP(h, hipMemcpyAsync(hctl, h->g_ctl.p, CTL_WORDS * 8, hipMemcpyDeviceToHost, h->stream));
     MXG_HIP(h, hipStreamSynchronize(h->stream));  // the stage's only sync; results stay in HBM
+    if (nb == 0) memset(hctl, 0, sizeof hctl);  // no minimizer at all: nothing was launched, nothing was written
     const uint64_t nv = hctl[0];
     for (uint32_t a = 1; a < A; ++a)
         if (hctl[a] != nv)
