@@ -405,7 +405,7 @@ int build_graph(mxg_handle *h)
     }
     if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
     MXG_HIP(h, hipMemcpyAsync(hctl, h->g_ctl.p, CTL_WORDS * 8, hipMemcpyDeviceToHost, h->stream));
-    MXG_HIP(h, hipStreamSynchronize(h->stream));  // the stage's only sync; results stay in HBM
+    MXG_HIP(h, stream_wait(h->stream));  // the stage's only sync; results stay in HBM
     if (nb == 0) memset(hctl, 0, sizeof hctl);  // no minimizer at all: nothing was launched, nothing was written
     const uint64_t nv = hctl[0];
     for (uint32_t a = 1; a < A; ++a)

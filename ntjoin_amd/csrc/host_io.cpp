@@ -49,24 +49,23 @@ void make_hash_tab(uint32_t k, HashTab *t)
         }
 }
 
-// Direct-initialisation table for the sketch kernel: the "warm-up state" after the first m = 4*(k/4) bases of a
-// strip is  F = XOR_j srol^{m-1-j}(seed[c_j]),  R = XOR_j srol^{k-m+j}(seed'[c_j]);  entry [b][v] holds the XOR of the
-// four terms of byte position b (bases 4b..4b+3, base i in bits 2i..2i+1 of v), so the state is the XOR of k/4 lookups;
-// the remaining k%4 bases are stepped as usual.
+// Byte table of the direct hash formula (sketch.hip init_direct): the "warm-up state" after the first m = 4*(k/4) bases
+// is  F = XOR_j srol^{m-1-j}(seed[c_j]),  R = XOR_j srol^{k-m+j}(seed'[c_j]).  Entry v (one packed byte = bases 4q..4q+3,
+// base i in bits 2i..2i+1) holds the four terms of a byte at position 0: f4 = XOR_i srol^{3-i} seed[c_i],
+// r4 = XOR_i srol^{i} seed'[c_i]; the byte's position enters through Horner rotations by 4 on the device.
 void make_init_tab(uint32_t k, std::vector<uint4> &out)
 {
-    const uint32_t P = k / 4, m = 4 * P;
-    out.assign((size_t)P * 256, make_uint4(0, 0, 0, 0));
-    for (uint32_t b = 0; b < P; ++b)
-        for (uint32_t v = 0; v < 256; ++v) {
-            uint64_t f = 0, r = 0;
-            for (uint32_t i = 0; i < 4; ++i) {
-                const uint32_t c = (v >> (2 * i)) & 3u, j = 4 * b + i;
-                f ^= srol_n(SEED[c], m - 1 - j);
-                r ^= srol_n(SEED[3 - c], k - m + j);
-            }
-            out[(size_t)b * 256 + v] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+    (void)k;  // the byte table does not depend on k: position enters through the Horner rotations on the device
+    out.assign(256, make_uint4(0, 0, 0, 0));
+    for (uint32_t v = 0; v < 256; ++v) {
+        uint64_t f = 0, r = 0;
+        for (uint32_t i = 0; i < 4; ++i) {
+            const uint32_t c = (v >> (2 * i)) & 3u;
+            f ^= srol_n(SEED[c], 3 - i);
+            r ^= srol_n(SEED[3 - c], i);
         }
+        out[v] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+    }
 }
 
 // ---- base code table -------------------------------------------------------------------------------

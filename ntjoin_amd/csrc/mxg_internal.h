@@ -153,7 +153,7 @@ struct mxg_handle {
     mxg::DevBuf pbuf[32];  // scratch of paths.hip
     mxg::Timers tm;
     mxg::HashTab tab{};
-    mxg::DevBuf d_init_tab;  // direct-initialisation table (k/4 x 256 x 16 B), built by the first sketch
+    mxg::DevBuf d_init_tab;  // byte table of the direct hash formula (256 x 16 B), built by the first sketch
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
     // scratch reused across calls
     mxg::DevBuf scratch[2][40];  // two sets, indexed by mxg::Scratch (sketch.hip): one per in-flight sketch driver
@@ -167,6 +167,18 @@ struct mxg_handle {
 namespace mxg {
 
 int set_err(mxg_handle *h, int code, const char *fmt, ...);
+// Wait for a stream by polling: hipStreamSynchronize parks the thread and its wake-up costs tens of microseconds, which
+// is a tenth of a whole sketch+graph step at 2 x 100 Mbp.  The two syncs on the hot path (end of the sketch stage, end
+// of the graph stage) poll for a bounded time, then fall back to the blocking wait.
+inline hipError_t stream_wait(hipStream_t s)
+{
+    for (int spin = 0; spin < 200000; ++spin) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+    }
+    return hipStreamSynchronize(s);
+}
+
 #define MXG_HIP(h, call)                                                                         \
     do {                                                                                         \
         hipError_t e_ = (call);                                                                  \

@@ -122,22 +122,58 @@ __device__ __forceinline__ void warm_up(H2 &h, const uint32_t *__restrict__ pack
     }
 }
 
-// Hash state of the first k-mer of a strip without k rolling steps: XOR of k/4 table lookups (one per byte of
-// packed bases; table built by make_init_tab), then k%4 ordinary warm-up steps.
+// split rotation by 4 positions (one packed byte = 4 bases), by -4, and by a wave-uniform n
+__device__ __forceinline__ void srol4(uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t b32 = hi & 1u, W = hi >> 1;
+    const uint32_t nlo = (lo << 4) | (b32 << 3) | (lo >> 29);
+    const uint32_t nW = ((W << 4) | (W >> 27)) & 0x7FFFFFFFu;
+    hi = (nW << 1) | ((lo >> 28) & 1u);
+    lo = nlo;
+}
+__device__ __forceinline__ void sror4(uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t b32 = hi & 1u, W = hi >> 1;
+    const uint32_t nlo = (lo >> 4) | (b32 << 28) | (lo << 29);
+    const uint32_t nW = (W >> 4) | ((W & 15u) << 27);
+    hi = (nW << 1) | ((lo >> 3) & 1u);
+    lo = nlo;
+}
+__device__ __forceinline__ void srol_var(uint32_t &lo, uint32_t &hi, uint32_t n)
+{
+    uint64_t V = ((uint64_t)(hi & 1u) << 32) | lo;
+    uint32_t W = hi >> 1;
+    const uint32_t a = n % 33u, b = n % 31u;
+    if (a) V = ((V << a) | (V >> (33u - a))) & 0x1FFFFFFFFull;
+    if (b) W = ((W << b) | (W >> (31u - b))) & 0x7FFFFFFFu;
+    lo = (uint32_t)V;
+    hi = (W << 1) | (uint32_t)(V >> 32);
+}
+
+// Hash state of a k-mer without k rolling steps.  With m = 4*(k/4) and v_q the q-th packed byte (4 bases),
+//     F = XOR_q srol^{4(P-1-q)} f4[v_q]            f4[v] = XOR_u srol^{3-u} seed[c_u]      (make_init_tab)
+//     R = srol^{k-m} XOR_q srol^{4q} r4[v_q]       r4[v] = XOR_u srol^{u}   seed'[c_u]
+// both by Horner over the bytes in memory order: F <- srol^4(F) ^ f4[v_q];  T <- sror^4(T) ^ r4[v_q], and
+// R = srol^{4(P-1) + k-m}(T).  One 256-entry table (4 KB, in LDS) for every k; then k%4 ordinary warm-up steps.
 template <class T>
 __device__ __forceinline__ void init_direct(H2 &h, const uint32_t *__restrict__ packed, uint64_t b, uint32_t k,
-                                            const uint4 *__restrict__ init_tab, const T *tab)
+                                            const uint4 *byte_tab, const T *tab)
 {
     const uint32_t P = k / 4;
+    uint32_t flo = 0, fhi = 0, tlo = 0, thi = 0;
     for (uint32_t q = 0; q < P; q += 4) {  // 16 bases = 4 table bytes per fetch
         const uint32_t word = fetch16(packed, b + 4u * q);
         const uint32_t nb = min(4u, P - q);
         for (uint32_t u = 0; u < nb; ++u) {
-            const uint4 e = init_tab[(size_t)(q + u) * 256u + ((word >> (8 * u)) & 255u)];
-            h.flo ^= e.x; h.fhi ^= e.y; h.rlo ^= e.z; h.rhi ^= e.w;
+            const uint4 e = byte_tab[(word >> (8 * u)) & 255u];
+            srol4(flo, fhi);
+            sror4(tlo, thi);
+            flo ^= e.x; fhi ^= e.y; tlo ^= e.z; thi ^= e.w;
         }
     }
     const uint32_t rem = k - 4 * P;
+    if (P) srol_var(tlo, thi, 4u * (P - 1u) + rem);
+    h.flo = flo; h.fhi = fhi; h.rlo = tlo; h.rhi = thi;
     if (rem) {
         uint32_t chunk = fetch16(packed, b + 4u * P);
         for (uint32_t u = 0; u < rem; ++u) {
@@ -226,7 +262,7 @@ struct SparseParams {
     uint32_t n_waves;
     uint32_t *done;       // ticket counters of last_block_ticket
     uint4 *strip_meta;    // [n_strips] {contig, kidx of the strip's first k-mer, base offset of it lo, hi}
-    const uint4 *init_tab; // direct-initialisation table (make_init_tab)
+    const uint4 *init_tab; // byte table of init_direct (make_init_tab), 256 entries
     HashTab tab;
 };
 
@@ -239,9 +275,16 @@ struct SparseParams {
 // then that interval test is a single unsigned compare:  (x<<1) + y  >=  2^32 - 2T - 2.  (Bit 31 of x and bit 0 of y
 // are don't-cares that the updates never propagate into the rings.)  min(fwd,rev) < tau is exactly F < T or R < T.
 // (min variant: max(x<<1, y) >= 2^32 - 2T.)
-__device__ __forceinline__ void ring_step(uint32_t &x, uint32_t &y, const uint2 t)
+// x2 = x << 1, produced by ring_double: the compiler would emit a shift, which issues at half the rate of an add
+__device__ __forceinline__ uint32_t ring_double(uint32_t x)
 {
-    x = ((x << 1) | ((x >> 30) & 1u)) ^ t.x;                      // v_bfe, v_lshl_or, v_xor
+    uint32_t x2;
+    asm("v_add_u32_e32 %0, %1, %1" : "=v"(x2) : "v"(x));
+    return x2;
+}
+__device__ __forceinline__ void ring_step(uint32_t &x, uint32_t x2, uint32_t &y, const uint2 t)
+{
+    x = (x2 | ((x >> 30) & 1u)) ^ t.x;                            // v_bfe, v_bitop3
     const uint32_t u = y ^ t.y;
     y = __builtin_amdgcn_alignbit(u >> 1, u, 1);                  // (u >> 1) | (u[1] << 31)
 }
@@ -261,6 +304,8 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
 {
     __shared__ uint4 tab[20];    // full step table: only init_direct's k%4 remainder uses it
     __shared__ uint2 ring[16];   // top rings of the rolling entries (out<<2 | in): {Tf, Tr<<1}
+    __shared__ uint4 btab[256];  // byte table of init_direct
+    btab[threadIdx.x] = p.init_tab[threadIdx.x];
     if (threadIdx.x < 20) {
         const uint4 e = p.tab.e[threadIdx.x];
         tab[threadIdx.x] = e;
@@ -293,7 +338,7 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     uint32_t x, y;
     {
         H2 h = {0u, 0u, 0u, 0u};
-        init_direct(h, p.packed, b, k, p.init_tab, tab);  // replaces k rolling warm-up steps per strip
+        init_direct(h, p.packed, b, k, btab, tab);  // replaces k rolling warm-up steps per strip
         x = ~(h.fhi >> 1);
         y = ~h.rhi;
     }
@@ -318,15 +363,16 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
 #pragma unroll
         for (uint32_t u = 0; u < 16; ++u) {
             // k-mer j = 16*blk + u is in (x, y): test, then roll to j+1 (the last roll of a strip is never looked at)
+            const uint32_t x2 = ring_double(x);
             if (ABL != 1) {
-                const uint32_t v = VARIANT == MXG_VARIANT_V1_MIN ? max(x << 1, y) : (x << 1) + y;
+                const uint32_t v = VARIANT == MXG_VARIANT_V1_MIN ? max(x2, y) : x2 + y;
                 // bits = 2*bits + (v >= thr): the compare's carry goes straight into the add
                 asm("v_cmp_le_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v), "s"(thr) : "vcc");
             }
             const uint32_t z = (u & 1u) ? zo : ze;
             const uint32_t sh = 4u * (u >> 1);
             const uint32_t off = (sh >= 3u ? z >> (sh - 3u) : z << (3u - sh)) & 0x78u;
-            ring_step(x, y, *reinterpret_cast<const uint2 *>(ringb + off));
+            ring_step(x, x2, y, *reinterpret_cast<const uint2 *>(ringb + off));
         }
         if (ABL == 1) { abl_acc ^= x + y; continue; }
         if (ABL == 2) { abl_acc += bits; continue; }
@@ -385,37 +431,49 @@ template <int VARIANT>
 __global__ __launch_bounds__(256) void k_reorder(const ReorderParams p)
 {
     __shared__ uint4 tab[20];
+    __shared__ uint4 btab[256];     // byte table of init_direct
     __shared__ uint32_t spref[64];  // ordered slot of the first candidate of each of this wave's 64 strips
+    __shared__ uint4 smeta[64];     // their {contig, first k-mer index, base offset}
+    btab[threadIdx.x] = p.init_tab[threadIdx.x];
     if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
     const uint32_t wv = blockIdx.x;
+    const uint32_t cnt = min(p.wave_cnt[wv], p.wave_cap);
+    const uint2 *src = p.arena + (size_t)wv * p.wave_cap;
+    // the first two entries of every thread are requested before anything else (a slice holds ~2 per thread)
+    const uint32_t i0 = threadIdx.x, i1 = threadIdx.x + 256u;
+    uint2 a0 = make_uint2(0u, 0u), a1 = make_uint2(0u, 0u);
+    if (i0 < cnt) a0 = src[i0];
+    if (i1 < cnt) a1 = src[i1];
     if (threadIdx.x < 64) {  // exclusive scan over the strips: the wave's first slot + prefix inside the wave
         const uint32_t s = wv * 64u + threadIdx.x;
-        const uint32_t c = s < p.n_strips ? p.strip_cnt[s] : 0u;
+        const bool in = s < p.n_strips;
+        const uint32_t c = in ? p.strip_cnt[s] : 0u;
+        if (in) smeta[threadIdx.x] = p.strip_meta[s];
         spref[threadIdx.x] = p.wave_pref[wv] + wave_inclusive_u32(c, threadIdx.x) - c;
     }
     __syncthreads();
-    const uint32_t cnt = min(p.wave_cnt[wv], p.wave_cap);
-    const uint2 *src = p.arena + (size_t)wv * p.wave_cap;
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-        const uint2 a = src[i];
+    auto place = [&](const uint2 a) {
         uint32_t bits = a.y & 0xFFFFu;
         const uint32_t j0 = ((a.y >> 16) & 63u) * 16u;
         uint32_t dst = spref[a.x & 63u] + (a.y >> 22);
-        const uint4 sm = p.strip_meta[a.x];
+        const uint4 sm = smeta[a.x & 63u];
         const uint64_t b0 = (((uint64_t)sm.w << 32) | sm.z) + j0;
         while (bits) {  // most significant bit = first k-mer of the block
             const uint32_t u = (uint32_t)__clz((int)bits) - 16u;
             bits &= ~(0x8000u >> u);
             if (dst < p.n_cap) {  // beyond it only when a wave overflowed: the host redoes the batch
                 H2 h = {0u, 0u, 0u, 0u};
-                init_direct(h, p.packed, b0 + u, p.k, p.init_tab, tab);
+                init_direct(h, p.packed, b0 + u, p.k, btab, tab);
                 p.ch[dst] = canonical<VARIANT>(h);
                 p.ck[dst] = sm.y + j0 + u;
                 p.cc[dst] = sm.x;
             }
             ++dst;
         }
-    }
+    };
+    place(a0);
+    place(a1);
+    for (uint32_t i = threadIdx.x + 512u; i < cnt; i += 256) place(src[i]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1398,7 +1456,7 @@ struct Driver {
                 int rc = enqueue_sparse(a, T, g, wave_cap, tau_hi, out, ctrl, &n_cap_now);
                 if (rc != MXG_OK) return rc;
                 n_cap64 = n_cap_now;
-                MXG_HIP(h, hipStreamSynchronize(st));
+                MXG_HIP(h, stream_wait(st));
                 if (ctrl[0] == 0) break;  // no wave overflowed its slice
                 if (attempt >= 2) return set_err(h, MXG_EDEVICE, "internal error: candidate arena keeps overflowing");
                 wave_cap = std::min<uint64_t>((uint64_t)ctrl[0] + 64, 64ull * S);  // exact need is known: redo the batch
@@ -1585,8 +1643,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
         last_on_slot[n_enq & 1] = i;
         ++n_enq;
     }
-    MXG_HIP(h, hipStreamSynchronize(h->stream));
-    MXG_HIP(h, hipStreamSynchronize(h->stream2));
+    MXG_HIP(h, stream_wait(h->stream));
+    MXG_HIP(h, stream_wait(h->stream2));
     for (size_t i = 0; i < n; ++i) {
         if (state[i] != 1) continue;
         Assembly *a = list[i];
