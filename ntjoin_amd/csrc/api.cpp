@@ -83,6 +83,7 @@ void mxg_destroy(mxg_handle *h)
     }
     for (auto *a : h->asms) delete a;
     h->asms.clear();
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->pinned_ctrl) (void)hipHostFree(h->pinned_ctrl);
@@ -541,6 +542,7 @@ int mxg_get_stats(mxg_handle *h, mxg_stats *out)
         }
         h->stat_unique = u;
     }
+    if (flush_timers(h) != MXG_OK) return MXG_EDEVICE;
     s.candidates = h->stat_candidates;
     s.dense_kmers = h->stat_dense_kmers;
     s.unique = h->graph.valid ? h->stat_unique : 0;
@@ -558,6 +560,8 @@ int mxg_get_stats(mxg_handle *h, mxg_stats *out)
 int mxg_reset_timers(mxg_handle *h)
 {
     if (!h) return MXG_EINVAL;
+    int rc = flush_timers(h);
+    if (rc != MXG_OK) return rc;
     h->tm = Timers();
     h->stat_candidates = h->stat_dense_kmers = 0;
     return MXG_OK;

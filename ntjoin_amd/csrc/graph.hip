@@ -65,8 +65,11 @@ __device__ __forceinline__ uint32_t asm_of_block(const AsmSet &p, uint32_t b)
 }
 
 // insert every minimizer of every assembly; remember its slot
-__global__ __launch_bounds__(256) void k_insert(const AsmSet p, Slot *tab, uint32_t mask, uint32_t cap)
+__global__ __launch_bounds__(256) void k_insert(const AsmSet p, Slot *tab, uint32_t mask, uint32_t cap, uint32_t *sup,
+                                                uint32_t n_sup)
 {
+    if (blockIdx.x == 0)  // super-counts of the two counting kernels that follow (scan_kernels.h)
+        for (uint32_t i = threadIdx.x; i < n_sup; i += 256) sup[i] = 0;
     const uint32_t a = asm_of_block(p, blockIdx.x);
     const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
     if (i >= p.n[a]) return;
@@ -77,10 +80,11 @@ __global__ __launch_bounds__(256) void k_insert(const AsmSet p, Slot *tab, uint3
     p.slot[a][i] = s;
 }
 
-// flags of every minimizer + number of shared ones per block of 256; the block that finishes last turns each assembly's
-// counts into exclusive offsets (cnt[bstart[a]..)) and its total (ctl[a])
-__global__ __launch_bounds__(256) void k_flags(const AsmSet p, const Slot *__restrict__ tab, uint32_t *cnt, uint32_t *tickets,
-                                               uint64_t *ctl)
+// flags of every minimizer + number of shared ones per block of 256 (cnt[b], super-counts per assembly at
+// sup[sup_start(a)..): scan_kernels.h); k_vertices turns them into offsets
+__device__ __forceinline__ uint32_t sup_start(const AsmSet &p, uint32_t a) { return ((p.bstart[a] >> SUP_SHIFT) + a) * SUP_STRIDE; }
+
+__global__ __launch_bounds__(256) void k_flags(const AsmSet p, const Slot *__restrict__ tab, uint32_t *cnt, uint32_t *sup)
 {
     const uint32_t a = asm_of_block(p, blockIdx.x);
     const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
@@ -96,16 +100,13 @@ __global__ __launch_bounds__(256) void k_flags(const AsmSet p, const Slot *__res
         p.shared[a][i] = sh ? 1 : 0;
     }
     const uint32_t c = (uint32_t)__syncthreads_count(sh ? 1 : 0);
-    if (threadIdx.x == 0) publish_u32(&cnt[blockIdx.x], c);
-    if (last_block_ticket(tickets, blockIdx.x, gridDim.x))
-        for (uint32_t q = 0; q < p.n_asm; ++q)
-            block_scan_counts(cnt + p.bstart[q], cnt + p.bstart[q], p.bstart[q + 1] - p.bstart[q],
-                              reinterpret_cast<uint32_t *>(ctl + q));
+    if (threadIdx.x == 0) count_publish(cnt + p.bstart[a], sup + sup_start(p, a), blockIdx.x - p.bstart[a], c);
 }
 
 struct VertexParams {
     const uint8_t *shared;
-    const uint32_t *bsum;   // exclusive offsets per 256 elements (k_flags): tile t starts at bsum[4 t]
+    const uint32_t *cnt, *sup;  // shared minimizers per 256 elements of this assembly + super-counts (k_flags)
+    uint64_t *n_shared;     // ctl[a]: total, written by the last tile
     const uint32_t *slot;
     const uint64_t *hash;
     const uint32_t *pos, *rec;
@@ -124,7 +125,17 @@ __global__ __launch_bounds__(256) void k_vertices(const VertexParams p)
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
     const uint32_t fl = load_flags4(p.shared, base, p.n);
     uint32_t c = count_flags4(fl);
-    uint32_t r = p.bsum[blockIdx.x * (TILE / 256)] + block_exclusive_256(c, sh);
+    __shared__ uint32_t sh_before;
+    if (threadIdx.x < 64) {
+        const uint32_t bef = count_prefix(p.cnt, p.sup, blockIdx.x * (TILE / 256));
+        if (threadIdx.x == 0) sh_before = bef;
+        if (blockIdx.x + 1 == gridDim.x) {  // the last tile also reports the total
+            const uint32_t all = count_prefix(p.cnt, p.sup, (p.n + 255u) / 256u);
+            if (threadIdx.x == 0) *p.n_shared = all;
+        }
+    }
+    __syncthreads();
+    uint32_t r = sh_before + block_exclusive_256(c, sh);
     if (c == 0) return;
     for (int u = 0; u < TILE_PER_THREAD; ++u) {
         uint32_t i = base + u;
@@ -172,9 +183,9 @@ struct EdgeParams {
     const uint64_t *nv_ptr;
     uint32_t nv, n_asm;
     uint8_t *eflag;       // [A*nv]
-    uint32_t *bsum;       // edges per 256 items -> exclusive offsets (scanned by the last block of k_edge_flags)
-    uint32_t *tickets;
-    uint32_t *n_edges;    // ctl[CTL_EDGES] (2 words)
+    uint32_t *bsum;       // edges per 256 items + super-counts (scan_kernels.h)
+    uint32_t *bsuper;
+    uint64_t *n_edges;    // ctl[CTL_EDGES], written by the last tile of k_edges
     uint32_t *eu, *ev, *esup;
     double *ew;
     double weights[MXG_MAX_ASSEMBLIES];
@@ -209,8 +220,7 @@ __global__ __launch_bounds__(256) void k_edge_flags(const EdgeParams p)
         p.eflag[item] = f;
     }
     const uint32_t c = (uint32_t)__syncthreads_count(f);
-    if (threadIdx.x == 0) publish_u32(&p.bsum[blockIdx.x], c);
-    if (last_block_ticket(p.tickets, blockIdx.x, gridDim.x)) block_scan_counts(p.bsum, p.bsum, gridDim.x, p.n_edges);
+    if (threadIdx.x == 0) count_publish(p.bsum, p.bsuper, blockIdx.x, c);
 }
 
 __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_items)
@@ -219,7 +229,17 @@ __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_it
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
     const uint32_t fl = load_flags4(p.eflag, base, n_items);
     uint32_t c = count_flags4(fl);
-    uint32_t e = p.bsum[blockIdx.x * (TILE / 256)] + block_exclusive_256(c, sh);
+    __shared__ uint32_t sh_before;
+    if (threadIdx.x < 64) {
+        const uint32_t bef = count_prefix(p.bsum, p.bsuper, blockIdx.x * (TILE / 256));
+        if (threadIdx.x == 0) sh_before = bef;
+        if (blockIdx.x + 1 == gridDim.x) {  // the last tile also reports the total
+            const uint32_t all = count_prefix(p.bsum, p.bsuper, (n_items + 255u) / 256u);
+            if (threadIdx.x == 0) *p.n_edges = all;
+        }
+    }
+    __syncthreads();
+    uint32_t e = sh_before + block_exclusive_256(c, sh);
     if (c == 0) return;
     for (int t = 0; t < TILE_PER_THREAD; ++t) {
         uint32_t item = base + t;
@@ -326,21 +346,16 @@ int build_graph(mxg_handle *h)
     const size_t anv = (size_t)A * nvs;
     const uint32_t n_items = (uint32_t)anv;
     const uint32_t e_blocks = (n_items + 255) / 256;
-    // ticket counters of the two fused count+scan kernels (scan_kernels.h): zeroed when allocated, self-resetting
-    {
-        const size_t need = ((size_t)std::max(nb, e_blocks) / 64 + 4) * LB_STRIDE * 4;
-        if (need > h->g_tickets.bytes) {
-            MXG_HIP(h, h->g_tickets.ensure(need));
-            MXG_HIP(h, hipMemsetAsync(h->g_tickets.p, 0, h->g_tickets.bytes, h->stream));
-        }
-    }
-    uint32_t *tickets = h->g_tickets.as<uint32_t>();
-    MXG_HIP(h, h->g_cnt.ensure((size_t)nb * 4 + 64));  // shared minimizers per 256 -> offsets, all assemblies
-    uint32_t *cnt = h->g_cnt.as<uint32_t>();
+    // per-256 counts of the two counting kernels and their super-counts (scan_kernels.h): [sup of k_flags, one run
+    // per assembly | sup of k_edge_flags | cnt of k_flags]; k_insert zeroes the super-counts
+    const uint32_t n_fsup = ((nb >> SUP_SHIFT) + A + 1) * SUP_STRIDE, n_esup = sup_words(e_blocks);
+    MXG_HIP(h, h->g_cnt.ensure(((size_t)n_fsup + n_esup + nb) * 4 + 64));
+    uint32_t *fsup = h->g_cnt.as<uint32_t>(), *esup = fsup + n_fsup, *cnt = esup + n_esup;
     if (nb) {
-        hipLaunchKernelGGL(k_insert, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), mask, cap);
-        // flags + number of shared minimizers per assembly (equal across assemblies by construction) -> ctl[a]
-        hipLaunchKernelGGL(k_flags, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), cnt, tickets, ctl);
+        hipLaunchKernelGGL(k_insert, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), mask, cap, fsup,
+                           n_fsup + n_esup);
+        // flags + shared minimizers per 256 of every assembly (their totals, equal by construction, land in ctl[a])
+        hipLaunchKernelGGL(k_flags, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), cnt, fsup);
     }
     MXG_HIP(h, hipGetLastError());
     if (nvs > 0) {
@@ -357,7 +372,9 @@ int build_graph(mxg_handle *h)
             const uint32_t n = (uint32_t)as->n_mx;
             VertexParams vp;
             vp.shared = as->d_shared.as<uint8_t>();
-            vp.bsum = cnt + as_all.bstart[a];
+            vp.cnt = cnt + as_all.bstart[a];
+            vp.sup = fsup + ((as_all.bstart[a] >> SUP_SHIFT) + a) * SUP_STRIDE;
+            vp.n_shared = ctl + a;
             vp.slot = as->d_slot.as<uint32_t>();
             vp.hash = as->d_hash.as<uint64_t>();
             vp.pos = as->d_pos.as<uint32_t>();
@@ -392,21 +409,21 @@ int build_graph(mxg_handle *h)
         ep.n_asm = A;
         ep.eflag = h->g_eflag.as<uint8_t>();
         ep.bsum = h->g_ebs.as<uint32_t>();
-        ep.tickets = tickets;
-        ep.n_edges = reinterpret_cast<uint32_t *>(ctl + CTL_EDGES);
+        ep.bsuper = esup;
+        ep.n_edges = ctl + CTL_EDGES;
         ep.eu = h->g_eu.as<uint32_t>();
         ep.ev = h->g_ev.as<uint32_t>();
         ep.esup = h->g_esup.as<uint32_t>();
         ep.ew = h->g_ew.as<double>();
         for (uint32_t a = 0; a < MXG_MAX_ASSEMBLIES; ++a) ep.weights[a] = a < A ? h->asms[a]->weight : 0.0;
-        hipLaunchKernelGGL(k_edge_flags, dim3(e_blocks), dim3(256), 0, h->stream, ep);  // + per-256 counts + their scan
+        hipLaunchKernelGGL(k_edge_flags, dim3(e_blocks), dim3(256), 0, h->stream, ep);  // + per-256 counts
         hipLaunchKernelGGL(k_edges, dim3(e_tiles), dim3(256), 0, h->stream, ep, n_items);
         MXG_HIP(h, hipGetLastError());
     }
     if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
     MXG_HIP(h, hipMemcpyAsync(hctl, h->g_ctl.p, CTL_WORDS * 8, hipMemcpyDeviceToHost, h->stream));
     MXG_HIP(h, stream_wait(h->stream));  // the stage's only sync; results stay in HBM
-    if (nb == 0) memset(hctl, 0, sizeof hctl);  // no minimizer at all: nothing was launched, nothing was written
+    if (nvs == 0) memset(hctl, 0, sizeof hctl);  // an assembly without minimizers: no vertex, and nothing wrote the counts
     const uint64_t nv = hctl[0];
     for (uint32_t a = 1; a < A; ++a)
         if (hctl[a] != nv)

@@ -138,6 +138,15 @@ struct Timers {
     uint64_t launches_hash = 0, hash_bases = 0;
 };
 
+// MXG_FLAG_TIMING: event pairs recorded around the hash kernel / the rest of a batch.  Events come from a pool and are
+// read back lazily (flush_timers: mxg_get_stats, mxg_reset_timers), so timing adds two hipEventRecord per pair to the
+// hot path and nothing else.
+struct TimedSpan {
+    hipEvent_t a, b;
+    uint64_t bases;
+    bool is_hash;
+};
+
 }  // namespace mxg
 
 struct mxg_handle {
@@ -149,6 +158,9 @@ struct mxg_handle {
     std::string err;
     std::vector<mxg::Assembly *> asms;
     mxg::Graph graph;
+    std::vector<hipEvent_t> ev_pool;       // every event ever created for timing; [0, ev_used) are in flight
+    size_t ev_used = 0;
+    std::vector<mxg::TimedSpan> ev_spans;  // not yet folded into tm
     mxg::Paths paths;
     mxg::DevBuf pbuf[32];  // scratch of paths.hip
     mxg::Timers tm;
@@ -216,6 +228,7 @@ int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t w
 int build_graph(mxg_handle *h);
 int graph_to_host(mxg_handle *h);
 int find_paths(mxg_handle *h, int64_t n_min);  // paths.hip
+int flush_timers(mxg_handle *h);                // sketch.hip: fold the recorded event pairs into h->tm
 int flags_to_host(mxg_handle *h, Assembly *a);
 
 }  // namespace mxg

@@ -114,83 +114,39 @@ static __global__ __launch_bounds__(256) void k_tile_excl_u32(const uint32_t *__
     }
 }
 
-// ---- scan fused into the producing kernel: the block that finishes LAST scans the per-block counts ------------------
-// Every block of the producer publishes its count and draws a ticket; the block that draws the last ticket knows all
-// counts are in memory and turns them into exclusive offsets (+ total) for the consumer kernel: no separate count /
-// scan launches, no spinning.
-// MI355X has eight XCDs whose L2s are not coherent with each other, so an agent-scope release/acquire FENCE means an L2
-// write-back + invalidate; one per block made the 100 us hash kernel take 670 us (and a look-back scan with
-// acquire/release status words 8x slower end to end).  What is needed is much less: the counts are published with
-// agent-scope RELAXED atomic stores (written through to memory), the publishing thread waits for its store to be
-// acknowledged (s_waitcnt vmcnt(0)) before the block draws its ticket, and the last block reads them with agent-scope
-// relaxed loads.  Everything else a block wrote is for the NEXT kernel and is made visible by the kernel boundary.
-// Tickets are two-level (one counter per group of 64 blocks, then one top counter: ~10 ns per same-address atomic
-// made a single counter cost 300 us for 35 k blocks) and self-resetting: whoever completes a counter zeroes it, so the
-// counters (zeroed once at allocation) are ready for the next launch.  Blocks that do not take part simply never call.
-__device__ __forceinline__ void publish_u32(uint32_t *p, uint32_t v)
+// ---- ordered offsets without count / scan launches: two-level counts ------------------------------------------------
+// A producer kernel whose block b yields c items stores cnt[b] = c and adds c to sup[b >> 8] (one fire-and-forget atomic
+// per block: nobody waits for it).  The consumer kernel's block that needs "items before producer block q" sums
+// sup[0 .. q>>8) and cnt[(q>>8)<<8 .. q): a few hundred words from L2 for one wave.  No scan kernel, no count kernel,
+// no inter-block waiting.  sup must be zero before the producer starts (an earlier kernel or the batch's memset does it).
+// (Measured and dropped on MI355X: a chained look-back scan -- ~100 dependent rounds for 10^4 tiny simultaneous tiles --
+// and a "last block scans" ticket scheme -- 3 us of atomic round trips at the end of every 10 us block; agent-scope
+// acquire/release FENCES in either cost an L2 write-back + invalidate each, because the eight XCDs' L2s are not
+// coherent with one another: 100 us -> 670 us for the hash kernel.)
+// Same-line atomics are served one after the other (~10 ns each on MI355X): every super-count sits on its own 128-byte
+// line, so the adds of different groups proceed in parallel and one group's 256 adds cost ~2.5 us, overlapped with the
+// rest of the kernel.  (All on one line: +46 us for the 6 104 adds of the hash kernel.)
+constexpr uint32_t SUP_SHIFT = 8;    // 256 producer blocks per super-count
+constexpr uint32_t SUP_STRIDE = 32;  // words between super-counts
+__host__ __device__ __forceinline__ uint32_t sup_words(uint32_t n_blocks) { return ((n_blocks >> SUP_SHIFT) + 1u) * SUP_STRIDE; }
+// thread 0 of producer block b
+__device__ __forceinline__ void count_publish(uint32_t *cnt, uint32_t *sup, uint32_t b, uint32_t c)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged by the memory side before anything that follows
+    cnt[b] = c;
+    if (c) atomicAdd(&sup[(b >> SUP_SHIFT) * SUP_STRIDE], c);
 }
-// counters: [0] top, [(1 + g) * LB_STRIDE] group g (64 blocks; one counter per 256 B so that the groups' atomics land on
-// different lines / channels instead of queueing behind each other); block = index among the n_blocks taking part.
-// Ends with a block barrier; block-uniform result: true for exactly one block, after all others have drawn.
-constexpr uint32_t LB_STRIDE = 64;  // words
-__device__ __forceinline__ bool last_block_ticket(uint32_t *counters, uint32_t block, uint32_t n_blocks)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v);
+// all 64 lanes of ONE wave: number of items of producer blocks [0, q)
+__device__ __forceinline__ uint32_t count_prefix(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ sup, uint32_t q)
 {
-    __shared__ uint32_t lb_last;
-    __syncthreads();   // every publish_u32 of the block is complete
-    if (threadIdx.x == 0) {
-        const uint32_t g = block >> 6, n_groups = (n_blocks + 63u) >> 6;
-        const uint32_t in_group = (g + 1u == n_groups) ? n_blocks - (g << 6) : 64u;
-        uint32_t last = 0;
-        uint32_t *gc = counters + (size_t)(1u + g) * LB_STRIDE;
-        if (atomicAdd(gc, 1u) == in_group - 1u) {
-            *gc = 0;
-            if (atomicAdd(&counters[0], 1u) == n_groups - 1u) {
-                counters[0] = 0;
-                last = 1;
-            }
-        }
-        lb_last = last;
-    }
-    __syncthreads();
-    return lb_last != 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ns = q >> SUP_SHIFT;
+    uint32_t acc = 0;
+    for (uint32_t i = lane; i < ns; i += 64) acc += sup[i * SUP_STRIDE];
+    for (uint32_t i = (ns << SUP_SHIFT) + lane; i < q; i += 64) acc += cnt[i];
+    return wave_sum_u32(acc);
 }
-__device__ __forceinline__ uint32_t load_coherent_u32(const uint32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // bypasses this CU's (non-coherent) L1
-}
-// exclusive scan of in[0..n) into out[0..n) by ONE 256-thread block (all threads call); total -> *total (u64).
-// `in` was written by other blocks of the same launch: read coherently.  in == out is allowed.
-__device__ __forceinline__ void block_scan_counts(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total2)
-{
-    __shared__ uint32_t sh[256];
-    uint64_t carry = 0;
-    for (uint32_t base = 0; base < n; base += 4096) {
-        const uint32_t i0 = base + threadIdx.x * 16u;
-        uint32_t v[16];
-        uint32_t c = 0;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            v[u] = i0 + u < n ? load_coherent_u32(in + i0 + u) : 0;
-            c += v[u];
-        }
-        uint32_t run = (uint32_t)carry + block_exclusive_256(c, sh);
-        const uint32_t tile_total = sh[255];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (i0 + u < n) out[i0 + u] = run;
-            run += v[u];
-        }
-        carry += tile_total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        total2[0] = (uint32_t)carry;
-        total2[1] = (uint32_t)(carry >> 32);
-    }
-}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
 #pragma unroll

@@ -45,7 +45,7 @@ namespace mxg {
 enum Scratch {
     SC_CAND_H, SC_CAND_K, SC_CAND_C, SC_SEL, SC_BSUM, SC_CTRL, SC_ARENA, SC_STRIP_CNT, SC_STRIP_META,
     SC_STRIP_PREF, SC_SBSUM, SC_GAPS, SC_WAVE_CNT, SC_ST_HASH, SC_ST_POS, SC_ST_REC, SC_ST_FWD, SC_G_HASH, SC_G_POS,
-    SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_TICKETS_HASH, SC_TICKETS_RESOLVE, SC_OFF256, SC_WAVE_PREF, SC_COUNT
+    SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_CNT256, SC_WAVE_TOT, SC_COUNT
 };
 static_assert(SC_COUNT <= 40, "scratch pool too small");
 
@@ -258,9 +258,8 @@ struct SparseParams {
     uint32_t *wave_cnt;   // [n_waves] candidates each wave produced (may exceed wave_cap: overflow, batch is redone)
     uint32_t *ctrl;       // [0] max over waves of wave_cnt (atomicMax, only written on overflow)
     uint32_t *strip_cnt;  // [n_strips] candidates per strip
-    uint32_t *wave_pref;  // [n_waves] candidates per wave; the block that finishes last scans it in place (exclusive)
-    uint32_t n_waves;
-    uint32_t *done;       // ticket counters of last_block_ticket
+    uint32_t *wave_tot;   // [n_waves] candidates per wave, and their super-counts (scan_kernels.h; zeroed with ctrl)
+    uint32_t *wave_sup;
     uint4 *strip_meta;    // [n_strips] {contig, kidx of the strip's first k-mer, base offset of it lo, hi}
     const uint4 *init_tab; // byte table of init_direct (make_init_tab), 256 entries
     HashTab tab;
@@ -398,13 +397,18 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     if (s < p.strip_hi) p.strip_cnt[srel] = seq;
     // candidates of the whole wave (the ordered arrays hold wave_cap per wave)
     const uint32_t tot = wave_sum_u32(seq);
+    __shared__ uint32_t wtot[4];
     if (lane == 0) {
         p.wave_cnt[wave_id] = cnt_w;
-        publish_u32(&p.wave_pref[wave_id], tot);
+        p.wave_tot[wave_id] = tot;  // k_reorder derives every wave's first ordered slot from these and the super-counts
+        wtot[wv] = tot;
         if (tot > wave_cap) atomicMax(&p.ctrl[0], tot);  // overflow: the host redoes the batch with this capacity
     }
-    // the block that finishes last turns the per-wave counts into each wave's first ordered slot (+ the total)
-    if (last_block_ticket(p.done, blockIdx.x, gridDim.x)) block_scan_counts(p.wave_pref, p.wave_pref, p.n_waves, p.ctrl + 4);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one add per block: its four waves share a super-count (256 waves = 64 blocks)
+        const uint32_t c = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        if (c) atomicAdd(&p.wave_sup[(wave_id >> SUP_SHIFT) * SUP_STRIDE], c);
+    }
 }
 
 // arena entry -> full hashes -> ordered candidate slots: one block per wave slice, one thread per entry (1.15
@@ -417,7 +421,9 @@ struct ReorderParams {
     uint32_t wave_cap, n_cap;
     const uint32_t *strip_cnt;   // [n_strips] candidates per strip
     uint32_t n_strips;
-    const uint32_t *wave_pref;   // [n_waves] ordered slot of each wave's first candidate (scanned by k_hash_sparse)
+    const uint32_t *wave_tot;    // [n_waves] candidates per wave + super-counts (k_hash_sparse)
+    const uint32_t *wave_sup;
+    uint32_t *n_cand;            // ctrl[4..5]: total, written by the block of the last wave
     const uint4 *strip_meta;
     const uint32_t *packed;
     const uint4 *init_tab;
@@ -449,7 +455,13 @@ __global__ __launch_bounds__(256) void k_reorder(const ReorderParams p)
         const bool in = s < p.n_strips;
         const uint32_t c = in ? p.strip_cnt[s] : 0u;
         if (in) smeta[threadIdx.x] = p.strip_meta[s];
-        spref[threadIdx.x] = p.wave_pref[wv] + wave_inclusive_u32(c, threadIdx.x) - c;
+        const uint32_t before = count_prefix(p.wave_tot, p.wave_sup, wv);
+        const uint32_t incl = wave_inclusive_u32(c, threadIdx.x);
+        spref[threadIdx.x] = before + incl - c;
+        if (wv + 1 == gridDim.x && threadIdx.x == 63) {
+            p.n_cand[0] = before + incl;
+            p.n_cand[1] = 0;
+        }
     }
     __syncthreads();
     auto place = [&](const uint2 a) {
@@ -494,10 +506,9 @@ struct ResolveParams {
     uint4 *gaps;              // {contig, k_lo, k_hi, 0}
     uint32_t gap_cap;
     uint32_t *gap_count;
-    // fused count + scan (COUNT): minimizers per block of 256 candidates; the block that finishes last scans them
-    uint32_t *off256;         // [gridDim.x] -> exclusive offsets
-    uint32_t *n_sel;          // ctrl[2..3]: number of selected candidates
-    uint32_t *done;           // ticket counters of last_block_ticket
+    // fused count (COUNT): minimizers per block of 256 candidates + super-counts (scan_kernels.h) for k_emit
+    uint32_t *cnt256;         // [gridDim.x]
+    uint32_t *sel_sup;        // zeroed with the control block
 };
 
 __device__ __forceinline__ void push_gap(const ResolveParams &p, uint32_t c, uint32_t lo, uint32_t hi)
@@ -571,15 +582,6 @@ __device__ __forceinline__ bool coop_right_blocked(const CoopCtx &q, uint32_t la
 
 constexpr int RH = 128;  // halo (candidates) staged on each side of a block's 256 candidates
 constexpr int RP = 4;    // padding entries so that 4-wide neighbour groups never index outside the arrays
-
-// the last thing a block of k_resolve<.., COUNT> that holds candidates does: its count, and the scan if it is the last
-// one out (blocks beyond the n candidates take no part)
-__device__ __forceinline__ void resolve_finish(const ResolveParams &p, uint32_t n, uint32_t block_count)
-{
-    const uint32_t n_blocks = (n + 255u) / 256u;
-    if (threadIdx.x == 0) publish_u32(&p.off256[blockIdx.x], block_count);
-    if (last_block_ticket(p.done, blockIdx.x, n_blocks)) block_scan_counts(p.off256, p.off256, n_blocks, p.n_sel);
-}
 
 template <bool GAPS, bool COUNT>
 __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
@@ -714,7 +716,10 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
                 for (uint32_t pc = p.ctg_lo; pc < p.ctg_hi; ++pc) push_gap(p, pc, 0, p.ctg_nk[pc] - 1);
         }
     }
-    if (COUNT) resolve_finish(p, n, (uint32_t)__syncthreads_count(chosen ? 1 : 0));
+    if (COUNT) {
+        const uint32_t c = (uint32_t)__syncthreads_count(chosen ? 1 : 0);
+        if (threadIdx.x == 0) count_publish(p.cnt256, p.sel_sup, blockIdx.x, c);
+    }
 }
 
 // k_count with the element count read from device memory
@@ -745,8 +750,9 @@ struct EmitParams {
     const uint32_t *n_ptr;
     uint32_t n_cap;
     const uint32_t *ovf;   // see ResolveParams
-    const uint32_t *bsum;  // exclusive offsets: tile t starts at bsum[t * bsum_stride]
-    uint32_t bsum_stride;  // 1: per 1024-tile (k_count_n + k_scan_sums), 4: per 256 candidates (k_resolve's fused scan)
+    const uint32_t *bsum;  // dense path: exclusive offsets per 1024-tile (k_count_n + k_scan_sums); sparse path: nullptr,
+    const uint32_t *cnt256, *sel_sup;  // ... offsets come from k_resolve's two-level counts
+    uint32_t *n_sel;       // sparse path: ctrl[2..3], written by the tile that holds the last candidate
     const Run *runs;
     const uint32_t *ctg_run0, *ctg_rec;
     uint64_t mult;         // 1 ^ (k * MULTISEED)
@@ -766,7 +772,26 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
     const uint32_t fl = load_flags4(p.sel, base, n);
     uint32_t c = count_flags4(fl);
-    uint64_t o = p.out_base + p.bsum[blockIdx.x * p.bsum_stride] + block_exclusive_256(c, sh);
+    uint32_t before;
+    if (p.bsum) {
+        before = p.bsum[blockIdx.x];
+    } else {
+        __shared__ uint32_t sh_before;
+        if (threadIdx.x < 64) {
+            const uint32_t bef = count_prefix(p.cnt256, p.sel_sup, blockIdx.x * (TILE / 256));
+            if (threadIdx.x == 0) sh_before = bef;
+            if ((n - 1) / TILE == blockIdx.x) {  // the tile holding the last candidate also reports the total
+                const uint32_t all = count_prefix(p.cnt256, p.sel_sup, (n + 255u) / 256u);
+                if (threadIdx.x == 0) {
+                    p.n_sel[0] = all;
+                    p.n_sel[1] = 0;
+                }
+            }
+        }
+        __syncthreads();
+        before = sh_before;
+    }
+    uint64_t o = p.out_base + before + block_exclusive_256(c, sh);
     if (c == 0) return;
     for (int u = 0; u < TILE_PER_THREAD; ++u) {
         uint32_t i = base + u;
@@ -941,15 +966,8 @@ static void build_strip_tables(const std::vector<Run> &runs, int S, std::vector<
     if (s >= (1ull << 32)) *overflow = true;
 }
 
-struct EventPair {
-    hipEvent_t a, b;
-    uint64_t bases;
-    bool is_hash;
-};
-
 struct Driver {
     mxg_handle *h;
-    std::vector<EventPair> evs;
     bool timing;
     hipStream_t st;   // stream this driver enqueues on
     int slot;         // which of the handle's two scratch sets it uses (two drivers can be in flight at once)
@@ -957,62 +975,40 @@ struct Driver {
         : h(h_), timing((h_->cfg.flags & MXG_FLAG_TIMING) != 0), st(slot_ == 0 ? h_->stream : h_->stream2), slot(slot_)
     {
     }
-    ~Driver()
-    {
-        for (auto &e : evs) {
-            (void)hipEventDestroy(e.a);
-            (void)hipEventDestroy(e.b);
-        }
-    }
     DevBuf &sc(int i) { return h->scratch[slot][i]; }
 
-    // ticket counters of a fused "last block scans" launch (scan_kernels.h): zeroed at allocation, self-resetting
-    int tickets(int which, uint32_t grid_blocks, uint32_t **counters)
-    {
-        DevBuf &b = sc(which);
-        const size_t need = ((size_t)grid_blocks / 64 + 4) * LB_STRIDE * 4;
-        if (need > b.bytes) {
-            MXG_HIP(h, b.ensure(need));
-            MXG_HIP(h, hipMemsetAsync(b.p, 0, b.bytes, st));
-        }
-        *counters = b.as<uint32_t>();
-        return MXG_OK;
-    }
+    // SC_CTRL holds the control block (16 words) followed by the two super-count arrays of the batch (scan_kernels.h):
+    // per hash-kernel wave, then per k_resolve block; ctrl_bytes() of it are zeroed by the batch's one memset
+    static constexpr uint32_t CTRL_WORDS = 16;
+    uint32_t n_wave_sup = 0;
+    uint32_t *wave_sup() { return sc(SC_CTRL).as<uint32_t>() + CTRL_WORDS; }
+    uint32_t *sel_sup(uint32_t) { return wave_sup() + n_wave_sup; }
+    static uint32_t n_sel_sup(uint32_t n_cap) { return sup_words((n_cap + 255) / 256); }
 
     int ev_begin(uint64_t bases, bool is_hash)
     {
         if (!timing) return MXG_OK;
-        EventPair e;
-        MXG_HIP(h, hipEventCreate(&e.a));
-        MXG_HIP(h, hipEventCreate(&e.b));
-        e.bases = bases;
-        e.is_hash = is_hash;
-        MXG_HIP(h, hipEventRecord(e.a, st));
-        evs.push_back(e);
+        while (h->ev_pool.size() < h->ev_used + 2) {
+            hipEvent_t e;
+            MXG_HIP(h, hipEventCreate(&e));
+            h->ev_pool.push_back(e);
+        }
+        TimedSpan sp{h->ev_pool[h->ev_used], h->ev_pool[h->ev_used + 1], bases, is_hash};
+        h->ev_used += 2;
+        MXG_HIP(h, hipEventRecord(sp.a, st));
+        h->ev_spans.push_back(sp);
         return MXG_OK;
     }
     int ev_end()
     {
         if (!timing) return MXG_OK;
-        MXG_HIP(h, hipEventRecord(evs.back().b, st));
+        MXG_HIP(h, hipEventRecord(h->ev_spans.back().b, st));
         return MXG_OK;
     }
     int collect()
     {
-        if (!timing) return MXG_OK;
-        MXG_HIP(h, hipStreamSynchronize(st));
-        for (auto &e : evs) {
-            float ms = 0;
-            MXG_HIP(h, hipEventElapsedTime(&ms, e.a, e.b));
-            if (e.is_hash) {
-                h->tm.ms_hash += ms;
-                h->tm.launches_hash += 1;
-                h->tm.hash_bases += e.bases;
-            } else {
-                h->tm.ms_resolve += ms;
-            }
-        }
-        return MXG_OK;
+        // read back lazily; only keep the number of events in flight bounded
+        return h->ev_spans.size() > 4096 ? flush_timers(h) : MXG_OK;
     }
 
     uint64_t batch_bases(const Tables &T, size_t c0, size_t c1) const
@@ -1023,14 +1019,14 @@ struct Driver {
         return b;
     }
 
-    // sparse path: resolve + gap detection + per-256 counts + their scan in ONE launch (offsets in SC_OFF256, total
-    // in ctrl[2..3]); emit(..., true) then places the minimizers
+    // sparse path: resolve + gap detection + per-256 counts (SC_CNT256 + super-counts behind the control block) in ONE
+    // launch; emit(..., true) turns them into offsets, places the minimizers and writes the total to ctrl[2..3]
     int resolve_count(const Tables &T, uint32_t n_cap, uint32_t ctg_lo, uint32_t ctg_hi, uint64_t tau)
     {
         if (!n_cap) return MXG_OK;
         MXG_HIP(h, sc(SC_SEL).ensure(std::max<uint32_t>(n_cap, 16)));
         const uint32_t blocks = (n_cap + 255) / 256;
-        MXG_HIP(h, sc(SC_OFF256).ensure((size_t)blocks * 4 + 64));
+        MXG_HIP(h, sc(SC_CNT256).ensure((size_t)blocks * 4 + 64));
         uint32_t *ctrl = sc(SC_CTRL).as<uint32_t>();
         ResolveParams rp;
         rp.ch = sc(SC_CAND_H).as<uint64_t>();
@@ -1048,10 +1044,8 @@ struct Driver {
         rp.gaps = sc(SC_GAPS).as<uint4>();
         rp.gap_cap = GAP_CAP;
         rp.gap_count = ctrl + 1;
-        rp.off256 = sc(SC_OFF256).as<uint32_t>();
-        rp.n_sel = ctrl + 2;
-        int rc = tickets(SC_TICKETS_RESOLVE, blocks, &rp.done);
-        if (rc != MXG_OK) return rc;
+        rp.cnt256 = sc(SC_CNT256).as<uint32_t>();
+        rp.sel_sup = sel_sup(n_cap);
         hipLaunchKernelGGL((k_resolve<true, true>), dim3(blocks), dim3(256), 0, st, rp);
         MXG_HIP(h, hipGetLastError());
         return MXG_OK;
@@ -1081,9 +1075,8 @@ struct Driver {
         rp.gaps = sc(SC_GAPS).as<uint4>();
         rp.gap_cap = GAP_CAP;
         rp.gap_count = ctrl + 1;
-        rp.off256 = nullptr;
-        rp.n_sel = nullptr;
-        rp.done = nullptr;
+        rp.cnt256 = nullptr;
+        rp.sel_sup = nullptr;
         if (n_cap) {
             hipLaunchKernelGGL((k_resolve<GAPS, false>), dim3((n_cap + 255) / 256), dim3(256), 0, st, rp);
             hipLaunchKernelGGL(k_count_n, dim3(n_tiles), dim3(256), 0, st, rp.sel, rp.n_ptr, n_cap,
@@ -1095,7 +1088,7 @@ struct Driver {
         return MXG_OK;
     }
 
-    // offsets: SC_BSUM per 1024-tile (after resolve_and_count / recount) or, fused = true, SC_OFF256 (after resolve_count)
+    // offsets: SC_BSUM per 1024-tile (after resolve_and_count) or, fused = true, from SC_CNT256 (after resolve_count)
     int emit(const uint32_t *d_packed, const Tables &T, uint32_t n_cap, DevBuf &oh, DevBuf &op, DevBuf &orc, DevBuf &of,
              uint64_t out_base, bool fused = false)
     {
@@ -1109,8 +1102,10 @@ struct Driver {
         ep.n_ptr = sc(SC_CTRL).as<uint32_t>() + 4;
         ep.ovf = sc(SC_CTRL).as<uint32_t>();
         ep.n_cap = n_cap;
-        ep.bsum = fused ? sc(SC_OFF256).as<uint32_t>() : sc(SC_BSUM).as<uint32_t>();
-        ep.bsum_stride = fused ? TILE / 256 : 1;
+        ep.bsum = fused ? nullptr : sc(SC_BSUM).as<uint32_t>();
+        ep.cnt256 = fused ? sc(SC_CNT256).as<uint32_t>() : nullptr;
+        ep.sel_sup = fused ? sel_sup(n_cap) : nullptr;
+        ep.n_sel = sc(SC_CTRL).as<uint32_t>() + 2;
         ep.runs = T.d_runs;
         ep.ctg_run0 = T.d_ctg_run0;
         ep.ctg_rec = T.d_ctg_rec;
@@ -1300,12 +1295,11 @@ struct Driver {
                        OutArrays &out, uint32_t *ctrl_host, uint32_t *n_cap_out)
     {
         const uint32_t S = a->S_sparse;
-        MXG_HIP(h, sc(SC_CTRL).ensure(64));
         MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
         MXG_HIP(h, sc(SC_STRIP_CNT).ensure((size_t)g.n_strips * 4 + 16));
         MXG_HIP(h, sc(SC_STRIP_META).ensure((size_t)g.n_strips * 16 + 16));
         MXG_HIP(h, sc(SC_WAVE_CNT).ensure((size_t)g.n_waves * 4 + 16));
-        MXG_HIP(h, sc(SC_WAVE_PREF).ensure((size_t)g.n_waves * 4 + 16));
+        MXG_HIP(h, sc(SC_WAVE_TOT).ensure((size_t)g.n_waves * 4 + 16));
         const uint64_t n_cap64 = (uint64_t)g.n_waves * wave_cap;
         if (n_cap64 >= (1ull << 32))
             return set_err(h, MXG_ELIMIT, "candidate arena would exceed 2^32 entries; use MXG_FLAG_DENSE_ONLY");
@@ -1315,7 +1309,10 @@ struct Driver {
         MXG_HIP(h, sc(SC_CAND_H).ensure((size_t)n_cap * 8));
         MXG_HIP(h, sc(SC_CAND_K).ensure((size_t)n_cap * 4));
         MXG_HIP(h, sc(SC_CAND_C).ensure((size_t)n_cap * 4));
-        MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, 32, st));
+        n_wave_sup = sup_words(g.n_waves);
+        const size_t ctrl_bytes = ((size_t)CTRL_WORDS + n_wave_sup + n_sel_sup(n_cap)) * 4;
+        MXG_HIP(h, sc(SC_CTRL).ensure(ctrl_bytes));
+        MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, ctrl_bytes, st));  // control block + both super-count arrays
         SparseParams sp;
         sp.packed = a->d_packed;
         sp.runs = T.d_runs;
@@ -1333,10 +1330,9 @@ struct Driver {
         sp.ctrl = sc(SC_CTRL).as<uint32_t>();
         sp.strip_cnt = sc(SC_STRIP_CNT).as<uint32_t>();
         sp.strip_meta = sc(SC_STRIP_META).as<uint4>();
-        sp.wave_pref = sc(SC_WAVE_PREF).as<uint32_t>();
-        sp.n_waves = g.n_waves;
-        int rc = tickets(SC_TICKETS_HASH, g.n_blocks, &sp.done);
-        if (rc != MXG_OK) return rc;
+        sp.wave_tot = sc(SC_WAVE_TOT).as<uint32_t>();
+        sp.wave_sup = wave_sup();
+        int rc;
         sp.init_tab = h->d_init_tab.as<uint4>();
         sp.tab = h->tab;
         if ((rc = ev_begin(batch_bases(T, g.c0, g.c1), true)) != MXG_OK) return rc;
@@ -1361,7 +1357,9 @@ struct Driver {
         op.n_cap = n_cap;
         op.strip_cnt = sp.strip_cnt;
         op.n_strips = g.n_strips;
-        op.wave_pref = sp.wave_pref;
+        op.wave_tot = sp.wave_tot;
+        op.wave_sup = sp.wave_sup;
+        op.n_cand = sp.ctrl + 4;
         op.strip_meta = sp.strip_meta;
         op.packed = sp.packed;
         op.init_tab = sp.init_tab;
@@ -1676,6 +1674,28 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
         if (state[i] == 0 && (rc = run_sketch_sync(h, list[i], tabs[i], drv0)) != MXG_OK) return rc;
     if ((rc = drv0.collect()) != MXG_OK) return rc;
     return drv1.collect();
+}
+
+int flush_timers(mxg_handle *h)
+{
+    if (h->ev_spans.empty()) return MXG_OK;
+    MXG_HIP(h, hipSetDevice(h->device));
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    MXG_HIP(h, hipStreamSynchronize(h->stream2));
+    for (auto &e : h->ev_spans) {
+        float ms = 0;
+        MXG_HIP(h, hipEventElapsedTime(&ms, e.a, e.b));
+        if (e.is_hash) {
+            h->tm.ms_hash += ms;
+            h->tm.launches_hash += 1;
+            h->tm.hash_bases += e.bases;
+        } else {
+            h->tm.ms_resolve += ms;
+        }
+    }
+    h->ev_spans.clear();
+    h->ev_used = 0;
+    return MXG_OK;
 }
 
 int ensure_strand(mxg_handle *h, Assembly *a)
