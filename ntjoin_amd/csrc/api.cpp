@@ -87,6 +87,7 @@ void mxg_destroy(mxg_handle *h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->pinned_ctrl) (void)hipHostFree(h->pinned_ctrl);
+    if (h->pinned_gctl) (void)hipHostFree(h->pinned_gctl);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

@@ -186,6 +186,7 @@ struct EdgeParams {
     uint32_t *bsum;       // edges per 256 items + super-counts (scan_kernels.h)
     uint32_t *bsuper;
     uint64_t *n_edges;    // ctl[CTL_EDGES], written by the last tile of k_edges
+    uint64_t *host_ctl;   // pinned host copy of the control block, written by that tile too (no copy on the stream)
     uint32_t *eu, *ev, *esup;
     double *ew;
     double weights[MXG_MAX_ASSEMBLIES];
@@ -235,7 +236,11 @@ __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_it
         if (threadIdx.x == 0) sh_before = bef;
         if (blockIdx.x + 1 == gridDim.x) {  // the last tile also reports the total
             const uint32_t all = count_prefix(p.bsum, p.bsuper, (n_items + 255u) / 256u);
-            if (threadIdx.x == 0) *p.n_edges = all;
+            if (threadIdx.x == 0) {
+                *p.n_edges = all;
+                p.host_ctl[32] = all;  // CTL_EDGES
+            }
+            if (threadIdx.x < p.n_asm) p.host_ctl[threadIdx.x] = p.nv_ptr[threadIdx.x];  // shared minimizers per assembly
         }
     }
     __syncthreads();
@@ -341,7 +346,9 @@ int build_graph(mxg_handle *h)
     // vertex arrays are strided by an upper bound of the vertex count (every vertex occurs once in every assembly), so
     // this stage needs no host sync before its kernels: they read the counts from the control block in HBM
     const uint64_t nvs = nmin;  // stride
-    uint64_t hctl[CTL_WORDS] = {0};
+    if (!h->pinned_gctl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_gctl, CTL_WORDS * 8));
+    uint64_t *const hctl = h->pinned_gctl;
+    memset(hctl, 0, CTL_WORDS * 8);
     if (nvs > 0 && (uint64_t)A * nvs >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "graph too large for 32-bit item indices");
     const size_t anv = (size_t)A * nvs;
     const uint32_t n_items = (uint32_t)anv;
@@ -411,6 +418,7 @@ int build_graph(mxg_handle *h)
         ep.bsum = h->g_ebs.as<uint32_t>();
         ep.bsuper = esup;
         ep.n_edges = ctl + CTL_EDGES;
+        ep.host_ctl = h->pinned_gctl;
         ep.eu = h->g_eu.as<uint32_t>();
         ep.ev = h->g_ev.as<uint32_t>();
         ep.esup = h->g_esup.as<uint32_t>();
@@ -421,9 +429,7 @@ int build_graph(mxg_handle *h)
         MXG_HIP(h, hipGetLastError());
     }
     if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
-    MXG_HIP(h, hipMemcpyAsync(hctl, h->g_ctl.p, CTL_WORDS * 8, hipMemcpyDeviceToHost, h->stream));
     MXG_HIP(h, stream_wait(h->stream));  // the stage's only sync; results stay in HBM
-    if (nvs == 0) memset(hctl, 0, sizeof hctl);  // an assembly without minimizers: no vertex, and nothing wrote the counts
     const uint64_t nv = hctl[0];
     for (uint32_t a = 1; a < A; ++a)
         if (hctl[a] != nv)

@@ -173,6 +173,7 @@ struct mxg_handle {
         g_ebs, g_eu, g_ev, g_esup, g_ew;  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
     uint64_t arena_cap_hint = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t *pinned_gctl = nullptr;  // pinned host copy of the graph stage's control block
     uint32_t *pinned_ctrl = nullptr;  // pinned host copies of per-assembly control blocks (pipelined sketch)
 };
 

@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "mxg_internal.h"
@@ -753,6 +754,8 @@ struct EmitParams {
     const uint32_t *bsum;  // dense path: exclusive offsets per 1024-tile (k_count_n + k_scan_sums); sparse path: nullptr,
     const uint32_t *cnt256, *sel_sup;  // ... offsets come from k_resolve's two-level counts
     uint32_t *n_sel;       // sparse path: ctrl[2..3], written by the tile that holds the last candidate
+    uint32_t *host_ctrl;   // sparse path: pinned host copy of the control block (8 words), written by that tile too:
+                           // no copy on the stream, the host reads it after the stream has drained
     const Run *runs;
     const uint32_t *ctg_run0, *ctg_rec;
     uint64_t mult;         // 1 ^ (k * MULTISEED)
@@ -766,8 +769,12 @@ struct EmitParams {
 __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
 {
     __shared__ uint32_t sh[256];
-    if (*p.ovf) return;
     const uint32_t n = min(*p.n_ptr, p.n_cap);
+    if (*p.ovf || n == 0) {  // arena overflow (the host redoes the batch) or no candidate at all: only report
+        if (p.host_ctrl && blockIdx.x == 0 && threadIdx.x < 8)
+            p.host_ctrl[threadIdx.x] = threadIdx.x == 0 ? *p.ovf : (threadIdx.x == 1 ? p.ovf[1] : 0u);
+        return;
+    }
     if (blockIdx.x * TILE >= n) return;  // whole tile beyond the candidates
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
     const uint32_t fl = load_flags4(p.sel, base, n);
@@ -785,6 +792,10 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
                 if (threadIdx.x == 0) {
                     p.n_sel[0] = all;
                     p.n_sel[1] = 0;
+                }
+                if (p.host_ctrl && threadIdx.x < 8) {  // {overflow, gaps, selected lo/hi, candidates lo/hi, 0, 0}
+                    const uint32_t w = threadIdx.x;
+                    p.host_ctrl[w] = w == 1 ? p.ovf[1] : w == 2 ? all : w == 4 ? *p.n_ptr : 0u;
                 }
             }
         }
@@ -1090,7 +1101,7 @@ struct Driver {
 
     // offsets: SC_BSUM per 1024-tile (after resolve_and_count) or, fused = true, from SC_CNT256 (after resolve_count)
     int emit(const uint32_t *d_packed, const Tables &T, uint32_t n_cap, DevBuf &oh, DevBuf &op, DevBuf &orc, DevBuf &of,
-             uint64_t out_base, bool fused = false)
+             uint64_t out_base, bool fused = false, uint32_t *host_ctrl = nullptr)
     {
         const uint64_t limit = std::min<uint64_t>({oh.bytes / 8, op.bytes / 4, orc.bytes / 4, of.bytes});
         if (!n_cap) return MXG_OK;
@@ -1106,6 +1117,7 @@ struct Driver {
         ep.cnt256 = fused ? sc(SC_CNT256).as<uint32_t>() : nullptr;
         ep.sel_sup = fused ? sel_sup(n_cap) : nullptr;
         ep.n_sel = sc(SC_CTRL).as<uint32_t>() + 2;
+        ep.host_ctrl = host_ctrl;
         ep.runs = T.d_runs;
         ep.ctg_run0 = T.d_ctg_run0;
         ep.ctg_rec = T.d_ctg_rec;
@@ -1289,8 +1301,8 @@ struct Driver {
         if (h->arena_cap_hint == 0) wave_cap = env_u64("MXG_WAVE_CAP", wave_cap);  // test knob
         return wave_cap;
     }
-    // Enqueue one batch completely (hash -> order -> resolve -> count -> speculative emit at out.n) and an async copy
-    // of the control block to `ctrl_host`; NO host sync.  *n_cap_out = capacity the candidate arrays were sized for.
+    // Enqueue one batch completely (hash -> order -> resolve+count -> speculative emit at out.n); the last kernel writes
+    // the control block to `ctrl_host` (PINNED host memory); NO host sync.  *n_cap_out = capacity the candidate arrays were sized for.
     int enqueue_sparse(Assembly *a, const Tables &T, const BatchGeom &g, uint64_t wave_cap, uint32_t tau_hi,
                        OutArrays &out, uint32_t *ctrl_host, uint32_t *n_cap_out)
     {
@@ -1376,10 +1388,8 @@ struct Driver {
         // resolve + speculative emit straight into the output arrays (guarded by their capacity): on the common path
         // (no gap, no overflow) the batch then needs a single host sync
         if ((rc = resolve_count(T, n_cap, (uint32_t)g.c0, (uint32_t)g.c1, (uint64_t)tau_hi << 32)) != MXG_OK) return rc;
-        if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true)) != MXG_OK) return rc;
-        if ((rc = ev_end()) != MXG_OK) return rc;
-        MXG_HIP(h, hipMemcpyAsync(ctrl_host, sc(SC_CTRL).p, 32, hipMemcpyDeviceToHost, st));
-        return MXG_OK;
+        if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host)) != MXG_OK) return rc;
+        return ev_end();
     }
 
     // Second half of a sparse batch, after the host has read the control block `ctrl` of a run that did not overflow:
@@ -1447,10 +1457,12 @@ struct Driver {
             batch_geom(T, c0, g);
             const size_t c1 = g.c1;
             uint64_t wave_cap = default_wave_cap(S, cand_frac);
-            uint32_t ctrl[8];
+            if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, (MXG_MAX_ASSEMBLIES + 1) * 32));
+            uint32_t *const ctrl = h->pinned_ctrl + 8 * MXG_MAX_ASSEMBLIES;  // the slot of the synchronous path
             uint64_t n_cap64 = 0;
             for (int attempt = 0;; ++attempt) {
                 uint32_t n_cap_now = 0;
+                memset(ctrl, 0xFF, 32);
                 int rc = enqueue_sparse(a, T, g, wave_cap, tau_hi, out, ctrl, &n_cap_now);
                 if (rc != MXG_OK) return rc;
                 n_cap64 = n_cap_now;
@@ -1460,7 +1472,9 @@ struct Driver {
                 wave_cap = std::min<uint64_t>((uint64_t)ctrl[0] + 64, 64ull * S);  // exact need is known: redo the batch
                 h->arena_cap_hint = wave_cap;
             }
-            int rcb = complete_batch(a, T, g, out, ctrl, (uint32_t)n_cap64);
+            uint32_t ctrl_copy[8];
+            memcpy(ctrl_copy, ctrl, 32);
+            int rcb = complete_batch(a, T, g, out, ctrl_copy, (uint32_t)n_cap64);
             if (rcb != MXG_OK) return rcb;
             c0 = c1;
         }
@@ -1601,7 +1615,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
 {
     if (n == 1) return sketch_assembly(h, list[0]);
     MXG_HIP(h, hipSetDevice(h->device));
-    if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, MXG_MAX_ASSEMBLIES * 32));
+    if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, (MXG_MAX_ASSEMBLIES + 1) * 32));
     double frac;
     uint32_t tau_hi;
     const bool sparse = sparse_mode(h, &frac, &tau_hi);
