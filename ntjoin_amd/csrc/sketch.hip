@@ -425,6 +425,7 @@ struct ReorderParams {
     const uint32_t *wave_tot;    // [n_waves] candidates per wave + super-counts (k_hash_sparse)
     const uint32_t *wave_sup;
     uint32_t *n_cand;            // ctrl[4..5]: total, written by the block of the last wave
+    uint32_t queue_cap;          // candidates the LDS queue holds (= wave_cap), 0: slice too large, hash per entry
     const uint4 *strip_meta;
     const uint32_t *packed;
     const uint4 *init_tab;
@@ -465,23 +466,50 @@ __global__ __launch_bounds__(256) void k_reorder(const ReorderParams p)
         }
     }
     __syncthreads();
-    auto place = [&](const uint2 a) {
-        uint32_t bits = a.y & 0xFFFFu;
+    auto hash_one = [&](const uint2 a, uint32_t u, uint32_t r) {  // candidate number r of entry a: k-mer u of its block
         const uint32_t j0 = ((a.y >> 16) & 63u) * 16u;
-        uint32_t dst = spref[a.x & 63u] + (a.y >> 22);
+        const uint32_t dst = spref[a.x & 63u] + (a.y >> 22) + r;
+        if (dst >= p.n_cap) return;  // beyond it only when a wave overflowed: the host redoes the batch
         const uint4 sm = smeta[a.x & 63u];
-        const uint64_t b0 = (((uint64_t)sm.w << 32) | sm.z) + j0;
-        while (bits) {  // most significant bit = first k-mer of the block
+        H2 h = {0u, 0u, 0u, 0u};
+        init_direct(h, p.packed, (((uint64_t)sm.w << 32) | sm.z) + j0 + u, p.k, btab, tab);
+        p.ch[dst] = canonical<VARIANT>(h);
+        p.ck[dst] = sm.y + j0 + u;
+        p.cc[dst] = sm.x;
+    };
+    if (p.queue_cap) {
+        // One thread per CANDIDATE: an entry holds 1.15 candidates on average but some lane of every wave holds 2 or 3,
+        // so hashing per entry makes the whole wave walk the 8 table lookups 2-3 times.  The entries are expanded into
+        // a queue in LDS (item = entry << 8 | k-mer << 4 | rank) and the queue is hashed densely.
+        extern __shared__ uint32_t queue[];
+        __shared__ uint32_t sh_scan[256];
+        uint32_t qn = 0;
+        for (uint32_t e0 = 0; e0 < cnt; e0 += 256) {
+            const uint32_t i = e0 + threadIdx.x;
+            const uint2 a = e0 == 0 ? a0 : (e0 == 256 ? a1 : (i < cnt ? src[i] : make_uint2(0u, 0u)));
+            uint32_t bits = a.y & 0xFFFFu;
+            uint32_t at = qn + block_exclusive_256((uint32_t)__popc(bits), sh_scan);
+            qn += sh_scan[255];
+            for (uint32_t r = 0; bits; ++r, ++at) {  // most significant bit = first k-mer of the block
+                const uint32_t u = (uint32_t)__clz((int)bits) - 16u;
+                bits &= ~(0x8000u >> u);
+                if (at < p.queue_cap) queue[at] = (i << 8) | (u << 4) | r;
+            }
+            __syncthreads();
+        }
+        qn = min(qn, p.queue_cap);
+        for (uint32_t q = threadIdx.x; q < qn; q += 256) {
+            const uint32_t item = queue[q];
+            hash_one(src[item >> 8], (item >> 4) & 15u, item & 15u);
+        }
+        return;
+    }
+    auto place = [&](const uint2 a) {  // (slices too large for the queue: one thread per entry)
+        uint32_t bits = a.y & 0xFFFFu;
+        for (uint32_t r = 0; bits; ++r) {
             const uint32_t u = (uint32_t)__clz((int)bits) - 16u;
             bits &= ~(0x8000u >> u);
-            if (dst < p.n_cap) {  // beyond it only when a wave overflowed: the host redoes the batch
-                H2 h = {0u, 0u, 0u, 0u};
-                init_direct(h, p.packed, b0 + u, p.k, btab, tab);
-                p.ch[dst] = canonical<VARIANT>(h);
-                p.ck[dst] = sm.y + j0 + u;
-                p.cc[dst] = sm.x;
-            }
-            ++dst;
+            hash_one(a, u, r);
         }
     };
     place(a0);
@@ -1380,10 +1408,12 @@ struct Driver {
         op.ck = sc(SC_CAND_K).as<uint32_t>();
         op.cc = sc(SC_CAND_C).as<uint32_t>();
         op.tab = h->tab;
+        op.queue_cap = sp.wave_cap <= 8192 ? sp.wave_cap : 0;
+        const size_t q_lds = (size_t)op.queue_cap * 4;
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-            hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V1_MIN>, dim3(g.n_waves), dim3(256), 0, st, op);
+            hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V1_MIN>, dim3(g.n_waves), dim3(256), q_lds, st, op);
         else
-            hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V2_SUM>, dim3(g.n_waves), dim3(256), 0, st, op);
+            hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V2_SUM>, dim3(g.n_waves), dim3(256), q_lds, st, op);
         MXG_HIP(h, hipGetLastError());
         // resolve + speculative emit straight into the output arrays (guarded by their capacity): on the common path
         // (no gap, no overflow) the batch then needs a single host sync
