@@ -906,23 +906,22 @@ __global__ __launch_bounds__(256) void k_merge(const MergeParams p)
 // ------------------------------------------------------------------------------------------------------
 constexpr int S_DENSE = 128;
 
-// MXG_SPARSE_S=<n> (environment) forces the strip length instead of the occupancy-balanced choice
-// Strip length for the sparse kernel: one lane hashes S consecutive k-mers after a k-step warm-up, so S should be
-// long (warm-up overhead k/S) but the launch should still fill the chip evenly: MI355X has 256 CUs x 4 SIMDs;
-// aim for a whole number of waves per SIMD (>= 4 for latency hiding) in a single round when the input is small.
+// MXG_SPARSE_S=<n> (environment) forces the strip length instead of the choice below.
+// Strip length for the sparse kernel: one lane rolls S consecutive k-mers.  A strip costs one direct hash evaluation
+// (k/4 table lookups) and 16 B of strip table, and every wave one slice of the candidate arena and one k_reorder block,
+// so long strips make the stages after the hash kernel cheaper; but a lane's 16-base words are S/4 bytes apart, so
+// long strips spread a wave's loads over more cache lines and leave fewer waves per SIMD on small inputs.  Measured on
+// MI355X (tools/sweep_S.sh, sketch+graph, k=32 w=1000): 2 x 100 Mbp 569 / 578 / 584 / 588 / 556 Gbp/s and 2 x 1 Gbp
+// 659 / 675 / 683 / 689 / 581 Gbp/s at S = 192 / 256 / 320 / 384 / 512; the hash kernel alone is fastest at 192-256.
 static uint32_t choose_sparse_S(uint64_t total_kmers)
 {
     const char *e = getenv("MXG_SPARSE_S");
     if (e && atoi(e) >= 16) return std::min(1024, (atoi(e) + 15) / 16 * 16);
     const uint64_t lanes = 1024ull * 64;  // SIMDs x lanes
-    // with the table-driven initialisation a strip has no warm-up cost, so short strips are fine: aim for ~12 waves per
-    // SIMD (measured 88 us at S=128 vs 94 us at S=256 for 100 Mbp), at least 128 k-mers per strip
-    {
-        uint64_t S = (total_kmers + lanes * 12 - 1) / (lanes * 12);
-        S = (S + 15) / 16 * 16;
-        if (S <= 512) return (uint32_t)std::max<uint64_t>(S, 128);
-    }
-    return 512;  // large inputs: many rounds anyway; warm-up overhead k/512
+    // small inputs: keep at least ~4 waves per SIMD in flight
+    uint64_t S = (total_kmers + lanes * 4 - 1) / (lanes * 4);
+    S = (S + 15) / 16 * 16;
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(S, 64), 320);
 }
 // batch sizes (whole records; a single record may exceed them).  Test knobs (environment, read per call):
 // MXG_DENSE_BATCH_KMERS / MXG_SPARSE_BATCH_KMERS shrink the batches, MXG_WAVE_CAP forces the arena-overflow retry.
