@@ -30,6 +30,22 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_BASE_HASH = 0.25  # hash kernel: one 2-bit packed base read per base
 
 
+def valu_info(st):
+    """integer-VALU view of the hash kernel: instructions per base and issue utilisation from the committed PMC summary
+    (profiles/hash_kernel_pmc.json, tools/pmc_bench.sh), rate from this run's HIP-event time"""
+    path = os.path.join(REPO, "profiles", "hash_kernel_pmc.json")
+    try:
+        pmc = json.load(open(path))
+    except Exception:
+        return None
+    per_base = pmc["valu_per_base"]
+    return {"wave64_instr_per_base": round(per_base, 2),
+            "int_lane_ops_per_s": round(per_base * st["hash_kernel_bases"] / max(st["ms_hash"], 1e-9) * 1e3, 0),
+            "peak_lane_ops_per_s": 256 * 4 * 32 * 2.4e9,  # 1024 SIMDs x 32 lane-ops per cycle (wave64 at ~2.3 cycles, profiles/ubench)
+            "valu_busy_pmc": round(pmc["valu_busy"], 3),
+            "source": "rocprofv3 SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE, profiles/hash_kernel_pmc.json"}
+
+
 def cpu_baseline(ref, tgt):
     """The oracle (scalar C port of indexlr + Python port of the graph stage) on the SAME workload, 1 core.
     Checker/baseline only: nothing here is on the product path."""
@@ -174,9 +190,7 @@ def main():
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(st["launches_hash"]),
                          "bases_per_launch": int(st["hash_kernel_bases"] / launches)},
             # the binding resource is integer VALU issue, not HBM: reported beside the HBM figure
-            "valu": {"wave64_instr_per_base": 30.3, "int_lane_ops_per_s": round(30.3 * 64 * st["hash_kernel_bases"] / 64 / max(st["ms_hash"], 1e-9) * 1e3, 0),
-                     "peak_lane_ops_per_s": 256 * 4 * 32 * 2.4e9, "valu_busy_pmc": 0.91,
-                     "source": "rocprofv3 SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU, profiles/r01_pmc_by_kernel.json"},
+            "valu": valu_info(st),
             "stage_ms_per_step": {"hash": round(st["ms_hash"] / args.steps, 4),
                                   "graph": round(gst["ms_graph"] / args.steps, 4)},
         }
