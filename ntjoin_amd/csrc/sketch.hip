@@ -1362,7 +1362,12 @@ struct Driver {
         sp.strip_hi = g.strip_hi;
         sp.k = h->cfg.k;
         sp.S = S;
-        sp.tau_hi = tau_hi;
+        // MXG_RING_SLACK=<percent> (test knob): the ring filter captures up to that many percent more k-mers than have
+        // hash < tau, i.e. entries that k_reorder finds to be >= tau and k_resolve must treat as absent.  On real runs
+        // such entries occur about once per 10^9 k-mers, so the tests force them.
+        const uint32_t ring_slack = (uint32_t)env_u64("MXG_RING_SLACK", 0);  // read per call, like the other knobs
+        sp.tau_hi = ring_slack ? (uint32_t)std::min<uint64_t>(0x7FFFFFFEull, (uint64_t)tau_hi * (100 + ring_slack) / 100) & ~1u
+                               : tau_hi;
         sp.arena = sc(SC_ARENA).as<uint2>();
         sp.wave_cap = (uint32_t)wave_cap;
         sp.wave_cnt = sc(SC_WAVE_CNT).as<uint32_t>();

@@ -34,7 +34,7 @@ def _check(oracle, recs, k, w, **kw):
         st = eng.stats()
     for r, (rid, seq) in enumerate(recs):
         lo, hi = int(sk["record_first"][r]), int(sk["record_first"][r + 1])
-        want = oracle.sketch(seq, k, w)
+        want = oracle.sketch(seq, k, w, _oracle.V1_MIN if kw.get("variant") == "v1" else _oracle.V2_SUM)
         got = list(zip(sk["out_hash"][lo:hi].tolist(), sk["pos"][lo:hi].tolist(), sk["forward"][lo:hi].tolist()))
         assert got == [(h, p, f) for h, p, f, _ in want], (rid, k, w)
     return st
@@ -42,7 +42,8 @@ def _check(oracle, recs, k, w, **kw):
 
 @pytest.fixture
 def knobs():
-    saved = {k: os.environ.get(k) for k in ("MXG_SPARSE_BATCH_KMERS", "MXG_DENSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S")}
+    saved = {k: os.environ.get(k) for k in ("MXG_SPARSE_BATCH_KMERS", "MXG_DENSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S",
+                                             "MXG_RING_SLACK")}
     yield os.environ
     for k, v in saved.items():
         if v is None:
@@ -68,6 +69,30 @@ def test_arena_overflow_retry(oracle, knobs):
     knobs["MXG_SPARSE_S"] = "128"
     st = _check(oracle, _records(3), 32, 200)
     assert st["candidates"] > 0
+
+
+def test_large_arena_slices_hash_per_entry(oracle, knobs):
+    knobs["MXG_WAVE_CAP"] = "9000"   # beyond the LDS queue of k_reorder: the one-thread-per-entry path
+    knobs["MXG_SPARSE_S"] = "256"
+    st = _check(oracle, _records(5), 32, 200)
+    assert st["candidates"] > 0
+
+
+@pytest.mark.parametrize("slack", ["7", "60", "400"])
+def test_ring_filter_false_positives_are_absent(oracle, knobs, slack):
+    """The sparse kernel decides "hash < tau" on the top 31 bits of the two strand hashes and cannot see the carry out
+    of the low 33 bits: a captured k-mer can turn out >= tau (about one in 10^9).  MXG_RING_SLACK widens the ring
+    threshold so that 7 % / 60 % / 400 % more k-mers are captured than are candidates: k_resolve must treat every one
+    of them as absent (never selected, never blocking, stepped over by the stretch detection), with and without
+    candidate-free stretches."""
+    knobs["MXG_SPARSE_BATCH_KMERS"] = "60000"
+    base = _check(oracle, _records(6), 32, 200)["candidates"]
+    knobs["MXG_RING_SLACK"] = slack
+    st = _check(oracle, _records(6), 32, 200)
+    assert st["candidates"] > base * (1 + int(slack) / 100) * 0.9   # the captured-but-absent entries are really there
+    st = _check(oracle, _records(7), 32, 500, cand_per_window=2)   # few real candidates: stretches between absent entries
+    assert st["dense_kmers"] > 0
+    _check(oracle, _records(8), 21, 300, cand_per_window=4, variant="v1")  # min(fwd,rev): the ring test is exact here
 
 
 def test_gaps_in_several_batches(oracle, knobs):
