@@ -115,7 +115,10 @@ def main():
     ref, tgt = synth.config2(seed=1 + 100 * rank, n_bases=n_bases)
     bases_rank = sum(len(c) for c in ref) + sum(len(c) for c in tgt)
     keep = []
-    eng = MxEngine(k=K, w=W, device=local_rank, timing=True, cand_per_window=args.cand)
+    # N > 1: the library works on the stream the collectives are issued on, so pack -> all-gather -> unpack need no host sync
+    xstream = torch.cuda.Stream() if (world > 1 or force_dist) else None
+    eng = MxEngine(k=K, w=W, device=local_rank, timing=True, cand_per_window=args.cand,
+                   stream=xstream.cuda_stream if xstream is not None else None)
     for name, weight, recs in (("ref.fa.k32.w1000.tsv", 2.0, ref), ("tgt.fa.k32.w1000.tsv", 1.0, tgt)):
         words, starts, lens = synth.pack_records(recs)
         d = torch.from_numpy(words.view(np.int32)).cuda()  # bases resident in HBM before the timed region
@@ -127,7 +130,7 @@ def main():
         nonlocal union
         eng.sketch(-2)  # MXG_SKETCH_ALL: both assemblies enqueued back to back, one host sync
         if world > 1 or force_dist:
-            union = allgather_union_graph(eng, K, W, local_rank, union)
+            union = allgather_union_graph(eng, K, W, local_rank, union, stream=xstream)
         else:
             eng.build_graph()
 

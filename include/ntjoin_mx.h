@@ -159,6 +159,10 @@ int mxg_add_assembly_packed_device(mxg_handle *h, const char *name, double weigh
                                    const char *const *ids, uint64_t n_records);
 /* A sketch computed elsewhere: an indexlr TSV (`id \t hash:pos[:seq] ...`), parsed as read_minimizers does. */
 int mxg_add_assembly_tsv(mxg_handle *h, const char *name, double weight, const char *tsv_path);
+/* ... or the binary side-car mxg_write_sketch_bin left next to the TSV (the reference re-parses ~65
+   bytes of text per minimizer in read_minimizers, bin/ntjoin_utils.py:167-193; the side-car is 12 bytes of raw arrays
+   per minimizer).  Fails with MXG_EINVAL when the file was written with another k or hash variant. */
+int mxg_add_assembly_bin(mxg_handle *h, const char *name, double weight, const char *bin_path);
 /* ... or arrays (sorted by record, then pos); record_ids has n_records entries. */
 int mxg_add_assembly_minimizers(mxg_handle *h, const char *name, double weight, const uint64_t *out_hash,
                                 const uint32_t *pos, const uint32_t *record, uint64_t n,
@@ -195,6 +199,8 @@ int mxg_set_sketch_gathered(mxg_handle *h, int assembly, const void *d_allbuf, u
    path "-" = stdout. */
 int mxg_write_tsv(mxg_handle *h, int assembly, const char *path, int with_pos, int with_strand,
                   int with_seq);
+/* the same sketch as raw arrays (record ids, lengths, out_hash, pos): read back by mxg_add_assembly_bin */
+int mxg_write_sketch_bin(mxg_handle *h, int assembly, const char *path);
 
 /* ---- graph stage (replaces read_minimizers' uniqueness, filter_minimizers, build_graph) -------- */
 int mxg_build_graph(mxg_handle *h);

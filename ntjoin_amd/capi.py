@@ -15,7 +15,7 @@ SYMBOLS = [
     "mxg_abi_version", "mxg_create", "mxg_destroy", "mxg_last_error",
     "mxg_add_assembly_fasta", "mxg_add_assembly_fasta_shard", "mxg_shard_range", "mxg_assembly_shard",
     "mxg_add_assembly_buffers", "mxg_add_assembly_packed_device",
-    "mxg_add_assembly_tsv", "mxg_add_assembly_minimizers", "mxg_num_assemblies", "mxg_assembly_name",
+    "mxg_add_assembly_tsv", "mxg_add_assembly_bin", "mxg_write_sketch_bin", "mxg_add_assembly_minimizers", "mxg_num_assemblies", "mxg_assembly_name",
     "mxg_record_id", "mxg_record_length", "mxg_num_records", "mxg_assembly_weight",
     "mxg_sketch", "mxg_get_sketch", "mxg_get_sketch_device", "mxg_compute_strands", "mxg_set_sketch_device",
     "mxg_pack_sketch_device", "mxg_set_sketch_gathered", "mxg_write_tsv",
@@ -138,6 +138,8 @@ def load():
     L.mxg_build_graph.argtypes = [vp]
     L.mxg_get_mx_flags.argtypes = [vp, i32, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(u64)]
     L.mxg_get_graph.argtypes = [vp, C.POINTER(GraphView)]
+    L.mxg_add_assembly_bin.argtypes = [vp, cp, C.c_double, cp]
+    L.mxg_write_sketch_bin.argtypes = [vp, i32, cp]
     L.mxg_find_paths.argtypes = [vp, C.c_int64, C.POINTER(PathsView)]
     L.mxg_write_dot.argtypes = [vp, cp]
     L.mxg_py_repr_double.argtypes = [C.c_double, C.c_char_p, C.c_size_t]

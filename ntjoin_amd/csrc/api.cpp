@@ -255,6 +255,23 @@ int mxg_add_assembly_tsv(mxg_handle *h, const char *name, double weight, const c
     return commit(h, a, rc);
 }
 
+int mxg_add_assembly_bin(mxg_handle *h, const char *name, double weight, const char *bin_path)
+{
+    Assembly *a;
+    int rc = new_assembly(h, name, weight, &a);
+    if (rc != MXG_OK) return rc;
+    if (!bin_path) return commit(h, a, set_err(h, MXG_EINVAL, "bin_path is NULL"));
+    std::vector<uint64_t> hash;
+    std::vector<uint32_t> pos, rec;
+    try {
+        rc = load_sketch_bin(h, a, bin_path, hash, pos, rec);
+        if (rc == MXG_OK) rc = adopt_host_sketch(h, a, hash, pos, rec);
+    } catch (const std::bad_alloc &) {
+        rc = set_err(h, MXG_ENOMEM, "out of host memory reading '%s'", bin_path);
+    }
+    return commit(h, a, rc);
+}
+
 int mxg_add_assembly_minimizers(mxg_handle *h, const char *name, double weight, const uint64_t *out_hash,
                                 const uint32_t *pos, const uint32_t *record, uint64_t n,
                                 const char *const *record_ids, uint64_t n_records)
@@ -436,6 +453,17 @@ int mxg_write_tsv(mxg_handle *h, int assembly, const char *path, int with_pos, i
         return write_tsv(h, a, path, with_pos, with_strand, with_seq);
     } catch (const std::bad_alloc &) {
         return set_err(h, MXG_ENOMEM, "out of host memory in mxg_write_tsv");
+    }
+}
+
+int mxg_write_sketch_bin(mxg_handle *h, int assembly, const char *path)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !path) return MXG_EINVAL;
+    try {
+        return write_sketch_bin(h, a, path);
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_write_sketch_bin");
     }
 }
 

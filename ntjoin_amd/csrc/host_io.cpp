@@ -654,4 +654,87 @@ int write_dot(mxg_handle *h, const char *path)
     return MXG_OK;
 }
 
+// ---- binary side-car of a sketch -------------------------------------------------------------------
+// The TSV stays the interchange / checkpoint format (ntJoin:202 .SECONDARY); next to it the library can leave the same
+// sketch as raw arrays, so that a later run (or the Python side) does not parse 65 bytes of text per minimizer again.
+// Layout (little endian): magic "MXGSKB1\0"; u32 k, w, variant, 0; u64 n_records, n_mx, id_bytes;
+// u64 record_len[n_records]; u64 record_first[n_records + 1]; char ids[id_bytes] ('\n'-terminated, in record order);
+// padding to 8; u64 out_hash[n_mx]; u32 pos[n_mx].
+static const char SKB_MAGIC[8] = {'M', 'X', 'G', 'S', 'K', 'B', '1', '\0'};
+
+int write_sketch_bin(mxg_handle *h, Assembly *a, const char *path)
+{
+    int rc = sync_sketch_to_host(h, a);
+    if (rc != MXG_OK) return rc;
+    FILE *f = fopen(path, "wb");
+    if (!f) return set_err(h, MXG_EIO, "cannot open '%s' for writing", path);
+    const uint64_t nr = a->recs.size(), n = a->n_mx;
+    std::string ids;
+    std::vector<uint64_t> lens(nr);
+    for (uint64_t r = 0; r < nr; ++r) {
+        ids += a->recs[r].id;
+        ids += '\n';
+        lens[r] = a->recs[r].len;
+    }
+    const uint32_t head32[4] = {h->cfg.k, h->cfg.w, h->cfg.variant, 0u};
+    const uint64_t head64[3] = {nr, n, (uint64_t)ids.size()};
+    const char pad[8] = {0};
+    bool ok = fwrite(SKB_MAGIC, 1, 8, f) == 8 && fwrite(head32, 4, 4, f) == 4 && fwrite(head64, 8, 3, f) == 3;
+    ok = ok && (nr == 0 || fwrite(lens.data(), 8, nr, f) == nr);
+    ok = ok && fwrite(a->rec_first.data(), 8, nr + 1, f) == nr + 1;
+    ok = ok && (ids.empty() || fwrite(ids.data(), 1, ids.size(), f) == ids.size());
+    ok = ok && fwrite(pad, 1, (8 - ids.size() % 8) % 8, f) == (8 - ids.size() % 8) % 8;
+    ok = ok && (n == 0 || (fwrite(a->h_hash.data(), 8, n, f) == n && fwrite(a->h_pos.data(), 4, n, f) == n));
+    ok = (fclose(f) == 0) && ok;
+    return ok ? MXG_OK : set_err(h, MXG_EIO, "write error on '%s'", path);
+}
+
+int load_sketch_bin(mxg_handle *h, Assembly *a, const char *path, std::vector<uint64_t> &hash, std::vector<uint32_t> &pos,
+                    std::vector<uint32_t> &rec)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return set_err(h, MXG_EIO, "cannot open '%s'", path);
+    char magic[8];
+    uint32_t head32[4];
+    uint64_t head64[3];
+    int rc = MXG_OK;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, SKB_MAGIC, 8) != 0 || fread(head32, 4, 4, f) != 4 ||
+        fread(head64, 8, 3, f) != 3)
+        rc = set_err(h, MXG_EIO, "'%s' is not a sketch side-car (bad header)", path);
+    else if (head32[0] != h->cfg.k || head32[2] != h->cfg.variant)
+        rc = set_err(h, MXG_EINVAL, "'%s' was written with k=%u variant=%u, this handle has k=%u variant=%u", path, head32[0],
+                     head32[2], h->cfg.k, h->cfg.variant);
+    if (rc != MXG_OK) {
+        fclose(f);
+        return rc;
+    }
+    const uint64_t nr = head64[0], n = head64[1], idb = head64[2];
+    std::vector<uint64_t> lens(nr), first(nr + 1);
+    std::string ids(idb, '\0');
+    hash.resize(n);
+    pos.resize(n);
+    rec.resize(n);
+    bool ok = (nr == 0 || fread(lens.data(), 8, nr, f) == nr) && fread(first.data(), 8, nr + 1, f) == nr + 1 &&
+              (idb == 0 || fread(&ids[0], 1, idb, f) == idb) && fseek(f, (long)((8 - idb % 8) % 8), SEEK_CUR) == 0 &&
+              (n == 0 || (fread(hash.data(), 8, n, f) == n && fread(pos.data(), 4, n, f) == n));
+    fclose(f);
+    if (!ok || first[0] != 0 || first[nr] != n) return set_err(h, MXG_EIO, "'%s' is truncated or inconsistent", path);
+    // like the TSV route (read_minimizers skips lines without minimizers, bin/ntjoin_utils.py:176), records without
+    // minimizers do not enter the record table
+    size_t at = 0;
+    for (uint64_t r = 0; r < nr; ++r) {
+        const size_t e = ids.find('\n', at);
+        if (e == std::string::npos || first[r + 1] < first[r]) return set_err(h, MXG_EIO, "'%s': bad record table", path);
+        if (first[r + 1] > first[r]) {
+            Record rc_;
+            rc_.id = ids.substr(at, e - at);
+            rc_.len = lens[r];
+            for (uint64_t i = first[r]; i < first[r + 1]; ++i) rec[i] = (uint32_t)a->recs.size();
+            a->recs.push_back(rc_);
+        }
+        at = e + 1;
+    }
+    return MXG_OK;
+}
+
 }  // namespace mxg

@@ -221,6 +221,9 @@ void make_init_tab(uint32_t k, std::vector<uint4> &out);
 int sketch_assembly(mxg_handle *h, Assembly *a);
 int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n);
 int sync_sketch_to_host(mxg_handle *h, Assembly *a);
+int write_sketch_bin(mxg_handle *h, Assembly *a, const char *path);  // host_io.cpp
+int load_sketch_bin(mxg_handle *h, Assembly *a, const char *path, std::vector<uint64_t> &hash, std::vector<uint32_t> &pos,
+                    std::vector<uint32_t> &rec);
 int ensure_strand(mxg_handle *h, Assembly *a);
 int pack_sketch(mxg_handle *h, Assembly *a, void *d_buf, uint64_t nmax);
 int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t world, uint64_t nmax,

@@ -1816,7 +1816,9 @@ int pack_sketch(mxg_handle *h, Assembly *a, void *d_buf, uint64_t nmax)
                            a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(), a->d_rec.as<uint32_t>(), a->n_mx, nmax,
                            static_cast<unsigned char *>(d_buf));
     MXG_HIP(h, hipGetLastError());
-    MXG_HIP(h, hipStreamSynchronize(h->stream));  // the caller hands the buffer to a collective on another stream
+    // a handle with its own stream syncs: the caller hands the buffer to a collective on some other stream.  A handle
+    // created on the CALLER's stream (mxg_config.stream) leaves the ordering to that stream.
+    if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));
     return MXG_OK;
 }
 

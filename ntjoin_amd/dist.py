@@ -90,21 +90,43 @@ def shard_records(lengths, world):
     return [sorted(x) for x in out]
 
 
-def allgather_union_graph(eng, k, w, device, union=None, group=None):
+def allgather_union_graph(eng, k, w, device, union=None, group=None, stream=None):
     """The exchange step + graph of the union.  Per step: ONE small all-gather with every assembly's (count, records)
     and ONE all-gather per assembly of its packed sketch (16 B per minimizer: out_hash, pos, record); packing and
     unpacking (rank-order concatenation, record-index shift) are library kernels (mxg_pack_sketch_device /
-    mxg_set_sketch_gathered).  `union` (an MxEngine holding the union's record tables) is created on first use."""
+    mxg_set_sketch_gathered).  `union` (an MxEngine holding the union's record tables) is created on first use.
+    `stream`: the torch.cuda.Stream that `eng` was created on (MxEngine(stream=stream.cuda_stream)); pack, collectives
+    and unpack are then ordered by that stream and the only host sync of the exchange is the size read-back."""
+    from .engine import MxEngine
+    if stream is not None:
+        with torch.cuda.stream(stream):
+            return _allgather_union_graph(eng, k, w, device, union, group, stream)
+    return _allgather_union_graph(eng, k, w, device, union, group, None)
+
+
+def _allgather_union_graph(eng, k, w, device, union, group, stream):
     from .engine import MxEngine
     A = eng.n_assemblies
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", device)
-    meta = torch.tensor([[eng.sketch_size(a), eng.n_records(a)] for a in range(A)], dtype=torch.int64, device=dev)
-    metas = torch.empty((world, A, 2), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(metas.view(-1), meta.view(-1), group=group)
-    metas = metas.cpu().numpy()  # the one host sync of the exchange: sizes of what follows
+    # sizes of what follows: (count, records) per assembly from every rank.  Staged through pinned host tensors kept on
+    # the engine (a fresh torch.tensor(list, device=...) alone costs ~50 us per step).
+    xm = getattr(eng, "_xmeta", None)
+    if xm is None or xm[0].shape[0] != A or xm[2].shape[0] != world:
+        xm = (torch.empty((A, 2), dtype=torch.int64).pin_memory(), torch.empty((A, 2), dtype=torch.int64, device=dev),
+              torch.empty((world, A, 2), dtype=torch.int64, device=dev), torch.empty((world, A, 2), dtype=torch.int64).pin_memory())
+        eng._xmeta = xm
+    meta_h, meta, metas_d, metas_h = xm
+    mh = meta_h.numpy()
+    for a in range(A):
+        mh[a, 0], mh[a, 1] = eng.sketch_size(a), eng.n_records(a)
+    meta.copy_(meta_h, non_blocking=True)
+    dist.all_gather_into_tensor(metas_d.view(-1), meta.view(-1), group=group)
+    metas_h.copy_(metas_d, non_blocking=True)
+    torch.cuda.current_stream().synchronize()  # the one host sync of the exchange
+    metas = metas_h.numpy().copy()
     if union is None:
-        union = MxEngine(k=k, w=w, device=device, timing=True)
+        union = MxEngine(k=k, w=w, device=device, timing=True, stream=stream.cuda_stream if stream is not None else None)
         for a in range(A):
             ids_local = [f"r{rank}:{x}" for x in eng.record_ids(a, eng.n_records(a))]
             all_ids = [None] * world
@@ -126,7 +148,8 @@ def allgather_union_graph(eng, k, w, device, union=None, group=None):
         send, recv = bufs[0][:16 * nmax], bufs[1][:world * 16 * nmax]
         eng.pack_sketch_device(a, send.data_ptr(), nmax)
         dist.all_gather_into_tensor(recv, send, group=group)
-        torch.cuda.current_stream().synchronize()
+        if stream is None:
+            torch.cuda.current_stream().synchronize()  # the union handle works on its own stream
         union.set_sketch_gathered(a, recv.data_ptr(), nmax, counts, rec_off)
     union.build_graph()
     return union

@@ -121,6 +121,19 @@ class MxEngine:
         return self._check(self._lib.mxg_add_assembly_tsv(self._h, str(name).encode(), float(weight),
                                                           str(tsv_path).encode()))
 
+    def add_bin(self, name, weight, bin_path):
+        """a sketch from the binary side-car written by write_sketch_bin (no text parsing)"""
+        rc = self._lib.mxg_add_assembly_bin(self._h, str(name).encode(), float(weight), str(bin_path).encode())
+        if rc < 0:
+            msg = (self._lib.mxg_last_error(self._h) or b"").decode()
+            if "cannot open" in msg:
+                raise FileNotFoundError(msg)
+            raise MxError(rc, msg)
+        return rc
+
+    def write_sketch_bin(self, a, path):
+        self._check(self._lib.mxg_write_sketch_bin(self._h, int(a), str(path).encode()))
+
     def add_minimizers(self, name, weight, out_hash, pos, record, record_ids):
         hh = np.ascontiguousarray(out_hash, dtype=np.uint64)
         pp = np.ascontiguousarray(pos, dtype=np.uint32)
@@ -145,6 +158,9 @@ class MxEngine:
 
     def record_ids(self, a, n_records):
         return [self._lib.mxg_record_id(self._h, a, r).decode() for r in range(int(n_records))]
+
+    def record_lengths(self, a):
+        return [int(self._lib.mxg_record_length(self._h, int(a), r)) for r in range(self.n_records(a))]
 
     # -- sketch stage -------------------------------------------------------------------------------------
     def sketch(self, assembly=-1):
