@@ -226,6 +226,22 @@ typedef struct mxg_paths_view {
 } mxg_paths_view;
 int mxg_find_paths(mxg_handle *h, int64_t min_edge_weight /* ntJoin's n */, mxg_paths_view *out);
 
+/* ---- next row: what the scaffolder derives from the paths for one assembly (the target) ------------
+   mxg_mx_extremes   = find_mx_min_max (bin/ntjoin_assemble.py:688-702): per record of the assembly, the smallest and
+                       largest position among its minimizers that are graph vertices (no vertex: min = 2^32-1, max = 0).
+   mxg_path_segments = the grouping loop of format_path (bin/ntjoin_assemble.py:175-218): every path of the last
+                       mxg_find_paths is cut into runs of consecutive vertices lying on the same record of `assembly`;
+                       per run what determine_orientation (:30-50) and calc_start/end_coord (:52-65) need. */
+typedef struct mxg_segments_view {
+    uint64_t n_segments;             /* in path order, then position in the path                                  */
+    const uint32_t *seg_path;        /* index into mxg_paths_view                                                 */
+    const uint32_t *seg_record;      /* record (contig) of the assembly                                           */
+    const uint32_t *seg_first;       /* offset of the run's first vertex in mxg_paths_view.path_vertex            */
+    const uint32_t *seg_stat;        /* 5 per run: vertices, min pos, max pos, increasing pairs, decreasing pairs */
+} mxg_segments_view;
+int mxg_path_segments(mxg_handle *h, int assembly, mxg_segments_view *out);
+int mxg_mx_extremes(mxg_handle *h, int assembly, const uint32_t **min_pos, const uint32_t **max_pos, uint64_t *n_records);
+
 /* ---- text helpers used by the writers (host only; usable without a device) --------------------- */
 /* python repr() of a float / of a str, as Ntjoin.print_graph's f-strings produce them.  Returns the length
    written (excluding the NUL), or the length needed if it exceeds cap. */

@@ -19,7 +19,7 @@ SYMBOLS = [
     "mxg_record_id", "mxg_record_length", "mxg_num_records", "mxg_assembly_weight",
     "mxg_sketch", "mxg_get_sketch", "mxg_get_sketch_device", "mxg_compute_strands", "mxg_set_sketch_device",
     "mxg_pack_sketch_device", "mxg_set_sketch_gathered", "mxg_write_tsv",
-    "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_write_dot",
+    "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_path_segments", "mxg_mx_extremes", "mxg_write_dot",
     "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers",
 ]
 
@@ -52,6 +52,11 @@ class GraphView(C.Structure):
 class PathsView(C.Structure):
     _fields_ = [("n_components", C.c_uint64), ("n_paths", C.c_uint64), ("path_first", C.POINTER(C.c_uint64)), ("path_vertex", C.POINTER(C.c_uint32)),
                 ("path_component", C.POINTER(C.c_uint32))]
+
+
+class SegmentsView(C.Structure):
+    _fields_ = [("n_segments", C.c_uint64), ("seg_path", C.POINTER(C.c_uint32)), ("seg_record", C.POINTER(C.c_uint32)),
+                ("seg_first", C.POINTER(C.c_uint32)), ("seg_stat", C.POINTER(C.c_uint32))]
 
 
 class Stats(C.Structure):
@@ -141,6 +146,9 @@ def load():
     L.mxg_add_assembly_bin.argtypes = [vp, cp, C.c_double, cp]
     L.mxg_write_sketch_bin.argtypes = [vp, i32, cp]
     L.mxg_find_paths.argtypes = [vp, C.c_int64, C.POINTER(PathsView)]
+    L.mxg_path_segments.argtypes = [vp, i32, C.POINTER(SegmentsView)]
+    L.mxg_mx_extremes.argtypes = [vp, i32, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)),
+                                  C.POINTER(C.c_uint64)]
     L.mxg_write_dot.argtypes = [vp, cp]
     L.mxg_py_repr_double.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
     L.mxg_py_repr_double.restype = C.c_size_t

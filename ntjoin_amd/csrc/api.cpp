@@ -525,6 +525,39 @@ int mxg_find_paths(mxg_handle *h, int64_t min_edge_weight, mxg_paths_view *out)
     return MXG_OK;
 }
 
+int mxg_path_segments(mxg_handle *h, int assembly, mxg_segments_view *out)
+{
+    if (!h || !out || assembly < 0) return MXG_EINVAL;
+    try {
+        int rc = path_segments(h, (uint32_t)assembly);
+        if (rc != MXG_OK) return rc;
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_path_segments");
+    }
+    const Segments &S = h->segs;
+    out->n_segments = S.path.size();
+    out->seg_path = S.path.data();
+    out->seg_record = S.record.data();
+    out->seg_first = S.first.data();
+    out->seg_stat = S.stat.data();
+    return MXG_OK;
+}
+
+int mxg_mx_extremes(mxg_handle *h, int assembly, const uint32_t **min_pos, const uint32_t **max_pos, uint64_t *n_records)
+{
+    if (!h || !min_pos || !max_pos || !n_records || assembly < 0) return MXG_EINVAL;
+    try {
+        int rc = mx_extremes(h, (uint32_t)assembly);
+        if (rc != MXG_OK) return rc;
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_mx_extremes");
+    }
+    *min_pos = h->segs.ext_min.data();
+    *max_pos = h->segs.ext_max.data();
+    *n_records = h->segs.ext_min.size();
+    return MXG_OK;
+}
+
 int mxg_write_dot(mxg_handle *h, const char *path)
 {
     if (!h || !path) return MXG_EINVAL;

@@ -133,6 +133,12 @@ struct Paths {  // result of mxg_find_paths (host copies)
     std::vector<uint32_t> component;  // [n_paths] component (root vertex index) of the globally filtered graph
 };
 
+struct Segments {  // results of mxg_path_segments / mxg_mx_extremes (host copies)
+    std::vector<uint32_t> path, record, first;  // per segment
+    std::vector<uint32_t> stat;                 // per segment: n, min pos, max pos, increasing pairs, decreasing pairs
+    std::vector<uint32_t> ext_min, ext_max;     // per record of the assembly last asked for
+};
+
 struct Timers {
     double ms_hash = 0, ms_resolve = 0, ms_graph = 0;
     uint64_t launches_hash = 0, hash_bases = 0;
@@ -162,7 +168,8 @@ struct mxg_handle {
     size_t ev_used = 0;
     std::vector<mxg::TimedSpan> ev_spans;  // not yet folded into tm
     mxg::Paths paths;
-    mxg::DevBuf pbuf[32];  // scratch of paths.hip
+    mxg::DevBuf pbuf[48];  // scratch of paths.hip
+    mxg::Segments segs;
     mxg::Timers tm;
     mxg::HashTab tab{};
     mxg::DevBuf d_init_tab;  // byte table of the direct hash formula (256 x 16 B), built by the first sketch
@@ -232,6 +239,8 @@ int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t w
 int build_graph(mxg_handle *h);
 int graph_to_host(mxg_handle *h);
 int find_paths(mxg_handle *h, int64_t n_min);  // paths.hip
+int path_segments(mxg_handle *h, uint32_t assembly);
+int mx_extremes(mxg_handle *h, uint32_t assembly);
 int flush_timers(mxg_handle *h);                // sketch.hip: fold the recorded event pairs into h->tm
 int flags_to_host(mxg_handle *h, Assembly *a);
 

@@ -21,6 +21,11 @@
 namespace mxg {
 
 static constexpr uint32_t NIL = 0xFFFFFFFFu;
+// scratch buffers of this file (mxg_handle::pbuf); PV / PF / PC keep the paths on the device after find_paths
+enum { ALIVE, COMP, SUB, DEG, NONLIN, FLAG, CNTV, CNTE, CNTD1, MAXDEG, FILL, NB, NBE, KEY0, KEY1, KEY2, SUCC0, CNT0, END0,
+       SUCC1, CNT1, END1, SIZE, ISSRC, FIRST, RANK, BSUM, TOTAL, PV, PF, PC, SG_FLAG, SG_EXCL, SG_FIRST, SG_REC, SG_PATH,
+       SG_STAT, XT_MIN, XT_MAX, PBUF_COUNT };
+static_assert(PBUF_COUNT <= 48, "mxg_handle::pbuf too small");
 
 __device__ __forceinline__ uint32_t find_root(uint32_t *parent, uint32_t v)
 {
@@ -381,8 +386,6 @@ int find_paths(mxg_handle *h, int64_t n_min)
     const uint32_t *pos_last = h->g_vpos.as<uint32_t>() + (size_t)last_max * g.nv_stride;
 
     DevBuf *B = h->pbuf;  // scratch of this stage
-    enum { ALIVE, COMP, SUB, DEG, NONLIN, FLAG, CNTV, CNTE, CNTD1, MAXDEG, FILL, NB, NBE, KEY0, KEY1, KEY2, SUCC0, CNT0, END0,
-           SUCC1, CNT1, END1, SIZE, ISSRC, FIRST, RANK, BSUM, TOTAL, PV, PF, PC };
     const size_t ne1 = std::max<uint32_t>(ne, 1);
     MXG_HIP(h, B[ALIVE].ensure(ne1));
     MXG_HIP(h, B[COMP].ensure((size_t)nv * 4));
@@ -507,6 +510,161 @@ int find_paths(mxg_handle *h, int64_t n_min)
     P.first[n_paths] = n_pv;
     P.n_components = n_comp;
     P.valid = true;
+    return MXG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// row f4: what the scaffolder derives from the paths for one assembly
+//   find_mx_min_max   reference bin/ntjoin_assemble.py:688-702   per contig: min / max position over its graph vertices
+//   format_path       reference bin/ntjoin_assemble.py:175-218   runs of path vertices on the same contig ("segments")
+//                     with what determine_orientation (:30-50) and calc_start/end_coord (:52-65) need of each run:
+//                     number of vertices, min / max position, number of increasing / decreasing consecutive pairs
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kx_extremes(const uint32_t *__restrict__ vrec, const uint32_t *__restrict__ vpos,
+                                                   uint32_t nv, uint32_t *mn, uint32_t *mx)
+{
+    uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v >= nv) return;
+    atomicMin(&mn[vrec[v]], vpos[v]);
+    atomicMax(&mx[vrec[v]], vpos[v]);
+}
+
+__global__ __launch_bounds__(256) void ks_mark_starts(const uint64_t *__restrict__ path_first, uint32_t n_paths, uint32_t *flag)
+{
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p < n_paths) flag[path_first[p]] = 1;
+}
+
+// flag[i] = 1 where a segment starts: a path starts there, or the contig differs from the previous path vertex's
+__global__ __launch_bounds__(256) void ks_flags(const uint32_t *__restrict__ pv, uint32_t n, const uint32_t *__restrict__ vrec,
+                                                uint32_t *flag)
+{
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0 || vrec[pv[i]] != vrec[pv[i - 1]]) flag[i] = 1;
+}
+
+__global__ __launch_bounds__(256) void ks_heads(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ excl, uint32_t n,
+                                                const uint32_t *__restrict__ pv, const uint32_t *__restrict__ vrec,
+                                                const uint64_t *__restrict__ path_first, uint32_t n_paths,
+                                                uint32_t *seg_first, uint32_t *seg_rec, uint32_t *seg_path)
+{
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const uint32_t s = excl[i];
+    seg_first[s] = i;
+    seg_rec[s] = vrec[pv[i]];
+    uint32_t lo = 0, hi = n_paths;  // last path with path_first <= i
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (path_first[mid] <= i) lo = mid; else hi = mid;
+    }
+    seg_path[s] = lo;
+}
+
+// one wave per segment: {n, min pos, max pos, increasing pairs, decreasing pairs}
+__global__ __launch_bounds__(256) void ks_stats(const uint32_t *__restrict__ seg_first, uint32_t n_seg, uint32_t n,
+                                                const uint32_t *__restrict__ pv, const uint32_t *__restrict__ vpos,
+                                                uint32_t *stat)
+{
+    const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (s >= n_seg) return;
+    const uint32_t lo = seg_first[s], hi = s + 1 < n_seg ? seg_first[s + 1] : n;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0, inc = 0, dec = 0;
+    for (uint32_t i = lo + lane; i < hi; i += 64) {
+        const uint32_t p = vpos[pv[i]];
+        mn = min(mn, p);
+        mx = max(mx, p);
+        if (i + 1 < hi) {
+            const uint32_t q = vpos[pv[i + 1]];
+            inc += p < q;
+            dec += p > q;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        inc += (uint32_t)__shfl_xor((int)inc, o, 64);
+        dec += (uint32_t)__shfl_xor((int)dec, o, 64);
+    }
+    if (lane == 0) {
+        uint32_t *o = stat + (size_t)s * 5;
+        o[0] = hi - lo; o[1] = mn; o[2] = mx; o[3] = inc; o[4] = dec;
+    }
+}
+
+int mx_extremes(mxg_handle *h, uint32_t a)
+{
+    Graph &g = h->graph;
+    if (!g.valid) return set_err(h, MXG_EINVAL, "mxg_mx_extremes: call mxg_build_graph first");
+    if (a >= g.n_asm) return set_err(h, MXG_EINVAL, "assembly index %u out of range", a);
+    MXG_HIP(h, hipSetDevice(h->device));
+    const size_t nr = h->asms[a]->recs.size();
+    Segments &S = h->segs;
+    S.ext_min.assign(nr, 0xFFFFFFFFu);
+    S.ext_max.assign(nr, 0u);
+    if (nr == 0 || g.nv == 0) return MXG_OK;
+    DevBuf *B = h->pbuf;
+    MXG_HIP(h, B[XT_MIN].ensure(nr * 4));
+    MXG_HIP(h, B[XT_MAX].ensure(nr * 4));
+    MXG_HIP(h, hipMemsetAsync(B[XT_MIN].p, 0xFF, nr * 4, h->stream));
+    MXG_HIP(h, hipMemsetAsync(B[XT_MAX].p, 0, nr * 4, h->stream));
+    const uint32_t nv = (uint32_t)g.nv;
+    hipLaunchKernelGGL(kx_extremes, dim3((nv + 255) / 256), dim3(256), 0, h->stream,
+                       h->g_vrec.as<uint32_t>() + (size_t)a * g.nv_stride, h->g_vpos.as<uint32_t>() + (size_t)a * g.nv_stride, nv,
+                       B[XT_MIN].as<uint32_t>(), B[XT_MAX].as<uint32_t>());
+    MXG_HIP(h, hipGetLastError());
+    MXG_HIP(h, hipMemcpyAsync(S.ext_min.data(), B[XT_MIN].p, nr * 4, hipMemcpyDeviceToHost, h->stream));
+    MXG_HIP(h, hipMemcpyAsync(S.ext_max.data(), B[XT_MAX].p, nr * 4, hipMemcpyDeviceToHost, h->stream));
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    return MXG_OK;
+}
+
+int path_segments(mxg_handle *h, uint32_t a)
+{
+    Graph &g = h->graph;
+    const Paths &P = h->paths;
+    if (!g.valid || !P.valid) return set_err(h, MXG_EINVAL, "mxg_path_segments: call mxg_find_paths first");
+    if (a >= g.n_asm) return set_err(h, MXG_EINVAL, "assembly index %u out of range", a);
+    MXG_HIP(h, hipSetDevice(h->device));
+    Segments &S = h->segs;
+    S.path.clear(); S.record.clear(); S.first.clear(); S.stat.clear();
+    const uint32_t n = (uint32_t)P.vertex.size(), n_paths = (uint32_t)P.component.size();
+    if (n == 0) return MXG_OK;
+    DevBuf *B = h->pbuf;
+    const uint32_t *pv = B[PV].as<uint32_t>();
+    const uint64_t *pf = B[PF].as<uint64_t>();
+    const uint32_t *vrec = h->g_vrec.as<uint32_t>() + (size_t)a * g.nv_stride;
+    const uint32_t *vpos = h->g_vpos.as<uint32_t>() + (size_t)a * g.nv_stride;
+    MXG_HIP(h, B[SG_FLAG].ensure((size_t)n * 4 + 16));
+    MXG_HIP(h, B[SG_EXCL].ensure((size_t)n * 4 + 16));
+    MXG_HIP(h, B[TOTAL].ensure(64));
+    MXG_HIP(h, hipMemsetAsync(B[SG_FLAG].p, 0, (size_t)n * 4, h->stream));
+    const dim3 gn((n + 255) / 256), b(256);
+    hipLaunchKernelGGL(ks_mark_starts, dim3((n_paths + 255) / 256), b, 0, h->stream, pf, n_paths, B[SG_FLAG].as<uint32_t>());
+    hipLaunchKernelGGL(ks_flags, gn, b, 0, h->stream, pv, n, vrec, B[SG_FLAG].as<uint32_t>());
+    int rc = exclusive_scan_u32(h, B[SG_FLAG].as<uint32_t>(), n, B[BSUM], B[SG_EXCL].as<uint32_t>(), B[TOTAL].as<uint64_t>());
+    if (rc != MXG_OK) return rc;
+    uint64_t n_seg64 = 0;
+    MXG_HIP(h, hipMemcpyAsync(&n_seg64, B[TOTAL].p, 8, hipMemcpyDeviceToHost, h->stream));
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    const uint32_t n_seg = (uint32_t)n_seg64;
+    MXG_HIP(h, B[SG_FIRST].ensure((size_t)n_seg * 4 + 16));
+    MXG_HIP(h, B[SG_REC].ensure((size_t)n_seg * 4 + 16));
+    MXG_HIP(h, B[SG_PATH].ensure((size_t)n_seg * 4 + 16));
+    MXG_HIP(h, B[SG_STAT].ensure((size_t)n_seg * 20 + 16));
+    hipLaunchKernelGGL(ks_heads, gn, b, 0, h->stream, B[SG_FLAG].as<uint32_t>(), B[SG_EXCL].as<uint32_t>(), n, pv, vrec, pf,
+                       n_paths, B[SG_FIRST].as<uint32_t>(), B[SG_REC].as<uint32_t>(), B[SG_PATH].as<uint32_t>());
+    hipLaunchKernelGGL(ks_stats, dim3((n_seg + 3) / 4), b, 0, h->stream, B[SG_FIRST].as<uint32_t>(), n_seg, n, pv, vpos,
+                       B[SG_STAT].as<uint32_t>());
+    MXG_HIP(h, hipGetLastError());
+    S.path.resize(n_seg); S.record.resize(n_seg); S.first.resize(n_seg); S.stat.resize((size_t)n_seg * 5);
+    MXG_HIP(h, hipMemcpyAsync(S.path.data(), B[SG_PATH].p, (size_t)n_seg * 4, hipMemcpyDeviceToHost, h->stream));
+    MXG_HIP(h, hipMemcpyAsync(S.record.data(), B[SG_REC].p, (size_t)n_seg * 4, hipMemcpyDeviceToHost, h->stream));
+    MXG_HIP(h, hipMemcpyAsync(S.first.data(), B[SG_FIRST].p, (size_t)n_seg * 4, hipMemcpyDeviceToHost, h->stream));
+    MXG_HIP(h, hipMemcpyAsync(S.stat.data(), B[SG_STAT].p, (size_t)n_seg * 20, hipMemcpyDeviceToHost, h->stream));
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
     return MXG_OK;
 }
 

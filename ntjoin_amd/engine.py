@@ -240,6 +240,24 @@ class MxEngine:
         self.n_components = int(v.n_components)
         return [(int(comp[i]), verts[int(first[i]):int(first[i + 1])].tolist()) for i in range(npaths)]
 
+    def path_segments(self, a):
+        """runs of consecutive path vertices on the same record of assembly a (after find_paths): dict of arrays
+        path, record, first (offset into the concatenated paths), n, min_pos, max_pos, inc, dec"""
+        v = capi.SegmentsView()
+        self._check(self._lib.mxg_path_segments(self._h, int(a), C.byref(v)))
+        n = int(v.n_segments)
+        st = _np(v.seg_stat, 5 * n, np.uint32).reshape(n, 5)
+        return {"path": _np(v.seg_path, n, np.uint32), "record": _np(v.seg_record, n, np.uint32),
+                "first": _np(v.seg_first, n, np.uint32), "n": st[:, 0], "min_pos": st[:, 1], "max_pos": st[:, 2],
+                "inc": st[:, 3], "dec": st[:, 4]}
+
+    def mx_extremes(self, a):
+        """per record of assembly a: (min, max) position over its graph vertices; None for records without one"""
+        mn, mx, n = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.c_uint64()
+        self._check(self._lib.mxg_mx_extremes(self._h, int(a), C.byref(mn), C.byref(mx), C.byref(n)))
+        lo, hi = _np(mn, n.value, np.uint32), _np(mx, n.value, np.uint32)
+        return [None if l > h_ else (int(l), int(h_)) for l, h_ in zip(lo.tolist(), hi.tolist())]
+
     def write_dot(self, path):
         self._check(self._lib.mxg_write_dot(self._h, str(path).encode()))
 

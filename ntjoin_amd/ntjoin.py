@@ -102,6 +102,7 @@ class Ntjoin:
         "Finds paths through the minimizer graph (global filter with args.n, branch filtering, linear paths)"
         print(datetime.datetime.today(), ": Finding paths", file=sys.stdout)
         found = self._engine.find_paths(int(getattr(self.args, "n", 1)))
+        self._found = found
         by_comp = {}
         for comp, verts in found:
             by_comp.setdefault(comp, []).append(([self.graph.names[v] for v in verts], None))
@@ -109,6 +110,86 @@ class Ntjoin:
         print("\nTotal number of components in graph:", n_comp, "\n", sep=" ", file=sys.stdout, flush=True)
         # one list per component, as the reference returns (components without an accepted path give [])
         return list(by_comp.values()) + [[] for _ in range(n_comp - len(by_comp))]
+
+    # -- what the scaffolder derives from the paths (reference bin/ntjoin_assemble.py) -----------------------------
+    def find_mx_min_max(self, target):
+        "Given the target assembly, find the min/max position of its graph-vertex minimizers per contig (:688-702)"
+        a = self._order.index(target)
+        ids = self._engine.record_ids(a, self._engine.n_records(a))
+        return {ids[r]: e for r, e in enumerate(self._engine.mx_extremes(a)) if e is not None}
+
+    @staticmethod
+    def determine_orientation(n, inc, dec, m=90):
+        "orientation of a run of n minimizers with inc / dec increasing / decreasing consecutive pairs (:30-50, no --mkt)"
+        if n > 1:
+            if dec == 0 and inc == n - 1:
+                return "+"
+            if inc == 0 and dec == n - 1:
+                return "-"
+            positive = inc / float(n - 1) * 100
+            if positive >= m:
+                return "+"
+            if 100 - positive >= m:
+                return "-"
+        return "?"
+
+    def format_paths(self, lengths=None, g=20, G=0, m=90):
+        """format_path (:175-218) for every path of the last find_paths() and the target assembly: one list per path of
+        [contig, ori, start, end, contig_size, first_mx, terminal_mx, gap_size, raw_gap_size].  The per-minimizer work
+        (grouping by contig, min/max, orientation tallies) is the library's (mxg_path_segments, mxg_mx_extremes); the
+        gap estimate between two oriented runs (calculate_gap_size :68-112) reads a handful of graph entries here."""
+        eng, k = self._engine, int(getattr(self.args, "k", 32))
+        tgt = len(self._order) - 1
+        ids = eng.record_ids(tgt, eng.n_records(tgt))
+        if lengths is None:
+            lengths = dict(zip(ids, eng.record_lengths(tgt)))
+        ext = eng.mx_extremes(tgt)
+        seg = eng.path_segments(tgt)
+        gr = eng.get_graph()
+        vpos, names = gr["vertex_pos"], self.graph.names
+        masks = {(min(u, v), max(u, v)): int(s) for u, v, s in
+                 zip(gr["edge_u"].tolist(), gr["edge_v"].tolist(), gr["edge_support"].tolist())}
+        offsets, at = [], 0
+        for _comp, verts in self._found:
+            offsets.append(at)
+            at += len(verts)
+        out = [[] for _ in self._found]
+        kept = [[] for _ in self._found]
+        cols = [seg[c].tolist() for c in ("path", "record", "first", "n", "min_pos", "max_pos", "inc", "dec")]
+        for p, rec, first, n, mn, mx, inc, dec in zip(*cols):
+            ori = self.determine_orientation(n, inc, dec, m)
+            if ori == "?":
+                continue
+            ctg, verts, lo = ids[rec], self._found[p][1], first - offsets[p]
+            start = 0 if mn == ext[rec][0] else mn
+            end = lengths[ctg] if mx == ext[rec][1] else mx + k
+            out[p].append([ctg, ori, start, end, lengths[ctg], names[verts[lo]], names[verts[lo + n - 1]], 0, 0])
+            kept[p].append((lo, lo + n - 1))
+        for p, nodes in enumerate(out):
+            verts = self._found[p][1]
+            for i in range(len(nodes) - 1):
+                u, v = nodes[i], nodes[i + 1]
+                iu, iv = kept[p][i][1], kept[p][i + 1][0]
+                common = -1
+                for a_, b_ in zip(verts[iu:iv], verts[iu + 1:iv + 1]):
+                    common &= masks[(min(a_, b_), max(a_, b_))]
+                sup = [b for b in range(len(self._order)) if common >> b & 1]
+                if not sup:
+                    u[7], u[8] = g, g
+                    continue
+                um, vm = verts[iu], verts[iv]
+                dists = [abs(int(vpos[b][vm]) - int(vpos[b][um])) for b in sup]
+                mean_dist = int(sum(dists) / len(dists)) - k
+                upos, vpos_t = int(vpos[tgt][um]), int(vpos[tgt][vm])
+                a_over = (u[3] - upos - k) if u[1] == "+" else (upos - u[2])
+                b_over = (vpos_t - v[2]) if v[1] == "+" else (v[3] - vpos_t - k)
+                if a_over < 0 or b_over < 0:
+                    raise ValueError(f"Gap distance estimation less than 0 between {u} and {v}")
+                gap = max(mean_dist - a_over - b_over, g)
+                if G > 0:
+                    gap = min(gap, G)
+                u[7], u[8] = gap, mean_dist - a_over - b_over
+        return out
 
     def print_graph(self, graph, out_prefix=None):
         "Prints the minimizer graph in dot format"

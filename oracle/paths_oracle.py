@@ -114,3 +114,78 @@ def find_paths(state, n):
 def canonical(paths_by_component):
     """order-free form: set of components, each a frozenset of path tuples (components without paths dropped)"""
     return {frozenset(tuple(p) for p in comp) for comp in paths_by_component if comp}
+
+
+# ---- row f4: what the scaffolder derives from a path for the target assembly --------------------------------------
+def mx_extremes(state, target):
+    """find_mx_min_max (reference bin/ntjoin_assemble.py:688-702): contig -> (min, max) position over the target's
+    minimizers that are graph vertices"""
+    out = {}
+    vertices = set(state["vertices"])
+    for mx, (ctg, pos) in state["list_mx_info"][target].items():
+        if mx not in vertices:
+            continue
+        lo, hi = out.get(ctg, (pos, pos))
+        out[ctg] = (min(lo, pos), max(hi, pos))
+    return out
+
+
+def determine_orientation(positions, m=90):
+    """reference bin/ntjoin_assemble.py:30-50 without --mkt"""
+    if len(positions) > 1:
+        pairs = list(zip(positions, positions[1:]))
+        if all(x < y for x, y in pairs):
+            return "+"
+        if all(x > y for x, y in pairs):
+            return "-"
+        positive = sum(1 for x, y in pairs if x < y) / float(len(positions) - 1) * 100
+        if positive >= m:
+            return "+"
+        if 100 - positive >= m:
+            return "-"
+    return "?"
+
+
+def format_path(state, path, target, lengths, k, g=20, G=0, m=90):
+    """format_path + calc_start/end_coord + calculate_gap_size (reference bin/ntjoin_assemble.py:175-218,52-65,68-112):
+    -> [[contig, ori, start, end, contig_size, first_mx, terminal_mx, gap_size, raw_gap_size], ...]"""
+    info = state["list_mx_info"]
+    extremes = mx_extremes(state, target)
+    support = {frozenset((s, t)): sup for s, t, sup, _w in state["edges"]}
+    index = {mx: i for i, mx in enumerate(path)}
+    groups, cur = [], None
+    for mx in path:                                         # runs of minimizers on the same target contig
+        ctg, pos = info[target][mx]
+        if cur is not None and cur["ctg"] == ctg:
+            cur["pos"].append(pos)
+        else:
+            cur = {"ctg": ctg, "pos": [pos], "first": mx}
+            groups.append(cur)
+        cur["last"] = mx
+    nodes = []
+    for grp in groups:
+        ori = determine_orientation(grp["pos"], m)
+        if ori == "?":
+            continue
+        lo, hi = min(grp["pos"]), max(grp["pos"])
+        start = 0 if lo == extremes[grp["ctg"]][0] else lo
+        end = lengths[grp["ctg"]] if hi == extremes[grp["ctg"]][1] else hi + k
+        nodes.append([grp["ctg"], ori, start, end, lengths[grp["ctg"]], grp["first"], grp["last"], 0, 0])
+    for u, v in zip(nodes, nodes[1:]):
+        u_mx, v_mx = u[6], v[5]
+        between = path[index[u_mx]:index[v_mx] + 1]          # the chain IS the shortest path
+        sups = [set(support[frozenset(e)]) for e in zip(between, between[1:])]
+        common = set.intersection(*sups)
+        if not common:
+            u[7], u[8] = g, g
+            continue
+        dists = [abs(info[a][v_mx][1] - info[a][u_mx][1]) for a in common]
+        mean_dist = int(sum(dists) / len(dists)) - k
+        a = (u[3] - info[target][u_mx][1] - k) if u[1] == "+" else (info[target][u_mx][1] - u[2])
+        b = (info[target][v_mx][1] - v[2]) if v[1] == "+" else (v[3] - info[target][v_mx][1] - k)
+        assert a >= 0 and b >= 0
+        gap = max(mean_dist - a - b, g)
+        if G > 0:
+            gap = min(gap, G)
+        u[7], u[8] = gap, mean_dist - a - b
+    return nodes

@@ -42,7 +42,10 @@ class _Seq(list):
             list.__setitem__(self, key, values)
 
     def find(self, name):
-        return next(v for v in self if v["name"] == name)
+        for v in self:
+            if v["name"] == name:
+                return v
+        raise ValueError(f"no such vertex: {name}")
 
 
 class Graph:
@@ -135,7 +138,7 @@ class Graph:
                 g.es.append(_Edge(len(g.es), min(a, b), max(a, b), dict(e)))
         return g
 
-    def get_shortest_paths(self, source, to=None):
+    def get_shortest_paths(self, source, to=None, output="vpath"):
         s, t = self._vid(source), self._vid(to)
         prev, adj, dq = {s: None}, self._adj(), deque([s])
         while dq:

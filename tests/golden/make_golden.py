@@ -62,7 +62,29 @@ def install_igraph_standin():
     igraph_standin.install()
 
 
-def run_reference(case_dir, ref_tsvs, ref_weights, target_tsv, target_weight, prefix):
+def fasta_lengths(path):
+    lens, rid = {}, None
+    with open(path, encoding="ascii") as fh:
+        for line in fh:
+            if line.startswith(">"):
+                rid = line[1:].split()[0]
+                lens[rid] = 0
+            elif rid is not None:
+                lens[rid] += len(line.strip())
+    return lens
+
+
+def import_scaffolder():
+    """bin/ntjoin_assemble.py imports pybedtools, pymannkendall and btllib at module level; none of them is installed
+    here and none is touched by the methods called below (format_path, find_mx_min_max, determine_orientation without
+    --mkt, calc_*_coord, calculate_gap_size), so empty modules stand in for the three names."""
+    for missing in ("pybedtools", "pymannkendall", "btllib"):
+        sys.modules.setdefault(missing, types.ModuleType(missing))
+    import ntjoin_assemble  # noqa: the reference's own module
+    return ntjoin_assemble
+
+
+def run_reference(case_dir, ref_tsvs, ref_weights, target_tsv, target_weight, prefix, k=32, target_fasta=None):
     sys.path.insert(0, os.path.join(REF, "bin"))
     import ntjoin_utils  # noqa: the reference's own module
     import ntjoin        # noqa: the reference's own module
@@ -86,6 +108,16 @@ def run_reference(case_dir, ref_tsvs, ref_weights, target_tsv, target_weight, pr
         # next row: the reference's own global filter + path extraction, for several -n values
         # (reference bin/ntjoin.py:80-89,137-176; called at bin/ntjoin_assemble.py:759,779)
         paths_by_n = {}
+        # row f4: what the reference's scaffolder derives from each path for the TARGET assembly
+        # (bin/ntjoin_assemble.py:688-702 find_mx_min_max, :175-218 format_path incl. determine_orientation :30-50,
+        #  calc_start/end_coord :52-65, calculate_gap_size :68-120), with its default -g 20 -G 0 -m 90 and no --mkt
+        asm_mod = import_scaffolder()
+        sc = object.__new__(asm_mod.NtjoinScaffolder)
+        sc.args = types.SimpleNamespace(k=k, g=20, G=0, m=90, mkt=False, s=args.s)
+        sc.list_mx_info = nj.list_mx_info
+        lens = fasta_lengths(target_fasta)
+        sc.scaffolds = {c: ntjoin_utils.Scaffold(id=c, length=n, sequence="") for c, n in lens.items()}
+        format_by_n, extremes_by_n = {}, {}
         total_w = sum(nj.weights.values())
         for n_min in sorted({1, 2, 3, int(total_w), int(total_w) + 1}):
             nj.args.n = n_min
@@ -93,6 +125,16 @@ def run_reference(case_dir, ref_tsvs, ref_weights, target_tsv, target_weight, pr
             with contextlib.redirect_stdout(io.StringIO()):
                 found = nj.find_paths()
             paths_by_n[str(n_min)] = [[list(path) for path, _sub in comp] for comp in found]
+            sc.graph = nj.graph
+            sc.mx_extremes = sc.find_mx_min_max(args.s)
+            extremes_by_n[str(n_min)] = {c: list(v) for c, v in sc.mx_extremes.items()}
+            formatted = []
+            for comp in found:
+                for path, sub in comp:
+                    nodes = sc.format_path(path, args.s, sub)
+                    formatted.append([[nd.contig, nd.ori, nd.start, nd.end, nd.contig_size, nd.first_mx, nd.terminal_mx,
+                                       nd.gap_size, nd.raw_gap_size] for nd in nodes])
+            format_by_n[str(n_min)] = formatted
         nj.graph = g
         names = [v["name"] for v in g.vs()]
         edges = []
@@ -107,6 +149,9 @@ def run_reference(case_dir, ref_tsvs, ref_weights, target_tsv, target_weight, pr
             "vertices": sorted(names, key=int),
             "edges": edges,
             "paths_by_n": paths_by_n,
+            "mx_extremes_by_n": extremes_by_n,
+            "format_by_n": format_by_n,
+            "format_args": {"g": 20, "G": 0, "m": 90, "mkt": False},
         }
     finally:
         os.chdir(cwd)
@@ -144,7 +189,8 @@ def main():
                                    "--pos", "--seq", "-o", os.path.join(case_dir, tsv), dst])
             tsvs.append(tsv)
         prefix = "out"
-        result = run_reference(case_dir, tsvs[:-1], [wt for _, wt in refs], tsvs[-1], target[1], prefix)
+        result = run_reference(case_dir, tsvs[:-1], [wt for _, wt in refs], tsvs[-1], target[1], prefix, k=k,
+                               target_fasta=os.path.join(fasta_dir, target[0]))
         os.replace(os.path.join(case_dir, prefix + ".mx.dot"), os.path.join(case_dir, "reference.mx.dot"))
         meta = {"name": name, "k": k, "w": w, "variant": variant,
                 "refs": [{"fasta": fa, "weight": wt, "tsv": t} for (fa, wt), t in zip(refs, tsvs[:-1])],

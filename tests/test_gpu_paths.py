@@ -231,3 +231,89 @@ def test_ntjoin_class_find_paths(tmp_path, capsys):
     assert po.canonical([[p for p, _g in comp] for comp in paths]) == po.canonical(ref["paths_by_n"]["2"])
     assert len(paths) == len(ref["paths_by_n"]["2"])      # one entry per component, empty ones included
     assert f"Total number of components in graph: {len(paths)}" in capsys.readouterr().out
+
+
+def _fasta_lengths(path):
+    lens, rid = {}, None
+    for line in open(path, encoding="ascii"):
+        if line.startswith(">"):
+            rid = line[1:].split()[0]
+            lens[rid] = 0
+        elif rid is not None:
+            lens[rid] += len(line.strip())
+    return lens
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_format_paths_match_reference_goldens(name):
+    """row f4: Ntjoin.find_mx_min_max / format_paths (segments and extremes from the GPU) against the reference's own
+    find_mx_min_max and format_path output for the target assembly, every golden case, every -n"""
+    import argparse
+    import contextlib
+    import io
+    from ntjoin_amd.ntjoin import Ntjoin
+    case = load_case(name)
+    meta, ref = case["meta"], case["reference"]
+    fa = ref["format_args"]
+    lengths = _fasta_lengths(os.path.join(GOLDEN, "fasta", meta["target"]["fasta"]))
+    cwd = os.getcwd()
+    os.chdir(os.path.join(GOLDEN, "cases", name))
+    try:
+        for n, want in ref["format_by_n"].items():
+            args = argparse.Namespace(FILES=[r["tsv"] for r in meta["refs"]], s=meta["target"]["tsv"],
+                                      l=meta["target"]["weight"], p="/tmp/mxg_fmt_" + name, k=meta["k"], n=int(n), t=1)
+            nj = Ntjoin(args, variant=meta["variant"])
+            try:
+                nj.weights_list = [r["weight"] for r in meta["refs"]]
+                with contextlib.redirect_stdout(io.StringIO()):
+                    nj.load_minimizers_scaffold()
+                    nj.make_minimizer_graph(materialize=False)
+                    nj.find_paths()
+                assert {c: list(v) for c, v in nj.find_mx_min_max(args.s).items()} == ref["mx_extremes_by_n"][n], (name, n)
+                got = nj.format_paths(lengths, g=fa["g"], G=fa["G"], m=fa["m"])
+            finally:
+                nj.close()
+            key = lambda nodes: tuple(tuple(x) for x in nodes)
+            assert sorted(map(key, got)) == sorted(map(key, want)), (name, n)
+    finally:
+        os.chdir(cwd)
+
+
+def test_fuzz_segments_vs_oracle(tmp_path):
+    """random multi-assembly graphs: per-path runs (contig, n, min, max, inc, dec) of every assembly against a plain
+    walk over the oracle's paths"""
+    from ntjoin_amd.engine import MxEngine
+    trials = int(os.environ.get("MXG_FUZZ_TRIALS", "40"))
+    rng = random.Random(99)
+    os.chdir(tmp_path)
+    for t in range(trials):
+        names, weights = _write_random_assemblies(rng, 1000 + t)
+        state = go.load_and_build(names[:-1], weights[:-1], names[-1], weights[-1])
+        with MxEngine(k=32, w=10) as eng:
+            for nm, wt in zip(names, weights):
+                eng.add_tsv(nm, wt, nm)
+            eng.build_graph()
+            vnames = [str(h) for h in eng.get_graph()["vertex_hash"].tolist()]
+            found = eng.find_paths(1)
+            for a, nm in enumerate(names):
+                seg = eng.path_segments(a)
+                ids = eng.record_ids(a, eng.n_records(a))
+                info = state["list_mx_info"][nm]
+                want = []
+                for p, (_c, verts) in enumerate(found):
+                    runs = []
+                    for v in verts:
+                        ctg, pos = info[vnames[v]]
+                        if runs and runs[-1][0] == ctg:
+                            runs[-1][1].append(pos)
+                        else:
+                            runs.append((ctg, [pos]))
+                    for ctg, ps in runs:
+                        pairs = list(zip(ps, ps[1:]))
+                        want.append((p, ctg, len(ps), min(ps), max(ps), sum(x < y for x, y in pairs), sum(x > y for x, y in pairs)))
+                got = [(p, ids[r], n, mn, mx, i, d) for p, r, n, mn, mx, i, d in
+                       zip(*[seg[c].tolist() for c in ("path", "record", "n", "min_pos", "max_pos", "inc", "dec")])]
+                assert got == want, (t, a)
+                ext = eng.mx_extremes(a)
+                exp = po.mx_extremes(state, nm)
+                assert {ids[r]: e for r, e in enumerate(ext) if e is not None} == exp, (t, a)

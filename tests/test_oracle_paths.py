@@ -39,3 +39,34 @@ def test_reference_expectation_f_f():
     ref_asm = case["meta"]["refs"][0]["tsv"]
     pos = [state["list_mx_info"][ref_asm][v][1] for v in paths[0]]
     assert pos == sorted(pos)
+
+
+def _fasta_lengths(path):
+    lens, rid = {}, None
+    for line in open(path, encoding="ascii"):
+        if line.startswith(">"):
+            rid = line[1:].split()[0]
+            lens[rid] = 0
+        elif rid is not None:
+            lens[rid] += len(line.strip())
+    return lens
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_format_path_oracle_matches_reference(name):
+    """row f4: find_mx_min_max and format_path of the reference's scaffolder (goldens: mx_extremes_by_n, format_by_n)"""
+    case = load_case(name)
+    meta, ref = case["meta"], case["reference"]
+    state = _state(meta)
+    target = meta["target"]["tsv"]
+    lengths = _fasta_lengths(os.path.join(GOLDEN, "fasta", meta["target"]["fasta"]))
+    fa = ref["format_args"]
+    for n, want in ref["format_by_n"].items():
+        filt = dict(state)
+        if not int(n) <= min(state["weights"].values()):      # the graph the scaffolder holds is the globally filtered one
+            filt["edges"] = [e for e in state["edges"] if not e[3] < int(n)]
+        assert {c: list(v) for c, v in po.mx_extremes(filt, target).items()} == ref["mx_extremes_by_n"][n], (name, n)
+        got = [po.format_path(filt, p, target, lengths, meta["k"], fa["g"], fa["G"], fa["m"])
+               for comp in po.find_paths(state, int(n)) for p in comp]
+        key = lambda nodes: tuple(tuple(x) for x in nodes)
+        assert sorted(map(key, got)) == sorted(map(key, want)), (name, n)
