@@ -275,6 +275,19 @@ struct SparseParams {
 // then that interval test is a single unsigned compare:  (x<<1) + y  >=  2^32 - 2T - 2.  (Bit 31 of x and bit 0 of y
 // are don't-cares that the updates never propagate into the rings.)  min(fwd,rev) < tau is exactly F < T or R < T.
 // (min variant: max(x<<1, y) >= 2^32 - 2T.)
+// byte n (a constant after unrolling) of a register as a zero-extended value: one SDWA move
+__device__ __forceinline__ uint32_t byte_of(uint32_t v, uint32_t n)
+{
+    uint32_t r;
+    switch (n) {
+    case 0: asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(r) : "v"(v)); break;
+    case 1: asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(r) : "v"(v)); break;
+    case 2: asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(r) : "v"(v)); break;
+    default: asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(r) : "v"(v)); break;
+    }
+    return r;
+}
+
 // x2 = x << 1, produced by ring_double: the compiler would emit a shift, which issues at half the rate of an add
 __device__ __forceinline__ uint32_t ring_double(uint32_t x)
 {
@@ -356,9 +369,12 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
         const uint32_t cout = __builtin_amdgcn_alignbit(o1, o0, so);
         const uint32_t cin = __builtin_amdgcn_alignbit(i1, i0, si);
         o0 = o1; o1 = o2; i0 = i1; i1 = i2;
-        constexpr uint32_t M = 0x33333333u;
+        constexpr uint32_t M = 0x33333333u, B = 0x78787878u;
         const uint32_t ze = ((cout & M) << 2) | (cin & M);        // nibble v = (out, in) of step 2v
         const uint32_t zo = (cout & ~M) | ((cin >> 2) & M);       // nibble v = (out, in) of step 2v+1
+        // one BYTE per step, already scaled to the entry's byte offset: a step then needs a single byte-select move
+        // (v_mov_b32_sdwa, full rate) instead of a shift (half rate) and a mask.  q[2*(u&1) + ((u>>1)&1)] byte u>>2.
+        const uint32_t q[4] = {(ze << 3) & B, (ze >> 1) & B, (zo << 3) & B, (zo >> 1) & B};
         uint32_t bits = 0;                                       // bit 15-u: k-mer 16*blk+u passed the ring test
 #pragma unroll
         for (uint32_t u = 0; u < 16; ++u) {
@@ -369,9 +385,7 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
                 // bits = 2*bits + (v >= thr): the compare's carry goes straight into the add
                 asm("v_cmp_le_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(v), "s"(thr) : "vcc");
             }
-            const uint32_t z = (u & 1u) ? zo : ze;
-            const uint32_t sh = 4u * (u >> 1);
-            const uint32_t off = (sh >= 3u ? z >> (sh - 3u) : z << (3u - sh)) & 0x78u;
+            const uint32_t off = byte_of(q[2u * (u & 1u) + ((u >> 1) & 1u)], u >> 2);
             ring_step(x, x2, y, *reinterpret_cast<const uint2 *>(ringb + off));
         }
         if (ABL == 1) { abl_acc ^= x + y; continue; }
