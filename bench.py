@@ -41,7 +41,7 @@ def valu_info(st):
     per_base = pmc["valu_per_base"]
     return {"wave64_instr_per_base": round(per_base, 2),
             "int_lane_ops_per_s": round(per_base * st["hash_kernel_bases"] / max(st["ms_hash"], 1e-9) * 1e3, 0),
-            "peak_lane_ops_per_s": 256 * 4 * 32 * 2.4e9,  # 1024 SIMDs x 32 lane-ops per cycle (wave64 at ~2.3 cycles, profiles/ubench)
+            "peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,  # 1024 SIMD16 units: one wave64 VALU instruction per 4 cycles
             "valu_busy_pmc": round(pmc["valu_busy"], 3),
             "source": "rocprofv3 SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE, profiles/hash_kernel_pmc.json"}
 

@@ -108,7 +108,7 @@ struct Assembly {
     std::vector<uint8_t> h_fwd;
     std::vector<uint64_t> rec_first;
     // graph stage
-    DevBuf d_flags, d_slot, d_shared, d_bs;
+    DevBuf d_flags, d_slot, d_shared;
     std::vector<uint8_t> h_flags;
     bool flags_valid = false;   // device flags computed
     bool flags_on_host = false; // h_flags mirrors d_flags
@@ -176,7 +176,7 @@ struct mxg_handle {
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
     // scratch reused across calls
     mxg::DevBuf scratch[2][40];  // two sets, indexed by mxg::Scratch (sketch.hip): one per in-flight sketch driver
-    mxg::DevBuf g_keys, g_tickets, g_cnt, g_vid, g_ctl, g_vhash, g_vpos, g_vrec, g_fv, g_frec, g_nxt, g_prv, g_eflag,
+    mxg::DevBuf g_keys, g_cnt, g_vid, g_ctl, g_vhash, g_vpos, g_vrec, g_fv, g_frec, g_nxt, g_prv, g_eflag,
         g_ebs, g_eu, g_ev, g_esup, g_ew;  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
     uint64_t arena_cap_hint = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -30,7 +30,8 @@
 //                  >= tau stay in the list and are skipped by k_resolve
 //   k_hash_dense   every k-mer is a candidate, written at its own index (DENSE_ONLY mode and gap fix-up)
 //   k_resolve      one lane per candidate: nearest smaller / smaller-or-equal neighbour scan; gap detection
-//   k_count/k_scan_sums/k_emit   ordered stream compaction into the sketch arrays
+//   k_emit         ordered stream compaction into the sketch arrays (offsets from k_resolve's two-level counts; the
+//                  dense path counts and scans with k_count_n / k_scan_sums)
 //   k_merge        merge of the (small) gap sketch into the batch sketch by (record,pos)
 #include <algorithm>
 #include <cmath>
@@ -45,7 +46,7 @@ namespace mxg {
 
 enum Scratch {
     SC_CAND_H, SC_CAND_K, SC_CAND_C, SC_SEL, SC_BSUM, SC_CTRL, SC_ARENA, SC_STRIP_CNT, SC_STRIP_META,
-    SC_STRIP_PREF, SC_SBSUM, SC_GAPS, SC_WAVE_CNT, SC_ST_HASH, SC_ST_POS, SC_ST_REC, SC_ST_FWD, SC_G_HASH, SC_G_POS,
+    SC_GAPS, SC_WAVE_CNT, SC_ST_HASH, SC_ST_POS, SC_ST_REC, SC_ST_FWD, SC_G_HASH, SC_G_POS,
     SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_CNT256, SC_WAVE_TOT, SC_COUNT
 };
 static_assert(SC_COUNT <= 40, "scratch pool too small");
@@ -1314,7 +1315,7 @@ struct Driver {
     struct BatchGeom {
         size_t c0, c1;
         uint64_t nk;
-        uint32_t r_lo, r_hi, strip_lo, strip_hi, n_strips, n_blocks, n_waves, s_tiles;
+        uint32_t r_lo, r_hi, strip_lo, strip_hi, n_strips, n_blocks, n_waves;
     };
     void batch_geom(const Tables &T, size_t c0, BatchGeom &g) const
     {
@@ -1330,7 +1331,6 @@ struct Driver {
         g.n_strips = g.strip_hi - g.strip_lo;
         g.n_blocks = (g.n_strips + 255) / 256;
         g.n_waves = g.n_blocks * 4;
-        g.s_tiles = (g.n_strips + TILE - 1) / TILE;
     }
     uint64_t default_wave_cap(uint32_t S, double cand_frac) const
     {
