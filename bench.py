@@ -94,6 +94,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MXG_BENCH_ONE_DEVICE") == "1":  # testing: several ranks share GPU 0 (with MXG_BENCH_BACKEND=gloo)
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py: for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N ...")
@@ -105,7 +107,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MXG_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo only for the one-GPU test
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ntjoin_amd import synth
     from ntjoin_amd.engine import MxEngine

@@ -1,0 +1,88 @@
+"""worker of tests/test_gpu_dist2.py: one of WORLD_SIZE processes that share cuda:0 and talk over gloo (RCCL cannot put two
+ranks on one GPU; the exchange code is the same).  Every rank owns a slice of the records of every assembly; rank 0
+checks the union graph against a single handle holding all records."""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ntjoin_amd.dist import allgather_union_graph  # noqa: E402
+from ntjoin_amd.engine import MxEngine  # noqa: E402
+
+
+def records(seed, n):
+    rng0 = random.Random(0)
+    base = "".join(rng0.choice("ACGT") for _ in range(90000))   # the genome every assembly is a copy of
+    rng = random.Random(seed)
+    cuts = sorted(rng.sample(range(2000, len(base) - 2000), n - 1))          # its own contig boundaries
+    out = []
+    for r, (lo, hi) in enumerate(zip([0] + cuts, cuts + [len(base)])):
+        s = list(base[lo:hi])
+        for _ in range(len(s) // 300):          # a few substitutions: assemblies share most minimizers, not all
+            s[rng.randrange(len(s))] = rng.choice("ACGT")
+        if r % 3 == 1:                          # some contigs reverse-complemented
+            s = ["TGCA"["ACGT".index(c)] for c in reversed(s)]
+        out.append((f"s{seed}_{r}", "".join(s)))
+    return out
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k, w = 32, 50
+    asms = [("refA", 2.0, records(1, 9)), ("refB", 1.5, records(2, 7)), ("tgt", 1.0, records(3, 11))]
+    use_stream = os.environ.get("MXG_TEST_STREAM") == "1"
+    xs = torch.cuda.Stream() if use_stream else None
+    eng = MxEngine(k=k, w=w, device=0, stream=xs.cuda_stream if xs is not None else None)
+    mine = []
+    for name, wt, recs in asms:
+        part = [r for i, r in enumerate(recs) if i * world // len(recs) == rank]   # contiguous slices, rank order
+        mine.append(part)
+        eng.add_records(name, wt, part)
+    union = None
+    for _step in range(2):                      # the second step reuses the union handle and its exchange buffers
+        eng.sketch(-2)
+        union = allgather_union_graph(eng, k, w, 0, union, stream=xs)
+    ok = True
+    if rank == 0:
+        with MxEngine(k=k, w=w, device=0) as whole:
+            for name, wt, recs in asms:
+                ids = []
+                for r in range(world):
+                    ids += [(f"r{r}:{rid}", seq) for i, (rid, seq) in enumerate(recs) if i * world // len(recs) == r]
+                whole.add_records(name, wt, ids)
+            whole.sketch()
+            whole.build_graph()
+            g0, g1 = whole.get_graph(), union.get_graph()
+            for key in g0:
+                if not np.array_equal(np.asarray(g0[key]), np.asarray(g1[key])):
+                    ok = False
+                    os.write(1, f"MISMATCH {key}\n".encode())
+            for a in range(len(asms)):
+                if not np.array_equal(whole.get_mx_flags(a), union.get_mx_flags(a)):
+                    ok = False
+                    os.write(1, f"MISMATCH flags {a}\n".encode())
+                if whole.record_ids(a, whole.n_records(a)) != union.record_ids(a, union.n_records(a)):
+                    ok = False
+                    os.write(1, f"MISMATCH ids {a}\n".encode())
+            os.write(1, f"union: {len(g1['vertex_hash'])} vertices, {len(g1['edge_u'])} edges; sketches "
+                        f"{[union.sketch_size(a) for a in range(len(asms))]} whole {[whole.sketch_size(a) for a in range(len(asms))]}\n".encode())
+            if len(g1["vertex_hash"]) < 100 or len(g1["edge_u"]) < 50:
+                ok = False
+                os.write(1, b"graph too small to mean anything\n")
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    union.close()
+    eng.close()
+    dist.destroy_process_group()
+    os.write(1, f"DIST2 {'OK' if int(flag) == 1 else 'FAILED'} rank {rank}\n".encode())  # one write: no interleaving
+    sys.exit(0 if int(flag) == 1 else 1)
+
+
+if __name__ == "__main__":
+    main()

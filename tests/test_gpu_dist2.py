@@ -1,0 +1,48 @@
+"""GPU test of the N>1 exchange with REAL world sizes: two and three processes share cuda:0 and talk over gloo (RCCL
+cannot put two ranks on one GPU; pack / all-gather / unpack / union graph are the same code the 8-GPU run uses).
+Rank 0 compares the union graph with the graph of a single handle that holds every rank's records."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from tests.conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("world,stream", [(2, "0"), (2, "1"), (3, "1")])
+def test_union_graph_world_size(world, stream):
+    env = dict(os.environ, MXG_TEST_STREAM=stream)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "tests", "_dist2_worker.py")]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("DIST2 OK") == world, out.stdout[-3000:]
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N>1 branch end to end (launch line of the driver, two ranks, gloo instead of RCCL): one JSON line,
+    aggregate over both ranks, graph counts of the union"""
+    import json
+    env = dict(os.environ, MXG_BENCH_BACKEND="gloo", MXG_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--mbp", "5"]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["bases_per_step"] > 1.9 * 2 * 5e6       # both ranks' 2 x 5 Mbp
+    assert d["config"]["vertices"] > 0 and d["config"]["edges"] > 0
