@@ -195,6 +195,10 @@ int mxg_set_sketch_device(mxg_handle *h, int assembly, const void *d_out_hash, c
 int mxg_pack_sketch_device(mxg_handle *h, int assembly, void *d_buf, uint64_t nmax);
 int mxg_set_sketch_gathered(mxg_handle *h, int assembly, const void *d_allbuf, uint32_t world, uint64_t nmax,
                             const uint64_t *counts, const uint64_t *rec_offsets);
+/* the same when rank r's packed buffer starts at d_allbuf + r * stride_bytes (several assemblies in ONE all-gather) */
+int mxg_set_sketch_gathered_strided(mxg_handle *h, int assembly, const void *d_allbuf, uint32_t world,
+                                    uint64_t stride_bytes, uint64_t nmax, const uint64_t *counts,
+                                    const uint64_t *rec_offsets);
 /* indexlr TSV: `id \t out_hash[:pos][:+|-][:kmer] ( out_hash...)* \n`, one line per record, input order.
    path "-" = stdout. */
 int mxg_write_tsv(mxg_handle *h, int assembly, const char *path, int with_pos, int with_strand,

@@ -18,7 +18,7 @@ SYMBOLS = [
     "mxg_add_assembly_tsv", "mxg_add_assembly_bin", "mxg_write_sketch_bin", "mxg_add_assembly_minimizers", "mxg_num_assemblies", "mxg_assembly_name",
     "mxg_record_id", "mxg_record_length", "mxg_num_records", "mxg_assembly_weight",
     "mxg_sketch", "mxg_get_sketch", "mxg_get_sketch_device", "mxg_compute_strands", "mxg_set_sketch_device",
-    "mxg_pack_sketch_device", "mxg_set_sketch_gathered", "mxg_write_tsv",
+    "mxg_pack_sketch_device", "mxg_set_sketch_gathered", "mxg_set_sketch_gathered_strided", "mxg_write_tsv",
     "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_path_segments", "mxg_mx_extremes", "mxg_write_dot",
     "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers",
 ]
@@ -139,6 +139,7 @@ def load():
     L.mxg_compute_strands.argtypes = [vp, i32]
     L.mxg_pack_sketch_device.argtypes = [vp, i32, vp, u64]
     L.mxg_set_sketch_gathered.argtypes = [vp, i32, vp, C.c_uint32, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.mxg_set_sketch_gathered_strided.argtypes = [vp, i32, vp, C.c_uint32, u64, u64, C.POINTER(u64), C.POINTER(u64)]
     L.mxg_write_tsv.argtypes = [vp, i32, cp, i32, i32, i32]
     L.mxg_build_graph.argtypes = [vp]
     L.mxg_get_mx_flags.argtypes = [vp, i32, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(u64)]

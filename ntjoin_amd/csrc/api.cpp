@@ -408,6 +408,14 @@ int mxg_set_sketch_gathered(mxg_handle *h, int assembly, const void *d_allbuf, u
     return unpack_gathered(h, a, d_allbuf, world, nmax, counts, rec_offsets);
 }
 
+int mxg_set_sketch_gathered_strided(mxg_handle *h, int assembly, const void *d_allbuf, uint32_t world, uint64_t stride_bytes,
+                                    uint64_t nmax, const uint64_t *counts, const uint64_t *rec_offsets)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !d_allbuf || !counts || !rec_offsets || stride_bytes < 16 * nmax) return MXG_EINVAL;
+    return unpack_gathered(h, a, d_allbuf, world, nmax, counts, rec_offsets, stride_bytes);
+}
+
 int mxg_set_sketch_device(mxg_handle *h, int assembly, const void *d_out_hash, const void *d_pos,
                           const void *d_record, const void *d_forward, uint64_t n)
 {

@@ -234,7 +234,7 @@ int load_sketch_bin(mxg_handle *h, Assembly *a, const char *path, std::vector<ui
 int ensure_strand(mxg_handle *h, Assembly *a);
 int pack_sketch(mxg_handle *h, Assembly *a, void *d_buf, uint64_t nmax);
 int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t world, uint64_t nmax,
-                    const uint64_t *counts, const uint64_t *rec_offsets);
+                    const uint64_t *counts, const uint64_t *rec_offsets, uint64_t stride_bytes = 0);
 // graph.hip
 int build_graph(mxg_handle *h);
 int graph_to_host(mxg_handle *h);

@@ -1800,6 +1800,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint64_t *__restrict__ hash,
 struct UnpackParams {
     const unsigned char *all;
     uint64_t nmax;
+    uint64_t stride;       // bytes between two ranks' buffers
     uint32_t world;
     uint64_t start[65];    // exclusive prefix of counts (world <= 64)
     uint32_t rec_off[64];
@@ -1814,7 +1815,7 @@ __global__ __launch_bounds__(256) void k_unpack(const UnpackParams p)
     uint32_t r = 0;
     while (o >= p.start[r + 1]) ++r;  // world is small
     const uint64_t i = o - p.start[r];
-    const unsigned char *buf = p.all + (size_t)r * 16 * p.nmax;
+    const unsigned char *buf = p.all + (size_t)r * p.stride;
     p.hash[o] = reinterpret_cast<const uint64_t *>(buf)[i];
     p.pos[o] = reinterpret_cast<const uint32_t *>(buf + 8 * p.nmax)[i];
     p.rec[o] = reinterpret_cast<const uint32_t *>(buf + 12 * p.nmax)[i] + p.rec_off[r];
@@ -1837,13 +1838,14 @@ int pack_sketch(mxg_handle *h, Assembly *a, void *d_buf, uint64_t nmax)
 }
 
 int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t world, uint64_t nmax,
-                    const uint64_t *counts, const uint64_t *rec_offsets)
+                    const uint64_t *counts, const uint64_t *rec_offsets, uint64_t stride_bytes)
 {
     if (world == 0 || world > 64) return set_err(h, MXG_ELIMIT, "world size must be 1..64");
     MXG_HIP(h, hipSetDevice(h->device));
     UnpackParams up;
     up.all = static_cast<const unsigned char *>(d_allbuf);
     up.nmax = nmax;
+    up.stride = stride_bytes ? stride_bytes : 16 * nmax;
     up.world = world;
     uint64_t total = 0;
     for (uint32_t r = 0; r < world; ++r) {

@@ -109,6 +109,12 @@ def _allgather_union_graph(eng, k, w, device, union, group, stream):
     A = eng.n_assemblies
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", device)
+    if union is not None and getattr(union, "_slots", None) is not None:
+        done = _exchange_one_gather(eng, union, A, world, dev, group, stream)
+        if done:
+            union.build_graph()
+            return union
+    # first step (or a sketch that outgrew its slot): sizes first, then one all-gather per assembly
     # sizes of what follows: (count, records) per assembly from every rank.  Staged through pinned host tensors kept on
     # the engine (a fresh torch.tensor(list, device=...) alone costs ~50 us per step).
     xm = getattr(eng, "_xmeta", None)
@@ -135,6 +141,7 @@ def _allgather_union_graph(eng, k, w, device, union, group, stream):
             union.add_minimizers(eng.assembly_name(a), eng.assembly_weight(a), np.zeros(0, np.uint64),
                                  np.zeros(0, np.uint32), np.zeros(0, np.uint32), flat)
         union._xbuf = {}
+        union._slots = None
     for a in range(A):
         counts = metas[:, a, 0].astype(np.uint64)
         nrecs = metas[:, a, 1].astype(np.uint64)
@@ -151,8 +158,54 @@ def _allgather_union_graph(eng, k, w, device, union, group, stream):
         if stream is None:
             torch.cuda.current_stream().synchronize()  # the union handle works on its own stream
         union.set_sketch_gathered(a, recv.data_ptr(), nmax, counts, rec_off)
+    # later steps: ONE all-gather.  Every rank's slot = header (count per assembly) + a fixed-capacity region per
+    # assembly, 25 % above the largest sketch seen in this step on any rank (the same on all ranks by construction).
+    caps = [((int(metas[:, a, 0].max()) * 5 // 4 + 64) + 7) // 8 * 8 for a in range(A)]
+    head = 64 * ((16 * A + 63) // 64)
+    slot = head + 16 * sum(caps)
+    union._slots = {"caps": caps, "head": head, "slot": slot,
+                    "rec_off": [np.concatenate([[0], np.cumsum(metas[:, a, 1])[:-1]]).astype(np.uint64) for a in range(A)],
+                    "send": torch.zeros(slot, dtype=torch.uint8, device=dev),
+                    "recv": torch.empty(world * slot, dtype=torch.uint8, device=dev),
+                    "head_h": torch.empty((A,), dtype=torch.int64).pin_memory(),
+                    "heads_h": torch.empty((world, head // 8), dtype=torch.int64).pin_memory()}
     union.build_graph()
     return union
+
+
+def _exchange_one_gather(eng, union, A, world, dev, group, stream):
+    """steady-state exchange: header + all assemblies in ONE all-gather and one host sync (the header read-back).
+    Returns False (nothing changed in `union`) when some sketch no longer fits its slot on some rank."""
+    sl = union._slots
+    caps, head, slot = sl["caps"], sl["head"], sl["slot"]
+    send, recv = sl["send"], sl["recv"]
+    hh = sl["head_h"].numpy()
+    fits = True
+    for a in range(A):
+        hh[a] = eng.sketch_size(a)
+        fits = fits and hh[a] <= caps[a]
+    if not fits:
+        hh[:] = -1                               # tell everybody: this rank needs bigger slots
+    send[:8 * A].view(torch.int64).copy_(sl["head_h"], non_blocking=True)
+    off = head
+    if fits:
+        for a in range(A):
+            eng.pack_sketch_device(a, send.data_ptr() + off, caps[a])
+            off += 16 * caps[a]
+    dist.all_gather_into_tensor(recv, send, group=group)
+    heads = recv.view(world, slot)[:, :head].contiguous().view(torch.int64).view(world, head // 8)
+    sl["heads_h"].copy_(heads, non_blocking=True)
+    torch.cuda.current_stream().synchronize()    # the one host sync of the exchange
+    counts_all = sl["heads_h"].numpy()[:, :A].copy()
+    if (counts_all < 0).any():
+        union._slots = None                      # every rank sees the same headers: all fall back together
+        return False
+    off = head
+    for a in range(A):
+        union.set_sketch_gathered_strided(a, recv.data_ptr() + off, slot, caps[a], counts_all[:, a].astype(np.uint64),
+                                          sl["rec_off"][a])
+        off += 16 * caps[a]
+    return True
 
 
 def shard_range(lengths, shard, n_shards):

@@ -198,6 +198,15 @@ class MxEngine:
                                                       cc.ctypes.data_as(C.POINTER(C.c_uint64)),
                                                       ro.ctypes.data_as(C.POINTER(C.c_uint64))))
 
+    def set_sketch_gathered_strided(self, a, d_allbuf, stride_bytes, nmax, counts, rec_offsets):
+        """like set_sketch_gathered, rank r's packed buffer at d_allbuf + r * stride_bytes"""
+        cc = np.ascontiguousarray(counts, dtype=np.uint64)
+        ro = np.ascontiguousarray(rec_offsets, dtype=np.uint64)
+        self._check(self._lib.mxg_set_sketch_gathered_strided(self._h, int(a), C.c_void_p(int(d_allbuf)), len(cc),
+                                                              int(stride_bytes), int(nmax),
+                                                              cc.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                              ro.ctypes.data_as(C.POINTER(C.c_uint64))))
+
     def set_sketch_device(self, a, d_hash, d_pos, d_record, d_forward, n):
         self._check(self._lib.mxg_set_sketch_device(self._h, int(a), C.c_void_p(int(d_hash)), C.c_void_p(int(d_pos)),
                                                     C.c_void_p(int(d_record)),
