@@ -566,6 +566,76 @@ int mxg_mx_extremes(mxg_handle *h, int assembly, const uint32_t **min_pos, const
     return MXG_OK;
 }
 
+// ---- distributed graph stage (dgraph.hip; the collectives are the caller's) -----------------------------------------
+#define DG_TRY(expr)                                                                     \
+    try {                                                                                \
+        return (expr);                                                                   \
+    } catch (const std::bad_alloc &) {                                                   \
+        return set_err(h, MXG_ENOMEM, "out of host memory in the distributed graph stage"); \
+    }
+
+int mxg_dg_owner_counts(mxg_handle *h, uint32_t world, uint64_t *counts)
+{
+    if (!h || !counts) return MXG_EINVAL;
+    DG_TRY(dg_owner_counts(h, world, counts))
+}
+
+int mxg_dg_pack_items(mxg_handle *h, int assembly, uint32_t world, uint32_t rec_offset, const uint64_t *starts, void *d_send)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !starts || !d_send || world == 0 || world > 64) return MXG_EINVAL;
+    DG_TRY(dg_pack_items(h, a, world, rec_offset, starts, d_send))
+}
+
+int mxg_dg_set_items(mxg_handle *h, int assembly, const void *d_items, uint32_t world, const uint64_t *sec_start,
+                     const uint64_t *sec_count)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !d_items || !sec_start || !sec_count) return MXG_EINVAL;
+    DG_TRY(dg_set_items(h, a, d_items, world, sec_start, sec_count))
+}
+
+int mxg_dg_vertices(mxg_handle *h, uint64_t *n_vertices)
+{
+    if (!h || !n_vertices) return MXG_EINVAL;
+    try {
+        int rc = build_graph(h, GRAPH_DG_VERTICES);
+        if (rc != MXG_OK) return rc;
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_dg_vertices");
+    }
+    *n_vertices = h->graph.nv;
+    return MXG_OK;
+}
+
+int mxg_dg_item_results(mxg_handle *h, int assembly, uint32_t gbase, uint32_t world, const uint64_t *sec_start,
+                        const uint64_t *sec_count, void *d_out)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !d_out || !sec_start || !sec_count) return MXG_EINVAL;
+    DG_TRY(dg_item_results(h, a, gbase, world, sec_start, sec_count, d_out))
+}
+
+int mxg_dg_msg_counts(mxg_handle *h, int assembly, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !d_ret || !d_bases || !counts || world == 0 || world > 64) return MXG_EINVAL;
+    DG_TRY(dg_msg_counts(h, a, world, d_ret, d_bases, counts))
+}
+
+int mxg_dg_pack_msgs(mxg_handle *h, int assembly, uint32_t world, const void *d_bases, const uint64_t *starts, void *d_send)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !d_bases || !starts || !d_send || world == 0 || world > 64) return MXG_EINVAL;
+    DG_TRY(dg_pack_msgs(h, a, (uint32_t)assembly, world, d_bases, starts, d_send))
+}
+
+int mxg_dg_edges(mxg_handle *h, const void *d_msgs, uint64_t n_msgs)
+{
+    if (!h || (n_msgs && !d_msgs)) return MXG_EINVAL;
+    DG_TRY(build_graph(h, GRAPH_DG_EDGES, d_msgs, n_msgs))
+}
+
 int mxg_write_dot(mxg_handle *h, const char *path)
 {
     if (!h || !path) return MXG_EINVAL;

@@ -1,0 +1,391 @@
+// dgraph.hip -- the graph stage distributed over ranks by hash range, device side.
+//
+// The union approach (every rank all-gathers every sketch and builds the whole graph) does N times the work on every
+// rank.  Here every minimizer is sent to the rank that OWNS its hash; the owner decides uniqueness and intersection for
+// its hashes with the ordinary kernels of graph.hip and numbers its vertices; the verdict (flags + global vertex id)
+// travels back; adjacency stays where the records are (a record is never split over ranks) and reaches the owners of the
+// two end points as messages; every owner emits the edges whose first supporter's source vertex it owns.
+// The collectives themselves (all-to-all with uneven splits) are issued by the caller (ntjoin_amd/dist.py over
+// torch.distributed = RCCL); this file packs, unpacks and counts.
+//
+//   sender                                   owner
+//   k_dg_owner_count / k_dg_pack_items  -->  k_dg_items_to_soa, build_graph(GRAPH_DG_VERTICES), k_dg_item_result
+//   k_dg_shared_cnt / k_dg_compact      <--  (flags | global vertex id << 8 per item, in the sender's bucket order)
+//   k_dg_msg_count / k_dg_pack_msgs     -->  build_graph(GRAPH_DG_EDGES): k_apply_msgs, k_edge_flags, k_edges
+#include <algorithm>
+
+#include "mxg_internal.h"
+#include "scan_kernels.h"
+
+namespace mxg {
+
+static constexpr uint32_t DG_NONE = 0xFFFFFFFFu;
+
+// rank that owns a hash: multiplicative mix, then the top bits scaled to [0, world)
+__device__ __forceinline__ uint32_t dg_owner(uint64_t hash, uint32_t world)
+{
+    const uint32_t m = (uint32_t)((hash * 0x9E3779B97F4A7C15ull) >> 32);
+    return (uint32_t)(((uint64_t)m * world) >> 32);
+}
+
+// all lanes of a wave: cnt[key] += number of active lanes holding that key (one atomic per distinct key and wave)
+__device__ __forceinline__ void wave_hist(unsigned long long *cnt, uint32_t key, bool active)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t todo = __ballot(active); todo;) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const uint64_t same = __ballot(active && key == k0);
+        if ((int)lane == leader) atomicAdd(&cnt[k0], (unsigned long long)__popcll(same));
+        todo &= ~same;
+    }
+}
+// all lanes of a wave: a slot in bucket `key` for every active lane (cursor[key] advances by the bucket's lanes)
+__device__ __forceinline__ uint64_t wave_slot(unsigned long long *cursor, uint32_t key, bool active)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t slot = 0;
+    for (uint64_t todo = __ballot(active); todo;) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const uint64_t same = __ballot(active && key == k0);
+        unsigned long long base = 0;
+        if ((int)lane == leader) base = atomicAdd(&cursor[k0], (unsigned long long)__popcll(same));
+        const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader);
+        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader);
+        if (active && key == k0)
+            slot = (((uint64_t)bhi << 32) | blo) + (uint64_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return slot;
+}
+
+__global__ __launch_bounds__(256) void k_dg_owner_count(const uint64_t *__restrict__ hash, uint64_t n, uint32_t world,
+                                                        unsigned long long *cnt)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const bool in = i < n;
+    wave_hist(cnt, in ? dg_owner(hash[i], world) : 0u, in);
+}
+
+// item = {hash, pos, global record}; perm[i] = where minimizer i went in the send buffer
+__global__ __launch_bounds__(256) void k_dg_pack_items(const uint64_t *__restrict__ hash, const uint32_t *__restrict__ pos,
+                                                       const uint32_t *__restrict__ rec, uint64_t n, uint32_t world,
+                                                       uint32_t rec_off, unsigned long long *cursor, uint4 *items, uint32_t *perm)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const bool in = i < n;
+    const uint64_t h = in ? hash[i] : 0;
+    const uint64_t s = wave_slot(cursor, in ? dg_owner(h, world) : 0u, in);
+    if (!in) return;
+    items[s] = make_uint4((uint32_t)h, (uint32_t)(h >> 32), pos[i], rec[i] + rec_off);
+    perm[i] = (uint32_t)s;
+}
+
+// The receive buffer holds, per source rank, one section per assembly; assembly a's items are its `world` sections in
+// source order.  start[s] = first item of source s's section in the buffer, first[s] = exclusive prefix of the counts.
+struct DgSections {
+    uint32_t world;
+    uint64_t start[64];
+    uint64_t first[65];
+};
+__device__ __forceinline__ uint64_t dg_locate(const DgSections &sc, uint64_t o)  // item o of the assembly -> buffer index
+{
+    uint32_t s = 0;
+    while (o >= sc.first[s + 1]) ++s;  // world is small
+    return sc.start[s] + (o - sc.first[s]);
+}
+
+__global__ __launch_bounds__(256) void k_dg_items_to_soa(const uint4 *__restrict__ items, const DgSections sc, uint64_t *hash,
+                                                         uint32_t *pos, uint32_t *rec)
+{
+    const uint64_t o = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (o >= sc.first[sc.world]) return;
+    const uint4 it = items[dg_locate(sc, o)];
+    hash[o] = ((uint64_t)it.y << 32) | it.x;
+    pos[o] = it.z;
+    rec[o] = it.w;
+}
+
+// what the owner tells the sender about an item: flags | (global vertex id or NONE) << 8, at the item's place in the
+// receive layout (the return trip uses the same splits backwards)
+__global__ __launch_bounds__(256) void k_dg_item_result(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ ivid,
+                                                        const DgSections sc, uint32_t gbase, unsigned long long *out)
+{
+    const uint64_t o = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (o >= sc.first[sc.world]) return;
+    const uint32_t v = ivid[o];
+    out[dg_locate(sc, o)] = ((unsigned long long)(v == DG_NONE ? DG_NONE : v + gbase) << 8) | flags[o];
+}
+
+// ---- sender, second half: adjacency of ITS records as messages to the owners of the two end points ---------------
+struct DgAdjParams {
+    const unsigned long long *ret;  // the owners' verdicts in send-buffer order
+    const uint32_t *perm;           // minimizer i -> its place in that order
+    const uint32_t *rec;
+    uint32_t n;
+    uint32_t *cnt, *sup;            // two-level counts of shared minimizers per 256 (scan_kernels.h)
+    uint32_t *fg, *frec;            // shared minimizers in order: global vertex id, record
+    uint32_t *n_shared;             // device scalar
+    uint8_t *flags_out;             // the assembly's flags array (mxg_get_mx_flags)
+};
+
+__global__ __launch_bounds__(256) void k_dg_shared_cnt(const DgAdjParams p)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool sh = false;
+    if (i < p.n) {
+        const unsigned long long v = p.ret[p.perm[i]];
+        p.flags_out[i] = (uint8_t)v;
+        sh = ((uint8_t)v & MXG_MX_SHARED) != 0;
+    }
+    const uint32_t c = (uint32_t)__syncthreads_count(sh ? 1 : 0);
+    if (threadIdx.x == 0) count_publish(p.cnt, p.sup, blockIdx.x, c);
+}
+
+__global__ __launch_bounds__(256) void k_dg_compact(const DgAdjParams p)
+{
+    __shared__ uint32_t sh_scan[256];
+    __shared__ uint32_t sh_before;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    unsigned long long v = 0;
+    bool sh = false;
+    if (i < p.n) {
+        v = p.ret[p.perm[i]];
+        sh = ((uint8_t)v & MXG_MX_SHARED) != 0;
+    }
+    const uint32_t rank = block_exclusive_256(sh ? 1u : 0u, sh_scan);
+    if (threadIdx.x < 64) {
+        const uint32_t bef = count_prefix(p.cnt, p.sup, blockIdx.x);
+        if (threadIdx.x == 0) sh_before = bef;
+        if (blockIdx.x + 1 == gridDim.x) {
+            const uint32_t all = count_prefix(p.cnt, p.sup, gridDim.x);
+            if (threadIdx.x == 0) *p.n_shared = all;
+        }
+    }
+    __syncthreads();
+    if (sh) {
+        const uint32_t r = sh_before + rank;
+        p.fg[r] = (uint32_t)(v >> 8);
+        p.frec[r] = p.rec[i];
+    }
+}
+
+// owner of a global vertex id: bases[r] <= g < bases[r + 1]
+__device__ __forceinline__ uint32_t dg_vertex_owner(const uint32_t *__restrict__ bases, uint32_t world, uint32_t g)
+{
+    uint32_t lo = 0, hi = world;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (bases[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// pair r = (shared minimizer r, r + 1) of the same record: one message to the owner of each end
+__global__ __launch_bounds__(256) void k_dg_msg_count(const uint32_t *__restrict__ fg, const uint32_t *__restrict__ frec,
+                                                      const uint32_t *__restrict__ n_shared, const uint32_t *__restrict__ bases,
+                                                      uint32_t world, unsigned long long *cnt)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t ns = *n_shared;
+    const bool in = r + 1 < ns && frec[r] == frec[r + 1];
+    wave_hist(cnt, in ? dg_vertex_owner(bases, world, fg[r]) : 0u, in);
+    wave_hist(cnt, in ? dg_vertex_owner(bases, world, fg[r + 1]) : 0u, in);
+}
+
+__global__ __launch_bounds__(256) void k_dg_pack_msgs(const uint32_t *__restrict__ fg, const uint32_t *__restrict__ frec,
+                                                      const uint32_t *__restrict__ n_shared, const uint32_t *__restrict__ bases,
+                                                      uint32_t world, uint32_t assembly, unsigned long long *cursor, uint4 *msgs)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t ns = *n_shared;
+    const bool in = r + 1 < ns && frec[r] == frec[r + 1];
+    const uint32_t u = in ? fg[r] : 0u, v = in ? fg[r + 1] : 0u;
+    const uint32_t ou = in ? dg_vertex_owner(bases, world, u) : 0u, ov = in ? dg_vertex_owner(bases, world, v) : 0u;
+    const uint64_t su = wave_slot(cursor, ou, in);
+    const uint64_t sv = wave_slot(cursor, ov, in);
+    if (!in) return;
+    msgs[su] = make_uint4(assembly, u - bases[ou], v, 0u);            // nxt[a][u] = v at the owner of u
+    msgs[sv] = make_uint4(assembly | 256u, v - bases[ov], u, 0u);     // prv[a][v] = u at the owner of v
+}
+
+// ------------------------------------------------------------------------------------------------------
+static int dg_counts_to_host(mxg_handle *h, DevBuf &b, uint32_t world, uint64_t *out)
+{
+    MXG_HIP(h, hipMemcpyAsync(out, b.p, (size_t)world * 8, hipMemcpyDeviceToHost, h->stream));
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    return MXG_OK;
+}
+
+static int dg_cursor(mxg_handle *h, uint32_t world, const uint64_t *starts)
+{
+    MXG_HIP(h, h->dg_cursor.ensure(64 * 8));
+    MXG_HIP(h, hipMemcpyAsync(h->dg_cursor.p, starts, (size_t)world * 8, hipMemcpyHostToDevice, h->stream));
+    return MXG_OK;
+}
+
+// sender: how many minimizers of every assembly go to every rank; counts[a * world + r]
+int dg_owner_counts(mxg_handle *h, uint32_t world, uint64_t *counts)
+{
+    if (world == 0 || world > 64) return set_err(h, MXG_ELIMIT, "world size must be 1..64");
+    MXG_HIP(h, hipSetDevice(h->device));
+    const size_t A = h->asms.size();
+    MXG_HIP(h, h->dg_cnt.ensure(A * 64 * 8 + 64));
+    MXG_HIP(h, hipMemsetAsync(h->dg_cnt.p, 0, A * 64 * 8, h->stream));
+    for (size_t a = 0; a < A; ++a) {
+        Assembly *as = h->asms[a];
+        if (!as->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch", as->name.c_str());
+        if (as->n_mx)
+            hipLaunchKernelGGL(k_dg_owner_count, dim3((uint32_t)((as->n_mx + 255) / 256)), dim3(256), 0, h->stream,
+                               as->d_hash.as<uint64_t>(), as->n_mx, world, h->dg_cnt.as<unsigned long long>() + a * 64);
+    }
+    MXG_HIP(h, hipGetLastError());
+    std::vector<uint64_t> tmp(A * 64);
+    MXG_HIP(h, hipMemcpyAsync(tmp.data(), h->dg_cnt.p, A * 64 * 8, hipMemcpyDeviceToHost, h->stream));
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    for (size_t a = 0; a < A; ++a)
+        for (uint32_t r = 0; r < world; ++r) counts[a * world + r] = tmp[a * 64 + r];
+    return MXG_OK;
+}
+
+// sender: assembly a's minimizers as 16-byte items bucketed by owner; bucket r starts at item starts[r] of d_send
+int dg_pack_items(mxg_handle *h, Assembly *a, uint32_t world, uint32_t rec_offset, const uint64_t *starts, void *d_send)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    int rc = dg_cursor(h, world, starts);
+    if (rc != MXG_OK) return rc;
+    MXG_HIP(h, a->d_perm.ensure(std::max<uint64_t>(a->n_mx * 4, 16)));
+    if (a->n_mx)
+        hipLaunchKernelGGL(k_dg_pack_items, dim3((uint32_t)((a->n_mx + 255) / 256)), dim3(256), 0, h->stream,
+                           a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(), a->d_rec.as<uint32_t>(), a->n_mx, world, rec_offset,
+                           h->dg_cursor.as<unsigned long long>(), static_cast<uint4 *>(d_send), a->d_perm.as<uint32_t>());
+    MXG_HIP(h, hipGetLastError());
+    if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));  // (see pack_sketch)
+    return MXG_OK;
+}
+
+static int dg_sections(mxg_handle *h, uint32_t world, const uint64_t *sec_start, const uint64_t *sec_count, DgSections *sc)
+{
+    if (world == 0 || world > 64) return set_err(h, MXG_ELIMIT, "world size must be 1..64");
+    sc->world = world;
+    uint64_t tot = 0;
+    for (uint32_t s = 0; s < world; ++s) {
+        sc->start[s] = sec_start[s];
+        sc->first[s] = tot;
+        tot += sec_count[s];
+    }
+    for (uint32_t s = world; s <= 64; ++s) sc->first[s] = tot;
+    return MXG_OK;
+}
+
+// owner: the items received for assembly a (one section per source rank) become its (unordered) sketch
+int dg_set_items(mxg_handle *h, Assembly *a, const void *d_items, uint32_t world, const uint64_t *sec_start,
+                 const uint64_t *sec_count)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    DgSections sc;
+    int rc = dg_sections(h, world, sec_start, sec_count, &sc);
+    if (rc != MXG_OK) return rc;
+    const uint64_t n = sc.first[world];
+    if (n >= (1ull << 31)) return set_err(h, MXG_ELIMIT, "too many items for one owner");
+    MXG_HIP(h, a->d_hash.ensure(std::max<uint64_t>(n * 8, 16)));
+    MXG_HIP(h, a->d_pos.ensure(std::max<uint64_t>(n * 4, 16)));
+    MXG_HIP(h, a->d_rec.ensure(std::max<uint64_t>(n * 4, 16)));
+    if (n)
+        hipLaunchKernelGGL(k_dg_items_to_soa, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, h->stream,
+                           static_cast<const uint4 *>(d_items), sc, a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(),
+                           a->d_rec.as<uint32_t>());
+    MXG_HIP(h, hipGetLastError());
+    a->n_mx = n;
+    a->has_sketch = true;
+    a->fwd_valid = false;
+    a->foreign_sketch = true;
+    a->host_valid = false;
+    a->flags_valid = false;
+    h->graph.valid = false;
+    return MXG_OK;
+}
+
+// owner: verdict per item of assembly a (after build_graph(GRAPH_DG_VERTICES)), written into the return buffer at the
+// places the items came from
+int dg_item_results(mxg_handle *h, Assembly *a, uint32_t gbase, uint32_t world, const uint64_t *sec_start,
+                    const uint64_t *sec_count, void *d_out)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    DgSections sc;
+    int rc = dg_sections(h, world, sec_start, sec_count, &sc);
+    if (rc != MXG_OK) return rc;
+    if (sc.first[world] != a->n_mx) return set_err(h, MXG_EINVAL, "sections do not add up to the assembly's items");
+    if (a->n_mx) {
+        if (h->graph.nv_stride == 0) {  // some assembly received nothing: no vertex, and nobody made d_ivid
+            MXG_HIP(h, a->d_ivid.ensure(a->n_mx * 4 + 16));
+            MXG_HIP(h, hipMemsetAsync(a->d_ivid.p, 0xFF, a->n_mx * 4, h->stream));
+        }
+        hipLaunchKernelGGL(k_dg_item_result, dim3((uint32_t)((a->n_mx + 255) / 256)), dim3(256), 0, h->stream,
+                           a->d_flags.as<uint8_t>(), a->d_ivid.as<uint32_t>(), sc, gbase, static_cast<unsigned long long *>(d_out));
+    }
+    MXG_HIP(h, hipGetLastError());
+    if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));
+    return MXG_OK;
+}
+
+// sender: the verdicts are back (d_ret, send-buffer order).  Flags of assembly a, its shared minimizers in order, and how
+// many adjacency messages go to every rank (counts[world]); d_bases = [world + 1] first global vertex id of every rank
+int dg_msg_counts(mxg_handle *h, Assembly *a, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    const uint32_t n = (uint32_t)a->n_mx;
+    const uint32_t blocks = (n + 255) / 256;
+    MXG_HIP(h, a->d_flags.ensure(std::max<uint32_t>(n, 16)));
+    MXG_HIP(h, h->dg_cnt.ensure(64 * 8 + 64));
+    MXG_HIP(h, a->d_dgtmp.ensure(((size_t)sup_words(blocks) + blocks + 16) * 4));
+    MXG_HIP(h, a->d_fg.ensure((size_t)n * 4 + 16));
+    MXG_HIP(h, a->d_frec.ensure((size_t)n * 4 + 16));
+    uint32_t *sup = a->d_dgtmp.as<uint32_t>(), *cnt = sup + sup_words(blocks), *n_shared = cnt + blocks;
+    MXG_HIP(h, hipMemsetAsync(sup, 0, (size_t)sup_words(blocks) * 4, h->stream));
+    MXG_HIP(h, hipMemsetAsync(n_shared, 0, 4, h->stream));
+    MXG_HIP(h, hipMemsetAsync(h->dg_cnt.p, 0, 64 * 8, h->stream));
+    if (n) {
+        DgAdjParams p;
+        p.ret = static_cast<const unsigned long long *>(d_ret);
+        p.perm = a->d_perm.as<uint32_t>();
+        p.rec = a->d_rec.as<uint32_t>();
+        p.n = n;
+        p.cnt = cnt;
+        p.sup = sup;
+        p.fg = a->d_fg.as<uint32_t>();
+        p.frec = a->d_frec.as<uint32_t>();
+        p.n_shared = n_shared;
+        p.flags_out = a->d_flags.as<uint8_t>();
+        hipLaunchKernelGGL(k_dg_shared_cnt, dim3(blocks), dim3(256), 0, h->stream, p);
+        hipLaunchKernelGGL(k_dg_compact, dim3(blocks), dim3(256), 0, h->stream, p);
+        hipLaunchKernelGGL(k_dg_msg_count, dim3(blocks), dim3(256), 0, h->stream, p.fg, p.frec, n_shared,
+                           static_cast<const uint32_t *>(d_bases), world, h->dg_cnt.as<unsigned long long>());
+        MXG_HIP(h, hipGetLastError());
+    }
+    a->flags_valid = true;
+    a->flags_on_host = false;
+    return dg_counts_to_host(h, h->dg_cnt, world, counts);
+}
+
+// sender: the messages of assembly a (after dg_msg_counts), bucket r at message starts[r] of d_send
+int dg_pack_msgs(mxg_handle *h, Assembly *a, uint32_t assembly, uint32_t world, const void *d_bases, const uint64_t *starts,
+                 void *d_send)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    const uint32_t n = (uint32_t)a->n_mx;
+    if (n == 0) return MXG_OK;
+    int rc = dg_cursor(h, world, starts);
+    if (rc != MXG_OK) return rc;
+    const uint32_t blocks = (n + 255) / 256;
+    uint32_t *n_shared = a->d_dgtmp.as<uint32_t>() + sup_words(blocks) + blocks;
+    hipLaunchKernelGGL(k_dg_pack_msgs, dim3(blocks), dim3(256), 0, h->stream, a->d_fg.as<uint32_t>(), a->d_frec.as<uint32_t>(),
+                       n_shared, static_cast<const uint32_t *>(d_bases), world, assembly, h->dg_cursor.as<unsigned long long>(),
+                       static_cast<uint4 *>(d_send));
+    MXG_HIP(h, hipGetLastError());
+    if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));
+    return MXG_OK;
+}
+
+}  // namespace mxg

@@ -116,6 +116,7 @@ struct VertexParams {
     uint64_t *vhash;  // [nv]
     uint32_t *vpos, *vrec;  // this assembly's slice [nv]
     uint32_t *fv, *frec;    // this assembly's filtered order -> vertex id / record
+    uint32_t *ivid;         // distributed graph (dgraph.hip): vertex id per ITEM (pre-filled with NONE), else nullptr
 };
 
 // ordered compaction of the shared minimizers of one assembly; rank r in filtered order
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(256) void k_vertices(const VertexParams p)
             }
             p.vpos[v] = p.pos[i];
             p.vrec[v] = p.rec[i];
+            if (p.ivid) p.ivid[i] = v;
             p.fv[r] = v;
             p.frec[r] = p.rec[i];
             ++r;
@@ -266,6 +268,24 @@ __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_it
     }
 }
 
+// distributed graph, owner side (dgraph.hip): adjacency arrives as messages {kind << 8 | assembly, local vertex, other
+// vertex (global id), 0}: kind 0 sets nxt[a][local], kind 1 sets prv[a][local]
+__global__ __launch_bounds__(256) void k_apply_msgs(const uint4 *__restrict__ msgs, uint64_t n, uint32_t stride, uint32_t *nxt,
+                                                    uint32_t *prv)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint4 m = msgs[i];
+    uint32_t *dst = (m.x >> 8) ? prv : nxt;
+    dst[(size_t)(m.x & 255u) * stride + m.y] = m.z;
+}
+
+__global__ __launch_bounds__(256) void k_iota_rows(uint32_t *a, uint32_t stride)  // a[row][i] = i
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < stride) a[(size_t)blockIdx.y * stride + i] = i;
+}
+
 // ------------------------------------------------------------------------------------------------------
 template <class T>
 static int d2h(mxg_handle *h, std::vector<T> &dst, const void *src, size_t n)
@@ -286,7 +306,10 @@ __global__ __launch_bounds__(256) void k_count_unique(const uint8_t *__restrict_
     if ((threadIdx.x & 63u) == 0 && m) atomicAdd(counter, (unsigned long long)__popcll(m));
 }
 
-int build_graph(mxg_handle *h)
+// mode GRAPH_FULL: the whole stage.  The distributed graph (dgraph.hip) runs it in two halves on the OWNER's handle:
+// GRAPH_DG_VERTICES stops after the vertices (and records the vertex id of every item), GRAPH_DG_EDGES resumes with the
+// adjacency taken from messages instead of from the handle's own record order.
+int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs)
 {
     MXG_HIP(h, hipSetDevice(h->device));
     const uint32_t A = (uint32_t)h->asms.size();
@@ -297,11 +320,11 @@ int build_graph(mxg_handle *h)
         if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch (call mxg_sketch)", a->name.c_str());
         N += a->n_mx;
         nmin = std::min(nmin, a->n_mx);
-        a->flags_valid = a->flags_on_host = false;
+        if (mode != GRAPH_DG_EDGES) a->flags_valid = a->flags_on_host = false;
     }
     if (N >= (1ull << 30)) return set_err(h, MXG_ELIMIT, "too many minimizers for one table (%llu)", (unsigned long long)N);
     Graph &g = h->graph;
-    g = Graph();
+    if (mode != GRAPH_DG_EDGES) g = Graph();
     g.n_asm = A;
     const bool timing = (h->cfg.flags & MXG_FLAG_TIMING) != 0;
     if (timing) MXG_HIP(h, hipEventRecord(h->ev0, h->stream));
@@ -314,7 +337,8 @@ int build_graph(mxg_handle *h)
     MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * sizeof(Slot)));
     MXG_HIP(h, h->g_vid.ensure(((size_t)cap + 1) * 4));
     MXG_HIP(h, h->g_ctl.ensure(CTL_WORDS * 8));
-    MXG_HIP(h, hipMemsetAsync(h->g_keys.p, 0xFF, ((size_t)cap + 1) * sizeof(Slot), h->stream));  // one fill: see Slot
+    if (mode != GRAPH_DG_EDGES)
+        MXG_HIP(h, hipMemsetAsync(h->g_keys.p, 0xFF, ((size_t)cap + 1) * sizeof(Slot), h->stream));  // one fill: see Slot
     uint64_t *ctl = h->g_ctl.as<uint64_t>();  // every word the host reads below is written by a kernel of this call
 
     AsmSet as_all;
@@ -358,7 +382,7 @@ int build_graph(mxg_handle *h)
     const uint32_t n_fsup = ((nb >> SUP_SHIFT) + A + 1) * SUP_STRIDE, n_esup = sup_words(e_blocks);
     MXG_HIP(h, h->g_cnt.ensure(((size_t)n_fsup + n_esup + nb) * 4 + 64));
     uint32_t *fsup = h->g_cnt.as<uint32_t>(), *esup = fsup + n_fsup, *cnt = esup + n_esup;
-    if (nb) {
+    if (nb && mode != GRAPH_DG_EDGES) {
         hipLaunchKernelGGL(k_insert, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), mask, cap, fsup,
                            n_fsup + n_esup);
         // flags + shared minimizers per 256 of every assembly (their totals, equal by construction, land in ctl[a])
@@ -372,9 +396,9 @@ int build_graph(mxg_handle *h)
         MXG_HIP(h, h->g_fv.ensure(anv * 4));
         MXG_HIP(h, h->g_frec.ensure(anv * 4));
         MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4));  // nxt[A][nvs] followed by prv[A][nvs]: one fill
-        MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));
+        if (mode != GRAPH_DG_VERTICES) MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));
         uint32_t *const d_prv = h->g_nxt.as<uint32_t>() + anv;
-        for (uint32_t a = 0; a < A; ++a) {  // assembly 0 assigns the vertex ids the others look up: one launch each
+        for (uint32_t a = 0; a < A && mode != GRAPH_DG_EDGES; ++a) {  // assembly 0 assigns the vertex ids the others look up
             Assembly *as = h->asms[a];
             const uint32_t n = (uint32_t)as->n_mx;
             VertexParams vp;
@@ -394,10 +418,31 @@ int build_graph(mxg_handle *h)
             vp.vrec = h->g_vrec.as<uint32_t>() + (size_t)a * nvs;
             vp.fv = h->g_fv.as<uint32_t>() + (size_t)a * nvs;
             vp.frec = h->g_frec.as<uint32_t>() + (size_t)a * nvs;
+            vp.ivid = nullptr;
+            if (mode == GRAPH_DG_VERTICES) {
+                MXG_HIP(h, as->d_ivid.ensure((size_t)n * 4 + 16));
+                MXG_HIP(h, hipMemsetAsync(as->d_ivid.p, 0xFF, (size_t)n * 4, h->stream));
+                vp.ivid = as->d_ivid.as<uint32_t>();
+            }
             hipLaunchKernelGGL(k_vertices, dim3((n + TILE - 1) / TILE), dim3(256), 0, h->stream, vp);
         }
-        hipLaunchKernelGGL(k_adjacency, dim3((uint32_t)((nvs + 255) / 256), A), dim3(256), 0, h->stream, h->g_fv.as<uint32_t>(),
-                           h->g_frec.as<uint32_t>(), ctl, h->g_nxt.as<uint32_t>(), d_prv, (uint32_t)nvs);
+        if (mode == GRAPH_DG_VERTICES) {  // the caller exchanges vertex ids and adjacency, then calls GRAPH_DG_EDGES
+            MXG_HIP(h, hipMemcpyAsync(hctl, ctl, (size_t)A * 8, hipMemcpyDeviceToHost, h->stream));
+            MXG_HIP(h, hipStreamSynchronize(h->stream));
+            g.nv = hctl[0];
+            g.nv_stride = nvs;
+            return MXG_OK;
+        }
+        if (mode == GRAPH_FULL) {
+            hipLaunchKernelGGL(k_adjacency, dim3((uint32_t)((nvs + 255) / 256), A), dim3(256), 0, h->stream,
+                               h->g_fv.as<uint32_t>(), h->g_frec.as<uint32_t>(), ctl, h->g_nxt.as<uint32_t>(), d_prv, (uint32_t)nvs);
+        } else {  // GRAPH_DG_EDGES: every local vertex is an item (fv = identity), adjacency from the messages
+            if (n_msgs)
+                hipLaunchKernelGGL(k_apply_msgs, dim3((uint32_t)((n_msgs + 255) / 256)), dim3(256), 0, h->stream,
+                                   static_cast<const uint4 *>(d_msgs), n_msgs, (uint32_t)nvs, h->g_nxt.as<uint32_t>(), d_prv);
+            hipLaunchKernelGGL(k_iota_rows, dim3((uint32_t)((nvs + 255) / 256), A), dim3(256), 0, h->stream,
+                               h->g_fv.as<uint32_t>(), (uint32_t)nvs);
+        }
         MXG_HIP(h, hipGetLastError());
         const uint32_t e_tiles = (n_items + TILE - 1) / TILE;
         MXG_HIP(h, h->g_eflag.ensure(n_items));
@@ -427,6 +472,11 @@ int build_graph(mxg_handle *h)
         hipLaunchKernelGGL(k_edge_flags, dim3(e_blocks), dim3(256), 0, h->stream, ep);  // + per-256 counts
         hipLaunchKernelGGL(k_edges, dim3(e_tiles), dim3(256), 0, h->stream, ep, n_items);
         MXG_HIP(h, hipGetLastError());
+    }
+    if (mode == GRAPH_DG_VERTICES) {  // (an assembly without items: no vertex)
+        g.nv = 0;
+        g.nv_stride = 0;
+        return MXG_OK;
     }
     if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
     MXG_HIP(h, stream_wait(h->stream));  // the stage's only sync; results stay in HBM
@@ -478,7 +528,8 @@ int graph_to_host(mxg_handle *h)
 
 int flags_to_host(mxg_handle *h, Assembly *a)
 {
-    if (!h->graph.valid || !a->flags_valid) return set_err(h, MXG_EINVAL, "call mxg_build_graph first");
+    // (flags also arrive from the owners of the distributed graph stage, without a graph on this handle)
+    if (!a->flags_valid) return set_err(h, MXG_EINVAL, "call mxg_build_graph first");
     if (a->flags_on_host) return MXG_OK;
     MXG_HIP(h, hipSetDevice(h->device));
     int rc = d2h(h, a->h_flags, a->d_flags.p, a->n_mx);

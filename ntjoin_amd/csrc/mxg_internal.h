@@ -108,7 +108,8 @@ struct Assembly {
     std::vector<uint8_t> h_fwd;
     std::vector<uint64_t> rec_first;
     // graph stage
-    DevBuf d_flags, d_slot, d_shared;
+    DevBuf d_flags, d_slot, d_shared, d_ivid;
+    DevBuf d_perm, d_fg, d_frec, d_dgtmp;  // distributed graph stage (dgraph.hip), sender side
     std::vector<uint8_t> h_flags;
     bool flags_valid = false;   // device flags computed
     bool flags_on_host = false; // h_flags mirrors d_flags
@@ -167,6 +168,7 @@ struct mxg_handle {
     std::vector<hipEvent_t> ev_pool;       // every event ever created for timing; [0, ev_used) are in flight
     size_t ev_used = 0;
     std::vector<mxg::TimedSpan> ev_spans;  // not yet folded into tm
+    mxg::DevBuf dg_cnt, dg_cursor;  // dgraph.hip: per-destination counts / cursors
     mxg::Paths paths;
     mxg::DevBuf pbuf[48];  // scratch of paths.hip
     mxg::Segments segs;
@@ -236,9 +238,20 @@ int pack_sketch(mxg_handle *h, Assembly *a, void *d_buf, uint64_t nmax);
 int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t world, uint64_t nmax,
                     const uint64_t *counts, const uint64_t *rec_offsets, uint64_t stride_bytes = 0);
 // graph.hip
-int build_graph(mxg_handle *h);
+enum { GRAPH_FULL = 0, GRAPH_DG_VERTICES = 1, GRAPH_DG_EDGES = 2 };
+int build_graph(mxg_handle *h, int mode = GRAPH_FULL, const void *d_msgs = nullptr, uint64_t n_msgs = 0);
 int graph_to_host(mxg_handle *h);
 int find_paths(mxg_handle *h, int64_t n_min);  // paths.hip
+// dgraph.hip
+int dg_owner_counts(mxg_handle *h, uint32_t world, uint64_t *counts);
+int dg_pack_items(mxg_handle *h, Assembly *a, uint32_t world, uint32_t rec_offset, const uint64_t *starts, void *d_send);
+int dg_set_items(mxg_handle *h, Assembly *a, const void *d_items, uint32_t world, const uint64_t *sec_start,
+                 const uint64_t *sec_count);
+int dg_item_results(mxg_handle *h, Assembly *a, uint32_t gbase, uint32_t world, const uint64_t *sec_start,
+                    const uint64_t *sec_count, void *d_out);
+int dg_msg_counts(mxg_handle *h, Assembly *a, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts);
+int dg_pack_msgs(mxg_handle *h, Assembly *a, uint32_t assembly, uint32_t world, const void *d_bases, const uint64_t *starts,
+                 void *d_send);
 int path_segments(mxg_handle *h, uint32_t assembly);
 int mx_extremes(mxg_handle *h, uint32_t assembly);
 int flush_timers(mxg_handle *h);                // sketch.hip: fold the recorded event pairs into h->tm

@@ -244,3 +244,135 @@ def allgather_inplace(eng, device, group=None):
         torch.cuda.current_stream().synchronize()
         eng.set_sketch_gathered(a, recv.data_ptr(), nmax, counts, zeros)
     return metas
+
+
+# ---- graph stage distributed by hash range (csrc/dgraph.hip) ------------------------------------------------------
+def _u64p(arr):
+    import ctypes as C
+    return arr.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _grow(cache, key, n_bytes, dev):
+    t = cache.get(key)
+    if t is None or t.numel() < n_bytes:
+        t = torch.empty(max(int(n_bytes * 5 // 4) + 256, 256), dtype=torch.uint8, device=dev)
+        cache[key] = t
+    return t
+
+
+def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
+    """The graph stage without replication: every minimizer goes to the rank that owns its hash (all-to-all), the owner
+    decides uniqueness / intersection for its hashes and numbers its vertices, the verdicts come back, the adjacency of
+    this rank's records goes to the owners of the end points, and every owner emits its edges.  Work and memory per rank
+    stay constant as ranks are added (the union path does N times the work on every rank).
+
+    Returns the OWNER engine of this rank (created on first use, reused afterwards).  owner.get_graph() is this rank's
+    part: vertex arrays of its own vertices, edges with edge_u = local vertex index, edge_v = GLOBAL vertex id; global
+    id = owner.dg["base"] + local index.  owner.dg also holds the global totals ("vertices", "edges") and "bases".
+    eng.get_mx_flags(a) afterwards are the flags of this rank's own minimizers."""
+    import ctypes as C
+    from .engine import MxEngine
+    if stream is not None and torch.cuda.current_stream() != stream:
+        with torch.cuda.stream(stream):
+            return partitioned_graph(eng, k, w, device, owner, group, stream)
+    lib, A = eng._lib, eng.n_assemblies
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device("cuda", device)
+    sync = torch.cuda.current_stream().synchronize
+    if owner is None:
+        owner = MxEngine(k=k, w=w, device=device, timing=True, stream=stream.cuda_stream if stream is not None else None)
+        owner._rec_off = []
+        for a in range(A):
+            ids_local = [f"r{rank}:{x}" for x in eng.record_ids(a, eng.n_records(a))]
+            all_ids = [None] * world
+            dist.all_gather_object(all_ids, ids_local, group=group)
+            owner._rec_off.append(sum(len(p) for p in all_ids[:rank]))
+            owner.add_minimizers(eng.assembly_name(a), eng.assembly_weight(a), np.zeros(0, np.uint64), np.zeros(0, np.uint32),
+                                 np.zeros(0, np.uint32), [x for part in all_ids for x in part])
+        owner._buf = {}
+        owner.dg = {}
+    buf = owner._buf
+
+    def chk(e, rc):
+        if rc < 0:
+            e._check(rc)
+
+    # 1. where do my minimizers go: cnt[a][dest]
+    cnt = np.zeros(A * world, dtype=np.uint64)
+    chk(eng, lib.mxg_dg_owner_counts(eng._h, world, _u64p(cnt)))
+    cnt = cnt.reshape(A, world).astype(np.int64)
+    to_dest = cnt.sum(axis=0)                                  # items per destination
+    dest_start = np.concatenate([[0], np.cumsum(to_dest)[:-1]])
+    n_send = int(to_dest.sum())
+    send = _grow(buf, "send", n_send * 16, dev)
+    for a in range(A):                                         # layout of the send buffer: [dest][assembly]
+        starts = (dest_start + cnt[:a].sum(axis=0)).astype(np.uint64)
+        chk(eng, lib.mxg_dg_pack_items(eng._h, a, world, owner._rec_off[a], _u64p(starts), C.c_void_p(send.data_ptr())))
+    # 2. tell every destination how much of which assembly is coming
+    c_out = torch.from_numpy(np.ascontiguousarray(cnt.T)).to(dev)          # [dest][a]
+    c_in = torch.empty_like(c_out)
+    dist.all_to_all_single(c_in.view(-1), c_out.view(-1), group=group)
+    got = c_in.cpu().numpy()                                   # [src][a]   (host sync)
+    from_src = got.sum(axis=1)
+    src_start = np.concatenate([[0], np.cumsum(from_src)[:-1]])
+    n_recv = int(from_src.sum())
+    # 3. the items
+    recv = _grow(buf, "recv", n_recv * 16, dev)
+    dist.all_to_all_single(recv[:n_recv * 16].view(n_recv, 16), send[:n_send * 16].view(n_send, 16),
+                           output_split_sizes=from_src.tolist(), input_split_sizes=to_dest.tolist(), group=group)
+    # 4. owner: uniqueness, intersection, local vertex ids
+    secs = []
+    for a in range(A):
+        sec_start = (src_start + got[:, :a].sum(axis=1)).astype(np.uint64)
+        sec_count = got[:, a].astype(np.uint64)
+        secs.append((sec_start, sec_count))
+        chk(owner, lib.mxg_dg_set_items(owner._h, a, C.c_void_p(recv.data_ptr()), world, _u64p(sec_start), _u64p(sec_count)))
+    nv_local = C.c_uint64()
+    chk(owner, lib.mxg_dg_vertices(owner._h, C.byref(nv_local)))
+    # 5. global vertex ids: rank r's vertices are [bases[r], bases[r + 1])
+    mine = torch.tensor([nv_local.value], dtype=torch.int64, device=dev)
+    every = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(every, mine, group=group)
+    nvs = every.cpu().numpy()
+    bases = np.concatenate([[0], np.cumsum(nvs)]).astype(np.int64)
+    if bases[-1] >= (1 << 32) - 1:
+        raise OverflowError("more than 2^32 - 2 vertices")
+    bases_dev = torch.from_numpy(bases.astype(np.uint32).view(np.int32)).to(dev)
+    # 6. the verdicts travel back along the same splits
+    ret_out = _grow(buf, "ret_out", n_recv * 8, dev)
+    for a in range(A):
+        chk(owner, lib.mxg_dg_item_results(owner._h, a, int(bases[rank]), world, _u64p(secs[a][0]), _u64p(secs[a][1]),
+                                           C.c_void_p(ret_out.data_ptr())))
+    ret_in = _grow(buf, "ret_in", n_send * 8, dev)
+    dist.all_to_all_single(ret_in[:n_send * 8].view(n_send, 8), ret_out[:n_recv * 8].view(n_recv, 8),
+                           output_split_sizes=to_dest.tolist(), input_split_sizes=from_src.tolist(), group=group)
+    # 7. adjacency of MY records -> messages to the owners of the two end points
+    mcnt = np.zeros((A, world), dtype=np.int64)
+    for a in range(A):
+        c = np.zeros(world, dtype=np.uint64)
+        chk(eng, lib.mxg_dg_msg_counts(eng._h, a, world, C.c_void_p(ret_in.data_ptr()), C.c_void_p(bases_dev.data_ptr()), _u64p(c)))
+        mcnt[a] = c.astype(np.int64)
+    m_to = mcnt.sum(axis=0)
+    m_start = np.concatenate([[0], np.cumsum(m_to)[:-1]])
+    n_msend = int(m_to.sum())
+    msend = _grow(buf, "msend", n_msend * 16, dev)
+    for a in range(A):                                         # messages carry their assembly: one bucket per destination
+        starts = (m_start + mcnt[:a].sum(axis=0)).astype(np.uint64)
+        chk(eng, lib.mxg_dg_pack_msgs(eng._h, a, world, C.c_void_p(bases_dev.data_ptr()), _u64p(starts), C.c_void_p(msend.data_ptr())))
+    m_out = torch.from_numpy(m_to).to(dev)
+    m_in = torch.empty_like(m_out)
+    dist.all_to_all_single(m_in, m_out, group=group)
+    m_from = m_in.cpu().numpy()
+    n_mrecv = int(m_from.sum())
+    mrecv = _grow(buf, "mrecv", n_mrecv * 16, dev)
+    dist.all_to_all_single(mrecv[:n_mrecv * 16].view(n_mrecv, 16), msend[:n_msend * 16].view(n_msend, 16),
+                           output_split_sizes=m_from.tolist(), input_split_sizes=m_to.tolist(), group=group)
+    # 8. owner: edges whose first supporter's source vertex is mine
+    sync()                                                     # (the owner handle may run on its own stream)
+    chk(owner, lib.mxg_dg_edges(owner._h, C.c_void_p(mrecv.data_ptr()), n_mrecv))
+    st = owner.stats()
+    tot = torch.tensor([st["vertices"], st["edges"]], dtype=torch.int64, device=dev)
+    dist.all_reduce(tot, group=group)
+    tot = tot.cpu().numpy()
+    owner.dg = {"base": int(bases[rank]), "bases": bases, "vertices": int(tot[0]), "edges": int(tot[1])}
+    return owner

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ntjoin_amd.dist import allgather_union_graph  # noqa: E402
+from ntjoin_amd.dist import allgather_union_graph, partitioned_graph  # noqa: E402
 from ntjoin_amd.engine import MxEngine  # noqa: E402
 
 
@@ -48,6 +48,18 @@ def main():
     for _step in range(2):                      # the second step reuses the union handle and its exchange buffers
         eng.sketch(-2)
         union = allgather_union_graph(eng, k, w, 0, union, stream=xs)
+    # the same graph, distributed by hash range: every rank ends up with its own vertices and edges
+    owner = None
+    for _step in range(2):
+        eng.sketch(-2)
+        owner = partitioned_graph(eng, k, w, 0, owner, stream=xs)
+    pg = owner.get_graph()
+    part = {"base": owner.dg["base"], "vhash": pg["vertex_hash"].tolist(),
+            "vpos": pg["vertex_pos"].tolist(), "vrec": pg["vertex_record"].tolist(),
+            "edges": list(zip(pg["edge_u"].tolist(), pg["edge_v"].tolist(), pg["edge_support"].tolist(), pg["edge_weight"].tolist())),
+            "rank": rank, "flags": [eng.get_mx_flags(a).tolist() for a in range(len(asms))], "totals": (owner.dg["vertices"], owner.dg["edges"])}
+    parts = [None] * world
+    dist.all_gather_object(parts, part)
     ok = True
     if rank == 0:
         with MxEngine(k=k, w=w, device=0) as whole:
@@ -70,6 +82,36 @@ def main():
                 if whole.record_ids(a, whole.n_records(a)) != union.record_ids(a, union.n_records(a)):
                     ok = False
                     os.write(1, f"MISMATCH ids {a}\n".encode())
+            # --- partitioned graph against the same single handle ---
+            parts.sort(key=lambda p: p["base"])
+            ghash = [h for p in parts for h in p["vhash"]]
+            names0 = g0["vertex_hash"].tolist()
+            want_e = {(names0[u], names0[v]): (s_, w_) for u, v, s_, w_ in
+                      zip(g0["edge_u"].tolist(), g0["edge_v"].tolist(), g0["edge_support"].tolist(), g0["edge_weight"].tolist())}
+            got_e = {}
+            for p in parts:
+                for u, v, s_, w_ in p["edges"]:
+                    got_e[(p["vhash"][u], ghash[v])] = (s_, w_)
+            n_e = sum(len(p["edges"]) for p in parts)
+            want_v = {h: (tuple(int(g0["vertex_pos"][a][i]) for a in range(len(asms))),
+                          tuple(int(g0["vertex_record"][a][i]) for a in range(len(asms)))) for i, h in enumerate(names0)}
+            got_v = {h: (tuple(p["vpos"][a][i] for a in range(len(asms))), tuple(p["vrec"][a][i] for a in range(len(asms))))
+                     for p in parts for i, h in enumerate(p["vhash"])}
+            if sorted(ghash) != sorted(names0) or got_v != want_v:
+                ok = False
+                os.write(1, f"MISMATCH partitioned vertices {len(ghash)} vs {len(names0)}\n".encode())
+            if got_e != want_e or n_e != len(want_e):
+                ok = False
+                os.write(1, f"MISMATCH partitioned edges {n_e} / {len(got_e)} vs {len(want_e)}\n".encode())
+            if any(p["totals"] != (len(names0), len(want_e)) for p in parts):
+                ok = False
+                os.write(1, f"MISMATCH partitioned totals {[p['totals'] for p in parts]}\n".encode())
+            byrank = sorted(parts, key=lambda p: p["base"])
+            for a in range(len(asms)):
+                cat = [f for p in sorted(parts, key=lambda q: q["rank"]) for f in p["flags"][a]]
+                if cat != whole.get_mx_flags(a).tolist():
+                    ok = False
+                    os.write(1, f"MISMATCH partitioned flags {a}\n".encode())
             os.write(1, f"union: {len(g1['vertex_hash'])} vertices, {len(g1['edge_u'])} edges; sketches "
                         f"{[union.sketch_size(a) for a in range(len(asms))]} whole {[whole.sketch_size(a) for a in range(len(asms))]}\n".encode())
             if len(g1["vertex_hash"]) < 100 or len(g1["edge_u"]) < 50:
@@ -78,6 +120,7 @@ def main():
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     union.close()
+    owner.close()
     eng.close()
     dist.destroy_process_group()
     os.write(1, f"DIST2 {'OK' if int(flag) == 1 else 'FAILED'} rank {rank}\n".encode())  # one write: no interleaving
