@@ -10,8 +10,12 @@ handed back through the C-ABI.  Workload = BASELINE.json configs[1]: 1 x 100 Mbp
 a target derived from it (weight 1), k=32, w=1000.  metric = Gbp/s = (sum of bases over all assemblies) / time.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank sketches its own
-100 Mbp + 100 Mbp shard of an N-times larger genome, the per-assembly sketches are exchanged with ONE RCCL
-all-gather each (the path's only exchange step), and every rank builds the graph of the union.
+100 Mbp + 100 Mbp shard of an N-times larger genome; then the graph of the WHOLE genome is built, either
+"union": one RCCL all-gather of the sketches and every rank builds the whole graph (N times the graph work on every
+rank, but only one collective: cheapest while a rank's share is small, as in configs[1]), or "partitioned": the graph
+stage distributed by hash range over RCCL all-to-alls (ntjoin_amd/dist.py, csrc/dgraph.hip), whose work per rank does
+not grow with N (measured on one GPU: 0.64 ms vs 0.26 ms per step at 100 Mbp per rank, 1.48 ms vs 0.78 ms x N at
+1 Gbp per rank).  Default: partitioned when N >= 4 and --mbp >= 400; MXG_BENCH_GRAPH=union|partitioned overrides.
 """
 import argparse
 import json
@@ -115,7 +119,7 @@ def main():
 
     from ntjoin_amd import synth
     from ntjoin_amd.engine import MxEngine
-    from ntjoin_amd.dist import allgather_union_graph
+    from ntjoin_amd.dist import allgather_union_graph, partitioned_graph, partitioned_totals
 
     n_bases = int(args.mbp * 1e6)
     ref, tgt = synth.config2(seed=1 + 100 * rank, n_bases=n_bases)
@@ -131,11 +135,14 @@ def main():
         keep.append(d)
         eng.add_packed_device(name, weight, d.data_ptr(), starts, lens)
     union = None
+    graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("partitioned" if world >= 4 and args.mbp >= 400 else "union")
 
     def step():
         nonlocal union
         eng.sketch(-2)  # MXG_SKETCH_ALL: both assemblies enqueued back to back, one host sync
-        if world > 1 or force_dist:
+        if (world > 1 or force_dist) and graph_mode == "partitioned":
+            union = partitioned_graph(eng, K, W, local_rank, union, stream=xstream)   # this rank's part of the graph
+        elif world > 1 or force_dist:
             union = allgather_union_graph(eng, K, W, local_rank, union, stream=xstream)
         else:
             eng.build_graph()
@@ -165,7 +172,11 @@ def main():
         bases_total = float(bases_rank)
 
     st = eng.stats()
-    gst = (union.stats() if union is not None else st)
+    if union is not None and graph_mode == "partitioned":
+        gst = dict(union.stats())
+        gst.update(partitioned_totals(union))      # global vertex / edge counts (collectives: every rank calls)
+    else:
+        gst = (union.stats() if union is not None else st)
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = bases_total * args.steps / dt / 1e9
@@ -190,7 +201,9 @@ def main():
                                    "k=32 w=1000, weights 2/1, bases resident in HBM (2-bit packed)",
                        "k": K, "w": W, "bases_per_step": int(bases_total), "minimizers": int(st["minimizers"]),
                        "vertices": int(gst["vertices"]), "edges": int(gst["edges"]),
-                       "parallelism": f"contig-sharded x{world}, RCCL all-gather of sketches" if world > 1 else "1 GPU"},
+                       "parallelism": ("1 GPU" if world == 1 else f"contig-sharded x{world}, " +
+                                       ("graph stage partitioned by hash range (RCCL all-to-all)" if graph_mode == "partitioned"
+                                        else "RCCL all-gather of sketches, graph of the union on every rank"))},
             "roofline": {"bound": "hbm", "kernel": "k_hash (ntHash fwd/rc rolling + candidate filter)",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,

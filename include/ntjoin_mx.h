@@ -256,29 +256,30 @@ int mxg_mx_extremes(mxg_handle *h, int assembly, const uint32_t **min_pos, const
      mxg_dg_owner_counts  counts[a * world + r] = minimizers of assembly a owned by rank r
      mxg_dg_pack_items    assembly a's minimizers as 16-byte items {hash, pos, record + rec_offset}, bucket r starting at
                           item starts[r] of d_send
-     mxg_dg_msg_counts    after the verdicts came back (d_ret: 8 bytes per item, same layout as d_send): flags of assembly
-                          a, and counts[r] = adjacency messages for rank r; d_bases = device array [world + 1], first global
-                          vertex id of every rank
+     mxg_dg_msg_counts    after the verdicts came back (d_ret: 8 bytes per item, same layout as d_send): flags of every
+                          assembly, and counts[a * world + r] = adjacency messages of assembly a for rank r; d_bases =
+                          device array u32[world + 1], first global vertex id of every rank
      mxg_dg_pack_msgs     those messages (16 bytes each), bucket r starting at message starts[r] of d_send
    Owner side (a second handle with the same assemblies registered, no sketches):
      mxg_dg_set_items     assembly a's received items: source s's section starts at item sec_start[s] of d_items and holds
                           sec_count[s] items
-     mxg_dg_vertices      uniqueness, intersection, local vertex ids; *n_vertices = this owner's vertices
+     mxg_dg_vertices      uniqueness, intersection, local vertex ids; the owner's vertex count is written to the DEVICE
+                          word d_n_vertices (u64) -- no host sync
      mxg_dg_item_results  the verdict of every item (flags | global vertex id << 8, or 2^32-1 << 8) written to d_out at the
-                          item's place in the receive layout; gbase = this owner's first global vertex id
+                          item's place in the receive layout; d_gbase = device u32 holding this owner's first global id
      mxg_dg_edges         adjacency from the received messages, then the edges whose first supporter's source vertex is
-                          local; afterwards mxg_get_graph gives this owner's vertices and edges (edge_u: local vertex index,
-                          edge_v: global vertex id) */
+                          local (the stage's sync); afterwards mxg_get_graph gives this owner's vertices and edges
+                          (edge_u: local vertex index, edge_v: global vertex id) */
 int mxg_dg_owner_counts(mxg_handle *h, uint32_t world, uint64_t *counts);
 int mxg_dg_pack_items(mxg_handle *h, int assembly, uint32_t world, uint32_t rec_offset, const uint64_t *starts, void *d_send);
 int mxg_dg_set_items(mxg_handle *h, int assembly, const void *d_items, uint32_t world, const uint64_t *sec_start,
                      const uint64_t *sec_count);
-int mxg_dg_vertices(mxg_handle *h, uint64_t *n_vertices);
-int mxg_dg_item_results(mxg_handle *h, int assembly, uint32_t gbase, uint32_t world, const uint64_t *sec_start,
+int mxg_dg_vertices(mxg_handle *h, void *d_n_vertices);
+int mxg_dg_item_results(mxg_handle *h, int assembly, const void *d_gbase, uint32_t world, const uint64_t *sec_start,
                         const uint64_t *sec_count, void *d_out);
-int mxg_dg_msg_counts(mxg_handle *h, int assembly, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts);
+int mxg_dg_msg_counts(mxg_handle *h, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts);
 int mxg_dg_pack_msgs(mxg_handle *h, int assembly, uint32_t world, const void *d_bases, const uint64_t *starts, void *d_send);
-int mxg_dg_edges(mxg_handle *h, const void *d_msgs, uint64_t n_msgs);
+int mxg_dg_edges(mxg_handle *h, const void *d_msgs, uint64_t n_msgs, uint64_t *n_vertices, uint64_t *n_edges);
 
 /* ---- text helpers used by the writers (host only; usable without a device) --------------------- */
 /* python repr() of a float / of a str, as Ntjoin.print_graph's f-strings produce them.  Returns the length

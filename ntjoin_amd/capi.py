@@ -154,11 +154,11 @@ def load():
     L.mxg_dg_owner_counts.argtypes = [vp, C.c_uint32, pu64]
     L.mxg_dg_pack_items.argtypes = [vp, i32, C.c_uint32, C.c_uint32, pu64, vp]
     L.mxg_dg_set_items.argtypes = [vp, i32, vp, C.c_uint32, pu64, pu64]
-    L.mxg_dg_vertices.argtypes = [vp, pu64]
-    L.mxg_dg_item_results.argtypes = [vp, i32, C.c_uint32, C.c_uint32, pu64, pu64, vp]
-    L.mxg_dg_msg_counts.argtypes = [vp, i32, C.c_uint32, vp, vp, pu64]
+    L.mxg_dg_vertices.argtypes = [vp, vp]
+    L.mxg_dg_item_results.argtypes = [vp, i32, vp, C.c_uint32, pu64, pu64, vp]
+    L.mxg_dg_msg_counts.argtypes = [vp, C.c_uint32, vp, vp, pu64]
     L.mxg_dg_pack_msgs.argtypes = [vp, i32, C.c_uint32, vp, pu64, vp]
-    L.mxg_dg_edges.argtypes = [vp, vp, u64]
+    L.mxg_dg_edges.argtypes = [vp, vp, u64, pu64, pu64]
     L.mxg_write_dot.argtypes = [vp, cp]
     L.mxg_py_repr_double.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
     L.mxg_py_repr_double.restype = C.c_size_t

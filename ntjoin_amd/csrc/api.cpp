@@ -88,6 +88,7 @@ void mxg_destroy(mxg_handle *h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->pinned_ctrl) (void)hipHostFree(h->pinned_ctrl);
     if (h->pinned_gctl) (void)hipHostFree(h->pinned_gctl);
+    if (h->pinned_dg) (void)hipHostFree(h->pinned_dg);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -595,32 +596,24 @@ int mxg_dg_set_items(mxg_handle *h, int assembly, const void *d_items, uint32_t 
     DG_TRY(dg_set_items(h, a, d_items, world, sec_start, sec_count))
 }
 
-int mxg_dg_vertices(mxg_handle *h, uint64_t *n_vertices)
+int mxg_dg_vertices(mxg_handle *h, void *d_n_vertices)
 {
-    if (!h || !n_vertices) return MXG_EINVAL;
-    try {
-        int rc = build_graph(h, GRAPH_DG_VERTICES);
-        if (rc != MXG_OK) return rc;
-    } catch (const std::bad_alloc &) {
-        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_dg_vertices");
-    }
-    *n_vertices = h->graph.nv;
-    return MXG_OK;
+    if (!h || !d_n_vertices) return MXG_EINVAL;
+    DG_TRY(build_graph(h, GRAPH_DG_VERTICES, d_n_vertices, 0))
 }
 
-int mxg_dg_item_results(mxg_handle *h, int assembly, uint32_t gbase, uint32_t world, const uint64_t *sec_start,
+int mxg_dg_item_results(mxg_handle *h, int assembly, const void *d_gbase, uint32_t world, const uint64_t *sec_start,
                         const uint64_t *sec_count, void *d_out)
 {
     Assembly *a = get_asm(h, assembly);
-    if (!a || !d_out || !sec_start || !sec_count) return MXG_EINVAL;
-    DG_TRY(dg_item_results(h, a, gbase, world, sec_start, sec_count, d_out))
+    if (!a || !d_gbase || !d_out || !sec_start || !sec_count) return MXG_EINVAL;
+    DG_TRY(dg_item_results(h, a, d_gbase, world, sec_start, sec_count, d_out))
 }
 
-int mxg_dg_msg_counts(mxg_handle *h, int assembly, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts)
+int mxg_dg_msg_counts(mxg_handle *h, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts)
 {
-    Assembly *a = get_asm(h, assembly);
-    if (!a || !d_ret || !d_bases || !counts || world == 0 || world > 64) return MXG_EINVAL;
-    DG_TRY(dg_msg_counts(h, a, world, d_ret, d_bases, counts))
+    if (!h || !d_ret || !d_bases || !counts || world == 0 || world > 64) return MXG_EINVAL;
+    DG_TRY(dg_msg_counts(h, world, d_ret, d_bases, counts))
 }
 
 int mxg_dg_pack_msgs(mxg_handle *h, int assembly, uint32_t world, const void *d_bases, const uint64_t *starts, void *d_send)
@@ -630,10 +623,18 @@ int mxg_dg_pack_msgs(mxg_handle *h, int assembly, uint32_t world, const void *d_
     DG_TRY(dg_pack_msgs(h, a, (uint32_t)assembly, world, d_bases, starts, d_send))
 }
 
-int mxg_dg_edges(mxg_handle *h, const void *d_msgs, uint64_t n_msgs)
+int mxg_dg_edges(mxg_handle *h, const void *d_msgs, uint64_t n_msgs, uint64_t *n_vertices, uint64_t *n_edges)
 {
     if (!h || (n_msgs && !d_msgs)) return MXG_EINVAL;
-    DG_TRY(build_graph(h, GRAPH_DG_EDGES, d_msgs, n_msgs))
+    try {
+        int rc = build_graph(h, GRAPH_DG_EDGES, d_msgs, n_msgs);
+        if (rc != MXG_OK) return rc;
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_dg_edges");
+    }
+    if (n_vertices) *n_vertices = h->graph.nv;
+    if (n_edges) *n_edges = h->graph.ne;
+    return MXG_OK;
 }
 
 int mxg_write_dot(mxg_handle *h, const char *path)

@@ -13,6 +13,7 @@
 //   k_dg_shared_cnt / k_dg_compact      <--  (flags | global vertex id << 8 per item, in the sender's bucket order)
 //   k_dg_msg_count / k_dg_pack_msgs     -->  build_graph(GRAPH_DG_EDGES): k_apply_msgs, k_edge_flags, k_edges
 #include <algorithm>
+#include <cstring>
 
 #include "mxg_internal.h"
 #include "scan_kernels.h"
@@ -28,33 +29,37 @@ __device__ __forceinline__ uint32_t dg_owner(uint64_t hash, uint32_t world)
     return (uint32_t)(((uint64_t)m * world) >> 32);
 }
 
-// all lanes of a wave: cnt[key] += number of active lanes holding that key (one atomic per distinct key and wave)
-__device__ __forceinline__ void wave_hist(unsigned long long *cnt, uint32_t key, bool active)
+// Bucketing by destination without hot atomics.  A block owns DG_IPB consecutive items: it builds the histogram of
+// their destinations in LDS (one LDS atomic per wave and distinct key), then touches global memory once per destination
+// -- to add its counts (counting kernels) or to reserve its range of every bucket (packing kernels); inside a reserved
+// range the slots come from LDS cursors.  (One global atomic per wave and key: 62 k same-address atomics for 4 M items
+// on a single rank, ~10 ns each.)
+constexpr uint32_t DG_IPB = 4096;  // items per block (16 rounds of 256 threads)
+
+__device__ __forceinline__ void lds_hist(uint32_t *lh, uint32_t key, bool active)
 {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint64_t todo = __ballot(active); todo;) {
         const int leader = __builtin_ctzll(todo);
         const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
         const uint64_t same = __ballot(active && key == k0);
-        if ((int)lane == leader) atomicAdd(&cnt[k0], (unsigned long long)__popcll(same));
+        if ((int)lane == leader) atomicAdd(&lh[k0], (uint32_t)__popcll(same));
         todo &= ~same;
     }
 }
-// all lanes of a wave: a slot in bucket `key` for every active lane (cursor[key] advances by the bucket's lanes)
-__device__ __forceinline__ uint64_t wave_slot(unsigned long long *cursor, uint32_t key, bool active)
+// a slot inside the block's range of bucket `key` (lcur[key] advances by the wave's lanes of that key)
+__device__ __forceinline__ uint32_t lds_slot(uint32_t *lcur, uint32_t key, bool active)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    uint64_t slot = 0;
+    uint32_t slot = 0;
     for (uint64_t todo = __ballot(active); todo;) {
         const int leader = __builtin_ctzll(todo);
         const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
         const uint64_t same = __ballot(active && key == k0);
-        unsigned long long base = 0;
-        if ((int)lane == leader) base = atomicAdd(&cursor[k0], (unsigned long long)__popcll(same));
-        const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader);
-        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader);
-        if (active && key == k0)
-            slot = (((uint64_t)bhi << 32) | blo) + (uint64_t)__popcll(same & ((1ull << lane) - 1ull));
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&lcur[k0], (uint32_t)__popcll(same));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (active && key == k0) slot = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
         todo &= ~same;
     }
     return slot;
@@ -63,9 +68,17 @@ __device__ __forceinline__ uint64_t wave_slot(unsigned long long *cursor, uint32
 __global__ __launch_bounds__(256) void k_dg_owner_count(const uint64_t *__restrict__ hash, uint64_t n, uint32_t world,
                                                         unsigned long long *cnt)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    const bool in = i < n;
-    wave_hist(cnt, in ? dg_owner(hash[i], world) : 0u, in);
+    __shared__ uint32_t lh[64];
+    if (threadIdx.x < 64) lh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * DG_IPB;
+    for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
+        const uint64_t i = i0 + it * 256u + threadIdx.x;
+        const bool in = i < n;
+        lds_hist(lh, in ? dg_owner(hash[i], world) : 0u, in);
+    }
+    __syncthreads();
+    if (threadIdx.x < world && lh[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
 }
 
 // item = {hash, pos, global record}; perm[i] = where minimizer i went in the send buffer
@@ -73,13 +86,31 @@ __global__ __launch_bounds__(256) void k_dg_pack_items(const uint64_t *__restric
                                                        const uint32_t *__restrict__ rec, uint64_t n, uint32_t world,
                                                        uint32_t rec_off, unsigned long long *cursor, uint4 *items, uint32_t *perm)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    const bool in = i < n;
-    const uint64_t h = in ? hash[i] : 0;
-    const uint64_t s = wave_slot(cursor, in ? dg_owner(h, world) : 0u, in);
-    if (!in) return;
-    items[s] = make_uint4((uint32_t)h, (uint32_t)(h >> 32), pos[i], rec[i] + rec_off);
-    perm[i] = (uint32_t)s;
+    __shared__ uint32_t lh[64], lcur[64];
+    __shared__ unsigned long long lbase[64];
+    if (threadIdx.x < 64) lh[threadIdx.x] = lcur[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * DG_IPB;
+    for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
+        const uint64_t i = i0 + it * 256u + threadIdx.x;
+        const bool in = i < n;
+        lds_hist(lh, in ? dg_owner(hash[i], world) : 0u, in);
+    }
+    __syncthreads();
+    if (threadIdx.x < world) lbase[threadIdx.x] = lh[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)lh[threadIdx.x]) : 0ull;
+    __syncthreads();
+    for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
+        const uint64_t i = i0 + it * 256u + threadIdx.x;
+        const bool in = i < n;
+        const uint64_t h = in ? hash[i] : 0;
+        const uint32_t d = in ? dg_owner(h, world) : 0u;
+        const uint32_t sl = lds_slot(lcur, d, in);
+        if (in) {
+            const uint64_t s = lbase[d] + sl;
+            items[s] = make_uint4((uint32_t)h, (uint32_t)(h >> 32), pos[i], rec[i] + rec_off);
+            perm[i] = (uint32_t)s;
+        }
+    }
 }
 
 // The receive buffer holds, per source rank, one section per assembly; assembly a's items are its `world` sections in
@@ -110,10 +141,12 @@ __global__ __launch_bounds__(256) void k_dg_items_to_soa(const uint4 *__restrict
 // what the owner tells the sender about an item: flags | (global vertex id or NONE) << 8, at the item's place in the
 // receive layout (the return trip uses the same splits backwards)
 __global__ __launch_bounds__(256) void k_dg_item_result(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ ivid,
-                                                        const DgSections sc, uint32_t gbase, unsigned long long *out)
+                                                        const DgSections sc, const uint32_t *__restrict__ gbase_ptr,
+                                                        unsigned long long *out)
 {
     const uint64_t o = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (o >= sc.first[sc.world]) return;
+    const uint32_t gbase = *gbase_ptr;  // this owner's first global vertex id, still on the device
     const uint32_t v = ivid[o];
     out[dg_locate(sc, o)] = ((unsigned long long)(v == DG_NONE ? DG_NONE : v + gbase) << 8) | flags[o];
 }
@@ -187,34 +220,65 @@ __global__ __launch_bounds__(256) void k_dg_msg_count(const uint32_t *__restrict
                                                       const uint32_t *__restrict__ n_shared, const uint32_t *__restrict__ bases,
                                                       uint32_t world, unsigned long long *cnt)
 {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    __shared__ uint32_t lh[64];
+    if (threadIdx.x < 64) lh[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t ns = *n_shared;
-    const bool in = r + 1 < ns && frec[r] == frec[r + 1];
-    wave_hist(cnt, in ? dg_vertex_owner(bases, world, fg[r]) : 0u, in);
-    wave_hist(cnt, in ? dg_vertex_owner(bases, world, fg[r + 1]) : 0u, in);
+    const uint32_t r0 = blockIdx.x * DG_IPB;
+    if (r0 + 1 < ns) {
+        for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
+            const uint32_t r = r0 + it * 256u + threadIdx.x;
+            const bool in = r + 1 < ns && frec[r] == frec[r + 1];
+            lds_hist(lh, in ? dg_vertex_owner(bases, world, fg[r]) : 0u, in);
+            lds_hist(lh, in ? dg_vertex_owner(bases, world, fg[r + 1]) : 0u, in);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < world && lh[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void k_dg_pack_msgs(const uint32_t *__restrict__ fg, const uint32_t *__restrict__ frec,
                                                       const uint32_t *__restrict__ n_shared, const uint32_t *__restrict__ bases,
                                                       uint32_t world, uint32_t assembly, unsigned long long *cursor, uint4 *msgs)
 {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    __shared__ uint32_t lh[64], lcur[64];
+    __shared__ unsigned long long lbase[64];
+    if (threadIdx.x < 64) lh[threadIdx.x] = lcur[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t ns = *n_shared;
-    const bool in = r + 1 < ns && frec[r] == frec[r + 1];
-    const uint32_t u = in ? fg[r] : 0u, v = in ? fg[r + 1] : 0u;
-    const uint32_t ou = in ? dg_vertex_owner(bases, world, u) : 0u, ov = in ? dg_vertex_owner(bases, world, v) : 0u;
-    const uint64_t su = wave_slot(cursor, ou, in);
-    const uint64_t sv = wave_slot(cursor, ov, in);
-    if (!in) return;
-    msgs[su] = make_uint4(assembly, u - bases[ou], v, 0u);            // nxt[a][u] = v at the owner of u
-    msgs[sv] = make_uint4(assembly | 256u, v - bases[ov], u, 0u);     // prv[a][v] = u at the owner of v
+    const uint32_t r0 = blockIdx.x * DG_IPB;
+    if (r0 + 1 >= ns) return;  // block-uniform
+    for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
+        const uint32_t r = r0 + it * 256u + threadIdx.x;
+        const bool in = r + 1 < ns && frec[r] == frec[r + 1];
+        lds_hist(lh, in ? dg_vertex_owner(bases, world, fg[r]) : 0u, in);
+        lds_hist(lh, in ? dg_vertex_owner(bases, world, fg[r + 1]) : 0u, in);
+    }
+    __syncthreads();
+    if (threadIdx.x < world) lbase[threadIdx.x] = lh[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)lh[threadIdx.x]) : 0ull;
+    __syncthreads();
+    for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
+        const uint32_t r = r0 + it * 256u + threadIdx.x;
+        const bool in = r + 1 < ns && frec[r] == frec[r + 1];
+        const uint32_t u = in ? fg[r] : 0u, v = in ? fg[r + 1] : 0u;
+        const uint32_t ou = in ? dg_vertex_owner(bases, world, u) : 0u, ov = in ? dg_vertex_owner(bases, world, v) : 0u;
+        const uint32_t su = lds_slot(lcur, ou, in);
+        const uint32_t sv = lds_slot(lcur, ov, in);
+        if (in) {
+            msgs[lbase[ou] + su] = make_uint4(assembly, u - bases[ou], v, 0u);         // nxt[a][u] = v at the owner of u
+            msgs[lbase[ov] + sv] = make_uint4(assembly | 256u, v - bases[ov], u, 0u);  // prv[a][v] = u at the owner of v
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
-static int dg_counts_to_host(mxg_handle *h, DevBuf &b, uint32_t world, uint64_t *out)
+// per-destination counters -> host through pinned memory, polling wait
+static int dg_counts_to_host(mxg_handle *h, size_t n_words, uint64_t *out)
 {
-    MXG_HIP(h, hipMemcpyAsync(out, b.p, (size_t)world * 8, hipMemcpyDeviceToHost, h->stream));
-    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    if (!h->pinned_dg) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_dg, MXG_MAX_ASSEMBLIES * 64 * 8));
+    MXG_HIP(h, hipMemcpyAsync(h->pinned_dg, h->dg_cnt.p, n_words * 8, hipMemcpyDeviceToHost, h->stream));
+    MXG_HIP(h, stream_wait(h->stream));
+    memcpy(out, h->pinned_dg, n_words * 8);
     return MXG_OK;
 }
 
@@ -237,13 +301,13 @@ int dg_owner_counts(mxg_handle *h, uint32_t world, uint64_t *counts)
         Assembly *as = h->asms[a];
         if (!as->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch", as->name.c_str());
         if (as->n_mx)
-            hipLaunchKernelGGL(k_dg_owner_count, dim3((uint32_t)((as->n_mx + 255) / 256)), dim3(256), 0, h->stream,
+            hipLaunchKernelGGL(k_dg_owner_count, dim3((uint32_t)((as->n_mx + DG_IPB - 1) / DG_IPB)), dim3(256), 0, h->stream,
                                as->d_hash.as<uint64_t>(), as->n_mx, world, h->dg_cnt.as<unsigned long long>() + a * 64);
     }
     MXG_HIP(h, hipGetLastError());
     std::vector<uint64_t> tmp(A * 64);
-    MXG_HIP(h, hipMemcpyAsync(tmp.data(), h->dg_cnt.p, A * 64 * 8, hipMemcpyDeviceToHost, h->stream));
-    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    int rc = dg_counts_to_host(h, A * 64, tmp.data());
+    if (rc != MXG_OK) return rc;
     for (size_t a = 0; a < A; ++a)
         for (uint32_t r = 0; r < world; ++r) counts[a * world + r] = tmp[a * 64 + r];
     return MXG_OK;
@@ -257,7 +321,7 @@ int dg_pack_items(mxg_handle *h, Assembly *a, uint32_t world, uint32_t rec_offse
     if (rc != MXG_OK) return rc;
     MXG_HIP(h, a->d_perm.ensure(std::max<uint64_t>(a->n_mx * 4, 16)));
     if (a->n_mx)
-        hipLaunchKernelGGL(k_dg_pack_items, dim3((uint32_t)((a->n_mx + 255) / 256)), dim3(256), 0, h->stream,
+        hipLaunchKernelGGL(k_dg_pack_items, dim3((uint32_t)((a->n_mx + DG_IPB - 1) / DG_IPB)), dim3(256), 0, h->stream,
                            a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(), a->d_rec.as<uint32_t>(), a->n_mx, world, rec_offset,
                            h->dg_cursor.as<unsigned long long>(), static_cast<uint4 *>(d_send), a->d_perm.as<uint32_t>());
     MXG_HIP(h, hipGetLastError());
@@ -309,7 +373,7 @@ int dg_set_items(mxg_handle *h, Assembly *a, const void *d_items, uint32_t world
 
 // owner: verdict per item of assembly a (after build_graph(GRAPH_DG_VERTICES)), written into the return buffer at the
 // places the items came from
-int dg_item_results(mxg_handle *h, Assembly *a, uint32_t gbase, uint32_t world, const uint64_t *sec_start,
+int dg_item_results(mxg_handle *h, Assembly *a, const void *d_gbase, uint32_t world, const uint64_t *sec_start,
                     const uint64_t *sec_count, void *d_out)
 {
     MXG_HIP(h, hipSetDevice(h->device));
@@ -323,50 +387,61 @@ int dg_item_results(mxg_handle *h, Assembly *a, uint32_t gbase, uint32_t world, 
             MXG_HIP(h, hipMemsetAsync(a->d_ivid.p, 0xFF, a->n_mx * 4, h->stream));
         }
         hipLaunchKernelGGL(k_dg_item_result, dim3((uint32_t)((a->n_mx + 255) / 256)), dim3(256), 0, h->stream,
-                           a->d_flags.as<uint8_t>(), a->d_ivid.as<uint32_t>(), sc, gbase, static_cast<unsigned long long *>(d_out));
+                           a->d_flags.as<uint8_t>(), a->d_ivid.as<uint32_t>(), sc, static_cast<const uint32_t *>(d_gbase),
+                           static_cast<unsigned long long *>(d_out));
     }
     MXG_HIP(h, hipGetLastError());
     if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));
     return MXG_OK;
 }
 
-// sender: the verdicts are back (d_ret, send-buffer order).  Flags of assembly a, its shared minimizers in order, and how
-// many adjacency messages go to every rank (counts[world]); d_bases = [world + 1] first global vertex id of every rank
-int dg_msg_counts(mxg_handle *h, Assembly *a, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts)
+// sender: the verdicts are back (d_ret, send-buffer order).  Flags of every assembly, its shared minimizers in order, and
+// how many adjacency messages go to every rank: counts[a * world + r]; d_bases = [world + 1] first global vertex id of
+// every rank (device).  One host sync for all assemblies.
+int dg_msg_counts(mxg_handle *h, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts)
 {
     MXG_HIP(h, hipSetDevice(h->device));
-    const uint32_t n = (uint32_t)a->n_mx;
-    const uint32_t blocks = (n + 255) / 256;
-    MXG_HIP(h, a->d_flags.ensure(std::max<uint32_t>(n, 16)));
-    MXG_HIP(h, h->dg_cnt.ensure(64 * 8 + 64));
-    MXG_HIP(h, a->d_dgtmp.ensure(((size_t)sup_words(blocks) + blocks + 16) * 4));
-    MXG_HIP(h, a->d_fg.ensure((size_t)n * 4 + 16));
-    MXG_HIP(h, a->d_frec.ensure((size_t)n * 4 + 16));
-    uint32_t *sup = a->d_dgtmp.as<uint32_t>(), *cnt = sup + sup_words(blocks), *n_shared = cnt + blocks;
-    MXG_HIP(h, hipMemsetAsync(sup, 0, (size_t)sup_words(blocks) * 4, h->stream));
-    MXG_HIP(h, hipMemsetAsync(n_shared, 0, 4, h->stream));
-    MXG_HIP(h, hipMemsetAsync(h->dg_cnt.p, 0, 64 * 8, h->stream));
-    if (n) {
-        DgAdjParams p;
-        p.ret = static_cast<const unsigned long long *>(d_ret);
-        p.perm = a->d_perm.as<uint32_t>();
-        p.rec = a->d_rec.as<uint32_t>();
-        p.n = n;
-        p.cnt = cnt;
-        p.sup = sup;
-        p.fg = a->d_fg.as<uint32_t>();
-        p.frec = a->d_frec.as<uint32_t>();
-        p.n_shared = n_shared;
-        p.flags_out = a->d_flags.as<uint8_t>();
-        hipLaunchKernelGGL(k_dg_shared_cnt, dim3(blocks), dim3(256), 0, h->stream, p);
-        hipLaunchKernelGGL(k_dg_compact, dim3(blocks), dim3(256), 0, h->stream, p);
-        hipLaunchKernelGGL(k_dg_msg_count, dim3(blocks), dim3(256), 0, h->stream, p.fg, p.frec, n_shared,
-                           static_cast<const uint32_t *>(d_bases), world, h->dg_cnt.as<unsigned long long>());
-        MXG_HIP(h, hipGetLastError());
+    const size_t A = h->asms.size();
+    MXG_HIP(h, h->dg_cnt.ensure(A * 64 * 8 + 64));
+    MXG_HIP(h, hipMemsetAsync(h->dg_cnt.p, 0, A * 64 * 8, h->stream));
+    for (size_t ai = 0; ai < A; ++ai) {
+        Assembly *a = h->asms[ai];
+        const uint32_t n = (uint32_t)a->n_mx;
+        const uint32_t blocks = (n + 255) / 256;
+        MXG_HIP(h, a->d_flags.ensure(std::max<uint32_t>(n, 16)));
+        MXG_HIP(h, a->d_dgtmp.ensure(((size_t)sup_words(blocks) + blocks + 16) * 4));
+        MXG_HIP(h, a->d_fg.ensure((size_t)n * 4 + 16));
+        MXG_HIP(h, a->d_frec.ensure((size_t)n * 4 + 16));
+        uint32_t *sup = a->d_dgtmp.as<uint32_t>(), *cnt = sup + sup_words(blocks), *n_shared = cnt + blocks;
+        MXG_HIP(h, hipMemsetAsync(sup, 0, (size_t)sup_words(blocks) * 4, h->stream));
+        MXG_HIP(h, hipMemsetAsync(n_shared, 0, 4, h->stream));
+        if (n) {
+            DgAdjParams p;
+            p.ret = static_cast<const unsigned long long *>(d_ret);
+            p.perm = a->d_perm.as<uint32_t>();
+            p.rec = a->d_rec.as<uint32_t>();
+            p.n = n;
+            p.cnt = cnt;
+            p.sup = sup;
+            p.fg = a->d_fg.as<uint32_t>();
+            p.frec = a->d_frec.as<uint32_t>();
+            p.n_shared = n_shared;
+            p.flags_out = a->d_flags.as<uint8_t>();
+            hipLaunchKernelGGL(k_dg_shared_cnt, dim3(blocks), dim3(256), 0, h->stream, p);
+            hipLaunchKernelGGL(k_dg_compact, dim3(blocks), dim3(256), 0, h->stream, p);
+            hipLaunchKernelGGL(k_dg_msg_count, dim3((n + DG_IPB - 1) / DG_IPB), dim3(256), 0, h->stream, p.fg, p.frec, n_shared,
+                               static_cast<const uint32_t *>(d_bases), world, h->dg_cnt.as<unsigned long long>() + ai * 64);
+            MXG_HIP(h, hipGetLastError());
+        }
+        a->flags_valid = true;
+        a->flags_on_host = false;
     }
-    a->flags_valid = true;
-    a->flags_on_host = false;
-    return dg_counts_to_host(h, h->dg_cnt, world, counts);
+    std::vector<uint64_t> tmp(A * 64);
+    int rc = dg_counts_to_host(h, A * 64, tmp.data());
+    if (rc != MXG_OK) return rc;
+    for (size_t ai = 0; ai < A; ++ai)
+        for (uint32_t r = 0; r < world; ++r) counts[ai * world + r] = tmp[ai * 64 + r];
+    return MXG_OK;
 }
 
 // sender: the messages of assembly a (after dg_msg_counts), bucket r at message starts[r] of d_send
@@ -380,7 +455,7 @@ int dg_pack_msgs(mxg_handle *h, Assembly *a, uint32_t assembly, uint32_t world, 
     if (rc != MXG_OK) return rc;
     const uint32_t blocks = (n + 255) / 256;
     uint32_t *n_shared = a->d_dgtmp.as<uint32_t>() + sup_words(blocks) + blocks;
-    hipLaunchKernelGGL(k_dg_pack_msgs, dim3(blocks), dim3(256), 0, h->stream, a->d_fg.as<uint32_t>(), a->d_frec.as<uint32_t>(),
+    hipLaunchKernelGGL(k_dg_pack_msgs, dim3((n + DG_IPB - 1) / DG_IPB), dim3(256), 0, h->stream, a->d_fg.as<uint32_t>(), a->d_frec.as<uint32_t>(),
                        n_shared, static_cast<const uint32_t *>(d_bases), world, assembly, h->dg_cursor.as<unsigned long long>(),
                        static_cast<uint4 *>(d_send));
     MXG_HIP(h, hipGetLastError());

@@ -426,11 +426,9 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs)
             }
             hipLaunchKernelGGL(k_vertices, dim3((n + TILE - 1) / TILE), dim3(256), 0, h->stream, vp);
         }
-        if (mode == GRAPH_DG_VERTICES) {  // the caller exchanges vertex ids and adjacency, then calls GRAPH_DG_EDGES
-            MXG_HIP(h, hipMemcpyAsync(hctl, ctl, (size_t)A * 8, hipMemcpyDeviceToHost, h->stream));
-            MXG_HIP(h, hipStreamSynchronize(h->stream));
-            g.nv = hctl[0];
-            g.nv_stride = nvs;
+        if (mode == GRAPH_DG_VERTICES) {  // the caller exchanges vertex ids and adjacency, then calls GRAPH_DG_EDGES;
+            g.nv_stride = nvs;            // no host sync: the vertex count stays on the device (ctl[0]) until then
+            if (d_msgs) MXG_HIP(h, hipMemcpyAsync(const_cast<void *>(d_msgs), ctl, 8, hipMemcpyDeviceToDevice, h->stream));
             return MXG_OK;
         }
         if (mode == GRAPH_FULL) {
@@ -476,6 +474,7 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs)
     if (mode == GRAPH_DG_VERTICES) {  // (an assembly without items: no vertex)
         g.nv = 0;
         g.nv_stride = 0;
+        if (d_msgs) MXG_HIP(h, hipMemsetAsync(const_cast<void *>(d_msgs), 0, 8, h->stream));
         return MXG_OK;
     }
     if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));

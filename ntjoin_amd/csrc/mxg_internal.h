@@ -182,6 +182,7 @@ struct mxg_handle {
         g_ebs, g_eu, g_ev, g_esup, g_ew;  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
     uint64_t arena_cap_hint = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t *pinned_dg = nullptr;    // dgraph.hip: pinned copy of the per-destination counters
     uint64_t *pinned_gctl = nullptr;  // pinned host copy of the graph stage's control block
     uint32_t *pinned_ctrl = nullptr;  // pinned host copies of per-assembly control blocks (pipelined sketch)
 };
@@ -247,9 +248,9 @@ int dg_owner_counts(mxg_handle *h, uint32_t world, uint64_t *counts);
 int dg_pack_items(mxg_handle *h, Assembly *a, uint32_t world, uint32_t rec_offset, const uint64_t *starts, void *d_send);
 int dg_set_items(mxg_handle *h, Assembly *a, const void *d_items, uint32_t world, const uint64_t *sec_start,
                  const uint64_t *sec_count);
-int dg_item_results(mxg_handle *h, Assembly *a, uint32_t gbase, uint32_t world, const uint64_t *sec_start,
+int dg_item_results(mxg_handle *h, Assembly *a, const void *d_gbase, uint32_t world, const uint64_t *sec_start,
                     const uint64_t *sec_count, void *d_out);
-int dg_msg_counts(mxg_handle *h, Assembly *a, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts);
+int dg_msg_counts(mxg_handle *h, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts);
 int dg_pack_msgs(mxg_handle *h, Assembly *a, uint32_t assembly, uint32_t world, const void *d_bases, const uint64_t *starts,
                  void *d_send);
 int path_segments(mxg_handle *h, uint32_t assembly);

@@ -268,8 +268,9 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
 
     Returns the OWNER engine of this rank (created on first use, reused afterwards).  owner.get_graph() is this rank's
     part: vertex arrays of its own vertices, edges with edge_u = local vertex index, edge_v = GLOBAL vertex id; global
-    id = owner.dg["base"] + local index.  owner.dg also holds the global totals ("vertices", "edges") and "bases".
-    eng.get_mx_flags(a) afterwards are the flags of this rank's own minimizers."""
+    id = base + local index with base = partitioned_totals(owner)["base"].  eng.get_mx_flags(a) afterwards are the flags
+    of this rank's own minimizers.  Per step: 6 collectives (two size exchanges, items, verdicts, vertex counts,
+    messages) and 5 host syncs (the split sizes of the two variable all-to-alls must be known on the host)."""
     import ctypes as C
     from .engine import MxEngine
     if stream is not None and torch.cuda.current_stream() != stream:
@@ -278,7 +279,7 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
     lib, A = eng._lib, eng.n_assemblies
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", device)
-    sync = torch.cuda.current_stream().synchronize
+    cur = torch.cuda.current_stream()
     if owner is None:
         owner = MxEngine(k=k, w=w, device=device, timing=True, stream=stream.cuda_stream if stream is not None else None)
         owner._rec_off = []
@@ -290,14 +291,29 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
             owner.add_minimizers(eng.assembly_name(a), eng.assembly_weight(a), np.zeros(0, np.uint64), np.zeros(0, np.uint32),
                                  np.zeros(0, np.uint32), [x for part in all_ids for x in part])
         owner._buf = {}
-        owner.dg = {}
-    buf = owner._buf
+        # small fixed-size staging, pinned on the host side: [world][A] size matrices, [world] message sizes, vertex counts
+        owner._st = {"c_h": torch.empty((world, A), dtype=torch.int64).pin_memory(), "c_out": torch.empty((world, A), dtype=torch.int64, device=dev),
+                     "c_in": torch.empty((world, A), dtype=torch.int64, device=dev), "g_h": torch.empty((world, A), dtype=torch.int64).pin_memory(),
+                     "m_h": torch.empty(world, dtype=torch.int64).pin_memory(), "m_out": torch.empty(world, dtype=torch.int64, device=dev),
+                     "m_in": torch.empty(world, dtype=torch.int64, device=dev), "mi_h": torch.empty(world, dtype=torch.int64).pin_memory(),
+                     "nv": torch.zeros(1, dtype=torch.int64, device=dev), "nvs": torch.empty(world, dtype=torch.int64, device=dev),
+                     "bases": torch.zeros(world + 1, dtype=torch.int32, device=dev)}
+    buf, st = owner._buf, owner._st
+    prof = getattr(owner, "_prof", None)     # tools: owner._prof = {} collects host seconds per section
+    import time as _time
+    t_last = [_time.perf_counter()]
+
+    def mark(name):
+        if prof is not None:
+            now = _time.perf_counter()
+            prof[name] = prof.get(name, 0.0) + now - t_last[0]
+            t_last[0] = now
 
     def chk(e, rc):
         if rc < 0:
             e._check(rc)
 
-    # 1. where do my minimizers go: cnt[a][dest]
+    # 1. where do my minimizers go: cnt[a][dest]                                                  (host sync 1)
     cnt = np.zeros(A * world, dtype=np.uint64)
     chk(eng, lib.mxg_dg_owner_counts(eng._h, world, _u64p(cnt)))
     cnt = cnt.reshape(A, world).astype(np.int64)
@@ -308,71 +324,88 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
     for a in range(A):                                         # layout of the send buffer: [dest][assembly]
         starts = (dest_start + cnt[:a].sum(axis=0)).astype(np.uint64)
         chk(eng, lib.mxg_dg_pack_items(eng._h, a, world, owner._rec_off[a], _u64p(starts), C.c_void_p(send.data_ptr())))
-    # 2. tell every destination how much of which assembly is coming
-    c_out = torch.from_numpy(np.ascontiguousarray(cnt.T)).to(dev)          # [dest][a]
-    c_in = torch.empty_like(c_out)
-    dist.all_to_all_single(c_in.view(-1), c_out.view(-1), group=group)
-    got = c_in.cpu().numpy()                                   # [src][a]   (host sync)
+    mark("1_counts_pack")
+    # 2. tell every destination how much of which assembly is coming                             (host sync 2)
+    st["c_h"].numpy()[:] = cnt.T
+    st["c_out"].copy_(st["c_h"], non_blocking=True)
+    dist.all_to_all_single(st["c_in"].view(-1), st["c_out"].view(-1), group=group)
+    st["g_h"].copy_(st["c_in"], non_blocking=True)
+    cur.synchronize()
+    got = st["g_h"].numpy().copy()                             # [src][a]
     from_src = got.sum(axis=1)
     src_start = np.concatenate([[0], np.cumsum(from_src)[:-1]])
     n_recv = int(from_src.sum())
+    mark("2_size_exchange")
     # 3. the items
     recv = _grow(buf, "recv", n_recv * 16, dev)
     dist.all_to_all_single(recv[:n_recv * 16].view(n_recv, 16), send[:n_send * 16].view(n_send, 16),
                            output_split_sizes=from_src.tolist(), input_split_sizes=to_dest.tolist(), group=group)
-    # 4. owner: uniqueness, intersection, local vertex ids
+    mark("3_items_a2a")
+    # 4. owner: uniqueness, intersection, local vertex ids (the vertex count stays on the device)
     secs = []
     for a in range(A):
         sec_start = (src_start + got[:, :a].sum(axis=1)).astype(np.uint64)
         sec_count = got[:, a].astype(np.uint64)
         secs.append((sec_start, sec_count))
         chk(owner, lib.mxg_dg_set_items(owner._h, a, C.c_void_p(recv.data_ptr()), world, _u64p(sec_start), _u64p(sec_count)))
-    nv_local = C.c_uint64()
-    chk(owner, lib.mxg_dg_vertices(owner._h, C.byref(nv_local)))
-    # 5. global vertex ids: rank r's vertices are [bases[r], bases[r + 1])
-    mine = torch.tensor([nv_local.value], dtype=torch.int64, device=dev)
-    every = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(every, mine, group=group)
-    nvs = every.cpu().numpy()
-    bases = np.concatenate([[0], np.cumsum(nvs)]).astype(np.int64)
-    if bases[-1] >= (1 << 32) - 1:
-        raise OverflowError("more than 2^32 - 2 vertices")
-    bases_dev = torch.from_numpy(bases.astype(np.uint32).view(np.int32)).to(dev)
+    chk(owner, lib.mxg_dg_vertices(owner._h, C.c_void_p(st["nv"].data_ptr())))
+    mark("4_owner_vertices")
+    # 5. global vertex ids: rank r's vertices are [bases[r], bases[r + 1]) -- computed on the device
+    dist.all_gather_into_tensor(st["nvs"], st["nv"], group=group)
+    st["bases"][1:] = torch.cumsum(st["nvs"], 0).to(torch.int32)
+    mark("5_bases")
     # 6. the verdicts travel back along the same splits
     ret_out = _grow(buf, "ret_out", n_recv * 8, dev)
+    gbase_ptr = st["bases"].data_ptr() + 4 * rank
     for a in range(A):
-        chk(owner, lib.mxg_dg_item_results(owner._h, a, int(bases[rank]), world, _u64p(secs[a][0]), _u64p(secs[a][1]),
+        chk(owner, lib.mxg_dg_item_results(owner._h, a, C.c_void_p(gbase_ptr), world, _u64p(secs[a][0]), _u64p(secs[a][1]),
                                            C.c_void_p(ret_out.data_ptr())))
     ret_in = _grow(buf, "ret_in", n_send * 8, dev)
     dist.all_to_all_single(ret_in[:n_send * 8].view(n_send, 8), ret_out[:n_recv * 8].view(n_recv, 8),
                            output_split_sizes=to_dest.tolist(), input_split_sizes=from_src.tolist(), group=group)
-    # 7. adjacency of MY records -> messages to the owners of the two end points
-    mcnt = np.zeros((A, world), dtype=np.int64)
-    for a in range(A):
-        c = np.zeros(world, dtype=np.uint64)
-        chk(eng, lib.mxg_dg_msg_counts(eng._h, a, world, C.c_void_p(ret_in.data_ptr()), C.c_void_p(bases_dev.data_ptr()), _u64p(c)))
-        mcnt[a] = c.astype(np.int64)
+    mark("6_verdicts_a2a")
+    # 7. adjacency of MY records -> messages to the owners of the two end points                  (host sync 3)
+    mcnt = np.zeros(A * world, dtype=np.uint64)
+    chk(eng, lib.mxg_dg_msg_counts(eng._h, world, C.c_void_p(ret_in.data_ptr()), C.c_void_p(st["bases"].data_ptr()), _u64p(mcnt)))
+    mcnt = mcnt.reshape(A, world).astype(np.int64)
     m_to = mcnt.sum(axis=0)
     m_start = np.concatenate([[0], np.cumsum(m_to)[:-1]])
     n_msend = int(m_to.sum())
     msend = _grow(buf, "msend", n_msend * 16, dev)
     for a in range(A):                                         # messages carry their assembly: one bucket per destination
         starts = (m_start + mcnt[:a].sum(axis=0)).astype(np.uint64)
-        chk(eng, lib.mxg_dg_pack_msgs(eng._h, a, world, C.c_void_p(bases_dev.data_ptr()), _u64p(starts), C.c_void_p(msend.data_ptr())))
-    m_out = torch.from_numpy(m_to).to(dev)
-    m_in = torch.empty_like(m_out)
-    dist.all_to_all_single(m_in, m_out, group=group)
-    m_from = m_in.cpu().numpy()
+        chk(eng, lib.mxg_dg_pack_msgs(eng._h, a, world, C.c_void_p(st["bases"].data_ptr()), _u64p(starts), C.c_void_p(msend.data_ptr())))
+    mark("7_msg_counts_pack")
+    st["m_h"].numpy()[:] = m_to
+    st["m_out"].copy_(st["m_h"], non_blocking=True)
+    dist.all_to_all_single(st["m_in"], st["m_out"], group=group)
+    st["mi_h"].copy_(st["m_in"], non_blocking=True)
+    cur.synchronize()                                          #                                     (host sync 4)
+    m_from = st["mi_h"].numpy().copy()
     n_mrecv = int(m_from.sum())
     mrecv = _grow(buf, "mrecv", n_mrecv * 16, dev)
     dist.all_to_all_single(mrecv[:n_mrecv * 16].view(n_mrecv, 16), msend[:n_msend * 16].view(n_msend, 16),
                            output_split_sizes=m_from.tolist(), input_split_sizes=m_to.tolist(), group=group)
-    # 8. owner: edges whose first supporter's source vertex is mine
-    sync()                                                     # (the owner handle may run on its own stream)
-    chk(owner, lib.mxg_dg_edges(owner._h, C.c_void_p(mrecv.data_ptr()), n_mrecv))
-    st = owner.stats()
-    tot = torch.tensor([st["vertices"], st["edges"]], dtype=torch.int64, device=dev)
-    dist.all_reduce(tot, group=group)
-    tot = tot.cpu().numpy()
-    owner.dg = {"base": int(bases[rank]), "bases": bases, "vertices": int(tot[0]), "edges": int(tot[1])}
+    mark("8_msg_exchange")
+    # 8. owner: edges whose first supporter's source vertex is mine                               (host sync 5)
+    if stream is None:
+        cur.synchronize()                                      # the owner handle runs on its own stream
+    nv_l, ne_l = C.c_uint64(), C.c_uint64()
+    chk(owner, lib.mxg_dg_edges(owner._h, C.c_void_p(mrecv.data_ptr()), n_mrecv, C.byref(nv_l), C.byref(ne_l)))
+    mark("9_owner_edges")
+    owner.dg = {"local_vertices": int(nv_l.value), "local_edges": int(ne_l.value), "rank": rank, "world": world}
     return owner
+
+
+def partitioned_totals(owner, group=None):
+    """global figures of the distributed graph (one all-reduce + one all-gather): total vertices / edges, every rank's
+    first global vertex id"""
+    dg = owner.dg
+    dev = owner._st["nv"].device
+    loc = torch.tensor([dg["local_vertices"], dg["local_edges"]], dtype=torch.int64, device=dev)
+    every = torch.empty((dg["world"], 2), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(every.view(-1), loc, group=group)
+    every = every.cpu().numpy()
+    bases = np.concatenate([[0], np.cumsum(every[:, 0])])
+    dg.update({"bases": bases, "base": int(bases[dg["rank"]]), "vertices": int(every[:, 0].sum()), "edges": int(every[:, 1].sum())})
+    return dg

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ntjoin_amd.dist import allgather_union_graph, partitioned_graph  # noqa: E402
+from ntjoin_amd.dist import allgather_union_graph, partitioned_graph, partitioned_totals  # noqa: E402
 from ntjoin_amd.engine import MxEngine  # noqa: E402
 
 
@@ -53,6 +53,7 @@ def main():
     for _step in range(2):
         eng.sketch(-2)
         owner = partitioned_graph(eng, k, w, 0, owner, stream=xs)
+    partitioned_totals(owner)
     pg = owner.get_graph()
     part = {"base": owner.dg["base"], "vhash": pg["vertex_hash"].tolist(),
             "vpos": pg["vertex_pos"].tolist(), "vrec": pg["vertex_record"].tolist(),

@@ -39,10 +39,26 @@ def test_union_graph_single_rank_nccl():
             g0, g1 = eng.get_graph(), union.get_graph()
             for key in g0:
                 assert np.array_equal(np.asarray(g0[key]), np.asarray(g1[key])), key
+            union_flags = [union.get_mx_flags(a).copy() for a in range(len(asms))]
             for a in range(len(asms)):
-                assert np.array_equal(eng.get_mx_flags(a), union.get_mx_flags(a))
+                assert np.array_equal(eng.get_mx_flags(a), union_flags[a])
                 assert union.record_ids(a, union.n_records(a)) == [f"r0:{x}" for x in eng.record_ids(a, eng.n_records(a))]
             union.close()
+            # the hash-partitioned graph stage over RCCL (one rank: every all-to-all is a copy, the code path is whole)
+            from ntjoin_amd.dist import partitioned_graph, partitioned_totals
+            owner = partitioned_graph(eng, meta["k"], meta["w"], 0)
+            owner = partitioned_graph(eng, meta["k"], meta["w"], 0, owner)
+            partitioned_totals(owner)
+            g2 = owner.get_graph()
+            assert owner.dg["base"] == 0 and owner.dg["vertices"] == len(g0["vertex_hash"]) and owner.dg["edges"] == len(g0["edge_u"])
+            e0 = {(int(g0["vertex_hash"][u]), int(g0["vertex_hash"][v])): (int(s_), float(w_)) for u, v, s_, w_ in
+                  zip(g0["edge_u"], g0["edge_v"], g0["edge_support"], g0["edge_weight"])}
+            e2 = {(int(g2["vertex_hash"][u]), int(g2["vertex_hash"][v])): (int(s_), float(w_)) for u, v, s_, w_ in
+                  zip(g2["edge_u"], g2["edge_v"], g2["edge_support"], g2["edge_weight"])}
+            assert e0 == e2 and sorted(g0["vertex_hash"].tolist()) == sorted(g2["vertex_hash"].tolist())
+            for a in range(len(asms)):
+                assert np.array_equal(eng.get_mx_flags(a), union_flags[a])
+            owner.close()
     finally:
         dist.destroy_process_group()
 

@@ -31,11 +31,12 @@ def test_union_graph_world_size(world, stream):
     assert out.stdout.count("DIST2 OK") == world, out.stdout[-3000:]
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("mode", ["union", "partitioned"])
+def test_bench_two_ranks_on_one_gpu(mode):
     """bench.py's N>1 branch end to end (launch line of the driver, two ranks, gloo instead of RCCL): one JSON line,
-    aggregate over both ranks, graph counts of the union"""
+    aggregate over both ranks, graph counts of the whole genome -- both ways of building the graph"""
     import json
-    env = dict(os.environ, MXG_BENCH_BACKEND="gloo", MXG_BENCH_ONE_DEVICE="1")
+    env = dict(os.environ, MXG_BENCH_BACKEND="gloo", MXG_BENCH_ONE_DEVICE="1", MXG_BENCH_GRAPH=mode)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--mbp", "5"]
@@ -46,3 +47,10 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["bases_per_step"] > 1.9 * 2 * 5e6       # both ranks' 2 x 5 Mbp
     assert d["config"]["vertices"] > 0 and d["config"]["edges"] > 0
+    assert ("partitioned" in d["config"]["parallelism"]) == (mode == "partitioned")
+    _BENCH_COUNTS[mode] = (d["config"]["vertices"], d["config"]["edges"])
+    if len(_BENCH_COUNTS) == 2:   # the same genome either way
+        assert _BENCH_COUNTS["union"] == _BENCH_COUNTS["partitioned"]
+
+
+_BENCH_COUNTS = {}
