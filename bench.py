@@ -139,6 +139,9 @@ def main():
 
     def step():
         nonlocal union
+        if world == 1 and not force_dist and os.environ.get("MXG_BENCH_FUSED") == "1":
+            eng.sketch_graph()  # sketches and graph stage in one call with one host sync (measured: no faster)
+            return
         eng.sketch(-2)  # MXG_SKETCH_ALL: both assemblies enqueued back to back, one host sync
         if (world > 1 or force_dist) and graph_mode == "partitioned":
             union = partitioned_graph(eng, K, W, local_rank, union, stream=xstream)   # this rank's part of the graph

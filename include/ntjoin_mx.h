@@ -179,6 +179,11 @@ double mxg_assembly_weight(const mxg_handle *h, int assembly);
 #define MXG_SKETCH_PENDING (-1) /* every assembly that has bases and no sketch yet                         */
 #define MXG_SKETCH_ALL (-2)     /* every assembly that has bases (re-sketch); pipelined: one host sync for all */
 int mxg_sketch(mxg_handle *h, int assembly /* index, MXG_SKETCH_PENDING or MXG_SKETCH_ALL */);
+/* mxg_sketch(h, MXG_SKETCH_ALL) followed by mxg_build_graph(h) in ONE call and, in the common case, with ONE host sync: the
+   graph kernels are enqueued behind the sketch kernels with upper bounds for the sizes and read the sketch sizes on the
+   device.  Same results as the two calls (what ntJoin's `%.tsv` rule plus make_minimizer_graph produce, ntJoin:204-205,
+   bin/ntjoin.py:189-204). */
+int mxg_sketch_graph(mxg_handle *h);
 int mxg_get_sketch(mxg_handle *h, int assembly, mxg_sketch_view *out);
 /* (forward is NULL until the strands have been computed: mxg_get_sketch, mxg_write_tsv or mxg_compute_strands) */
 int mxg_get_sketch_device(mxg_handle *h, int assembly, mxg_sketch_dview *out);

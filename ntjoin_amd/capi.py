@@ -17,7 +17,7 @@ SYMBOLS = [
     "mxg_add_assembly_buffers", "mxg_add_assembly_packed_device",
     "mxg_add_assembly_tsv", "mxg_add_assembly_bin", "mxg_write_sketch_bin", "mxg_add_assembly_minimizers", "mxg_num_assemblies", "mxg_assembly_name",
     "mxg_record_id", "mxg_record_length", "mxg_num_records", "mxg_assembly_weight",
-    "mxg_sketch", "mxg_get_sketch", "mxg_get_sketch_device", "mxg_compute_strands", "mxg_set_sketch_device",
+    "mxg_sketch", "mxg_sketch_graph", "mxg_get_sketch", "mxg_get_sketch_device", "mxg_compute_strands", "mxg_set_sketch_device",
     "mxg_pack_sketch_device", "mxg_set_sketch_gathered", "mxg_set_sketch_gathered_strided", "mxg_write_tsv",
     "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_path_segments", "mxg_mx_extremes", "mxg_dg_owner_counts", "mxg_dg_pack_items", "mxg_dg_set_items", "mxg_dg_vertices", "mxg_dg_item_results", "mxg_dg_msg_counts", "mxg_dg_pack_msgs", "mxg_dg_edges", "mxg_write_dot",
     "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers",
@@ -133,6 +133,7 @@ def load():
     L.mxg_assembly_weight.argtypes = [vp, i32]
     L.mxg_assembly_weight.restype = C.c_double
     L.mxg_sketch.argtypes = [vp, i32]
+    L.mxg_sketch_graph.argtypes = [vp]
     L.mxg_get_sketch.argtypes = [vp, i32, C.POINTER(SketchView)]
     L.mxg_get_sketch_device.argtypes = [vp, i32, C.POINTER(SketchDView)]
     L.mxg_set_sketch_device.argtypes = [vp, i32, vp, vp, vp, vp, u64]

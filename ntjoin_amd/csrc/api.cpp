@@ -84,6 +84,7 @@ void mxg_destroy(mxg_handle *h)
     for (auto *a : h->asms) delete a;
     h->asms.clear();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->pinned_ctrl) (void)hipHostFree(h->pinned_ctrl);
@@ -355,6 +356,29 @@ int mxg_sketch(mxg_handle *h, int assembly)
         return set_err(h, MXG_ENOMEM, "out of host memory in mxg_sketch");
     }
     return MXG_OK;
+}
+
+int mxg_sketch_graph(mxg_handle *h)
+{
+    if (!h) return MXG_EINVAL;
+    try {
+        std::vector<Assembly *> todo;
+        bool all_bases = !h->asms.empty();
+        for (auto *a : h->asms) {
+            all_bases = all_bases && a->has_bases;
+            if (a->has_bases) todo.push_back(a);
+        }
+        if (!all_bases) {  // some assembly came as a sketch (TSV, arrays): sketch what has bases, then the ordinary graph stage
+            if (!todo.empty()) {
+                int rc = sketch_assemblies(h, todo.data(), todo.size());
+                if (rc != MXG_OK) return rc;
+            }
+            return build_graph(h);
+        }
+        return sketch_assemblies(h, todo.data(), todo.size(), true);
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_sketch_graph");
+    }
 }
 
 int mxg_get_sketch(mxg_handle *h, int assembly, mxg_sketch_view *out)

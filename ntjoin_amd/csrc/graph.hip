@@ -49,7 +49,8 @@ __device__ __forceinline__ uint32_t ht_slot(Slot *tab, uint32_t mask, uint32_t c
 struct AsmSet {
     uint32_t n_asm;
     uint32_t full;                              // mask with one bit per assembly
-    uint32_t n[MXG_MAX_ASSEMBLIES];             // minimizers per assembly
+    uint32_t n[MXG_MAX_ASSEMBLIES];             // minimizers per assembly (an upper bound when n_ptr[a] is set)
+    const uint32_t *n_ptr[MXG_MAX_ASSEMBLIES];  // fused sketch+graph call: the count is still on the device
     uint32_t bstart[MXG_MAX_ASSEMBLIES + 1];    // exclusive prefix of 256-element blocks
     const uint64_t *hash[MXG_MAX_ASSEMBLIES];
     uint32_t *slot[MXG_MAX_ASSEMBLIES];
@@ -57,6 +58,10 @@ struct AsmSet {
     uint8_t *shared[MXG_MAX_ASSEMBLIES];
 };
 
+__device__ __forceinline__ uint32_t asm_n(const AsmSet &p, uint32_t a)
+{
+    return p.n_ptr[a] ? min(*p.n_ptr[a], p.n[a]) : p.n[a];
+}
 __device__ __forceinline__ uint32_t asm_of_block(const AsmSet &p, uint32_t b)
 {
     uint32_t a = 0;
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256) void k_insert(const AsmSet p, Slot *tab, uint3
         for (uint32_t i = threadIdx.x; i < n_sup; i += 256) sup[i] = 0;
     const uint32_t a = asm_of_block(p, blockIdx.x);
     const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
-    if (i >= p.n[a]) return;
+    if (i >= asm_n(p, a)) return;
     const uint32_t bit = 1u << a;
     uint32_t s = ht_slot(tab, mask, cap, p.hash[a][i]);
     uint32_t old = atomicAnd(&tab[s].nseen, ~bit);
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) void k_flags(const AsmSet p, const Slot *__res
     const uint32_t a = asm_of_block(p, blockIdx.x);
     const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
     bool sh = false;
-    if (i < p.n[a]) {
+    if (i < asm_n(p, a)) {
         const uint32_t bit = 1u << a, full = p.full;
         const Slot sl = tab[p.slot[a][i]];
         const uint32_t seen = ~sl.nseen & full, d = ~sl.ndup & full;
@@ -110,7 +115,8 @@ struct VertexParams {
     const uint32_t *slot;
     const uint64_t *hash;
     const uint32_t *pos, *rec;
-    uint32_t n;
+    uint32_t n;             // (an upper bound when n_ptr is set: fused sketch+graph call)
+    const uint32_t *n_ptr;
     uint32_t first;   // 1: this is assembly 0 -> assign vertex ids
     uint32_t *vid;    // [cap+1] slot -> vertex id
     uint64_t *vhash;  // [nv]
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void k_vertices(const VertexParams p)
 {
     __shared__ uint32_t sh[256];
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
-    const uint32_t fl = load_flags4(p.shared, base, p.n);
+    const uint32_t fl = load_flags4(p.shared, base, p.n_ptr ? min(*p.n_ptr, p.n) : p.n);
     uint32_t c = count_flags4(fl);
     __shared__ uint32_t sh_before;
     if (threadIdx.x < 64) {
@@ -309,17 +315,22 @@ __global__ __launch_bounds__(256) void k_count_unique(const uint8_t *__restrict_
 // mode GRAPH_FULL: the whole stage.  The distributed graph (dgraph.hip) runs it in two halves on the OWNER's handle:
 // GRAPH_DG_VERTICES stops after the vertices (and records the vertex id of every item), GRAPH_DG_EDGES resumes with the
 // adjacency taken from messages instead of from the handle's own record order.
-int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs)
+// gb (fused sketch+graph call, GRAPH_FULL only): the sketches are still being computed on the stream; sizes are the
+// bounds gb->n_bound[a], the kernels read the counts from gb->n_ptr[a] on the device.
+int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, const GraphBounds *gb)
 {
     MXG_HIP(h, hipSetDevice(h->device));
     const uint32_t A = (uint32_t)h->asms.size();
     if (A == 0) return set_err(h, MXG_EINVAL, "mxg_build_graph: no assemblies");
     if (A > MXG_MAX_ASSEMBLIES) return set_err(h, MXG_ELIMIT, "at most %d assemblies", MXG_MAX_ASSEMBLIES);
     uint64_t N = 0, nmin = ~0ull;
-    for (auto *a : h->asms) {
-        if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch (call mxg_sketch)", a->name.c_str());
-        N += a->n_mx;
-        nmin = std::min(nmin, a->n_mx);
+    std::vector<uint64_t> n_of(A);
+    for (uint32_t ai = 0; ai < A; ++ai) {
+        Assembly *a = h->asms[ai];
+        if (!gb && !a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch (call mxg_sketch)", a->name.c_str());
+        n_of[ai] = gb ? gb->n_bound[ai] : a->n_mx;
+        N += n_of[ai];
+        nmin = std::min(nmin, n_of[ai]);
         if (mode != GRAPH_DG_EDGES) a->flags_valid = a->flags_on_host = false;
     }
     if (N >= (1ull << 30)) return set_err(h, MXG_ELIMIT, "too many minimizers for one table (%llu)", (unsigned long long)N);
@@ -347,12 +358,13 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs)
     uint32_t nb = 0;
     for (uint32_t a = 0; a < A; ++a) {
         Assembly *as = h->asms[a];
-        MXG_HIP(h, as->d_slot.ensure(std::max<uint64_t>(as->n_mx * 4, 16)));
-        MXG_HIP(h, as->d_flags.ensure(std::max<uint64_t>(as->n_mx, 16)));
-        MXG_HIP(h, as->d_shared.ensure(std::max<uint64_t>(as->n_mx, 16)));
-        as_all.n[a] = (uint32_t)as->n_mx;
+        MXG_HIP(h, as->d_slot.ensure(std::max<uint64_t>(n_of[a] * 4, 16)));
+        MXG_HIP(h, as->d_flags.ensure(std::max<uint64_t>(n_of[a], 16)));
+        MXG_HIP(h, as->d_shared.ensure(std::max<uint64_t>(n_of[a], 16)));
+        as_all.n[a] = (uint32_t)n_of[a];
+        as_all.n_ptr[a] = gb ? gb->n_ptr[a] : nullptr;
         as_all.bstart[a] = nb;
-        nb += (uint32_t)((as->n_mx + 255) / 256);
+        nb += (uint32_t)((n_of[a] + 255) / 256);
         as_all.hash[a] = as->d_hash.as<uint64_t>();
         as_all.slot[a] = as->d_slot.as<uint32_t>();
         as_all.flags[a] = as->d_flags.as<uint8_t>();
@@ -362,6 +374,7 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs)
     as_all.bstart[A] = nb;
     for (uint32_t a = A; a < MXG_MAX_ASSEMBLIES; ++a) {
         as_all.n[a] = 0;
+        as_all.n_ptr[a] = nullptr;
         as_all.bstart[a + 1] = nb;
         as_all.hash[a] = nullptr;
         as_all.slot[a] = nullptr;
@@ -400,7 +413,7 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs)
         uint32_t *const d_prv = h->g_nxt.as<uint32_t>() + anv;
         for (uint32_t a = 0; a < A && mode != GRAPH_DG_EDGES; ++a) {  // assembly 0 assigns the vertex ids the others look up
             Assembly *as = h->asms[a];
-            const uint32_t n = (uint32_t)as->n_mx;
+            const uint32_t n = (uint32_t)n_of[a];
             VertexParams vp;
             vp.shared = as->d_shared.as<uint8_t>();
             vp.cnt = cnt + as_all.bstart[a];
@@ -411,6 +424,7 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs)
             vp.pos = as->d_pos.as<uint32_t>();
             vp.rec = as->d_rec.as<uint32_t>();
             vp.n = n;
+            vp.n_ptr = gb ? gb->n_ptr[a] : nullptr;
             vp.first = a == 0;
             vp.vid = h->g_vid.as<uint32_t>();
             vp.vhash = h->g_vhash.as<uint64_t>();

@@ -168,6 +168,8 @@ struct mxg_handle {
     std::vector<hipEvent_t> ev_pool;       // every event ever created for timing; [0, ev_used) are in flight
     size_t ev_used = 0;
     std::vector<mxg::TimedSpan> ev_spans;  // not yet folded into tm
+    mxg::DevBuf d_nmx;              // fused sketch+graph call: sketch sizes on the device
+    hipEvent_t ev_join = nullptr;   // ... and the event that joins the second stream into the first
     mxg::DevBuf dg_cnt, dg_cursor;  // dgraph.hip: per-destination counts / cursors
     mxg::Paths paths;
     mxg::DevBuf pbuf[48];  // scratch of paths.hip
@@ -229,7 +231,7 @@ void make_init_tab(uint32_t k, std::vector<uint4> &out);
 
 // sketch.hip
 int sketch_assembly(mxg_handle *h, Assembly *a);
-int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n);
+int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_graph = false);
 int sync_sketch_to_host(mxg_handle *h, Assembly *a);
 int write_sketch_bin(mxg_handle *h, Assembly *a, const char *path);  // host_io.cpp
 int load_sketch_bin(mxg_handle *h, Assembly *a, const char *path, std::vector<uint64_t> &hash, std::vector<uint32_t> &pos,
@@ -240,7 +242,12 @@ int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t w
                     const uint64_t *counts, const uint64_t *rec_offsets, uint64_t stride_bytes = 0);
 // graph.hip
 enum { GRAPH_FULL = 0, GRAPH_DG_VERTICES = 1, GRAPH_DG_EDGES = 2 };
-int build_graph(mxg_handle *h, int mode = GRAPH_FULL, const void *d_msgs = nullptr, uint64_t n_msgs = 0);
+struct GraphBounds {  // fused sketch+graph call: per assembly an upper bound of its sketch and where the count will be
+    uint64_t n_bound[MXG_MAX_ASSEMBLIES];
+    const uint32_t *n_ptr[MXG_MAX_ASSEMBLIES];
+};
+int build_graph(mxg_handle *h, int mode = GRAPH_FULL, const void *d_msgs = nullptr, uint64_t n_msgs = 0,
+                const GraphBounds *gb = nullptr);
 int graph_to_host(mxg_handle *h);
 int find_paths(mxg_handle *h, int64_t n_min);  // paths.hip
 // dgraph.hip

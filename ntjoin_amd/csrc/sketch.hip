@@ -797,6 +797,7 @@ struct EmitParams {
     const uint32_t *bsum;  // dense path: exclusive offsets per 1024-tile (k_count_n + k_scan_sums); sparse path: nullptr,
     const uint32_t *cnt256, *sel_sup;  // ... offsets come from k_resolve's two-level counts
     uint32_t *n_sel;       // sparse path: ctrl[2..3], written by the tile that holds the last candidate
+    uint32_t *n_out;       // sparse path, optional: a second device word that receives the total (fused sketch+graph call)
     uint32_t *host_ctrl;   // sparse path: pinned host copy of the control block (8 words), written by that tile too:
                            // no copy on the stream, the host reads it after the stream has drained
     const Run *runs;
@@ -835,6 +836,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
                 if (threadIdx.x == 0) {
                     p.n_sel[0] = all;
                     p.n_sel[1] = 0;
+                    if (p.n_out) *p.n_out = all;
                 }
                 if (p.host_ctrl && threadIdx.x < 8) {  // {overflow, gaps, selected lo/hi, candidates lo/hi, 0, 0}
                     const uint32_t w = threadIdx.x;
@@ -1142,6 +1144,7 @@ struct Driver {
     }
 
     // offsets: SC_BSUM per 1024-tile (after resolve_and_count) or, fused = true, from SC_CNT256 (after resolve_count)
+    uint32_t *n_out = nullptr;  // see EmitParams::n_out (set by sketch_assemblies for the fused call)
     int emit(const uint32_t *d_packed, const Tables &T, uint32_t n_cap, DevBuf &oh, DevBuf &op, DevBuf &orc, DevBuf &of,
              uint64_t out_base, bool fused = false, uint32_t *host_ctrl = nullptr)
     {
@@ -1160,6 +1163,7 @@ struct Driver {
         ep.sel_sup = fused ? sel_sup(n_cap) : nullptr;
         ep.n_sel = sc(SC_CTRL).as<uint32_t>() + 2;
         ep.host_ctrl = host_ctrl;
+        ep.n_out = host_ctrl ? n_out : nullptr;
         ep.runs = T.d_runs;
         ep.ctg_run0 = T.d_ctg_run0;
         ep.ctg_rec = T.d_ctg_rec;
@@ -1659,9 +1663,13 @@ int sketch_assembly(mxg_handle *h, Assembly *a)
 // a speculative emit into its own sketch arrays and an async copy of its control block), then ONE host sync covers
 // them all.  An assembly that turns out to need more (arena overflow, candidate-free stretches, output growth)
 // is simply redone through the synchronous path -- rare, and nothing of it was kept.
-int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
+// fuse_graph: also run the graph stage, enqueued BEHIND the sketches with upper bounds for the sizes and the counts read
+// on the device, so that the whole sketch + graph step has one host sync.  Needs the common case everywhere (every
+// assembly of the handle in one sparse batch, no candidate-free stretch, no arena overflow, sketches within their
+// bounds); otherwise the sketches are completed as usual and the graph stage runs afterwards in the ordinary way.
+int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_graph)
 {
-    if (n == 1) return sketch_assembly(h, list[0]);
+    if (n == 1 && !fuse_graph) return sketch_assembly(h, list[0]);
     MXG_HIP(h, hipSetDevice(h->device));
     if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, (MXG_MAX_ASSEMBLIES + 1) * 32));
     double frac;
@@ -1695,6 +1703,10 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
         OutArrays out{&list[i]->d_hash, &list[i]->d_pos, &list[i]->d_rec, &list[i]->d_fwd, 0};
         uint32_t *slot = h->pinned_ctrl + 8 * i;
         memset(slot, 0xFF, 32);
+        if (fuse_graph) {
+            MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
+            drv.n_out = h->d_nmx.as<uint32_t>() + i;
+        }
         if ((rc = drv.enqueue_sparse(list[i], tabs[i], g, drv.default_wave_cap(list[i]->S_sparse, frac), tau_hi, out, slot,
                                      &ncap[i])) != MXG_OK)
             return rc;
@@ -1702,6 +1714,26 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
         slot_of[i] = (int)(n_enq & 1);
         last_on_slot[n_enq & 1] = i;
         ++n_enq;
+    }
+    bool fused = false;
+    size_t n_fast = 0;  // assemblies whose speculative emit stood as it was (no stretch, no overflow, within capacity)
+    GraphBounds gb;
+    if (fuse_graph && n_enq == n && n == h->asms.size() && n <= MXG_MAX_ASSEMBLIES) {
+        bool same = true;
+        for (size_t i = 0; i < n; ++i) same = same && list[i] == h->asms[i];
+        if (same) {
+            // the second stream joins the first; the graph stage follows the sketches on it
+            if (!h->ev_join) MXG_HIP(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+            MXG_HIP(h, hipEventRecord(h->ev_join, h->stream2));
+            MXG_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            for (size_t i = 0; i < n; ++i) {
+                Assembly *a = list[i];
+                const uint64_t cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
+                gb.n_bound[i] = std::min<uint64_t>(cap, (uint64_t)(2.3 * (double)a->total_kmers / (double)(h->cfg.w + 1)) + 2048);
+                gb.n_ptr[i] = h->d_nmx.as<uint32_t>() + i;
+            }
+            fused = build_graph(h, GRAPH_FULL, nullptr, 0, &gb) == MXG_OK;  // (its sync is this call's sync)
+        }
     }
     MXG_HIP(h, stream_wait(h->stream));
     MXG_HIP(h, stream_wait(h->stream2));
@@ -1716,6 +1748,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
             a->has_sketch = true;
             h->stat_candidates += n_cand;
             state[i] = 2;
+            if (fused && total > gb.n_bound[i]) fused = false;  // a sketch outgrew the bound the graph stage was sized for
+            ++n_fast;
         } else if (c[0] == 0 && last_on_slot[slot_of[i]] == i) {
             // candidate-free stretches (or an output that outgrew its estimate) and the run's candidate arrays are still
             // intact in its driver's scratch: finish from there (staging emit, dense fix-up, merge) instead of redoing it
@@ -1732,10 +1766,17 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n)
             state[i] = 0;  // a wave overflowed its arena slice (or the scratch was reused): redo synchronously
         }
     }
-    for (size_t i = 0; i < n; ++i)
+    if (n_fast != n) fused = false;  // not the common case everywhere: the graph stage ran on incomplete input
+    for (size_t i = 0; i < n; ++i) {
         if (state[i] == 0 && (rc = run_sketch_sync(h, list[i], tabs[i], drv0)) != MXG_OK) return rc;
+    }
     if ((rc = drv0.collect()) != MXG_OK) return rc;
-    return drv1.collect();
+    if ((rc = drv1.collect()) != MXG_OK) return rc;
+    if (fuse_graph && !fused) {
+        h->graph.valid = false;
+        return build_graph(h);
+    }
+    return MXG_OK;
 }
 
 int flush_timers(mxg_handle *h)

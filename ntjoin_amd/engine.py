@@ -166,6 +166,10 @@ class MxEngine:
     def sketch(self, assembly=-1):
         self._check(self._lib.mxg_sketch(self._h, int(assembly)))
 
+    def sketch_graph(self):
+        """sketch every assembly and build the graph in one call (one host sync in the common case)"""
+        self._check(self._lib.mxg_sketch_graph(self._h))
+
     def get_sketch(self, a):
         v = capi.SketchView()
         self._check(self._lib.mxg_get_sketch(self._h, int(a), C.byref(v)))

@@ -1,0 +1,103 @@
+"""GPU test of mxg_sketch_graph (sketch + graph stage in one call, one host sync in the common case): same sketches, flags
+and graph as mxg_sketch + mxg_build_graph, on the goldens, on configs[1]-shaped input, and on the inputs that leave the
+common case (candidate-free stretches, arena overflow, dense path, an assembly that came as a TSV)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN, golden_cases, load_case
+
+pytestmark = pytest.mark.gpu
+FASTA = os.path.join(GOLDEN, "fasta")
+CASES = [m["name"] for m in golden_cases()]
+
+
+def _same(e1, e2, n_asm):
+    for a in range(n_asm):
+        s1, s2 = e1.get_sketch(a), e2.get_sketch(a)
+        for key in ("out_hash", "pos", "record", "forward", "record_first"):
+            assert np.array_equal(s1[key], s2[key]), (a, key)
+        assert np.array_equal(e1.get_mx_flags(a), e2.get_mx_flags(a)), a
+    g1, g2 = e1.get_graph(), e2.get_graph()
+    for key in g1:
+        assert np.array_equal(np.asarray(g1[key]), np.asarray(g2[key])), key
+    st1, st2 = e1.stats(), e2.stats()
+    for key in ("minimizers", "unique", "vertices", "edges"):
+        assert st1[key] == st2[key], key
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fused_equals_two_calls_on_goldens(name):
+    from ntjoin_amd.engine import MxEngine
+    meta = load_case(name)["meta"]
+    asms = meta["refs"] + [meta["target"]]
+    with MxEngine(k=meta["k"], w=meta["w"], variant=meta["variant"]) as e1, MxEngine(k=meta["k"], w=meta["w"], variant=meta["variant"]) as e2:
+        for a in asms:
+            e1.add_fasta(a["tsv"], a["weight"], os.path.join(FASTA, a["fasta"]))
+            e2.add_fasta(a["tsv"], a["weight"], os.path.join(FASTA, a["fasta"]))
+        e1.sketch_graph()
+        e1.sketch_graph()          # again on the same handle (buffers, counters and flags of the first run are stale)
+        e2.sketch()
+        e2.build_graph()
+        _same(e1, e2, len(asms))
+
+
+def _packed(eng, name, weight, recs):
+    import torch
+    from ntjoin_amd import synth
+    words, starts, lens = synth.pack_records(recs)
+    d = torch.from_numpy(words.view(np.int32)).cuda()
+    eng.add_packed_device(name, weight, d.data_ptr(), starts, lens, keepalive=d)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(cand_per_window=2), dict(dense_only=True)])
+def test_fused_on_synthetic_genome(kw):
+    """common case (one sync), candidate-free stretches everywhere (fallback), dense path (fallback)"""
+    from ntjoin_amd import synth
+    from ntjoin_amd.engine import MxEngine
+    ref, tgt = synth.config2(seed=3, n_bases=20_000_000)
+    with MxEngine(k=32, w=1000, **kw) as e1, MxEngine(k=32, w=1000, **kw) as e2:
+        for e in (e1, e2):
+            _packed(e, "ref", 2.0, ref)
+            _packed(e, "tgt", 1.0, tgt)
+        e1.sketch_graph()
+        e2.sketch(-2)
+        e2.build_graph()
+        _same(e1, e2, 2)
+        assert e1.stats()["vertices"] > 10000
+
+
+def test_fused_after_arena_overflow(monkeypatch):
+    from ntjoin_amd import synth
+    from ntjoin_amd.engine import MxEngine
+    monkeypatch.setenv("MXG_WAVE_CAP", "8")      # every wave overflows its arena slice: the batch is redone
+    ref, tgt = synth.config2(seed=4, n_bases=3_000_000)
+    with MxEngine(k=32, w=200) as e1, MxEngine(k=32, w=200) as e2:
+        for e in (e1, e2):
+            _packed(e, "ref", 2.0, ref)
+            _packed(e, "tgt", 1.0, tgt)
+        e1.sketch_graph()
+        e2.sketch(-2)
+        e2.build_graph()
+        _same(e1, e2, 2)
+
+
+def test_fused_with_an_assembly_from_tsv():
+    from ntjoin_amd.engine import MxEngine
+    meta = load_case("synth3_w50")["meta"]
+    asms = meta["refs"] + [meta["target"]]
+    cdir = os.path.join(GOLDEN, "cases", "synth3_w50")
+    with MxEngine(k=meta["k"], w=meta["w"]) as e1, MxEngine(k=meta["k"], w=meta["w"]) as e2:
+        for i, a in enumerate(asms):
+            for e in (e1, e2):
+                if i == 0:
+                    e.add_tsv(a["tsv"], a["weight"], os.path.join(cdir, a["tsv"]))
+                else:
+                    e.add_fasta(a["tsv"], a["weight"], os.path.join(FASTA, a["fasta"]))
+        e1.sketch_graph()
+        e2.sketch()
+        e2.build_graph()
+        g1, g2 = e1.get_graph(), e2.get_graph()
+        for key in g1:
+            assert np.array_equal(np.asarray(g1[key]), np.asarray(g2[key])), key
