@@ -1,6 +1,7 @@
-// scan_kernels.h -- ordered stream-compaction building blocks shared by sketch.hip and graph.hip.
-// Pattern: k_count (flags -> per-tile counts) ; k_scan_sums (exclusive scan of tile counts, one block) ;
-// then a consumer kernel re-scans its tile in LDS (tile_exclusive_rank) and writes in order.
+// scan_kernels.h -- ordered stream-compaction building blocks shared by sketch.hip, graph.hip, paths.hip, dgraph.hip.
+// Hot path: two-level counts (count_publish / count_prefix below): the producer kernel stores its per-block counts, the
+// consumer kernel sums what precedes its tile and re-scans the tile in LDS (block_exclusive_256): no scan launch.
+// Cold paths (dense sketch path, path extraction): k_count_n / k_tile_sum_u32 -> k_scan_sums (one block) -> consumer.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>

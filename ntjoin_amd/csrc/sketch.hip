@@ -11,9 +11,9 @@
 //     R(p) = number of consecutive k-mers right of p with hash >  h(p)  (capped by n-1-p and w-1)
 // i.e. there is room for a window of w k-mers around p in which p is the rightmost minimum.
 //
-// Fast path (sparse candidates): only k-mers with min_hash < tau (tau = 2^64 * c / w, c ~ 12 expected per
+// Fast path (sparse candidates): only k-mers with min_hash < tau (tau = 2^64 * c / w, c = 18 expected per
 // window) can be the minimum of a window that contains at least one of them, and k-mers >= tau never block
-// a candidate.  So the window logic runs on ~1.2 % of the k-mers.  Windows that contain NO candidate lie
+// a candidate.  So the window logic runs on ~1.8 % of the k-mers.  Windows that contain NO candidate lie
 // inside a candidate-free stretch ("gap") of >= w k-mers; those stretches are detected exactly and re-done
 // by the dense path (every k-mer a candidate) as stand-alone ranges; the two result sets are disjoint and
 // their union is the exact sketch (low-complexity sequence simply degrades to the dense path).
@@ -257,8 +257,9 @@ struct SparseParams {
     uint32_t tau_hi;      // candidate iff high word of min_hash < tau_hi (EVEN: tau_hi = 2T, T on the top 31 bits)
     uint2 *arena;         // wave w owns entries [w*wave_cap, (w+1)*wave_cap): {strip (rel.), j | seq<<10}
     uint32_t wave_cap;
-    uint32_t *wave_cnt;   // [n_waves] candidates each wave produced (may exceed wave_cap: overflow, batch is redone)
-    uint32_t *ctrl;       // [0] max over waves of wave_cnt (atomicMax, only written on overflow)
+    uint32_t *wave_cnt;   // [n_waves] ENTRIES each wave wrote to its slice (k_reorder reads that many)
+    uint32_t *ctrl;       // [0] max over waves of their candidate count when it exceeds wave_cap (atomicMax): the host
+                          //     then redoes the batch with that capacity
     uint32_t *strip_cnt;  // [n_strips] candidates per strip
     uint32_t *wave_tot;   // [n_waves] candidates per wave, and their super-counts (scan_kernels.h; zeroed with ctrl)
     uint32_t *wave_sup;
