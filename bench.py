@@ -14,8 +14,8 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- eve
 "union": one RCCL all-gather of the sketches and every rank builds the whole graph (N times the graph work on every
 rank, but only one collective: cheapest while a rank's share is small, as in configs[1]), or "partitioned": the graph
 stage distributed by hash range over RCCL all-to-alls (ntjoin_amd/dist.py, csrc/dgraph.hip), whose work per rank does
-not grow with N (measured on one GPU: 0.64 ms vs 0.26 ms per step at 100 Mbp per rank, 1.48 ms vs 0.78 ms x N at
-1 Gbp per rank).  Default: partitioned when N >= 4 and --mbp >= 400; MXG_BENCH_GRAPH=union|partitioned overrides.
+not grow with N (measured on one GPU: 0.51 ms vs 0.26 ms per step at 100 Mbp per rank, 1.5 ms vs 0.8-1.0 ms x N at
+1 Gbp per rank).  Default: partitioned from N = 4 up; MXG_BENCH_GRAPH=union|partitioned overrides.
 """
 import argparse
 import json
@@ -135,7 +135,7 @@ def main():
         keep.append(d)
         eng.add_packed_device(name, weight, d.data_ptr(), starts, lens)
     union = None
-    graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("partitioned" if world >= 4 and args.mbp >= 400 else "union")
+    graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("partitioned" if world >= 4 else "union")
 
     def step():
         nonlocal union

@@ -285,6 +285,20 @@ int mxg_dg_item_results(mxg_handle *h, int assembly, const void *d_gbase, uint32
 int mxg_dg_msg_counts(mxg_handle *h, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts);
 int mxg_dg_pack_msgs(mxg_handle *h, int assembly, uint32_t world, const void *d_bases, const uint64_t *starts, void *d_send);
 int mxg_dg_edges(mxg_handle *h, const void *d_msgs, uint64_t n_msgs, uint64_t *n_vertices, uint64_t *n_edges);
+/* Steady state of the same exchange with FIXED-CAPACITY SLOTS: once one exact step has shown the sizes, every (source,
+   destination) pair gets a slot = 64-byte header (u64 count per assembly, <= 8 assemblies) + cap[a] 16-byte items per
+   assembly; the all-to-alls then have equal splits and the receivers read the counts on the device: no size exchange,
+   no host sync before mxg_dg_edges_slots.  A count above its capacity sets *overflow there: repeat the step the exact
+   way.  Message slots: 64-byte header (word 0 = count) + max_msgs 16-byte messages.  mxg_dg_pack_slots clears the
+   headers when called for assembly 0 (pack the assemblies in order), mxg_dg_pack_msg_slots at its start. */
+int mxg_dg_pack_slots(mxg_handle *h, int assembly, uint32_t rec_offset, uint32_t world, uint32_t n_asm, const uint32_t *cap,
+                      void *d_send);
+int mxg_dg_owner_slots(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv, void *d_n_vertices);
+int mxg_dg_slot_results(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv,
+                        const void *d_gbase, void *d_out /* [world][sum cap] u64 */);
+int mxg_dg_pack_msg_slots(mxg_handle *h, uint32_t world, uint32_t max_msgs, const void *d_ret, const void *d_bases, void *d_send);
+int mxg_dg_edges_slots(mxg_handle *h, const void *d_recv, uint32_t world, uint32_t max_msgs, uint64_t *n_vertices,
+                       uint64_t *n_edges, uint32_t *overflow);
 
 /* ---- text helpers used by the writers (host only; usable without a device) --------------------- */
 /* python repr() of a float / of a str, as Ntjoin.print_graph's f-strings produce them.  Returns the length

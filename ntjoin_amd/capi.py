@@ -19,7 +19,7 @@ SYMBOLS = [
     "mxg_record_id", "mxg_record_length", "mxg_num_records", "mxg_assembly_weight",
     "mxg_sketch", "mxg_sketch_graph", "mxg_get_sketch", "mxg_get_sketch_device", "mxg_compute_strands", "mxg_set_sketch_device",
     "mxg_pack_sketch_device", "mxg_set_sketch_gathered", "mxg_set_sketch_gathered_strided", "mxg_write_tsv",
-    "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_path_segments", "mxg_mx_extremes", "mxg_dg_owner_counts", "mxg_dg_pack_items", "mxg_dg_set_items", "mxg_dg_vertices", "mxg_dg_item_results", "mxg_dg_msg_counts", "mxg_dg_pack_msgs", "mxg_dg_edges", "mxg_write_dot",
+    "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_path_segments", "mxg_mx_extremes", "mxg_dg_owner_counts", "mxg_dg_pack_items", "mxg_dg_set_items", "mxg_dg_vertices", "mxg_dg_item_results", "mxg_dg_msg_counts", "mxg_dg_pack_msgs", "mxg_dg_edges", "mxg_dg_pack_slots", "mxg_dg_owner_slots", "mxg_dg_slot_results", "mxg_dg_pack_msg_slots", "mxg_dg_edges_slots", "mxg_write_dot",
     "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers",
 ]
 
@@ -160,6 +160,12 @@ def load():
     L.mxg_dg_msg_counts.argtypes = [vp, C.c_uint32, vp, vp, pu64]
     L.mxg_dg_pack_msgs.argtypes = [vp, i32, C.c_uint32, vp, pu64, vp]
     L.mxg_dg_edges.argtypes = [vp, vp, u64, pu64, pu64]
+    pu32 = C.POINTER(C.c_uint32)
+    L.mxg_dg_pack_slots.argtypes = [vp, i32, C.c_uint32, C.c_uint32, C.c_uint32, pu32, vp]
+    L.mxg_dg_owner_slots.argtypes = [vp, C.c_uint32, C.c_uint32, pu32, vp, vp]
+    L.mxg_dg_slot_results.argtypes = [vp, C.c_uint32, C.c_uint32, pu32, vp, vp, vp]
+    L.mxg_dg_pack_msg_slots.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.mxg_dg_edges_slots.argtypes = [vp, vp, C.c_uint32, C.c_uint32, pu64, pu64, pu32]
     L.mxg_write_dot.argtypes = [vp, cp]
     L.mxg_py_repr_double.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
     L.mxg_py_repr_double.restype = C.c_size_t

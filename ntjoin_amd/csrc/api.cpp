@@ -623,7 +623,13 @@ int mxg_dg_set_items(mxg_handle *h, int assembly, const void *d_items, uint32_t 
 int mxg_dg_vertices(mxg_handle *h, void *d_n_vertices)
 {
     if (!h || !d_n_vertices) return MXG_EINVAL;
-    DG_TRY(build_graph(h, GRAPH_DG_VERTICES, d_n_vertices, 0))
+    try {
+        int rc = build_graph(h, GRAPH_DG_VERTICES, d_n_vertices, 0);
+        if (rc == MXG_OK && h->own_stream && hipStreamSynchronize(h->stream) != hipSuccess) rc = MXG_EDEVICE;
+        return rc;  // (own stream: the word feeds a collective on another stream)
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_dg_vertices");
+    }
 }
 
 int mxg_dg_item_results(mxg_handle *h, int assembly, const void *d_gbase, uint32_t world, const uint64_t *sec_start,
@@ -659,6 +665,40 @@ int mxg_dg_edges(mxg_handle *h, const void *d_msgs, uint64_t n_msgs, uint64_t *n
     if (n_vertices) *n_vertices = h->graph.nv;
     if (n_edges) *n_edges = h->graph.ne;
     return MXG_OK;
+}
+
+int mxg_dg_pack_slots(mxg_handle *h, int assembly, uint32_t rec_offset, uint32_t world, uint32_t n_asm, const uint32_t *cap,
+                      void *d_send)
+{
+    Assembly *a = get_asm(h, assembly);
+    if (!a || !cap || !d_send) return MXG_EINVAL;
+    DG_TRY(dg_pack_slots(h, a, (uint32_t)assembly, rec_offset, world, n_asm, cap, d_send))
+}
+
+int mxg_dg_owner_slots(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv, void *d_n_vertices)
+{
+    if (!h || !cap || !d_recv || !d_n_vertices) return MXG_EINVAL;
+    DG_TRY(dg_owner_slots(h, world, n_asm, cap, d_recv, d_n_vertices))
+}
+
+int mxg_dg_slot_results(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv,
+                        const void *d_gbase, void *d_out)
+{
+    if (!h || !cap || !d_recv || !d_gbase || !d_out) return MXG_EINVAL;
+    DG_TRY(dg_slot_results(h, world, n_asm, cap, d_recv, d_gbase, d_out))
+}
+
+int mxg_dg_pack_msg_slots(mxg_handle *h, uint32_t world, uint32_t max_msgs, const void *d_ret, const void *d_bases, void *d_send)
+{
+    if (!h || !d_ret || !d_bases || !d_send || world == 0 || world > 64) return MXG_EINVAL;
+    DG_TRY(dg_pack_msg_slots(h, world, max_msgs, d_ret, d_bases, d_send))
+}
+
+int mxg_dg_edges_slots(mxg_handle *h, const void *d_recv, uint32_t world, uint32_t max_msgs, uint64_t *n_vertices,
+                       uint64_t *n_edges, uint32_t *overflow)
+{
+    if (!h || !d_recv || world == 0 || world > 64) return MXG_EINVAL;
+    DG_TRY(dg_edges_slots(h, d_recv, world, max_msgs, n_vertices, n_edges, overflow))
 }
 
 int mxg_write_dot(mxg_handle *h, const char *path)

@@ -463,4 +463,331 @@ int dg_pack_msgs(mxg_handle *h, Assembly *a, uint32_t assembly, uint32_t world, 
     return MXG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Steady state: fixed-capacity slots.  Once the sizes of one exact exchange are known, every (source, destination) pair
+// gets a slot of fixed capacity (header of counts + one region per assembly); the all-to-alls then have equal splits
+// (no size exchange), and the receivers read the counts from the headers ON THE DEVICE (no host sync until the stage's
+// last kernel).  A count above its capacity raises an overflow word and the caller repeats the step the exact way.
+// ------------------------------------------------------------------------------------------------------
+struct DgSlots {
+    uint32_t world, n_asm;
+    uint32_t cap[8];   // items per assembly and slot
+    uint32_t off[8];   // first item of assembly a inside a slot's item area
+    uint32_t items;    // items per slot
+    uint64_t stride;   // bytes per slot: 64 (header: u64 count per assembly) + 16 * items
+};
+
+static int dg_layout(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, DgSlots *L)
+{
+    if (world == 0 || world > 64 || n_asm == 0 || n_asm > 8) return set_err(h, MXG_ELIMIT, "slots: 1..64 ranks, 1..8 assemblies");
+    L->world = world;
+    L->n_asm = n_asm;
+    uint32_t off = 0;
+    for (uint32_t a = 0; a < 8; ++a) {
+        L->cap[a] = a < n_asm ? cap[a] : 0;
+        L->off[a] = off;
+        off += L->cap[a];
+    }
+    L->items = off;
+    L->stride = 64 + (uint64_t)off * 16;
+    return MXG_OK;
+}
+
+__device__ __forceinline__ const unsigned long long *slot_hdr(const unsigned char *buf, const DgSlots &L, uint32_t s)
+{
+    return reinterpret_cast<const unsigned long long *>(buf + (size_t)s * L.stride);
+}
+
+__global__ __launch_bounds__(256) void k_dg_pack_slots(const uint64_t *__restrict__ hash, const uint32_t *__restrict__ pos,
+                                                       const uint32_t *__restrict__ rec, uint64_t n, uint32_t a, uint32_t rec_off,
+                                                       const DgSlots L, unsigned char *send, uint32_t *perm)
+{
+    __shared__ uint32_t lh[64], lcur[64];
+    __shared__ unsigned long long lbase[64];
+    if (threadIdx.x < 64) lh[threadIdx.x] = lcur[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * DG_IPB;
+    for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
+        const uint64_t i = i0 + it * 256u + threadIdx.x;
+        const bool in = i < n;
+        lds_hist(lh, in ? dg_owner(hash[i], L.world) : 0u, in);
+    }
+    __syncthreads();
+    if (threadIdx.x < L.world && lh[threadIdx.x])  // the header word of the destination's slot is the bucket's cursor
+        lbase[threadIdx.x] = atomicAdd(reinterpret_cast<unsigned long long *>(send + (size_t)threadIdx.x * L.stride) + a,
+                                       (unsigned long long)lh[threadIdx.x]);
+    __syncthreads();
+    for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
+        const uint64_t i = i0 + it * 256u + threadIdx.x;
+        const bool in = i < n;
+        const uint64_t h = in ? hash[i] : 0;
+        const uint32_t d = in ? dg_owner(h, L.world) : 0u;
+        const uint32_t sl = lds_slot(lcur, d, in);
+        if (in) {
+            const uint64_t idx = lbase[d] + sl;
+            if (idx < L.cap[a]) {
+                reinterpret_cast<uint4 *>(send + (size_t)d * L.stride + 64)[L.off[a] + idx] =
+                    make_uint4((uint32_t)h, (uint32_t)(h >> 32), pos[i], rec[i] + rec_off);
+                perm[i] = d * L.items + L.off[a] + (uint32_t)idx;
+            } else {
+                perm[i] = 0;  // slot overflow: the receiver raises the overflow word, the step is repeated
+            }
+        }
+    }
+}
+
+// assembly a's items of all sources, in source order, as SoA; n_out[a] = their number; *ovf |= some count > capacity
+__global__ __launch_bounds__(256) void k_dg_slots_to_soa(const unsigned char *__restrict__ recv, const DgSlots L, uint32_t a,
+                                                         uint64_t *hash, uint32_t *pos, uint32_t *rec, uint32_t *n_out, uint32_t *ovf)
+{
+    const uint32_t cap = L.cap[a];
+    const uint64_t o = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (o >= (uint64_t)L.world * cap) return;
+    const uint32_t src = (uint32_t)(o / cap), idx = (uint32_t)(o % cap);
+    uint32_t before = 0, mine = 0, total = 0;
+    for (uint32_t s = 0; s < L.world; ++s) {
+        const unsigned long long raw = slot_hdr(recv, L, s)[a];
+        if (raw > cap && o == 0) *ovf = 1;
+        const uint32_t c = (uint32_t)min(raw, (unsigned long long)cap);
+        if (s < src) before += c;
+        if (s == src) mine = c;
+        total += c;
+    }
+    if (o == 0) n_out[a] = total;
+    if (idx >= mine) return;
+    const uint4 it = reinterpret_cast<const uint4 *>(recv + (size_t)src * L.stride + 64)[L.off[a] + idx];
+    const uint32_t t = before + idx;
+    hash[t] = ((uint64_t)it.y << 32) | it.x;
+    pos[t] = it.z;
+    rec[t] = it.w;
+}
+
+// the verdicts of assembly a's items, written where the items sat: out[src][off[a] + idx]
+__global__ __launch_bounds__(256) void k_dg_slot_results(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ ivid,
+                                                         const unsigned char *__restrict__ recv, const DgSlots L, uint32_t a,
+                                                         const uint32_t *__restrict__ gbase_ptr, unsigned long long *out)
+{
+    const uint32_t cap = L.cap[a];
+    const uint64_t o = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (o >= (uint64_t)L.world * cap) return;
+    const uint32_t src = (uint32_t)(o / cap), idx = (uint32_t)(o % cap);
+    uint32_t before = 0, mine = 0;
+    for (uint32_t s = 0; s <= src; ++s) {
+        const uint32_t c = (uint32_t)min(slot_hdr(recv, L, s)[a], (unsigned long long)cap);
+        if (s < src) before += c; else mine = c;
+    }
+    if (idx >= mine) return;
+    const uint32_t t = before + idx, v = ivid[t];
+    out[(size_t)src * L.items + L.off[a] + idx] = ((unsigned long long)(v == DG_NONE ? DG_NONE : v + *gbase_ptr) << 8) | flags[t];
+}
+
+// adjacency messages into slots of M messages per destination (header word 0 = count)
+__global__ __launch_bounds__(256) void k_dg_pack_msg_slots(const uint32_t *__restrict__ fg, const uint32_t *__restrict__ frec,
+                                                           const uint32_t *__restrict__ n_shared, const uint32_t *__restrict__ bases,
+                                                           uint32_t world, uint32_t assembly, uint32_t M, unsigned char *send)
+{
+    __shared__ uint32_t lh[64], lcur[64];
+    __shared__ unsigned long long lbase[64];
+    if (threadIdx.x < 64) lh[threadIdx.x] = lcur[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t ns = *n_shared;
+    const uint32_t r0 = blockIdx.x * DG_IPB;
+    if (r0 + 1 >= ns) return;  // block-uniform
+    const uint64_t stride = 64 + (uint64_t)M * 16;
+    for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
+        const uint32_t r = r0 + it * 256u + threadIdx.x;
+        const bool in = r + 1 < ns && frec[r] == frec[r + 1];
+        lds_hist(lh, in ? dg_vertex_owner(bases, world, fg[r]) : 0u, in);
+        lds_hist(lh, in ? dg_vertex_owner(bases, world, fg[r + 1]) : 0u, in);
+    }
+    __syncthreads();
+    if (threadIdx.x < world && lh[threadIdx.x])
+        lbase[threadIdx.x] = atomicAdd(reinterpret_cast<unsigned long long *>(send + (size_t)threadIdx.x * stride),
+                                       (unsigned long long)lh[threadIdx.x]);
+    __syncthreads();
+    for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
+        const uint32_t r = r0 + it * 256u + threadIdx.x;
+        const bool in = r + 1 < ns && frec[r] == frec[r + 1];
+        const uint32_t u = in ? fg[r] : 0u, v = in ? fg[r + 1] : 0u;
+        const uint32_t ou = in ? dg_vertex_owner(bases, world, u) : 0u, ov = in ? dg_vertex_owner(bases, world, v) : 0u;
+        const uint32_t su = lds_slot(lcur, ou, in);
+        const uint32_t sv = lds_slot(lcur, ov, in);
+        if (in) {
+            const uint64_t iu = lbase[ou] + su, iv = lbase[ov] + sv;
+            if (iu < M) reinterpret_cast<uint4 *>(send + (size_t)ou * stride + 64)[iu] = make_uint4(assembly, u - bases[ou], v, 0u);
+            if (iv < M) reinterpret_cast<uint4 *>(send + (size_t)ov * stride + 64)[iv] = make_uint4(assembly | 256u, v - bases[ov], u, 0u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_apply_msg_slots(const unsigned char *__restrict__ recv, uint32_t world, uint32_t M,
+                                                         uint32_t nvs, uint32_t *nxt, uint32_t *prv, uint32_t *ovf)
+{
+    const uint64_t o = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (o >= (uint64_t)world * M) return;
+    const uint32_t src = (uint32_t)(o / M), idx = (uint32_t)(o % M);
+    const uint64_t stride = 64 + (uint64_t)M * 16;
+    const unsigned long long raw = *reinterpret_cast<const unsigned long long *>(recv + (size_t)src * stride);
+    if (raw > M && idx == 0) *ovf = 1;
+    if (idx >= min(raw, (unsigned long long)M)) return;
+    const uint4 m = reinterpret_cast<const uint4 *>(recv + (size_t)src * stride + 64)[idx];
+    uint32_t *dst = (m.x >> 8) ? prv : nxt;
+    dst[(size_t)(m.x & 255u) * nvs + m.y] = m.z;
+}
+
+// sender: assembly a's minimizers into the slots of d_send (headers zeroed by the caller)
+int dg_pack_slots(mxg_handle *h, Assembly *a, uint32_t ai, uint32_t rec_offset, uint32_t world, uint32_t n_asm, const uint32_t *cap,
+                  void *d_send)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    DgSlots L;
+    int rc = dg_layout(h, world, n_asm, cap, &L);
+    if (rc != MXG_OK) return rc;
+    MXG_HIP(h, a->d_perm.ensure(std::max<uint64_t>(a->n_mx * 4, 16)));
+    if (ai == 0)  // the slot headers are the buckets' cursors: cleared here, on the stream the packing kernels run on
+        MXG_HIP(h, hipMemset2DAsync(d_send, L.stride, 0, 64, world, h->stream));
+    if (a->n_mx)
+        hipLaunchKernelGGL(k_dg_pack_slots, dim3((uint32_t)((a->n_mx + DG_IPB - 1) / DG_IPB)), dim3(256), 0, h->stream,
+                           a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(), a->d_rec.as<uint32_t>(), a->n_mx, ai, rec_offset, L,
+                           static_cast<unsigned char *>(d_send), a->d_perm.as<uint32_t>());
+    MXG_HIP(h, hipGetLastError());
+    if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));
+    return MXG_OK;
+}
+
+// owner: everything between the item exchange and the verdict exchange, no host sync: items of every assembly out of
+// the slots, uniqueness / intersection / local vertex ids with the counts read on the device, vertex count -> d_nv
+int dg_owner_slots(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv, void *d_nv)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    DgSlots L;
+    int rc = dg_layout(h, world, n_asm, cap, &L);
+    if (rc != MXG_OK) return rc;
+    if (n_asm != h->asms.size()) return set_err(h, MXG_EINVAL, "slots: the owner handle has %zu assemblies", h->asms.size());
+    MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4 + 16));
+    uint32_t *ovf = h->d_nmx.as<uint32_t>() + MXG_MAX_ASSEMBLIES;  // the word after the counts
+    MXG_HIP(h, hipMemsetAsync(ovf, 0, 4, h->stream));
+    GraphBounds gb;
+    for (uint32_t ai = 0; ai < n_asm; ++ai) {
+        Assembly *a = h->asms[ai];
+        const uint64_t bound = (uint64_t)world * L.cap[ai];
+        MXG_HIP(h, a->d_hash.ensure(std::max<uint64_t>(bound * 8, 16)));
+        MXG_HIP(h, a->d_pos.ensure(std::max<uint64_t>(bound * 4, 16)));
+        MXG_HIP(h, a->d_rec.ensure(std::max<uint64_t>(bound * 4, 16)));
+        if (bound)
+            hipLaunchKernelGGL(k_dg_slots_to_soa, dim3((uint32_t)((bound + 255) / 256)), dim3(256), 0, h->stream,
+                               static_cast<const unsigned char *>(d_recv), L, ai, a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(),
+                               a->d_rec.as<uint32_t>(), h->d_nmx.as<uint32_t>(), ovf);
+        a->n_mx = bound;  // an upper bound until mxg_dg_edges_slots reads the counts back
+        a->has_sketch = true;
+        a->fwd_valid = false;
+        a->foreign_sketch = true;
+        a->host_valid = false;
+        gb.n_bound[ai] = bound;
+        gb.n_ptr[ai] = h->d_nmx.as<uint32_t>() + ai;
+    }
+    MXG_HIP(h, hipGetLastError());
+    rc = build_graph(h, GRAPH_DG_VERTICES, d_nv, 0, &gb);
+    if (rc == MXG_OK && h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));  // d_nv feeds a collective elsewhere
+    return rc;
+}
+
+int dg_slot_results(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv, const void *d_gbase,
+                    void *d_out)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    DgSlots L;
+    int rc = dg_layout(h, world, n_asm, cap, &L);
+    if (rc != MXG_OK) return rc;
+    for (uint32_t ai = 0; ai < n_asm; ++ai) {
+        Assembly *a = h->asms[ai];
+        const uint64_t bound = (uint64_t)world * L.cap[ai];
+        if (!bound) continue;
+        if (h->graph.nv_stride == 0) {  // no vertex at this owner: nobody made d_ivid
+            MXG_HIP(h, a->d_ivid.ensure(bound * 4 + 16));
+            MXG_HIP(h, hipMemsetAsync(a->d_ivid.p, 0xFF, bound * 4, h->stream));
+        }
+        hipLaunchKernelGGL(k_dg_slot_results, dim3((uint32_t)((bound + 255) / 256)), dim3(256), 0, h->stream,
+                           a->d_flags.as<uint8_t>(), a->d_ivid.as<uint32_t>(), static_cast<const unsigned char *>(d_recv), L, ai,
+                           static_cast<const uint32_t *>(d_gbase), static_cast<unsigned long long *>(d_out));
+    }
+    MXG_HIP(h, hipGetLastError());
+    if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));
+    return MXG_OK;
+}
+
+// sender: verdicts -> flags, shared minimizers in order, adjacency messages of every assembly into the message slots
+int dg_pack_msg_slots(mxg_handle *h, uint32_t world, uint32_t M, const void *d_ret, const void *d_bases, void *d_send)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    const size_t A = h->asms.size();
+    MXG_HIP(h, hipMemset2DAsync(d_send, 64 + (size_t)M * 16, 0, 64, world, h->stream));  // headers = cursors
+    for (size_t ai = 0; ai < A; ++ai) {
+        Assembly *a = h->asms[ai];
+        const uint32_t n = (uint32_t)a->n_mx;
+        const uint32_t blocks = (n + 255) / 256;
+        MXG_HIP(h, a->d_flags.ensure(std::max<uint32_t>(n, 16)));
+        MXG_HIP(h, a->d_dgtmp.ensure(((size_t)sup_words(blocks) + blocks + 16) * 4));
+        MXG_HIP(h, a->d_fg.ensure((size_t)n * 4 + 16));
+        MXG_HIP(h, a->d_frec.ensure((size_t)n * 4 + 16));
+        uint32_t *sup = a->d_dgtmp.as<uint32_t>(), *cnt = sup + sup_words(blocks), *n_shared = cnt + blocks;
+        MXG_HIP(h, hipMemsetAsync(sup, 0, (size_t)sup_words(blocks) * 4, h->stream));
+        MXG_HIP(h, hipMemsetAsync(n_shared, 0, 4, h->stream));
+        if (n) {
+            DgAdjParams p;
+            p.ret = static_cast<const unsigned long long *>(d_ret);
+            p.perm = a->d_perm.as<uint32_t>();
+            p.rec = a->d_rec.as<uint32_t>();
+            p.n = n;
+            p.cnt = cnt;
+            p.sup = sup;
+            p.fg = a->d_fg.as<uint32_t>();
+            p.frec = a->d_frec.as<uint32_t>();
+            p.n_shared = n_shared;
+            p.flags_out = a->d_flags.as<uint8_t>();
+            hipLaunchKernelGGL(k_dg_shared_cnt, dim3(blocks), dim3(256), 0, h->stream, p);
+            hipLaunchKernelGGL(k_dg_compact, dim3(blocks), dim3(256), 0, h->stream, p);
+            hipLaunchKernelGGL(k_dg_pack_msg_slots, dim3((n + DG_IPB - 1) / DG_IPB), dim3(256), 0, h->stream, p.fg, p.frec, n_shared,
+                               static_cast<const uint32_t *>(d_bases), world, (uint32_t)ai, M, static_cast<unsigned char *>(d_send));
+        }
+        a->flags_valid = true;
+        a->flags_on_host = false;
+    }
+    MXG_HIP(h, hipGetLastError());
+    if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));
+    return MXG_OK;
+}
+
+// owner: adjacency out of the message slots, edges, the stage's one host sync; *overflow != 0: some slot was too small
+// somewhere on this rank's receiving side, the results are incomplete
+int dg_edges_slots(mxg_handle *h, const void *d_recv, uint32_t world, uint32_t M, uint64_t *n_vertices, uint64_t *n_edges,
+                   uint32_t *overflow)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    Graph &g = h->graph;
+    const uint32_t A = (uint32_t)h->asms.size();
+    const uint64_t nvs = g.nv_stride;
+    uint32_t *ovf = h->d_nmx.as<uint32_t>() + MXG_MAX_ASSEMBLIES;
+    if (nvs) {
+        const size_t anv = (size_t)A * nvs;
+        MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4));
+        MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));
+        const uint64_t tot = (uint64_t)world * M;
+        if (tot)
+            hipLaunchKernelGGL(k_apply_msg_slots, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, h->stream,
+                               static_cast<const unsigned char *>(d_recv), world, M, (uint32_t)nvs, h->g_nxt.as<uint32_t>(),
+                               h->g_nxt.as<uint32_t>() + anv, ovf);
+        MXG_HIP(h, hipGetLastError());
+    }
+    int rc = build_graph(h, GRAPH_DG_EDGES_APPLIED);
+    if (rc != MXG_OK) return rc;
+    uint32_t back[MXG_MAX_ASSEMBLIES + 1];
+    MXG_HIP(h, hipMemcpy(back, h->d_nmx.p, sizeof back, hipMemcpyDeviceToHost));
+    for (uint32_t ai = 0; ai < A; ++ai) h->asms[ai]->n_mx = back[ai];  // the real item counts
+    if (n_vertices) *n_vertices = g.nv;
+    if (n_edges) *n_edges = g.ne;
+    if (overflow) *overflow = back[MXG_MAX_ASSEMBLIES];
+    return MXG_OK;
+}
+
 }  // namespace mxg

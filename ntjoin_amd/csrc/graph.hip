@@ -331,11 +331,12 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, co
         n_of[ai] = gb ? gb->n_bound[ai] : a->n_mx;
         N += n_of[ai];
         nmin = std::min(nmin, n_of[ai]);
-        if (mode != GRAPH_DG_EDGES) a->flags_valid = a->flags_on_host = false;
+        if (mode != GRAPH_DG_EDGES && mode != GRAPH_DG_EDGES_APPLIED) a->flags_valid = a->flags_on_host = false;
     }
     if (N >= (1ull << 30)) return set_err(h, MXG_ELIMIT, "too many minimizers for one table (%llu)", (unsigned long long)N);
     Graph &g = h->graph;
-    if (mode != GRAPH_DG_EDGES) g = Graph();
+    const bool resume = mode == GRAPH_DG_EDGES || mode == GRAPH_DG_EDGES_APPLIED;  // second half on the owner's handle
+    if (!resume) g = Graph();
     g.n_asm = A;
     const bool timing = (h->cfg.flags & MXG_FLAG_TIMING) != 0;
     if (timing) MXG_HIP(h, hipEventRecord(h->ev0, h->stream));
@@ -348,7 +349,7 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, co
     MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * sizeof(Slot)));
     MXG_HIP(h, h->g_vid.ensure(((size_t)cap + 1) * 4));
     MXG_HIP(h, h->g_ctl.ensure(CTL_WORDS * 8));
-    if (mode != GRAPH_DG_EDGES)
+    if (!resume)
         MXG_HIP(h, hipMemsetAsync(h->g_keys.p, 0xFF, ((size_t)cap + 1) * sizeof(Slot), h->stream));  // one fill: see Slot
     uint64_t *ctl = h->g_ctl.as<uint64_t>();  // every word the host reads below is written by a kernel of this call
 
@@ -395,7 +396,7 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, co
     const uint32_t n_fsup = ((nb >> SUP_SHIFT) + A + 1) * SUP_STRIDE, n_esup = sup_words(e_blocks);
     MXG_HIP(h, h->g_cnt.ensure(((size_t)n_fsup + n_esup + nb) * 4 + 64));
     uint32_t *fsup = h->g_cnt.as<uint32_t>(), *esup = fsup + n_fsup, *cnt = esup + n_esup;
-    if (nb && mode != GRAPH_DG_EDGES) {
+    if (nb && !resume) {
         hipLaunchKernelGGL(k_insert, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), mask, cap, fsup,
                            n_fsup + n_esup);
         // flags + shared minimizers per 256 of every assembly (their totals, equal by construction, land in ctl[a])
@@ -409,9 +410,9 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, co
         MXG_HIP(h, h->g_fv.ensure(anv * 4));
         MXG_HIP(h, h->g_frec.ensure(anv * 4));
         MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4));  // nxt[A][nvs] followed by prv[A][nvs]: one fill
-        if (mode != GRAPH_DG_VERTICES) MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));
+        if (mode == GRAPH_FULL || mode == GRAPH_DG_EDGES) MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));
         uint32_t *const d_prv = h->g_nxt.as<uint32_t>() + anv;
-        for (uint32_t a = 0; a < A && mode != GRAPH_DG_EDGES; ++a) {  // assembly 0 assigns the vertex ids the others look up
+        for (uint32_t a = 0; a < A && !resume; ++a) {  // assembly 0 assigns the vertex ids the others look up
             Assembly *as = h->asms[a];
             const uint32_t n = (uint32_t)n_of[a];
             VertexParams vp;
@@ -448,8 +449,8 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, co
         if (mode == GRAPH_FULL) {
             hipLaunchKernelGGL(k_adjacency, dim3((uint32_t)((nvs + 255) / 256), A), dim3(256), 0, h->stream,
                                h->g_fv.as<uint32_t>(), h->g_frec.as<uint32_t>(), ctl, h->g_nxt.as<uint32_t>(), d_prv, (uint32_t)nvs);
-        } else {  // GRAPH_DG_EDGES: every local vertex is an item (fv = identity), adjacency from the messages
-            if (n_msgs)
+        } else {  // second half on the owner: every local vertex is an item (fv = identity), adjacency from messages
+            if (n_msgs && mode == GRAPH_DG_EDGES)
                 hipLaunchKernelGGL(k_apply_msgs, dim3((uint32_t)((n_msgs + 255) / 256)), dim3(256), 0, h->stream,
                                    static_cast<const uint4 *>(d_msgs), n_msgs, (uint32_t)nvs, h->g_nxt.as<uint32_t>(), d_prv);
             hipLaunchKernelGGL(k_iota_rows, dim3((uint32_t)((nvs + 255) / 256), A), dim3(256), 0, h->stream,

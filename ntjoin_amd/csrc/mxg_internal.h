@@ -241,7 +241,7 @@ int pack_sketch(mxg_handle *h, Assembly *a, void *d_buf, uint64_t nmax);
 int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t world, uint64_t nmax,
                     const uint64_t *counts, const uint64_t *rec_offsets, uint64_t stride_bytes = 0);
 // graph.hip
-enum { GRAPH_FULL = 0, GRAPH_DG_VERTICES = 1, GRAPH_DG_EDGES = 2 };
+enum { GRAPH_FULL = 0, GRAPH_DG_VERTICES = 1, GRAPH_DG_EDGES = 2, GRAPH_DG_EDGES_APPLIED = 3 /* nxt/prv already filled */ };
 struct GraphBounds {  // fused sketch+graph call: per assembly an upper bound of its sketch and where the count will be
     uint64_t n_bound[MXG_MAX_ASSEMBLIES];
     const uint32_t *n_ptr[MXG_MAX_ASSEMBLIES];
@@ -260,6 +260,14 @@ int dg_item_results(mxg_handle *h, Assembly *a, const void *d_gbase, uint32_t wo
 int dg_msg_counts(mxg_handle *h, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts);
 int dg_pack_msgs(mxg_handle *h, Assembly *a, uint32_t assembly, uint32_t world, const void *d_bases, const uint64_t *starts,
                  void *d_send);
+int dg_pack_slots(mxg_handle *h, Assembly *a, uint32_t ai, uint32_t rec_offset, uint32_t world, uint32_t n_asm, const uint32_t *cap,
+                  void *d_send);
+int dg_owner_slots(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv, void *d_nv);
+int dg_slot_results(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv, const void *d_gbase,
+                    void *d_out);
+int dg_pack_msg_slots(mxg_handle *h, uint32_t world, uint32_t M, const void *d_ret, const void *d_bases, void *d_send);
+int dg_edges_slots(mxg_handle *h, const void *d_recv, uint32_t world, uint32_t M, uint64_t *n_vertices, uint64_t *n_edges,
+                   uint32_t *overflow);
 int path_segments(mxg_handle *h, uint32_t assembly);
 int mx_extremes(mxg_handle *h, uint32_t assembly);
 int flush_timers(mxg_handle *h);                // sketch.hip: fold the recorded event pairs into h->tm

@@ -12,6 +12,8 @@ concatenation => results identical for any number of ranks).  Every rank then bu
 gather_sketches() is device-agnostic (tensors in, tensors out) so the same code is exercised on CPU with gloo
 in tests/test_dist_cpu.py.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -299,6 +301,10 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
                      "nv": torch.zeros(1, dtype=torch.int64, device=dev), "nvs": torch.empty(world, dtype=torch.int64, device=dev),
                      "bases": torch.zeros(world + 1, dtype=torch.int32, device=dev)}
     buf, st = owner._buf, owner._st
+    if getattr(owner, "_slots", None) is not None and os.environ.get("MXG_DG_EXACT") != "1":
+        if _partitioned_slots(eng, owner, A, world, rank, dev, group, stream):
+            return owner
+        owner._slots = None                  # a slot was too small somewhere: this step the exact way, new capacities
     prof = getattr(owner, "_prof", None)     # tools: owner._prof = {} collects host seconds per section
     import time as _time
     t_last = [_time.perf_counter()]
@@ -342,6 +348,8 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
                            output_split_sizes=from_src.tolist(), input_split_sizes=to_dest.tolist(), group=group)
     mark("3_items_a2a")
     # 4. owner: uniqueness, intersection, local vertex ids (the vertex count stays on the device)
+    if stream is None:
+        cur.synchronize()                                      # ... and the items must have arrived
     secs = []
     for a in range(A):
         sec_start = (src_start + got[:, :a].sum(axis=1)).astype(np.uint64)
@@ -365,6 +373,8 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
                            output_split_sizes=to_dest.tolist(), input_split_sizes=from_src.tolist(), group=group)
     mark("6_verdicts_a2a")
     # 7. adjacency of MY records -> messages to the owners of the two end points                  (host sync 3)
+    if stream is None:
+        cur.synchronize()
     mcnt = np.zeros(A * world, dtype=np.uint64)
     chk(eng, lib.mxg_dg_msg_counts(eng._h, world, C.c_void_p(ret_in.data_ptr()), C.c_void_p(st["bases"].data_ptr()), _u64p(mcnt)))
     mcnt = mcnt.reshape(A, world).astype(np.int64)
@@ -394,7 +404,70 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
     chk(owner, lib.mxg_dg_edges(owner._h, C.c_void_p(mrecv.data_ptr()), n_mrecv, C.byref(nv_l), C.byref(ne_l)))
     mark("9_owner_edges")
     owner.dg = {"local_vertices": int(nv_l.value), "local_edges": int(ne_l.value), "rank": rank, "world": world}
+    # capacities for the steady state (fixed slots, device-side counts): 30 % above the largest bucket any rank saw
+    if A <= 8 and os.environ.get("MXG_DG_EXACT") != "1":
+        big = torch.tensor(list(cnt.max(axis=1)) + [int(m_to.max()) if world else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(big, op=dist.ReduceOp.MAX, group=group)
+        big = big.cpu().numpy()
+        pct = int(os.environ.get("MXG_DG_SLOT_PCT", "130"))    # test knob: < 100 makes every slot overflow
+        pad = 64 if pct >= 100 else 0
+        caps = np.array([((int(x) * pct // 100 + pad) + 7) // 8 * 8 for x in big[:A]], dtype=np.uint32)
+        owner._slots = {"caps": caps, "items": int(caps.sum()), "M": ((int(big[A]) * pct // 100 + pad) + 7) // 8 * 8,
+                        "flag": torch.zeros(1, dtype=torch.int32, device=dev)}
     return owner
+
+
+def _partitioned_slots(eng, owner, A, world, rank, dev, group, stream):
+    """one step of the partitioned graph stage with fixed-capacity slots: 4 all-to-all / all-gather collectives with equal
+    splits, counts read on the device, ONE host sync (the owner's last kernel) + the agreement on overflow.  False: a
+    slot overflowed on some rank (all ranks return False together)."""
+    import ctypes as C
+    lib, sl, st, buf = eng._lib, owner._slots, owner._st, owner._buf
+    caps, items, M = sl["caps"], sl["items"], sl["M"]
+    capp = caps.ctypes.data_as(C.POINTER(C.c_uint32))
+    cur = torch.cuda.current_stream()
+    stride, mstride = 64 + 16 * items, 64 + 16 * M
+
+    def chk(e, rc):
+        if rc < 0:
+            e._check(rc)
+
+    send = _grow(buf, "s_send", world * stride, dev)[:world * stride]
+    recv = _grow(buf, "s_recv", world * stride, dev)[:world * stride]
+    for a in range(A):
+        chk(eng, lib.mxg_dg_pack_slots(eng._h, a, owner._rec_off[a], world, A, capp, C.c_void_p(send.data_ptr())))
+    own = stream is None                                                      # handles on their own streams: a collective's
+    dist.all_to_all_single(recv.view(world, stride), send.view(world, stride), group=group)
+    if own:                                                                   # result must be complete before a handle reads it
+        cur.synchronize()
+    chk(owner, lib.mxg_dg_owner_slots(owner._h, world, A, capp, C.c_void_p(recv.data_ptr()), C.c_void_p(st["nv"].data_ptr())))
+    dist.all_gather_into_tensor(st["nvs"], st["nv"], group=group)
+    st["bases"][1:] = torch.cumsum(st["nvs"], 0).to(torch.int32)
+    if own:
+        cur.synchronize()
+    ret_out = _grow(buf, "s_ret_out", world * items * 8, dev)[:world * items * 8]
+    ret_in = _grow(buf, "s_ret_in", world * items * 8, dev)[:world * items * 8]
+    chk(owner, lib.mxg_dg_slot_results(owner._h, world, A, capp, C.c_void_p(recv.data_ptr()),
+                                       C.c_void_p(st["bases"].data_ptr() + 4 * rank), C.c_void_p(ret_out.data_ptr())))
+    dist.all_to_all_single(ret_in.view(world, items * 8), ret_out.view(world, items * 8), group=group)
+    if own:
+        cur.synchronize()
+    msend = _grow(buf, "s_msend", world * mstride, dev)[:world * mstride]
+    mrecv = _grow(buf, "s_mrecv", world * mstride, dev)[:world * mstride]
+    chk(eng, lib.mxg_dg_pack_msg_slots(eng._h, world, M, C.c_void_p(ret_in.data_ptr()), C.c_void_p(st["bases"].data_ptr()),
+                                       C.c_void_p(msend.data_ptr())))
+    dist.all_to_all_single(mrecv.view(world, mstride), msend.view(world, mstride), group=group)
+    if own:
+        cur.synchronize()
+    nv_l, ne_l, ovf = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    chk(owner, lib.mxg_dg_edges_slots(owner._h, C.c_void_p(mrecv.data_ptr()), world, M, C.byref(nv_l), C.byref(ne_l), C.byref(ovf)))
+    # overflow anywhere means everybody repeats the step the exact way: the ranks have to agree
+    sl["flag"].fill_(int(ovf.value != 0))
+    dist.all_reduce(sl["flag"], op=dist.ReduceOp.MAX, group=group)
+    if int(sl["flag"].item()):
+        return False
+    owner.dg = {"local_vertices": int(nv_l.value), "local_edges": int(ne_l.value), "rank": rank, "world": world}
+    return True
 
 
 def partitioned_totals(owner, group=None):

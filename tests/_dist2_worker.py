@@ -50,9 +50,10 @@ def main():
         union = allgather_union_graph(eng, k, w, 0, union, stream=xs)
     # the same graph, distributed by hash range: every rank ends up with its own vertices and edges
     owner = None
-    for _step in range(2):
+    for _step in range(3):                       # exact exchange, then twice with the fixed-capacity slots
         eng.sketch(-2)
         owner = partitioned_graph(eng, k, w, 0, owner, stream=xs)
+    os.write(1, f"slots in use: {owner._slots is not None}\n".encode())
     partitioned_totals(owner)
     pg = owner.get_graph()
     part = {"base": owner.dg["base"], "vhash": pg["vertex_hash"].tolist(),
@@ -104,6 +105,9 @@ def main():
             if got_e != want_e or n_e != len(want_e):
                 ok = False
                 os.write(1, f"MISMATCH partitioned edges {n_e} / {len(got_e)} vs {len(want_e)}\n".encode())
+                bad = [(k_, got_e.get(k_), want_e.get(k_)) for k_ in list(want_e) if got_e.get(k_) != want_e[k_]][:5]
+                extra = [(k_, got_e[k_]) for k_ in got_e if k_ not in want_e][:5]
+                os.write(1, f"  differing {bad}\n  extra {extra}\n".encode())
             if any(p["totals"] != (len(names0), len(want_e)) for p in parts):
                 ok = False
                 os.write(1, f"MISMATCH partitioned totals {[p['totals'] for p in parts]}\n".encode())
