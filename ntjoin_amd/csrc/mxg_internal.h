@@ -93,6 +93,7 @@ struct Assembly {
     // device copies of the tables above + strip / k-mer prefix tables (built once, by the first sketch)
     bool tables_ready = false;
     uint32_t S_sparse = 256;  // strip length chosen for the sparse hash kernel
+    uint32_t cand_hint = 0;   // candidates of the last sparse run (k_resolve: which blocks may load before the count arrives)
     std::vector<uint32_t> strip0_dense, strip0_sparse;  // [n_runs+1] exclusive prefix of strips per run
     std::vector<uint64_t> g0;                           // [n_runs+1] exclusive prefix of k-mers per run
     DevBuf d_runs, d_strip0_dense, d_strip0_sparse, d_g0, d_ctg_nk, d_ctg_rec, d_ctg_run0;

@@ -38,19 +38,30 @@ static __global__ __launch_bounds__(256) void k_count(const uint8_t *__restrict_
     if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
 }
 
-// inside a 256-thread block: exclusive prefix of per-thread counts `c` (uses sh[256]); all threads must call
-__device__ __forceinline__ uint32_t block_exclusive_256(uint32_t c, uint32_t *sh)
+__device__ __forceinline__ uint32_t wave_inclusive_u32(uint32_t v, uint32_t lane);
+
+// inside a block of NW waves: exclusive prefix of per-thread counts `c`; afterwards sh[255] holds the block total
+// (sh: >= 256 words, NW <= 8).  Wave scans by lane shuffles + NW wave totals through LDS: two barriers (a Hillis-Steele
+// scan over LDS took 17).  All threads of the block must call.
+template <int NW>
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t c, uint32_t *sh)
 {
-    sh[threadIdx.x] = c;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t incl = wave_inclusive_u32(c, lane);
+    if (lane == 63u) sh[wv] = incl;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t t = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < (uint32_t)NW; ++u) {
+        const uint32_t t = sh[u];
+        base += u < wv ? t : 0u;
+        total += t;
     }
-    return sh[threadIdx.x] - c;
+    if (threadIdx.x == 0) sh[255] = total;
+    __syncthreads();  // sh[255] visible; nobody still reads sh[0..NW) when a later call overwrites it
+    return base + incl - c;
 }
+__device__ __forceinline__ uint32_t block_exclusive_256(uint32_t c, uint32_t *sh) { return block_exclusive<4>(c, sh); }
 
 // exclusive scan of bsum[0..n) in place by ONE 256-thread block (16 elements per thread per pass); total -> *total
 static __global__ __launch_bounds__(256) void k_scan_sums(uint32_t *__restrict__ bsum, uint32_t n, uint64_t *__restrict__ total)
@@ -142,9 +153,13 @@ __device__ __forceinline__ uint32_t count_prefix(const uint32_t *__restrict__ cn
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ns = q >> SUP_SHIFT;
-    uint32_t acc = 0;
-    for (uint32_t i = lane; i < ns; i += 64) acc += sup[i * SUP_STRIDE];
-    for (uint32_t i = (ns << SUP_SHIFT) + lane; i < q; i += 64) acc += cnt[i];
+    // five independent loads per lane, issued together (as accumulating loops they were up to five dependent round trips)
+    const uint32_t b0 = (ns << SUP_SHIFT) + lane;
+    const uint32_t s0 = lane < ns ? sup[lane * SUP_STRIDE] : 0u;
+    const uint32_t v0 = b0 < q ? cnt[b0] : 0u, v1 = b0 + 64u < q ? cnt[b0 + 64u] : 0u;
+    const uint32_t v2 = b0 + 128u < q ? cnt[b0 + 128u] : 0u, v3 = b0 + 192u < q ? cnt[b0 + 192u] : 0u;
+    uint32_t acc = s0 + v0 + v1 + v2 + v3;
+    for (uint32_t i = lane + 64u; i < ns; i += 64) acc += sup[i * SUP_STRIDE];  // > 16384 producer blocks only
     return wave_sum_u32(acc);
 }
 

@@ -451,23 +451,29 @@ struct ReorderParams {
     HashTab tab;
 };
 
-template <int VARIANT>
-__global__ __launch_bounds__(256) void k_reorder(const ReorderParams p)
+// 320 threads: a slice holds ~290 candidates (64 strips x 320 k-mers x 1.4 %), so one pass of the block hashes them
+// all; with 256 threads a second, nearly empty pass doubled the block's lifetime (the kernel is latency-bound).
+constexpr uint32_t RB = 320;
+template <int VARIANT, int ABL = 0>
+__global__ __launch_bounds__(RB) void k_reorder(const ReorderParams p)
 {
     __shared__ uint4 tab[20];
     __shared__ uint4 btab[256];     // byte table of init_direct
     __shared__ uint32_t spref[64];  // ordered slot of the first candidate of each of this wave's 64 strips
     __shared__ uint4 smeta[64];     // their {contig, first k-mer index, base offset}
-    btab[threadIdx.x] = p.init_tab[threadIdx.x];
+    __shared__ uint32_t sh_last;    // candidates of the slice's last strip
+    if (threadIdx.x < 256) btab[threadIdx.x] = p.init_tab[threadIdx.x];
     if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
     const uint32_t wv = blockIdx.x;
-    const uint32_t cnt = min(p.wave_cnt[wv], p.wave_cap);
     const uint2 *src = p.arena + (size_t)wv * p.wave_cap;
-    // the first two entries of every thread are requested before anything else (a slice holds ~2 per thread)
-    const uint32_t i0 = threadIdx.x, i1 = threadIdx.x + 256u;
+    // The kernel is a chain of dependent memory round trips, so everything that can be asked for at once is: the first
+    // two entries of every thread (a slice holds about one per thread) are requested without waiting for the slice's
+    // entry count (the slice is allocated in full; what lies beyond the count is masked afterwards).
+    const uint32_t i0 = threadIdx.x, i1 = threadIdx.x + RB;
     uint2 a0 = make_uint2(0u, 0u), a1 = make_uint2(0u, 0u);
-    if (i0 < cnt) a0 = src[i0];
-    if (i1 < cnt) a1 = src[i1];
+    if (i0 < p.wave_cap) a0 = src[i0];
+    if (i1 < p.wave_cap) a1 = src[i1];
+    const uint32_t cnt = min(p.wave_cnt[wv], p.wave_cap);
     if (threadIdx.x < 64) {  // exclusive scan over the strips: the wave's first slot + prefix inside the wave
         const uint32_t s = wv * 64u + threadIdx.x;
         const bool in = s < p.n_strips;
@@ -476,19 +482,24 @@ __global__ __launch_bounds__(256) void k_reorder(const ReorderParams p)
         const uint32_t before = count_prefix(p.wave_tot, p.wave_sup, wv);
         const uint32_t incl = wave_inclusive_u32(c, threadIdx.x);
         spref[threadIdx.x] = before + incl - c;
+        if (threadIdx.x == 63) sh_last = c;
         if (wv + 1 == gridDim.x && threadIdx.x == 63) {
             p.n_cand[0] = before + incl;
             p.n_cand[1] = 0;
         }
     }
     __syncthreads();
-    auto hash_one = [&](const uint2 a, uint32_t u, uint32_t r) {  // candidate number r of entry a: k-mer u of its block
-        const uint32_t j0 = ((a.y >> 16) & 63u) * 16u;
-        const uint32_t dst = spref[a.x & 63u] + (a.y >> 22) + r;
+    // item = strip (lane of the hash kernel) | block << 6 | k-mer in the block << 12; dst = its ordered slot
+    auto hash_item = [&](const uint32_t item, const uint32_t dst) {
+        const uint32_t j0 = ((item >> 6) & 63u) * 16u, u = (item >> 12) & 15u;
         if (dst >= p.n_cap) return;  // beyond it only when a wave overflowed: the host redoes the batch
-        const uint4 sm = smeta[a.x & 63u];
+        const uint4 sm = smeta[item & 63u];
         H2 h = {0u, 0u, 0u, 0u};
-        init_direct(h, p.packed, (((uint64_t)sm.w << 32) | sm.z) + j0 + u, p.k, btab, tab);
+        if (ABL == 1) {  // (profiling only) no hashing: what the rest of the kernel costs
+            h.flo = sm.z + j0 + u; h.fhi = 0x00100000u; h.rlo = u; h.rhi = 0u;
+        } else {
+            init_direct(h, p.packed, (((uint64_t)sm.w << 32) | sm.z) + j0 + u, p.k, btab, tab);
+        }
         p.ch[dst] = canonical<VARIANT>(h);
         p.ck[dst] = sm.y + j0 + u;
         p.cc[dst] = sm.x;
@@ -496,41 +507,42 @@ __global__ __launch_bounds__(256) void k_reorder(const ReorderParams p)
     if (p.queue_cap) {
         // One thread per CANDIDATE: an entry holds 1.15 candidates on average but some lane of every wave holds 2 or 3,
         // so hashing per entry makes the whole wave walk the 8 table lookups 2-3 times.  The entries are expanded into
-        // a queue in LDS (item = entry << 8 | k-mer << 4 | rank) and the queue is hashed densely.
+        // a queue in LDS, every candidate at its ORDERED position inside the slice (first slot of its strip + rank:
+        // no scan), and the queue is hashed densely: thread q's candidate goes to slot base + q, so the stores of a
+        // wave are contiguous and its reads of the packed bases are neighbours.
         extern __shared__ uint32_t queue[];
-        __shared__ uint32_t sh_scan[256];
-        uint32_t qn = 0;
-        for (uint32_t e0 = 0; e0 < cnt; e0 += 256) {
+        const uint32_t base = spref[0];
+        const uint32_t qn = min(spref[63] + sh_last - base, p.queue_cap);
+        for (uint32_t e0 = 0; e0 < cnt; e0 += RB) {
             const uint32_t i = e0 + threadIdx.x;
-            const uint2 a = e0 == 0 ? a0 : (e0 == 256 ? a1 : (i < cnt ? src[i] : make_uint2(0u, 0u)));
+            uint2 a = e0 == 0 ? a0 : (e0 == RB ? a1 : (i < cnt ? src[i] : make_uint2(0u, 0u)));
+            if (i >= cnt) a = make_uint2(0u, 0u);
             uint32_t bits = a.y & 0xFFFFu;
-            uint32_t at = qn + block_exclusive_256((uint32_t)__popc(bits), sh_scan);
-            qn += sh_scan[255];
-            for (uint32_t r = 0; bits; ++r, ++at) {  // most significant bit = first k-mer of the block
+            const uint32_t item0 = (a.x & 63u) | (((a.y >> 16) & 63u) << 6);
+            uint32_t at = spref[a.x & 63u] - base + (a.y >> 22);
+            for (; bits; ++at) {  // most significant bit = first k-mer of the block
                 const uint32_t u = (uint32_t)__clz((int)bits) - 16u;
                 bits &= ~(0x8000u >> u);
-                if (at < p.queue_cap) queue[at] = (i << 8) | (u << 4) | r;
+                if (at < qn) queue[at] = item0 + (u << 12);
             }
-            __syncthreads();
         }
-        qn = min(qn, p.queue_cap);
-        for (uint32_t q = threadIdx.x; q < qn; q += 256) {
-            const uint32_t item = queue[q];
-            hash_one(src[item >> 8], (item >> 4) & 15u, item & 15u);
-        }
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < qn; q += RB) hash_item(queue[q], base + q);
         return;
     }
     auto place = [&](const uint2 a) {  // (slices too large for the queue: one thread per entry)
         uint32_t bits = a.y & 0xFFFFu;
-        for (uint32_t r = 0; bits; ++r) {
+        const uint32_t item0 = (a.x & 63u) | (((a.y >> 16) & 63u) << 6);
+        uint32_t dst = spref[a.x & 63u] + (a.y >> 22);
+        for (; bits; ++dst) {
             const uint32_t u = (uint32_t)__clz((int)bits) - 16u;
             bits &= ~(0x8000u >> u);
-            hash_one(a, u, r);
+            hash_item(item0 + (u << 12), dst);
         }
     };
-    place(a0);
-    place(a1);
-    for (uint32_t i = threadIdx.x + 512u; i < cnt; i += 256) place(src[i]);
+    place(i0 < cnt ? a0 : make_uint2(0u, 0u));
+    place(i1 < cnt ? a1 : make_uint2(0u, 0u));
+    for (uint32_t i = threadIdx.x + 2u * RB; i < cnt; i += RB) place(src[i]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -541,6 +553,8 @@ struct ResolveParams {
     const uint32_t *ck, *cc;
     const uint32_t *n_ptr;  // number of candidates (device), clamped to n_cap
     uint32_t n_cap;
+    uint32_t n_likely;      // hint (the count of the previous run of this batch, 0: none): blocks below it request their
+                            // entries before the count has arrived
     const uint32_t *ovf;    // != 0: a wave overflowed its arena slice, candidate arrays are incomplete -> do nothing
     uint64_t tau;           // entries with hash >= tau are not candidates (ring-test false positives); dense: 2^64-1
     const uint32_t *ctg_nk;
@@ -625,27 +639,56 @@ __device__ __forceinline__ bool coop_right_blocked(const CoopCtx &q, uint32_t la
     }
 }
 
-constexpr int RH = 128;  // halo (candidates) staged on each side of a block's 256 candidates
+constexpr int RH = 64;   // halo (candidates) staged on each side of a block's 256 candidates
 constexpr int RP = 4;    // padding entries so that 4-wide neighbour groups never index outside the arrays
 
-template <bool GAPS, bool COUNT>
+template <bool GAPS, bool COUNT, int ABL = 0>
 __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
 {
     __shared__ uint64_t lh[256 + 2 * RH + 2 * RP];
     __shared__ uint2 lkc[256 + 2 * RH + 2 * RP];  // {k-mer index, contig}; contig = ~0 outside the candidate array
-    const uint32_t n = min(*p.n_ptr, p.n_cap);
+    constexpr uint32_t TOT = 256 + 2 * RH + 2 * RP;
+    static_assert(TOT <= 512, "two staged entries per thread");
     const uint32_t i0 = blockIdx.x * 256u;
-    if (i0 >= n || *p.ovf) return;
-    for (uint32_t e = threadIdx.x; e < 256 + 2 * RH + 2 * RP; e += 256) {
+    // Blocks that the previous run's count says will be in use request their entries before the candidate count has
+    // arrived (the arrays hold n_cap entries; what lies beyond the count is masked below): one memory round trip for
+    // the block instead of two.  The others (the grid covers n_cap, about twice the count) wait for it and mostly exit.
+    const bool early = i0 + 256u <= p.n_likely;  // (block-uniform)
+    uint32_t n = 0, ovf = 0;
+    if (!early) {
+        n = min(*p.n_ptr, p.n_cap);
+        ovf = *p.ovf;
+        if (i0 >= n || ovf) return;
+    }
+    const uint32_t bound = early ? p.n_cap : n;
+    uint64_t vh[2];
+    uint32_t vk[2], vc[2];
+#pragma unroll
+    for (uint32_t r = 0; r < 2; ++r) {
+        const uint32_t e = threadIdx.x + 256u * r;
         const int64_t g = (int64_t)i0 - RH - RP + e;
-        if (g >= 0 && g < (int64_t)n) {
-            lh[e] = p.ch[g];
-            lkc[e] = make_uint2(p.ck[g], p.cc[g] & 0x7FFFFFFFu);
-        } else {
-            lh[e] = 0;
-            lkc[e] = make_uint2(0u, 0xFFFFFFFFu);
+        vh[r] = 0; vk[r] = 0; vc[r] = 0;
+        if (e < TOT && g >= 0 && g < (int64_t)bound) {
+            vh[r] = p.ch[g];
+            vk[r] = p.ck[g];
+            vc[r] = p.cc[g];
         }
     }
+    if (early) {
+        n = min(*p.n_ptr, p.n_cap);
+        ovf = *p.ovf;
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < 2; ++r) {
+        const uint32_t e = threadIdx.x + 256u * r;
+        const int64_t g = (int64_t)i0 - RH - RP + e;
+        if (e < TOT) {
+            const bool in = g >= 0 && g < (int64_t)n;
+            lh[e] = in ? vh[r] : 0ull;
+            lkc[e] = in ? make_uint2(vk[r], vc[r] & 0x7FFFFFFFu) : make_uint2(0u, 0xFFFFFFFFu);
+        }
+    }
+    if (i0 >= n || ovf) return;  // (block-uniform)
     __syncthreads();
     const uint32_t i = i0 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -662,8 +705,8 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
     // one-neighbour-per-iteration divergent loop (exec-mask bookkeeping, ~535 SALU per wave) dominated this kernel.
     // ---- left: nearest strictly smaller (ties: rightmost wins) ----
     uint32_t L = min(kx, wm1);
-    bool ldone = !live;
-    if (live) {
+    bool ldone = !live || ABL == 1;
+    if (live && ABL != 1) {
         for (uint32_t t = 1; t <= (uint32_t)RH; t += 4) {
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
@@ -692,7 +735,7 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
     const uint32_t R = min(nk - 1 - kx, wm1);
     bool s = live && (L + R + 1 >= w);  // enough room if nothing blocks on the right
     const uint32_t need = wm1 - min(L, wm1);  // need R >= need
-    bool rdone = !(s && need > 0);
+    bool rdone = !(s && need > 0) || ABL == 1 || ABL == 2;
     if (!rdone) {
         for (uint32_t t = 1; t <= (uint32_t)RH; t += 4) {
 #pragma unroll
@@ -726,32 +769,37 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
     const bool chosen = live && s && !absent && h != 0xFFFFFFFFFFFFFFFFull;
     if (live) p.sel[i] = chosen ? 1 : 0;
 
-    if (GAPS && live) {
+    if (GAPS && live && ABL == 0) {
         // candidate-free stretches of >= w k-mers hold windows whose minimum is not a candidate.  Every real candidate
         // reports the stretch up to the next real one (and the first reports what precedes it); absent entries
         // (about one in 10^9) are stepped over.  lh[] outside the candidate array is 0, i.e. "not absent".
         if (!absent) {
-            int64_t jp = (int64_t)i - 1;
+            // the neighbours come from the staged copy (contig ~0: outside the array) unless absent entries intervene
+            uint32_t pcg = lkc[li - 1].y;
             if (lh[li - 1] >= tau) {
+                int64_t jp = (int64_t)i - 1;
                 do --jp; while (jp >= 0 && p.ch[jp] >= tau);
+                pcg = jp < 0 ? 0xFFFFFFFFu : (p.cc[jp] & 0x7FFFFFFFu);
             }
-            const bool first = (jp < 0) || ((p.cc[jp] & 0x7FFFFFFFu) != c);
+            const bool first = pcg != c;
             if (first) {
-                uint32_t pc = (jp < 0) ? p.ctg_lo : (p.cc[jp] & 0x7FFFFFFFu) + 1;
+                uint32_t pc = pcg == 0xFFFFFFFFu ? p.ctg_lo : pcg + 1;
                 for (; pc < c; ++pc) push_gap(p, pc, 0, p.ctg_nk[pc] - 1);  // contigs without any candidate
                 if (kx >= w) push_gap(p, c, 0, kx - 1);
             }
-            uint32_t jn = i + 1;
+            uint32_t ncg = lkc[li + 1].y, nx = lkc[li + 1].x;
             if (lh[li + 1] >= tau) {
+                uint32_t jn = i + 1;
                 do ++jn; while (jn < n && p.ch[jn] >= tau);
+                ncg = jn < n ? (p.cc[jn] & 0x7FFFFFFFu) : 0xFFFFFFFFu;
+                nx = jn < n ? p.ck[jn] : 0u;
             }
-            const bool last = (jn >= n) || ((p.cc[jn] & 0x7FFFFFFFu) != c);
+            const bool last = ncg != c;
             if (!last) {
-                uint32_t nx = p.ck[jn];
                 if (nx - kx - 1 >= w) push_gap(p, c, kx + 1, nx - 1);
             } else {
                 if (nk - 1 - kx >= w) push_gap(p, c, kx + 1, nk - 1);
-                if (jn >= n)
+                if (ncg == 0xFFFFFFFFu)
                     for (uint32_t nc = c + 1; nc < p.ctg_hi; ++nc) push_gap(p, nc, 0, p.ctg_nk[nc] - 1);
             }
         } else if (i == 0) {  // nobody else speaks for a batch whose every entry is absent
@@ -1077,7 +1125,7 @@ struct Driver {
 
     // sparse path: resolve + gap detection + per-256 counts (SC_CNT256 + super-counts behind the control block) in ONE
     // launch; emit(..., true) turns them into offsets, places the minimizers and writes the total to ctrl[2..3]
-    int resolve_count(const Tables &T, uint32_t n_cap, uint32_t ctg_lo, uint32_t ctg_hi, uint64_t tau)
+    int resolve_count(const Tables &T, uint32_t n_cap, uint32_t ctg_lo, uint32_t ctg_hi, uint64_t tau, uint32_t n_likely)
     {
         if (!n_cap) return MXG_OK;
         MXG_HIP(h, sc(SC_SEL).ensure(std::max<uint32_t>(n_cap, 16)));
@@ -1090,6 +1138,7 @@ struct Driver {
         rp.cc = sc(SC_CAND_C).as<uint32_t>();
         rp.n_ptr = ctrl + 4;
         rp.n_cap = n_cap;
+        rp.n_likely = 0;
         rp.ovf = ctrl;
         rp.tau = tau;
         rp.ctg_nk = T.d_ctg_nk;
@@ -1102,7 +1151,16 @@ struct Driver {
         rp.gap_count = ctrl + 1;
         rp.cnt256 = sc(SC_CNT256).as<uint32_t>();
         rp.sel_sup = sel_sup(n_cap);
-        hipLaunchKernelGGL((k_resolve<true, true>), dim3(blocks), dim3(256), 0, st, rp);
+        rp.n_likely = std::min(n_likely, n_cap);
+        static const int abl = getenv("MXG_ABLATE_RESOLVE") ? atoi(getenv("MXG_ABLATE_RESOLVE")) : 0;  // profiling only
+        if (abl == 1)
+            hipLaunchKernelGGL((k_resolve<true, true, 1>), dim3(blocks), dim3(256), 0, st, rp);
+        else if (abl == 2)
+            hipLaunchKernelGGL((k_resolve<true, true, 2>), dim3(blocks), dim3(256), 0, st, rp);
+        else if (abl == 3)
+            hipLaunchKernelGGL((k_resolve<true, true, 3>), dim3(blocks), dim3(256), 0, st, rp);
+        else
+            hipLaunchKernelGGL((k_resolve<true, true>), dim3(blocks), dim3(256), 0, st, rp);
         MXG_HIP(h, hipGetLastError());
         return MXG_OK;
     }
@@ -1121,6 +1179,7 @@ struct Driver {
         rp.cc = sc(SC_CAND_C).as<uint32_t>();
         rp.n_ptr = ctrl + 4;
         rp.n_cap = n_cap;
+        rp.n_likely = 0;
         rp.ovf = ctrl;
         rp.tau = tau;
         rp.ctg_nk = T.d_ctg_nk;
@@ -1434,13 +1493,19 @@ struct Driver {
         op.queue_cap = sp.wave_cap <= 8192 ? sp.wave_cap : 0;
         const size_t q_lds = (size_t)op.queue_cap * 4;
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-            hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V1_MIN>, dim3(g.n_waves), dim3(256), q_lds, st, op);
+            hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V1_MIN>, dim3(g.n_waves), dim3(RB), q_lds, st, op);
         else
-            hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V2_SUM>, dim3(g.n_waves), dim3(256), q_lds, st, op);
+        {
+            static const int rabl = getenv("MXG_ABLATE_REORDER") ? atoi(getenv("MXG_ABLATE_REORDER")) : 0;  // profiling only
+            if (rabl == 1)
+                hipLaunchKernelGGL((k_reorder<MXG_VARIANT_V2_SUM, 1>), dim3(g.n_waves), dim3(RB), q_lds, st, op);
+            else
+                hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V2_SUM>, dim3(g.n_waves), dim3(RB), q_lds, st, op);
+        }
         MXG_HIP(h, hipGetLastError());
         // resolve + speculative emit straight into the output arrays (guarded by their capacity): on the common path
         // (no gap, no overflow) the batch then needs a single host sync
-        if ((rc = resolve_count(T, n_cap, (uint32_t)g.c0, (uint32_t)g.c1, (uint64_t)tau_hi << 32)) != MXG_OK) return rc;
+        if ((rc = resolve_count(T, n_cap, (uint32_t)g.c0, (uint32_t)g.c1, (uint64_t)tau_hi << 32, a->cand_hint)) != MXG_OK) return rc;
         if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host)) != MXG_OK) return rc;
         return ev_end();
     }
@@ -1455,6 +1520,7 @@ struct Driver {
         uint32_t n_gaps = ctrl[1];
         const uint64_t total = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
         h->stat_candidates += n_cand;
+        a->cand_hint = (uint32_t)std::min<uint64_t>(n_cand, 0xFFFFFFFFull);
         int rc;
         std::vector<uint4> gaps;
         if (n_cand == 0) {  // no candidate at all: every contig of the batch is one stretch
@@ -1748,6 +1814,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             a->n_mx = total;
             a->has_sketch = true;
             h->stat_candidates += n_cand;
+            a->cand_hint = (uint32_t)std::min<uint64_t>(n_cand, 0xFFFFFFFFull);
             state[i] = 2;
             if (fused && total > gb.n_bound[i]) fused = false;  // a sketch outgrew the bound the graph stage was sized for
             ++n_fast;
