@@ -13,6 +13,7 @@
 // refs in CLI order, then target) that contains it, in that assembly's first-seen orientation --
 // the same (s,t) the reference's `edges[s][t]` dictionary keeps (bin/ntjoin_utils.py:101-108).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "mxg_internal.h"
@@ -103,6 +104,229 @@ __global__ __launch_bounds__(256) void k_flags(const AsmSet p, const Slot *__res
         sh = inall && d == 0;
         p.flags[a][i] = (uint8_t)((uniq ? MXG_MX_UNIQUE : 0) | (sh ? MXG_MX_SHARED : 0) | (inall ? MXG_MX_INALL : 0));
         p.shared[a][i] = sh ? 1 : 0;
+    }
+    const uint32_t c = (uint32_t)__syncthreads_count(sh ? 1 : 0);
+    if (threadIdx.x == 0) count_publish(cnt + p.bstart[a], sup + sup_start(p, a), blockIdx.x - p.bstart[a], c);
+}
+
+// ---- the same join without far atomics: partition by hash, one LDS table per partition ---------------------------------
+// k_insert spends its time in ~2 dependent device-scope atomics per minimizer on a table far larger than L2 (43 us for
+// 4 x 10^5 keys).  Here every block of k_pj_bucket takes 4096 minimizers (of all assemblies, in the order of the
+// concatenated 256-blocks), sorts them by a hash of their key into P partitions INSIDE ITS OWN 4096-record region
+// (LDS histogram, LDS prefix, LDS cursors: no global atomics at all) and writes its row of partition offsets to M.
+// One block of k_pj_join per partition then collects the partition's short segments from every region (column of M),
+// builds the partition's table in LDS and leaves {seen mask, dup mask, slot} in each record, which k_flags_pj picks up
+// through the record position k_pj_bucket stored in slot[a][i].  Slot numbers are partition * (PJ_T + 1) + local slot.
+// A partition with more distinct keys than its table holds reports failure through pinned host memory and build_graph
+// redoes the stage with the global table.
+constexpr uint32_t PJ_IPB = 4096;  // items per bucketing block = 16 blocks of 256
+constexpr uint32_t PJ_T = 2048;    // slots of a partition's table (+1: the slot of the key that equals the empty mark)
+constexpr uint32_t PJ_MAX_P = 4096;
+
+__device__ __forceinline__ uint32_t pj_part(uint64_t key, uint32_t pmask)
+{
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 44) & pmask;  // (the slot inside the table uses bits 32..42)
+}
+
+constexpr uint32_t PJ_BT = 1024;   // threads of a bucketing block (4 items each): 16 waves hide the latency of its passes
+__global__ __launch_bounds__(PJ_BT) void k_pj_bucket(const AsmSet p, uint32_t nb, uint32_t pmask, uint32_t *M, uint4 *recs,
+                                                   uint32_t *sup, uint32_t n_sup)
+{
+    extern __shared__ uint32_t pj_lds[];
+    uint32_t *hist = pj_lds, *start = pj_lds + pmask + 1;
+    __shared__ uint32_t sh[256];
+    if (blockIdx.x == 0)  // super-counts of the two counting kernels that follow (scan_kernels.h)
+        for (uint32_t i = threadIdx.x; i < n_sup; i += PJ_BT) sup[i] = 0;
+    constexpr uint32_t U = PJ_IPB / PJ_BT;  // items per thread: item u of thread t = 256-block u * BPU + t / 256, element t % 256
+    constexpr uint32_t BPU = PJ_BT / 256;
+    const uint32_t j = blockIdx.x, sub = threadIdx.x >> 8, t256 = threadIdx.x & 255u;
+    // Almost every block lies inside one assembly: its table entries (scalar loads from the argument block, dependent
+    // on one another) are then fetched once, not once per item.
+    const uint32_t blk0 = j * (PJ_IPB / 256), a0 = asm_of_block(p, blk0), a1 = asm_of_block(p, min(blk0 + PJ_IPB / 256, nb) - 1u);
+    const bool one = a0 == a1;
+    const uint64_t *hp0 = p.hash[a0];
+    uint32_t *sp0 = p.slot[a0];
+    const uint32_t n0 = asm_n(p, a0), ib0 = (blk0 - p.bstart[a0]) * 256u;
+    uint64_t key[U];
+    uint32_t live = 0;  // bit u: item u of this thread exists
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+        const uint32_t blk = blk0 + u * BPU + sub;
+        key[u] = 0;
+        if (blk >= nb) continue;
+        if (one) {
+            const uint32_t i = ib0 + (u * BPU + sub) * 256u + t256;
+            if (i < n0) {
+                key[u] = hp0[i];
+                live |= 1u << u;
+            }
+        } else {
+            const uint32_t a = asm_of_block(p, blk);
+            const uint32_t i = (blk - p.bstart[a]) * 256u + t256;
+            if (i < asm_n(p, a)) {
+                key[u] = p.hash[a][i];
+                live |= 1u << u;
+            }
+        }
+    }
+    for (uint32_t b = threadIdx.x; b <= pmask; b += PJ_BT) hist[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u)
+        if ((live >> u) & 1u) atomicAdd(&hist[pj_part(key[u], pmask)], 1u);
+    __syncthreads();
+    // exclusive prefix of the block's histogram: thread t owns `per` consecutive partitions (none beyond P)
+    const uint32_t P = pmask + 1, per = P >= PJ_BT ? P / PJ_BT : 1u, b0 = threadIdx.x * per;
+    uint32_t c = 0;
+    if (b0 < P)
+        for (uint32_t u = 0; u < per; ++u) c += hist[b0 + u];
+    uint32_t run = block_exclusive<PJ_BT / 64>(c, sh);
+    uint32_t *row = M + (size_t)j * (P + 1);
+    if (b0 < P)
+        for (uint32_t u = 0; u < per; ++u) {
+            const uint32_t cb = hist[b0 + u];
+            start[b0 + u] = run;
+            row[b0 + u] = run;
+            hist[b0 + u] = 0;  // from here on: items already placed in that partition
+            run += cb;
+        }
+    if (threadIdx.x == 0) row[P] = sh[255];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+        if (!((live >> u) & 1u)) continue;
+        const uint32_t blk = blk0 + u * BPU + sub;
+        uint32_t a = a0, i = ib0 + (u * BPU + sub) * 256u + t256;
+        uint32_t *sp = sp0;
+        if (!one) {
+            a = asm_of_block(p, blk);
+            i = (blk - p.bstart[a]) * 256u + t256;
+            sp = p.slot[a];
+        }
+        const uint32_t b = pj_part(key[u], pmask);
+        const uint32_t pos = j * PJ_IPB + start[b] + atomicAdd(&hist[b], 1u);
+        recs[pos] = make_uint4((uint32_t)key[u], (uint32_t)(key[u] >> 32), i, a);
+        sp[i] = pos;  // k_flags_pj replaces it by the slot
+    }
+}
+
+// slot of `key` in the partition's LDS table, inserting it if absent; PJ_T + 1: table full
+__device__ __forceinline__ uint32_t pj_slot(unsigned long long *keys, uint64_t key)
+{
+    if (key == HT_EMPTY) return PJ_T;
+    uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & (PJ_T - 1u);
+    for (uint32_t step = 0; step < PJ_T; ++step) {
+        const unsigned long long cur = keys[s];
+        if (cur == key) return s;
+        if (cur == HT_EMPTY) {
+            const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)HT_EMPTY, (unsigned long long)key);
+            if (old == HT_EMPTY || old == key) return s;
+        }
+        s = (s + 1u) & (PJ_T - 1u);
+    }
+    return PJ_T + 1u;
+}
+
+__global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__restrict__ M, uint32_t P, uint32_t n_rows,
+                                                 uint64_t *host_fail, uint32_t force_fail)
+{
+    __shared__ unsigned long long keys[PJ_T + 1];
+    __shared__ uint32_t seen[PJ_T + 1], dup[PJ_T + 1];
+    __shared__ uint32_t seg_off[257], seg_rec[256], sh[256];
+    __shared__ uint32_t failed;
+    const uint32_t b = blockIdx.x;
+    for (uint32_t s = threadIdx.x; s <= PJ_T; s += 256) {
+        keys[s] = HT_EMPTY;
+        seen[s] = 0;
+        dup[s] = 0;
+    }
+    if (threadIdx.x == 0) failed = force_fail;
+    // The partition's records are short segments, one per region.  Per 256 regions: every thread fetches one segment's
+    // bounds, a block scan lays the segments end to end, and the records are dealt out to the threads one by one (binary
+    // search in the scan): all loads of a pass are independent.  Pass 0 inserts, pass 1 writes the table state back; with
+    // at most 256 regions (10^6 minimizers) pass 1 reuses the layout and the slots of the first QC records per thread.
+    constexpr uint32_t QC = 4;
+    uint32_t rc[QC], sc[QC];
+    const bool single = n_rows <= 256;
+    for (uint32_t pass = 0; pass < 2; ++pass) {
+        const bool bad = pass == 1 && failed != 0;  // report, and make every key of this partition "seen nowhere"
+        if (bad && threadIdx.x == 0) *host_fail = 1;
+        for (uint32_t j0 = 0; j0 < n_rows; j0 += 256) {
+            if (pass == 0 || !single) {
+                const uint32_t j = j0 + threadIdx.x;
+                uint32_t lo = 0, len = 0;
+                if (j < n_rows) {
+                    const uint32_t *row = M + (size_t)j * (P + 1);
+                    lo = row[b];
+                    len = row[b + 1] - lo;
+                }
+                const uint32_t off = block_exclusive_256(len, sh);
+                seg_off[threadIdx.x] = off;
+                seg_rec[threadIdx.x] = j * PJ_IPB + lo;
+                __syncthreads();
+            }
+            const uint32_t total = sh[255];
+            auto locate = [&](uint32_t q) {  // record number q of the laid-out segments
+                uint32_t l = 0, h = 256;     // last segment with seg_off <= q (empty segments share offsets: take the last)
+                while (h - l > 1) {
+                    const uint32_t m = (l + h) >> 1;
+                    if (seg_off[m] <= q) l = m; else h = m;
+                }
+                return seg_rec[l] + (q - seg_off[l]);
+            };
+            auto insert = [&](uint32_t r) {  // pass 0; also the lookup of pass 1
+                const uint4 rec = recs[r];
+                const uint32_t s = pj_slot(keys, ((uint64_t)rec.y << 32) | rec.x);
+                if (pass == 0) {
+                    const uint32_t bit = 1u << rec.w;
+                    if (s > PJ_T) failed = 1;
+                    else if (atomicOr(&seen[s], bit) & bit) atomicOr(&dup[s], bit);  // second occurrence in this assembly
+                }
+                return s;
+            };
+            auto finish = [&](uint32_t r, uint32_t s) {
+                recs[r] = bad ? make_uint4(0u, 0u, b * (PJ_T + 1u), 0u) : make_uint4(seen[s], dup[s], b * (PJ_T + 1u) + s, 0u);
+            };
+#pragma unroll
+            for (uint32_t it = 0; it < QC; ++it) {
+                const uint32_t q = threadIdx.x + it * 256u;
+                if (q >= total) break;
+                if (pass == 0) {
+                    rc[it] = locate(q);
+                    sc[it] = insert(rc[it]);
+                } else if (single) {
+                    finish(rc[it], sc[it]);
+                } else {
+                    const uint32_t r = locate(q);
+                    finish(r, bad ? 0u : insert(r));
+                }
+            }
+            for (uint32_t q = threadIdx.x + QC * 256u; q < total; q += 256) {
+                const uint32_t r = locate(q);
+                if (pass == 0) insert(r);
+                else finish(r, bad ? 0u : insert(r));
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// k_flags for the partitioned join: the table state of minimizer i sits in recs[slot[a][i]]
+__global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, const uint4 *__restrict__ recs, uint32_t *cnt, uint32_t *sup)
+{
+    const uint32_t a = asm_of_block(p, blockIdx.x);
+    const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
+    bool sh = false;
+    if (i < asm_n(p, a)) {
+        const uint32_t bit = 1u << a, full = p.full;
+        const uint4 r = recs[p.slot[a][i]];
+        const uint32_t seen = r.x & full, d = r.y & full;
+        const bool uniq = !(d & bit);
+        const bool inall = seen == full;
+        sh = inall && d == 0;
+        p.flags[a][i] = (uint8_t)((uniq ? MXG_MX_UNIQUE : 0) | (sh ? MXG_MX_SHARED : 0) | (inall ? MXG_MX_INALL : 0));
+        p.shared[a][i] = sh ? 1 : 0;
+        p.slot[a][i] = r.z;
     }
     const uint32_t c = (uint32_t)__syncthreads_count(sh ? 1 : 0);
     if (threadIdx.x == 0) count_publish(cnt + p.bstart[a], sup + sup_start(p, a), blockIdx.x - p.bstart[a], c);
@@ -317,7 +541,19 @@ __global__ __launch_bounds__(256) void k_count_unique(const uint8_t *__restrict_
 // adjacency taken from messages instead of from the handle's own record order.
 // gb (fused sketch+graph call, GRAPH_FULL only): the sketches are still being computed on the stream; sizes are the
 // bounds gb->n_bound[a], the kernels read the counts from gb->n_ptr[a] on the device.
+static constexpr int CTL_PJ_FAIL = 34;  // pinned control block: a partition's table overflowed (k_pj_join)
+static constexpr int RC_RETRY_GLOBAL = 1;
+
+static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, const GraphBounds *gb, bool global_table);
+
 int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, const GraphBounds *gb)
+{
+    int rc = build_graph_impl(h, mode, d_msgs, n_msgs, gb, false);
+    if (rc == RC_RETRY_GLOBAL) rc = build_graph_impl(h, mode, d_msgs, n_msgs, gb, true);
+    return rc;
+}
+
+static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, const GraphBounds *gb, bool global_table)
 {
     MXG_HIP(h, hipSetDevice(h->device));
     const uint32_t A = (uint32_t)h->asms.size();
@@ -345,12 +581,22 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, co
     while (cap < 2 * N) cap <<= 1;
     const uint32_t mask = cap - 1;
     const uint32_t full = (A == 32) ? 0xFFFFFFFFu : ((1u << A) - 1u);
+    // the join: LDS tables per hash partition (the whole-stage call, up to PJ_MAX_P partitions of <= 1280 records), else
+    // the global table.  MXG_GRAPH_JOIN=global|lds and MXG_PJ_FORCE_FAIL=1 are test knobs (read per call).
+    uint32_t P = 256;
+    while ((uint64_t)P * 1280 < N) P <<= 1;
+    const char *join_env = getenv("MXG_GRAPH_JOIN");
+    const bool pj = mode == GRAPH_FULL && !global_table && P <= PJ_MAX_P && !(join_env && !strcmp(join_env, "global"));
+    const uint32_t pj_force_fail = getenv("MXG_PJ_FORCE_FAIL") && atoi(getenv("MXG_PJ_FORCE_FAIL")) ? 1u : 0u;
 
-    MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * sizeof(Slot)));
-    MXG_HIP(h, h->g_vid.ensure(((size_t)cap + 1) * 4));
+    MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * sizeof(Slot)));  // (the partitioned join keeps its N records here)
+    MXG_HIP(h, h->g_vid.ensure(std::max<size_t>((size_t)cap + 1, pj ? (size_t)P * (PJ_T + 1) : 0) * 4));
     MXG_HIP(h, h->g_ctl.ensure(CTL_WORDS * 8));
-    if (!resume)
+    if (pj) {
+        // (nothing to clear: every word of M and of the record regions that is read is written by this call)
+    } else if (!resume) {
         MXG_HIP(h, hipMemsetAsync(h->g_keys.p, 0xFF, ((size_t)cap + 1) * sizeof(Slot), h->stream));  // one fill: see Slot
+    }
     uint64_t *ctl = h->g_ctl.as<uint64_t>();  // every word the host reads below is written by a kernel of this call
 
     AsmSet as_all;
@@ -396,7 +642,17 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, co
     const uint32_t n_fsup = ((nb >> SUP_SHIFT) + A + 1) * SUP_STRIDE, n_esup = sup_words(e_blocks);
     MXG_HIP(h, h->g_cnt.ensure(((size_t)n_fsup + n_esup + nb) * 4 + 64));
     uint32_t *fsup = h->g_cnt.as<uint32_t>(), *esup = fsup + n_fsup, *cnt = esup + n_esup;
-    if (nb && !resume) {
+    if (nb && !resume && pj) {
+        const uint32_t n_rows = (nb + PJ_IPB / 256 - 1) / (PJ_IPB / 256);  // bucketing blocks = record regions = rows of M
+        MXG_HIP(h, h->g_part.ensure((size_t)n_rows * (P + 1) * 4));
+        MXG_HIP(h, h->g_keys.ensure((size_t)n_rows * PJ_IPB * sizeof(uint4)));
+        uint32_t *M = h->g_part.as<uint32_t>();
+        uint4 *recs = h->g_keys.as<uint4>();
+        hipLaunchKernelGGL(k_pj_bucket, dim3(n_rows), dim3(PJ_BT), (size_t)P * 8, h->stream, as_all, nb, P - 1, M, recs, fsup,
+                           n_fsup + n_esup);
+        hipLaunchKernelGGL(k_pj_join, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, hctl + CTL_PJ_FAIL, pj_force_fail);
+        hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, recs, cnt, fsup);
+    } else if (nb && !resume) {
         hipLaunchKernelGGL(k_insert, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), mask, cap, fsup,
                            n_fsup + n_esup);
         // flags + shared minimizers per 256 of every assembly (their totals, equal by construction, land in ctl[a])
@@ -494,6 +750,7 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, co
     }
     if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
     MXG_HIP(h, stream_wait(h->stream));  // the stage's only sync; results stay in HBM
+    if (pj && hctl[CTL_PJ_FAIL]) return RC_RETRY_GLOBAL;  // a partition outgrew its LDS table: redo with the global table
     const uint64_t nv = hctl[0];
     for (uint32_t a = 1; a < A; ++a)
         if (hctl[a] != nv)

@@ -181,6 +181,7 @@ struct mxg_handle {
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
     // scratch reused across calls
     mxg::DevBuf scratch[2][40];  // two sets, indexed by mxg::Scratch (sketch.hip): one per in-flight sketch driver
+    mxg::DevBuf g_part;     // partitioned join (graph.hip): partition offsets of every bucketing block
     mxg::DevBuf g_keys, g_cnt, g_vid, g_ctl, g_vhash, g_vpos, g_vrec, g_fv, g_frec, g_nxt, g_prv, g_eflag,
         g_ebs, g_eu, g_ev, g_esup, g_ew;  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
     uint64_t arena_cap_hint = 0;

@@ -1,0 +1,111 @@
+"""GPU test of the two joins behind mxg_build_graph: per-partition LDS tables (default for the whole-stage call) and the
+global table (MXG_GRAPH_JOIN=global; also the fallback when a partition's table overflows, forced here with
+MXG_PJ_FORCE_FAIL=1).  Flags and graph must be identical; the golden parity tests pin the default against the reference."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN, golden_cases, load_case
+
+pytestmark = pytest.mark.gpu
+FASTA = os.path.join(GOLDEN, "fasta")
+CASES = [m["name"] for m in golden_cases()]
+
+
+def _graph_state(eng, n_asm):
+    out = {f"flags{a}": eng.get_mx_flags(a).copy() for a in range(n_asm)}
+    for key, val in eng.get_graph().items():
+        out[key] = np.asarray(val).copy()
+    return out
+
+
+def _three_ways(monkeypatch, build):
+    res = []
+    for env in ({}, {"MXG_GRAPH_JOIN": "global"}, {"MXG_PJ_FORCE_FAIL": "1"}):
+        for key in ("MXG_GRAPH_JOIN", "MXG_PJ_FORCE_FAIL"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        res.append(build())
+    for other in res[1:]:
+        assert other.keys() == res[0].keys()
+        for key in res[0]:
+            assert np.array_equal(res[0][key], other[key]), key
+    return res[0]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_joins_agree_on_goldens(name, monkeypatch):
+    from ntjoin_amd.engine import MxEngine
+    meta = load_case(name)["meta"]
+    asms = meta["refs"] + [meta["target"]]
+
+    def build():
+        with MxEngine(k=meta["k"], w=meta["w"], variant=meta["variant"]) as eng:
+            for a in asms:
+                eng.add_fasta(a["tsv"], a["weight"], os.path.join(FASTA, a["fasta"]))
+            eng.sketch()
+            eng.build_graph()
+            eng.build_graph()  # twice on one handle: the partition counters must come back clean
+            return _graph_state(eng, len(asms))
+    _three_ways(monkeypatch, build)
+
+
+def test_joins_agree_on_repeats_and_three_assemblies(monkeypatch):
+    """minimizer lists with heavy duplication inside an assembly (one key 5000 times: a single partition takes them all),
+    keys missing from one assembly, the key 2^64-1, three assemblies"""
+    from ntjoin_amd.engine import MxEngine
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, 2**63, size=60000, dtype=np.int64).astype(np.uint64)
+    base[0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def mk(seed, drop, extra_dups):
+        r = np.random.default_rng(seed)
+        keep = r.random(base.size) >= drop
+        hs = base[keep].copy()
+        r.shuffle(hs)
+        hs = np.concatenate([hs, np.repeat(hs[:3], extra_dups), r.integers(0, 2**63, size=3000, dtype=np.int64).astype(np.uint64)])
+        n_rec = 40
+        rec = np.sort(r.integers(0, n_rec, size=hs.size)).astype(np.uint32)
+        pos = np.zeros(hs.size, np.uint32)
+        for c in range(n_rec):
+            m = rec == c
+            pos[m] = np.arange(int(m.sum()), dtype=np.uint32) * 37
+        return hs, pos, rec, [f"c{i}" for i in range(n_rec)]
+
+    sets = [mk(1, 0.02, 5000), mk(2, 0.05, 2), mk(3, 0.0, 700)]
+
+    def build():
+        with MxEngine(k=32, w=1000) as eng:
+            for i, (hs, pos, rec, ids) in enumerate(sets):
+                eng.add_minimizers(f"a{i}", float(i + 1), hs, pos, rec, ids)
+            eng.build_graph()
+            st = eng.stats()
+            assert st["vertices"] > 40000
+            return _graph_state(eng, len(sets))
+    _three_ways(monkeypatch, build)
+
+
+def test_joins_agree_on_synthetic_genome(monkeypatch):
+    import torch
+    from ntjoin_amd import synth
+    from ntjoin_amd.engine import MxEngine
+    ref, tgt = synth.config2(seed=5, n_bases=30_000_000)
+
+    def build():
+        with MxEngine(k=32, w=1000) as eng:
+            for name, wt, recs in (("ref", 2.0, ref), ("tgt", 1.0, tgt)):
+                words, starts, lens = synth.pack_records(recs)
+                d = torch.from_numpy(words.view(np.int32)).cuda()
+                eng.add_packed_device(name, wt, d.data_ptr(), starts, lens, keepalive=d)
+            eng.sketch_graph()     # device-side counts
+            st1 = _graph_state(eng, 2)
+            eng.sketch()
+            eng.build_graph()
+            st2 = _graph_state(eng, 2)
+            for key in st1:
+                assert np.array_equal(st1[key], st2[key]), key
+            return st2
+    g = _three_ways(monkeypatch, build)
+    assert len(g["flags0"]) > 50000
