@@ -141,6 +141,18 @@ int mxg_add_assembly_fasta(mxg_handle *h, const char *name, double weight, const
    sketches in rank order yields the globally (record,pos)-sorted sketch. */
 int mxg_add_assembly_fasta_shard(mxg_handle *h, const char *name, double weight, const char *fasta_path,
                                  uint32_t shard, uint32_t n_shards);
+/* Sub-record sharding (chunks with a halo): as ..._fasta_shard, but shard s owns the BASE range
+   [total*s/n, total*(s+1)/n) of the concatenated records, whatever the record boundaries: a record cut by the range is
+   sketched in pieces.  Every window belongs to the shard its last k-mer starts in; a piece that does not start its
+   record also loads the w valid k-mers before its first own one and withholds its first minimizer (the last minimizer
+   of the piece before it), so the rank-ordered concatenation of the shards' sketches is exactly the sketch of the
+   whole file: positions and record indices are those of the whole records.  mxg_assembly_shard gives the records the
+   handle holds pieces of; mxg_assembly_continues says whether the first of them began on the shard before (its TSV
+   line is then the continuation of that shard's last line).  Replaces a single `indexlr` process per assembly,
+   reference ntJoin:204-205, for inputs with few very long records. */
+int mxg_add_assembly_fasta_split(mxg_handle *h, const char *name, double weight, const char *fasta_path,
+                                 uint32_t shard, uint32_t n_shards);
+int mxg_assembly_continues(const mxg_handle *h, int assembly);  /* 1 / 0, negative: error */
 /* records [*lo,*hi) of shard `shard`: cut points at multiples of total/n_shards of the cumulative base count
    (a record belongs to the shard its midpoint falls in).  Host only; usable without a device. */
 int mxg_shard_range(const uint64_t *lengths, uint64_t n_records, uint32_t shard, uint32_t n_shards, uint64_t *lo,

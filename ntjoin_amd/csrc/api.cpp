@@ -151,6 +151,28 @@ int mxg_add_assembly_fasta_shard(mxg_handle *h, const char *name, double weight,
     return commit(h, a, rc);
 }
 
+int mxg_add_assembly_fasta_split(mxg_handle *h, const char *name, double weight, const char *fasta_path,
+                                 uint32_t shard, uint32_t n_shards)
+{
+    Assembly *a;
+    int rc = new_assembly(h, name, weight, &a);
+    if (rc != MXG_OK) return rc;
+    if (!fasta_path || n_shards == 0 || shard >= n_shards)
+        return commit(h, a, set_err(h, MXG_EINVAL, "need fasta_path and shard < n_shards"));
+    try {
+        rc = load_fasta(h, a, fasta_path, shard, n_shards, true);
+    } catch (const std::bad_alloc &) {
+        rc = set_err(h, MXG_ENOMEM, "out of host memory reading '%s'", fasta_path);
+    }
+    return commit(h, a, rc);
+}
+
+int mxg_assembly_continues(const mxg_handle *h, int assembly)
+{
+    if (!h || assembly < 0 || (size_t)assembly >= h->asms.size()) return MXG_EINVAL;
+    return h->asms[assembly]->split_first_cont ? 1 : 0;
+}
+
 int mxg_shard_range(const uint64_t *lengths, uint64_t n_records, uint32_t shard, uint32_t n_shards, uint64_t *lo,
                     uint64_t *hi)
 {

@@ -92,12 +92,25 @@ struct Ingest {
     uint64_t cur_base = 0;  // next free global base slot
     // current record
     uint64_t rec_start = 0, rec_pos = 0, run_len = 0;
+    uint64_t fpos = 0;        // position one past the last base fed to the packer / run tracker (== rec_pos unless a piece)
     std::vector<std::pair<uint32_t, uint32_t>> rec_runs;  // (pos0, n_kmers) of the open record
     uint32_t cur_word = 0;
     bool skip = false;        // current record is outside this handle's shard: only its length is recorded
     bool lengths_only = false;  // first pass of a sharded load: record nothing but lengths
     uint64_t keep_lo = 0, keep_hi = ~0ull;
     std::vector<uint64_t> lengths;
+    // split load (records may be cut between shards, see plan_pieces): pass 1 also keeps every record's valid runs,
+    // pass 2 feeds only the bases [p_lo, p_hi) of a record
+    struct Piece {
+        uint64_t lo = 0, hi = 0;
+        bool keep = false, drop = false;
+        bool cont = false;  // the record began on an earlier shard (which printed its TSV line so far)
+    };
+    bool collect_runs = false, split = false;
+    std::vector<std::vector<std::pair<uint64_t, uint64_t>>> all_runs;  // per record: (pos0, n_kmers)
+    std::vector<Piece> pieces;
+    uint64_t p_lo = 0, p_hi = ~0ull;
+    bool p_drop = false;
 
     Ingest(mxg_handle *h_, Assembly *a_) : h(h_), a(a_), k(h_->cfg.k), w(h_->cfg.w) {}
 
@@ -105,47 +118,81 @@ struct Ingest {
     {
         if (lengths_only) {
             lengths.push_back(0);
+            if (collect_runs) all_runs.emplace_back();
             rec_pos = 0;
+            run_len = 0;
             skip = true;
             return;
         }
         const uint64_t ridx = a->recs.size();
         skip = ridx < keep_lo || ridx >= keep_hi;
+        p_lo = 0;
+        p_hi = ~0ull;
+        p_drop = false;
+        if (split) {
+            const Piece &pc = pieces[ridx];
+            skip = !pc.keep;
+            p_lo = pc.lo;
+            p_hi = pc.hi;
+            p_drop = pc.drop;
+        }
         cur_base = (cur_base + 15) & ~uint64_t(15);
         Record r;
         r.id = id;
-        r.base_off = cur_base;
-        r.text_off = a->text.size();
+        // a piece packs the bases [p_lo, p_hi) only; the offsets stay "of base 0" (they wrap; every use adds a position)
+        r.base_off = cur_base - (p_lo & ~uint64_t(15));
+        r.text_off = (uint64_t)a->text.size() - p_lo;
         a->recs.push_back(r);
         rec_start = cur_base;
         rec_pos = 0;
+        fpos = p_lo;
         run_len = 0;
         rec_runs.clear();
         cur_word = 0;
     }
     inline void close_run()
     {
-        if (run_len >= k) rec_runs.emplace_back((uint32_t)(rec_pos - run_len), (uint32_t)(run_len - k + 1));
+        if (run_len >= k) rec_runs.emplace_back((uint32_t)(fpos - run_len), (uint32_t)(run_len - k + 1));
         run_len = 0;
     }
     void add_bases(const uint8_t *s, size_t n, bool keep_text)
     {
+        if (lengths_only && collect_runs) {  // pass 1 of a split load: valid runs of every record
+            const uint8_t *lut = code_lut();
+            for (size_t i = 0; i < n; ++i) {
+                if (lut[s[i]] < 4) {
+                    ++run_len;
+                } else {
+                    if (run_len >= k) all_runs.back().emplace_back(rec_pos + i - run_len, run_len - k + 1);
+                    run_len = 0;
+                }
+            }
+            rec_pos += n;
+            return;
+        }
         if (skip) {
             rec_pos += n;
             return;
         }
+        // the part of [rec_pos, rec_pos + n) inside the piece (everything, for a whole record)
+        const uint64_t s0 = rec_pos, s1 = rec_pos + n;
+        rec_pos = s1;
+        const uint64_t c0 = std::max(s0, p_lo), c1 = std::min(s1, p_hi);
+        if (c0 >= c1) return;
+        s += c0 - s0;
+        n = (size_t)(c1 - c0);
         const uint8_t *lut = code_lut();
         if (keep_text) a->text.append(reinterpret_cast<const char *>(s), n);
         for (size_t i = 0; i < n; ++i) {
             uint8_t c = lut[s[i]];
-            unsigned slot = (unsigned)(rec_pos & 15);
+            unsigned slot = (unsigned)(fpos & 15);
             if (c < 4) {
                 cur_word |= (uint32_t)c << (2 * slot);
                 ++run_len;
             } else {
-                close_run();  // rec_pos = position of the invalid base = one past the run's last base
+                close_run();  // fpos = position of the invalid base = one past the run's last base
             }
-            ++rec_pos;
+            ++fpos;
             if (slot == 15) {
                 a->h_packed.push_back(cur_word);
                 cur_word = 0;
@@ -156,6 +203,7 @@ struct Ingest {
     {
         if (lengths_only) {
             lengths.back() = rec_pos;
+            if (collect_runs && run_len >= k) all_runs.back().emplace_back(rec_pos - run_len, run_len - k + 1);
             return MXG_OK;
         }
         if (skip) {  // registered (global record index, id, length) but neither packed nor sketched here
@@ -168,15 +216,15 @@ struct Ingest {
             return MXG_OK;
         }
         close_run();
-        if (rec_pos & 15) a->h_packed.push_back(cur_word);
+        if (fpos & 15) a->h_packed.push_back(cur_word);
         cur_word = 0;
         Record &r = a->recs.back();
         r.len = rec_pos;
         if (r.len >= (uint64_t(1) << 32))
             return set_err(h, MXG_ELIMIT, "record '%s' has %llu bases; the engine indexes positions with 32 bits",
                            r.id.c_str(), (unsigned long long)r.len);
-        cur_base = rec_start + ((rec_pos + 15) & ~uint64_t(15));
-        a->total_bases += r.len;
+        cur_base = rec_start + ((fpos - (p_lo & ~uint64_t(15)) + 15) & ~uint64_t(15));
+        a->total_bases += fpos - p_lo;
         uint64_t nk = 0;
         for (auto &rr : rec_runs) nk += rr.second;
         if (nk >= w && nk > 0) {
@@ -184,6 +232,10 @@ struct Ingest {
             a->ctg_rec.push_back((uint32_t)(a->recs.size() - 1));
             a->ctg_nk.push_back((uint32_t)nk);
             a->ctg_run0.push_back((uint32_t)a->runs.size());
+            if (split) {
+                a->ctg_drop.push_back(p_drop ? 1 : 0);
+                a->any_drop = a->any_drop || p_drop;
+            }
             uint32_t kidx = 0;
             for (auto &rr : rec_runs) {
                 Run run;
@@ -293,14 +345,78 @@ static int parse_fasta_stream(mxg_handle *h, FILE *f, const char *path, Ingest &
     return rc;
 }
 
-int load_fasta(mxg_handle *h, Assembly *a, const char *path, uint32_t shard, uint32_t n_shards)
+// Split load: shard s of n owns the base range [total*s/n, total*(s+1)/n) of the concatenated records, and with it every
+// window whose LAST k-mer starts inside that range.  For a record cut by the range's start it needs the w valid k-mers
+// before its first own k-mer: w-1 of them complete its first own window, one more makes its first window the LAST
+// window of the shard before it, whose minimizer that shard reports -- so this piece's first minimizer is always
+// dropped (k_resolve, ctg_drop) and nothing is reported twice or lost, whatever the hashes are (the
+// sketch is the sequence of distinct window arg-mins, non-decreasing in the window).  Pieces whose first own k-mer is
+// among the record's first w valid k-mers start at the record's beginning instead (the shards before them then hold
+// fewer than w k-mers of it and report nothing).
+static void plan_pieces(Ingest &in, uint32_t shard, uint32_t n_shards, uint32_t k, uint32_t w)
+{
+    const size_t n = in.lengths.size();
+    unsigned __int128 total = 0;
+    for (size_t r = 0; r < n; ++r) total += in.lengths[r];
+    const uint64_t cut_lo = (uint64_t)(total * shard / n_shards), cut_hi = (uint64_t)(total * (shard + 1) / n_shards);
+    in.pieces.assign(n, Ingest::Piece());
+    uint64_t cum = 0;
+    for (size_t r = 0; r < n; ++r) {
+        const uint64_t len = in.lengths[r], r0 = cum, r1 = cum + len;
+        cum = r1;
+        if (len == 0 || r1 <= cut_lo || r0 >= cut_hi) continue;
+        const uint64_t P_lo = std::max(cut_lo, r0) - r0, P_hi = std::min(cut_hi, r1) - r0;  // own k-mer starts: [P_lo, P_hi)
+        Ingest::Piece &pc = in.pieces[r];
+        pc.keep = true;
+        pc.hi = P_hi == len ? len : std::min<uint64_t>(len, P_hi + k - 1);
+        pc.lo = 0;
+        pc.cont = P_lo > 0;
+        if (P_lo > 0) {
+            uint64_t t_first = 0;  // valid k-mers that start before P_lo
+            for (auto &run : in.all_runs[r])
+                if (run.first < P_lo) t_first += std::min<uint64_t>(run.second, P_lo - run.first);
+            if (t_first >= w) {
+                uint64_t want = t_first - w, seen = 0;  // the piece starts at valid k-mer number t_first - w
+                for (auto &run : in.all_runs[r]) {
+                    if (want < seen + run.second) {
+                        pc.lo = run.first + (want - seen);
+                        break;
+                    }
+                    seen += run.second;
+                }
+                pc.drop = true;
+            }
+        }
+    }
+}
+
+int load_fasta(mxg_handle *h, Assembly *a, const char *path, uint32_t shard, uint32_t n_shards, bool split)
 {
     FILE *f = fopen(path, "rb");
     if (!f) return set_err(h, MXG_EIO, "cannot open FASTA '%s'", path);
     const bool keep = !(h->cfg.flags & MXG_FLAG_DROP_SEQ);
     Ingest in(h, a);
     int rc = MXG_OK;
-    if (n_shards > 1) {  // pass 1: record lengths -> this rank's contiguous record range (same on every rank)
+    if (n_shards > 1 && split) {  // pass 1: lengths and valid runs of every record -> this rank's pieces (same plan on every rank)
+        in.lengths_only = in.collect_runs = true;
+        rc = parse_fasta_stream(h, f, path, in, false);
+        if (rc == MXG_OK) {
+            plan_pieces(in, shard, n_shards, h->cfg.k, h->cfg.w);
+            uint64_t lo = in.pieces.size(), hi = 0;
+            for (size_t r = 0; r < in.pieces.size(); ++r)
+                if (in.pieces[r].keep) {
+                    lo = std::min<uint64_t>(lo, r);
+                    hi = r + 1;
+                }
+            a->shard_lo = std::min(lo, hi);
+            a->shard_hi = hi;
+            a->split_first_cont = hi > lo && in.pieces[lo].cont;
+            in.lengths_only = in.collect_runs = false;
+            in.split = true;
+            in.all_runs.clear();
+            rewind(f);
+        }
+    } else if (n_shards > 1) {  // pass 1: record lengths -> this rank's contiguous record range (same on every rank)
         in.lengths_only = true;
         rc = parse_fasta_stream(h, f, path, in, false);
         if (rc == MXG_OK) {
@@ -572,7 +688,7 @@ int write_tsv(mxg_handle *h, Assembly *a, const char *path, int with_pos, int wi
             if (with_seq) {
                 o.put(':');
                 if (a->has_text) {
-                    o.put(a->text.data() + rec.text_off + a->h_pos[i], k);
+                    o.put(a->text.data() + (size_t)(rec.text_off + a->h_pos[i]), k);
                 } else {
                     uint64_t b0 = rec.base_off + a->h_pos[i];
                     for (uint32_t j = 0; j < k; ++j) {

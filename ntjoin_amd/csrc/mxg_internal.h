@@ -89,6 +89,9 @@ struct Assembly {
     std::vector<uint32_t> ctg_rec;   // eligible contig -> record index
     std::vector<uint32_t> ctg_nk;    // eligible contig -> valid k-mer count
     std::vector<uint32_t> ctg_run0;  // eligible contig -> first run (size n+1)
+    std::vector<uint8_t> ctg_drop;   // split load only: the contig is a piece whose first minimizer belongs to the shard before
+    bool any_drop = false;
+    bool split_first_cont = false;   // split load: this handle's first record continues a record begun on the shard before
     uint64_t total_kmers = 0;        // over eligible contigs
     // device copies of the tables above + strip / k-mer prefix tables (built once, by the first sketch)
     bool tables_ready = false;
@@ -96,7 +99,7 @@ struct Assembly {
     uint32_t cand_hint = 0;   // candidates of the last sparse run (k_resolve: which blocks may load before the count arrives)
     std::vector<uint32_t> strip0_dense, strip0_sparse;  // [n_runs+1] exclusive prefix of strips per run
     std::vector<uint64_t> g0;                           // [n_runs+1] exclusive prefix of k-mers per run
-    DevBuf d_runs, d_strip0_dense, d_strip0_sparse, d_g0, d_ctg_nk, d_ctg_rec, d_ctg_run0;
+    DevBuf d_runs, d_strip0_dense, d_strip0_sparse, d_g0, d_ctg_nk, d_ctg_rec, d_ctg_run0, d_ctg_drop;
     // sketch (device, ordered by (record,pos)) + lazily filled host mirror
     bool has_sketch = false;
     uint64_t n_mx = 0;
@@ -216,7 +219,7 @@ inline hipError_t stream_wait(hipStream_t s)
     } while (0)
 
 // host_io.cpp
-int load_fasta(mxg_handle *h, Assembly *a, const char *path, uint32_t shard = 0, uint32_t n_shards = 1);
+int load_fasta(mxg_handle *h, Assembly *a, const char *path, uint32_t shard = 0, uint32_t n_shards = 1, bool split = false);
 void shard_range(const uint64_t *lengths, uint64_t n, uint32_t shard, uint32_t n_shards, uint64_t *lo, uint64_t *hi);
 int load_buffers(mxg_handle *h, Assembly *a, const uint8_t *ascii, const uint64_t *offsets,
                  const char *const *ids, uint64_t n_records);

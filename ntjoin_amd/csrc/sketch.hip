@@ -47,7 +47,7 @@ namespace mxg {
 enum Scratch {
     SC_CAND_H, SC_CAND_K, SC_CAND_C, SC_SEL, SC_BSUM, SC_CTRL, SC_ARENA, SC_STRIP_CNT, SC_STRIP_META,
     SC_GAPS, SC_WAVE_CNT, SC_ST_HASH, SC_ST_POS, SC_ST_REC, SC_ST_FWD, SC_G_HASH, SC_G_POS,
-    SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_CNT256, SC_WAVE_TOT, SC_COUNT
+    SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_V_DROP, SC_CNT256, SC_WAVE_TOT, SC_COUNT
 };
 static_assert(SC_COUNT <= 40, "scratch pool too small");
 
@@ -558,6 +558,7 @@ struct ResolveParams {
     const uint32_t *ovf;    // != 0: a wave overflowed its arena slice, candidate arrays are incomplete -> do nothing
     uint64_t tau;           // entries with hash >= tau are not candidates (ring-test false positives); dense: 2^64-1
     const uint32_t *ctg_nk;
+    const uint8_t *ctg_drop;  // split load (host_io.cpp plan_pieces): contigs whose first window's minimizer is not reported
     uint32_t w;
     uint8_t *sel;
     // gap detection (sparse mode)
@@ -762,6 +763,10 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
         const bool blocked = coop_right_blocked(q, lane, bi, bh, bkx, bc, RH + 1, bneed);
         if ((int)lane == src && blocked) s = false;
     }
+    // A piece of a record that starts with the halo of the shard before it: the arg-min of its FIRST window (nothing
+    // smaller on the left down to the contig's first k-mer, nothing smaller-or-equal up to k-mer w-1) is that shard's
+    // last minimizer, not this one's.
+    if (p.ctg_drop && s && kx <= wm1 && L == kx && p.ctg_drop[c]) s = false;
     // An entry >= tau is not a candidate at all (it never blocks anybody: every real candidate is < tau <= it).
     // btllib never reports min_hash == 2^64-1.
     const uint64_t tau = p.tau;
@@ -1039,6 +1044,7 @@ struct Tables {
     const Run *d_runs;
     const uint32_t *d_strip0_dense, *d_strip0_sparse, *d_ctg_nk, *d_ctg_rec, *d_ctg_run0;
     const uint64_t *d_g0;
+    const uint8_t *d_ctg_drop = nullptr;  // split load: contigs whose first minimizer is not reported (k_resolve), else null
     const std::vector<Record> *recs;  // for base accounting (may be null)
 };
 
@@ -1142,6 +1148,7 @@ struct Driver {
         rp.ovf = ctrl;
         rp.tau = tau;
         rp.ctg_nk = T.d_ctg_nk;
+        rp.ctg_drop = T.d_ctg_drop;
         rp.w = h->cfg.w;
         rp.sel = sc(SC_SEL).as<uint8_t>();
         rp.ctg_lo = ctg_lo;
@@ -1183,6 +1190,7 @@ struct Driver {
         rp.ovf = ctrl;
         rp.tau = tau;
         rp.ctg_nk = T.d_ctg_nk;
+        rp.ctg_drop = T.d_ctg_drop;
         rp.w = h->cfg.w;
         rp.sel = sc(SC_SEL).as<uint8_t>();
         rp.ctg_lo = ctg_lo;
@@ -1309,8 +1317,10 @@ struct Driver {
         // every stretch becomes a stand-alone virtual contig made of pieces of the real contig's runs
         std::vector<Run> vruns;
         std::vector<uint32_t> v_nk, v_rec, v_run0;
+        std::vector<uint8_t> v_drop;
         for (size_t v = 0; v < gaps.size(); ++v) {
             const uint32_t c = gaps[v].x, klo = gaps[v].y, khi = gaps[v].z;
+            if (a->any_drop) v_drop.push_back(a->ctg_drop[c] && klo == 0 ? 1 : 0);  // the stretch holds the contig's first window
             v_run0.push_back((uint32_t)vruns.size());
             v_nk.push_back(khi - klo + 1);
             v_rec.push_back((*T.ctg_rec)[c]);
@@ -1347,6 +1357,7 @@ struct Driver {
         if ((rc = upload(h, sc(SC_V_NK), v_nk, st)) != MXG_OK) return rc;
         if ((rc = upload(h, sc(SC_V_REC), v_rec, st)) != MXG_OK) return rc;
         if ((rc = upload(h, sc(SC_V_RUN0), v_run0, st)) != MXG_OK) return rc;
+        if (a->any_drop && (rc = upload(h, sc(SC_V_DROP), v_drop, st)) != MXG_OK) return rc;
         Tables V;
         V.runs = &vruns;
         V.ctg_nk = &v_nk;
@@ -1362,6 +1373,7 @@ struct Driver {
         V.d_ctg_rec = sc(SC_V_REC).as<uint32_t>();
         V.d_ctg_run0 = sc(SC_V_RUN0).as<uint32_t>();
         V.d_g0 = sc(SC_V_G0).as<uint64_t>();
+        V.d_ctg_drop = a->any_drop ? sc(SC_V_DROP).as<uint8_t>() : nullptr;
         V.recs = nullptr;
         OutArrays og{&sc(SC_G_HASH), &sc(SC_G_POS), &sc(SC_G_REC), &sc(SC_G_FWD), 0};
         MXG_HIP(h, og.hash->ensure(1024 * 8));
@@ -1626,6 +1638,7 @@ static int prepare_tables(mxg_handle *h, Assembly *a)
     if ((rc = upload(h, a->d_ctg_nk, a->ctg_nk)) != MXG_OK) return rc;
     if ((rc = upload(h, a->d_ctg_rec, a->ctg_rec)) != MXG_OK) return rc;
     if ((rc = upload(h, a->d_ctg_run0, a->ctg_run0)) != MXG_OK) return rc;
+    if (a->any_drop && (rc = upload(h, a->d_ctg_drop, a->ctg_drop)) != MXG_OK) return rc;
     MXG_HIP(h, hipStreamSynchronize(h->stream));
     a->tables_ready = true;
     return MXG_OK;
@@ -1682,6 +1695,7 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
     T.d_ctg_rec = a->d_ctg_rec.as<uint32_t>();
     T.d_ctg_run0 = a->d_ctg_run0.as<uint32_t>();
     T.d_g0 = a->d_g0.as<uint64_t>();
+    T.d_ctg_drop = a->any_drop ? a->d_ctg_drop.as<uint8_t>() : nullptr;
     T.recs = &a->recs;
     // output capacity estimate: density 2/(w+1) per k-mer plus slack; grown on demand
     uint64_t cap = (uint64_t)(3.0 * (double)a->total_kmers / (double)(w + 1)) + 4096;

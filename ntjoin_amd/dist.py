@@ -210,6 +210,30 @@ def _exchange_one_gather(eng, union, A, world, dev, group, stream):
     return True
 
 
+def concat_tsv_parts(parts, continues, out_path):
+    """Rank-ordered concatenation of the shards' TSV parts into `out_path`.  continues[r] (mxg_assembly_continues on rank
+    r): part r's first line continues the record of the last line written so far (sub-record sharding) -- its entries
+    are appended to that line instead of starting a new one."""
+    with open(out_path, "wb") as out:
+        pending = None                      # last line written so far, without its newline, kept back for a continuation
+        for r, path in enumerate(parts):
+            with open(path, "rb") as f:
+                first = True
+                for line in f:
+                    line = line.rstrip(b"\n")
+                    if first and continues[r] and pending is not None:
+                        rest = line.split(b"\t", 1)[1] if b"\t" in line else b""
+                        if rest:
+                            pending += rest if pending.endswith(b"\t") else b" " + rest
+                    else:
+                        if pending is not None:
+                            out.write(pending + b"\n")
+                        pending = line
+                    first = False
+        if pending is not None:
+            out.write(pending + b"\n")
+
+
 def shard_range(lengths, shard, n_shards):
     """[lo, hi) of the records shard `shard` owns: contiguous, balanced by base count (the library's rule)."""
     import ctypes as C

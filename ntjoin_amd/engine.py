@@ -83,6 +83,19 @@ class MxEngine:
         return self._check(self._lib.mxg_add_assembly_fasta_shard(self._h, str(name).encode(), float(weight),
                                                                   str(fasta_path).encode(), int(shard), int(n_shards)))
 
+    def add_fasta_split(self, name, weight, fasta_path, shard, n_shards):
+        """as add_fasta_shard, but the shards are equal BASE ranges: long records are sketched in pieces (with a halo) and the
+        rank-ordered concatenation of the shards' sketches is the sketch of the whole file"""
+        return self._check(self._lib.mxg_add_assembly_fasta_split(self._h, str(name).encode(), float(weight),
+                                                                  str(fasta_path).encode(), int(shard), int(n_shards)))
+
+    def assembly_continues(self, a):
+        """split load: does this handle's first record continue a record begun on the shard before?"""
+        rc = self._lib.mxg_assembly_continues(self._h, int(a))
+        if rc < 0:
+            raise ValueError("mxg_assembly_continues: bad arguments")
+        return bool(rc)
+
     def assembly_shard(self, a):
         lo, hi = C.c_uint64(), C.c_uint64()
         self._check(self._lib.mxg_assembly_shard(self._h, int(a), C.byref(lo), C.byref(hi)))

@@ -6,21 +6,20 @@ Multi-GPU driver of the hot path, one process per GPU:
         -m ntjoin_amd.run_dist -k 32 -w 1000 -p out --target scaf.fa --target_weight 1 \
         --references ref1.fa ref2.fa --reference_weights 2 2
 
-Every rank opens every FASTA, keeps the records of its shard (contiguous record ranges balanced by bases; record
-indices are global), sketches them, and writes its part of `<fasta>.k<k>.w<w>.tsv` (rank 0 concatenates the parts in
+Every rank opens every FASTA, keeps the records of its shard (contiguous record ranges balanced by bases, or with --split
+equal base ranges that cut long records into pieces with a halo; record indices are global), sketches them, and writes its part of `<fasta>.k<k>.w<w>.tsv` (rank 0 concatenates the parts in
 rank order = input order).  The sketches are exchanged with one RCCL all-gather per assembly; every rank then holds
 the full sketches and builds the minimizer graph; rank 0 writes `<prefix>.mx.dot`.  Same file names as ntJoin
 (reference ntJoin:26,204 and bin/ntjoin.py:28).
 """
 import argparse
 import os
-import shutil
 import sys
 
 import torch
 import torch.distributed as dist
 
-from .dist import allgather_inplace
+from .dist import allgather_inplace, concat_tsv_parts
 from .engine import MxEngine
 
 
@@ -34,6 +33,8 @@ def main(argv=None):
     ap.add_argument("--references", nargs="+", required=True)
     ap.add_argument("--reference_weights", nargs="+", type=float, required=True)
     ap.add_argument("--variant", default="v2")
+    ap.add_argument("--split", action="store_true",
+                    help="shard by equal base ranges, cutting long records into pieces with a halo (default: whole records)")
     args = ap.parse_args(argv)
     if len(args.references) != len(args.reference_weights):
         sys.exit("ERROR: The length of supplied reference weights and number of references must be equal.")
@@ -43,26 +44,34 @@ def main(argv=None):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29512")
+    # test knobs: NTJOIN_DIST_BACKEND=gloo with NTJOIN_DIST_ONE_DEVICE=1 runs several ranks on ONE GPU (RCCL cannot share a
+    # device between ranks); production is one rank per GPU over RCCL
+    backend = os.environ.get("NTJOIN_DIST_BACKEND", "nccl")
+    if os.environ.get("NTJOIN_DIST_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         fastas = list(args.references) + [args.target]          # references first (CLI order), target last
         weights = list(args.reference_weights) + [args.target_weight]
         tsvs = [f"{fa}.k{args.k}.w{args.w}.tsv" for fa in fastas]
         with MxEngine(k=args.k, w=args.w, variant=args.variant, device=local_rank) as eng:
             for fa, wt, tsv in zip(fastas, weights, tsvs):
-                eng.add_fasta_shard(tsv, wt, fa, rank, world)
+                (eng.add_fasta_split if args.split else eng.add_fasta_shard)(tsv, wt, fa, rank, world)
             eng.sketch()
             for a, tsv in enumerate(tsvs):                       # this rank's records only
                 eng.write_tsv(a, f"{tsv}.part{rank}", with_pos=True, with_strand=False, with_seq=True)
-            dist.barrier()
-            if rank == 0:
-                for tsv in tsvs:
-                    with open(tsv, "wb") as out:
-                        for r in range(world):
-                            with open(f"{tsv}.part{r}", "rb") as part:
-                                shutil.copyfileobj(part, out)
-                            os.remove(f"{tsv}.part{r}")
+            cont = [[False] * len(tsvs) for _ in range(world)]
+            dist.all_gather_object(cont, [eng.assembly_continues(a) for a in range(len(tsvs))])
+            if rank == 0:                                        # (all_gather_object also orders the part files before this)
+                for a, tsv in enumerate(tsvs):
+                    parts = [f"{tsv}.part{r}" for r in range(world)]
+                    concat_tsv_parts(parts, [cont[r][a] for r in range(world)], tsv)
+                    for part in parts:
+                        os.remove(part)
             allgather_inplace(eng, local_rank)
             eng.build_graph()
             if rank == 0:

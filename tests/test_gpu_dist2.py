@@ -56,3 +56,33 @@ def test_bench_two_ranks_on_one_gpu(mode):
 
 
 _BENCH_COUNTS = {}
+
+
+@pytest.mark.parametrize("world,split", [(3, True), (2, False)])
+def test_run_dist_ranks_on_one_gpu(tmp_path, world, split):
+    """the torchrun-able FASTA driver with several ranks (gloo, one GPU): with --split the shards are equal base ranges
+    that cut the records into pieces with halos.  TSVs byte-identical to the committed sketches, canonical .mx.dot
+    identical to the reference's."""
+    import filecmp
+    import shutil
+    import subprocess
+    import sys
+    from oracle import graph_oracle as go
+    from tests.conftest import GOLDEN, REPO, load_case
+    fasta_dir = os.path.join(GOLDEN, "fasta")
+    meta = load_case("synth3_w50")["meta"]
+    asms = meta["refs"] + [meta["target"]]
+    for a in asms:
+        shutil.copy(os.path.join(fasta_dir, a["fasta"]), tmp_path / a["fasta"])
+    env = dict(os.environ, PYTHONPATH=REPO, NTJOIN_DIST_BACKEND="gloo", NTJOIN_DIST_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + world), "-m", "ntjoin_amd.run_dist", "-k", str(meta["k"]), "-w", str(meta["w"]), "-p", "out",
+           "--target", meta["target"]["fasta"], "--target_weight", str(meta["target"]["weight"]),
+           "--references"] + [a["fasta"] for a in meta["refs"]] + ["--reference_weights"] + \
+          [str(a["weight"]) for a in meta["refs"]] + (["--split"] if split else [])
+    subprocess.check_call(cmd, cwd=tmp_path, env=env, timeout=600)
+    for a in asms:
+        assert filecmp.cmp(str(tmp_path / a["tsv"]), os.path.join(GOLDEN, "cases", meta["name"], a["tsv"]), shallow=False), a["tsv"]
+    with open(os.path.join(GOLDEN, "cases", meta["name"], "reference.mx.dot"), encoding="utf-8") as fh:
+        want = go.canonical_dot_from_text(fh.read())
+    assert go.canonical_dot_from_text((tmp_path / "out.mx.dot").read_text(encoding="utf-8")) == want
