@@ -352,13 +352,14 @@ struct VertexParams {
 // ordered compaction of the shared minimizers of one assembly; rank r in filtered order
 __global__ __launch_bounds__(256) void k_vertices(const VertexParams p)
 {
+    // one minimizer per thread: a few hundred thousand items are too few for four per thread (196 blocks on 256 CUs,
+    // each thread walking four dependent gathers)
     __shared__ uint32_t sh[256];
-    uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
-    const uint32_t fl = load_flags4(p.shared, base, p.n_ptr ? min(*p.n_ptr, p.n) : p.n);
-    uint32_t c = count_flags4(fl);
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool f = i < (p.n_ptr ? min(*p.n_ptr, p.n) : p.n) && p.shared[i];
     __shared__ uint32_t sh_before;
     if (threadIdx.x < 64) {
-        const uint32_t bef = count_prefix(p.cnt, p.sup, blockIdx.x * (TILE / 256));
+        const uint32_t bef = count_prefix(p.cnt, p.sup, blockIdx.x);
         if (threadIdx.x == 0) sh_before = bef;
         if (blockIdx.x + 1 == gridDim.x) {  // the last tile also reports the total
             const uint32_t all = count_prefix(p.cnt, p.sup, (p.n + 255u) / 256u);
@@ -366,28 +367,23 @@ __global__ __launch_bounds__(256) void k_vertices(const VertexParams p)
         }
     }
     __syncthreads();
-    uint32_t r = sh_before + block_exclusive_256(c, sh);
-    if (c == 0) return;
-    for (int u = 0; u < TILE_PER_THREAD; ++u) {
-        uint32_t i = base + u;
-        if ((fl >> (8 * u)) & 1u) {
-            uint32_t s = p.slot[i];
-            uint32_t v;
-            if (p.first) {
-                v = r;
-                p.vid[s] = v;
-                p.vhash[v] = p.hash[i];
-            } else {
-                v = p.vid[s];
-            }
-            p.vpos[v] = p.pos[i];
-            p.vrec[v] = p.rec[i];
-            if (p.ivid) p.ivid[i] = v;
-            p.fv[r] = v;
-            p.frec[r] = p.rec[i];
-            ++r;
-        }
+    const uint32_t r = sh_before + block_exclusive_256(f ? 1u : 0u, sh);
+    if (!f) return;
+    const uint32_t s = p.slot[i];
+    uint32_t v;
+    if (p.first) {
+        v = r;
+        p.vid[s] = v;
+        p.vhash[v] = p.hash[i];
+    } else {
+        v = p.vid[s];
     }
+    const uint32_t rec = p.rec[i];
+    p.vpos[v] = p.pos[i];
+    p.vrec[v] = rec;
+    if (p.ivid) p.ivid[i] = v;
+    p.fv[r] = v;
+    p.frec[r] = rec;
 }
 
 // blockIdx.y = assembly; all arrays are [A][stride]
@@ -459,12 +455,11 @@ __global__ __launch_bounds__(256) void k_edge_flags(const EdgeParams p)
 __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_items)
 {
     __shared__ uint32_t sh[256];
-    uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
-    const uint32_t fl = load_flags4(p.eflag, base, n_items);
-    uint32_t c = count_flags4(fl);
+    const uint32_t item = blockIdx.x * 256u + threadIdx.x;  // (one per thread: see k_vertices)
+    const bool f = item < n_items && p.eflag[item];
     __shared__ uint32_t sh_before;
     if (threadIdx.x < 64) {
-        const uint32_t bef = count_prefix(p.bsum, p.bsuper, blockIdx.x * (TILE / 256));
+        const uint32_t bef = count_prefix(p.bsum, p.bsuper, blockIdx.x);
         if (threadIdx.x == 0) sh_before = bef;
         if (blockIdx.x + 1 == gridDim.x) {  // the last tile also reports the total
             const uint32_t all = count_prefix(p.bsum, p.bsuper, (n_items + 255u) / 256u);
@@ -476,26 +471,20 @@ __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_it
         }
     }
     __syncthreads();
-    uint32_t e = sh_before + block_exclusive_256(c, sh);
-    if (c == 0) return;
-    for (int t = 0; t < TILE_PER_THREAD; ++t) {
-        uint32_t item = base + t;
-        if ((fl >> (8 * t)) & 1u) {
-            uint32_t a = item / p.nv, r = item % p.nv;
-            uint32_t u = p.fv[(size_t)a * p.nv + r];
-            uint32_t v = p.nxt[(size_t)a * p.nv + u];
-            uint32_t m = edge_mask(p, u, v);
-            // python: sum(weights[f] for f in support) -- int 0 start, then float adds in support (= assembly) order
-            double wsum = 0.0;
-            for (uint32_t b = 0; b < p.n_asm; ++b)
-                if (m & (1u << b)) wsum = wsum + p.weights[b];
-            p.eu[e] = u;
-            p.ev[e] = v;
-            p.esup[e] = m;
-            p.ew[e] = wsum;
-            ++e;
-        }
-    }
+    const uint32_t e = sh_before + block_exclusive_256(f ? 1u : 0u, sh);
+    if (!f) return;
+    const uint32_t a = item / p.nv, r = item % p.nv;
+    const uint32_t u = p.fv[(size_t)a * p.nv + r];
+    const uint32_t v = p.nxt[(size_t)a * p.nv + u];
+    const uint32_t m = edge_mask(p, u, v);
+    // python: sum(weights[f] for f in support) -- int 0 start, then float adds in support (= assembly) order
+    double wsum = 0.0;
+    for (uint32_t b = 0; b < p.n_asm; ++b)
+        if (m & (1u << b)) wsum = wsum + p.weights[b];
+    p.eu[e] = u;
+    p.ev[e] = v;
+    p.esup[e] = m;
+    p.ew[e] = wsum;
 }
 
 // distributed graph, owner side (dgraph.hip): adjacency arrives as messages {kind << 8 | assembly, local vertex, other
@@ -695,7 +684,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
                 MXG_HIP(h, hipMemsetAsync(as->d_ivid.p, 0xFF, (size_t)n * 4, h->stream));
                 vp.ivid = as->d_ivid.as<uint32_t>();
             }
-            hipLaunchKernelGGL(k_vertices, dim3((n + TILE - 1) / TILE), dim3(256), 0, h->stream, vp);
+            hipLaunchKernelGGL(k_vertices, dim3((n + 255) / 256), dim3(256), 0, h->stream, vp);
         }
         if (mode == GRAPH_DG_VERTICES) {  // the caller exchanges vertex ids and adjacency, then calls GRAPH_DG_EDGES;
             g.nv_stride = nvs;            // no host sync: the vertex count stays on the device (ctl[0]) until then
@@ -713,7 +702,6 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
                                h->g_fv.as<uint32_t>(), (uint32_t)nvs);
         }
         MXG_HIP(h, hipGetLastError());
-        const uint32_t e_tiles = (n_items + TILE - 1) / TILE;
         MXG_HIP(h, h->g_eflag.ensure(n_items));
         MXG_HIP(h, h->g_ebs.ensure((size_t)e_blocks * 4 + 64));
         // every item yields at most one edge: size the edge arrays by that bound
@@ -739,7 +727,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         ep.ew = h->g_ew.as<double>();
         for (uint32_t a = 0; a < MXG_MAX_ASSEMBLIES; ++a) ep.weights[a] = a < A ? h->asms[a]->weight : 0.0;
         hipLaunchKernelGGL(k_edge_flags, dim3(e_blocks), dim3(256), 0, h->stream, ep);  // + per-256 counts
-        hipLaunchKernelGGL(k_edges, dim3(e_tiles), dim3(256), 0, h->stream, ep, n_items);
+        hipLaunchKernelGGL(k_edges, dim3(e_blocks), dim3(256), 0, h->stream, ep, n_items);
         MXG_HIP(h, hipGetLastError());
     }
     if (mode == GRAPH_DG_VERTICES) {  // (an assembly without items: no vertex)
