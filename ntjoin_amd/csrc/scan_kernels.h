@@ -41,7 +41,7 @@ static __global__ __launch_bounds__(256) void k_count(const uint8_t *__restrict_
 __device__ __forceinline__ uint32_t wave_inclusive_u32(uint32_t v, uint32_t lane);
 
 // inside a block of NW waves: exclusive prefix of per-thread counts `c`; afterwards sh[255] holds the block total
-// (sh: >= 256 words, NW <= 8).  Wave scans by lane shuffles + NW wave totals through LDS: two barriers (a Hillis-Steele
+// (sh: >= 256 words, NW <= 16).  Wave scans by lane shuffles + NW wave totals through LDS: two barriers (a Hillis-Steele
 // scan over LDS took 17).  All threads of the block must call.
 template <int NW>
 __device__ __forceinline__ uint32_t block_exclusive(uint32_t c, uint32_t *sh)

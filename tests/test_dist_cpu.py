@@ -79,3 +79,24 @@ def test_shard_records_balanced():
         loads = [int(lens[s].sum()) for s in shards]
         assert max(loads) - min(loads) <= lens.max()
         assert all(s == sorted(s) for s in shards)
+
+
+def test_concat_tsv_parts(tmp_path):
+    """rank-ordered TSV parts of a split load: a part whose first line continues the previous part's last record is
+    appended to that line (with or without entries on either side); other lines pass through"""
+    from ntjoin_amd.dist import concat_tsv_parts
+    parts = [b"r0\t1:2:AC 3:4:GT\nr1\t5:6:AA\n",      # rank 0: r0 complete, r1 begun
+             b"r1\t7:8:CC\n",                            # rank 1: continues r1, nothing else
+             b"r1\t\nr2\t\n",                           # rank 2: continues r1 without entries, begins r2 without entries
+             b"",                                          # rank 3: holds nothing
+             b"r2\t9:10:GG\nr3\t11:12:TT\n",            # rank 4: continues r2 (first entries of that line), r3
+             b"r4\t13:14:AT\n"]                          # rank 5: a new record, no continuation
+    cont = [False, True, True, False, True, False]
+    paths = []
+    for i, data in enumerate(parts):
+        path = tmp_path / f"p{i}"
+        path.write_bytes(data)
+        paths.append(str(path))
+    out = tmp_path / "joined.tsv"
+    concat_tsv_parts(paths, cont, str(out))
+    assert out.read_bytes() == (b"r0\t1:2:AC 3:4:GT\nr1\t5:6:AA 7:8:CC\nr2\t9:10:GG\nr3\t11:12:TT\nr4\t13:14:AT\n")
