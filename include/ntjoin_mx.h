@@ -216,6 +216,17 @@ int mxg_set_sketch_gathered(mxg_handle *h, int assembly, const void *d_allbuf, u
 int mxg_set_sketch_gathered_strided(mxg_handle *h, int assembly, const void *d_allbuf, uint32_t world,
                                     uint64_t stride_bytes, uint64_t nmax, const uint64_t *counts,
                                     const uint64_t *rec_offsets);
+/* Steady-state exchange with the counts on the device (the union path of ntjoin_amd/dist.py after its first step): a
+   rank's slot = [int64 count per assembly (-1: does not fit) padded to head_bytes | caps[0] entries of assembly 0 as
+   mxg_pack_sketch_device lays them out | caps[1] entries of assembly 1 | ...].  mxg_xchg_pack fills this handle's slot
+   (every assembly, the counts written by the packing kernels); after ONE all-gather of the slots,
+   mxg_xchg_unpack_graph on the union's handle unpacks all `world` slots with the counts read from the headers on the
+   device (rec_offsets[a * world + r] = record index shift of rank r) and runs the graph stage behind it: one host sync
+   for exchange + graph.  Returns 1 when some rank's header says "does not fit" (nothing usable: exchange sizes first,
+   mxg_set_sketch_gathered), else as mxg_build_graph.  No counterpart in the reference (single process). */
+int mxg_xchg_pack(mxg_handle *h, void *d_slot, uint64_t head_bytes, const uint64_t *caps);
+int mxg_xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t slot_bytes, uint64_t head_bytes,
+                          const uint64_t *caps, const uint64_t *rec_offsets);
 /* indexlr TSV: `id \t out_hash[:pos][:+|-][:kmer] ( out_hash...)* \n`, one line per record, input order.
    path "-" = stdout. */
 int mxg_write_tsv(mxg_handle *h, int assembly, const char *path, int with_pos, int with_strand,

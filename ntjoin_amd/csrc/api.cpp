@@ -463,6 +463,19 @@ int mxg_set_sketch_gathered_strided(mxg_handle *h, int assembly, const void *d_a
     return unpack_gathered(h, a, d_allbuf, world, nmax, counts, rec_offsets, stride_bytes);
 }
 
+int mxg_xchg_pack(mxg_handle *h, void *d_slot, uint64_t head_bytes, const uint64_t *caps)
+{
+    if (!h || !d_slot || !caps || head_bytes < 8 * h->asms.size()) return MXG_EINVAL;
+    return xchg_pack(h, d_slot, head_bytes, caps);
+}
+
+int mxg_xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t slot_bytes, uint64_t head_bytes,
+                          const uint64_t *caps, const uint64_t *rec_offsets)
+{
+    if (!h || !d_all || !caps || !rec_offsets) return MXG_EINVAL;
+    return xchg_unpack_graph(h, d_all, world, slot_bytes, head_bytes, caps, rec_offsets);
+}
+
 int mxg_set_sketch_device(mxg_handle *h, int assembly, const void *d_out_hash, const void *d_pos,
                           const void *d_record, const void *d_forward, uint64_t n)
 {

@@ -253,6 +253,9 @@ struct GraphBounds {  // fused sketch+graph call: per assembly an upper bound of
 };
 int build_graph(mxg_handle *h, int mode = GRAPH_FULL, const void *d_msgs = nullptr, uint64_t n_msgs = 0,
                 const GraphBounds *gb = nullptr);
+int xchg_pack(mxg_handle *h, void *d_slot, uint64_t head_bytes, const uint64_t *caps);
+int xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t slot_bytes, uint64_t head_bytes,
+                      const uint64_t *caps, const uint64_t *rec_offsets);
 int graph_to_host(mxg_handle *h);
 int find_paths(mxg_handle *h, int64_t n_min);  // paths.hip
 // dgraph.hip

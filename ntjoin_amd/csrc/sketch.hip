@@ -1996,6 +1996,144 @@ int unpack_gathered(mxg_handle *h, Assembly *a, const void *d_allbuf, uint32_t w
     return MXG_OK;
 }
 
+// ---- steady-state exchange with device-side counts -------------------------------------------------------------------
+// A rank's slot: [header: one int64 per assembly = its minimizer count, -1: does not fit | region of assembly 0 (caps[0]
+// entries laid out as k_pack does: hash | pos | rec) | region of assembly 1 | ...].  After the all-gather every rank
+// unpacks all slots with the counts read from the headers ON THE DEVICE and runs the graph stage behind it with upper
+// bounds (GraphBounds): the whole exchange + graph step has ONE host sync (build_graph's).
+__global__ __launch_bounds__(256) void k_pack_slot(const uint64_t *__restrict__ hash, const uint32_t *__restrict__ pos,
+                                                   const uint32_t *__restrict__ rec, uint64_t n, uint64_t cap, long long count,
+                                                   long long *header, unsigned char *__restrict__ region)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) *header = count;
+    if (i >= n) return;
+    reinterpret_cast<uint64_t *>(region)[i] = hash[i];
+    reinterpret_cast<uint32_t *>(region + 8 * cap)[i] = pos[i];
+    reinterpret_cast<uint32_t *>(region + 12 * cap)[i] = rec[i];
+}
+
+int xchg_pack(mxg_handle *h, void *d_slot, uint64_t head_bytes, const uint64_t *caps)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    unsigned char *base = static_cast<unsigned char *>(d_slot);
+    uint64_t off = head_bytes;
+    for (size_t ai = 0; ai < h->asms.size(); ++ai) {
+        Assembly *a = h->asms[ai];
+        if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch yet", a->name.c_str());
+        if (caps[ai] & 7) return set_err(h, MXG_EINVAL, "slot capacities must be multiples of 8");
+        const bool fits = a->n_mx <= caps[ai];
+        const uint64_t n = fits ? a->n_mx : 0;
+        hipLaunchKernelGGL(k_pack_slot, dim3((uint32_t)std::max<uint64_t>((n + 255) / 256, 1)), dim3(256), 0, h->stream,
+                           a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(), a->d_rec.as<uint32_t>(), n, caps[ai],
+                           fits ? (long long)a->n_mx : -1ll, reinterpret_cast<long long *>(base) + ai, base + off);
+        off += 16 * caps[ai];
+    }
+    MXG_HIP(h, hipGetLastError());
+    if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));
+    return MXG_OK;
+}
+
+struct UnpackSlotParams {
+    const unsigned char *all;  // world slots
+    uint64_t slot_bytes, region_off, cap;
+    uint32_t world, a;
+    uint32_t rec_off[64];
+    uint64_t *hash;
+    uint32_t *pos, *rec;
+    uint32_t *n_dev;        // device word that receives the total (GraphBounds::n_ptr)
+    uint32_t *host_total;   // pinned: total, 0xFFFFFFFF if some rank's header says "does not fit"
+};
+
+__global__ __launch_bounds__(256) void k_unpack_slot(const UnpackSlotParams p)
+{
+    const uint32_t r = blockIdx.y;
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    uint64_t start = 0, total = 0;
+    bool bad = false;
+    long long mine = 0;
+    for (uint32_t q = 0; q < p.world; ++q) {  // world is small; the headers sit in L2
+        const long long c = reinterpret_cast<const long long *>(p.all + (size_t)q * p.slot_bytes)[p.a];
+        bad = bad || c < 0 || (uint64_t)c > p.cap;
+        if (q < r) start += (uint64_t)max(c, 0ll);
+        if (q == r) mine = c;
+        total += (uint64_t)max(c, 0ll);
+    }
+    if (r == 0 && i == 0) {
+        *p.n_dev = bad ? 0u : (uint32_t)total;
+        *p.host_total = bad ? 0xFFFFFFFFu : (uint32_t)total;
+    }
+    if (bad || (long long)i >= mine) return;
+    const unsigned char *reg = p.all + (size_t)r * p.slot_bytes + p.region_off;
+    const uint64_t o = start + i;
+    p.hash[o] = reinterpret_cast<const uint64_t *>(reg)[i];
+    p.pos[o] = reinterpret_cast<const uint32_t *>(reg + 8 * p.cap)[i];
+    p.rec[o] = reinterpret_cast<const uint32_t *>(reg + 12 * p.cap)[i] + p.rec_off[r];
+}
+
+// returns 1 (nothing usable: some sketch did not fit its slot on some rank, the caller exchanges sizes first) or the
+// result of build_graph
+int xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t slot_bytes, uint64_t head_bytes,
+                      const uint64_t *caps, const uint64_t *rec_offsets)
+{
+    if (world == 0 || world > 64) return set_err(h, MXG_ELIMIT, "world size must be 1..64");
+    const size_t A = h->asms.size();
+    if (A == 0 || A > MXG_MAX_ASSEMBLIES) return set_err(h, MXG_EINVAL, "mxg_xchg_unpack_graph: 1..%d assemblies", MXG_MAX_ASSEMBLIES);
+    MXG_HIP(h, hipSetDevice(h->device));
+    if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, (MXG_MAX_ASSEMBLIES + 1) * 32));
+    MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
+    GraphBounds gb;
+    uint64_t off = head_bytes;
+    for (size_t ai = 0; ai < A; ++ai) {
+        Assembly *a = h->asms[ai];
+        const uint64_t bound = (uint64_t)world * caps[ai];
+        if (bound >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "exchange slots too large");
+        MXG_HIP(h, a->d_hash.ensure(std::max<uint64_t>(bound * 8, 16)));
+        MXG_HIP(h, a->d_pos.ensure(std::max<uint64_t>(bound * 4, 16)));
+        MXG_HIP(h, a->d_rec.ensure(std::max<uint64_t>(bound * 4, 16)));
+        UnpackSlotParams up;
+        up.all = static_cast<const unsigned char *>(d_all);
+        up.slot_bytes = slot_bytes;
+        up.region_off = off;
+        up.cap = caps[ai];
+        up.world = world;
+        up.a = (uint32_t)ai;
+        for (uint32_t r = 0; r < world; ++r) up.rec_off[r] = (uint32_t)rec_offsets[ai * world + r];
+        up.hash = a->d_hash.as<uint64_t>();
+        up.pos = a->d_pos.as<uint32_t>();
+        up.rec = a->d_rec.as<uint32_t>();
+        up.n_dev = h->d_nmx.as<uint32_t>() + ai;
+        up.host_total = h->pinned_ctrl + 8 * ai;
+        h->pinned_ctrl[8 * ai] = 0xFFFFFFFFu;
+        hipLaunchKernelGGL(k_unpack_slot, dim3((uint32_t)std::max<uint64_t>((caps[ai] + 255) / 256, 1), world), dim3(256), 0,
+                           h->stream, up);
+        off += 16 * caps[ai];
+        gb.n_bound[ai] = bound;
+        gb.n_ptr[ai] = h->d_nmx.as<uint32_t>() + ai;
+        a->has_sketch = true;
+        a->n_mx = 0;  // (known after the sync below)
+        a->fwd_valid = false;
+        a->foreign_sketch = true;
+        a->host_valid = false;
+        a->flags_valid = false;
+    }
+    MXG_HIP(h, hipGetLastError());
+    h->graph.valid = false;
+    const int rc = build_graph(h, GRAPH_FULL, nullptr, 0, &gb);  // its sync is the exchange's sync
+    if (rc != MXG_OK) return rc;
+    bool bad = false;
+    for (size_t ai = 0; ai < A; ++ai) {
+        const uint32_t t = h->pinned_ctrl[8 * ai];
+        bad = bad || t == 0xFFFFFFFFu;
+        h->asms[ai]->n_mx = t == 0xFFFFFFFFu ? 0 : t;
+    }
+    if (bad) {
+        h->graph.valid = false;
+        return 1;
+    }
+    return MXG_OK;
+}
+
 int sync_sketch_to_host(mxg_handle *h, Assembly *a)
 {
     if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch yet (call mxg_sketch)", a->name.c_str());

@@ -112,9 +112,7 @@ def _allgather_union_graph(eng, k, w, device, union, group, stream):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", device)
     if union is not None and getattr(union, "_slots", None) is not None:
-        done = _exchange_one_gather(eng, union, A, world, dev, group, stream)
-        if done:
-            union.build_graph()
+        if _exchange_one_gather(eng, union, A, world, dev, group, stream):
             return union
     # first step (or a sketch that outgrew its slot): sizes first, then one all-gather per assembly
     # sizes of what follows: (count, records) per assembly from every rank.  Staged through pinned host tensors kept on
@@ -161,53 +159,34 @@ def _allgather_union_graph(eng, k, w, device, union, group, stream):
             torch.cuda.current_stream().synchronize()  # the union handle works on its own stream
         union.set_sketch_gathered(a, recv.data_ptr(), nmax, counts, rec_off)
     # later steps: ONE all-gather.  Every rank's slot = header (count per assembly) + a fixed-capacity region per
-    # assembly, 25 % above the largest sketch seen in this step on any rank (the same on all ranks by construction).
-    caps = [((int(metas[:, a, 0].max()) * 5 // 4 + 64) + 7) // 8 * 8 for a in range(A)]
+    # assembly, 25 % above the largest sketch seen in this step on any rank (the same on all ranks by construction);
+    # pack, unpack and the graph stage then run with the counts on the device (mxg_xchg_*): one host sync per step.
+    pct = int(os.environ.get("MXG_XCHG_SLOT_PCT", "125"))  # test knob: < 100 forces the fallback on every later step
+    caps = [((int(metas[:, a, 0].max()) * pct // 100 + (64 if pct >= 100 else 0)) + 7) // 8 * 8 for a in range(A)]
     head = 64 * ((16 * A + 63) // 64)
     slot = head + 16 * sum(caps)
     union._slots = {"caps": caps, "head": head, "slot": slot,
-                    "rec_off": [np.concatenate([[0], np.cumsum(metas[:, a, 1])[:-1]]).astype(np.uint64) for a in range(A)],
+                    "rec_off_flat": np.concatenate([np.concatenate([[0], np.cumsum(metas[:, a, 1])[:-1]]) for a in range(A)]).astype(np.uint64),
                     "send": torch.zeros(slot, dtype=torch.uint8, device=dev),
-                    "recv": torch.empty(world * slot, dtype=torch.uint8, device=dev),
-                    "head_h": torch.empty((A,), dtype=torch.int64).pin_memory(),
-                    "heads_h": torch.empty((world, head // 8), dtype=torch.int64).pin_memory()}
+                    "recv": torch.empty(world * slot, dtype=torch.uint8, device=dev)}
     union.build_graph()
     return union
 
 
 def _exchange_one_gather(eng, union, A, world, dev, group, stream):
-    """steady-state exchange: header + all assemblies in ONE all-gather and one host sync (the header read-back).
-    Returns False (nothing changed in `union`) when some sketch no longer fits its slot on some rank."""
+    """steady-state exchange + graph of the union: pack (library, counts written by the kernels) -> ONE all-gather ->
+    unpack with the counts read from the headers on the device + graph stage, one host sync in all (mxg_xchg_*).
+    Returns False (nothing usable in `union`) when some sketch no longer fits its slot on some rank: every rank sees
+    the same headers, so all fall back to the size exchange together."""
     sl = union._slots
-    caps, head, slot = sl["caps"], sl["head"], sl["slot"]
-    send, recv = sl["send"], sl["recv"]
-    hh = sl["head_h"].numpy()
-    fits = True
-    for a in range(A):
-        hh[a] = eng.sketch_size(a)
-        fits = fits and hh[a] <= caps[a]
-    if not fits:
-        hh[:] = -1                               # tell everybody: this rank needs bigger slots
-    send[:8 * A].view(torch.int64).copy_(sl["head_h"], non_blocking=True)
-    off = head
-    if fits:
-        for a in range(A):
-            eng.pack_sketch_device(a, send.data_ptr() + off, caps[a])
-            off += 16 * caps[a]
-    dist.all_gather_into_tensor(recv, send, group=group)
-    heads = recv.view(world, slot)[:, :head].contiguous().view(torch.int64).view(world, head // 8)
-    sl["heads_h"].copy_(heads, non_blocking=True)
-    torch.cuda.current_stream().synchronize()    # the one host sync of the exchange
-    counts_all = sl["heads_h"].numpy()[:, :A].copy()
-    if (counts_all < 0).any():
-        union._slots = None                      # every rank sees the same headers: all fall back together
-        return False
-    off = head
-    for a in range(A):
-        union.set_sketch_gathered_strided(a, recv.data_ptr() + off, slot, caps[a], counts_all[:, a].astype(np.uint64),
-                                          sl["rec_off"][a])
-        off += 16 * caps[a]
-    return True
+    eng.xchg_pack(sl["send"].data_ptr(), sl["head"], sl["caps"])
+    dist.all_gather_into_tensor(sl["recv"], sl["send"], group=group)
+    if stream is None:
+        torch.cuda.current_stream().synchronize()    # the union handle works on its own stream
+    ok = union.xchg_unpack_graph(sl["recv"].data_ptr(), world, sl["slot"], sl["head"], sl["caps"], sl["rec_off_flat"])
+    if not ok:
+        union._slots = None
+    return ok
 
 
 def concat_tsv_parts(parts, continues, out_path):

@@ -96,6 +96,22 @@ class MxEngine:
             raise ValueError("mxg_assembly_continues: bad arguments")
         return bool(rc)
 
+    def xchg_pack(self, d_slot, head_bytes, caps):
+        cc = np.ascontiguousarray(caps, dtype=np.uint64)
+        return self._check(self._lib.mxg_xchg_pack(self._h, C.c_void_p(int(d_slot)), int(head_bytes),
+                                                   cc.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+    def xchg_unpack_graph(self, d_all, world, slot_bytes, head_bytes, caps, rec_offsets):
+        """-> False when some rank's sketch did not fit its slot (nothing usable), True: sketches unpacked + graph built"""
+        cc = np.ascontiguousarray(caps, dtype=np.uint64)
+        ro = np.ascontiguousarray(rec_offsets, dtype=np.uint64)
+        rc = self._lib.mxg_xchg_unpack_graph(self._h, C.c_void_p(int(d_all)), int(world), int(slot_bytes), int(head_bytes),
+                                             cc.ctypes.data_as(C.POINTER(C.c_uint64)), ro.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if rc == 1:
+            return False
+        self._check(rc)
+        return True
+
     def assembly_shard(self, a):
         lo, hi = C.c_uint64(), C.c_uint64()
         self._check(self._lib.mxg_assembly_shard(self._h, int(a), C.byref(lo), C.byref(hi)))

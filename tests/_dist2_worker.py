@@ -45,7 +45,7 @@ def main():
         mine.append(part)
         eng.add_records(name, wt, part)
     union = None
-    for _step in range(2):                      # the second step reuses the union handle and its exchange buffers
+    for _step in range(3):                      # later steps reuse the union handle and its fixed-capacity slots
         eng.sketch(-2)
         union = allgather_union_graph(eng, k, w, 0, union, stream=xs)
     # the same graph, distributed by hash range: every rank ends up with its own vertices and edges

@@ -23,9 +23,10 @@ def _free_port():
 
 @pytest.mark.parametrize("world,stream,slot_pct", [(2, "0", "130"), (2, "1", "130"), (3, "1", "130"), (2, "1", "60"), (3, "0", "100")])
 def test_union_graph_world_size(world, stream, slot_pct):
-    """slot_pct: capacity of the partitioned exchange's fixed slots relative to the largest bucket of the first step
-    (130 = default; 60: every later step overflows and falls back to the exact exchange; 100: no slack at all)"""
-    env = dict(os.environ, MXG_TEST_STREAM=stream, MXG_DG_SLOT_PCT=slot_pct)
+    """slot_pct: capacity of the fixed slots of both exchanges (union: one all-gather; partitioned: all-to-alls) relative
+    to the largest sketch / bucket of the first step (130 ~ default; 60: every later step overflows and falls back to the
+    exchange of exact sizes; 100: no slack at all)"""
+    env = dict(os.environ, MXG_TEST_STREAM=stream, MXG_DG_SLOT_PCT=slot_pct, MXG_XCHG_SLOT_PCT=slot_pct)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(REPO, "tests", "_dist2_worker.py")]
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
