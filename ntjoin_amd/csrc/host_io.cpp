@@ -111,6 +111,9 @@ struct Ingest {
     std::vector<Piece> pieces;
     uint64_t p_lo = 0, p_hi = ~0ull;
     bool p_drop = false;
+    std::string stage;        // line bodies waiting to be packed when the text is not kept
+    size_t pending = 0;       // bytes at the end of a->text / stage not packed yet
+    bool pending_keep = false;
 
     Ingest(mxg_handle *h_, Assembly *a_) : h(h_), a(a_), k(h_->cfg.k), w(h_->cfg.w) {}
 
@@ -181,11 +184,24 @@ struct Ingest {
         if (c0 >= c1) return;
         s += c0 - s0;
         n = (size_t)(c1 - c0);
+        // the line bodies are first laid end to end (the record's text, or a staging buffer when the text is not kept) and
+        // packed from there in long contiguous stretches, whatever the line length of the file
+        std::string &dst = keep_text ? a->text : stage;
+        dst.append(reinterpret_cast<const char *>(s), n);
+        pending += n;
+        pending_keep = keep_text;
+        if (pending >= (size_t(1) << 20)) pack_pending();
+    }
+    void pack_pending()
+    {
+        if (!pending) return;
+        std::string &src = pending_keep ? a->text : stage;
+        const uint8_t *s = reinterpret_cast<const uint8_t *>(src.data()) + (src.size() - pending);
+        const size_t n = pending;
         const uint8_t *lut = code_lut();
-        if (keep_text) a->text.append(reinterpret_cast<const char *>(s), n);
-        for (size_t i = 0; i < n; ++i) {
-            uint8_t c = lut[s[i]];
-            unsigned slot = (unsigned)(fpos & 15);
+        auto one = [&](uint8_t ch) {
+            const uint8_t c = lut[ch];
+            const unsigned slot = (unsigned)(fpos & 15);
             if (c < 4) {
                 cur_word |= (uint32_t)c << (2 * slot);
                 ++run_len;
@@ -197,7 +213,28 @@ struct Ingest {
                 a->h_packed.push_back(cur_word);
                 cur_word = 0;
             }
+        };
+        size_t i = 0;
+        while (i < n && (fpos & 15)) one(s[i++]);
+        while (i + 16 <= n) {  // a whole packed word of valid bases at a time (no per-base branches)
+            uint32_t wd = 0, bad = 0;
+            for (unsigned j = 0; j < 16; ++j) {
+                const uint32_t c = lut[s[i + j]];
+                wd |= (c & 3u) << (2 * j);
+                bad |= c;
+            }
+            if (bad & 4u) {
+                for (unsigned j = 0; j < 16; ++j) one(s[i + j]);
+            } else {
+                a->h_packed.push_back(wd);
+                run_len += 16;
+                fpos += 16;
+            }
+            i += 16;
         }
+        while (i < n) one(s[i++]);
+        pending = 0;
+        if (!pending_keep) stage.clear();
     }
     int end_record()
     {
@@ -206,6 +243,7 @@ struct Ingest {
             if (collect_runs && run_len >= k) all_runs.back().emplace_back(rec_pos - run_len, run_len - k + 1);
             return MXG_OK;
         }
+        pack_pending();
         if (skip) {  // registered (global record index, id, length) but neither packed nor sketched here
             Record &r = a->recs.back();
             r.len = rec_pos;
