@@ -61,7 +61,8 @@ LENS = [30_000, 500, 260_000, 80_000, 31, 1_000, 150_000, 40, 90_000]
 
 
 @pytest.mark.parametrize("k,w,kw", [(32, 500, {}), (32, 50, {}), (15, 10, {}), (32, 500, {"variant": "v1"}),
-                                    (32, 300, {"cand_per_window": 2}), (32, 200, {"dense_only": True})])
+                                    (32, 300, {"cand_per_window": 2}), (32, 200, {"dense_only": True}),
+                                    (32, 400, {"drop_seq": True})])
 @pytest.mark.parametrize("n_shards", [2, 3, 7])
 def test_split_shards_concatenate_to_whole(tmp_path, k, w, kw, n_shards):
     fa = str(tmp_path / "g.fa")
@@ -149,3 +150,16 @@ def test_split_graph_of_exchanged_pieces_equals_whole(tmp_path):
     assert g1.keys() == g2.keys() and len(g1["vertex_hash"]) > 1000
     for key in g1:
         assert np.array_equal(g1[key], g2[key]), key
+
+
+def test_split_with_small_batches(tmp_path, monkeypatch):
+    """pieces and whole records spread over several sketch batches (the batch boundaries fall between contigs)"""
+    monkeypatch.setenv("MXG_SPARSE_BATCH_KMERS", "120000")
+    monkeypatch.setenv("MXG_DENSE_BATCH_KMERS", "50000")
+    fa = str(tmp_path / "g.fa")
+    _genome(fa, 13, LENS)
+    for kw in ({}, {"cand_per_window": 2}):
+        whole = _whole(fa, 32, 300, **kw)
+        got, _, _, _ = _pieces(fa, 32, 300, 5, **kw)
+        for key in whole:
+            assert np.array_equal(whole[key], got[key]), (kw, key)
