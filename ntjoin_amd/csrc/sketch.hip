@@ -642,19 +642,19 @@ __device__ __forceinline__ bool coop_right_blocked(const CoopCtx &q, uint32_t la
 
 constexpr int RH = 64;   // halo (candidates) staged on each side of a block's 256 candidates
 constexpr int RP = 4;    // padding entries so that 4-wide neighbour groups never index outside the arrays
+constexpr uint32_t RK = 256;  // candidates (= threads) per k_resolve block (measured: 128 -> 32.7 us, 256 -> 31.4, 512 -> 35.0)
 
 template <bool GAPS, bool COUNT, int ABL = 0>
-__global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
+__global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
 {
-    __shared__ uint64_t lh[256 + 2 * RH + 2 * RP];
-    __shared__ uint2 lkc[256 + 2 * RH + 2 * RP];  // {k-mer index, contig}; contig = ~0 outside the candidate array
-    constexpr uint32_t TOT = 256 + 2 * RH + 2 * RP;
-    static_assert(TOT <= 512, "two staged entries per thread");
-    const uint32_t i0 = blockIdx.x * 256u;
+    __shared__ uint64_t lh[RK + 2 * RH + 2 * RP];
+    __shared__ uint2 lkc[RK + 2 * RH + 2 * RP];  // {k-mer index, contig}; contig = ~0 outside the candidate array
+    constexpr uint32_t TOT = RK + 2 * RH + 2 * RP, NST = (TOT + RK - 1) / RK;  // staged entries (per thread)
+    const uint32_t i0 = blockIdx.x * RK;
     // Blocks that the previous run's count says will be in use request their entries before the candidate count has
     // arrived (the arrays hold n_cap entries; what lies beyond the count is masked below): one memory round trip for
     // the block instead of two.  The others (the grid covers n_cap, about twice the count) wait for it and mostly exit.
-    const bool early = i0 + 256u <= p.n_likely;  // (block-uniform)
+    const bool early = i0 + RK <= p.n_likely;  // (block-uniform)
     uint32_t n = 0, ovf = 0;
     if (!early) {
         n = min(*p.n_ptr, p.n_cap);
@@ -662,11 +662,11 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
         if (i0 >= n || ovf) return;
     }
     const uint32_t bound = early ? p.n_cap : n;
-    uint64_t vh[2];
-    uint32_t vk[2], vc[2];
+    uint64_t vh[NST];
+    uint32_t vk[NST], vc[NST];
 #pragma unroll
-    for (uint32_t r = 0; r < 2; ++r) {
-        const uint32_t e = threadIdx.x + 256u * r;
+    for (uint32_t r = 0; r < NST; ++r) {
+        const uint32_t e = threadIdx.x + RK * r;
         const int64_t g = (int64_t)i0 - RH - RP + e;
         vh[r] = 0; vk[r] = 0; vc[r] = 0;
         if (e < TOT && g >= 0 && g < (int64_t)bound) {
@@ -680,8 +680,8 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
         ovf = *p.ovf;
     }
 #pragma unroll
-    for (uint32_t r = 0; r < 2; ++r) {
-        const uint32_t e = threadIdx.x + 256u * r;
+    for (uint32_t r = 0; r < NST; ++r) {
+        const uint32_t e = threadIdx.x + RK * r;
         const int64_t g = (int64_t)i0 - RH - RP + e;
         if (e < TOT) {
             const bool in = g >= 0 && g < (int64_t)n;
@@ -883,10 +883,10 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     } else {
         __shared__ uint32_t sh_before;
         if (threadIdx.x < 64) {
-            const uint32_t bef = count_prefix(p.cnt256, p.sel_sup, blockIdx.x * (TILE / 256));
+            const uint32_t bef = count_prefix(p.cnt256, p.sel_sup, blockIdx.x * (TILE / RK));
             if (threadIdx.x == 0) sh_before = bef;
             if ((n - 1) / TILE == blockIdx.x) {  // the tile holding the last candidate also reports the total
-                const uint32_t all = count_prefix(p.cnt256, p.sel_sup, (n + 255u) / 256u);
+                const uint32_t all = count_prefix(p.cnt256, p.sel_sup, (n + RK - 1u) / RK);
                 if (threadIdx.x == 0) {
                     p.n_sel[0] = all;
                     p.n_sel[1] = 0;
@@ -1093,7 +1093,7 @@ struct Driver {
     uint32_t n_wave_sup = 0;
     uint32_t *wave_sup() { return sc(SC_CTRL).as<uint32_t>() + CTRL_WORDS; }
     uint32_t *sel_sup(uint32_t) { return wave_sup() + n_wave_sup; }
-    static uint32_t n_sel_sup(uint32_t n_cap) { return sup_words((n_cap + 255) / 256); }
+    static uint32_t n_sel_sup(uint32_t n_cap) { return sup_words((n_cap + RK - 1) / RK); }
 
     int ev_begin(uint64_t bases, bool is_hash)
     {
@@ -1135,7 +1135,7 @@ struct Driver {
     {
         if (!n_cap) return MXG_OK;
         MXG_HIP(h, sc(SC_SEL).ensure(std::max<uint32_t>(n_cap, 16)));
-        const uint32_t blocks = (n_cap + 255) / 256;
+        const uint32_t blocks = (n_cap + RK - 1) / RK;
         MXG_HIP(h, sc(SC_CNT256).ensure((size_t)blocks * 4 + 64));
         uint32_t *ctrl = sc(SC_CTRL).as<uint32_t>();
         ResolveParams rp;
@@ -1161,13 +1161,13 @@ struct Driver {
         rp.n_likely = std::min(n_likely, n_cap);
         static const int abl = getenv("MXG_ABLATE_RESOLVE") ? atoi(getenv("MXG_ABLATE_RESOLVE")) : 0;  // profiling only
         if (abl == 1)
-            hipLaunchKernelGGL((k_resolve<true, true, 1>), dim3(blocks), dim3(256), 0, st, rp);
+            hipLaunchKernelGGL((k_resolve<true, true, 1>), dim3(blocks), dim3(RK), 0, st, rp);
         else if (abl == 2)
-            hipLaunchKernelGGL((k_resolve<true, true, 2>), dim3(blocks), dim3(256), 0, st, rp);
+            hipLaunchKernelGGL((k_resolve<true, true, 2>), dim3(blocks), dim3(RK), 0, st, rp);
         else if (abl == 3)
-            hipLaunchKernelGGL((k_resolve<true, true, 3>), dim3(blocks), dim3(256), 0, st, rp);
+            hipLaunchKernelGGL((k_resolve<true, true, 3>), dim3(blocks), dim3(RK), 0, st, rp);
         else
-            hipLaunchKernelGGL((k_resolve<true, true>), dim3(blocks), dim3(256), 0, st, rp);
+            hipLaunchKernelGGL((k_resolve<true, true>), dim3(blocks), dim3(RK), 0, st, rp);
         MXG_HIP(h, hipGetLastError());
         return MXG_OK;
     }
@@ -1201,7 +1201,7 @@ struct Driver {
         rp.cnt256 = nullptr;
         rp.sel_sup = nullptr;
         if (n_cap) {
-            hipLaunchKernelGGL((k_resolve<GAPS, false>), dim3((n_cap + 255) / 256), dim3(256), 0, st, rp);
+            hipLaunchKernelGGL((k_resolve<GAPS, false>), dim3((n_cap + RK - 1) / RK), dim3(RK), 0, st, rp);
             hipLaunchKernelGGL(k_count_n, dim3(n_tiles), dim3(256), 0, st, rp.sel, rp.n_ptr, n_cap,
                                sc(SC_BSUM).as<uint32_t>());
         }
