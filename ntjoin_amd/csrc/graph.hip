@@ -312,10 +312,16 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
 }
 
 // k_flags for the partitioned join: the table state of minimizer i sits in recs[slot[a][i]]
-__global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, const uint4 *__restrict__ recs, uint32_t *cnt, uint32_t *sup)
+// (also clears this item's cells of the adjacency arrays nxt[A][nvs] | prv[A][nvs]: saves the fill launch)
+__global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, const uint4 *__restrict__ recs, uint32_t *cnt, uint32_t *sup,
+                                                  uint32_t *nxt, uint32_t nvs)
 {
     const uint32_t a = asm_of_block(p, blockIdx.x);
     const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
+    if (i < nvs) {
+        nxt[(size_t)a * nvs + i] = NONE32;
+        nxt[(size_t)(p.n_asm + a) * nvs + i] = NONE32;
+    }
     bool sh = false;
     if (i < asm_n(p, a)) {
         const uint32_t bit = 1u << a, full = p.full;
@@ -640,7 +646,9 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         hipLaunchKernelGGL(k_pj_bucket, dim3(n_rows), dim3(PJ_BT), (size_t)P * 8, h->stream, as_all, nb, P - 1, M, recs, fsup,
                            n_fsup + n_esup);
         hipLaunchKernelGGL(k_pj_join, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, hctl + CTL_PJ_FAIL, pj_force_fail);
-        hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, recs, cnt, fsup);
+        MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4 + 16));  // nxt[A][nvs] followed by prv[A][nvs], cleared by k_flags_pj
+        hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, recs, cnt, fsup, h->g_nxt.as<uint32_t>(),
+                           (uint32_t)nvs);
     } else if (nb && !resume) {
         hipLaunchKernelGGL(k_insert, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), mask, cap, fsup,
                            n_fsup + n_esup);
@@ -655,7 +663,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         MXG_HIP(h, h->g_fv.ensure(anv * 4));
         MXG_HIP(h, h->g_frec.ensure(anv * 4));
         MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4));  // nxt[A][nvs] followed by prv[A][nvs]: one fill
-        if (mode == GRAPH_FULL || mode == GRAPH_DG_EDGES) MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));
+        if ((mode == GRAPH_FULL && !pj) || mode == GRAPH_DG_EDGES) MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));
         uint32_t *const d_prv = h->g_nxt.as<uint32_t>() + anv;
         for (uint32_t a = 0; a < A && !resume; ++a) {  // assembly 0 assigns the vertex ids the others look up
             Assembly *as = h->asms[a];
