@@ -15,7 +15,7 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- eve
 rank, but only one collective: cheapest while a rank's share is small, as in configs[1]), or "partitioned": the graph
 stage distributed by hash range over RCCL all-to-alls (ntjoin_amd/dist.py, csrc/dgraph.hip), whose work per rank does
 not grow with N.  Measured on one GPU, M = minimizers per rank in millions (0.4 per 100 Mbp + 100 Mbp at w = 1000): the union
-path costs about 0.1 ms for the exchange + 0.11 ms x N x M for the graph of the union, the partitioned path about
+path costs about 0.04 ms for the exchange + 0.11 ms x N x M for the graph of the union, the partitioned path about
 0.5 ms + 0.25 ms x M.  Default: partitioned when M x (0.11 N - 0.25) > 0.5, i.e. never at N = 2, above ~650 Mbp per
 rank at N = 4 and above ~200 Mbp per rank at N = 8 (configs[1] runs the union path at every N <= 8);
 MXG_BENCH_GRAPH=union|partitioned overrides.
@@ -122,7 +122,7 @@ def main():
 
     from ntjoin_amd import synth
     from ntjoin_amd.engine import MxEngine
-    from ntjoin_amd.dist import allgather_union_graph, partitioned_graph, partitioned_totals
+    from ntjoin_amd.dist import partitioned_graph, partitioned_totals, sketch_union_graph
 
     n_bases = int(args.mbp * 1e6)
     ref, tgt = synth.config2(seed=1 + 100 * rank, n_bases=n_bases)
@@ -146,11 +146,13 @@ def main():
         if world == 1 and not force_dist and os.environ.get("MXG_BENCH_FUSED") == "1":
             eng.sketch_graph()  # sketches and graph stage in one call with one host sync (measured: no faster)
             return
+        if (world > 1 or force_dist) and graph_mode != "partitioned":
+            # sketch -> pack -> all-gather -> unpack -> graph of the union, one host sync per step in steady state
+            union = sketch_union_graph(eng, K, W, local_rank, union, stream=xstream)
+            return
         eng.sketch(-2)  # MXG_SKETCH_ALL: both assemblies enqueued back to back, one host sync
-        if (world > 1 or force_dist) and graph_mode == "partitioned":
+        if world > 1 or force_dist:
             union = partitioned_graph(eng, K, W, local_rank, union, stream=xstream)   # this rank's part of the graph
-        elif world > 1 or force_dist:
-            union = allgather_union_graph(eng, K, W, local_rank, union, stream=xstream)
         else:
             eng.build_graph()
 

@@ -225,6 +225,14 @@ int mxg_set_sketch_gathered_strided(mxg_handle *h, int assembly, const void *d_a
    for exchange + graph.  Returns 1 when some rank's header says "does not fit" (nothing usable: exchange sizes first,
    mxg_set_sketch_gathered), else as mxg_build_graph.  No counterpart in the reference (single process). */
 int mxg_xchg_pack(mxg_handle *h, void *d_slot, uint64_t head_bytes, const uint64_t *caps);
+/* mxg_sketch(h, MXG_SKETCH_ALL) + mxg_xchg_pack without the host sync in between: the sketches are enqueued, the packing
+   kernels follow them on the stream and read the counts on the device (a sketch that did not end the common way -- arena
+   overflow, candidate-free stretch, several batches -- or does not fit its slot travels as -1, so every rank falls back
+   together).  The handle must have been created on the caller's stream (mxg_config.stream).  After the caller's next
+   sync on that stream (mxg_xchg_unpack_graph on the union's handle does it), mxg_sketch_finish completes this handle's
+   sketches (those that travelled as -1 are redone the ordinary way); until then the handle has no sketches. */
+int mxg_sketch_pack(mxg_handle *h, void *d_slot, uint64_t head_bytes, const uint64_t *caps);
+int mxg_sketch_finish(mxg_handle *h);
 int mxg_xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t slot_bytes, uint64_t head_bytes,
                           const uint64_t *caps, const uint64_t *rec_offsets);
 /* indexlr TSV: `id \t out_hash[:pos][:+|-][:kmer] ( out_hash...)* \n`, one line per record, input order.

@@ -13,7 +13,7 @@ ABI_VERSION = 1
 
 SYMBOLS = [
     "mxg_abi_version", "mxg_create", "mxg_destroy", "mxg_last_error",
-    "mxg_add_assembly_fasta", "mxg_add_assembly_fasta_shard", "mxg_add_assembly_fasta_split", "mxg_assembly_continues", "mxg_xchg_pack", "mxg_xchg_unpack_graph", "mxg_shard_range", "mxg_assembly_shard",
+    "mxg_add_assembly_fasta", "mxg_add_assembly_fasta_shard", "mxg_add_assembly_fasta_split", "mxg_assembly_continues", "mxg_xchg_pack", "mxg_xchg_unpack_graph", "mxg_sketch_pack", "mxg_sketch_finish", "mxg_shard_range", "mxg_assembly_shard",
     "mxg_add_assembly_buffers", "mxg_add_assembly_packed_device",
     "mxg_add_assembly_tsv", "mxg_add_assembly_bin", "mxg_write_sketch_bin", "mxg_add_assembly_minimizers", "mxg_num_assemblies", "mxg_assembly_name",
     "mxg_record_id", "mxg_record_length", "mxg_num_records", "mxg_assembly_weight",
@@ -117,6 +117,8 @@ def load():
     L.mxg_add_assembly_fasta_split.argtypes = [vp, cp, C.c_double, cp, C.c_uint32, C.c_uint32]
     L.mxg_assembly_continues.argtypes = [vp, i32]
     L.mxg_xchg_pack.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.mxg_sketch_pack.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.mxg_sketch_finish.argtypes = [vp]
     L.mxg_xchg_unpack_graph.argtypes = [vp, vp, C.c_uint32, u64, u64, C.POINTER(u64), C.POINTER(u64)]
     L.mxg_shard_range.argtypes = [C.POINTER(u64), u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
     L.mxg_assembly_shard.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(u64)]

@@ -184,6 +184,8 @@ struct mxg_handle {
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
     // scratch reused across calls
     mxg::DevBuf scratch[2][40];  // two sets, indexed by mxg::Scratch (sketch.hip): one per in-flight sketch driver
+    std::vector<mxg::Assembly *> pend_list;  // mxg_sketch_pack in flight: assemblies and how each was enqueued
+    std::vector<int> pend_state;
     mxg::DevBuf g_part;     // partitioned join (graph.hip): partition offsets of every bucketing block
     mxg::DevBuf g_keys, g_cnt, g_vid, g_ctl, g_vhash, g_vpos, g_vrec, g_fv, g_frec, g_nxt, g_prv, g_eflag,
         g_ebs, g_eu, g_ev, g_esup, g_ew;  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
@@ -236,7 +238,13 @@ void make_init_tab(uint32_t k, std::vector<uint4> &out);
 
 // sketch.hip
 int sketch_assembly(mxg_handle *h, Assembly *a);
-int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_graph = false);
+struct XchgPackReq {  // mxg_sketch_pack: where the sketches go once they exist (see xchg_pack for the slot layout)
+    void *d_slot;
+    uint64_t head_bytes;
+    const uint64_t *caps;
+};
+int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_graph = false, const XchgPackReq *xp = nullptr);
+int sketch_finish(mxg_handle *h);
 int sync_sketch_to_host(mxg_handle *h, Assembly *a);
 int write_sketch_bin(mxg_handle *h, Assembly *a, const char *path);  // host_io.cpp
 int load_sketch_bin(mxg_handle *h, Assembly *a, const char *path, std::vector<uint64_t> &hash, std::vector<uint32_t> &pos,

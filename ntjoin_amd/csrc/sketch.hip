@@ -1748,9 +1748,36 @@ int sketch_assembly(mxg_handle *h, Assembly *a)
 // on the device, so that the whole sketch + graph step has one host sync.  Needs the common case everywhere (every
 // assembly of the handle in one sparse batch, no candidate-free stretch, no arena overflow, sketches within their
 // bounds); otherwise the sketches are completed as usual and the graph stage runs afterwards in the ordinary way.
-int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_graph)
+// xchg_pack's kernel with everything read on the device: the sketch may still be in flight on the stream.  The header
+// says -1 (the caller exchanges sizes first) unless the batch ended the common way -- no arena overflow, no
+// candidate-free stretch, at least one candidate -- and the sketch fits the slot and the output arrays.
+__global__ __launch_bounds__(256) void k_pack_slot_dev(const uint64_t *__restrict__ hash, const uint32_t *__restrict__ pos,
+                                                       const uint32_t *__restrict__ rec, const uint32_t *__restrict__ n_ptr,
+                                                       const uint32_t *__restrict__ ctrl, uint64_t out_cap, uint64_t cap,
+                                                       long long fixed, long long *header, unsigned char *__restrict__ region)
 {
-    if (n == 1 && !fuse_graph) return sketch_assembly(h, list[0]);
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (fixed != -2) {  // the host already knows: empty assembly (0) or not through the one-batch pipeline (-1)
+        if (i == 0) *header = fixed;
+        return;
+    }
+    const uint64_t n = *n_ptr;
+    const bool ok = ctrl[0] == 0 && ctrl[1] == 0 && (ctrl[4] | ctrl[5]) != 0 && n <= cap && n <= out_cap;
+    if (i == 0) *header = ok ? (long long)n : -1ll;
+    if (!ok || i >= n) return;
+    reinterpret_cast<uint64_t *>(region)[i] = hash[i];
+    reinterpret_cast<uint32_t *>(region + 8 * cap)[i] = pos[i];
+    reinterpret_cast<uint32_t *>(region + 12 * cap)[i] = rec[i];
+}
+
+int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_graph, const XchgPackReq *xp)
+{
+    if (n == 1 && !fuse_graph && !xp) return sketch_assembly(h, list[0]);
+    if (xp) {
+        bool same = n == h->asms.size() && n <= MXG_MAX_ASSEMBLIES;
+        for (size_t i = 0; same && i < n; ++i) same = list[i] == h->asms[i];
+        if (!same || fuse_graph) return set_err(h, MXG_EINVAL, "mxg_sketch_pack: every assembly of the handle must have bases");
+    }
     MXG_HIP(h, hipSetDevice(h->device));
     if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, (MXG_MAX_ASSEMBLIES + 1) * 32));
     double frac;
@@ -1784,7 +1811,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         OutArrays out{&list[i]->d_hash, &list[i]->d_pos, &list[i]->d_rec, &list[i]->d_fwd, 0};
         uint32_t *slot = h->pinned_ctrl + 8 * i;
         memset(slot, 0xFF, 32);
-        if (fuse_graph) {
+        if (fuse_graph || xp) {
             MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
             drv.n_out = h->d_nmx.as<uint32_t>() + i;
         }
@@ -1795,6 +1822,31 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         slot_of[i] = (int)(n_enq & 1);
         last_on_slot[n_enq & 1] = i;
         ++n_enq;
+    }
+    if (xp) {
+        // the second stream joins the first; the pack kernels follow the sketches on it and read the counts there.  No
+        // host sync: mxg_sketch_finish completes the bookkeeping after the caller's next sync on this stream.
+        if (!h->ev_join) MXG_HIP(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        MXG_HIP(h, hipEventRecord(h->ev_join, h->stream2));
+        MXG_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        unsigned char *base = static_cast<unsigned char *>(xp->d_slot);
+        uint64_t off = xp->head_bytes;
+        for (size_t i = 0; i < n; ++i) {
+            Assembly *a = list[i];
+            const uint64_t cap = xp->caps[i];
+            const uint64_t out_cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
+            const long long fixed = state[i] == 1 ? -2ll : (state[i] == 2 ? 0ll : -1ll);
+            const uint32_t grid = state[i] == 1 ? (uint32_t)std::max<uint64_t>((cap + 255) / 256, 1) : 1u;
+            hipLaunchKernelGGL(k_pack_slot_dev, dim3(grid), dim3(256), 0, h->stream, a->d_hash.as<uint64_t>(),
+                               a->d_pos.as<uint32_t>(), a->d_rec.as<uint32_t>(), h->d_nmx.as<uint32_t>() + i,
+                               drvs[slot_of[i]]->sc(SC_CTRL).as<uint32_t>(), out_cap, cap, fixed,
+                               reinterpret_cast<long long *>(base) + i, base + off);
+            off += 16 * cap;
+        }
+        MXG_HIP(h, hipGetLastError());
+        h->pend_list.assign(list, list + n);
+        h->pend_state = state;
+        return MXG_OK;
     }
     bool fused = false;
     size_t n_fast = 0;  // assemblies whose speculative emit stood as it was (no stretch, no overflow, within capacity)
@@ -1859,6 +1911,41 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         return build_graph(h);
     }
     return MXG_OK;
+}
+
+// second half of mxg_sketch_pack: after the stream has drained (the caller's sync on it), accept the sketches that ended
+// the common way and redo the others through the synchronous path
+int sketch_finish(mxg_handle *h)
+{
+    if (h->pend_list.empty()) return MXG_OK;
+    MXG_HIP(h, hipSetDevice(h->device));
+    MXG_HIP(h, stream_wait(h->stream));
+    MXG_HIP(h, stream_wait(h->stream2));
+    std::vector<Assembly *> list;
+    std::vector<int> state;
+    list.swap(h->pend_list);
+    state.swap(h->pend_state);
+    int rc;
+    for (size_t i = 0; i < list.size(); ++i) {
+        Assembly *a = list[i];
+        if (state[i] == 1) {
+            const uint32_t *c = h->pinned_ctrl + 8 * i;
+            const uint64_t total = (uint64_t)c[2] | ((uint64_t)c[3] << 32), n_cand = (uint64_t)c[4] | ((uint64_t)c[5] << 32);
+            const uint64_t cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
+            if (c[0] == 0 && c[1] == 0 && n_cand > 0 && total <= cap) {
+                a->n_mx = total;
+                a->has_sketch = true;
+                h->stat_candidates += n_cand;
+                a->cand_hint = (uint32_t)std::min<uint64_t>(n_cand, 0xFFFFFFFFull);
+                continue;
+            }
+        } else if (state[i] == 2) {
+            continue;  // (empty: prepare_sketch left it complete)
+        }
+        if ((rc = sketch_assembly(h, a)) != MXG_OK) return rc;
+    }
+    Driver drv(h);
+    return drv.collect();
 }
 
 int flush_timers(mxg_handle *h)

@@ -173,6 +173,27 @@ def _allgather_union_graph(eng, k, w, device, union, group, stream):
     return union
 
 
+def sketch_union_graph(eng, k, w, device, union=None, group=None, stream=None):
+    """One step of the union path: sketch this rank's assemblies, exchange, graph of the union.  In steady state (fixed
+    slots known, `eng` and `union` on `stream`) nothing waits for the host between the first sketch kernel and the last
+    graph kernel: the sketches are enqueued, the packing kernels follow them and read the counts on the device
+    (mxg_sketch_pack), then ONE all-gather, then mxg_xchg_unpack_graph, whose sync is the step's only one."""
+    if stream is not None and union is not None and getattr(union, "_slots", None) is not None:
+        sl = union._slots
+        with torch.cuda.stream(stream):
+            eng.sketch_pack(sl["send"].data_ptr(), sl["head"], sl["caps"])
+            dist.all_gather_into_tensor(sl["recv"], sl["send"], group=group)
+            ok = union.xchg_unpack_graph(sl["recv"].data_ptr(), dist.get_world_size(group), sl["slot"], sl["head"], sl["caps"],
+                                         sl["rec_off_flat"])
+        eng.sketch_finish()
+        if ok:
+            return union
+        union._slots = None              # some rank's sketch travelled as -1: sizes first (the sketches are complete now)
+    else:
+        eng.sketch(-2)
+    return allgather_union_graph(eng, k, w, device, union, group=group, stream=stream)
+
+
 def _exchange_one_gather(eng, union, A, world, dev, group, stream):
     """steady-state exchange + graph of the union: pack (library, counts written by the kernels) -> ONE all-gather ->
     unpack with the counts read from the headers on the device + graph stage, one host sync in all (mxg_xchg_*).

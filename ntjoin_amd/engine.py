@@ -101,6 +101,15 @@ class MxEngine:
         return self._check(self._lib.mxg_xchg_pack(self._h, C.c_void_p(int(d_slot)), int(head_bytes),
                                                    cc.ctypes.data_as(C.POINTER(C.c_uint64))))
 
+    def sketch_pack(self, d_slot, head_bytes, caps):
+        """sketch every assembly and pack the sketches into the exchange slot without a host sync (finish with sketch_finish)"""
+        cc = np.ascontiguousarray(caps, dtype=np.uint64)
+        return self._check(self._lib.mxg_sketch_pack(self._h, C.c_void_p(int(d_slot)), int(head_bytes),
+                                                     cc.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+    def sketch_finish(self):
+        return self._check(self._lib.mxg_sketch_finish(self._h))
+
     def xchg_unpack_graph(self, d_all, world, slot_bytes, head_bytes, caps, rec_offsets):
         """-> False when some rank's sketch did not fit its slot (nothing usable), True: sketches unpacked + graph built"""
         cc = np.ascontiguousarray(caps, dtype=np.uint64)

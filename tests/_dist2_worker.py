@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ntjoin_amd.dist import allgather_union_graph, partitioned_graph, partitioned_totals  # noqa: E402
+from ntjoin_amd.dist import allgather_union_graph, partitioned_graph, partitioned_totals, sketch_union_graph  # noqa: E402
 from ntjoin_amd.engine import MxEngine  # noqa: E402
 
 
@@ -46,8 +46,12 @@ def main():
         eng.add_records(name, wt, part)
     union = None
     for _step in range(3):                      # later steps reuse the union handle and its fixed-capacity slots
-        eng.sketch(-2)
-        union = allgather_union_graph(eng, k, w, 0, union, stream=xs)
+        if _step == 1:
+            eng.sketch(-2)                      # the two-call form ...
+            union = allgather_union_graph(eng, k, w, 0, union, stream=xs)
+        else:                                   # ... and the one-call form (no host sync between sketch and exchange when on a stream)
+            union = sketch_union_graph(eng, k, w, 0, union, stream=xs)
+    assert all(eng.sketch_size(a) > 0 for a in range(len(asms)))
     # the same graph, distributed by hash range: every rank ends up with its own vertices and edges
     owner = None
     for _step in range(3):                       # exact exchange, then twice with the fixed-capacity slots
