@@ -1804,7 +1804,13 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             continue;
         }
         if (!sparse || i >= MXG_MAX_ASSEMBLIES) continue;
-        Driver &drv = *drvs[n_enq & 1];
+        // the LAST assembly goes to driver 0 = the handle's main stream: whatever follows the sketches on that stream
+        // (graph stage of mxg_sketch_graph, packing kernels of mxg_sketch_pack) then waits for the other stream's chain,
+        // which has finished earlier, instead of for an event that is still in the future (~20 us of signal latency)
+        // (measured: 1 % on the two-call step, 4 % on mxg_sketch_graph; on a caller's stream, whose partner is the
+        // high-priority second stream, the plain order is 3 % better)
+        const size_t sl = h->own_stream ? ((n - 1 - i) & 1) : (i & 1);
+        Driver &drv = *drvs[sl];
         Driver::BatchGeom &g = geoms[i];
         drv.batch_geom(tabs[i], 0, g);
         if (g.c1 != tabs[i].ctg_rec->size()) continue;  // more than one batch: synchronous path
@@ -1819,8 +1825,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                                      &ncap[i])) != MXG_OK)
             return rc;
         state[i] = 1;
-        slot_of[i] = (int)(n_enq & 1);
-        last_on_slot[n_enq & 1] = i;
+        slot_of[i] = (int)sl;
+        last_on_slot[sl] = i;
         ++n_enq;
     }
     if (xp) {
