@@ -38,7 +38,8 @@ def main():
     asms = [("refA", 2.0, records(1, 9)), ("refB", 1.5, records(2, 7)), ("tgt", 1.0, records(3, 11))]
     use_stream = os.environ.get("MXG_TEST_STREAM") == "1"
     xs = torch.cuda.Stream() if use_stream else None
-    eng = MxEngine(k=k, w=w, device=0, stream=xs.cuda_stream if xs is not None else None)
+    kw = {"cand_per_window": int(os.environ["MXG_TEST_CAND"])} if os.environ.get("MXG_TEST_CAND") else {}
+    eng = MxEngine(k=k, w=w, device=0, stream=xs.cuda_stream if xs is not None else None, **kw)
     mine = []
     for name, wt, recs in asms:
         part = [r for i, r in enumerate(recs) if i * world // len(recs) == rank]   # contiguous slices, rank order

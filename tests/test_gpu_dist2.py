@@ -34,6 +34,19 @@ def test_union_graph_world_size(world, stream, slot_pct):
     assert out.stdout.count("DIST2 OK") == world, out.stdout[-3000:]
 
 
+@pytest.mark.parametrize("knob", [{"MXG_TEST_CAND": "2"}, {"MXG_WAVE_CAP": "8"}])
+def test_union_step_when_sketches_leave_the_common_case(knob):
+    """mxg_sketch_pack with sketches that do not end the common way on the device -- candidate-free stretches everywhere
+    (2 candidates per window) / every wave overflowing its arena slice: their slots travel as -1, every rank falls back
+    to the size exchange, mxg_sketch_finish redoes them through the general path; same graph as a single handle"""
+    env = dict(os.environ, MXG_TEST_STREAM="1", **knob)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "tests", "_dist2_worker.py")]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("DIST2 OK") == 2, out.stdout[-3000:]
+
+
 @pytest.mark.parametrize("mode", ["union", "partitioned"])
 def test_bench_two_ranks_on_one_gpu(mode):
     """bench.py's N>1 branch end to end (launch line of the driver, two ranks, gloo instead of RCCL): one JSON line,
