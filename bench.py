@@ -16,8 +16,8 @@ rank, but only one collective: cheapest while a rank's share is small, as in con
 stage distributed by hash range over RCCL all-to-alls (ntjoin_amd/dist.py, csrc/dgraph.hip), whose work per rank does
 not grow with N.  Measured on one GPU (world = 1 over RCCL), M = minimizers per rank in millions (0.4 per 100 Mbp + 100 Mbp
 at w = 1000): the union path costs about 0.04 ms for the exchange + 0.14 ms x N x M for unpacking and the graph of the
-union, the partitioned path about 0.46 ms + 0.2 ms x M.  Default: partitioned when M x (0.14 N - 0.2) > 0.46, i.e.
-above ~1.4 Gbp per rank at N = 2, ~320 Mbp per rank at N = 4 and ~125 Mbp per rank at N = 8 (configs[1] runs the union path
+union, the partitioned path about 0.39 ms + 0.2 ms x M.  Default: partitioned when M x (0.14 N - 0.2) > 0.39, i.e.
+above ~1.2 Gbp per rank at N = 2, ~270 Mbp per rank at N = 4 and ~105 Mbp per rank at N = 8 (configs[1] runs the union path
 at every N <= 8);
 MXG_BENCH_GRAPH=union|partitioned overrides.
 """
@@ -140,7 +140,7 @@ def main():
         eng.add_packed_device(name, weight, d.data_ptr(), starts, lens)
     union = None
     m_rank = 4e-3 * args.mbp * 1000.0 / W  # minimizers per rank, millions (both assemblies, density 2/(w+1))
-    graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("partitioned" if m_rank * (0.14 * world - 0.2) > 0.46 else "union")
+    graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("partitioned" if m_rank * (0.14 * world - 0.2) > 0.39 else "union")
 
     def step():
         nonlocal union
