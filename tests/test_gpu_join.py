@@ -109,3 +109,30 @@ def test_joins_agree_on_synthetic_genome(monkeypatch):
             return st2
     g = _three_ways(monkeypatch, build)
     assert len(g["flags0"]) > 50000
+
+
+def test_joins_agree_beyond_256_regions(monkeypatch):
+    """1.5 million minimizers: more than 256 bucketing regions, so k_pj_join lays its segments out in several rounds"""
+    from ntjoin_amd.engine import MxEngine
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 2**63, size=760_000, dtype=np.int64).astype(np.uint64)
+
+    def mk(seed, drop):
+        r = np.random.default_rng(seed)
+        hs = base[r.random(base.size) >= drop].copy()
+        r.shuffle(hs)
+        hs = np.concatenate([hs, np.repeat(hs[:2], 1500)])
+        rec = np.sort(r.integers(0, 64, size=hs.size)).astype(np.uint32)
+        pos = np.arange(hs.size, dtype=np.uint32)
+        return hs, pos, rec, [f"c{i}" for i in range(64)]
+
+    sets = [mk(1, 0.01), mk(2, 0.03)]
+
+    def build():
+        with MxEngine(k=32, w=1000) as eng:
+            for i, (hs, pos, rec, ids) in enumerate(sets):
+                eng.add_minimizers(f"a{i}", float(i + 1), hs, pos, rec, ids)
+            eng.build_graph()
+            assert eng.stats()["vertices"] > 700_000
+            return _graph_state(eng, len(sets))
+    _three_ways(monkeypatch, build)
