@@ -1,29 +1,33 @@
 #!/usr/bin/env python3
 """
-bench.py -- headline benchmark of the hot path on MI355X (contract: see the task statement / DESIGN.md).
+bench.py -- headline benchmark of the hot path on MI355X (contract: the task statement; numbers explained in DESIGN.md 6).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--mbp M]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|configs1|configs2|configs3|configs4] [--mbp M]
 
-One STEP = one pass of the whole hot path over one batch of synthetic input already resident in HBM:
-sketch every assembly (ntHash + window arg-min) -> uniqueness -> intersection -> adjacency edges, results
-handed back through the C-ABI.  Workload = BASELINE.json configs[1]: 1 x 100 Mbp reference (weight 2) +
-a target derived from it (weight 1), k=32, w=1000.  metric = Gbp/s = (sum of bases over all assemblies) / time.
+One STEP = one pass of the whole hot path over one batch of synthetic input already resident in HBM (2-bit packed bases,
+produced on the device by the counter-based generator of ntjoin_amd/csrc/synth.hip): sketch every assembly (ntHash +
+window arg-min) -> uniqueness -> intersection -> adjacency edges, results handed back through the C-ABI.
+metric = Gbp/s = (sum of bases over all assemblies) / time  (device-resident).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank sketches its own
-100 Mbp + 100 Mbp shard of an N-times larger genome; then the graph of the WHOLE genome is built, either
-"union": one RCCL all-gather of the sketches and every rank builds the whole graph (N times the graph work on every
-rank, but only one collective: cheapest while a rank's share is small, as in configs[1]), or "partitioned": the graph
-stage distributed by hash range over RCCL all-to-alls (ntjoin_amd/dist.py, csrc/dgraph.hip), whose work per rank does
-not grow with N.  Measured on one GPU (world = 1 over RCCL), M = minimizers per rank in millions (0.4 per 100 Mbp + 100 Mbp
-at w = 1000): the union path costs about 0.04 ms for the exchange + 0.14 ms x N x M for unpacking and the graph of the
-union, the partitioned path about 0.39 ms + 0.2 ms x M.  Default: partitioned when M x (0.14 N - 0.2) > 0.39, i.e.
-above ~1.2 Gbp per rank at N = 2, ~270 Mbp per rank at N = 4 and ~105 Mbp per rank at N = 8 (configs[1] runs the union path
-at every N <= 8);
-MXG_BENCH_GRAPH=union|partitioned overrides.
+Workloads (BASELINE.json configs; `auto` = the config the metric names for this GPU count):
+  N=1  configs[2]  24 reference records of 60-220 Mbp totalling 3.0 Gbp (weight 2) + a ~3.0 Gbp target of ~26 k contigs
+                   derived from it (cut, half reverse-complemented, 0.5 % substitutions, 20-500 bp dropped, shuffled;
+                   weight 1), k=32 w=1000                                    [--workload configs1 / --mbp M: 1 x M Mbp + target]
+  N>1  see main(): contig-sharded over the ranks, one RCCL exchange per step (ntjoin_amd/dist.py)
+
+Beside the contract's fields the JSON line carries
+  roofline      the dominant kernel (k_hash_sparse) against the HBM roof: algorithmic bytes = 0.25 B/bp, time = HIP events
+                recorded by the library on ITS launch stream around every launch of the timed region (live)
+  step_roofline the whole step's algorithmic bytes (0.25 L + 70 M) over the step time
+  kernels       per-kernel GPU time of a step, measured in a second, shorter pass with one HIP-event pair per kernel
+  cpu_baseline  the oracle's `indexlr -t nproc` + graph stage in C on the host cores, on a stated sample of the workload
+  end_to_end    FASTA files (page cache) -> .tsv + .mx.dot on disk through the CLI a ntJoin user runs (never `value`)
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -33,57 +37,112 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-K, W = 32, 1000
+K = 32
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
-ALG_BYTES_PER_BASE_HASH = 0.25  # hash kernel: one 2-bit packed base read per base
+ALG_BYTES_PER_BASE_HASH = 0.25   # hash kernel: one 2-bit packed base read per base
+ALG_BYTES_PER_MINIMIZER = 70.0   # whole path: sketch tuple + uniqueness + intersection + edge build
 
 
-def valu_info(st):
-    """integer-VALU view of the hash kernel: instructions per base and issue utilisation from the committed PMC summary
-    (profiles/hash_kernel_pmc.json, tools/pmc_bench.sh), rate from this run's HIP-event time"""
-    path = os.path.join(REPO, "profiles", "hash_kernel_pmc.json")
+def cpu_model():
     try:
-        pmc = json.load(open(path))
-    except Exception:
-        return None
-    per_base = pmc["valu_per_base"]
-    return {"wave64_instr_per_base": round(per_base, 2),
-            "int_lane_ops_per_s": round(per_base * st["hash_kernel_bases"] / max(st["ms_hash"], 1e-9) * 1e3, 0),
-            "peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,  # 1024 SIMD16 units: one wave64 VALU instruction per 4 cycles
-            "valu_busy_pmc": round(pmc["valu_busy"], 3),
-            "source": "rocprofv3 SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE, profiles/hash_kernel_pmc.json"}
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(ref, tgt):
-    """The oracle (scalar C port of indexlr + Python port of the graph stage) on the SAME workload, 1 core.
-    Checker/baseline only: nothing here is on the product path."""
+def n_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def workload_tables(name, mbp, w, seed=1):
+    """segment tables of the assemblies of a workload: list of (assembly name, weight, segs, n_words, sub_per_65536)"""
     from ntjoin_amd import synth
-    from oracle import graph_oracle
+    if name == "configs1":
+        cfg = synth.genome_config(int(mbp * 1e6), 1, seed=seed)
+        label = f"configs[1]: synthetic 1x{mbp:g} Mbp reference + derived target, k=32 w={w}, weights 2/1"
+    elif name == "configs2":
+        cfg = synth.genome_config(int(mbp * 1e6), 24, seed=seed, min_len=3000, max_len=600_000)
+        label = (f"configs[2]: synthetic human-scale {mbp / 1000:g} Gbp reference (24 records) + derived ~{mbp / 1000:g} Gbp "
+                 f"target, k=32 w={w}, weights 2/1")
+    else:
+        raise ValueError(name)
+    asms = [(f"ref.fa.k{K}.w{w}.tsv", 2.0, cfg["ref_segs"], cfg["ref_words"], 0),
+            (f"tgt.fa.k{K}.w{w}.tsv", 1.0, cfg["tgt_segs"], cfg["tgt_words"], synth.SUB_PER_65536)]
+    return cfg, asms, label
+
+
+def cpu_baseline(asms_host, w, budget_s):
+    """The oracle (checker / reported baseline only: nothing here is on the product path): the C restatement of
+    `indexlr -t nproc` (chunked records, one worker per core) + the C restatement of read_minimizers' uniqueness,
+    filter_minimizers and build_graph, on a sample of the workload sized for ~budget_s seconds of wall time."""
     from tests import _oracle
     orc = _oracle.load()
-    warm = synth.to_ascii(ref[0][:2_000_000])
-    orc.sketch(warm, K, W)  # fault the allocator's pages in once
+    cores = n_cores()
+    # calibrate on ~16 Mbp per core, then size the sample
+    words0, starts0, lens0 = asms_host[0]
+    cal_len = int(min(int(lens0[0]), 4_000_000 * cores))
     t0 = time.perf_counter()
-    sketches = []
-    for recs in (ref, tgt):
-        out = []
-        for codes in recs:
-            out.append(orc.sketch(synth.to_ascii(codes), K, W))
-        sketches.append(out)
+    orc.sketch_packed_mt(words0, starts0[:1], np.array([cal_len], dtype=np.uint64), K, w, threads=cores, chunk_kmers=1 << 20)
+    rate = cal_len / max(time.perf_counter() - t0, 1e-6)  # bases per second, all cores
+    total = sum(int(l.sum()) for _, _, l in asms_host)
+    frac = min(1.0, rate * budget_s / total)
+    sample, bases = [], 0
+    for words, starts, lens in asms_host:
+        csum = np.cumsum(lens.astype(np.int64))
+        n = int(np.searchsorted(csum, frac * csum[-1], side="left")) + 1
+        n = min(max(n, 1), len(lens))
+        sample.append((words, starts[:n], lens[:n]))
+        bases += int(lens[:n].sum())
+    t0 = time.perf_counter()
+    sk = [orc.sketch_packed_mt(wd, st, ln, K, w, threads=cores, chunk_kmers=1 << 20) for wd, st, ln in sample]
     t_sketch = time.perf_counter() - t0
-    with tempfile.TemporaryDirectory() as td:
-        names = [os.path.join(td, "ref.k32.w1000.tsv"), os.path.join(td, "tgt.k32.w1000.tsv")]
-        for path, out in zip(names, sketches):
-            with open(path, "w", encoding="ascii") as fh:
-                for r, mxs in enumerate(out):
-                    fh.write(f"{r}\t" + " ".join(f"{h}:{p}:N" for h, p, _, _ in mxs) + "\n")
-        t1 = time.perf_counter()
-        state = graph_oracle.load_and_build([names[0]], [2.0], names[1], 1.0)
-        t_graph = time.perf_counter() - t1
-    bases = sum(len(c) for c in ref) + sum(len(c) for c in tgt)
-    n_mx = sum(len(m) for out in sketches for m in out)
-    return {"seconds": t_sketch + t_graph, "t_sketch": t_sketch, "t_graph": t_graph, "bases": bases,
-            "minimizers": n_mx, "vertices": len(state["vertices"]), "edges": len(state["edges"])}
+    t1 = time.perf_counter()
+    g = orc.graph([s[0] for s in sk], [s[2] for s in sk], [2.0, 1.0][:len(sk)] if len(sk) == 2 else [1.0] * len(sk))
+    t_graph = time.perf_counter() - t1
+    return {"bases": bases, "seconds": t_sketch + t_graph, "t_sketch": t_sketch, "t_graph": t_graph, "cores": cores,
+            "minimizers": int(sum(len(s[0]) for s in sk)), "vertices": g["vertices"], "edges": g["edges"], "frac": frac,
+            "records": [len(s[1]) for s in sample]}
+
+
+def end_to_end(asms_host, w, td, threads):
+    """FASTA files in the page cache -> .tsv + .mx.dot on disk, through what a user of ntJoin:204-205 runs: the native
+    `indexlr` CLI per assembly (cold process, HIP init included), then `python -m ntjoin_amd.run` (TSVs -> .mx.dot)."""
+    from ntjoin_amd import capi
+    lib = capi.load()
+    fas, sizes = [], 0
+    for i, (words, starts, lens) in enumerate(asms_host):
+        fa = os.path.join(td, ("ref.fa", "tgt.fa")[i] if len(asms_host) == 2 else f"asm{i}.fa")
+        rc = lib.mxg_synth_write_fasta(fa.encode(), words.ctypes.data, np.ascontiguousarray(starts, dtype=np.uint64).ctypes.data,
+                                       np.ascontiguousarray(lens, dtype=np.uint64).ctypes.data, len(lens), b"s", 80, max(threads, 1))
+        if rc != 0:
+            raise RuntimeError(f"mxg_synth_write_fasta failed ({rc})")
+        fas.append(fa)
+        sizes += os.path.getsize(fa)
+    for fa in fas:  # make sure the text is in the page cache (it was just written; read it once anyway)
+        with open(fa, "rb") as fh:
+            while fh.read(1 << 26):
+                pass
+    exe = os.path.join(REPO, "ntjoin_amd", "bin", "indexlr")
+    tsvs = [f"{fa}.k{K}.w{w}.tsv" for fa in fas]
+    t0 = time.perf_counter()
+    for fa, tsv in zip(fas, tsvs):
+        subprocess.check_call([exe, "--seq", "--long", "--pos", f"-k{K}", f"-w{w}", f"-t{threads}", "-o", tsv, fa])
+    t_sketch = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    subprocess.check_call([sys.executable, "-m", "ntjoin_amd.run", "-p", os.path.join(td, "out"), "-n", "1", "-s", tsvs[-1], "-l", "1",
+                           "-r", " ".join(["2"] * (len(tsvs) - 1)), "-k", str(K)] + tsvs[:-1], env=env, stdout=subprocess.DEVNULL)
+    t_graph = time.perf_counter() - t1
+    bases = sum(int(l.sum()) for _, _, l in asms_host)
+    return {"bases": bases, "fasta_bytes": sizes, "t_sketch_cli": t_sketch, "t_graph_cli": t_graph,
+            "tsv_bytes": sum(os.path.getsize(t) for t in tsvs), "dot_bytes": os.path.getsize(os.path.join(td, "out.mx.dot"))}
 
 
 def main():
@@ -91,8 +150,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mbp", type=float, default=100.0, help="reference size per rank in Mbp (configs[1]: 100)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "configs1", "configs2"])
+    ap.add_argument("--mbp", type=float, default=0.0, help="reference size in Mbp (default: 100 for configs1, 3000 for configs2)")
+    ap.add_argument("--w", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel breakdown pass")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall-time budget of the cpu_baseline sample")
+    ap.add_argument("--e2e-mbp", type=float, default=0.0, help="end-to-end sample: Mbp per assembly (0 = the whole workload)")
     ap.add_argument("--cand", type=int, default=0, help="candidates per window for the sparse path (0 = library default)")
     args = ap.parse_args()
 
@@ -111,7 +176,8 @@ def main():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     force_dist = os.environ.get("MXG_BENCH_FORCE_DIST") == "1"  # exercise the N>1 path with one rank (testing)
-    if world > 1 or force_dist:
+    multi = world > 1 or force_dist
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -125,37 +191,43 @@ def main():
     from ntjoin_amd.engine import MxEngine
     from ntjoin_amd.dist import partitioned_graph, partitioned_totals, sketch_union_graph
 
-    n_bases = int(args.mbp * 1e6)
-    ref, tgt = synth.config2(seed=1 + 100 * rank, n_bases=n_bases)
-    bases_rank = sum(len(c) for c in ref) + sum(len(c) for c in tgt)
-    keep = []
+    W = args.w
+    wl = args.workload
+    if wl == "auto":
+        wl = "configs2" if not multi else "configs1"
+    mbp = args.mbp or (100.0 if wl == "configs1" else 3000.0)
+    cfg, asms, label = workload_tables(wl, mbp, W, seed=1 + 100 * rank)
+    keep, host_layout = [], []
     # N > 1: the library works on the stream the collectives are issued on, so pack -> all-gather -> unpack need no host sync
-    xstream = torch.cuda.Stream() if (world > 1 or force_dist) else None
+    xstream = torch.cuda.Stream() if multi else None
     eng = MxEngine(k=K, w=W, device=local_rank, timing=True, cand_per_window=args.cand,
                    stream=xstream.cuda_stream if xstream is not None else None)
-    for name, weight, recs in (("ref.fa.k32.w1000.tsv", 2.0, ref), ("tgt.fa.k32.w1000.tsv", 1.0, tgt)):
-        words, starts, lens = synth.pack_records(recs)
-        d = torch.from_numpy(words.view(np.int32)).cuda()  # bases resident in HBM before the timed region
+    bases_rank = 0
+    for name, weight, segs, n_words, sub in asms:
+        d = synth.fill_device(segs, n_words, cfg["seed"], cfg["sub_seed"], sub, device=local_rank)  # bases born in HBM
         keep.append(d)
-        eng.add_packed_device(name, weight, d.data_ptr(), starts, lens)
+        eng.add_packed_device(name, weight, d.data_ptr(), segs[:, 0], segs[:, 2])
+        host_layout.append((d, segs[:, 0].copy(), segs[:, 2].copy()))
+        bases_rank += int(segs[:, 2].sum())
+    torch.cuda.synchronize()
     union = None
-    m_rank = 4e-3 * args.mbp * 1000.0 / W  # minimizers per rank, millions (both assemblies, density 2/(w+1))
+    m_rank = 4e-3 * mbp * 1000.0 / W  # minimizers per rank, millions (both assemblies, density 2/(w+1))
     graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("partitioned" if m_rank * (0.14 * world - 0.2) > 0.39 else "union")
 
-    def step():
+    def step(e=eng):
         nonlocal union
-        if world == 1 and not force_dist and os.environ.get("MXG_BENCH_FUSED") == "1":
-            eng.sketch_graph()  # sketches and graph stage in one call with one host sync (measured: no faster)
+        if not multi and os.environ.get("MXG_BENCH_FUSED") == "1":
+            e.sketch_graph()  # sketches and graph stage in one call with one host sync (measured: no faster)
             return
-        if (world > 1 or force_dist) and graph_mode != "partitioned":
+        if multi and graph_mode != "partitioned":
             # sketch -> pack -> all-gather -> unpack -> graph of the union, one host sync per step in steady state
-            union = sketch_union_graph(eng, K, W, local_rank, union, stream=xstream)
+            union = sketch_union_graph(e, K, W, local_rank, union, stream=xstream)
             return
-        eng.sketch(-2)  # MXG_SKETCH_ALL: both assemblies enqueued back to back, one host sync
-        if world > 1 or force_dist:
-            union = partitioned_graph(eng, K, W, local_rank, union, stream=xstream)   # this rank's part of the graph
+        e.sketch(-2)  # MXG_SKETCH_ALL: every assembly enqueued back to back
+        if multi:
+            union = partitioned_graph(e, K, W, local_rank, union, stream=xstream)   # this rank's part of the graph
         else:
-            eng.build_graph()
+            e.build_graph()
 
     def fence():
         torch.cuda.synchronize()
@@ -168,8 +240,11 @@ def main():
     eng.reset_timers()
     fence()
     t0 = time.perf_counter()
+    step_times = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
+        step_times.append(time.perf_counter() - ts)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -187,6 +262,7 @@ def main():
         gst.update(partitioned_totals(union))      # global vertex / edge counts (collectives: every rank calls)
     else:
         gst = (union.stats() if union is not None else st)
+    result_line = None
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = bases_total * args.steps / dt / 1e9
@@ -195,64 +271,107 @@ def main():
         avg_ms = st["ms_hash"] / launches
         bytes_per_launch = ALG_BYTES_PER_BASE_HASH * st["hash_kernel_bases"] / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        n_mx = int(st["minimizers"]) if not multi else int(gst.get("minimizers", st["minimizers"]))
+        step_alg_bytes = ALG_BYTES_PER_BASE_HASH * bases_total + ALG_BYTES_PER_MINIMIZER * float(st["minimizers"]) * (world if multi else 1)
+        step_gbs = step_alg_bytes / (ms_step * 1e-3) / 1e9
+        # PMC traffic of the hash kernel: only quoted when the committed counters were collected on THIS workload
+        traffic, traffic_src = None, None
+        tpath = os.path.join(REPO, "profiles", "r02_hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                # measured on the 100 Mbp launch of configs[1]; the kernel's traffic is linear in the bases of a launch
-                traffic = round(json.load(open(tpath)).get("k_hash_bytes_per_base") * st["hash_kernel_bases"] / launches)
+                tj = json.load(open(tpath))
+                if tj.get("workload") == wl and abs(tj.get("mbp", 0) - mbp) < 1e-9 and not multi:
+                    traffic = round(tj["k_hash_bytes_per_base"] * st["hash_kernel_bases"] / launches)
+                    traffic_src = "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload, profiles/r02_hbm_traffic.json"
             except Exception:
                 traffic = None
-        # the committed rocprofv3 kernel-trace summary of this same command, for comparison with the live HIP-event time
-        # (the events also wait while the other assembly's kernels hold the machine: two streams)
-        rocprof_ms = None
-        try:
-            import csv
-            with open(os.path.join(REPO, "profiles", "r01_bench_kernel_stats.csv"), newline="") as fh:
-                for row in csv.DictReader(fh):
-                    if "k_hash_sparse" in row["Name"]:
-                        rocprof_ms = round(float(row["AverageNs"]) / 1e6, 4)
-        except Exception:
-            rocprof_ms = None
         out = {
-            "metric": "Gbp/s minimizer-sketch+graph-build (k=32,w=1000)", "value": round(value, 4), "unit": "Gbp/s",
+            "metric": f"Gbp/s minimizer-sketch+graph-build (k=32,w={W})", "value": round(value, 4), "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: synthetic 1x{args.mbp:g} Mbp reference + derived target per GPU, "
-                                   "k=32 w=1000, weights 2/1, bases resident in HBM (2-bit packed)",
+            "config": {"workload": label + ", bases resident in HBM (2-bit packed, generated on the device)",
                        "k": K, "w": W, "bases_per_step": int(bases_total), "minimizers": int(st["minimizers"]),
                        "vertices": int(gst["vertices"]), "edges": int(gst["edges"]),
+                       "records": [int(len(a[2])) for a in asms],
                        "parallelism": ("1 GPU" if world == 1 else f"contig-sharded x{world}, " +
                                        ("graph stage partitioned by hash range (RCCL all-to-all)" if graph_mode == "partitioned"
                                         else "RCCL all-gather of sketches, graph of the union on every rank"))},
-            "roofline": {"bound": "hbm", "kernel": "k_hash (ntHash fwd/rc rolling + candidate filter)",
+            "step_ms_min_max": [round(min(step_times) * 1e3, 4), round(max(step_times) * 1e3, 4)],
+            "roofline": {"bound": "hbm", "kernel": "k_hash_sparse (ntHash fwd/rc rings + candidate filter)",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/hbm_traffic.json)",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_base": ALG_BYTES_PER_BASE_HASH, "alg_bytes_per_launch": int(bytes_per_launch),
-                         "avg_launch_ms": round(avg_ms, 4),
-                         "avg_launch_ms_rocprofv3": rocprof_ms if abs(args.mbp - 100.0) < 1e-9 else None,
-                         "launches": int(st["launches_hash"]),
-                         "bases_per_launch": int(st["hash_kernel_bases"] / launches)},
-            # the binding resource is integer VALU issue, not HBM: reported beside the HBM figure
-            "valu": valu_info(st),
+                         "avg_launch_ms": round(avg_ms, 4), "launches": int(st["launches_hash"]),
+                         "bases_per_launch": int(st["hash_kernel_bases"] / launches),
+                         "share_of_step_time": round(st["ms_hash"] / args.steps / ms_step, 4)},
+            "step_roofline": {"bound": "hbm", "alg_bytes_per_step": int(step_alg_bytes),
+                              "formula": "0.25 B x bases + 70 B x minimizers (SURVEY.md 8d)",
+                              "achieved": round(step_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(step_gbs / HBM_PEAK_GBS, 6)},
             "stage_ms_per_step": {"hash": round(st["ms_hash"] / args.steps, 4),
+                                  "behind_hash": round(st["ms_resolve"] / args.steps, 4),
                                   "graph": round(gst["ms_graph"] / args.steps, 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(ref, tgt)
+        if not multi and not args.no_kernels:
+            # per-kernel GPU time: a second handle on the same bases with one event pair per kernel (a few steps)
+            eng2 = MxEngine(k=K, w=W, device=local_rank, timing_fine=True, cand_per_window=args.cand)
+            for (name, weight, segs, _, _), d in zip(asms, keep):
+                eng2.add_packed_device(name, weight, d.data_ptr(), segs[:, 0], segs[:, 2])
+            nk = 3
+            step(eng2)
+            eng2.reset_timers()
+            for _ in range(nk):
+                step(eng2)
+            s2 = eng2.stats()
+            ker = {"k_hash_sparse": s2["ms_hash"] / nk, "k_reorder": s2["ms_reorder"] / nk, "k_resolve": s2["ms_resolve_kernel"] / nk,
+                   "k_emit": s2["ms_emit"] / nk, "join (k_pj_* / k_insert+k_flags)": s2["ms_join"] / nk,
+                   "k_vertices+k_adjacency": s2["ms_vertices"] / nk, "k_edge_flags+k_edges": s2["ms_edges"] / nk}
+            tot = sum(ker.values()) or 1.0
+            out["kernels"] = {"ms_per_step": {k_: round(v, 4) for k_, v in ker.items()},
+                              "share": {k_: round(v / tot, 4) for k_, v in ker.items()},
+                              "note": "HIP-event pair per kernel on a second handle (3 steps after the timed region); "
+                                      "spans of the two streams may overlap when the assemblies are pipelined"}
+            eng2.close()
+        asms_host = None
+        if not multi and not (args.no_cpu_baseline and args.no_end_to_end):
+            asms_host = [(d.cpu().numpy().view(np.uint32), st_, ln_) for d, st_, ln_ in host_layout]
+        if not multi and not args.no_cpu_baseline:
+            cb = cpu_baseline(asms_host, W, args.cpu_seconds)
             out["cpu_baseline"] = {
-                "value": round(cb["bases"] / cb["seconds"] / 1e9, 5), "unit": "Gbp/s", "cores": 1, "kind": "port",
-                "sample": f"the whole step workload ({cb['bases'] / 1e6:.0f} Mbp): scalar C port of indexlr "
-                          f"({cb['t_sketch']:.1f} s) + Python port of read/filter/build_graph ({cb['t_graph']:.1f} s)",
-            }
-            # same inputs -> same counts (full bit-exact parity lives in tests/)
-            out["parity_counts_match_cpu"] = bool(cb["minimizers"] == st["minimizers"] and
-                                                  cb["vertices"] == st["vertices"] and cb["edges"] == st["edges"])
+                "value": round(cb["bases"] / cb["seconds"] / 1e9, 5), "unit": "Gbp/s", "cores": cb["cores"], "kind": "port",
+                "cpu": cpu_model(),
+                "sample": f"first {cb['records'][0]} reference records + first {cb['records'][1]} target contigs "
+                          f"({cb['bases'] / 1e6:.0f} Mbp, {100 * cb['frac']:.0f} % of the step's workload): C restatement of "
+                          f"`indexlr -t {cb['cores']}` (records chunked, one worker per core: {cb['t_sketch']:.2f} s) + C restatement of "
+                          f"read_minimizers/filter_minimizers/build_graph on arrays, 1 thread like the reference ({cb['t_graph']:.2f} s)",
+                "seconds": round(cb["seconds"], 3)}
+            if cb["frac"] >= 1.0:  # whole workload: same inputs -> same counts (bit-exact parity lives in tests/)
+                out["parity_counts_match_cpu"] = bool(cb["minimizers"] == st["minimizers"] and
+                                                      cb["vertices"] == st["vertices"] and cb["edges"] == st["edges"])
+        if not multi and not args.no_end_to_end:
+            td = tempfile.mkdtemp(prefix="mxg_e2e_")
+            try:
+                sample = asms_host
+                if args.e2e_mbp > 0:
+                    sample = []
+                    for words, starts, lens in asms_host:
+                        csum = np.cumsum(lens.astype(np.int64))
+                        n = min(int(np.searchsorted(csum, args.e2e_mbp * 1e6, side="left")) + 1, len(lens))
+                        sample.append((words, starts[:n], lens[:n]))
+                e2e = end_to_end(sample, W, td, n_cores())
+                t_all = e2e["t_sketch_cli"] + e2e["t_graph_cli"]
+                out["end_to_end"] = {
+                    "value": round(e2e["bases"] / t_all / 1e9, 4), "unit": "Gbp/s",
+                    "sketch_only_value": round(e2e["bases"] / e2e["t_sketch_cli"] / 1e9, 4),
+                    "boundary": "FASTA text in the page cache -> <asm>.k32.w%d.tsv (--seq --pos) + out.mx.dot on disk; cold processes "
+                                "(HIP init included): `indexlr` per assembly, then `python -m ntjoin_amd.run`" % W,
+                    "bases": int(e2e["bases"]), "fasta_bytes": int(e2e["fasta_bytes"]), "tsv_bytes": int(e2e["tsv_bytes"]),
+                    "dot_bytes": int(e2e["dot_bytes"]), "seconds_indexlr": round(e2e["t_sketch_cli"], 3),
+                    "seconds_graph": round(e2e["t_graph_cli"], 3), "threads": n_cores()}
+            finally:
+                shutil.rmtree(td, ignore_errors=True)
         result_line = json.dumps(out)
-    else:
-        result_line = None
-    if world > 1 or force_dist:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     # RCCL writes its banner through C stdio, which is flushed at exit: flush it first so that the JSON line is
@@ -261,7 +380,6 @@ def main():
     ctypes.CDLL(None).fflush(None)
     if result_line is not None:
         print(result_line, flush=True)
-
 
 
 if __name__ == "__main__":

@@ -49,6 +49,7 @@ extern "C" {
 #define MXG_FLAG_DENSE_ONLY 0x1u  /* disable the sparse-candidate fast path (every k-mer is a candidate) */
 #define MXG_FLAG_DROP_SEQ 0x2u    /* do not keep FASTA text on the host (mxg_write_tsv then decodes k-mers from the packed bases: upper-case) */
 #define MXG_FLAG_TIMING 0x4u      /* bracket each kernel family with HIP events (read back through mxg_stats) */
+#define MXG_FLAG_TIMING_FINE 0x8u /* ... one event pair per kernel (profiling; fills the per-kernel fields of mxg_stats) */
 
 #define MXG_MAX_ASSEMBLIES 32
 
@@ -122,7 +123,14 @@ typedef struct mxg_stats {
     double ms_graph;           /* uniqueness, intersection, vertex ids, edges                   */
     uint64_t launches_hash;    /* number of hash-kernel launches in ms_hash                     */
     uint64_t hash_kernel_bases;/* bases covered by those launches                               */
-    double reserved[8];
+    /* MXG_FLAG_TIMING_FINE: ms_resolve split by kernel, ms_graph split into its three parts     */
+    double ms_reorder;         /* arena entry -> exact hash -> ordered candidate slot            */
+    double ms_resolve_kernel;  /* window arg-min decision per candidate                          */
+    double ms_emit;            /* ordered compaction into the sketch arrays                      */
+    double ms_join;            /* uniqueness + intersection (hash join, flags)                   */
+    double ms_vertices;        /* vertex ids + adjacency arrays                                  */
+    double ms_edges;           /* edge flags + edge compaction                                   */
+    double reserved[2];
 } mxg_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */
@@ -336,6 +344,32 @@ int mxg_dg_edges_slots(mxg_handle *h, const void *d_recv, uint32_t world, uint32
    written (excluding the NUL), or the length needed if it exceeds cap. */
 size_t mxg_py_repr_double(double v, char *buf, size_t cap);
 size_t mxg_py_repr_str(const char *s, char *buf, size_t cap);
+
+
+/* ---- synthetic inputs (bench / test support; no counterpart in the reference, whose tests hold four small FASTA files)
+   SURVEY.md 8(d) configs 2-5: assemblies of 0.1-20 Gbp "generated on device from a counter-based RNG mirrored on the
+   CPU".  The genome is a pure function of (seed, coordinate): 32 bases per splitmix64 output; an assembly is a list of
+   segments, output bases [dst_base, dst_base+len) = genome coordinates src..src+len-1, reverse-complemented when rc,
+   each base substituted with probability sub_per_65536/65536 (decided by a second splitmix64 stream indexed by the
+   coordinate).  Segments must be sorted by dst_base (multiples of 16, non-overlapping); words outside are zero.
+   Formulas: ntjoin_amd/csrc/synth.hip, mirrored in numpy by ntjoin_amd/synth.py. */
+typedef struct mxg_synth_seg {
+    uint64_t dst_base; /* first output base (multiple of 16)          */
+    uint64_t src;      /* genome coordinate of the segment's first base (its LAST output base when rc) */
+    uint64_t len;      /* bases                                       */
+    uint32_t rc;       /* 1: output is the reverse complement         */
+    uint32_t reserved;
+} mxg_synth_seg;
+/* fills d_out[0..n_words) (HBM, 2-bit packed as mxg_add_assembly_packed_device expects); device < 0 = current device */
+int mxg_synth_fill_packed_device(void *d_out, uint64_t n_words, const mxg_synth_seg *segs, uint64_t n_segs, uint64_t seed,
+                                 uint64_t sub_seed, uint32_t sub_per_65536, int device);
+/* the same words computed on the host (n_threads workers); usable without a device */
+int mxg_synth_fill_packed_host(uint32_t *out, uint64_t n_words, const mxg_synth_seg *segs, uint64_t n_segs, uint64_t seed,
+                               uint64_t sub_seed, uint32_t sub_per_65536, uint32_t n_threads);
+/* FASTA text of packed host records (ids "<id_prefix><r>", `line` bases per line): materialises a synthetic assembly
+   as a file for the end-to-end (FASTA -> .tsv + .mx.dot) measurement.  Host only. */
+int mxg_synth_write_fasta(const char *path, const uint32_t *packed, const uint64_t *rec_start, const uint64_t *rec_len,
+                          uint64_t n_records, const char *id_prefix, uint32_t line, uint32_t n_threads);
 
 /* ---- introspection ----------------------------------------------------------------------------- */
 int mxg_get_stats(mxg_handle *h, mxg_stats *out);

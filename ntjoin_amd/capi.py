@@ -7,7 +7,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libntjoin_mx.so")
 
 MXG_OK, MXG_EINVAL, MXG_EIO, MXG_ENOMEM, MXG_EDEVICE, MXG_ELIMIT = 0, -1, -2, -3, -4, -5
 VARIANT_V2_SUM, VARIANT_V1_MIN = 0, 1
-FLAG_DENSE_ONLY, FLAG_DROP_SEQ, FLAG_TIMING = 0x1, 0x2, 0x4
+FLAG_DENSE_ONLY, FLAG_DROP_SEQ, FLAG_TIMING, FLAG_TIMING_FINE = 0x1, 0x2, 0x4, 0x8
 MX_UNIQUE, MX_SHARED, MX_INALL = 0x1, 0x2, 0x4
 ABI_VERSION = 1
 
@@ -21,6 +21,7 @@ SYMBOLS = [
     "mxg_pack_sketch_device", "mxg_set_sketch_gathered", "mxg_set_sketch_gathered_strided", "mxg_write_tsv",
     "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_path_segments", "mxg_mx_extremes", "mxg_dg_owner_counts", "mxg_dg_pack_items", "mxg_dg_set_items", "mxg_dg_vertices", "mxg_dg_item_results", "mxg_dg_msg_counts", "mxg_dg_pack_msgs", "mxg_dg_edges", "mxg_dg_pack_slots", "mxg_dg_owner_slots", "mxg_dg_slot_results", "mxg_dg_pack_msg_slots", "mxg_dg_edges_slots", "mxg_write_dot",
     "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers",
+    "mxg_synth_fill_packed_device", "mxg_synth_fill_packed_host", "mxg_synth_write_fasta",
 ]
 
 
@@ -59,13 +60,20 @@ class SegmentsView(C.Structure):
                 ("seg_first", C.POINTER(C.c_uint32)), ("seg_stat", C.POINTER(C.c_uint32))]
 
 
+class SynthSeg(C.Structure):
+    _fields_ = [("dst_base", C.c_uint64), ("src", C.c_uint64), ("len", C.c_uint64), ("rc", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_assemblies", C.c_uint32), ("bases", C.c_uint64),
                 ("kmers", C.c_uint64), ("minimizers", C.c_uint64), ("candidates", C.c_uint64),
                 ("dense_kmers", C.c_uint64), ("unique", C.c_uint64), ("vertices", C.c_uint64),
                 ("edges", C.c_uint64), ("ms_hash", C.c_double), ("ms_resolve", C.c_double),
                 ("ms_graph", C.c_double), ("launches_hash", C.c_uint64), ("hash_kernel_bases", C.c_uint64),
-                ("reserved", C.c_double * 8)]
+                ("ms_reorder", C.c_double), ("ms_resolve_kernel", C.c_double), ("ms_emit", C.c_double),
+                ("ms_join", C.c_double), ("ms_vertices", C.c_double), ("ms_edges", C.c_double),
+                ("reserved", C.c_double * 2)]
 
 
 _lib = None
@@ -179,6 +187,9 @@ def load():
     L.mxg_py_repr_str.restype = C.c_size_t
     L.mxg_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mxg_reset_timers.argtypes = [vp]
+    L.mxg_synth_fill_packed_device.argtypes = [vp, u64, vp, u64, u64, u64, C.c_uint32, i32]
+    L.mxg_synth_fill_packed_host.argtypes = [vp, u64, vp, u64, u64, u64, C.c_uint32, C.c_uint32]
+    L.mxg_synth_write_fasta.argtypes = [cp, vp, vp, vp, u64, cp, C.c_uint32, C.c_uint32]
     for name in SYMBOLS:
         fn = getattr(L, name)  # raises AttributeError if the symbol is not exported
         if fn.restype is C.c_int and name not in ("mxg_abi_version",):

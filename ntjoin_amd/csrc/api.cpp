@@ -96,6 +96,8 @@ void mxg_destroy(mxg_handle *h)
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->ev_g)
+        if (e) (void)hipEventDestroy(e);
     if (h->pinned_ctrl) (void)hipHostFree(h->pinned_ctrl);
     if (h->pinned_gctl) (void)hipHostFree(h->pinned_gctl);
     if (h->pinned_dg) (void)hipHostFree(h->pinned_dg);
@@ -830,6 +832,12 @@ int mxg_get_stats(mxg_handle *h, mxg_stats *out)
     s.ms_graph = h->tm.ms_graph;
     s.launches_hash = h->tm.launches_hash;
     s.hash_kernel_bases = h->tm.hash_bases;
+    s.ms_reorder = h->tm.ms_reorder;
+    s.ms_resolve_kernel = h->tm.ms_resolve_k;
+    s.ms_emit = h->tm.ms_emit;
+    s.ms_join = h->tm.ms_join;
+    s.ms_vertices = h->tm.ms_vertices;
+    s.ms_edges = h->tm.ms_edges;
     *out = s;
     return MXG_OK;
 }

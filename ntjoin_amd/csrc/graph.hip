@@ -569,7 +569,12 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
     const bool resume = mode == GRAPH_DG_EDGES || mode == GRAPH_DG_EDGES_APPLIED;  // second half on the owner's handle
     if (!resume) g = Graph();
     g.n_asm = A;
-    const bool timing = (h->cfg.flags & MXG_FLAG_TIMING) != 0;
+    const bool fine = (h->cfg.flags & MXG_FLAG_TIMING_FINE) != 0 && mode == GRAPH_FULL;
+    const bool timing = (h->cfg.flags & MXG_FLAG_TIMING) != 0 || fine;
+    if (fine && !h->ev_g[0]) {
+        MXG_HIP(h, hipEventCreate(&h->ev_g[0]));
+        MXG_HIP(h, hipEventCreate(&h->ev_g[1]));
+    }
     if (timing) MXG_HIP(h, hipEventRecord(h->ev0, h->stream));
 
     uint32_t cap = 1024;
@@ -656,6 +661,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         hipLaunchKernelGGL(k_flags, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), cnt, fsup);
     }
     MXG_HIP(h, hipGetLastError());
+    if (fine) MXG_HIP(h, hipEventRecord(h->ev_g[0], h->stream));
     if (nvs > 0) {
         MXG_HIP(h, h->g_vhash.ensure(nvs * 8));
         MXG_HIP(h, h->g_vpos.ensure(anv * 4));
@@ -710,6 +716,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
                                h->g_fv.as<uint32_t>(), (uint32_t)nvs);
         }
         MXG_HIP(h, hipGetLastError());
+        if (fine) MXG_HIP(h, hipEventRecord(h->ev_g[1], h->stream));
         MXG_HIP(h, h->g_eflag.ensure(n_items));
         MXG_HIP(h, h->g_ebs.ensure((size_t)e_blocks * 4 + 64));
         // every item yields at most one edge: size the edge arrays by that bound
@@ -760,6 +767,15 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         float ms = 0;
         MXG_HIP(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
         h->tm.ms_graph += ms;
+        if (fine && nvs > 0) {
+            float a = 0, b = 0, c = 0;
+            MXG_HIP(h, hipEventElapsedTime(&a, h->ev0, h->ev_g[0]));
+            MXG_HIP(h, hipEventElapsedTime(&b, h->ev_g[0], h->ev_g[1]));
+            MXG_HIP(h, hipEventElapsedTime(&c, h->ev_g[1], h->ev1));
+            h->tm.ms_join += a;
+            h->tm.ms_vertices += b;
+            h->tm.ms_edges += c;
+        }
     }
     g.valid = true;
     g.host_valid = false;

@@ -146,6 +146,8 @@ struct Segments {  // results of mxg_path_segments / mxg_mx_extremes (host copie
 
 struct Timers {
     double ms_hash = 0, ms_resolve = 0, ms_graph = 0;
+    // MXG_FLAG_TIMING_FINE: one span per kernel (ms_resolve stays the sum of the three behind the hash kernel)
+    double ms_reorder = 0, ms_resolve_k = 0, ms_emit = 0, ms_join = 0, ms_vertices = 0, ms_edges = 0;
     uint64_t launches_hash = 0, hash_bases = 0;
 };
 
@@ -156,6 +158,7 @@ struct TimedSpan {
     hipEvent_t a, b;
     uint64_t bases;
     bool is_hash;
+    int kind;  // 0 hash, 1 everything behind it (coarse timing), 2 reorder, 3 resolve, 4 emit (fine timing)
 };
 
 }  // namespace mxg
@@ -191,6 +194,7 @@ struct mxg_handle {
         g_ebs, g_eu, g_ev, g_esup, g_ew;  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
     uint64_t arena_cap_hint = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_g[2] = {nullptr, nullptr};  // MXG_FLAG_TIMING_FINE: after the join, after vertices + adjacency
     uint64_t *pinned_dg = nullptr;    // dgraph.hip: pinned copy of the per-destination counters
     uint64_t *pinned_gctl = nullptr;  // pinned host copy of the graph stage's control block
     uint32_t *pinned_ctrl = nullptr;  // pinned host copies of per-assembly control blocks (pipelined sketch)

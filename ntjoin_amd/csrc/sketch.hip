@@ -1082,8 +1082,9 @@ struct Driver {
     hipStream_t st;   // stream this driver enqueues on
     int slot;         // which of the handle's two scratch sets it uses (two drivers can be in flight at once)
     explicit Driver(mxg_handle *h_, int slot_ = 0)
-        : h(h_), timing((h_->cfg.flags & MXG_FLAG_TIMING) != 0), st(slot_ == 0 ? h_->stream : h_->stream2), slot(slot_)
+        : h(h_), timing((h_->cfg.flags & (MXG_FLAG_TIMING | MXG_FLAG_TIMING_FINE)) != 0), st(slot_ == 0 ? h_->stream : h_->stream2), slot(slot_)
     {
+        fine = (h_->cfg.flags & MXG_FLAG_TIMING_FINE) != 0;
     }
     DevBuf &sc(int i) { return h->scratch[slot][i]; }
 
@@ -1095,15 +1096,23 @@ struct Driver {
     uint32_t *sel_sup(uint32_t) { return wave_sup() + n_wave_sup; }
     static uint32_t n_sel_sup(uint32_t n_cap) { return sup_words((n_cap + RK - 1) / RK); }
 
-    int ev_begin(uint64_t bases, bool is_hash)
+    bool fine = false;  // MXG_FLAG_TIMING_FINE: a span per kernel
+    int ev_next(int kind)  // fine timing only: close the running span and open one of `kind`
+    {
+        if (!timing || !fine) return MXG_OK;
+        int rc = ev_end();
+        return rc != MXG_OK ? rc : ev_begin(0, false, kind);
+    }
+    int ev_begin(uint64_t bases, bool is_hash, int kind = -1)
     {
         if (!timing) return MXG_OK;
+        if (kind < 0) kind = is_hash ? 0 : (fine ? 2 : 1);
         while (h->ev_pool.size() < h->ev_used + 2) {
             hipEvent_t e;
             MXG_HIP(h, hipEventCreate(&e));
             h->ev_pool.push_back(e);
         }
-        TimedSpan sp{h->ev_pool[h->ev_used], h->ev_pool[h->ev_used + 1], bases, is_hash};
+        TimedSpan sp{h->ev_pool[h->ev_used], h->ev_pool[h->ev_used + 1], bases, is_hash, kind};
         h->ev_used += 2;
         MXG_HIP(h, hipEventRecord(sp.a, st));
         h->ev_spans.push_back(sp);
@@ -1517,7 +1526,9 @@ struct Driver {
         MXG_HIP(h, hipGetLastError());
         // resolve + speculative emit straight into the output arrays (guarded by their capacity): on the common path
         // (no gap, no overflow) the batch then needs a single host sync
+        if ((rc = ev_next(3)) != MXG_OK) return rc;
         if ((rc = resolve_count(T, n_cap, (uint32_t)g.c0, (uint32_t)g.c1, (uint64_t)tau_hi << 32, a->cand_hint)) != MXG_OK) return rc;
+        if ((rc = ev_next(4)) != MXG_OK) return rc;
         if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host)) != MXG_OK) return rc;
         return ev_end();
     }
@@ -1969,6 +1980,9 @@ int flush_timers(mxg_handle *h)
             h->tm.hash_bases += e.bases;
         } else {
             h->tm.ms_resolve += ms;
+            if (e.kind == 2) h->tm.ms_reorder += ms;
+            else if (e.kind == 3) h->tm.ms_resolve_k += ms;
+            else if (e.kind == 4) h->tm.ms_emit += ms;
         }
     }
     h->ev_spans.clear();

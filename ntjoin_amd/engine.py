@@ -32,7 +32,7 @@ def _np(ptr, n, dtype):
 
 class MxEngine:
     def __init__(self, k=32, w=1000, variant="v2", device=-1, stream=None, dense_only=False, drop_seq=False,
-                 timing=False, cand_per_window=0):
+                 timing=False, cand_per_window=0, timing_fine=False):
         self._lib = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -41,7 +41,7 @@ class MxEngine:
         cfg.variant = capi.VARIANT_V1_MIN if str(variant).lower() in ("v1", "min", "1") else capi.VARIANT_V2_SUM
         cfg.device = int(device)
         cfg.flags = ((capi.FLAG_DENSE_ONLY if dense_only else 0) | (capi.FLAG_DROP_SEQ if drop_seq else 0) |
-                     (capi.FLAG_TIMING if timing else 0))
+                     (capi.FLAG_TIMING if timing else 0) | (capi.FLAG_TIMING_FINE if timing_fine else 0))
         cfg.stream = C.c_void_p(stream) if stream else None
         cfg.cand_per_window = int(cand_per_window)
         rc = self._lib.mxg_create(C.byref(cfg), C.byref(self._h))

@@ -77,3 +77,161 @@ def config2(seed=1, n_bases=100_000_000):
     ref = make_reference(seed, n_bases, 1)
     tgt = derive_target(ref, seed + 1)
     return ref, tgt
+
+
+# ---- counter-based genomes (mirror of ntjoin_amd/csrc/synth.hip) ---------------------------
+# The genome is a pure function of (seed, coordinate), so the GPU fills multi-Gbp assemblies straight into HBM
+# (mxg_synth_fill_packed_device) and the CPU side (oracle, tests) reproduces any excerpt of them from the same formulas.
+GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+SUB_PER_65536 = 328  # 0.5 % substitutions (config 2)
+
+
+def mix64(z):
+    """splitmix64's output function on a uint64 array (wrapping arithmetic)"""
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def counter_codes(seed, g0, n, sub_seed=0, sub_per_65536=0):
+    """2-bit codes of genome coordinates [g0, g0 + n) (substitutions applied when sub_per_65536 > 0)"""
+    g0, n = int(g0), int(n)
+    if n <= 0:
+        return np.zeros(0, dtype=np.uint8)
+    out = np.empty(n, dtype=np.uint8)
+    step = 1 << 22
+    with np.errstate(over="ignore"):
+        for o in range(0, n, step):
+            m = min(step, n - o)
+            g = np.arange(g0 + o, g0 + o + m, dtype=np.uint64)
+            b_lo, b_hi = (g0 + o) >> 5, (g0 + o + m - 1) >> 5
+            blocks = mix64(np.uint64(seed) + (np.arange(b_lo, b_hi + 1, dtype=np.uint64) + np.uint64(1)) * GOLDEN)
+            b = ((blocks[(g >> np.uint64(5)) - np.uint64(b_lo)] >> (np.uint64(2) * (g & np.uint64(31)))) & np.uint64(3)).astype(np.uint8)
+            if sub_per_65536:
+                h = mix64(np.uint64(sub_seed) + (g + np.uint64(1)) * GOLDEN)
+                hit = (h & np.uint64(0xFFFF)) < np.uint64(sub_per_65536)
+                add = (np.uint64(1) + (h >> np.uint64(16)) % np.uint64(3)).astype(np.uint8)
+                b = np.where(hit, (b + add) & np.uint8(3), b).astype(np.uint8)
+            out[o:o + m] = b
+    return out
+
+
+def segment_codes(seg, seed, sub_seed=0, sub_per_65536=0):
+    """codes of one segment (dst_base, src, len, rc) in OUTPUT order"""
+    _, src, ln, rc = (int(x) for x in seg)
+    c = counter_codes(seed, src, ln, sub_seed, sub_per_65536)
+    return (np.uint8(3) - c)[::-1].copy() if rc else c
+
+
+def layout(lengths):
+    """packed layout of records of the given lengths: (rec_start (multiples of 16), total words incl. read padding)"""
+    lens = np.asarray(lengths, dtype=np.uint64)
+    padded = (lens + np.uint64(15)) // np.uint64(16) * np.uint64(16)
+    starts = np.zeros(len(lens), dtype=np.uint64)
+    if len(lens) > 1:
+        starts[1:] = np.cumsum(padded[:-1])
+    return starts, int(padded.sum()) // 16 + 512
+
+
+def reference_segments(lengths):
+    """a reference: record r = genome coordinates [gstart[r], gstart[r] + len[r]), gstart multiples of 32"""
+    lens = np.asarray(lengths, dtype=np.uint64)
+    g = np.zeros(len(lens), dtype=np.uint64)
+    if len(lens) > 1:
+        g[1:] = np.cumsum((lens[:-1] + np.uint64(31)) // np.uint64(32) * np.uint64(32))
+    starts, n_words = layout(lens)
+    segs = np.zeros((len(lens), 4), dtype=np.uint64)
+    segs[:, 0], segs[:, 1], segs[:, 2] = starts, g, lens
+    return segs, n_words, g
+
+
+def target_segments(ref_gstart, ref_lens, seed, min_len=10_000, max_len=2_000_000, gap=(20, 500), min_keep=1000):
+    """a target derived from the reference (config 2's recipe, vectorised): every reference record cut into contigs of
+    log-uniform length with 20-500 bp dropped between them, half of them reverse-complemented, order shuffled.
+    -> (segs [n,4] = dst_base, src, len, rc; n_words)"""
+    rng = np.random.default_rng(seed)
+    mean = (max_len - min_len) / np.log(max_len / min_len)
+    srcs, lens = [], []
+    for g0, L in zip(np.asarray(ref_gstart).tolist(), np.asarray(ref_lens).tolist()):
+        n_est = int(2.0 * L / mean) + 64
+        while True:
+            ln = np.exp(rng.uniform(np.log(min_len), np.log(max_len), size=n_est)).astype(np.int64)
+            gp = rng.integers(gap[0], gap[1] + 1, size=n_est)
+            start = np.concatenate(([0], np.cumsum(ln + gp)[:-1]))
+            if start[-1] >= L:
+                break
+            n_est *= 2
+        keep = start < L
+        start, ln = start[keep], ln[keep]
+        ln = np.minimum(ln, L - start)
+        ok = ln >= min(min_keep, min_len)
+        srcs.append(start[ok] + g0)
+        lens.append(ln[ok])
+    src = np.concatenate(srcs).astype(np.uint64)
+    ln = np.concatenate(lens).astype(np.uint64)
+    rc = (rng.random(len(src)) < 0.5).astype(np.uint64)
+    order = rng.permutation(len(src))
+    src, ln, rc = src[order], ln[order], rc[order]
+    starts, n_words = layout(ln)
+    segs = np.zeros((len(src), 4), dtype=np.uint64)
+    segs[:, 0], segs[:, 1], segs[:, 2], segs[:, 3] = starts, src, ln, rc
+    return segs, n_words
+
+
+def record_lengths(seed, total, n_records, lo_frac=0.2):
+    """n_records lengths adding up to `total`, spread like chromosomes (config 3: 24 records of 50-250 Mbp in 3 Gbp)"""
+    rng = np.random.default_rng(seed)
+    wts = rng.uniform(lo_frac, 1.0, size=n_records)
+    lens = np.floor(wts / wts.sum() * total).astype(np.int64)
+    lens[-1] += int(total) - int(lens.sum())
+    return lens.astype(np.uint64)
+
+
+def _segs_buffer(segs):
+    """the mxg_synth_seg array as one numpy buffer (fast for millions of segments)"""
+    s = np.asarray(segs, dtype=np.uint64).reshape(-1, 4)
+    buf = np.zeros((len(s), 4), dtype=np.uint64)
+    buf[:, 0:3] = s[:, 0:3]
+    buf[:, 3] = s[:, 3] & np.uint64(0xFFFFFFFF)  # rc in the low 32 bits, reserved = 0
+    return np.ascontiguousarray(buf)
+
+
+def fill_host(segs, n_words, seed, sub_seed=0, sub_per_65536=0, n_threads=8):
+    """packed words of an assembly on the host through the library's own CPU mirror of the kernel (no device needed)"""
+    from . import capi
+    lib = capi.load()
+    out = np.zeros(int(n_words), dtype=np.uint32)
+    buf = _segs_buffer(segs)
+    rc = lib.mxg_synth_fill_packed_host(out.ctypes.data, int(n_words), buf.ctypes.data, len(buf), int(seed), int(sub_seed),
+                                        int(sub_per_65536), int(n_threads))
+    if rc != 0:
+        raise RuntimeError(f"mxg_synth_fill_packed_host failed ({rc})")
+    return out
+
+
+def fill_device(segs, n_words, seed, sub_seed=0, sub_per_65536=0, device=0):
+    """-> torch int32 tensor [n_words] on `device`, filled by the generator kernel (nothing crosses PCIe but the segment table)"""
+    import torch
+    from . import capi
+    lib = capi.load()
+    t = torch.empty(int(n_words), dtype=torch.int32, device=torch.device("cuda", device))
+    buf = _segs_buffer(segs)
+    rc = lib.mxg_synth_fill_packed_device(t.data_ptr(), int(n_words), buf.ctypes.data, len(buf), int(seed), int(sub_seed),
+                                          int(sub_per_65536), int(device))
+    if rc != 0:
+        raise RuntimeError(f"mxg_synth_fill_packed_device failed ({rc})")
+    return t
+
+
+def genome_config(total_bases, n_records, seed=1, target=True, min_len=10_000, max_len=2_000_000, rec_seed=None):
+    """segment tables of a reference of n_records records totalling total_bases and (optionally) a target derived from it.
+    -> dict(ref_segs, ref_words, tgt_segs, tgt_words, seed, sub_seed)"""
+    lens = record_lengths(rec_seed if rec_seed is not None else seed + 7, total_bases, n_records) if n_records > 1 \
+        else np.array([int(total_bases)], dtype=np.uint64)
+    ref_segs, ref_words, g = reference_segments(lens)
+    out = {"ref_segs": ref_segs, "ref_words": ref_words, "seed": int(seed), "sub_seed": int(seed) * 7919 + 13}
+    if target:
+        out["tgt_segs"], out["tgt_words"] = target_segments(g, lens, seed + 1, min_len=min_len, max_len=max_len)
+    return out

@@ -85,6 +85,23 @@ int mxo_sketch_fasta_to_tsv(const char *path, const char *out_path, unsigned k, 
                             int variant, int with_pos, int with_strand, int with_seq,
                             uint64_t *stats);
 
+/*
+ * CPU baseline legs (mx_oracle_mt.c).  mxo_sketch_packed_mt: `indexlr -t T` on 2-bit packed N-free records (record r =
+ * bases [rec_start[r], +rec_len[r]) of `packed`, 16 bases per word): n_threads workers over chunks of chunk_kmers
+ * k-mers (0 = 4 Mi) with a w-1 halo, each running the stateful loop above; outputs are malloc'd arrays sorted by
+ * (record, pos) (free with mxo_free).  Returns the number of minimizers.
+ */
+size_t mxo_sketch_packed_mt(const uint32_t *packed, const uint64_t *rec_start, const uint64_t *rec_len, size_t n_rec, unsigned k,
+                            unsigned w, int variant, unsigned n_threads, uint64_t chunk_kmers, uint64_t **out_hash,
+                            uint32_t **out_pos, uint32_t **out_rec);
+/*
+ * Graph stage on arrays: uniqueness per assembly, intersection, adjacency edges with support masks and weights
+ * (reference bin/ntjoin_utils.py:182-193,152-165,83-141), single-threaded.  counts = {unique minimizers, vertices, edges}.
+ * Edge arrays (optional, malloc'd): source hash, target hash (first-seen orientation), support mask, weight.
+ */
+int mxo_graph(unsigned A, const uint64_t *const *hash, const uint32_t *const *rec, const uint64_t *n, const double *weights,
+              uint64_t counts[3], uint64_t **eu, uint64_t **ev, uint32_t **esup, double **ew);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,61 @@ class Oracle:
         L.mxo_ext_hash.restype = ctypes.c_uint64
         L.mxo_ext_hash.argtypes = [ctypes.c_uint64, ctypes.c_uint]
 
+    def sketch_packed_mt(self, words, rec_start, rec_len, k, w, variant=V2_SUM, threads=1, chunk_kmers=0):
+        """`indexlr -t threads` on 2-bit packed N-free records -> (out_hash u64[], pos u32[], record u32[])"""
+        L = self.lib
+        L.mxo_sketch_packed_mt.restype = ctypes.c_size_t
+        L.mxo_sketch_packed_mt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint,
+                                           ctypes.c_uint, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64,
+                                           ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                           ctypes.POINTER(ctypes.c_void_p)]
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        rs = np.ascontiguousarray(rec_start, dtype=np.uint64)
+        rl = np.ascontiguousarray(rec_len, dtype=np.uint64)
+        ph, pp, pr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        n = L.mxo_sketch_packed_mt(words.ctypes.data, rs.ctypes.data, rl.ctypes.data, len(rs), k, w, variant, threads,
+                                   chunk_kmers, ctypes.byref(ph), ctypes.byref(pp), ctypes.byref(pr))
+
+        def take(p, ct, dt):
+            a = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ct)), shape=(max(n, 1),))[:n].astype(dt, copy=True)
+            L.mxo_free(p)
+            return a
+        return take(ph, ctypes.c_uint64, np.uint64), take(pp, ctypes.c_uint32, np.uint32), take(pr, ctypes.c_uint32, np.uint32)
+
+    def graph(self, hashes, recs, weights, edges=False):
+        """C restatement of uniqueness + intersection + build_graph on arrays (assemblies in the reference's order)
+        -> dict(unique, vertices, edges[, eu, ev, esup, ew])"""
+        L = self.lib
+        A = len(hashes)
+        hh = [np.ascontiguousarray(h, dtype=np.uint64) for h in hashes]
+        rr = [np.ascontiguousarray(r, dtype=np.uint32) for r in recs]
+        ph = (ctypes.c_void_p * A)(*[h.ctypes.data for h in hh])
+        pr = (ctypes.c_void_p * A)(*[r.ctypes.data for r in rr])
+        nn = (ctypes.c_uint64 * A)(*[len(h) for h in hh])
+        ww = (ctypes.c_double * A)(*[float(x) for x in weights])
+        counts = (ctypes.c_uint64 * 3)()
+        L.mxo_graph.restype = ctypes.c_int
+        L.mxo_graph.argtypes = [ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        eu, ev, es, ew = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        if edges:
+            rc = L.mxo_graph(A, ph, pr, nn, ww, counts, ctypes.byref(eu), ctypes.byref(ev), ctypes.byref(es), ctypes.byref(ew))
+        else:
+            rc = L.mxo_graph(A, ph, pr, nn, ww, counts, None, None, None, None)
+        if rc != 0:
+            raise RuntimeError(f"mxo_graph failed ({rc})")
+        out = {"unique": int(counts[0]), "vertices": int(counts[1]), "edges": int(counts[2])}
+        if edges:
+            ne = out["edges"]
+
+            def take(p, ct, dt):
+                a = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ct)), shape=(max(ne, 1),))[:ne].astype(dt, copy=True)
+                L.mxo_free(p)
+                return a
+            out["eu"], out["ev"] = take(eu, ctypes.c_uint64, np.uint64), take(ev, ctypes.c_uint64, np.uint64)
+            out["esup"], out["ew"] = take(es, ctypes.c_uint32, np.uint32), take(ew, ctypes.c_double, np.float64)
+        return out
+
     def _sketch(self, fn, seq, k, w, variant):
         if isinstance(seq, str):
             seq = seq.encode("ascii")
