@@ -89,7 +89,7 @@ def cpu_baseline(asms_host, w, budget_s):
     words0, starts0, lens0 = asms_host[0]
     cal_len = int(min(int(lens0[0]), 4_000_000 * cores))
     t0 = time.perf_counter()
-    orc.sketch_packed_mt(words0, starts0[:1], np.array([cal_len], dtype=np.uint64), K, w, threads=cores, chunk_kmers=1 << 20)
+    orc.sketch_packed_mt(words0, starts0[:1], np.array([cal_len], dtype=np.uint64), K, w, threads=cores, chunk_kmers=1 << 18)
     rate = cal_len / max(time.perf_counter() - t0, 1e-6)  # bases per second, all cores
     total = sum(int(l.sum()) for _, _, l in asms_host)
     frac = min(1.0, rate * budget_s / total)
@@ -101,7 +101,7 @@ def cpu_baseline(asms_host, w, budget_s):
         sample.append((words, starts[:n], lens[:n]))
         bases += int(lens[:n].sum())
     t0 = time.perf_counter()
-    sk = [orc.sketch_packed_mt(wd, st, ln, K, w, threads=cores, chunk_kmers=1 << 20) for wd, st, ln in sample]
+    sk = [orc.sketch_packed_mt(wd, st, ln, K, w, threads=cores, chunk_kmers=1 << 18) for wd, st, ln in sample]
     t_sketch = time.perf_counter() - t0
     t1 = time.perf_counter()
     g = orc.graph([s[0] for s in sk], [s[2] for s in sk], [2.0, 1.0][:len(sk)] if len(sk) == 2 else [1.0] * len(sk))

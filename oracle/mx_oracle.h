@@ -88,7 +88,7 @@ int mxo_sketch_fasta_to_tsv(const char *path, const char *out_path, unsigned k, 
 /*
  * CPU baseline legs (mx_oracle_mt.c).  mxo_sketch_packed_mt: `indexlr -t T` on 2-bit packed N-free records (record r =
  * bases [rec_start[r], +rec_len[r]) of `packed`, 16 bases per word): n_threads workers over chunks of chunk_kmers
- * k-mers (0 = 4 Mi) with a w-1 halo, each running the stateful loop above; outputs are malloc'd arrays sorted by
+ * k-mers (0 = 256 Ki) with a w-1 halo, each running the stateful loop above; outputs are malloc'd arrays sorted by
  * (record, pos) (free with mxo_free).  Returns the number of minimizers.
  */
 size_t mxo_sketch_packed_mt(const uint32_t *packed, const uint64_t *rec_start, const uint64_t *rec_len, size_t n_rec, unsigned k,

@@ -14,6 +14,7 @@
  *     152-165, 83-141) restated on arrays in plain C, single-threaded like the reference; checked against
  *     oracle/graph_oracle.py (itself pinned by fixtures generated from the imported reference) in tests/.
  */
+#include <malloc.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -77,8 +78,12 @@ size_t mxo_sketch_packed_mt(const uint32_t *packed, const uint64_t *rec_start, c
 {
     *out_hash = NULL;
     *out_pos = *out_rec = NULL;
-    if (!chunk_kmers) chunk_kmers = 4u << 20;
+    if (!chunk_kmers) chunk_kmers = 1u << 18;
     if (!n_threads) n_threads = 1;
+    /* every work item allocates ~17 B per k-mer in the pinned single-record routine: keep those blocks in the threads'
+       arenas instead of mmap/munmap-ing them per item (with 256 workers the page faults serialise in the kernel) */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
     size_t n_items = 0;
     for (size_t r = 0; r < n_rec; ++r) {
         if (rec_len[r] < k) continue;

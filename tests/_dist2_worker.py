@@ -14,9 +14,9 @@ from ntjoin_amd.dist import allgather_union_graph, partitioned_graph, partitione
 from ntjoin_amd.engine import MxEngine  # noqa: E402
 
 
-def records(seed, n):
+def records(seed, n, genome=90000):
     rng0 = random.Random(0)
-    base = "".join(rng0.choice("ACGT") for _ in range(90000))   # the genome every assembly is a copy of
+    base = "".join(rng0.choice("ACGT") for _ in range(genome))   # the genome every assembly is a copy of
     rng = random.Random(seed)
     cuts = sorted(rng.sample(range(2000, len(base) - 2000), n - 1))          # its own contig boundaries
     out = []
@@ -36,6 +36,10 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     k, w = 32, 50
     asms = [("refA", 2.0, records(1, 9)), ("refB", 1.5, records(2, 7)), ("tgt", 1.0, records(3, 11))]
+    if os.environ.get("MXG_TEST_CONFIG3") == "1":   # BASELINE configs[3]'s shape: target + 3 references, w=500, weights 1/2/2/2
+        w = 500
+        asms = [("ref1", 2.0, records(11, 17, 700000)), ("ref2", 2.0, records(12, 13, 700000)), ("ref3", 2.0, records(13, 19, 700000)),
+                ("tgt", 1.0, records(14, 41, 700000))]
     use_stream = os.environ.get("MXG_TEST_STREAM") == "1"
     xs = torch.cuda.Stream() if use_stream else None
     kw = {"cand_per_window": int(os.environ["MXG_TEST_CAND"])} if os.environ.get("MXG_TEST_CAND") else {}
@@ -52,7 +56,7 @@ def main():
             union = allgather_union_graph(eng, k, w, 0, union, stream=xs)
         else:                                   # ... and the one-call form (no host sync between sketch and exchange when on a stream)
             union = sketch_union_graph(eng, k, w, 0, union, stream=xs)
-    assert all(eng.sketch_size(a) > 0 for a in range(len(asms)))
+    assert all(eng.sketch_size(a) > 0 for a in range(len(asms)) if mine[a])   # (8 ranks: some own no record of an assembly)
     # the same graph, distributed by hash range: every rank ends up with its own vertices and edges
     owner = None
     for _step in range(3):                       # exact exchange, then twice with the fixed-capacity slots

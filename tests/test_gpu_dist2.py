@@ -34,6 +34,19 @@ def test_union_graph_world_size(world, stream, slot_pct):
     assert out.stdout.count("DIST2 OK") == world, out.stdout[-3000:]
 
 
+@pytest.mark.parametrize("world,config3", [(4, "1"), (4, "0"), (8, "0"), (8, "1")])
+def test_four_and_eight_ranks_on_one_gpu(world, config3):
+    """rank counts of BASELINE configs[3] (4 GPUs: target + 3 references, w=500, weights 1/2/2/2) and configs[4] (8 GPUs), at
+    sizes the checker finishes in seconds: both exchange modes (union all-gather, graph partitioned by hash range) against
+    a single handle holding every rank's records.  With 8 ranks some ranks own no record of the smaller assemblies."""
+    env = dict(os.environ, MXG_TEST_STREAM="1", MXG_TEST_CONFIG3=config3)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "tests", "_dist2_worker.py")]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("DIST2 OK") == world, out.stdout[-3000:]
+
+
 @pytest.mark.parametrize("knob", [{"MXG_TEST_CAND": "2"}, {"MXG_WAVE_CAP": "8"}])
 def test_union_step_when_sketches_leave_the_common_case(knob):
     """mxg_sketch_pack with sketches that do not end the common way on the device -- candidate-free stretches everywhere
