@@ -97,6 +97,7 @@ struct Assembly {
     bool tables_ready = false;
     uint32_t S_sparse = 256;  // strip length chosen for the sparse hash kernel
     uint32_t cand_hint = 0;   // candidates of the last sparse run (k_resolve: which blocks may load before the count arrives)
+    std::vector<uint32_t> cand_hints;  // ... per batch of the pipelined multi-batch driver
     std::vector<uint32_t> strip0_dense, strip0_sparse;  // [n_runs+1] exclusive prefix of strips per run
     std::vector<uint64_t> g0;                           // [n_runs+1] exclusive prefix of k-mers per run
     DevBuf d_runs, d_strip0_dense, d_strip0_sparse, d_g0, d_ctg_nk, d_ctg_rec, d_ctg_run0, d_ctg_drop;
@@ -176,6 +177,8 @@ struct mxg_handle {
     size_t ev_used = 0;
     std::vector<mxg::TimedSpan> ev_spans;  // not yet folded into tm
     mxg::DevBuf d_nmx;              // fused sketch+graph call: sketch sizes on the device
+    mxg::DevBuf d_chain;            // pipelined batches: where the next batch of an assembly starts in its sketch (u64 per batch)
+    std::vector<hipEvent_t> ev_sync;  // ... and the events by which a batch waits for its predecessor on the other stream
     hipEvent_t ev_join = nullptr;   // ... and the event that joins the second stream into the first
     mxg::DevBuf dg_cnt, dg_cursor;  // dgraph.hip: per-destination counts / cursors
     mxg::Paths paths;

@@ -47,7 +47,9 @@ namespace mxg {
 enum Scratch {
     SC_CAND_H, SC_CAND_K, SC_CAND_C, SC_SEL, SC_BSUM, SC_CTRL, SC_ARENA, SC_STRIP_CNT, SC_STRIP_META,
     SC_GAPS, SC_WAVE_CNT, SC_ST_HASH, SC_ST_POS, SC_ST_REC, SC_ST_FWD, SC_G_HASH, SC_G_POS,
-    SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_V_DROP, SC_CNT256, SC_WAVE_TOT, SC_COUNT
+    SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_V_DROP, SC_CNT256, SC_WAVE_TOT,
+    SC_GR_HASH, SC_GR_POS, SC_GR_REC, SC_GR_CNT, SC_GR_KEY, SC_GD_HASH, SC_GD_POS, SC_GD_REC,  // device-side stretch fix-up
+    SC_COUNT
 };
 static_assert(SC_COUNT <= 40, "scratch pool too small");
 
@@ -862,6 +864,17 @@ struct EmitParams {
     uint64_t *o_hash;
     uint32_t *o_pos, *o_rec;
     uint8_t *o_fwd;
+    // batches of one assembly enqueued without a host sync in between: where this batch starts is the sum of the batches
+    // before it, which is still on the device (null: 0); the tile holding the last candidate passes the sum on
+    const uint64_t *base_in;
+    uint64_t *base_out;
+    // device-side fix-up of candidate-free stretches (k_gap_fix ... k_merge_fin): when the batch has such stretches the
+    // minimizers go to staging arrays (from index 0) and k_merge_fin merges the stretches' minimizers in; that kernel
+    // also does the reporting, so this one only leaves the count in n_sel
+    uint32_t dev_gaps;
+    uint64_t *s_hash;
+    uint32_t *s_pos, *s_rec;
+    uint64_t s_limit;
 };
 
 __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
@@ -869,8 +882,9 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     __shared__ uint32_t sh[256];
     const uint32_t n = min(*p.n_ptr, p.n_cap);
     if (*p.ovf || n == 0) {  // arena overflow (the host redoes the batch) or no candidate at all: only report
-        if (p.host_ctrl && blockIdx.x == 0 && threadIdx.x < 8)
+        if (!p.dev_gaps && p.host_ctrl && blockIdx.x == 0 && threadIdx.x < 16)
             p.host_ctrl[threadIdx.x] = threadIdx.x == 0 ? *p.ovf : (threadIdx.x == 1 ? p.ovf[1] : 0u);
+        if (!p.dev_gaps && p.base_out && blockIdx.x == 0 && threadIdx.x == 0) *p.base_out = p.base_in ? *p.base_in : 0ull;
         return;
     }
     if (blockIdx.x * TILE >= n) return;  // whole tile beyond the candidates
@@ -878,6 +892,14 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     const uint32_t fl = load_flags4(p.sel, base, n);
     uint32_t c = count_flags4(fl);
     uint32_t before;
+    uint64_t obase = p.out_base + (p.base_in ? *p.base_in : 0ull), limit = p.out_limit;
+    uint64_t *o_hash = p.o_hash;
+    uint32_t *o_pos = p.o_pos, *o_rec = p.o_rec;
+    if (p.dev_gaps && p.ovf[1] != 0u) {  // stretches: to staging, merged by k_merge_fin
+        o_hash = p.s_hash; o_pos = p.s_pos; o_rec = p.s_rec;
+        obase = 0;
+        limit = p.s_limit;
+    }
     if (p.bsum) {
         before = p.bsum[blockIdx.x];
     } else {
@@ -890,18 +912,22 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
                 if (threadIdx.x == 0) {
                     p.n_sel[0] = all;
                     p.n_sel[1] = 0;
-                    if (p.n_out) *p.n_out = all;
+                    if (!p.dev_gaps) {
+                        if (p.n_out) *p.n_out = (uint32_t)(obase + all);
+                        if (p.base_out) *p.base_out = obase + all;
+                    }
                 }
-                if (p.host_ctrl && threadIdx.x < 8) {  // {overflow, gaps, selected lo/hi, candidates lo/hi, 0, 0}
+                if (!p.dev_gaps && p.host_ctrl && threadIdx.x < 16) {  // layout: see HostCtrl
                     const uint32_t w = threadIdx.x;
-                    p.host_ctrl[w] = w == 1 ? p.ovf[1] : w == 2 ? all : w == 4 ? *p.n_ptr : 0u;
+                    p.host_ctrl[w] = w == 1 ? p.ovf[1] : (w == 2 || w == 6) ? all : w == 4 ? *p.n_ptr
+                                   : w == 8 ? (uint32_t)obase : w == 9 ? (uint32_t)(obase >> 32) : 0u;
                 }
             }
         }
         __syncthreads();
         before = sh_before;
     }
-    uint64_t o = p.out_base + before + block_exclusive_256(c, sh);
+    uint64_t o = obase + before + block_exclusive_256(c, sh);
     if (c == 0) return;
     for (int u = 0; u < TILE_PER_THREAD; ++u) {
         uint32_t i = base + u;
@@ -913,10 +939,10 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
                 uint32_t mid = (lo + hi) >> 1;
                 if (p.runs[mid].kidx0 <= kx) lo = mid; else hi = mid;
             }
-            if (o < p.out_limit) {  // (the strand byte is filled lazily by k_strand, only when somebody asks for it)
-                p.o_hash[o] = ext_hash(p.ch[i], p.mult);
-                p.o_pos[o] = p.runs[lo].pos0 + (kx - p.runs[lo].kidx0);
-                p.o_rec[o] = p.ctg_rec[ctg];
+            if (o < limit) {  // (the strand byte is filled lazily by k_strand, only when somebody asks for it)
+                o_hash[o] = ext_hash(p.ch[i], p.mult);
+                o_pos[o] = p.runs[lo].pos0 + (kx - p.runs[lo].kidx0);
+                o_rec[o] = p.ctg_rec[ctg];
             }
             ++o;
         }
@@ -972,6 +998,237 @@ __global__ __launch_bounds__(256) void k_merge(const MergeParams p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// candidate-free stretches fixed up on the device
+// ------------------------------------------------------------------------------------------------------
+// A window without any candidate lies inside a stretch of >= w k-mers whose hashes are all >= tau (k_resolve finds every
+// such stretch exactly).  The minimizers of the windows INSIDE a stretch are the stretch's own sketch as a stand-alone
+// contig.  The host-driven route (process_gaps: virtual contigs through the dense pipeline) costs several host round trips
+// per batch; at genome scale almost every batch of 10^9 k-mers holds a few stretches (about 0.3 per 10^9 k-mers at 18
+// candidates per window, hundreds at 12), so here they are sketched by one block each without leaving the stream:
+//   k_gap_fix    block = stretch: exact hashes of its k-mers into LDS, rightmost arg-min of every window through a sparse
+//                table (log2 w doubling passes), distinct arg-mins compacted in order into the stretch's region
+//   k_gap_post   one block: ranks the stretches by (contig, first k-mer), lays their minimizers end to end
+//   k_merge_fin  merges them into the batch's own minimizers (which k_emit then left in staging) and reports the batch
+// Anything this route cannot hold -- more than GAP_DEV_MAX stretches, a stretch longer than GAP_DEV_NMAX k-mers or cut by
+// invalid bases, more than GAP_DEV_REG minimizers in one stretch (low-complexity sequence) -- raises ctrl[6] and the host
+// redoes the batch the general way.
+constexpr uint32_t GAP_DEV_MAX = 2048;
+constexpr uint32_t GAP_DEV_REG = 64;
+constexpr uint32_t GAP_DEV_NMAX = 4096;
+
+struct GapFixParams {
+    const uint4 *gaps;   // {contig, k_lo, k_hi, 0} in arrival order (k_resolve)
+    uint32_t *ctrl;      // [1] stretches, [6] "host must redo", [10] k-mers hashed here
+    const Run *runs;
+    const uint32_t *ctg_run0, *ctg_rec;
+    const uint8_t *ctg_drop;
+    const uint32_t *packed;
+    const uint4 *init_tab;
+    uint32_t k, w;
+    uint64_t mult;
+    uint64_t *r_hash;    // [GAP_DEV_MAX][GAP_DEV_REG]
+    uint32_t *r_pos, *r_rec;
+    uint32_t *r_cnt;     // [GAP_DEV_MAX]
+    uint64_t *r_key;     // [GAP_DEV_MAX] contig << 32 | k_lo
+    HashTab tab;
+};
+
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
+{
+    const uint32_t n_g = p.ctrl[1];
+    const uint32_t j = blockIdx.x;
+    if (j >= n_g || n_g > GAP_DEV_MAX || p.ctrl[0]) return;
+    __shared__ uint64_t lh[GAP_DEV_NMAX];
+    __shared__ uint16_t lidx[2][GAP_DEV_NMAX];
+    __shared__ uint32_t selbits[GAP_DEV_NMAX / 32];
+    __shared__ uint4 btab[256];
+    __shared__ uint4 tab[20];
+    __shared__ uint32_t sh[256];
+    __shared__ uint32_t drop_idx;
+    const uint4 gp = p.gaps[j];
+    const uint32_t c = gp.x, klo = gp.y, khi = gp.z, n = khi - klo + 1u, w = p.w, k = p.k;
+    if (threadIdx.x == 0) {
+        p.r_key[j] = ((uint64_t)c << 32) | klo;
+        p.r_cnt[j] = 0;
+    }
+    // the run holding k_lo; a stretch that is not inside one run (invalid bases in it) goes to the host
+    uint32_t lo = p.ctg_run0[c], hi = p.ctg_run0[c + 1];
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (p.runs[mid].kidx0 <= klo) lo = mid; else hi = mid;
+    }
+    const Run run = p.runs[lo];
+    if (n > GAP_DEV_NMAX || n < w || khi >= run.kidx0 + run.n_kmers) {
+        if (threadIdx.x == 0) p.ctrl[6] = 1;
+        return;
+    }
+    btab[threadIdx.x] = p.init_tab[threadIdx.x];
+    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < GAP_DEV_NMAX / 32; i += 256) selbits[i] = 0;
+    if (threadIdx.x == 0) drop_idx = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint64_t b = run.base_off + (klo - run.kidx0);
+    const uint32_t per = (n + 255u) / 256u, i0 = threadIdx.x * per, i1 = min(i0 + per, n);
+    if (i0 < n) {  // exact hashes: the direct formula once, then rolling
+        H2 h = {0u, 0u, 0u, 0u};
+        init_direct(h, p.packed, b + i0, k, btab, tab);
+        lh[i0] = canonical<VARIANT>(h);
+        for (uint32_t i = i0 + 1; i < i1; ++i) {
+            const uint64_t go = b + i - 1, gi = go + k;
+            const uint32_t o = (p.packed[go >> 4] >> (2u * ((uint32_t)go & 15u))) & 3u;
+            const uint32_t in = (p.packed[gi >> 4] >> (2u * ((uint32_t)gi & 15u))) & 3u;
+            nt_step(h, tab[o * 4u + in]);
+            lh[i] = canonical<VARIANT>(h);
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 256) lidx[0][i] = (uint16_t)i;
+    __syncthreads();
+    // the smaller hash, the RIGHT one of equals (btllib rescans with <=)
+    auto best = [&](uint32_t a, uint32_t c2) {
+        const uint64_t ha = lh[a], hc = lh[c2];
+        return (hc < ha || (hc == ha && c2 > a)) ? c2 : a;
+    };
+    uint32_t J = 0;
+    while ((2u << J) <= w) ++J;  // 2^J <= w < 2^(J+1)
+    uint32_t cur = 0;
+    for (uint32_t lv = 0; lv < J; ++lv) {  // lidx[cur][i] = arg-min over [i, i + 2^lv) -> [i, i + 2^(lv+1))
+        const uint32_t step = 1u << lv;
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint32_t a = lidx[cur][i];
+            lidx[cur ^ 1][i] = (uint16_t)(i + step < n ? best(a, lidx[cur][i + step]) : a);
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    const uint32_t span = 1u << J;
+    const bool drop = klo == 0 && p.ctg_drop && p.ctg_drop[c];
+    for (uint32_t s = threadIdx.x; s + w <= n; s += 256) {
+        const uint32_t a = best(lidx[cur][s], lidx[cur][s + w - span]);
+        if (lh[a] != 0xFFFFFFFFFFFFFFFFull) atomicOr(&selbits[a >> 5], 1u << (a & 31u));  // btllib never reports 2^64-1
+        if (s == 0 && drop) drop_idx = a;  // a piece's first window belongs to the shard before it (plan_pieces)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && drop_idx != 0xFFFFFFFFu) selbits[drop_idx >> 5] &= ~(1u << (drop_idx & 31u));
+    __syncthreads();
+    uint32_t cnt = 0;
+    for (uint32_t i = i0; i < i1 && i0 < n; ++i) cnt += (selbits[i >> 5] >> (i & 31u)) & 1u;
+    uint32_t o = block_exclusive_256(cnt, sh);
+    const uint32_t total = sh[255];
+    if (threadIdx.x == 0) atomicAdd(&p.ctrl[10], n);
+    if (total > GAP_DEV_REG) {
+        if (threadIdx.x == 0) p.ctrl[6] = 1;
+        return;
+    }
+    if (threadIdx.x == 0) p.r_cnt[j] = total;
+    const uint32_t rec = p.ctg_rec[c];
+    for (uint32_t i = i0; i < i1 && i0 < n; ++i)
+        if ((selbits[i >> 5] >> (i & 31u)) & 1u) {
+            const size_t at = (size_t)j * GAP_DEV_REG + o++;
+            p.r_hash[at] = ext_hash(lh[i], p.mult);
+            p.r_pos[at] = run.pos0 + (klo + i - run.kidx0);
+            p.r_rec[at] = rec;
+        }
+}
+
+struct GapPostParams {
+    uint32_t *ctrl;  // [1] stretches, [6] flag, [7] <- minimizers found in them
+    const uint64_t *r_hash; const uint32_t *r_pos, *r_rec, *r_cnt; const uint64_t *r_key;
+    uint64_t *d_hash; uint32_t *d_pos, *d_rec;  // laid end to end in (record, position) order
+};
+
+__global__ __launch_bounds__(1024) void k_gap_post(const GapPostParams p)
+{
+    __shared__ uint64_t keys[GAP_DEV_MAX];
+    __shared__ uint32_t src[GAP_DEV_MAX], off[GAP_DEV_MAX], sh[256];
+    const uint32_t n_g = p.ctrl[1];
+    if (n_g == 0 || n_g > GAP_DEV_MAX || p.ctrl[0]) {
+        if (threadIdx.x == 0) {
+            p.ctrl[7] = 0;
+            if (n_g > GAP_DEV_MAX) p.ctrl[6] = 1;
+        }
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < n_g; i += 1024) keys[i] = p.r_key[i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_g; i += 1024) {  // rank by counting: the keys (contig, first k-mer) are distinct
+        const uint64_t key = keys[i];
+        uint32_t r = 0;
+        for (uint32_t q = 0; q < n_g; ++q) r += keys[q] < key ? 1u : 0u;
+        src[r] = i;
+    }
+    __syncthreads();
+    constexpr uint32_t PER = GAP_DEV_MAX / 1024;
+    uint32_t c[PER], tot = 0;
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t r = threadIdx.x * PER + u;
+        c[u] = r < n_g ? p.r_cnt[src[r]] : 0u;
+        tot += c[u];
+    }
+    uint32_t run = block_exclusive<16>(tot, sh);
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t r = threadIdx.x * PER + u;
+        if (r < n_g) off[r] = run;
+        run += c[u];
+    }
+    if (threadIdx.x == 0) p.ctrl[7] = sh[255];
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < n_g; r += 1024) {
+        const uint32_t g = src[r], cn = p.r_cnt[g];
+        for (uint32_t e = 0; e < cn; ++e) {
+            p.d_hash[off[r] + e] = p.r_hash[(size_t)g * GAP_DEV_REG + e];
+            p.d_pos[off[r] + e] = p.r_pos[(size_t)g * GAP_DEV_REG + e];
+            p.d_rec[off[r] + e] = p.r_rec[(size_t)g * GAP_DEV_REG + e];
+        }
+    }
+}
+
+// Pinned host copy of a batch's control block (16 words), written by the batch's last kernel:
+// [0] largest wave count if a wave overflowed its arena slice, [1] candidate-free stretches, [2] minimizers among the
+// candidates, [3] "the device route could not finish the stretches", [4] candidates, [5] minimizers inside stretches,
+// [6..7] minimizers of the batch, [8..9] where the batch starts in the assembly's sketch, [10] k-mers hashed by k_gap_fix
+struct FinParams {
+    const uint32_t *ctrl;
+    uint32_t *host_ctrl;
+    const uint64_t *base_in;
+    uint64_t *base_out;
+    uint32_t *n_out;
+    const uint64_t *a_hash; const uint32_t *a_pos, *a_rec; uint64_t a_limit;  // staging (k_emit)
+    const uint64_t *b_hash; const uint32_t *b_pos, *b_rec;                    // stretches (k_gap_post)
+    uint64_t *o_hash; uint32_t *o_pos, *o_rec; uint64_t out_limit;
+};
+
+__global__ __launch_bounds__(256) void k_merge_fin(const FinParams p)
+{
+    const uint32_t ovf = p.ctrl[0], n_g = p.ctrl[1], nA = p.ctrl[2], n_cand = p.ctrl[4], nB = n_g ? p.ctrl[7] : 0u;
+    const uint32_t flag = p.ctrl[6] | ((n_g && nA > p.a_limit) ? 1u : 0u);
+    const uint64_t base = p.base_in ? *p.base_in : 0ull;
+    const uint64_t total = ovf ? 0ull : (uint64_t)nA + nB;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (p.base_out) *p.base_out = base + total;
+        if (p.n_out) *p.n_out = (uint32_t)(base + total);
+        uint32_t *hc = p.host_ctrl;
+        hc[0] = ovf; hc[1] = n_g; hc[2] = nA; hc[3] = flag; hc[4] = n_cand; hc[5] = nB;
+        hc[6] = (uint32_t)total; hc[7] = (uint32_t)(total >> 32);
+        hc[8] = (uint32_t)base; hc[9] = (uint32_t)(base >> 32);
+        hc[10] = p.ctrl[10];
+    }
+    if (n_g == 0 || flag || ovf) return;  // no stretch: k_emit wrote the output itself
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < nA) {
+        const uint64_t key = ((uint64_t)p.a_rec[t] << 32) | p.a_pos[t];
+        const uint64_t d = base + t + lower_bound_key(p.b_rec, p.b_pos, nB, key);
+        if (d < p.out_limit) { p.o_hash[d] = p.a_hash[t]; p.o_pos[d] = p.a_pos[t]; p.o_rec[d] = p.a_rec[t]; }
+    } else if (t < nA + nB) {
+        const uint32_t u = t - nA;
+        const uint64_t key = ((uint64_t)p.b_rec[u] << 32) | p.b_pos[u];
+        const uint64_t d = base + u + lower_bound_key(p.a_rec, p.a_pos, nA, key);
+        if (d < p.out_limit) { p.o_hash[d] = p.b_hash[u]; p.o_pos[d] = p.b_pos[u]; p.o_rec[d] = p.b_rec[u]; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------------------
@@ -1002,7 +1259,7 @@ static uint64_t env_u64(const char *name, uint64_t dflt)
     return (e && *e) ? strtoull(e, nullptr, 10) : dflt;
 }
 #define DENSE_BATCH_KMERS env_u64("MXG_DENSE_BATCH_KMERS", 96ull << 20)    /* dense arena = 16 B per k-mer */
-#define SPARSE_BATCH_KMERS env_u64("MXG_SPARSE_BATCH_KMERS", 2040ull << 20) /* < 2^31 k-mers per batch */
+#define SPARSE_BATCH_KMERS env_u64("MXG_SPARSE_BATCH_KMERS", 1024ull << 20) /* < 2^31 k-mers per batch */
 constexpr uint32_t GAP_CAP = 1u << 20;
 
 static hipError_t grow_preserve(DevBuf &b, size_t used_bytes, size_t need_bytes, hipStream_t st)
@@ -1074,6 +1331,14 @@ static void build_strip_tables(const std::vector<Run> &runs, int S, std::vector<
     }
     strip0[runs.size()] = (uint32_t)s;
     if (s >= (1ull << 32)) *overflow = true;
+}
+
+// pinned host copies of the batches' control blocks: 16 words each; the last slot belongs to the synchronous path
+constexpr uint32_t PINNED_SLOTS = 1024;
+static int ensure_pinned_ctrl(mxg_handle *h)
+{
+    if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, (size_t)PINNED_SLOTS * 64));
+    return MXG_OK;
 }
 
 struct Driver {
@@ -1222,8 +1487,15 @@ struct Driver {
 
     // offsets: SC_BSUM per 1024-tile (after resolve_and_count) or, fused = true, from SC_CNT256 (after resolve_count)
     uint32_t *n_out = nullptr;  // see EmitParams::n_out (set by sketch_assemblies for the fused call)
+    // how a batch hangs together with the batches before it and with the device-side stretch fix-up (see EmitParams)
+    struct ChainIO {
+        const uint64_t *base_in = nullptr;
+        uint64_t *base_out = nullptr;
+        bool dev_gaps = false;
+        hipEvent_t wait = nullptr;  // recorded behind the previous batch of the assembly when that ran on the other stream
+    };
     int emit(const uint32_t *d_packed, const Tables &T, uint32_t n_cap, DevBuf &oh, DevBuf &op, DevBuf &orc, DevBuf &of,
-             uint64_t out_base, bool fused = false, uint32_t *host_ctrl = nullptr)
+             uint64_t out_base, bool fused = false, uint32_t *host_ctrl = nullptr, const ChainIO *io = nullptr)
     {
         const uint64_t limit = std::min<uint64_t>({oh.bytes / 8, op.bytes / 4, orc.bytes / 4, of.bytes});
         if (!n_cap) return MXG_OK;
@@ -1252,6 +1524,18 @@ struct Driver {
         ep.o_pos = op.as<uint32_t>();
         ep.o_rec = orc.as<uint32_t>();
         ep.o_fwd = of.as<uint8_t>();
+        ep.base_in = io ? io->base_in : nullptr;
+        ep.base_out = io ? io->base_out : nullptr;
+        ep.dev_gaps = io && io->dev_gaps ? 1u : 0u;
+        ep.s_hash = nullptr;
+        ep.s_pos = ep.s_rec = nullptr;
+        ep.s_limit = 0;
+        if (ep.dev_gaps) {
+            ep.s_hash = sc(SC_ST_HASH).as<uint64_t>();
+            ep.s_pos = sc(SC_ST_POS).as<uint32_t>();
+            ep.s_rec = sc(SC_ST_REC).as<uint32_t>();
+            ep.s_limit = std::min<uint64_t>({sc(SC_ST_HASH).bytes / 8, sc(SC_ST_POS).bytes / 4, sc(SC_ST_REC).bytes / 4});
+        }
         hipLaunchKernelGGL(k_emit, dim3((n_cap + TILE - 1) / TILE), dim3(256), 0, st, ep);
         MXG_HIP(h, hipGetLastError());
         return MXG_OK;
@@ -1430,7 +1714,8 @@ struct Driver {
     // Enqueue one batch completely (hash -> order -> resolve+count -> speculative emit at out.n); the last kernel writes
     // the control block to `ctrl_host` (PINNED host memory); NO host sync.  *n_cap_out = capacity the candidate arrays were sized for.
     int enqueue_sparse(Assembly *a, const Tables &T, const BatchGeom &g, uint64_t wave_cap, uint32_t tau_hi,
-                       OutArrays &out, uint32_t *ctrl_host, uint32_t *n_cap_out)
+                       OutArrays &out, uint32_t *ctrl_host, uint32_t *n_cap_out, const ChainIO *io = nullptr,
+                       uint32_t cand_hint = 0xFFFFFFFFu)
     {
         const uint32_t S = a->S_sparse;
         MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
@@ -1527,9 +1812,84 @@ struct Driver {
         // resolve + speculative emit straight into the output arrays (guarded by their capacity): on the common path
         // (no gap, no overflow) the batch then needs a single host sync
         if ((rc = ev_next(3)) != MXG_OK) return rc;
-        if ((rc = resolve_count(T, n_cap, (uint32_t)g.c0, (uint32_t)g.c1, (uint64_t)tau_hi << 32, a->cand_hint)) != MXG_OK) return rc;
+        if ((rc = resolve_count(T, n_cap, (uint32_t)g.c0, (uint32_t)g.c1, (uint64_t)tau_hi << 32,
+                                cand_hint != 0xFFFFFFFFu ? cand_hint : a->cand_hint)) != MXG_OK) return rc;
+        const bool dev = io && io->dev_gaps;
+        if (dev) {  // stretches sketched on the device, one block each (results wait in their regions for k_gap_post)
+            MXG_HIP(h, sc(SC_GR_HASH).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 8));
+            MXG_HIP(h, sc(SC_GR_POS).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
+            MXG_HIP(h, sc(SC_GR_REC).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
+            MXG_HIP(h, sc(SC_GR_CNT).ensure((size_t)GAP_DEV_MAX * 4));
+            MXG_HIP(h, sc(SC_GR_KEY).ensure((size_t)GAP_DEV_MAX * 8));
+            MXG_HIP(h, sc(SC_GD_HASH).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 8));
+            MXG_HIP(h, sc(SC_GD_POS).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
+            MXG_HIP(h, sc(SC_GD_REC).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
+            // staging for the batch's own minimizers when it has stretches: density 2/(w+1) plus slack
+            const uint64_t st_cap = (uint64_t)(2.5 * (double)g.nk / (double)(h->cfg.w + 1)) + 4096;
+            MXG_HIP(h, sc(SC_ST_HASH).ensure(st_cap * 8));
+            MXG_HIP(h, sc(SC_ST_POS).ensure(st_cap * 4));
+            MXG_HIP(h, sc(SC_ST_REC).ensure(st_cap * 4));
+            GapFixParams gp;
+            gp.gaps = sc(SC_GAPS).as<uint4>();
+            gp.ctrl = sc(SC_CTRL).as<uint32_t>();
+            gp.runs = T.d_runs;
+            gp.ctg_run0 = T.d_ctg_run0;
+            gp.ctg_rec = T.d_ctg_rec;
+            gp.ctg_drop = T.d_ctg_drop;
+            gp.packed = a->d_packed;
+            gp.init_tab = h->d_init_tab.as<uint4>();
+            gp.k = h->cfg.k;
+            gp.w = h->cfg.w;
+            gp.mult = 1ull ^ ((uint64_t)h->cfg.k * 0x90b45d39fb6da1faull);
+            gp.r_hash = sc(SC_GR_HASH).as<uint64_t>();
+            gp.r_pos = sc(SC_GR_POS).as<uint32_t>();
+            gp.r_rec = sc(SC_GR_REC).as<uint32_t>();
+            gp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
+            gp.r_key = sc(SC_GR_KEY).as<uint64_t>();
+            gp.tab = h->tab;
+            if (h->cfg.variant == MXG_VARIANT_V1_MIN)
+                hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V1_MIN>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
+            else
+                hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V2_SUM>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
+            MXG_HIP(h, hipGetLastError());
+        }
         if ((rc = ev_next(4)) != MXG_OK) return rc;
-        if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host)) != MXG_OK) return rc;
+        // the batch before this one (same assembly, other stream) must have passed its count on
+        if (io && io->wait) MXG_HIP(h, hipStreamWaitEvent(st, io->wait, 0));
+        if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host, io)) != MXG_OK) return rc;
+        if (dev) {
+            GapPostParams pp;
+            pp.ctrl = sc(SC_CTRL).as<uint32_t>();
+            pp.r_hash = sc(SC_GR_HASH).as<uint64_t>();
+            pp.r_pos = sc(SC_GR_POS).as<uint32_t>();
+            pp.r_rec = sc(SC_GR_REC).as<uint32_t>();
+            pp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
+            pp.r_key = sc(SC_GR_KEY).as<uint64_t>();
+            pp.d_hash = sc(SC_GD_HASH).as<uint64_t>();
+            pp.d_pos = sc(SC_GD_POS).as<uint32_t>();
+            pp.d_rec = sc(SC_GD_REC).as<uint32_t>();
+            hipLaunchKernelGGL(k_gap_post, dim3(1), dim3(1024), 0, st, pp);
+            FinParams fp;
+            fp.ctrl = sc(SC_CTRL).as<uint32_t>();
+            fp.host_ctrl = ctrl_host;
+            fp.base_in = io->base_in;
+            fp.base_out = io->base_out;
+            fp.n_out = n_out;
+            fp.a_hash = sc(SC_ST_HASH).as<uint64_t>();
+            fp.a_pos = sc(SC_ST_POS).as<uint32_t>();
+            fp.a_rec = sc(SC_ST_REC).as<uint32_t>();
+            fp.a_limit = std::min<uint64_t>({sc(SC_ST_HASH).bytes / 8, sc(SC_ST_POS).bytes / 4, sc(SC_ST_REC).bytes / 4});
+            fp.b_hash = pp.d_hash;
+            fp.b_pos = pp.d_pos;
+            fp.b_rec = pp.d_rec;
+            fp.o_hash = out.hash->as<uint64_t>();
+            fp.o_pos = out.pos->as<uint32_t>();
+            fp.o_rec = out.rec->as<uint32_t>();
+            fp.out_limit = out.cap();
+            const uint64_t bound = std::min<uint64_t>(n_cap, fp.a_limit) + (uint64_t)GAP_DEV_MAX * GAP_DEV_REG;
+            hipLaunchKernelGGL(k_merge_fin, dim3((uint32_t)((bound + 255) / 256)), dim3(256), 0, st, fp);
+            MXG_HIP(h, hipGetLastError());
+        }
         return ev_end();
     }
 
@@ -1539,9 +1899,9 @@ struct Driver {
     int complete_batch(Assembly *a, const Tables &T, const BatchGeom &g, OutArrays &out, const uint32_t *ctrl, uint32_t n_cap)
     {
         const size_t c0 = g.c0, c1 = g.c1;
-                const uint64_t n_cand = (uint64_t)ctrl[4] | ((uint64_t)ctrl[5] << 32);
+        const uint64_t n_cand = ctrl[4];  // (layout: FinParams)
         uint32_t n_gaps = ctrl[1];
-        const uint64_t total = (uint64_t)ctrl[2] | ((uint64_t)ctrl[3] << 32);
+        const uint64_t total = ctrl[2];
         h->stat_candidates += n_cand;
         a->cand_hint = (uint32_t)std::min<uint64_t>(n_cand, 0xFFFFFFFFull);
         int rc;
@@ -1599,12 +1959,13 @@ struct Driver {
             batch_geom(T, c0, g);
             const size_t c1 = g.c1;
             uint64_t wave_cap = default_wave_cap(S, cand_frac);
-            if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, (MXG_MAX_ASSEMBLIES + 1) * 32));
-            uint32_t *const ctrl = h->pinned_ctrl + 8 * MXG_MAX_ASSEMBLIES;  // the slot of the synchronous path
+            int rcp = ensure_pinned_ctrl(h);
+            if (rcp != MXG_OK) return rcp;
+            uint32_t *const ctrl = h->pinned_ctrl + 16 * (PINNED_SLOTS - 1);  // the slot of the synchronous path
             uint64_t n_cap64 = 0;
             for (int attempt = 0;; ++attempt) {
                 uint32_t n_cap_now = 0;
-                memset(ctrl, 0xFF, 32);
+                memset(ctrl, 0xFF, 64);
                 int rc = enqueue_sparse(a, T, g, wave_cap, tau_hi, out, ctrl, &n_cap_now);
                 if (rc != MXG_OK) return rc;
                 n_cap64 = n_cap_now;
@@ -1614,8 +1975,8 @@ struct Driver {
                 wave_cap = std::min<uint64_t>((uint64_t)ctrl[0] + 64, 64ull * S);  // exact need is known: redo the batch
                 h->arena_cap_hint = wave_cap;
             }
-            uint32_t ctrl_copy[8];
-            memcpy(ctrl_copy, ctrl, 32);
+            uint32_t ctrl_copy[16];
+            memcpy(ctrl_copy, ctrl, 64);
             int rcb = complete_batch(a, T, g, out, ctrl_copy, (uint32_t)n_cap64);
             if (rcb != MXG_OK) return rcb;
             c0 = c1;
@@ -1717,22 +2078,38 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
     return MXG_OK;
 }
 
-// sparse path: expected c candidates per window; it pays while candidates are a small fraction of k-mers
-static bool sparse_mode(const mxg_handle *h, double *frac, uint32_t *tau_hi)
+// Sparse path: expected c candidates per window; it pays while candidates are a small fraction of k-mers.
+// c trades the work behind the hash kernel (linear in c) against candidate-free stretches (a candidate is followed by
+// one with probability e^-c).  With the stretches fixed up on the device (k_gap_fix) they are cheap, so large assemblies
+// run with c = 12 (a few hundred stretches per 10^9 k-mers); small ones keep c = 18, where a stretch (then handled by the
+// host-driven route) turns up once per ~4 x 10^9 k-mers, and save the three extra launches per batch.
+// mxg_config.cand_per_window fixes c; MXG_DEV_GAPS=0|1 forces the route (test / profiling knobs, read per call).
+struct SparsePlan {
+    bool sparse;
+    bool dev_gaps;
+    double frac;
+    uint32_t tau_hi;
+};
+static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
 {
-    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : 18;
-    *frac = (double)c / (double)h->cfg.w;
+    SparsePlan sp;
+    const uint64_t big = env_u64("MXG_DEV_GAPS_MIN_KMERS", 256ull << 20);
+    sp.dev_gaps = a && a->total_kmers >= big && h->cfg.w <= GAP_DEV_NMAX / 2;
+    const char *e = getenv("MXG_DEV_GAPS");
+    if (e && *e) sp.dev_gaps = atoi(e) != 0 && h->cfg.w <= GAP_DEV_NMAX / 2;
+    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : (sp.dev_gaps ? (uint32_t)env_u64("MXG_DEV_CAND", 12) : 18u);
+    sp.frac = (double)c / (double)h->cfg.w;
     // even: the threshold then falls on the top 31-bit ring of the hash, which is all the sparse kernel rolls
-    *tau_hi = std::max(2u, (uint32_t)std::min<double>(4294967294.0, *frac * 4294967296.0) & ~1u);
-    return !(h->cfg.flags & MXG_FLAG_DENSE_ONLY) && *frac <= 0.125;
+    sp.tau_hi = std::max(2u, (uint32_t)std::min<double>(4294967294.0, sp.frac * 4294967296.0) & ~1u);
+    sp.sparse = !(h->cfg.flags & MXG_FLAG_DENSE_ONLY) && sp.frac <= 0.125;
+    return sp;
 }
 
 static int run_sketch_sync(mxg_handle *h, Assembly *a, const Tables &T, Driver &drv)
 {
     OutArrays out{&a->d_hash, &a->d_pos, &a->d_rec, &a->d_fwd, 0};
-    double frac;
-    uint32_t tau_hi;
-    int rc = sparse_mode(h, &frac, &tau_hi) ? drv.sparse_all(a, T, out, tau_hi, frac) : drv.dense_all(a->d_packed, T, out, true);
+    const SparsePlan sp = sparse_plan(h, a);
+    int rc = sp.sparse ? drv.sparse_all(a, T, out, sp.tau_hi, sp.frac) : drv.dense_all(a->d_packed, T, out, true);
     if (rc != MXG_OK) return rc;
     MXG_HIP(h, hipStreamSynchronize(drv.st));
     a->n_mx = out.n;
@@ -1742,23 +2119,10 @@ static int run_sketch_sync(mxg_handle *h, Assembly *a, const Tables &T, Driver &
 
 int sketch_assembly(mxg_handle *h, Assembly *a)
 {
-    Tables T;
-    bool empty = false;
-    int rc = prepare_sketch(h, a, T, &empty);
-    if (rc != MXG_OK || empty) return rc;
-    Driver drv(h);
-    if ((rc = run_sketch_sync(h, a, T, drv)) != MXG_OK) return rc;
-    return drv.collect();
+    Assembly *list[1] = {a};
+    return sketch_assemblies(h, list, 1);
 }
 
-// Several assemblies: every assembly whose work is one sparse batch is ENQUEUED completely (its pipeline ends with
-// a speculative emit into its own sketch arrays and an async copy of its control block), then ONE host sync covers
-// them all.  An assembly that turns out to need more (arena overflow, candidate-free stretches, output growth)
-// is simply redone through the synchronous path -- rare, and nothing of it was kept.
-// fuse_graph: also run the graph stage, enqueued BEHIND the sketches with upper bounds for the sizes and the counts read
-// on the device, so that the whole sketch + graph step has one host sync.  Needs the common case everywhere (every
-// assembly of the handle in one sparse batch, no candidate-free stretch, no arena overflow, sketches within their
-// bounds); otherwise the sketches are completed as usual and the graph stage runs afterwards in the ordinary way.
 // xchg_pack's kernel with everything read on the device: the sketch may still be in flight on the stream.  The header
 // says -1 (the caller exchanges sizes first) unless the batch ended the common way -- no arena overflow, no
 // candidate-free stretch, at least one candidate -- and the sketch fits the slot and the output arrays.
@@ -1781,71 +2145,127 @@ __global__ __launch_bounds__(256) void k_pack_slot_dev(const uint64_t *__restric
     reinterpret_cast<uint32_t *>(region + 12 * cap)[i] = rec[i];
 }
 
+// Every assembly is cut into batches of whole records (SPARSE_BATCH_KMERS) and EVERY batch of EVERY assembly is enqueued
+// completely -- hash -> order -> resolve (-> stretches on the device) -> emit -- alternating between the handle's two
+// streams with their own scratch, before the host waits once for both streams.  A batch starts in the assembly's sketch
+// where the batches before it end: that sum travels through a device word (ChainIO), and a batch whose predecessor ran on
+// the other stream waits for it just before its emit, so its hash / order / resolve kernels overlap the predecessor's
+// latency-bound tail.  What did not end the common way (arena overflow, stretches the device route could not hold,
+// output beyond its estimate) is redone afterwards: from the candidate arrays when they are still intact in the
+// scratch, else through the synchronous path.
+// fuse_graph: also run the graph stage, enqueued BEHIND the sketches with upper bounds for the sizes and the counts read
+// on the device (one host sync for the whole step; needs one batch per assembly).  xp: mxg_sketch_pack.
 int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_graph, const XchgPackReq *xp)
 {
-    if (n == 1 && !fuse_graph && !xp) return sketch_assembly(h, list[0]);
     if (xp) {
         bool same = n == h->asms.size() && n <= MXG_MAX_ASSEMBLIES;
         for (size_t i = 0; same && i < n; ++i) same = list[i] == h->asms[i];
         if (!same || fuse_graph) return set_err(h, MXG_EINVAL, "mxg_sketch_pack: every assembly of the handle must have bases");
     }
     MXG_HIP(h, hipSetDevice(h->device));
-    if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, (MXG_MAX_ASSEMBLIES + 1) * 32));
-    double frac;
-    uint32_t tau_hi;
-    const bool sparse = sparse_mode(h, &frac, &tau_hi);
-    // two drivers = two streams with their own scratch: assembly i+1's hash kernel overlaps the small, latency-bound
-    // kernels (ordering, resolve, compaction) that follow assembly i's hash kernel
+    int rc = ensure_pinned_ctrl(h);
+    if (rc != MXG_OK) return rc;
     Driver drv0(h, 0), drv1(h, 1);
-    static const bool one_stream = getenv("MXG_ONE_STREAM") != nullptr;  // profiling: kernels of the two assemblies do not overlap
+    static const bool one_stream = getenv("MXG_ONE_STREAM") != nullptr;  // profiling: kernels of the two streams do not overlap
     Driver *drvs[2] = {&drv0, one_stream ? &drv0 : &drv1};
+    struct Item {
+        size_t asm_i;
+        Driver::BatchGeom g;
+        int slot;
+        uint32_t n_cap;
+        uint32_t *hc;  // pinned control block
+    };
     std::vector<Tables> tabs(n);
-    std::vector<int> state(n, 0);  // 0 = synchronous path, 1 = enqueued, 2 = done (empty)
-    std::vector<uint32_t> ncap(n, 0);
-    std::vector<Driver::BatchGeom> geoms(n);
-    std::vector<int> slot_of(n, 0);
+    std::vector<int> state(n, 0);  // 0 = synchronous path, 1 = enqueued, 2 = done
+    std::vector<SparsePlan> plans(n);
+    std::vector<Item> items;
+    std::vector<size_t> item0(n + 1, 0);
     size_t last_on_slot[2] = {(size_t)-1, (size_t)-1};
-    int rc;
-    size_t n_enq = 0;
+    size_t n_enq = 0, next_slot = 0;
+    const bool chain_modes = fuse_graph || xp;  // (these two need one batch per assembly)
     for (size_t i = 0; i < n; ++i) {
+        item0[i] = items.size();
         bool empty = false;
         if ((rc = prepare_sketch(h, list[i], tabs[i], &empty)) != MXG_OK) return rc;
         if (empty) {
             state[i] = 2;
             continue;
         }
-        if (!sparse || i >= MXG_MAX_ASSEMBLIES) continue;
-        // the LAST assembly goes to driver 0 = the handle's main stream: whatever follows the sketches on that stream
-        // (graph stage of mxg_sketch_graph, packing kernels of mxg_sketch_pack) then waits for the other stream's chain,
-        // which has finished earlier, instead of for an event that is still in the future (~20 us of signal latency)
-        // (measured: 1 % on the two-call step, 4 % on mxg_sketch_graph; on a caller's stream, whose partner is the
-        // high-priority second stream, the plain order is 3 % better)
-        const size_t sl = h->own_stream ? ((n - 1 - i) & 1) : (i & 1);
-        Driver &drv = *drvs[sl];
-        Driver::BatchGeom &g = geoms[i];
-        drv.batch_geom(tabs[i], 0, g);
-        if (g.c1 != tabs[i].ctg_rec->size()) continue;  // more than one batch: synchronous path
-        OutArrays out{&list[i]->d_hash, &list[i]->d_pos, &list[i]->d_rec, &list[i]->d_fwd, 0};
-        uint32_t *slot = h->pinned_ctrl + 8 * i;
-        memset(slot, 0xFF, 32);
-        if (fuse_graph || xp) {
-            MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
-            drv.n_out = h->d_nmx.as<uint32_t>() + i;
+        plans[i] = sparse_plan(h, list[i]);
+        if (!plans[i].sparse || i >= MXG_MAX_ASSEMBLIES) continue;
+        std::vector<Driver::BatchGeom> gs;
+        const size_t n_ctg = tabs[i].ctg_rec->size();
+        for (size_t c0 = 0; c0 < n_ctg;) {
+            Driver::BatchGeom g;
+            drv0.batch_geom(tabs[i], c0, g);
+            gs.push_back(g);
+            c0 = g.c1;
         }
-        if ((rc = drv.enqueue_sparse(list[i], tabs[i], g, drv.default_wave_cap(list[i]->S_sparse, frac), tau_hi, out, slot,
-                                     &ncap[i])) != MXG_OK)
-            return rc;
+        if (gs.empty() || (chain_modes && gs.size() > 1) || items.size() + gs.size() >= PINNED_SLOTS - 1) continue;
+        if (gs.size() > 1 && list[i]->any_drop && !plans[i].dev_gaps) {
+            // (fine either way; nothing special: ctg_drop travels with the tables)
+        }
+        OutArrays out{&list[i]->d_hash, &list[i]->d_pos, &list[i]->d_rec, &list[i]->d_fwd, 0};
+        // chain words: [item] = where the NEXT batch starts
+        MXG_HIP(h, h->d_chain.ensure((size_t)PINNED_SLOTS * 8));
+        if (list[i]->cand_hints.size() != gs.size()) list[i]->cand_hints.assign(gs.size(), 0u);
+        for (size_t b = 0; b < gs.size(); ++b) {
+            // a single-batch assembly keeps the round-1 placement: the LAST assembly goes to driver 0 = the handle's main
+            // stream (whatever follows the sketches on that stream then waits for the other stream's chain, which has
+            // finished earlier); batches of a multi-batch assembly simply alternate
+            size_t sl;
+            if (gs.size() == 1) sl = h->own_stream ? ((n - 1 - i) & 1) : (i & 1);
+            else sl = next_slot++ & 1;
+            Driver &drv = *drvs[sl];
+            Item it;
+            it.asm_i = i;
+            it.g = gs[b];
+            it.slot = (int)sl;
+            it.n_cap = 0;
+            it.hc = h->pinned_ctrl + 16 * items.size();
+            memset(it.hc, 0xFF, 64);
+            Driver::ChainIO io;
+            io.dev_gaps = plans[i].dev_gaps && !chain_modes;
+            uint64_t *chain = h->d_chain.as<uint64_t>();
+            io.base_in = b == 0 ? nullptr : chain + (items.size() - 1);
+            io.base_out = gs.size() > 1 ? chain + items.size() : nullptr;
+            if (b > 0 && drvs[items.back().slot] != &drv) {  // predecessor on the other stream: wait for its count before the emit
+                while (h->ev_sync.size() <= items.size()) {
+                    hipEvent_t e;
+                    MXG_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    h->ev_sync.push_back(e);
+                }
+                hipEvent_t e = h->ev_sync[items.size()];
+                MXG_HIP(h, hipEventRecord(e, drvs[items.back().slot]->st));
+                io.wait = e;
+            }
+            drv.n_out = nullptr;
+            if (fuse_graph || xp) {
+                MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
+                drv.n_out = h->d_nmx.as<uint32_t>() + i;
+            }
+            if ((rc = drv.enqueue_sparse(list[i], tabs[i], it.g, drv.default_wave_cap(list[i]->S_sparse, plans[i].frac),
+                                         plans[i].tau_hi, out, it.hc, &it.n_cap, &io, list[i]->cand_hints[b])) != MXG_OK)
+                return rc;
+            last_on_slot[sl] = items.size();
+            items.push_back(it);
+        }
         state[i] = 1;
-        slot_of[i] = (int)sl;
-        last_on_slot[sl] = i;
         ++n_enq;
     }
+    item0[n] = items.size();
+    for (size_t i = n; i-- > 0;)
+        if (state[i] != 1) item0[i] = item0[i + 1];  // (assemblies without items: empty range)
+    std::vector<int> slot_of(n, 0);
+    for (size_t i = 0; i < n; ++i)
+        if (state[i] == 1) slot_of[i] = items[item0[i]].slot;
     if (xp) {
         // the second stream joins the first; the pack kernels follow the sketches on it and read the counts there.  No
         // host sync: mxg_sketch_finish completes the bookkeeping after the caller's next sync on this stream.
         if (!h->ev_join) MXG_HIP(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         MXG_HIP(h, hipEventRecord(h->ev_join, h->stream2));
         MXG_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
         unsigned char *base = static_cast<unsigned char *>(xp->d_slot);
         uint64_t off = xp->head_bytes;
         for (size_t i = 0; i < n; ++i) {
@@ -1866,7 +2286,6 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         return MXG_OK;
     }
     bool fused = false;
-    size_t n_fast = 0;  // assemblies whose speculative emit stood as it was (no stretch, no overflow, within capacity)
     GraphBounds gb;
     if (fuse_graph && n_enq == n && n == h->asms.size() && n <= MXG_MAX_ASSEMBLIES) {
         bool same = true;
@@ -1887,34 +2306,48 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
     }
     MXG_HIP(h, stream_wait(h->stream));
     MXG_HIP(h, stream_wait(h->stream2));
+    size_t n_fast = 0;  // assemblies whose every batch ended the common way
     for (size_t i = 0; i < n; ++i) {
         if (state[i] != 1) continue;
         Assembly *a = list[i];
-        const uint32_t *c = h->pinned_ctrl + 8 * i;
-        const uint64_t total = (uint64_t)c[2] | ((uint64_t)c[3] << 32), n_cand = (uint64_t)c[4] | ((uint64_t)c[5] << 32);
+        const size_t q0 = item0[i], q1 = item0[i + 1];
         const uint64_t cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
-        if (c[0] == 0 && c[1] == 0 && n_cand > 0 && total <= cap) {
+        bool good = true;
+        uint64_t total = 0, n_cand = 0, gap_kmers = 0;
+        for (size_t q = q0; q < q1; ++q) {
+            const uint32_t *c = items[q].hc;
+            const uint64_t t = (uint64_t)c[6] | ((uint64_t)c[7] << 32);
+            const bool dev = plans[i].dev_gaps && !chain_modes;
+            // (not the device route: any stretch sends the batch to the general route below)
+            good = good && c[0] == 0 && c[3] == 0 && c[4] != 0 && c[4] != 0xFFFFFFFFu && (dev || c[1] == 0);
+            total += t;
+            n_cand += c[4];
+            gap_kmers += c[10] == 0xFFFFFFFFu ? 0 : c[10];
+        }
+        if (good && total <= cap) {
             a->n_mx = total;
             a->has_sketch = true;
             h->stat_candidates += n_cand;
-            a->cand_hint = (uint32_t)std::min<uint64_t>(n_cand, 0xFFFFFFFFull);
+            h->stat_dense_kmers += gap_kmers;
+            for (size_t q = q0; q < q1; ++q) a->cand_hints[q - q0] = items[q].hc[4];
+            a->cand_hint = a->cand_hints[0];
             state[i] = 2;
             if (fused && total > gb.n_bound[i]) fused = false;  // a sketch outgrew the bound the graph stage was sized for
             ++n_fast;
-        } else if (c[0] == 0 && last_on_slot[slot_of[i]] == i) {
-            // candidate-free stretches (or an output that outgrew its estimate) and the run's candidate arrays are still
-            // intact in its driver's scratch: finish from there (staging emit, dense fix-up, merge) instead of redoing it
-            Driver &drv = *drvs[slot_of[i]];
+        } else if (q1 - q0 == 1 && items[q0].hc[0] == 0 && items[q0].hc[4] != 0xFFFFFFFFu && last_on_slot[items[q0].slot] == q0) {
+            // one batch, no arena overflow, and its candidate arrays are still intact in the driver's scratch: finish from
+            // there the general way (staging emit, dense fix-up of the stretches, merge) instead of redoing the batch
+            Driver &drv = *drvs[items[q0].slot];
             OutArrays out{&a->d_hash, &a->d_pos, &a->d_rec, &a->d_fwd, 0};
-            uint32_t ctrl_copy[8];
-            memcpy(ctrl_copy, c, 32);
-            if ((rc = drv.complete_batch(a, tabs[i], geoms[i], out, ctrl_copy, ncap[i])) != MXG_OK) return rc;
+            uint32_t ctrl_copy[16];
+            memcpy(ctrl_copy, items[q0].hc, 64);
+            if ((rc = drv.complete_batch(a, tabs[i], items[q0].g, out, ctrl_copy, items[q0].n_cap)) != MXG_OK) return rc;
             MXG_HIP(h, hipStreamSynchronize(drv.st));
             a->n_mx = out.n;
             a->has_sketch = true;
             state[i] = 2;
         } else {
-            state[i] = 0;  // a wave overflowed its arena slice (or the scratch was reused): redo synchronously
+            state[i] = 0;  // redo synchronously
         }
     }
     if (n_fast != n) fused = false;  // not the common case everywhere: the graph stage ran on incomplete input
@@ -1943,23 +2376,29 @@ int sketch_finish(mxg_handle *h)
     list.swap(h->pend_list);
     state.swap(h->pend_state);
     int rc;
+    size_t q = 0;  // (one item per enqueued assembly, in order)
     for (size_t i = 0; i < list.size(); ++i) {
         Assembly *a = list[i];
         if (state[i] == 1) {
-            const uint32_t *c = h->pinned_ctrl + 8 * i;
-            const uint64_t total = (uint64_t)c[2] | ((uint64_t)c[3] << 32), n_cand = (uint64_t)c[4] | ((uint64_t)c[5] << 32);
+            const uint32_t *c = h->pinned_ctrl + 16 * q++;
+            const uint64_t total = (uint64_t)c[6] | ((uint64_t)c[7] << 32), n_cand = c[4];
             const uint64_t cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
-            if (c[0] == 0 && c[1] == 0 && n_cand > 0 && total <= cap) {
+            if (c[0] == 0 && c[1] == 0 && n_cand > 0 && c[4] != 0xFFFFFFFFu && total <= cap) {
                 a->n_mx = total;
                 a->has_sketch = true;
                 h->stat_candidates += n_cand;
-                a->cand_hint = (uint32_t)std::min<uint64_t>(n_cand, 0xFFFFFFFFull);
+                a->cand_hint = (uint32_t)n_cand;
                 continue;
             }
         } else if (state[i] == 2) {
             continue;  // (empty: prepare_sketch left it complete)
         }
-        if ((rc = sketch_assembly(h, a)) != MXG_OK) return rc;
+        Tables T;
+        bool empty = false;
+        if ((rc = prepare_sketch(h, a, T, &empty)) != MXG_OK) return rc;
+        if (empty) continue;
+        Driver drv(h);
+        if ((rc = run_sketch_sync(h, a, T, drv)) != MXG_OK) return rc;
     }
     Driver drv(h);
     return drv.collect();
@@ -2187,7 +2626,10 @@ int xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t
     const size_t A = h->asms.size();
     if (A == 0 || A > MXG_MAX_ASSEMBLIES) return set_err(h, MXG_EINVAL, "mxg_xchg_unpack_graph: 1..%d assemblies", MXG_MAX_ASSEMBLIES);
     MXG_HIP(h, hipSetDevice(h->device));
-    if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, (MXG_MAX_ASSEMBLIES + 1) * 32));
+    {
+        const int rcp = ensure_pinned_ctrl(h);
+        if (rcp != MXG_OK) return rcp;
+    }
     MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
     GraphBounds gb;
     uint64_t off = head_bytes;
@@ -2210,8 +2652,8 @@ int xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t
         up.pos = a->d_pos.as<uint32_t>();
         up.rec = a->d_rec.as<uint32_t>();
         up.n_dev = h->d_nmx.as<uint32_t>() + ai;
-        up.host_total = h->pinned_ctrl + 8 * ai;
-        h->pinned_ctrl[8 * ai] = 0xFFFFFFFFu;
+        up.host_total = h->pinned_ctrl + 16 * ai;
+        h->pinned_ctrl[16 * ai] = 0xFFFFFFFFu;
         hipLaunchKernelGGL(k_unpack_slot, dim3((uint32_t)std::max<uint64_t>((caps[ai] + 255) / 256, 1), world), dim3(256), 0,
                            h->stream, up);
         off += 16 * caps[ai];
@@ -2230,7 +2672,7 @@ int xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t
     if (rc != MXG_OK) return rc;
     bool bad = false;
     for (size_t ai = 0; ai < A; ++ai) {
-        const uint32_t t = h->pinned_ctrl[8 * ai];
+        const uint32_t t = h->pinned_ctrl[16 * ai];
         bad = bad || t == 0xFFFFFFFFu;
         h->asms[ai]->n_mx = t == 0xFFFFFFFFu ? 0 : t;
     }

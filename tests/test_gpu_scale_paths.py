@@ -107,3 +107,75 @@ def test_output_growth(oracle, knobs):
     recs = [("polyA", "A" * 30000), ("mix", "ACGT" * 5000), ("polyT", "T" * 12000)]
     _check(oracle, recs, 16, 50)
     _check(oracle, recs, 16, 50, dense_only=True)
+
+
+@pytest.fixture
+def dev_knobs(knobs):
+    saved = {k: os.environ.get(k) for k in ("MXG_DEV_GAPS", "MXG_DEV_CAND")}
+    yield knobs
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def _plain_records(seed, n_rec, lo, hi):
+    rng = random.Random(seed)
+    return [(f"r{r}", "".join(rng.choice("ACGT") for _ in range(rng.randint(lo, hi)))) for r in range(n_rec)]
+
+
+@pytest.mark.parametrize("cand,w,variant", [(5, 200, "v2"), (3, 500, "v2"), (8, 100, "v2"), (4, 300, "v1")])
+def test_stretches_fixed_up_on_the_device(oracle, dev_knobs, cand, w, variant):
+    """MXG_DEV_GAPS=1: the route genome-scale assemblies take (k_gap_fix / k_gap_post / k_merge_fin), forced on small random
+    records with few candidates per window so that hundreds of candidate-free stretches occur -- bit-exact against the
+    oracle, and the stretches were really sketched on the device (dense_kmers counts the k-mers hashed there)"""
+    dev_knobs["MXG_DEV_GAPS"] = "1"
+    recs = _plain_records(31, 12, 20_000, 90_000) + [("short", "ACGT" * 40)]
+    st = _check(oracle, recs, 32 if variant == "v2" else 25, w, cand_per_window=cand, variant=variant)
+    assert st["dense_kmers"] > 0 and st["candidates"] > 0
+
+
+def test_device_stretch_route_in_chained_batches(oracle, dev_knobs):
+    """several batches per assembly enqueued back to back on the two streams (the sum of the earlier batches travels
+    through a device word), with and without stretches, plus what the device route must hand back to the host: a
+    low-complexity island (more minimizers in one stretch than its region holds) and N-runs inside stretches"""
+    dev_knobs["MXG_DEV_GAPS"] = "1"
+    dev_knobs["MXG_SPARSE_BATCH_KMERS"] = "150000"
+    recs = _plain_records(32, 30, 15_000, 70_000)
+    st = _check(oracle, recs, 32, 200, cand_per_window=5)
+    assert st["dense_kmers"] > 0
+    st = _check(oracle, recs, 32, 200)            # 18 candidates per window: (almost) no stretch, chained all the same
+    assert st["candidates"] > 0
+    _check(oracle, _records(4), 32, 500, cand_per_window=2)   # islands + N-runs: falls back to the general route
+    dev_knobs["MXG_DEV_GAPS"] = "0"
+    _check(oracle, recs, 32, 200, cand_per_window=5)           # chained batches, stretches through the host route
+
+
+def test_two_assemblies_many_batches_and_graph(oracle, dev_knobs):
+    """two assemblies x several batches interleaved on the two streams, then the graph stage: same result as one batch each"""
+    from ntjoin_amd.engine import MxEngine
+    import numpy as np
+    recs_a = _plain_records(41, 25, 10_000, 50_000)
+    recs_b = [(f"b{i}", s[::-1].translate(str.maketrans("ACGT", "TGCA")) if i % 2 else s) for i, (_, s) in enumerate(recs_a)][::-1]
+    results = []
+    for batch, dev in (("1000000000", "0"), ("120000", "1"), ("90000", "0")):
+        dev_knobs["MXG_SPARSE_BATCH_KMERS"] = batch
+        dev_knobs["MXG_DEV_GAPS"] = dev
+        with MxEngine(k=32, w=150, cand_per_window=6) as eng:
+            eng.add_records("a", 2.0, recs_a)
+            eng.add_records("b", 1.0, recs_b)
+            eng.sketch(-2)
+            eng.build_graph()
+            results.append(([eng.get_sketch(a) for a in range(2)], eng.get_graph()))
+    for sks, g in results[1:]:
+        for a in range(2):
+            for key in ("out_hash", "pos", "record", "forward"):
+                assert np.array_equal(sks[a][key], results[0][0][a][key]), key
+        for key in ("vertex_hash", "edge_u", "edge_v", "edge_support", "edge_weight"):
+            assert np.array_equal(g[key], results[0][1][key]), key
+    first = results[0][0][0]["record_first"]
+    for r, (_, seq) in enumerate(recs_a[:5]):
+        want = oracle.sketch(seq, 32, 150)
+        lo, hi = int(first[r]), int(first[r + 1])
+        assert results[0][0][0]["out_hash"][lo:hi].tolist() == [x[0] for x in want]
