@@ -1259,7 +1259,8 @@ static uint64_t env_u64(const char *name, uint64_t dflt)
     return (e && *e) ? strtoull(e, nullptr, 10) : dflt;
 }
 #define DENSE_BATCH_KMERS env_u64("MXG_DENSE_BATCH_KMERS", 96ull << 20)    /* dense arena = 16 B per k-mer */
-#define SPARSE_BATCH_KMERS env_u64("MXG_SPARSE_BATCH_KMERS", 1024ull << 20) /* < 2^31 k-mers per batch */
+#define SPARSE_BATCH_KMERS env_u64("MXG_SPARSE_BATCH_KMERS", 512ull << 20) /* < 2^31 k-mers per batch; measured on MI355X
+   (3 Gbp + 3 Gbp, k=32 w=1000): 985 / 968 / 931 Gbp/s at 512 Mi / 1 Gi / 2040 Mi k-mers per batch */
 constexpr uint32_t GAP_CAP = 1u << 20;
 
 static hipError_t grow_preserve(DevBuf &b, size_t used_bytes, size_t need_bytes, hipStream_t st)
@@ -1686,13 +1687,14 @@ struct Driver {
         uint64_t nk;
         uint32_t r_lo, r_hi, strip_lo, strip_hi, n_strips, n_blocks, n_waves;
     };
-    void batch_geom(const Tables &T, size_t c0, BatchGeom &g) const
+    void batch_geom(const Tables &T, size_t c0, BatchGeom &g, uint64_t budget = 0) const
     {
         const size_t n_ctg = T.ctg_rec->size();
+        if (!budget) budget = SPARSE_BATCH_KMERS;
         g.c0 = c0;
         g.c1 = c0;
         g.nk = 0;
-        while (g.c1 < n_ctg && (g.c1 == c0 || g.nk + (*T.ctg_nk)[g.c1] <= SPARSE_BATCH_KMERS)) g.nk += (*T.ctg_nk)[g.c1++];
+        while (g.c1 < n_ctg && (g.c1 == c0 || g.nk + (*T.ctg_nk)[g.c1] <= budget)) g.nk += (*T.ctg_nk)[g.c1++];
         g.r_lo = (*T.ctg_run0)[g.c0];
         g.r_hi = (*T.ctg_run0)[g.c1];
         g.strip_lo = (*T.strip0_sparse)[g.r_lo];
@@ -2081,7 +2083,7 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
 // Sparse path: expected c candidates per window; it pays while candidates are a small fraction of k-mers.
 // c trades the work behind the hash kernel (linear in c) against candidate-free stretches (a candidate is followed by
 // one with probability e^-c).  With the stretches fixed up on the device (k_gap_fix) they are cheap, so large assemblies
-// run with c = 12 (a few hundred stretches per 10^9 k-mers); small ones keep c = 18, where a stretch (then handled by the
+// run with c = 10 (about 450 stretches per 10^9 k-mers at w = 1000); small ones keep c = 18, where a stretch (then handled by the
 // host-driven route) turns up once per ~4 x 10^9 k-mers, and save the three extra launches per batch.
 // mxg_config.cand_per_window fixes c; MXG_DEV_GAPS=0|1 forces the route (test / profiling knobs, read per call).
 struct SparsePlan {
@@ -2089,6 +2091,7 @@ struct SparsePlan {
     bool dev_gaps;
     double frac;
     uint32_t tau_hi;
+    uint64_t batch_kmers;  // device route: batches small enough for ~GAP_DEV_MAX / 4 expected stretches (0: the default size)
 };
 static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
 {
@@ -2097,11 +2100,18 @@ static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
     sp.dev_gaps = a && a->total_kmers >= big && h->cfg.w <= GAP_DEV_NMAX / 2;
     const char *e = getenv("MXG_DEV_GAPS");
     if (e && *e) sp.dev_gaps = atoi(e) != 0 && h->cfg.w <= GAP_DEV_NMAX / 2;
-    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : (sp.dev_gaps ? (uint32_t)env_u64("MXG_DEV_CAND", 12) : 18u);
+    // measured on MI355X (3 Gbp + 3 Gbp, w=1000, batches of 512 Mi k-mers): 941 / 985 / 945 / 897 Gbp/s at c = 8 / 10 / 12 / 14
+    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : (sp.dev_gaps ? (uint32_t)env_u64("MXG_DEV_CAND", 10) : 18u);
     sp.frac = (double)c / (double)h->cfg.w;
     // even: the threshold then falls on the top 31-bit ring of the hash, which is all the sparse kernel rolls
     sp.tau_hi = std::max(2u, (uint32_t)std::min<double>(4294967294.0, sp.frac * 4294967296.0) & ~1u);
     sp.sparse = !(h->cfg.flags & MXG_FLAG_DENSE_ONLY) && sp.frac <= 0.125;
+    sp.batch_kmers = 0;
+    if (sp.dev_gaps) {  // a candidate is followed by a stretch with probability e^-c
+        const double per_kmer = sp.frac * std::exp(-(double)c);
+        const double lim = (double)(GAP_DEV_MAX / 4) / std::max(per_kmer, 1e-30);
+        if (lim < (double)SPARSE_BATCH_KMERS) sp.batch_kmers = std::max<uint64_t>((uint64_t)lim, 1u << 20);
+    }
     return sp;
 }
 
@@ -2197,7 +2207,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         const size_t n_ctg = tabs[i].ctg_rec->size();
         for (size_t c0 = 0; c0 < n_ctg;) {
             Driver::BatchGeom g;
-            drv0.batch_geom(tabs[i], c0, g);
+            drv0.batch_geom(tabs[i], c0, g, plans[i].batch_kmers);
             gs.push_back(g);
             c0 = g.c1;
         }
