@@ -63,8 +63,9 @@ typedef struct mxg_config {
     int32_t device;        /* HIP device ordinal, -1 = current device                         */
     uint32_t flags;        /* MXG_FLAG_*                                                      */
     void *stream;          /* hipStream_t to launch on; NULL = the library creates its own    */
-    uint32_t cand_per_window; /* sparse path: expected candidates per window (0 = default 18) */
-    uint32_t reserved[5];
+    uint32_t cand_per_window; /* sparse path: expected candidates per window (0 = chosen by assembly size: 18 / 10) */
+    uint32_t host_threads;    /* worker threads for file ingest and output (`indexlr -t`); 0 = min(16, cores) */
+    uint32_t reserved[4];
 } mxg_config;
 
 /* host view of one assembly's ordered sketch: minimizer i is (out_hash[i], pos[i], record[i], strand[i]);

@@ -28,7 +28,7 @@ SYMBOLS = [
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("k", C.c_uint32), ("w", C.c_uint32), ("variant", C.c_uint32),
                 ("device", C.c_int32), ("flags", C.c_uint32), ("stream", C.c_void_p),
-                ("cand_per_window", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("cand_per_window", C.c_uint32), ("host_threads", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 class SketchView(C.Structure):

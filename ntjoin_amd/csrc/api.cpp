@@ -1,6 +1,7 @@
 // api.cpp -- extern "C" entry points of libntjoin_mx.so (declared in include/ntjoin_mx.h).
 #include <algorithm>
 #include <new>
+#include <thread>
 
 #include "mxg_internal.h"
 
@@ -140,7 +141,15 @@ int mxg_add_assembly_fasta(mxg_handle *h, const char *name, double weight, const
     if (rc != MXG_OK) return rc;
     if (!fasta_path) return commit(h, a, set_err(h, MXG_EINVAL, "fasta_path is NULL"));
     try {
-        rc = load_fasta(h, a, fasta_path);
+        // regular files: raw text to HBM, classified and packed there (ingest.hip); MXG_HOST_INGEST=1 keeps the host parser
+        rc = getenv("MXG_HOST_INGEST") ? 1 : load_fasta_device(h, a, fasta_path, host_threads(h));
+        if (rc == 1) {
+            Assembly *fresh;
+            delete a;
+            if ((rc = new_assembly(h, name, weight, &fresh)) != MXG_OK) return rc;
+            a = fresh;
+            rc = load_fasta(h, a, fasta_path);
+        }
     } catch (const std::bad_alloc &) {
         rc = set_err(h, MXG_ENOMEM, "out of host memory reading '%s'", fasta_path);
     }

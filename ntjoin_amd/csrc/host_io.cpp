@@ -158,8 +158,19 @@ struct Ingest {
         if (run_len >= k) rec_runs.emplace_back((uint32_t)(fpos - run_len), (uint32_t)(run_len - k + 1));
         run_len = 0;
     }
+    std::string no_cr;        // a line body with its carriage returns taken out
     void add_bases(const uint8_t *s, size_t n, bool keep_text)
     {
+        // CRLF files: a '\r' is never a base, wherever the read buffer happened to cut the line (a "\r\n" split between two
+        // 4 MiB reads used to leave the '\r' in the sequence: one invalid base, every later position off by one)
+        if (memchr(s, '\r', n)) {
+            no_cr.clear();
+            for (size_t i = 0; i < n; ++i)
+                if (s[i] != '\r') no_cr.push_back((char)s[i]);
+            s = reinterpret_cast<const uint8_t *>(no_cr.data());
+            n = no_cr.size();
+            if (!n) return;
+        }
         if (lengths_only && collect_runs) {  // pass 1 of a split load: valid runs of every record
             const uint8_t *lut = code_lut();
             for (size_t i = 0; i < n; ++i) {
@@ -692,6 +703,12 @@ struct OutBuf {
 
 int write_tsv(mxg_handle *h, Assembly *a, const char *path, int with_pos, int with_strand, int with_seq)
 {
+    // Text formatted on the device (ingest.hip) unless the k-mer column must come from text kept on the HOST (records
+    // handed over in buffers, sharded loads) or nothing on the device can spell the k-mers.  MXG_HOST_TSV=1: host writer.
+    const bool whole = a->shard_lo == 0 && a->shard_hi >= a->recs.size();
+    if (a->has_sketch && !a->has_text && whole && h->cfg.k <= 200 && !getenv("MXG_HOST_TSV") &&
+        (!with_seq || a->text_on_device || (a->has_bases && a->d_packed && !a->foreign_sketch)))
+        return write_tsv_device(h, a, path, with_pos, with_strand, with_seq);
     int rc = sync_sketch_to_host(h, a);
     if (rc != MXG_OK) return rc;
     const uint32_t k = h->cfg.k;

@@ -22,7 +22,7 @@ static void usage(FILE *f)
           "  --strand       print minimizer strands              (hash[:pos]:+|-)\n"
           "  --seq          print minimizer k-mer sequences      (hash[:pos][:strand]:seq)\n"
           "  --long         accepted for compatibility (records are sketched on the GPU regardless of length)\n"
-          "  -t T           accepted for compatibility (thread count; the GPU does the work)\n"
+          "  -t T           host worker threads for reading the FASTA / writing the TSV (the GPU does the hashing)\n"
           "  -o FILE        write to FILE instead of stdout\n"
           "  --variant v2|v1   canonical hash: v2 = fwd+rev (current btllib, default), v1 = min(fwd,rev)\n"
           "  --device N     HIP device ordinal (default: current)\n"
@@ -53,7 +53,7 @@ static bool opt_val(int argc, char **argv, int &i, const char *name, const char 
 
 int main(int argc, char **argv)
 {
-    unsigned k = 0, w = 0;
+    unsigned k = 0, w = 0, threads = 0;
     int with_pos = 0, with_strand = 0, with_seq = 0, verbose = 0, device = -1, dense = 0;
     unsigned variant = MXG_VARIANT_V2_SUM;
     const char *out = "-", *in = nullptr, *v = nullptr;
@@ -69,7 +69,7 @@ int main(int argc, char **argv)
         else if (opt_val(argc, argv, i, "--device", &v)) device = atoi(v);
         else if (opt_val(argc, argv, i, "-k", &v)) k = (unsigned)strtoul(v, nullptr, 10);
         else if (opt_val(argc, argv, i, "-w", &v)) w = (unsigned)strtoul(v, nullptr, 10);
-        else if (opt_val(argc, argv, i, "-t", &v)) { /* accepted */ }
+        else if (opt_val(argc, argv, i, "-t", &v)) threads = (unsigned)strtoul(v, nullptr, 10);
         else if (opt_val(argc, argv, i, "-o", &v)) out = v;
         else if (argv[i][0] == '-' && argv[i][1] != 0) {
             fprintf(stderr, "indexlr: unknown option '%s'\n", argv[i]);
@@ -94,6 +94,7 @@ int main(int argc, char **argv)
     cfg.variant = variant;
     cfg.device = device;
     cfg.flags = dense ? MXG_FLAG_DENSE_ONLY : 0;
+    cfg.host_threads = threads;  // `-t`: workers that move the FASTA text to the GPU and the TSV text out (reference ntJoin:205)
     mxg_handle *h = nullptr;
     int rc = mxg_create(&cfg, &h);
     if (rc != MXG_OK) {

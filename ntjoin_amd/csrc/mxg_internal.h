@@ -81,6 +81,11 @@ struct Assembly {
     std::string text;                // concatenated record text as read (kept unless MXG_FLAG_DROP_SEQ)
     bool has_text = false;
     std::vector<uint32_t> h_packed;  // host 2-bit packing (dropped after upload)
+    // device ingest (ingest.hip): the raw FASTA text in HBM + the tile index that maps a base to its byte
+    bool text_on_device = false;
+    uint64_t text_bytes = 0;
+    DevBuf d_text, d_ing_items, d_ing_cnt, d_ing_sub, d_ing_pbase, d_ing_item0;
+    std::vector<uint64_t> ing_item0;  // [n_records + 1] first tile of every record
     DevBuf d_packed_own;
     const uint32_t *d_packed = nullptr;  // owned (above) or borrowed
     uint64_t packed_words = 0;
@@ -236,6 +241,10 @@ int load_tsv(mxg_handle *h, Assembly *a, const char *path, std::vector<uint64_t>
              std::vector<uint32_t> &pos, std::vector<uint32_t> &rec);
 void build_runs_from_lengths(mxg_handle *h, Assembly *a);  // N-free packed-device input
 int write_tsv(mxg_handle *h, Assembly *a, const char *path, int with_pos, int with_strand, int with_seq);
+// ingest.hip: FASTA -> packed bases + run table on the device (1: not for this route, use load_fasta); TSV text on the device
+int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_threads);
+int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos, int with_strand, int with_seq);
+uint32_t host_threads(const mxg_handle *h);
 int write_dot(mxg_handle *h, const char *path);
 void build_rec_first(Assembly *a);
 std::string py_repr_str(const std::string &s);

@@ -32,7 +32,7 @@ def _np(ptr, n, dtype):
 
 class MxEngine:
     def __init__(self, k=32, w=1000, variant="v2", device=-1, stream=None, dense_only=False, drop_seq=False,
-                 timing=False, cand_per_window=0, timing_fine=False):
+                 timing=False, cand_per_window=0, timing_fine=False, threads=0):
         self._lib = capi.load()
         self._h = C.c_void_p()
         cfg = capi.Config()
@@ -44,6 +44,7 @@ class MxEngine:
                      (capi.FLAG_TIMING if timing else 0) | (capi.FLAG_TIMING_FINE if timing_fine else 0))
         cfg.stream = C.c_void_p(stream) if stream else None
         cfg.cand_per_window = int(cand_per_window)
+        cfg.host_threads = int(threads)
         rc = self._lib.mxg_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             raise MxError(rc, (self._lib.mxg_last_error(None) or b"").decode())
