@@ -2,10 +2,14 @@
 // TSV / .mx.dot writers.  Text formats follow the reference exactly:
 //   TSV grammar           ntJoin:205 (`indexlr --seq --long --pos`), parsed at bin/ntjoin_utils.py:173-185
 //   .mx.dot grammar       bin/ntjoin.py:25-62 (python repr() of (contig,pos) tuples and float weights)
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <charconv>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
+#include <thread>
 
 #include "mxg_internal.h"
 
@@ -532,68 +536,138 @@ static inline bool is_py_space(char c)
     return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f';
 }
 
+// One line of the TSV as read_minimizers takes it apart (bin/ntjoin_utils.py:173-185); [b, e) excludes the '\n'.
+// Returns 0, or -1 with *bad pointing at the offending entry (msg says why).
+struct TsvPart {
+    std::vector<Record> recs;
+    std::vector<uint64_t> hash;
+    std::vector<uint32_t> pos, rec;  // rec: index into this part's recs
+    const char *bad = nullptr, *bad_end = nullptr;
+    int bad_kind = 0;  // 1: not three fields, 2: not <u64>:<u32>:<seq>
+};
+
+static int parse_tsv_line(const char *b, const char *e, TsvPart &out)
+{
+    // line.strip()
+    while (b < e && is_py_space(*b)) ++b;
+    while (e > b && is_py_space(e[-1])) --e;
+    // .split("\t"): need field 0 and field 1
+    const char *t1 = (const char *)memchr(b, '\t', (size_t)(e - b));
+    if (!t1) return 0;  // len(line) == 1 : record without minimizers is skipped (:176)
+    const char *f1 = t1 + 1;
+    const char *t2 = (const char *)memchr(f1, '\t', (size_t)(e - f1));
+    const char *f1e = t2 ? t2 : e;
+    Record r;
+    r.id.assign(b, (size_t)(t1 - b));
+    const uint32_t ridx = (uint32_t)out.recs.size();
+    out.recs.push_back(r);
+    const char *p = f1;  // field 1 .split(" ")
+    while (true) {
+        const char *sp = (const char *)memchr(p, ' ', (size_t)(f1e - p));
+        const char *ee = sp ? sp : f1e;
+        // entry.split(":") must have exactly three fields (mx, pos, seq) at HEAD (:181)
+        const char *c1 = (const char *)memchr(p, ':', (size_t)(ee - p));
+        const char *c2 = c1 ? (const char *)memchr(c1 + 1, ':', (size_t)(ee - c1 - 1)) : nullptr;
+        const char *c3 = c2 ? (const char *)memchr(c2 + 1, ':', (size_t)(ee - c2 - 1)) : nullptr;
+        if (!c1 || !c2 || c3) {
+            out.bad = p;
+            out.bad_end = ee;
+            out.bad_kind = 1;
+            return -1;
+        }
+        uint64_t hv = 0;
+        auto r1 = std::from_chars(p, c1, hv);
+        uint32_t pv = 0;
+        auto r2 = std::from_chars(c1 + 1, c2, pv);
+        if (r1.ec != std::errc() || r1.ptr != c1 || p == c1 || r2.ec != std::errc() || r2.ptr != c2 || c1 + 1 == c2) {
+            out.bad = p;
+            out.bad_end = ee;
+            out.bad_kind = 2;
+            return -1;
+        }
+        out.hash.push_back(hv);
+        out.pos.push_back(pv);
+        out.rec.push_back(ridx);
+        if (!sp) break;
+        p = sp + 1;
+    }
+    return 0;
+}
+
+// the parse half of read_minimizers on `host_threads` workers: the file is cut at line ends into one piece per worker
+// (the reference parses ~65 bytes of text per minimizer in Python, 5.7 us each: SURVEY.md 6)
 int load_tsv(mxg_handle *h, Assembly *a, const char *path, std::vector<uint64_t> &hash,
              std::vector<uint32_t> &pos, std::vector<uint32_t> &rec)
 {
     FILE *f = fopen(path, "rb");
     if (!f) return set_err(h, MXG_EIO, "cannot open TSV '%s'", path);
-    char *line = nullptr;
-    size_t cap = 0;
-    ssize_t ll;
-    uint64_t lineno = 0;
-    int rc = MXG_OK;
-    while (rc == MXG_OK && (ll = getline(&line, &cap, f)) >= 0) {
-        ++lineno;
-        // line.strip()
-        char *b = line, *e = line + ll;
-        while (b < e && is_py_space(*b)) ++b;
-        while (e > b && is_py_space(e[-1])) --e;
-        // .split("\t"): need field 0 and field 1
-        char *t1 = (char *)memchr(b, '\t', (size_t)(e - b));
-        if (!t1) continue;  // len(line) == 1 : record without minimizers is skipped (:176)
-        char *f1 = t1 + 1;
-        char *t2 = (char *)memchr(f1, '\t', (size_t)(e - f1));
-        char *f1e = t2 ? t2 : e;
-        Record r;
-        r.id.assign(b, (size_t)(t1 - b));
-        uint32_t ridx = (uint32_t)a->recs.size();
-        a->recs.push_back(r);
-        // field 1 .split(" ")
-        char *p = f1;
-        while (true) {
-            char *sp = (char *)memchr(p, ' ', (size_t)(f1e - p));
-            char *ee = sp ? sp : f1e;
-            // entry.split(":") must have exactly three fields (mx, pos, seq) at HEAD (:181)
-            char *c1 = (char *)memchr(p, ':', (size_t)(ee - p));
-            char *c2 = c1 ? (char *)memchr(c1 + 1, ':', (size_t)(ee - c1 - 1)) : nullptr;
-            char *c3 = c2 ? (char *)memchr(c2 + 1, ':', (size_t)(ee - c2 - 1)) : nullptr;
-            if (!c1 || !c2 || c3) {
-                rc = set_err(h, MXG_EIO,
-                             "%s:%llu: entry '%.*s' does not have exactly three ':'-separated fields "
-                             "(hash:pos:seq), as ntJoin's read_minimizers requires",
-                             path, (unsigned long long)lineno, (int)std::min<ptrdiff_t>(ee - p, 60), p);
-                break;
-            }
-            uint64_t hv = 0;
-            auto r1 = std::from_chars(p, c1, hv);
-            uint32_t pv = 0;
-            auto r2 = std::from_chars(c1 + 1, c2, pv);
-            if (r1.ec != std::errc() || r1.ptr != c1 || p == c1 || r2.ec != std::errc() || r2.ptr != c2 ||
-                c1 + 1 == c2) {
-                rc = set_err(h, MXG_EIO, "%s:%llu: cannot parse '%.*s' as <u64 hash>:<u32 pos>:<seq>", path,
-                             (unsigned long long)lineno, (int)std::min<ptrdiff_t>(ee - p, 60), p);
-                break;
-            }
-            hash.push_back(hv);
-            pos.push_back(pv);
-            rec.push_back(ridx);
-            if (!sp) break;
-            p = sp + 1;
+    std::string text;
+    {
+        char buf[1 << 16];
+        struct stat sb;
+        if (fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) text.reserve((size_t)sb.st_size);
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, got);
+    }
+    const bool rerr = ferror(f) != 0;
+    fclose(f);
+    if (rerr) return set_err(h, MXG_EIO, "read error on '%s'", path);
+    const char *t0 = text.data();
+    const size_t n = text.size();
+    uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(host_threads(h), (uint32_t)(n / (1 << 20)) + 1));
+    std::vector<size_t> cut(T + 1, n);
+    cut[0] = 0;
+    for (uint32_t t = 1; t < T; ++t) {
+        size_t c = std::max(cut[t - 1], n * t / T);
+        const char *nl = c < n ? (const char *)memchr(t0 + c, '\n', n - c) : nullptr;
+        cut[t] = nl ? (size_t)(nl - t0) + 1 : n;
+    }
+    std::vector<TsvPart> parts(T);
+    auto work = [&](uint32_t t) {
+        const char *p = t0 + cut[t], *end = t0 + cut[t + 1];
+        while (p < end) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+            const char *e = nl ? nl : end;
+            if (parse_tsv_line(p, e, parts[t]) != 0) return;
+            p = nl ? nl + 1 : end;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint32_t t = 1; t < T; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (uint32_t t = 0; t < T; ++t) {
+        const TsvPart &pt = parts[t];
+        if (pt.bad) {
+            const unsigned long long lineno = 1ull + (unsigned long long)std::count(t0, pt.bad, '\n');
+            const int len = (int)std::min<ptrdiff_t>(pt.bad_end - pt.bad, 60);
+            if (pt.bad_kind == 1)
+                return set_err(h, MXG_EIO,
+                               "%s:%llu: entry '%.*s' does not have exactly three ':'-separated fields "
+                               "(hash:pos:seq), as ntJoin's read_minimizers requires",
+                               path, lineno, len, pt.bad);
+            return set_err(h, MXG_EIO, "%s:%llu: cannot parse '%.*s' as <u64 hash>:<u32 pos>:<seq>", path, lineno, len, pt.bad);
         }
     }
-    free(line);
-    fclose(f);
-    return rc;
+    size_t n_mx = 0, n_rec = 0;
+    for (auto &pt : parts) {
+        n_mx += pt.hash.size();
+        n_rec += pt.recs.size();
+    }
+    hash.reserve(n_mx);
+    pos.reserve(n_mx);
+    rec.reserve(n_mx);
+    a->recs.reserve(a->recs.size() + n_rec);
+    for (auto &pt : parts) {
+        const uint32_t r0 = (uint32_t)a->recs.size();
+        for (auto &r : pt.recs) a->recs.push_back(std::move(r));
+        hash.insert(hash.end(), pt.hash.begin(), pt.hash.end());
+        pos.insert(pos.end(), pt.pos.begin(), pt.pos.end());
+        for (uint32_t r : pt.rec) rec.push_back(r0 + r);
+    }
+    return MXG_OK;
 }
 
 void build_rec_first(Assembly *a)
@@ -673,6 +747,10 @@ struct OutBuf {
     explicit OutBuf(FILE *f_) : f(f_), b(1 << 22) {}
     inline void room(size_t need)
     {
+        if (!f) {  // memory only: grows (the parallel .mx.dot writer formats chunks into such buffers)
+            if (n + need > b.size()) b.resize(std::max(b.size() * 2, n + need));
+            return;
+        }
         if (n + need > b.size()) flush();
         if (need > b.size()) b.resize(need * 2);
     }
@@ -773,53 +851,79 @@ int write_dot(mxg_handle *h, const char *path)
     const uint32_t A = g.n_asm;
     FILE *f = fopen(path, "wb");
     if (!f) return set_err(h, MXG_EIO, "cannot open '%s' for writing", path);
-    OutBuf o(f);
-    o.put("graph G {\n");
-    // label line per assembly: f"{file_name}_{(contig, pos)}"  (bin/ntjoin.py:43-47)
+    // label line per assembly: f"{file_name}_{(contig, pos)}"  (bin/ntjoin.py:43-47); python repr() of every record id once
     std::vector<std::vector<std::string>> rec_repr(A);
     for (uint32_t a = 0; a < A; ++a) {
         rec_repr[a].resize(h->asms[a]->recs.size());
+        for (size_t r = 0; r < rec_repr[a].size(); ++r) rec_repr[a][r] = py_repr_str(h->asms[a]->recs[r].id);
     }
-    for (uint64_t v = 0; v < g.nv; ++v) {
-        o.put('"');
-        o.put_u64(g.vhash[v]);
-        o.put("\" [label=\"", 10);
-        o.put_u64(g.vhash[v]);
-        for (uint32_t a = 0; a < A; ++a) {
-            o.put('\n');
-            o.put(h->asms[a]->name);
-            o.put("_(", 2);
-            uint32_t r = g.vrec[(uint64_t)a * g.nv + v];
-            std::string &rr = rec_repr[a][r];
-            if (rr.empty()) rr = py_repr_str(h->asms[a]->recs[r].id);
-            o.put(rr);
-            o.put(", ", 2);
-            o.put_u64(g.vpos[(uint64_t)a * g.nv + v]);
-            o.put(')');
+    auto vertices = [&](uint64_t v0, uint64_t v1, OutBuf &o) {
+        for (uint64_t v = v0; v < v1; ++v) {
+            o.put('"');
+            o.put_u64(g.vhash[v]);
+            o.put("\" [label=\"", 10);
+            o.put_u64(g.vhash[v]);
+            for (uint32_t a = 0; a < A; ++a) {
+                o.put('\n');
+                o.put(h->asms[a]->name);
+                o.put("_(", 2);
+                o.put(rec_repr[a][g.vrec[(uint64_t)a * g.nv + v]]);
+                o.put(", ", 2);
+                o.put_u64(g.vpos[(uint64_t)a * g.nv + v]);
+                o.put(')');
+            }
+            o.put("\"]\n", 3);
         }
-        o.put("\"]\n", 3);
+    };
+    auto edges = [&](uint64_t e0, uint64_t e1, OutBuf &o) {
+        for (uint64_t e = e0; e < e1; ++e) {
+            o.put('"');
+            o.put_u64(g.vhash[g.eu[e]]);
+            o.put("\" --\"", 5);
+            o.put_u64(g.vhash[g.ev[e]]);
+            o.put("\" [weight=", 10);
+            o.put(py_repr_float(g.ew[e]));
+            o.put(" color=", 7);
+            const uint32_t m = g.esup[e];
+            const int pc = __builtin_popcount(m);
+            const char *col;
+            if (pc == 1) col = (A > 10) ? "red" : COLOURS[__builtin_ctz(m)];
+            else if (pc == 2) col = "lightgrey";
+            else col = "black";
+            o.put(col, strlen(col));
+            o.put("]\n", 2);
+        }
+    };
+    // ~200 bytes per vertex and ~75 per edge (1.2 GB at 3 Gbp + 3 Gbp): chunks formatted by `host_threads` workers into
+    // memory, written out in order
+    const uint32_t T = std::max(1u, host_threads(h));
+    constexpr uint64_t CH = 1u << 16;
+    std::vector<OutBuf> bufs;
+    bufs.reserve(T);
+    for (uint32_t t = 0; t < T; ++t) {
+        bufs.emplace_back(nullptr);
+        bufs.back().b.resize(1 << 20);
     }
-    std::vector<std::string> wrepr;  // weight repr cache by support mask is not safe (>32 masks) -> format each
-    for (uint64_t e = 0; e < g.ne; ++e) {
-        o.put('"');
-        o.put_u64(g.vhash[g.eu[e]]);
-        o.put("\" --\"", 5);
-        o.put_u64(g.vhash[g.ev[e]]);
-        o.put("\" [weight=", 10);
-        o.put(py_repr_float(g.ew[e]));
-        o.put(" color=", 7);
-        uint32_t m = g.esup[e];
-        int pc = __builtin_popcount(m);
-        const char *col;
-        if (pc == 1) col = (A > 10) ? "red" : COLOURS[__builtin_ctz(m)];
-        else if (pc == 2) col = "lightgrey";
-        else col = "black";
-        o.put(col, strlen(col));
-        o.put("]\n", 2);
-    }
-    o.put("}\n", 2);
-    o.flush();
-    bool ok = o.ok;
+    bool ok = fwrite("graph G {\n", 1, 10, f) == 10;
+    auto run = [&](uint64_t n_items, const std::function<void(uint64_t, uint64_t, OutBuf &)> &fmt) {
+        for (uint64_t base = 0; base < n_items && ok; base += CH * T) {
+            auto work = [&](uint32_t t) {
+                const uint64_t lo = base + (uint64_t)t * CH, hi = std::min(n_items, lo + CH);
+                bufs[t].n = 0;
+                if (lo < hi) fmt(lo, hi, bufs[t]);
+            };
+            std::vector<std::thread> th;
+            const uint32_t used = (uint32_t)std::min<uint64_t>(T, (n_items - base + CH - 1) / CH);
+            for (uint32_t t = 1; t < used; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+            for (uint32_t t = 0; t < used && ok; ++t)
+                if (bufs[t].n) ok = fwrite(bufs[t].b.data(), 1, bufs[t].n, f) == bufs[t].n;
+        }
+    };
+    run(g.nv, vertices);
+    run(g.ne, edges);
+    ok = ok && fwrite("}\n", 1, 2, f) == 2;
     ok = (fclose(f) == 0) && ok;
     if (!ok) return set_err(h, MXG_EIO, "write error on '%s'", path);
     return MXG_OK;

@@ -17,7 +17,7 @@ import numpy as np
 
 from . import capi
 from .engine import MxEngine
-from .ntjoin_utils import MxGraph
+from .ntjoin_utils import MxGraph, sketch_views
 
 COLOURS = ["red", "green", "blue", "purple", "orange", "turquoise", "pink", "yellow", "orchid", "salmon"]
 
@@ -75,6 +75,16 @@ class Ntjoin:
         eng = self._engine
         eng.build_graph()
         g = eng.get_graph()
+        if materialize == "views":
+            # array-backed state for genome-scale inputs: same objects to index and iterate, no per-minimizer Python work
+            self.graph = MxGraph.from_arrays(g["vertex_hash"], g["edge_u"], g["edge_v"], g["edge_support"], g["edge_weight"],
+                                             self._order)
+            for a, assembly in enumerate(self._order):
+                sk = eng.get_sketch(a)
+                uniq = (eng.get_mx_flags(a) & capi.MX_UNIQUE) != 0
+                self.list_mx_info[assembly], self.list_mxs[assembly] = sketch_views(sk, uniq)
+            self.print_graph(self.graph)
+            return
         names = [str(h) for h in g["vertex_hash"].tolist()]
         support = [[self._order[b] for b in range(len(self._order)) if m >> b & 1] for m in g["edge_support"].tolist()]
         self.graph = MxGraph(names, zip(g["edge_u"].tolist(), g["edge_v"].tolist()), support,

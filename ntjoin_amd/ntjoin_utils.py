@@ -16,6 +16,7 @@ offers the small part of the igraph API the reference touches on this path.
 """
 import datetime
 import sys
+from collections.abc import Mapping, Sequence
 
 import numpy as np
 
@@ -23,10 +24,108 @@ from .engine import MxEngine, MxError
 from . import capi
 
 
+class MxInfo(Mapping):
+    """`mx_info` of the reference (hash string -> (contig, position), bin/ntjoin_utils.py:187-192) as a read-only mapping
+    over numpy arrays: at 6 M minimizers per assembly a real dict of Python strings and tuples costs seconds and ~1 GB;
+    this costs one argsort.  Keys may be given as decimal strings (the reference's spelling) or ints.  Picklable."""
+
+    def __init__(self, out_hash, pos, record, record_ids):
+        order = np.argsort(out_hash, kind="stable")
+        self.hash = np.ascontiguousarray(out_hash[order])
+        self.pos = np.ascontiguousarray(pos[order])
+        self.record = np.ascontiguousarray(record[order])
+        self.record_ids = list(record_ids)
+
+    def _find(self, key):
+        try:
+            v = np.uint64(int(key))
+        except (TypeError, ValueError, OverflowError):
+            return -1
+        i = int(np.searchsorted(self.hash, v))
+        return i if i < len(self.hash) and self.hash[i] == v else -1
+
+    def __getitem__(self, key):
+        i = self._find(key)
+        if i < 0:
+            raise KeyError(key)
+        return (self.record_ids[int(self.record[i])], int(self.pos[i]))
+
+    def __contains__(self, key):
+        return self._find(key) >= 0
+
+    def __len__(self):
+        return len(self.hash)
+
+    def __iter__(self):
+        return (str(h) for h in self.hash.tolist())
+
+    def to_dict(self):
+        return {str(h): (self.record_ids[r], p) for h, r, p in zip(self.hash.tolist(), self.record.tolist(), self.pos.tolist())}
+
+
+class MxLists(Sequence):
+    """`mxs` of the reference (per contig the ordered list of hash strings, bin/ntjoin_utils.py:178,193) over one hash
+    array + offsets; item i materialises contig i's list of decimal strings on demand.  .hashes / .offsets are the arrays."""
+
+    def __init__(self, hashes, offsets):
+        self.hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return [str(x) for x in self.hashes[self.offsets[i]:self.offsets[i + 1]].tolist()]
+
+    def to_lists(self):
+        return [self[i] for i in range(len(self))]
+
+
 class MxGraph:
     """Undirected minimizer graph: vertices = decimal-string hashes, edge attributes support / weight."""
 
+    @classmethod
+    def from_arrays(cls, vertex_hash, edge_u, edge_v, edge_support, edge_weight, assembly_names):
+        """the same container over the engine's arrays: names, index and support lists are built on first use, so a
+        4.5 M-vertex graph (3 Gbp + 3 Gbp) costs nothing until somebody asks for strings"""
+        g = cls.__new__(cls)
+        g.vertex_hash = np.ascontiguousarray(vertex_hash, dtype=np.uint64)
+        g.edge_u, g.edge_v = np.ascontiguousarray(edge_u), np.ascontiguousarray(edge_v)
+        g.edge_support_mask = np.ascontiguousarray(edge_support)
+        g.edge_weight = np.ascontiguousarray(edge_weight, dtype=np.float64)
+        g.assembly_names = list(assembly_names)
+        g._lazy = True
+        return g
+
+    def __getattr__(self, name):
+        # (only reached for attributes not set yet: the lazily built views of from_arrays)
+        if name.startswith("__") or not self.__dict__.get("_lazy"):
+            raise AttributeError(name)
+        if name == "names":
+            self.names = [str(h) for h in self.vertex_hash.tolist()]
+        elif name == "_index":
+            self._index = {n: i for i, n in enumerate(self.names)}
+        elif name == "edges":
+            self.edges = list(zip(self.edge_u.tolist(), self.edge_v.tolist()))
+        elif name == "support":
+            nm = self.assembly_names
+            self.support = [[nm[b] for b in range(len(nm)) if m >> b & 1] for m in self.edge_support_mask.tolist()]
+        elif name == "weight":
+            self.weight = self.edge_weight.tolist()
+        elif name == "_eid":
+            self._eid = {(min(s, t), max(s, t)): e for e, (s, t) in enumerate(self.edges)}
+        else:
+            raise AttributeError(name)
+        return self.__dict__[name]
+
     def __init__(self, names, edges, support, weight):
+        self._lazy = False
         self.names = list(names)                  # vertex id -> name
         self._index = {n: i for i, n in enumerate(self.names)}
         self.edges = [(int(s), int(t)) for s, t in edges]  # (source id, target id), first-seen orientation
@@ -37,10 +136,10 @@ class MxGraph:
             self._eid[(min(s, t), max(s, t))] = e
 
     def vcount(self):
-        return len(self.names)
+        return len(self.vertex_hash) if self.__dict__.get("_lazy") else len(self.names)
 
     def ecount(self):
-        return len(self.edges)
+        return len(self.edge_u) if self.__dict__.get("_lazy") else len(self.edges)
 
     def vertex_index(self, name):
         return self._index[name]
@@ -88,8 +187,10 @@ def _lists_from_sketch(sk, keep):
     return out
 
 
-def read_minimizers(tsv_filename, repeat_bf=False, k=32):
-    "Read the minimizers from a file, removing duplicate minimizers"
+def read_minimizers(tsv_filename, repeat_bf=False, k=32, views=False):
+    """Read the minimizers from a file, removing duplicate minimizers.
+    views=True: the same two objects as array-backed views (MxInfo, MxLists) instead of a dict and lists of Python strings --
+    what a 3 Gbp assembly needs (6 M minimizers: ~0.2 s instead of ~15 s; SURVEY.md B2 "numpy views at scale")."""
     print(datetime.datetime.today(), ": Reading minimizers", tsv_filename, file=sys.stdout)
     if repeat_bf:
         raise NotImplementedError("repeat_bf is never supplied on ntJoin's own path (bin/ntjoin.py:178)")
@@ -107,9 +208,21 @@ def read_minimizers(tsv_filename, repeat_bf=False, k=32):
         raise
     uniq = (flags & capi.MX_UNIQUE) != 0
     ids = sk["record_ids"]
+    if views:
+        return sketch_views(sk, uniq)
     mx_info = {str(h): (ids[r], int(p)) for h, p, r in
                zip(sk["out_hash"][uniq].tolist(), sk["pos"][uniq].tolist(), sk["record"][uniq].tolist())}
     return mx_info, _lists_from_sketch(sk, uniq)
+
+
+def sketch_views(sk, uniq):
+    """(MxInfo, MxLists) of one assembly from its sketch arrays and the "occurs once in this assembly" mask"""
+    first = sk["record_first"].astype(np.int64)
+    kept_before = np.concatenate(([0], np.cumsum(uniq, dtype=np.int64)))
+    has = first[1:] > first[:-1]  # only records with at least one entry appear in the reference's `mxs` (:176)
+    offs = np.concatenate((kept_before[first[:-1]][has], [kept_before[-1]])) if has.any() else np.zeros(1, dtype=np.int64)
+    return (MxInfo(sk["out_hash"][uniq], sk["pos"][uniq], sk["record"][uniq], sk["record_ids"]),
+            MxLists(sk["out_hash"][uniq], offs))
 
 
 def _engine_from_lists(list_mxs, weights=None):
