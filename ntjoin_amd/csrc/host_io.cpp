@@ -2,9 +2,12 @@
 // TSV / .mx.dot writers.  Text formats follow the reference exactly:
 //   TSV grammar           ntJoin:205 (`indexlr --seq --long --pos`), parsed at bin/ntjoin_utils.py:173-185
 //   .mx.dot grammar       bin/ntjoin.py:25-62 (python repr() of (contig,pos) tuples and float weights)
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdlib>
@@ -601,19 +604,38 @@ int load_tsv(mxg_handle *h, Assembly *a, const char *path, std::vector<uint64_t>
 {
     FILE *f = fopen(path, "rb");
     if (!f) return set_err(h, MXG_EIO, "cannot open TSV '%s'", path);
+    // a regular file is mapped (the workers then parse straight out of the page cache); anything else is read
     std::string text;
-    {
+    const char *t0 = nullptr;
+    size_t n = 0;
+    void *map = MAP_FAILED;
+    struct stat sb;
+    if (fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+        map = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+        if (map != MAP_FAILED) {
+            t0 = static_cast<const char *>(map);
+            n = (size_t)sb.st_size;
+        }
+    }
+    bool rerr = false;
+    if (map == MAP_FAILED) {
         char buf[1 << 16];
-        struct stat sb;
-        if (fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) text.reserve((size_t)sb.st_size);
         size_t got;
         while ((got = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, got);
+        rerr = ferror(f) != 0;
+        t0 = text.data();
+        n = text.size();
     }
-    const bool rerr = ferror(f) != 0;
     fclose(f);
+    struct Unmap {
+        void *p;
+        size_t n;
+        ~Unmap()
+        {
+            if (p != MAP_FAILED) munmap(p, n);
+        }
+    } unmap{map, n};
     if (rerr) return set_err(h, MXG_EIO, "read error on '%s'", path);
-    const char *t0 = text.data();
-    const size_t n = text.size();
     uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(host_threads(h), (uint32_t)(n / (1 << 20)) + 1));
     std::vector<size_t> cut(T + 1, n);
     cut[0] = 0;
@@ -905,25 +927,52 @@ int write_dot(mxg_handle *h, const char *path)
         bufs.back().b.resize(1 << 20);
     }
     bool ok = fwrite("graph G {\n", 1, 10, f) == 10;
+    ok = fflush(f) == 0 && ok;
+    const int fd = fileno(f);
+    uint64_t file_off = 10;
+    // a round: every worker formats its chunk, then writes it at its own offset (pwrite: the copies into the page cache
+    // run in parallel too)
     auto run = [&](uint64_t n_items, const std::function<void(uint64_t, uint64_t, OutBuf &)> &fmt) {
         for (uint64_t base = 0; base < n_items && ok; base += CH * T) {
+            const uint32_t used = (uint32_t)std::min<uint64_t>(T, (n_items - base + CH - 1) / CH);
             auto work = [&](uint32_t t) {
                 const uint64_t lo = base + (uint64_t)t * CH, hi = std::min(n_items, lo + CH);
                 bufs[t].n = 0;
                 if (lo < hi) fmt(lo, hi, bufs[t]);
             };
-            std::vector<std::thread> th;
-            const uint32_t used = (uint32_t)std::min<uint64_t>(T, (n_items - base + CH - 1) / CH);
-            for (uint32_t t = 1; t < used; ++t) th.emplace_back(work, t);
-            work(0);
-            for (auto &x : th) x.join();
-            for (uint32_t t = 0; t < used && ok; ++t)
-                if (bufs[t].n) ok = fwrite(bufs[t].b.data(), 1, bufs[t].n, f) == bufs[t].n;
+            {
+                std::vector<std::thread> th;
+                for (uint32_t t = 1; t < used; ++t) th.emplace_back(work, t);
+                work(0);
+                for (auto &x : th) x.join();
+            }
+            std::vector<uint64_t> at(used + 1, file_off);
+            for (uint32_t t = 0; t < used; ++t) at[t + 1] = at[t] + bufs[t].n;
+            std::atomic<bool> good{true};
+            auto put = [&](uint32_t t) {
+                size_t done = 0;
+                while (done < bufs[t].n) {
+                    const ssize_t wr = pwrite(fd, bufs[t].b.data() + done, bufs[t].n - done, (off_t)(at[t] + done));
+                    if (wr <= 0) {
+                        good = false;
+                        return;
+                    }
+                    done += (size_t)wr;
+                }
+            };
+            {
+                std::vector<std::thread> th;
+                for (uint32_t t = 1; t < used; ++t) th.emplace_back(put, t);
+                put(0);
+                for (auto &x : th) x.join();
+            }
+            ok = ok && good;
+            file_off = at[used];
         }
     };
     run(g.nv, vertices);
     run(g.ne, edges);
-    ok = ok && fwrite("}\n", 1, 2, f) == 2;
+    ok = ok && pwrite(fd, "}\n", 2, (off_t)file_off) == 2;
     ok = (fclose(f) == 0) && ok;
     if (!ok) return set_err(h, MXG_EIO, "write error on '%s'", path);
     return MXG_OK;

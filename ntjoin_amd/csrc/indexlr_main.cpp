@@ -4,6 +4,7 @@
 // and run_indexlr()'s spelling at reference bin/ntjoin_utils.py:198 (`-k32 -w1000 -t4 ... -o file`).
 // stdout carries only the TSV; diagnostics go to stderr; any failure exits non-zero (ntJoin runs its recipes
 // under `bash -e -o pipefail`, reference ntJoin:89).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,20 +96,27 @@ int main(int argc, char **argv)
     cfg.device = device;
     cfg.flags = dense ? MXG_FLAG_DENSE_ONLY : 0;
     cfg.host_threads = threads;  // `-t`: workers that move the FASTA text to the GPU and the TSV text out (reference ntJoin:205)
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     mxg_handle *h = nullptr;
     int rc = mxg_create(&cfg, &h);
     if (rc != MXG_OK) {
         fprintf(stderr, "indexlr: %s\n", mxg_last_error(nullptr));
         return 1;
     }
+    const double t1 = now();
     int a = mxg_add_assembly_fasta(h, in, 1.0, in);
-    if (a < 0 || (rc = mxg_sketch(h, a)) != MXG_OK || (rc = mxg_write_tsv(h, a, out, with_pos, with_strand, with_seq)) != MXG_OK) {
+    const double t2 = now();
+    double t3 = t2;
+    if (a < 0 || (rc = mxg_sketch(h, a)) != MXG_OK || (t3 = now(), rc = mxg_write_tsv(h, a, out, with_pos, with_strand, with_seq)) != MXG_OK) {
         fprintf(stderr, "indexlr: %s\n", mxg_last_error(h));
         mxg_destroy(h);
         if (strcmp(out, "-") != 0) remove(out);  // leave no partial output behind
         return 1;
     }
     if (verbose) {
+        fprintf(stderr, "indexlr: device + handle %.3f s, FASTA -> packed bases in HBM %.3f s, sketch %.3f s, TSV %.3f s\n", t1 - t0, t2 - t1,
+                t3 - t2, now() - t3);
         mxg_stats st;
         memset(&st, 0, sizeof st);
         st.struct_size = sizeof st;

@@ -456,8 +456,8 @@ struct ReorderParams {
 // 320 threads: a slice holds ~290 candidates (64 strips x 320 k-mers x 1.4 %), so one pass of the block hashes them
 // all; with 256 threads a second, nearly empty pass doubled the block's lifetime (the kernel is latency-bound).
 constexpr uint32_t RB = 320;
-template <int VARIANT, int ABL = 0>
-__global__ __launch_bounds__(RB) void k_reorder(const ReorderParams p)
+template <int VARIANT, int ABL = 0, uint32_t RBT = RB>
+__global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
 {
     __shared__ uint4 tab[20];
     __shared__ uint4 btab[256];     // byte table of init_direct
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(RB) void k_reorder(const ReorderParams p)
     // The kernel is a chain of dependent memory round trips, so everything that can be asked for at once is: the first
     // two entries of every thread (a slice holds about one per thread) are requested without waiting for the slice's
     // entry count (the slice is allocated in full; what lies beyond the count is masked afterwards).
-    const uint32_t i0 = threadIdx.x, i1 = threadIdx.x + RB;
+    const uint32_t i0 = threadIdx.x, i1 = threadIdx.x + RBT;
     uint2 a0 = make_uint2(0u, 0u), a1 = make_uint2(0u, 0u);
     if (i0 < p.wave_cap) a0 = src[i0];
     if (i1 < p.wave_cap) a1 = src[i1];
@@ -515,9 +515,9 @@ __global__ __launch_bounds__(RB) void k_reorder(const ReorderParams p)
         extern __shared__ uint32_t queue[];
         const uint32_t base = spref[0];
         const uint32_t qn = min(spref[63] + sh_last - base, p.queue_cap);
-        for (uint32_t e0 = 0; e0 < cnt; e0 += RB) {
+        for (uint32_t e0 = 0; e0 < cnt; e0 += RBT) {
             const uint32_t i = e0 + threadIdx.x;
-            uint2 a = e0 == 0 ? a0 : (e0 == RB ? a1 : (i < cnt ? src[i] : make_uint2(0u, 0u)));
+            uint2 a = e0 == 0 ? a0 : (e0 == RBT ? a1 : (i < cnt ? src[i] : make_uint2(0u, 0u)));
             if (i >= cnt) a = make_uint2(0u, 0u);
             uint32_t bits = a.y & 0xFFFFu;
             const uint32_t item0 = (a.x & 63u) | (((a.y >> 16) & 63u) << 6);
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(RB) void k_reorder(const ReorderParams p)
             }
         }
         __syncthreads();
-        for (uint32_t q = threadIdx.x; q < qn; q += RB) hash_item(queue[q], base + q);
+        for (uint32_t q = threadIdx.x; q < qn; q += RBT) hash_item(queue[q], base + q);
         return;
     }
     auto place = [&](const uint2 a) {  // (slices too large for the queue: one thread per entry)
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(RB) void k_reorder(const ReorderParams p)
     };
     place(i0 < cnt ? a0 : make_uint2(0u, 0u));
     place(i1 < cnt ? a1 : make_uint2(0u, 0u));
-    for (uint32_t i = threadIdx.x + 2u * RB; i < cnt; i += RB) place(src[i]);
+    for (uint32_t i = threadIdx.x + 2u * RBT; i < cnt; i += RBT) place(src[i]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -646,12 +646,12 @@ constexpr int RH = 64;   // halo (candidates) staged on each side of a block's 2
 constexpr int RP = 4;    // padding entries so that 4-wide neighbour groups never index outside the arrays
 constexpr uint32_t RK = 256;  // candidates (= threads) per k_resolve block (measured: 128 -> 32.7 us, 256 -> 31.4, 512 -> 35.0)
 
-template <bool GAPS, bool COUNT, int ABL = 0>
+template <bool GAPS, bool COUNT, int ABL = 0, int RHT = RH>
 __global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
 {
-    __shared__ uint64_t lh[RK + 2 * RH + 2 * RP];
-    __shared__ uint2 lkc[RK + 2 * RH + 2 * RP];  // {k-mer index, contig}; contig = ~0 outside the candidate array
-    constexpr uint32_t TOT = RK + 2 * RH + 2 * RP, NST = (TOT + RK - 1) / RK;  // staged entries (per thread)
+    __shared__ uint64_t lh[RK + 2 * RHT + 2 * RP];
+    __shared__ uint2 lkc[RK + 2 * RHT + 2 * RP];  // {k-mer index, contig}; contig = ~0 outside the candidate array
+    constexpr uint32_t TOT = RK + 2 * RHT + 2 * RP, NST = (TOT + RK - 1) / RK;  // staged entries (per thread)
     const uint32_t i0 = blockIdx.x * RK;
     // Blocks that the previous run's count says will be in use request their entries before the candidate count has
     // arrived (the arrays hold n_cap entries; what lies beyond the count is masked below): one memory round trip for
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
 #pragma unroll
     for (uint32_t r = 0; r < NST; ++r) {
         const uint32_t e = threadIdx.x + RK * r;
-        const int64_t g = (int64_t)i0 - RH - RP + e;
+        const int64_t g = (int64_t)i0 - RHT - RP + e;
         vh[r] = 0; vk[r] = 0; vc[r] = 0;
         if (e < TOT && g >= 0 && g < (int64_t)bound) {
             vh[r] = p.ch[g];
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
 #pragma unroll
     for (uint32_t r = 0; r < NST; ++r) {
         const uint32_t e = threadIdx.x + RK * r;
-        const int64_t g = (int64_t)i0 - RH - RP + e;
+        const int64_t g = (int64_t)i0 - RHT - RP + e;
         if (e < TOT) {
             const bool in = g >= 0 && g < (int64_t)n;
             lh[e] = in ? vh[r] : 0ull;
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
     const uint32_t i = i0 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const bool live = i < n;
-    const uint32_t li = RH + RP + threadIdx.x;
+    const uint32_t li = RHT + RP + threadIdx.x;
     const uint64_t h = lh[li];
     const uint32_t kx = lkc[li].x;
     const uint32_t c = live ? lkc[li].y : 0u;
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
     uint32_t L = min(kx, wm1);
     bool ldone = !live || ABL == 1;
     if (live && ABL != 1) {
-        for (uint32_t t = 1; t <= (uint32_t)RH; t += 4) {
+        for (uint32_t t = 1; t <= (uint32_t)RHT; t += 4) {
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
                 const uint2 kc = lkc[li - t - u];
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
         const uint32_t bc = (uint32_t)__builtin_amdgcn_readlane((int)c, src);
         const uint64_t bh = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), src) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, src);
-        const uint32_t d = coop_left(q, lane, bi, bh, bkx, bc, RH + 1);
+        const uint32_t d = coop_left(q, lane, bi, bh, bkx, bc, RHT + 1);
         if ((int)lane == src && d != 0xFFFFFFFFu) L = d - 1;
     }
     // ---- right: any smaller-or-equal within the distance still needed ----
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
     const uint32_t need = wm1 - min(L, wm1);  // need R >= need
     bool rdone = !(s && need > 0) || ABL == 1 || ABL == 2;
     if (!rdone) {
-        for (uint32_t t = 1; t <= (uint32_t)RH; t += 4) {
+        for (uint32_t t = 1; t <= (uint32_t)RHT; t += 4) {
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
                 const uint2 kc = lkc[li + t + u];
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
         const uint32_t bneed = (uint32_t)__builtin_amdgcn_readlane((int)need, src);
         const uint64_t bh = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(h >> 32), src) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h, src);
-        const bool blocked = coop_right_blocked(q, lane, bi, bh, bkx, bc, RH + 1, bneed);
+        const bool blocked = coop_right_blocked(q, lane, bi, bh, bkx, bc, RHT + 1, bneed);
         if ((int)lane == src && blocked) s = false;
     }
     // A piece of a record that starts with the halo of the shard before it: the arg-min of its FIRST window (nothing
@@ -1441,6 +1441,8 @@ struct Driver {
             hipLaunchKernelGGL((k_resolve<true, true, 2>), dim3(blocks), dim3(RK), 0, st, rp);
         else if (abl == 3)
             hipLaunchKernelGGL((k_resolve<true, true, 3>), dim3(blocks), dim3(RK), 0, st, rp);
+        else if (env_u64("MXG_RH", few_cand ? 32 : 64) == 32)  // halo of 32 candidates: enough for <= 12 per window (976 -> 985 Gbp/s)
+            hipLaunchKernelGGL((k_resolve<true, true, 0, 32>), dim3(blocks), dim3(RK), 0, st, rp);
         else
             hipLaunchKernelGGL((k_resolve<true, true>), dim3(blocks), dim3(RK), 0, st, rp);
         MXG_HIP(h, hipGetLastError());
@@ -1488,6 +1490,7 @@ struct Driver {
 
     // offsets: SC_BSUM per 1024-tile (after resolve_and_count) or, fused = true, from SC_CNT256 (after resolve_count)
     uint32_t *n_out = nullptr;  // see EmitParams::n_out (set by sketch_assemblies for the fused call)
+    bool few_cand = false;      // <= 12 candidates per window: smaller k_reorder blocks and k_resolve halos (set per batch)
     // how a batch hangs together with the batches before it and with the device-side stretch fix-up (see EmitParams)
     struct ChainIO {
         const uint64_t *base_in = nullptr;
@@ -1720,6 +1723,7 @@ struct Driver {
                        uint32_t cand_hint = 0xFFFFFFFFu)
     {
         const uint32_t S = a->S_sparse;
+        few_cand = (double)tau_hi / 4294967296.0 * (double)h->cfg.w <= 12.5;
         MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
         MXG_HIP(h, sc(SC_STRIP_CNT).ensure((size_t)g.n_strips * 4 + 16));
         MXG_HIP(h, sc(SC_STRIP_META).ensure((size_t)g.n_strips * 16 + 16));
@@ -1807,6 +1811,8 @@ struct Driver {
             static const int rabl = getenv("MXG_ABLATE_REORDER") ? atoi(getenv("MXG_ABLATE_REORDER")) : 0;  // profiling only
             if (rabl == 1)
                 hipLaunchKernelGGL((k_reorder<MXG_VARIANT_V2_SUM, 1>), dim3(g.n_waves), dim3(RB), q_lds, st, op);
+            else if (env_u64("MXG_RB", few_cand ? 256 : RB) == 256)  // ~205 candidates per slice at 10 per window: one pass of 256 threads
+                hipLaunchKernelGGL((k_reorder<MXG_VARIANT_V2_SUM, 0, 256>), dim3(g.n_waves), dim3(256), q_lds, st, op);
             else
                 hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V2_SUM>, dim3(g.n_waves), dim3(RB), q_lds, st, op);
         }

@@ -74,6 +74,12 @@ class Ntjoin:
         print(datetime.datetime.today(), ": Building graph", file=sys.stdout)
         eng = self._engine
         eng.build_graph()
+        if not materialize:
+            # only the .mx.dot is wanted (ntjoin_amd.run): the library writes it from its own arrays; no Python object
+            # per vertex or edge is ever made (4.5 M vertices at 3 Gbp + 3 Gbp: seconds of str() and dict inserts)
+            self.graph = None
+            self.print_graph(None)
+            return
         g = eng.get_graph()
         if materialize == "views":
             # array-backed state for genome-scale inputs: same objects to index and iterate, no per-minimizer Python work

@@ -163,18 +163,47 @@ static void mvec_push(mvec *m, mxo_minimizer x)
 size_t mxo_sketch_stateful(const char *seq, size_t len, unsigned k, unsigned w, int variant,
                            mxo_minimizer **out)
 {
+    mxo_workspace ws;
+    memset(&ws, 0, sizeof ws);
+    size_t n = mxo_sketch_stateful_ws(seq, len, k, w, variant, out, &ws);
+    mxo_workspace_free(&ws);
+    return n;
+}
+
+void mxo_workspace_free(mxo_workspace *ws)
+{
+    free(ws->mh); free(ws->oh); free(ws->fw); free(ws->ok); free(ws->ring);
+    memset(ws, 0, sizeof *ws);
+}
+
+/* the loop itself; the per-k-mer arrays live in a caller-owned workspace that grows on demand, so that a worker thread of
+   the threaded driver (mx_oracle_mt.c) allocates once, not once per chunk */
+size_t mxo_sketch_stateful_ws(const char *seq, size_t len, unsigned k, unsigned w, int variant,
+                              mxo_minimizer **out, mxo_workspace *ws)
+{
     *out = NULL;
     if (k == 0 || w == 0 || k > len || (size_t)w > len - k + 1) return 0;
     size_t n = len - k + 1;
-    uint64_t *mh = (uint64_t *)malloc(n * sizeof(uint64_t));
-    uint64_t *oh = (uint64_t *)malloc(n * sizeof(uint64_t));
-    uint8_t *fw = (uint8_t *)malloc(n);
-    uint8_t *ok = (uint8_t *)malloc(n);
-    if (!mh || !oh || !fw || !ok) { fprintf(stderr, "mx_oracle: out of memory\n"); abort(); }
+    if (n > ws->cap) {
+        free(ws->mh); free(ws->oh); free(ws->fw); free(ws->ok);
+        ws->cap = n + n / 8;
+        ws->mh = (uint64_t *)malloc(ws->cap * sizeof(uint64_t));
+        ws->oh = (uint64_t *)malloc(ws->cap * sizeof(uint64_t));
+        ws->fw = (uint8_t *)malloc(ws->cap);
+        ws->ok = (uint8_t *)malloc(ws->cap);
+    }
+    size_t ring_n = (size_t)w + 1;
+    if (ring_n > ws->ring_cap) {
+        free(ws->ring);
+        ws->ring_cap = ring_n;
+        ws->ring = (mxo_minimizer *)malloc(ring_n * sizeof(mxo_minimizer));
+    }
+    uint64_t *mh = ws->mh, *oh = ws->oh;
+    uint8_t *fw = ws->fw, *ok = ws->ok;
+    mxo_minimizer *ring = ws->ring;
+    if (!mh || !oh || !fw || !ok || !ring) { fprintf(stderr, "mx_oracle: out of memory\n"); abort(); }
     mxo_kmer_hashes(seq, len, k, variant, mh, oh, fw, ok);
 
-    size_t ring_n = (size_t)w + 1;
-    mxo_minimizer *ring = (mxo_minimizer *)malloc(ring_n * sizeof(mxo_minimizer));
     mvec res = {0, 0, 0};
     long long min_pos_prev = -1;
     const mxo_minimizer *cur = NULL;
@@ -206,8 +235,6 @@ size_t mxo_sketch_stateful(const char *seq, size_t len, unsigned k, unsigned w, 
         }
         ++idx;
     }
-    free(ring);
-    free(mh); free(oh); free(fw); free(ok);
     *out = res.v;
     return res.n;
 }

@@ -66,6 +66,17 @@ size_t mxo_kmer_hashes(const char *seq, size_t len, unsigned k, int variant, uin
  */
 size_t mxo_sketch_stateful(const char *seq, size_t len, unsigned k, unsigned w, int variant,
                            mxo_minimizer **out);
+/* the same loop with its per-k-mer arrays in a caller-owned workspace (zero-initialise; free with mxo_workspace_free) */
+typedef struct {
+    uint64_t *mh, *oh;
+    uint8_t *fw, *ok;
+    size_t cap;
+    mxo_minimizer *ring;
+    size_t ring_cap;
+} mxo_workspace;
+size_t mxo_sketch_stateful_ws(const char *seq, size_t len, unsigned k, unsigned w, int variant,
+                              mxo_minimizer **out, mxo_workspace *ws);
+void mxo_workspace_free(mxo_workspace *ws);
 /*
  * Same result from the STATELESS definition (rightmost arg-min of every window of w consecutive
  * valid k-mers, distinct arg-mins in order), computed with a monotone deque.  Independent code path

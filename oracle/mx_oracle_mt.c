@@ -45,6 +45,8 @@ static void *worker(void *arg)
     job_t *j = (job_t *)arg;
     char *buf = NULL;
     size_t cap = 0;
+    mxo_workspace ws;
+    memset(&ws, 0, sizeof ws);
     for (;;) {
         pthread_mutex_lock(&j->mu);
         size_t i = j->next++;
@@ -65,10 +67,11 @@ static void *worker(void *arg)
             buf[q] = "ACGT"[(j->packed[g >> 4] >> (2 * (g & 15))) & 3u];
         }
         buf[nb] = 0;
-        it->n = mxo_sketch_stateful(buf, (size_t)nb, j->k, j->w, j->variant, &it->mx);
+        it->n = mxo_sketch_stateful_ws(buf, (size_t)nb, j->k, j->w, j->variant, &it->mx, &ws);
         for (size_t m = 0; m < it->n; ++m) it->mx[m].pos += (uint32_t)b0;
     }
     free(buf);
+    mxo_workspace_free(&ws);
     return NULL;
 }
 
