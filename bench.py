@@ -55,10 +55,32 @@ def cpu_model():
 
 
 def n_cores():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup's CPU quota (the GPU boxes show 256 logical
+    CPUs but run the container with a quota of 16: more threads than that only add contention)"""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
+                        n = min(n, max(1, q // int(fh2.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def logical_cpus():
+    return os.cpu_count() or 1
 
 
 def workload_tables(name, mbp, w, seed=1):
@@ -339,7 +361,7 @@ def main():
             cb = cpu_baseline(asms_host, W, args.cpu_seconds)
             out["cpu_baseline"] = {
                 "value": round(cb["bases"] / cb["seconds"] / 1e9, 5), "unit": "Gbp/s", "cores": cb["cores"], "kind": "port",
-                "cpu": cpu_model(),
+                "cpu": cpu_model(), "logical_cpus_visible": logical_cpus(),
                 "sample": f"first {cb['records'][0]} reference records + first {cb['records'][1]} target contigs "
                           f"({cb['bases'] / 1e6:.0f} Mbp, {100 * cb['frac']:.0f} % of the step's workload): C restatement of "
                           f"`indexlr -t {cb['cores']}` (records chunked, one worker per core: {cb['t_sketch']:.2f} s) + C restatement of "
@@ -358,7 +380,7 @@ def main():
                         csum = np.cumsum(lens.astype(np.int64))
                         n = min(int(np.searchsorted(csum, args.e2e_mbp * 1e6, side="left")) + 1, len(lens))
                         sample.append((words, starts[:n], lens[:n]))
-                e2e = end_to_end(sample, W, td, n_cores())
+                e2e = end_to_end(sample, W, td, min(n_cores(), 8))
                 t_all = e2e["t_sketch_cli"] + e2e["t_graph_cli"]
                 out["end_to_end"] = {
                     "value": round(e2e["bases"] / t_all / 1e9, 4), "unit": "Gbp/s",
@@ -367,7 +389,7 @@ def main():
                                 "(HIP init included): `indexlr` per assembly, then `python -m ntjoin_amd.run`" % W,
                     "bases": int(e2e["bases"]), "fasta_bytes": int(e2e["fasta_bytes"]), "tsv_bytes": int(e2e["tsv_bytes"]),
                     "dot_bytes": int(e2e["dot_bytes"]), "seconds_indexlr": round(e2e["t_sketch_cli"], 3),
-                    "seconds_graph": round(e2e["t_graph_cli"], 3), "threads": n_cores()}
+                    "seconds_graph": round(e2e["t_graph_cli"], 3), "threads": min(n_cores(), 8)}
             finally:
                 shutil.rmtree(td, ignore_errors=True)
         result_line = json.dumps(out)

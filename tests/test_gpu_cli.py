@@ -164,3 +164,38 @@ def test_tsv_parsed_by_several_threads(tmp_path):
         with pytest.raises(MxError) as ei:
             eng.add_tsv("a", 1.0, str(path))
         assert f":{60_001}:" in str(ei.value) and "three" in str(ei.value)
+
+
+def test_make_j_concurrent_indexlr_instances_and_log_time(tmp_path):
+    """B1 convention: make runs one `indexlr` per assembly, concurrently under `make -j` (one GPU context each on the same
+    device); with time=True every target gets its `.time` file (reference ntJoin:98-107,205)"""
+    import stat
+    meta = load_case("synth3_w50")["meta"]
+    asms = meta["refs"] + [meta["target"]]
+    for a in asms:
+        shutil.copy(os.path.join(FASTA, a["fasta"]), tmp_path / a["fasta"])
+    bind = tmp_path / "bin"
+    bind.mkdir()
+    fake_time = bind / "time"   # GNU time is not installed here: a stand-in with its `-v -o FILE cmd...` interface
+    fake_time.write_text('#!/bin/bash\nout=""; while [ "$1" = "-v" ] || [ "$1" = "-o" ]; do if [ "$1" = "-o" ]; then out="$2"; shift; fi; shift; done\n'
+                         'echo "ran: $*" > "$out"; exec "$@"\n')
+    fake_time.chmod(fake_time.stat().st_mode | stat.S_IXUSR)
+    env = dict(os.environ, PATH=f"{bind}:{os.environ['PATH']}")
+    refs = " ".join(a["fasta"] for a in meta["refs"])
+    wts = " ".join(str(a["weight"]) for a in meta["refs"])
+    subprocess.check_call(["make", "-j", "8", "-f", os.path.join(REPO, "ntJoin-mx"), "mxgraph", f"target={meta['target']['fasta']}",
+                           f"target_weight={meta['target']['weight']}", f"references={refs}", f"reference_weights={wts}",
+                           f"k={meta['k']}", f"w={meta['w']}", "prefix=out", "time=True"], cwd=tmp_path, env=env)
+    for a in asms:
+        assert filecmp.cmp(str(tmp_path / a["tsv"]), os.path.join(GOLDEN, "cases", meta["name"], a["tsv"]), shallow=False)
+        assert (tmp_path / (a["tsv"] + ".time")).read_text().startswith("ran: ")
+    assert "ntjoin_amd.run" in (tmp_path / "out.mx.dot.time").read_text()
+    with open(os.path.join(GOLDEN, "cases", meta["name"], "reference.mx.dot"), encoding="utf-8") as fh:
+        want = go.canonical_dot_from_text(fh.read())
+    assert go.canonical_dot_from_text((tmp_path / "out.mx.dot").read_text(encoding="utf-8")) == want
+    # the same instances started at the same moment by hand
+    procs = [subprocess.Popen([INDEXLR, "--seq", "--long", "--pos", f"-k{meta['k']}", f"-w{meta['w']}", "-t2", "-o", str(tmp_path / f"c{i}.tsv"),
+                               str(tmp_path / asms[i % len(asms)]["fasta"])]) for i in range(6)]
+    assert [p.wait() for p in procs] == [0] * 6
+    for i in range(6):
+        assert filecmp.cmp(str(tmp_path / f"c{i}.tsv"), os.path.join(GOLDEN, "cases", meta["name"], asms[i % len(asms)]["tsv"]), shallow=False)

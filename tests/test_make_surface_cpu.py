@@ -1,0 +1,57 @@
+"""CPU tests of the make front-end: `ntJoin-mx assemble` hands the job to the reference's own ntJoin with this
+repository's `indexlr` FIRST on PATH (so the reference's recipe at ntJoin:204-205 runs on the GPU) and forwards every
+variable; `time=True` wraps the recipes in `$(log_time)` exactly as the reference does (ntJoin:98-107)."""
+import os
+import stat
+import subprocess
+
+from tests.conftest import REPO
+
+MK = os.path.join(REPO, "ntJoin-mx")
+
+
+def _stub(path, body):
+    with open(path, "w") as fh:
+        fh.write("#!/bin/bash\n" + body)
+    os.chmod(path, os.stat(path).st_mode | stat.S_IXUSR)
+
+
+def test_assemble_delegates_with_our_indexlr_first_on_path(tmp_path):
+    stub = tmp_path / "ntJoin"
+    _stub(stub, 'echo "indexlr=$(command -v indexlr)" > "$PWD/seen.txt"\nfor a in "$@"; do echo "arg=$a" >> "$PWD/seen.txt"; done\n')
+    subprocess.check_call(["make", "-f", MK, "assemble", "target=scaf.fa", "references=r1.fa r2.fa", "reference_weights=2 3",
+                           "target_weight=1", "k=24", "w=250", "n=2", "t=7", "prefix=pre", "time=True", f"ntjoin={stub}"],
+                          cwd=tmp_path)
+    seen = (tmp_path / "seen.txt").read_text().splitlines()
+    assert seen[0] == "indexlr=" + os.path.join(REPO, "ntjoin_amd", "bin", "indexlr")
+    args = [l[4:] for l in seen[1:]]
+    assert args[0] == "assemble"
+    for want in ("target=scaf.fa", "references=r1.fa r2.fa", "reference_weights=2 3", "target_weight=1", "k=24", "w=250", "n=2",
+                 "t=7", "prefix=pre", "time=True", "reference_config=None"):
+        assert want in args, (want, args)
+
+
+def test_assemble_without_reference_path_is_an_error(tmp_path):
+    r = subprocess.run(["make", "-f", MK, "assemble", "target=a.fa", "references=b.fa", "reference_weights=2"], cwd=tmp_path,
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "ntjoin=" in r.stderr
+
+
+def test_log_time_wraps_the_sketch_recipe(tmp_path):
+    """time=True: `command time -v -o <target>.time <recipe>` (GNU time is looked up on PATH like in the reference; here a
+    stand-in that records what it was asked to run, and a stand-in indexlr through mx_engine=indexlr)"""
+    bind = tmp_path / "bin"
+    bind.mkdir()
+    _stub(bind / "time", 'out=""; while [ "$1" = "-v" ] || [ "$1" = "-o" ]; do if [ "$1" = "-o" ]; then out="$2"; shift; fi; shift; done\n'
+                         'echo "ran: $*" > "$out"; exec "$@"\n')
+    _stub(bind / "indexlr", 'echo "fake sketch of ${@: -1}"\n')
+    (tmp_path / "a.fa").write_text(">x\nACGT\n")
+    env = dict(os.environ, PATH=f"{bind}:{os.environ['PATH']}")
+    subprocess.check_call(["make", "-f", MK, "a.fa.k32.w100.tsv", "k=32", "w=100", "t=3", "time=True", "mx_engine=indexlr"], cwd=tmp_path, env=env)
+    assert (tmp_path / "a.fa.k32.w100.tsv").read_text() == "fake sketch of a.fa\n"
+    assert (tmp_path / "a.fa.k32.w100.tsv.time").read_text().strip() == "ran: indexlr --seq --long --pos -k 32 -w 100 -t 3 a.fa"
+    # time=False (the default): no wrapper, no .time file
+    os.remove(tmp_path / "a.fa.k32.w100.tsv")
+    os.remove(tmp_path / "a.fa.k32.w100.tsv.time")
+    subprocess.check_call(["make", "-f", MK, "a.fa.k32.w100.tsv", "k=32", "w=100", "mx_engine=indexlr"], cwd=tmp_path, env=env)
+    assert not (tmp_path / "a.fa.k32.w100.tsv.time").exists()
