@@ -84,23 +84,62 @@ def logical_cpus():
 
 
 def workload_tables(name, mbp, w, seed=1):
-    """segment tables of the assemblies of a workload: list of (assembly name, weight, segs, n_words, sub_per_65536)"""
+    """segment tables of the assemblies of a workload, references first (the reference's load order, bin/ntjoin.py:178-186):
+    list of (assembly name, weight, segs, n_words, sub_per_65536, sub_seed)"""
     from ntjoin_amd import synth
     if name == "configs1":
         cfg = synth.genome_config(int(mbp * 1e6), 1, seed=seed)
         label = f"configs[1]: synthetic 1x{mbp:g} Mbp reference + derived target, k=32 w={w}, weights 2/1"
-    elif name == "configs2":
+    elif name in ("configs2", "configs3"):
         cfg = synth.genome_config(int(mbp * 1e6), 24, seed=seed, min_len=3000, max_len=600_000)
         label = (f"configs[2]: synthetic human-scale {mbp / 1000:g} Gbp reference (24 records) + derived ~{mbp / 1000:g} Gbp "
                  f"target, k=32 w={w}, weights 2/1")
+    elif name == "configs4":
+        cfg = synth.genome_config(int(mbp * 1e6), 12, seed=seed, min_len=1000, max_len=200_000)
+        label = (f"configs[4]: synthetic conifer-scale {mbp / 1000:g} Gbp reference (12 records of ~{mbp / 12000:.2f} Gbp, cut between "
+                 f"ranks) + derived ~{mbp / 1000:g} Gbp target of {len(cfg['tgt_segs'])} contigs of 1-200 kbp, k=32 w={w}, weights 2/1")
     else:
         raise ValueError(name)
-    asms = [(f"ref.fa.k{K}.w{w}.tsv", 2.0, cfg["ref_segs"], cfg["ref_words"], 0),
-            (f"tgt.fa.k{K}.w{w}.tsv", 1.0, cfg["tgt_segs"], cfg["tgt_words"], synth.SUB_PER_65536)]
+    ss = cfg["sub_seed"]
+    if name == "configs3":
+        # target + 3 references: the same base genome with independent 0.5 / 1 / 2 % divergence, weights 2/2/2 and 1
+        label = (f"configs[3]: synthetic {mbp / 1000:g} Gbp target + 3 references (0.5 / 1 / 2 % divergence), k=32 w={w}, "
+                 "weights 2/2/2/1")
+        asms = [(f"ref{i}.fa.k{K}.w{w}.tsv", 2.0, cfg["ref_segs"], cfg["ref_words"], rate, ss + 101 * (i + 1))
+                for i, rate in enumerate((328, 655, 1311))]
+        asms.append((f"tgt.fa.k{K}.w{w}.tsv", 1.0, cfg["tgt_segs"], cfg["tgt_words"], synth.SUB_PER_65536, ss))
+    else:
+        asms = [(f"ref.fa.k{K}.w{w}.tsv", 2.0, cfg["ref_segs"], cfg["ref_words"], 0, ss),
+                (f"tgt.fa.k{K}.w{w}.tsv", 1.0, cfg["tgt_segs"], cfg["tgt_words"], synth.SUB_PER_65536, ss)]
     return cfg, asms, label
 
 
-def cpu_baseline(asms_host, w, budget_s):
+def add_rank_share(eng, name, weight, segs, seed, sub_seed, sub, rank, world, device):
+    """this rank's share of one assembly, born in HBM: shard `rank` of `world` EQUAL BASE RANGES of the concatenated records,
+    whatever the record borders (records cut by a range travel as pieces with a halo of w k-mers, mxg_plan_split); every rank
+    registers every record, so record indices are global.  world = 1: the whole assembly.
+    -> (device tensor, rec_start, rec_len) of what the rank holds"""
+    from ntjoin_amd import synth
+    lens = np.ascontiguousarray(segs[:, 2])
+    lo, hi, drop = eng.plan_split(lens, rank, world)
+    keep = hi > lo
+    b0 = lo & ~np.uint64(15)
+    plen = np.where(keep, hi - b0, 0).astype(np.uint64)
+    starts_k, n_words = synth.layout(plen[keep])
+    rec_start = np.zeros(len(lens), dtype=np.uint64)
+    rec_start[keep] = starts_k
+    loc = np.zeros((int(keep.sum()), 4), dtype=np.uint64)
+    rc = segs[keep, 3]
+    loc[:, 0] = starts_k
+    loc[:, 1] = np.where(rc == 1, segs[keep, 1] + (lens[keep] - hi[keep]), segs[keep, 1] + b0[keep])
+    loc[:, 2] = plen[keep]
+    loc[:, 3] = rc
+    d = synth.fill_device(loc, n_words, seed, sub_seed, sub, device=device)
+    eng.add_packed_device_pieces(name, weight, d.data_ptr(), rec_start, lens, lo, hi, drop)
+    return d, rec_start, lens
+
+
+def cpu_baseline(asms_host, w, budget_s, weights):
     """The oracle (checker / reported baseline only: nothing here is on the product path): the C restatement of
     `indexlr -t nproc` (chunked records, one worker per core) + the C restatement of read_minimizers' uniqueness,
     filter_minimizers and build_graph, on a sample of the workload sized for ~budget_s seconds of wall time."""
@@ -126,7 +165,7 @@ def cpu_baseline(asms_host, w, budget_s):
     sk = [orc.sketch_packed_mt(wd, st, ln, K, w, threads=cores, chunk_kmers=1 << 18) for wd, st, ln in sample]
     t_sketch = time.perf_counter() - t0
     t1 = time.perf_counter()
-    g = orc.graph([s[0] for s in sk], [s[2] for s in sk], [2.0, 1.0][:len(sk)] if len(sk) == 2 else [1.0] * len(sk))
+    g = orc.graph([s[0] for s in sk], [s[2] for s in sk], list(weights))
     t_graph = time.perf_counter() - t1
     return {"bases": bases, "seconds": t_sketch + t_graph, "t_sketch": t_sketch, "t_graph": t_graph, "cores": cores,
             "minimizers": int(sum(len(s[0]) for s in sk)), "vertices": g["vertices"], "edges": g["edges"], "frac": frac,
@@ -172,9 +211,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="auto", choices=["auto", "configs1", "configs2"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "configs1", "configs2", "configs3", "configs4"])
     ap.add_argument("--mbp", type=float, default=0.0, help="reference size in Mbp (default: 100 for configs1, 3000 for configs2)")
-    ap.add_argument("--w", type=int, default=1000)
+    ap.add_argument("--w", type=int, default=0, help="window size (default: 500 for configs3, else 1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel breakdown pass")
@@ -213,27 +252,28 @@ def main():
     from ntjoin_amd.engine import MxEngine
     from ntjoin_amd.dist import partitioned_graph, partitioned_totals, sketch_union_graph
 
-    W = args.w
     wl = args.workload
-    if wl == "auto":
-        wl = "configs2" if not multi else "configs1"
-    mbp = args.mbp or (100.0 if wl == "configs1" else 3000.0)
-    cfg, asms, label = workload_tables(wl, mbp, W, seed=1 + 100 * rank)
+    if wl == "auto":  # the configuration BASELINE.json's metric names for this GPU count
+        wl = {1: "configs2", 2: "configs2", 4: "configs3", 8: "configs4"}.get(world, "configs2")
+    W = args.w or (500 if wl == "configs3" else 1000)
+    mbp = args.mbp or {"configs1": 100.0, "configs2": 3000.0, "configs3": 3000.0, "configs4": 20000.0}[wl]
+    cfg, asms, label = workload_tables(wl, mbp, W, seed=1)  # the same genome on every rank: each takes its share of it
     keep, host_layout = [], []
     # N > 1: the library works on the stream the collectives are issued on, so pack -> all-gather -> unpack need no host sync
     xstream = torch.cuda.Stream() if multi else None
     eng = MxEngine(k=K, w=W, device=local_rank, timing=True, cand_per_window=args.cand,
                    stream=xstream.cuda_stream if xstream is not None else None)
-    bases_rank = 0
-    for name, weight, segs, n_words, sub in asms:
-        d = synth.fill_device(segs, n_words, cfg["seed"], cfg["sub_seed"], sub, device=local_rank)  # bases born in HBM
+    bases_job = 0
+    for name, weight, segs, n_words, sub, sub_seed in asms:
+        d, rec_start, rec_len = add_rank_share(eng, name, weight, segs, cfg["seed"], sub_seed, sub, rank if world > 1 else 0, world,
+                                               local_rank)  # bases born in HBM
         keep.append(d)
-        eng.add_packed_device(name, weight, d.data_ptr(), segs[:, 0], segs[:, 2])
-        host_layout.append((d, segs[:, 0].copy(), segs[:, 2].copy()))
-        bases_rank += int(segs[:, 2].sum())
+        host_layout.append((d, rec_start, rec_len))
+        bases_job += int(segs[:, 2].sum())
+    eng.global_records = True
     torch.cuda.synchronize()
     union = None
-    m_rank = 4e-3 * mbp * 1000.0 / W  # minimizers per rank, millions (both assemblies, density 2/(w+1))
+    m_rank = 2e-6 * bases_job / (W + 1) / world  # minimizers per rank, millions (density 2/(w+1))
     graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("partitioned" if m_rank * (0.14 * world - 0.2) > 0.39 else "union")
 
     def step(e=eng):
@@ -270,13 +310,10 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt, float(bases_rank)], dtype=torch.float64, device="cuda")
-        tmax = t.clone()
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, bases_total = float(tmax[0]), float(t[1])
-    else:
-        bases_total = float(bases_rank)
+        dt = float(tmax[0])
+    bases_total = float(bases_job)  # the whole job's bases: every rank sketched 1/world of every assembly
 
     st = eng.stats()
     if union is not None and graph_mode == "partitioned":
@@ -294,7 +331,7 @@ def main():
         bytes_per_launch = ALG_BYTES_PER_BASE_HASH * st["hash_kernel_bases"] / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         n_mx = int(st["minimizers"]) if not multi else int(gst.get("minimizers", st["minimizers"]))
-        step_alg_bytes = ALG_BYTES_PER_BASE_HASH * bases_total + ALG_BYTES_PER_MINIMIZER * float(st["minimizers"]) * (world if multi else 1)
+        step_alg_bytes = ALG_BYTES_PER_BASE_HASH * bases_total + ALG_BYTES_PER_MINIMIZER * float(st["minimizers"]) * world
         step_gbs = step_alg_bytes / (ms_step * 1e-3) / 1e9
         # PMC traffic of the hash kernel: only quoted when the committed counters were collected on THIS workload
         traffic, traffic_src = None, None
@@ -310,12 +347,15 @@ def main():
         out = {
             "metric": f"Gbp/s minimizer-sketch+graph-build (k=32,w={W})", "value": round(value, 4), "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if (world > 1 and wl == "configs2") else "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
             "config": {"workload": label + ", bases resident in HBM (2-bit packed, generated on the device)",
-                       "k": K, "w": W, "bases_per_step": int(bases_total), "minimizers": int(st["minimizers"]),
+                       "k": K, "w": W, "bases_per_step": int(bases_total), "minimizers": int(st["minimizers"]) if world == 1 else None,
+                       "minimizers_rank0": int(st["minimizers"]),
                        "vertices": int(gst["vertices"]), "edges": int(gst["edges"]),
                        "records": [int(len(a[2])) for a in asms],
-                       "parallelism": ("1 GPU" if world == 1 else f"contig-sharded x{world}, " +
+                       "parallelism": ("1 GPU" if world == 1 else f"{world} ranks, each 1/{world} of every assembly's bases "
+                                       "(records cut at the range borders travel as pieces with a w-k-mer halo), " +
                                        ("graph stage partitioned by hash range (RCCL all-to-all)" if graph_mode == "partitioned"
                                         else "RCCL all-gather of sketches, graph of the union on every rank"))},
             "step_ms_min_max": [round(min(step_times) * 1e3, 4), round(max(step_times) * 1e3, 4)],
@@ -337,7 +377,7 @@ def main():
         if not multi and not args.no_kernels:
             # per-kernel GPU time: a second handle on the same bases with one event pair per kernel (a few steps)
             eng2 = MxEngine(k=K, w=W, device=local_rank, timing_fine=True, cand_per_window=args.cand)
-            for (name, weight, segs, _, _), d in zip(asms, keep):
+            for (name, weight, segs, _, _, _), d in zip(asms, keep):
                 eng2.add_packed_device(name, weight, d.data_ptr(), segs[:, 0], segs[:, 2])
             nk = 3
             step(eng2)
@@ -358,11 +398,11 @@ def main():
         if not multi and not (args.no_cpu_baseline and args.no_end_to_end):
             asms_host = [(d.cpu().numpy().view(np.uint32), st_, ln_) for d, st_, ln_ in host_layout]
         if not multi and not args.no_cpu_baseline:
-            cb = cpu_baseline(asms_host, W, args.cpu_seconds)
+            cb = cpu_baseline(asms_host, W, args.cpu_seconds, [a[1] for a in asms])
             out["cpu_baseline"] = {
                 "value": round(cb["bases"] / cb["seconds"] / 1e9, 5), "unit": "Gbp/s", "cores": cb["cores"], "kind": "port",
                 "cpu": cpu_model(), "logical_cpus_visible": logical_cpus(),
-                "sample": f"first {cb['records'][0]} reference records + first {cb['records'][1]} target contigs "
+                "sample": f"the first {' / '.join(str(x) for x in cb['records'])} records of the assemblies "
                           f"({cb['bases'] / 1e6:.0f} Mbp, {100 * cb['frac']:.0f} % of the step's workload): C restatement of "
                           f"`indexlr -t {cb['cores']}` (records chunked, one worker per core: {cb['t_sketch']:.2f} s) + C restatement of "
                           f"read_minimizers/filter_minimizers/build_graph on arrays, 1 thread like the reference ({cb['t_graph']:.2f} s)",

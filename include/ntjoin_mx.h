@@ -178,6 +178,20 @@ int mxg_add_assembly_buffers(mxg_handle *h, const char *name, double weight, con
 int mxg_add_assembly_packed_device(mxg_handle *h, const char *name, double weight, const void *d_packed,
                                    const uint64_t *rec_start, const uint64_t *rec_len,
                                    const char *const *ids, uint64_t n_records);
+/* Sub-record sharding of bases already in HBM (the packed counterpart of mxg_add_assembly_fasta_split, for inputs that never
+   were text: generated or produced on the device).  Every record is registered (ids, full lengths: record indices are global);
+   the handle holds the bases [piece_lo[r], piece_hi[r]) of record r where piece_hi > piece_lo: base b of the record sits at
+   packed index rec_start[r] + (b - (piece_lo[r] & ~15)) (rec_start a multiple of 16); piece_drop[r] = the piece begins with
+   the halo of the shard before it and withholds its first minimizer.  mxg_plan_split computes the pieces of shard `shard` of
+   `n_shards` for N-free records (equal base ranges, a halo of w k-mers: the rule of mxg_add_assembly_fasta_split), so that the
+   rank-ordered concatenation of the shards' sketches is the sketch of the whole assembly.  No counterpart in the reference
+   (one process per assembly, ntJoin:204-205). */
+int mxg_plan_split(const uint64_t *lengths, uint64_t n_records, uint32_t shard, uint32_t n_shards, uint32_t k, uint32_t w,
+                   uint64_t *piece_lo, uint64_t *piece_hi, uint8_t *piece_drop);
+int mxg_add_assembly_packed_device_pieces(mxg_handle *h, const char *name, double weight, const void *d_packed,
+                                          const uint64_t *rec_start, const uint64_t *rec_len, const uint64_t *piece_lo,
+                                          const uint64_t *piece_hi, const uint8_t *piece_drop, const char *const *ids,
+                                          uint64_t n_records);
 /* A sketch computed elsewhere: an indexlr TSV (`id \t hash:pos[:seq] ...`), parsed as read_minimizers does. */
 int mxg_add_assembly_tsv(mxg_handle *h, const char *name, double weight, const char *tsv_path);
 /* ... or the binary side-car mxg_write_sketch_bin left next to the TSV (the reference re-parses ~65

@@ -22,6 +22,7 @@ SYMBOLS = [
     "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_path_segments", "mxg_mx_extremes", "mxg_dg_owner_counts", "mxg_dg_pack_items", "mxg_dg_set_items", "mxg_dg_vertices", "mxg_dg_item_results", "mxg_dg_msg_counts", "mxg_dg_pack_msgs", "mxg_dg_edges", "mxg_dg_pack_slots", "mxg_dg_owner_slots", "mxg_dg_slot_results", "mxg_dg_pack_msg_slots", "mxg_dg_edges_slots", "mxg_write_dot",
     "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers",
     "mxg_synth_fill_packed_device", "mxg_synth_fill_packed_host", "mxg_synth_write_fasta",
+    "mxg_plan_split", "mxg_add_assembly_packed_device_pieces",
 ]
 
 
@@ -133,6 +134,8 @@ def load():
     L.mxg_add_assembly_buffers.argtypes = [vp, cp, C.c_double, vp, C.POINTER(u64), C.POINTER(cp), u64]
     L.mxg_add_assembly_packed_device.argtypes = [vp, cp, C.c_double, vp, C.POINTER(u64), C.POINTER(u64),
                                                  C.POINTER(cp), u64]
+    L.mxg_plan_split.argtypes = [vp, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.mxg_add_assembly_packed_device_pieces.argtypes = [vp, cp, C.c_double, vp, vp, vp, vp, vp, vp, C.POINTER(cp), u64]
     L.mxg_add_assembly_tsv.argtypes = [vp, cp, C.c_double, cp]
     L.mxg_add_assembly_minimizers.argtypes = [vp, cp, C.c_double, vp, vp, vp, u64, C.POINTER(cp), u64]
     L.mxg_num_assemblies.argtypes = [vp]

@@ -253,6 +253,94 @@ int mxg_add_assembly_packed_device(mxg_handle *h, const char *name, double weigh
     return commit(h, a, rc);
 }
 
+int mxg_plan_split(const uint64_t *lengths, uint64_t n_records, uint32_t shard, uint32_t n_shards, uint32_t k, uint32_t w,
+                   uint64_t *piece_lo, uint64_t *piece_hi, uint8_t *piece_drop)
+{
+    if ((!lengths && n_records) || !piece_lo || !piece_hi || !piece_drop || n_shards == 0 || shard >= n_shards || k == 0 || w == 0)
+        return MXG_EINVAL;
+    unsigned __int128 total = 0;
+    for (uint64_t r = 0; r < n_records; ++r) total += lengths[r];
+    const uint64_t cut_lo = (uint64_t)(total * shard / n_shards), cut_hi = (uint64_t)(total * (shard + 1) / n_shards);
+    uint64_t cum = 0;
+    for (uint64_t r = 0; r < n_records; ++r) {
+        const uint64_t len = lengths[r], r0 = cum, r1 = cum + len;
+        cum = r1;
+        piece_lo[r] = piece_hi[r] = 0;
+        piece_drop[r] = 0;
+        if (len == 0 || r1 <= cut_lo || r0 >= cut_hi) continue;
+        // own k-mer starts [P_lo, P_hi): the same rule as the FASTA route's plan_pieces (host_io.cpp), every k-mer valid
+        const uint64_t P_lo = std::max(cut_lo, r0) - r0, P_hi = std::min(cut_hi, r1) - r0;
+        piece_hi[r] = P_hi == len ? len : std::min<uint64_t>(len, P_hi + k - 1);
+        if (P_lo > 0) {
+            const uint64_t nk = len >= k ? len - k + 1 : 0, t_first = std::min(P_lo, nk);  // valid k-mers that start before P_lo
+            if (t_first >= w) {
+                piece_lo[r] = t_first - w;
+                piece_drop[r] = 1;
+            }
+        }
+        if (piece_hi[r] <= piece_lo[r]) piece_hi[r] = piece_lo[r] = 0;
+    }
+    return MXG_OK;
+}
+
+int mxg_add_assembly_packed_device_pieces(mxg_handle *h, const char *name, double weight, const void *d_packed,
+                                          const uint64_t *rec_start, const uint64_t *rec_len, const uint64_t *piece_lo,
+                                          const uint64_t *piece_hi, const uint8_t *piece_drop, const char *const *ids,
+                                          uint64_t n_records)
+{
+    Assembly *a;
+    int rc = new_assembly(h, name, weight, &a);
+    if (rc != MXG_OK) return rc;
+    if (!d_packed || !rec_start || !rec_len || !piece_lo || !piece_hi || !piece_drop)
+        return commit(h, a, set_err(h, MXG_EINVAL, "null argument"));
+    const uint32_t k = h->cfg.k, w = h->cfg.w;
+    uint64_t end = 0, lo_rec = n_records, hi_rec = 0;
+    for (uint64_t r = 0; r < n_records && rc == MXG_OK; ++r) {
+        Record rec;
+        rec.id = (ids && ids[r]) ? std::string(ids[r]) : std::to_string(r);
+        rec.len = rec_len[r];
+        if (rec_len[r] >= (1ull << 32)) rc = set_err(h, MXG_ELIMIT, "record %llu too long", (unsigned long long)r);
+        const uint64_t lo = piece_lo[r], hi = piece_hi[r];
+        if (hi > lo) {
+            if ((rec_start[r] & 15) || hi > rec_len[r]) rc = set_err(h, MXG_EINVAL, "bad piece of record %llu", (unsigned long long)r);
+            // base b of the record (lo <= b < hi) sits at packed index rec_start + (b - (lo & ~15)); offsets stay "of base 0"
+            rec.base_off = rec_start[r] - (lo & ~uint64_t(15));
+            a->recs.push_back(rec);
+            lo_rec = std::min(lo_rec, r);
+            hi_rec = r + 1;
+            end = std::max(end, rec_start[r] + (hi - (lo & ~uint64_t(15))));
+            a->total_bases += hi - lo;
+            if (hi - lo >= k && hi - lo - k + 1 >= w) {
+                Run run;
+                run.base_off = rec.base_off + lo;
+                run.n_kmers = (uint32_t)(hi - lo - k + 1);
+                run.contig = (uint32_t)a->ctg_rec.size();
+                run.kidx0 = 0;
+                run.pos0 = (uint32_t)lo;
+                a->ctg_rec.push_back((uint32_t)r);
+                a->ctg_nk.push_back(run.n_kmers);
+                a->ctg_run0.push_back((uint32_t)a->runs.size());
+                a->ctg_drop.push_back(piece_drop[r] ? 1 : 0);
+                a->any_drop = a->any_drop || piece_drop[r];
+                a->runs.push_back(run);
+                a->total_kmers += run.n_kmers;
+            }
+        } else {
+            a->recs.push_back(rec);  // registered (global record index, id, length), held by another shard
+        }
+    }
+    if (rc == MXG_OK) {
+        a->ctg_run0.push_back((uint32_t)a->runs.size());
+        a->d_packed = static_cast<const uint32_t *>(d_packed);
+        a->packed_words = (end + 15) / 16 + 1;
+        a->has_bases = true;
+        a->shard_lo = std::min(lo_rec, hi_rec);
+        a->shard_hi = hi_rec;
+        a->split_first_cont = hi_rec > lo_rec && piece_lo[lo_rec] > 0;
+    }
+    return commit(h, a, rc);
+}
+
 static int adopt_host_sketch(mxg_handle *h, Assembly *a, const std::vector<uint64_t> &hash,
                              const std::vector<uint32_t> &pos, const std::vector<uint32_t> &rec)
 {

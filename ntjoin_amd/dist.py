@@ -124,8 +124,9 @@ def _allgather_union_graph(eng, k, w, device, union, group, stream):
         eng._xmeta = xm
     meta_h, meta, metas_d, metas_h = xm
     mh = meta_h.numpy()
+    glob = bool(getattr(eng, "global_records", False))  # every rank registered ALL records (shard / split loads): no index shift
     for a in range(A):
-        mh[a, 0], mh[a, 1] = eng.sketch_size(a), eng.n_records(a)
+        mh[a, 0], mh[a, 1] = eng.sketch_size(a), (0 if glob else eng.n_records(a))
     meta.copy_(meta_h, non_blocking=True)
     dist.all_gather_into_tensor(metas_d.view(-1), meta.view(-1), group=group)
     metas_h.copy_(metas_d, non_blocking=True)
@@ -134,10 +135,13 @@ def _allgather_union_graph(eng, k, w, device, union, group, stream):
     if union is None:
         union = MxEngine(k=k, w=w, device=device, timing=True, stream=stream.cuda_stream if stream is not None else None)
         for a in range(A):
-            ids_local = [f"r{rank}:{x}" for x in eng.record_ids(a, eng.n_records(a))]
-            all_ids = [None] * world
-            dist.all_gather_object(all_ids, ids_local, group=group)
-            flat = [x for part in all_ids for x in part]
+            if glob:
+                flat = eng.record_ids(a, eng.n_records(a))
+            else:
+                ids_local = [f"r{rank}:{x}" for x in eng.record_ids(a, eng.n_records(a))]
+                all_ids = [None] * world
+                dist.all_gather_object(all_ids, ids_local, group=group)
+                flat = [x for part in all_ids for x in part]
             union.add_minimizers(eng.assembly_name(a), eng.assembly_weight(a), np.zeros(0, np.uint64),
                                  np.zeros(0, np.uint32), np.zeros(0, np.uint32), flat)
         union._xbuf = {}
@@ -309,13 +313,19 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
     if owner is None:
         owner = MxEngine(k=k, w=w, device=device, timing=True, stream=stream.cuda_stream if stream is not None else None)
         owner._rec_off = []
+        glob = bool(getattr(eng, "global_records", False))  # every rank registered ALL records: record indices are global already
         for a in range(A):
-            ids_local = [f"r{rank}:{x}" for x in eng.record_ids(a, eng.n_records(a))]
-            all_ids = [None] * world
-            dist.all_gather_object(all_ids, ids_local, group=group)
-            owner._rec_off.append(sum(len(p) for p in all_ids[:rank]))
+            if glob:
+                owner._rec_off.append(0)
+                flat = eng.record_ids(a, eng.n_records(a))
+            else:
+                ids_local = [f"r{rank}:{x}" for x in eng.record_ids(a, eng.n_records(a))]
+                all_ids = [None] * world
+                dist.all_gather_object(all_ids, ids_local, group=group)
+                owner._rec_off.append(sum(len(p) for p in all_ids[:rank]))
+                flat = [x for part in all_ids for x in part]
             owner.add_minimizers(eng.assembly_name(a), eng.assembly_weight(a), np.zeros(0, np.uint64), np.zeros(0, np.uint32),
-                                 np.zeros(0, np.uint32), [x for part in all_ids for x in part])
+                                 np.zeros(0, np.uint32), flat)
         owner._buf = {}
         # small fixed-size staging, pinned on the host side: [world][A] size matrices, [world] message sizes, vertex counts
         owner._st = {"c_h": torch.empty((world, A), dtype=torch.int64).pin_memory(), "c_out": torch.empty((world, A), dtype=torch.int64, device=dev),

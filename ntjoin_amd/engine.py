@@ -156,6 +156,30 @@ class MxEngine:
             self._h, str(name).encode(), float(weight), C.c_void_p(int(d_ptr)),
             rs.ctypes.data_as(C.POINTER(C.c_uint64)), rl.ctypes.data_as(C.POINTER(C.c_uint64)), arr_ids, len(rs)))
 
+    def plan_split(self, lengths, shard, n_shards):
+        """pieces of shard `shard` of `n_shards` for N-free records of the given lengths -> (lo, hi, drop) arrays"""
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        lo, hi = np.zeros(len(ln), dtype=np.uint64), np.zeros(len(ln), dtype=np.uint64)
+        drop = np.zeros(len(ln), dtype=np.uint8)
+        rc = self._lib.mxg_plan_split(ln.ctypes.data, len(ln), int(shard), int(n_shards), self.k, self.w, lo.ctypes.data, hi.ctypes.data,
+                                      drop.ctypes.data)
+        if rc != 0:
+            raise ValueError("mxg_plan_split: bad arguments")
+        return lo, hi, drop
+
+    def add_packed_device_pieces(self, name, weight, d_ptr, rec_start, rec_len, lo, hi, drop, ids=None, keepalive=None):
+        """sub-record shard of 2-bit packed bases in HBM (see include/ntjoin_mx.h); d_ptr is borrowed"""
+        arrs = [np.ascontiguousarray(x, dtype=np.uint64) for x in (rec_start, rec_len, lo, hi)]
+        dr = np.ascontiguousarray(drop, dtype=np.uint8)
+        arr_ids = None
+        if ids is not None:
+            arr_ids = (C.c_char_p * len(ids))(*[str(i).encode() for i in ids])
+        if keepalive is not None:
+            self._keep.append(keepalive)
+        return self._check(self._lib.mxg_add_assembly_packed_device_pieces(
+            self._h, str(name).encode(), float(weight), C.c_void_p(int(d_ptr)), arrs[0].ctypes.data, arrs[1].ctypes.data,
+            arrs[2].ctypes.data, arrs[3].ctypes.data, dr.ctypes.data, arr_ids, len(arrs[0])))
+
     def add_tsv(self, name, weight, tsv_path):
         return self._check(self._lib.mxg_add_assembly_tsv(self._h, str(name).encode(), float(weight),
                                                           str(tsv_path).encode()))

@@ -113,3 +113,40 @@ def test_run_dist_ranks_on_one_gpu(tmp_path, world, split):
     with open(os.path.join(GOLDEN, "cases", meta["name"], "reference.mx.dot"), encoding="utf-8") as fh:
         want = go.canonical_dot_from_text(fh.read())
     assert go.canonical_dot_from_text((tmp_path / "out.mx.dot").read_text(encoding="utf-8")) == want
+
+
+@pytest.mark.parametrize("world,workload,mbp,graph", [(2, "configs2", "40", "union"), (4, "configs3", "24", "union"),
+                                                     (4, "configs3", "24", "partitioned"), (8, "configs4", "60", "partitioned"),
+                                                     (8, "configs4", "60", "union")])
+def test_bench_named_workloads_scaled_down(world, workload, mbp, graph):
+    """bench.py --gpus N on the workloads BASELINE.json names for N = 2 / 4 / 8 (configs[2] strong-scaled, configs[3]: four
+    assemblies at w=500, configs[4]: few very long records cut between the ranks + a fragmented target), scaled down: every
+    rank takes an equal base range of every assembly (pieces with halos).  The graph of the whole job must have exactly the
+    vertex and edge counts of the same workload on ONE rank."""
+    import json
+
+    def run(n):
+        env = dict(os.environ, MXG_BENCH_BACKEND="gloo", MXG_BENCH_ONE_DEVICE="1", MXG_BENCH_GRAPH=graph)
+        common = [os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--workload", workload, "--mbp", mbp,
+                  "--no-cpu-baseline", "--no-end-to-end", "--no-kernels"]
+        if n == 1:
+            cmd = [sys.executable] + common
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port())] + common
+        out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    many = run(world)
+    key = (workload, mbp)
+    if key not in _ONE_RANK:
+        _ONE_RANK[key] = run(1)
+    one = _ONE_RANK[key]
+    assert many["n_gpus"] == world and workload.replace("configs", "configs[")[:9] in many["config"]["workload"].replace("]", "")
+    assert many["config"]["bases_per_step"] == one["config"]["bases_per_step"]
+    assert many["config"]["vertices"] == one["config"]["vertices"] > 1000
+    assert many["config"]["edges"] == one["config"]["edges"] > 1000
+    assert many["scaling"] == ("strong" if workload == "configs2" else "weak")
+
+
+_ONE_RANK = {}
