@@ -114,14 +114,21 @@ def workload_tables(name, mbp, w, seed=1):
     return cfg, asms, label
 
 
-def add_rank_share(eng, name, weight, segs, seed, sub_seed, sub, rank, world, device):
-    """this rank's share of one assembly, born in HBM: shard `rank` of `world` EQUAL BASE RANGES of the concatenated records,
-    whatever the record borders (records cut by a range travel as pieces with a halo of w k-mers, mxg_plan_split); every rank
-    registers every record, so record indices are global.  world = 1: the whole assembly.
-    -> (device tensor, rec_start, rec_len) of what the rank holds"""
+def add_rank_share(eng, name, weight, segs, seed, sub_seed, sub, rank, world, device, split=True):
+    """this rank's share of one assembly, born in HBM.  split=True: shard `rank` of `world` EQUAL BASE RANGES of the concatenated
+    records, whatever the record borders (records cut by a range travel as pieces with a halo of w k-mers, mxg_plan_split);
+    split=False: a contiguous range of WHOLE records balanced by base count (mxg_shard_range) -- what the hash-partitioned graph
+    stage needs, whose adjacency messages never leave a record's rank.  Every rank registers every record, so record indices
+    are global.  world = 1: the whole assembly.  -> (device tensor, rec_start, rec_len) of what the rank holds"""
     from ntjoin_amd import synth
+    from ntjoin_amd.dist import shard_range
     lens = np.ascontiguousarray(segs[:, 2])
-    lo, hi, drop = eng.plan_split(lens, rank, world)
+    if split or world == 1:
+        lo, hi, drop = eng.plan_split(lens, rank, world)
+    else:
+        r0, r1 = shard_range(lens, rank, world)
+        lo, hi, drop = np.zeros(len(lens), dtype=np.uint64), np.zeros(len(lens), dtype=np.uint64), np.zeros(len(lens), dtype=np.uint8)
+        hi[r0:r1] = lens[r0:r1]
     keep = hi > lo
     b0 = lo & ~np.uint64(15)
     plen = np.where(keep, hi - b0, 0).astype(np.uint64)
@@ -263,18 +270,17 @@ def main():
     xstream = torch.cuda.Stream() if multi else None
     eng = MxEngine(k=K, w=W, device=local_rank, timing=True, cand_per_window=args.cand,
                    stream=xstream.cuda_stream if xstream is not None else None)
-    bases_job = 0
+    bases_job = sum(int(a[2][:, 2].sum()) for a in asms)
+    m_rank = 2e-6 * bases_job / (W + 1) / world  # minimizers per rank, millions (density 2/(w+1))
+    graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("partitioned" if m_rank * (0.14 * world - 0.2) > 0.39 else "union")
     for name, weight, segs, n_words, sub, sub_seed in asms:
         d, rec_start, rec_len = add_rank_share(eng, name, weight, segs, cfg["seed"], sub_seed, sub, rank if world > 1 else 0, world,
-                                               local_rank)  # bases born in HBM
+                                               local_rank, split=graph_mode != "partitioned")  # bases born in HBM
         keep.append(d)
         host_layout.append((d, rec_start, rec_len))
-        bases_job += int(segs[:, 2].sum())
     eng.global_records = True
     torch.cuda.synchronize()
     union = None
-    m_rank = 2e-6 * bases_job / (W + 1) / world  # minimizers per rank, millions (density 2/(w+1))
-    graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("partitioned" if m_rank * (0.14 * world - 0.2) > 0.39 else "union")
 
     def step(e=eng):
         nonlocal union
@@ -354,8 +360,11 @@ def main():
                        "minimizers_rank0": int(st["minimizers"]),
                        "vertices": int(gst["vertices"]), "edges": int(gst["edges"]),
                        "records": [int(len(a[2])) for a in asms],
-                       "parallelism": ("1 GPU" if world == 1 else f"{world} ranks, each 1/{world} of every assembly's bases "
-                                       "(records cut at the range borders travel as pieces with a w-k-mer halo), " +
+                       "parallelism": ("1 GPU" if world == 1 else f"{world} ranks, " +
+                                       ("a contiguous range of whole records of every assembly each (balanced by bases), "
+                                        if graph_mode == "partitioned" else
+                                        f"each 1/{world} of every assembly's bases (records cut at the range borders travel as pieces "
+                                        "with a w-k-mer halo), ") +
                                        ("graph stage partitioned by hash range (RCCL all-to-all)" if graph_mode == "partitioned"
                                         else "RCCL all-gather of sketches, graph of the union on every rank"))},
             "step_ms_min_max": [round(min(step_times) * 1e3, 4), round(max(step_times) * 1e3, 4)],

@@ -310,6 +310,11 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", device)
     cur = torch.cuda.current_stream()
+    if world > 1 and any(eng.assembly_continues(a) for a in range(A)):
+        # the adjacency messages are made per rank from ITS records' consecutive shared minimizers: a record cut between two
+        # ranks would lose the edge across the cut.  Shard whole records for this route (the union route takes pieces).
+        raise ValueError("partitioned_graph needs whole records per rank (this handle holds a piece of a record begun on the "
+                         "rank before it: use shard loads, or the union exchange)")
     if owner is None:
         owner = MxEngine(k=k, w=w, device=device, timing=True, stream=stream.cuda_stream if stream is not None else None)
         owner._rec_off = []
