@@ -227,14 +227,29 @@ __device__ __forceinline__ uint32_t pj_slot(unsigned long long *keys, uint64_t k
     return PJ_T + 1u;
 }
 
+// Two levels (more than PJ_MAX_P x 1280 minimizers): `cursor` != nullptr.  k_pj1_scatter has dealt the minimizers into P1 coarse
+// partitions of capacity cap1 (coarse partition c holds cursor[c * PJ1_CS] records from c * cap1 on), k_pj2_bucket has sorted
+// every 4096-record region of a coarse partition into P sub-partitions (rows of M: rows2 per coarse partition); block
+// blockIdx.x = c * P + b joins sub-partition b of coarse partition c.
+constexpr uint32_t PJ1_CS = 32;  // words between the coarse partitions' cursors (own 128-byte lines: same-line atomics serialise)
 __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__restrict__ M, uint32_t P, uint32_t n_rows,
-                                                 uint64_t *host_fail, uint32_t force_fail)
+                                                 uint64_t *host_fail, uint32_t force_fail, const uint32_t *__restrict__ cursor,
+                                                 uint32_t cap1, uint32_t rows2)
 {
     __shared__ unsigned long long keys[PJ_T + 1];
     __shared__ uint32_t seen[PJ_T + 1], dup[PJ_T + 1];
     __shared__ uint32_t seg_off[257], seg_rec[256], sh[256];
     __shared__ uint32_t failed;
-    const uint32_t b = blockIdx.x;
+    uint32_t b = blockIdx.x, rec_off = 0;
+    if (cursor) {
+        const uint32_t c = blockIdx.x / P;
+        b = blockIdx.x % P;
+        const uint32_t n_c = min(cursor[c * PJ1_CS], cap1);
+        n_rows = (n_c + PJ_IPB - 1) / PJ_IPB;
+        M += (size_t)c * rows2 * (P + 1);
+        rec_off = c * cap1;
+        if (cursor[c * PJ1_CS] > cap1 && threadIdx.x == 0) *host_fail = 1;  // the coarse partition overflowed: global table
+    }
     for (uint32_t s = threadIdx.x; s <= PJ_T; s += 256) {
         keys[s] = HT_EMPTY;
         seen[s] = 0;
@@ -262,7 +277,7 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
                 }
                 const uint32_t off = block_exclusive_256(len, sh);
                 seg_off[threadIdx.x] = off;
-                seg_rec[threadIdx.x] = j * PJ_IPB + lo;
+                seg_rec[threadIdx.x] = rec_off + j * PJ_IPB + lo;
                 __syncthreads();
             }
             const uint32_t total = sh[255];
@@ -285,7 +300,7 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
                 return s;
             };
             auto finish = [&](uint32_t r, uint32_t s) {
-                recs[r] = bad ? make_uint4(0u, 0u, b * (PJ_T + 1u), 0u) : make_uint4(seen[s], dup[s], b * (PJ_T + 1u) + s, 0u);
+                recs[r] = bad ? make_uint4(0u, 0u, blockIdx.x * (PJ_T + 1u), 0u) : make_uint4(seen[s], dup[s], blockIdx.x * (PJ_T + 1u) + s, 0u);
             };
 #pragma unroll
             for (uint32_t it = 0; it < QC; ++it) {
@@ -311,10 +326,121 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
     }
 }
 
+
+// level 1 of the two-level join: 4096 minimizers per block (the same item order as k_pj_bucket), LDS histogram over P1
+// coarse partitions (hash bits 52..63), ONE device-scope add per non-empty (block, partition) bin reserves the bin's place
+// in the partition (4096 / P1 records per add; the cursors sit on their own lines), then the records are dealt out.
+__device__ __forceinline__ uint32_t pj1_part(uint64_t key, uint32_t p1mask) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 52) & p1mask; }
+
+__global__ __launch_bounds__(PJ_BT) void k_pj1_scatter(const AsmSet p, uint32_t nb, uint32_t p1mask, uint32_t cap1, uint32_t *cursor,
+                                                     uint4 *recs1, uint32_t *sup, uint32_t n_sup)
+{
+    extern __shared__ uint32_t pj_lds[];
+    uint32_t *hist = pj_lds, *start = pj_lds + p1mask + 1;
+    if (blockIdx.x == 0)  // super-counts of the two counting kernels that follow (scan_kernels.h)
+        for (uint32_t i = threadIdx.x; i < n_sup; i += PJ_BT) sup[i] = 0;
+    constexpr uint32_t U = PJ_IPB / PJ_BT, BPU = PJ_BT / 256;
+    const uint32_t j = blockIdx.x, sub = threadIdx.x >> 8, t256 = threadIdx.x & 255u;
+    const uint32_t blk0 = j * (PJ_IPB / 256);
+    uint64_t key[U];
+    uint32_t ia[U], ii[U], live = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+        const uint32_t blk = blk0 + u * BPU + sub;
+        key[u] = 0;
+        ia[u] = ii[u] = 0;
+        if (blk >= nb) continue;
+        const uint32_t a = asm_of_block(p, blk);
+        const uint32_t i = (blk - p.bstart[a]) * 256u + t256;
+        if (i < asm_n(p, a)) {
+            key[u] = p.hash[a][i];
+            ia[u] = a;
+            ii[u] = i;
+            live |= 1u << u;
+        }
+    }
+    for (uint32_t b = threadIdx.x; b <= p1mask; b += PJ_BT) hist[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u)
+        if ((live >> u) & 1u) atomicAdd(&hist[pj1_part(key[u], p1mask)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b <= p1mask; b += PJ_BT) {
+        const uint32_t c = hist[b];
+        start[b] = c ? atomicAdd(&cursor[b * PJ1_CS], c) : 0u;
+        hist[b] = 0;  // from here on: records of this bin already placed
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+        if (!((live >> u) & 1u)) continue;
+        const uint32_t b = pj1_part(key[u], p1mask);
+        const uint32_t pos = start[b] + atomicAdd(&hist[b], 1u);
+        if (pos < cap1) recs1[(size_t)b * cap1 + pos] = make_uint4((uint32_t)key[u], (uint32_t)(key[u] >> 32), ii[u], ia[u]);
+        // (beyond the capacity: the cursor says so, k_pj_join reports it and the host redoes the stage with the global table)
+    }
+}
+
+// level 2: block (j, c) sorts records [j * 4096, (j + 1) * 4096) of coarse partition c by sub-partition (hash bits 44..) inside
+// their region of recs2, writes its row of M and tells every minimizer where its record went (slot[a][i], read by k_flags_pj)
+__global__ __launch_bounds__(PJ_BT) void k_pj2_bucket(const AsmSet p, const uint4 *__restrict__ recs1, const uint32_t *__restrict__ cursor,
+                                                    uint32_t cap1, uint32_t rows2, uint32_t pmask, uint32_t *M, uint4 *recs2)
+{
+    extern __shared__ uint32_t pj_lds[];
+    uint32_t *hist = pj_lds, *start = pj_lds + pmask + 1;
+    __shared__ uint32_t sh[256];
+    const uint32_t j = blockIdx.x, c = blockIdx.y;
+    const uint32_t n_c = min(cursor[c * PJ1_CS], cap1);
+    if (j * PJ_IPB >= n_c) return;  // (block-uniform) nothing of this coarse partition in this region
+    constexpr uint32_t U = PJ_IPB / PJ_BT;
+    const size_t base = (size_t)c * cap1 + (size_t)j * PJ_IPB;
+    uint4 rec[U];
+    uint32_t live = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+        const uint32_t q = u * PJ_BT + threadIdx.x;
+        rec[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (j * PJ_IPB + q < n_c) {
+            rec[u] = recs1[base + q];
+            live |= 1u << u;
+        }
+    }
+    for (uint32_t b = threadIdx.x; b <= pmask; b += PJ_BT) hist[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u)
+        if ((live >> u) & 1u) atomicAdd(&hist[pj_part(((uint64_t)rec[u].y << 32) | rec[u].x, pmask)], 1u);
+    __syncthreads();
+    const uint32_t P = pmask + 1, per = P >= PJ_BT ? P / PJ_BT : 1u, b0 = threadIdx.x * per;
+    uint32_t cn = 0;
+    if (b0 < P)
+        for (uint32_t u = 0; u < per; ++u) cn += hist[b0 + u];
+    uint32_t run = block_exclusive<PJ_BT / 64>(cn, sh);
+    uint32_t *row = M + ((size_t)c * rows2 + j) * (P + 1);
+    if (b0 < P)
+        for (uint32_t u = 0; u < per; ++u) {
+            const uint32_t cb = hist[b0 + u];
+            start[b0 + u] = run;
+            row[b0 + u] = run;
+            hist[b0 + u] = 0;
+            run += cb;
+        }
+    if (threadIdx.x == 0) row[P] = sh[255];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+        if (!((live >> u) & 1u)) continue;
+        const uint32_t b = pj_part(((uint64_t)rec[u].y << 32) | rec[u].x, pmask);
+        const uint32_t pos = (uint32_t)base + start[b] + atomicAdd(&hist[b], 1u);
+        recs2[pos] = rec[u];
+        p.slot[rec[u].w][rec[u].z] = pos;  // k_flags_pj replaces it by the slot
+    }
+}
+
 // k_flags for the partitioned join: the table state of minimizer i sits in recs[slot[a][i]]
 // (also clears this item's cells of the adjacency arrays nxt[A][nvs] | prv[A][nvs]: saves the fill launch)
 __global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, const uint4 *__restrict__ recs, uint32_t *cnt, uint32_t *sup,
-                                                  uint32_t *nxt, uint32_t nvs)
+                                                  uint32_t *nxt, uint32_t nvs, uint32_t rec_limit)
 {
     const uint32_t a = asm_of_block(p, blockIdx.x);
     const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
@@ -325,7 +451,8 @@ __global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, const uint4 *_
     bool sh = false;
     if (i < asm_n(p, a)) {
         const uint32_t bit = 1u << a, full = p.full;
-        const uint4 r = recs[p.slot[a][i]];
+        // (rec_limit: a record dropped by an overflowing coarse partition left no position behind; the stage is redone then)
+        const uint4 r = recs[min(p.slot[a][i], rec_limit)];
         const uint32_t seen = r.x & full, d = r.y & full;
         const bool uniq = !(d & bit);
         const bool inall = seen == full;
@@ -586,11 +713,24 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
     uint32_t P = 256;
     while ((uint64_t)P * 1280 < N) P <<= 1;
     const char *join_env = getenv("MXG_GRAPH_JOIN");
-    const bool pj = mode == GRAPH_FULL && !global_table && P <= PJ_MAX_P && !(join_env && !strcmp(join_env, "global"));
+    // beyond PJ_MAX_P partitions of <= 1280 records: two levels -- P1 coarse partitions, each sorted into 256 sub-partitions
+    // (MXG_PJ_TWO_LEVEL=1 forces them on small inputs: test knob)
+    uint32_t P1 = 0, cap1 = 0, rows2 = 0;
+    if (P > PJ_MAX_P || (getenv("MXG_PJ_TWO_LEVEL") && atoi(getenv("MXG_PJ_TWO_LEVEL")))) {
+        P = 256;
+        P1 = 2;
+        while ((uint64_t)P1 * P * 1000 < N) P1 <<= 1;
+        const uint64_t c1 = (N / P1) + (N / P1) / 4 + 4096;  // 25 % above the mean (hash skew: keys of huge multiplicity)
+        cap1 = (uint32_t)((c1 + PJ_IPB - 1) / PJ_IPB * PJ_IPB);
+        rows2 = cap1 / PJ_IPB;
+    }
+    const bool two_level = P1 != 0 && P1 <= 4096 && (uint64_t)P1 * cap1 < (1ull << 32);
+    const bool pj = mode == GRAPH_FULL && !global_table && (P1 == 0 || two_level) && P <= PJ_MAX_P &&
+                    !(join_env && !strcmp(join_env, "global"));
     const uint32_t pj_force_fail = getenv("MXG_PJ_FORCE_FAIL") && atoi(getenv("MXG_PJ_FORCE_FAIL")) ? 1u : 0u;
 
-    MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * sizeof(Slot)));  // (the partitioned join keeps its N records here)
-    MXG_HIP(h, h->g_vid.ensure(std::max<size_t>((size_t)cap + 1, pj ? (size_t)P * (PJ_T + 1) : 0) * 4));
+    if (!pj) MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * sizeof(Slot)));  // (the partitioned join keeps its N records here)
+    MXG_HIP(h, h->g_vid.ensure(std::max<size_t>((size_t)cap + 1, pj ? (size_t)std::max(P1, 1u) * P * (PJ_T + 1) : 0) * 4));
     MXG_HIP(h, h->g_ctl.ensure(CTL_WORDS * 8));
     if (pj) {
         // (nothing to clear: every word of M and of the record regions that is read is written by this call)
@@ -642,7 +782,26 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
     const uint32_t n_fsup = ((nb >> SUP_SHIFT) + A + 1) * SUP_STRIDE, n_esup = sup_words(e_blocks);
     MXG_HIP(h, h->g_cnt.ensure(((size_t)n_fsup + n_esup + nb) * 4 + 64));
     uint32_t *fsup = h->g_cnt.as<uint32_t>(), *esup = fsup + n_fsup, *cnt = esup + n_esup;
-    if (nb && !resume && pj) {
+    if (nb && !resume && pj && two_level) {
+        const uint32_t n_rows1 = (nb + PJ_IPB / 256 - 1) / (PJ_IPB / 256);
+        const size_t n_recs = (size_t)P1 * cap1;
+        MXG_HIP(h, h->g_part.ensure((size_t)P1 * rows2 * (P + 1) * 4 + (size_t)P1 * PJ1_CS * 4));
+        MXG_HIP(h, h->g_keys.ensure(n_recs * sizeof(uint4)));   // level-2 records (what k_flags_pj reads)
+        MXG_HIP(h, h->g_recs1.ensure(n_recs * sizeof(uint4)));  // level-1 records
+        uint32_t *M = h->g_part.as<uint32_t>();
+        uint32_t *cursor = M + (size_t)P1 * rows2 * (P + 1);
+        MXG_HIP(h, hipMemsetAsync(cursor, 0, (size_t)P1 * PJ1_CS * 4, h->stream));
+        uint4 *recs1 = h->g_recs1.as<uint4>(), *recs2 = h->g_keys.as<uint4>();
+        hipLaunchKernelGGL(k_pj1_scatter, dim3(n_rows1), dim3(PJ_BT), (size_t)P1 * 8, h->stream, as_all, nb, P1 - 1, cap1, cursor, recs1,
+                           fsup, n_fsup + n_esup);
+        hipLaunchKernelGGL(k_pj2_bucket, dim3(rows2, P1), dim3(PJ_BT), (size_t)P * 8, h->stream, as_all, recs1, cursor, cap1, rows2, P - 1, M,
+                           recs2);
+        hipLaunchKernelGGL(k_pj_join, dim3(P1 * P), dim3(256), 0, h->stream, recs2, M, P, 0u, hctl + CTL_PJ_FAIL, pj_force_fail, cursor, cap1,
+                           rows2);
+        MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4 + 16));  // nxt[A][nvs] followed by prv[A][nvs], cleared by k_flags_pj
+        hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, recs2, cnt, fsup, h->g_nxt.as<uint32_t>(),
+                           (uint32_t)nvs, (uint32_t)(n_recs - 1));
+    } else if (nb && !resume && pj) {
         const uint32_t n_rows = (nb + PJ_IPB / 256 - 1) / (PJ_IPB / 256);  // bucketing blocks = record regions = rows of M
         MXG_HIP(h, h->g_part.ensure((size_t)n_rows * (P + 1) * 4));
         MXG_HIP(h, h->g_keys.ensure((size_t)n_rows * PJ_IPB * sizeof(uint4)));
@@ -650,10 +809,10 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         uint4 *recs = h->g_keys.as<uint4>();
         hipLaunchKernelGGL(k_pj_bucket, dim3(n_rows), dim3(PJ_BT), (size_t)P * 8, h->stream, as_all, nb, P - 1, M, recs, fsup,
                            n_fsup + n_esup);
-        hipLaunchKernelGGL(k_pj_join, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, hctl + CTL_PJ_FAIL, pj_force_fail);
+        hipLaunchKernelGGL(k_pj_join, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, hctl + CTL_PJ_FAIL, pj_force_fail, nullptr, 0u, 0u);
         MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4 + 16));  // nxt[A][nvs] followed by prv[A][nvs], cleared by k_flags_pj
         hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, recs, cnt, fsup, h->g_nxt.as<uint32_t>(),
-                           (uint32_t)nvs);
+                           (uint32_t)nvs, n_rows * PJ_IPB - 1u);
     } else if (nb && !resume) {
         hipLaunchKernelGGL(k_insert, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), mask, cap, fsup,
                            n_fsup + n_esup);

@@ -22,8 +22,11 @@ def _graph_state(eng, n_asm):
 
 def _three_ways(monkeypatch, build):
     res = []
-    for env in ({}, {"MXG_GRAPH_JOIN": "global"}, {"MXG_PJ_FORCE_FAIL": "1"}):
-        for key in ("MXG_GRAPH_JOIN", "MXG_PJ_FORCE_FAIL"):
+    # default (LDS tables per hash partition), the global table, the fallback after a failed LDS join, and the two-level LDS
+    # join that genome-scale inputs (> 5 M minimizers) take, forced here
+    for env in ({}, {"MXG_GRAPH_JOIN": "global"}, {"MXG_PJ_FORCE_FAIL": "1"}, {"MXG_PJ_TWO_LEVEL": "1"},
+                {"MXG_PJ_TWO_LEVEL": "1", "MXG_PJ_FORCE_FAIL": "1"}):
+        for key in ("MXG_GRAPH_JOIN", "MXG_PJ_FORCE_FAIL", "MXG_PJ_TWO_LEVEL"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
@@ -136,3 +139,35 @@ def test_joins_agree_beyond_256_regions(monkeypatch):
             assert eng.stats()["vertices"] > 700_000
             return _graph_state(eng, len(sets))
     _three_ways(monkeypatch, build)
+
+
+def test_two_level_join_coarse_partition_overflow_falls_back(monkeypatch):
+    """one key 400 000 times among 900 000 minimizers: its coarse partition outgrows the capacity reserved for it (25 % above
+    the mean); the stage must notice and redo itself with the global table -- same result as asking for that table directly"""
+    from ntjoin_amd.engine import MxEngine
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 2**63, size=500_000, dtype=np.int64).astype(np.uint64)
+
+    def mk(seed, heavy):
+        r = np.random.default_rng(seed)
+        hs = base.copy()
+        r.shuffle(hs)
+        hs = np.concatenate([hs, np.full(heavy, base[7], dtype=np.uint64)])
+        rec = np.sort(r.integers(0, 16, size=hs.size)).astype(np.uint32)
+        return hs, np.arange(hs.size, dtype=np.uint32), rec, [f"c{i}" for i in range(16)]
+
+    sets = [mk(1, 400_000), mk(2, 0)]
+    res = []
+    for env in ({"MXG_PJ_TWO_LEVEL": "1"}, {"MXG_GRAPH_JOIN": "global"}):
+        for key in ("MXG_GRAPH_JOIN", "MXG_PJ_TWO_LEVEL"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        with MxEngine(k=32, w=1000) as eng:
+            for i, (hs, pos, rec, ids) in enumerate(sets):
+                eng.add_minimizers(f"a{i}", float(i + 1), hs, pos, rec, ids)
+            eng.build_graph()
+            assert eng.stats()["vertices"] == 499_999
+            res.append(_graph_state(eng, 2))
+    for key in res[0]:
+        assert np.array_equal(res[0][key], res[1][key]), key
