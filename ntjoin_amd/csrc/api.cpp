@@ -91,6 +91,11 @@ void mxg_destroy(mxg_handle *h)
         (void)hipStreamSynchronize(h->stream2);
         (void)hipStreamDestroy(h->stream2);
     }
+    for (hipStream_t s : h->stream_x)
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
     for (auto *a : h->asms) delete a;
     h->asms.clear();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);

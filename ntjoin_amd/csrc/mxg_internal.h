@@ -174,6 +174,7 @@ struct mxg_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // second stream of the pipelined multi-assembly sketch (always library-owned)
+    hipStream_t stream_x[2] = {nullptr, nullptr};  // third / fourth stream: batches of multi-batch assemblies (created on first use)
     bool own_stream = false;
     std::string err;
     std::vector<mxg::Assembly *> asms;
@@ -194,7 +195,7 @@ struct mxg_handle {
     mxg::DevBuf d_init_tab;  // byte table of the direct hash formula (256 x 16 B), built by the first sketch
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
     // scratch reused across calls
-    mxg::DevBuf scratch[2][40];  // two sets, indexed by mxg::Scratch (sketch.hip): one per in-flight sketch driver
+    mxg::DevBuf scratch[4][40];  // indexed by mxg::Scratch (sketch.hip): one set per in-flight sketch driver (= stream)
     std::vector<mxg::Assembly *> pend_list;  // mxg_sketch_pack in flight: assemblies and how each was enqueued
     std::vector<int> pend_state;
     mxg::DevBuf g_part;     // partitioned join (graph.hip): partition offsets of every bucketing block

@@ -1348,7 +1348,7 @@ struct Driver {
     hipStream_t st;   // stream this driver enqueues on
     int slot;         // which of the handle's two scratch sets it uses (two drivers can be in flight at once)
     explicit Driver(mxg_handle *h_, int slot_ = 0)
-        : h(h_), timing((h_->cfg.flags & (MXG_FLAG_TIMING | MXG_FLAG_TIMING_FINE)) != 0), st(slot_ == 0 ? h_->stream : h_->stream2), slot(slot_)
+        : h(h_), timing((h_->cfg.flags & (MXG_FLAG_TIMING | MXG_FLAG_TIMING_FINE)) != 0), st(slot_ == 0 ? h_->stream : slot_ == 1 ? h_->stream2 : h_->stream_x[slot_ - 2]), slot(slot_)
     {
         fine = (h_->cfg.flags & MXG_FLAG_TIMING_FINE) != 0;
     }
@@ -2181,9 +2181,17 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
     MXG_HIP(h, hipSetDevice(h->device));
     int rc = ensure_pinned_ctrl(h);
     if (rc != MXG_OK) return rc;
-    Driver drv0(h, 0), drv1(h, 1);
-    static const bool one_stream = getenv("MXG_ONE_STREAM") != nullptr;  // profiling: kernels of the two streams do not overlap
-    Driver *drvs[2] = {&drv0, one_stream ? &drv0 : &drv1};
+    // batches of multi-batch assemblies rotate over the streams (MXG_STREAMS = 2..4), so that one batch's latency-bound tail
+    // (emit, stretch fix-up) has another batch's hash kernel to run beside.  Two are enough: measured on MI355X at 3 Gbp +
+    // 3 Gbp, 1072 / 1076 / 1046 Gbp/s with 2 / 3 / 4 streams -- the sum of the kernels' own times (9 ms per step under
+    // rocprofv3) already overlaps into 5.6 ms of wall time
+    uint32_t n_str = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(2, env_u64("MXG_STREAMS", 2)));
+    for (uint32_t x = 0; x + 2 < n_str; ++x)
+        if (!h->stream_x[x]) MXG_HIP(h, hipStreamCreateWithFlags(&h->stream_x[x], hipStreamNonBlocking));
+    Driver drv0(h, 0), drv1(h, 1), drv2(h, n_str > 2 ? 2 : 1), drv3(h, n_str > 3 ? 3 : 1);
+    static const bool one_stream = getenv("MXG_ONE_STREAM") != nullptr;  // profiling: kernels of the streams do not overlap
+    Driver *drvs[4] = {&drv0, one_stream ? &drv0 : &drv1, one_stream ? &drv0 : &drv2, one_stream ? &drv0 : &drv3};
+    if (one_stream) n_str = 2;
     struct Item {
         size_t asm_i;
         Driver::BatchGeom g;
@@ -2196,7 +2204,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
     std::vector<SparsePlan> plans(n);
     std::vector<Item> items;
     std::vector<size_t> item0(n + 1, 0);
-    size_t last_on_slot[2] = {(size_t)-1, (size_t)-1};
+    size_t last_on_slot[4] = {(size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
     size_t n_enq = 0, next_slot = 0;
     const bool chain_modes = fuse_graph || xp;  // (these two need one batch per assembly)
     for (size_t i = 0; i < n; ++i) {
@@ -2231,7 +2239,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             // finished earlier); batches of a multi-batch assembly simply alternate
             size_t sl;
             if (gs.size() == 1) sl = h->own_stream ? ((n - 1 - i) & 1) : (i & 1);
-            else sl = next_slot++ & 1;
+            else sl = next_slot++ % n_str;
             Driver &drv = *drvs[sl];
             Item it;
             it.asm_i = i;
@@ -2322,6 +2330,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
     }
     MXG_HIP(h, stream_wait(h->stream));
     MXG_HIP(h, stream_wait(h->stream2));
+    for (hipStream_t sx : h->stream_x)
+        if (sx) MXG_HIP(h, stream_wait(sx));
     size_t n_fast = 0;  // assemblies whose every batch ended the common way
     for (size_t i = 0; i < n; ++i) {
         if (state[i] != 1) continue;
@@ -2371,7 +2381,6 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         if (state[i] == 0 && (rc = run_sketch_sync(h, list[i], tabs[i], drv0)) != MXG_OK) return rc;
     }
     if ((rc = drv0.collect()) != MXG_OK) return rc;
-    if ((rc = drv1.collect()) != MXG_OK) return rc;
     if (fuse_graph && !fused) {
         h->graph.valid = false;
         return build_graph(h);
@@ -2426,6 +2435,8 @@ int flush_timers(mxg_handle *h)
     MXG_HIP(h, hipSetDevice(h->device));
     MXG_HIP(h, hipStreamSynchronize(h->stream));
     MXG_HIP(h, hipStreamSynchronize(h->stream2));
+    for (hipStream_t sx : h->stream_x)
+        if (sx) MXG_HIP(h, hipStreamSynchronize(sx));
     for (auto &e : h->ev_spans) {
         float ms = 0;
         MXG_HIP(h, hipEventElapsedTime(&ms, e.a, e.b));
