@@ -927,25 +927,30 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
         __syncthreads();
         before = sh_before;
     }
-    uint64_t o = obase + before + block_exclusive_256(c, sh);
-    if (c == 0) return;
-    for (int u = 0; u < TILE_PER_THREAD; ++u) {
-        uint32_t i = base + u;
-        if ((fl >> (8 * u)) & 1u) {
-            uint32_t cs = p.cc[i], ctg = cs & 0x7FFFFFFFu, kx = p.ck[i];
-            // contig-local valid-k-mer index -> base position, through the contig's run table
-            uint32_t lo = p.ctg_run0[ctg], hi = p.ctg_run0[ctg + 1];
-            while (hi - lo > 1) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (p.runs[mid].kidx0 <= kx) lo = mid; else hi = mid;
-            }
-            if (o < limit) {  // (the strand byte is filled lazily by k_strand, only when somebody asks for it)
-                o_hash[o] = ext_hash(p.ch[i], p.mult);
-                o_pos[o] = p.runs[lo].pos0 + (kx - p.runs[lo].kidx0);
-                o_rec[o] = p.ctg_rec[ctg];
-            }
-            ++o;
+    // About one candidate in ten is selected: the selected ones' indices are first laid end to end in LDS, then consecutive
+    // threads turn them into minimizers -- full waves of gathers (candidate arrays, run table) and contiguous stores instead
+    // of a few lanes per wave.
+    __shared__ uint16_t picked[TILE];
+    uint32_t l = block_exclusive_256(c, sh);
+    const uint32_t tile_total = sh[255];
+    for (int u = 0; u < TILE_PER_THREAD; ++u)
+        if ((fl >> (8 * u)) & 1u) picked[l++] = (uint16_t)(threadIdx.x * TILE_PER_THREAD + u);
+    __syncthreads();
+    const uint64_t o0 = obase + before;
+    for (uint32_t r = threadIdx.x; r < tile_total; r += 256u) {
+        const uint32_t i = blockIdx.x * TILE + picked[r];
+        const uint64_t o = o0 + r;
+        if (o >= limit) continue;  // (speculative emit into arrays sized by an estimate)
+        const uint32_t ctg = p.cc[i] & 0x7FFFFFFFu, kx = p.ck[i];
+        // contig-local valid-k-mer index -> base position, through the contig's run table
+        uint32_t lo = p.ctg_run0[ctg], hi = p.ctg_run0[ctg + 1];
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (p.runs[mid].kidx0 <= kx) lo = mid; else hi = mid;
         }
+        o_hash[o] = ext_hash(p.ch[i], p.mult);  // (the strand byte is filled lazily by k_strand, only when somebody asks for it)
+        o_pos[o] = p.runs[lo].pos0 + (kx - p.runs[lo].kidx0);
+        o_rec[o] = p.ctg_rec[ctg];
     }
 }
 
@@ -1139,7 +1144,10 @@ struct GapPostParams {
     uint64_t *d_hash; uint32_t *d_pos, *d_rec;  // laid end to end in (record, position) order
 };
 
-__global__ __launch_bounds__(1024) void k_gap_post(const GapPostParams p)
+// (256 threads: a single block of 1024 had to wait for sixteen free wave slots on one CU while the other stream's hash kernel
+// held them all -- 23 us per launch under rocprofv3 for a microsecond of work)
+constexpr uint32_t GPB = 256;
+__global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
 {
     __shared__ uint64_t keys[GAP_DEV_MAX];
     __shared__ uint32_t src[GAP_DEV_MAX], off[GAP_DEV_MAX], sh[256];
@@ -1151,23 +1159,23 @@ __global__ __launch_bounds__(1024) void k_gap_post(const GapPostParams p)
         }
         return;
     }
-    for (uint32_t i = threadIdx.x; i < n_g; i += 1024) keys[i] = p.r_key[i];
+    for (uint32_t i = threadIdx.x; i < n_g; i += GPB) keys[i] = p.r_key[i];
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_g; i += 1024) {  // rank by counting: the keys (contig, first k-mer) are distinct
+    for (uint32_t i = threadIdx.x; i < n_g; i += GPB) {  // rank by counting: the keys (contig, first k-mer) are distinct
         const uint64_t key = keys[i];
         uint32_t r = 0;
         for (uint32_t q = 0; q < n_g; ++q) r += keys[q] < key ? 1u : 0u;
         src[r] = i;
     }
     __syncthreads();
-    constexpr uint32_t PER = GAP_DEV_MAX / 1024;
+    constexpr uint32_t PER = GAP_DEV_MAX / GPB;
     uint32_t c[PER], tot = 0;
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t r = threadIdx.x * PER + u;
         c[u] = r < n_g ? p.r_cnt[src[r]] : 0u;
         tot += c[u];
     }
-    uint32_t run = block_exclusive<16>(tot, sh);
+    uint32_t run = block_exclusive<GPB / 64>(tot, sh);
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t r = threadIdx.x * PER + u;
         if (r < n_g) off[r] = run;
@@ -1175,7 +1183,7 @@ __global__ __launch_bounds__(1024) void k_gap_post(const GapPostParams p)
     }
     if (threadIdx.x == 0) p.ctrl[7] = sh[255];
     __syncthreads();
-    for (uint32_t r = threadIdx.x; r < n_g; r += 1024) {
+    for (uint32_t r = threadIdx.x; r < n_g; r += GPB) {
         const uint32_t g = src[r], cn = p.r_cnt[g];
         for (uint32_t e = 0; e < cn; ++e) {
             p.d_hash[off[r] + e] = p.r_hash[(size_t)g * GAP_DEV_REG + e];
@@ -1876,7 +1884,7 @@ struct Driver {
             pp.d_hash = sc(SC_GD_HASH).as<uint64_t>();
             pp.d_pos = sc(SC_GD_POS).as<uint32_t>();
             pp.d_rec = sc(SC_GD_REC).as<uint32_t>();
-            hipLaunchKernelGGL(k_gap_post, dim3(1), dim3(1024), 0, st, pp);
+            hipLaunchKernelGGL(k_gap_post, dim3(1), dim3(GPB), 0, st, pp);
             FinParams fp;
             fp.ctrl = sc(SC_CTRL).as<uint32_t>();
             fp.host_ctrl = ctrl_host;
