@@ -205,8 +205,8 @@ __global__ __launch_bounds__(PJ_BT) void k_pj_bucket(const AsmSet p, uint32_t nb
         }
         const uint32_t b = pj_part(key[u], pmask);
         const uint32_t pos = j * PJ_IPB + start[b] + atomicAdd(&hist[b], 1u);
-        recs[pos] = make_uint4((uint32_t)key[u], (uint32_t)(key[u] >> 32), i, a);
-        sp[i] = pos;  // k_flags_pj replaces it by the slot
+        recs[pos] = make_uint4((uint32_t)key[u], (uint32_t)(key[u] >> 32), i, a);  // (the record knows whose it is: k_pj_join
+        (void)sp;                                                                   //  sends the verdict straight to slot[a][i])
     }
 }
 
@@ -234,8 +234,9 @@ __device__ __forceinline__ uint32_t pj_slot(unsigned long long *keys, uint64_t k
 constexpr uint32_t PJ1_CS = 32;  // words between the coarse partitions' cursors (own 128-byte lines: same-line atomics serialise)
 __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__restrict__ M, uint32_t P, uint32_t n_rows,
                                                  uint64_t *host_fail, uint32_t force_fail, const uint32_t *__restrict__ cursor,
-                                                 uint32_t cap1, uint32_t rows2, uint32_t *__restrict__ verd, uint32_t full)
+                                                 uint32_t cap1, uint32_t rows2, const AsmSet p)
 {
+    const uint32_t full = p.full;
     __shared__ unsigned long long keys[PJ_T + 1];
     __shared__ uint32_t seen[PJ_T + 1], dup[PJ_T + 1];
     __shared__ uint32_t seg_off[257], seg_rec[256], sh[256];
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
     // search in the scan): all loads of a pass are independent.  Pass 0 inserts, pass 1 writes the table state back; with
     // at most 256 regions (10^6 minimizers) pass 1 reuses the layout and the slots of the first QC records per thread.
     constexpr uint32_t QC = 4;
-    uint32_t rc[QC], sc[QC], ac[QC];
+    uint32_t rc[QC], sc[QC], ac[QC], ic[QC];
     const bool single = n_rows <= 256;
     for (uint32_t pass = 0; pass < 2; ++pass) {
         const bool bad = pass == 1 && failed != 0;  // report, and make every key of this partition "seen nowhere"
@@ -289,10 +290,11 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
                 }
                 return seg_rec[l] + (q - seg_off[l]);
             };
-            uint32_t last_a = 0;             // assembly of the record insert() looked at last
-            auto insert = [&](uint32_t r) {  // pass 0; also the lookup of pass 1
+            uint32_t last_a = 0, last_i = 0;  // assembly / item of the record insert() looked at last
+            auto insert = [&](uint32_t r) {   // pass 0; also the lookup of pass 1
                 const uint4 rec = recs[r];
                 last_a = rec.w;
+                last_i = rec.z;
                 const uint32_t s = pj_slot(keys, ((uint64_t)rec.y << 32) | rec.x);
                 if (pass == 0) {
                     const uint32_t bit = 1u << rec.w;
@@ -301,16 +303,16 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
                 }
                 return s;
             };
-            // the verdict of record r, 4 bytes: slot << 3 | MXG_MX_* flags of the minimizer it stands for (k_flags_pj gathers
-            // these through slot[a][i]: a 4-byte gather out of an array a quarter the records' size)
-            auto finish = [&](uint32_t r, uint32_t s, uint32_t a) {
+            // the verdict of a record, 4 bytes: slot << 3 | MXG_MX_* flags, sent straight to the minimizer it stands for
+            // (slot[a][i]: the ONE random access per minimizer of the whole join; k_flags_pj then reads the verdicts in order)
+            auto finish = [&](uint32_t i, uint32_t s, uint32_t a) {
                 uint32_t fl = 0;
                 if (!bad) {
                     const uint32_t sn = seen[s] & full, d = dup[s] & full;
                     const bool inall = sn == full;
                     fl = (!(d & (1u << a)) ? MXG_MX_UNIQUE : 0u) | ((inall && d == 0) ? MXG_MX_SHARED : 0u) | (inall ? MXG_MX_INALL : 0u);
                 }
-                verd[r] = ((blockIdx.x * (PJ_T + 1u) + (bad ? 0u : s)) << 3) | fl;
+                p.slot[a][i] = ((blockIdx.x * (PJ_T + 1u) + (bad ? 0u : s)) << 3) | fl;
             };
 #pragma unroll
             for (uint32_t it = 0; it < QC; ++it) {
@@ -320,12 +322,13 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
                     rc[it] = locate(q);
                     sc[it] = insert(rc[it]);
                     ac[it] = last_a;
+                    ic[it] = last_i;
                 } else if (single) {
-                    finish(rc[it], sc[it], ac[it]);
+                    finish(ic[it], sc[it], ac[it]);
                 } else {
                     const uint32_t r = locate(q);
-                    const uint32_t s = insert(r);  // (also reads the record's assembly)
-                    finish(r, s, last_a);
+                    const uint32_t s = insert(r);  // (also reads the record's assembly and item)
+                    finish(last_i, s, last_a);
                 }
             }
             for (uint32_t q = threadIdx.x + QC * 256u; q < total; q += 256) {
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
                 if (pass == 0) insert(r);
                 else {
                     const uint32_t s = insert(r);
-                    finish(r, s, last_a);
+                    finish(last_i, s, last_a);
                 }
             }
             __syncthreads();
@@ -392,7 +395,8 @@ __global__ __launch_bounds__(PJ_BT) void k_pj1_scatter(const AsmSet p, uint32_t 
         const uint32_t b = pj1_part(key[u], p1mask);
         const uint32_t pos = start[b] + atomicAdd(&hist[b], 1u);
         if (pos < cap1) recs1[(size_t)b * cap1 + pos] = make_uint4((uint32_t)key[u], (uint32_t)(key[u] >> 32), ii[u], ia[u]);
-        // (beyond the capacity: the cursor says so, k_pj_join reports it and the host redoes the stage with the global table)
+        else p.slot[ia[u]][ii[u]] = 0;  // beyond the capacity: no verdict will come (the cursor says so, k_pj_join reports it and
+                                        // the host redoes the stage with the global table); leave a harmless one behind
     }
 }
 
@@ -448,14 +452,13 @@ __global__ __launch_bounds__(PJ_BT) void k_pj2_bucket(const AsmSet p, const uint
         const uint32_t b = pj_part(((uint64_t)rec[u].y << 32) | rec[u].x, pmask);
         const uint32_t pos = (uint32_t)base + start[b] + atomicAdd(&hist[b], 1u);
         recs2[pos] = rec[u];
-        p.slot[rec[u].w][rec[u].z] = pos;  // k_flags_pj replaces it by the slot
     }
 }
 
 // k_flags for the partitioned join: the table state of minimizer i sits in recs[slot[a][i]]
 // (also clears this item's cells of the adjacency arrays nxt[A][nvs] | prv[A][nvs]: saves the fill launch)
-__global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, const uint32_t *__restrict__ verd, uint32_t *cnt, uint32_t *sup,
-                                                  uint32_t *nxt, uint32_t nvs, uint32_t rec_limit)
+__global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, uint32_t *cnt, uint32_t *sup, uint32_t *nxt, uint32_t nvs,
+                                                  uint32_t slot_limit)
 {
     const uint32_t a = asm_of_block(p, blockIdx.x);
     const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
@@ -465,12 +468,11 @@ __global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, const uint32_t
     }
     bool sh = false;
     if (i < asm_n(p, a)) {
-        // (rec_limit: a record dropped by an overflowing coarse partition left no position behind; the stage is redone then)
-        const uint32_t v = verd[min(p.slot[a][i], rec_limit)];
+        const uint32_t v = p.slot[a][i];  // the verdict k_pj_join left here
         sh = (v & MXG_MX_SHARED) != 0;
         p.flags[a][i] = (uint8_t)(v & 7u);
         p.shared[a][i] = sh ? 1 : 0;
-        p.slot[a][i] = v >> 3;
+        p.slot[a][i] = min(v >> 3, slot_limit);
     }
     const uint32_t c = (uint32_t)__syncthreads_count(sh ? 1 : 0);
     if (threadIdx.x == 0) count_publish(cnt + p.bstart[a], sup + sup_start(p, a), blockIdx.x - p.bstart[a], c);
@@ -807,12 +809,11 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
                            fsup, n_fsup + n_esup);
         hipLaunchKernelGGL(k_pj2_bucket, dim3(rows2, P1), dim3(PJ_BT), (size_t)P * 8, h->stream, as_all, recs1, cursor, cap1, rows2, P - 1, M,
                            recs2);
-        MXG_HIP(h, h->g_verd.ensure(n_recs * 4));
         hipLaunchKernelGGL(k_pj_join, dim3(P1 * P), dim3(256), 0, h->stream, recs2, M, P, 0u, hctl + CTL_PJ_FAIL, pj_force_fail, cursor, cap1,
-                           rows2, h->g_verd.as<uint32_t>(), full);
+                           rows2, as_all);
         MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4 + 16));  // nxt[A][nvs] followed by prv[A][nvs], cleared by k_flags_pj
-        hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_verd.as<uint32_t>(), cnt, fsup,
-                           h->g_nxt.as<uint32_t>(), (uint32_t)nvs, (uint32_t)(n_recs - 1));
+        hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, cnt, fsup, h->g_nxt.as<uint32_t>(), (uint32_t)nvs,
+                           P1 * P * (PJ_T + 1u) - 1u);
     } else if (nb && !resume && pj) {
         const uint32_t n_rows = (nb + PJ_IPB / 256 - 1) / (PJ_IPB / 256);  // bucketing blocks = record regions = rows of M
         MXG_HIP(h, h->g_part.ensure((size_t)n_rows * (P + 1) * 4));
@@ -821,12 +822,11 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         uint4 *recs = h->g_keys.as<uint4>();
         hipLaunchKernelGGL(k_pj_bucket, dim3(n_rows), dim3(PJ_BT), (size_t)P * 8, h->stream, as_all, nb, P - 1, M, recs, fsup,
                            n_fsup + n_esup);
-        MXG_HIP(h, h->g_verd.ensure((size_t)n_rows * PJ_IPB * 4));
         hipLaunchKernelGGL(k_pj_join, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, hctl + CTL_PJ_FAIL, pj_force_fail, nullptr, 0u, 0u,
-                           h->g_verd.as<uint32_t>(), full);
+                           as_all);
         MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4 + 16));  // nxt[A][nvs] followed by prv[A][nvs], cleared by k_flags_pj
-        hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_verd.as<uint32_t>(), cnt, fsup,
-                           h->g_nxt.as<uint32_t>(), (uint32_t)nvs, n_rows * PJ_IPB - 1u);
+        hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, cnt, fsup, h->g_nxt.as<uint32_t>(), (uint32_t)nvs,
+                           P * (PJ_T + 1u) - 1u);
     } else if (nb && !resume) {
         hipLaunchKernelGGL(k_insert, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), mask, cap, fsup,
                            n_fsup + n_esup);

@@ -200,7 +200,6 @@ struct mxg_handle {
     std::vector<int> pend_state;
     mxg::DevBuf g_part;     // partitioned join (graph.hip): partition offsets of every bucketing block
     mxg::DevBuf g_recs1;    // two-level join: the coarse partitions' records
-    mxg::DevBuf g_verd;     // LDS joins: 4-byte verdict (slot << 3 | flags) per record
     mxg::DevBuf g_keys, g_cnt, g_vid, g_ctl, g_vhash, g_vpos, g_vrec, g_fv, g_frec, g_nxt, g_prv, g_eflag,
         g_ebs, g_eu, g_ev, g_esup, g_ew;  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
     uint64_t arena_cap_hint = 0;

@@ -265,7 +265,9 @@ struct SparseParams {
     uint32_t *strip_cnt;  // [n_strips] candidates per strip
     uint32_t *wave_tot;   // [n_waves] candidates per wave, and their super-counts (scan_kernels.h; zeroed with ctrl)
     uint32_t *wave_sup;
-    uint4 *strip_meta;    // [n_strips] {contig, kidx of the strip's first k-mer, base offset of it lo, hi}
+    uint32_t *strip_meta; // [n_strips] the strip's run (k_reorder derives contig, first k-mer index and base offset from it: 4
+                          // bytes per strip written and read instead of 16 -- at 3 Gbp the strip tables were 0.6 GB of HBM
+                          // traffic per step)
     const uint4 *init_tab; // byte table of init_direct (make_init_tab), 256 entries
     HashTab tab;
 };
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
         const uint32_t j0 = (s - p.run_strip0[lo]) * S;
         len = min(S, run.n_kmers - j0);
         b = run.base_off + j0;
-        p.strip_meta[srel] = make_uint4(run.contig, run.kidx0 + j0, (uint32_t)b, (uint32_t)(b >> 32));
+        p.strip_meta[srel] = lo;
     }
     const uint32_t k = p.k;
     const uint32_t thr = 0u - p.tau_hi - (VARIANT == MXG_VARIANT_V1_MIN ? 0u : 2u);
@@ -444,7 +446,10 @@ struct ReorderParams {
     const uint32_t *wave_sup;
     uint32_t *n_cand;            // ctrl[4..5]: total, written by the block of the last wave
     uint32_t queue_cap;          // candidates the LDS queue holds (= wave_cap), 0: slice too large, hash per entry
-    const uint4 *strip_meta;
+    const uint32_t *strip_meta;  // run of every strip (k_hash_sparse)
+    const Run *runs;
+    const uint32_t *run_strip0;
+    uint32_t strip_lo, S;
     const uint32_t *packed;
     const uint4 *init_tab;
     uint32_t k;
@@ -480,7 +485,13 @@ __global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
         const uint32_t s = wv * 64u + threadIdx.x;
         const bool in = s < p.n_strips;
         const uint32_t c = in ? p.strip_cnt[s] : 0u;
-        if (in) smeta[threadIdx.x] = p.strip_meta[s];
+        if (in) {
+            const uint32_t ri = p.strip_meta[s];
+            const Run run = p.runs[ri];
+            const uint32_t j0 = (p.strip_lo + s - p.run_strip0[ri]) * p.S;
+            const uint64_t b = run.base_off + j0;
+            smeta[threadIdx.x] = make_uint4(run.contig, run.kidx0 + j0, (uint32_t)b, (uint32_t)(b >> 32));
+        }
         const uint32_t before = count_prefix(p.wave_tot, p.wave_sup, wv);
         const uint32_t incl = wave_inclusive_u32(c, threadIdx.x);
         spref[threadIdx.x] = before + incl - c;
@@ -1734,7 +1745,7 @@ struct Driver {
         few_cand = (double)tau_hi / 4294967296.0 * (double)h->cfg.w <= 12.5;
         MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
         MXG_HIP(h, sc(SC_STRIP_CNT).ensure((size_t)g.n_strips * 4 + 16));
-        MXG_HIP(h, sc(SC_STRIP_META).ensure((size_t)g.n_strips * 16 + 16));
+        MXG_HIP(h, sc(SC_STRIP_META).ensure((size_t)g.n_strips * 4 + 16));
         MXG_HIP(h, sc(SC_WAVE_CNT).ensure((size_t)g.n_waves * 4 + 16));
         MXG_HIP(h, sc(SC_WAVE_TOT).ensure((size_t)g.n_waves * 4 + 16));
         const uint64_t n_cap64 = (uint64_t)g.n_waves * wave_cap;
@@ -1771,7 +1782,7 @@ struct Driver {
         sp.wave_cnt = sc(SC_WAVE_CNT).as<uint32_t>();
         sp.ctrl = sc(SC_CTRL).as<uint32_t>();
         sp.strip_cnt = sc(SC_STRIP_CNT).as<uint32_t>();
-        sp.strip_meta = sc(SC_STRIP_META).as<uint4>();
+        sp.strip_meta = sc(SC_STRIP_META).as<uint32_t>();
         sp.wave_tot = sc(SC_WAVE_TOT).as<uint32_t>();
         sp.wave_sup = wave_sup();
         int rc;
@@ -1803,6 +1814,10 @@ struct Driver {
         op.wave_sup = sp.wave_sup;
         op.n_cand = sp.ctrl + 4;
         op.strip_meta = sp.strip_meta;
+        op.runs = sp.runs;
+        op.run_strip0 = sp.run_strip0;
+        op.strip_lo = sp.strip_lo;
+        op.S = sp.S;
         op.packed = sp.packed;
         op.init_tab = sp.init_tab;
         op.k = sp.k;
