@@ -1798,7 +1798,16 @@ struct Driver {
         else if (abl == 2)
             hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 2>), grid, block, 0, st, sp);
         else
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), grid, block, 0, st, sp);
+        {
+            // Every lane keeps one 128-byte line of packed bases "open" for 32 block iterations (16 bases = 4 bytes per
+            // iteration), so the waves resident on an XCD hold (waves x 64 x 128 B) of live lines.  At full occupancy that is
+            // more than the XCD's 4 MB of L2 once the input no longer fits the caches behind it: measured at 3 Gbp (PMC
+            // FETCH_SIZE x 2), the kernel fetched 336 MB for 115 MB of bases.  Unused dynamic LDS caps the residency at four
+            // blocks per CU: 131 MB fetched, the kernel itself 10-25 % slower, the step 2 % faster (1146 -> 1172 Gbp/s) because
+            // everything that runs beside it gets the bandwidth back.  Small inputs (cache-resident) keep full occupancy.
+            const size_t pad = (size_t)env_u64("MXG_HASH_LDS", g.nk >= (256ull << 20) ? 28000 : 0);
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), grid, block, pad, st, sp);
+        }
         if ((rc = ev_end()) != MXG_OK) return rc;
         MXG_HIP(h, hipGetLastError());
         // order the candidates: exclusive scan of per-strip counts (total = number of candidates), then scatter
