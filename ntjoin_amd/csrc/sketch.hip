@@ -49,6 +49,7 @@ enum Scratch {
     SC_GAPS, SC_WAVE_CNT, SC_ST_HASH, SC_ST_POS, SC_ST_REC, SC_ST_FWD, SC_G_HASH, SC_G_POS,
     SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_V_DROP, SC_CNT256, SC_WAVE_TOT,
     SC_GR_HASH, SC_GR_POS, SC_GR_REC, SC_GR_CNT, SC_GR_KEY, SC_GD_HASH, SC_GD_POS, SC_GD_REC,  // device-side stretch fix-up
+    SC_CS_H, SC_CS_K, SC_CS_C,  // selected candidates per k_resolve block
     SC_COUNT
 };
 static_assert(SC_COUNT <= 40, "scratch pool too small");
@@ -582,6 +583,12 @@ struct ResolveParams {
     // fused count (COUNT): minimizers per block of 256 candidates + super-counts (scan_kernels.h) for k_emit
     uint32_t *cnt256;         // [gridDim.x]
     uint32_t *sel_sup;        // zeroed with the control block
+    // COUNT, optional: the selected candidates of block b laid end to end from entry b * 256 of these arrays {hash, k-mer
+    // index, contig} instead of one flag per candidate.  About one candidate in ten is selected: k_emit then reads 16 bytes
+    // per MINIMIZER in order, where gathering through the flags pulled a 64-byte sector for every 4-8 bytes it wanted
+    // (80 MB fetched per launch at 3 Gbp to emit 7 MB).
+    uint64_t *cs_h;
+    uint32_t *cs_k, *cs_c;
 };
 
 __device__ __forceinline__ void push_gap(const ResolveParams &p, uint32_t c, uint32_t lo, uint32_t hi)
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
     const uint64_t tau = p.tau;
     const bool absent = h >= tau;
     const bool chosen = live && s && !absent && h != 0xFFFFFFFFFFFFFFFFull;
-    if (live) p.sel[i] = chosen ? 1 : 0;
+    if (live && !(COUNT && p.cs_h)) p.sel[i] = chosen ? 1 : 0;
 
     if (GAPS && live && ABL == 0) {
         // candidate-free stretches of >= w k-mers hold windows whose minimum is not a candidate.  Every real candidate
@@ -828,8 +835,29 @@ __global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
         }
     }
     if (COUNT) {
-        const uint32_t c = (uint32_t)__syncthreads_count(chosen ? 1 : 0);
-        if (threadIdx.x == 0) count_publish(p.cnt256, p.sel_sup, blockIdx.x, c);
+        if (p.cs_h) {
+            __shared__ uint32_t wsel[RK / 64];
+            const uint64_t bm = __ballot(chosen);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            if (lane == 0) wsel[threadIdx.x >> 6] = (uint32_t)__popcll(bm);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < RK / 64; ++u) {
+                before += u < (threadIdx.x >> 6) ? wsel[u] : 0u;
+                total += wsel[u];
+            }
+            if (chosen) {
+                const uint32_t dst = blockIdx.x * RK + before + rank;
+                p.cs_h[dst] = h;
+                p.cs_k[dst] = kx;
+                p.cs_c[dst] = c;
+            }
+            if (threadIdx.x == 0) count_publish(p.cnt256, p.sel_sup, blockIdx.x, total);
+        } else {
+            const uint32_t cn = (uint32_t)__syncthreads_count(chosen ? 1 : 0);
+            if (threadIdx.x == 0) count_publish(p.cnt256, p.sel_sup, blockIdx.x, cn);
+        }
     }
 }
 
@@ -886,6 +914,9 @@ struct EmitParams {
     uint64_t *s_hash;
     uint32_t *s_pos, *s_rec;
     uint64_t s_limit;
+    // the selected candidates laid out per k_resolve block (ResolveParams::cs_*): replaces sel / ch / ck / cc
+    const uint64_t *cs_h;
+    const uint32_t *cs_k, *cs_c;
 };
 
 __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
@@ -900,7 +931,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     }
     if (blockIdx.x * TILE >= n) return;  // whole tile beyond the candidates
     uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
-    const uint32_t fl = load_flags4(p.sel, base, n);
+    const uint32_t fl = p.cs_h ? 0u : load_flags4(p.sel, base, n);
     uint32_t c = count_flags4(fl);
     uint32_t before;
     uint64_t obase = p.out_base + (p.base_in ? *p.base_in : 0ull), limit = p.out_limit;
@@ -942,24 +973,51 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     // threads turn them into minimizers -- full waves of gathers (candidate arrays, run table) and contiguous stores instead
     // of a few lanes per wave.
     __shared__ uint16_t picked[TILE];
-    uint32_t l = block_exclusive_256(c, sh);
-    const uint32_t tile_total = sh[255];
-    for (int u = 0; u < TILE_PER_THREAD; ++u)
-        if ((fl >> (8 * u)) & 1u) picked[l++] = (uint16_t)(threadIdx.x * TILE_PER_THREAD + u);
-    __syncthreads();
+    uint32_t tile_total;
+    uint32_t pre[TILE / RK + 1];  // compact mode: the tile = TILE / RK blocks of k_resolve, their selected counts as a prefix
+    if (p.cs_h) {
+        const uint32_t nblk = (n + RK - 1u) / RK;
+        pre[0] = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < TILE / RK; ++u) {
+            const uint32_t b = blockIdx.x * (TILE / RK) + u;
+            pre[u + 1] = pre[u] + (b < nblk ? p.cnt256[b] : 0u);
+        }
+        tile_total = pre[TILE / RK];
+    } else {
+        uint32_t l = block_exclusive_256(c, sh);
+        tile_total = sh[255];
+        for (int u = 0; u < TILE_PER_THREAD; ++u)
+            if ((fl >> (8 * u)) & 1u) picked[l++] = (uint16_t)(threadIdx.x * TILE_PER_THREAD + u);
+        __syncthreads();
+    }
     const uint64_t o0 = obase + before;
     for (uint32_t r = threadIdx.x; r < tile_total; r += 256u) {
-        const uint32_t i = blockIdx.x * TILE + picked[r];
         const uint64_t o = o0 + r;
         if (o >= limit) continue;  // (speculative emit into arrays sized by an estimate)
-        const uint32_t ctg = p.cc[i] & 0x7FFFFFFFu, kx = p.ck[i];
+        uint32_t ctg, kx;
+        uint64_t hsh;
+        if (p.cs_h) {
+            static_assert(TILE / RK == 4, "the selects below spell out four blocks per tile");
+            const uint32_t u = r >= pre[3] ? 3u : r >= pre[2] ? 2u : r >= pre[1] ? 1u : 0u;
+            const uint32_t poff = r >= pre[3] ? pre[3] : r >= pre[2] ? pre[2] : r >= pre[1] ? pre[1] : 0u;
+            const uint32_t src = (blockIdx.x * (TILE / RK) + u) * RK + (r - poff);
+            hsh = p.cs_h[src];
+            kx = p.cs_k[src];
+            ctg = p.cs_c[src];
+        } else {
+            const uint32_t i = blockIdx.x * TILE + picked[r];
+            hsh = p.ch[i];
+            kx = p.ck[i];
+            ctg = p.cc[i] & 0x7FFFFFFFu;
+        }
         // contig-local valid-k-mer index -> base position, through the contig's run table
         uint32_t lo = p.ctg_run0[ctg], hi = p.ctg_run0[ctg + 1];
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if (p.runs[mid].kidx0 <= kx) lo = mid; else hi = mid;
         }
-        o_hash[o] = ext_hash(p.ch[i], p.mult);  // (the strand byte is filled lazily by k_strand, only when somebody asks for it)
+        o_hash[o] = ext_hash(hsh, p.mult);  // (the strand byte is filled lazily by k_strand, only when somebody asks for it)
         o_pos[o] = p.runs[lo].pos0 + (kx - p.runs[lo].kidx0);
         o_rec[o] = p.ctg_rec[ctg];
     }
@@ -1452,6 +1510,12 @@ struct Driver {
         rp.gap_count = ctrl + 1;
         rp.cnt256 = sc(SC_CNT256).as<uint32_t>();
         rp.sel_sup = sel_sup(n_cap);
+        MXG_HIP(h, sc(SC_CS_H).ensure((size_t)blocks * RK * 8));
+        MXG_HIP(h, sc(SC_CS_K).ensure((size_t)blocks * RK * 4));
+        MXG_HIP(h, sc(SC_CS_C).ensure((size_t)blocks * RK * 4));
+        rp.cs_h = sc(SC_CS_H).as<uint64_t>();
+        rp.cs_k = sc(SC_CS_K).as<uint32_t>();
+        rp.cs_c = sc(SC_CS_C).as<uint32_t>();
         rp.n_likely = std::min(n_likely, n_cap);
         static const int abl = getenv("MXG_ABLATE_RESOLVE") ? atoi(getenv("MXG_ABLATE_RESOLVE")) : 0;  // profiling only
         if (abl == 1)
@@ -1496,6 +1560,8 @@ struct Driver {
         rp.gap_count = ctrl + 1;
         rp.cnt256 = nullptr;
         rp.sel_sup = nullptr;
+        rp.cs_h = nullptr;
+        rp.cs_k = rp.cs_c = nullptr;
         if (n_cap) {
             hipLaunchKernelGGL((k_resolve<GAPS, false>), dim3((n_cap + RK - 1) / RK), dim3(RK), 0, st, rp);
             hipLaunchKernelGGL(k_count_n, dim3(n_tiles), dim3(256), 0, st, rp.sel, rp.n_ptr, n_cap,
@@ -1547,6 +1613,9 @@ struct Driver {
         ep.o_pos = op.as<uint32_t>();
         ep.o_rec = orc.as<uint32_t>();
         ep.o_fwd = of.as<uint8_t>();
+        ep.cs_h = fused ? sc(SC_CS_H).as<uint64_t>() : nullptr;  // (the sparse path's k_resolve laid the selected ones out per block)
+        ep.cs_k = fused ? sc(SC_CS_K).as<uint32_t>() : nullptr;
+        ep.cs_c = fused ? sc(SC_CS_C).as<uint32_t>() : nullptr;
         ep.base_in = io ? io->base_in : nullptr;
         ep.base_out = io ? io->base_out : nullptr;
         ep.dev_gaps = io && io->dev_gaps ? 1u : 0u;
@@ -1802,10 +1871,11 @@ struct Driver {
             // Every lane keeps one 128-byte line of packed bases "open" for 32 block iterations (16 bases = 4 bytes per
             // iteration), so the waves resident on an XCD hold (waves x 64 x 128 B) of live lines.  At full occupancy that is
             // more than the XCD's 4 MB of L2 once the input no longer fits the caches behind it: measured at 3 Gbp (PMC
-            // FETCH_SIZE x 2), the kernel fetched 336 MB for 115 MB of bases.  Unused dynamic LDS caps the residency at four
-            // blocks per CU: 131 MB fetched, the kernel itself 10-25 % slower, the step 2 % faster (1146 -> 1172 Gbp/s) because
-            // everything that runs beside it gets the bandwidth back.  Small inputs (cache-resident) keep full occupancy.
-            const size_t pad = (size_t)env_u64("MXG_HASH_LDS", g.nk >= (256ull << 20) ? 28000 : 0);
+            // FETCH_SIZE x 2), the kernel fetched 336 MB for 115 MB of bases.  24 KB of unused dynamic LDS cap the residency at
+            // five blocks per CU: 131 MB fetched, the kernel itself ~10 % slower (0.188 -> 0.21 ms; with 30-36 KB: 0.24-0.25 ms
+            // for the same step time), the step 2 % faster (1146 -> 1172 Gbp/s) because everything that runs beside it gets
+            // the bandwidth back.  Small inputs (cache-resident) keep full occupancy.
+            const size_t pad = (size_t)env_u64("MXG_HASH_LDS", g.nk >= (256ull << 20) ? 24000 : 0);
             hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), grid, block, pad, st, sp);
         }
         if ((rc = ev_end()) != MXG_OK) return rc;
