@@ -50,7 +50,6 @@ enum Scratch {
     SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_V_DROP, SC_CNT256, SC_WAVE_TOT,
     SC_GR_HASH, SC_GR_POS, SC_GR_REC, SC_GR_CNT, SC_GR_KEY, SC_GD_HASH, SC_GD_POS, SC_GD_REC,  // device-side stretch fix-up
     SC_CS_H, SC_CS_K, SC_CS_C,  // selected candidates per k_resolve block
-    SC_ARENA_W,                 // windows of the arena entries (k = 32)
     SC_COUNT
 };
 static_assert(SC_COUNT <= 40, "scratch pool too small");
@@ -259,8 +258,6 @@ struct SparseParams {
     uint32_t k;
     uint32_t S;           // k-mers per strip (multiple of 16, <= 1024)
     uint32_t tau_hi;      // candidate iff high word of min_hash < tau_hi (EVEN: tau_hi = 2T, T on the top 31 bits)
-    uint4 *arena_w;       // k = 32 only (else null): beside every entry the 48 bases its 16 k-mers are made of, so that
-                          // k_reorder hashes from the entry instead of reading the packed bases a second time
     uint2 *arena;         // wave w owns entries [w*wave_cap, (w+1)*wave_cap): {strip (rel.), j | seq<<10}
     uint32_t wave_cap;
     uint32_t *wave_cnt;   // [n_waves] ENTRIES each wave wrote to its slice (k_reorder reads that many)
@@ -322,7 +319,7 @@ __device__ __forceinline__ void ring_step(uint32_t &x, uint32_t x2, uint32_t &y,
 // {strip, bits | block<<16 | rank<<22} to the wave's own arena slice (slot = running count + rank among the storing
 // lanes: no atomics, no LDS staging, nothing waits on the stores).  k_reorder expands the bits.
 // ABL (profiling builds only): 1 = ring updates only, 2 = + test and history, 0 = full.
-template <int VARIANT, int ABL = 0, bool WIN = false>
+template <int VARIANT, int ABL = 0>
 __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
 {
     __shared__ uint4 tab[20];    // full step table: only init_direct's k%4 remainder uses it
@@ -409,11 +406,7 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
             if (bits) {
                 const uint32_t slot = cnt_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (slot < wave_cap) {
-                    region[slot] = make_uint2(srel, bits | (blk << 16) | (seq << 22));
-                    // k = 32: bases j0 .. j0+47 = this block's outgoing word, the next block's, and this block's incoming one
-                    if (WIN) p.arena_w[(size_t)wave_id * wave_cap + slot] = make_uint4(cout, __builtin_amdgcn_alignbit(o1, o0, so), cin, 0u);
-                }
+                if (slot < wave_cap) region[slot] = make_uint2(srel, bits | (blk << 16) | (seq << 22));
                 seq += (uint32_t)__popc(bits);
             }
             cnt_w += (uint32_t)__popcll(mask);
@@ -445,7 +438,6 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
 // (k/4 table lookups on the packed bases, which this block's 64 strips keep hot in L2).  An entry whose exact hash is
 // >= tau (the ring test cannot see the carry out of the low 33 bits) keeps its slot; k_resolve treats it as absent.
 struct ReorderParams {
-    const uint4 *arena_w;        // windows of the entries (k = 32), or null: hashes come from the packed bases
     const uint2 *arena;
     const uint32_t *wave_cnt;
     uint32_t wave_cap, n_cap;
@@ -482,7 +474,6 @@ __global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
     if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
     const uint32_t wv = blockIdx.x;
     const uint2 *src = p.arena + (size_t)wv * p.wave_cap;
-    const uint4 *src_w = p.arena_w ? p.arena_w + (size_t)wv * p.wave_cap : nullptr;
     // The kernel is a chain of dependent memory round trips, so everything that can be asked for at once is: the first
     // two entries of every thread (a slice holds about one per thread) are requested without waiting for the slice's
     // entry count (the slice is allocated in full; what lies beyond the count is masked afterwards).
@@ -512,7 +503,7 @@ __global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
         }
     }
     __syncthreads();
-    // item = strip (lane of the hash kernel) | block << 6 | k-mer in the block << 12 | entry << 16; dst = its ordered slot
+    // item = strip (lane of the hash kernel) | block << 6 | k-mer in the block << 12; dst = its ordered slot
     auto hash_item = [&](const uint32_t item, const uint32_t dst) {
         const uint32_t j0 = ((item >> 6) & 63u) * 16u, u = (item >> 12) & 15u;
         if (dst >= p.n_cap) return;  // beyond it only when a wave overflowed: the host redoes the batch
@@ -520,21 +511,6 @@ __global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
         H2 h = {0u, 0u, 0u, 0u};
         if (ABL == 1) {  // (profiling only) no hashing: what the rest of the kernel costs
             h.flo = sm.z + j0 + u; h.fhi = 0x00100000u; h.rlo = u; h.rhi = 0u;
-        } else if (p.arena_w) {
-            // k = 32: the k-mer is bases u .. u+31 of the entry's 48-base window: two funnel shifts, then the direct formula
-            // over its 8 packed bytes (init_direct without the fetches)
-            const uint4 wd = src_w[item >> 16];
-            const uint32_t lo = __builtin_amdgcn_alignbit(wd.y, wd.x, 2u * u), hi = __builtin_amdgcn_alignbit(wd.z, wd.y, 2u * u);
-            uint32_t flo = 0, fhi = 0, tlo = 0, thi = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < 8; ++q) {
-                const uint4 e = btab[((q < 4 ? lo : hi) >> (8u * (q & 3u))) & 255u];
-                srol4(flo, fhi);
-                sror4(tlo, thi);
-                flo ^= e.x; fhi ^= e.y; tlo ^= e.z; thi ^= e.w;
-            }
-            srol_var(tlo, thi, 28u);
-            h.flo = flo; h.fhi = fhi; h.rlo = tlo; h.rhi = thi;
         } else {
             init_direct(h, p.packed, (((uint64_t)sm.w << 32) | sm.z) + j0 + u, p.k, btab, tab);
         }
@@ -556,7 +532,7 @@ __global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
             uint2 a = e0 == 0 ? a0 : (e0 == RBT ? a1 : (i < cnt ? src[i] : make_uint2(0u, 0u)));
             if (i >= cnt) a = make_uint2(0u, 0u);
             uint32_t bits = a.y & 0xFFFFu;
-            const uint32_t item0 = (a.x & 63u) | (((a.y >> 16) & 63u) << 6) | (i << 16);
+            const uint32_t item0 = (a.x & 63u) | (((a.y >> 16) & 63u) << 6);
             uint32_t at = spref[a.x & 63u] - base + (a.y >> 22);
             for (; bits; ++at) {  // most significant bit = first k-mer of the block
                 const uint32_t u = (uint32_t)__clz((int)bits) - 16u;
@@ -568,9 +544,9 @@ __global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
         for (uint32_t q = threadIdx.x; q < qn; q += RBT) hash_item(queue[q], base + q);
         return;
     }
-    auto place = [&](const uint2 a, const uint32_t ei) {  // (slices too large for the queue: one thread per entry)
+    auto place = [&](const uint2 a) {  // (slices too large for the queue: one thread per entry)
         uint32_t bits = a.y & 0xFFFFu;
-        const uint32_t item0 = (a.x & 63u) | (((a.y >> 16) & 63u) << 6) | (ei << 16);
+        const uint32_t item0 = (a.x & 63u) | (((a.y >> 16) & 63u) << 6);
         uint32_t dst = spref[a.x & 63u] + (a.y >> 22);
         for (; bits; ++dst) {
             const uint32_t u = (uint32_t)__clz((int)bits) - 16u;
@@ -578,9 +554,9 @@ __global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
             hash_item(item0 + (u << 12), dst);
         }
     };
-    place(i0 < cnt ? a0 : make_uint2(0u, 0u), i0);
-    place(i1 < cnt ? a1 : make_uint2(0u, 0u), i1);
-    for (uint32_t i = threadIdx.x + 2u * RBT; i < cnt; i += RBT) place(src[i], i);
+    place(i0 < cnt ? a0 : make_uint2(0u, 0u));
+    place(i1 < cnt ? a1 : make_uint2(0u, 0u));
+    for (uint32_t i = threadIdx.x + 2u * RBT; i < cnt; i += RBT) place(src[i]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1871,14 +1847,6 @@ struct Driver {
         sp.tau_hi = ring_slack ? (uint32_t)std::min<uint64_t>(0x7FFFFFFEull, (uint64_t)tau_hi * (100 + ring_slack) / 100) & ~1u
                                : tau_hi;
         sp.arena = sc(SC_ARENA).as<uint2>();
-        // k = 32 and slices small enough for the entry index to ride in the queue item (16 bits): entries carry their bases
-        static const int abl0 = getenv("MXG_ABLATE") ? atoi(getenv("MXG_ABLATE")) : 0;
-        const bool win = h->cfg.k == 32 && wave_cap <= 8192 && h->cfg.variant == MXG_VARIANT_V2_SUM && abl0 == 0 && !getenv("MXG_NO_WINDOWS");
-        sp.arena_w = nullptr;
-        if (win) {
-            MXG_HIP(h, sc(SC_ARENA_W).ensure((size_t)n_cap * 16));
-            sp.arena_w = sc(SC_ARENA_W).as<uint4>();
-        }
         sp.wave_cap = (uint32_t)wave_cap;
         sp.wave_cnt = sc(SC_WAVE_CNT).as<uint32_t>();
         sp.ctrl = sc(SC_CTRL).as<uint32_t>();
@@ -1898,11 +1866,6 @@ struct Driver {
             hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 1>), grid, block, 0, st, sp);
         else if (abl == 2)
             hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 2>), grid, block, 0, st, sp);
-        else if (win)
-        {
-            const size_t pad = (size_t)env_u64("MXG_HASH_LDS", g.nk >= (256ull << 20) ? 24000 : 0);  // (see below)
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 0, true>), grid, block, pad, st, sp);
-        }
         else
         {
             // Every lane keeps one 128-byte line of packed bases "open" for 32 block iterations (16 bases = 4 bytes per
@@ -1920,7 +1883,6 @@ struct Driver {
         // order the candidates: exclusive scan of per-strip counts (total = number of candidates), then scatter
         if ((rc = ev_begin(0, false)) != MXG_OK) return rc;
         ReorderParams op;
-        op.arena_w = sp.arena_w;
         op.arena = sp.arena;
         op.wave_cnt = sp.wave_cnt;
         op.wave_cap = sp.wave_cap;
