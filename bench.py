@@ -83,6 +83,22 @@ def logical_cpus():
     return os.cpu_count() or 1
 
 
+def valu_static(wl, mbp, multi):
+    """what really binds the dominant kernel is integer-VALU issue, not HBM: instructions per base and VALU
+    utilisation from the committed PMC pass over THIS workload (static: not measured in this run), or None"""
+    path = os.path.join(REPO, "profiles", "r02", "configs2_hash_kernel_pmc.json")
+    if multi or wl != "configs2" or abs(mbp - 3000.0) > 1e-9 or not os.path.exists(path):
+        return None
+    try:
+        v = json.load(open(path))
+        return {"wave64_instr_per_base": round(v["valu_per_base"], 2), "valu_busy": round(v["valu_busy"], 3),
+                "peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,
+                "source": "static: rocprofv3 SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE on this workload, "
+                          "profiles/r02/configs2_hash_kernel_pmc.json (kernel alone on one stream)"}
+    except Exception:
+        return None
+
+
 def workload_tables(name, mbp, w, seed=1):
     """segment tables of the assemblies of a workload, references first (the reference's load order, bin/ntjoin.py:178-186):
     list of (assembly name, weight, segs, n_words, sub_per_65536, sub_seed)"""
@@ -375,6 +391,7 @@ def main():
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(st["launches_hash"]),
                          "bases_per_launch": int(st["hash_kernel_bases"] / launches),
                          "share_of_step_time": round(st["ms_hash"] / args.steps / ms_step, 4)},
+            "valu": valu_static(wl, mbp, multi),
             "step_roofline": {"bound": "hbm", "alg_bytes_per_step": int(step_alg_bytes),
                               "formula": "0.25 B x bases + 70 B x minimizers (SURVEY.md 8d)",
                               "achieved": round(step_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
