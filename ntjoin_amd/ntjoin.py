@@ -28,7 +28,8 @@ class Ntjoin:
     def __init__(self, args, fasta=None, w=None, variant="v2"):
         self.list_mx_info = {}  # assembly -> {mx: (contig, position)}
         self.list_mxs = {}      # assembly -> [lists of mx]
-        self.graph = None
+        self._graph = None
+        self._graph_pending = False
         self.args = args
         self.weights = {}
         self.weights_list = []
@@ -38,6 +39,20 @@ class Ntjoin:
 
     def close(self):
         self._engine.close()
+
+    @property
+    def graph(self):
+        if self._graph is None and getattr(self, "_graph_pending", False):
+            g = self._engine.get_graph()
+            self._graph = MxGraph.from_arrays(g["vertex_hash"], g["edge_u"], g["edge_v"], g["edge_support"], g["edge_weight"],
+                                              self._order)
+            self._graph_pending = False
+        return self._graph
+
+    @graph.setter
+    def graph(self, value):
+        self._graph = value
+        self._graph_pending = False
 
     # -- loading (reference order: refs in FILES order, then target) --------------------------------------
     def _add(self, assembly, weight):
@@ -76,8 +91,10 @@ class Ntjoin:
         eng.build_graph()
         if not materialize:
             # only the .mx.dot is wanted (ntjoin_amd.run): the library writes it from its own arrays; no Python object
-            # per vertex or edge is ever made (4.5 M vertices at 3 Gbp + 3 Gbp: seconds of str() and dict inserts)
-            self.graph = None
+            # per vertex or edge is made (4.5 M vertices at 3 Gbp + 3 Gbp: seconds of str() and dict inserts) unless
+            # somebody asks for self.graph afterwards (then: the array-backed container, built on first use)
+            self._graph = None
+            self._graph_pending = True
             self.print_graph(None)
             return
         g = eng.get_graph()
