@@ -34,6 +34,9 @@ class Ntjoin:
         self.weights = {}
         self.weights_list = []
         self._fasta = dict(fasta or {})
+        if self._fasta and w is None:
+            # (w is only unused on the TSV route; sketching with a default of 1 would write a huge, wrong checkpoint file)
+            raise ValueError("Ntjoin(fasta=...): the window size w must be given when assemblies are sketched from FASTA")
         self._engine = MxEngine(k=int(getattr(args, "k", 32)), w=int(w if w is not None else 1), variant=variant)
         self._order = []
 
@@ -175,7 +178,13 @@ class Ntjoin:
         tgt = len(self._order) - 1
         ids = eng.record_ids(tgt, eng.n_records(tgt))
         if lengths is None:
-            lengths = dict(zip(ids, eng.record_lengths(tgt)))
+            lens = eng.record_lengths(tgt)
+            if ids and not any(lens):
+                # a target loaded from its TSV carries no record lengths (the reference takes them from the FASTA index,
+                # calc_end_coord / scaffolds[ctg].length): silently using 0 would put every contig end at 0
+                raise ValueError("format_paths: the target was loaded from a minimizer TSV, which holds no contig lengths; "
+                                 "pass lengths={contig: length}")
+            lengths = dict(zip(ids, lens))
         ext = eng.mx_extremes(tgt)
         seg = eng.path_segments(tgt)
         gr = eng.get_graph()

@@ -94,3 +94,12 @@ def test_shard_range_partitions_records():
             if len(lens) >= 50 * world:
                 loads = [sum(int(x) for x in lens[lo:hi]) for lo, hi in ranges]
                 assert max(loads) <= sum(loads) / world + max(int(x) for x in lens)
+
+
+def test_ntjoin_constructor_needs_w_for_fasta():
+    """sketching FASTA with the TSV route's placeholder w=1 would write a huge, wrong checkpoint TSV"""
+    import argparse
+    import pytest
+    from ntjoin_amd.ntjoin import Ntjoin
+    with pytest.raises(ValueError):
+        Ntjoin(argparse.Namespace(FILES=[], s="t.tsv", l=1, p="o", k=32), fasta={"t.tsv": "t.fa"})
