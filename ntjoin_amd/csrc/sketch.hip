@@ -441,6 +441,7 @@ struct ReorderParams {
     const uint2 *arena;
     const uint32_t *wave_cnt;
     uint32_t wave_cap, n_cap;
+    uint32_t n_waves;            // slices; a block takes slices blockIdx.x, blockIdx.x + gridDim.x, ...
     const uint32_t *strip_cnt;   // [n_strips] candidates per strip
     uint32_t n_strips;
     const uint32_t *wave_tot;    // [n_waves] candidates per wave + super-counts (k_hash_sparse)
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
     __shared__ uint32_t sh_last;    // candidates of the slice's last strip
     if (threadIdx.x < 256) btab[threadIdx.x] = p.init_tab[threadIdx.x];
     if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
-    const uint32_t wv = blockIdx.x;
+    for (uint32_t wv = blockIdx.x; wv < p.n_waves; wv += gridDim.x) {  // (the tables above are loaded once per block)
     const uint2 *src = p.arena + (size_t)wv * p.wave_cap;
     // The kernel is a chain of dependent memory round trips, so everything that can be asked for at once is: the first
     // two entries of every thread (a slice holds about one per thread) are requested without waiting for the slice's
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
         const uint32_t incl = wave_inclusive_u32(c, threadIdx.x);
         spref[threadIdx.x] = before + incl - c;
         if (threadIdx.x == 63) sh_last = c;
-        if (wv + 1 == gridDim.x && threadIdx.x == 63) {
+        if (wv + 1 == p.n_waves && threadIdx.x == 63) {
             p.n_cand[0] = before + incl;
             p.n_cand[1] = 0;
         }
@@ -542,7 +543,8 @@ __global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
         }
         __syncthreads();
         for (uint32_t q = threadIdx.x; q < qn; q += RBT) hash_item(queue[q], base + q);
-        return;
+        __syncthreads();  // the next slice reuses spref / smeta / queue
+        continue;
     }
     auto place = [&](const uint2 a) {  // (slices too large for the queue: one thread per entry)
         uint32_t bits = a.y & 0xFFFFu;
@@ -557,6 +559,8 @@ __global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
     place(i0 < cnt ? a0 : make_uint2(0u, 0u));
     place(i1 < cnt ? a1 : make_uint2(0u, 0u));
     for (uint32_t i = threadIdx.x + 2u * RBT; i < cnt; i += RBT) place(src[i]);
+    __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1122,6 +1126,7 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
     __shared__ uint4 tab[20];
     __shared__ uint32_t sh[256];
     __shared__ uint32_t drop_idx;
+    __shared__ uint32_t lw[GAP_DEV_NMAX / 16 + 1024 / 16 + 4];  // the stretch's packed bases (+ k): every later read is local
     const uint4 gp = p.gaps[j];
     const uint32_t c = gp.x, klo = gp.y, khi = gp.z, n = khi - klo + 1u, w = p.w, k = p.k;
     if (threadIdx.x == 0) {
@@ -1144,16 +1149,22 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
     for (uint32_t i = threadIdx.x; i < GAP_DEV_NMAX / 32; i += 256) selbits[i] = 0;
     if (threadIdx.x == 0) drop_idx = 0xFFFFFFFFu;
     __syncthreads();
-    const uint64_t b = run.base_off + (klo - run.kidx0);
+    const uint64_t b_glob = run.base_off + (klo - run.kidx0);
+    {
+        const uint32_t n_words = (uint32_t)(((b_glob & 15u) + n + k + 15u) / 16u) + 1u;  // <= the size of lw: n <= NMAX, k <= 1024
+        for (uint32_t q = threadIdx.x; q < n_words; q += 256) lw[q] = p.packed[(b_glob >> 4) + q];
+    }
+    __syncthreads();
+    const uint64_t b = b_glob & 15u;  // base index inside lw
     const uint32_t per = (n + 255u) / 256u, i0 = threadIdx.x * per, i1 = min(i0 + per, n);
     if (i0 < n) {  // exact hashes: the direct formula once, then rolling
         H2 h = {0u, 0u, 0u, 0u};
-        init_direct(h, p.packed, b + i0, k, btab, tab);
+        init_direct(h, lw, b + i0, k, btab, tab);
         lh[i0] = canonical<VARIANT>(h);
         for (uint32_t i = i0 + 1; i < i1; ++i) {
             const uint64_t go = b + i - 1, gi = go + k;
-            const uint32_t o = (p.packed[go >> 4] >> (2u * ((uint32_t)go & 15u))) & 3u;
-            const uint32_t in = (p.packed[gi >> 4] >> (2u * ((uint32_t)gi & 15u))) & 3u;
+            const uint32_t o = (lw[go >> 4] >> (2u * ((uint32_t)go & 15u))) & 3u;
+            const uint32_t in = (lw[gi >> 4] >> (2u * ((uint32_t)gi & 15u))) & 3u;
             nt_step(h, tab[o * 4u + in]);
             lh[i] = canonical<VARIANT>(h);
         }
@@ -1294,9 +1305,20 @@ __global__ __launch_bounds__(256) void k_merge_fin(const FinParams p)
     }
     if (n_g == 0 || flag || ovf) return;  // no stretch: k_emit wrote the output itself
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    // A few hundred stretch minimizers among a million of the batch's own: almost every block of 256 consecutive own
+    // minimizers lies between two neighbouring stretch minimizers, so the block's first and last key are searched once
+    // and only a block that straddles one searches per thread.
+    __shared__ uint32_t lb_edge[2];
+    const uint32_t t0 = blockIdx.x * 256u;
+    if (t0 < nA && (threadIdx.x == 0 || threadIdx.x == 255)) {
+        const uint32_t te = min(t0 + threadIdx.x, nA - 1u);
+        lb_edge[threadIdx.x ? 1 : 0] = lower_bound_key(p.b_rec, p.b_pos, nB, ((uint64_t)p.a_rec[te] << 32) | p.a_pos[te]);
+    }
+    __syncthreads();
     if (t < nA) {
-        const uint64_t key = ((uint64_t)p.a_rec[t] << 32) | p.a_pos[t];
-        const uint64_t d = base + t + lower_bound_key(p.b_rec, p.b_pos, nB, key);
+        uint32_t lb = lb_edge[0];
+        if (lb_edge[1] != lb) lb = lower_bound_key(p.b_rec, p.b_pos, nB, ((uint64_t)p.a_rec[t] << 32) | p.a_pos[t]);
+        const uint64_t d = base + t + lb;
         if (d < p.out_limit) { p.o_hash[d] = p.a_hash[t]; p.o_pos[d] = p.a_pos[t]; p.o_rec[d] = p.a_rec[t]; }
     } else if (t < nA + nB) {
         const uint32_t u = t - nA;
@@ -1887,6 +1909,7 @@ struct Driver {
         op.wave_cnt = sp.wave_cnt;
         op.wave_cap = sp.wave_cap;
         op.n_cap = n_cap;
+        op.n_waves = g.n_waves;
         op.strip_cnt = sp.strip_cnt;
         op.n_strips = g.n_strips;
         op.wave_tot = sp.wave_tot;
@@ -1906,17 +1929,20 @@ struct Driver {
         op.tab = h->tab;
         op.queue_cap = sp.wave_cap <= 8192 ? sp.wave_cap : 0;
         const size_t q_lds = (size_t)op.queue_cap * 4;
+        // slices per block (MXG_REORDER_G): the block's byte table is loaded once for all of them
+        const uint32_t r_g = (uint32_t)std::max<uint64_t>(1, env_u64("MXG_REORDER_G", 1));
+        const uint32_t r_grid = (g.n_waves + r_g - 1) / r_g;
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-            hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V1_MIN>, dim3(g.n_waves), dim3(RB), q_lds, st, op);
+            hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V1_MIN>, dim3(r_grid), dim3(RB), q_lds, st, op);
         else
         {
             static const int rabl = getenv("MXG_ABLATE_REORDER") ? atoi(getenv("MXG_ABLATE_REORDER")) : 0;  // profiling only
             if (rabl == 1)
-                hipLaunchKernelGGL((k_reorder<MXG_VARIANT_V2_SUM, 1>), dim3(g.n_waves), dim3(RB), q_lds, st, op);
+                hipLaunchKernelGGL((k_reorder<MXG_VARIANT_V2_SUM, 1>), dim3(r_grid), dim3(RB), q_lds, st, op);
             else if (env_u64("MXG_RB", few_cand ? 256 : RB) == 256)  // ~205 candidates per slice at 10 per window: one pass of 256 threads
-                hipLaunchKernelGGL((k_reorder<MXG_VARIANT_V2_SUM, 0, 256>), dim3(g.n_waves), dim3(256), q_lds, st, op);
+                hipLaunchKernelGGL((k_reorder<MXG_VARIANT_V2_SUM, 0, 256>), dim3(r_grid), dim3(256), q_lds, st, op);
             else
-                hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V2_SUM>, dim3(g.n_waves), dim3(RB), q_lds, st, op);
+                hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V2_SUM>, dim3(r_grid), dim3(RB), q_lds, st, op);
         }
         MXG_HIP(h, hipGetLastError());
         // resolve + speculative emit straight into the output arrays (guarded by their capacity): on the common path
