@@ -5,6 +5,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -352,14 +353,39 @@ void shard_range(const uint64_t *lengths, uint64_t n, uint32_t shard, uint32_t n
     *hi = hgh;
 }
 
-static int parse_fasta_stream(mxg_handle *h, FILE *f, const char *path, Ingest &in, bool keep)
+// plain or gzip-compressed text (indexlr reads both; B1 in SURVEY.md 8b lists `.gz` as optional): zlib's gzread passes
+// uncompressed files through unchanged, so one reader serves both
+struct TextReader {
+    gzFile g = nullptr;
+    bool open(const char *path)
+    {
+        g = gzopen(path, "rb");
+        if (g) gzbuffer(g, 1 << 20);
+        return g != nullptr;
+    }
+    size_t read(char *dst, size_t n)
+    {
+        const int got = gzread(g, dst, (unsigned)n);
+        if (got < 0) bad = true;
+        return got > 0 ? (size_t)got : 0;
+    }
+    void rewind() { gzrewind(g); }
+    void close()
+    {
+        if (g) gzclose(g);
+        g = nullptr;
+    }
+    bool bad = false;
+};
+
+static int parse_fasta_stream(mxg_handle *h, TextReader &f, const char *path, Ingest &in, bool keep)
 {
     std::vector<char> buf(1 << 22);
     std::string carry;  // partial header line across buffer boundaries
     bool in_header = false, have_rec = false, at_line_start = true;
     int rc = MXG_OK;
     size_t got;
-    while (rc == MXG_OK && (got = fread(buf.data(), 1, buf.size(), f)) > 0) {
+    while (rc == MXG_OK && (got = f.read(buf.data(), buf.size())) > 0) {
         size_t i = 0;
         while (i < got && rc == MXG_OK) {
             if (in_header) {
@@ -390,7 +416,7 @@ static int parse_fasta_stream(mxg_handle *h, FILE *f, const char *path, Ingest &
             }
         }
     }
-    if (ferror(f)) rc = set_err(h, MXG_EIO, "read error on '%s'", path);
+    if (f.bad) rc = set_err(h, MXG_EIO, "read error on '%s'", path);
     if (rc != MXG_OK) return rc;
     if (in_header) {  // header without trailing newline at EOF
         if (have_rec) rc = in.end_record();
@@ -448,8 +474,8 @@ static void plan_pieces(Ingest &in, uint32_t shard, uint32_t n_shards, uint32_t 
 
 int load_fasta(mxg_handle *h, Assembly *a, const char *path, uint32_t shard, uint32_t n_shards, bool split)
 {
-    FILE *f = fopen(path, "rb");
-    if (!f) return set_err(h, MXG_EIO, "cannot open FASTA '%s'", path);
+    TextReader f;
+    if (!f.open(path)) return set_err(h, MXG_EIO, "cannot open FASTA '%s'", path);
     const bool keep = !(h->cfg.flags & MXG_FLAG_DROP_SEQ);
     Ingest in(h, a);
     int rc = MXG_OK;
@@ -470,7 +496,7 @@ int load_fasta(mxg_handle *h, Assembly *a, const char *path, uint32_t shard, uin
             in.lengths_only = in.collect_runs = false;
             in.split = true;
             in.all_runs.clear();
-            rewind(f);
+            f.rewind();
         }
     } else if (n_shards > 1) {  // pass 1: record lengths -> this rank's contiguous record range (same on every rank)
         in.lengths_only = true;
@@ -480,11 +506,11 @@ int load_fasta(mxg_handle *h, Assembly *a, const char *path, uint32_t shard, uin
             a->shard_lo = in.keep_lo;
             a->shard_hi = in.keep_hi;
             in.lengths_only = false;
-            rewind(f);
+            f.rewind();
         }
     }
     if (rc == MXG_OK) rc = parse_fasta_stream(h, f, path, in, keep);
-    fclose(f);
+    f.close();
     if (rc != MXG_OK) return rc;
     in.finish();
     a->has_text = keep;

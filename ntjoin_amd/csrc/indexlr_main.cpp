@@ -14,7 +14,7 @@
 
 static void usage(FILE *f)
 {
-    fputs("Usage: indexlr -k K -w W [--id] [--pos] [--strand] [--seq] [--long] [-t T] [-o FILE] FASTA\n"
+    fputs("Usage: indexlr -k K -w W [--id] [--pos] [--strand] [--seq] [--long] [-t T] [-o FILE] FASTA[.gz]\n"
           "  GPU (MI355X) minimizer sketcher, output-compatible with btllib indexlr for these options:\n"
           "  -k K           k-mer size (required)\n"
           "  -w W           window size in k-mers (required)\n"

@@ -176,7 +176,9 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
         return 1;
     }
     const uint64_t fsz = (uint64_t)sb.st_size;
-    if (fsz == 0) {  // (let the host parser produce the empty assembly)
+    unsigned char magic[2] = {0, 0};
+    const bool gz = fsz >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (fsz == 0 || gz) {  // (the host parser produces the empty assembly / inflates gzip input)
         close(fd);
         return 1;
     }

@@ -149,3 +149,32 @@ def test_tsv_of_packed_device_assembly_is_formatted_on_the_device(tmp_path, orac
             else:
                 assert rest.count(b" ") + (1 if rest else 0) == hi - lo
     assert r == len(segs) - 1
+
+
+def test_gzip_fasta_input(tmp_path):
+    """`.gz` input (indexlr reads both; SURVEY.md 8b B1 lists it as optional): same TSV as the plain file, through the CLI and
+    through the sub-record split loader"""
+    import gzip
+    orc = _oracle.load()
+    fa = str(tmp_path / "m.fa")
+    _write_fasta(fa, _messy_records(11), width=60)
+    gz = fa + ".gz"
+    with open(fa, "rb") as src, gzip.open(gz, "wb") as dst:
+        dst.write(src.read())
+    want = str(tmp_path / "want.tsv")
+    orc.fasta_to_tsv(fa, want, 32, 100)
+    exe = os.path.join(REPO, "ntjoin_amd", "bin", "indexlr")
+    out = subprocess.run([exe, "--seq", "--long", "--pos", "-k32", "-w100", "-t2", gz], capture_output=True, check=True).stdout
+    assert out == open(want, "rb").read()
+    parts = []
+    for s in range(3):
+        with MxEngine(k=32, w=100) as eng:
+            eng.add_fasta_split("x", 1.0, gz, s, 3)
+            eng.sketch()
+            parts.append(eng.get_sketch(0))
+    with MxEngine(k=32, w=100) as eng:
+        eng.add_fasta("x", 1.0, fa)
+        eng.sketch()
+        whole = eng.get_sketch(0)
+    for key in ("out_hash", "pos", "record"):
+        assert np.array_equal(np.concatenate([p[key] for p in parts]), whole[key]), key
