@@ -291,7 +291,7 @@ def main():
     graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("partitioned" if m_rank * (0.14 * world - 0.2) > 0.39 else "union")
     for name, weight, segs, n_words, sub, sub_seed in asms:
         d, rec_start, rec_len = add_rank_share(eng, name, weight, segs, cfg["seed"], sub_seed, sub, rank if world > 1 else 0, world,
-                                               local_rank, split=graph_mode != "partitioned")  # bases born in HBM
+                                               local_rank, split=os.environ.get("MXG_BENCH_WHOLE_RECORDS") != "1")  # bases born in HBM
         keep.append(d)
         host_layout.append((d, rec_start, rec_len))
     eng.global_records = True
@@ -378,7 +378,7 @@ def main():
                        "records": [int(len(a[2])) for a in asms],
                        "parallelism": ("1 GPU" if world == 1 else f"{world} ranks, " +
                                        ("a contiguous range of whole records of every assembly each (balanced by bases), "
-                                        if graph_mode == "partitioned" else
+                                        if os.environ.get("MXG_BENCH_WHOLE_RECORDS") == "1" else
                                         f"each 1/{world} of every assembly's bases (records cut at the range borders travel as pieces "
                                         "with a w-k-mer halo), ") +
                                        ("graph stage partitioned by hash range (RCCL all-to-all)" if graph_mode == "partitioned"

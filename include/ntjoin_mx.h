@@ -338,6 +338,14 @@ int mxg_dg_item_results(mxg_handle *h, int assembly, const void *d_gbase, uint32
                         const uint64_t *sec_count, void *d_out);
 int mxg_dg_msg_counts(mxg_handle *h, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts);
 int mxg_dg_pack_msgs(mxg_handle *h, int assembly, uint32_t world, const void *d_bases, const uint64_t *starts, void *d_send);
+/* Records cut between ranks (mxg_add_assembly_fasta_split / ..._packed_device_pieces): the adjacency between the last shared
+   minimizer of one rank's piece and the first shared minimizer of the next rank's piece lies with neither rank.  After the
+   verdicts came back, mxg_dg_last_shared writes {record, global vertex id} of this rank's LAST shared minimizer of every
+   assembly (2^32-1: none) to d_out (device u32[A][2]); the caller all-gathers these (u32[world][A][2]) and hands them to
+   mxg_dg_set_ghosts, after which mxg_dg_msg_counts / mxg_dg_pack_msgs / mxg_dg_pack_msg_slots also emit the pair (nearest
+   shared minimizer of that record on an earlier rank, this rank's first).  d_all = NULL switches it off.  No host sync. */
+int mxg_dg_last_shared(mxg_handle *h, const void *d_ret, void *d_out);
+int mxg_dg_set_ghosts(mxg_handle *h, const void *d_all, uint32_t world, uint32_t rank);
 int mxg_dg_edges(mxg_handle *h, const void *d_msgs, uint64_t n_msgs, uint64_t *n_vertices, uint64_t *n_edges);
 /* Steady state of the same exchange with FIXED-CAPACITY SLOTS: once one exact step has shown the sizes, every (source,
    destination) pair gets a slot = 64-byte header (u64 count per assembly, <= 8 assemblies) + cap[a] 16-byte items per

@@ -22,7 +22,7 @@ SYMBOLS = [
     "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_path_segments", "mxg_mx_extremes", "mxg_dg_owner_counts", "mxg_dg_pack_items", "mxg_dg_set_items", "mxg_dg_vertices", "mxg_dg_item_results", "mxg_dg_msg_counts", "mxg_dg_pack_msgs", "mxg_dg_edges", "mxg_dg_pack_slots", "mxg_dg_owner_slots", "mxg_dg_slot_results", "mxg_dg_pack_msg_slots", "mxg_dg_edges_slots", "mxg_write_dot",
     "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers",
     "mxg_synth_fill_packed_device", "mxg_synth_fill_packed_host", "mxg_synth_write_fasta",
-    "mxg_plan_split", "mxg_add_assembly_packed_device_pieces",
+    "mxg_plan_split", "mxg_add_assembly_packed_device_pieces", "mxg_dg_last_shared", "mxg_dg_set_ghosts",
 ]
 
 
@@ -177,6 +177,8 @@ def load():
     L.mxg_dg_msg_counts.argtypes = [vp, C.c_uint32, vp, vp, pu64]
     L.mxg_dg_pack_msgs.argtypes = [vp, i32, C.c_uint32, vp, pu64, vp]
     L.mxg_dg_edges.argtypes = [vp, vp, u64, pu64, pu64]
+    L.mxg_dg_last_shared.argtypes = [vp, vp, vp]
+    L.mxg_dg_set_ghosts.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     pu32 = C.POINTER(C.c_uint32)
     L.mxg_dg_pack_slots.argtypes = [vp, i32, C.c_uint32, C.c_uint32, C.c_uint32, pu32, vp]
     L.mxg_dg_owner_slots.argtypes = [vp, C.c_uint32, C.c_uint32, pu32, vp, vp]

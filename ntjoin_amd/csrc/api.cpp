@@ -823,6 +823,18 @@ int mxg_dg_msg_counts(mxg_handle *h, uint32_t world, const void *d_ret, const vo
     DG_TRY(dg_msg_counts(h, world, d_ret, d_bases, counts))
 }
 
+int mxg_dg_last_shared(mxg_handle *h, const void *d_ret, void *d_out)
+{
+    if (!h || !d_ret || !d_out) return MXG_EINVAL;
+    DG_TRY(dg_last_shared(h, d_ret, d_out))
+}
+
+int mxg_dg_set_ghosts(mxg_handle *h, const void *d_all, uint32_t world, uint32_t rank)
+{
+    if (!h || world == 0 || world > 64) return MXG_EINVAL;
+    DG_TRY(dg_set_ghosts(h, d_all, world, rank))
+}
+
 int mxg_dg_pack_msgs(mxg_handle *h, int assembly, uint32_t world, const void *d_bases, const uint64_t *starts, void *d_send)
 {
     Assembly *a = get_asm(h, assembly);

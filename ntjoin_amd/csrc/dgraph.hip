@@ -215,22 +215,42 @@ __device__ __forceinline__ uint32_t dg_vertex_owner(const uint32_t *__restrict__
     return lo;
 }
 
+// Records cut between ranks (sub-record shards): the adjacency between the last shared minimizer of one rank's piece and
+// the first shared minimizer of the next rank's piece is seen by neither.  `ghost` = {record, global vertex id} of the
+// nearest shared minimizer BEFORE this rank's first one (from the ranks before it, mxg_dg_set_ghosts; record 2^32-1: none):
+// pair number ns - 1 (otherwise unused: pairs are (r, r + 1) for r + 1 < ns) stands for (ghost, shared minimizer 0).
+struct DgPair {
+    bool in;
+    uint32_t u, v;
+};
+__device__ __forceinline__ DgPair dg_pair(const uint32_t *__restrict__ fg, const uint32_t *__restrict__ frec, uint32_t ns, uint32_t r,
+                                          const uint32_t *__restrict__ ghost)
+{
+    DgPair p{false, 0u, 0u};
+    if (r + 1 < ns) {
+        if (frec[r] == frec[r + 1]) p = DgPair{true, fg[r], fg[r + 1]};
+    } else if (r + 1 == ns && ghost && ghost[0] != 0xFFFFFFFFu && ghost[0] == frec[0]) {
+        p = DgPair{true, ghost[1], fg[0]};
+    }
+    return p;
+}
+
 // pair r = (shared minimizer r, r + 1) of the same record: one message to the owner of each end
 __global__ __launch_bounds__(256) void k_dg_msg_count(const uint32_t *__restrict__ fg, const uint32_t *__restrict__ frec,
                                                       const uint32_t *__restrict__ n_shared, const uint32_t *__restrict__ bases,
-                                                      uint32_t world, unsigned long long *cnt)
+                                                      uint32_t world, unsigned long long *cnt, const uint32_t *__restrict__ ghost)
 {
     __shared__ uint32_t lh[64];
     if (threadIdx.x < 64) lh[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t ns = *n_shared;
     const uint32_t r0 = blockIdx.x * DG_IPB;
-    if (r0 + 1 < ns) {
+    if (r0 < ns) {
         for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
             const uint32_t r = r0 + it * 256u + threadIdx.x;
-            const bool in = r + 1 < ns && frec[r] == frec[r + 1];
-            lds_hist(lh, in ? dg_vertex_owner(bases, world, fg[r]) : 0u, in);
-            lds_hist(lh, in ? dg_vertex_owner(bases, world, fg[r + 1]) : 0u, in);
+            const DgPair pr = dg_pair(fg, frec, ns, r, ghost);
+            lds_hist(lh, pr.in ? dg_vertex_owner(bases, world, pr.u) : 0u, pr.in);
+            lds_hist(lh, pr.in ? dg_vertex_owner(bases, world, pr.v) : 0u, pr.in);
         }
     }
     __syncthreads();
@@ -239,7 +259,8 @@ __global__ __launch_bounds__(256) void k_dg_msg_count(const uint32_t *__restrict
 
 __global__ __launch_bounds__(256) void k_dg_pack_msgs(const uint32_t *__restrict__ fg, const uint32_t *__restrict__ frec,
                                                       const uint32_t *__restrict__ n_shared, const uint32_t *__restrict__ bases,
-                                                      uint32_t world, uint32_t assembly, unsigned long long *cursor, uint4 *msgs)
+                                                      uint32_t world, uint32_t assembly, unsigned long long *cursor, uint4 *msgs,
+                                                      const uint32_t *__restrict__ ghost)
 {
     __shared__ uint32_t lh[64], lcur[64];
     __shared__ unsigned long long lbase[64];
@@ -247,20 +268,21 @@ __global__ __launch_bounds__(256) void k_dg_pack_msgs(const uint32_t *__restrict
     __syncthreads();
     const uint32_t ns = *n_shared;
     const uint32_t r0 = blockIdx.x * DG_IPB;
-    if (r0 + 1 >= ns) return;  // block-uniform
+    if (r0 >= ns) return;  // block-uniform
     for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
         const uint32_t r = r0 + it * 256u + threadIdx.x;
-        const bool in = r + 1 < ns && frec[r] == frec[r + 1];
-        lds_hist(lh, in ? dg_vertex_owner(bases, world, fg[r]) : 0u, in);
-        lds_hist(lh, in ? dg_vertex_owner(bases, world, fg[r + 1]) : 0u, in);
+        const DgPair pr = dg_pair(fg, frec, ns, r, ghost);
+        lds_hist(lh, pr.in ? dg_vertex_owner(bases, world, pr.u) : 0u, pr.in);
+        lds_hist(lh, pr.in ? dg_vertex_owner(bases, world, pr.v) : 0u, pr.in);
     }
     __syncthreads();
     if (threadIdx.x < world) lbase[threadIdx.x] = lh[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)lh[threadIdx.x]) : 0ull;
     __syncthreads();
     for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
         const uint32_t r = r0 + it * 256u + threadIdx.x;
-        const bool in = r + 1 < ns && frec[r] == frec[r + 1];
-        const uint32_t u = in ? fg[r] : 0u, v = in ? fg[r + 1] : 0u;
+        const DgPair pr = dg_pair(fg, frec, ns, r, ghost);
+        const bool in = pr.in;
+        const uint32_t u = pr.u, v = pr.v;
         const uint32_t ou = in ? dg_vertex_owner(bases, world, u) : 0u, ov = in ? dg_vertex_owner(bases, world, v) : 0u;
         const uint32_t su = lds_slot(lcur, ou, in);
         const uint32_t sv = lds_slot(lcur, ov, in);
@@ -395,6 +417,88 @@ int dg_item_results(mxg_handle *h, Assembly *a, const void *d_gbase, uint32_t wo
     return MXG_OK;
 }
 
+// ---- records cut between ranks: the last shared minimizer of every rank travels to the ranks after it -----------------------
+__global__ void k_dg_last(const uint32_t *__restrict__ fg, const uint32_t *__restrict__ frec, const uint32_t *__restrict__ n_shared,
+                          uint32_t *out)
+{
+    const uint32_t ns = *n_shared;
+    out[0] = ns ? frec[ns - 1] : 0xFFFFFFFFu;
+    out[1] = ns ? fg[ns - 1] : 0xFFFFFFFFu;
+}
+__global__ void k_dg_pick_ghost(const uint32_t *__restrict__ all, uint32_t n_asm, uint32_t rank, uint32_t *ghost)
+{
+    const uint32_t a = threadIdx.x;
+    if (a >= n_asm) return;
+    uint32_t rec = 0xFFFFFFFFu, g = 0xFFFFFFFFu;
+    for (uint32_t q = rank; q-- > 0;) {  // the nearest rank before this one that has a shared minimizer of assembly a
+        const uint32_t *e = all + ((size_t)q * n_asm + a) * 2;
+        if (e[0] != 0xFFFFFFFFu) {
+            rec = e[0];
+            g = e[1];
+            break;
+        }
+    }
+    ghost[2 * a] = rec;
+    ghost[2 * a + 1] = g;
+}
+
+// sender, after the verdicts came back: {record, global vertex id} of this rank's LAST shared minimizer of every assembly
+// (2^32-1, 2^32-1: none) into d_out (u32[A][2], device).  No host sync.
+int dg_last_shared(mxg_handle *h, const void *d_ret, void *d_out)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    const size_t A = h->asms.size();
+    for (size_t ai = 0; ai < A; ++ai) {
+        Assembly *a = h->asms[ai];
+        const uint32_t n = (uint32_t)a->n_mx;
+        const uint32_t blocks = (n + 255) / 256;
+        MXG_HIP(h, a->d_flags.ensure(std::max<uint32_t>(n, 16)));
+        MXG_HIP(h, a->d_dgtmp.ensure(((size_t)sup_words(blocks) + blocks + 16) * 4));
+        MXG_HIP(h, a->d_fg.ensure((size_t)n * 4 + 16));
+        MXG_HIP(h, a->d_frec.ensure((size_t)n * 4 + 16));
+        uint32_t *sup = a->d_dgtmp.as<uint32_t>(), *cnt = sup + sup_words(blocks), *n_shared = cnt + blocks;
+        MXG_HIP(h, hipMemsetAsync(sup, 0, (size_t)sup_words(blocks) * 4, h->stream));
+        MXG_HIP(h, hipMemsetAsync(n_shared, 0, 4, h->stream));
+        if (n) {
+            DgAdjParams p;
+            p.ret = static_cast<const unsigned long long *>(d_ret);
+            p.perm = a->d_perm.as<uint32_t>();
+            p.rec = a->d_rec.as<uint32_t>();
+            p.n = n;
+            p.cnt = cnt;
+            p.sup = sup;
+            p.fg = a->d_fg.as<uint32_t>();
+            p.frec = a->d_frec.as<uint32_t>();
+            p.n_shared = n_shared;
+            p.flags_out = a->d_flags.as<uint8_t>();
+            hipLaunchKernelGGL(k_dg_shared_cnt, dim3(blocks), dim3(256), 0, h->stream, p);
+            hipLaunchKernelGGL(k_dg_compact, dim3(blocks), dim3(256), 0, h->stream, p);
+        }
+        hipLaunchKernelGGL(k_dg_last, dim3(1), dim3(1), 0, h->stream, a->d_fg.as<uint32_t>(), a->d_frec.as<uint32_t>(), n_shared,
+                           static_cast<uint32_t *>(d_out) + 2 * ai);
+    }
+    MXG_HIP(h, hipGetLastError());
+    if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));
+    return MXG_OK;
+}
+
+// sender: d_all = the all-gather of every rank's dg_last_shared (u32[world][A][2]); from here on the message kernels also
+// make the adjacency across the cut before this rank's first shared minimizer.  d_all = NULL: off.
+int dg_set_ghosts(mxg_handle *h, const void *d_all, uint32_t world, uint32_t rank)
+{
+    MXG_HIP(h, hipSetDevice(h->device));
+    h->dg_ghost_on = false;
+    if (!d_all) return MXG_OK;
+    if (rank >= world) return set_err(h, MXG_EINVAL, "rank out of range");
+    const size_t A = h->asms.size();
+    MXG_HIP(h, h->dg_ghost.ensure(MXG_MAX_ASSEMBLIES * 8));
+    hipLaunchKernelGGL(k_dg_pick_ghost, dim3(1), dim3(MXG_MAX_ASSEMBLIES), 0, h->stream, static_cast<const uint32_t *>(d_all), (uint32_t)A,
+                       rank, h->dg_ghost.as<uint32_t>());
+    MXG_HIP(h, hipGetLastError());
+    h->dg_ghost_on = true;
+    return MXG_OK;
+}
+
 // sender: the verdicts are back (d_ret, send-buffer order).  Flags of every assembly, its shared minimizers in order, and
 // how many adjacency messages go to every rank: counts[a * world + r]; d_bases = [world + 1] first global vertex id of
 // every rank (device).  One host sync for all assemblies.
@@ -430,7 +534,8 @@ int dg_msg_counts(mxg_handle *h, uint32_t world, const void *d_ret, const void *
             hipLaunchKernelGGL(k_dg_shared_cnt, dim3(blocks), dim3(256), 0, h->stream, p);
             hipLaunchKernelGGL(k_dg_compact, dim3(blocks), dim3(256), 0, h->stream, p);
             hipLaunchKernelGGL(k_dg_msg_count, dim3((n + DG_IPB - 1) / DG_IPB), dim3(256), 0, h->stream, p.fg, p.frec, n_shared,
-                               static_cast<const uint32_t *>(d_bases), world, h->dg_cnt.as<unsigned long long>() + ai * 64);
+                               static_cast<const uint32_t *>(d_bases), world, h->dg_cnt.as<unsigned long long>() + ai * 64,
+                               h->dg_ghost_on ? h->dg_ghost.as<uint32_t>() + 2 * ai : nullptr);
             MXG_HIP(h, hipGetLastError());
         }
         a->flags_valid = true;
@@ -457,7 +562,7 @@ int dg_pack_msgs(mxg_handle *h, Assembly *a, uint32_t assembly, uint32_t world, 
     uint32_t *n_shared = a->d_dgtmp.as<uint32_t>() + sup_words(blocks) + blocks;
     hipLaunchKernelGGL(k_dg_pack_msgs, dim3((n + DG_IPB - 1) / DG_IPB), dim3(256), 0, h->stream, a->d_fg.as<uint32_t>(), a->d_frec.as<uint32_t>(),
                        n_shared, static_cast<const uint32_t *>(d_bases), world, assembly, h->dg_cursor.as<unsigned long long>(),
-                       static_cast<uint4 *>(d_send));
+                       static_cast<uint4 *>(d_send), h->dg_ghost_on ? h->dg_ghost.as<uint32_t>() + 2 * assembly : nullptr);
     MXG_HIP(h, hipGetLastError());
     if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));
     return MXG_OK;
@@ -584,7 +689,8 @@ __global__ __launch_bounds__(256) void k_dg_slot_results(const uint8_t *__restri
 // adjacency messages into slots of M messages per destination (header word 0 = count)
 __global__ __launch_bounds__(256) void k_dg_pack_msg_slots(const uint32_t *__restrict__ fg, const uint32_t *__restrict__ frec,
                                                            const uint32_t *__restrict__ n_shared, const uint32_t *__restrict__ bases,
-                                                           uint32_t world, uint32_t assembly, uint32_t M, unsigned char *send)
+                                                           uint32_t world, uint32_t assembly, uint32_t M, unsigned char *send,
+                                                           const uint32_t *__restrict__ ghost)
 {
     __shared__ uint32_t lh[64], lcur[64];
     __shared__ unsigned long long lbase[64];
@@ -592,13 +698,13 @@ __global__ __launch_bounds__(256) void k_dg_pack_msg_slots(const uint32_t *__res
     __syncthreads();
     const uint32_t ns = *n_shared;
     const uint32_t r0 = blockIdx.x * DG_IPB;
-    if (r0 + 1 >= ns) return;  // block-uniform
+    if (r0 >= ns) return;  // block-uniform
     const uint64_t stride = 64 + (uint64_t)M * 16;
     for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
         const uint32_t r = r0 + it * 256u + threadIdx.x;
-        const bool in = r + 1 < ns && frec[r] == frec[r + 1];
-        lds_hist(lh, in ? dg_vertex_owner(bases, world, fg[r]) : 0u, in);
-        lds_hist(lh, in ? dg_vertex_owner(bases, world, fg[r + 1]) : 0u, in);
+        const DgPair pr = dg_pair(fg, frec, ns, r, ghost);
+        lds_hist(lh, pr.in ? dg_vertex_owner(bases, world, pr.u) : 0u, pr.in);
+        lds_hist(lh, pr.in ? dg_vertex_owner(bases, world, pr.v) : 0u, pr.in);
     }
     __syncthreads();
     if (threadIdx.x < world && lh[threadIdx.x])
@@ -607,8 +713,9 @@ __global__ __launch_bounds__(256) void k_dg_pack_msg_slots(const uint32_t *__res
     __syncthreads();
     for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
         const uint32_t r = r0 + it * 256u + threadIdx.x;
-        const bool in = r + 1 < ns && frec[r] == frec[r + 1];
-        const uint32_t u = in ? fg[r] : 0u, v = in ? fg[r + 1] : 0u;
+        const DgPair pr = dg_pair(fg, frec, ns, r, ghost);
+        const bool in = pr.in;
+        const uint32_t u = pr.u, v = pr.v;
         const uint32_t ou = in ? dg_vertex_owner(bases, world, u) : 0u, ov = in ? dg_vertex_owner(bases, world, v) : 0u;
         const uint32_t su = lds_slot(lcur, ou, in);
         const uint32_t sv = lds_slot(lcur, ov, in);
@@ -748,7 +855,8 @@ int dg_pack_msg_slots(mxg_handle *h, uint32_t world, uint32_t M, const void *d_r
             hipLaunchKernelGGL(k_dg_shared_cnt, dim3(blocks), dim3(256), 0, h->stream, p);
             hipLaunchKernelGGL(k_dg_compact, dim3(blocks), dim3(256), 0, h->stream, p);
             hipLaunchKernelGGL(k_dg_pack_msg_slots, dim3((n + DG_IPB - 1) / DG_IPB), dim3(256), 0, h->stream, p.fg, p.frec, n_shared,
-                               static_cast<const uint32_t *>(d_bases), world, (uint32_t)ai, M, static_cast<unsigned char *>(d_send));
+                               static_cast<const uint32_t *>(d_bases), world, (uint32_t)ai, M, static_cast<unsigned char *>(d_send),
+                               h->dg_ghost_on ? h->dg_ghost.as<uint32_t>() + 2 * ai : nullptr);
         }
         a->flags_valid = true;
         a->flags_on_host = false;

@@ -187,6 +187,8 @@ struct mxg_handle {
     std::vector<hipEvent_t> ev_sync;  // ... and the events by which a batch waits for its predecessor on the other stream
     hipEvent_t ev_join = nullptr;   // ... and the event that joins the second stream into the first
     mxg::DevBuf dg_cnt, dg_cursor;  // dgraph.hip: per-destination counts / cursors
+    mxg::DevBuf dg_ghost;           // ... {record, global vertex id} of the shared minimizer before this rank's first, per assembly
+    bool dg_ghost_on = false;
     mxg::Paths paths;
     mxg::DevBuf pbuf[48];  // scratch of paths.hip
     mxg::Segments segs;
@@ -292,6 +294,8 @@ int dg_set_items(mxg_handle *h, Assembly *a, const void *d_items, uint32_t world
 int dg_item_results(mxg_handle *h, Assembly *a, const void *d_gbase, uint32_t world, const uint64_t *sec_start,
                     const uint64_t *sec_count, void *d_out);
 int dg_msg_counts(mxg_handle *h, uint32_t world, const void *d_ret, const void *d_bases, uint64_t *counts);
+int dg_last_shared(mxg_handle *h, const void *d_ret, void *d_out);
+int dg_set_ghosts(mxg_handle *h, const void *d_all, uint32_t world, uint32_t rank);
 int dg_pack_msgs(mxg_handle *h, Assembly *a, uint32_t assembly, uint32_t world, const void *d_bases, const uint64_t *starts,
                  void *d_send);
 int dg_pack_slots(mxg_handle *h, Assembly *a, uint32_t ai, uint32_t rec_offset, uint32_t world, uint32_t n_asm, const uint32_t *cap,

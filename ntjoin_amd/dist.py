@@ -310,11 +310,6 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", device)
     cur = torch.cuda.current_stream()
-    if world > 1 and any(eng.assembly_continues(a) for a in range(A)):
-        # the adjacency messages are made per rank from ITS records' consecutive shared minimizers: a record cut between two
-        # ranks would lose the edge across the cut.  Shard whole records for this route (the union route takes pieces).
-        raise ValueError("partitioned_graph needs whole records per rank (this handle holds a piece of a record begun on the "
-                         "rank before it: use shard loads, or the union exchange)")
     if owner is None:
         owner = MxEngine(k=k, w=w, device=device, timing=True, stream=stream.cuda_stream if stream is not None else None)
         owner._rec_off = []
@@ -332,6 +327,13 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
             owner.add_minimizers(eng.assembly_name(a), eng.assembly_weight(a), np.zeros(0, np.uint64), np.zeros(0, np.uint32),
                                  np.zeros(0, np.uint32), flat)
         owner._buf = {}
+        # records cut between ranks (sub-record shards)?  Then the last shared minimizer of every rank travels to the ranks
+        # after it, so that the adjacency across a cut is not lost (mxg_dg_last_shared / mxg_dg_set_ghosts).  Decided once,
+        # together: the extra all-gather must be entered by every rank or by none.
+        cut = torch.tensor([1 if (world > 1 and any(eng.assembly_continues(a) for a in range(A))) else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(cut, op=dist.ReduceOp.MAX, group=group)
+        owner._cut = bool(int(cut.item()))
         # small fixed-size staging, pinned on the host side: [world][A] size matrices, [world] message sizes, vertex counts
         owner._st = {"c_h": torch.empty((world, A), dtype=torch.int64).pin_memory(), "c_out": torch.empty((world, A), dtype=torch.int64, device=dev),
                      "c_in": torch.empty((world, A), dtype=torch.int64, device=dev), "g_h": torch.empty((world, A), dtype=torch.int64).pin_memory(),
@@ -414,6 +416,7 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
     # 7. adjacency of MY records -> messages to the owners of the two end points                  (host sync 3)
     if stream is None:
         cur.synchronize()
+    _ghosts(eng, owner, lib, A, world, rank, dev, ret_in, group, stream is None)
     mcnt = np.zeros(A * world, dtype=np.uint64)
     chk(eng, lib.mxg_dg_msg_counts(eng._h, world, C.c_void_p(ret_in.data_ptr()), C.c_void_p(st["bases"].data_ptr()), _u64p(mcnt)))
     mcnt = mcnt.reshape(A, world).astype(np.int64)
@@ -456,6 +459,27 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
     return owner
 
 
+def _ghosts(eng, owner, lib, A, world, rank, dev, ret_in, group, own):
+    """records cut between ranks: every rank's last shared minimizer per assembly, all-gathered, becomes the predecessor of the
+    first shared minimizer of the ranks after it (device-side; one small collective, no host sync)"""
+    import ctypes as C
+    if not getattr(owner, "_cut", False):
+        return
+    st = owner._st
+    if "last" not in st:
+        st["last"] = torch.empty(A * 2, dtype=torch.int32, device=dev)
+        st["lasts"] = torch.empty(world * A * 2, dtype=torch.int32, device=dev)
+    rc = lib.mxg_dg_last_shared(eng._h, C.c_void_p(ret_in.data_ptr()), C.c_void_p(st["last"].data_ptr()))
+    if rc < 0:
+        eng._check(rc)
+    dist.all_gather_into_tensor(st["lasts"], st["last"], group=group)
+    if own:
+        torch.cuda.current_stream().synchronize()   # the handle works on its own stream: the gathered values must be there
+    rc = lib.mxg_dg_set_ghosts(eng._h, C.c_void_p(st["lasts"].data_ptr()), world, rank)
+    if rc < 0:
+        eng._check(rc)
+
+
 def _partitioned_slots(eng, owner, A, world, rank, dev, group, stream):
     """one step of the partitioned graph stage with fixed-capacity slots: 4 all-to-all / all-gather collectives with equal
     splits, counts read on the device, ONE host sync (the owner's last kernel) + the agreement on overflow.  False: a
@@ -493,6 +517,7 @@ def _partitioned_slots(eng, owner, A, world, rank, dev, group, stream):
         cur.synchronize()
     msend = _grow(buf, "s_msend", world * mstride, dev)[:world * mstride]
     mrecv = _grow(buf, "s_mrecv", world * mstride, dev)[:world * mstride]
+    _ghosts(eng, owner, lib, A, world, rank, dev, ret_in, group, own)
     chk(eng, lib.mxg_dg_pack_msg_slots(eng._h, world, M, C.c_void_p(ret_in.data_ptr()), C.c_void_p(st["bases"].data_ptr()),
                                        C.c_void_p(msend.data_ptr())))
     dist.all_to_all_single(mrecv.view(world, mstride), msend.view(world, mstride), group=group)

@@ -150,3 +150,29 @@ def test_bench_named_workloads_scaled_down(world, workload, mbp, graph):
 
 
 _ONE_RANK = {}
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_partitioned_graph_with_records_cut_between_ranks(tmp_path, world):
+    """three assemblies of a few long records each, every rank an equal base range of each (so most ranks start in the middle
+    of a record): the hash-partitioned graph must not lose the edge across a cut"""
+    import random
+    rng = random.Random(77)
+    base = "".join(rng.choice("ACGT") for _ in range(240_000))
+    fastas = []
+    for a, n_rec in enumerate((2, 3, 5)):
+        cuts = sorted(rng.sample(range(20_000, len(base) - 20_000), n_rec - 1))
+        path = tmp_path / f"asm{a}.fa"
+        with open(path, "w") as fh:
+            for r, (lo, hi) in enumerate(zip([0] + cuts, cuts + [len(base)])):
+                s = list(base[lo:hi])
+                for _ in range(len(s) // 400):
+                    s[rng.randrange(len(s))] = rng.choice("ACGT")
+                fh.write(f">a{a}_r{r}\n" + "".join(s) + "\n")
+        fastas.append(str(path))
+    env = dict(os.environ, MXG_TEST_FASTAS=":".join(fastas), MXG_TEST_W="60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "tests", "_dist_split_worker.py")]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("SPLIT OK") == world, out.stdout[-3000:]
