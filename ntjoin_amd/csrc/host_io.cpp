@@ -64,7 +64,7 @@ void make_hash_tab(uint32_t k, HashTab *t)
 void make_init_tab(uint32_t k, std::vector<uint4> &out)
 {
     (void)k;  // the byte table does not depend on k: position enters through the Horner rotations on the device
-    out.assign(256, make_uint4(0, 0, 0, 0));
+    out.assign(256 + 8 * 256, make_uint4(0, 0, 0, 0));
     for (uint32_t v = 0; v < 256; ++v) {
         uint64_t f = 0, r = 0;
         for (uint32_t i = 0; i < 4; ++i) {
@@ -73,6 +73,12 @@ void make_init_tab(uint32_t k, std::vector<uint4> &out)
             r ^= srol_n(SEED[3 - c], i);
         }
         out[v] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+        // position tables (sketch.hip init_pos): byte j of a group of 8 bytes (32 bases) contributes srol^{4(7-j)} f4 to the
+        // forward hash and srol^{4j} r4 to the reverse-complement hash -- one lookup and four XORs per byte, no rotation
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint64_t fj = srol_n(f, 4 * (7 - j)), rj = srol_n(r, 4 * j);
+            out[256 + j * 256 + v] = make_uint4((uint32_t)fj, (uint32_t)(fj >> 32), (uint32_t)rj, (uint32_t)(rj >> 32));
+        }
     }
 }
 

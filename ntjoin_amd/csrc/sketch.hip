@@ -188,6 +188,63 @@ __device__ __forceinline__ void init_direct(H2 &h, const uint32_t *__restrict__ 
     }
 }
 
+// The same state from POSITION tables (make_init_tab, entries 256..): ptab[j][v] = {srol^{4(7-j)} f4[v], srol^{4j} r4[v]}, so a
+// group of 8 bytes (32 bases) is 8 lookups and 32 XORs with no rotation at all; groups are combined by rotations of 32
+// (k > 35 only) and the last t < 8 bytes use the tables j + 8 - t (forward) and j (reverse).  k = 32: one group, nothing else.
+//     F = XOR_G srol^{4(P - 8(G+1))} F_G          R = srol^{k-m} XOR_G srol^{32 G} R_G
+template <class T>
+__device__ __forceinline__ void init_pos(H2 &h, const uint32_t *__restrict__ packed, uint64_t b, uint32_t k,
+                                         const uint4 *ptab, const T *tab)
+{
+    const uint32_t P = k / 4;
+    const uint32_t *pw = packed + (b >> 4);
+    const uint32_t sh = ((uint32_t)b & 15u) * 2u;
+    uint32_t flo = 0, fhi = 0, tlo = 0, thi = 0;
+    uint32_t q = 0;
+    for (; q + 8 <= P; q += 8) {
+        const uint32_t w0 = pw[q >> 2], w1 = pw[(q >> 2) + 1], w2 = pw[(q >> 2) + 2];
+        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+        uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint4 e0 = ptab[u * 256u + ((lo >> (8 * u)) & 255u)];
+            const uint4 e1 = ptab[(4u + u) * 256u + ((hi >> (8 * u)) & 255u)];
+            acc.x ^= e0.x ^ e1.x; acc.y ^= e0.y ^ e1.y; acc.z ^= e0.z ^ e1.z; acc.w ^= e0.w ^ e1.w;
+        }
+        if (q) {
+            srol_var(flo, fhi, 32u);
+            srol_var(acc.z, acc.w, 4u * q);
+        }
+        flo ^= acc.x; fhi ^= acc.y; tlo ^= acc.z; thi ^= acc.w;
+    }
+    const uint32_t t = P - q;  // bytes after the last full group
+    if (t) {
+        const uint32_t w0 = pw[q >> 2], w1 = pw[(q >> 2) + 1], w2 = pw[(q >> 2) + 2];
+        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+        uint32_t ax = 0, ay = 0, az = 0, aw = 0;
+        for (uint32_t j = 0; j < t; ++j) {
+            const uint32_t v = ((j < 4 ? lo : hi) >> (8u * (j & 3u))) & 255u;
+            const uint4 ef = ptab[(j + 8u - t) * 256u + v], er = ptab[j * 256u + v];
+            ax ^= ef.x; ay ^= ef.y; az ^= er.z; aw ^= er.w;
+        }
+        if (q) {
+            srol_var(flo, fhi, 4u * t);
+            srol_var(az, aw, 4u * q);
+        }
+        flo ^= ax; fhi ^= ay; tlo ^= az; thi ^= aw;
+    }
+    const uint32_t rem = k - 4 * P;
+    if (rem) srol_var(tlo, thi, rem);
+    h.flo = flo; h.fhi = fhi; h.rlo = tlo; h.rhi = thi;
+    if (rem) {
+        uint32_t chunk = fetch16(packed, b + 4u * P);
+        for (uint32_t u = 0; u < rem; ++u) {
+            nt_step(h, tab[16 + (chunk & 3u)]);
+            chunk >>= 2;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // dense hash kernel
 // ------------------------------------------------------------------------------------------------------
@@ -560,6 +617,86 @@ __global__ __launch_bounds__(RBT) void k_reorder(const ReorderParams p)
     place(i1 < cnt ? a1 : make_uint2(0u, 0u));
     for (uint32_t i = threadIdx.x + 2u * RBT; i < cnt; i += RBT) place(src[i]);
     __syncthreads();
+    }
+}
+
+// The same step with one WAVE per slice and position tables (init_pos): a block of RW_WAVES waves loads the 32 KB of tables
+// once and its waves walk slices on their own -- no block barrier inside the loop, so the waves of a CU drift apart and
+// cover one another's memory round trips.  Lane = strip while the slice is set up (its prefix and its run stay in that
+// lane's registers; the candidates fetch them by lane shuffles), lane = candidate while hashing.  VALU per candidate falls
+// from ~300 (Horner: two split rotations by 4 per byte) to ~100.
+constexpr uint32_t RW_WAVES = 8;
+template <int VARIANT>
+__global__ __launch_bounds__(RW_WAVES * 64) void k_reorder_w(const ReorderParams p)
+{
+    extern __shared__ uint4 rw_lds[];  // [2048] position tables | RW_WAVES queues of queue_cap words
+    __shared__ uint4 tab[20];
+    uint4 *ptab = rw_lds;
+    for (uint32_t i = threadIdx.x; i < 2048u; i += RW_WAVES * 64u) ptab[i] = p.init_tab[256u + i];
+    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    uint32_t *queue = reinterpret_cast<uint32_t *>(rw_lds + 2048) + wib * p.queue_cap;
+    for (uint32_t wv = blockIdx.x * RW_WAVES + wib; wv < p.n_waves; wv += gridDim.x * RW_WAVES) {
+        const uint2 *src = p.arena + (size_t)wv * p.wave_cap;
+        // everything that can be asked for at once is: three entries per lane (a slice holds ~180) before the count is known
+        uint2 a0 = make_uint2(0u, 0u), a1 = a0, a2 = a0;
+        if (lane < p.wave_cap) a0 = src[lane];
+        if (lane + 64u < p.wave_cap) a1 = src[lane + 64u];
+        if (lane + 128u < p.wave_cap) a2 = src[lane + 128u];
+        const uint32_t cnt = min(p.wave_cnt[wv], p.wave_cap);
+        const uint32_t s = wv * 64u + lane;
+        const bool in = s < p.n_strips;
+        const uint32_t c = in ? p.strip_cnt[s] : 0u;
+        uint32_t m_c = 0, m_k = 0, m_blo = 0, m_bhi = 0;  // the strip's contig, first k-mer index, base offset
+        if (in) {
+            const uint32_t ri = p.strip_meta[s];
+            const Run run = p.runs[ri];
+            const uint32_t j0 = (p.strip_lo + s - p.run_strip0[ri]) * p.S;
+            const uint64_t b = run.base_off + j0;
+            m_c = run.contig; m_k = run.kidx0 + j0; m_blo = (uint32_t)b; m_bhi = (uint32_t)(b >> 32);
+        }
+        const uint32_t before = count_prefix(p.wave_tot, p.wave_sup, wv);
+        const uint32_t incl = wave_inclusive_u32(c, lane);
+        const uint32_t pref = before + incl - c;
+        const uint32_t base = before, tot = (uint32_t)__shfl((int)incl, 63, 64);
+        if (wv + 1 == p.n_waves && lane == 63u) {
+            p.n_cand[0] = before + incl;
+            p.n_cand[1] = 0;
+        }
+        const uint32_t qn = min(tot, p.queue_cap);
+        for (uint32_t e0 = 0; e0 < cnt; e0 += 64u) {
+            const uint32_t i = e0 + lane;
+            uint2 a = e0 == 0 ? a0 : (e0 == 64u ? a1 : (e0 == 128u ? a2 : (i < cnt ? src[i] : make_uint2(0u, 0u))));
+            if (i >= cnt) a = make_uint2(0u, 0u);
+            uint32_t bits = a.y & 0xFFFFu;
+            const uint32_t item0 = (a.x & 63u) | (((a.y >> 16) & 63u) << 6);
+            uint32_t at = (uint32_t)__shfl((int)pref, (int)(a.x & 63u), 64) - base + (a.y >> 22);
+            for (; bits; ++at) {  // most significant bit = first k-mer of the block
+                const uint32_t u = (uint32_t)__clz((int)bits) - 16u;
+                bits &= ~(0x8000u >> u);
+                if (at < qn) queue[at] = item0 + (u << 12);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave complete in order)
+        for (uint32_t q0 = 0; q0 < qn; q0 += 64u) {
+            const uint32_t q = q0 + lane;
+            const bool act = q < qn;
+            const uint32_t item = act ? queue[q] : 0u;
+            const int sl = (int)(item & 63u);
+            const uint32_t sc = (uint32_t)__shfl((int)m_c, sl, 64), sk = (uint32_t)__shfl((int)m_k, sl, 64);
+            const uint32_t sblo = (uint32_t)__shfl((int)m_blo, sl, 64), sbhi = (uint32_t)__shfl((int)m_bhi, sl, 64);
+            const uint32_t dst = base + q;
+            if (act && dst < p.n_cap) {  // beyond n_cap only when a wave overflowed: the host redoes the batch
+                const uint32_t ju = ((item >> 6) & 63u) * 16u + ((item >> 12) & 15u);
+                H2 h;
+                init_pos(h, p.packed, (((uint64_t)sbhi << 32) | sblo) + ju, p.k, ptab, tab);
+                p.ch[dst] = canonical<VARIANT>(h);
+                p.ck[dst] = sk + ju;
+                p.cc[dst] = sc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the next slice reuses the queue
     }
 }
 
@@ -1932,7 +2069,16 @@ struct Driver {
         // slices per block (MXG_REORDER_G): the block's byte table is loaded once for all of them
         const uint32_t r_g = (uint32_t)std::max<uint64_t>(1, env_u64("MXG_REORDER_G", 1));
         const uint32_t r_grid = (g.n_waves + r_g - 1) / r_g;
-        if (h->cfg.variant == MXG_VARIANT_V1_MIN)
+        // one wave per slice + position tables when the queues of a block fit beside the 32 KB of tables
+        const size_t w_lds = (size_t)2048 * 16 + (size_t)RW_WAVES * op.queue_cap * 4;
+        const bool r_wave = op.queue_cap && w_lds + 512 <= 65536 && env_u64("MXG_REORDER_W", 1) != 0;
+        const uint32_t w_grid = std::min<uint32_t>((g.n_waves + RW_WAVES - 1) / RW_WAVES,
+                                                   (uint32_t)env_u64("MXG_REORDER_W_GRID", 256 * 3));
+        if (r_wave && h->cfg.variant == MXG_VARIANT_V1_MIN)
+            hipLaunchKernelGGL(k_reorder_w<MXG_VARIANT_V1_MIN>, dim3(w_grid), dim3(RW_WAVES * 64), w_lds, st, op);
+        else if (r_wave && !getenv("MXG_ABLATE_REORDER"))
+            hipLaunchKernelGGL(k_reorder_w<MXG_VARIANT_V2_SUM>, dim3(w_grid), dim3(RW_WAVES * 64), w_lds, st, op);
+        else if (h->cfg.variant == MXG_VARIANT_V1_MIN)
             hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V1_MIN>, dim3(r_grid), dim3(RB), q_lds, st, op);
         else
         {

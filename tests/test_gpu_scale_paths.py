@@ -179,3 +179,23 @@ def test_two_assemblies_many_batches_and_graph(oracle, dev_knobs):
         want = oracle.sketch(seq, 32, 150)
         lo, hi = int(first[r]), int(first[r + 1])
         assert results[0][0][0]["out_hash"][lo:hi].tolist() == [x[0] for x in want]
+
+
+@pytest.mark.parametrize("variant", ["v2", "v1"])
+def test_exact_hash_from_position_tables_every_group_shape(oracle, variant):
+    """k_reorder_w takes the exact hash of a candidate from position tables: groups of 8 packed bytes (32 bases) with no
+    rotation, combined by rotations of 32 for k > 35, a partial last group, and k % 4 ordinary steps -- every shape of
+    (full groups, leftover bytes, leftover bases), and the old block-per-slice kernel (MXG_REORDER_W=0) on the same input"""
+    recs = _records(11)[:12]
+    saved = os.environ.get("MXG_REORDER_W")
+    try:
+        for k in (3, 4, 7, 8, 29, 31, 32, 33, 35, 36, 39, 40, 61, 63, 64, 65, 67, 68, 96, 99, 100, 131, 200):
+            for rw in ("1", "0") if k in (32, 47, 100) or k % 32 == 3 else ("1",):
+                os.environ["MXG_REORDER_W"] = rw
+                st = _check(oracle, recs, k, 100, variant=variant, cand_per_window=6)
+                assert st["candidates"] > 0 or k < 8, k
+    finally:
+        if saved is None:
+            os.environ.pop("MXG_REORDER_W", None)
+        else:
+            os.environ["MXG_REORDER_W"] = saved
