@@ -25,9 +25,10 @@
 //                  table, and "is (fwd+rev) below tau" decided from the rings up to the unknown carry out of the low
 //                  33 bits (a superset, exact for the min(fwd,rev) variant).  Captured k-mer indices go to the wave's
 //                  own arena slice (8 B entries, no atomics).
-//   k_reorder      arena entry -> full 64-bit hash of that k-mer (table-driven direct formula) -> its ordered slot
-//                  (exclusive scan of per-strip counts + rank inside the strip); entries whose exact hash turns out
-//                  >= tau stay in the list and are skipped by k_resolve
+//   k_reorder_w    arena entry -> full 64-bit hash of that k-mer (position tables: one lookup per packed byte, no
+//                  rotation) -> its ordered slot (exclusive scan of per-strip counts + rank inside the strip), one wave
+//                  per arena slice; entries whose exact hash turns out >= tau stay in the list and are skipped by
+//                  k_resolve.  (k_reorder: the block-per-slice Horner version, kept for slices too large for the queues)
 //   k_hash_dense   every k-mer is a candidate, written at its own index (DENSE_ONLY mode and gap fix-up)
 //   k_resolve      one lane per candidate: nearest smaller / smaller-or-equal neighbour scan; gap detection
 //   k_emit         ordered stream compaction into the sketch arrays (offsets from k_resolve's two-level counts; the
@@ -314,6 +315,8 @@ struct SparseParams {
     uint32_t strip_lo, strip_hi;
     uint32_t k;
     uint32_t S;           // k-mers per strip (multiple of 16, <= 1024)
+    uint32_t n_tiles;     // tiles of 256 strips; the (persistent) blocks of the grid share them
+    uint32_t five;        // k = 32: the five-block loop (one word fetched per block); 0 = the general loop (MXG_HASH_FIVE=0)
     uint32_t tau_hi;      // candidate iff high word of min_hash < tau_hi (EVEN: tau_hi = 2T, T on the top 31 bits)
     uint2 *arena;         // wave w owns entries [w*wave_cap, (w+1)*wave_cap): {strip (rel.), j | seq<<10}
     uint32_t wave_cap;
@@ -391,7 +394,14 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     __syncthreads();
     const uint32_t S = p.S;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t srel = blockIdx.x * 256u + threadIdx.x;        // strip index relative to strip_lo
+    __shared__ uint32_t wtot[4];
+    // Block g works on the 256-strip tiles g, g + gridDim.x, ...; by default the grid has one block per tile.  (MXG_HASH_BPC=n
+    // launches n blocks per CU that share the tiles: a residency cap by grid size instead of by unused LDS.  Measured at
+    // 3 Gbp: 1231 Gbp/s against 1304 -- with the CU's LDS free, the other stream's kernels move in beside the hash kernel
+    // and both run slower than one after the other.)
+#pragma unroll 1
+    for (uint32_t vb = blockIdx.x; vb < p.n_tiles; vb += gridDim.x) {
+    const uint32_t srel = vb * 256u + threadIdx.x;        // strip index relative to strip_lo
     const uint32_t s = p.strip_lo + srel;
     uint32_t len = 0;                                            // 0 for lanes beyond the batch: they stay alive
     uint64_t b = 0;                                              // (wave-wide steps) and never capture anything
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     }
     const uint32_t k = p.k;
     const uint32_t thr = 0u - p.tau_hi - (VARIANT == MXG_VARIANT_V1_MIN ? 0u : 2u);
-    const uint32_t wave_id = blockIdx.x * 4u + wv;
+    const uint32_t wave_id = vb * 4u + wv;
     uint2 *const region = p.arena + (size_t)wave_id * p.wave_cap;  // this wave's private slice of the arena
     const uint32_t wave_cap = p.wave_cap;
     uint32_t cnt_w = 0;  // wave-uniform: entries this wave has written
@@ -425,21 +435,21 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     const unsigned char *ringb = reinterpret_cast<const unsigned char *>(ring);
     const uint32_t *po = p.packed + (b >> 4), *pi = p.packed + ((b + k) >> 4);
     const uint32_t so = ((uint32_t)b & 15u) * 2u, si = ((uint32_t)(b + k) & 15u) * 2u;
-    uint32_t o0 = po[0], o1 = po[1], i0 = pi[0], i1 = pi[1];
     const uint32_t nblk = S / 16;
-#pragma unroll 1
-    for (uint32_t blk = 0; blk < nblk; ++blk) {
-        const uint32_t o2 = po[blk + 2], i2 = pi[blk + 2];       // next block's words; reads stay inside the padding
-        const uint32_t cout = __builtin_amdgcn_alignbit(o1, o0, so);
-        const uint32_t cin = __builtin_amdgcn_alignbit(i1, i0, si);
-        o0 = o1; o1 = o2; i0 = i1; i1 = i2;
+    // blocks that are complete in every lane of the wave (all of them but in the last wave of a run): no length mask
+    uint32_t nfast = len / 16u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nfast = min(nfast, (uint32_t)__shfl_xor((int)nfast, o, 64));
+    nfast = (uint32_t)__builtin_amdgcn_readfirstlane((int)nfast);
+    uint32_t bits = 0;  // bit 15-u: k-mer 16*blk+u passed the ring test (never reset: the block's mask drops what is older)
+    // the 16 steps of a block: cout / cin = the 16 outgoing / incoming bases
+    auto steps16 = [&](const uint32_t cout, const uint32_t cin) {
         constexpr uint32_t M = 0x33333333u, B = 0x78787878u;
         const uint32_t ze = ((cout & M) << 2) | (cin & M);        // nibble v = (out, in) of step 2v
         const uint32_t zo = (cout & ~M) | ((cin >> 2) & M);       // nibble v = (out, in) of step 2v+1
         // one BYTE per step, already scaled to the entry's byte offset: a step then needs a single byte-select move
         // (v_mov_b32_sdwa, full rate) instead of a shift (half rate) and a mask.  q[2*(u&1) + ((u>>1)&1)] byte u>>2.
         const uint32_t q[4] = {(ze << 3) & B, (ze >> 1) & B, (zo << 3) & B, (zo >> 1) & B};
-        uint32_t bits = 0;                                       // bit 15-u: k-mer 16*blk+u passed the ring test
 #pragma unroll
         for (uint32_t u = 0; u < 16; ++u) {
             // k-mer j = 16*blk + u is in (x, y): test, then roll to j+1 (the last roll of a strip is never looked at)
@@ -452,21 +462,68 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
             const uint32_t off = byte_of(q[2u * (u & 1u) + ((u >> 1) & 1u)], u >> 2);
             ring_step(x, x2, y, *reinterpret_cast<const uint2 *>(ringb + off));
         }
-        if (ABL == 1) { abl_acc ^= x + y; continue; }
-        if (ABL == 2) { abl_acc += bits; continue; }
+    };
+    // what a block caught: one arena entry per lane with a candidate
+    auto store_entry = [&](const uint32_t blk, const uint32_t mine) {
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(mine != 0u);
+        if (mask) {  // wave-uniform; almost always taken (64 lanes x 16 k-mers at ~1 %)
+            if (mine) {
+                const uint32_t slot = cnt_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (slot < wave_cap) region[slot] = make_uint2(srel, mine | (blk << 16) | (seq << 22));
+                seq += (uint32_t)__popc(mine);
+            }
+            cnt_w += (uint32_t)__popcll(mask);
+        }
+    };
+    auto capture_full = [&](const uint32_t blk) {
+        if (ABL == 1) { abl_acc ^= x + y; return; }
+        if (ABL == 2) { abl_acc += bits; return; }
+        store_entry(blk, bits & 0xFFFFu);
+    };
+    auto capture = [&](const uint32_t blk) {
+        if (ABL == 1) { abl_acc ^= x + y; return; }
+        if (ABL == 2) { abl_acc += bits; return; }
         // k-mers at or beyond the strip's length (end of a run, lanes beyond the batch) do not count
         const uint32_t j0 = 16u * blk;
         const uint32_t nvalid = len > j0 ? min(len - j0, 16u) : 0u;
-        bits &= 0xFFFFu & ~(0xFFFFu >> nvalid);
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(bits != 0u);
-        if (mask) {  // wave-uniform; almost always taken (64 lanes x 16 k-mers at ~1.8 %)
-            if (bits) {
-                const uint32_t slot = cnt_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (slot < wave_cap) region[slot] = make_uint2(srel, bits | (blk << 16) | (seq << 22));
-                seq += (uint32_t)__popc(bits);
-            }
-            cnt_w += (uint32_t)__popcll(mask);
+        store_entry(blk, bits & 0xFFFFu & ~(0xFFFFu >> nvalid));
+    };
+    uint32_t blk = 0;
+    if (k == 32u && p.five) {
+        // k = 32: the incoming bases are the outgoing bases two words later, so ONE word per block is fetched (one block
+        // ahead) and five blocks are written out so that the five-word window needs no register moves
+        uint32_t w0 = po[0], w1 = po[1], w2 = po[2], w3 = po[3], w4;
+        const uint32_t *pw = po;  // (one pointer, constant offsets: one 64-bit add per five blocks)
+#pragma unroll 1
+        for (; blk + 5u <= nfast; blk += 5u, pw += 5) {
+            w4 = pw[4];
+            steps16(__builtin_amdgcn_alignbit(w1, w0, so), __builtin_amdgcn_alignbit(w3, w2, so));
+            capture_full(blk);
+            w0 = pw[5];
+            steps16(__builtin_amdgcn_alignbit(w2, w1, so), __builtin_amdgcn_alignbit(w4, w3, so));
+            capture_full(blk + 1u);
+            w1 = pw[6];
+            steps16(__builtin_amdgcn_alignbit(w3, w2, so), __builtin_amdgcn_alignbit(w0, w4, so));
+            capture_full(blk + 2u);
+            w2 = pw[7];
+            steps16(__builtin_amdgcn_alignbit(w4, w3, so), __builtin_amdgcn_alignbit(w1, w0, so));
+            capture_full(blk + 3u);
+            w3 = pw[8];
+            steps16(__builtin_amdgcn_alignbit(w0, w4, so), __builtin_amdgcn_alignbit(w2, w1, so));
+            capture_full(blk + 4u);
+        }
+    }
+    if (blk < nblk) {  // any k; the blocks the five-block loop left over
+        uint32_t o0 = po[blk], o1 = po[blk + 1], i0 = pi[blk], i1 = pi[blk + 1];
+#pragma unroll 1
+        for (; blk < nblk; ++blk) {
+            const uint32_t o2 = po[blk + 2], i2 = pi[blk + 2];       // next block's words; reads stay inside the padding
+            const uint32_t cout = __builtin_amdgcn_alignbit(o1, o0, so);
+            const uint32_t cin = __builtin_amdgcn_alignbit(i1, i0, si);
+            o0 = o1; o1 = o2; i0 = i1; i1 = i2;
+            steps16(cout, cin);
+            capture(blk);
         }
     }
     if (ABL != 0) {
@@ -476,7 +533,6 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     if (s < p.strip_hi) p.strip_cnt[srel] = seq;
     // candidates of the whole wave (the ordered arrays hold wave_cap per wave)
     const uint32_t tot = wave_sum_u32(seq);
-    __shared__ uint32_t wtot[4];
     if (lane == 0) {
         p.wave_cnt[wave_id] = cnt_w;
         p.wave_tot[wave_id] = tot;  // k_reorder derives every wave's first ordered slot from these and the super-counts
@@ -487,6 +543,8 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     if (threadIdx.x == 0) {  // one add per block: its four waves share a super-count (256 waves = 64 blocks)
         const uint32_t c = wtot[0] + wtot[1] + wtot[2] + wtot[3];
         if (c) atomicAdd(&p.wave_sup[(wave_id >> SUP_SHIFT) * SUP_STRIDE], c);
+    }
+    __syncthreads();  // wtot is reused by the next tile
     }
 }
 
@@ -732,10 +790,12 @@ struct ResolveParams {
     uint32_t *cs_k, *cs_c;
 };
 
-__device__ __forceinline__ void push_gap(const ResolveParams &p, uint32_t c, uint32_t lo, uint32_t hi)
+// hint = index of the candidate that reports the stretch: the stretch lies right before or right after it, which tells
+// k_emit's placement blocks in which k_resolve block to count the minimizers that precede the stretch
+__device__ __forceinline__ void push_gap(const ResolveParams &p, uint32_t c, uint32_t lo, uint32_t hi, uint32_t hint)
 {
     uint32_t idx = atomicAdd(p.gap_count, 1u);
-    if (idx < p.gap_cap) p.gaps[idx] = make_uint4(c, lo, hi, 0u);
+    if (idx < p.gap_cap) p.gaps[idx] = make_uint4(c, lo, hi, hint);
 }
 
 // One lane per candidate, wave-cooperative for long scans.  sel[i] = 1 iff candidate i is a minimizer.
@@ -950,8 +1010,8 @@ __global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
             const bool first = pcg != c;
             if (first) {
                 uint32_t pc = pcg == 0xFFFFFFFFu ? p.ctg_lo : pcg + 1;
-                for (; pc < c; ++pc) push_gap(p, pc, 0, p.ctg_nk[pc] - 1);  // contigs without any candidate
-                if (kx >= w) push_gap(p, c, 0, kx - 1);
+                for (; pc < c; ++pc) push_gap(p, pc, 0, p.ctg_nk[pc] - 1, i);  // contigs without any candidate
+                if (kx >= w) push_gap(p, c, 0, kx - 1, i);
             }
             uint32_t ncg = lkc[li + 1].y, nx = lkc[li + 1].x;
             if (lh[li + 1] >= tau) {
@@ -962,17 +1022,17 @@ __global__ __launch_bounds__(RK) void k_resolve(const ResolveParams p)
             }
             const bool last = ncg != c;
             if (!last) {
-                if (nx - kx - 1 >= w) push_gap(p, c, kx + 1, nx - 1);
+                if (nx - kx - 1 >= w) push_gap(p, c, kx + 1, nx - 1, i);
             } else {
-                if (nk - 1 - kx >= w) push_gap(p, c, kx + 1, nk - 1);
+                if (nk - 1 - kx >= w) push_gap(p, c, kx + 1, nk - 1, i);
                 if (ncg == 0xFFFFFFFFu)
-                    for (uint32_t nc = c + 1; nc < p.ctg_hi; ++nc) push_gap(p, nc, 0, p.ctg_nk[nc] - 1);
+                    for (uint32_t nc = c + 1; nc < p.ctg_hi; ++nc) push_gap(p, nc, 0, p.ctg_nk[nc] - 1, i);
             }
         } else if (i == 0) {  // nobody else speaks for a batch whose every entry is absent
             uint32_t jn = 1;
             while (jn < n && p.ch[jn] >= tau) ++jn;
             if (jn >= n)
-                for (uint32_t pc = p.ctg_lo; pc < p.ctg_hi; ++pc) push_gap(p, pc, 0, p.ctg_nk[pc] - 1);
+                for (uint32_t pc = p.ctg_lo; pc < p.ctg_hi; ++pc) push_gap(p, pc, 0, p.ctg_nk[pc] - 1, i);
         }
     }
     if (COUNT) {
@@ -1023,6 +1083,8 @@ __global__ __launch_bounds__(256) void k_count_n(const uint8_t *__restrict__ sel
     if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
 }
 
+constexpr uint32_t GAP_DEV_MAX = 2048;  // stretches per batch the device route holds (defined here: k_emit places them)
+constexpr uint32_t GAP_DEV_REG = 64;    // minimizers per stretch
 struct EmitParams {
     const uint8_t *sel;
     const uint64_t *ch;
@@ -1048,26 +1110,68 @@ struct EmitParams {
     // before it, which is still on the device (null: 0); the tile holding the last candidate passes the sum on
     const uint64_t *base_in;
     uint64_t *base_out;
-    // device-side fix-up of candidate-free stretches (k_gap_fix ... k_merge_fin): when the batch has such stretches the
-    // minimizers go to staging arrays (from index 0) and k_merge_fin merges the stretches' minimizers in; that kernel
-    // also does the reporting, so this one only leaves the count in n_sel
+    // device-side fix-up of candidate-free stretches (k_gap_fix, k_gap_post run BEFORE this kernel): the batch's own
+    // minimizers are written to their final places at once -- minimizer t of the batch goes to base + t + (minimizers in
+    // the stretches before it; s_key / s_off of k_gap_post, searched once per tile unless a stretch falls inside it) -- and
+    // GAP_DEV_MAX / 4 extra blocks at the end of the grid, one wave per stretch, put the stretches' minimizers between them:
+    // stretch r goes to base + (own minimizers before it) + s_off[r].  No staging copy, no merge pass.
     uint32_t dev_gaps;
-    uint64_t *s_hash;
-    uint32_t *s_pos, *s_rec;
-    uint64_t s_limit;
+    uint32_t n_tiles;      // tiles of the candidate array = blocks that emit; blocks beyond them place stretches (dev_gaps)
+    const uint64_t *s_key; const uint32_t *s_off, *s_src;
+    const uint4 *gaps;
+    const uint64_t *r_hash; const uint32_t *r_pos, *r_rec, *r_cnt;
     // the selected candidates laid out per k_resolve block (ResolveParams::cs_*): replaces sel / ch / ck / cc
     const uint64_t *cs_h;
     const uint32_t *cs_k, *cs_c;
 };
 
+// number of keys < key in the sorted array keys[0..n)
+__device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *__restrict__ keys, uint32_t n, uint64_t key)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
 {
     __shared__ uint32_t sh[256];
     const uint32_t n = min(*p.n_ptr, p.n_cap);
+    const uint32_t n_g_raw = p.ovf[1];
     if (*p.ovf || n == 0) {  // arena overflow (the host redoes the batch) or no candidate at all: only report
-        if (!p.dev_gaps && p.host_ctrl && blockIdx.x == 0 && threadIdx.x < 16)
-            p.host_ctrl[threadIdx.x] = threadIdx.x == 0 ? *p.ovf : (threadIdx.x == 1 ? p.ovf[1] : 0u);
-        if (!p.dev_gaps && p.base_out && blockIdx.x == 0 && threadIdx.x == 0) *p.base_out = p.base_in ? *p.base_in : 0ull;
+        if (p.host_ctrl && blockIdx.x == 0 && threadIdx.x < 16)
+            p.host_ctrl[threadIdx.x] = threadIdx.x == 0 ? *p.ovf : (threadIdx.x == 1 ? n_g_raw : 0u);
+        if (p.base_out && blockIdx.x == 0 && threadIdx.x == 0) *p.base_out = p.base_in ? *p.base_in : 0ull;
+        return;
+    }
+    // stretches sketched on the device: count, their minimizers, "could not be finished here" (the host then redoes the batch)
+    const uint32_t flag = p.dev_gaps ? p.ovf[6] : 0u;
+    const uint32_t n_g = p.dev_gaps && !flag && n_g_raw <= GAP_DEV_MAX ? n_g_raw : 0u;
+    const uint32_t nB = n_g ? p.ovf[7] : 0u;
+    const uint64_t obase = p.out_base + (p.base_in ? *p.base_in : 0ull), limit = p.out_limit;
+    if (p.dev_gaps && blockIdx.x >= p.n_tiles) {  // placement of the stretches' minimizers: one wave per stretch
+        const uint32_t r = (blockIdx.x - p.n_tiles) * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+        if (r >= n_g) return;
+        const uint32_t g = p.s_src[r];
+        const uint64_t key = p.s_key[r];
+        const uint32_t nblk = (n + RK - 1u) / RK;
+        const uint32_t b = min(p.gaps[g].w / RK, nblk - 1u);  // the block of the candidate that reported the stretch
+        const uint32_t cb = p.cnt256[b];
+        uint32_t below = 0;  // minimizers of block b in front of the stretch
+        for (uint32_t e = lane; e < cb; e += 64u) {
+            const uint32_t src = b * RK + e;
+            below += ((((uint64_t)p.cs_c[src] << 32) | p.cs_k[src]) < key) ? 1u : 0u;
+        }
+        const uint64_t o0 = obase + count_prefix(p.cnt256, p.sel_sup, b) + wave_sum_u32(below) + p.s_off[r];
+        if (lane < p.r_cnt[g] && o0 + lane < limit) {
+            const size_t at = (size_t)g * GAP_DEV_REG + lane;
+            p.o_hash[o0 + lane] = p.r_hash[at];
+            p.o_pos[o0 + lane] = p.r_pos[at];
+            p.o_rec[o0 + lane] = p.r_rec[at];
+        }
         return;
     }
     if (blockIdx.x * TILE >= n) return;  // whole tile beyond the candidates
@@ -1075,14 +1179,6 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     const uint32_t fl = p.cs_h ? 0u : load_flags4(p.sel, base, n);
     uint32_t c = count_flags4(fl);
     uint32_t before;
-    uint64_t obase = p.out_base + (p.base_in ? *p.base_in : 0ull), limit = p.out_limit;
-    uint64_t *o_hash = p.o_hash;
-    uint32_t *o_pos = p.o_pos, *o_rec = p.o_rec;
-    if (p.dev_gaps && p.ovf[1] != 0u) {  // stretches: to staging, merged by k_merge_fin
-        o_hash = p.s_hash; o_pos = p.s_pos; o_rec = p.s_rec;
-        obase = 0;
-        limit = p.s_limit;
-    }
     if (p.bsum) {
         before = p.bsum[blockIdx.x];
     } else {
@@ -1090,20 +1186,21 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
         if (threadIdx.x < 64) {
             const uint32_t bef = count_prefix(p.cnt256, p.sel_sup, blockIdx.x * (TILE / RK));
             if (threadIdx.x == 0) sh_before = bef;
-            if ((n - 1) / TILE == blockIdx.x) {  // the tile holding the last candidate also reports the total
+            if ((n - 1) / TILE == blockIdx.x) {  // the tile holding the last candidate also reports the totals
                 const uint32_t all = count_prefix(p.cnt256, p.sel_sup, (n + RK - 1u) / RK);
+                const uint64_t total = (uint64_t)all + nB;
                 if (threadIdx.x == 0) {
                     p.n_sel[0] = all;
                     p.n_sel[1] = 0;
-                    if (!p.dev_gaps) {
-                        if (p.n_out) *p.n_out = (uint32_t)(obase + all);
-                        if (p.base_out) *p.base_out = obase + all;
-                    }
+                    if (p.n_out) *p.n_out = (uint32_t)(obase + total);
+                    if (p.base_out) *p.base_out = obase + total;
                 }
-                if (!p.dev_gaps && p.host_ctrl && threadIdx.x < 16) {  // layout: see HostCtrl
+                if (p.host_ctrl && threadIdx.x < 16) {  // layout: see HostCtrl
                     const uint32_t w = threadIdx.x;
-                    p.host_ctrl[w] = w == 1 ? p.ovf[1] : (w == 2 || w == 6) ? all : w == 4 ? *p.n_ptr
-                                   : w == 8 ? (uint32_t)obase : w == 9 ? (uint32_t)(obase >> 32) : 0u;
+                    p.host_ctrl[w] = w == 1 ? n_g_raw : w == 2 ? all : w == 3 ? flag : w == 4 ? *p.n_ptr : w == 5 ? nB
+                                   : w == 6 ? (uint32_t)total : w == 7 ? (uint32_t)(total >> 32)
+                                   : w == 8 ? (uint32_t)obase : w == 9 ? (uint32_t)(obase >> 32)
+                                   : (w == 10 && p.dev_gaps) ? p.ovf[10] : 0u;
                 }
             }
         }
@@ -1132,12 +1229,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
             if ((fl >> (8 * u)) & 1u) picked[l++] = (uint16_t)(threadIdx.x * TILE_PER_THREAD + u);
         __syncthreads();
     }
-    const uint64_t o0 = obase + before;
-    for (uint32_t r = threadIdx.x; r < tile_total; r += 256u) {
-        const uint64_t o = o0 + r;
-        if (o >= limit) continue;  // (speculative emit into arrays sized by an estimate)
-        uint32_t ctg, kx;
-        uint64_t hsh;
+    auto item = [&](uint32_t r, uint64_t &hsh, uint32_t &kx, uint32_t &ctg) {  // minimizer r of the tile
         if (p.cs_h) {
             static_assert(TILE / RK == 4, "the selects below spell out four blocks per tile");
             const uint32_t u = r >= pre[3] ? 3u : r >= pre[2] ? 2u : r >= pre[1] ? 1u : 0u;
@@ -1152,15 +1244,37 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
             kx = p.ck[i];
             ctg = p.cc[i] & 0x7FFFFFFFu;
         }
+    };
+    // A few hundred stretches among a million minimizers: almost every tile lies between two neighbouring stretches, so the
+    // tile's first and last key are searched once and only a tile that straddles a stretch searches per minimizer.
+    __shared__ uint32_t lb_edge[2];
+    if (n_g && tile_total && (threadIdx.x == 0 || threadIdx.x == 64)) {
+        uint64_t hsh; uint32_t kx, ctg;
+        item(threadIdx.x ? tile_total - 1u : 0u, hsh, kx, ctg);
+        lb_edge[threadIdx.x ? 1 : 0] = lower_bound_u64(p.s_key, n_g, ((uint64_t)ctg << 32) | kx);
+    }
+    if (n_g) __syncthreads();
+    const uint64_t o0 = obase + before;
+    for (uint32_t r = threadIdx.x; r < tile_total; r += 256u) {
+        uint32_t ctg, kx;
+        uint64_t hsh;
+        item(r, hsh, kx, ctg);
+        uint64_t o = o0 + r;
+        if (n_g) {
+            uint32_t lb = lb_edge[0];
+            if (lb_edge[1] != lb) lb = lower_bound_u64(p.s_key, n_g, ((uint64_t)ctg << 32) | kx);
+            o += p.s_off[lb];  // (s_off[n_g] = all of them)
+        }
+        if (o >= limit) continue;  // (speculative emit into arrays sized by an estimate)
         // contig-local valid-k-mer index -> base position, through the contig's run table
         uint32_t lo = p.ctg_run0[ctg], hi = p.ctg_run0[ctg + 1];
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if (p.runs[mid].kidx0 <= kx) lo = mid; else hi = mid;
         }
-        o_hash[o] = ext_hash(hsh, p.mult);  // (the strand byte is filled lazily by k_strand, only when somebody asks for it)
-        o_pos[o] = p.runs[lo].pos0 + (kx - p.runs[lo].kidx0);
-        o_rec[o] = p.ctg_rec[ctg];
+        p.o_hash[o] = ext_hash(hsh, p.mult);  // (the strand byte is filled lazily by k_strand, only when somebody asks for it)
+        p.o_pos[o] = p.runs[lo].pos0 + (kx - p.runs[lo].kidx0);
+        p.o_rec[o] = p.ctg_rec[ctg];
     }
 }
 
@@ -1224,17 +1338,16 @@ __global__ __launch_bounds__(256) void k_merge(const MergeParams p)
 // candidates per window, hundreds at 12), so here they are sketched by one block each without leaving the stream:
 //   k_gap_fix    block = stretch: exact hashes of its k-mers into LDS, rightmost arg-min of every window through a sparse
 //                table (log2 w doubling passes), distinct arg-mins compacted in order into the stretch's region
-//   k_gap_post   one block: ranks the stretches by (contig, first k-mer), lays their minimizers end to end
-//   k_merge_fin  merges them into the batch's own minimizers (which k_emit then left in staging) and reports the batch
+//   k_gap_post   one block: ranks the stretches by (contig, first k-mer); sorted keys + minimizers before each stretch
+//   k_emit       (runs after them) writes the batch's own minimizers straight to their final places, shifted by the
+//                stretch minimizers before each; a few extra blocks put the stretches' minimizers in between; reports
 // Anything this route cannot hold -- more than GAP_DEV_MAX stretches, a stretch longer than GAP_DEV_NMAX k-mers or cut by
 // invalid bases, more than GAP_DEV_REG minimizers in one stretch (low-complexity sequence) -- raises ctrl[6] and the host
 // redoes the batch the general way.
-constexpr uint32_t GAP_DEV_MAX = 2048;
-constexpr uint32_t GAP_DEV_REG = 64;
 constexpr uint32_t GAP_DEV_NMAX = 4096;
 
 struct GapFixParams {
-    const uint4 *gaps;   // {contig, k_lo, k_hi, 0} in arrival order (k_resolve)
+    const uint4 *gaps;   // {contig, k_lo, k_hi, reporting candidate} in arrival order (k_resolve)
     uint32_t *ctrl;      // [1] stretches, [6] "host must redo", [10] k-mers hashed here
     const Run *runs;
     const uint32_t *ctg_run0, *ctg_rec;
@@ -1250,22 +1363,31 @@ struct GapFixParams {
     HashTab tab;
 };
 
-template <int VARIANT>
+// Two launches share the work by stretch length.  Blocks with 56 KB of LDS do not fit beside the other stream's hash kernel
+// (which fills the CUs to its own LDS cap): 2048 of them, nearly all with nothing to do, waited 100-160 us for places.  So
+// the common stretches (<= GAP_DEV_NSMALL k-mers: 99.5 %) get one 20 KB block each (NMAX = GAP_DEV_NSMALL, grid =
+// GAP_DEV_MAX), which fits into what the hash kernel leaves free, and the long ones are walked by a few large blocks
+// (NMAX = GAP_DEV_NMAX, BIG, grid = GAP_DEV_BIG_BLOCKS).
+constexpr uint32_t GAP_DEV_NSMALL = 1536;
+constexpr uint32_t GAP_DEV_BIG_BLOCKS = 4;
+template <int VARIANT, uint32_t NMAX, bool BIG>
 __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
 {
     const uint32_t n_g = p.ctrl[1];
-    const uint32_t j = blockIdx.x;
-    if (j >= n_g || n_g > GAP_DEV_MAX || p.ctrl[0]) return;
-    __shared__ uint64_t lh[GAP_DEV_NMAX];
-    __shared__ uint16_t lidx[2][GAP_DEV_NMAX];
-    __shared__ uint32_t selbits[GAP_DEV_NMAX / 32];
-    __shared__ uint4 btab[256];
+    if (blockIdx.x >= n_g || n_g > GAP_DEV_MAX || p.ctrl[0]) return;
+    __shared__ uint64_t lh[NMAX];
+    __shared__ uint16_t lidx[2][NMAX];
+    __shared__ uint32_t selbits[NMAX / 32];
     __shared__ uint4 tab[20];
     __shared__ uint32_t sh[256];
     __shared__ uint32_t drop_idx;
-    __shared__ uint32_t lw[GAP_DEV_NMAX / 16 + 1024 / 16 + 4];  // the stretch's packed bases (+ k): every later read is local
+    __shared__ uint32_t lw[NMAX / 16 + 1024 / 16 + 4];  // the stretch's packed bases (+ k): every later read is local
+    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
+    for (uint32_t j = blockIdx.x; j < n_g; j += gridDim.x) {
+    __syncthreads();  // (the shared arrays are reused from stretch to stretch)
     const uint4 gp = p.gaps[j];
     const uint32_t c = gp.x, klo = gp.y, khi = gp.z, n = khi - klo + 1u, w = p.w, k = p.k;
+    if (BIG ? n <= GAP_DEV_NSMALL : n > GAP_DEV_NSMALL) continue;  // the other launch's
     if (threadIdx.x == 0) {
         p.r_key[j] = ((uint64_t)c << 32) | klo;
         p.r_cnt[j] = 0;
@@ -1277,13 +1399,11 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
         if (p.runs[mid].kidx0 <= klo) lo = mid; else hi = mid;
     }
     const Run run = p.runs[lo];
-    if (n > GAP_DEV_NMAX || n < w || khi >= run.kidx0 + run.n_kmers) {
+    if (n > NMAX || n < w || khi >= run.kidx0 + run.n_kmers) {
         if (threadIdx.x == 0) p.ctrl[6] = 1;
-        return;
+        continue;
     }
-    btab[threadIdx.x] = p.init_tab[threadIdx.x];
-    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
-    for (uint32_t i = threadIdx.x; i < GAP_DEV_NMAX / 32; i += 256) selbits[i] = 0;
+    for (uint32_t i = threadIdx.x; i < NMAX / 32; i += 256) selbits[i] = 0;
     if (threadIdx.x == 0) drop_idx = 0xFFFFFFFFu;
     __syncthreads();
     const uint64_t b_glob = run.base_off + (klo - run.kidx0);
@@ -1296,7 +1416,7 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
     const uint32_t per = (n + 255u) / 256u, i0 = threadIdx.x * per, i1 = min(i0 + per, n);
     if (i0 < n) {  // exact hashes: the direct formula once, then rolling
         H2 h = {0u, 0u, 0u, 0u};
-        init_direct(h, lw, b + i0, k, btab, tab);
+        warm_up(h, lw, b + i0, k, tab);  // (k rolling steps: no byte table in this kernel's LDS)
         lh[i0] = canonical<VARIANT>(h);
         for (uint32_t i = i0 + 1; i < i1; ++i) {
             const uint64_t go = b + i - 1, gi = go + k;
@@ -1342,7 +1462,7 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
     if (threadIdx.x == 0) atomicAdd(&p.ctrl[10], n);
     if (total > GAP_DEV_REG) {
         if (threadIdx.x == 0) p.ctrl[6] = 1;
-        return;
+        continue;
     }
     if (threadIdx.x == 0) p.r_cnt[j] = total;
     const uint32_t rec = p.ctg_rec[c];
@@ -1353,12 +1473,14 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
             p.r_pos[at] = run.pos0 + (klo + i - run.kidx0);
             p.r_rec[at] = rec;
         }
+    }
 }
 
 struct GapPostParams {
     uint32_t *ctrl;  // [1] stretches, [6] flag, [7] <- minimizers found in them
-    const uint64_t *r_hash; const uint32_t *r_pos, *r_rec, *r_cnt; const uint64_t *r_key;
-    uint64_t *d_hash; uint32_t *d_pos, *d_rec;  // laid end to end in (record, position) order
+    const uint32_t *r_cnt; const uint64_t *r_key;
+    // the stretches in (contig, first k-mer) order: key, minimizers in the stretches before it ([n] = all), index of its region
+    uint64_t *s_key; uint32_t *s_off, *s_src;
 };
 
 // (256 threads: a single block of 1024 had to wait for sixteen free wave slots on one CU while the other stream's hash kernel
@@ -1367,7 +1489,7 @@ constexpr uint32_t GPB = 256;
 __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
 {
     __shared__ uint64_t keys[GAP_DEV_MAX];
-    __shared__ uint32_t src[GAP_DEV_MAX], off[GAP_DEV_MAX], sh[256];
+    __shared__ uint32_t src[GAP_DEV_MAX], sh[256];
     const uint32_t n_g = p.ctrl[1];
     if (n_g == 0 || n_g > GAP_DEV_MAX || p.ctrl[0]) {
         if (threadIdx.x == 0) {
@@ -1383,6 +1505,8 @@ __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
         uint32_t r = 0;
         for (uint32_t q = 0; q < n_g; ++q) r += keys[q] < key ? 1u : 0u;
         src[r] = i;
+        p.s_key[r] = key;
+        p.s_src[r] = i;
     }
     __syncthreads();
     constexpr uint32_t PER = GAP_DEV_MAX / GPB;
@@ -1395,18 +1519,12 @@ __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
     uint32_t run = block_exclusive<GPB / 64>(tot, sh);
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t r = threadIdx.x * PER + u;
-        if (r < n_g) off[r] = run;
+        if (r < n_g) p.s_off[r] = run;
         run += c[u];
     }
-    if (threadIdx.x == 0) p.ctrl[7] = sh[255];
-    __syncthreads();
-    for (uint32_t r = threadIdx.x; r < n_g; r += GPB) {
-        const uint32_t g = src[r], cn = p.r_cnt[g];
-        for (uint32_t e = 0; e < cn; ++e) {
-            p.d_hash[off[r] + e] = p.r_hash[(size_t)g * GAP_DEV_REG + e];
-            p.d_pos[off[r] + e] = p.r_pos[(size_t)g * GAP_DEV_REG + e];
-            p.d_rec[off[r] + e] = p.r_rec[(size_t)g * GAP_DEV_REG + e];
-        }
+    if (threadIdx.x == 0) {
+        p.ctrl[7] = sh[255];
+        p.s_off[n_g] = sh[255];
     }
 }
 
@@ -1414,57 +1532,6 @@ __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
 // [0] largest wave count if a wave overflowed its arena slice, [1] candidate-free stretches, [2] minimizers among the
 // candidates, [3] "the device route could not finish the stretches", [4] candidates, [5] minimizers inside stretches,
 // [6..7] minimizers of the batch, [8..9] where the batch starts in the assembly's sketch, [10] k-mers hashed by k_gap_fix
-struct FinParams {
-    const uint32_t *ctrl;
-    uint32_t *host_ctrl;
-    const uint64_t *base_in;
-    uint64_t *base_out;
-    uint32_t *n_out;
-    const uint64_t *a_hash; const uint32_t *a_pos, *a_rec; uint64_t a_limit;  // staging (k_emit)
-    const uint64_t *b_hash; const uint32_t *b_pos, *b_rec;                    // stretches (k_gap_post)
-    uint64_t *o_hash; uint32_t *o_pos, *o_rec; uint64_t out_limit;
-};
-
-__global__ __launch_bounds__(256) void k_merge_fin(const FinParams p)
-{
-    const uint32_t ovf = p.ctrl[0], n_g = p.ctrl[1], nA = p.ctrl[2], n_cand = p.ctrl[4], nB = n_g ? p.ctrl[7] : 0u;
-    const uint32_t flag = p.ctrl[6] | ((n_g && nA > p.a_limit) ? 1u : 0u);
-    const uint64_t base = p.base_in ? *p.base_in : 0ull;
-    const uint64_t total = ovf ? 0ull : (uint64_t)nA + nB;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (p.base_out) *p.base_out = base + total;
-        if (p.n_out) *p.n_out = (uint32_t)(base + total);
-        uint32_t *hc = p.host_ctrl;
-        hc[0] = ovf; hc[1] = n_g; hc[2] = nA; hc[3] = flag; hc[4] = n_cand; hc[5] = nB;
-        hc[6] = (uint32_t)total; hc[7] = (uint32_t)(total >> 32);
-        hc[8] = (uint32_t)base; hc[9] = (uint32_t)(base >> 32);
-        hc[10] = p.ctrl[10];
-    }
-    if (n_g == 0 || flag || ovf) return;  // no stretch: k_emit wrote the output itself
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    // A few hundred stretch minimizers among a million of the batch's own: almost every block of 256 consecutive own
-    // minimizers lies between two neighbouring stretch minimizers, so the block's first and last key are searched once
-    // and only a block that straddles one searches per thread.
-    __shared__ uint32_t lb_edge[2];
-    const uint32_t t0 = blockIdx.x * 256u;
-    if (t0 < nA && (threadIdx.x == 0 || threadIdx.x == 255)) {
-        const uint32_t te = min(t0 + threadIdx.x, nA - 1u);
-        lb_edge[threadIdx.x ? 1 : 0] = lower_bound_key(p.b_rec, p.b_pos, nB, ((uint64_t)p.a_rec[te] << 32) | p.a_pos[te]);
-    }
-    __syncthreads();
-    if (t < nA) {
-        uint32_t lb = lb_edge[0];
-        if (lb_edge[1] != lb) lb = lower_bound_key(p.b_rec, p.b_pos, nB, ((uint64_t)p.a_rec[t] << 32) | p.a_pos[t]);
-        const uint64_t d = base + t + lb;
-        if (d < p.out_limit) { p.o_hash[d] = p.a_hash[t]; p.o_pos[d] = p.a_pos[t]; p.o_rec[d] = p.a_rec[t]; }
-    } else if (t < nA + nB) {
-        const uint32_t u = t - nA;
-        const uint64_t key = ((uint64_t)p.b_rec[u] << 32) | p.b_pos[u];
-        const uint64_t d = base + u + lower_bound_key(p.a_rec, p.a_pos, nA, key);
-        if (d < p.out_limit) { p.o_hash[d] = p.b_hash[u]; p.o_pos[d] = p.b_pos[u]; p.o_rec[d] = p.b_rec[u]; }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------------------
@@ -1778,16 +1845,25 @@ struct Driver {
         ep.base_in = io ? io->base_in : nullptr;
         ep.base_out = io ? io->base_out : nullptr;
         ep.dev_gaps = io && io->dev_gaps ? 1u : 0u;
-        ep.s_hash = nullptr;
-        ep.s_pos = ep.s_rec = nullptr;
-        ep.s_limit = 0;
+        ep.n_tiles = (n_cap + TILE - 1) / TILE;
+        ep.s_key = nullptr;
+        ep.s_off = ep.s_src = nullptr;
+        ep.gaps = nullptr;
+        ep.r_hash = nullptr;
+        ep.r_pos = ep.r_rec = ep.r_cnt = nullptr;
+        uint32_t grid = ep.n_tiles;
         if (ep.dev_gaps) {
-            ep.s_hash = sc(SC_ST_HASH).as<uint64_t>();
-            ep.s_pos = sc(SC_ST_POS).as<uint32_t>();
-            ep.s_rec = sc(SC_ST_REC).as<uint32_t>();
-            ep.s_limit = std::min<uint64_t>({sc(SC_ST_HASH).bytes / 8, sc(SC_ST_POS).bytes / 4, sc(SC_ST_REC).bytes / 4});
+            ep.s_key = sc(SC_GD_HASH).as<uint64_t>();
+            ep.s_off = sc(SC_GD_POS).as<uint32_t>();
+            ep.s_src = sc(SC_GD_REC).as<uint32_t>();
+            ep.gaps = sc(SC_GAPS).as<uint4>();
+            ep.r_hash = sc(SC_GR_HASH).as<uint64_t>();
+            ep.r_pos = sc(SC_GR_POS).as<uint32_t>();
+            ep.r_rec = sc(SC_GR_REC).as<uint32_t>();
+            ep.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
+            grid += GAP_DEV_MAX / 4;
         }
-        hipLaunchKernelGGL(k_emit, dim3((n_cap + TILE - 1) / TILE), dim3(256), 0, st, ep);
+        hipLaunchKernelGGL(k_emit, dim3(grid), dim3(256), 0, st, ep);
         MXG_HIP(h, hipGetLastError());
         return MXG_OK;
     }
@@ -1965,6 +2041,16 @@ struct Driver {
     }
     // Enqueue one batch completely (hash -> order -> resolve+count -> speculative emit at out.n); the last kernel writes
     // the control block to `ctrl_host` (PINNED host memory); NO host sync.  *n_cap_out = capacity the candidate arrays were sized for.
+    // grid of the hash kernel: one block per tile of 256 strips, or (MXG_HASH_BPC=n, an experiment: see the kernel) about n
+    // blocks per CU with an equal number of tiles each
+    uint32_t sparse_grid(uint32_t n_tiles, uint64_t nk) const
+    {
+        (void)nk;
+        const uint64_t bpc = env_u64("MXG_HASH_BPC", 0);
+        if (bpc == 0 || n_tiles <= 256 * bpc) return n_tiles;
+        const uint32_t rounds = (uint32_t)std::max<uint64_t>(1, (n_tiles + 128 * bpc) / (256 * bpc));  // nearest
+        return (n_tiles + rounds - 1) / rounds;
+    }
     int enqueue_sparse(Assembly *a, const Tables &T, const BatchGeom &g, uint64_t wave_cap, uint32_t tau_hi,
                        OutArrays &out, uint32_t *ctrl_host, uint32_t *n_cap_out, const ChainIO *io = nullptr,
                        uint32_t cand_hint = 0xFFFFFFFFu)
@@ -1999,6 +2085,7 @@ struct Driver {
         sp.strip_hi = g.strip_hi;
         sp.k = h->cfg.k;
         sp.S = S;
+        sp.five = env_u64("MXG_HASH_FIVE", 1) != 0 ? 1u : 0u;
         // MXG_RING_SLACK=<percent> (test knob): the ring filter captures up to that many percent more k-mers than have
         // hash < tau, i.e. entries that k_reorder finds to be >= tau and k_resolve must treat as absent.  On real runs
         // such entries occur about once per 10^9 k-mers, so the tests force them.
@@ -2017,7 +2104,8 @@ struct Driver {
         sp.init_tab = h->d_init_tab.as<uint4>();
         sp.tab = h->tab;
         if ((rc = ev_begin(batch_bases(T, g.c0, g.c1), true)) != MXG_OK) return rc;
-        dim3 grid(g.n_blocks), block(256);
+        sp.n_tiles = g.n_blocks;
+        dim3 grid(sparse_grid(g.n_blocks, g.nk)), block(256);
         static const int abl = getenv("MXG_ABLATE") ? atoi(getenv("MXG_ABLATE")) : 0;  // profiling only
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
             hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V1_MIN>), grid, block, 0, st, sp);
@@ -2030,12 +2118,12 @@ struct Driver {
             // Every lane keeps one 128-byte line of packed bases "open" for 32 block iterations (16 bases = 4 bytes per
             // iteration), so the waves resident on an XCD hold (waves x 64 x 128 B) of live lines.  At full occupancy that is
             // more than the XCD's 4 MB of L2 once the input no longer fits the caches behind it: measured at 3 Gbp (PMC
-            // FETCH_SIZE x 2), the kernel fetched 336 MB for 115 MB of bases.  24 KB of unused dynamic LDS cap the residency at
-            // five blocks per CU: 131 MB fetched, the kernel itself ~10 % slower (0.188 -> 0.21 ms; with 30-36 KB: 0.24-0.25 ms
-            // for the same step time), the step 2 % faster (1146 -> 1172 Gbp/s) because everything that runs beside it gets
-            // the bandwidth back.  Small inputs (cache-resident) keep full occupancy.
-            const size_t pad = (size_t)env_u64("MXG_HASH_LDS", g.nk >= (256ull << 20) ? 24000 : 0);
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), grid, block, pad, st, sp);
+            // FETCH_SIZE x 2), the kernel fetched 336 MB for 115 MB of bases.  Unused dynamic LDS caps the residency at six
+            // blocks per CU (18 KB; five with 24 KB: 1285-1308 Gbp/s against 1304-1331; none: 1257).  It also keeps the other
+            // stream's kernels from moving in beside this one, which costs both more than it gains.  Small inputs
+            // (cache-resident) keep full occupancy.
+            const size_t pad = (size_t)env_u64("MXG_HASH_LDS", g.nk >= (256ull << 20) ? 18000 : 0);
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), dim3(sparse_grid(g.n_blocks, g.nk)), block, pad, st, sp);
         }
         if ((rc = ev_end()) != MXG_OK) return rc;
         MXG_HIP(h, hipGetLastError());
@@ -2103,14 +2191,9 @@ struct Driver {
             MXG_HIP(h, sc(SC_GR_REC).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
             MXG_HIP(h, sc(SC_GR_CNT).ensure((size_t)GAP_DEV_MAX * 4));
             MXG_HIP(h, sc(SC_GR_KEY).ensure((size_t)GAP_DEV_MAX * 8));
-            MXG_HIP(h, sc(SC_GD_HASH).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 8));
-            MXG_HIP(h, sc(SC_GD_POS).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
-            MXG_HIP(h, sc(SC_GD_REC).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
-            // staging for the batch's own minimizers when it has stretches: density 2/(w+1) plus slack
-            const uint64_t st_cap = (uint64_t)(2.5 * (double)g.nk / (double)(h->cfg.w + 1)) + 4096;
-            MXG_HIP(h, sc(SC_ST_HASH).ensure(st_cap * 8));
-            MXG_HIP(h, sc(SC_ST_POS).ensure(st_cap * 4));
-            MXG_HIP(h, sc(SC_ST_REC).ensure(st_cap * 4));
+            MXG_HIP(h, sc(SC_GD_HASH).ensure((size_t)(GAP_DEV_MAX + 1) * 8));  // the stretches in order: key,
+            MXG_HIP(h, sc(SC_GD_POS).ensure((size_t)(GAP_DEV_MAX + 1) * 4));   // minimizers before,
+            MXG_HIP(h, sc(SC_GD_REC).ensure((size_t)(GAP_DEV_MAX + 1) * 4));   // region
             GapFixParams gp;
             gp.gaps = sc(SC_GAPS).as<uint4>();
             gp.ctrl = sc(SC_CTRL).as<uint32_t>();
@@ -2129,49 +2212,27 @@ struct Driver {
             gp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
             gp.r_key = sc(SC_GR_KEY).as<uint64_t>();
             gp.tab = h->tab;
-            if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-                hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V1_MIN>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
-            else
-                hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V2_SUM>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
+            if (h->cfg.variant == MXG_VARIANT_V1_MIN) {
+                hipLaunchKernelGGL((k_gap_fix<MXG_VARIANT_V1_MIN, GAP_DEV_NSMALL, false>), dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
+                hipLaunchKernelGGL((k_gap_fix<MXG_VARIANT_V1_MIN, GAP_DEV_NMAX, true>), dim3(GAP_DEV_BIG_BLOCKS), dim3(256), 0, st, gp);
+            } else {
+                hipLaunchKernelGGL((k_gap_fix<MXG_VARIANT_V2_SUM, GAP_DEV_NSMALL, false>), dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
+                hipLaunchKernelGGL((k_gap_fix<MXG_VARIANT_V2_SUM, GAP_DEV_NMAX, true>), dim3(GAP_DEV_BIG_BLOCKS), dim3(256), 0, st, gp);
+            }
+            GapPostParams pp;
+            pp.ctrl = sc(SC_CTRL).as<uint32_t>();
+            pp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
+            pp.r_key = sc(SC_GR_KEY).as<uint64_t>();
+            pp.s_key = sc(SC_GD_HASH).as<uint64_t>();
+            pp.s_off = sc(SC_GD_POS).as<uint32_t>();
+            pp.s_src = sc(SC_GD_REC).as<uint32_t>();
+            hipLaunchKernelGGL(k_gap_post, dim3(1), dim3(GPB), 0, st, pp);
             MXG_HIP(h, hipGetLastError());
         }
         if ((rc = ev_next(4)) != MXG_OK) return rc;
         // the batch before this one (same assembly, other stream) must have passed its count on
         if (io && io->wait) MXG_HIP(h, hipStreamWaitEvent(st, io->wait, 0));
         if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host, io)) != MXG_OK) return rc;
-        if (dev) {
-            GapPostParams pp;
-            pp.ctrl = sc(SC_CTRL).as<uint32_t>();
-            pp.r_hash = sc(SC_GR_HASH).as<uint64_t>();
-            pp.r_pos = sc(SC_GR_POS).as<uint32_t>();
-            pp.r_rec = sc(SC_GR_REC).as<uint32_t>();
-            pp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
-            pp.r_key = sc(SC_GR_KEY).as<uint64_t>();
-            pp.d_hash = sc(SC_GD_HASH).as<uint64_t>();
-            pp.d_pos = sc(SC_GD_POS).as<uint32_t>();
-            pp.d_rec = sc(SC_GD_REC).as<uint32_t>();
-            hipLaunchKernelGGL(k_gap_post, dim3(1), dim3(GPB), 0, st, pp);
-            FinParams fp;
-            fp.ctrl = sc(SC_CTRL).as<uint32_t>();
-            fp.host_ctrl = ctrl_host;
-            fp.base_in = io->base_in;
-            fp.base_out = io->base_out;
-            fp.n_out = n_out;
-            fp.a_hash = sc(SC_ST_HASH).as<uint64_t>();
-            fp.a_pos = sc(SC_ST_POS).as<uint32_t>();
-            fp.a_rec = sc(SC_ST_REC).as<uint32_t>();
-            fp.a_limit = std::min<uint64_t>({sc(SC_ST_HASH).bytes / 8, sc(SC_ST_POS).bytes / 4, sc(SC_ST_REC).bytes / 4});
-            fp.b_hash = pp.d_hash;
-            fp.b_pos = pp.d_pos;
-            fp.b_rec = pp.d_rec;
-            fp.o_hash = out.hash->as<uint64_t>();
-            fp.o_pos = out.pos->as<uint32_t>();
-            fp.o_rec = out.rec->as<uint32_t>();
-            fp.out_limit = out.cap();
-            const uint64_t bound = std::min<uint64_t>(n_cap, fp.a_limit) + (uint64_t)GAP_DEV_MAX * GAP_DEV_REG;
-            hipLaunchKernelGGL(k_merge_fin, dim3((uint32_t)((bound + 255) / 256)), dim3(256), 0, st, fp);
-            MXG_HIP(h, hipGetLastError());
-        }
         return ev_end();
     }
 
