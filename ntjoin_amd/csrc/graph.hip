@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
     const uint32_t full = p.full;
     __shared__ unsigned long long keys[PJ_T + 1];
     __shared__ uint32_t seen[PJ_T + 1], dup[PJ_T + 1];
+    __shared__ uint32_t item0[PJ_T + 1];  // the key's minimizer in assembly 0 (what the others look their vertex up by)
     __shared__ uint32_t seg_off[257], seg_rec[256], sh[256];
     __shared__ uint32_t failed;
     uint32_t b = blockIdx.x, rec_off = 0;
@@ -299,12 +300,16 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
                 if (pass == 0) {
                     const uint32_t bit = 1u << rec.w;
                     if (s > PJ_T) failed = 1;
-                    else if (atomicOr(&seen[s], bit) & bit) atomicOr(&dup[s], bit);  // second occurrence in this assembly
+                    else {
+                        if (atomicOr(&seen[s], bit) & bit) atomicOr(&dup[s], bit);  // second occurrence in this assembly
+                        if (rec.w == 0) item0[s] = rec.z;  // (a key that occurs twice in assembly 0 is not shared: never read)
+                    }
                 }
                 return s;
             };
-            // the verdict of a record, 4 bytes: slot << 3 | MXG_MX_* flags, sent straight to the minimizer it stands for
-            // (slot[a][i]: the ONE random access per minimizer of the whole join; k_flags_pj then reads the verdicts in order)
+            // the verdict of a record, 4 bytes: (shared: the key's minimizer in assembly 0) << 3 | MXG_MX_* flags, sent straight
+            // to the minimizer it stands for (slot[a][i]: the ONE random access per minimizer of the whole join; k_flags_pj
+            // then reads the verdicts in order)
             auto finish = [&](uint32_t i, uint32_t s, uint32_t a) {
                 uint32_t fl = 0;
                 if (!bad) {
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
                     const bool inall = sn == full;
                     fl = (!(d & (1u << a)) ? MXG_MX_UNIQUE : 0u) | ((inall && d == 0) ? MXG_MX_SHARED : 0u) | (inall ? MXG_MX_INALL : 0u);
                 }
-                p.slot[a][i] = ((blockIdx.x * (PJ_T + 1u) + (bad ? 0u : s)) << 3) | fl;
+                p.slot[a][i] = ((fl & MXG_MX_SHARED) ? item0[s] << 3 : 0u) | fl;
             };
 #pragma unroll
             for (uint32_t it = 0; it < QC; ++it) {
@@ -457,8 +462,9 @@ __global__ __launch_bounds__(PJ_BT) void k_pj2_bucket(const AsmSet p, const uint
 
 // k_flags for the partitioned join: the table state of minimizer i sits in recs[slot[a][i]]
 // (also clears this item's cells of the adjacency arrays nxt[A][nvs] | prv[A][nvs]: saves the fill launch)
+// mask0[w]: which of minimizers 64 w .. 64 w + 63 of assembly 0 are shared (k_vertices_pj ranks by it)
 __global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, uint32_t *cnt, uint32_t *sup, uint32_t *nxt, uint32_t nvs,
-                                                  uint32_t slot_limit)
+                                                  uint64_t *mask0)
 {
     const uint32_t a = asm_of_block(p, blockIdx.x);
     const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
@@ -472,8 +478,10 @@ __global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, uint32_t *cnt,
         sh = (v & MXG_MX_SHARED) != 0;
         p.flags[a][i] = (uint8_t)(v & 7u);
         p.shared[a][i] = sh ? 1 : 0;
-        p.slot[a][i] = min(v >> 3, slot_limit);
+        p.slot[a][i] = v >> 3;
     }
+    const uint64_t bm = __ballot(sh);
+    if (a == 0 && (threadIdx.x & 63u) == 0) mask0[(blockIdx.x - p.bstart[0]) * 4u + (threadIdx.x >> 6)] = bm;
     const uint32_t c = (uint32_t)__syncthreads_count(sh ? 1 : 0);
     if (threadIdx.x == 0) count_publish(cnt + p.bstart[a], sup + sup_start(p, a), blockIdx.x - p.bstart[a], c);
 }
@@ -530,6 +538,85 @@ __global__ __launch_bounds__(256) void k_vertices(const VertexParams p)
     if (p.ivid) p.ivid[i] = v;
     p.fv[r] = v;
     p.frec[r] = rec;
+}
+
+// exclusive prefix of n counts by ONE block (the shared minimizers before every 256-block of assembly 0)
+__global__ __launch_bounds__(256) void k_block_prefix(const uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t sh[256];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 4096) {
+        const uint32_t i0 = base + threadIdx.x * 16u;
+        uint32_t v[16], c = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            v[u] = i0 + u < n ? cnt[i0 + u] : 0u;
+            c += v[u];
+        }
+        uint32_t run = carry + block_exclusive_256(c, sh);
+        const uint32_t tile_total = sh[255];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (i0 + u < n) out[i0 + u] = run;
+            run += v[u];
+        }
+        carry += tile_total;
+        __syncthreads();
+    }
+}
+
+// The vertex pass of the partitioned join, ALL assemblies in one launch.  A shared minimizer of assembly a > 0 carries the
+// index i0 of its key's minimizer in assembly 0 (k_pj_join); its vertex id is the rank of i0 among assembly 0's shared
+// minimizers = shared ones before i0's 256-block (bpref0) + set bits of mask0 before i0 inside the block: two small
+// arrays (1 bit and 1/64 word per minimizer) that stay in L2, where the table-slot -> vertex-id array of k_vertices took a
+// random 4-byte HBM write per vertex in assembly 0 and a random read per vertex in every other assembly.
+struct VertexPjParams {
+    AsmSet as;
+    const uint32_t *pos[MXG_MAX_ASSEMBLIES], *rec[MXG_MAX_ASSEMBLIES];
+    const uint32_t *cnt, *sup;
+    uint64_t *n_shared;  // ctl[a]
+    const uint64_t *mask0;
+    const uint32_t *bpref0;
+    uint64_t *vhash;
+    uint32_t *vpos, *vrec, *fv, *frec;  // [A][nvs]
+    uint32_t nvs;
+};
+
+__global__ __launch_bounds__(256) void k_vertices_pj(const VertexPjParams p)
+{
+    __shared__ uint32_t sh[256];
+    __shared__ uint32_t sh_before;
+    const uint32_t a = asm_of_block(p.as, blockIdx.x);
+    const uint32_t blk = blockIdx.x - p.as.bstart[a], nblk = p.as.bstart[a + 1] - p.as.bstart[a];
+    const uint32_t i = blk * 256u + threadIdx.x;
+    const bool f = i < asm_n(p.as, a) && p.as.shared[a][i];
+    if (threadIdx.x < 64) {
+        const uint32_t *cnt = p.cnt + p.as.bstart[a], *sup = p.sup + sup_start(p.as, a);
+        const uint32_t bef = count_prefix(cnt, sup, blk);
+        if (threadIdx.x == 0) sh_before = bef;
+        if (blk + 1 == nblk) {  // the assembly's last tile also reports its total
+            const uint32_t all = count_prefix(cnt, sup, nblk);
+            if (threadIdx.x == 0) p.n_shared[a] = all;
+        }
+    }
+    __syncthreads();
+    const uint32_t r = sh_before + block_exclusive_256(f ? 1u : 0u, sh);
+    if (!f) return;
+    uint32_t v = r;
+    if (a) {
+        const uint32_t i0 = p.as.slot[a][i], w = i0 >> 6;
+        const uint64_t *m = p.mask0 + (w & ~3u);
+        v = p.bpref0[i0 >> 8] + (uint32_t)__popcll(p.mask0[w] & ((1ull << (i0 & 63u)) - 1ull));
+        for (uint32_t q = 0; q < (w & 3u); ++q) v += (uint32_t)__popcll(m[q]);
+    } else {
+        p.vhash[v] = p.as.hash[0][i];
+    }
+    const size_t o = (size_t)a * p.nvs;
+    const uint32_t rec = p.rec[a][i];
+    p.vpos[o + v] = p.pos[a][i];
+    p.vrec[o + v] = rec;
+    p.fv[o + r] = v;
+    p.frec[o + r] = rec;
 }
 
 // blockIdx.y = assembly; all arrays are [A][stride]
@@ -743,7 +830,11 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
     const uint32_t pj_force_fail = getenv("MXG_PJ_FORCE_FAIL") && atoi(getenv("MXG_PJ_FORCE_FAIL")) ? 1u : 0u;
 
     if (!pj) MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * sizeof(Slot)));  // (the partitioned join keeps its N records here)
-    MXG_HIP(h, h->g_vid.ensure(std::max<size_t>((size_t)cap + 1, pj ? (size_t)std::max(P1, 1u) * P * (PJ_T + 1) : 0) * 4));
+    // global table: slot -> vertex id; partitioned join: assembly 0's shared mask (8 B per 64 minimizers) + block prefix
+    const size_t nb0 = (size_t)((n_of[0] + 255) / 256);
+    MXG_HIP(h, h->g_vid.ensure(pj ? nb0 * 4 * 8 + nb0 * 4 + 64 : ((size_t)cap + 1) * 4));
+    uint64_t *const pj_mask0 = h->g_vid.as<uint64_t>();
+    uint32_t *const pj_bpref0 = reinterpret_cast<uint32_t *>(pj_mask0 + nb0 * 4);
     MXG_HIP(h, h->g_ctl.ensure(CTL_WORDS * 8));
     if (pj) {
         // (nothing to clear: every word of M and of the record regions that is read is written by this call)
@@ -813,7 +904,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
                            rows2, as_all);
         MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4 + 16));  // nxt[A][nvs] followed by prv[A][nvs], cleared by k_flags_pj
         hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, cnt, fsup, h->g_nxt.as<uint32_t>(), (uint32_t)nvs,
-                           P1 * P * (PJ_T + 1u) - 1u);
+                           pj_mask0);
     } else if (nb && !resume && pj) {
         const uint32_t n_rows = (nb + PJ_IPB / 256 - 1) / (PJ_IPB / 256);  // bucketing blocks = record regions = rows of M
         MXG_HIP(h, h->g_part.ensure((size_t)n_rows * (P + 1) * 4));
@@ -826,7 +917,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
                            as_all);
         MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4 + 16));  // nxt[A][nvs] followed by prv[A][nvs], cleared by k_flags_pj
         hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, cnt, fsup, h->g_nxt.as<uint32_t>(), (uint32_t)nvs,
-                           P * (PJ_T + 1u) - 1u);
+                           pj_mask0);
     } else if (nb && !resume) {
         hipLaunchKernelGGL(k_insert, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), mask, cap, fsup,
                            n_fsup + n_esup);
@@ -844,7 +935,28 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4));  // nxt[A][nvs] followed by prv[A][nvs]: one fill
         if ((mode == GRAPH_FULL && !pj) || mode == GRAPH_DG_EDGES) MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));
         uint32_t *const d_prv = h->g_nxt.as<uint32_t>() + anv;
-        for (uint32_t a = 0; a < A && !resume; ++a) {  // assembly 0 assigns the vertex ids the others look up
+        if (pj && nb && !resume) {
+            VertexPjParams vp;
+            vp.as = as_all;
+            for (uint32_t a = 0; a < MXG_MAX_ASSEMBLIES; ++a) {
+                vp.pos[a] = a < A ? h->asms[a]->d_pos.as<uint32_t>() : nullptr;
+                vp.rec[a] = a < A ? h->asms[a]->d_rec.as<uint32_t>() : nullptr;
+            }
+            vp.cnt = cnt;
+            vp.sup = fsup;
+            vp.n_shared = ctl;
+            vp.mask0 = pj_mask0;
+            vp.bpref0 = pj_bpref0;
+            vp.vhash = h->g_vhash.as<uint64_t>();
+            vp.vpos = h->g_vpos.as<uint32_t>();
+            vp.vrec = h->g_vrec.as<uint32_t>();
+            vp.fv = h->g_fv.as<uint32_t>();
+            vp.frec = h->g_frec.as<uint32_t>();
+            vp.nvs = (uint32_t)nvs;
+            hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, h->stream, cnt + as_all.bstart[0], (uint32_t)nb0, pj_bpref0);
+            hipLaunchKernelGGL(k_vertices_pj, dim3(nb), dim3(256), 0, h->stream, vp);
+        }
+        for (uint32_t a = 0; a < A && !resume && !pj; ++a) {  // assembly 0 assigns the vertex ids the others look up
             Assembly *as = h->asms[a];
             const uint32_t n = (uint32_t)n_of[a];
             VertexParams vp;
