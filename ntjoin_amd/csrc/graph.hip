@@ -232,13 +232,15 @@ __device__ __forceinline__ uint32_t pj_slot(unsigned long long *keys, uint64_t k
 // every 4096-record region of a coarse partition into P sub-partitions (rows of M: rows2 per coarse partition); block
 // blockIdx.x = c * P + b joins sub-partition b of coarse partition c.
 constexpr uint32_t PJ1_CS = 32;  // words between the coarse partitions' cursors (own 128-byte lines: same-line atomics serialise)
+// NARROW (at most 16 assemblies): the seen and dup masks share one word per slot (32 KB of LDS per block instead of 44)
+template <bool NARROW>
 __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__restrict__ M, uint32_t P, uint32_t n_rows,
                                                  uint64_t *host_fail, uint32_t force_fail, const uint32_t *__restrict__ cursor,
                                                  uint32_t cap1, uint32_t rows2, const AsmSet p)
 {
     const uint32_t full = p.full;
     __shared__ unsigned long long keys[PJ_T + 1];
-    __shared__ uint32_t seen[PJ_T + 1], dup[PJ_T + 1];
+    __shared__ uint32_t seen[PJ_T + 1], dup[NARROW ? 1 : PJ_T + 1];
     __shared__ uint32_t item0[PJ_T + 1];  // the key's minimizer in assembly 0 (what the others look their vertex up by)
     __shared__ uint32_t seg_off[257], seg_rec[256], sh[256];
     __shared__ uint32_t failed;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
     for (uint32_t s = threadIdx.x; s <= PJ_T; s += 256) {
         keys[s] = HT_EMPTY;
         seen[s] = 0;
-        dup[s] = 0;
+        if (!NARROW) dup[s] = 0;
     }
     if (threadIdx.x == 0) failed = force_fail;
     // The partition's records are short segments, one per region.  Per 256 regions: every thread fetches one segment's
@@ -301,7 +303,9 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
                     const uint32_t bit = 1u << rec.w;
                     if (s > PJ_T) failed = 1;
                     else {
-                        if (atomicOr(&seen[s], bit) & bit) atomicOr(&dup[s], bit);  // second occurrence in this assembly
+                        if (atomicOr(&seen[s], bit) & bit) {  // second occurrence in this assembly
+                            if (NARROW) atomicOr(&seen[s], bit << 16); else atomicOr(&dup[s], bit);
+                        }
                         if (rec.w == 0) item0[s] = rec.z;  // (a key that occurs twice in assembly 0 is not shared: never read)
                     }
                 }
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
             auto finish = [&](uint32_t i, uint32_t s, uint32_t a) {
                 uint32_t fl = 0;
                 if (!bad) {
-                    const uint32_t sn = seen[s] & full, d = dup[s] & full;
+                    const uint32_t sn = seen[s] & full, d = (NARROW ? seen[s] >> 16 : dup[s]) & full;
                     const bool inall = sn == full;
                     fl = (!(d & (1u << a)) ? MXG_MX_UNIQUE : 0u) | ((inall && d == 0) ? MXG_MX_SHARED : 0u) | (inall ? MXG_MX_INALL : 0u);
                 }
@@ -900,8 +904,12 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
                            fsup, n_fsup + n_esup);
         hipLaunchKernelGGL(k_pj2_bucket, dim3(rows2, P1), dim3(PJ_BT), (size_t)P * 8, h->stream, as_all, recs1, cursor, cap1, rows2, P - 1, M,
                            recs2);
-        hipLaunchKernelGGL(k_pj_join, dim3(P1 * P), dim3(256), 0, h->stream, recs2, M, P, 0u, hctl + CTL_PJ_FAIL, pj_force_fail, cursor, cap1,
-                           rows2, as_all);
+        if (A <= 16)
+            hipLaunchKernelGGL(k_pj_join<true>, dim3(P1 * P), dim3(256), 0, h->stream, recs2, M, P, 0u, hctl + CTL_PJ_FAIL, pj_force_fail,
+                               cursor, cap1, rows2, as_all);
+        else
+            hipLaunchKernelGGL(k_pj_join<false>, dim3(P1 * P), dim3(256), 0, h->stream, recs2, M, P, 0u, hctl + CTL_PJ_FAIL, pj_force_fail,
+                               cursor, cap1, rows2, as_all);
         MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4 + 16));  // nxt[A][nvs] followed by prv[A][nvs], cleared by k_flags_pj
         hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, cnt, fsup, h->g_nxt.as<uint32_t>(), (uint32_t)nvs,
                            pj_mask0);
@@ -913,8 +921,12 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         uint4 *recs = h->g_keys.as<uint4>();
         hipLaunchKernelGGL(k_pj_bucket, dim3(n_rows), dim3(PJ_BT), (size_t)P * 8, h->stream, as_all, nb, P - 1, M, recs, fsup,
                            n_fsup + n_esup);
-        hipLaunchKernelGGL(k_pj_join, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, hctl + CTL_PJ_FAIL, pj_force_fail, nullptr, 0u, 0u,
-                           as_all);
+        if (A <= 16)
+            hipLaunchKernelGGL(k_pj_join<true>, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, hctl + CTL_PJ_FAIL, pj_force_fail, nullptr,
+                               0u, 0u, as_all);
+        else
+            hipLaunchKernelGGL(k_pj_join<false>, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, hctl + CTL_PJ_FAIL, pj_force_fail, nullptr,
+                               0u, 0u, as_all);
         MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4 + 16));  // nxt[A][nvs] followed by prv[A][nvs], cleared by k_flags_pj
         hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, cnt, fsup, h->g_nxt.as<uint32_t>(), (uint32_t)nvs,
                            pj_mask0);

@@ -171,3 +171,31 @@ def test_two_level_join_coarse_partition_overflow_falls_back(monkeypatch):
             res.append(_graph_state(eng, 2))
     for key in res[0]:
         assert np.array_equal(res[0][key], res[1][key]), key
+
+
+@pytest.mark.parametrize("n_asm", [16, 17, 32])
+def test_joins_agree_with_many_assemblies(monkeypatch, n_asm):
+    """16 assemblies: the LDS join keeps the seen and the duplicate mask of a key in one word; 17 and 32 (the maximum):
+    two words.  Keys missing from some assemblies, duplicated in others."""
+    from ntjoin_amd.engine import MxEngine
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 2**63, size=6000, dtype=np.int64).astype(np.uint64)
+
+    def mk(a):
+        r = np.random.default_rng(100 + a)
+        hs = base[r.random(base.size) >= (0.01 if a % 3 else 0.0)].copy()
+        r.shuffle(hs)
+        if a % 4 == 1:
+            hs = np.concatenate([hs, hs[:40]])  # 40 keys twice in this assembly
+        rec = np.sort(r.integers(0, 12, size=hs.size)).astype(np.uint32)
+        return hs, np.arange(hs.size, dtype=np.uint32), rec, [f"c{i}" for i in range(12)]
+    sets = [mk(a) for a in range(n_asm)]
+
+    def build():
+        with MxEngine(k=32, w=1000) as eng:
+            for i, (hs, pos, rec, ids) in enumerate(sets):
+                eng.add_minimizers(f"a{i}", 1.0 + i / 8, hs, pos, rec, ids)
+            eng.build_graph()
+            assert eng.stats()["vertices"] > 3000
+            return _graph_state(eng, len(sets))
+    _three_ways(monkeypatch, build)
