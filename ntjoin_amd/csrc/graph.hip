@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_insert(const AsmSet p, Slot *tab, uint3
 
 // flags of every minimizer + number of shared ones per block of 256 (cnt[b], super-counts per assembly at
 // sup[sup_start(a)..): scan_kernels.h); k_vertices turns them into offsets
-__device__ __forceinline__ uint32_t sup_start(const AsmSet &p, uint32_t a) { return ((p.bstart[a] >> SUP_SHIFT) + a) * SUP_STRIDE; }
+__host__ __device__ __forceinline__ uint32_t sup_start(const AsmSet &p, uint32_t a) { return ((p.bstart[a] >> SUP_SHIFT) + a) * SUP_STRIDE; }
 
 __global__ __launch_bounds__(256) void k_flags(const AsmSet p, const Slot *__restrict__ tab, uint32_t *cnt, uint32_t *sup)
 {
@@ -544,29 +544,22 @@ __global__ __launch_bounds__(256) void k_vertices(const VertexParams p)
     p.frec[r] = rec;
 }
 
-// exclusive prefix of n counts by ONE block (the shared minimizers before every 256-block of assembly 0)
-__global__ __launch_bounds__(256) void k_block_prefix(const uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ out)
+// out[e] = shared minimizers before 256-block e of assembly 0: every block of this kernel takes 256 entries -- what precedes
+// them from the two-level counts, the rest by a scan in LDS (one block scanning all 23 000 entries took 33 us)
+__global__ __launch_bounds__(256) void k_block_prefix(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ sup, uint32_t n,
+                                                      uint32_t *__restrict__ out)
 {
     __shared__ uint32_t sh[256];
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n; base += 4096) {
-        const uint32_t i0 = base + threadIdx.x * 16u;
-        uint32_t v[16], c = 0;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            v[u] = i0 + u < n ? cnt[i0 + u] : 0u;
-            c += v[u];
-        }
-        uint32_t run = carry + block_exclusive_256(c, sh);
-        const uint32_t tile_total = sh[255];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (i0 + u < n) out[i0 + u] = run;
-            run += v[u];
-        }
-        carry += tile_total;
-        __syncthreads();
+    __shared__ uint32_t sh_before;
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t c = e < n ? cnt[e] : 0u;
+    if (threadIdx.x < 64) {
+        const uint32_t bef = count_prefix(cnt, sup, blockIdx.x * 256u);
+        if (threadIdx.x == 0) sh_before = bef;
     }
+    __syncthreads();
+    const uint32_t r = sh_before + block_exclusive_256(c, sh);
+    if (e < n) out[e] = r;
 }
 
 // The vertex pass of the partitioned join, ALL assemblies in one launch.  A shared minimizer of assembly a > 0 carries the
@@ -965,7 +958,8 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
             vp.fv = h->g_fv.as<uint32_t>();
             vp.frec = h->g_frec.as<uint32_t>();
             vp.nvs = (uint32_t)nvs;
-            hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(256), 0, h->stream, cnt + as_all.bstart[0], (uint32_t)nb0, pj_bpref0);
+            hipLaunchKernelGGL(k_block_prefix, dim3((uint32_t)((nb0 + 255) / 256)), dim3(256), 0, h->stream, cnt + as_all.bstart[0],
+                               fsup + sup_start(as_all, 0), (uint32_t)nb0, pj_bpref0);
             hipLaunchKernelGGL(k_vertices_pj, dim3(nb), dim3(256), 0, h->stream, vp);
         }
         for (uint32_t a = 0; a < A && !resume && !pj; ++a) {  // assembly 0 assigns the vertex ids the others look up

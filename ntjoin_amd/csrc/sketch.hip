@@ -51,6 +51,7 @@ enum Scratch {
     SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_V_DROP, SC_CNT256, SC_WAVE_TOT,
     SC_GR_HASH, SC_GR_POS, SC_GR_REC, SC_GR_CNT, SC_GR_KEY, SC_GD_HASH, SC_GD_POS, SC_GD_REC,  // device-side stretch fix-up
     SC_CS_H, SC_CS_K, SC_CS_C,  // selected candidates per k_resolve block
+    SC_GB_WORK,                 // work arrays of the long stretches (k_gap_post)
     SC_COUNT
 };
 static_assert(SC_COUNT <= 40, "scratch pool too small");
@@ -1363,31 +1364,19 @@ struct GapFixParams {
     HashTab tab;
 };
 
-// Two launches share the work by stretch length.  Blocks with 56 KB of LDS do not fit beside the other stream's hash kernel
-// (which fills the CUs to its own LDS cap): 2048 of them, nearly all with nothing to do, waited 100-160 us for places.  So
-// the common stretches (<= GAP_DEV_NSMALL k-mers: 99.5 %) get one 20 KB block each (NMAX = GAP_DEV_NSMALL, grid =
-// GAP_DEV_MAX), which fits into what the hash kernel leaves free, and the long ones are walked by a few large blocks
-// (NMAX = GAP_DEV_NMAX, BIG, grid = GAP_DEV_BIG_BLOCKS).
-constexpr uint32_t GAP_DEV_NSMALL = 1536;
-constexpr uint32_t GAP_DEV_BIG_BLOCKS = 4;
-template <int VARIANT, uint32_t NMAX, bool BIG>
-__global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
+// One stretch by one block of 256 threads.  The work arrays are the caller's: LDS for the common stretches (k_gap_fix, at
+// most GAP_DEV_NSMALL k-mers: 23 KB per block, which fits beside the other stream's hash kernel -- blocks of 56 KB, nearly
+// all with nothing to do, waited 100-160 us for a CU with room), global scratch for the rare long ones (k_gap_post's one
+// block walks them before it ranks the stretches).  All early exits are block-uniform.
+constexpr uint32_t GAP_DEV_NSMALL = 1792;
+template <int VARIANT>
+__device__ __forceinline__ void gap_fix_one(const GapFixParams &p, const uint32_t j, const uint32_t nmax, uint64_t *lh,
+                                            uint16_t *lidx0, uint16_t *lidx1, uint32_t *selbits, uint32_t *lw, uint32_t *sh,
+                                            const uint4 *tab, uint32_t *drop_idx)
 {
-    const uint32_t n_g = p.ctrl[1];
-    if (blockIdx.x >= n_g || n_g > GAP_DEV_MAX || p.ctrl[0]) return;
-    __shared__ uint64_t lh[NMAX];
-    __shared__ uint16_t lidx[2][NMAX];
-    __shared__ uint32_t selbits[NMAX / 32];
-    __shared__ uint4 tab[20];
-    __shared__ uint32_t sh[256];
-    __shared__ uint32_t drop_idx;
-    __shared__ uint32_t lw[NMAX / 16 + 1024 / 16 + 4];  // the stretch's packed bases (+ k): every later read is local
-    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
-    for (uint32_t j = blockIdx.x; j < n_g; j += gridDim.x) {
-    __syncthreads();  // (the shared arrays are reused from stretch to stretch)
+    auto lidxc = [&](uint32_t which) { return which ? lidx1 : lidx0; };
     const uint4 gp = p.gaps[j];
     const uint32_t c = gp.x, klo = gp.y, khi = gp.z, n = khi - klo + 1u, w = p.w, k = p.k;
-    if (BIG ? n <= GAP_DEV_NSMALL : n > GAP_DEV_NSMALL) continue;  // the other launch's
     if (threadIdx.x == 0) {
         p.r_key[j] = ((uint64_t)c << 32) | klo;
         p.r_cnt[j] = 0;
@@ -1399,12 +1388,12 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
         if (p.runs[mid].kidx0 <= klo) lo = mid; else hi = mid;
     }
     const Run run = p.runs[lo];
-    if (n > NMAX || n < w || khi >= run.kidx0 + run.n_kmers) {
+    if (n > nmax || n < w || khi >= run.kidx0 + run.n_kmers) {
         if (threadIdx.x == 0) p.ctrl[6] = 1;
-        continue;
+        return;
     }
-    for (uint32_t i = threadIdx.x; i < NMAX / 32; i += 256) selbits[i] = 0;
-    if (threadIdx.x == 0) drop_idx = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < nmax / 32; i += 256) selbits[i] = 0;
+    if (threadIdx.x == 0) *drop_idx = 0xFFFFFFFFu;
     __syncthreads();
     const uint64_t b_glob = run.base_off + (klo - run.kidx0);
     {
@@ -1426,7 +1415,7 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
             lh[i] = canonical<VARIANT>(h);
         }
     }
-    for (uint32_t i = threadIdx.x; i < n; i += 256) lidx[0][i] = (uint16_t)i;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) lidx0[i] = (uint16_t)i;
     __syncthreads();
     // the smaller hash, the RIGHT one of equals (btllib rescans with <=)
     auto best = [&](uint32_t a, uint32_t c2) {
@@ -1436,11 +1425,11 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
     uint32_t J = 0;
     while ((2u << J) <= w) ++J;  // 2^J <= w < 2^(J+1)
     uint32_t cur = 0;
-    for (uint32_t lv = 0; lv < J; ++lv) {  // lidx[cur][i] = arg-min over [i, i + 2^lv) -> [i, i + 2^(lv+1))
+    for (uint32_t lv = 0; lv < J; ++lv) {  // lidxc(cur)[i] = arg-min over [i, i + 2^lv) -> [i, i + 2^(lv+1))
         const uint32_t step = 1u << lv;
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            const uint32_t a = lidx[cur][i];
-            lidx[cur ^ 1][i] = (uint16_t)(i + step < n ? best(a, lidx[cur][i + step]) : a);
+            const uint32_t a = lidxc(cur)[i];
+            lidxc(cur ^ 1)[i] = (uint16_t)(i + step < n ? best(a, lidxc(cur)[i + step]) : a);
         }
         cur ^= 1;
         __syncthreads();
@@ -1448,12 +1437,12 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
     const uint32_t span = 1u << J;
     const bool drop = klo == 0 && p.ctg_drop && p.ctg_drop[c];
     for (uint32_t s = threadIdx.x; s + w <= n; s += 256) {
-        const uint32_t a = best(lidx[cur][s], lidx[cur][s + w - span]);
+        const uint32_t a = best(lidxc(cur)[s], lidxc(cur)[s + w - span]);
         if (lh[a] != 0xFFFFFFFFFFFFFFFFull) atomicOr(&selbits[a >> 5], 1u << (a & 31u));  // btllib never reports 2^64-1
-        if (s == 0 && drop) drop_idx = a;  // a piece's first window belongs to the shard before it (plan_pieces)
+        if (s == 0 && drop) *drop_idx = a;  // a piece's first window belongs to the shard before it (plan_pieces)
     }
     __syncthreads();
-    if (threadIdx.x == 0 && drop_idx != 0xFFFFFFFFu) selbits[drop_idx >> 5] &= ~(1u << (drop_idx & 31u));
+    if (threadIdx.x == 0 && *drop_idx != 0xFFFFFFFFu) selbits[*drop_idx >> 5] &= ~(1u << (*drop_idx & 31u));
     __syncthreads();
     uint32_t cnt = 0;
     for (uint32_t i = i0; i < i1 && i0 < n; ++i) cnt += (selbits[i >> 5] >> (i & 31u)) & 1u;
@@ -1462,7 +1451,7 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
     if (threadIdx.x == 0) atomicAdd(&p.ctrl[10], n);
     if (total > GAP_DEV_REG) {
         if (threadIdx.x == 0) p.ctrl[6] = 1;
-        continue;
+        return;
     }
     if (threadIdx.x == 0) p.r_cnt[j] = total;
     const uint32_t rec = p.ctg_rec[c];
@@ -1473,7 +1462,25 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
             p.r_pos[at] = run.pos0 + (klo + i - run.kidx0);
             p.r_rec[at] = rec;
         }
-    }
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
+{
+    const uint32_t n_g = p.ctrl[1], j = blockIdx.x;
+    if (j >= n_g || n_g > GAP_DEV_MAX || p.ctrl[0]) return;
+    __shared__ uint64_t lh[GAP_DEV_NSMALL];
+    __shared__ uint16_t lidx[2][GAP_DEV_NSMALL];
+    __shared__ uint32_t selbits[GAP_DEV_NSMALL / 32];
+    __shared__ uint4 tab[20];
+    __shared__ uint32_t sh[256];
+    __shared__ uint32_t drop_idx;
+    __shared__ uint32_t lw[GAP_DEV_NSMALL / 16 + 1024 / 16 + 4];  // the stretch's packed bases (+ k): every later read is local
+    const uint4 g = p.gaps[j];
+    if (g.z - g.y + 1u > GAP_DEV_NSMALL) return;  // k_gap_post takes the long ones
+    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
+    __syncthreads();
+    gap_fix_one<VARIANT>(p, j, GAP_DEV_NSMALL, lh, lidx[0], lidx[1], selbits, lw, sh, tab, &drop_idx);
 }
 
 struct GapPostParams {
@@ -1481,15 +1488,22 @@ struct GapPostParams {
     const uint32_t *r_cnt; const uint64_t *r_key;
     // the stretches in (contig, first k-mer) order: key, minimizers in the stretches before it ([n] = all), index of its region
     uint64_t *s_key; uint32_t *s_off, *s_src;
+    GapFixParams fx;     // the long stretches (more than GAP_DEV_NSMALL k-mers) are sketched here, one after the other,
+    uint32_t *big_work;  // with these GAP_BIG_WORK_WORDS words of global memory in place of k_gap_fix's LDS arrays
 };
+constexpr uint32_t GAP_BIG_WORK_WORDS = GAP_DEV_NMAX * 2 + GAP_DEV_NMAX + GAP_DEV_NMAX / 32 + (GAP_DEV_NMAX / 16 + 1024 / 16 + 4);
+constexpr uint32_t GAP_BIG_LIST = 64;  // long stretches per batch (more: the host redoes the batch)
 
 // (256 threads: a single block of 1024 had to wait for sixteen free wave slots on one CU while the other stream's hash kernel
 // held them all -- 23 us per launch under rocprofv3 for a microsecond of work)
 constexpr uint32_t GPB = 256;
+template <int VARIANT>
 __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
 {
     __shared__ uint64_t keys[GAP_DEV_MAX];
-    __shared__ uint32_t src[GAP_DEV_MAX], sh[256];
+    __shared__ uint32_t sh[256];
+    __shared__ uint4 tab[20];
+    __shared__ uint32_t big_list[GAP_BIG_LIST], n_big, drop_idx;
     const uint32_t n_g = p.ctrl[1];
     if (n_g == 0 || n_g > GAP_DEV_MAX || p.ctrl[0]) {
         if (threadIdx.x == 0) {
@@ -1498,22 +1512,44 @@ __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
         }
         return;
     }
+    // the long stretches first (about one batch in two has one at 10 candidates per window)
+    if (threadIdx.x == 0) n_big = 0;
+    if (threadIdx.x < 20) tab[threadIdx.x] = p.fx.tab.e[threadIdx.x];
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < n_g; j += GPB) {
+        const uint4 g = p.fx.gaps[j];
+        if (g.z - g.y + 1u > GAP_DEV_NSMALL) {
+            const uint32_t at = atomicAdd(&n_big, 1u);
+            if (at < GAP_BIG_LIST) big_list[at] = j;
+        }
+    }
+    __syncthreads();
+    const uint32_t nb = n_big;
+    if (nb > GAP_BIG_LIST && threadIdx.x == 0) p.ctrl[6] = 1;
+    for (uint32_t q = 0; q < min(nb, GAP_BIG_LIST); ++q) {
+        uint64_t *lh = reinterpret_cast<uint64_t *>(p.big_work);
+        uint16_t *lidx0 = reinterpret_cast<uint16_t *>(p.big_work + GAP_DEV_NMAX * 2), *lidx1 = lidx0 + GAP_DEV_NMAX;
+        uint32_t *selbits = p.big_work + GAP_DEV_NMAX * 3, *lw = selbits + GAP_DEV_NMAX / 32;
+        gap_fix_one<VARIANT>(p.fx, big_list[q], GAP_DEV_NMAX, lh, lidx0, lidx1, selbits, lw, sh, tab, &drop_idx);
+        __threadfence();
+        __syncthreads();  // (the work arrays are reused; what this block wrote to global memory is read below)
+    }
     for (uint32_t i = threadIdx.x; i < n_g; i += GPB) keys[i] = p.r_key[i];
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_g; i += GPB) {  // rank by counting: the keys (contig, first k-mer) are distinct
         const uint64_t key = keys[i];
         uint32_t r = 0;
         for (uint32_t q = 0; q < n_g; ++q) r += keys[q] < key ? 1u : 0u;
-        src[r] = i;
         p.s_key[r] = key;
         p.s_src[r] = i;
     }
+    __threadfence();
     __syncthreads();
     constexpr uint32_t PER = GAP_DEV_MAX / GPB;
     uint32_t c[PER], tot = 0;
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t r = threadIdx.x * PER + u;
-        c[u] = r < n_g ? p.r_cnt[src[r]] : 0u;
+        c[u] = r < n_g ? p.r_cnt[p.s_src[r]] : 0u;
         tot += c[u];
     }
     uint32_t run = block_exclusive<GPB / 64>(tot, sh);
@@ -2212,13 +2248,10 @@ struct Driver {
             gp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
             gp.r_key = sc(SC_GR_KEY).as<uint64_t>();
             gp.tab = h->tab;
-            if (h->cfg.variant == MXG_VARIANT_V1_MIN) {
-                hipLaunchKernelGGL((k_gap_fix<MXG_VARIANT_V1_MIN, GAP_DEV_NSMALL, false>), dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
-                hipLaunchKernelGGL((k_gap_fix<MXG_VARIANT_V1_MIN, GAP_DEV_NMAX, true>), dim3(GAP_DEV_BIG_BLOCKS), dim3(256), 0, st, gp);
-            } else {
-                hipLaunchKernelGGL((k_gap_fix<MXG_VARIANT_V2_SUM, GAP_DEV_NSMALL, false>), dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
-                hipLaunchKernelGGL((k_gap_fix<MXG_VARIANT_V2_SUM, GAP_DEV_NMAX, true>), dim3(GAP_DEV_BIG_BLOCKS), dim3(256), 0, st, gp);
-            }
+            if (h->cfg.variant == MXG_VARIANT_V1_MIN)
+                hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V1_MIN>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
+            else
+                hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V2_SUM>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
             GapPostParams pp;
             pp.ctrl = sc(SC_CTRL).as<uint32_t>();
             pp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
@@ -2226,7 +2259,13 @@ struct Driver {
             pp.s_key = sc(SC_GD_HASH).as<uint64_t>();
             pp.s_off = sc(SC_GD_POS).as<uint32_t>();
             pp.s_src = sc(SC_GD_REC).as<uint32_t>();
-            hipLaunchKernelGGL(k_gap_post, dim3(1), dim3(GPB), 0, st, pp);
+            pp.fx = gp;
+            MXG_HIP(h, sc(SC_GB_WORK).ensure((size_t)GAP_BIG_WORK_WORDS * 4));
+            pp.big_work = sc(SC_GB_WORK).as<uint32_t>();
+            if (h->cfg.variant == MXG_VARIANT_V1_MIN)
+                hipLaunchKernelGGL(k_gap_post<MXG_VARIANT_V1_MIN>, dim3(1), dim3(GPB), 0, st, pp);
+            else
+                hipLaunchKernelGGL(k_gap_post<MXG_VARIANT_V2_SUM>, dim3(1), dim3(GPB), 0, st, pp);
             MXG_HIP(h, hipGetLastError());
         }
         if ((rc = ev_next(4)) != MXG_OK) return rc;
