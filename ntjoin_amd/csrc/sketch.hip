@@ -1127,7 +1127,7 @@ struct EmitParams {
 };
 
 // number of keys < key in the sorted array keys[0..n)
-__device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *__restrict__ keys, uint32_t n, uint64_t key)
+__device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *keys, uint32_t n, uint64_t key)
 {
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
@@ -1153,8 +1153,9 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     const uint32_t n_g = p.dev_gaps && !flag && n_g_raw <= GAP_DEV_MAX ? n_g_raw : 0u;
     const uint32_t nB = n_g ? p.ovf[7] : 0u;
     const uint64_t obase = p.out_base + (p.base_in ? *p.base_in : 0ull), limit = p.out_limit;
-    if (p.dev_gaps && blockIdx.x >= p.n_tiles) {  // placement of the stretches' minimizers: one wave per stretch
-        const uint32_t r = (blockIdx.x - p.n_tiles) * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t n_place = p.dev_gaps ? GAP_DEV_MAX / 4u : 0u;  // the grid's FIRST blocks: they start at once
+    if (blockIdx.x < n_place) {  // placement of the stretches' minimizers: one wave per stretch
+        const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
         if (r >= n_g) return;
         const uint32_t g = p.s_src[r];
         const uint64_t key = p.s_key[r];
@@ -1175,19 +1176,20 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
         }
         return;
     }
-    if (blockIdx.x * TILE >= n) return;  // whole tile beyond the candidates
-    uint32_t base = blockIdx.x * TILE + threadIdx.x * TILE_PER_THREAD;
+    const uint32_t tile = blockIdx.x - n_place;
+    if (tile * TILE >= n) return;  // whole tile beyond the candidates
+    uint32_t base = tile * TILE + threadIdx.x * TILE_PER_THREAD;
     const uint32_t fl = p.cs_h ? 0u : load_flags4(p.sel, base, n);
     uint32_t c = count_flags4(fl);
     uint32_t before;
     if (p.bsum) {
-        before = p.bsum[blockIdx.x];
+        before = p.bsum[tile];
     } else {
         __shared__ uint32_t sh_before;
         if (threadIdx.x < 64) {
-            const uint32_t bef = count_prefix(p.cnt256, p.sel_sup, blockIdx.x * (TILE / RK));
+            const uint32_t bef = count_prefix(p.cnt256, p.sel_sup, tile * (TILE / RK));
             if (threadIdx.x == 0) sh_before = bef;
-            if ((n - 1) / TILE == blockIdx.x) {  // the tile holding the last candidate also reports the totals
+            if ((n - 1) / TILE == tile) {  // the tile holding the last candidate also reports the totals
                 const uint32_t all = count_prefix(p.cnt256, p.sel_sup, (n + RK - 1u) / RK);
                 const uint64_t total = (uint64_t)all + nB;
                 if (threadIdx.x == 0) {
@@ -1219,7 +1221,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
         pre[0] = 0;
 #pragma unroll
         for (uint32_t u = 0; u < TILE / RK; ++u) {
-            const uint32_t b = blockIdx.x * (TILE / RK) + u;
+            const uint32_t b = tile * (TILE / RK) + u;
             pre[u + 1] = pre[u] + (b < nblk ? p.cnt256[b] : 0u);
         }
         tile_total = pre[TILE / RK];
@@ -1235,12 +1237,12 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
             static_assert(TILE / RK == 4, "the selects below spell out four blocks per tile");
             const uint32_t u = r >= pre[3] ? 3u : r >= pre[2] ? 2u : r >= pre[1] ? 1u : 0u;
             const uint32_t poff = r >= pre[3] ? pre[3] : r >= pre[2] ? pre[2] : r >= pre[1] ? pre[1] : 0u;
-            const uint32_t src = (blockIdx.x * (TILE / RK) + u) * RK + (r - poff);
+            const uint32_t src = (tile * (TILE / RK) + u) * RK + (r - poff);
             hsh = p.cs_h[src];
             kx = p.cs_k[src];
             ctg = p.cs_c[src];
         } else {
-            const uint32_t i = blockIdx.x * TILE + picked[r];
+            const uint32_t i = tile * TILE + picked[r];
             hsh = p.ch[i];
             kx = p.ck[i];
             ctg = p.cc[i] & 0x7FFFFFFFu;
@@ -1248,11 +1250,20 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     };
     // A few hundred stretches among a million minimizers: almost every tile lies between two neighbouring stretches, so the
     // tile's first and last key are searched once and only a tile that straddles a stretch searches per minimizer.
+    // (up to EK stretch keys are copied to LDS in one round trip: the searches then do not walk through L2)
+    constexpr uint32_t EK = 512;
+    __shared__ uint64_t skeys[EK];
     __shared__ uint32_t lb_edge[2];
+    const uint64_t *keys = p.s_key;
+    if (n_g && n_g <= EK) {
+        for (uint32_t q = threadIdx.x; q < n_g; q += 256u) skeys[q] = p.s_key[q];
+        keys = skeys;
+        __syncthreads();
+    }
     if (n_g && tile_total && (threadIdx.x == 0 || threadIdx.x == 64)) {
         uint64_t hsh; uint32_t kx, ctg;
         item(threadIdx.x ? tile_total - 1u : 0u, hsh, kx, ctg);
-        lb_edge[threadIdx.x ? 1 : 0] = lower_bound_u64(p.s_key, n_g, ((uint64_t)ctg << 32) | kx);
+        lb_edge[threadIdx.x ? 1 : 0] = lower_bound_u64(keys, n_g, ((uint64_t)ctg << 32) | kx);
     }
     if (n_g) __syncthreads();
     const uint64_t o0 = obase + before;
@@ -1263,7 +1274,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
         uint64_t o = o0 + r;
         if (n_g) {
             uint32_t lb = lb_edge[0];
-            if (lb_edge[1] != lb) lb = lower_bound_u64(p.s_key, n_g, ((uint64_t)ctg << 32) | kx);
+            if (lb_edge[1] != lb) lb = lower_bound_u64(keys, n_g, ((uint64_t)ctg << 32) | kx);
             o += p.s_off[lb];  // (s_off[n_g] = all of them)
         }
         if (o >= limit) continue;  // (speculative emit into arrays sized by an estimate)
