@@ -247,6 +247,39 @@ __device__ __forceinline__ void init_pos(H2 &h, const uint32_t *__restrict__ pac
     }
 }
 
+// split rotation by 16 positions
+__device__ __forceinline__ void srol16(uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t b32 = hi & 1u, W = hi >> 1;
+    const uint32_t nlo = (lo << 16) | (b32 << 15) | (lo >> 17);
+    const uint32_t nW = ((W << 16) | (W >> 15)) & 0x7FFFFFFFu;
+    hi = (nW << 1) | ((lo >> 16) & 1u);
+    lo = nlo;
+}
+
+// k = 32 from HALF the position tables (16 KB): half[j][v] = {srol^{4(3-j)} f4[v], srol^{4j} r4[v]}, j = 0..3.  Bytes 0..3
+// of the k-mer give Fa, Ra and bytes 4..7 give Fb, Rb through the same four tables;  F = srol^16(Fa) ^ Fb,
+// R = Ra ^ srol^16(Rb).  8 lookups, 32 XORs and two rotations where init_direct walks 16 rotations by 4 (k_hash_sparse, once
+// per strip, in the LDS the kernel reserves anyway).
+__device__ __forceinline__ void init32_half(H2 &h, const uint32_t *__restrict__ packed, uint64_t b, const uint4 *half)
+{
+    const uint32_t *pw = packed + (b >> 4);
+    const uint32_t sh = ((uint32_t)b & 15u) * 2u;
+    const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    uint4 a = make_uint4(0u, 0u, 0u, 0u), c = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+        const uint4 e0 = half[u * 256u + ((lo >> (8 * u)) & 255u)];
+        const uint4 e1 = half[u * 256u + ((hi >> (8 * u)) & 255u)];
+        a.x ^= e0.x; a.y ^= e0.y; a.z ^= e0.z; a.w ^= e0.w;
+        c.x ^= e1.x; c.y ^= e1.y; c.z ^= e1.z; c.w ^= e1.w;
+    }
+    srol16(a.x, a.y);
+    srol16(c.z, c.w);
+    h.flo = a.x ^ c.x; h.fhi = a.y ^ c.y; h.rlo = a.z ^ c.z; h.rhi = a.w ^ c.w;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // dense hash kernel
 // ------------------------------------------------------------------------------------------------------
@@ -386,7 +419,17 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     __shared__ uint4 tab[20];    // full step table: only init_direct's k%4 remainder uses it
     __shared__ uint2 ring[16];   // top rings of the rolling entries (out<<2 | in): {Tf, Tr<<1}
     __shared__ uint4 btab[256];  // byte table of init_direct
-    btab[threadIdx.x] = p.init_tab[threadIdx.x];
+    extern __shared__ uint4 half_tab[];  // k = 32 (p.five): 4 x 256 entries of init32_half, in the LDS that caps the residency
+    const bool use_half = p.five != 0 && p.k == 32u;
+    if (use_half) {
+        for (uint32_t i = threadIdx.x; i < 1024u; i += 256u) {
+            const uint32_t j = i >> 8, v = i & 255u;
+            const uint4 f = p.init_tab[256u + (j + 4u) * 256u + v], r = p.init_tab[256u + j * 256u + v];
+            half_tab[i] = make_uint4(f.x, f.y, r.z, r.w);
+        }
+    } else {
+        btab[threadIdx.x] = p.init_tab[threadIdx.x];
+    }
     if (threadIdx.x < 20) {
         const uint4 e = p.tab.e[threadIdx.x];
         tab[threadIdx.x] = e;
@@ -426,7 +469,8 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     uint32_t x, y;
     {
         H2 h = {0u, 0u, 0u, 0u};
-        init_direct(h, p.packed, b, k, btab, tab);  // replaces k rolling warm-up steps per strip
+        if (use_half) init32_half(h, p.packed, b, half_tab);
+        else init_direct(h, p.packed, b, k, btab, tab);  // replaces k rolling warm-up steps per strip
         x = ~(h.fhi >> 1);
         y = ~h.rhi;
     }
@@ -2154,24 +2198,23 @@ struct Driver {
         sp.n_tiles = g.n_blocks;
         dim3 grid(sparse_grid(g.n_blocks, g.nk)), block(256);
         static const int abl = getenv("MXG_ABLATE") ? atoi(getenv("MXG_ABLATE")) : 0;  // profiling only
+        // Every lane keeps one 128-byte line of packed bases "open" for 32 block iterations (16 bases = 4 bytes per iteration),
+        // so the waves resident on an XCD hold (waves x 64 x 128 B) of live lines.  At full occupancy that is more than the
+        // XCD's 4 MB of L2 once the input no longer fits the caches behind it: measured at 3 Gbp (PMC FETCH_SIZE x 2), the
+        // kernel fetched 336 MB for 115 MB of bases.  Dynamic LDS caps the residency at six blocks per CU (18 KB; five with
+        // 24 KB: 1285-1308 Gbp/s against 1304-1331; none: 1257).  It also keeps the other stream's kernels from moving in
+        // beside this one, which costs both more than it gains.  Small inputs (cache-resident) keep full occupancy.  At
+        // k = 32 the first 16 KB of it hold init32_half's tables.
+        size_t pad = (size_t)env_u64("MXG_HASH_LDS", g.nk >= (256ull << 20) ? 18000 : 0);
+        if (sp.five && sp.k == 32) pad = std::max<size_t>(pad, 16384);
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V1_MIN>), grid, block, 0, st, sp);
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V1_MIN>), grid, block, pad, st, sp);
         else if (abl == 1)
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 1>), grid, block, 0, st, sp);
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 1>), grid, block, pad, st, sp);
         else if (abl == 2)
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 2>), grid, block, 0, st, sp);
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 2>), grid, block, pad, st, sp);
         else
-        {
-            // Every lane keeps one 128-byte line of packed bases "open" for 32 block iterations (16 bases = 4 bytes per
-            // iteration), so the waves resident on an XCD hold (waves x 64 x 128 B) of live lines.  At full occupancy that is
-            // more than the XCD's 4 MB of L2 once the input no longer fits the caches behind it: measured at 3 Gbp (PMC
-            // FETCH_SIZE x 2), the kernel fetched 336 MB for 115 MB of bases.  Unused dynamic LDS caps the residency at six
-            // blocks per CU (18 KB; five with 24 KB: 1285-1308 Gbp/s against 1304-1331; none: 1257).  It also keeps the other
-            // stream's kernels from moving in beside this one, which costs both more than it gains.  Small inputs
-            // (cache-resident) keep full occupancy.
-            const size_t pad = (size_t)env_u64("MXG_HASH_LDS", g.nk >= (256ull << 20) ? 18000 : 0);
-            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), dim3(sparse_grid(g.n_blocks, g.nk)), block, pad, st, sp);
-        }
+            hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM>), grid, block, pad, st, sp);
         if ((rc = ev_end()) != MXG_OK) return rc;
         MXG_HIP(h, hipGetLastError());
         // order the candidates: exclusive scan of per-strip counts (total = number of candidates), then scatter
