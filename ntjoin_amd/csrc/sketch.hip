@@ -1130,6 +1130,7 @@ __global__ __launch_bounds__(256) void k_count_n(const uint8_t *__restrict__ sel
 
 constexpr uint32_t GAP_DEV_MAX = 2048;  // stretches per batch the device route holds (defined here: k_emit places them)
 constexpr uint32_t GAP_DEV_REG = 64;    // minimizers per stretch
+constexpr uint32_t EMIT_COMPACT_BLOCKS = 16;  // k_resolve blocks per k_emit tile on the sparse path (a power of two)
 struct EmitParams {
     const uint8_t *sel;
     const uint64_t *ch;
@@ -1220,20 +1221,33 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
         }
         return;
     }
+    // compact mode (the sparse path: k_resolve laid the selected candidates out per block): a tile = ECB blocks of k_resolve,
+    // ~400 minimizers; flag mode (dense path): a tile = TILE candidates
+    constexpr uint32_t ECB = EMIT_COMPACT_BLOCKS;
     const uint32_t tile = blockIdx.x - n_place;
-    if (tile * TILE >= n) return;  // whole tile beyond the candidates
+    const uint32_t span = p.cs_h ? ECB * RK : (uint32_t)TILE;
+    if ((uint64_t)tile * span >= n) return;  // whole tile beyond the candidates
     uint32_t base = tile * TILE + threadIdx.x * TILE_PER_THREAD;
     const uint32_t fl = p.cs_h ? 0u : load_flags4(p.sel, base, n);
     uint32_t c = count_flags4(fl);
     uint32_t before;
+    __shared__ uint32_t spre[ECB + 1];  // compact mode: the selected counts of the tile's blocks as a prefix
     if (p.bsum) {
         before = p.bsum[tile];
     } else {
         __shared__ uint32_t sh_before;
         if (threadIdx.x < 64) {
-            const uint32_t bef = count_prefix(p.cnt256, p.sel_sup, tile * (TILE / RK));
+            const uint32_t bpt = span / RK;  // k_resolve blocks per tile
+            const uint32_t bef = count_prefix(p.cnt256, p.sel_sup, tile * bpt);
             if (threadIdx.x == 0) sh_before = bef;
-            if ((n - 1) / TILE == tile) {  // the tile holding the last candidate also reports the totals
+            if (p.cs_h) {
+                const uint32_t nblk = (n + RK - 1u) / RK, b = tile * ECB + threadIdx.x;
+                const uint32_t cb = threadIdx.x < ECB && b < nblk ? p.cnt256[b] : 0u;
+                const uint32_t incl = wave_inclusive_u32(cb, threadIdx.x);
+                if (threadIdx.x < ECB) spre[threadIdx.x + 1] = incl;
+                if (threadIdx.x == 0) spre[0] = 0;
+            }
+            if ((n - 1) / span == tile) {  // the tile holding the last candidate also reports the totals
                 const uint32_t all = count_prefix(p.cnt256, p.sel_sup, (n + RK - 1u) / RK);
                 const uint64_t total = (uint64_t)all + nB;
                 if (threadIdx.x == 0) {
@@ -1259,16 +1273,8 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     // of a few lanes per wave.
     __shared__ uint16_t picked[TILE];
     uint32_t tile_total;
-    uint32_t pre[TILE / RK + 1];  // compact mode: the tile = TILE / RK blocks of k_resolve, their selected counts as a prefix
     if (p.cs_h) {
-        const uint32_t nblk = (n + RK - 1u) / RK;
-        pre[0] = 0;
-#pragma unroll
-        for (uint32_t u = 0; u < TILE / RK; ++u) {
-            const uint32_t b = tile * (TILE / RK) + u;
-            pre[u + 1] = pre[u] + (b < nblk ? p.cnt256[b] : 0u);
-        }
-        tile_total = pre[TILE / RK];
+        tile_total = spre[ECB];
     } else {
         uint32_t l = block_exclusive_256(c, sh);
         tile_total = sh[255];
@@ -1278,10 +1284,11 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     }
     auto item = [&](uint32_t r, uint64_t &hsh, uint32_t &kx, uint32_t &ctg) {  // minimizer r of the tile
         if (p.cs_h) {
-            static_assert(TILE / RK == 4, "the selects below spell out four blocks per tile");
-            const uint32_t u = r >= pre[3] ? 3u : r >= pre[2] ? 2u : r >= pre[1] ? 1u : 0u;
-            const uint32_t poff = r >= pre[3] ? pre[3] : r >= pre[2] ? pre[2] : r >= pre[1] ? pre[1] : 0u;
-            const uint32_t src = (tile * (TILE / RK) + u) * RK + (r - poff);
+            uint32_t u = 0;  // the block holding it: last u with spre[u] <= r
+#pragma unroll
+            for (uint32_t st = ECB / 2; st > 0; st >>= 1)
+                if (spre[u + st] <= r) u += st;
+            const uint32_t src = (tile * ECB + u) * RK + (r - spre[u]);
             hsh = p.cs_h[src];
             kx = p.cs_k[src];
             ctg = p.cs_c[src];
@@ -1555,7 +1562,7 @@ constexpr uint32_t GPB = 256;
 template <int VARIANT>
 __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
 {
-    __shared__ uint64_t keys[GAP_DEV_MAX];
+    __shared__ uint64_t keys[512];
     __shared__ uint32_t sh[256];
     __shared__ uint4 tab[20];
     __shared__ uint32_t big_list[GAP_BIG_LIST], n_big, drop_idx;
@@ -1589,14 +1596,34 @@ __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
         __threadfence();
         __syncthreads();  // (the work arrays are reused; what this block wrote to global memory is read below)
     }
-    for (uint32_t i = threadIdx.x; i < n_g; i += GPB) keys[i] = p.r_key[i];
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_g; i += GPB) {  // rank by counting: the keys (contig, first k-mer) are distinct
-        const uint64_t key = keys[i];
-        uint32_t r = 0;
-        for (uint32_t q = 0; q < n_g; ++q) r += keys[q] < key ? 1u : 0u;
-        p.s_key[r] = key;
-        p.s_src[r] = i;
+    // rank by counting (the keys (contig, first k-mer) are distinct), 512 keys at a time through 4 KB of LDS: with all
+    // GAP_DEV_MAX keys in LDS (16 KB) the block often waited tens of microseconds for a CU with that much room
+    constexpr uint32_t PERK = GAP_DEV_MAX / GPB, CH = 512;
+    uint64_t mine[PERK];
+    uint32_t rank[PERK];
+#pragma unroll
+    for (uint32_t u = 0; u < PERK; ++u) {
+        const uint32_t i = threadIdx.x + u * GPB;
+        mine[u] = i < n_g ? p.r_key[i] : ~0ull;
+        rank[u] = 0;
+    }
+    for (uint32_t c0 = 0; c0 < n_g; c0 += CH) {
+        const uint32_t cn = min(CH, n_g - c0);
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < cn; q += GPB) keys[q] = p.r_key[c0 + q];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < PERK; ++u)
+            if (threadIdx.x + u * GPB < n_g)
+                for (uint32_t q = 0; q < cn; ++q) rank[u] += keys[q] < mine[u] ? 1u : 0u;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < PERK; ++u) {
+        const uint32_t i = threadIdx.x + u * GPB;
+        if (i < n_g) {
+            p.s_key[rank[u]] = mine[u];
+            p.s_src[rank[u]] = i;
+        }
     }
     __threadfence();
     __syncthreads();
@@ -1936,7 +1963,7 @@ struct Driver {
         ep.base_in = io ? io->base_in : nullptr;
         ep.base_out = io ? io->base_out : nullptr;
         ep.dev_gaps = io && io->dev_gaps ? 1u : 0u;
-        ep.n_tiles = (n_cap + TILE - 1) / TILE;
+        ep.n_tiles = fused ? (n_cap + EMIT_COMPACT_BLOCKS * RK - 1) / (EMIT_COMPACT_BLOCKS * RK) : (n_cap + TILE - 1) / TILE;
         ep.s_key = nullptr;
         ep.s_off = ep.s_src = nullptr;
         ep.gaps = nullptr;
