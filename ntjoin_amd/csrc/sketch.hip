@@ -1831,7 +1831,7 @@ struct Driver {
     {
         if (!n_cap) return MXG_OK;
         MXG_HIP(h, sc(SC_SEL).ensure(std::max<uint32_t>(n_cap, 16)));
-        const uint32_t blocks = (n_cap + RK - 1) / RK;
+        const uint32_t blocks = ((grid_cand ? std::min(grid_cand, n_cap) : n_cap) + RK - 1) / RK;
         MXG_HIP(h, sc(SC_CNT256).ensure((size_t)blocks * 4 + 64));
         uint32_t *ctrl = sc(SC_CTRL).as<uint32_t>();
         ResolveParams rp;
@@ -1920,6 +1920,11 @@ struct Driver {
     // offsets: SC_BSUM per 1024-tile (after resolve_and_count) or, fused = true, from SC_CNT256 (after resolve_count)
     uint32_t *n_out = nullptr;  // see EmitParams::n_out (set by sketch_assemblies for the fused call)
     bool few_cand = false;      // <= 12 candidates per window: smaller k_reorder blocks and k_resolve halos (set per batch)
+    // Batches enqueued without a host sync: k_resolve and k_emit are launched for the EXPECTED number of candidates (+ 20 %)
+    // instead of the arrays' capacity (about 2.7 x the expectation), so that half their blocks do not start just to find
+    // nothing to do -- blocks that each hold a wave slot for a memory round trip beside the other stream's hash kernel.  A batch
+    // with more candidates than that never reports (no tile holds its last candidate): the host redoes the assembly.
+    uint32_t grid_cand = 0;     // 0: the capacity
     // how a batch hangs together with the batches before it and with the device-side stretch fix-up (see EmitParams)
     struct ChainIO {
         const uint64_t *base_in = nullptr;
@@ -1963,7 +1968,8 @@ struct Driver {
         ep.base_in = io ? io->base_in : nullptr;
         ep.base_out = io ? io->base_out : nullptr;
         ep.dev_gaps = io && io->dev_gaps ? 1u : 0u;
-        ep.n_tiles = fused ? (n_cap + EMIT_COMPACT_BLOCKS * RK - 1) / (EMIT_COMPACT_BLOCKS * RK) : (n_cap + TILE - 1) / TILE;
+        const uint32_t n_grid = grid_cand ? std::min(grid_cand, n_cap) : n_cap;
+        ep.n_tiles = fused ? (n_grid + EMIT_COMPACT_BLOCKS * RK - 1) / (EMIT_COMPACT_BLOCKS * RK) : (n_grid + TILE - 1) / TILE;
         ep.s_key = nullptr;
         ep.s_off = ep.s_src = nullptr;
         ep.gaps = nullptr;
@@ -2299,6 +2305,19 @@ struct Driver {
         // resolve + speculative emit straight into the output arrays (guarded by their capacity): on the common path
         // (no gap, no overflow) the batch then needs a single host sync
         if ((rc = ev_next(3)) != MXG_OK) return rc;
+        grid_cand = 0;
+        if (const uint64_t by_est = io ? env_u64("MXG_GRID_BY_ESTIMATE", 1) : 0) {
+            // (min(fwd, rev) < tau: either strand may pass)
+            const uint64_t expect = (uint64_t)((double)g.nk * (double)sp.tau_hi / 4294967296.0) *
+                                    (h->cfg.variant == MXG_VARIANT_V1_MIN ? 2u : 1u);
+            const uint64_t hint = cand_hint != 0xFFFFFFFFu ? cand_hint : 0;
+            uint64_t gc = std::max(expect, hint) * 6 / 5 + 16384;
+            if (by_est == 2) gc = std::max<uint64_t>(RK, expect / 2);  // (test knob: too small on purpose)
+            // a whole number of k_emit tiles, so that k_resolve (256 candidates per block) and k_emit cover the same candidates:
+            // a tile that reports must have had all its blocks resolved
+            constexpr uint64_t ET = (uint64_t)EMIT_COMPACT_BLOCKS * RK;
+            grid_cand = (uint32_t)std::min<uint64_t>(n_cap, (gc + ET - 1) / ET * ET);
+        }
         if ((rc = resolve_count(T, n_cap, (uint32_t)g.c0, (uint32_t)g.c1, (uint64_t)tau_hi << 32,
                                 cand_hint != 0xFFFFFFFFu ? cand_hint : a->cand_hint)) != MXG_OK) return rc;
         const bool dev = io && io->dev_gaps;
@@ -2352,7 +2371,9 @@ struct Driver {
         if ((rc = ev_next(4)) != MXG_OK) return rc;
         // the batch before this one (same assembly, other stream) must have passed its count on
         if (io && io->wait) MXG_HIP(h, hipStreamWaitEvent(st, io->wait, 0));
-        if ((rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host, io)) != MXG_OK) return rc;
+        rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host, io);
+        grid_cand = 0;
+        if (rc != MXG_OK) return rc;
         return ev_end();
     }
 

@@ -199,3 +199,22 @@ def test_exact_hash_from_position_tables_every_group_shape(oracle, variant):
             os.environ.pop("MXG_REORDER_W", None)
         else:
             os.environ["MXG_REORDER_W"] = saved
+
+
+def test_more_candidates_than_the_launch_was_sized_for(oracle, knobs):
+    """Batches enqueued without a host sync launch k_resolve / k_emit for the expected number of candidates + 20 %; a batch
+    with more never reports and the host redoes the assembly.  MXG_GRID_BY_ESTIMATE=2 sizes the launch for HALF the
+    expectation, so every batch takes that way out -- with one batch per assembly, with several, with stretches."""
+    saved = os.environ.get("MXG_GRID_BY_ESTIMATE")
+    os.environ["MXG_GRID_BY_ESTIMATE"] = "2"
+    try:
+        _check(oracle, _records(21), 32, 200)
+        knobs["MXG_SPARSE_BATCH_KMERS"] = "50000"
+        _check(oracle, _records(22), 32, 200)
+        st = _check(oracle, _records(23), 32, 500, cand_per_window=2)
+        assert st["dense_kmers"] > 0
+    finally:
+        if saved is None:
+            os.environ.pop("MXG_GRID_BY_ESTIMATE", None)
+        else:
+            os.environ["MXG_GRID_BY_ESTIMATE"] = saved
