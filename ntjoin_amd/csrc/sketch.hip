@@ -1597,14 +1597,18 @@ __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
         __syncthreads();  // (the work arrays are reused; what this block wrote to global memory is read below)
     }
     // rank by counting (the keys (contig, first k-mer) are distinct), 512 keys at a time through 4 KB of LDS: with all
-    // GAP_DEV_MAX keys in LDS (16 KB) the block often waited tens of microseconds for a CU with that much room
+    // GAP_DEV_MAX keys in LDS (16 KB) the block often waited tens of microseconds for a CU with that much room.  Every
+    // thread asks for its keys AND their stretches' counts at once; with at most CH stretches (the usual case) the counts
+    // reach their ranks through LDS, so that nothing written here is read back from global memory.
     constexpr uint32_t PERK = GAP_DEV_MAX / GPB, CH = 512;
+    __shared__ uint32_t cnt_sorted[CH];
     uint64_t mine[PERK];
-    uint32_t rank[PERK];
+    uint32_t rank[PERK], mcnt[PERK];
 #pragma unroll
     for (uint32_t u = 0; u < PERK; ++u) {
         const uint32_t i = threadIdx.x + u * GPB;
         mine[u] = i < n_g ? p.r_key[i] : ~0ull;
+        mcnt[u] = i < n_g ? p.r_cnt[i] : 0u;
         rank[u] = 0;
     }
     for (uint32_t c0 = 0; c0 < n_g; c0 += CH) {
@@ -1617,21 +1621,23 @@ __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
             if (threadIdx.x + u * GPB < n_g)
                 for (uint32_t q = 0; q < cn; ++q) rank[u] += keys[q] < mine[u] ? 1u : 0u;
     }
+    const bool small = n_g <= CH;
 #pragma unroll
     for (uint32_t u = 0; u < PERK; ++u) {
         const uint32_t i = threadIdx.x + u * GPB;
         if (i < n_g) {
             p.s_key[rank[u]] = mine[u];
             p.s_src[rank[u]] = i;
+            if (small) cnt_sorted[rank[u]] = mcnt[u];
         }
     }
-    __threadfence();
+    if (!small) __threadfence();
     __syncthreads();
     constexpr uint32_t PER = GAP_DEV_MAX / GPB;
     uint32_t c[PER], tot = 0;
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t r = threadIdx.x * PER + u;
-        c[u] = r < n_g ? p.r_cnt[p.s_src[r]] : 0u;
+        c[u] = r < n_g ? (small ? cnt_sorted[r] : p.r_cnt[p.s_src[r]]) : 0u;
         tot += c[u];
     }
     uint32_t run = block_exclusive<GPB / 64>(tot, sh);
@@ -1920,7 +1926,7 @@ struct Driver {
     // offsets: SC_BSUM per 1024-tile (after resolve_and_count) or, fused = true, from SC_CNT256 (after resolve_count)
     uint32_t *n_out = nullptr;  // see EmitParams::n_out (set by sketch_assemblies for the fused call)
     bool few_cand = false;      // <= 12 candidates per window: smaller k_reorder blocks and k_resolve halos (set per batch)
-    // Batches enqueued without a host sync: k_resolve and k_emit are launched for the EXPECTED number of candidates (+ 20 %)
+    // Batches enqueued without a host sync: k_resolve and k_emit are launched for the EXPECTED number of candidates (+ 30 %)
     // instead of the arrays' capacity (about 2.7 x the expectation), so that half their blocks do not start just to find
     // nothing to do -- blocks that each hold a wave slot for a memory round trip beside the other stream's hash kernel.  A batch
     // with more candidates than that never reports (no tile holds its last candidate): the host redoes the assembly.
@@ -2311,7 +2317,7 @@ struct Driver {
             const uint64_t expect = (uint64_t)((double)g.nk * (double)sp.tau_hi / 4294967296.0) *
                                     (h->cfg.variant == MXG_VARIANT_V1_MIN ? 2u : 1u);
             const uint64_t hint = cand_hint != 0xFFFFFFFFu ? cand_hint : 0;
-            uint64_t gc = std::max(expect, hint) * 6 / 5 + 16384;
+            uint64_t gc = std::max(expect, hint) * 13 / 10 + 16384;
             if (by_est == 2) gc = std::max<uint64_t>(RK, expect / 2);  // (test knob: too small on purpose)
             // a whole number of k_emit tiles, so that k_resolve (256 candidates per block) and k_emit cover the same candidates:
             // a tile that reports must have had all its blocks resolved
