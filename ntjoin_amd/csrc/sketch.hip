@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     // A few hundred stretches among a million minimizers: almost every tile lies between two neighbouring stretches, so the
     // tile's first and last key are searched once and only a tile that straddles a stretch searches per minimizer.
     // (up to EK stretch keys are copied to LDS in one round trip: the searches then do not walk through L2)
-    constexpr uint32_t EK = 512;
+    constexpr uint32_t EK = 1024;
     __shared__ uint64_t skeys[EK];
     __shared__ uint32_t lb_edge[2];
     const uint64_t *keys = p.s_key;
@@ -2597,7 +2597,7 @@ static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
     sp.batch_kmers = 0;
     if (sp.dev_gaps) {  // a candidate is followed by a stretch with probability e^-c
         const double per_kmer = sp.frac * std::exp(-(double)c);
-        const double lim = (double)(GAP_DEV_MAX / 4) / std::max(per_kmer, 1e-30);
+        const double lim = (double)env_u64("MXG_GAP_BUDGET", GAP_DEV_MAX / 4) / std::max(per_kmer, 1e-30);  // expected stretches per batch
         if (lim < (double)SPARSE_BATCH_KMERS) sp.batch_kmers = std::max<uint64_t>((uint64_t)lim, 1u << 20);
     }
     return sp;
