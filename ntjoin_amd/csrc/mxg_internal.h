@@ -174,6 +174,7 @@ struct mxg_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // second stream of the pipelined multi-assembly sketch (always library-owned)
+    uint64_t timing_batches = 0;    // batches enqueued with MXG_FLAG_TIMING (MXG_TIMING_SAMPLE picks one in n)
     hipStream_t stream_x[2] = {nullptr, nullptr};  // third / fourth stream: batches of multi-batch assemblies (created on first use)
     bool own_stream = false;
     std::string err;

@@ -2185,6 +2185,15 @@ struct Driver {
                        OutArrays &out, uint32_t *ctrl_host, uint32_t *n_cap_out, const ChainIO *io = nullptr,
                        uint32_t cand_hint = 0xFFFFFFFFu)
     {
+        // MXG_TIMING_SAMPLE=n: event pairs around one batch in n only (four event records per batch cost 2 % of the step at
+        // 3 Gbp; bench.py asks for one in four and scales the sums by the bases they cover)
+        struct TimingGuard {
+            bool &t; bool saved;
+            TimingGuard(bool &t_, bool now) : t(t_), saved(t_) { t = now; }
+            ~TimingGuard() { t = saved; }
+        };
+        const uint64_t t_sample = timing && !fine && io ? env_u64("MXG_TIMING_SAMPLE", 1) : 1;
+        TimingGuard timing_guard(timing, timing && (t_sample <= 1 || (h->timing_batches++ % t_sample) == 0));
         const uint32_t S = a->S_sparse;
         few_cand = (double)tau_hi / 4294967296.0 * (double)h->cfg.w <= 12.5;
         MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
