@@ -218,3 +218,49 @@ def test_more_candidates_than_the_launch_was_sized_for(oracle, knobs):
             os.environ.pop("MXG_GRID_BY_ESTIMATE", None)
         else:
             os.environ["MXG_GRID_BY_ESTIMATE"] = saved
+
+
+def _repeat_rich_records(seed, n_rec, rec_len):
+    """records with the structure real genomes add to random sequence: interspersed copies of a few repeat families
+    (5-15 % diverged), tandem arrays of a 171-base unit, homopolymer / dinucleotide runs and a few N gaps"""
+    rng = random.Random(seed)
+    fams = ["".join(rng.choice("ACGT") for _ in range(rng.choice([300, 1200, 6000]))) for _ in range(6)]
+    sat = "".join(rng.choice("ACGT") for _ in range(171))
+    recs = []
+    for r in range(n_rec):
+        parts, n = [], 0
+        while n < rec_len:
+            kind = rng.random()
+            if kind < 0.55:
+                p = "".join(rng.choice("ACGT") for _ in range(rng.randint(500, 8000)))
+            elif kind < 0.85:
+                f = list(rng.choice(fams))
+                div = rng.uniform(0.05, 0.15)
+                for i in range(len(f)):
+                    if rng.random() < div:
+                        f[i] = rng.choice("ACGT")
+                p = "".join(f)
+                if rng.random() < 0.5:
+                    p = p[::-1].translate(str.maketrans("ACGT", "TGCA"))
+            elif kind < 0.93:
+                p = sat * rng.randint(20, 120)
+            elif kind < 0.98:
+                p = rng.choice(["A", "T", "AC", "AT", "GGC"]) * rng.randint(30, 900)
+            else:
+                p = "N" * rng.choice([1, 20, 300])
+            parts.append(p)
+            n += len(p)
+        recs.append((f"chr{r}", "".join(parts)[:rec_len]))
+    return recs
+
+
+@pytest.mark.parametrize("w,cand", [(200, 6), (500, 10)])
+def test_repeat_rich_genome_on_the_device_route(oracle, dev_knobs, w, cand):
+    """what random test genomes lack: repeat families, satellite arrays, low-complexity runs -- candidate floods (one k-mer
+    below tau occurs thousands of times), stretches with more minimizers than a region holds, arena slices that overflow.
+    Through the route genome-scale assemblies take, in several chained batches; bit-exact against the oracle."""
+    dev_knobs["MXG_DEV_GAPS"] = "1"
+    dev_knobs["MXG_SPARSE_BATCH_KMERS"] = "400000"
+    recs = _repeat_rich_records(5, 6, 250_000)
+    st = _check(oracle, recs, 32, w, cand_per_window=cand)
+    assert st["candidates"] > 0
