@@ -38,6 +38,18 @@ KERNEL(k_addco, "v_add_co_u32 %0, vcc, %0, %8\n", "v_addc_co_u32 %1, vcc, %1, %9
 KERNEL(k_cmp, "v_cmp_gt_u32 vcc, %10, %0\n", "v_cmp_gt_u32 vcc, %10, %1\n", "v_cmp_gt_u32 vcc, %10, %2\n", "v_cmp_gt_u32 vcc, %10, %3\n")
 KERNEL(k_bfe, "v_bfe_u32 %0, %0, 2, 30\n", "v_bfe_u32 %1, %1, 2, 30\n", "v_bfe_u32 %2, %2, 2, 30\n", "v_bfe_u32 %3, %3, 2, 30\n")
 KERNEL(k_mov, "v_mov_b32 %0, %8\n", "v_mov_b32 %1, %8\n", "v_mov_b32 %2, %8\n", "v_mov_b32 %3, %8\n")
+// round 3: the instructions of the bit-sliced ring filter (hash_bs) and candidates for it
+KERNEL(k_perm, "v_perm_b32 %0, %0, %8, %9\n", "v_perm_b32 %1, %1, %8, %9\n", "v_perm_b32 %2, %2, %8, %9\n", "v_perm_b32 %3, %3, %8, %9\n")
+KERNEL(k_xnor, "v_xnor_b32 %0, %0, %8\n", "v_xnor_b32 %1, %1, %8\n", "v_xnor_b32 %2, %2, %8\n", "v_xnor_b32 %3, %3, %8\n")
+KERNEL(k_not, "v_not_b32 %0, %0\n", "v_not_b32 %1, %1\n", "v_not_b32 %2, %2\n", "v_not_b32 %3, %3\n")
+KERNEL(k_bcnt, "v_bcnt_u32_b32 %0, %8, %0\n", "v_bcnt_u32_b32 %1, %8, %1\n", "v_bcnt_u32_b32 %2, %8, %2\n", "v_bcnt_u32_b32 %3, %8, %3\n")
+KERNEL(k_bfi, "v_bfi_b32 %0, %8, %0, %9\n", "v_bfi_b32 %1, %8, %1, %9\n", "v_bfi_b32 %2, %8, %2, %9\n", "v_bfi_b32 %3, %8, %3, %9\n")
+KERNEL(k_bitop3s, "v_bitop3_b32 %0, %0, %8, %10 bitop3:0x8e\n", "v_bitop3_b32 %1, %1, %8, %10 bitop3:0x8e\n", "v_bitop3_b32 %2, %2, %8, %10 bitop3:0x8e\n", "v_bitop3_b32 %3, %3, %8, %10 bitop3:0x8e\n")
+KERNEL(k_max, "v_max_u32 %0, %0, %8\n", "v_max_u32 %1, %1, %8\n", "v_max_u32 %2, %2, %8\n", "v_max_u32 %3, %3, %8\n")
+KERNEL(k_add3, "v_add3_u32 %0, %0, %8, %9\n", "v_add3_u32 %1, %1, %8, %9\n", "v_add3_u32 %2, %2, %8, %9\n", "v_add3_u32 %3, %3, %8, %9\n")
+KERNEL(k_sdwa, "v_mov_b32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n", "v_mov_b32_sdwa %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n", "v_mov_b32_sdwa %2, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n", "v_mov_b32_sdwa %3, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n")
+KERNEL(k_lshr, "v_lshrrev_b32 %0, 1, %0\n", "v_lshrrev_b32 %1, 1, %1\n", "v_lshrrev_b32 %2, 1, %2\n", "v_lshrrev_b32 %3, 1, %3\n")
+KERNEL(k_mad24, "v_mad_u32_u24 %0, %0, %8, %9\n", "v_mad_u32_u24 %1, %1, %8, %9\n", "v_mad_u32_u24 %2, %2, %8, %9\n", "v_mad_u32_u24 %3, %3, %8, %9\n")
 
 // LDS: one ds_read_b128 + wait per "step", table of 20 x 16 B, random entry per lane
 __global__ __launch_bounds__(256) void k_ds128(unsigned *out, unsigned seed)
@@ -80,7 +92,10 @@ int main()
         {"v_xor_b32", k_xor, 32}, {"v_and_b32", k_and, 32}, {"v_lshlrev_b32", k_lshl, 32}, {"v_alignbit_b32", k_alignbit, 32},
         {"v_bitop3_b32", k_bitop3, 32}, {"v_or3_b32", k_or3, 32}, {"v_lshl_or_b32", k_lshl_or, 32}, {"v_lshl_add_u64", k_add64, 32},
         {"v_add_u32", k_add32, 32}, {"v_add_co/addc pair", k_addco, 32}, {"v_cmp_gt_u32", k_cmp, 32}, {"v_bfe_u32", k_bfe, 32},
-        {"v_mov_b32", k_mov, 32}};
+        {"v_mov_b32", k_mov, 32}, {"v_perm_b32", k_perm, 32}, {"v_xnor_b32", k_xnor, 32}, {"v_not_b32", k_not, 32},
+        {"v_bcnt_u32_b32", k_bcnt, 32}, {"v_bfi_b32", k_bfi, 32}, {"v_bitop3_b32 (sgpr src2)", k_bitop3s, 32},
+        {"v_max_u32", k_max, 32}, {"v_add3_u32", k_add3, 32}, {"v_mov_b32_sdwa", k_sdwa, 32}, {"v_lshrrev_b32", k_lshr, 32},
+        {"v_mad_u32_u24", k_mad24, 32}};
     printf("%-22s %10s %10s %10s\n", "instruction", "cyc@1w/SIMD", "cyc@2w", "cyc@4w");
     for (auto &e : ks) {
         double c[3];
