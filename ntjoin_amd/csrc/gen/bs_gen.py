@@ -124,6 +124,9 @@ def to_asm(ins):
     if op == 'gload2':
         d = int(ins[1][1:])
         return f"global_load_dwordx2 v[{d}:{d + 1}], {ins[2][0]}, {ins[2][1]} offset:{ins[3]}"
+    if op == 'gstore2':
+        d = int(ins[1][1:])
+        return f"global_store_dwordx2 {ins[2][0]}, v[{d}:{d + 1}], {ins[2][1]} offset:{ins[3]}"
     if op == 'gstore4':
         d = int(ins[1][1:])
         return f"global_store_dwordx4 {ins[2][0]}, v[{d}:{d + 3}], {ins[2][1]} offset:{ins[3]}"
@@ -138,17 +141,34 @@ def to_asm(ins):
 
 # ---------------------------------------------------------------------------------------------------------------
 # register map (physical VGPRs / SGPRs the generated block owns: the inline-asm clobber list)
+#
+# VGPR banks.  Measured on MI355X (profiles/ubench/issue_bench_mi355x.txt): v_bitop3_b32 with three VGPR sources issues
+# every 2.4 cycles when the three registers lie in different banks (register index mod 4) and every 4.4-4.5 cycles when
+# two of them share a bank; VOP2 (v_xor_b32 ...) does not care.  So the map is built around the banks:
+#     bank 0: forward ring planes FP[0..30]          bank 1: reverse ring planes RP[0..30]
+#     bank 2: word 0 of the lane's 32 strips,        bank 3: word 1 of the strips,
+#             then W[t] for t < 16                            then W[t] for t >= 16
+# (group i = registers B0 + 4 i .. + 3; dwordx2 loads fill the bank 2 / 3 pair of a group), and 8 more groups hold the
+# masks of the outgoing base (the bank of its W registers), the masks of the incoming base (the other of banks 2 / 3),
+# the adder's carry (bank 2) and sum (bank 3), and in banks 0 / 1 the step's result, temporaries and transpose masks.
 # ---------------------------------------------------------------------------------------------------------------
-V0 = 16                    # first VGPR of the block (the compiler keeps v0..v15 for its own values)
-ST = V0                    # 64 state registers: FP = ST[0..30], RP = ST[31..61], ST[62..63] spare
-RAW = ST + 64              # 64 registers: the lane's 256 bytes, then the transposed bases W, then the step masks
-XW = RAW + 64              # 2: the 8 bytes after the lane's region (first strip of the next lane)
-XR = XW + 2                # 2: running shifts of them (bit 0 = the next lane's bit of this step)
-MA = XR + 2                # 5: masks of the outgoing base (x o a c1 c2; b0 b1 are W registers)
-MB = MA + 5                # 7: in-bits b0 b1 and their masks
-TT = MB + 7                # test temporaries: s0 s1 carry le ones
-TR = TT + 5                # 2 rotating temporaries of the transposes
-VEND = TR + 2              # one past the last VGPR used
+B0 = 8                     # first VGPR of the block (the compiler keeps v0..v7 for its own values)
+NGRP_X = 8                 # extra groups
+VEND = B0 + 4 * (32 + NGRP_X)  # one past the last VGPR used: 168 = three waves per SIMD
+
+
+def grp(i, q):
+    return B0 + 4 * i + q
+
+
+def ex(g, q):
+    return B0 + 128 + 4 * g + q
+
+
+def bank(reg):
+    return int(reg[1:]) % 4
+
+
 S0 = 36                    # first SGPR of the block
 S_M4, S_M2, S_M1 = f"s{S0}", f"s{S0 + 1}", f"s{S0 + 2}"
 S_P16L, S_P16H, S_P8L, S_P8H = (f"s{S0 + 3 + i}" for i in range(4))
@@ -163,90 +183,122 @@ def v(i):
 
 
 class Gen:
-    def __init__(self, k=32, b_planes=B_PLANES, use_perm=True):
+    def __init__(self, k=32, b_planes=B_PLANES, use_perm=False):
         assert k == 32, "strips of 32 k-mers: k = 32 only (other k: k_hash_sparse)"
         self.k = k
         self.b = b_planes
         self.use_perm = use_perm
         self.p = Prog()
         self.fo, self.fi, self.ro, self.ri = plane_funcs(k)
-        self.FP = [v(ST + i) for i in range(31)]
-        self.RP = [v(ST + 31 + i) for i in range(31)]
+        self.FP = [v(grp(i, 0)) for i in range(31)]
+        self.RP = [v(grp(i, 1)) for i in range(31)]
+        self.RAW0 = [v(grp(i, 2)) for i in range(32)]
+        self.RAW1 = [v(grp(i, 3)) for i in range(32)]
+        self.XW = [v(ex(0, 0)), v(ex(0, 1))]     # the 8 bytes behind the lane's region (a dwordx2 pair)
+        self.XR = [v(ex(1, 0)), v(ex(1, 1))]     # their running shifts
+        self.le, self.ones = v(ex(2, 0)), v(ex(2, 1))
+        self.tmp0 = [v(ex(g, 0)) for g in range(3, 8)] + [v(ex(2, 0))]       # bank 0 temporaries of the transposes (le is idle then)
+        self.tmask_regs = [v(ex(g, 1)) for g in range(3, 8)]              # bank 1: the transposes' select masks
+        self.E2 = [v(ex(g, 2)) for g in range(7)]
+        self.E3 = [v(ex(g, 3)) for g in range(7)]
+        self.cy, self.s = v(ex(7, 2)), v(ex(7, 3))
         self.send = S_CM + self.b
         self.neg = {}
 
     # ---- 32 x 32 bit transpose by renaming --------------------------------------------------------------
     def transpose_masks(self):
-        """the select masks of the transposes' shift stages in VGPRs that are idle while a transpose runs (v_bitop3_b32 with
-        an SGPR source issues at half rate: profiles/ubench)"""
+        """the select masks of the transposes in bank 1 VGPRs (v_bitop3_b32 with an SGPR source issues at half rate)"""
         e = self.p.emit
         self.tmask = {}
         for i, (j, sreg) in enumerate(((16, S_M16), (8, S_M8), (4, S_M4), (2, S_M2), (1, S_M1))):
             if self.use_perm and j >= 8:
                 continue
-            self.tmask[j] = v(MA + i)
-            e('mov', v(MA + i), sreg)
+            self.tmask[j] = self.tmask_regs[i]
+            e('mov', self.tmask_regs[i], sreg)
 
-    def transpose(self, rows, free, final=None):
-        """rows: 32 register names, row i = input word i.  Afterwards out[i] bit s = in[s] bit i; returns the list of
-        registers holding out[0..31] (a permutation of rows + free, or `final` when given: the last stage writes there).
-        free: 2 scratch registers (which ones are scratch afterwards changes: returned as second value)."""
+    def transpose(self, rows, spare, home, final=None):
+        """rows: 32 registers, row i = input word i.  Afterwards out[i] bit s = in[s] bit i; returns the registers holding
+        out[0..31].  Rows move by renaming: a pair's new rows are written to free registers (`spare` at first, then the
+        registers earlier pairs gave up; registers of `home` are preferred), shifted copies go to bank 0 temporaries and
+        the masks sit in bank 1, so no v_bitop3_b32 reads two registers of one bank.  With `final` the last stage writes
+        row i to final[i]; without it, rows that ended outside `home` are moved there."""
         e = self.p.emit
         rows = list(rows)
-        free = list(free)
+        pool = list(spare)
+        home = set(home)
+        tq = list(self.tmp0)
+        sel = self.tt3(lambda a, b2, c: a if c else b2)
+
+        def take():
+            for r in pool:
+                if r in home:
+                    pool.remove(r)
+                    return r
+            return pool.pop(0)
+
+        # A select right behind the half-rate shift it depends on stalls the wave (measured: the mixed stream took 1.4 x the
+        # sum of its parts), so the shifts run two pairs ahead of the selects: three pairs of temporaries in flight.
         stages = [16, 8, 4, 2, 1]
         for si, j in enumerate(stages):
             last = si == len(stages) - 1
-            for kk in range(32):
-                if kk & j:
-                    continue
+            pairs = [kk for kk in range(32) if not kk & j]
+            sh, se = [], []
+            for kk in pairs:
                 a, bq = rows[kk], rows[kk + j]
-                d0 = final[kk] if (last and final) else None
-                d1 = final[kk + j] if (last and final) else None
+                if self.use_perm and j >= 8:
+                    sh.append([])
+                else:
+                    t0, t1 = tq[0], tq[1]
+                    tq = tq[2:] + [t0, t1]
+                    # (v_lshlrev_b32 issues at half rate, v_add_u32 at full rate)
+                    sh.append([('add', t0, bq, bq) if j == 1 else ('lshl', t0, bq, j), ('lshr', t1, a, j)])
+                se.append((kk, a, bq, sh[-1]))
+            ahead = 2
+            for q in range(min(ahead, len(pairs))):
+                for ins in sh[q]:
+                    e(*ins)
+            for q, (kk, a, bq, shq) in enumerate(se):
+                if q + ahead < len(pairs):
+                    for ins in sh[q + ahead]:
+                        e(*ins)
+                if last and final:
+                    d0, d1 = final[kk], final[kk + j]
+                else:
+                    d0, d1 = take(), take()
                 if self.use_perm and j >= 8:
                     selL, selH = (S_P16L, S_P16H) if j == 16 else (S_P8L, S_P8H)
-                    t0 = d0 or free.pop()
-                    e('perm', t0, bq, a, selL)   # new row kk
-                    t1 = d1 or free.pop()
-                    e('perm', t1, bq, a, selH)   # new row kk + j
-                    if not d0:
-                        free += [a, bq]
-                    rows[kk], rows[kk + j] = t0, t1
+                    e('perm', d0, bq, a, selL)   # new row kk
+                    e('perm', d1, bq, a, selH)   # new row kk + j
                 else:
                     m = self.tmask[j]
-                    t0 = free.pop()
-                    t1 = free.pop()
-                    if j == 1:
-                        e('add', t0, bq, bq)  # (v_lshlrev_b32 issues at half rate, v_add_u32 at full rate)
-                    else:
-                        e('lshl', t0, bq, j)
-                    e('lshr', t1, a, j)
-                    n0 = d0 or t0
-                    n1 = d1 or t1
-                    e('bitop3', n0, a, t0, m, self._sel_tt())
-                    e('bitop3', n1, t1, bq, m, self._sel_tt())
-                    if d0:
-                        free += [t0, t1]
-                    else:
-                        free += [a, bq]
-                    rows[kk], rows[kk + j] = n0, n1
-        return rows, free
+                    e('bitop3', d0, a, shq[0][1], m, sel)
+                    e('bitop3', d1, shq[1][1], bq, m, sel)
+                pool += [a, bq]
+                rows[kk], rows[kk + j] = d0, d1
+        if not final:
+            for i, r in enumerate(rows):
+                if r not in home:
+                    d = take()
+                    assert d in home
+                    e('mov', d, r)
+                    rows[i] = d
+        return rows
 
     @staticmethod
-    def _sel_tt():
-        # f(a, b, c) = c ? a : b  with index a*4 + b*2 + c
+    def tt3(fn, na=0, nb=0, nc=0):
+        """truth table of fn(a ^ na, b ^ nb, c ^ nc), index a*4 + b*2 + c"""
         tt = 0
         for a in (0, 1):
             for b in (0, 1):
                 for c in (0, 1):
-                    if (a if c else b):
+                    if fn(a ^ na, b ^ nb, c ^ nc):
                         tt |= 1 << (a * 4 + b * 2 + c)
         return tt
 
     # ---- the seven masks of a base given its two bit planes ---------------------------------------------
-    def masks(self, b0, b1, base):
+    def masks(self, b0, b1, regs):
         e = self.p.emit
-        m = {'b0': b0, 'b1': b1, 'x': v(base), 'o': v(base + 1), 'a': v(base + 2), 'c1': v(base + 3), 'c2': v(base + 4)}
+        m = {'b0': b0, 'b1': b1, 'x': regs[0], 'o': regs[1], 'a': regs[2], 'c1': regs[3], 'c2': regs[4]}
         e('xor', m['x'], b0, b1)
         e('or', m['o'], b0, b1)
         e('and', m['a'], b0, b1)
@@ -281,17 +333,6 @@ class Gen:
         else:
             e('bitop3', dst, dst, ra, rb, 0x96)
 
-    @staticmethod
-    def tt3(fn, na=0, nb=0, nc=0):
-        """truth table of fn(a ^ na, b ^ nb, c ^ nc), index a*4 + b*2 + c"""
-        tt = 0
-        for a in (0, 1):
-            for b in (0, 1):
-                for c in (0, 1):
-                    if fn(a ^ na, b ^ nb, c ^ nc):
-                        tt |= 1 << (a * 4 + b * 2 + c)
-        return tt
-
     # ---- one chunk ------------------------------------------------------------------------------------
     def build(self, addr_in=('%5', '%1'), addr_kv=('%6', '%2'), addr_out=('%6', '%3'), s_tt='%4', v_cnt='%0'):
         """addresses: (VGPR byte offset of the lane, SGPR pair holding the chunk's base)"""
@@ -310,27 +351,26 @@ class Gen:
         for i in range(b):  # compare masks: Cm_i = all ones iff bit i of the threshold is set
             e('s_bfe', S_TMP, s_tt, i, 1)
             e('s_sub', f"s{S_CM + i}", 0, S_TMP)
-        # loads: 16 x 16 bytes + the 8 bytes behind them
-        for q in range(16):
-            e('gload4', v(RAW + 4 * q), addr_in, 16 * q)
-        e('gload2', v(XW), addr_in, 256)
+        # loads: the lane's 32 strips (8 bytes each: word 0 -> bank 2, word 1 -> bank 3) + the 8 bytes behind them
+        for i in range(32):
+            e('gload2', self.RAW0[i], addr_in, 8 * i)
+        e('gload2', self.XW[0], addr_in, 256)
         e('waitcnt', 'vmcnt(0)')
-        # transposes: matrix A = word 0 of every strip (even registers), B = word 1 (odd registers)
-        free = [v(TR), v(TR + 1)]
+        e('comment', 'PHASE transpose_in')
         self.transpose_masks()
-        rowsA, free = self.transpose([v(RAW + 2 * s) for s in range(32)], free)
-        rowsB, free = self.transpose([v(RAW + 2 * s + 1) for s in range(32)], free)
+        rowsA = self.transpose(self.RAW0, self.E2 + [self.cy], self.RAW0)
+        rowsB = self.transpose(self.RAW1, self.E3 + [self.s], self.RAW1)
         # W[t][beta]: bit s = bit beta of base t of strip s
         W = {}
         for t in range(16):
             for be in (0, 1):
                 W[(t, be)] = rowsA[2 * t + be]
                 W[(t + 16, be)] = rowsB[2 * t + be]
-        tr_free = free
         FP, RP = self.FP, self.RP
         # ---- warm-up: steps n = 0..31, incoming base = base n of the strip itself
+        e('comment', 'PHASE warmup')
         for n in range(32):
-            mB = self.masks(W[(n, 0)], W[(n, 1)], MB + 2)
+            mB = self.masks(W[(n, 0)], W[(n, 1)], (self.E2 if n < 16 else self.E3)[2:7])
             for r in range(31):
                 jf = (r + n + 1) % 31
                 self.plane_update(FP[r], None, None, self.fi[jf], mB, first=(n == 0))
@@ -338,51 +378,52 @@ class Gen:
                 jr = (r - n) % 31
                 self.plane_update(RP[r], None, None, self.ri[jr], mB, first=(n == 0))
         # ---- productive steps t = 0..31 (n = 32 + t): test the k-mer, then roll
-        e('mov', v(XR), v(XW))
-        e('lshr', v(XR + 1), v(XW), 1)
+        e('comment', 'PHASE productive')
+        XR, XW = self.XR, self.XW
+        e('mov', XR[0], XW[0])
+        e('lshr', XR[1], XW[0], 1)
         M = {}
-        sA, sB, cy, le, ones = (v(TT + i) for i in range(5))
+        s, cy, le, ones = self.s, self.cy, self.le, self.ones
         for t in range(32):
             n = 32 + t
             if t == 16:
-                e('mov', v(XR), v(XW + 1))
-                e('lshr', v(XR + 1), v(XW + 1), 1)
+                e('mov', XR[0], XW[1])
+                e('lshr', XR[1], XW[1], 1)
+            mt = W[(t, 0)]  # the step's result replaces the step's first base plane after the roll
+            if t < 31:
+                # masks of the outgoing base in the bank of its W registers, those of the incoming base in the other one.
+                # They are made BEFORE the test: the roll must not start right behind the half-rate v_alignbit_b32.
+                EA, EB = (self.E2, self.E3) if t < 16 else (self.E3, self.E2)
+                in0, in1 = EB[0], EB[1]
+                # in-bits: W shifted by one strip, bit 31 from the next lane's first strip
+                e('alignbit', in0, XR[0], W[(t, 0)], 1)
+                e('alignbit', in1, XR[1], W[(t, 1)], 1)
+                if t % 16 != 15:
+                    e('lshr', XR[0], XR[0], 2)
+                    e('lshr', XR[1], XR[1], 2)
+                mA = self.masks(W[(t, 0)], W[(t, 1)], EA[0:5])
+                mB = self.masks(in0, in1, EB[2:7])
             # test: top b planes of F + R.  s (sum plane), cy (carry), le, ones hold true values; the planes' complement
-            # flags go into the truth tables.
+            # flags go into the truth tables.  Banks: f 0, r 1, cy 2, s 3, le 0, ones 1.
             jlo = 31 - b
             e('mov', le, -1)
             for j in range(jlo, 31):
                 f, r = FP[(j - n) % 31], RP[(j + n) % 31]
                 nf, nr = self.neg[f], self.neg[r]
-                s = sA if (j - jlo) % 2 == 0 else sB
-                if j == jlo:
-                    e('bitop3', s, f, r, r, self.tt3(lambda a, b2, c: a ^ b2, nf, nr, nr))
-                    e('bitop3', cy, f, r, r, self.tt3(lambda a, b2, c: a & b2, nf, nr, nr))
+                if j == jlo:  # (third source: ignored by the truth table)
+                    e('bitop3', s, f, r, cy, self.tt3(lambda a, b2, c: a ^ b2, nf, nr, 0))
+                    e('bitop3', cy, f, r, cy, self.tt3(lambda a, b2, c: a & b2, nf, nr, 0))
                 else:
                     e('bitop3', s, f, r, cy, self.tt3(lambda a, b2, c: a ^ b2 ^ c, nf, nr, 0))
                     if j < 30:
                         e('bitop3', cy, f, r, cy, self.tt3(lambda a, b2, c: (a & b2) | (a & c) | (b2 & c), nf, nr, 0))
                 e('bitop3', le, s, le, f"s{S_CM + (j - jlo)}", 0x8E)
-                # all-ones over planes jlo+1 .. 30, two planes per op
-                idx = j - jlo
+                idx = j - jlo  # all-ones over planes jlo+1 .. 30
                 if idx == 1:
                     e('mov', ones, s)
-                elif idx >= 2 and idx % 2 == 1:
-                    prev = sA if s is sB else sB
-                    e('bitop3', ones, ones, prev, s, 0x80)
-                elif idx >= 2 and j == 30:
+                elif idx >= 2:
                     e('and', ones, ones, s)
-            mt = W[(t, 0)]  # the step's result replaces the step's first base plane after the roll
             if t < 31:
-                # in-bits: W shifted by one strip, bit 31 from the next lane's first strip
-                in0, in1 = v(MB), v(MB + 1)
-                e('alignbit', in0, v(XR), W[(t, 0)], 1)
-                e('alignbit', in1, v(XR + 1), W[(t, 1)], 1)
-                if t % 16 != 15:
-                    e('lshr', v(XR), v(XR), 2)
-                    e('lshr', v(XR + 1), v(XR + 1), 2)
-                mA = self.masks(W[(t, 0)], W[(t, 1)], MA)
-                mB = self.masks(in0, in1, MB + 2)
                 for r in range(31):
                     jf = (r + n + 1) % 31
                     self.plane_update(FP[r], self.fo[jf], mA, self.fi[jf], mB)
@@ -391,24 +432,47 @@ class Gen:
                     self.plane_update(RP[r], self.ro[jr], mA, self.ri[jr], mB)
             e('or', mt, le, ones)
             M[t] = mt
-        # ---- out: transpose the 32 step masks into position order (the state registers are free now)
-        OUT = [v(ST + i) for i in range(32)]
-        KV = [v(ST + 32 + i) for i in range(32)]
-        for q in range(8):
-            e('gload4', KV[4 * q], addr_kv, 16 * q)
+        # ---- out: transpose the 32 step masks into position order (the state registers are free now): words 2 i, 2 i + 1
+        # of the lane land in the (bank 0, bank 1) pair of group i, the valid-k-mer words in the pairs of groups 16..31
+        e('comment', 'PHASE out')
+        OUT, KV = [], []
+        for i in range(16):
+            OUT += [v(grp(i, 0)), v(grp(i, 1))]
+            KV += [v(grp(16 + i, 0)), v(grp(16 + i, 1))]
+        for i in range(16):
+            e('gload2', KV[2 * i], addr_kv, 8 * i)
         self.transpose_masks()
-        rowsM, _ = self.transpose([M[t] for t in range(32)], tr_free, final=OUT)
+        free_raw = [W[(t, 1)] for t in range(32)]
+        self.transpose([M[t] for t in range(32)], free_raw, self.RAW0 + self.RAW1, final=OUT)
         e('waitcnt', 'vmcnt(0)')
-        e('mov', v_cnt, 0)
-        for s in range(32):
-            e('and', OUT[s], OUT[s], KV[s])
-            e('bcnt', v_cnt, OUT[s], v_cnt)
-        for q in range(8):
-            e('gstore4', OUT[4 * q], addr_out, 16 * q)
+        for i in range(32):
+            e('and', OUT[i], OUT[i], KV[i])
+        acc = self.tmp0[0:4]  # (four chains: v_bcnt_u32_b32 issues at half rate and a dependent one would wait for it)
+        for q in range(4):
+            e('mov', acc[q], 0)
+        for i in range(32):
+            e('bcnt', acc[i % 4], OUT[i], acc[i % 4])
+        e('add', acc[0], acc[0], acc[1])
+        e('add', acc[2], acc[2], acc[3])
+        e('add', v_cnt, acc[0], acc[2])
+        for i in range(16):
+            e('gstore2', OUT[2 * i], addr_out, 8 * i)
+        self.check_banks()
         return self.p
 
+    def check_banks(self):
+        """no v_bitop3_b32 may read two VGPRs of one bank"""
+        bad = 0
+        for ins in self.p.ins:
+            if ins[0] == 'bitop3':
+                srcs = [x for x in ins[2:5] if isinstance(x, str) and x.startswith('v')]
+                banks = [bank(x) for x in set(srcs)]
+                if len(banks) != len(set(banks)):
+                    bad += 1
+        assert bad == 0, f"{bad} v_bitop3_b32 with a register bank conflict"
+
     def clobbers(self):
-        return [f"v{i}" for i in range(V0, VEND)] + [f"s{i}" for i in range(S0, self.send)] + ["vcc", "scc", "memory"]
+        return [f"v{i}" for i in range(B0, VEND)] + [f"s{i}" for i in range(S0, self.send)] + ["vcc", "scc", "memory"]
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -508,9 +572,9 @@ class VM:
                 else:
                     for q in range(nw):
                         self.vr[f"v{d + q}"] = self.mem_kv[:, ins[3] // 4 + q].copy()
-            elif op == 'gstore4':
+            elif op in ('gstore4', 'gstore2'):
                 d = int(ins[1][1:])
-                for q in range(4):
+                for q in range(4 if op == 'gstore4' else 2):
                     self.out[:, ins[3] // 4 + q] = self.vr[f"v{d + q}"]
             elif op in ('waitcnt', 'nop', 'comment'):
                 pass
@@ -548,10 +612,63 @@ def reference_bits(codes, k, tt, b_planes=B_PLANES):
     return (St <= np.uint64(tt)) | (St >= np.uint64((1 << b_planes) - 2))
 
 
-def emit_inc(path, k, use_perm=True, prefix="HASH_BS"):
+E64_OK = ('xor', 'and', 'or', 'add', 'lshl', 'lshr', 'mov', 'not', 'xnor')
+
+
+def ins_size(ins):
+    """encoded size in bytes"""
+    op = ins[0]
+    if op in ('bitop3', 'alignbit', 'perm', 'bcnt') or op.startswith(('gload', 'gstore')):
+        return 8
+    if op in E64_OK:
+        lit = any(isinstance(x, int) and not -16 <= x <= 64 for x in ins[2:])
+        return 8 if lit else 4
+    if op == 's_mov':
+        return 8 if not -16 <= ins[2] <= 64 else 4
+    if op == 's_bfe':
+        return 8
+    if op in ('s_sub', 'waitcnt', 'nop'):
+        return 4
+    if op == 'comment':
+        return 0
+    raise ValueError(op)
+
+
+def asm_lines(ins_list, align8=True):
+    """assembly text; with align8 every 8-byte instruction starts on an 8-byte boundary (the block begins with .p2align 3):
+    a 4-byte VALU instruction in front of an 8-byte one is encoded as VOP3 (_e64), anything else gets an s_nop behind it.
+    (Measured on MI355X: the aligned stream is SLOWER, 595 vs 519 us per 3 Gbp -- the VOP3 encodings of the promoted
+    instructions cost more than the straddling; the option remains for the record.)"""
+    real = [i for i in ins_list if ins_size(i) > 0]
+    lines = ['.p2align 3'] if align8 else []
+    off = 0
+    n_e64 = n_nop = 0
+    for idx, ins in enumerate(real):
+        sz = ins_size(ins)
+        txt = to_asm(ins)
+        if align8 and sz == 4 and off % 8 == 0:
+            nxt = ins_size(real[idx + 1]) if idx + 1 < len(real) else 8
+            if nxt == 8:
+                if ins[0] in E64_OK:
+                    head, rest = txt.split(' ', 1)
+                    txt = f"{head}_e64 {rest}"
+                    sz = 8
+                    n_e64 += 1
+                else:
+                    lines.append(txt)
+                    lines.append('s_nop 0')
+                    off += 8
+                    n_nop += 1
+                    continue
+        lines.append(txt)
+        off += sz
+    return lines, n_e64, n_nop
+
+
+def emit_inc(path, k, use_perm=False, prefix="HASH_BS", align8=False):
     g = Gen(k, use_perm=use_perm)
     prog = g.build()
-    lines = [to_asm(i) for i in prog.ins]
+    lines, n_e64, n_nop = asm_lines(prog.ins, align8)
     n_valu = sum(1 for i in prog.ins if not i[0].startswith(('s_', 'g', 'wait', 'nop', 'comment')))
     with open(path, 'w') as fh:
         fh.write(f"// GENERATED by gen/bs_gen.py (k = {k}, {B_PLANES} sum planes): one chunk of the bit-sliced ring filter.\n")
@@ -572,8 +689,9 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('-k', type=int, default=32)
     ap.add_argument('-o', default='hash_bs_k32.inc')
-    ap.add_argument('--no-perm', action='store_true', help="transposes with shifts only (bench variant)")
+    ap.add_argument('--perm', action='store_true', help="byte stages of the transposes with v_perm_b32 (bench variant)")
     ap.add_argument('--prefix', default='HASH_BS')
+    ap.add_argument('--align8', action='store_true', help="8-byte encodings on 8-byte boundaries (bench variant: it is slower)")
     a = ap.parse_args()
-    n, nv = emit_inc(a.o, a.k, not a.no_perm, a.prefix)
+    n, nv = emit_inc(a.o, a.k, a.perm, a.prefix, a.align8)
     print(f"{a.o}: {n} instructions, {nv} VALU", file=sys.stderr)

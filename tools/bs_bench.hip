@@ -29,15 +29,16 @@ __global__ __launch_bounds__(64 * WPB) void k_hash_bs(const uint32_t *__restrict
                                                       uint32_t *__restrict__ bitmap, uint32_t *__restrict__ cnt,
                                                       uint32_t n_chunks, uint32_t tt)
 {
-    extern __shared__ uint32_t pad[];  // (dynamic LDS only caps the residency)
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * WPB + (threadIdx.x >> 6), n_waves = gridDim.x * WPB;
-    for (uint32_t c = wave; c < n_chunks; c += n_waves) {
-        const uint32_t cu = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);  // (wave-uniform: the addresses stay in SGPRs)
-        const uint32_t *pin = packed + (size_t)cu * 4096u;
-        const uint32_t *pkv = kvalid + (size_t)cu * 2048u;
-        uint32_t *pout = bitmap + (size_t)cu * 2048u;
-        const uint32_t off256 = lane * 256u, off128 = lane * 128u;
+    // (few live VGPRs around the block: it owns v8..v167 and the kernel must stay at 168 for three waves per SIMD)
+    __shared__ uint32_t acc[WPB];
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WPB + wib)), n_waves = gridDim.x * WPB;
+    const uint32_t off256 = lane * 256u, off128 = lane * 128u;
+    if (lane == 0) acc[wib] = 0;
+    for (uint32_t c = wave; c < n_chunks; c += n_waves) {  // (wave-uniform: the addresses stay in SGPRs)
+        const uint32_t *pin = packed + (size_t)c * 4096u;
+        const uint32_t *pkv = kvalid + (size_t)c * 2048u;
+        uint32_t *pout = bitmap + (size_t)c * 2048u;
         uint32_t n;
         if (VAR == 0)
             asm volatile(HASH_BS_ASM : "=&v"(n) : "s"(pin), "s"(pkv), "s"(pout), "s"(tt), "v"(off256), "v"(off128) : HASH_BS_CLOBBERS);
@@ -45,9 +46,12 @@ __global__ __launch_bounds__(64 * WPB) void k_hash_bs(const uint32_t *__restrict
         else
             asm volatile(HASH_BSNP_ASM : "=&v"(n) : "s"(pin), "s"(pkv), "s"(pout), "s"(tt), "v"(off256), "v"(off128) : HASH_BSNP_CLOBBERS);
 #endif
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o, 64);
-        if (lane == 0) cnt[c] = n;
+        atomicAdd(&acc[wib], n);  // (LDS operations of one wave complete in order)
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            cnt[c] = acc[wib];
+            acc[wib] = 0;
+        }
     }
 }
 
