@@ -4,8 +4,8 @@ register-only loop (loads / stores / waits removed), timed at 1..3 waves per SIM
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "ntjoin_amd", "csrc", "gen"))
-import bs_gen as G  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bs_gen_v1 as G  # noqa: E402
 
 g = G.Gen(32)
 
