@@ -16,7 +16,10 @@
 
 namespace mxg {
 
+#ifndef MXG_BS_CHUNK_DEFINED
+#define MXG_BS_CHUNK_DEFINED
 constexpr uint32_t BS_CHUNK = 65536;        // base positions per chunk
+#endif
 constexpr uint32_t BS_T_WORDS = 4096;       // u32 words of T per chunk (= the chunk's packed words)
 constexpr uint32_t BS_Q_WORDS = 128;        // u32 words of Q per chunk
 constexpr uint32_t BS_OUT_WORDS = 2048;     // u32 words of OUT per chunk
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(64) void k_bs_transpose(const uint32_t *__restrict_
 
 // The filter.  Blocks of 256 threads = one wave per SIMD; the grid is sized for TWO waves per SIMD (an even number of waves
 // per SIMD issues at 2.05 cycles per instruction, an odd one at 2.5-2.7: profiles/ubench), every wave takes the chunks
-// c0, c0 + stride, ...  The body is generated (gen/bs_gen.py) and owns v8..v215 and s24..s65; the few values around it
+// c0, c0 + stride, ...  The body is generated (gen/bs_gen.py) and owns v8..v215 and s36..s77; the few values around it
 // stay in v0..v7.
 __global__ __launch_bounds__(256) void k_hash_bs(const uint32_t *__restrict__ T, const uint32_t *__restrict__ Q,
                                                  uint32_t *__restrict__ OUT, uint32_t c_lo, uint32_t c_hi, uint32_t tt)

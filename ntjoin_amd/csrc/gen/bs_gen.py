@@ -153,7 +153,7 @@ def bank(reg):
 
 
 # SGPRs of the block
-S0 = 24
+S0 = 36
 S_C = S0            # chunk index (pair: high word 0)
 S_N = S0 + 2        # one past the last chunk
 S_STRIDE = S0 + 3

@@ -106,6 +106,10 @@ struct Assembly {
     std::vector<uint32_t> strip0_dense, strip0_sparse;  // [n_runs+1] exclusive prefix of strips per run
     std::vector<uint64_t> g0;                           // [n_runs+1] exclusive prefix of k-mers per run
     DevBuf d_runs, d_strip0_dense, d_strip0_sparse, d_g0, d_ctg_nk, d_ctg_rec, d_ctg_run0, d_ctg_drop;
+    // k = 32 route (sketch_bs.hip): the bases transposed for the bit-sliced ring filter, its result, chunk -> first run
+    bool bs_ready = false, bs_impossible = false;
+    uint32_t bs_chunks = 0;
+    DevBuf d_bs_T, d_bs_Q, d_bs_out, d_bs_run0;
     // sketch (device, ordered by (record,pos)) + lazily filled host mirror
     bool has_sketch = false;
     uint64_t n_mx = 0;
@@ -187,6 +191,9 @@ struct mxg_handle {
     mxg::DevBuf d_chain;            // pipelined batches: where the next batch of an assembly starts in its sketch (u64 per batch)
     std::vector<hipEvent_t> ev_sync;  // ... and the events by which a batch waits for its predecessor on the other stream
     hipEvent_t ev_join = nullptr;   // ... and the event that joins the second stream into the first
+    mxg::DevBuf dbg_buf;            // (profiling: MXG_BSR_DBG)
+    uint32_t dbg_blocks = 0;
+    std::vector<hipEvent_t> ev_bs;  // k = 32 route: "the assembly's filter has run" (batches on other streams wait for it)
     mxg::DevBuf dg_cnt, dg_cursor;  // dgraph.hip: per-destination counts / cursors
     mxg::DevBuf dg_ghost;           // ... {record, global vertex id} of the shared minimizer before this rank's first, per assembly
     bool dg_ghost_on = false;

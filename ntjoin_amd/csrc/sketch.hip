@@ -41,7 +41,9 @@
 #include <type_traits>
 
 #include "mxg_internal.h"
+#include "nthash_dev.h"
 #include "scan_kernels.h"
+#include "sketch_bs.h"
 
 namespace mxg {
 
@@ -55,230 +57,6 @@ enum Scratch {
     SC_COUNT
 };
 static_assert(SC_COUNT <= 40, "scratch pool too small");
-
-// ------------------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------------------
-struct H2 {
-    uint32_t flo, fhi, rlo, rhi;
-};
-
-// one ntHash step:  fwd = srol(fwd) ^ t.xy ;  rev = sror(rev ^ t.zw)
-// srol/sror = rotate the low 33 bits and the high 31 bits by one, each within itself.
-__device__ __forceinline__ void nt_step(H2 &h, const uint4 t)
-{
-    uint32_t nlo = (h.flo << 1) | (h.fhi & 1u);                       // bit 32 -> bit 0
-    uint32_t nhi = __builtin_amdgcn_alignbit(h.fhi, h.flo, 31);       // (fhi << 1) | (flo >> 31)
-    nhi = (nhi & ~2u) | ((h.fhi >> 30) & 2u);                         // bit 63 -> bit 33
-    h.flo = nlo ^ t.x;
-    h.fhi = nhi ^ t.y;
-    uint32_t xlo = h.rlo ^ t.z, xhi = h.rhi ^ t.w;
-    h.rlo = __builtin_amdgcn_alignbit(xhi, xlo, 1);                   // (xlo >> 1) | (xhi << 31)
-    h.rhi = ((xhi >> 1) & 0x7FFFFFFEu) | (xlo & 1u) | ((xhi & 2u) << 30);  // bit 0 -> bit 32, bit 33 -> bit 63
-}
-
-// 16 consecutive 2-bit bases starting at global base index `pos` (any alignment)
-__device__ __forceinline__ uint32_t fetch16(const uint32_t *__restrict__ packed, uint64_t pos)
-{
-    uint64_t wi = pos >> 4;
-    uint32_t sh = ((uint32_t)pos & 15u) * 2u;
-    uint32_t lo = packed[wi], hi = packed[wi + 1];
-    return __builtin_amdgcn_alignbit(hi, lo, sh);
-}
-
-template <int VARIANT>
-__device__ __forceinline__ uint64_t canonical(const H2 &h)
-{
-    uint64_t f = ((uint64_t)h.fhi << 32) | h.flo, r = ((uint64_t)h.rhi << 32) | h.rlo;
-    if (VARIANT == MXG_VARIANT_V1_MIN) return f <= r ? f : r;
-    return f + r;
-}
-
-__device__ __forceinline__ bool is_forward(const H2 &h)
-{
-    uint64_t f = ((uint64_t)h.fhi << 32) | h.flo, r = ((uint64_t)h.rhi << 32) | h.rlo;
-    return f <= r;
-}
-
-__device__ __forceinline__ uint64_t ext_hash(uint64_t h0, uint64_t mult)
-{
-    uint64_t t = h0 * mult;  // mult = 1 ^ (k * MULTISEED)
-    return t ^ (t >> 27);
-}
-
-// locate strip s: run index lo with run_strip0[lo] <= s < run_strip0[lo+1]
-__device__ __forceinline__ uint32_t find_run(const uint32_t *__restrict__ run_strip0, uint32_t lo, uint32_t hi, uint32_t s)
-{
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (run_strip0[mid] <= s) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-template <class T>
-__device__ __forceinline__ void warm_up(H2 &h, const uint32_t *__restrict__ packed, uint64_t b, uint32_t k, const T *tab)
-{
-    for (uint32_t t = 0; t < k; t += 16) {  // k steps with no outgoing base
-        uint32_t chunk = fetch16(packed, b + t);
-        uint32_t n = min(16u, k - t);
-        for (uint32_t u = 0; u < n; ++u) {
-            nt_step(h, tab[16 + (chunk & 3u)]);
-            chunk >>= 2;
-        }
-    }
-}
-
-// split rotation by 4 positions (one packed byte = 4 bases), by -4, and by a wave-uniform n
-__device__ __forceinline__ void srol4(uint32_t &lo, uint32_t &hi)
-{
-    const uint32_t b32 = hi & 1u, W = hi >> 1;
-    const uint32_t nlo = (lo << 4) | (b32 << 3) | (lo >> 29);
-    const uint32_t nW = ((W << 4) | (W >> 27)) & 0x7FFFFFFFu;
-    hi = (nW << 1) | ((lo >> 28) & 1u);
-    lo = nlo;
-}
-__device__ __forceinline__ void sror4(uint32_t &lo, uint32_t &hi)
-{
-    const uint32_t b32 = hi & 1u, W = hi >> 1;
-    const uint32_t nlo = (lo >> 4) | (b32 << 28) | (lo << 29);
-    const uint32_t nW = (W >> 4) | ((W & 15u) << 27);
-    hi = (nW << 1) | ((lo >> 3) & 1u);
-    lo = nlo;
-}
-__device__ __forceinline__ void srol_var(uint32_t &lo, uint32_t &hi, uint32_t n)
-{
-    uint64_t V = ((uint64_t)(hi & 1u) << 32) | lo;
-    uint32_t W = hi >> 1;
-    const uint32_t a = n % 33u, b = n % 31u;
-    if (a) V = ((V << a) | (V >> (33u - a))) & 0x1FFFFFFFFull;
-    if (b) W = ((W << b) | (W >> (31u - b))) & 0x7FFFFFFFu;
-    lo = (uint32_t)V;
-    hi = (W << 1) | (uint32_t)(V >> 32);
-}
-
-// Hash state of a k-mer without k rolling steps.  With m = 4*(k/4) and v_q the q-th packed byte (4 bases),
-//     F = XOR_q srol^{4(P-1-q)} f4[v_q]            f4[v] = XOR_u srol^{3-u} seed[c_u]      (make_init_tab)
-//     R = srol^{k-m} XOR_q srol^{4q} r4[v_q]       r4[v] = XOR_u srol^{u}   seed'[c_u]
-// both by Horner over the bytes in memory order: F <- srol^4(F) ^ f4[v_q];  T <- sror^4(T) ^ r4[v_q], and
-// R = srol^{4(P-1) + k-m}(T).  One 256-entry table (4 KB, in LDS) for every k; then k%4 ordinary warm-up steps.
-template <class T>
-__device__ __forceinline__ void init_direct(H2 &h, const uint32_t *__restrict__ packed, uint64_t b, uint32_t k,
-                                            const uint4 *byte_tab, const T *tab)
-{
-    const uint32_t P = k / 4;
-    uint32_t flo = 0, fhi = 0, tlo = 0, thi = 0;
-    for (uint32_t q = 0; q < P; q += 4) {  // 16 bases = 4 table bytes per fetch
-        const uint32_t word = fetch16(packed, b + 4u * q);
-        const uint32_t nb = min(4u, P - q);
-        for (uint32_t u = 0; u < nb; ++u) {
-            const uint4 e = byte_tab[(word >> (8 * u)) & 255u];
-            srol4(flo, fhi);
-            sror4(tlo, thi);
-            flo ^= e.x; fhi ^= e.y; tlo ^= e.z; thi ^= e.w;
-        }
-    }
-    const uint32_t rem = k - 4 * P;
-    if (P) srol_var(tlo, thi, 4u * (P - 1u) + rem);
-    h.flo = flo; h.fhi = fhi; h.rlo = tlo; h.rhi = thi;
-    if (rem) {
-        uint32_t chunk = fetch16(packed, b + 4u * P);
-        for (uint32_t u = 0; u < rem; ++u) {
-            nt_step(h, tab[16 + (chunk & 3u)]);
-            chunk >>= 2;
-        }
-    }
-}
-
-// The same state from POSITION tables (make_init_tab, entries 256..): ptab[j][v] = {srol^{4(7-j)} f4[v], srol^{4j} r4[v]}, so a
-// group of 8 bytes (32 bases) is 8 lookups and 32 XORs with no rotation at all; groups are combined by rotations of 32
-// (k > 35 only) and the last t < 8 bytes use the tables j + 8 - t (forward) and j (reverse).  k = 32: one group, nothing else.
-//     F = XOR_G srol^{4(P - 8(G+1))} F_G          R = srol^{k-m} XOR_G srol^{32 G} R_G
-template <class T>
-__device__ __forceinline__ void init_pos(H2 &h, const uint32_t *__restrict__ packed, uint64_t b, uint32_t k,
-                                         const uint4 *ptab, const T *tab)
-{
-    const uint32_t P = k / 4;
-    const uint32_t *pw = packed + (b >> 4);
-    const uint32_t sh = ((uint32_t)b & 15u) * 2u;
-    uint32_t flo = 0, fhi = 0, tlo = 0, thi = 0;
-    uint32_t q = 0;
-    for (; q + 8 <= P; q += 8) {
-        const uint32_t w0 = pw[q >> 2], w1 = pw[(q >> 2) + 1], w2 = pw[(q >> 2) + 2];
-        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-        uint4 acc = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-            const uint4 e0 = ptab[u * 256u + ((lo >> (8 * u)) & 255u)];
-            const uint4 e1 = ptab[(4u + u) * 256u + ((hi >> (8 * u)) & 255u)];
-            acc.x ^= e0.x ^ e1.x; acc.y ^= e0.y ^ e1.y; acc.z ^= e0.z ^ e1.z; acc.w ^= e0.w ^ e1.w;
-        }
-        if (q) {
-            srol_var(flo, fhi, 32u);
-            srol_var(acc.z, acc.w, 4u * q);
-        }
-        flo ^= acc.x; fhi ^= acc.y; tlo ^= acc.z; thi ^= acc.w;
-    }
-    const uint32_t t = P - q;  // bytes after the last full group
-    if (t) {
-        const uint32_t w0 = pw[q >> 2], w1 = pw[(q >> 2) + 1], w2 = pw[(q >> 2) + 2];
-        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-        uint32_t ax = 0, ay = 0, az = 0, aw = 0;
-        for (uint32_t j = 0; j < t; ++j) {
-            const uint32_t v = ((j < 4 ? lo : hi) >> (8u * (j & 3u))) & 255u;
-            const uint4 ef = ptab[(j + 8u - t) * 256u + v], er = ptab[j * 256u + v];
-            ax ^= ef.x; ay ^= ef.y; az ^= er.z; aw ^= er.w;
-        }
-        if (q) {
-            srol_var(flo, fhi, 4u * t);
-            srol_var(az, aw, 4u * q);
-        }
-        flo ^= ax; fhi ^= ay; tlo ^= az; thi ^= aw;
-    }
-    const uint32_t rem = k - 4 * P;
-    if (rem) srol_var(tlo, thi, rem);
-    h.flo = flo; h.fhi = fhi; h.rlo = tlo; h.rhi = thi;
-    if (rem) {
-        uint32_t chunk = fetch16(packed, b + 4u * P);
-        for (uint32_t u = 0; u < rem; ++u) {
-            nt_step(h, tab[16 + (chunk & 3u)]);
-            chunk >>= 2;
-        }
-    }
-}
-
-// split rotation by 16 positions
-__device__ __forceinline__ void srol16(uint32_t &lo, uint32_t &hi)
-{
-    const uint32_t b32 = hi & 1u, W = hi >> 1;
-    const uint32_t nlo = (lo << 16) | (b32 << 15) | (lo >> 17);
-    const uint32_t nW = ((W << 16) | (W >> 15)) & 0x7FFFFFFFu;
-    hi = (nW << 1) | ((lo >> 16) & 1u);
-    lo = nlo;
-}
-
-// k = 32 from HALF the position tables (16 KB): half[j][v] = {srol^{4(3-j)} f4[v], srol^{4j} r4[v]}, j = 0..3.  Bytes 0..3
-// of the k-mer give Fa, Ra and bytes 4..7 give Fb, Rb through the same four tables;  F = srol^16(Fa) ^ Fb,
-// R = Ra ^ srol^16(Rb).  8 lookups, 32 XORs and two rotations where init_direct walks 16 rotations by 4 (k_hash_sparse, once
-// per strip, in the LDS the kernel reserves anyway).
-__device__ __forceinline__ void init32_half(H2 &h, const uint32_t *__restrict__ packed, uint64_t b, const uint4 *half)
-{
-    const uint32_t *pw = packed + (b >> 4);
-    const uint32_t sh = ((uint32_t)b & 15u) * 2u;
-    const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
-    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-    uint4 a = make_uint4(0u, 0u, 0u, 0u), c = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {
-        const uint4 e0 = half[u * 256u + ((lo >> (8 * u)) & 255u)];
-        const uint4 e1 = half[u * 256u + ((hi >> (8 * u)) & 255u)];
-        a.x ^= e0.x; a.y ^= e0.y; a.z ^= e0.z; a.w ^= e0.w;
-        c.x ^= e1.x; c.y ^= e1.y; c.z ^= e1.z; c.w ^= e1.w;
-    }
-    srol16(a.x, a.y);
-    srol16(c.z, c.w);
-    h.flo = a.x ^ c.x; h.fhi = a.y ^ c.y; h.rlo = a.z ^ c.z; h.rhi = a.w ^ c.w;
-}
 
 // ------------------------------------------------------------------------------------------------------
 // dense hash kernel
@@ -1169,6 +947,10 @@ struct EmitParams {
     // the selected candidates laid out per k_resolve block (ResolveParams::cs_*): replaces sel / ch / ck / cc
     const uint64_t *cs_h;
     const uint32_t *cs_k, *cs_c;
+    // entries per producer block in the cs_* arrays (RK behind k_resolve; k_bs_resolve has its own) and, behind k_bs_resolve,
+    // the number of entries to walk (blocks x rk: the candidate count in *n_ptr is then only reported)
+    uint32_t rk, n_fixed;
+    const uint32_t *cand_spread;  // k_bs_resolve's candidate counters (64, 32 words apart) or null: then *n_ptr is the count
 };
 
 // number of keys < key in the sorted array keys[0..n)
@@ -1185,7 +967,8 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *keys, uint32
 __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
 {
     __shared__ uint32_t sh[256];
-    const uint32_t n = min(*p.n_ptr, p.n_cap);
+    const uint32_t RKe = p.rk;  // entries per producer block
+    const uint32_t n = p.n_fixed ? p.n_fixed : min(*p.n_ptr, p.n_cap);
     const uint32_t n_g_raw = p.ovf[1];
     if (*p.ovf || n == 0) {  // arena overflow (the host redoes the batch) or no candidate at all: only report
         if (p.host_ctrl && blockIdx.x == 0 && threadIdx.x < 16)
@@ -1204,12 +987,12 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
         if (r >= n_g) return;
         const uint32_t g = p.s_src[r];
         const uint64_t key = p.s_key[r];
-        const uint32_t nblk = (n + RK - 1u) / RK;
-        const uint32_t b = min(p.gaps[g].w / RK, nblk - 1u);  // the block of the candidate that reported the stretch
+        const uint32_t nblk = (n + RKe - 1u) / RKe;
+        const uint32_t b = min(p.gaps[g].w / RKe, nblk - 1u);  // the block of the candidate that reported the stretch
         const uint32_t cb = p.cnt256[b];
         uint32_t below = 0;  // minimizers of block b in front of the stretch
         for (uint32_t e = lane; e < cb; e += 64u) {
-            const uint32_t src = b * RK + e;
+            const uint32_t src = b * RKe + e;
             below += ((((uint64_t)p.cs_c[src] << 32) | p.cs_k[src]) < key) ? 1u : 0u;
         }
         const uint64_t o0 = obase + count_prefix(p.cnt256, p.sel_sup, b) + wave_sum_u32(below) + p.s_off[r];
@@ -1225,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     // ~400 minimizers; flag mode (dense path): a tile = TILE candidates
     constexpr uint32_t ECB = EMIT_COMPACT_BLOCKS;
     const uint32_t tile = blockIdx.x - n_place;
-    const uint32_t span = p.cs_h ? ECB * RK : (uint32_t)TILE;
+    const uint32_t span = p.cs_h ? ECB * RKe : (uint32_t)TILE;
     if ((uint64_t)tile * span >= n) return;  // whole tile beyond the candidates
     uint32_t base = tile * TILE + threadIdx.x * TILE_PER_THREAD;
     const uint32_t fl = p.cs_h ? 0u : load_flags4(p.sel, base, n);
@@ -1237,18 +1020,19 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     } else {
         __shared__ uint32_t sh_before;
         if (threadIdx.x < 64) {
-            const uint32_t bpt = span / RK;  // k_resolve blocks per tile
+            const uint32_t bpt = span / RKe;  // k_resolve blocks per tile
             const uint32_t bef = count_prefix(p.cnt256, p.sel_sup, tile * bpt);
             if (threadIdx.x == 0) sh_before = bef;
             if (p.cs_h) {
-                const uint32_t nblk = (n + RK - 1u) / RK, b = tile * ECB + threadIdx.x;
+                const uint32_t nblk = (n + RKe - 1u) / RKe, b = tile * ECB + threadIdx.x;
                 const uint32_t cb = threadIdx.x < ECB && b < nblk ? p.cnt256[b] : 0u;
                 const uint32_t incl = wave_inclusive_u32(cb, threadIdx.x);
                 if (threadIdx.x < ECB) spre[threadIdx.x + 1] = incl;
                 if (threadIdx.x == 0) spre[0] = 0;
             }
             if ((n - 1) / span == tile) {  // the tile holding the last candidate also reports the totals
-                const uint32_t all = count_prefix(p.cnt256, p.sel_sup, (n + RK - 1u) / RK);
+                const uint32_t all = count_prefix(p.cnt256, p.sel_sup, (n + RKe - 1u) / RKe);
+                const uint32_t n_report = p.cand_spread ? wave_sum_u32(p.cand_spread[threadIdx.x * 32u]) : *p.n_ptr;
                 const uint64_t total = (uint64_t)all + nB;
                 if (threadIdx.x == 0) {
                     p.n_sel[0] = all;
@@ -1258,7 +1042,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
                 }
                 if (p.host_ctrl && threadIdx.x < 16) {  // layout: see HostCtrl
                     const uint32_t w = threadIdx.x;
-                    p.host_ctrl[w] = w == 1 ? n_g_raw : w == 2 ? all : w == 3 ? flag : w == 4 ? *p.n_ptr : w == 5 ? nB
+                    p.host_ctrl[w] = w == 1 ? n_g_raw : w == 2 ? all : w == 3 ? flag : w == 4 ? n_report : w == 5 ? nB
                                    : w == 6 ? (uint32_t)total : w == 7 ? (uint32_t)(total >> 32)
                                    : w == 8 ? (uint32_t)obase : w == 9 ? (uint32_t)(obase >> 32)
                                    : (w == 10 && p.dev_gaps) ? p.ovf[10] : 0u;
@@ -1288,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
 #pragma unroll
             for (uint32_t st = ECB / 2; st > 0; st >>= 1)
                 if (spre[u + st] <= r) u += st;
-            const uint32_t src = (tile * ECB + u) * RK + (r - spre[u]);
+            const uint32_t src = (tile * ECB + u) * RKe + (r - spre[u]);
             hsh = p.cs_h[src];
             kx = p.cs_k[src];
             ctg = p.cs_c[src];
@@ -1939,7 +1723,8 @@ struct Driver {
         hipEvent_t wait = nullptr;  // recorded behind the previous batch of the assembly when that ran on the other stream
     };
     int emit(const uint32_t *d_packed, const Tables &T, uint32_t n_cap, DevBuf &oh, DevBuf &op, DevBuf &orc, DevBuf &of,
-             uint64_t out_base, bool fused = false, uint32_t *host_ctrl = nullptr, const ChainIO *io = nullptr)
+             uint64_t out_base, bool fused = false, uint32_t *host_ctrl = nullptr, const ChainIO *io = nullptr,
+             uint32_t rk = RK, uint32_t n_fixed = 0, const uint32_t *cand_spread = nullptr)
     {
         const uint64_t limit = std::min<uint64_t>({oh.bytes / 8, op.bytes / 4, orc.bytes / 4, of.bytes});
         if (!n_cap) return MXG_OK;
@@ -1974,8 +1759,11 @@ struct Driver {
         ep.base_in = io ? io->base_in : nullptr;
         ep.base_out = io ? io->base_out : nullptr;
         ep.dev_gaps = io && io->dev_gaps ? 1u : 0u;
-        const uint32_t n_grid = grid_cand ? std::min(grid_cand, n_cap) : n_cap;
-        ep.n_tiles = fused ? (n_grid + EMIT_COMPACT_BLOCKS * RK - 1) / (EMIT_COMPACT_BLOCKS * RK) : (n_grid + TILE - 1) / TILE;
+        ep.rk = rk;
+        ep.n_fixed = n_fixed;
+        ep.cand_spread = cand_spread;
+        const uint32_t n_grid = n_fixed ? n_fixed : (grid_cand ? std::min(grid_cand, n_cap) : n_cap);
+        ep.n_tiles = fused ? (n_grid + EMIT_COMPACT_BLOCKS * rk - 1) / (EMIT_COMPACT_BLOCKS * rk) : (n_grid + TILE - 1) / TILE;
         ep.s_key = nullptr;
         ep.s_off = ep.s_src = nullptr;
         ep.gaps = nullptr;
@@ -2181,6 +1969,57 @@ struct Driver {
         const uint32_t rounds = (uint32_t)std::max<uint64_t>(1, (n_tiles + 128 * bpc) / (256 * bpc));  // nearest
         return (n_tiles + rounds - 1) / rounds;
     }
+    // stretches sketched on the device, one block each (results wait in their regions for k_gap_post): reads SC_GAPS / ctrl[1]
+    int enqueue_dev_gaps(Assembly *a, const Tables &T)
+    {
+        MXG_HIP(h, sc(SC_GR_HASH).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 8));
+        MXG_HIP(h, sc(SC_GR_POS).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
+        MXG_HIP(h, sc(SC_GR_REC).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
+        MXG_HIP(h, sc(SC_GR_CNT).ensure((size_t)GAP_DEV_MAX * 4));
+        MXG_HIP(h, sc(SC_GR_KEY).ensure((size_t)GAP_DEV_MAX * 8));
+        MXG_HIP(h, sc(SC_GD_HASH).ensure((size_t)(GAP_DEV_MAX + 1) * 8));  // the stretches in order: key,
+        MXG_HIP(h, sc(SC_GD_POS).ensure((size_t)(GAP_DEV_MAX + 1) * 4));   // minimizers before,
+        MXG_HIP(h, sc(SC_GD_REC).ensure((size_t)(GAP_DEV_MAX + 1) * 4));   // region
+        GapFixParams gp;
+        gp.gaps = sc(SC_GAPS).as<uint4>();
+        gp.ctrl = sc(SC_CTRL).as<uint32_t>();
+        gp.runs = T.d_runs;
+        gp.ctg_run0 = T.d_ctg_run0;
+        gp.ctg_rec = T.d_ctg_rec;
+        gp.ctg_drop = T.d_ctg_drop;
+        gp.packed = a->d_packed;
+        gp.init_tab = h->d_init_tab.as<uint4>();
+        gp.k = h->cfg.k;
+        gp.w = h->cfg.w;
+        gp.mult = 1ull ^ ((uint64_t)h->cfg.k * 0x90b45d39fb6da1faull);
+        gp.r_hash = sc(SC_GR_HASH).as<uint64_t>();
+        gp.r_pos = sc(SC_GR_POS).as<uint32_t>();
+        gp.r_rec = sc(SC_GR_REC).as<uint32_t>();
+        gp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
+        gp.r_key = sc(SC_GR_KEY).as<uint64_t>();
+        gp.tab = h->tab;
+        if (h->cfg.variant == MXG_VARIANT_V1_MIN)
+            hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V1_MIN>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
+        else
+            hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V2_SUM>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
+        GapPostParams pp;
+        pp.ctrl = sc(SC_CTRL).as<uint32_t>();
+        pp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
+        pp.r_key = sc(SC_GR_KEY).as<uint64_t>();
+        pp.s_key = sc(SC_GD_HASH).as<uint64_t>();
+        pp.s_off = sc(SC_GD_POS).as<uint32_t>();
+        pp.s_src = sc(SC_GD_REC).as<uint32_t>();
+        pp.fx = gp;
+        MXG_HIP(h, sc(SC_GB_WORK).ensure((size_t)GAP_BIG_WORK_WORDS * 4));
+        pp.big_work = sc(SC_GB_WORK).as<uint32_t>();
+        if (h->cfg.variant == MXG_VARIANT_V1_MIN)
+            hipLaunchKernelGGL(k_gap_post<MXG_VARIANT_V1_MIN>, dim3(1), dim3(GPB), 0, st, pp);
+        else
+            hipLaunchKernelGGL(k_gap_post<MXG_VARIANT_V2_SUM>, dim3(1), dim3(GPB), 0, st, pp);
+        MXG_HIP(h, hipGetLastError());
+        return MXG_OK;
+    }
+
     int enqueue_sparse(Assembly *a, const Tables &T, const BatchGeom &g, uint64_t wave_cap, uint32_t tau_hi,
                        OutArrays &out, uint32_t *ctrl_host, uint32_t *n_cap_out, const ChainIO *io = nullptr,
                        uint32_t cand_hint = 0xFFFFFFFFu)
@@ -2336,58 +2175,120 @@ struct Driver {
         if ((rc = resolve_count(T, n_cap, (uint32_t)g.c0, (uint32_t)g.c1, (uint64_t)tau_hi << 32,
                                 cand_hint != 0xFFFFFFFFu ? cand_hint : a->cand_hint)) != MXG_OK) return rc;
         const bool dev = io && io->dev_gaps;
-        if (dev) {  // stretches sketched on the device, one block each (results wait in their regions for k_gap_post)
-            MXG_HIP(h, sc(SC_GR_HASH).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 8));
-            MXG_HIP(h, sc(SC_GR_POS).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
-            MXG_HIP(h, sc(SC_GR_REC).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
-            MXG_HIP(h, sc(SC_GR_CNT).ensure((size_t)GAP_DEV_MAX * 4));
-            MXG_HIP(h, sc(SC_GR_KEY).ensure((size_t)GAP_DEV_MAX * 8));
-            MXG_HIP(h, sc(SC_GD_HASH).ensure((size_t)(GAP_DEV_MAX + 1) * 8));  // the stretches in order: key,
-            MXG_HIP(h, sc(SC_GD_POS).ensure((size_t)(GAP_DEV_MAX + 1) * 4));   // minimizers before,
-            MXG_HIP(h, sc(SC_GD_REC).ensure((size_t)(GAP_DEV_MAX + 1) * 4));   // region
-            GapFixParams gp;
-            gp.gaps = sc(SC_GAPS).as<uint4>();
-            gp.ctrl = sc(SC_CTRL).as<uint32_t>();
-            gp.runs = T.d_runs;
-            gp.ctg_run0 = T.d_ctg_run0;
-            gp.ctg_rec = T.d_ctg_rec;
-            gp.ctg_drop = T.d_ctg_drop;
-            gp.packed = a->d_packed;
-            gp.init_tab = h->d_init_tab.as<uint4>();
-            gp.k = h->cfg.k;
-            gp.w = h->cfg.w;
-            gp.mult = 1ull ^ ((uint64_t)h->cfg.k * 0x90b45d39fb6da1faull);
-            gp.r_hash = sc(SC_GR_HASH).as<uint64_t>();
-            gp.r_pos = sc(SC_GR_POS).as<uint32_t>();
-            gp.r_rec = sc(SC_GR_REC).as<uint32_t>();
-            gp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
-            gp.r_key = sc(SC_GR_KEY).as<uint64_t>();
-            gp.tab = h->tab;
-            if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-                hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V1_MIN>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
-            else
-                hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V2_SUM>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
-            GapPostParams pp;
-            pp.ctrl = sc(SC_CTRL).as<uint32_t>();
-            pp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
-            pp.r_key = sc(SC_GR_KEY).as<uint64_t>();
-            pp.s_key = sc(SC_GD_HASH).as<uint64_t>();
-            pp.s_off = sc(SC_GD_POS).as<uint32_t>();
-            pp.s_src = sc(SC_GD_REC).as<uint32_t>();
-            pp.fx = gp;
-            MXG_HIP(h, sc(SC_GB_WORK).ensure((size_t)GAP_BIG_WORK_WORDS * 4));
-            pp.big_work = sc(SC_GB_WORK).as<uint32_t>();
-            if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-                hipLaunchKernelGGL(k_gap_post<MXG_VARIANT_V1_MIN>, dim3(1), dim3(GPB), 0, st, pp);
-            else
-                hipLaunchKernelGGL(k_gap_post<MXG_VARIANT_V2_SUM>, dim3(1), dim3(GPB), 0, st, pp);
-            MXG_HIP(h, hipGetLastError());
-        }
+        if (dev && (rc = enqueue_dev_gaps(a, T)) != MXG_OK) return rc;
         if ((rc = ev_next(4)) != MXG_OK) return rc;
         // the batch before this one (same assembly, other stream) must have passed its count on
         if (io && io->wait) MXG_HIP(h, hipStreamWaitEvent(st, io->wait, 0));
         rc = emit(a->d_packed, T, n_cap, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host, io);
         grid_cand = 0;
+        if (rc != MXG_OK) return rc;
+        return ev_end();
+    }
+
+    // ---- k = 32 route (sketch_bs.hip): the assembly's filter bitmap is in a->d_bs_out (bs_hash, enqueued by the caller on
+    // some stream this one has been made to wait for); one batch = k_bs_resolve over the batch's chunks -> stretches -> emit.
+    struct BsGeom {
+        uint32_t chunk_lo, n_blocks, rk, halo_l, halo_r, max_cand;
+        bool ok;
+    };
+    BsGeom bs_geom(const Tables &T, const BatchGeom &g, double frac) const
+    {
+        BsGeom b{};
+        const uint32_t w = h->cfg.w;
+        const Run &r0 = (*T.runs)[g.r_lo], &r1 = (*T.runs)[g.r_hi - 1];
+        const uint64_t pos_lo = r0.base_off, pos_hi = r1.base_off + r1.n_kmers;  // first positions of the batch's k-mers
+        b.chunk_lo = (uint32_t)((pos_lo + 32) / BS_CHUNK);
+        b.n_blocks = (uint32_t)((pos_hi - 1 + 32) / BS_CHUNK) - b.chunk_lo + 1;
+        b.halo_l = (w - 1 + BSR_HALO_LANE - 1) / BSR_HALO_LANE;
+        b.halo_r = (GAP_DEV_NMAX + w + BSR_HALO_LANE - 1) / BSR_HALO_LANE;
+        const double range = (double)BS_CHUNK + (double)(b.halo_l + b.halo_r) * BSR_HALO_LANE;
+        // raw candidates of a block's range: what passes the ring test (the top-bits sum lets ~2 % more through than tau)
+        const double raw = range * frac * 1.05;
+        uint32_t mc = (uint32_t)(raw * 1.25 + 6.0 * std::sqrt(raw) + 128.0);
+        mc = std::max<uint32_t>(mc, (uint32_t)((range / 32 + 8) / 4) + 1);  // (the position-order bitmap lies over the candidates)
+        b.max_cand = (mc + 255u) / 256u * 256u;
+        const double sel = (double)BS_CHUNK * 2.0 / (double)(w + 1);
+        b.rk = ((uint32_t)(sel * 1.5 + 6.0 * std::sqrt(sel) + 96.0) + 63u) / 64u * 64u;
+        b.ok = b.max_cand <= 3072 && (uint64_t)b.n_blocks * b.rk < (1ull << 31) && b.halo_l + b.halo_r <= 12;
+        return b;
+    }
+    int enqueue_bs(Assembly *a, const Tables &T, const BatchGeom &g, const BsGeom &b, uint32_t tau_hi, OutArrays &out,
+                   uint32_t *ctrl_host, const ChainIO *io)
+    {
+        int rc;
+        MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
+        n_wave_sup = 0;
+        const size_t ctrl_bytes = ((size_t)CTRL_WORDS + sup_words(b.n_blocks) + 64 * 32) * 4;  // + the candidate counters
+        MXG_HIP(h, sc(SC_CTRL).ensure(ctrl_bytes));
+        MXG_HIP(h, sc(SC_CNT256).ensure((size_t)b.n_blocks * 4 + 64));
+        const size_t n_ent = (size_t)b.n_blocks * b.rk;
+        MXG_HIP(h, sc(SC_CS_H).ensure(n_ent * 8));
+        MXG_HIP(h, sc(SC_CS_K).ensure(n_ent * 4));
+        MXG_HIP(h, sc(SC_CS_C).ensure(n_ent * 4));
+        MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, ctrl_bytes, st));
+        if ((rc = ev_begin(0, false, fine ? 3 : 1)) != MXG_OK) return rc;
+        BsResolveParams bp{};
+        bp.out = a->d_bs_out.as<uint32_t>();
+        bp.n_chunks = a->bs_chunks;
+        bp.packed = a->d_packed;
+        bp.n_words = a->packed_words;
+        bp.runs = T.d_runs;
+        bp.chunk_run0 = a->d_bs_run0.as<uint32_t>();
+        bp.ctg_nk = T.d_ctg_nk;
+        bp.ctg_drop = T.d_ctg_drop;
+        bp.init_tab = h->d_init_tab.as<uint4>();
+        bp.tab = h->tab;
+        bp.run_lo = g.r_lo;
+        bp.run_hi = g.r_hi;
+        bp.ctg_lo = (uint32_t)g.c0;
+        bp.ctg_hi = (uint32_t)g.c1;
+        bp.chunk_lo = b.chunk_lo;
+        bp.k = h->cfg.k;
+        bp.w = h->cfg.w;
+        bp.tau = (uint64_t)tau_hi << 32;
+        bp.halo_l = b.halo_l;
+        bp.halo_r = b.halo_r;
+        bp.max_cand = b.max_cand;
+        bp.rk = b.rk;
+        bp.cs_h = sc(SC_CS_H).as<uint64_t>();
+        bp.cs_k = sc(SC_CS_K).as<uint32_t>();
+        bp.cs_c = sc(SC_CS_C).as<uint32_t>();
+        bp.cnt = sc(SC_CNT256).as<uint32_t>();
+        bp.sup = sel_sup(0);
+        bp.gaps = sc(SC_GAPS).as<uint4>();
+        bp.gap_cap = GAP_CAP;
+        bp.ctrl = sc(SC_CTRL).as<uint32_t>();
+        bp.cand_spread = sel_sup(0) + sup_words(b.n_blocks);
+        bp.ablate = (uint32_t)env_u64("MXG_BSR_ABLATE", 0);  // (profiling only)
+        bp.dbg = nullptr;
+        if (env_u64("MXG_BSR_DBG", 0)) {  // (profiling only: cycle stamps of the phases, printed for one launch)
+            MXG_HIP(h, h->dbg_buf.ensure((size_t)b.n_blocks * 16 * 8));
+            bp.dbg = h->dbg_buf.as<unsigned long long>();
+            MXG_HIP(h, hipMemsetAsync(h->dbg_buf.p, 0, (size_t)b.n_blocks * 16 * 8, st));
+            h->dbg_blocks = b.n_blocks;
+        }
+        launch_bs_resolve(bp, b.n_blocks, st);
+        MXG_HIP(h, hipGetLastError());
+        if (bp.dbg) {
+            MXG_HIP(h, hipStreamSynchronize(st));
+            std::vector<unsigned long long> v((size_t)b.n_blocks * 16);
+            MXG_HIP(h, hipMemcpy(v.data(), bp.dbg, v.size() * 8, hipMemcpyDeviceToHost));
+            double acc[9] = {0};
+            unsigned long long t_min = ~0ull, t_max = 0;
+            for (uint32_t q = 0; q < b.n_blocks; ++q) {
+                for (int k = 1; k <= 8; ++k) acc[k] += (double)(v[q * 16 + k] - v[q * 16 + k - 1]);
+                t_min = std::min(t_min, v[q * 16]);
+                t_max = std::max(t_max, v[q * 16 + 8]);
+            }
+            fprintf(stderr, "k_bs_resolve phases (mean ticks per block, %u blocks): issue %.0f | to LDS + window %.0f | scatter %.0f | enumerate %.0f | hash %.0f | resolve %.0f | leading %.0f | counts %.0f ; kernel span %.0f ticks\n",
+                    b.n_blocks, acc[1] / b.n_blocks, acc[2] / b.n_blocks, acc[3] / b.n_blocks, acc[4] / b.n_blocks, acc[5] / b.n_blocks,
+                    acc[6] / b.n_blocks, acc[7] / b.n_blocks, acc[8] / b.n_blocks, (double)(t_max - t_min));
+        }
+        if ((rc = enqueue_dev_gaps(a, T)) != MXG_OK) return rc;
+        if ((rc = ev_next(4)) != MXG_OK) return rc;
+        if (io && io->wait) MXG_HIP(h, hipStreamWaitEvent(st, io->wait, 0));
+        rc = emit(a->d_packed, T, (uint32_t)n_ent, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host, io, b.rk,
+                  (uint32_t)n_ent, bp.cand_spread);
         if (rc != MXG_OK) return rc;
         return ev_end();
     }
@@ -2689,7 +2590,9 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         int slot;
         uint32_t n_cap;
         uint32_t *hc;  // pinned control block
+        bool bs;       // went through the k = 32 route (no candidate arrays to finish from)
     };
+    static const bool bs_env = env_u64("MXG_BS", 1) != 0;
     std::vector<Tables> tabs(n);
     std::vector<int> state(n, 0);  // 0 = synchronous path, 1 = enqueued, 2 = done
     std::vector<SparsePlan> plans(n);
@@ -2720,6 +2623,20 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         if (gs.size() > 1 && list[i]->any_drop && !plans[i].dev_gaps) {
             // (fine either way; nothing special: ctg_drop travels with the tables)
         }
+        // the k = 32 route: the bit-sliced filter over the whole assembly, then one k_bs_resolve per batch (sketch_bs.hip)
+        bool use_bs = bs_env && plans[i].dev_gaps && !chain_modes && h->cfg.w >= 256 && h->cfg.w <= GAP_DEV_NMAX / 2 &&
+                      bs_possible(h, list[i]);
+        std::vector<Driver::BsGeom> bgs;
+        if (use_bs) {
+            if ((rc = bs_prepare(h, list[i])) != MXG_OK) return rc;
+            use_bs = list[i]->bs_ready;
+            for (size_t b = 0; use_bs && b < gs.size(); ++b) {
+                bgs.push_back(drv0.bs_geom(tabs[i], gs[b], plans[i].frac));
+                use_bs = bgs.back().ok;
+            }
+        }
+        hipEvent_t ev_hash = nullptr;
+        hipStream_t st_hash = nullptr;
         OutArrays out{&list[i]->d_hash, &list[i]->d_pos, &list[i]->d_rec, &list[i]->d_fwd, 0};
         // chain words: [item] = where the NEXT batch starts
         MXG_HIP(h, h->d_chain.ensure((size_t)PINNED_SLOTS * 8));
@@ -2737,6 +2654,24 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             it.g = gs[b];
             it.slot = (int)sl;
             it.n_cap = 0;
+            it.bs = use_bs;
+            if (use_bs && b == 0) {  // the filter, once per assembly, on the first batch's stream
+                st_hash = drv.st;
+                if ((rc = drv.ev_begin(list[i]->total_bases, true)) != MXG_OK) return rc;
+                if ((rc = bs_hash(h, list[i], plans[i].tau_hi, drv.st)) != MXG_OK) return rc;
+                if ((rc = drv.ev_end()) != MXG_OK) return rc;
+                if (gs.size() > 1) {
+                    while (h->ev_bs.size() <= i) {
+                        hipEvent_t e;
+                        MXG_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                        h->ev_bs.push_back(e);
+                    }
+                    ev_hash = h->ev_bs[i];
+                    MXG_HIP(h, hipEventRecord(ev_hash, drv.st));
+                }
+            } else if (use_bs && drv.st != st_hash) {
+                MXG_HIP(h, hipStreamWaitEvent(drv.st, ev_hash, 0));
+            }
             it.hc = h->pinned_ctrl + 16 * items.size();
             memset(it.hc, 0xFF, 64);
             Driver::ChainIO io;
@@ -2759,8 +2694,10 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
                 drv.n_out = h->d_nmx.as<uint32_t>() + i;
             }
-            if ((rc = drv.enqueue_sparse(list[i], tabs[i], it.g, drv.default_wave_cap(list[i]->S_sparse, plans[i].frac),
-                                         plans[i].tau_hi, out, it.hc, &it.n_cap, &io, list[i]->cand_hints[b])) != MXG_OK)
+            if (use_bs) {
+                if ((rc = drv.enqueue_bs(list[i], tabs[i], it.g, bgs[b], plans[i].tau_hi, out, it.hc, &io)) != MXG_OK) return rc;
+            } else if ((rc = drv.enqueue_sparse(list[i], tabs[i], it.g, drv.default_wave_cap(list[i]->S_sparse, plans[i].frac),
+                                                plans[i].tau_hi, out, it.hc, &it.n_cap, &io, list[i]->cand_hints[b])) != MXG_OK)
                 return rc;
             last_on_slot[sl] = items.size();
             items.push_back(it);
@@ -2851,7 +2788,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             state[i] = 2;
             if (fused && total > gb.n_bound[i]) fused = false;  // a sketch outgrew the bound the graph stage was sized for
             ++n_fast;
-        } else if (q1 - q0 == 1 && items[q0].hc[0] == 0 && items[q0].hc[4] != 0xFFFFFFFFu && last_on_slot[items[q0].slot] == q0) {
+        } else if (q1 - q0 == 1 && !items[q0].bs && items[q0].hc[0] == 0 && items[q0].hc[4] != 0xFFFFFFFFu &&
+                   last_on_slot[items[q0].slot] == q0) {
             // one batch, no arena overflow, and its candidate arrays are still intact in the driver's scratch: finish from
             // there the general way (staging emit, dense fix-up of the stretches, merge) instead of redoing the batch
             Driver &drv = *drvs[items[q0].slot];
