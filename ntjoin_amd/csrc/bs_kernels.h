@@ -6,7 +6,7 @@
 // Layouts (see gen/bs_gen.py for why): a chunk = 65 536 base positions = 64 lanes x 32 strips x 32 positions
 //     T[chunk][t / 2][lane][2 (t & 1) + beta]  u32   bit s = bit beta of the base at chunk * 65536 + (32 lane + s) * 32 + t
 //     Q[chunk][lane][beta]                     u32   bit t = bit beta of the base at chunk * 65536 + (32 lane - 1) * 32 + t
-//     OUT[chunk][t / 4][lane][t & 3]           u32   bit s = the 32-mer at chunk * 65536 + (32 lane + s - 1) * 32 + t passed the ring test
+//     OUT[chunk][s / 4][lane][s & 3]           u32   bit t = the 32-mer at chunk * 65536 + (32 lane + s - 1) * 32 + t passed the ring test
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void k_bs_transpose(const uint32_t *__restrict_
 
 // The filter.  Blocks of 256 threads = one wave per SIMD; the grid is sized for TWO waves per SIMD (an even number of waves
 // per SIMD issues at 2.05 cycles per instruction, an odd one at 2.5-2.7: profiles/ubench), every wave takes the chunks
-// c0, c0 + stride, ...  The body is generated (gen/bs_gen.py) and owns v8..v215 and s36..s77; the few values around it
+// c0, c0 + stride, ...  The body is generated (gen/bs_gen.py) and owns v8..v243 and s36..s82; the few values around it
 // stay in v0..v7.
 __global__ __launch_bounds__(256) void k_hash_bs(const uint32_t *__restrict__ T, const uint32_t *__restrict__ Q,
                                                  uint32_t *__restrict__ OUT, uint32_t c_lo, uint32_t c_hi, uint32_t tt)

@@ -28,9 +28,11 @@ the previous lane's last strip coming in at the bottom (bit t of Q: a running v_
 (v_addc_co_u32 with the carry in an SGPR pair would do it in one instruction -- and is slow class: the body ran at 3.7
 cycles per instruction with 126 of them among 5 860, at 2.25 without.)  The 32
 bases of a strip are at once the warm-up input of its own slot, the outgoing bases of that slot and the incoming bases of
-the slot below.  Per chunk: 32 warm-up steps (no outgoing base, no test), 32 productive steps (test, then roll); the result
-of step t goes out as it is:
-    OUT[chunk][t / 4][lane][t & 3]           (u32)   bit s = the 32-mer at chunk * 65536 + (32 lane + s - 1) * 32 + t passed
+the slot below.  Per chunk: 32 warm-up steps (no outgoing base, no test), 32 productive steps (test, then roll); the 32
+result words of a lane (word t: bit s = slot s) are transposed in registers (32 x 32 bits, left shifts as chains of
+v_add_u32) into position order and go out as
+    OUT[chunk][s / 4][lane][s & 3]           (u32)   bit t = the 32-mer at chunk * 65536 + (32 lane + s - 1) * 32 + t passed
+(the consumer then reads whole strips; as words per step it had to scatter every set bit: 5 000 cycles per chunk)
 The words of the next chunk are requested into the registers of the current one as soon as a step has read them.
 
 The same instruction list is (1) printed as gfx950 assembly for one inline-asm block with fixed registers (the chunk loop
@@ -141,7 +143,7 @@ B0 = 8                     # first VGPR of the block (the compiler keeps v0..v7)
 W0 = B0                    # 64 registers
 G0 = W0 + 64               # 31 groups of 4: FP[i], RP[i], bank 2, bank 3
 X0 = G0 + 124              # the rest
-VEND = X0 + 20
+VEND = X0 + 48
 
 
 def grp(i, q):
@@ -166,7 +168,8 @@ S_OC = S0 + 20      # 2 pairs: this chunk's OUT words + k * 4096
 S_QN = S0 + 24      # pair: the next chunk's Q words
 S_TMP = S0 + 26     # pair
 S_CM = S0 + 28      # B_PLANES compare masks
-SEND = S_CM + B_PLANES
+S_M16, S_M8, S_M4, S_M2, S_M1 = (S0 + 28 + B_PLANES + i for i in range(5))  # the transpose's select masks
+SEND = S_M1 + 1
 
 
 class Gen:
@@ -183,11 +186,12 @@ class Gen:
         self.B = [grp(g, 3) for g in range(7)]   # in0 in1 ... of the incoming base
         self.cy, self.s = grp(7, 2), grp(7, 3)
         assert X0 % 4 == 0
-        self.mt = [[f"v{X0 + i}" for i in range(4)], [f"v{X0 + 4 + i}" for i in range(4)]]  # results of 4 steps, two blocks
-        self.Qn = [f"v{X0 + 8}", f"v{X0 + 9}"]     # the next chunk's Q words (a dwordx2), the chunk's, their running shifts
-        self.Q = [f"v{X0 + 10}", f"v{X0 + 11}"]
-        self.Qr = [f"v{X0 + 12}", f"v{X0 + 13}"]   # banks 0, 1 (read with a bank 2 register by one v_bitop3_b32)
-        self.le, self.ones = f"v{X0 + 16}", f"v{X0 + 17}"
+        self.M = [f"v{X0 + i}" for i in range(32)]  # the steps' results, then their transpose (8 x dwordx4 go out)
+        self.Qn = [f"v{X0 + 32}", f"v{X0 + 33}"]   # the next chunk's Q words (a dwordx2), the chunk's, their running shifts
+        self.Q = [f"v{X0 + 34}", f"v{X0 + 35}"]
+        self.Qr = [f"v{X0 + 36}", f"v{X0 + 37}"]   # banks 0, 1 (read with a bank 2 register by one v_bitop3_b32)
+        self.le, self.ones = f"v{X0 + 40}", f"v{X0 + 41}"
+        self.TT = [f"v{X0 + 44 + i}" for i in range(4)]  # temporaries of the transpose, one per bank
         self.neg = {}
 
     def e(self, *t):
@@ -311,10 +315,7 @@ class Gen:
                     e('mov', ones, s)
                 elif idx >= 2:
                     e('and', ones, ones, s)
-            mblk = self.mt[(t // 4) % 2]
-            e('or', mblk[t % 4], le, ones)
-            if t % 4 == 3:
-                e('gstore4', mblk[0], S_OC + 2 * ((t // 4) // 4), ((t // 4) % 4) * 1024)
+            e('or', self.M[t], le, ones)
             if t < 31:
                 for r in range(31):
                     jf = (r + n + 1) % 31
@@ -322,8 +323,33 @@ class Gen:
                 for r in range(31):
                     jr = (r - n) % 31
                     self.plane_update(RP[r], self.ro[jr], mA, self.ri[jr], mB)
+        self.transpose_out()
+        for q in range(8):
+            e('gstore4', self.M[4 * q], S_OC + 2 * (q // 4), (q % 4) * 1024)
         self.check_banks()
         return self.ins
+
+    def transpose_out(self):
+        """M[t] bit s -> M[s] bit t, in place.  Stage j pairs rows k, k + j: new_k = (k & m) | ((k+j << j) & ~m),
+        new_k+j = ((k >> j) & m) | (k+j & ~m), m = the bits whose index has bit j clear (an SGPR: v_bitop3_b32 with one SGPR source
+        stays fast class); the left shift is j times v_add_u32 x, x (v_lshlrev_b32 is slow class)."""
+        e = self.e
+        sel = self.tt3(lambda a, b2, c: a if c else b2)
+        for j, sm in ((16, S_M16), (8, S_M8), (4, S_M4), (2, S_M2), (1, S_M1)):
+            for k in range(32):
+                if k & j:
+                    continue
+                a, bq = self.M[k], self.M[k + j]
+                t0 = self.TT[(bank(a) + 1) % 4]
+                t1 = self.TT[(bank(bq) + 1) % 4]
+                if t1 == t0:
+                    t1 = self.TT[(bank(bq) + 2) % 4]
+                e('add', t0, bq, bq)
+                for _ in range(j - 1):
+                    e('add', t0, t0, t0)
+                e('lshr', t1, a, j)
+                e('bitop3', a, a, t0, f"s{sm}", sel)
+                e('bitop3', bq, t1, bq, f"s{sm}", sel)
 
     def check_banks(self):
         """no v_bitop3_b32 may read two VGPRs of one bank"""
@@ -383,6 +409,8 @@ class Gen:
         for i in range(self.b):  # compare masks: Cm_i = all ones iff bit i of the threshold is set
             A(f"s_bfe_u32 s{S_TMP}, s{S_TT}, {hex((1 << 16) | i)}")
             A(f"s_sub_u32 s{S_CM + i}, 0, s{S_TMP}")
+        for sm, val in ((S_M16, 0x0000FFFF), (S_M8, 0x00FF00FF), (S_M4, 0x0F0F0F0F), (S_M2, 0x33333333), (S_M1, 0x55555555)):
+            A(f"s_mov_b32 s{sm}, {hex(val)}")
         A(f"s_cmp_ge_u32 s{S_C}, s{S_N}")
         A("s_cbranch_scc1 L_bs_end_%=")
         # prologue: the first chunk's words and P entries
@@ -426,6 +454,7 @@ class VM:
         self.c, self.cn = c, c_next
         self.vr = {}
         self.sr = {S_CM + i: (0xFFFFFFFF if (tt >> i) & 1 else 0) for i in range(B_PLANES)}
+        self.sr.update({S_M16: 0x0000FFFF, S_M8: 0x00FF00FF, S_M4: 0x0F0F0F0F, S_M2: 0x33333333, S_M1: 0x55555555})
         self.out = np.zeros((8, 64, 4), dtype=np.uint32)
 
     def V(self, x):
@@ -548,7 +577,7 @@ def reference_bits(codes, k, tt, b_planes=B_PLANES):
 
 
 def out_position(c, t, lane, s):
-    """position of the k-mer behind bit s of OUT[c][t / 4][lane][t & 3]"""
+    """position of the k-mer behind bit t of OUT[c][s / 4][lane][s & 3]"""
     return c * CHUNK + (32 * lane + s - 1) * 32 + t
 
 

@@ -29,29 +29,30 @@ __device__ __forceinline__ uint32_t lds_base2(const uint32_t *pk, uint32_t rel) 
     return __builtin_amdgcn_alignbit(pk[wi + 1], pk[wi], sh);
 }
 
-// canonical hash (fwd + rev) of the 32-mer at LDS base index rel: byte table of the direct formula, Horner over the bytes
-__device__ __forceinline__ uint64_t hash32_lds(const uint32_t *pk, uint32_t rel, const uint4 *btab)
+// canonical hash (fwd + rev) of the 32-mer at LDS base index rel: half position tables (init32_half, nthash_dev.h:
+// half[j][v] = {srol^{4(3-j)} f4[v], srol^{4j} r4[v]}; bytes 0..3 and 4..7 of the k-mer through the same four tables, joined by
+// two rotations by 16) -- 16 KB of LDS where the full position tables take 32 KB and a second block per CU
+__device__ __forceinline__ uint64_t hash32_lds(const uint32_t *pk, uint32_t rel, const uint4 *half)
 {
-    uint32_t flo = 0, fhi = 0, tlo = 0, thi = 0;
+    const uint32_t wi = rel >> 4, sh = (rel & 15u) * 2u;
+    const uint32_t w0 = pk[wi], w1 = pk[wi + 1], w2 = pk[wi + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    uint4 a = make_uint4(0u, 0u, 0u, 0u), c = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (uint32_t q = 0; q < 2; ++q) {
-        const uint32_t word = lds_base2(pk, rel + 16u * q);
-#pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-            const uint4 e = btab[(word >> (8 * u)) & 255u];
-            srol4(flo, fhi);
-            sror4(tlo, thi);
-            flo ^= e.x; fhi ^= e.y; tlo ^= e.z; thi ^= e.w;
-        }
+    for (uint32_t u = 0; u < 4; ++u) {
+        const uint4 e0 = half[u * 256u + ((lo >> (8 * u)) & 255u)];
+        const uint4 e1 = half[u * 256u + ((hi >> (8 * u)) & 255u)];
+        a.x ^= e0.x; a.y ^= e0.y; a.z ^= e0.z; a.w ^= e0.w;
+        c.x ^= e1.x; c.y ^= e1.y; c.z ^= e1.z; c.w ^= e1.w;
     }
-    srol_var(tlo, thi, 28u);  // R = srol^{4 (P - 1)}(T), P = 8 bytes
-    const uint64_t f = ((uint64_t)fhi << 32) | flo, r = ((uint64_t)thi << 32) | tlo;
-    return f + r;
+    srol16(a.x, a.y);
+    srol16(c.z, c.w);
+    return (((uint64_t)(a.y ^ c.y) << 32) | (a.x ^ c.x)) + (((uint64_t)(a.w ^ c.w) << 32) | (a.z ^ c.z));
 }
 
 constexpr uint32_t BSR_PAD = 4;  // sentinel entries on either side of the candidates (the scans look at four at a time)
 struct BsLds {
-    uint4 *btab;        // [256]
+    uint4 *btab;        // [1024] half position tables of the direct hash formula
     uint32_t *pk;       // packed words of the block's range (+ 3)
     uint32_t *nat;      // position-order bitmap of the range: word g = strip g (32 positions); lies over cand (dead before)
     uint32_t *posl;     // candidates: position relative to the range start
@@ -64,13 +65,13 @@ struct BsLds {
 
 }  // namespace
 
-// LDS of a block: byte table | cand | posl | cnk | pk | runs | rnk | scan scratch; the position-order bitmap lies over cand
+// LDS of a block: half position tables | cand | posl | cnk | pk | runs | rnk | scan scratch; the position-order bitmap lies over cand
 // (it is dead before that is written), which max_cand must be large enough for (the host sizes max_cand)
 static __host__ __device__ inline uint32_t bsr_range_cap(const BsResolveParams &p) { return BS_CHUNK + (p.halo_l + p.halo_r) * BSR_HALO_LANE; }
 size_t bs_resolve_lds(const BsResolveParams &p)
 {
     const size_t rc = bsr_range_cap(p);
-    return 256 * 16 + ((size_t)p.max_cand + 2 * BSR_PAD) * 16 + (size_t)p.max_cand * 8 + (rc / 16 + 8) * 4 + BSR_RUNS * (sizeof(Run) + 4) +
+    return 1024 * 16 + ((size_t)p.max_cand + 2 * BSR_PAD) * 16 + (size_t)p.max_cand * 8 + (rc / 16 + 8) * 4 + BSR_RUNS * (sizeof(Run) + 4) +
            (256 + 8) * 4;
 }
 
@@ -86,7 +87,7 @@ size_t bs_resolve_lds(const BsResolveParams &p)
         return;                                                         \
     }
 
-__global__ __launch_bounds__(BSR_THREADS, BSR_THREADS / 128) void k_bs_resolve(const BsResolveParams p)
+__global__ __launch_bounds__(BSR_THREADS, 8) void k_bs_resolve(const BsResolveParams p)
 {
     extern __shared__ uint4 lds_raw[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(BSR_THREADS, BSR_THREADS / 128) void k_bs_resolve(c
     // ---- LDS carving (see bs_resolve_lds)
     BsLds L;
     unsigned char *bp = reinterpret_cast<unsigned char *>(lds_raw);
-    L.btab = reinterpret_cast<uint4 *>(bp); bp += 256 * 16;
+    L.btab = reinterpret_cast<uint4 *>(bp); bp += 1024 * 16;
     L.nat = reinterpret_cast<uint32_t *>(bp);
     L.cand = reinterpret_cast<uint4 *>(bp) + BSR_PAD; bp += ((size_t)p.max_cand + 2 * BSR_PAD) * 16;
     L.posl = reinterpret_cast<uint32_t *>(bp); bp += (size_t)p.max_cand * 4;
@@ -114,15 +115,40 @@ __global__ __launch_bounds__(BSR_THREADS, BSR_THREADS / 128) void k_bs_resolve(c
     __shared__ uint32_t s_klo_ctg, s_klo, s_khi_ctg, s_khi;  // the contig cut by the range's start / end and its k-mer there
     if (tid == 0) { s_flag = 0; s_nwin = 0; }
     BSR_STAMP(0)
-    // ---- loads.  Everything the block reads from global memory is requested here, before anything waits (as separate
-    // load-then-store loops the block spent ~20 memory round trips one after the other: 0.5 ms per batch of 7 000 blocks).
+    // ---- loads.  Everything the block reads from global memory is requested at once, by role: wave 0 = the chunk's own 64
+    // lanes of OUT words, the first threads of wave 1 = the halo lanes (the last lanes of the chunks before, the first of the
+    // chunks behind), every thread a share of the packed bases and of the position tables, the first BSR_RUNS + 32 a run.
     const uint4 *o4 = reinterpret_cast<const uint4 *>(p.out);
     const uint32_t rc = (uint32_t)(range_lo / BS_CHUNK);
     const uint32_t run0_c = p.chunk_run0[rc];
-    const uint4 bt = p.init_tab[tid & 255u];
-    constexpr uint32_t PKV = (1536u + BSR_THREADS - 1u) / BSR_THREADS;  // uint4 loads of packed words per thread: the range has <= (65536 + 32 * 1024) / 64 of them
+    uint4 bt0;  // half tables (see init32_half): entry tid = table tid / 256, byte value tid % 256
+    {
+        const uint32_t j = tid >> 8, vb = tid & 255u;
+        const uint4 f = p.init_tab[256u + (j + 4u) * 256u + vb], r = p.init_tab[256u + j * 256u + vb];
+        bt0 = make_uint4(f.x, f.y, r.z, r.w);
+    }
     const uint64_t w0 = (uint64_t)range_lo >> 4;            // (a multiple of 2: range_lo is a multiple of 32)
     const uint32_t nw = (uint32_t)((range_hi - range_lo) >> 4) + 3u;
+    const int64_t strip0 = range_lo >> 5;
+    // the filter's words: OUT[chunk][s/4][lane][s&3] = the 32 positions of strip 32 lane + s - 1 (strips and lanes counted
+    // over all chunks).  Threads 0..511 take the chunk's own 512 uint4, the next (halo_l + halo_r) * 8 the halo lanes' (the
+    // last lanes of the chunks before, the first lanes of the chunks behind).
+    const uint32_t hl = p.halo_l, hr = p.halo_r;
+    int64_t lane_abs = -1;  // lane index over all chunks
+    uint32_t s4 = 0;
+    if (tid < 512u) {
+        lane_abs = (int64_t)c * 64 + (tid & 63u);
+        s4 = tid >> 6;
+    } else if (tid < 512u + (hl + hr) * 8u) {
+        const uint32_t j = tid - 512u, u = j >> 3;
+        s4 = j & 7u;
+        lane_abs = u < hl ? (int64_t)c * 64 - 1 - u : (int64_t)(c + 1) * 64 + (u - hl);
+    }
+    const bool o_on = lane_abs >= 0 && lane_abs < (int64_t)p.n_chunks * 64;
+    uint4 oq = make_uint4(0u, 0u, 0u, 0u);
+    if (o_on) oq = o4[((size_t)(lane_abs >> 6) * 8u + s4) * 64u + (uint32_t)(lane_abs & 63)];
+    // the packed words of the range, four per load
+    constexpr uint32_t PKV = (1536u + BSR_THREADS - 1u) / BSR_THREADS;
     uint4 pkv[PKV];
 #pragma unroll
     for (uint32_t u = 0; u < PKV; ++u) {
@@ -131,40 +157,12 @@ __global__ __launch_bounds__(BSR_THREADS, BSR_THREADS / 128) void k_bs_resolve(c
         if (i < nw) {
             const uint64_t wq = w0 + i;
             if (wq + 4 <= p.n_words) {
-                // (8-byte aligned for sure: two dwordx2 unless the address is 16-byte aligned -- let the compiler choose)
                 const uint2 lo = *reinterpret_cast<const uint2 *>(p.packed + wq), hi = *reinterpret_cast<const uint2 *>(p.packed + wq + 2);
                 pkv[u] = make_uint4(lo.x, lo.y, hi.x, hi.y);
             } else {
                 if (wq < p.n_words) pkv[u].x = p.packed[wq];
                 if (wq + 1 < p.n_words) pkv[u].y = p.packed[wq + 1];
                 if (wq + 2 < p.n_words) pkv[u].z = p.packed[wq + 2];
-            }
-        }
-    }
-    constexpr uint32_t OWN = (512u + BSR_THREADS - 1u) / BSR_THREADS;  // the chunk's own 512 uint4
-    uint4 own[OWN];
-#pragma unroll
-    for (uint32_t u = 0; u < OWN; ++u) {
-        const uint32_t i = tid + u * BSR_THREADS;
-        own[u] = i < 512u ? o4[(size_t)c * 512u + i] : make_uint4(0u, 0u, 0u, 0u);
-    }
-    // halo words: the last lanes of the chunks before, the first lanes of the chunks behind (a halo may span chunks)
-    uint4 hq = make_uint4(0u, 0u, 0u, 0u);
-    uint32_t h_chunk = 0, h_lane = 0, h_t4 = 0;
-    bool h_on = false;
-    {
-        const uint32_t hl = p.halo_l, hr = p.halo_r;
-        if (tid < (hl + hr) * 8u) {  // (halo_l + halo_r <= 32)
-            const bool left = tid < hl * 8u;
-            const uint32_t j = left ? tid : tid - hl * 8u;
-            h_t4 = j & 7u;
-            const uint32_t u = j >> 3;  // u-th lane of the halo, counted away from the core
-            const int64_t lane_abs = left ? (int64_t)c * 64 - 1 - u : (int64_t)(c + 1) * 64 + u;  // lane index over all chunks
-            if (lane_abs >= 0 && lane_abs < (int64_t)p.n_chunks * 64) {
-                h_on = true;
-                h_chunk = (uint32_t)(lane_abs >> 6);
-                h_lane = (uint32_t)(lane_abs & 63);
-                hq = o4[((size_t)h_chunk * 8u + h_t4) * 64u + h_lane];
             }
         }
     }
@@ -178,7 +176,7 @@ __global__ __launch_bounds__(BSR_THREADS, BSR_THREADS / 128) void k_bs_resolve(c
     if (tid == 0 && r_first + BSR_RUNS + 32u < p.run_hi) beyond_off = p.runs[r_first + BSR_RUNS + 32u].base_off;
     BSR_STAMP(1)
     // ---- into LDS
-    if (tid < 256u) L.btab[tid] = bt;
+    L.btab[tid] = bt0;
 #pragma unroll
     for (uint32_t u = 0; u < PKV; ++u) {
         const uint32_t i = (tid + u * BSR_THREADS) * 4u;
@@ -186,7 +184,17 @@ __global__ __launch_bounds__(BSR_THREADS, BSR_THREADS / 128) void k_bs_resolve(c
             L.pk[i] = pkv[u].x; L.pk[i + 1] = pkv[u].y; L.pk[i + 2] = pkv[u].z; L.pk[i + 3] = pkv[u].w;
         }
     }
-    for (uint32_t i = tid; i < n_strips + 1u; i += BSR_THREADS) L.nat[i] = 0u;
+    if (o_on) {  // the strips' words at their places in position order (every strip of the range comes from exactly one lane)
+        const int64_t g0 = lane_abs * 32 + 4 * (int64_t)s4 - 1 - strip0;
+        const uint32_t wq[4] = {oq.x, oq.y, oq.z, oq.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const int64_t g = g0 + j;
+            if (g >= 0 && g < (int64_t)n_strips) L.nat[g] = wq[j];
+        }
+    }
+    // (no lane holds the assembly's last strip: it lies in the padding behind the bases)
+    if (tid == 0 && range_hi == n_pos) L.nat[n_strips - 1u] = 0u;
     {
         // (chunk_run0 is exact for a chunk's first position; the range starts behind it: the runs that end before it are
         // skipped here)
@@ -194,12 +202,12 @@ __global__ __launch_bounds__(BSR_THREADS, BSR_THREADS / 128) void k_bs_resolve(c
         const Run &run = my_run;
         if (my_run_on) in = (int64_t)(run.base_off + run.n_kmers) > range_lo && (int64_t)run.base_off < range_hi;
         // runs are sorted by position: the overlapping ones are consecutive
-        const uint64_t m = __ballot(in);
+        const uint64_t mb = __ballot(in);
         constexpr uint32_t NWV = BSR_THREADS / 64u;
         __shared__ uint32_t s_cnt[NWV], s_first[NWV];
         if (lane == 0) {
-            s_cnt[tid >> 6] = (uint32_t)__popcll(m);
-            s_first[tid >> 6] = m ? (uint32_t)__builtin_ctzll(m) + (tid & ~63u) : 0xFFFFFFFFu;
+            s_cnt[tid >> 6] = (uint32_t)__popcll(mb);
+            s_first[tid >> 6] = mb ? (uint32_t)__builtin_ctzll(mb) + (tid & ~63u) : 0xFFFFFFFFu;
         }
         __syncthreads();
         uint32_t first = 0xFFFFFFFFu, total = 0;
@@ -225,50 +233,30 @@ __global__ __launch_bounds__(BSR_THREADS, BSR_THREADS / 128) void k_bs_resolve(c
     BSR_STAMP(2)
     BSR_ABLATE(1)
     const uint32_t n_win = s_nwin;
-    // ---- the filter's bits -> bitmap in position order.  Bit s of OUT[chunk][t/4][lane][t&3] = strip chunk * 2048 + 32 lane + s - 1
-    const int64_t strip0 = range_lo >> 5;
-    auto scatter = [&](uint32_t chunk, uint32_t l, uint32_t t, uint32_t word) {
-        while (word) {
-            const uint32_t s = (uint32_t)__builtin_ctz(word);
-            word &= word - 1u;
-            const int64_t g = (int64_t)chunk * 2048 + 32 * l + s - 1 - strip0;
-            if (g >= 0 && g < (int64_t)n_strips) atomicOr(&L.nat[g], 1u << t);
-        }
-    };
-    {
-#pragma unroll
-        for (uint32_t u = 0; u < OWN; ++u) {
-            const uint32_t i = tid + u * BSR_THREADS, l = i & 63u, t4 = i >> 6;  // entry i of the chunk's 512
-            if (i < 512u) {
-                scatter(c, l, 4u * t4, own[u].x); scatter(c, l, 4u * t4 + 1u, own[u].y);
-                scatter(c, l, 4u * t4 + 2u, own[u].z); scatter(c, l, 4u * t4 + 3u, own[u].w);
-            }
-        }
-        if (h_on) {
-            scatter(h_chunk, h_lane, 4u * h_t4, hq.x); scatter(h_chunk, h_lane, 4u * h_t4 + 1u, hq.y);
-            scatter(h_chunk, h_lane, 4u * h_t4 + 2u, hq.z); scatter(h_chunk, h_lane, 4u * h_t4 + 3u, hq.w);
-        }
-    }
-    __syncthreads();
     BSR_STAMP(3)
     BSR_ABLATE(2)
-    // ---- positions of the set bits, in order: thread t takes the strips [t * spt, (t + 1) * spt)
-    const uint32_t spt = (n_strips + BSR_THREADS - 1u) / BSR_THREADS;
+    // ---- positions of the set bits, in order: thread t takes the strips [4 t, 4 t + 4)
     {
-        uint32_t cnt = 0;
-        for (uint32_t g = tid * spt; g < std::min(n_strips, (tid + 1u) * spt); ++g) cnt += (uint32_t)__popc(L.nat[g]);
+        uint32_t wd[4], cnt = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t g = 4u * tid + u;
+            wd[u] = g < n_strips ? L.nat[g] : 0u;
+            cnt += (uint32_t)__popc(wd[u]);
+        }
         uint32_t at = block_exclusive<BSR_THREADS / 64>(cnt, L.sh);
         const uint32_t total = L.sh[255];
         if (tid == 0) {
             s_nraw = std::min(total, p.max_cand);
             if (total > p.max_cand) s_flag = 1;
         }
-        for (uint32_t g = tid * spt; g < std::min(n_strips, (tid + 1u) * spt); ++g) {
-            uint32_t word = L.nat[g];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            uint32_t word = wd[u];
             while (word) {
                 const uint32_t t = (uint32_t)__builtin_ctz(word);
                 word &= word - 1u;
-                if (at < p.max_cand) L.posl[at] = g * 32u + t;
+                if (at < p.max_cand) L.posl[at] = (4u * tid + u) * 32u + t;
                 ++at;
             }
         }
@@ -505,7 +493,7 @@ int bs_prepare(mxg_handle *h, Assembly *a)
             a->bs_impossible = true;
             return MXG_OK;
         }
-    const uint64_t n_pos = a->packed_words * 16ull;
+    const uint64_t n_pos = a->packed_words * 16ull + 64;  // (+ two strips: no k-mer of the assembly starts in the last one)
     const uint32_t n_chunks = (uint32_t)((n_pos + BS_CHUNK - 1) / BS_CHUNK);
     a->bs_chunks = n_chunks;
     MXG_HIP(h, a->d_bs_T.ensure((size_t)n_chunks * BS_T_WORDS * 4));

@@ -75,17 +75,17 @@ int main(int argc, char **argv)
     uint64_t bad = 0, total = 0;
     for (uint32_t c : {0u, 1u, n_chunks / 2, n_chunks - 1}) {
         CK(hipMemcpy(ho.data(), dO + (size_t)c * mxg::BS_OUT_WORDS, mxg::BS_OUT_WORDS * 4, hipMemcpyDeviceToHost));
-        for (uint32_t t = 0; t < 32; ++t)
+        for (uint32_t s = 0; s < 32; ++s)
             for (uint32_t lane = 0; lane < 64; ++lane) {
                 uint32_t want = 0, care = 0;
-                for (uint32_t s = 0; s < 32; ++s) {
+                for (uint32_t t = 0; t < 32; ++t) {
                     const int64_t p = (int64_t)c * 65536 + ((int64_t)32 * lane + s - 1) * 32 + t;
                     if (p < 0) continue;
-                    care |= 1u << s;
-                    if (ref_bit(hp, (uint64_t)p, tt, HASH_BS_PLANES)) want |= 1u << s;
+                    care |= 1u << t;
+                    if (ref_bit(hp, (uint64_t)p, tt, HASH_BS_PLANES)) want |= 1u << t;
                 }
-                const uint32_t got = ho[((t >> 2) * 64 + lane) * 4 + (t & 3)] & care;
-                if (got != want && bad++ < 5) printf("MISMATCH chunk %u t %u lane %u: got %08x want %08x\n", c, t, lane, got, want);
+                const uint32_t got = ho[((s >> 2) * 64 + lane) * 4 + (s & 3)] & care;
+                if (got != want && bad++ < 5) printf("MISMATCH chunk %u strip %u lane %u: got %08x want %08x\n", c, s, lane, got, want);
                 total += __builtin_popcount(want);
             }
     }
