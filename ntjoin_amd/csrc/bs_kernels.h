@@ -6,7 +6,8 @@
 // Layouts (see gen/bs_gen.py for why): a chunk = 65 536 base positions = 64 lanes x 32 strips x 32 positions
 //     T[chunk][t / 2][lane][2 (t & 1) + beta]  u32   bit s = bit beta of the base at chunk * 65536 + (32 lane + s) * 32 + t
 //     Q[chunk][lane][beta]                     u32   bit t = bit beta of the base at chunk * 65536 + (32 lane - 1) * 32 + t
-//     OUT[chunk][s / 4][lane][s & 3]           u32   bit t = the 32-mer at chunk * 65536 + (32 lane + s - 1) * 32 + t passed the ring test
+//     OUT[p / 32] bit p % 32                   u32   the 32-mer at position p passed the ring test (a plain bitmap; the word in
+//                                                    front of OUT[0] is written too: BS_OUT_PAD words of padding)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,6 +24,7 @@ constexpr uint32_t BS_CHUNK = 65536;        // base positions per chunk
 constexpr uint32_t BS_T_WORDS = 4096;       // u32 words of T per chunk (= the chunk's packed words)
 constexpr uint32_t BS_Q_WORDS = 128;        // u32 words of Q per chunk
 constexpr uint32_t BS_OUT_WORDS = 2048;     // u32 words of OUT per chunk
+constexpr uint32_t BS_OUT_PAD = 4;          // words in front of OUT[0] (slot 0 of the first lane writes OUT[-1])
 
 // 32 x 32 bit transpose in registers: afterwards a[i] bit s = (before) a[s] bit i
 __device__ __forceinline__ void bs_transpose32(uint32_t (&a)[32])
@@ -103,10 +105,10 @@ __global__ __launch_bounds__(256) void k_hash_bs(const uint32_t *__restrict__ T,
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
-    const uint32_t stride = gridDim.x * 4u, c0 = c_lo + wave, voff = lane * 16u, voff8 = lane * 8u;
+    const uint32_t stride = gridDim.x * 4u, c0 = c_lo + wave, voff = lane * 16u, voff8 = lane * 8u, voff128 = lane * 128u;
     asm volatile(HASH_BS_ASM
                  :
-                 : [t] "s"(T), [p] "s"(Q), [o] "s"(OUT), [c0] "s"(c0), [n] "s"(c_hi), [stride] "s"(stride), [tt] "s"(tt), [voff] "v"(voff), [voff8] "v"(voff8)
+                 : [t] "s"(T), [p] "s"(Q), [o] "s"(OUT), [c0] "s"(c0), [n] "s"(c_hi), [stride] "s"(stride), [tt] "s"(tt), [voff] "v"(voff), [voff8] "v"(voff8), [voff128] "v"(voff128)
                  : HASH_BS_CLOBBERS);
 }
 

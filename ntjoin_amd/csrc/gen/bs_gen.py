@@ -30,9 +30,9 @@ cycles per instruction with 126 of them among 5 860, at 2.25 without.)  The 32
 bases of a strip are at once the warm-up input of its own slot, the outgoing bases of that slot and the incoming bases of
 the slot below.  Per chunk: 32 warm-up steps (no outgoing base, no test), 32 productive steps (test, then roll); the 32
 result words of a lane (word t: bit s = slot s) are transposed in registers (32 x 32 bits, left shifts as chains of
-v_add_u32) into position order and go out as
-    OUT[chunk][s / 4][lane][s & 3]           (u32)   bit t = the 32-mer at chunk * 65536 + (32 lane + s - 1) * 32 + t passed
-(the consumer then reads whole strips; as words per step it had to scatter every set bit: 5 000 cycles per chunk)
+v_add_u32) into position order and go out as a plain bitmap, one bit per base position:
+    OUT[p / 32] bit p % 32 = the 32-mer at position p passed      (word index chunk * 2048 + 32 lane + s - 1 for slot s)
+(slots 1..31 of a lane are 124 contiguous bytes on a 128-byte boundary, slot 0 is the word in front of them)
 The words of the next chunk are requested into the registers of the current one as soon as a step has read them.
 
 The same instruction list is (1) printed as gfx950 assembly for one inline-asm block with fixed registers (the chunk loop
@@ -116,9 +116,12 @@ def to_asm(ins):
     if op == 'gload2':  # (lane * 8: %[voff8])
         d = int(ins[1][1:])
         return f"global_load_dwordx2 v[{d}:{d + 1}], %[voff8], {sp(ins[2])} offset:{ins[3]}"
-    if op == 'gstore4':
+    if op in ('gstore4', 'gstore3', 'gstore1'):  # first data register, base SGPR pair, byte offset; lane * 128: %[voff128]
         d = int(ins[1][1:])
-        return f"global_store_dwordx4 %[voff], v[{d}:{d + 3}], {sp(ins[2])} offset:{ins[3]}"
+        n = int(op[-1])
+        regs = f"v[{d}:{d + n - 1}]" if n > 1 else f"v{d}"
+        suffix = {4: 'dwordx4', 3: 'dwordx3', 1: 'dword'}[n]
+        return f"global_store_{suffix} %[voff128], {regs}, {sp(ins[2])} offset:{ins[3]}"
     if op == 'waitcnt':
         return f"s_waitcnt {ins[1]}"
     if op == 'comment':
@@ -143,7 +146,7 @@ B0 = 8                     # first VGPR of the block (the compiler keeps v0..v7)
 W0 = B0                    # 64 registers
 G0 = W0 + 64               # 31 groups of 4: FP[i], RP[i], bank 2, bank 3
 X0 = G0 + 124              # the rest
-VEND = X0 + 48
+VEND = X0 + 52
 
 
 def grp(i, q):
@@ -164,7 +167,7 @@ S_T = S0 + 6        # T base (pair), S_P = Q base (pair), S_O = OUT base (pair)
 S_P = S0 + 8
 S_O = S0 + 10
 S_TN = S0 + 12      # 4 pairs: next chunk's T words + k * 4096
-S_OC = S0 + 20      # 2 pairs: this chunk's OUT words + k * 4096
+S_OC = S0 + 20      # 2 pairs: this chunk's OUT words - 4 bytes, this chunk's OUT words
 S_QN = S0 + 24      # pair: the next chunk's Q words
 S_TMP = S0 + 26     # pair
 S_CM = S0 + 28      # B_PLANES compare masks
@@ -186,12 +189,13 @@ class Gen:
         self.B = [grp(g, 3) for g in range(7)]   # in0 in1 ... of the incoming base
         self.cy, self.s = grp(7, 2), grp(7, 3)
         assert X0 % 4 == 0
-        self.M = [f"v{X0 + i}" for i in range(32)]  # the steps' results, then their transpose (8 x dwordx4 go out)
-        self.Qn = [f"v{X0 + 32}", f"v{X0 + 33}"]   # the next chunk's Q words (a dwordx2), the chunk's, their running shifts
-        self.Q = [f"v{X0 + 34}", f"v{X0 + 35}"]
-        self.Qr = [f"v{X0 + 36}", f"v{X0 + 37}"]   # banks 0, 1 (read with a bank 2 register by one v_bitop3_b32)
-        self.le, self.ones = f"v{X0 + 40}", f"v{X0 + 41}"
-        self.TT = [f"v{X0 + 44 + i}" for i in range(4)]  # temporaries of the transpose, one per bank
+        # the steps' results, then their transpose: M[1..] go out as dwordx4 (register tuples must start on an even register)
+        self.M = [f"v{X0 + 1 + i}" for i in range(32)]
+        self.Qn = [f"v{X0 + 34}", f"v{X0 + 35}"]   # the next chunk's Q words (a dwordx2), the chunk's, their running shifts
+        self.Q = [f"v{X0 + 36}", f"v{X0 + 37}"]
+        self.Qr = [f"v{X0 + 40}", f"v{X0 + 41}"]   # banks 0, 1 (read with a bank 2 register by one v_bitop3_b32)
+        self.le, self.ones = f"v{X0 + 44}", f"v{X0 + 45}"
+        self.TT = [f"v{X0 + 48 + i}" for i in range(4)]  # temporaries of the transpose, one per bank
         self.neg = {}
 
     def e(self, *t):
@@ -324,8 +328,11 @@ class Gen:
                     jr = (r - n) % 31
                     self.plane_update(RP[r], self.ro[jr], mA, self.ri[jr], mB)
         self.transpose_out()
-        for q in range(8):
-            e('gstore4', self.M[4 * q], S_OC + 2 * (q // 4), (q % 4) * 1024)
+        # M[s] = the 32 positions of strip 32 lane + s - 1: slots 1..31 at bytes 0..123 of the lane's 128, slot 0 in front
+        e('gstore1', self.M[0], S_OC, 0)
+        for q in range(7):
+            e('gstore4', self.M[4 * q + 1], S_OC + 2, 16 * q)
+        e('gstore3', self.M[29], S_OC + 2, 112)
         self.check_banks()
         return self.ins
 
@@ -383,18 +390,16 @@ class Gen:
         L(f"s_lshl_b64 {sp(S_QN)}, {sp(t0)}, 9")
         L(f"s_add_u32 s{S_QN}, s{S_QN}, s{S_P}")
         L(f"s_addc_u32 s{S_QN + 1}, s{S_QN + 1}, s{S_P + 1}")
-        for k in range(2):
-            d = S_OC + 2 * k
-            L(f"s_lshl_b64 {sp(d)}, {sp(S_C)}, 13")
-            L(f"s_add_u32 s{d}, s{d}, s{S_O}")
-            L(f"s_addc_u32 s{d + 1}, s{d + 1}, s{S_O + 1}")
-            if k:
-                L(f"s_add_u32 s{d}, s{d}, {hex(4096 * k)}")
-                L(f"s_addc_u32 s{d + 1}, s{d + 1}, 0")
+        d = S_OC + 2  # the chunk's 2048 words; S_OC: the same minus one word (slot 0 of a lane = the word in front of its 31)
+        L(f"s_lshl_b64 {sp(d)}, {sp(S_C)}, 13")
+        L(f"s_add_u32 s{d}, s{d}, s{S_O}")
+        L(f"s_addc_u32 s{d + 1}, s{d + 1}, s{S_O + 1}")
+        L(f"s_add_u32 s{S_OC}, s{d}, -4")
+        L(f"s_addc_u32 s{S_OC + 1}, s{d + 1}, -1")
 
     def asm(self):
         """the inline-asm text.  Operands: %[t] %[p] %[o] (SGPR pairs: T, Q, OUT bases), %[c0] first chunk of the wave,
-        %[n] one past the last chunk, %[stride] chunks between a wave's chunks, %[tt] threshold, %[voff] VGPR lane * 16, %[voff8] VGPR lane * 8"""
+        %[n] one past the last chunk, %[stride] chunks between a wave's chunks, %[tt] threshold, VGPRs %[voff] = lane * 16, %[voff8] = lane * 8, %[voff128] = lane * 128"""
         body = self.chunk()
         L = []
         A = L.append
@@ -455,7 +460,7 @@ class VM:
         self.vr = {}
         self.sr = {S_CM + i: (0xFFFFFFFF if (tt >> i) & 1 else 0) for i in range(B_PLANES)}
         self.sr.update({S_M16: 0x0000FFFF, S_M8: 0x00FF00FF, S_M4: 0x0F0F0F0F, S_M2: 0x33333333, S_M1: 0x55555555})
-        self.out = np.zeros((8, 64, 4), dtype=np.uint32)
+        self.out = np.zeros(2048 + 1, dtype=np.uint32)  # word index + 1 (slot 0 of lane 0 lies in front of the chunk)
 
     def V(self, x):
         if isinstance(x, int):
@@ -506,12 +511,13 @@ class VM:
                 d = int(ins[1][1:])
                 for j in range(4):
                     pend[f"v{d + j}"] = self.T[self.cn, t2, :, j].copy()
-            elif op == 'gstore4':
-                k = (ins[2] - S_OC) // 2
-                t4 = (k * 4096 + ins[3]) // 1024
+            elif op in ('gstore4', 'gstore3', 'gstore1'):
+                n = int(op[-1])
+                base = -1 if ins[2] == S_OC else 0  # word offset of the SGPR pair relative to the chunk
                 d = int(ins[1][1:])
-                for j in range(4):
-                    self.out[t4, :, j] = self.vr[f"v{d + j}"]
+                lanes = np.arange(64)
+                for j in range(n):
+                    self.out[1 + base + 32 * lanes + ins[3] // 4 + j] = self.vr[f"v{d + j}"]
             elif op in ('waitcnt', 'comment'):
                 pass
             else:
@@ -577,7 +583,7 @@ def reference_bits(codes, k, tt, b_planes=B_PLANES):
 
 
 def out_position(c, t, lane, s):
-    """position of the k-mer behind bit t of OUT[c][s / 4][lane][s & 3]"""
+    """position of the k-mer behind bit t of slot s of a lane (= bit index in OUT)"""
     return c * CHUNK + (32 * lane + s - 1) * 32 + t
 
 
@@ -588,7 +594,7 @@ def emit_inc(path, k):
     with open(path, 'w') as fh:
         fh.write(f"// GENERATED by gen/bs_gen.py (k = {k}, {B_PLANES} sum planes): the bit-sliced ring filter, chunk loop included.\n")
         fh.write(f"// {n_valu} VALU per chunk of 65 536 base positions per wave, all of them full-rate (see gen/bs_gen.py).  Do not edit.\n")
-        fh.write("// operands: [t] [p] [o] SGPR pairs (T, Q, OUT bases), [c0] [n] [stride] [tt] SGPRs, [voff] VGPR = lane * 16, [voff8] = lane * 8\n")
+        fh.write("// operands: [t] [p] [o] SGPR pairs (T, Q, OUT bases), [c0] [n] [stride] [tt] SGPRs, [voff] VGPR = lane * 16, [voff8] = lane * 8, [voff128] = lane * 128\n")
         fh.write(f"#define HASH_BS_VGPR_END {VEND}\n")
         fh.write(f"#define HASH_BS_VALU_PER_CHUNK {n_valu}\n")
         fh.write(f"#define HASH_BS_PLANES {B_PLANES}\n")

@@ -371,6 +371,88 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     }
 }
 
+// k = 32 route: the same arena entries from the bitmap that k_hash_bs (bs_kernels.h) wrote for the whole assembly -- bit p =
+// "the 32-mer at base position p passed the ring test".  Everything behind the hash kernel (k_reorder_w, k_resolve, ...) runs
+// unchanged; what the bit-sliced filter lets through beyond hash < tau (it compares the top 14 bits of the ring sum: ~2 % more)
+// are entries whose exact hash k_reorder_w finds >= tau, which k_resolve treats as absent.
+__global__ __launch_bounds__(256) void k_bs_arena(const SparseParams p, const uint32_t *__restrict__ bm)
+{
+    const uint32_t S = p.S;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    __shared__ uint32_t wtot[4];
+#pragma unroll 1
+    for (uint32_t vb = blockIdx.x; vb < p.n_tiles; vb += gridDim.x) {
+        const uint32_t srel = vb * 256u + threadIdx.x;
+        const uint32_t s = p.strip_lo + srel;
+        uint32_t len = 0;
+        uint64_t b = 0;
+        if (s < p.strip_hi) {
+            const uint32_t lo = find_run(p.run_strip0, p.run_lo, p.run_hi, s);
+            const Run run = p.runs[lo];
+            const uint32_t j0 = (s - p.run_strip0[lo]) * S;
+            len = min(S, run.n_kmers - j0);
+            b = run.base_off + j0;
+            p.strip_meta[srel] = lo;
+        }
+        const uint32_t wave_id = vb * 4u + wv;
+        uint2 *const region = p.arena + (size_t)wave_id * p.wave_cap;
+        const uint32_t wave_cap = p.wave_cap;
+        uint32_t cnt_w = 0, seq = 0;
+        auto store_entry = [&](const uint32_t blk, const uint32_t mine) {
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(mine != 0u);
+            if (mask) {
+                if (mine) {
+                    const uint32_t slot = cnt_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (slot < wave_cap) region[slot] = make_uint2(srel, mine | (blk << 16) | (seq << 22));
+                    seq += (uint32_t)__popc(mine);
+                }
+                cnt_w += (uint32_t)__popcll(mask);
+            }
+        };
+        // 32 k-mers (two entries) per word step: bits [b + 32 j, b + 32 j + 32) of the bitmap; eight words are requested at a
+        // time (one dependent load per step left the kernel waiting for memory: 58 us per batch)
+        const uint32_t *bw = bm + (b >> 5);
+        const uint32_t sh = (uint32_t)b & 31u;
+        const uint32_t nblk = S / 16u, nwords = (nblk + 1u) / 2u;
+        uint32_t w0 = bw[0];
+#pragma unroll 1
+        for (uint32_t j0w = 0; j0w < nwords; j0w += 8u) {
+            uint32_t wn[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) wn[u] = j0w + u < nwords ? bw[j0w + u + 1u] : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t j = j0w + u;
+                if (j < nwords) {  // (wave-uniform)
+                    uint32_t bits = __builtin_amdgcn_alignbit(wn[u], w0, sh);  // k-mers 32 j .. 32 j + 31 of the strip, LSB first
+                    w0 = wn[u];
+                    const uint32_t k0 = 32u * j;
+                    const uint32_t nvalid = len > k0 ? min(len - k0, 32u) : 0u;
+                    bits &= nvalid >= 32u ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
+                    const uint32_t rev = __brev(bits);  // the entries' bit 15 = the block's first k-mer
+                    store_entry(2u * j, rev >> 16);
+                    if (2u * j + 1u < nblk) store_entry(2u * j + 1u, rev & 0xFFFFu);
+                }
+            }
+        }
+        if (s < p.strip_hi) p.strip_cnt[srel] = seq;
+        const uint32_t tot = wave_sum_u32(seq);
+        if (lane == 0) {
+            p.wave_cnt[wave_id] = cnt_w;
+            p.wave_tot[wave_id] = tot;
+            wtot[wv] = tot;
+            if (tot > wave_cap) atomicMax(&p.ctrl[0], tot);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t c = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            if (c) atomicAdd(&p.wave_sup[(wave_id >> SUP_SHIFT) * SUP_STRIDE], c);
+        }
+        __syncthreads();
+    }
+}
+
 // arena entry -> full hashes -> ordered candidate slots: one block per wave slice, one thread per entry (1.15
 // candidates per entry on average).  The 64-bit canonical hash of each captured k-mer comes from the direct formula
 // (k/4 table lookups on the packed bases, which this block's 64 strips keep hot in L2).  An entry whose exact hash is
@@ -2022,7 +2104,7 @@ struct Driver {
 
     int enqueue_sparse(Assembly *a, const Tables &T, const BatchGeom &g, uint64_t wave_cap, uint32_t tau_hi,
                        OutArrays &out, uint32_t *ctrl_host, uint32_t *n_cap_out, const ChainIO *io = nullptr,
-                       uint32_t cand_hint = 0xFFFFFFFFu)
+                       uint32_t cand_hint = 0xFFFFFFFFu, const uint32_t *bs_bitmap = nullptr)
     {
         // MXG_TIMING_SAMPLE=n: event pairs around one batch in n only (four event records per batch cost 2 % of the step at
         // 3 Gbp; bench.py asks for one in four and scales the sums by the bases they cover)
@@ -2081,7 +2163,7 @@ struct Driver {
         int rc;
         sp.init_tab = h->d_init_tab.as<uint4>();
         sp.tab = h->tab;
-        if ((rc = ev_begin(batch_bases(T, g.c0, g.c1), true)) != MXG_OK) return rc;
+        if ((rc = bs_bitmap ? ev_begin(0, false) : ev_begin(batch_bases(T, g.c0, g.c1), true)) != MXG_OK) return rc;
         sp.n_tiles = g.n_blocks;
         dim3 grid(sparse_grid(g.n_blocks, g.nk)), block(256);
         static const int abl = getenv("MXG_ABLATE") ? atoi(getenv("MXG_ABLATE")) : 0;  // profiling only
@@ -2094,7 +2176,9 @@ struct Driver {
         // k = 32 the first 16 KB of it hold init32_half's tables.
         size_t pad = (size_t)env_u64("MXG_HASH_LDS", g.nk >= (256ull << 20) ? 18000 : 0);
         if (sp.five && sp.k == 32) pad = std::max<size_t>(pad, 16384);
-        if (h->cfg.variant == MXG_VARIANT_V1_MIN)
+        if (bs_bitmap)  // (k = 32 route: the filter has run over the whole assembly; only its bits are turned into entries)
+            hipLaunchKernelGGL(k_bs_arena, dim3(g.n_blocks), block, 0, st, sp, bs_bitmap);
+        else if (h->cfg.variant == MXG_VARIANT_V1_MIN)
             hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V1_MIN>), grid, block, pad, st, sp);
         else if (abl == 1)
             hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V2_SUM, 1>), grid, block, pad, st, sp);
@@ -2228,7 +2312,7 @@ struct Driver {
         MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, ctrl_bytes, st));
         if ((rc = ev_begin(0, false, fine ? 3 : 1)) != MXG_OK) return rc;
         BsResolveParams bp{};
-        bp.out = a->d_bs_out.as<uint32_t>();
+        bp.out = a->d_bs_out.as<uint32_t>() + 4;  // (BS_OUT_PAD)
         bp.n_chunks = a->bs_chunks;
         bp.packed = a->d_packed;
         bp.n_words = a->packed_words;
@@ -2593,6 +2677,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         bool bs;       // went through the k = 32 route (no candidate arrays to finish from)
     };
     static const bool bs_env = env_u64("MXG_BS", 1) != 0;
+    static const bool bs_fused = env_u64("MXG_BS_FUSED", 0) != 0;  // k_bs_resolve instead of arena -> reorder -> resolve
     std::vector<Tables> tabs(n);
     std::vector<int> state(n, 0);  // 0 = synchronous path, 1 = enqueued, 2 = done
     std::vector<SparsePlan> plans(n);
@@ -2624,17 +2709,18 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             // (fine either way; nothing special: ctg_drop travels with the tables)
         }
         // the k = 32 route: the bit-sliced filter over the whole assembly, then one k_bs_resolve per batch (sketch_bs.hip)
-        bool use_bs = bs_env && plans[i].dev_gaps && !chain_modes && h->cfg.w >= 256 && h->cfg.w <= GAP_DEV_NMAX / 2 &&
-                      bs_possible(h, list[i]);
+        bool use_bs = bs_env && bs_possible(h, list[i]);
+        bool fused_ok = use_bs && bs_fused && plans[i].dev_gaps && !chain_modes && h->cfg.w >= 256 && h->cfg.w <= GAP_DEV_NMAX / 2;
         std::vector<Driver::BsGeom> bgs;
         if (use_bs) {
             if ((rc = bs_prepare(h, list[i])) != MXG_OK) return rc;
             use_bs = list[i]->bs_ready;
-            for (size_t b = 0; use_bs && b < gs.size(); ++b) {
+            for (size_t b = 0; use_bs && fused_ok && b < gs.size(); ++b) {
                 bgs.push_back(drv0.bs_geom(tabs[i], gs[b], plans[i].frac));
-                use_bs = bgs.back().ok;
+                fused_ok = bgs.back().ok;
             }
         }
+        fused_ok = fused_ok && use_bs;
         hipEvent_t ev_hash = nullptr;
         hipStream_t st_hash = nullptr;
         OutArrays out{&list[i]->d_hash, &list[i]->d_pos, &list[i]->d_rec, &list[i]->d_fwd, 0};
@@ -2654,7 +2740,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             it.g = gs[b];
             it.slot = (int)sl;
             it.n_cap = 0;
-            it.bs = use_bs;
+            it.bs = fused_ok;
             if (use_bs && b == 0) {  // the filter, once per assembly, on the first batch's stream
                 st_hash = drv.st;
                 if ((rc = drv.ev_begin(list[i]->total_bases, true)) != MXG_OK) return rc;
@@ -2694,10 +2780,11 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
                 drv.n_out = h->d_nmx.as<uint32_t>() + i;
             }
-            if (use_bs) {
+            if (fused_ok) {
                 if ((rc = drv.enqueue_bs(list[i], tabs[i], it.g, bgs[b], plans[i].tau_hi, out, it.hc, &io)) != MXG_OK) return rc;
             } else if ((rc = drv.enqueue_sparse(list[i], tabs[i], it.g, drv.default_wave_cap(list[i]->S_sparse, plans[i].frac),
-                                                plans[i].tau_hi, out, it.hc, &it.n_cap, &io, list[i]->cand_hints[b])) != MXG_OK)
+                                                plans[i].tau_hi, out, it.hc, &it.n_cap, &io, list[i]->cand_hints[b],
+                                                use_bs ? list[i]->d_bs_out.as<uint32_t>() + 4 : nullptr)) != MXG_OK)
                 return rc;
             last_on_slot[sl] = items.size();
             items.push_back(it);

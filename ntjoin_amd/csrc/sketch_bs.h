@@ -15,7 +15,7 @@ constexpr uint32_t BSR_HALO_LANE = 1024; // base positions per halo unit (one la
 
 struct BsResolveParams {
     // the filter's result for the whole assembly, the assembly's bases and tables
-    const uint32_t *out;       // OUT[chunk][t / 4][lane][t & 3]
+    const uint32_t *out;       // the filter's bitmap: bit p = position p (bs_kernels.h)
     uint32_t n_chunks;
     const uint32_t *packed;
     uint64_t n_words;

@@ -50,6 +50,54 @@ __device__ __forceinline__ uint64_t hash32_lds(const uint32_t *pk, uint32_t rel,
     return (((uint64_t)(a.y ^ c.y) << 32) | (a.x ^ c.x)) + (((uint64_t)(a.w ^ c.w) << 32) | (a.z ^ c.z));
 }
 
+// exclusive prefix of v over the block's threads (16 waves); total = the block's sum.  sh: 40 words; two barriers; a following
+// call may start at once.  (block_exclusive of scan_kernels.h has every thread walk the 16 wave totals: ~120 instructions per
+// wave where this takes ~40, and the kernel is bound by instruction issue.)
+__device__ __forceinline__ uint32_t bsr_scan(uint32_t v, uint32_t *sh, uint32_t &total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t incl = wave_inclusive_u32(v, lane);
+    if (lane == 63u) sh[wv] = incl;
+    __syncthreads();
+    if (wv == 0 && lane < 16u) {
+        const uint32_t x = sh[lane];
+        uint32_t inc = x;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 16);
+            if (lane >= (uint32_t)o) inc += t;
+        }
+        sh[16u + lane] = inc - x;
+        if (lane == 15u) sh[32] = inc;
+    }
+    __syncthreads();
+    total = sh[32];
+    return sh[16u + wv] + incl - v;
+}
+// the same for one flag per thread (rank inside the wave from the ballot)
+__device__ __forceinline__ uint32_t bsr_scan_flag(bool f, uint32_t *sh, uint32_t &total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t m = __ballot(f);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (lane == 0u) sh[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (wv == 0 && lane < 16u) {
+        const uint32_t x = sh[lane];
+        uint32_t inc = x;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 16);
+            if (lane >= (uint32_t)o) inc += t;
+        }
+        sh[16u + lane] = inc - x;
+        if (lane == 15u) sh[32] = inc;
+    }
+    __syncthreads();
+    total = sh[32];
+    return sh[16u + wv] + rank;
+}
+
 constexpr uint32_t BSR_PAD = 4;  // sentinel entries on either side of the candidates (the scans look at four at a time)
 struct BsLds {
     uint4 *btab;        // [1024] half position tables of the direct hash formula
@@ -118,7 +166,6 @@ __global__ __launch_bounds__(BSR_THREADS, 8) void k_bs_resolve(const BsResolvePa
     // ---- loads.  Everything the block reads from global memory is requested at once, by role: wave 0 = the chunk's own 64
     // lanes of OUT words, the first threads of wave 1 = the halo lanes (the last lanes of the chunks before, the first of the
     // chunks behind), every thread a share of the packed bases and of the position tables, the first BSR_RUNS + 32 a run.
-    const uint4 *o4 = reinterpret_cast<const uint4 *>(p.out);
     const uint32_t rc = (uint32_t)(range_lo / BS_CHUNK);
     const uint32_t run0_c = p.chunk_run0[rc];
     uint4 bt0;  // half tables (see init32_half): entry tid = table tid / 256, byte value tid % 256
@@ -130,23 +177,14 @@ __global__ __launch_bounds__(BSR_THREADS, 8) void k_bs_resolve(const BsResolvePa
     const uint64_t w0 = (uint64_t)range_lo >> 4;            // (a multiple of 2: range_lo is a multiple of 32)
     const uint32_t nw = (uint32_t)((range_hi - range_lo) >> 4) + 3u;
     const int64_t strip0 = range_lo >> 5;
-    // the filter's words: OUT[chunk][s/4][lane][s&3] = the 32 positions of strip 32 lane + s - 1 (strips and lanes counted
-    // over all chunks).  Threads 0..511 take the chunk's own 512 uint4, the next (halo_l + halo_r) * 8 the halo lanes' (the
-    // last lanes of the chunks before, the first lanes of the chunks behind).
-    const uint32_t hl = p.halo_l, hr = p.halo_r;
-    int64_t lane_abs = -1;  // lane index over all chunks
-    uint32_t s4 = 0;
-    if (tid < 512u) {
-        lane_abs = (int64_t)c * 64 + (tid & 63u);
-        s4 = tid >> 6;
-    } else if (tid < 512u + (hl + hr) * 8u) {
-        const uint32_t j = tid - 512u, u = j >> 3;
-        s4 = j & 7u;
-        lane_abs = u < hl ? (int64_t)c * 64 - 1 - u : (int64_t)(c + 1) * 64 + (u - hl);
+    // the filter's words of the range: a plain bitmap, word = strip (32 positions)
+    constexpr uint32_t NWV3 = (3072u + BSR_THREADS - 1u) / BSR_THREADS;  // n_strips <= (65536 + 32 * 1024) / 32
+    uint32_t natw[NWV3];
+#pragma unroll
+    for (uint32_t u = 0; u < NWV3; ++u) {
+        const uint32_t g = tid + u * BSR_THREADS;
+        natw[u] = g < n_strips ? p.out[strip0 + g] : 0u;
     }
-    const bool o_on = lane_abs >= 0 && lane_abs < (int64_t)p.n_chunks * 64;
-    uint4 oq = make_uint4(0u, 0u, 0u, 0u);
-    if (o_on) oq = o4[((size_t)(lane_abs >> 6) * 8u + s4) * 64u + (uint32_t)(lane_abs & 63)];
     // the packed words of the range, four per load
     constexpr uint32_t PKV = (1536u + BSR_THREADS - 1u) / BSR_THREADS;
     uint4 pkv[PKV];
@@ -184,17 +222,11 @@ __global__ __launch_bounds__(BSR_THREADS, 8) void k_bs_resolve(const BsResolvePa
             L.pk[i] = pkv[u].x; L.pk[i + 1] = pkv[u].y; L.pk[i + 2] = pkv[u].z; L.pk[i + 3] = pkv[u].w;
         }
     }
-    if (o_on) {  // the strips' words at their places in position order (every strip of the range comes from exactly one lane)
-        const int64_t g0 = lane_abs * 32 + 4 * (int64_t)s4 - 1 - strip0;
-        const uint32_t wq[4] = {oq.x, oq.y, oq.z, oq.w};
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            const int64_t g = g0 + j;
-            if (g >= 0 && g < (int64_t)n_strips) L.nat[g] = wq[j];
-        }
+    for (uint32_t u = 0; u < NWV3; ++u) {
+        const uint32_t g = tid + u * BSR_THREADS;
+        if (g < n_strips) L.nat[g] = natw[u];
     }
-    // (no lane holds the assembly's last strip: it lies in the padding behind the bases)
-    if (tid == 0 && range_hi == n_pos) L.nat[n_strips - 1u] = 0u;
     {
         // (chunk_run0 is exact for a chunk's first position; the range starts behind it: the runs that end before it are
         // skipped here)
@@ -244,8 +276,8 @@ __global__ __launch_bounds__(BSR_THREADS, 8) void k_bs_resolve(const BsResolvePa
             wd[u] = g < n_strips ? L.nat[g] : 0u;
             cnt += (uint32_t)__popc(wd[u]);
         }
-        uint32_t at = block_exclusive<BSR_THREADS / 64>(cnt, L.sh);
-        const uint32_t total = L.sh[255];
+        uint32_t total;
+        uint32_t at = bsr_scan(cnt, L.sh, total);
         if (tid == 0) {
             s_nraw = std::min(total, p.max_cand);
             if (total > p.max_cand) s_flag = 1;
@@ -301,9 +333,10 @@ __global__ __launch_bounds__(BSR_THREADS, 8) void k_bs_resolve(const BsResolvePa
         }
     }
     {
-        uint32_t at = block_exclusive<BSR_THREADS / 64>((uint32_t)__popc(keep), L.sh);
-        if (tid == 0) s_ncand = L.sh[255];
-        __syncthreads();  // (the bitmap and the raw positions are dead: cand / posl / cnk may be written)
+        uint32_t total;
+        uint32_t at = bsr_scan((uint32_t)__popc(keep), L.sh, total);
+        if (tid == 0) s_ncand = total;
+        // (behind the scan's barriers the bitmap and the raw positions are dead: cand / posl / cnk may be written)
 #pragma unroll
         for (uint32_t u = 0; u < IPT_MAX; ++u)
             if ((keep >> u) & 1u) {
@@ -338,19 +371,51 @@ __global__ __launch_bounds__(BSR_THREADS, 8) void k_bs_resolve(const BsResolvePa
     // (chunk 0: positions -32..-1 do not exist)
     const uint32_t core_rel_lo = (uint32_t)(std::max(core_lo, range_lo) - range_lo);
     const uint32_t core_rel_hi = (uint32_t)(std::min(core_hi, range_hi) - range_lo);
-    // ---- the window decision on the block's own candidates: k_resolve's per-lane scans (sketch.hip), everything in LDS,
-    // four neighbours per iteration (one ds_read_b128 each).  Candidate i = tid + 256 * round; the selected ones of a round go
-    // out in order behind those of the rounds before.
-    uint32_t n_own = 0, out_at = 0;
-    for (uint32_t i0 = 0; i0 < n_c; i0 += BSR_THREADS) {
+    // ---- the window decision on the block's own candidates: k_resolve's scans (sketch.hip), everything in LDS.  Pass 1: every
+    // candidate looks at its four neighbours on either side (one ds_read_b128 each), which decides four in five; pass 2: the
+    // undecided ones, laid end to end, walk on four neighbours at a time with full waves.  The flags go to LDS (the raw
+    // position list is dead: its first bytes are reused); the selected ones then leave in order.
+    uint8_t *selb = reinterpret_cast<uint8_t *>(L.pk);            // [max_cand] 0 / 1 (the packed words are dead behind the hashes)
+    uint32_t *undl = reinterpret_cast<uint32_t *>(L.pk) + (p.max_cand / 4u + 4u);  // undecided candidates: index | state
+    uint32_t n_own = 0;
+    auto scan_left = [&](uint32_t i, uint32_t kx, uint32_t cg, uint64_t h, uint32_t t0, uint32_t &Ld, bool &done, bool one) {
+        for (uint32_t t = t0; !done; t += 4) {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint4 e = L.cand[(int)i - (int)t - (int)u];
+                const uint32_t d = kx - e.x;
+                const bool stop = e.y != cg || d > wm1;
+                const bool hit = !stop && ((((uint64_t)e.w << 32) | e.z) < h);
+                Ld = (!done && hit) ? d - 1u : Ld;
+                done = done || stop || hit;
+            }
+            if (one) break;
+        }
+    };
+    auto scan_right = [&](uint32_t i, uint32_t kx, uint32_t cg, uint64_t h, uint32_t need, uint32_t t0, bool &sel, bool &done, bool one) {
+        for (uint32_t t = t0; !done; t += 4) {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint4 e = L.cand[i + t + u];
+                const uint32_t d = e.x - kx;
+                const bool stop = e.y != cg || d > need;
+                const bool hit = !stop && ((((uint64_t)e.w << 32) | e.z) <= h);
+                sel = (!done && hit) ? false : sel;
+                done = done || stop || hit;
+            }
+            if (one) break;
+        }
+    };
+    for (uint32_t i0 = 0; i0 < n_c; i0 += BSR_THREADS) {  // (one round unless max_cand > 1024)
         const uint32_t i = i0 + tid;
-        bool sel = false;
-        uint4 me = make_uint4(0u, 0u, 0u, 0u);
+        bool undecided = false;
+        uint32_t st_word = 0;
         if (i < n_c) {
+            bool sel = false;
             const uint32_t rel = L.posl[i];
             if (rel >= core_rel_lo && rel < core_rel_hi) {  // (a halo candidate: its own block decides it)
                 ++n_own;
-                me = L.cand[i];
+                const uint4 me = L.cand[i];
                 const uint64_t h = ((uint64_t)me.w << 32) | me.z;
                 const uint32_t kx = me.x, cg = me.y, nk = L.cnk[i];
                 // is everything this candidate can need inside the range?
@@ -358,37 +423,25 @@ __global__ __launch_bounds__(BSR_THREADS, 8) void k_bs_resolve(const BsResolvePa
                 if ((cg == s_klo_ctg && need_lo < s_klo) || (cg == s_khi_ctg && need_hi > s_khi)) {
                     s_flag = 1;
                 } else {
-                    // left: nearest strictly smaller
                     uint32_t Ld = std::min(kx, wm1);
-                    bool done = false;
-                    for (uint32_t t = 1; !done; t += 4) {
-#pragma unroll
-                        for (uint32_t u = 0; u < 4; ++u) {
-                            const uint4 e = L.cand[(int)i - (int)t - (int)u];
-                            const uint32_t d = kx - e.x;
-                            const bool stop = e.y != cg || d > wm1;
-                            const bool hit = !stop && ((((uint64_t)e.w << 32) | e.z) < h);
-                            Ld = (!done && hit) ? d - 1u : Ld;
-                            done = done || stop || hit;
+                    bool ldone = false;
+                    scan_left(i, kx, cg, h, 1u, Ld, ldone, true);
+                    if (!ldone) {
+                        undecided = true;  // (left scan unfinished)
+                    } else {
+                        const uint32_t Rd = std::min(nk - 1u - kx, wm1);
+                        sel = Ld + Rd + 1u >= w;
+                        const uint32_t need = wm1 - std::min(Ld, wm1);
+                        bool rdone = !(sel && need > 0);
+                        scan_right(i, kx, cg, h, need, 1u, sel, rdone, true);
+                        if (!rdone) {
+                            undecided = true;
+                            st_word = 0x80000000u | (Ld << 16);  // (left part known: Ld < 2^15 as w <= 2048)
+                        } else {
+                            if (p.ctg_drop && sel && kx <= wm1 && Ld == kx && p.ctg_drop[cg]) sel = false;
+                            if (h == 0xFFFFFFFFFFFFFFFFull) sel = false;
                         }
                     }
-                    const uint32_t Rd = std::min(nk - 1u - kx, wm1);
-                    sel = Ld + Rd + 1u >= w;
-                    const uint32_t need = wm1 - std::min(Ld, wm1);
-                    done = !(sel && need > 0);
-                    for (uint32_t t = 1; !done; t += 4) {
-#pragma unroll
-                        for (uint32_t u = 0; u < 4; ++u) {
-                            const uint4 e = L.cand[i + t + u];
-                            const uint32_t d = e.x - kx;
-                            const bool stop = e.y != cg || d > need;
-                            const bool hit = !stop && ((((uint64_t)e.w << 32) | e.z) <= h);
-                            sel = (!done && hit) ? false : sel;
-                            done = done || stop || hit;
-                        }
-                    }
-                    if (p.ctg_drop && sel && kx <= wm1 && Ld == kx && p.ctg_drop[cg]) sel = false;
-                    if (h == 0xFFFFFFFFFFFFFFFFull) sel = false;
                     // candidate-free stretches behind this candidate (the candidate in front of a stretch reports it)
                     const uint4 nxt = L.cand[i + 1u];
                     if (nxt.y == cg) {
@@ -408,11 +461,46 @@ __global__ __launch_bounds__(BSR_THREADS, 8) void k_bs_resolve(const BsResolvePa
                     }
                 }
             }
+            selb[i] = sel ? 1 : 0;
         }
-        // the round's selected ones, in order
-        const uint32_t at = out_at + block_exclusive<BSR_THREADS / 64>(sel ? 1u : 0u, L.sh);
-        out_at += L.sh[255];
+        uint32_t n_und;
+        const uint32_t ua = bsr_scan_flag(undecided, L.sh, n_und);
+        if (undecided) undl[ua] = i | st_word;  // (i < 2^15)
+        __syncthreads();
+        for (uint32_t q = tid; q < n_und; q += BSR_THREADS) {  // pass 2
+            const uint32_t wd = undl[q], ii = wd & 0x7FFFu;
+            const uint4 me = L.cand[ii];
+            const uint64_t h = ((uint64_t)me.w << 32) | me.z;
+            const uint32_t kx = me.x, cg = me.y, nk = L.cnk[ii];
+            uint32_t Ld;
+            if (wd & 0x80000000u) {
+                Ld = (wd >> 16) & 0x7FFFu;
+            } else {
+                Ld = std::min(kx, wm1);
+                bool ldone = false;
+                scan_left(ii, kx, cg, h, 5u, Ld, ldone, false);
+            }
+            const uint32_t Rd = std::min(nk - 1u - kx, wm1);
+            bool sel = Ld + Rd + 1u >= w;
+            const uint32_t need = wm1 - std::min(Ld, wm1);
+            bool rdone = !(sel && need > 0);
+            scan_right(ii, kx, cg, h, need, (wd & 0x80000000u) ? 5u : 1u, sel, rdone, false);
+            if (p.ctg_drop && sel && kx <= wm1 && Ld == kx && p.ctg_drop[cg]) sel = false;
+            if (h == 0xFFFFFFFFFFFFFFFFull) sel = false;
+            selb[ii] = sel ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    // the selected ones, in order
+    uint32_t out_at = 0;
+    for (uint32_t i0 = 0; i0 < n_c; i0 += BSR_THREADS) {
+        const uint32_t i = i0 + tid;
+        const bool sel = i < n_c && selb[i];
+        uint32_t tot;
+        const uint32_t at = out_at + bsr_scan_flag(sel, L.sh, tot);
+        out_at += tot;
         if (sel && at < p.rk) {
+            const uint4 me = L.cand[i];
             const size_t dst = (size_t)blockIdx.x * p.rk + at;
             p.cs_h[dst] = ((uint64_t)me.w << 32) | me.z;
             p.cs_k[dst] = me.x;
@@ -498,7 +586,7 @@ int bs_prepare(mxg_handle *h, Assembly *a)
     a->bs_chunks = n_chunks;
     MXG_HIP(h, a->d_bs_T.ensure((size_t)n_chunks * BS_T_WORDS * 4));
     MXG_HIP(h, a->d_bs_Q.ensure((size_t)n_chunks * BS_Q_WORDS * 4));
-    MXG_HIP(h, a->d_bs_out.ensure((size_t)n_chunks * BS_OUT_WORDS * 4 + 64));
+    MXG_HIP(h, a->d_bs_out.ensure(((size_t)n_chunks * BS_OUT_WORDS + BS_OUT_PAD) * 4 + 64));
     hipLaunchKernelGGL(k_bs_transpose, dim3(n_chunks), dim3(64), 0, h->stream, a->d_packed, (uint64_t)a->packed_words,
                        a->d_bs_T.as<uint32_t>(), a->d_bs_Q.as<uint32_t>(), 0u, n_chunks);
     MXG_HIP(h, hipGetLastError());
@@ -525,7 +613,7 @@ int bs_hash(mxg_handle *h, Assembly *a, uint32_t tau_hi, hipStream_t st)
     const uint32_t tt = T ? (T - 1u) >> (31 - HASH_BS_PLANES) : 0u;
     const uint32_t blocks = std::min<uint32_t>(512u, (a->bs_chunks + 3u) / 4u);  // two waves per SIMD (see k_hash_bs)
     hipLaunchKernelGGL(k_hash_bs, dim3(blocks), dim3(256), 0, st, a->d_bs_T.as<uint32_t>(), a->d_bs_Q.as<uint32_t>(),
-                       a->d_bs_out.as<uint32_t>(), 0u, a->bs_chunks, tt);
+                       a->d_bs_out.as<uint32_t>() + BS_OUT_PAD, 0u, a->bs_chunks, tt);
     MXG_HIP(h, hipGetLastError());
     return MXG_OK;
 }

@@ -53,9 +53,10 @@ int main(int argc, char **argv)
     CK(hipMalloc(&dp, n_words * 4));
     CK(hipMalloc(&dT, (size_t)n_chunks * mxg::BS_T_WORDS * 4));
     CK(hipMalloc(&dP, (size_t)n_chunks * mxg::BS_Q_WORDS * 4));
-    CK(hipMalloc(&dO, (size_t)n_chunks * mxg::BS_OUT_WORDS * 4));
+    CK(hipMalloc(&dO, ((size_t)n_chunks * mxg::BS_OUT_WORDS + mxg::BS_OUT_PAD) * 4));
+    dO += mxg::BS_OUT_PAD;
     CK(hipMemcpy(dp, hp.data(), n_words * 4, hipMemcpyHostToDevice));
-    CK(hipMemset(dO, 0xAB, (size_t)n_chunks * mxg::BS_OUT_WORDS * 4));
+    CK(hipMemset(dO - mxg::BS_OUT_PAD, 0xAB, ((size_t)n_chunks * mxg::BS_OUT_WORDS + mxg::BS_OUT_PAD) * 4));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -74,20 +75,17 @@ int main(int argc, char **argv)
     std::vector<uint32_t> ho(mxg::BS_OUT_WORDS);
     uint64_t bad = 0, total = 0;
     for (uint32_t c : {0u, 1u, n_chunks / 2, n_chunks - 1}) {
-        CK(hipMemcpy(ho.data(), dO + (size_t)c * mxg::BS_OUT_WORDS, mxg::BS_OUT_WORDS * 4, hipMemcpyDeviceToHost));
-        for (uint32_t s = 0; s < 32; ++s)
-            for (uint32_t lane = 0; lane < 64; ++lane) {
-                uint32_t want = 0, care = 0;
-                for (uint32_t t = 0; t < 32; ++t) {
-                    const int64_t p = (int64_t)c * 65536 + ((int64_t)32 * lane + s - 1) * 32 + t;
-                    if (p < 0) continue;
-                    care |= 1u << t;
-                    if (ref_bit(hp, (uint64_t)p, tt, HASH_BS_PLANES)) want |= 1u << t;
-                }
-                const uint32_t got = ho[((s >> 2) * 64 + lane) * 4 + (s & 3)] & care;
-                if (got != want && bad++ < 5) printf("MISMATCH chunk %u strip %u lane %u: got %08x want %08x\n", c, s, lane, got, want);
-                total += __builtin_popcount(want);
-            }
+        // the chunk writes the words [c * 2048 - 1, c * 2048 + 2047)
+        CK(hipMemcpy(ho.data(), dO + (size_t)c * mxg::BS_OUT_WORDS - 1, mxg::BS_OUT_WORDS * 4, hipMemcpyDeviceToHost));
+        for (uint32_t wi = 0; wi < 2048; ++wi) {
+            const int64_t g = (int64_t)c * 2048 + wi - 1;
+            if (g < 0) continue;
+            uint32_t want = 0;
+            for (uint32_t t = 0; t < 32; ++t)
+                if (ref_bit(hp, (uint64_t)g * 32 + t, tt, HASH_BS_PLANES)) want |= 1u << t;
+            if (ho[wi] != want && bad++ < 5) printf("MISMATCH chunk %u word %u: got %08x want %08x\n", c, wi, ho[wi], want);
+            total += __builtin_popcount(want);
+        }
     }
     printf("verify: %s (%llu candidates in 4 chunks)\n", bad ? "FAILED" : "ok", (unsigned long long)total);
     const double kmers = (double)n_chunks * 65536.0;
