@@ -371,11 +371,24 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     }
 }
 
-// k = 32 route: the same arena entries from the bitmap that k_hash_bs (bs_kernels.h) wrote for the whole assembly -- bit p =
-// "the 32-mer at base position p passed the ring test".  Everything behind the hash kernel (k_reorder_w, k_resolve, ...) runs
-// unchanged; what the bit-sliced filter lets through beyond hash < tau (it compares the top 14 bits of the ring sum: ~2 % more)
-// are entries whose exact hash k_reorder_w finds >= tau, which k_resolve treats as absent.
-__global__ __launch_bounds__(256) void k_bs_arena(const SparseParams p, const uint32_t *__restrict__ bm)
+// k = 32 route: k_hash_bs (bs_kernels.h) has written one bit per base position of the whole assembly -- bit p = "the 32-mer at
+// base position p passed the ring test" -- so a batch needs no arena: k_bs_count counts the bits of every strip (the strips'
+// k-mer ranges mask out positions whose k-mer would cross a run's end) and publishes the per-wave totals, k_bs_reorder_w reads
+// the same words again (58 MB per 461 Mbp batch) and writes the ordered candidate arrays.  What the filter lets through beyond
+// hash < tau (it compares the top 14 bits of the ring sum: ~2 % more) are entries whose exact hash turns out >= tau, which
+// k_resolve treats as absent.
+//
+// the bits of k-mers [32 j, 32 j + 32) of a strip whose first k-mer is base position b (bw = bm + b / 32, sh = b % 32), LSB first
+__device__ __forceinline__ uint32_t bs_strip_bits(const uint32_t w_lo, const uint32_t w_hi, const uint32_t sh, const uint32_t len,
+                                                  const uint32_t j)
+{
+    const uint32_t bits = __builtin_amdgcn_alignbit(w_hi, w_lo, sh);
+    const uint32_t k0 = 32u * j;
+    const uint32_t nvalid = len > k0 ? min(len - k0, 32u) : 0u;
+    return bits & (nvalid >= 32u ? 0xFFFFFFFFu : ((1u << nvalid) - 1u));
+}
+
+__global__ __launch_bounds__(256) void k_bs_count(const SparseParams p, const uint32_t *__restrict__ bm)
 {
     const uint32_t S = p.S;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -395,27 +408,11 @@ __global__ __launch_bounds__(256) void k_bs_arena(const SparseParams p, const ui
             p.strip_meta[srel] = lo;
         }
         const uint32_t wave_id = vb * 4u + wv;
-        uint2 *const region = p.arena + (size_t)wave_id * p.wave_cap;
-        const uint32_t wave_cap = p.wave_cap;
-        uint32_t cnt_w = 0, seq = 0;
-        auto store_entry = [&](const uint32_t blk, const uint32_t mine) {
-            const uint64_t mask = __builtin_amdgcn_ballot_w64(mine != 0u);
-            if (mask) {
-                if (mine) {
-                    const uint32_t slot = cnt_w + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    if (slot < wave_cap) region[slot] = make_uint2(srel, mine | (blk << 16) | (seq << 22));
-                    seq += (uint32_t)__popc(mine);
-                }
-                cnt_w += (uint32_t)__popcll(mask);
-            }
-        };
-        // 32 k-mers (two entries) per word step: bits [b + 32 j, b + 32 j + 32) of the bitmap; eight words are requested at a
-        // time (one dependent load per step left the kernel waiting for memory: 58 us per batch)
+        // eight words are requested at a time (one dependent load per word left the kernel waiting for memory)
         const uint32_t *bw = bm + (b >> 5);
         const uint32_t sh = (uint32_t)b & 31u;
-        const uint32_t nblk = S / 16u, nwords = (nblk + 1u) / 2u;
-        uint32_t w0 = bw[0];
+        const uint32_t nwords = (S + 31u) / 32u;
+        uint32_t w0 = bw[0], cnt = 0;
 #pragma unroll 1
         for (uint32_t j0w = 0; j0w < nwords; j0w += 8u) {
             uint32_t wn[8];
@@ -423,26 +420,16 @@ __global__ __launch_bounds__(256) void k_bs_arena(const SparseParams p, const ui
             for (uint32_t u = 0; u < 8; ++u) wn[u] = j0w + u < nwords ? bw[j0w + u + 1u] : 0u;
 #pragma unroll
             for (uint32_t u = 0; u < 8; ++u) {
-                const uint32_t j = j0w + u;
-                if (j < nwords) {  // (wave-uniform)
-                    uint32_t bits = __builtin_amdgcn_alignbit(wn[u], w0, sh);  // k-mers 32 j .. 32 j + 31 of the strip, LSB first
-                    w0 = wn[u];
-                    const uint32_t k0 = 32u * j;
-                    const uint32_t nvalid = len > k0 ? min(len - k0, 32u) : 0u;
-                    bits &= nvalid >= 32u ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
-                    const uint32_t rev = __brev(bits);  // the entries' bit 15 = the block's first k-mer
-                    store_entry(2u * j, rev >> 16);
-                    if (2u * j + 1u < nblk) store_entry(2u * j + 1u, rev & 0xFFFFu);
-                }
+                cnt += (uint32_t)__popc(bs_strip_bits(w0, wn[u], sh, len, j0w + u));
+                w0 = wn[u];
             }
         }
-        if (s < p.strip_hi) p.strip_cnt[srel] = seq;
-        const uint32_t tot = wave_sum_u32(seq);
+        if (s < p.strip_hi) p.strip_cnt[srel] = cnt;
+        const uint32_t tot = wave_sum_u32(cnt);
         if (lane == 0) {
-            p.wave_cnt[wave_id] = cnt_w;
             p.wave_tot[wave_id] = tot;
             wtot[wv] = tot;
-            if (tot > wave_cap) atomicMax(&p.ctrl[0], tot);
+            if (tot > p.wave_cap) atomicMax(&p.ctrl[0], tot);  // more than a queue / the ordered arrays hold: the host redoes the batch
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -478,6 +465,7 @@ struct ReorderParams {
     uint64_t *ch;
     uint32_t *ck, *cc;
     HashTab tab;
+    const uint32_t *bm;          // k = 32 route (k_bs_reorder_w): the filter's bitmap instead of the arena
 };
 
 // 320 threads: a slice holds ~290 candidates (64 strips x 320 k-mers x 1.4 %), so one pass of the block hashes them
@@ -652,6 +640,84 @@ __global__ __launch_bounds__(RW_WAVES * 64) void k_reorder_w(const ReorderParams
             const uint32_t dst = base + q;
             if (act && dst < p.n_cap) {  // beyond n_cap only when a wave overflowed: the host redoes the batch
                 const uint32_t ju = ((item >> 6) & 63u) * 16u + ((item >> 12) & 15u);
+                H2 h;
+                init_pos(h, p.packed, (((uint64_t)sbhi << 32) | sblo) + ju, p.k, ptab, tab);
+                p.ch[dst] = canonical<VARIANT>(h);
+                p.ck[dst] = sk + ju;
+                p.cc[dst] = sc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the next slice reuses the queue
+    }
+}
+
+// k = 32 route: the same step from the filter's bitmap.  Lane = strip while the queue is filled (the strip's bits, its count from
+// k_bs_count, its run), lane = candidate while hashing; queue item = strip | k-mer of the strip << 6.
+template <int VARIANT>
+__global__ __launch_bounds__(RW_WAVES * 64) void k_bs_reorder_w(const ReorderParams p)
+{
+    extern __shared__ uint4 rw_lds[];  // [2048] position tables | RW_WAVES queues of queue_cap words
+    __shared__ uint4 tab[20];
+    uint4 *ptab = rw_lds;
+    for (uint32_t i = threadIdx.x; i < 2048u; i += RW_WAVES * 64u) ptab[i] = p.init_tab[256u + i];
+    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    uint32_t *queue = reinterpret_cast<uint32_t *>(rw_lds + 2048) + wib * p.queue_cap;
+    const uint32_t nwords = (p.S + 31u) / 32u;
+    for (uint32_t wv = blockIdx.x * RW_WAVES + wib; wv < p.n_waves; wv += gridDim.x * RW_WAVES) {
+        const uint32_t s = wv * 64u + lane;
+        const bool in = s < p.n_strips;
+        const uint32_t c = in ? p.strip_cnt[s] : 0u;
+        uint32_t m_c = 0, m_k = 0, m_blo = 0, m_bhi = 0, len = 0;  // the strip's contig, first k-mer index, base offset, k-mers
+        if (in) {
+            const uint32_t ri = p.strip_meta[s];
+            const Run run = p.runs[ri];
+            const uint32_t j0 = (p.strip_lo + s - p.run_strip0[ri]) * p.S;
+            const uint64_t b = run.base_off + j0;
+            m_c = run.contig; m_k = run.kidx0 + j0; m_blo = (uint32_t)b; m_bhi = (uint32_t)(b >> 32);
+            len = min(p.S, run.n_kmers - j0);
+        }
+        const uint32_t before = count_prefix(p.wave_tot, p.wave_sup, wv);
+        const uint32_t incl = wave_inclusive_u32(c, lane);
+        const uint32_t base = before, tot = (uint32_t)__shfl((int)incl, 63, 64);
+        if (wv + 1 == p.n_waves && lane == 63u) {
+            p.n_cand[0] = before + incl;
+            p.n_cand[1] = 0;
+        }
+        const uint32_t qn = min(tot, p.queue_cap);
+        // every set bit -> the queue, at the strip's first slot + its rank inside the strip
+        const uint32_t *bw = p.bm + ((((uint64_t)m_bhi << 32) | m_blo) >> 5);
+        const uint32_t sh = m_blo & 31u;
+        uint32_t at = incl - c;
+        uint32_t w0 = in ? bw[0] : 0u;
+#pragma unroll 1
+        for (uint32_t j0w = 0; j0w < nwords; j0w += 8u) {
+            uint32_t wn[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) wn[u] = in && j0w + u < nwords ? bw[j0w + u + 1u] : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                uint32_t bits = bs_strip_bits(w0, wn[u], sh, len, j0w + u);
+                w0 = wn[u];
+                const uint32_t item0 = lane | ((32u * (j0w + u)) << 6);
+                for (; bits; bits &= bits - 1u, ++at) {
+                    const uint32_t t = (uint32_t)__builtin_ctz(bits);
+                    if (at < qn) queue[at] = item0 + (t << 6);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave complete in order)
+        for (uint32_t q0 = 0; q0 < qn; q0 += 64u) {
+            const uint32_t q = q0 + lane;
+            const bool act = q < qn;
+            const uint32_t item = act ? queue[q] : 0u;
+            const int sl = (int)(item & 63u);
+            const uint32_t sc = (uint32_t)__shfl((int)m_c, sl, 64), sk = (uint32_t)__shfl((int)m_k, sl, 64);
+            const uint32_t sblo = (uint32_t)__shfl((int)m_blo, sl, 64), sbhi = (uint32_t)__shfl((int)m_bhi, sl, 64);
+            const uint32_t dst = base + q;
+            if (act && dst < p.n_cap) {  // beyond n_cap only when a wave overflowed: the host redoes the batch
+                const uint32_t ju = item >> 6;
                 H2 h;
                 init_pos(h, p.packed, (((uint64_t)sbhi << 32) | sblo) + ju, p.k, ptab, tab);
                 p.ch[dst] = canonical<VARIANT>(h);
@@ -2127,7 +2193,6 @@ struct Driver {
             return set_err(h, MXG_ELIMIT, "candidate arena would exceed 2^32 entries; use MXG_FLAG_DENSE_ONLY");
         const uint32_t n_cap = (uint32_t)n_cap64;
         *n_cap_out = n_cap;
-        MXG_HIP(h, sc(SC_ARENA).ensure((size_t)n_cap * 8));
         MXG_HIP(h, sc(SC_CAND_H).ensure((size_t)n_cap * 8));
         MXG_HIP(h, sc(SC_CAND_K).ensure((size_t)n_cap * 4));
         MXG_HIP(h, sc(SC_CAND_C).ensure((size_t)n_cap * 4));
@@ -2152,7 +2217,6 @@ struct Driver {
         const uint32_t ring_slack = (uint32_t)env_u64("MXG_RING_SLACK", 0);  // read per call, like the other knobs
         sp.tau_hi = ring_slack ? (uint32_t)std::min<uint64_t>(0x7FFFFFFEull, (uint64_t)tau_hi * (100 + ring_slack) / 100) & ~1u
                                : tau_hi;
-        sp.arena = sc(SC_ARENA).as<uint2>();
         sp.wave_cap = (uint32_t)wave_cap;
         sp.wave_cnt = sc(SC_WAVE_CNT).as<uint32_t>();
         sp.ctrl = sc(SC_CTRL).as<uint32_t>();
@@ -2160,6 +2224,20 @@ struct Driver {
         sp.strip_meta = sc(SC_STRIP_META).as<uint32_t>();
         sp.wave_tot = sc(SC_WAVE_TOT).as<uint32_t>();
         sp.wave_sup = wave_sup();
+        // reorder geometry (needed first: the k = 32 route's reorder kernel exists in the one-wave-per-slice form only)
+        const uint32_t queue_cap = sp.wave_cap <= 8192 ? sp.wave_cap : 0;
+        const size_t q_lds = (size_t)queue_cap * 4;
+        // slices per block (MXG_REORDER_G): the block's byte table is loaded once for all of them
+        const uint32_t r_g = (uint32_t)std::max<uint64_t>(1, env_u64("MXG_REORDER_G", 1));
+        const uint32_t r_grid = (g.n_waves + r_g - 1) / r_g;
+        // one wave per slice + position tables when the queues of a block fit beside the 32 KB of tables
+        const size_t w_lds = (size_t)2048 * 16 + (size_t)RW_WAVES * queue_cap * 4;
+        const bool r_wave = queue_cap && w_lds + 512 <= 65536 && env_u64("MXG_REORDER_W", 1) != 0;
+        const uint32_t w_grid = std::min<uint32_t>((g.n_waves + RW_WAVES - 1) / RW_WAVES,
+                                                   (uint32_t)env_u64("MXG_REORDER_W_GRID", 256 * 3));
+        if (!r_wave) bs_bitmap = nullptr;  // (a batch whose slices outgrow the LDS queues takes the rolling-hash kernel)
+        if (!bs_bitmap) MXG_HIP(h, sc(SC_ARENA).ensure((size_t)n_cap * 8));
+        sp.arena = sc(SC_ARENA).as<uint2>();
         int rc;
         sp.init_tab = h->d_init_tab.as<uint4>();
         sp.tab = h->tab;
@@ -2177,7 +2255,7 @@ struct Driver {
         size_t pad = (size_t)env_u64("MXG_HASH_LDS", g.nk >= (256ull << 20) ? 18000 : 0);
         if (sp.five && sp.k == 32) pad = std::max<size_t>(pad, 16384);
         if (bs_bitmap)  // (k = 32 route: the filter has run over the whole assembly; only its bits are turned into entries)
-            hipLaunchKernelGGL(k_bs_arena, dim3(g.n_blocks), block, 0, st, sp, bs_bitmap);
+            hipLaunchKernelGGL(k_bs_count, dim3(g.n_blocks), block, 0, st, sp, bs_bitmap);
         else if (h->cfg.variant == MXG_VARIANT_V1_MIN)
             hipLaunchKernelGGL((k_hash_sparse<MXG_VARIANT_V1_MIN>), grid, block, pad, st, sp);
         else if (abl == 1)
@@ -2213,17 +2291,11 @@ struct Driver {
         op.ck = sc(SC_CAND_K).as<uint32_t>();
         op.cc = sc(SC_CAND_C).as<uint32_t>();
         op.tab = h->tab;
-        op.queue_cap = sp.wave_cap <= 8192 ? sp.wave_cap : 0;
-        const size_t q_lds = (size_t)op.queue_cap * 4;
-        // slices per block (MXG_REORDER_G): the block's byte table is loaded once for all of them
-        const uint32_t r_g = (uint32_t)std::max<uint64_t>(1, env_u64("MXG_REORDER_G", 1));
-        const uint32_t r_grid = (g.n_waves + r_g - 1) / r_g;
-        // one wave per slice + position tables when the queues of a block fit beside the 32 KB of tables
-        const size_t w_lds = (size_t)2048 * 16 + (size_t)RW_WAVES * op.queue_cap * 4;
-        const bool r_wave = op.queue_cap && w_lds + 512 <= 65536 && env_u64("MXG_REORDER_W", 1) != 0;
-        const uint32_t w_grid = std::min<uint32_t>((g.n_waves + RW_WAVES - 1) / RW_WAVES,
-                                                   (uint32_t)env_u64("MXG_REORDER_W_GRID", 256 * 3));
-        if (r_wave && h->cfg.variant == MXG_VARIANT_V1_MIN)
+        op.bm = bs_bitmap;
+        op.queue_cap = queue_cap;
+        if (bs_bitmap)  // (bs_possible: V2, and enqueue_sparse's caller has checked that the queues fit)
+            hipLaunchKernelGGL(k_bs_reorder_w<MXG_VARIANT_V2_SUM>, dim3(w_grid), dim3(RW_WAVES * 64), w_lds, st, op);
+        else if (r_wave && h->cfg.variant == MXG_VARIANT_V1_MIN)
             hipLaunchKernelGGL(k_reorder_w<MXG_VARIANT_V1_MIN>, dim3(w_grid), dim3(RW_WAVES * 64), w_lds, st, op);
         else if (r_wave && !getenv("MXG_ABLATE_REORDER"))
             hipLaunchKernelGGL(k_reorder_w<MXG_VARIANT_V2_SUM>, dim3(w_grid), dim3(RW_WAVES * 64), w_lds, st, op);

@@ -586,7 +586,8 @@ int bs_prepare(mxg_handle *h, Assembly *a)
     a->bs_chunks = n_chunks;
     MXG_HIP(h, a->d_bs_T.ensure((size_t)n_chunks * BS_T_WORDS * 4));
     MXG_HIP(h, a->d_bs_Q.ensure((size_t)n_chunks * BS_Q_WORDS * 4));
-    MXG_HIP(h, a->d_bs_out.ensure(((size_t)n_chunks * BS_OUT_WORDS + BS_OUT_PAD) * 4 + 64));
+    // (+ 256 bytes behind it: the batch kernels request the words of a whole strip, up to 1024 positions + 2 words, before masking)
+    MXG_HIP(h, a->d_bs_out.ensure(((size_t)n_chunks * BS_OUT_WORDS + BS_OUT_PAD) * 4 + 256));
     hipLaunchKernelGGL(k_bs_transpose, dim3(n_chunks), dim3(64), 0, h->stream, a->d_packed, (uint64_t)a->packed_words,
                        a->d_bs_T.as<uint32_t>(), a->d_bs_Q.as<uint32_t>(), 0u, n_chunks);
     MXG_HIP(h, hipGetLastError());
