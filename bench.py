@@ -16,8 +16,11 @@ Workloads (BASELINE.json configs; `auto` = the config the metric names for this 
   N>1  see main(): contig-sharded over the ranks, one RCCL exchange per step (ntjoin_amd/dist.py)
 
 Beside the contract's fields the JSON line carries
-  roofline      the dominant kernel (k_hash_sparse) against the HBM roof: algorithmic bytes = 0.25 B/bp, time = HIP events
-                recorded by the library on ITS launch stream around every launch of the timed region (live)
+  roofline      the kernel that reads every base (k_hash_bs, the bit-sliced ring filter; one launch per assembly) against the
+                HBM roof: algorithmic bytes = 0.25 B/bp, time = HIP events recorded by the library on ITS launch stream around
+                every launch of the timed region (live)
+  valu          the same kernel against what really bounds it, VALU issue: wave64 instructions per chunk counted by the
+                generator (csrc/hash_bs_k32.inc) x chunks per launch / 1024 SIMDs x 2 cycles at 2.4 GHz
   step_roofline the whole step's algorithmic bytes (0.25 L + 70 M) over the step time
   kernels       per-kernel GPU time of a step, measured in a second, shorter pass with one HIP-event pair per kernel
   cpu_baseline  the oracle's `indexlr -t nproc` + graph stage in C on the host cores, on a stated sample of the workload
@@ -83,20 +86,33 @@ def logical_cpus():
     return os.cpu_count() or 1
 
 
-def valu_static(wl, mbp, multi):
-    """what really binds the dominant kernel is integer-VALU issue, not HBM: instructions per base and VALU
-    utilisation from the committed PMC pass over THIS workload (static: not measured in this run), or None"""
-    path = os.path.join(REPO, "profiles", "r02", "configs2_hash_kernel_pmc.json")
-    if multi or wl != "configs2" or abs(mbp - 3000.0) > 1e-9 or not os.path.exists(path):
-        return None
+SIMDS = 256 * 4            # MI355X: 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9           # peak engine clock (MI355X_MICROARCH.md)
+ISSUE_CYCLES = 2.0         # a wave64 VALU instruction occupies its SIMD for 2 cycles at best (measured: profiles/ubench/README.md)
+BS_CHUNK = 65536           # base positions per chunk of the bit-sliced filter (csrc/bs_kernels.h)
+
+
+def bs_route():
+    return os.environ.get("MXG_BS", "1") != "0"
+
+
+def valu_model(bases_per_launch, avg_ms):
+    """k_hash_bs against VALU issue, the roof that binds it: the generator counts the wave64 VALU instructions of one chunk
+    (HASH_BS_VALU_PER_CHUNK, all of the fast class); a launch's chunks are spread over all SIMDs"""
     try:
-        v = json.load(open(path))
-        return {"wave64_instr_per_base": round(v["valu_per_base"], 2), "valu_busy": round(v["valu_busy"], 3),
-                "peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,
-                "source": "static: rocprofv3 SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE on this workload, "
-                          "profiles/r02/configs2_hash_kernel_pmc.json (kernel alone on one stream)"}
+        txt = open(os.path.join(REPO, "ntjoin_amd", "csrc", "hash_bs_k32.inc")).read()
+        per_chunk = int(txt.split("#define HASH_BS_VALU_PER_CHUNK", 1)[1].split()[0])
     except Exception:
         return None
+    chunks = bases_per_launch / BS_CHUNK
+    bound_ms = per_chunk * chunks / SIMDS * ISSUE_CYCLES / CLOCK_HZ * 1e3
+    return {"kernel": "k_hash_bs", "wave64_valu_instr_per_chunk": per_chunk, "bases_per_chunk": BS_CHUNK,
+            "wave64_valu_instr_per_base": round(per_chunk / BS_CHUNK, 5),
+            "lane_ops_per_base": round(per_chunk * 64 / BS_CHUNK, 3),
+            "valu_issue_bound_ms": round(bound_ms, 4), "avg_launch_ms": round(avg_ms, 4),
+            "frac_of_issue_bound": round(bound_ms / avg_ms, 4) if avg_ms > 0 else None,
+            "model": f"instructions x chunks / {SIMDS} SIMDs x {ISSUE_CYCLES:g} cycles / {CLOCK_HZ / 1e9:g} GHz; the instruction count is "
+                     "static (generated code: ntjoin_amd/csrc/gen/bs_gen.py), the launch time is this run's"}
 
 
 def workload_tables(name, mbp, w, seed=1):
@@ -361,13 +377,14 @@ def main():
         step_gbs = step_alg_bytes / (ms_step * 1e-3) / 1e9
         # PMC traffic of the hash kernel: only quoted when the committed counters were collected on THIS workload
         traffic, traffic_src = None, None
-        tpath = os.path.join(REPO, "profiles", "r02_hbm_traffic.json")
-        if os.path.exists(tpath):
+        tpath = os.path.join(REPO, "profiles", "r03", "hbm_traffic.json")
+        if os.path.exists(tpath) and bs_route():
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == wl and abs(tj.get("mbp", 0) - mbp) < 1e-9 and not multi:
                     traffic = round(tj["k_hash_bytes_per_base"] * st["hash_kernel_bases"] / launches)
-                    traffic_src = "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload, profiles/r02_hbm_traffic.json"
+                    traffic_src = ("static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload at commit "
+                                   f"{tj.get('commit', '?')}, profiles/r03/hbm_traffic.json")
             except Exception:
                 traffic = None
         out = {
@@ -388,22 +405,25 @@ def main():
                                        ("graph stage partitioned by hash range (RCCL all-to-all)" if graph_mode == "partitioned"
                                         else "RCCL all-gather of sketches, graph of the union on every rank"))},
             "step_ms_min_max": [round(min(step_times) * 1e3, 4), round(max(step_times) * 1e3, 4)],
-            "roofline": {"bound": "hbm", "kernel": "k_hash_sparse (ntHash fwd/rc rings + candidate filter)",
+            "roofline": {"bound": "hbm",
+                         "kernel": ("k_hash_bs (bit-sliced ntHash top rings + candidate filter, one launch per assembly)" if bs_route()
+                                    else "k_hash_sparse (ntHash fwd/rc rings + candidate filter)"),
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_base": ALG_BYTES_PER_BASE_HASH, "alg_bytes_per_launch": int(bytes_per_launch),
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(st["launches_hash"]),
-                         "timed": f"HIP-event pair around one hash-kernel launch in {os.environ.get('MXG_TIMING_SAMPLE', '1')} "
-                                  "inside the timed region, on the launch stream",
+                         "timed": "HIP-event pair around every launch of the kernel inside the timed region, on the launch stream",
+                         "min_traffic_bytes_per_base": 0.25 + 0.25 / 32 + 0.125,
+                         "min_traffic_note": "what this formulation must move: 2 bits per base (bit planes) + 1/32 of that (the "
+                                             "strips' predecessors) read, 1 bit per position (the candidate bitmap) written",
                          "bases_per_launch": int(st["hash_kernel_bases"] / launches),
                          "share_of_step_time": round(st["ms_hash"] * t_scale / args.steps / ms_step, 4)},
-            "valu": valu_static(wl, mbp, multi),
+            "valu": valu_model(st["hash_kernel_bases"] / launches, avg_ms) if bs_route() else None,
             "step_roofline": {"bound": "hbm", "alg_bytes_per_step": int(step_alg_bytes),
                               "formula": "0.25 B x bases + 70 B x minimizers (SURVEY.md 8d)",
                               "achieved": round(step_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(step_gbs / HBM_PEAK_GBS, 6)},
-            "stage_ms_per_step": {"hash": round(st["ms_hash"] * t_scale / args.steps, 4),
-                                  "behind_hash": round(st["ms_resolve"] * t_scale / args.steps, 4),
+            "stage_ms_per_step": {"filter": round(st["ms_hash"] * t_scale / args.steps, 4),
                                   "graph": round(gst["ms_graph"] / args.steps, 4)},
         }
         if not multi and not args.no_kernels:
@@ -417,8 +437,10 @@ def main():
             for _ in range(nk):
                 step(eng2)
             s2 = eng2.stats()
-            ker = {"k_hash_sparse": s2["ms_hash"] / nk, "k_reorder": s2["ms_reorder"] / nk, "k_resolve": s2["ms_resolve_kernel"] / nk,
-                   "k_emit": s2["ms_emit"] / nk, "join (k_pj_* / k_insert+k_flags)": s2["ms_join"] / nk,
+            bs = bs_route()
+            ker = {"k_hash_bs" if bs else "k_hash_sparse": s2["ms_hash"] / nk,
+                   "k_bs_count+k_bs_reorder_w" if bs else "k_reorder_w": s2["ms_reorder"] / nk,
+                   "k_resolve+k_gap_fix+k_gap_post": s2["ms_resolve_kernel"] / nk, "k_emit": s2["ms_emit"] / nk, "join (k_pj_* / k_insert+k_flags)": s2["ms_join"] / nk,
                    "k_vertices+k_adjacency": s2["ms_vertices"] / nk, "k_edge_flags+k_edges": s2["ms_edges"] / nk}
             tot = sum(ker.values()) or 1.0
             out["kernels"] = {"ms_per_step": {k_: round(v, 4) for k_, v in ker.items()},

@@ -131,7 +131,8 @@ typedef struct mxg_stats {
     double ms_join;            /* uniqueness + intersection (hash join, flags)                   */
     double ms_vertices;        /* vertex ids + adjacency arrays                                  */
     double ms_edges;           /* edge flags + edge compaction                                   */
-    double reserved[2];
+    uint64_t bs_filter_bases;  /* bases covered by the bit-sliced filter (k = 32 route; 0: the rolling-hash kernel ran) */
+    double reserved[1];
 } mxg_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */

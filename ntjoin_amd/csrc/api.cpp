@@ -938,6 +938,7 @@ int mxg_get_stats(mxg_handle *h, mxg_stats *out)
     }
     if (flush_timers(h) != MXG_OK) return MXG_EDEVICE;
     s.candidates = h->stat_candidates;
+    s.bs_filter_bases = h->stat_bs_bases;
     s.dense_kmers = h->stat_dense_kmers;
     s.unique = h->graph.valid ? h->stat_unique : 0;
     s.vertices = h->graph.valid ? h->graph.nv : 0;
@@ -963,7 +964,7 @@ int mxg_reset_timers(mxg_handle *h)
     int rc = flush_timers(h);
     if (rc != MXG_OK) return rc;
     h->tm = Timers();
-    h->stat_candidates = h->stat_dense_kmers = 0;
+    h->stat_candidates = h->stat_dense_kmers = h->stat_bs_bases = 0;
     return MXG_OK;
 }
 

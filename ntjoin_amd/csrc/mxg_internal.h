@@ -204,6 +204,7 @@ struct mxg_handle {
     mxg::HashTab tab{};
     mxg::DevBuf d_init_tab;  // byte table of the direct hash formula (256 x 16 B), built by the first sketch
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
+    uint64_t stat_bs_bases = 0;  // bases the bit-sliced filter (k = 32 route) has covered
     // scratch reused across calls
     mxg::DevBuf scratch[4][40];  // indexed by mxg::Scratch (sketch.hip): one set per in-flight sketch driver (= stream)
     std::vector<mxg::Assembly *> pend_list;  // mxg_sketch_pack in flight: assemblies and how each was enqueued

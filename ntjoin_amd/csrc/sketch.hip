@@ -2748,8 +2748,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         uint32_t *hc;  // pinned control block
         bool bs;       // went through the k = 32 route (no candidate arrays to finish from)
     };
-    static const bool bs_env = env_u64("MXG_BS", 1) != 0;
-    static const bool bs_fused = env_u64("MXG_BS_FUSED", 0) != 0;  // k_bs_resolve instead of arena -> reorder -> resolve
+    const bool bs_env = env_u64("MXG_BS", 1) != 0;
+    const bool bs_fused = env_u64("MXG_BS_FUSED", 0) != 0;  // k_bs_resolve instead of count -> reorder -> resolve
     std::vector<Tables> tabs(n);
     std::vector<int> state(n, 0);  // 0 = synchronous path, 1 = enqueued, 2 = done
     std::vector<SparsePlan> plans(n);
@@ -2817,6 +2817,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 st_hash = drv.st;
                 if ((rc = drv.ev_begin(list[i]->total_bases, true)) != MXG_OK) return rc;
                 if ((rc = bs_hash(h, list[i], plans[i].tau_hi, drv.st)) != MXG_OK) return rc;
+                h->stat_bs_bases += list[i]->total_bases;
                 if ((rc = drv.ev_end()) != MXG_OK) return rc;
                 if (gs.size() > 1) {
                     while (h->ev_bs.size() <= i) {

@@ -1,0 +1,116 @@
+"""The generated bit-sliced ring filter (ntjoin_amd/csrc/gen/bs_gen.py -> csrc/hash_bs_k32.inc) checked on the CPU:
+
+  * the generator's numpy VM executes the instruction list it emits (64 lanes x 32-bit registers, the same operand banks) on
+    random bases and must reproduce `reference_bits`, the plain restatement of the ring test, word for word -- including the
+    word in front of a chunk, the prefetch of the next chunk's planes and thresholds at both ends of the range;
+  * `reference_bits` itself is pinned to the oracle: every k-mer whose canonical hash (oracle: reference ntHash)
+    is < tau must pass the test (the filter may let more through, never fewer), and what it lets through beyond them stays
+    within the few percent the design states;
+  * the committed .inc is what the generator emits now (a stale generated file would ship an unchecked kernel).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "ntjoin_amd", "csrc", "gen"))
+import bs_gen as G  # noqa: E402
+
+
+def _vm_chunk(seed, tt, c, n_chunks=3):
+    rng = np.random.default_rng(seed)
+    codes = rng.integers(0, 4, n_chunks * G.CHUNK).astype(np.uint8)
+    T, Q = G.transpose_layout(codes, n_chunks)
+    g = G.Gen(32)
+    g.chunk()
+    c_next = min(c + 1, n_chunks - 1)
+    vm = G.VM(T, Q, tt, c, c_next)
+    out = vm.run(g)[:2048]  # (the VM's last word belongs to the next chunk's first slot)
+    ext = np.concatenate([codes, np.zeros(64, dtype=np.uint8)])  # (bases behind the assembly read as A, like k_bs_transpose)
+    ref = G.reference_bits(ext[:n_chunks * G.CHUNK + 31], 32, tt)
+    # the chunk writes the words [c * 2048 - 1, c * 2048 + 2047) of the position bitmap
+    lo = c * 2048 - 1
+    want = np.zeros(2048, dtype=np.uint64)
+    sh = np.arange(32, dtype=np.uint64)
+    for wi in range(2048):
+        gi = lo + wi
+        if gi >= 0:
+            want[wi] = int((ref[gi * 32: gi * 32 + 32].astype(np.uint64) << sh).sum())
+    first = 1 if lo < 0 else 0
+    assert np.array_equal(np.asarray(out[first:], dtype=np.uint64), want[first:])
+    # the planes left in the W registers are the next chunk's (loaded while this one was computed)
+    for (t, be), reg in g.W.items():
+        assert np.array_equal(vm.vr[reg], T[c_next, t // 2, :, 2 * (t & 1) + be]), (t, be)
+    return float(ref.mean())
+
+
+@pytest.mark.parametrize("seed,tt,c", [(1, 164, 1), (2, 40, 0), (3, (1 << G.B_PLANES) - 1, 2), (4, 0, 1)])
+def test_vm_matches_reference_bits(seed, tt, c):
+    dens = _vm_chunk(seed, tt, c)
+    if tt == (1 << G.B_PLANES) - 1:
+        assert dens == 1.0  # every sum is <= the largest threshold
+    else:
+        expect = (tt + 3) / float(1 << G.B_PLANES)  # St in {-2, -1, 0 .. tt}
+        assert abs(dens - expect) < 0.15 * expect + 2e-4
+
+
+def test_instruction_classes_and_banks():
+    """only instructions of the class that issues at full rate on gfx950 (profiles/ubench/README.md), and three-register
+    v_bitop3 operands in three different register banks"""
+    g = G.Gen(32)
+    g.chunk()
+    ops = {i[0] for i in g.ins}
+    valu = {"xor", "and", "or", "mov", "bitop3", "add", "lshr"}
+    assert ops - valu <= {"gload4", "gload2", "gstore1", "gstore3", "gstore4", "waitcnt", "comment"}
+    g.check_banks()
+    n_valu = sum(1 for i in g.ins if i[0] in valu)
+    inc = open(os.path.join(REPO, "ntjoin_amd", "csrc", "hash_bs_k32.inc")).read()
+    assert f"#define HASH_BS_VALU_PER_CHUNK {n_valu}\n" in inc
+    assert f"#define HASH_BS_VGPR_END {G.VEND}\n" in inc
+    assert G.VEND <= 256  # two waves per SIMD need <= 256 VGPRs each
+
+
+def test_committed_inc_is_current(tmp_path):
+    p = tmp_path / "hash_bs_k32.inc"
+    G.emit_inc(str(p), 32)
+    assert p.read_text() == open(os.path.join(REPO, "ntjoin_amd", "csrc", "hash_bs_k32.inc")).read()
+
+
+def test_layout_of_transpose():
+    """T / Q hold what bs_kernels.h says they hold"""
+    rng = np.random.default_rng(9)
+    codes = rng.integers(0, 4, 2 * G.CHUNK).astype(np.uint8)
+    T, Q = G.transpose_layout(codes, 2)
+    for _ in range(200):
+        c, lane, s, t, be = (int(rng.integers(0, n)) for n in (2, 64, 32, 32, 2))
+        p = c * G.CHUNK + (32 * lane + s) * 32 + t
+        assert (int(T[c, t // 2, lane, 2 * (t & 1) + be]) >> s) & 1 == (int(codes[p]) >> be) & 1
+        q = c * G.CHUNK + (32 * lane - 1) * 32 + t
+        if q >= 0:
+            assert (int(Q[c, lane, be]) >> t) & 1 == (int(codes[q]) >> be) & 1
+
+
+@pytest.mark.parametrize("cand_per_window,w", [(10, 1000), (10, 200), (18, 500), (2, 500)])
+def test_reference_bits_is_a_superset_of_the_oracle(oracle, cand_per_window, w):
+    """tau as the library sets it (sparse_plan: tau_hi = even(frac * 2^32), tau = tau_hi << 32; bs_hash: T = tau_hi / 2,
+    tt = (T - 1) >> 17): no k-mer with hash < tau may fail the ring test"""
+    rng = np.random.default_rng(cand_per_window * 1000 + w)
+    n = 400_000
+    codes = rng.integers(0, 4, n).astype(np.uint8)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].tobytes()
+    mh, _, _, ok = oracle.kmer_hashes(seq, 32)
+    assert ok.all()
+    frac = cand_per_window / w
+    tau_hi = max(2, int(min(4294967294.0, frac * 4294967296.0)) & ~1)
+    tau = tau_hi << 32
+    t31 = tau_hi >> 1
+    tt = (t31 - 1) >> (31 - G.B_PLANES)
+    bits = G.reference_bits(codes, 32, tt)
+    real = mh < np.uint64(tau)
+    assert real.sum() > 0
+    assert not (real & ~bits).any()
+    extra = bits.sum() / real.sum() - 1.0
+    # two extra sums (-2, -1) and the rounding of T up to a multiple of 2^17: a few percent at the library's densities
+    assert extra < (3.0 + (1 << (31 - G.B_PLANES)) / t31 * (tt + 1) - 0.0) / (tt + 1) + 0.05

@@ -1,0 +1,98 @@
+"""GPU tests of the k = 32 route of the sketch stage (csrc/bs_kernels.h, sketch_bs.hip, k_bs_count / k_bs_reorder_w):
+
+  * the generated filter kernel against the direct ring formula on random bases (standalone binary built with the library:
+    layout kernel + filter over whole chunks, ragged tail, first / middle / last chunks compared word for word);
+  * the three routes of the library -- bit-sliced filter + batch kernels (default), bit-sliced filter + the fused resolve kernel
+    (MXG_BS_FUSED=1), the rolling-hash kernel (MXG_BS=0) -- against the CPU oracle on the same records, bit for bit, with the
+    statistics saying which route ran;
+  * inputs the filter does not take (k != 32, the min(fwd, rev) variant) still go the old way.
+"""
+import os
+import random
+import subprocess
+
+import pytest
+
+from tests import _oracle
+from tests.test_gpu_scale_paths import _check, _records
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUTE_KNOBS = ("MXG_BS", "MXG_BS_FUSED", "MXG_SPARSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S", "MXG_DEV_GAPS")
+
+
+@pytest.fixture
+def env():
+    saved = {k: os.environ.get(k) for k in ROUTE_KNOBS}
+    yield os.environ
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize("mbp,tt", [(1, 164), (3, 40), (2, 0), (1, 16383)])
+def test_filter_kernel_against_direct_formula(mbp, tt):
+    exe = os.path.join(REPO, "ntjoin_amd", "bin", "bs_check")
+    assert os.path.exists(exe), "ntjoin_amd/bin/bs_check missing: run __graft_entry__.build()"
+    r = subprocess.run([exe, str(mbp), str(tt)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "verify: ok" in r.stdout
+
+
+def _bases(recs):
+    return sum(len(s) for _, s in recs)
+
+
+@pytest.mark.parametrize("seed,w", [(11, 200), (12, 1000), (13, 150)])
+def test_three_routes_agree_with_the_oracle(oracle, env, seed, w):
+    recs = _records(seed)
+    env["MXG_BS"] = "1"
+    st = _check(oracle, recs, 32, w)
+    assert st["bs_filter_bases"] == _bases(recs), "the k = 32 route did not run"
+    assert st["candidates"] > 0
+    env["MXG_BS_FUSED"] = "1"
+    st = _check(oracle, recs, 32, w)
+    assert st["bs_filter_bases"] == _bases(recs)
+    env["MXG_BS_FUSED"] = "0"
+    env["MXG_BS"] = "0"
+    st = _check(oracle, recs, 32, w)
+    assert st["bs_filter_bases"] == 0
+
+
+def test_many_batches_and_overflow_on_the_bs_route(oracle, env):
+    env["MXG_SPARSE_BATCH_KMERS"] = "30000"
+    st = _check(oracle, _records(21), 32, 200)
+    assert st["bs_filter_bases"] > 0
+    env["MXG_WAVE_CAP"] = "8"       # every slice outgrows its queue: the batch is redone with the capacity it asked for
+    env["MXG_SPARSE_S"] = "128"
+    st = _check(oracle, _records(22), 32, 200)
+    assert st["bs_filter_bases"] > 0
+    env["MXG_WAVE_CAP"] = "9000"    # queues beyond LDS: such a batch takes the rolling-hash kernel instead
+    env["MXG_SPARSE_S"] = "256"
+    _check(oracle, _records(23), 32, 200)
+
+
+def test_inputs_the_filter_does_not_take(oracle, env):
+    st = _check(oracle, _records(31), 31, 200)
+    assert st["bs_filter_bases"] == 0
+    st = _check(oracle, _records(32), 32, 300, cand_per_window=4, variant="v1")
+    assert st["bs_filter_bases"] == 0
+
+
+def test_run_borders_and_short_records(oracle, env):
+    """N runs every few hundred bases, records shorter than a window, records of exactly k .. k + w bases: positions whose
+    32-mer crosses a run border are set in the bitmap (the filter sees bases, not runs) and must be masked by the batch kernels"""
+    rng = random.Random(77)
+    recs = []
+    for r in range(60):
+        n = rng.choice([31, 32, 33, 100, 231, 232, 233, 700, 3000, 9000])
+        s = [rng.choice("ACGT") for _ in range(n)]
+        for _ in range(n // 400):
+            p = rng.randrange(0, n)
+            s[p:p + rng.choice([1, 2, 31, 32, 33, 90])] = "N" * min(rng.choice([1, 2, 31, 32, 33, 90]), n - p)
+        recs.append((f"r{r}", "".join(s)[:n]))
+    recs.append(("long", "".join(rng.choice("ACGT") for _ in range(150000))))
+    st = _check(oracle, recs, 32, 200)
+    assert st["bs_filter_bases"] > 0
