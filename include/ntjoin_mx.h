@@ -182,8 +182,9 @@ int mxg_add_assembly_packed_device(mxg_handle *h, const char *name, double weigh
 /* Sub-record sharding of bases already in HBM (the packed counterpart of mxg_add_assembly_fasta_split, for inputs that never
    were text: generated or produced on the device).  Every record is registered (ids, full lengths: record indices are global);
    the handle holds the bases [piece_lo[r], piece_hi[r]) of record r where piece_hi > piece_lo: base b of the record sits at
-   packed index rec_start[r] + (b - (piece_lo[r] & ~15)) (rec_start a multiple of 16); piece_drop[r] = the piece begins with
-   the halo of the shard before it and withholds its first minimizer.  mxg_plan_split computes the pieces of shard `shard` of
+   packed index rec_start[r] + (b - (piece_lo[r] & ~15)) (rec_start a multiple of 16); piece_drop[r] bit 0 = the piece begins
+   with the halo of the shard before it and withholds its first minimizer, bit 1 = the record began on an earlier shard (what
+   mxg_assembly_continues reports for the handle's first record; set even when the halo reaches back to the record's base 0).  mxg_plan_split computes the pieces of shard `shard` of
    `n_shards` for N-free records (equal base ranges, a halo of w k-mers: the rule of mxg_add_assembly_fasta_split), so that the
    rank-ordered concatenation of the shards' sketches is the sketch of the whole assembly.  No counterpart in the reference
    (one process per assembly, ntJoin:204-205). */

@@ -277,13 +277,17 @@ int mxg_plan_split(const uint64_t *lengths, uint64_t n_records, uint32_t shard, 
         const uint64_t P_lo = std::max(cut_lo, r0) - r0, P_hi = std::min(cut_hi, r1) - r0;
         piece_hi[r] = P_hi == len ? len : std::min<uint64_t>(len, P_hi + k - 1);
         if (P_lo > 0) {
+            piece_drop[r] = 2;  // the record began on an earlier shard (even when the halo reaches back to its first base)
             const uint64_t nk = len >= k ? len - k + 1 : 0, t_first = std::min(P_lo, nk);  // valid k-mers that start before P_lo
             if (t_first >= w) {
                 piece_lo[r] = t_first - w;
-                piece_drop[r] = 1;
+                piece_drop[r] = 3;
             }
         }
-        if (piece_hi[r] <= piece_lo[r]) piece_hi[r] = piece_lo[r] = 0;
+        if (piece_hi[r] <= piece_lo[r]) {
+            piece_hi[r] = piece_lo[r] = 0;
+            piece_drop[r] = 0;
+        }
     }
     return MXG_OK;
 }
@@ -325,8 +329,8 @@ int mxg_add_assembly_packed_device_pieces(mxg_handle *h, const char *name, doubl
                 a->ctg_rec.push_back((uint32_t)r);
                 a->ctg_nk.push_back(run.n_kmers);
                 a->ctg_run0.push_back((uint32_t)a->runs.size());
-                a->ctg_drop.push_back(piece_drop[r] ? 1 : 0);
-                a->any_drop = a->any_drop || piece_drop[r];
+                a->ctg_drop.push_back((piece_drop[r] & 1) ? 1 : 0);
+                a->any_drop = a->any_drop || (piece_drop[r] & 1);
                 a->runs.push_back(run);
                 a->total_kmers += run.n_kmers;
             }
@@ -341,7 +345,8 @@ int mxg_add_assembly_packed_device_pieces(mxg_handle *h, const char *name, doubl
         a->has_bases = true;
         a->shard_lo = std::min(lo_rec, hi_rec);
         a->shard_hi = hi_rec;
-        a->split_first_cont = hi_rec > lo_rec && piece_lo[lo_rec] > 0;
+        // (the FASTA split route's rule, host_io.cpp: pieces[lo].cont = the shard's range starts inside the record)
+        a->split_first_cont = hi_rec > lo_rec && (piece_lo[lo_rec] > 0 || (piece_drop[lo_rec] & 2));
     }
     return commit(h, a, rc);
 }

@@ -822,8 +822,9 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         rows2 = cap1 / PJ_IPB;
     }
     const bool two_level = P1 != 0 && P1 <= 4096 && (uint64_t)P1 * cap1 < (1ull << 32) && (uint64_t)P1 * P * (PJ_T + 1) < (1ull << 29);
+    // (k_pj_join's verdict word carries the index of the key's minimizer in assembly 0 above three flag bits: < 2^29)
     const bool pj = mode == GRAPH_FULL && !global_table && (P1 == 0 || two_level) && P <= PJ_MAX_P &&
-                    !(join_env && !strcmp(join_env, "global"));
+                    (uint64_t)n_of[0] < (1ull << 29) && !(join_env && !strcmp(join_env, "global"));
     const uint32_t pj_force_fail = getenv("MXG_PJ_FORCE_FAIL") && atoi(getenv("MXG_PJ_FORCE_FAIL")) ? 1u : 0u;
 
     if (!pj) MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * sizeof(Slot)));  // (the partitioned join keeps its N records here)

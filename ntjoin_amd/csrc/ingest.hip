@@ -194,28 +194,52 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
     MXG_HIP(h, hipSetDevice(h->device));
 
     // ---- (2) raw text -> HBM through pinned staging buffers, started first so that it overlaps the header scan ----
+    // A device allocation that fails here (the route keeps ~1 byte per base of text in HBM) is no error: the host parser
+    // takes the file instead (return 1; nothing has been committed to `a` that the caller's delete / new does not undo).
+    auto dev_fallback = [&](hipError_t e) {
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation;
+    };
     const uint64_t text_alloc = ((fsz + ING_TILE - 1) / ING_TILE + 1) * ING_TILE;
-    MXG_HIP(h, a->d_text.ensure(text_alloc));
+    {
+        const hipError_t e = a->d_text.ensure(text_alloc);
+        if (e != hipSuccess) return dev_fallback(e) ? 1 : set_err(h, MXG_EDEVICE, "device allocation failed: %s", hipGetErrorString(e));
+    }
     unsigned char *d_text = a->d_text.as<unsigned char>();
     constexpr uint64_t STAGE = 32ull << 20;
     constexpr int NB = 4;
-    unsigned char *stage[NB] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t sev[NB];
-    hipStream_t cs = nullptr;
-    MXG_HIP(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    // staging resources + the uploader thread: joined and released on every way out of this function (an exception thrown
+    // by the host-side section below must not unwind through a joinable std::thread)
+    struct Staging {
+        unsigned char *buf[NB] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t ev[NB] = {nullptr, nullptr, nullptr, nullptr};
+        hipStream_t cs = nullptr;
+        std::thread uploader;
+        void finish()
+        {
+            if (uploader.joinable()) uploader.join();
+        }
+        ~Staging()
+        {
+            finish();
+            for (int b = 0; b < NB; ++b) {
+                if (buf[b]) (void)hipHostFree(buf[b]);
+                if (ev[b]) (void)hipEventDestroy(ev[b]);
+            }
+            if (cs) (void)hipStreamDestroy(cs);
+        }
+    } sg;
+    unsigned char **stage = sg.buf;
+    hipEvent_t *sev = sg.ev;
+    MXG_HIP(h, hipStreamCreateWithFlags(&sg.cs, hipStreamNonBlocking));
+    hipStream_t cs = sg.cs;
     for (int b = 0; b < NB; ++b) {
-        MXG_HIP(h, hipHostMalloc((void **)&stage[b], STAGE));
+        const hipError_t e = hipHostMalloc((void **)&stage[b], STAGE);
+        if (e != hipSuccess) return dev_fallback(e) ? 1 : set_err(h, MXG_EDEVICE, "pinned allocation failed: %s", hipGetErrorString(e));
         MXG_HIP(h, hipEventCreateWithFlags(&sev[b], hipEventDisableTiming));
     }
-    auto free_stage = [&]() {
-        for (int b = 0; b < NB; ++b) {
-            if (stage[b]) (void)hipHostFree(stage[b]);
-            (void)hipEventDestroy(sev[b]);
-        }
-        (void)hipStreamDestroy(cs);
-    };
     hipError_t uerr = hipSuccess;
-    std::thread uploader([&]() {
+    sg.uploader = std::thread([&]() {
         (void)hipSetDevice(h->device);
         const uint32_t T = std::max(1u, n_threads - 1u);
         uint64_t c = 0;
@@ -223,10 +247,14 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
             const int b = (int)(c % NB);
             const uint64_t n = std::min(STAGE, fsz - off);
             if (c >= NB) uerr = hipEventSynchronize(sev[b]);
-            parallel_for(T, [&](uint32_t t) {
-                const uint64_t lo = n * t / T, hi = n * (t + 1) / T;
-                memcpy(stage[b] + lo, txt + off + lo, hi - lo);
-            });
+            try {
+                parallel_for(T, [&](uint32_t t) {
+                    const uint64_t lo = n * t / T, hi = n * (t + 1) / T;
+                    memcpy(stage[b] + lo, txt + off + lo, hi - lo);
+                });
+            } catch (const std::exception &) {  // (no thread to be had: copy alone)
+                memcpy(stage[b], txt + off, n);
+            }
             if (uerr == hipSuccess) uerr = hipMemcpyAsync(d_text + off, stage[b], n, hipMemcpyHostToDevice, cs);
             if (uerr == hipSuccess) uerr = hipEventRecord(sev[b], cs);
         }
@@ -261,11 +289,7 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
         for (auto &x : v)
             if (hdr.empty() || x.at > hdr.back().end) hdr.push_back(x);  // (a chunk border inside a header line)
     const size_t n_rec = hdr.size();
-    if (n_rec >= (1ull << 32)) {
-        uploader.join();
-        free_stage();
-        return set_err(h, MXG_ELIMIT, "too many records in '%s'", path);
-    }
+    if (n_rec >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "too many records in '%s'", path);
     // ---- work items: the tiles every record's sequence text overlaps ----
     std::vector<IngItem> items;
     std::vector<uint64_t> rec_item0(n_rec + 1);
@@ -283,33 +307,20 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
     }
     rec_item0[n_rec] = items.size();
     const size_t n_items = items.size();
-    if (n_items >= (1ull << 31)) {
-        uploader.join();
-        free_stage();
-        return set_err(h, MXG_ELIMIT, "'%s' is too large for one handle", path);
-    }
+    if (n_items >= (1ull << 31)) return set_err(h, MXG_ELIMIT, "'%s' is too large for one handle", path);
     hipStream_t st = h->stream;
     DevBuf &d_items = a->d_ing_items, &d_cnt = a->d_ing_cnt, &d_sub = a->d_ing_sub, &d_pbase = a->d_ing_pbase;
     int rc = MXG_OK;
-    auto fail = [&](int code) {
-        uploader.join();
-        free_stage();
-        return code;
-    };
     if (n_items) {
         hipError_t e;
         if ((e = d_items.ensure(n_items * sizeof(IngItem))) != hipSuccess || (e = d_cnt.ensure(n_items * 4)) != hipSuccess ||
             (e = d_sub.ensure(n_items * 32)) != hipSuccess || (e = d_pbase.ensure(n_items * 8)) != hipSuccess)
-            return fail(set_err(h, MXG_ENOMEM, "device allocation failed: %s", hipGetErrorString(e)));
+            return dev_fallback(e) ? 1 : set_err(h, MXG_EDEVICE, "device allocation failed: %s", hipGetErrorString(e));
         if ((e = hipMemcpyAsync(d_items.p, items.data(), n_items * sizeof(IngItem), hipMemcpyHostToDevice, st)) != hipSuccess)
-            return fail(set_err(h, MXG_EDEVICE, "upload failed: %s", hipGetErrorString(e)));
+            return set_err(h, MXG_EDEVICE, "upload failed: %s", hipGetErrorString(e));
     }
-    uploader.join();  // the text is in HBM
-    if (uerr != hipSuccess) {
-        free_stage();
-        return set_err(h, MXG_EDEVICE, "text upload failed: %s", hipGetErrorString(uerr));
-    }
-    free_stage();
+    sg.finish();  // the text is in HBM
+    if (uerr != hipSuccess) return set_err(h, MXG_EDEVICE, "text upload failed: %s", hipGetErrorString(uerr));
     std::vector<uint32_t> cnt(n_items);
     if (n_items) {
         hipLaunchKernelGGL(k_ing_count, dim3((uint32_t)n_items), dim3(256), 0, st, d_text, d_items.as<IngItem>(), d_cnt.as<uint32_t>(),
@@ -338,9 +349,14 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
     }
     const size_t pad = 256 + (k + 15) / 16 + 16;  // the hash kernel reads up to one strip + k bases past a run's end
     a->packed_words = cur / 16 + pad;
-    MXG_HIP(h, a->d_packed_own.ensure(a->packed_words * 4));
+    {
+        const hipError_t e = a->d_packed_own.ensure(a->packed_words * 4);
+        if (e != hipSuccess) return dev_fallback(e) ? 1 : set_err(h, MXG_EDEVICE, "device allocation failed: %s", hipGetErrorString(e));
+    }
     MXG_HIP(h, hipMemsetAsync(a->d_packed_own.p, 0, a->packed_words * 4, st));
-    constexpr uint32_t EV_CAP = 4u << 20;
+    // changes between valid and invalid bases inside the tiles; MXG_INGEST_EV_CAP: test knob
+    const char *ev_env = getenv("MXG_INGEST_EV_CAP");
+    const uint32_t EV_CAP = ev_env && *ev_env ? (uint32_t)std::max(1, atoi(ev_env)) : 4u << 20;
     std::vector<uint8_t> fv(n_items), lv(n_items);
     std::vector<IngEvent> events;
     if (n_items) {
@@ -360,8 +376,8 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
         MXG_HIP(h, hipMemcpyAsync(lv.data(), d_lv.p, n_items, hipMemcpyDeviceToHost, st));
         MXG_HIP(h, hipMemcpyAsync(&n_ev, d_evn.p, 4, hipMemcpyDeviceToHost, st));
         MXG_HIP(h, hipStreamSynchronize(st));
-        if (n_ev > EV_CAP)
-            return set_err(h, MXG_ELIMIT, "'%s': more than %u changes between valid and invalid bases; not a nucleotide FASTA?", path, EV_CAP);
+        // more changes than the buffer holds (drafts with scattered N / IUPAC codes): the host parser has no such limit
+        if (n_ev > EV_CAP) return 1;
         events.resize(n_ev);
         if (n_ev) {
             MXG_HIP(h, hipMemcpy(events.data(), d_ev.p, (size_t)n_ev * sizeof(IngEvent), hipMemcpyDeviceToHost));
@@ -731,8 +747,32 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
     const int ofd = fileno(f);
     fflush(f);
     constexpr uint64_t WIN = 64ull << 20;
-    char *pin[2] = {nullptr, nullptr};
-    hipEvent_t ev[2];
+    // the file, the pinned windows and their events are released on every way out; a file left incomplete is removed
+    struct Out {
+        FILE *f;
+        const char *path;
+        hipStream_t st;
+        char *pin[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool complete = false, closed = false;
+        bool close()
+        {
+            closed = true;
+            return f == stdout ? fflush(f) == 0 : fclose(f) == 0;
+        }
+        ~Out()
+        {
+            (void)hipStreamSynchronize(st);
+            for (int b = 0; b < 2; ++b) {
+                if (pin[b]) (void)hipHostFree(pin[b]);
+                if (ev[b]) (void)hipEventDestroy(ev[b]);
+            }
+            if (!closed) (void)close();
+            if (!complete && f != stdout) (void)remove(path);
+        }
+    } out{f, path, st};
+    char **pin = out.pin;
+    hipEvent_t *ev = out.ev;
     bool ok = true;
     for (int b = 0; b < 2; ++b) {
         MXG_HIP(h, d_out[b].ensure(WIN));
@@ -775,13 +815,10 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
         if (!ok) break;
     }
     (void)hipStreamSynchronize(st);
-    for (int b = 0; b < 2; ++b) {
-        (void)hipHostFree(pin[b]);
-        (void)hipEventDestroy(ev[b]);
-    }
-    if (f != stdout) ok = (fclose(f) == 0) && ok;
+    ok = out.close() && ok;
     if (rc != MXG_OK) return rc;
     if (!ok) return set_err(h, MXG_EIO, "write error on '%s'", path);
+    out.complete = true;
     return MXG_OK;
 }
 

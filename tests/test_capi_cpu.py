@@ -96,6 +96,54 @@ def test_shard_range_partitions_records():
                 assert max(loads) <= sum(loads) / world + max(int(x) for x in lens)
 
 
+def test_plan_split_pieces_and_continuation_bit():
+    """sub-record sharding plan (host only): the shards' own k-mer starts tile every record; piece_drop bit 0 = the piece opens with
+    a halo of w k-mers and withholds its first minimizer, bit 1 = the record began on an earlier shard -- also when the cut
+    falls inside the record's first w k-mers, where the halo reaches back to base 0 (the FASTA split route's `cont`)"""
+    import numpy as np
+    from ntjoin_amd import capi
+    L = capi.load()
+    k, w = 32, 100
+
+    def plan(lens, s, n):
+        ln = np.ascontiguousarray(lens, dtype=np.uint64)
+        lo, hi = np.zeros(len(ln), dtype=np.uint64), np.zeros(len(ln), dtype=np.uint64)
+        dr = np.zeros(len(ln), dtype=np.uint8)
+        assert L.mxg_plan_split(ln.ctypes.data, len(ln), s, n, k, w, lo.ctypes.data, hi.ctypes.data, dr.ctypes.data) == 0
+        return lo, hi, dr
+
+    # two shards of one record of 1000 bases + a short one: the cut (base 550) is far from both ends
+    lo, hi, dr = plan([1000, 100], 1, 2)
+    assert (int(lo[0]), int(hi[0]), int(dr[0])) == (550 - w, 1000, 3) and (int(lo[1]), int(hi[1]), int(dr[1])) == (0, 100, 0)
+    lo, hi, dr = plan([1000, 100], 0, 2)
+    assert (int(lo[0]), int(hi[0]), int(dr[0])) == (0, 550 + k - 1, 0) and int(hi[1]) == 0
+    # the cut 60 bases into the second record: fewer than w k-mers before it -> the piece starts at base 0, nothing withheld,
+    # but the record did begin on the shard before
+    lens = [940, 1060]
+    lo, hi, dr = plan(lens, 1, 2)
+    assert int(hi[0]) == 0 and (int(lo[1]), int(hi[1]), int(dr[1])) == (0, 1060, 2)
+    lo0, hi0, dr0 = plan(lens, 0, 2)
+    assert (int(lo0[1]), int(hi0[1]), int(dr0[1])) == (0, 60 + k - 1, 0)
+    # random plans: every base range is owned exactly once, bits consistent
+    rng = np.random.default_rng(3)
+    for _ in range(30):
+        lens = rng.integers(1, 5000, size=int(rng.integers(1, 40)))
+        n = int(rng.integers(1, 9))
+        total = int(lens.sum())
+        for s in range(n):
+            lo, hi, dr = plan(lens, s, n)
+            cut_lo = total * s // n
+            starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+            for r in range(len(lens)):
+                if hi[r] > lo[r]:
+                    began_before = starts[r] < cut_lo
+                    assert bool(dr[r] & 2) == bool(began_before)
+                    assert not (dr[r] & 1) or (dr[r] & 2)
+                    assert not lo[r] > 0 or (dr[r] & 1)  # a piece that does not start at base 0 opens with a halo
+                else:
+                    assert dr[r] == 0
+
+
 def test_ntjoin_constructor_needs_w_for_fasta():
     """sketching FASTA with the TSV route's placeholder w=1 would write a huge, wrong checkpoint TSV"""
     import argparse
