@@ -277,3 +277,100 @@ def test_configs1_variant_with_n_runs_100mbp(oracle):
                 assert sk["pos"][lo:hi].tolist() == [x[1] for x in want], (a, r)
         eng.build_graph()
         check_graph_against_numpy(eng, [2.0, 1.0])
+
+
+def _bench_workload(eng, name, mbp, w):
+    """the assemblies bench.py times for `--workload name`, born in HBM the same way (whole records, one GPU)"""
+    import bench
+    cfg, asms, _ = bench.workload_tables(name, mbp, w, seed=1)
+    for aname, weight, segs, n_words, sub, sub_seed in asms:
+        d = synth.fill_device(segs, n_words, cfg["seed"], sub_seed, sub)
+        eng.add_packed_device(aname, weight, d.data_ptr(), segs[:, 0], segs[:, 2], keepalive=d)
+    return cfg, asms
+
+
+def _density_ok(sk, segs, w, tol=0.02):
+    lens = segs[:, 2].astype(np.int64)
+    elig = lens[lens - K + 1 >= w].sum()
+    return abs(len(sk["pos"]) / float(elig) - 2.0 / (w + 1)) < tol * 2.0 / (w + 1)
+
+
+def test_configs3_full_size_target_and_three_references_w500():
+    """BASELINE configs[3] at full size on one GPU (`bench.py --workload configs3`): a 3 Gbp target + three 3 Gbp references
+    of 0.5 / 1 / 2 % divergence, w = 500, weights 2/2/2/1 -- 12 Gbp and 48 M minimizers per step.  Graph stage against the
+    numpy checker (four assemblies: support masks and summed weights), sketches against the oracle on excerpts of every
+    reference (each has its own substitution stream) and on whole target contigs, plus the size-independent properties."""
+    orc = _oracle.load()
+    w = 500
+    with MxEngine(k=K, w=w) as eng:
+        cfg, asms = _bench_workload(eng, "configs3", 3000.0, w)
+        eng.sketch(-2)
+        eng.build_graph()
+        st = eng.stats()
+        assert st["bases"] > 11_900_000_000 and st["minimizers"] > 47_000_000
+        assert st["bs_filter_bases"] == st["bases"]  # the k = 32 route took every assembly
+        weights = [a[1] for a in asms]
+        assert weights == [2.0, 2.0, 2.0, 1.0]
+        sks, g = check_graph_against_numpy(eng, weights)
+        assert len(g["vertex_hash"]) > 1_500_000
+        assert set(np.unique(g["edge_weight"]).tolist()) <= {1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0}
+        for sk, a in zip(sks, asms):
+            sketch_properties(sk, a[2][:, 2], w)
+            assert _density_ok(sk, a[2], w)
+        for ai in range(3):  # the references: same records, different substitutions
+            _, _, segs, _, sub, sub_seed = asms[ai]
+            for r, lo in ((0, 0), (11, 20_000_000), (23, int(segs[23][2]) - 200_000)):
+                excerpt_check(orc, sks[ai], segs[r], r, cfg["seed"], sub_seed, sub, w, lo, 200_000)
+        _, _, tsegs, _, tsub, tsub_seed = asms[3]
+        order = np.argsort(tsegs[:, 2])
+        for r in list(order[:2]) + list(order[len(order) // 2: len(order) // 2 + 2]) + [0, len(tsegs) - 1]:
+            whole_record_check(orc, sks[3], tsegs[r], int(r), cfg["seed"], tsub_seed, tsub, w)
+
+
+def test_configs4_full_size_40gbp_on_one_gpu():
+    """BASELINE configs[4] at full size on ONE GPU (`bench.py --workload configs4`): a 20 Gbp reference of 12 records of
+    ~1.67 Gbp + a ~20 Gbp target of > 5 x 10^5 contigs of 1-200 kbp, w = 1000: 4 x 10^10 k-mers per step (beyond 2^32 per
+    job, beyond 2^32 per assembly), 79 M minimizers, ~30 M vertices.  Graph stage against the numpy checker; sketches against the
+    oracle on excerpts around the 2^32-nd base of the assembly and of the packed layout, whole target contigs (the shortest
+    that hold a window, the longest, both strands), known-answer hashes, size-independent properties."""
+    orc = _oracle.load()
+    w = 1000
+    with MxEngine(k=K, w=w) as eng:
+        cfg, asms = _bench_workload(eng, "configs4", 20000.0, w)
+        eng.sketch(-2)
+        eng.build_graph()
+        st = eng.stats()
+        assert st["bases"] > 39_000_000_000 and st["kmers"] > (1 << 32) * 9
+        assert st["bs_filter_bases"] == st["bases"]
+        assert st["minimizers"] > 78_000_000
+        sks, g = check_graph_against_numpy(eng, [a[1] for a in asms])
+        assert len(g["vertex_hash"]) > 25_000_000 and len(g["edge_u"]) > 25_000_000
+        for sk, a in zip(sks, asms):
+            sketch_properties(sk, a[2][:, 2], w)
+            assert _density_ok(sk, a[2], w)
+        _, _, rsegs, _, rsub, rsub_seed = asms[0]
+        assert len(rsegs) == 12 and int(rsegs[:, 2].min()) > 500_000_000 and int(rsegs[:, 2].max()) > 2_500_000_000
+        # record 2 holds the assembly's 2^32-nd base; the last record ends near base 2 x 10^10
+        cum = np.cumsum(rsegs[:, 2].astype(np.int64))
+        r32 = int(np.searchsorted(cum, 1 << 32))
+        lo32 = int((1 << 32) - (cum[r32 - 1] if r32 else 0)) - 150_000
+        for r, lo in ((0, 0), (r32, max(lo32, 0)), (7, 1_000_000_000), (11, int(rsegs[11][2]) - 300_000)):
+            excerpt_check(orc, sks[0], rsegs[r], r, cfg["seed"], rsub_seed, rsub, w, lo, 300_000)
+        _, _, tsegs, _, tsub, tsub_seed = asms[1]
+        tl = tsegs[:, 2].astype(np.int64)
+        order = np.argsort(tl)
+        n_short = int((tl < K + w - 1).sum())
+        pick = list(order[max(n_short - 2, 0): n_short + 3]) + list(order[-2:]) + [0, len(tsegs) - 1] + \
+            list(np.random.default_rng(4).integers(0, len(tsegs), 6))
+        assert {int(tsegs[i][3]) for i in pick} == {0, 1}
+        for r in pick:
+            whole_record_check(orc, sks[1], tsegs[r], int(r), cfg["seed"], tsub_seed, tsub, w)
+        rng = np.random.default_rng(6)
+        for sk, segs, sub, sub_seed in ((sks[0], rsegs, rsub, rsub_seed), (sks[1], tsegs, tsub, tsub_seed)):
+            for i in rng.integers(0, len(sk["pos"]), size=100):
+                r, p = int(sk["record"][i]), int(sk["pos"][i])
+                seg = segs[r]
+                src = int(seg[1]) + (int(seg[2]) - p - K if seg[3] else p)
+                kmer = synth.segment_codes((0, src, K, int(seg[3])), cfg["seed"], sub_seed, sub)
+                _, oh, fw, ok = orc.kmer_hashes(synth.to_ascii(kmer), K)
+                assert ok[0] and int(oh[0]) == int(sk["out_hash"][i]) and int(fw[0]) == int(sk["forward"][i])
