@@ -14,6 +14,10 @@ Workloads (BASELINE.json configs; `auto` = the config the metric names for this 
                    derived from it (cut, half reverse-complemented, 0.5 % substitutions, 20-500 bp dropped, shuffled;
                    weight 1), k=32 w=1000                                    [--workload configs1 / --mbp M: 1 x M Mbp + target]
   N>1  see main(): contig-sharded over the ranks, one RCCL exchange per step (ntjoin_amd/dist.py)
+  --workload repeats [--mbp M]: what random genomes lack -- repeat families, satellite arrays, low-complexity runs, N gaps
+                   (synth.repeat_rich_records; ASCII route, so N is really there) + a target derived from it: prices the
+                   fallbacks (`fallbacks` block: k-mers re-sketched densely, batches redone, assemblies redone whole); compare
+                   with `--workload configs2 --mbp M`, the same sizes of i.i.d. sequence
 
 Beside the contract's fields the JSON line carries
   roofline      the kernel that reads every base (k_hash_bs, the bit-sliced ring filter; one launch per assembly) against the
@@ -250,7 +254,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="auto", choices=["auto", "configs1", "configs2", "configs3", "configs4"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "configs1", "configs2", "configs3", "configs4", "repeats"])
     ap.add_argument("--mbp", type=float, default=0.0, help="reference size in Mbp (default: 100 for configs1, 3000 for configs2)")
     ap.add_argument("--w", type=int, default=0, help="window size (default: 500 for configs3, else 1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -295,8 +299,22 @@ def main():
     if wl == "auto":  # the configuration BASELINE.json's metric names for this GPU count
         wl = {1: "configs2", 2: "configs2", 4: "configs3", 8: "configs4"}.get(world, "configs2")
     W = args.w or (500 if wl == "configs3" else 1000)
-    mbp = args.mbp or {"configs1": 100.0, "configs2": 3000.0, "configs3": 3000.0, "configs4": 20000.0}[wl]
-    cfg, asms, label = workload_tables(wl, mbp, W, seed=1)  # the same genome on every rank: each takes its share of it
+    mbp = args.mbp or {"configs1": 100.0, "configs2": 3000.0, "configs3": 3000.0, "configs4": 20000.0, "repeats": 1000.0}[wl]
+    repeats = wl == "repeats"
+    if repeats:
+        if multi:
+            sys.exit("bench.py: --workload repeats is a one-GPU workload")
+        args.no_kernels = args.no_cpu_baseline = args.no_end_to_end = True
+        n_rec = 24
+        ref_recs = synth.repeat_rich_records(1, n_rec, int(mbp * 1e6) // n_rec)
+        tgt_recs = synth.derive_target_with_n(ref_recs, 2, min_len=3000, max_len=600_000)
+        label = (f"repeat-rich synthetic {mbp / 1000:g} Gbp reference ({n_rec} records: 30 % repeat-family copies, 8 % satellite arrays, "
+                 f"5 % low-complexity runs, 2 % N gaps) + derived target of {len(tgt_recs)} contigs, k=32 w={W}, weights 2/1, ASCII route")
+        as_segs = lambda recs: np.array([[0, 0, len(r), 0] for r in recs], dtype=np.uint64)  # noqa: E731  (lengths only)
+        cfg = {"seed": 1}
+        asms = [(f"ref.fa.k{K}.w{W}.tsv", 2.0, as_segs(ref_recs), 0, 0, 0), (f"tgt.fa.k{K}.w{W}.tsv", 1.0, as_segs(tgt_recs), 0, 0, 0)]
+    else:
+        cfg, asms, label = workload_tables(wl, mbp, W, seed=1)  # the same genome on every rank: each takes its share of it
     keep, host_layout = [], []
     # N > 1: the library works on the stream the collectives are issued on, so pack -> all-gather -> unpack need no host sync
     xstream = torch.cuda.Stream() if multi else None
@@ -307,7 +325,11 @@ def main():
     bases_job = sum(int(a[2][:, 2].sum()) for a in asms)
     m_rank = 2e-6 * bases_job / (W + 1) / world  # minimizers per rank, millions (density 2/(w+1))
     graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("partitioned" if m_rank * (0.14 * world - 0.2) > 0.39 else "union")
-    for name, weight, segs, n_words, sub, sub_seed in asms:
+    if repeats:
+        for (name, weight, *_), recs in zip(asms, (ref_recs, tgt_recs)):
+            eng.add_records(name, weight, [(f"r{i}", synth.to_ascii5(c)) for i, c in enumerate(recs)])
+        del ref_recs, tgt_recs
+    for name, weight, segs, n_words, sub, sub_seed in ([] if repeats else asms):
         d, rec_start, rec_len = add_rank_share(eng, name, weight, segs, cfg["seed"], sub_seed, sub, rank if world > 1 else 0, world,
                                                local_rank, split=os.environ.get("MXG_BENCH_WHOLE_RECORDS") != "1")  # bases born in HBM
         keep.append(d)
@@ -337,8 +359,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    cold = None
+    for i in range(args.warmup):
+        if i == 0 and not multi:  # the first pass of a fresh handle (what a one-shot CLI run pays): no candidate counts yet
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            cs = eng.stats()
+            cold = {"ms": round((time.perf_counter() - tc) * 1e3, 3), "batches_redone": int(cs["batches_redone"]),
+                    "assemblies_redone_whole": int(cs["sync_assemblies"]), "dense_kmers": int(cs["dense_kmers"]),
+                    "assemblies_enqueued_twice": int(cs["retried_assemblies"]), "stretches_sketched_apart": int(cs["deferred_stretches"])}
+        else:
+            step()
     eng.reset_timers()
     fence()
     t0 = time.perf_counter()
@@ -425,6 +458,15 @@ def main():
                               "frac": round(step_gbs / HBM_PEAK_GBS, 6)},
             "stage_ms_per_step": {"filter": round(st["ms_hash"] * t_scale / args.steps, 4),
                                   "graph": round(gst["ms_graph"] / args.steps, 4)},
+            # what the common route (every batch enqueued once, one host sync per step) could not finish, per step
+            "fallbacks": {"dense_kmers_per_step": int(st["dense_kmers"] / max(args.steps, 1)),
+                          "batches_redone_per_step": round(st["batches_redone"] / max(args.steps, 1), 3),
+                          "assemblies_redone_whole_per_step": round(st["sync_assemblies"] / max(args.steps, 1), 3),
+                          "assemblies_enqueued_twice_per_step": round(st["retried_assemblies"] / max(args.steps, 1), 3),
+                          "stretches_sketched_apart_per_step": round(st["deferred_stretches"] / max(args.steps, 1), 1),
+                          "candidates_per_step": int(st["candidates"] / max(args.steps, 1)),
+                          "first_step_of_the_handle": cold,
+                          "note": "counted over the timed steps (warm: the candidate counts of the warm-up steps size the grids)"},
         }
         if not multi and not args.no_kernels:
             # per-kernel GPU time: a second handle on the same bases with one event pair per kernel (a few steps)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MXG_ABI_VERSION 1
+#define MXG_ABI_VERSION 2
 
 /* error codes */
 #define MXG_OK 0
@@ -133,6 +133,12 @@ typedef struct mxg_stats {
     double ms_edges;           /* edge flags + edge compaction                                   */
     uint64_t bs_filter_bases;  /* bases covered by the bit-sliced filter (k = 32 route; 0: the rolling-hash kernel ran) */
     double reserved[1];
+    /* what the common route (every batch enqueued once, one host sync) could not finish: candidate floods beyond the estimate,
+       stretches the device route cannot hold, output beyond its bound.  Such batches are redone one by one behind the good ones */
+    uint64_t batches_redone;   /* batches redone through the synchronous route                               */
+    uint64_t sync_assemblies;  /* assemblies none of whose batches could be kept                             */
+    uint64_t retried_assemblies; /* assemblies whose batches went through the streams a second time, re-sized    */
+    uint64_t deferred_stretches; /* candidate-free stretches sketched apart and merged in (satellites, low complexity) */
 } mxg_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */

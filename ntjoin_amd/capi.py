@@ -9,7 +9,7 @@ MXG_OK, MXG_EINVAL, MXG_EIO, MXG_ENOMEM, MXG_EDEVICE, MXG_ELIMIT = 0, -1, -2, -3
 VARIANT_V2_SUM, VARIANT_V1_MIN = 0, 1
 FLAG_DENSE_ONLY, FLAG_DROP_SEQ, FLAG_TIMING, FLAG_TIMING_FINE = 0x1, 0x2, 0x4, 0x8
 MX_UNIQUE, MX_SHARED, MX_INALL = 0x1, 0x2, 0x4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 SYMBOLS = [
     "mxg_abi_version", "mxg_create", "mxg_destroy", "mxg_last_error",
@@ -74,7 +74,8 @@ class Stats(C.Structure):
                 ("ms_graph", C.c_double), ("launches_hash", C.c_uint64), ("hash_kernel_bases", C.c_uint64),
                 ("ms_reorder", C.c_double), ("ms_resolve_kernel", C.c_double), ("ms_emit", C.c_double),
                 ("ms_join", C.c_double), ("ms_vertices", C.c_double), ("ms_edges", C.c_double),
-                ("bs_filter_bases", C.c_uint64), ("reserved", C.c_double * 1)]
+                ("bs_filter_bases", C.c_uint64), ("reserved", C.c_double * 1),
+                ("batches_redone", C.c_uint64), ("sync_assemblies", C.c_uint64), ("retried_assemblies", C.c_uint64), ("deferred_stretches", C.c_uint64)]
 
 
 _lib = None

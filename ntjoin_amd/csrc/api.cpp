@@ -106,6 +106,7 @@ void mxg_destroy(mxg_handle *h)
     for (hipEvent_t e : h->ev_g)
         if (e) (void)hipEventDestroy(e);
     if (h->pinned_ctrl) (void)hipHostFree(h->pinned_ctrl);
+    if (h->pinned_defer) (void)hipHostFree(h->pinned_defer);
     if (h->pinned_gctl) (void)hipHostFree(h->pinned_gctl);
     if (h->pinned_dg) (void)hipHostFree(h->pinned_dg);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -136,6 +137,7 @@ static int commit(mxg_handle *h, Assembly *a, int rc)
     }
     h->asms.push_back(a);
     h->graph.valid = false;
+    h->pj_overflowed = false;
     return (int)h->asms.size() - 1;
 }
 
@@ -944,6 +946,10 @@ int mxg_get_stats(mxg_handle *h, mxg_stats *out)
     if (flush_timers(h) != MXG_OK) return MXG_EDEVICE;
     s.candidates = h->stat_candidates;
     s.bs_filter_bases = h->stat_bs_bases;
+    s.batches_redone = h->stat_batches_redone;
+    s.sync_assemblies = h->stat_sync_assemblies;
+    s.deferred_stretches = h->stat_deferred;
+    s.retried_assemblies = h->stat_retries;
     s.dense_kmers = h->stat_dense_kmers;
     s.unique = h->graph.valid ? h->stat_unique : 0;
     s.vertices = h->graph.valid ? h->graph.nv : 0;
@@ -970,6 +976,7 @@ int mxg_reset_timers(mxg_handle *h)
     if (rc != MXG_OK) return rc;
     h->tm = Timers();
     h->stat_candidates = h->stat_dense_kmers = h->stat_bs_bases = 0;
+    h->stat_batches_redone = h->stat_sync_assemblies = h->stat_deferred = h->stat_retries = 0;
     return MXG_OK;
 }
 

@@ -78,12 +78,32 @@ __global__ __launch_bounds__(256) void k_insert(const AsmSet p, Slot *tab, uint3
         for (uint32_t i = threadIdx.x; i < n_sup; i += 256) sup[i] = 0;
     const uint32_t a = asm_of_block(p, blockIdx.x);
     const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
-    if (i >= asm_n(p, a)) return;
+    const bool live = i < asm_n(p, a);
     const uint32_t bit = 1u << a;
-    uint32_t s = ht_slot(tab, mask, cap, p.hash[a][i]);
-    uint32_t old = atomicAnd(&tab[s].nseen, ~bit);
-    if (!(old & bit)) atomicAnd(&tab[s].ndup, ~bit);  // bit already cleared: second occurrence in this assembly
-    p.slot[a][i] = s;
+    // A key of huge multiplicity (a satellite's minimizer: 10^5-10^6 occurrences) would queue that many atomics on one slot
+    // (49 ms for a repeat-rich Gbp).  Two remedies: the bits only ever get cleared, so a (possibly stale) read that shows both
+    // cleared proves there is nothing left to record; and runs of equal keys in neighbouring lanes (a satellite array: the same
+    // minimizer every 171 bases, for kilobases) are served by the run's first lane -- one probe, and a run of two or more IS
+    // "twice in this assembly".
+    const uint64_t key = live ? p.hash[a][i] : 0ull;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(key >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)key, 1, 64);
+    const bool prev_live = __shfl_up((int)live, 1, 64) != 0;
+    const bool start = lane == 0 || !live || !prev_live || key != prev;
+    const uint64_t starts = __ballot(start);
+    const uint32_t leader = 63u - (uint32_t)__builtin_clzll(starts & (lane == 63u ? ~0ull : ((2ull << lane) - 1ull)));
+    const bool followed = lane < 63u && !((starts >> (lane + 1u)) & 1ull);  // (the lane behind belongs to this run)
+    uint32_t s = 0;
+    if (live && start) {
+        s = ht_slot(tab, mask, cap, key);
+        const uint32_t ns = __atomic_load_n(&tab[s].nseen, __ATOMIC_RELAXED), nd = __atomic_load_n(&tab[s].ndup, __ATOMIC_RELAXED);
+        if ((ns & bit) || (nd & bit)) {
+            const uint32_t old = atomicAnd(&tab[s].nseen, ~bit);
+            if (!(old & bit) || followed) atomicAnd(&tab[s].ndup, ~bit);  // second occurrence in this assembly
+        }
+    }
+    s = (uint32_t)__shfl((int)s, (int)leader, 64);
+    if (live) p.slot[a][i] = s;
 }
 
 // flags of every minimizer + number of shared ones per block of 256 (cnt[b], super-counts per assembly at
@@ -294,8 +314,7 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
                 return seg_rec[l] + (q - seg_off[l]);
             };
             uint32_t last_a = 0, last_i = 0;  // assembly / item of the record insert() looked at last
-            auto insert = [&](uint32_t r) {   // pass 0; also the lookup of pass 1
-                const uint4 rec = recs[r];
+            auto insert_rec = [&](const uint4 rec) {   // pass 0; also the lookup of pass 1
                 last_a = rec.w;
                 last_i = rec.z;
                 const uint32_t s = pj_slot(keys, ((uint64_t)rec.y << 32) | rec.x);
@@ -303,14 +322,20 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
                     const uint32_t bit = 1u << rec.w;
                     if (s > PJ_T) failed = 1;
                     else {
-                        if (atomicOr(&seen[s], bit) & bit) {  // second occurrence in this assembly
-                            if (NARROW) atomicOr(&seen[s], bit << 16); else atomicOr(&dup[s], bit);
+                        // (a key of huge multiplicity -- a satellite's minimizer -- brings tens of thousands of records to one
+                        // slot: once its state says "seen twice here" there is nothing left to record, and no atomic to queue for)
+                        const uint32_t cur = seen[s], dcur = NARROW ? cur >> 16 : dup[s];
+                        if (!((cur & bit) && (dcur & bit))) {
+                            if (atomicOr(&seen[s], bit) & bit) {  // second occurrence in this assembly
+                                if (NARROW) atomicOr(&seen[s], bit << 16); else atomicOr(&dup[s], bit);
+                            }
+                            if (rec.w == 0) item0[s] = rec.z;  // (a key that occurs twice in assembly 0 is not shared: never read)
                         }
-                        if (rec.w == 0) item0[s] = rec.z;  // (a key that occurs twice in assembly 0 is not shared: never read)
                     }
                 }
                 return s;
             };
+            auto insert = [&](uint32_t r) { return insert_rec(recs[r]); };
             // the verdict of a record, 4 bytes: (shared: the key's minimizer in assembly 0) << 3 | MXG_MX_* flags, sent straight
             // to the minimizer it stands for (slot[a][i]: the ONE random access per minimizer of the whole join; k_flags_pj
             // then reads the verdicts in order)
@@ -340,12 +365,22 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
                     finish(last_i, s, last_a);
                 }
             }
-            for (uint32_t q = threadIdx.x + QC * 256u; q < total; q += 256) {
-                const uint32_t r = locate(q);
-                if (pass == 0) insert(r);
-                else {
-                    const uint32_t s = insert(r);
-                    finish(last_i, s, last_a);
+            // beyond QC records per thread (a partition that holds a key of huge multiplicity: hundreds of thousands of records
+            // for this one block): eight records per thread are requested before the first is looked at -- one record per
+            // iteration made the block wait a memory round trip 1 000 times over (5.7 ms on a repeat-rich 0.3 Gbp genome)
+            constexpr uint32_t TU = 8;
+            for (uint32_t q0 = threadIdx.x + QC * 256u; q0 < total; q0 += 256u * TU) {
+                uint4 rv[TU];
+#pragma unroll
+                for (uint32_t u = 0; u < TU; ++u) {
+                    const uint32_t q = q0 + u * 256u;
+                    rv[u] = q < total ? recs[locate(q)] : make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < TU; ++u) {
+                    if (q0 + u * 256u >= total) break;
+                    const uint32_t s = insert_rec(rv[u]);
+                    if (pass == 1) finish(last_i, s, last_a);
                 }
             }
             __syncthreads();
@@ -767,8 +802,13 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
 
 int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, const GraphBounds *gb)
 {
-    int rc = build_graph_impl(h, mode, d_msgs, n_msgs, gb, false);
-    if (rc == RC_RETRY_GLOBAL) rc = build_graph_impl(h, mode, d_msgs, n_msgs, gb, true);
+    // (a handle whose minimizers once overflowed a partition -- a key of huge multiplicity: satellite arrays -- goes straight to
+    // the global table afterwards: the same assemblies would overflow again)
+    int rc = build_graph_impl(h, mode, d_msgs, n_msgs, gb, h->pj_overflowed);
+    if (rc == RC_RETRY_GLOBAL) {
+        h->pj_overflowed = true;
+        rc = build_graph_impl(h, mode, d_msgs, n_msgs, gb, true);
+    }
     return rc;
 }
 

@@ -102,6 +102,8 @@ struct Assembly {
     bool tables_ready = false;
     uint32_t S_sparse = 256;  // strip length chosen for the sparse hash kernel
     uint32_t cand_hint = 0;   // candidates of the last sparse run (k_resolve: which blocks may load before the count arrives)
+    bool full_grid_once = false;       // the next enqueue sizes every grid for the candidate capacity, not the estimate
+    double gap_rate_hint = 0;          // candidate-free stretches per k-mer met by earlier sketches (sizes the batches)
     std::vector<uint32_t> cand_hints;  // ... per batch of the pipelined multi-batch driver
     std::vector<uint32_t> strip0_dense, strip0_sparse;  // [n_runs+1] exclusive prefix of strips per run
     std::vector<uint64_t> g0;                           // [n_runs+1] exclusive prefix of k-mers per run
@@ -205,6 +207,10 @@ struct mxg_handle {
     mxg::DevBuf d_init_tab;  // byte table of the direct hash formula (256 x 16 B), built by the first sketch
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
     uint64_t stat_bs_bases = 0;  // bases the bit-sliced filter (k = 32 route) has covered
+    bool pj_overflowed = false;  // graph stage: the partitioned join overflowed once (build_graph then starts with the global table)
+    uint64_t stat_retries = 0;   // assemblies enqueued a second time (their batches did not all end the common way)
+    uint64_t stat_deferred = 0;  // candidate-free stretches the device route handed to the host
+    uint64_t stat_batches_redone = 0, stat_sync_assemblies = 0;  // batches that did not end the common way / assemblies redone whole
     // scratch reused across calls
     mxg::DevBuf scratch[4][40];  // indexed by mxg::Scratch (sketch.hip): one set per in-flight sketch driver (= stream)
     std::vector<mxg::Assembly *> pend_list;  // mxg_sketch_pack in flight: assemblies and how each was enqueued
@@ -219,6 +225,7 @@ struct mxg_handle {
     uint64_t *pinned_dg = nullptr;    // dgraph.hip: pinned copy of the per-destination counters
     uint64_t *pinned_gctl = nullptr;  // pinned host copy of the graph stage's control block
     uint32_t *pinned_ctrl = nullptr;  // pinned host copies of per-assembly control blocks (pipelined sketch)
+    void *pinned_defer = nullptr;     // per control block: the stretches its batch left to the host (sketch.hip defer_stretch)
 };
 
 namespace mxg {

@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
                     p.host_ctrl[w] = w == 1 ? n_g_raw : w == 2 ? all : w == 3 ? flag : w == 4 ? n_report : w == 5 ? nB
                                    : w == 6 ? (uint32_t)total : w == 7 ? (uint32_t)(total >> 32)
                                    : w == 8 ? (uint32_t)obase : w == 9 ? (uint32_t)(obase >> 32)
-                                   : (w == 10 && p.dev_gaps) ? p.ovf[10] : 0u;
+                                   : (w == 10 && p.dev_gaps) ? p.ovf[10] : (w == 11 && p.dev_gaps && !flag) ? p.ovf[11] : 0u;
                 }
             }
         }
@@ -1337,8 +1337,8 @@ __global__ __launch_bounds__(256) void k_merge(const MergeParams p)
 //   k_emit       (runs after them) writes the batch's own minimizers straight to their final places, shifted by the
 //                stretch minimizers before each; a few extra blocks put the stretches' minimizers in between; reports
 // Anything this route cannot hold -- more than GAP_DEV_MAX stretches, a stretch longer than GAP_DEV_NMAX k-mers or cut by
-// invalid bases, more than GAP_DEV_REG minimizers in one stretch (low-complexity sequence) -- raises ctrl[6] and the host
-// redoes the batch the general way.
+// invalid bases, more than GAP_DEV_REG minimizers in one stretch (low-complexity sequence) -- is left out here: more than
+// GAP_DEV_MAX stretches raise ctrl[6] and the host redoes the batch; single stretches are handed to the host (defer_stretch).
 constexpr uint32_t GAP_DEV_NMAX = 4096;
 
 struct GapFixParams {
@@ -1355,8 +1355,19 @@ struct GapFixParams {
     uint32_t *r_pos, *r_rec;
     uint32_t *r_cnt;     // [GAP_DEV_MAX]
     uint64_t *r_key;     // [GAP_DEV_MAX] contig << 32 | k_lo
+    uint4 *defer;        // [GAP_DEV_MAX] (pinned host memory) stretches left to the host: ctrl[11] of them
     HashTab tab;
 };
+
+// A stretch this route cannot hold (longer than GAP_DEV_NMAX k-mers, cut by invalid bases, more than GAP_DEV_REG minimizers:
+// satellite arrays, low-complexity runs) contributes nothing here; the host sketches it afterwards through the dense pipeline
+// and merges its minimizers into the assembly's sketch (Driver::merge_deferred).  One thread of the block calls this.
+__device__ __forceinline__ void defer_stretch(const GapFixParams &p, const uint4 gp)
+{
+    const uint32_t at = atomicAdd(&p.ctrl[11], 1u);
+    if (at < GAP_DEV_MAX) p.defer[at] = gp;
+    else p.ctrl[6] = 1;
+}
 
 // One stretch by one block of 256 threads.  The work arrays are the caller's: LDS for the common stretches (k_gap_fix, at
 // most GAP_DEV_NSMALL k-mers: 23 KB per block, which fits beside the other stream's hash kernel -- blocks of 56 KB, nearly
@@ -1383,7 +1394,7 @@ __device__ __forceinline__ void gap_fix_one(const GapFixParams &p, const uint32_
     }
     const Run run = p.runs[lo];
     if (n > nmax || n < w || khi >= run.kidx0 + run.n_kmers) {
-        if (threadIdx.x == 0) p.ctrl[6] = 1;
+        if (threadIdx.x == 0) defer_stretch(p, gp);
         return;
     }
     for (uint32_t i = threadIdx.x; i < nmax / 32; i += 256) selbits[i] = 0;
@@ -1444,7 +1455,7 @@ __device__ __forceinline__ void gap_fix_one(const GapFixParams &p, const uint32_
     const uint32_t total = sh[255];
     if (threadIdx.x == 0) atomicAdd(&p.ctrl[10], n);
     if (total > GAP_DEV_REG) {
-        if (threadIdx.x == 0) p.ctrl[6] = 1;
+        if (threadIdx.x == 0) defer_stretch(p, gp);
         return;
     }
     if (threadIdx.x == 0) p.r_cnt[j] = total;
@@ -1486,7 +1497,7 @@ struct GapPostParams {
     uint32_t *big_work;  // with these GAP_BIG_WORK_WORDS words of global memory in place of k_gap_fix's LDS arrays
 };
 constexpr uint32_t GAP_BIG_WORK_WORDS = GAP_DEV_NMAX * 2 + GAP_DEV_NMAX + GAP_DEV_NMAX / 32 + (GAP_DEV_NMAX / 16 + 1024 / 16 + 4);
-constexpr uint32_t GAP_BIG_LIST = 64;  // long stretches per batch (more: the host redoes the batch)
+constexpr uint32_t GAP_BIG_LIST = 4;   // long stretches per batch walked by k_gap_post, ~30 us each (more: all left to the host)
 
 // (256 threads: a single block of 1024 had to wait for sixteen free wave slots on one CU while the other stream's hash kernel
 // held them all -- 23 us per launch under rocprofv3 for a microsecond of work)
@@ -1512,14 +1523,29 @@ __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < n_g; j += GPB) {
         const uint4 g = p.fx.gaps[j];
+        if (g.z - g.y + 1u > GAP_DEV_NSMALL && g.z - g.y + 1u <= GAP_DEV_NMAX) atomicAdd(&n_big, 1u);
+    }
+    __syncthreads();
+    // up to GAP_BIG_LIST long stretches are walked here (random sequence: about one batch in two has one); a batch with more
+    // of them is repeat-rich sequence, whose long stretches all go to the host's tile kernel
+    const bool walk = n_big <= GAP_BIG_LIST;
+    __syncthreads();
+    if (threadIdx.x == 0) n_big = 0;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < n_g; j += GPB) {
+        const uint4 g = p.fx.gaps[j];
         if (g.z - g.y + 1u > GAP_DEV_NSMALL) {
-            const uint32_t at = atomicAdd(&n_big, 1u);
-            if (at < GAP_BIG_LIST) big_list[at] = j;
+            if (walk && g.z - g.y + 1u <= GAP_DEV_NMAX) {
+                big_list[atomicAdd(&n_big, 1u)] = j;
+            } else {
+                p.fx.r_key[j] = ((uint64_t)g.x << 32) | g.y;
+                p.fx.r_cnt[j] = 0;
+                defer_stretch(p.fx, g);
+            }
         }
     }
     __syncthreads();
     const uint32_t nb = n_big;
-    if (nb > GAP_BIG_LIST && threadIdx.x == 0) p.ctrl[6] = 1;
     for (uint32_t q = 0; q < min(nb, GAP_BIG_LIST); ++q) {
         uint64_t *lh = reinterpret_cast<uint64_t *>(p.big_work);
         uint16_t *lidx0 = reinterpret_cast<uint16_t *>(p.big_work + GAP_DEV_NMAX * 2), *lidx1 = lidx0 + GAP_DEV_NMAX;
@@ -1584,10 +1610,151 @@ __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// stretches of any length, any number of minimizers: tiles
+// ------------------------------------------------------------------------------------------------------
+// What k_gap_fix leaves to the host (defer_stretch) is the repeat structure of real genomes: satellite arrays (tens of
+// thousands of k-mers none of which is a candidate), homopolymer / dinucleotide runs (every k-mer hashes alike, so every window
+// reports its LAST k-mer: hundreds of minimizers in a row), stretches that span N gaps.  The dense pipeline would take them,
+// but its window decision scans up to w neighbours per k-mer when hashes tie -- 30 ms for the 2 x 10^7 such k-mers of a
+// repeat-rich Gbp.  Here a stretch is cut into tiles of ST_WIN window starts; a block hashes the tile's k-mers (+ w - 1
+// behind them, + 1 in front) into LDS and takes every window's rightmost arg-min from a doubling table, O(log w) per window
+// whatever the hashes.  The arg-min moves right monotonically with the window, so the only minimizer a tile can share with the
+// tile before it is the arg-min of the window just in front: the tile computes that one too and leaves it out.
+// Two passes over the same tiles: counts, then (offsets known) the minimizers themselves, in (contig, position) order.
+constexpr uint32_t ST_WIN = 1024;                       // window starts per tile (49 KB of LDS per block at ST_WMAX)
+constexpr uint32_t ST_WMAX = 2048;                      // largest w this route takes (the caller checks)
+constexpr uint32_t ST_LDS = ST_WIN + ST_WMAX + 1;       // k-mers a tile holds
+
+struct StretchTile {
+    uint32_t contig, klo;    // the stretch: contig, its first k-mer (contig-local valid-k-mer index)
+    uint32_t t0, nwin;       // this tile: first window start relative to klo, window starts
+};
+struct StretchParams {
+    const StretchTile *tiles;
+    uint32_t n_tiles;
+    const Run *runs;
+    const uint32_t *ctg_run0, *ctg_rec;
+    const uint8_t *ctg_drop;
+    const uint32_t *packed;
+    uint32_t k, w;
+    uint64_t mult;
+    HashTab tab;
+    uint32_t *cnt;           // [n_tiles] pass 0: minimizers per tile
+    const uint32_t *off;     // [n_tiles] pass 1: where the tile's minimizers start
+    uint64_t *o_hash;
+    uint32_t *o_pos, *o_rec;
+};
+
+template <int VARIANT, int PASS>
+__global__ __launch_bounds__(256) void k_stretch_tiles(const StretchParams p)
+{
+    __shared__ uint64_t lh[ST_LDS];
+    __shared__ uint16_t lidx[2][ST_LDS];
+    __shared__ uint32_t lpos[PASS ? ST_LDS : 1];  // base position (contig-local) of every k-mer
+    __shared__ uint32_t selbits[(ST_LDS + 31) / 32];
+    __shared__ uint4 tab[20];
+    __shared__ uint32_t sh[256];
+    __shared__ uint32_t excl[2];
+    const StretchTile tl = p.tiles[blockIdx.x];
+    const uint32_t w = p.w, k = p.k, c = tl.contig;
+    const uint32_t front = tl.t0 ? 1u : 0u;                       // the window in front of the tile (for the exclusion)
+    const uint32_t i_lo = tl.klo + tl.t0 - front;                 // first k-mer held (contig-local index)
+    const uint32_t m = front + tl.nwin + w - 1u;                  // k-mers held: <= ST_LDS
+    if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < (ST_LDS + 31) / 32; i += 256) selbits[i] = 0;
+    if (threadIdx.x < 2) excl[threadIdx.x] = 0xFFFFFFFFu;
+    __syncthreads();
+    // exact hashes: every thread a run of consecutive k-mers -- the direct formula at its first k-mer and wherever a new run of
+    // valid bases begins, rolling in between
+    const uint32_t per = (m + 255u) / 256u, a0 = threadIdx.x * per, a1 = min(a0 + per, m);
+    if (a0 < m) {
+        uint32_t lo = p.ctg_run0[c], hi = p.ctg_run0[c + 1];
+        const uint32_t ki = i_lo + a0;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (p.runs[mid].kidx0 <= ki) lo = mid; else hi = mid;
+        }
+        Run run = p.runs[lo];
+        H2 h = {0u, 0u, 0u, 0u};
+        bool fresh = true;
+        for (uint32_t a = a0; a < a1; ++a) {
+            const uint32_t kx = i_lo + a;
+            if (kx >= run.kidx0 + run.n_kmers) {
+                run = p.runs[++lo];
+                fresh = true;
+            }
+            const uint64_t b = run.base_off + (kx - run.kidx0);
+            if (fresh) {
+                h = H2{0u, 0u, 0u, 0u};
+                warm_up(h, p.packed, b, k, tab);
+                fresh = false;
+            } else {
+                const uint64_t go = b - 1, gi = go + k;
+                const uint32_t o = (p.packed[go >> 4] >> (2u * ((uint32_t)go & 15u))) & 3u;
+                const uint32_t in = (p.packed[gi >> 4] >> (2u * ((uint32_t)gi & 15u))) & 3u;
+                nt_step(h, tab[o * 4u + in]);
+            }
+            lh[a] = canonical<VARIANT>(h);
+            if (PASS) lpos[a] = run.pos0 + (kx - run.kidx0);
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < m; i += 256) lidx[0][i] = (uint16_t)i;
+    __syncthreads();
+    auto best = [&](uint32_t a, uint32_t c2) {  // the smaller hash, the RIGHT one of equals (btllib rescans with <=)
+        const uint64_t ha = lh[a], hc = lh[c2];
+        return (hc < ha || (hc == ha && c2 > a)) ? c2 : a;
+    };
+    uint32_t J = 0;
+    while ((2u << J) <= w) ++J;  // 2^J <= w < 2^(J+1)
+    uint32_t cur = 0;
+    for (uint32_t lv = 0; lv < J; ++lv) {  // lidx[cur][i] = arg-min over [i, i + 2^lv) -> [i, i + 2^(lv+1))
+        const uint32_t step = 1u << lv;
+        for (uint32_t i = threadIdx.x; i < m; i += 256) {
+            const uint32_t a = lidx[cur][i];
+            lidx[cur ^ 1][i] = (uint16_t)(i + step < m ? best(a, lidx[cur][i + step]) : a);
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    const uint32_t span = 1u << J;
+    const bool drop = tl.klo == 0 && tl.t0 == 0 && p.ctg_drop && p.ctg_drop[c];
+    for (uint32_t s = threadIdx.x; s < front + tl.nwin; s += 256) {
+        const uint32_t a = best(lidx[cur][s], lidx[cur][s + w - span]);
+        if (s < front) {
+            excl[0] = a;  // the window in front of the tile: its arg-min is the previous tile's to report
+        } else {
+            if (lh[a] != 0xFFFFFFFFFFFFFFFFull) atomicOr(&selbits[a >> 5], 1u << (a & 31u));  // btllib never reports 2^64-1
+            if (s == 0 && drop) excl[1] = a;  // a piece's first window belongs to the shard before it (plan_pieces)
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && excl[threadIdx.x] != 0xFFFFFFFFu) atomicAnd(&selbits[excl[threadIdx.x] >> 5], ~(1u << (excl[threadIdx.x] & 31u)));
+    __syncthreads();
+    uint32_t cnt = 0;
+    for (uint32_t i = a0; i < a1 && a0 < m; ++i) cnt += (selbits[i >> 5] >> (i & 31u)) & 1u;
+    uint32_t o = block_exclusive_256(cnt, sh);
+    if (PASS == 0) {
+        if (threadIdx.x == 0) p.cnt[blockIdx.x] = sh[255];
+        return;
+    }
+    const uint32_t rec = p.ctg_rec[c];
+    const size_t base = p.off[blockIdx.x];
+    for (uint32_t i = a0; i < a1 && a0 < m; ++i)
+        if ((selbits[i >> 5] >> (i & 31u)) & 1u) {
+            const size_t at = base + o++;
+            p.o_hash[at] = ext_hash(lh[i], p.mult);
+            p.o_pos[at] = lpos[i];
+            p.o_rec[at] = rec;
+        }
+}
+
 // Pinned host copy of a batch's control block (16 words), written by the batch's last kernel:
 // [0] largest wave count if a wave overflowed its arena slice, [1] candidate-free stretches, [2] minimizers among the
 // candidates, [3] "the device route could not finish the stretches", [4] candidates, [5] minimizers inside stretches,
-// [6..7] minimizers of the batch, [8..9] where the batch starts in the assembly's sketch, [10] k-mers hashed by k_gap_fix
+// [6..7] minimizers of the batch, [8..9] where the batch starts in the assembly's sketch, [10] k-mers hashed by k_gap_fix,
+// [11] stretches left to the host (their {contig, first, last k-mer} in the batch's slice of pinned_defer)
 // ------------------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------------------
@@ -1698,6 +1865,7 @@ constexpr uint32_t PINNED_SLOTS = 1024;
 static int ensure_pinned_ctrl(mxg_handle *h)
 {
     if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, (size_t)PINNED_SLOTS * 64));
+    if (!h->pinned_defer) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_defer, (size_t)PINNED_SLOTS * GAP_DEV_MAX * 16));
     return MXG_OK;
 }
 
@@ -2118,7 +2286,7 @@ struct Driver {
         return (n_tiles + rounds - 1) / rounds;
     }
     // stretches sketched on the device, one block each (results wait in their regions for k_gap_post): reads SC_GAPS / ctrl[1]
-    int enqueue_dev_gaps(Assembly *a, const Tables &T)
+    int enqueue_dev_gaps(Assembly *a, const Tables &T, const uint32_t *ctrl_host)
     {
         MXG_HIP(h, sc(SC_GR_HASH).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 8));
         MXG_HIP(h, sc(SC_GR_POS).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
@@ -2145,6 +2313,8 @@ struct Driver {
         gp.r_rec = sc(SC_GR_REC).as<uint32_t>();
         gp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
         gp.r_key = sc(SC_GR_KEY).as<uint64_t>();
+        // the batch's slice of the pinned list of deferred stretches goes with its pinned control block
+        gp.defer = reinterpret_cast<uint4 *>(h->pinned_defer) + (size_t)((ctrl_host - h->pinned_ctrl) / 16) * GAP_DEV_MAX;
         gp.tab = h->tab;
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
             hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V1_MIN>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
@@ -2331,7 +2501,7 @@ struct Driver {
         if ((rc = resolve_count(T, n_cap, (uint32_t)g.c0, (uint32_t)g.c1, (uint64_t)tau_hi << 32,
                                 cand_hint != 0xFFFFFFFFu ? cand_hint : a->cand_hint)) != MXG_OK) return rc;
         const bool dev = io && io->dev_gaps;
-        if (dev && (rc = enqueue_dev_gaps(a, T)) != MXG_OK) return rc;
+        if (dev && (rc = enqueue_dev_gaps(a, T, ctrl_host)) != MXG_OK) return rc;
         if ((rc = ev_next(4)) != MXG_OK) return rc;
         // the batch before this one (same assembly, other stream) must have passed its count on
         if (io && io->wait) MXG_HIP(h, hipStreamWaitEvent(st, io->wait, 0));
@@ -2440,7 +2610,7 @@ struct Driver {
                     b.n_blocks, acc[1] / b.n_blocks, acc[2] / b.n_blocks, acc[3] / b.n_blocks, acc[4] / b.n_blocks, acc[5] / b.n_blocks,
                     acc[6] / b.n_blocks, acc[7] / b.n_blocks, acc[8] / b.n_blocks, (double)(t_max - t_min));
         }
-        if ((rc = enqueue_dev_gaps(a, T)) != MXG_OK) return rc;
+        if ((rc = enqueue_dev_gaps(a, T, ctrl_host)) != MXG_OK) return rc;
         if ((rc = ev_next(4)) != MXG_OK) return rc;
         if (io && io->wait) MXG_HIP(h, hipStreamWaitEvent(st, io->wait, 0));
         rc = emit(a->d_packed, T, (uint32_t)n_ent, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host, io, b.rk,
@@ -2504,12 +2674,123 @@ struct Driver {
         return MXG_OK;
     }
 
+    // stretches of any shape through k_stretch_tiles -> SC_G_* (hash, pos, rec) in (contig, position) order
+    int sketch_stretches(Assembly *a, const Tables &T, std::vector<uint4> &gaps, uint64_t *n_gap_mx)
+    {
+        std::sort(gaps.begin(), gaps.end(), [](const uint4 &x, const uint4 &y) { return x.x != y.x ? x.x < y.x : x.y < y.y; });
+        const uint32_t w = h->cfg.w;
+        std::vector<StretchTile> tiles;
+        for (const uint4 &g : gaps) {
+            const uint32_t n = g.z - g.y + 1u;
+            if (n < w) continue;  // (no window inside)
+            const uint32_t n_win = n - w + 1u;
+            for (uint32_t t0 = 0; t0 < n_win; t0 += ST_WIN) tiles.push_back(StretchTile{g.x, g.y, t0, std::min(ST_WIN, n_win - t0)});
+        }
+        *n_gap_mx = 0;
+        if (tiles.empty()) return MXG_OK;
+        if (tiles.size() >= (1ull << 31)) return set_err(h, MXG_ELIMIT, "too many stretch tiles");
+        int rc;
+        const uint32_t nt = (uint32_t)tiles.size();
+        if ((rc = upload(h, sc(SC_V_RUNS), tiles, st)) != MXG_OK) return rc;
+        MXG_HIP(h, sc(SC_V_NK).ensure((size_t)nt * 4));
+        MXG_HIP(h, sc(SC_V_REC).ensure((size_t)nt * 4));
+        StretchParams sp;
+        sp.tiles = sc(SC_V_RUNS).as<StretchTile>();
+        sp.n_tiles = nt;
+        sp.runs = T.d_runs;
+        sp.ctg_run0 = T.d_ctg_run0;
+        sp.ctg_rec = T.d_ctg_rec;
+        sp.ctg_drop = T.d_ctg_drop;
+        sp.packed = a->d_packed;
+        sp.k = h->cfg.k;
+        sp.w = w;
+        sp.mult = 1ull ^ ((uint64_t)h->cfg.k * 0x90b45d39fb6da1faull);
+        sp.tab = h->tab;
+        sp.cnt = sc(SC_V_NK).as<uint32_t>();
+        sp.off = nullptr;
+        sp.o_hash = nullptr;
+        sp.o_pos = sp.o_rec = nullptr;
+        const bool v1 = h->cfg.variant == MXG_VARIANT_V1_MIN;
+        if (v1) hipLaunchKernelGGL((k_stretch_tiles<MXG_VARIANT_V1_MIN, 0>), dim3(nt), dim3(256), 0, st, sp);
+        else hipLaunchKernelGGL((k_stretch_tiles<MXG_VARIANT_V2_SUM, 0>), dim3(nt), dim3(256), 0, st, sp);
+        MXG_HIP(h, hipGetLastError());
+        std::vector<uint32_t> cnt(nt), off(nt);
+        MXG_HIP(h, hipMemcpyAsync(cnt.data(), sp.cnt, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+        MXG_HIP(h, hipStreamSynchronize(st));
+        uint64_t total = 0;
+        for (uint32_t t = 0; t < nt; ++t) {
+            off[t] = (uint32_t)total;
+            total += cnt[t];
+        }
+        if (total >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "too many minimizers in candidate-free stretches");
+        *n_gap_mx = total;
+        if (!total) return MXG_OK;
+        MXG_HIP(h, sc(SC_G_HASH).ensure(total * 8));
+        MXG_HIP(h, sc(SC_G_POS).ensure(total * 4));
+        MXG_HIP(h, sc(SC_G_REC).ensure(total * 4));
+        MXG_HIP(h, sc(SC_G_FWD).ensure(total));
+        MXG_HIP(h, hipMemsetAsync(sc(SC_G_FWD).p, 0, total, st));  // (strands are computed on demand: ensure_strand)
+        MXG_HIP(h, hipMemcpyAsync(sc(SC_V_REC).p, off.data(), (size_t)nt * 4, hipMemcpyHostToDevice, st));
+        sp.off = sc(SC_V_REC).as<uint32_t>();
+        sp.o_hash = sc(SC_G_HASH).as<uint64_t>();
+        sp.o_pos = sc(SC_G_POS).as<uint32_t>();
+        sp.o_rec = sc(SC_G_REC).as<uint32_t>();
+        if (v1) hipLaunchKernelGGL((k_stretch_tiles<MXG_VARIANT_V1_MIN, 1>), dim3(nt), dim3(256), 0, st, sp);
+        else hipLaunchKernelGGL((k_stretch_tiles<MXG_VARIANT_V2_SUM, 1>), dim3(nt), dim3(256), 0, st, sp);
+        MXG_HIP(h, hipGetLastError());
+        MXG_HIP(h, hipStreamSynchronize(st));  // (off / tiles are read by the kernel until here)
+        return MXG_OK;
+    }
+
+    // The stretches the device route left out (defer_stretch), for a whole assembly whose batches are all in place: sketched
+    // as stand-alone contigs (k_stretch_tiles; beyond its window limit the dense pipeline), then merged into the assembly's n
+    // minimizers (one pass over the sketch).
+    int merge_deferred(Assembly *a, const Tables &T, std::vector<uint4> &gaps, uint64_t n, uint64_t *n_out)
+    {
+        int rc;
+        uint64_t n_gap_mx = 0;
+        *n_out = n;
+        if (h->cfg.w <= ST_WMAX && !getenv("MXG_STRETCH_DENSE")) {
+            if ((rc = sketch_stretches(a, T, gaps, &n_gap_mx)) != MXG_OK) return rc;
+            for (const uint4 &g : gaps) h->stat_dense_kmers += g.z - g.y + 1u;
+        } else if ((rc = process_gaps(a, T, gaps, &n_gap_mx)) != MXG_OK) {  // (dense_all counts its k-mers itself)
+            return rc;
+        }
+        if (!n_gap_mx) return MXG_OK;
+        if (n + n_gap_mx >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "sketch too large to merge");
+        OutArrays out{&a->d_hash, &a->d_pos, &a->d_rec, &a->d_fwd, n};
+        if ((rc = out_reserve(h, out, n + n_gap_mx, st)) != MXG_OK) return rc;
+        MXG_HIP(h, sc(SC_ST_HASH).ensure(std::max<uint64_t>(n * 8, 16)));
+        MXG_HIP(h, sc(SC_ST_POS).ensure(std::max<uint64_t>(n * 4, 16)));
+        MXG_HIP(h, sc(SC_ST_REC).ensure(std::max<uint64_t>(n * 4, 16)));
+        MXG_HIP(h, sc(SC_ST_FWD).ensure(std::max<uint64_t>(n, 16)));
+        if (n) {
+            MXG_HIP(h, hipMemcpyAsync(sc(SC_ST_HASH).p, a->d_hash.p, n * 8, hipMemcpyDeviceToDevice, st));
+            MXG_HIP(h, hipMemcpyAsync(sc(SC_ST_POS).p, a->d_pos.p, n * 4, hipMemcpyDeviceToDevice, st));
+            MXG_HIP(h, hipMemcpyAsync(sc(SC_ST_REC).p, a->d_rec.p, n * 4, hipMemcpyDeviceToDevice, st));
+            MXG_HIP(h, hipMemcpyAsync(sc(SC_ST_FWD).p, a->d_fwd.p, n, hipMemcpyDeviceToDevice, st));
+        }
+        MergeParams mp;
+        mp.a_hash = sc(SC_ST_HASH).as<uint64_t>(); mp.a_pos = sc(SC_ST_POS).as<uint32_t>();
+        mp.a_rec = sc(SC_ST_REC).as<uint32_t>(); mp.a_fwd = sc(SC_ST_FWD).as<uint8_t>(); mp.nA = (uint32_t)n;
+        mp.b_hash = sc(SC_G_HASH).as<uint64_t>(); mp.b_pos = sc(SC_G_POS).as<uint32_t>();
+        mp.b_rec = sc(SC_G_REC).as<uint32_t>(); mp.b_fwd = sc(SC_G_FWD).as<uint8_t>(); mp.nB = (uint32_t)n_gap_mx;
+        mp.o_hash = a->d_hash.as<uint64_t>(); mp.o_pos = a->d_pos.as<uint32_t>();
+        mp.o_rec = a->d_rec.as<uint32_t>(); mp.o_fwd = a->d_fwd.as<uint8_t>();
+        hipLaunchKernelGGL(k_merge, dim3((mp.nA + mp.nB + 255) / 256), dim3(256), 0, st, mp);
+        MXG_HIP(h, hipGetLastError());
+        MXG_HIP(h, hipStreamSynchronize(st));
+        *n_out = n + n_gap_mx;
+        return MXG_OK;
+    }
+
     // every contig of T, appended to `out` (synchronous: one sync per batch, retries and gap fix-ups inline)
-    int sparse_all(Assembly *a, const Tables &T, OutArrays &out, uint32_t tau_hi, double cand_frac)
+    // (c_start / out.n: the redo of an assembly's batches from contig c_start on, behind the minimizers already in place)
+    int sparse_all(Assembly *a, const Tables &T, OutArrays &out, uint32_t tau_hi, double cand_frac, size_t c_start = 0)
     {
         const size_t n_ctg = T.ctg_rec->size();
         const uint32_t S = a->S_sparse;
-        size_t c0 = 0;
+        size_t c0 = c_start;
         while (c0 < n_ctg) {
             BatchGeom g;
             batch_geom(T, c0, g);
@@ -2662,7 +2943,8 @@ static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
     sp.sparse = !(h->cfg.flags & MXG_FLAG_DENSE_ONLY) && sp.frac <= 0.125;
     sp.batch_kmers = 0;
     if (sp.dev_gaps) {  // a candidate is followed by a stretch with probability e^-c
-        const double per_kmer = sp.frac * std::exp(-(double)c);
+        // (a->gap_rate_hint: what earlier sketches of this assembly met, 25 % on top)
+        const double per_kmer = std::max(sp.frac * std::exp(-(double)c), a->gap_rate_hint * 1.25);
         const double lim = (double)env_u64("MXG_GAP_BUDGET", GAP_DEV_MAX / 4) / std::max(per_kmer, 1e-30);  // expected stretches per batch
         if (lim < (double)SPARSE_BATCH_KMERS) sp.batch_kmers = std::max<uint64_t>((uint64_t)lim, 1u << 20);
     }
@@ -2758,16 +3040,14 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
     size_t last_on_slot[4] = {(size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
     size_t n_enq = 0, next_slot = 0;
     const bool chain_modes = fuse_graph || xp;  // (these two need one batch per assembly)
-    for (size_t i = 0; i < n; ++i) {
-        item0[i] = items.size();
-        bool empty = false;
-        if ((rc = prepare_sketch(h, list[i], tabs[i], &empty)) != MXG_OK) return rc;
-        if (empty) {
-            state[i] = 2;
-            continue;
-        }
+    // the batches of assembly i -> the streams (attempt 0; attempt 1: once more for an assembly whose batches did not all end
+    // the common way, now sized by what the first attempt saw: stretch density, candidate counts, slice capacity)
+    std::vector<size_t> q_lo(n, 0), q_hi(n, 0);
+    auto enqueue_asm = [&](size_t i, int attempt) -> int {
+        q_lo[i] = q_hi[i] = items.size();
+        state[i] = 0;
         plans[i] = sparse_plan(h, list[i]);
-        if (!plans[i].sparse || i >= MXG_MAX_ASSEMBLIES) continue;
+        if (!plans[i].sparse || i >= MXG_MAX_ASSEMBLIES) return MXG_OK;
         std::vector<Driver::BatchGeom> gs;
         const size_t n_ctg = tabs[i].ctg_rec->size();
         for (size_t c0 = 0; c0 < n_ctg;) {
@@ -2776,10 +3056,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             gs.push_back(g);
             c0 = g.c1;
         }
-        if (gs.empty() || (chain_modes && gs.size() > 1) || items.size() + gs.size() >= PINNED_SLOTS - 1) continue;
-        if (gs.size() > 1 && list[i]->any_drop && !plans[i].dev_gaps) {
-            // (fine either way; nothing special: ctg_drop travels with the tables)
-        }
+        if (gs.empty() || (chain_modes && gs.size() > 1) || items.size() + gs.size() >= PINNED_SLOTS - 1) return MXG_OK;
         // the k = 32 route: the bit-sliced filter over the whole assembly, then one k_bs_resolve per batch (sketch_bs.hip)
         bool use_bs = bs_env && bs_possible(h, list[i]);
         bool fused_ok = use_bs && bs_fused && plans[i].dev_gaps && !chain_modes && h->cfg.w >= 256 && h->cfg.w <= GAP_DEV_NMAX / 2;
@@ -2798,7 +3075,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         OutArrays out{&list[i]->d_hash, &list[i]->d_pos, &list[i]->d_rec, &list[i]->d_fwd, 0};
         // chain words: [item] = where the NEXT batch starts
         MXG_HIP(h, h->d_chain.ensure((size_t)PINNED_SLOTS * 8));
-        if (list[i]->cand_hints.size() != gs.size()) list[i]->cand_hints.assign(gs.size(), 0u);
+        if (list[i]->cand_hints.size() != gs.size()) list[i]->cand_hints.assign(gs.size(), list[i]->full_grid_once ? 0xFFFFFFFEu : 0u);
+        list[i]->full_grid_once = false;
         for (size_t b = 0; b < gs.size(); ++b) {
             // a single-batch assembly keeps the round-1 placement: the LAST assembly goes to driver 0 = the handle's main
             // stream (whatever follows the sketches on that stream then waits for the other stream's chain, which has
@@ -2813,7 +3091,9 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             it.slot = (int)sl;
             it.n_cap = 0;
             it.bs = fused_ok;
-            if (use_bs && b == 0) {  // the filter, once per assembly, on the first batch's stream
+            if (use_bs && attempt > 0) {
+                // (the bitmap of the first attempt is still there, and every stream has been waited for)
+            } else if (use_bs && b == 0) {  // the filter, once per assembly, on the first batch's stream
                 st_hash = drv.st;
                 if ((rc = drv.ev_begin(list[i]->total_bases, true)) != MXG_OK) return rc;
                 if ((rc = bs_hash(h, list[i], plans[i].tau_hi, drv.st)) != MXG_OK) return rc;
@@ -2863,7 +3143,19 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             items.push_back(it);
         }
         state[i] = 1;
-        ++n_enq;
+        q_hi[i] = items.size();
+        return MXG_OK;
+    };
+    for (size_t i = 0; i < n; ++i) {
+        item0[i] = items.size();
+        bool empty = false;
+        if ((rc = prepare_sketch(h, list[i], tabs[i], &empty)) != MXG_OK) return rc;
+        if (empty) {
+            state[i] = 2;
+            continue;
+        }
+        if ((rc = enqueue_asm(i, 0)) != MXG_OK) return rc;
+        if (state[i] == 1) ++n_enq;
     }
     item0[n] = items.size();
     for (size_t i = n; i-- > 0;)
@@ -2921,10 +3213,10 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
     for (hipStream_t sx : h->stream_x)
         if (sx) MXG_HIP(h, stream_wait(sx));
     size_t n_fast = 0;  // assemblies whose every batch ended the common way
-    for (size_t i = 0; i < n; ++i) {
-        if (state[i] != 1) continue;
+    // what became of assembly i's batches: state 2 = its sketch is complete, 3 = enqueue it once more, 0 = synchronous path
+    auto evaluate = [&](size_t i, bool final) -> int {
         Assembly *a = list[i];
-        const size_t q0 = item0[i], q1 = item0[i + 1];
+        const size_t q0 = q_lo[i], q1 = q_hi[i];
         const uint64_t cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
         bool good = true;
         uint64_t total = 0, n_cand = 0, gap_kmers = 0;
@@ -2938,8 +3230,34 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             n_cand += c[4];
             gap_kmers += c[10] == 0xFFFFFFFFu ? 0 : c[10];
         }
+        if (!(good && total <= cap) && getenv("MXG_DEBUG_BATCH")) {  // (diagnostics: the reports of an assembly's batches)
+            for (size_t q = q0; q < q1; ++q) {
+                const uint32_t *c = items[q].hc;
+                fprintf(stderr, "[mxg] asm %zu batch %zu: ovf %u gaps %u sel %u flag %u cand %u nB %u total %u obase %u gapk %u (cap %llu)\n", i,
+                        q - q0, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[8], c[10], (unsigned long long)cap);
+            }
+        }
+        // what the batches saw of candidate-free stretches sizes the next sketch's batches (sparse_plan): real genomes hold
+        // far more of them than the i.i.d. estimate (satellite arrays, low-complexity runs)
+        for (size_t q = q0; q < q1; ++q) {
+            const uint32_t *c = items[q].hc;
+            if (c[1] != 0xFFFFFFFFu && items[q].g.nk) a->gap_rate_hint = std::max(a->gap_rate_hint, (double)c[1] / (double)items[q].g.nk);
+        }
         if (good && total <= cap) {
-            a->n_mx = total;
+            // stretches the device route left to the host (too long, too many minimizers, invalid bases inside)
+            std::vector<uint4> deferred;
+            for (size_t q = q0; q < q1 && !chain_modes; ++q) {
+                const uint32_t nd = items[q].hc[11] == 0xFFFFFFFFu ? 0u : std::min(items[q].hc[11], GAP_DEV_MAX);
+                const uint4 *src = reinterpret_cast<const uint4 *>(h->pinned_defer) + (size_t)((items[q].hc - h->pinned_ctrl) / 16) * GAP_DEV_MAX;
+                deferred.insert(deferred.end(), src, src + nd);
+            }
+            uint64_t n_final = total;
+            if (!deferred.empty()) {
+                if ((rc = drv0.merge_deferred(a, tabs[i], deferred, total, &n_final)) != MXG_OK) return rc;
+                h->stat_deferred += deferred.size();
+                fused = false;  // (the graph stage ran on a sketch without them)
+            }
+            a->n_mx = n_final;
             a->has_sketch = true;
             h->stat_candidates += n_cand;
             h->stat_dense_kmers += gap_kmers;
@@ -2961,13 +3279,86 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             a->n_mx = out.n;
             a->has_sketch = true;
             state[i] = 2;
+        } else if (q1 - q0 > 1 && !chain_modes && !final) {
+            // several batches, first attempt: once more through the streams (a few ms per Gbp; the synchronous route costs
+            // ten times that), with batches sized for the stretch density just seen (gap_rate_hint, above), every grid sized by
+            // the batch's own candidate count where it reported one, and slices as large as the largest wave asked for
+            for (size_t q = q0; q < q1; ++q) {
+                const uint32_t *c = items[q].hc;
+                if (c[0] != 0 && c[0] != 0xFFFFFFFFu) h->arena_cap_hint = std::max<uint64_t>(h->arena_cap_hint, (uint64_t)c[0] + 64);
+            }
+            a->cand_hints.clear();  // (the batches will be cut differently)
+            a->cand_hint = 0xFFFFFFFEu;
+            a->full_grid_once = true;
+            ++h->stat_retries;
+            state[i] = 3;
+        } else if (q1 - q0 > 1 && !chain_modes) {
+            // several batches: keep the leading ones that ended the common way AND lie where they belong (a batch starts
+            // where its predecessors end), redo the first bad one and everything behind it batch by batch through the
+            // synchronous route.  That route finishes stretches from the host, so it takes the threshold of the host route
+            // (18 candidates per window: a stretch per ~10^8 k-mers instead of one per ~2 x 10^6).
+            const bool dev = plans[i].dev_gaps;
+            uint64_t offset = 0, nc = 0, gk = 0;
+            size_t j = q0;
+            for (; j < q1; ++j) {
+                const uint32_t *c = items[j].hc;
+                const uint64_t t = (uint64_t)c[6] | ((uint64_t)c[7] << 32), ob = (uint64_t)c[8] | ((uint64_t)c[9] << 32);
+                const bool ok = c[0] == 0 && c[3] == 0 && c[4] != 0 && c[4] != 0xFFFFFFFFu && (dev || c[1] == 0) && ob == offset &&
+                                offset + t <= cap;
+                if (!ok) break;
+                offset += t;
+                nc += c[4];
+                gk += c[10] == 0xFFFFFFFFu ? 0 : c[10];
+                a->cand_hints[j - q0] = c[4];
+            }
+            for (size_t q = j; q < q1; ++q)  // (next time: the whole grid for what did not report, the count for what did)
+                a->cand_hints[q - q0] = items[q].hc[4] != 0xFFFFFFFFu && items[q].hc[4] != 0 ? items[q].hc[4] : 0xFFFFFFFEu;
+            a->cand_hint = a->cand_hints[0];
+            SparsePlan rp = plans[i];
+            if (!h->cfg.cand_per_window && 18.0 / (double)h->cfg.w <= 0.125) {
+                rp.frac = 18.0 / (double)h->cfg.w;
+                rp.tau_hi = std::max(2u, (uint32_t)std::min<double>(4294967294.0, rp.frac * 4294967296.0) & ~1u);
+            }
+            OutArrays out{&a->d_hash, &a->d_pos, &a->d_rec, &a->d_fwd, offset};
+            h->stat_candidates += nc;
+            h->stat_dense_kmers += gk;
+            h->stat_batches_redone += q1 - j;
+            if (j == q0) ++h->stat_sync_assemblies;
+            if ((rc = drv0.sparse_all(a, tabs[i], out, rp.tau_hi, rp.frac, items[j].g.c0)) != MXG_OK) return rc;
+            MXG_HIP(h, hipStreamSynchronize(drv0.st));
+            a->n_mx = out.n;
+            a->has_sketch = true;
+            state[i] = 2;
         } else {
             state[i] = 0;  // redo synchronously
         }
+        return MXG_OK;
+    };
+    for (size_t i = 0; i < n; ++i)
+        if (state[i] == 1 && (rc = evaluate(i, chain_modes)) != MXG_OK) return rc;
+    {
+        std::vector<size_t> again;
+        for (size_t i = 0; i < n; ++i)
+            if (state[i] == 3) again.push_back(i);
+        for (size_t i : again)
+            if ((rc = enqueue_asm(i, 1)) != MXG_OK) return rc;
+        if (!again.empty()) {
+            MXG_HIP(h, stream_wait(h->stream));
+            MXG_HIP(h, stream_wait(h->stream2));
+            for (hipStream_t sx : h->stream_x)
+                if (sx) MXG_HIP(h, stream_wait(sx));
+        }
+        for (size_t i : again)
+            if (state[i] == 1 && (rc = evaluate(i, true)) != MXG_OK) return rc;
     }
     if (n_fast != n) fused = false;  // not the common case everywhere: the graph stage ran on incomplete input
     for (size_t i = 0; i < n; ++i) {
-        if (state[i] == 0 && (rc = run_sketch_sync(h, list[i], tabs[i], drv0)) != MXG_OK) return rc;
+        if (state[i] != 0) continue;
+        if (item0[i + 1] > item0[i]) {  // (was enqueued: the common route did not finish it)
+            ++h->stat_sync_assemblies;
+            h->stat_batches_redone += item0[i + 1] - item0[i];
+        }
+        if ((rc = run_sketch_sync(h, list[i], tabs[i], drv0)) != MXG_OK) return rc;
     }
     if ((rc = drv0.collect()) != MXG_OK) return rc;
     if (fuse_graph && !fused) {

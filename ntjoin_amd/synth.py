@@ -38,6 +38,83 @@ def derive_target(ref_records, seed, min_len=10_000, max_len=2_000_000, sub_rate
     return [contigs[i] for i in order]
 
 
+LUT5 = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+
+def repeat_rich_records(seed, n_records, rec_len):
+    """records with the structure real genomes add to random sequence (codes 0..3, 4 = N): 55 % unique stretches of 0.5-8 kbp,
+    30 % copies of six repeat families (0.3 / 1.2 / 6 kbp consensus, 5-15 % diverged, either strand), 8 % tandem arrays of a
+    171-base unit (20-120 copies), 5 % homopolymer / di- / trinucleotide runs of 30-900 units, 2 % N gaps of 1 / 20 / 300 bases.
+    What it provokes in the sketch stage: k-mers below the candidate threshold that occur thousands of times (candidate floods
+    beyond any estimate), windows whose every k-mer hashes alike (low-complexity: the rightmost-tie rule reports each), long
+    candidate-free stretches, many short valid runs."""
+    rng = np.random.default_rng(seed)
+    fams = [rng.integers(0, 4, size=int(n), dtype=np.uint8) for n in rng.choice([300, 1200, 6000], size=6)]
+    sat = rng.integers(0, 4, size=171, dtype=np.uint8)
+    units = [np.array(u, dtype=np.uint8) for u in ([0], [3], [0, 1], [0, 3], [2, 2, 1])]
+    recs = []
+    for _ in range(n_records):
+        out = np.empty(rec_len + 25000, dtype=np.uint8)
+        n = 0
+        while n < rec_len:
+            kind = rng.random()
+            if kind < 0.55:
+                p = rng.integers(0, 4, size=int(rng.integers(500, 8001)), dtype=np.uint8)
+            elif kind < 0.85:
+                f = fams[int(rng.integers(0, len(fams)))].copy()
+                m = rng.random(len(f)) < rng.uniform(0.05, 0.15)
+                f[m] = rng.integers(0, 4, size=int(m.sum()), dtype=np.uint8)
+                p = (3 - f)[::-1] if rng.random() < 0.5 else f
+            elif kind < 0.93:
+                p = np.tile(sat, int(rng.integers(20, 121)))
+            elif kind < 0.98:
+                p = np.tile(units[int(rng.integers(0, len(units)))], int(rng.integers(30, 901)))
+            else:
+                p = np.full(int(rng.choice([1, 20, 300])), 4, dtype=np.uint8)
+            m = min(len(p), len(out) - n)
+            out[n:n + m] = p[:m]
+            n += m
+        recs.append(out[:rec_len].copy())
+    return recs
+
+
+def derive_target_with_n(ref_records, seed, **kw):
+    """derive_target for records that hold N (code 4): the N positions travel with their contig, unchanged"""
+    clean = []
+    for codes in ref_records:
+        c = codes.copy()
+        c[c == 4] = 0
+        clean.append(c | ((codes == 4).astype(np.uint8) << 7))  # bit 7 marks N through the cutting / reversal
+    out = []
+    rng_state = np.random.default_rng(seed)
+    min_len, max_len = kw.get("min_len", 10_000), kw.get("max_len", 2_000_000)
+    sub_rate, gap = kw.get("sub_rate", 0.005), kw.get("gap", (20, 500))
+    for codes in clean:
+        p, n = 0, len(codes)
+        while p < n:
+            ln = int(np.exp(rng_state.uniform(np.log(min_len), np.log(max_len))))
+            seg = codes[p:p + ln].copy()
+            p += ln + int(rng_state.integers(gap[0], gap[1] + 1))
+            if len(seg) < 1000:
+                continue
+            isn = (seg & 0x80) != 0
+            seg &= 3
+            n_sub = rng_state.binomial(len(seg), sub_rate)
+            if n_sub:
+                idx = rng_state.integers(0, len(seg), size=n_sub)
+                seg[idx] = (seg[idx] + rng_state.integers(1, 4, size=n_sub, dtype=np.uint8)) & 3
+            if rng_state.random() < 0.5:
+                seg, isn = (3 - seg)[::-1].copy(), isn[::-1].copy()
+            seg[isn] = 4
+            out.append(seg)
+    order = rng_state.permutation(len(out))
+    return [out[i] for i in order]
+
+
+def to_ascii5(codes):
+    return LUT5[codes].tobytes()
+
+
 def pack_records(records, pad_words=512):
     """-> (packed uint32[...], rec_start uint64[n], rec_len uint64[n]); record r starts at a multiple of 16 bases."""
     lens = np.array([len(r) for r in records], dtype=np.uint64)
