@@ -264,3 +264,85 @@ def test_repeat_rich_genome_on_the_device_route(oracle, dev_knobs, w, cand):
     recs = _repeat_rich_records(5, 6, 250_000)
     st = _check(oracle, recs, 32, w, cand_per_window=cand)
     assert st["candidates"] > 0
+
+
+def _repeat_rich_numpy(seed, n_rec, rec_len):
+    from ntjoin_amd import synth
+    return [(f"chr{i}", synth.to_ascii5(c).decode()) for i, c in enumerate(synth.repeat_rich_records(seed, n_rec, rec_len))]
+
+
+@pytest.fixture
+def route_knobs(dev_knobs):
+    saved = {k: os.environ.get(k) for k in ("MXG_GAP_BUDGET", "MXG_GRID_BY_ESTIMATE", "MXG_STRETCH_DENSE")}
+    yield dev_knobs
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def test_stretches_left_to_the_tile_kernel(oracle, route_knobs):
+    """satellite arrays and low-complexity runs: candidate-free stretches longer than the device route's 4096 k-mers, stretches
+    with hundreds of minimizers in a row (every window of a homopolymer reports its last k-mer), stretches across N gaps --
+    handed to k_stretch_tiles and merged into the sketch; the same through the dense pipeline (MXG_STRETCH_DENSE=1)"""
+    route_knobs["MXG_DEV_GAPS"] = "1"
+    route_knobs["MXG_SPARSE_BATCH_KMERS"] = "600000"
+    recs = _repeat_rich_numpy(3, 4, 700_000)
+    st = _check(oracle, recs, 32, 500, cand_per_window=10)
+    assert st["deferred_stretches"] > 5 and st["batches_redone"] == 0 and st["sync_assemblies"] == 0
+    st2 = _check(oracle, recs, 32, 200, cand_per_window=6)
+    assert st2["deferred_stretches"] > 5
+    route_knobs["MXG_STRETCH_DENSE"] = "1"
+    st3 = _check(oracle, recs, 32, 500, cand_per_window=10)
+    assert st3["deferred_stretches"] == st["deferred_stretches"]
+
+
+def test_tile_borders_of_long_stretches(oracle, route_knobs):
+    """one record that is a single candidate-free stretch of many tiles (a 7-base unit repeated: 7 distinct k-mers, none below
+    the threshold at 2 candidates per window), another of a homopolymer (every k-mer equal): every tile border decides which
+    tile reports the minimizer the windows on both sides share"""
+    route_knobs["MXG_DEV_GAPS"] = "1"
+    rng = random.Random(9)
+    unit = "ACGGTCA"
+    recs = [("sat", unit * 3000), ("polyA", "A" * 9000),
+            ("mixed", "".join(rng.choice("ACGT") for _ in range(30000)) + "AC" * 4000 + "".join(rng.choice("ACGT") for _ in range(20000)))]
+    for w in (100, 1000, 2048):
+        st = _check(oracle, recs, 32, w, cand_per_window=2)
+        assert st["deferred_stretches"] > 0 or st["dense_kmers"] > 0
+
+
+def test_second_attempt_with_resized_batches(oracle, route_knobs):
+    """more stretches in a batch than the device route holds (forced: budget of 2 expected stretches per batch is what the
+    i.i.d. estimate plans for; the repeat-rich records hold hundreds): the assembly goes through the streams a second time with
+    batches cut for the density the first attempt met, and nothing is left to the synchronous route"""
+    route_knobs["MXG_DEV_GAPS"] = "1"
+    recs = _repeat_rich_numpy(4, 6, 900_000)
+    from ntjoin_amd.engine import MxEngine
+    with MxEngine(k=32, w=300, cand_per_window=8) as eng:
+        eng.add_records("x", 1.0, recs)
+        os.environ["MXG_SPARSE_BATCH_KMERS"] = "3000000"
+        eng.sketch()
+        st = eng.stats()
+        sk = eng.get_sketch(0)
+        # a second sketch of the same handle starts from what the first one learnt
+        eng.reset_timers()
+        eng.sketch()
+        st_warm = eng.stats()
+    for r, (rid, seq) in enumerate(recs):
+        lo, hi = int(sk["record_first"][r]), int(sk["record_first"][r + 1])
+        want = oracle.sketch(seq, 32, 300)
+        assert list(zip(sk["out_hash"][lo:hi].tolist(), sk["pos"][lo:hi].tolist())) == [(h, p) for h, p, _, _ in want], rid
+    if st["retried_assemblies"]:  # (the device route's capacity was exceeded: GAP_DEV_MAX stretches in a batch)
+        assert st["sync_assemblies"] == 0 and st["batches_redone"] == 0
+        assert st_warm["retried_assemblies"] == 0 and st_warm["batches_redone"] == 0
+
+
+def test_batches_redone_one_by_one(oracle, route_knobs):
+    """a batch that never reports (its grids sized below its candidate count: MXG_GRID_BY_ESTIMATE=2) is redone, with the
+    batches behind it, through the synchronous route -- after the second pipelined attempt, which sizes the grids in full"""
+    route_knobs["MXG_DEV_GAPS"] = "1"
+    route_knobs["MXG_SPARSE_BATCH_KMERS"] = "150000"
+    route_knobs["MXG_GRID_BY_ESTIMATE"] = "2"
+    st = _check(oracle, _records(41), 32, 200)
+    assert st["retried_assemblies"] + st["batches_redone"] + st["sync_assemblies"] > 0
