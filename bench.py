@@ -96,6 +96,20 @@ ISSUE_CYCLES = 2.0         # a wave64 VALU instruction occupies its SIMD for 2 c
 BS_CHUNK = 65536           # base positions per chunk of the bit-sliced filter (csrc/bs_kernels.h)
 
 
+KERNEL_SOURCES = ("sketch.hip", "sketch_bs.hip", "bs_kernels.h", "hash_bs_k32.inc", "nthash_dev.h", "scan_kernels.h", "graph.hip")
+
+
+def kernel_sources_digest():
+    """sha256 over the kernel sources: profile summaries under profiles/ carry the digest they were captured at, and a static
+    figure (PMC traffic) is only quoted while the kernels are still the ones that were profiled"""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(REPO, "ntjoin_amd", "csrc", f), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
 def bs_route():
     return os.environ.get("MXG_BS", "1") != "0"
 
@@ -244,8 +258,22 @@ def end_to_end(asms_host, w, td, threads):
     subprocess.check_call([sys.executable, "-m", "ntjoin_amd.run", "-p", os.path.join(td, "out"), "-n", "1", "-s", tsvs[-1], "-l", "1",
                            "-r", " ".join(["2"] * (len(tsvs) - 1)), "-k", str(K)] + tsvs[:-1], env=env, stdout=subprocess.DEVNULL)
     t_graph = time.perf_counter() - t1
+    two = {t: open(t, "rb").read(1 << 16) for t in tsvs}  # (heads of the two-process outputs, compared with the one-process ones)
+    dot_size = os.path.getsize(os.path.join(td, "out.mx.dot"))
+    for t in tsvs:
+        os.remove(t)
+    # the same job in ONE process (ntJoin-mx mxgraph's default recipe): FASTA -> TSVs + .mx.dot, one HIP initialisation, the graph
+    # stage on the sketches in HBM
+    one = os.path.join(REPO, "ntjoin_amd", "bin", "mxgraph")
+    t2 = time.perf_counter()
+    pr = subprocess.run([one, "-v", f"-k{K}", f"-w{w}", f"-t{threads}", "-p", os.path.join(td, "one"), "-s", fas[-1], "-l", "1",
+                         "-r", " ".join(["2"] * (len(fas) - 1))] + fas[:-1], check=True, stderr=subprocess.PIPE, text=True)
+    t_one = time.perf_counter() - t2
+    phases = next((ln.split("mxgraph: ", 1)[1] for ln in pr.stderr.splitlines() if "device + handle" in ln), None)
+    same = all(open(t, "rb").read(1 << 16) == two[t] for t in tsvs) and os.path.getsize(os.path.join(td, "one.mx.dot")) == dot_size
     bases = sum(int(l.sum()) for _, _, l in asms_host)
-    return {"bases": bases, "fasta_bytes": sizes, "t_sketch_cli": t_sketch, "t_graph_cli": t_graph,
+    return {"bases": bases, "fasta_bytes": sizes, "t_sketch_cli": t_sketch, "t_graph_cli": t_graph, "t_one_process": t_one,
+            "one_process_same_outputs": bool(same), "one_process_phases": phases,
             "tsv_bytes": sum(os.path.getsize(t) for t in tsvs), "dot_bytes": os.path.getsize(os.path.join(td, "out.mx.dot"))}
 
 
@@ -409,15 +437,20 @@ def main():
         step_alg_bytes = ALG_BYTES_PER_BASE_HASH * bases_total + ALG_BYTES_PER_MINIMIZER * float(st["minimizers"]) * world
         step_gbs = step_alg_bytes / (ms_step * 1e-3) / 1e9
         # PMC traffic of the hash kernel: only quoted when the committed counters were collected on THIS workload
-        traffic, traffic_src = None, None
+        traffic, traffic_src, tj_commit = None, None, None
         tpath = os.path.join(REPO, "profiles", "r03", "hbm_traffic.json")
         if os.path.exists(tpath) and bs_route():
             try:
                 tj = json.load(open(tpath))
+                tj_commit = tj.get("commit")
                 if tj.get("workload") == wl and abs(tj.get("mbp", 0) - mbp) < 1e-9 and not multi:
-                    traffic = round(tj["k_hash_bytes_per_base"] * st["hash_kernel_bases"] / launches)
-                    traffic_src = ("static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload at commit "
-                                   f"{tj.get('commit', '?')}, profiles/r03/hbm_traffic.json")
+                    if tj.get("kernel_sources_digest") == kernel_sources_digest():
+                        traffic = round(tj["k_hash_bytes_per_base"] * st["hash_kernel_bases"] / launches)
+                        traffic_src = ("static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload at commit "
+                                       f"{tj.get('commit', '?')}, profiles/r03/hbm_traffic.json")
+                    else:
+                        traffic_src = (f"stale: profiles/r03/hbm_traffic.json was captured at commit {tj.get('commit', '?')} and the "
+                                       "kernel sources have changed since; not quoted")
             except Exception:
                 traffic = None
         out = {
@@ -437,12 +470,14 @@ def main():
                                         "with a w-k-mer halo), ") +
                                        ("graph stage partitioned by hash range (RCCL all-to-all)" if graph_mode == "partitioned"
                                         else "RCCL all-gather of sketches, graph of the union on every rank"))},
+            "kernel_sources_digest": kernel_sources_digest(),
             "step_ms_min_max": [round(min(step_times) * 1e3, 4), round(max(step_times) * 1e3, 4)],
             "roofline": {"bound": "hbm",
                          "kernel": ("k_hash_bs (bit-sliced ntHash top rings + candidate filter, one launch per assembly)" if bs_route()
                                     else "k_hash_sparse (ntHash fwd/rc rings + candidate filter)"),
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_commit": tj_commit,
                          "alg_bytes_per_base": ALG_BYTES_PER_BASE_HASH, "alg_bytes_per_launch": int(bytes_per_launch),
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(st["launches_hash"]),
                          "timed": "HIP-event pair around every launch of the kernel inside the timed region, on the launch stream",
@@ -519,7 +554,10 @@ def main():
                 e2e = end_to_end(sample, W, td, min(n_cores(), 8))
                 t_all = e2e["t_sketch_cli"] + e2e["t_graph_cli"]
                 out["end_to_end"] = {
-                    "value": round(e2e["bases"] / t_all / 1e9, 4), "unit": "Gbp/s",
+                    "value": round(e2e["bases"] / e2e["t_one_process"] / 1e9, 4), "unit": "Gbp/s",
+                    "route": "one process (ntjoin_amd/bin/mxgraph = `ntJoin-mx mxgraph`): FASTA -> TSVs + .mx.dot, cold (HIP init included)",
+                    "seconds": round(e2e["t_one_process"], 3), "phases": e2e["one_process_phases"], "same_outputs_as_two_process_route": e2e["one_process_same_outputs"],
+                    "two_process_value": round(e2e["bases"] / t_all / 1e9, 4),
                     "sketch_only_value": round(e2e["bases"] / e2e["t_sketch_cli"] / 1e9, 4),
                     "boundary": "FASTA text in the page cache -> <asm>.k32.w%d.tsv (--seq --pos) + out.mx.dot on disk; cold processes "
                                 "(HIP init included): `indexlr` per assembly, then `python -m ntjoin_amd.run`" % W,

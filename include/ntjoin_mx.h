@@ -281,6 +281,13 @@ int mxg_get_graph(mxg_handle *h, mxg_graph_view *out);
 /* `.mx.dot` as Ntjoin.print_graph writes it (HEAD syntax); vertex/edge line order: vertices in first-assembly
    order, edges in first-seen order (the reference's own order is unspecified: python set order). */
 int mxg_write_dot(mxg_handle *h, const char *path);
+/* The text outputs of a whole run in one call: <prefix>.mx.dot (mxg_write_dot) formatted by the host workers WHILE the TSVs of
+   the assemblies (mxg_write_tsv with these flags; tsv_paths[a] == NULL: none for assembly a) are formatted on the device and
+   written out -- the two use different resources (host threads / GPU + one writer), so a run's text output takes the longer
+   of the two instead of their sum.  Same bytes as the separate calls.  Replaces the tail of reference ntJoin:204-205 (the
+   `> $@` of every indexlr recipe) and bin/ntjoin.py:25-67 (print_graph) when one process does both. */
+int mxg_write_outputs(mxg_handle *h, const char *dot_path, const char *const *tsv_paths, int with_pos, int with_strand,
+                      int with_seq);
 
 /* ---- next row: linear paths through the minimizer graph -------------------------------------------
    What the reference computes with igraph right after the graph (bin/ntjoin_assemble.py:759,779): filter_graph_global

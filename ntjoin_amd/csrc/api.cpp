@@ -909,6 +909,32 @@ int mxg_write_dot(mxg_handle *h, const char *path)
     }
 }
 
+int mxg_write_outputs(mxg_handle *h, const char *dot_path, const char *const *tsv_paths, int with_pos, int with_strand, int with_seq)
+{
+    if (!h || !dot_path || !tsv_paths) return MXG_EINVAL;
+    try {
+        int rc = graph_to_host(h);  // (device -> host copies on the handle's stream: before the TSV kernels use it)
+        if (rc != MXG_OK) return rc;
+        int rc_dot = MXG_OK;
+        std::thread dot([&]() {
+            try {
+                rc_dot = write_dot(h, dot_path);  // host arrays only from here on
+            } catch (const std::bad_alloc &) {
+                rc_dot = MXG_ENOMEM;
+            }
+        });
+        int rc_tsv = MXG_OK;
+        for (size_t a = 0; a < h->asms.size() && rc_tsv == MXG_OK; ++a)
+            if (tsv_paths[a]) rc_tsv = mxg_write_tsv(h, (int)a, tsv_paths[a], with_pos, with_strand, with_seq);
+        dot.join();
+        return rc_tsv != MXG_OK ? rc_tsv : rc_dot;
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_write_outputs");
+    } catch (const std::system_error &) {
+        return set_err(h, MXG_ENOMEM, "cannot start a writer thread");
+    }
+}
+
 static size_t copy_out(const std::string &r, char *buf, size_t cap)
 {
     if (buf && cap) {

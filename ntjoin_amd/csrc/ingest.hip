@@ -742,7 +742,7 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
         MXG_HIP(h, hipMemsetAsync(d_off.p, 0, 8, st));
     }
     const uint64_t total = pre + total_entries;
-    FILE *f = strcmp(path, "-") == 0 ? stdout : fopen(path, "wb");
+    FILE *f = strcmp(path, "-") == 0 ? stdout : fopen(path, "w+b");  // (read access too: put_parallel maps the file)
     if (!f) return set_err(h, MXG_EIO, "cannot open '%s' for writing", path);
     const int ofd = fileno(f);
     fflush(f);
@@ -803,14 +803,26 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
             break;
         }
         const uint64_t bytes = std::min(total, (c + 1) * WIN) - c * WIN;
-        uint64_t done = 0;
-        while (done < bytes) {
-            const ssize_t wr = write(ofd, pin[b] + done, bytes - done);
-            if (wr <= 0) {
-                ok = false;
-                break;
+        if (f == stdout) {  // (a pipe or the shell's redirection: in order, at the descriptor's own position)
+            uint64_t done = 0;
+            while (done < bytes) {
+                const ssize_t wr = write(ofd, pin[b] + done, bytes - done);
+                if (wr <= 0) {
+                    ok = false;
+                    break;
+                }
+                done += (uint64_t)wr;
             }
-            done += (uint64_t)wr;
+        } else {  // the window in `-t` parts, copied into the file's pages side by side
+            const uint32_t T = (uint32_t)std::min<uint64_t>(std::min(16u, std::max(1u, host_threads(h))), (bytes + (1u << 20) - 1) >> 20);
+            const char *src[16];
+            size_t len[16];
+            for (uint32_t t = 0; t < T; ++t) {
+                const uint64_t lo = bytes * t / T, hi = bytes * (t + 1) / T;
+                src[t] = pin[b] + lo;
+                len[t] = hi - lo;
+            }
+            ok = put_parallel(ofd, c * WIN, src, len, T);
         }
         if (!ok) break;
     }

@@ -265,6 +265,8 @@ int write_tsv(mxg_handle *h, Assembly *a, const char *path, int with_pos, int wi
 int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_threads);
 int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos, int with_strand, int with_seq);
 uint32_t host_threads(const mxg_handle *h);
+// n_parts byte ranges written to fd at consecutive offsets from `off` on, by that many threads (host_io.cpp)
+bool put_parallel(int fd, uint64_t off, const char *const *data, const size_t *len, uint32_t n_parts);
 int write_dot(mxg_handle *h, const char *path);
 void build_rec_first(Assembly *a);
 std::string py_repr_str(const std::string &s);

@@ -7,24 +7,25 @@ GPU and write <prefix>.mx.dot, exactly the state the reference has after `make_m
 reference's Python and is out of scope here; flags that only matter downstream are accepted and ignored.
 """
 import argparse
-import re
 import sys
 
 from .ntjoin import Ntjoin
 
 
 def parse_arguments(argv=None):
+    """same flag names, defaults and required-ness as the reference's parser (bin/ntjoin_run.py:10-60), so that its Makefile
+    recipe runs unchanged; the descriptions are ours"""
     parser = argparse.ArgumentParser(description="ntJoin hot path on MI355X: minimizer TSVs -> <prefix>.mx.dot")
-    parser.add_argument("FILES", nargs="+", help="Minimizer TSV files of references")
-    parser.add_argument("-s", help="Target scaffolds minimizer TSV file", required=True)
-    parser.add_argument("-l", help="Weight of target genome assembly [1]", required=False, default=1, type=float)
-    parser.add_argument("-r", help="List of reference assembly weights (in quotes, separated by spaces, "
-                                   "in same order as minimizer TSV files)", required=True, type=str)
-    parser.add_argument("-p", help="Output prefix [out]", default="out", type=str, required=False)
-    parser.add_argument("-n", help="Minimum edge weight [1]", default=1, type=int)
-    parser.add_argument("-k", help="Kmer size used for minimizer step", required=True, type=int)
-    parser.add_argument("-g", help="Minimum gap size (bp)", required=False, default=20, type=int)
-    parser.add_argument("-G", help="Maximum gap size (bp) (0 if no maximum threshold)", required=False, default=0, type=int)
+    parser.add_argument("FILES", nargs="+", help="sketches of the reference assemblies (indexlr TSVs), in the order their weights are given")
+    parser.add_argument("-s", required=True, help="sketch (indexlr TSV) of the assembly to be scaffolded")
+    parser.add_argument("-l", required=False, default=1, type=float, help="edge weight contributed by the target assembly (default 1)")
+    parser.add_argument("-r", required=True, type=str, help="one edge weight per reference, blank-separated inside one quoted argument")
+    parser.add_argument("-p", default="out", type=str, required=False, help="prefix of the files written (default: out)")
+    parser.add_argument("-n", default=1, type=int, help="edges lighter than this are dropped downstream (default 1; not used by the graph build)")
+    parser.add_argument("-k", required=True, type=int, help="the k the sketches were computed with")
+    parser.add_argument("-g", required=False, default=20, type=int, help="downstream only: smallest gap written between joined pieces")
+    parser.add_argument("-G", required=False, default=0, type=int, help="downstream only: largest gap allowed, 0 = unlimited")
+    # flags of the stages behind the graph build: accepted so that the reference's command line parses, otherwise unused here
     parser.add_argument("--mkt", action="store_true")
     parser.add_argument("-m", type=int, default=50, required=False)
     parser.add_argument("-t", type=int, default=1)
@@ -40,15 +41,14 @@ def parse_arguments(argv=None):
 
 
 def set_weights(args):
-    "Parse the supplied weights (reference bin/ntjoin_assemble.py:788-797)"
-    weights = [float(w) for w in re.split(r"\s+", args.r.strip())]
-    if len(weights) != len(args.FILES):
-        print("ERROR: The length of supplied reference weights (-r) and "
-              "number of assembly minimizer TSV inputs must be equal.")
-        print("Supplied lengths of arguments:")
-        print("Weights (-r):", len(weights), "Minimizer TSV files:", len(args.FILES), sep=" ")
-        sys.exit(1)
-    return weights
+    """-r as a list of floats, one per reference TSV; a count mismatch ends the run with status 1, as in the reference
+    (bin/ntjoin_assemble.py:788-797: same condition, same exit status)"""
+    weights = [float(tok) for tok in args.r.split()]
+    if len(weights) == len(args.FILES):
+        return weights
+    sys.stdout.write(f"ERROR: -r lists {len(weights)} weight(s) but {len(args.FILES)} reference sketch file(s) were given; "
+                     "there must be exactly one weight per reference, in the same order.\n")
+    sys.exit(1)
 
 
 def main(argv=None):

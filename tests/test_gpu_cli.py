@@ -67,6 +67,43 @@ def test_make_front_end_mxgraph(tmp_path):
     assert go.canonical_dot_from_text((tmp_path / "out.mx.dot").read_text(encoding="utf-8")) == want
 
 
+@pytest.mark.parametrize("case_name", ["f-f-f_w100_weights", "f-f_w1000", "f-f_termN_w1000", "gap-dist_w500"])
+def test_one_process_route_is_byte_identical_to_the_two_process_route(tmp_path, case_name):
+    """`ntJoin-mx mxgraph` in one process (ntjoin_amd/bin/mxgraph: FASTA -> TSVs + .mx.dot, sketches never leave HBM) against the
+    reference's two steps (`indexlr` per assembly, then the graph stage on the parsed TSVs): the same bytes in every TSV and in
+    the .mx.dot"""
+    meta = load_case(case_name)["meta"]
+    outs = {}
+    for mode in ("True", "False"):
+        d = tmp_path / mode
+        d.mkdir()
+        for a in meta["refs"] + [meta["target"]]:
+            shutil.copy(os.path.join(FASTA, a["fasta"]), d / a["fasta"])
+        refs = " ".join(a["fasta"] for a in meta["refs"])
+        wts = " ".join(str(a["weight"]) for a in meta["refs"])
+        subprocess.check_call(["make", "-f", os.path.join(REPO, "ntJoin-mx"), "mxgraph", f"target={meta['target']['fasta']}",
+                               f"target_weight={meta['target']['weight']}", f"references={refs}", f"reference_weights={wts}",
+                               f"k={meta['k']}", f"w={meta['w']}", "prefix=out", f"mx_one_process={mode}"], cwd=d)
+        outs[mode] = d
+    for a in meta["refs"] + [meta["target"]]:
+        assert filecmp.cmp(str(outs["True"] / a["tsv"]), str(outs["False"] / a["tsv"]), shallow=False)
+    assert filecmp.cmp(str(outs["True"] / "out.mx.dot"), str(outs["False"] / "out.mx.dot"), shallow=False)
+    assert os.path.getsize(outs["True"] / "out.mx.dot") > 100
+
+
+def test_mxgraph_cli_failures_are_loud(tmp_path):
+    exe = os.path.join(REPO, "ntjoin_amd", "bin", "mxgraph")
+    fa = tmp_path / "a.fa"
+    fa.write_text(">x\n" + "ACGT" * 100 + "\n")
+    r = subprocess.run([exe, "-k", "32", "-w", "10", "-s", str(fa), "-r", "1 2", str(fa)], capture_output=True, text=True)
+    assert r.returncode == 1 and "one weight per reference" in r.stdout          # the reference's check and exit status
+    r = subprocess.run([exe, "-k", "32", "-w", "10", "-s", str(tmp_path / "missing.fa"), "-r", "1", str(fa)], capture_output=True, text=True)
+    assert r.returncode == 1 and "missing.fa" in r.stderr
+    assert not (tmp_path / "out.mx.dot").exists()
+    r = subprocess.run([exe, "-k", "32"], capture_output=True, text=True)
+    assert r.returncode == 2
+
+
 def test_python_mirror_functions(tmp_path):
     """read_minimizers / filter_minimizers / build_graph counterparts return what the reference's returned"""
     from ntjoin_amd import ntjoin_utils as nu
@@ -185,7 +222,7 @@ def test_make_j_concurrent_indexlr_instances_and_log_time(tmp_path):
     wts = " ".join(str(a["weight"]) for a in meta["refs"])
     subprocess.check_call(["make", "-j", "8", "-f", os.path.join(REPO, "ntJoin-mx"), "mxgraph", f"target={meta['target']['fasta']}",
                            f"target_weight={meta['target']['weight']}", f"references={refs}", f"reference_weights={wts}",
-                           f"k={meta['k']}", f"w={meta['w']}", "prefix=out", "time=True"], cwd=tmp_path, env=env)
+                           f"k={meta['k']}", f"w={meta['w']}", "prefix=out", "time=True", "mx_one_process=False"], cwd=tmp_path, env=env)
     for a in asms:
         assert filecmp.cmp(str(tmp_path / a["tsv"]), os.path.join(GOLDEN, "cases", meta["name"], a["tsv"]), shallow=False)
         assert (tmp_path / (a["tsv"] + ".time")).read_text().startswith("ran: ")
