@@ -6,6 +6,10 @@ Graph(), add_vertices, add_edges, get_eid, vs / vs(), es / es(), es()[attr] = li
 subgraph, incident, neighbors, get_shortest_paths, Vertex.degree().  Semantics follow igraph's documented behaviour:
 undirected simple graph, an edge is reported as (lower vertex id, higher vertex id), subgraph() renumbers vertices
 and edges preserving their relative order, components() lists components by their lowest vertex id.
+The contracts it models (C1-C8: edge tuples low/high in insertion order; edge ids compact after delete_edges; subgraph renumbers in
+ascending original id; components by lowest vertex; unique shortest path on a chain / tree, empty when unreachable; get_eid either
+way round and by name; degree / incident / neighbors consistent after deletions; element-wise attribute assignment, deep copy) are
+listed with their igraph documentation references in tests/test_igraph_standin_cpu.py, which checks each on random graphs.
 """
 import sys
 import types

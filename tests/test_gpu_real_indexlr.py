@@ -49,3 +49,49 @@ def test_tsv_equals_real_indexlr(tmp_path, k, w):
         theirs = subprocess.run([REAL, "--pos", "--strand", "-k", str(k), "-w", str(w), fa], capture_output=True, check=True).stdout
         ours = subprocess.run([OURS, "--pos", "--strand", "-k", str(k), "-w", str(w), fa], capture_output=True, check=True).stdout
         assert ours == theirs, ("--strand", os.path.basename(fa))
+
+
+def _dropped_in_tsvs():
+    """TSVs produced ELSEWHERE by a real indexlr: tests/golden/real_indexlr/<fasta>.k<k>.w<w>[.strand].tsv (see the README
+    there), or the same names in the directory MXG_REAL_INDEXLR_TSV_DIR points at"""
+    import re
+    out = []
+    for d in (os.environ.get("MXG_REAL_INDEXLR_TSV_DIR"), os.path.join(GOLDEN, "real_indexlr")):
+        if not d or not os.path.isdir(d):
+            continue
+        for f in sorted(os.listdir(d)):
+            m = re.fullmatch(r"(.+\.fa)\.k(\d+)\.w(\d+)(\.strand)?\.tsv", f)
+            if m:
+                out.append((os.path.join(d, f), m.group(1), int(m.group(2)), int(m.group(3)), bool(m.group(4))))
+    return out
+
+
+DROPPED = _dropped_in_tsvs()
+
+
+@pytest.mark.skipif(not DROPPED, reason="no TSV from a real indexlr in tests/golden/real_indexlr/ or $MXG_REAL_INDEXLR_TSV_DIR")
+@pytest.mark.parametrize("path,fasta,k,w,strand", DROPPED or [(None, None, 0, 0, False)])
+def test_tsv_equals_files_from_a_real_indexlr(path, fasta, k, w, strand):
+    fa = next((p for p in (os.path.join(GOLDEN, "fasta", fasta), os.path.join(GOLDEN, "real_indexlr", fasta)) if os.path.exists(p)), None)
+    assert fa is not None, f"{fasta}: no such FASTA under tests/golden/"
+    flags = ["--pos", "--strand"] if strand else ["--seq", "--long", "--pos", "-t", "2"]
+    ours = subprocess.run([OURS] + flags + ["-k", str(k), "-w", str(w), fa], capture_output=True, check=True).stdout
+    with open(path, "rb") as fh:
+        assert ours == fh.read(), os.path.basename(path)
+
+
+def test_the_unpinned_shapes_are_sketched_like_the_oracle(oracle, tmp_path):
+    """until a real indexlr's output is dropped in, the committed shapes file is at least pinned to the oracle's reading of
+    btllib: upper/lower case and U are bases, IUPAC codes and N break k-mers, short records yield nothing"""
+    from tests import _oracle
+    fa = os.path.join(GOLDEN, "real_indexlr", "unpinned_shapes.fa")
+    for k, w in ((32, 100), (15, 10)):
+        out = tmp_path / f"o.{k}.{w}.tsv"
+        subprocess.run([OURS, "--pos", "-k", str(k), "-w", str(w), "-o", str(out), fa], check=True)
+        got = {}
+        for line in out.read_text().splitlines():
+            rid, _, rest = line.partition("\t")
+            got[rid] = [(int(x.split(":")[0]), int(x.split(":")[1])) for x in rest.split()] if rest else []
+        for rid, seq in _oracle.read_fasta(fa):
+            want = [(h, p) for h, p, _, _ in oracle.sketch(seq, k, w)]
+            assert got.get(rid, []) == want, (rid, k, w)
