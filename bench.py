@@ -277,6 +277,82 @@ def end_to_end(asms_host, w, td, threads):
             "tsv_bytes": sum(os.path.getsize(t) for t in tsvs), "dot_bytes": os.path.getsize(os.path.join(td, "out.mx.dot"))}
 
 
+XGMI_LINK_GBS = 153.0 * 0.5   # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, both directions)
+
+
+def dry_run(args):
+    """bench.py --gpus N --dry on one GPU: rank r = 0..N-1 of the N-GPU workload one after the other, each at its real share
+    (configs[4] for N = 8: 1/8 of the bases of both assemblies = 5 Gbp per rank), sketch stage timed for real; the exchange is
+    priced from the counts (16 B per minimizer to its hash's owner, 8 B verdict back, 16 B per adjacency message to each end
+    point's owner; (N-1)/N of it leaves the rank, spread over N-1 links); the owner's graph work is taken as the graph stage on
+    this rank's own minimizers (the same number of keys and records, not the same keys)."""
+    import torch
+    from ntjoin_amd.engine import MxEngine
+    N = args.gpus
+    if N < 2 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        sys.exit("bench.py --dry: one process, --gpus N >= 2")
+    torch.cuda.set_device(0)
+    wl = args.workload if args.workload != "auto" else {2: "configs2", 4: "configs3", 8: "configs4"}.get(N, "configs2")
+    W = args.w or (500 if wl == "configs3" else 1000)
+    mbp = args.mbp or {"configs1": 100.0, "configs2": 3000.0, "configs3": 3000.0, "configs4": 20000.0}[wl]
+    cfg, asms, label = workload_tables(wl, mbp, W, seed=1)
+    bases_job = sum(int(a[2][:, 2].sum()) for a in asms)
+    ranks = []
+    for r in range(N):
+        eng = MxEngine(k=K, w=W, device=0, timing=True, timing_fine=True, cand_per_window=args.cand)
+        keep = [add_rank_share(eng, name, weight, segs, cfg["seed"], sub_seed, sub, r, N, 0)[0] for name, weight, segs, _, sub, sub_seed in asms]
+        eng.global_records = True
+        for _ in range(max(args.warmup, 1)):
+            eng.sketch(-2)
+            eng.build_graph()
+        eng.reset_timers()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.sketch(-2)
+        torch.cuda.synchronize()
+        t_sk = (time.perf_counter() - t0) / args.steps * 1e3
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.build_graph()
+        torch.cuda.synchronize()
+        t_gr = (time.perf_counter() - t1) / args.steps * 1e3
+        st = eng.stats()
+        # shared minimizers on this rank: the job's vertex count x assemblies / minimizers, from the committed one-GPU run of the
+        # same workload when there is one (a rank's own two shares are different stretches of the genome: its own graph says nothing)
+        frac = 0.75
+        try:
+            one = json.loads(open(os.path.join(REPO, "profiles", "r03", f"bench_{wl}.json")).read().strip().splitlines()[-1])
+            frac = one["config"]["vertices"] * len(asms) / max(one["config"]["minimizers"], 1)
+        except Exception:
+            pass
+        m = int(st["minimizers"])
+        shared = int(frac * m)
+        out_frac = (N - 1) / N
+        sent = {"items": int(16 * m * out_frac), "verdicts": int(8 * m * out_frac), "adjacency_messages": int(2 * 16 * shared * out_frac)}  # one message to each end point's owner
+        per_link = sum(sent.values()) / (N - 1)
+        ranks.append({"rank": r, "bases": int(st["bases"]), "minimizers": m, "sketch_ms": round(t_sk, 3), "graph_stage_on_own_minimizers_ms": round(t_gr, 3),
+                      "kernel_ms_per_step": {"filter": round(st["ms_hash"] / args.steps, 3), "count+reorder": round(st["ms_reorder"] / args.steps, 3),
+                                             "resolve+stretches": round(st["ms_resolve_kernel"] / args.steps, 3), "emit": round(st["ms_emit"] / args.steps, 3),
+                                             "join": round(st["ms_join"] / args.steps, 3), "vertices": round(st["ms_vertices"] / args.steps, 3),
+                                             "edges": round(st["ms_edges"] / args.steps, 3)},
+                      "bytes_sent_per_step": sent, "exchange_ms_at_link_rate": round(per_link / (XGMI_LINK_GBS * 1e9) * 1e3, 3)})
+        eng.close()
+        del keep
+        torch.cuda.empty_cache()
+    step_ms = max(x["sketch_ms"] + x["graph_stage_on_own_minimizers_ms"] + x["exchange_ms_at_link_rate"] for x in ranks) + 6 * 0.03
+    out = {"metric": f"PREDICTION of Gbp/s minimizer-sketch+graph-build (k=32,w={W}) on {N} GPUs, from one GPU playing every rank in turn",
+           "value": round(bases_job / (step_ms * 1e-3) / 1e9, 2), "unit": "Gbp/s", "n_gpus": N, "dry": True, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(step_ms, 3), "higher_is_better": True, "data": "synthetic", "dtype": "u64",
+           "config": {"workload": label + f", rank shares of 1/{N} of every assembly's bases", "bases_per_step": int(bases_job)},
+           "model": "step = max over ranks of (sketch stage + exchange bytes / (N-1) links at "
+                    f"{XGMI_LINK_GBS:g} GB/s per link and direction + graph stage on as many minimizers as the rank owns) + 6 collectives x 30 us; "
+                    "the five host syncs of the exact partitioned exchange are inside the measured stages' own syncs or not modelled",
+           "ranks": ranks}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,7 +367,13 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall-time budget of the cpu_baseline sample")
     ap.add_argument("--e2e-mbp", type=float, default=0.0, help="end-to-end sample: Mbp per assembly (0 = the whole workload)")
     ap.add_argument("--cand", type=int, default=0, help="candidates per window for the sparse path (0 = library default)")
+    ap.add_argument("--dry", action="store_true",
+                    help="with --gpus N on ONE GPU and one process: play every rank's share of the N-GPU workload in turn (real sizes, real "
+                         "kernels, no collective) and print the per-rank kernel times, the bytes each rank would send and the step time "
+                         "they predict -- a prediction to hold the first real N-GPU run against, never a measurement of it")
     args = ap.parse_args()
+    if args.dry:
+        return dry_run(args)
 
     import torch
     import torch.distributed as dist

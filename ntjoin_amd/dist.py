@@ -79,6 +79,39 @@ def gather_sketches(local, n_records_local, group=None):
             "forward": cat(fs, torch.uint8), "n_records": rec_off, "record_offset": my_off, "counts": counts}
 
 
+def all_gather_strings(strings, dev, group=None):
+    """every rank's list of strings -> [list of rank 0, list of rank 1, ...] with two tensor collectives (lengths, then the
+    length-prefixed bytes padded to the longest), instead of all_gather_object's pickling + per-object size exchange: record
+    ids are the only Python objects this module ever sent, and at 5 x 10^5 contigs per assembly their pickles were the
+    largest host-side cost of a first step.  `dev`: where the backend wants its tensors (the GPU for RCCL, the CPU for gloo)."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":
+        dev = torch.device("cpu")
+    enc = [s.encode("utf-8") for s in strings]
+    lens = np.fromiter((len(b) for b in enc), dtype=np.uint32, count=len(enc))
+    blob = lens.tobytes() + b"".join(enc)
+    head = torch.tensor([len(enc), len(blob)], dtype=torch.int64, device=dev)
+    heads = torch.empty((world, 2), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(heads.view(-1), head, group=group)
+    heads = heads.cpu().numpy()
+    cap = int(heads[:, 1].max())
+    mine = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
+    if blob:
+        mine[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    every = torch.empty((world, max(cap, 1)), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(every.view(-1), mine, group=group)
+    every = every.cpu().numpy()
+    out = []
+    for r in range(world):
+        n, nb = int(heads[r, 0]), int(heads[r, 1])
+        raw = every[r, :nb].tobytes()
+        ln = np.frombuffer(raw[:4 * n], dtype=np.uint32)
+        ends = 4 * n + np.cumsum(ln.astype(np.int64))
+        starts = ends - ln
+        out.append([raw[int(a):int(b)].decode("utf-8") for a, b in zip(starts, ends)])
+    return out
+
+
 def shard_records(lengths, world):
     """Greedy longest-processing-time assignment of records (by base count) to ranks, then restored to input
     order inside each rank: returns a list (per rank) of record indices.  Contigs shard naturally."""
@@ -139,8 +172,7 @@ def _allgather_union_graph(eng, k, w, device, union, group, stream):
                 flat = eng.record_ids(a, eng.n_records(a))
             else:
                 ids_local = [f"r{rank}:{x}" for x in eng.record_ids(a, eng.n_records(a))]
-                all_ids = [None] * world
-                dist.all_gather_object(all_ids, ids_local, group=group)
+                all_ids = all_gather_strings(ids_local, dev, group)
                 flat = [x for part in all_ids for x in part]
             union.add_minimizers(eng.assembly_name(a), eng.assembly_weight(a), np.zeros(0, np.uint64),
                                  np.zeros(0, np.uint32), np.zeros(0, np.uint32), flat)
@@ -320,8 +352,7 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
                 flat = eng.record_ids(a, eng.n_records(a))
             else:
                 ids_local = [f"r{rank}:{x}" for x in eng.record_ids(a, eng.n_records(a))]
-                all_ids = [None] * world
-                dist.all_gather_object(all_ids, ids_local, group=group)
+                all_ids = all_gather_strings(ids_local, dev, group)
                 owner._rec_off.append(sum(len(p) for p in all_ids[:rank]))
                 flat = [x for part in all_ids for x in part]
             owner.add_minimizers(eng.assembly_name(a), eng.assembly_weight(a), np.zeros(0, np.uint64), np.zeros(0, np.uint32),

@@ -69,6 +69,44 @@ def test_gather_sketches_gloo(world):
         assert g["counts"] == [l["out_hash"].numel() for l, _ in locs]
 
 
+def _ids_of(rank):
+    rng = np.random.default_rng(7 + rank)
+    n = [0, 5, 2000, 3][rank % 4]
+    return [f"r{rank}:" + "".join(chr(int(c)) for c in rng.integers(33, 127, size=int(rng.integers(0, 40)))) + ("_é" if i % 7 == 0 else "")
+            for i in range(n)]
+
+
+def _worker_ids(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ntjoin_amd.dist import all_gather_strings
+    got = all_gather_strings(_ids_of(rank), torch.device("cpu"))
+    q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_record_ids_travel_as_length_prefixed_bytes(world):
+    """the record ids of the exchange step (the only strings it moves): two tensor collectives instead of all_gather_object;
+    empty lists, empty strings, non-ASCII ids, lists of very different sizes"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ids, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [_ids_of(r) for r in range(world)]
+    for r in range(world):
+        assert results[r] == want
+
+
 def test_shard_records_balanced():
     from ntjoin_amd.dist import shard_records
     rng = np.random.default_rng(0)
