@@ -281,6 +281,16 @@ int mxg_get_graph(mxg_handle *h, mxg_graph_view *out);
 /* `.mx.dot` as Ntjoin.print_graph writes it (HEAD syntax); vertex/edge line order: vertices in first-assembly
    order, edges in first-seen order (the reference's own order is unspecified: python set order). */
 int mxg_write_dot(mxg_handle *h, const char *path);
+/* The .mx.dot written by several processes that each hold the WHOLE graph (one process per GPU, union route): part `part` of
+   `n_parts` = the vertex lines [nv part / n, nv (part + 1) / n) and the edge lines likewise.  mxg_dot_part_format formats the
+   part's two segments into memory and reports their sizes (bytes[0] vertices, bytes[1] edges); the caller exchanges the sizes
+   (one small all-gather) and every process writes its segments at
+       v_off = 10 + sum of bytes[0] of the parts before it,   e_off = 10 + sum of ALL bytes[0] + sum of bytes[1] of the parts before it
+   (10 = strlen("graph G {\n"), written by the part with first != 0; the part with last != 0 appends "}\n").  The file must not
+   be truncated by anybody after the first write.  Together the parts are byte for byte what mxg_write_dot writes.
+   No counterpart in the reference (bin/ntjoin.py:25-67 is one process). */
+int mxg_dot_part_format(mxg_handle *h, uint32_t part, uint32_t n_parts, uint64_t bytes[2]);
+int mxg_dot_part_write(mxg_handle *h, const char *path, uint64_t v_off, uint64_t e_off, int first, int last);
 /* The text outputs of a whole run in one call: <prefix>.mx.dot (mxg_write_dot) formatted by the host workers WHILE the TSVs of
    the assemblies (mxg_write_tsv with these flags; tsv_paths[a] == NULL: none for assembly a) are formatted on the device and
    written out -- the two use different resources (host threads / GPU + one writer), so a run's text output takes the longer

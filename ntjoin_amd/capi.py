@@ -19,7 +19,7 @@ SYMBOLS = [
     "mxg_record_id", "mxg_record_length", "mxg_num_records", "mxg_assembly_weight",
     "mxg_sketch", "mxg_sketch_graph", "mxg_get_sketch", "mxg_get_sketch_device", "mxg_compute_strands", "mxg_set_sketch_device",
     "mxg_pack_sketch_device", "mxg_set_sketch_gathered", "mxg_set_sketch_gathered_strided", "mxg_write_tsv",
-    "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_path_segments", "mxg_mx_extremes", "mxg_dg_owner_counts", "mxg_dg_pack_items", "mxg_dg_set_items", "mxg_dg_vertices", "mxg_dg_item_results", "mxg_dg_msg_counts", "mxg_dg_pack_msgs", "mxg_dg_edges", "mxg_dg_pack_slots", "mxg_dg_owner_slots", "mxg_dg_slot_results", "mxg_dg_pack_msg_slots", "mxg_dg_edges_slots", "mxg_write_dot", "mxg_write_outputs",
+    "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_path_segments", "mxg_mx_extremes", "mxg_dg_owner_counts", "mxg_dg_pack_items", "mxg_dg_set_items", "mxg_dg_vertices", "mxg_dg_item_results", "mxg_dg_msg_counts", "mxg_dg_pack_msgs", "mxg_dg_edges", "mxg_dg_pack_slots", "mxg_dg_owner_slots", "mxg_dg_slot_results", "mxg_dg_pack_msg_slots", "mxg_dg_edges_slots", "mxg_write_dot", "mxg_write_outputs", "mxg_dot_part_format", "mxg_dot_part_write",
     "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers",
     "mxg_synth_fill_packed_device", "mxg_synth_fill_packed_host", "mxg_synth_write_fasta",
     "mxg_plan_split", "mxg_add_assembly_packed_device_pieces", "mxg_dg_last_shared", "mxg_dg_set_ghosts",
@@ -188,6 +188,8 @@ def load():
     L.mxg_dg_edges_slots.argtypes = [vp, vp, C.c_uint32, C.c_uint32, pu64, pu64, pu32]
     L.mxg_write_dot.argtypes = [vp, cp]
     L.mxg_write_outputs.argtypes = [vp, cp, C.POINTER(cp), i32, i32, i32]
+    L.mxg_dot_part_format.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.mxg_dot_part_write.argtypes = [vp, cp, u64, u64, i32, i32]
     L.mxg_py_repr_double.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
     L.mxg_py_repr_double.restype = C.c_size_t
     L.mxg_py_repr_str.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]

@@ -909,6 +909,24 @@ int mxg_write_dot(mxg_handle *h, const char *path)
     }
 }
 
+int mxg_dot_part_format(mxg_handle *h, uint32_t part, uint32_t n_parts, uint64_t bytes[2])
+{
+    if (!h || !bytes) return MXG_EINVAL;
+    try {
+        int rc = graph_to_host(h);
+        if (rc != MXG_OK) return rc;
+        return dot_part_format(h, part, n_parts, bytes);
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_dot_part_format");
+    }
+}
+
+int mxg_dot_part_write(mxg_handle *h, const char *path, uint64_t v_off, uint64_t e_off, int first, int last)
+{
+    if (!h || !path) return MXG_EINVAL;
+    return dot_part_write(h, path, v_off, e_off, first, last);
+}
+
 int mxg_write_outputs(mxg_handle *h, const char *dot_path, const char *const *tsv_paths, int with_pos, int with_strand, int with_seq)
 {
     if (!h || !dot_path || !tsv_paths) return MXG_EINVAL;

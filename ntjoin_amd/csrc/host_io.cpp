@@ -2,6 +2,7 @@
 // TSV / .mx.dot writers.  Text formats follow the reference exactly:
 //   TSV grammar           ntJoin:205 (`indexlr --seq --long --pos`), parsed at bin/ntjoin_utils.py:173-185
 //   .mx.dot grammar       bin/ntjoin.py:25-62 (python repr() of (contig,pos) tuples and float weights)
+#include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -937,22 +938,22 @@ int write_tsv(mxg_handle *h, Assembly *a, const char *path, int with_pos, int wi
     return MXG_OK;
 }
 
-int write_dot(mxg_handle *h, const char *path)
-{
-    const Graph &g = h->graph;
-    if (!g.valid) return set_err(h, MXG_EINVAL, "mxg_write_dot: call mxg_build_graph first");
-    static const char *COLOURS[10] = {"red",       "green", "blue",   "purple", "orange",
-                                      "turquoise", "pink",  "yellow", "orchid", "salmon"};
-    const uint32_t A = g.n_asm;
-    FILE *f = fopen(path, "w+b");  // (read access too: the workers fill a shared mapping, put_parallel)
-    if (!f) return set_err(h, MXG_EIO, "cannot open '%s' for writing", path);
-    // label line per assembly: f"{file_name}_{(contig, pos)}"  (bin/ntjoin.py:43-47); python repr() of every record id once
-    std::vector<std::vector<std::string>> rec_repr(A);
-    for (uint32_t a = 0; a < A; ++a) {
-        rec_repr[a].resize(h->asms[a]->recs.size());
-        for (size_t r = 0; r < rec_repr[a].size(); ++r) rec_repr[a][r] = py_repr_str(h->asms[a]->recs[r].id);
+// the text of the .mx.dot: vertex lines and edge lines of the host copy of the graph (reference bin/ntjoin.py:25-67)
+struct DotText {
+    const mxg_handle *h;
+    const Graph &g;
+    uint32_t A;
+    std::vector<std::vector<std::string>> rec_repr;  // python repr() of every record id, once
+    explicit DotText(const mxg_handle *h_) : h(h_), g(h_->graph), A(h_->graph.n_asm), rec_repr(h_->graph.n_asm)
+    {
+        for (uint32_t a = 0; a < A; ++a) {
+            rec_repr[a].resize(h->asms[a]->recs.size());
+            for (size_t r = 0; r < rec_repr[a].size(); ++r) rec_repr[a][r] = py_repr_str(h->asms[a]->recs[r].id);
+        }
     }
-    auto vertices = [&](uint64_t v0, uint64_t v1, OutBuf &o) {
+    // label line per assembly: f"{file_name}_{(contig, pos)}"  (bin/ntjoin.py:43-47)
+    void vertices(uint64_t v0, uint64_t v1, OutBuf &o) const
+    {
         for (uint64_t v = v0; v < v1; ++v) {
             o.put('"');
             o.put_u64(g.vhash[v]);
@@ -969,8 +970,11 @@ int write_dot(mxg_handle *h, const char *path)
             }
             o.put("\"]\n", 3);
         }
-    };
-    auto edges = [&](uint64_t e0, uint64_t e1, OutBuf &o) {
+    }
+    void edges(uint64_t e0, uint64_t e1, OutBuf &o) const
+    {
+        static const char *COLOURS[10] = {"red",       "green", "blue",   "purple", "orange",
+                                          "turquoise", "pink",  "yellow", "orchid", "salmon"};
         for (uint64_t e = e0; e < e1; ++e) {
             o.put('"');
             o.put_u64(g.vhash[g.eu[e]]);
@@ -988,7 +992,83 @@ int write_dot(mxg_handle *h, const char *path)
             o.put(col, strlen(col));
             o.put("]\n", 2);
         }
+    }
+};
+
+// One part of the .mx.dot, for runs in which every rank holds the whole graph (the union route of ntjoin_amd/dist.py): part p of
+// n takes the vertex lines [nv p / n, nv (p + 1) / n) and the edge lines likewise.  The file is "graph G {\n", every part's vertex
+// segment, every part's edge segment, "}\n": a part's two segments are formatted into memory first (their sizes decide where
+// everybody's segments go), then written at the offsets the caller computed from all parts' sizes.
+int dot_part_format(mxg_handle *h, uint32_t part, uint32_t n_parts, uint64_t bytes[2])
+{
+    const Graph &g = h->graph;
+    if (!g.valid || !g.host_valid) return set_err(h, MXG_EINVAL, "mxg_dot_part_format: no graph on the host");
+    if (n_parts == 0 || part >= n_parts) return set_err(h, MXG_EINVAL, "mxg_dot_part_format: part out of range");
+    const DotText dt(h);
+    const uint32_t T = std::min(64u, std::max(1u, host_threads(h)));
+    for (int seg = 0; seg < 2; ++seg) {
+        const uint64_t n = seg ? g.ne : g.nv, lo = n * part / n_parts, hi = n * (part + 1) / n_parts;
+        std::vector<OutBuf> bufs;
+        bufs.reserve(T);
+        for (uint32_t t = 0; t < T; ++t) bufs.emplace_back(nullptr);
+        auto work = [&](uint32_t t) {
+            const uint64_t a = lo + (hi - lo) * t / T, b = lo + (hi - lo) * (t + 1) / T;
+            bufs[t].n = 0;
+            if (seg) dt.edges(a, b, bufs[t]); else dt.vertices(a, b, bufs[t]);
+        };
+        {
+            std::vector<std::thread> th;
+            for (uint32_t t = 1; t < T; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+        }
+        size_t total = 0;
+        for (auto &b : bufs) total += b.n;
+        h->dot_part[seg].resize(total);
+        size_t at = 0;
+        for (auto &b : bufs) {
+            memcpy(h->dot_part[seg].data() + at, b.b.data(), b.n);
+            at += b.n;
+        }
+        bytes[seg] = total;
+    }
+    return MXG_OK;
+}
+
+int dot_part_write(mxg_handle *h, const char *path, uint64_t v_off, uint64_t e_off, int first, int last)
+{
+    const int fd = open(path, O_WRONLY | O_CREAT, 0644);
+    if (fd < 0) return set_err(h, MXG_EIO, "cannot open '%s' for writing", path);
+    auto put = [&](const char *p, size_t n, uint64_t off) {
+        size_t done = 0;
+        while (done < n) {
+            const ssize_t wr = pwrite(fd, p + done, n - done, (off_t)(off + done));
+            if (wr <= 0) return false;
+            done += (size_t)wr;
+        }
+        return true;
     };
+    bool ok = true;
+    if (first) ok = put("graph G {\n", 10, 0);
+    ok = ok && put(h->dot_part[0].data(), h->dot_part[0].size(), v_off);
+    ok = ok && put(h->dot_part[1].data(), h->dot_part[1].size(), e_off);
+    if (last) ok = ok && put("}\n", 2, e_off + h->dot_part[1].size());
+    ok = (close(fd) == 0) && ok;
+    h->dot_part[0] = std::vector<char>();
+    h->dot_part[1] = std::vector<char>();
+    if (!ok) return set_err(h, MXG_EIO, "write error on '%s'", path);
+    return MXG_OK;
+}
+
+int write_dot(mxg_handle *h, const char *path)
+{
+    const Graph &g = h->graph;
+    if (!g.valid) return set_err(h, MXG_EINVAL, "mxg_write_dot: call mxg_build_graph first");
+    FILE *f = fopen(path, "w+b");
+    if (!f) return set_err(h, MXG_EIO, "cannot open '%s' for writing", path);
+    const DotText dt(h);
+    auto vertices = [&](uint64_t v0, uint64_t v1, OutBuf &o) { dt.vertices(v0, v1, o); };
+    auto edges = [&](uint64_t e0, uint64_t e1, OutBuf &o) { dt.edges(e0, e1, o); };
     // ~200 bytes per vertex and ~75 per edge (1.2 GB at 3 Gbp + 3 Gbp).  `host_threads` workers format chunks of 16 Ki items
     // into memory (two buffers each); this thread writes the chunks out in order AS THEY COMPLETE, so formatting and the
     // (serial: one file) copy into the page cache overlap -- formatting rounds alternating with writing rounds took their sum.

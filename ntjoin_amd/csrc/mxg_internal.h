@@ -225,6 +225,7 @@ struct mxg_handle {
     uint64_t *pinned_dg = nullptr;    // dgraph.hip: pinned copy of the per-destination counters
     uint64_t *pinned_gctl = nullptr;  // pinned host copy of the graph stage's control block
     uint32_t *pinned_ctrl = nullptr;  // pinned host copies of per-assembly control blocks (pipelined sketch)
+    std::vector<char> dot_part[2];    // a formatted part of the .mx.dot (mxg_dot_part_format -> mxg_dot_part_write)
     void *pinned_defer = nullptr;     // per control block: the stretches its batch left to the host (sketch.hip defer_stretch)
 };
 
@@ -268,6 +269,8 @@ uint32_t host_threads(const mxg_handle *h);
 // n_parts byte ranges written to fd at consecutive offsets from `off` on, by that many threads (host_io.cpp)
 bool put_parallel(int fd, uint64_t off, const char *const *data, const size_t *len, uint32_t n_parts);
 int write_dot(mxg_handle *h, const char *path);
+int dot_part_format(mxg_handle *h, uint32_t part, uint32_t n_parts, uint64_t bytes[2]);
+int dot_part_write(mxg_handle *h, const char *path, uint64_t v_off, uint64_t e_off, int first, int last);
 void build_rec_first(Assembly *a);
 std::string py_repr_str(const std::string &s);
 std::string py_repr_float(double v);

@@ -334,6 +334,15 @@ class MxEngine:
         lo, hi = _np(mn, n.value, np.uint32), _np(mx, n.value, np.uint32)
         return [None if l > h_ else (int(l), int(h_)) for l, h_ in zip(lo.tolist(), hi.tolist())]
 
+    def dot_part_format(self, part, n_parts):
+        """format part `part` of `n_parts` of the .mx.dot into memory -> (vertex segment bytes, edge segment bytes)"""
+        b = (C.c_uint64 * 2)()
+        self._check(self._lib.mxg_dot_part_format(self._h, int(part), int(n_parts), b))
+        return int(b[0]), int(b[1])
+
+    def dot_part_write(self, path, v_off, e_off, first, last):
+        self._check(self._lib.mxg_dot_part_write(self._h, str(path).encode(), int(v_off), int(e_off), int(bool(first)), int(bool(last))))
+
     def write_dot(self, path):
         self._check(self._lib.mxg_write_dot(self._h, str(path).encode()))
 

@@ -9,7 +9,7 @@ Multi-GPU driver of the hot path, one process per GPU:
 Every rank opens every FASTA, keeps the records of its shard (contiguous record ranges balanced by bases, or with --split
 equal base ranges that cut long records into pieces with a halo; record indices are global), sketches them, and writes its part of `<fasta>.k<k>.w<w>.tsv` (rank 0 concatenates the parts in
 rank order = input order).  The sketches are exchanged with one RCCL all-gather per assembly; every rank then holds
-the full sketches and builds the minimizer graph; rank 0 writes `<prefix>.mx.dot`.  Same file names as ntJoin
+the full sketches and builds the minimizer graph; every rank writes its 1/N of `<prefix>.mx.dot` at its own offset.  Same file names as ntJoin
 (reference ntJoin:26,204 and bin/ntjoin.py:28).
 """
 import argparse
@@ -64,9 +64,14 @@ def main(argv=None):
             eng.sketch()
             for a, tsv in enumerate(tsvs):                       # this rank's records only
                 eng.write_tsv(a, f"{tsv}.part{rank}", with_pos=True, with_strand=False, with_seq=True)
-            cont = [[False] * len(tsvs) for _ in range(world)]
-            dist.all_gather_object(cont, [eng.assembly_continues(a) for a in range(len(tsvs))])
-            if rank == 0:                                        # (all_gather_object also orders the part files before this)
+            # one flag per (rank, assembly): "my first record was begun by the rank before me" -- a tensor collective, which also
+            # orders the part files before rank 0 reads them
+            tdev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+            mine = torch.tensor([int(eng.assembly_continues(a)) for a in range(len(tsvs))], dtype=torch.int32, device=tdev)
+            every = torch.empty((world, len(tsvs)), dtype=torch.int32, device=tdev)
+            dist.all_gather_into_tensor(every.view(-1), mine)
+            cont = every.cpu().numpy().astype(bool).tolist()
+            if rank == 0:
                 for a, tsv in enumerate(tsvs):
                     parts = [f"{tsv}.part{r}" for r in range(world)]
                     concat_tsv_parts(parts, [cont[r][a] for r in range(world)], tsv)
@@ -74,8 +79,20 @@ def main(argv=None):
                         os.remove(part)
             allgather_inplace(eng, local_rank)
             eng.build_graph()
+            # every rank holds the whole graph: each formats 1/world of the .mx.dot text and writes it at its own place
+            # (the sizes travel in one small all-gather); rank 0 alone took world times as long for the same bytes
+            dot = args.prefix + ".mx.dot"
+            vb, eb = eng.dot_part_format(rank, world)
+            sizes = torch.empty((world, 2), dtype=torch.int64, device=tdev)
+            dist.all_gather_into_tensor(sizes.view(-1), torch.tensor([vb, eb], dtype=torch.int64, device=tdev))
+            sizes = sizes.cpu().numpy()
+            if rank == 0 and os.path.exists(dot):
+                os.remove(dot)                                   # (nobody truncates once the writing has begun)
+            dist.barrier()
+            v_off = 10 + int(sizes[:rank, 0].sum())
+            e_off = 10 + int(sizes[:, 0].sum()) + int(sizes[:rank, 1].sum())
+            eng.dot_part_write(dot, v_off, e_off, rank == 0, rank == world - 1)
             if rank == 0:
-                eng.write_dot(args.prefix + ".mx.dot")
                 st = eng.stats()
                 print(f"ntjoin_amd.run_dist: {world} GPU(s), {st['minimizers']} minimizers, {st['vertices']} vertices, "
                       f"{st['edges']} edges -> {args.prefix}.mx.dot", flush=True)

@@ -113,6 +113,15 @@ def test_run_dist_ranks_on_one_gpu(tmp_path, world, split):
     with open(os.path.join(GOLDEN, "cases", meta["name"], "reference.mx.dot"), encoding="utf-8") as fh:
         want = go.canonical_dot_from_text(fh.read())
     assert go.canonical_dot_from_text((tmp_path / "out.mx.dot").read_text(encoding="utf-8")) == want
+    # the ranks wrote the file in parts (mxg_dot_part_format / _write): byte for byte what one process writes
+    one = tmp_path / "one"
+    one.mkdir()
+    for a in asms:
+        shutil.copy(os.path.join(fasta_dir, a["fasta"]), one / a["fasta"])
+    subprocess.check_call([os.path.join(REPO, "ntjoin_amd", "bin", "mxgraph"), "-k", str(meta["k"]), "-w", str(meta["w"]), "-p", "out",
+                           "-s", meta["target"]["fasta"], "-l", str(meta["target"]["weight"]), "-r",
+                           " ".join(str(a["weight"]) for a in meta["refs"])] + [a["fasta"] for a in meta["refs"]], cwd=one)
+    assert filecmp.cmp(str(tmp_path / "out.mx.dot"), str(one / "out.mx.dot"), shallow=False)
 
 
 @pytest.mark.parametrize("world,workload,mbp,graph", [(2, "configs2", "40", "union"), (4, "configs3", "24", "union"),
