@@ -111,7 +111,7 @@ struct Assembly {
     // k = 32 route (sketch_bs.hip): the bases transposed for the bit-sliced ring filter, its result, chunk -> first run
     bool bs_ready = false, bs_impossible = false;
     uint32_t bs_chunks = 0;
-    DevBuf d_bs_T, d_bs_Q, d_bs_out, d_bs_run0;
+    DevBuf d_bs_tail, d_bs_out, d_bs_run0;  // k = 32 route: padded copy of the last chunk's words, the filter's bitmap, chunk -> run
     // sketch (device, ordered by (record,pos)) + lazily filled host mirror
     bool has_sketch = false;
     uint64_t n_mx = 0;

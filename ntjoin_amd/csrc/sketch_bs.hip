@@ -1,8 +1,8 @@
 // sketch_bs.hip -- the k = 32 route of the sketch stage (replaces `indexlr`, reference ntJoin:204-205; semantics SURVEY.md App. A).
 //
-//   k_bs_transpose  (bs_kernels.h)  packed bases -> the bit-plane layout T / Q, once per assembly
-//   k_hash_bs       (bs_kernels.h)  the bit-sliced ring filter over the whole assembly: one bit per base position, "the 32-mer
-//                                   starting here may have canonical hash < tau" (a superset)
+//   k_hash_bs       (bs_kernels.h)  the bit-sliced ring filter over the whole assembly, straight from the 2-bit packed bases (bit
+//                                   planes are made in registers): one bit per base position, "the 32-mer starting here may have
+//                                   canonical hash < tau" (a superset)
 //   k_bs_resolve    (here)          one block per chunk of 65 536 positions: the filter's bits of the chunk and of a halo on
 //                                   either side -> candidates in position order -> valid ones (run table) with their exact
 //                                   64-bit hashes < tau -> the window decision of k_resolve (sketch.hip) on the block's own
@@ -584,13 +584,15 @@ int bs_prepare(mxg_handle *h, Assembly *a)
     const uint64_t n_pos = a->packed_words * 16ull + 64;  // (+ two strips: no k-mer of the assembly starts in the last one)
     const uint32_t n_chunks = (uint32_t)((n_pos + BS_CHUNK - 1) / BS_CHUNK);
     a->bs_chunks = n_chunks;
-    MXG_HIP(h, a->d_bs_T.ensure((size_t)n_chunks * BS_T_WORDS * 4));
-    MXG_HIP(h, a->d_bs_Q.ensure((size_t)n_chunks * BS_Q_WORDS * 4));
     // (+ 256 bytes behind it: the batch kernels request the words of a whole strip, up to 1024 positions + 2 words, before masking)
     MXG_HIP(h, a->d_bs_out.ensure(((size_t)n_chunks * BS_OUT_WORDS + BS_OUT_PAD) * 4 + 256));
-    hipLaunchKernelGGL(k_bs_transpose, dim3(n_chunks), dim3(64), 0, h->stream, a->d_packed, (uint64_t)a->packed_words,
-                       a->d_bs_T.as<uint32_t>(), a->d_bs_Q.as<uint32_t>(), 0u, n_chunks);
-    MXG_HIP(h, hipGetLastError());
+    // the last chunk's words, padded with zeros to a whole chunk: the filter reads whole chunks (bases behind the assembly = A)
+    MXG_HIP(h, a->d_bs_tail.ensure((size_t)BS_CHUNK_WORDS * 4));
+    MXG_HIP(h, hipMemsetAsync(a->d_bs_tail.p, 0, (size_t)BS_CHUNK_WORDS * 4, h->stream));
+    const uint64_t tail_lo = (uint64_t)(n_chunks - 1) * BS_CHUNK_WORDS;
+    if (a->packed_words > tail_lo)
+        MXG_HIP(h, hipMemcpyAsync(a->d_bs_tail.p, a->d_packed + tail_lo, (size_t)(a->packed_words - tail_lo) * 4, hipMemcpyDeviceToDevice,
+                                  h->stream));
     // chunk -> first run whose k-mers end behind the chunk's first position (runs are sorted)
     std::vector<uint32_t> run0((size_t)n_chunks + 1);
     size_t r = 0;
@@ -612,9 +614,13 @@ int bs_hash(mxg_handle *h, Assembly *a, uint32_t tau_hi, hipStream_t st)
     // tt = (T - 1) >> (31 - planes) (gen/bs_gen.py: reference_bits)
     const uint32_t T = tau_hi >> 1;
     const uint32_t tt = T ? (T - 1u) >> (31 - HASH_BS_PLANES) : 0u;
-    const uint32_t blocks = std::min<uint32_t>(512u, (a->bs_chunks + 3u) / 4u);  // two waves per SIMD (see k_hash_bs)
-    hipLaunchKernelGGL(k_hash_bs, dim3(blocks), dim3(256), 0, st, a->d_bs_T.as<uint32_t>(), a->d_bs_Q.as<uint32_t>(),
-                       a->d_bs_out.as<uint32_t>() + BS_OUT_PAD, 0u, a->bs_chunks, tt);
+    // (alone on the GPU 1024 blocks over the 512 resident ones even out the tail: 478 us against 500 us at 3 Gbp; beside the other
+    // stream's kernels the step is the same or better with 512.  MXG_BS_BLOCKS: sweep knob)
+    const char *eb = getenv("MXG_BS_BLOCKS");
+    const unsigned env_blocks = eb && atoi(eb) > 0 ? (unsigned)atoi(eb) : 512u;
+    const uint32_t blocks = std::min<uint32_t>((uint32_t)env_blocks, (a->bs_chunks + 3u) / 4u);  // two waves per SIMD are resident (see k_hash_bs)
+    hipLaunchKernelGGL(k_hash_bs, dim3(blocks), dim3(256), 0, st, a->d_packed, a->d_bs_tail.as<uint32_t>(),
+                       a->d_bs_out.as<uint32_t>() + BS_OUT_PAD, 0u, a->bs_chunks, tt, a->bs_chunks - 1u);
     MXG_HIP(h, hipGetLastError());
     return MXG_OK;
 }

@@ -16,18 +16,12 @@ seven masks made of the base's two bit planes (5 VALU per base).  The sum test i
 bit-sliced compare.  The stream consists of full-rate ("fast class") instructions only: v_xor/and/or/mov, v_bitop3_b32,
 v_add_u32, v_lshrrev_b32 -- no left shift, no compare, no add-with-carry, no popcount, no permute.
 
-Geometry (k = 32).  A chunk = 65 536 consecutive base positions = 64 lanes x 32 strips x 32 positions = 4096 words of the
-2-bit packed assembly (16 bases per u32, base i of a word in bits 2i, 2i+1).  Lane L reads ITS 64 words (strip 32 L + s = words
-64 L + 2 s, + 1) with 16 global_load_dwordx4 and turns them into bit planes in registers: two 32 x 32 bit transposes (the strips'
-first / second words), after which
-    plane (t, beta) = a register whose bit s = bit beta of the base at chunk * 65536 + (32 lane + s) * 32 + t.
-A 32 x 32 transpose = 5 stages x 16 register pairs; a pair is swapped with v_lshrrev_b32, one v_bitop3_b32 against an SGPR mask,
-two v_xor_b32 and the left shift as a chain of v_add_u32 x, x (v_lshlrev_b32 is slow class): 1 632 instructions per chunk,
-+24 % on the filter itself.  (Until late in round 3 a pre-transposed copy of the assembly was kept instead, built by a kernel
-of its own: 0.26 B/bp of HBM and one more pass over the assembly per sketch, 0.33 ms per 3 Gbp -- as long as the filter's launch.)
-The strip in front of a lane's first one (its bases are the outgoing bases of slot 0) is the previous lane's last strip: its
-two words come over by DPP wave_shr:1 (lane 0: the two words in front of the chunk, by a scalar load), and their even / odd bits
-are separated into four registers of 16 steps each.
+Geometry (k = 32).  A chunk = 65 536 consecutive base positions = 64 lanes x 32 strips x 32 positions.  The bases come
+TRANSPOSED (mxg bs layout, built once per assembly by k_bs_transpose in sketch_bs.hip):
+    T[chunk][t / 2][lane][2 (t & 1) + beta]  (u32)   bit s = bit beta of the base at chunk * 65536 + (32 lane + s) * 32 + t
+    Q[chunk][lane][beta]                     (u32)   bit t = bit beta of the base at chunk * 65536 + (32 lane - 1) * 32 + t
+(16 bytes per lane and pair of steps: one global_load_dwordx4 of 1 KB per wave; with 4-byte loads of 256 B per wave the
+filter stayed at 3.0 TB/s of traffic, a third below what its instruction stream allows)
 Slot s of lane L rolls the k-mers of strip 32 L + s - 1 (the strip BEFORE the one whose bits sit at position s): the
 incoming base of step t is then W[t] itself and the outgoing base is W[t] shifted up by one slot (v_add_u32 W, W) with
 the previous lane's last strip coming in at the bottom (bit t of Q: a running v_lshrrev_b32 and one v_bitop3_b32).
@@ -39,8 +33,7 @@ result words of a lane (word t: bit s = slot s) are transposed in registers (32 
 v_add_u32) into position order and go out as a plain bitmap, one bit per base position:
     OUT[p / 32] bit p % 32 = the 32-mer at position p passed      (word index chunk * 2048 + 32 lane + s - 1 for slot s)
 (slots 1..31 of a lane are 124 contiguous bytes on a 128-byte boundary, slot 0 is the word in front of them)
-The words of the next chunk are requested into the registers of the current one as soon as the steps have read them (a load
-fills the planes of steps k and 16 + k: it goes out after step 16 + k).
+The words of the next chunk are requested into the registers of the current one as soon as a step has read them.
 
 The same instruction list is (1) printed as gfx950 assembly for one inline-asm block with fixed registers (the chunk loop
 included) and (2) executed by a numpy model (class VM): tests/test_bs_gen_cpu.py runs the model against the direct ntHash
@@ -117,19 +110,12 @@ def to_asm(ins):
         return f"v_add_u32 {a[0]}, {a[1]}, {a[2]}"
     if op == 'lshr':
         return f"v_lshrrev_b32 {a[0]}, {a[2]}, {a[1]}"
-    if op == 'gload4':  # first dst register, base SGPR pair, byte offset; the lane's offset (lane * 256) is operand %[voff256]
+    if op == 'gload4':  # first dst register, base SGPR pair, byte offset; the lane's offset (lane * 16) is operand %[voff]
         d = int(ins[1][1:])
-        return f"global_load_dwordx4 v[{d}:{d + 3}], %[voff256], {sp(ins[2])} offset:{ins[3]}"
-    if op == 'dpp_shr1':  # dst[lane] = src[lane - 1], lane 0: 0   (two per chunk: their being slow class does not matter)
-        return f"v_mov_b32_dpp {a[0]}, {a[1]} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-    if op == 'writelane0':  # lane 0 of dst <- SGPR
-        return f"v_writelane_b32 {a[0]}, {a[1]}, 0"
-    if op == 'sprev':  # SGPR pair <- the two packed words in front of the chunk (chunk 0: zeros); S_CB = the chunk's first word
-        d = ins[1]
-        return "\n".join([f"s_add_u32 s{d}, s{S_CB}, -8", f"s_addc_u32 s{d + 1}, s{S_CB + 1}, -1",
-                          f"s_cmp_eq_u32 s{S_C}, 0", f"s_cselect_b64 {sp(d)}, {sp(S_CB)}, {sp(d)}",
-                          f"s_load_dwordx2 {sp(d)}, {sp(d)}, 0x0", "s_waitcnt lgkmcnt(0)",
-                          f"s_cmp_eq_u32 s{S_C}, 0", f"s_cselect_b32 s{d}, 0, s{d}", f"s_cselect_b32 s{d + 1}, 0, s{d + 1}"])
+        return f"global_load_dwordx4 v[{d}:{d + 3}], %[voff], {sp(ins[2])} offset:{ins[3]}"
+    if op == 'gload2':  # (lane * 8: %[voff8])
+        d = int(ins[1][1:])
+        return f"global_load_dwordx2 v[{d}:{d + 1}], %[voff8], {sp(ins[2])} offset:{ins[3]}"
     if op in ('gstore4', 'gstore3', 'gstore1'):  # first data register, base SGPR pair, byte offset; lane * 128: %[voff128]
         d = int(ins[1][1:])
         n = int(op[-1])
@@ -177,15 +163,12 @@ S_C = S0            # chunk index (pair: high word 0)
 S_N = S0 + 2        # one past the last chunk
 S_STRIDE = S0 + 3
 S_TT = S0 + 4
-S_T = S0 + 6        # packed bases (pair), S_P = the copy of the last chunk's words (pair), S_O = OUT base (pair)
+S_T = S0 + 6        # T base (pair), S_P = Q base (pair), S_O = OUT base (pair)
 S_P = S0 + 8
 S_O = S0 + 10
-S_TN = S0 + 12      # pair: the next chunk's words
-S_CB = S0 + 14      # pair: this chunk's words
-S_PV = S0 + 16      # pair: the two words in front of this chunk
-S_CTAIL = S0 + 18   # the chunk whose words are taken from the copy (the assembly's last, ragged chunk)
+S_TN = S0 + 12      # 4 pairs: next chunk's T words + k * 4096
 S_OC = S0 + 20      # 2 pairs: this chunk's OUT words - 4 bytes, this chunk's OUT words
-S_QN = S0 + 24      # (free)
+S_QN = S0 + 24      # pair: the next chunk's Q words
 S_TMP = S0 + 26     # pair
 S_CM = S0 + 28      # B_PLANES compare masks
 S_M16, S_M8, S_M4, S_M2, S_M1 = (S0 + 28 + B_PLANES + i for i in range(5))  # the transpose's select masks
@@ -201,19 +184,15 @@ class Gen:
         self.fo, self.fi, self.ro, self.ri = plane_funcs(k)
         self.FP = [grp(i, 0) for i in range(31)]
         self.RP = [grp(i, 1) for i in range(31)]
-        # the lane's 64 packed words as loaded: word 2 s + h (h = 0: bases 0..15 of strip s, 1: bases 16..31) in v(W0 + 2 s + h);
-        # after the two transposes plane (t, beta) of the first words sits where word 2 (2 t + beta) was, of the second words likewise
-        self.RAW = [[f"v{W0 + 2 * s_ + h_}" for s_ in range(32)] for h_ in (0, 1)]
-        self.W = {(t, be): f"v{W0 + 4 * (t % 16) + 2 * be + t // 16}" for t in range(32) for be in (0, 1)}
+        self.W = {(t, be): f"v{W0 + 2 * t + be}" for t in range(32) for be in (0, 1)}
         self.A = [grp(g, 2) for g in range(7)]   # o0 o1 x o a c1 c2 of the outgoing base
         self.B = [grp(g, 3) for g in range(7)]   # in0 in1 ... of the incoming base
         self.cy, self.s = grp(7, 2), grp(7, 3)
         assert X0 % 4 == 0
         # the steps' results, then their transpose: M[1..] go out as dwordx4 (register tuples must start on an even register)
         self.M = [f"v{X0 + 1 + i}" for i in range(32)]
-        # the strip in front of the lane's first one, bit planes: QL[beta] bit t = bases 0..15, QH[beta] = bases 16..31; Qr: running
-        self.QL = [f"v{X0 + 34}", f"v{X0 + 35}"]
-        self.QH = [f"v{X0 + 36}", f"v{X0 + 37}"]
+        self.Qn = [f"v{X0 + 34}", f"v{X0 + 35}"]   # the next chunk's Q words (a dwordx2), the chunk's, their running shifts
+        self.Q = [f"v{X0 + 36}", f"v{X0 + 37}"]
         self.Qr = [f"v{X0 + 40}", f"v{X0 + 41}"]   # banks 0, 1 (read with a bank 2 register by one v_bitop3_b32)
         self.le, self.ones = f"v{X0 + 44}", f"v{X0 + 45}"
         self.TT = [f"v{X0 + 48 + i}" for i in range(4)]  # temporaries of the transpose, one per bank
@@ -273,11 +252,9 @@ class Gen:
         e = self.e
         tt = self.tt3(lambda a, b2, c: a | (b2 & c))
         for be in (0, 1):
-            if t % 16 == 0:
-                e('mov', self.Qr[be], (self.QL if t == 0 else self.QH)[be])
             e('add', self.A[be], self.W[(t, be)], self.W[(t, be)])
             e('bitop3', self.A[be], self.A[be], self.Qr[be], 1, tt)
-            if t % 16 != 15:
+            if t < 31:
                 e('lshr', self.Qr[be], self.Qr[be], 1)
 
     def chunk(self):
@@ -286,10 +263,16 @@ class Gen:
         b = self.b
         FP, RP, W = self.FP, self.RP, self.W
         A, B = self.A, self.B
-        # ---- the chunk's 64 words per lane -> bit planes
-        self.planes_in()
         # ---- warm-up: steps n = 0..31: the slot's own strip, i.e. the o-stream (W shifted up by one slot)
         for n in range(32):
+            # W[n] has arrived when at most the loads issued after it are outstanding (loads return in order; stores in
+            # between only make the wait stricter)
+            if n % 2 == 0:
+                e('waitcnt', f'vmcnt({15 - n // 2})')
+            if n == 0:  # (the Q words were requested before all of W)
+                for be in (0, 1):
+                    e('mov', self.Q[be], self.Qn[be])
+                    e('mov', self.Qr[be], self.Qn[be])
             self.o_stream(n)
             mB = self.masks(A)
             for r in range(31):
@@ -302,13 +285,17 @@ class Gen:
         s, cy, le, ones = self.s, self.cy, self.le, self.ones
         for t in range(32):
             n = 32 + t
+            if t == 0:
+                for be in (0, 1):
+                    e('mov', self.Qr[be], self.Q[be])
+                e('gload2', self.Qn[0], S_QN, 0)  # the next chunk's Q words (before its W words: they wait for less)
             if t < 31:
                 # masks of the outgoing base (bank 2) and of the incoming base (bank 3), made before the test
                 self.o_stream(t)
                 e('mov', B[0], W[(t, 0)])
                 e('mov', B[1], W[(t, 1)])
-            if t >= 16:  # the planes of steps t - 16 and t are dead: the next chunk's words 4 (t - 16) .. + 3 can come
-                e('gload4', f"v{W0 + 4 * (t - 16)}", S_TN, 16 * (t - 16))
+            if t % 2 == 1:  # W[t - 1], W[t] are dead: the next chunk's words can come
+                e('gload4', W[(t - 1, 0)], S_TN + 2 * ((t // 2) // 4), ((t // 2) % 4) * 1024)
             if t < 31:
                 mA = self.masks(A)
                 mB = self.masks(B)
@@ -349,70 +336,6 @@ class Gen:
         self.check_banks()
         return self.ins
 
-    def swap_stage(self, regs, j, sm, temps, only=None):
-        """one stage of a 32 x 32 bit transpose in place: rows k, k + j (k & j == 0) exchange the bits whose index has bit j set
-        / clear:  t = ((x >> j) ^ y) & m;  y ^= t;  x ^= t << j   (m in an SGPR; the left shift = j times v_add_u32 t, t).
-        Two pairs are interleaved (their add chains are independent)."""
-        e = self.e
-        tt = self.tt3(lambda a, b2, c: (a ^ b2) & c)
-        pairs = [(regs[k], regs[k + j]) for k in range(32) if not k & j]
-        if only is not None:
-            pairs = pairs[only:only + 2]
-        for i in range(0, len(pairs), 2):
-            grp2 = pairs[i:i + 2]
-            tmp = []
-            for (x, y) in grp2:
-                cands = [t_ for t_ in temps if bank(t_) != bank(y) and t_ not in tmp]
-                tmp.append(cands[0])
-            for (x, y), t_ in zip(grp2, tmp):
-                e('lshr', t_, x, j)
-            for (x, y), t_ in zip(grp2, tmp):
-                e('bitop3', t_, t_, y, f"s{sm}", tt)
-            for (x, y), t_ in zip(grp2, tmp):
-                e('xor', y, y, t_)
-            for _ in range(j):
-                for t_ in tmp:
-                    e('add', t_, t_, t_)
-            for (x, y), t_ in zip(grp2, tmp):
-                e('xor', x, x, t_)
-
-    def even_bits(self, dst, src, shift):
-        """dst = the bits 2 i + shift of src, packed into bits 0..15 (right shifts only)"""
-        e = self.e
-        tt = self.tt3(lambda a, b2, c: (a | b2) & c)
-        t_ = self.TT[(bank(dst) + 1) % 4]
-        if shift:
-            e('lshr', dst, src, shift)
-            e('and', dst, dst, f"s{S_M1}")
-        else:
-            e('and', dst, src, f"s{S_M1}")
-        for j, sm in ((1, S_M2), (2, S_M4), (4, S_M8), (8, S_M16)):
-            e('lshr', t_, dst, j)
-            e('bitop3', dst, t_, dst, f"s{sm}", tt)
-
-    def planes_in(self):
-        """the lane's 64 packed words (RAW) -> the strip in front (QL, QH) and the 64 bit planes (W), in place"""
-        e = self.e
-        pa, pb = self.M[0], self.M[1]   # (M is free until the first productive step)
-        # the first stage pairs strips s and s + 16, i.e. the words of loads s / 2 and s / 2 + 8: it starts as soon as nine of the
-        # sixteen loads are back and follows the others in (loads return in order), instead of waiting for the last one first
-        for k in range(0, 16, 2):
-            e('waitcnt', f'vmcnt({7 - k // 2})')
-            if k == 14:  # strip 31's words are in (and still as loaded: the last pair of the stage changes them)
-                e('sprev', S_PV)
-                e('dpp_shr1', pa, self.RAW[0][31])
-                e('dpp_shr1', pb, self.RAW[1][31])
-                e('writelane0', pa, f"s{S_PV}")
-                e('writelane0', pb, f"s{S_PV + 1}")
-            for h_ in (0, 1):
-                self.swap_stage(self.RAW[h_], 16, S_M16, self.TT, only=k)
-        for be in (0, 1):
-            self.even_bits(self.QL[be], pa, be)
-            self.even_bits(self.QH[be], pb, be)
-        for h_ in (0, 1):
-            for j, sm in ((8, S_M8), (4, S_M4), (2, S_M2), (1, S_M1)):
-                self.swap_stage(self.RAW[h_], j, sm, self.TT)
-
     def transpose_out(self):
         """M[t] bit s -> M[s] bit t, in place.  Stage j pairs rows k, k + j: new_k = (k & m) | ((k+j << j) & ~m),
         new_k+j = ((k >> j) & m) | (k+j & ~m), m = the bits whose index has bit j clear (an SGPR: v_bitop3_b32 with one SGPR source
@@ -448,23 +371,25 @@ class Gen:
 
     # ---- the whole block: prologue, chunk loop ---------------------------------------------------------------
     def address_setup(self, lines):
-        """SALU: bases of this chunk's OUT words and packed words, and of the NEXT chunk's packed words (the last chunk of a
-        wave asks for its own words again)"""
+        """SALU: bases of this chunk's OUT / P words and of the NEXT chunk's T / P words (the last chunk of a wave asks for
+        its own words again)"""
         L = lines.append
         t0, t1 = S_TMP, S_TMP + 1
         L(f"s_add_u32 s{t0}, s{S_C}, s{S_STRIDE}")
         L(f"s_cmp_lt_u32 s{t0}, s{S_N}")
         L(f"s_cselect_b32 s{t0}, s{t0}, s{S_C}")
         L(f"s_mov_b32 s{t1}, 0")
-        # this chunk's words (for the pair in front of them) and the next chunk's (the last, ragged chunk: its padded copy)
-        L(f"s_lshl_b64 {sp(S_CB)}, {sp(S_C)}, 14")
-        L(f"s_add_u32 s{S_CB}, s{S_CB}, s{S_T}")
-        L(f"s_addc_u32 s{S_CB + 1}, s{S_CB + 1}, s{S_T + 1}")
-        L(f"s_lshl_b64 {sp(S_TN)}, {sp(t0)}, 14")
-        L(f"s_add_u32 s{S_TN}, s{S_TN}, s{S_T}")
-        L(f"s_addc_u32 s{S_TN + 1}, s{S_TN + 1}, s{S_T + 1}")
-        L(f"s_cmp_eq_u32 s{t0}, s{S_CTAIL}")
-        L(f"s_cselect_b64 {sp(S_TN)}, {sp(S_P)}, {sp(S_TN)}")
+        for k in range(4):
+            d = S_TN + 2 * k
+            L(f"s_lshl_b64 {sp(d)}, {sp(t0)}, 14")
+            L(f"s_add_u32 s{d}, s{d}, s{S_T}")
+            L(f"s_addc_u32 s{d + 1}, s{d + 1}, s{S_T + 1}")
+            if k:
+                L(f"s_add_u32 s{d}, s{d}, {hex(4096 * k)}")
+                L(f"s_addc_u32 s{d + 1}, s{d + 1}, 0")
+        L(f"s_lshl_b64 {sp(S_QN)}, {sp(t0)}, 9")
+        L(f"s_add_u32 s{S_QN}, s{S_QN}, s{S_P}")
+        L(f"s_addc_u32 s{S_QN + 1}, s{S_QN + 1}, s{S_P + 1}")
         d = S_OC + 2  # the chunk's 2048 words; S_OC: the same minus one word (slot 0 of a lane = the word in front of its 31)
         L(f"s_lshl_b64 {sp(d)}, {sp(S_C)}, 13")
         L(f"s_add_u32 s{d}, s{d}, s{S_O}")
@@ -473,9 +398,8 @@ class Gen:
         L(f"s_addc_u32 s{S_OC + 1}, s{d + 1}, -1")
 
     def asm(self):
-        """the inline-asm text.  Operands: %[t] %[p] %[o] (SGPR pairs: packed bases, padded copy of the last chunk's words, OUT),
-        %[c0] first chunk of the wave, %[n] one past the last chunk, %[stride] chunks between a wave's chunks, %[tt] threshold,
-        %[ctail] the chunk read from the copy, VGPRs %[voff256] = lane * 256, %[voff128] = lane * 128"""
+        """the inline-asm text.  Operands: %[t] %[p] %[o] (SGPR pairs: T, Q, OUT bases), %[c0] first chunk of the wave,
+        %[n] one past the last chunk, %[stride] chunks between a wave's chunks, %[tt] threshold, VGPRs %[voff] = lane * 16, %[voff8] = lane * 8, %[voff128] = lane * 128"""
         body = self.chunk()
         L = []
         A = L.append
@@ -487,7 +411,6 @@ class Gen:
         A(f"s_mov_b64 {sp(S_T)}, %[t]")
         A(f"s_mov_b64 {sp(S_P)}, %[p]")
         A(f"s_mov_b64 {sp(S_O)}, %[o]")
-        A(f"s_mov_b32 s{S_CTAIL}, %[ctail]")
         for i in range(self.b):  # compare masks: Cm_i = all ones iff bit i of the threshold is set
             A(f"s_bfe_u32 s{S_TMP}, s{S_TT}, {hex((1 << 16) | i)}")
             A(f"s_sub_u32 s{S_CM + i}, 0, s{S_TMP}")
@@ -495,20 +418,25 @@ class Gen:
             A(f"s_mov_b32 s{sm}, {hex(val)}")
         A(f"s_cmp_ge_u32 s{S_C}, s{S_N}")
         A("s_cbranch_scc1 L_bs_end_%=")
-        # prologue: the first chunk's words
-        A(f"s_lshl_b64 {sp(S_TN)}, {sp(S_C)}, 14")
-        A(f"s_add_u32 s{S_TN}, s{S_TN}, s{S_T}")
-        A(f"s_addc_u32 s{S_TN + 1}, s{S_TN + 1}, s{S_T + 1}")
-        A(f"s_cmp_eq_u32 s{S_C}, s{S_CTAIL}")
-        A(f"s_cselect_b64 {sp(S_TN)}, {sp(S_P)}, {sp(S_TN)}")
-        for k in range(16):
-            A(to_asm(('gload4', f"v{W0 + 4 * k}", S_TN, 16 * k)))
+        # prologue: the first chunk's words and P entries
+        A(f"s_lshl_b64 {sp(S_TMP)}, {sp(S_C)}, 14")
+        A(f"s_add_u32 s{S_TMP}, s{S_TMP}, s{S_T}")
+        A(f"s_addc_u32 s{S_TMP + 1}, s{S_TMP + 1}, s{S_T + 1}")
+        for k in range(4):
+            d = S_TN + 2 * k
+            A(f"s_add_u32 s{d}, s{S_TMP}, {hex(4096 * k)}")
+            A(f"s_addc_u32 s{d + 1}, s{S_TMP + 1}, 0")
+        A(f"s_lshl_b64 {sp(S_QN)}, {sp(S_C)}, 9")
+        A(f"s_add_u32 s{S_QN}, s{S_QN}, s{S_P}")
+        A(f"s_addc_u32 s{S_QN + 1}, s{S_QN + 1}, s{S_P + 1}")
+        A(to_asm(('gload2', self.Qn[0], S_QN, 0)))
+        for t2 in range(16):
+            A(to_asm(('gload4', self.W[(2 * t2, 0)], S_TN + 2 * (t2 // 4), (t2 % 4) * 1024)))
         A("L_bs_loop_%=:")
         self.address_setup(L)
         for ins in body:
             if ins[0] != 'comment':
-                for piece in to_asm(ins).split("\n"):
-                    A(piece)
+                A(to_asm(ins))
         A(f"s_add_u32 s{S_C}, s{S_C}, s{S_STRIDE}")
         A(f"s_cmp_lt_u32 s{S_C}, s{S_N}")
         A("s_cbranch_scc1 L_bs_loop_%=")
@@ -524,11 +452,10 @@ class Gen:
 # numpy model of the chunk body (64 lanes)
 # ---------------------------------------------------------------------------------------------------------------
 class VM:
-    def __init__(self, packed, tt, c, c_next):
-        """packed: uint32 [n_chunks][4096], the chunks' packed words; runs chunk c (whose words are preloaded into the W
-        registers, as the prologue / the previous iteration does) and collects the chunk's OUT words and the words requested
-        for chunk c_next"""
-        self.packed = packed
+    def __init__(self, T, P, tt, c, c_next):
+        """T: uint32 [n_chunks][16][64][4], P (= Q): uint32 [n_chunks][64][2]; runs chunk c (whose words are preloaded into W, as the
+        prologue / the previous iteration does) and collects OUT[32][64] and the words requested for chunk c_next"""
+        self.T, self.P = T, P
         self.c, self.cn = c, c_next
         self.vr = {}
         self.sr = {S_CM + i: (0xFFFFFFFF if (tt >> i) & 1 else 0) for i in range(B_PLANES)}
@@ -546,16 +473,12 @@ class VM:
             return np.full(64, self.sr[int(x[1:])] & 0xFFFFFFFF, dtype=np.uint32)
         raise KeyError(x)
 
-    def lane_words(self, chunk, k):
-        """what global_load_dwordx4 number k brings: words 64 lane + 4 k .. + 3 of the chunk"""
-        lanes = np.arange(64)
-        return [self.packed[chunk, 64 * lanes + 4 * k + j].copy() for j in range(4)]
-
     def run(self, g):
         U = np.uint32
-        for k in range(16):
-            for j, wds in enumerate(self.lane_words(self.c, k)):
-                self.vr[f"v{W0 + 4 * k + j}"] = wds
+        for (t, be), reg in g.W.items():
+            self.vr[reg] = self.T[self.c, t // 2, :, 2 * (t & 1) + be].copy()
+        for be in (0, 1):
+            self.vr[g.Qn[be]] = self.P[self.c, :, be].copy()
         pend = {}  # loads in flight: they land when the body ends (no instruction of this chunk may see them)
         for ins in g.ins:
             op = ins[0]
@@ -578,26 +501,16 @@ class VM:
                 self.vr[ins[1]] = (self.V(ins[2]) + self.V(ins[3])).astype(U)
             elif op == 'lshr':
                 self.vr[ins[1]] = (self.V(ins[2]) >> U(ins[3])).astype(U)
-            elif op == 'dpp_shr1':
-                src = self.V(ins[2])
-                r = np.zeros(64, dtype=U)
-                r[1:] = src[:-1]
-                self.vr[ins[1]] = r
-            elif op == 'writelane0':
-                r = self.V(ins[1]).copy()
-                r[0] = self.sr[int(ins[2][1:])] & 0xFFFFFFFF
-                self.vr[ins[1]] = r
-            elif op == 'sprev':
-                flat = self.packed.reshape(-1)
-                at = self.c * 4096
-                self.sr[ins[1]] = int(flat[at - 2]) if self.c else 0
-                self.sr[ins[1] + 1] = int(flat[at - 1]) if self.c else 0
-            elif op == 'gload4':
-                k = ins[3] // 16
+            elif op == 'gload2':
                 d = int(ins[1][1:])
-                assert d == W0 + 4 * k
-                for j, wds in enumerate(self.lane_words(self.cn, k)):
-                    pend[f"v{d + j}"] = wds
+                for j in range(2):
+                    pend[f"v{d + j}"] = self.P[self.cn, :, j].copy()
+            elif op == 'gload4':
+                k = (ins[2] - S_TN) // 2
+                t2 = (k * 4096 + ins[3]) // 1024
+                d = int(ins[1][1:])
+                for j in range(4):
+                    pend[f"v{d + j}"] = self.T[self.cn, t2, :, j].copy()
             elif op in ('gstore4', 'gstore3', 'gstore1'):
                 n = int(op[-1])
                 base = -1 if ins[2] == S_OC else 0  # word offset of the SGPR pair relative to the chunk
@@ -617,12 +530,30 @@ class VM:
 # ---------------------------------------------------------------------------------------------------------------
 # layouts and the direct formula (what the generated code must reproduce)
 # ---------------------------------------------------------------------------------------------------------------
-def pack_chunks(codes, n_chunks):
-    """base codes (0..3) of n_chunks * 65536 positions -> uint32 [n_chunks][4096]: 16 bases per word, base i in bits 2i, 2i+1"""
-    codes = np.asarray(codes, dtype=np.uint32)
+def transpose_layout(codes, n_chunks):
+    """base codes (0..3) of n_chunks * 65536 positions -> T [n_chunks][16][64][4] u32, Q [n_chunks][64][2] u32"""
+    codes = np.asarray(codes, dtype=np.uint8)
     assert len(codes) == n_chunks * CHUNK
-    sh = (2 * np.arange(16, dtype=np.uint32))[None, :]
-    return (codes.reshape(-1, 16) << sh).sum(axis=1, dtype=np.uint32).reshape(n_chunks, 4096)
+    c4 = codes.reshape(n_chunks, 64, 32, 32)  # chunk, lane, slot, t
+    T = np.zeros((n_chunks, 16, 64, 4), dtype=np.uint32)
+    for be in (0, 1):
+        bits = ((c4 >> be) & 1).astype(np.uint32)  # chunk, lane, slot, t
+        for t in range(32):
+            w = np.zeros((n_chunks, 64), dtype=np.uint32)
+            for s in range(32):
+                w |= bits[:, :, s, t] << np.uint32(s)
+            T[:, t // 2, :, 2 * (t & 1) + be] = w
+    Q = np.zeros((n_chunks, 64, 2), dtype=np.uint32)
+    tsh = np.arange(32, dtype=np.uint32)
+    for c in range(n_chunks):
+        for lane in range(64):
+            p0 = c * CHUNK + (32 * lane - 1) * 32
+            if p0 < 0:
+                continue
+            seg = codes[p0:p0 + 32].astype(np.uint32)
+            for be in (0, 1):
+                Q[c, lane, be] = int((((seg >> be) & 1) << tsh).sum())
+    return T, Q
 
 
 def reference_bits(codes, k, tt, b_planes=B_PLANES):
@@ -659,11 +590,11 @@ def out_position(c, t, lane, s):
 def emit_inc(path, k):
     g = Gen(k)
     lines = g.asm()
-    n_valu = sum(1 for i in g.ins if i[0] in ('xor', 'and', 'or', 'mov', 'bitop3', 'add', 'lshr', 'dpp_shr1', 'writelane0'))
+    n_valu = sum(1 for i in g.ins if i[0] in ('xor', 'and', 'or', 'mov', 'bitop3', 'add', 'lshr'))
     with open(path, 'w') as fh:
         fh.write(f"// GENERATED by gen/bs_gen.py (k = {k}, {B_PLANES} sum planes): the bit-sliced ring filter, chunk loop included.\n")
         fh.write(f"// {n_valu} VALU per chunk of 65 536 base positions per wave, all of them full-rate (see gen/bs_gen.py).  Do not edit.\n")
-        fh.write("// operands: [t] [p] [o] SGPR pairs (packed bases, padded copy of the last chunk, OUT), [c0] [n] [stride] [tt] [ctail] SGPRs, [voff256] VGPR = lane * 256, [voff128] = lane * 128\n")
+        fh.write("// operands: [t] [p] [o] SGPR pairs (T, Q, OUT bases), [c0] [n] [stride] [tt] SGPRs, [voff] VGPR = lane * 16, [voff8] = lane * 8, [voff128] = lane * 128\n")
         fh.write(f"#define HASH_BS_VGPR_END {VEND}\n")
         fh.write(f"#define HASH_BS_VALU_PER_CHUNK {n_valu}\n")
         fh.write(f"#define HASH_BS_PLANES {B_PLANES}\n")

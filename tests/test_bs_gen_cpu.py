@@ -1,7 +1,7 @@
 """The generated bit-sliced ring filter (ntjoin_amd/csrc/gen/bs_gen.py -> csrc/hash_bs_k32.inc) checked on the CPU:
 
   * the generator's numpy VM executes the instruction list it emits (64 lanes x 32-bit registers, the same operand banks) on
-    random bases and must reproduce `reference_bits`, the plain restatement of the ring test, word for word -- including the
+    random packed bases -- from the lane's 64 packed words through the in-register bit transposes to the candidate bitmap -- and must reproduce `reference_bits`, the plain restatement of the ring test, word for word -- including the
     word in front of a chunk, the prefetch of the next chunk's planes and thresholds at both ends of the range;
   * `reference_bits` itself is pinned to the oracle: every k-mer whose canonical hash (oracle: reference ntHash)
     is < tau must pass the test (the filter may let more through, never fewer), and what it lets through beyond them stays
@@ -22,11 +22,11 @@ import bs_gen as G  # noqa: E402
 def _vm_chunk(seed, tt, c, n_chunks=3):
     rng = np.random.default_rng(seed)
     codes = rng.integers(0, 4, n_chunks * G.CHUNK).astype(np.uint8)
-    T, Q = G.transpose_layout(codes, n_chunks)
+    packed = G.pack_chunks(codes, n_chunks)
     g = G.Gen(32)
     g.chunk()
     c_next = min(c + 1, n_chunks - 1)
-    vm = G.VM(T, Q, tt, c, c_next)
+    vm = G.VM(packed, tt, c, c_next)
     out = vm.run(g)[:2048]  # (the VM's last word belongs to the next chunk's first slot)
     ext = np.concatenate([codes, np.zeros(64, dtype=np.uint8)])  # (bases behind the assembly read as A, like k_bs_transpose)
     ref = G.reference_bits(ext[:n_chunks * G.CHUNK + 31], 32, tt)
@@ -40,9 +40,10 @@ def _vm_chunk(seed, tt, c, n_chunks=3):
             want[wi] = int((ref[gi * 32: gi * 32 + 32].astype(np.uint64) << sh).sum())
     first = 1 if lo < 0 else 0
     assert np.array_equal(np.asarray(out[first:], dtype=np.uint64), want[first:])
-    # the planes left in the W registers are the next chunk's (loaded while this one was computed)
-    for (t, be), reg in g.W.items():
-        assert np.array_equal(vm.vr[reg], T[c_next, t // 2, :, 2 * (t & 1) + be]), (t, be)
+    # the words left in the W registers are the next chunk's (requested while this one was computed): lane L holds words 64 L ..
+    lanes = np.arange(64)
+    for i in range(64):
+        assert np.array_equal(vm.vr[f"v{G.W0 + i}"], packed[c_next, 64 * lanes + i]), i
     return float(ref.mean())
 
 
@@ -63,9 +64,11 @@ def test_instruction_classes_and_banks():
     g.chunk()
     ops = {i[0] for i in g.ins}
     valu = {"xor", "and", "or", "mov", "bitop3", "add", "lshr"}
-    assert ops - valu <= {"gload4", "gload2", "gstore1", "gstore3", "gstore4", "waitcnt", "comment"}
+    # besides them, per chunk: two DPP moves + two v_writelane (the strip in front of the lane's first) and one scalar load
+    assert ops - valu <= {"gload4", "gstore1", "gstore3", "gstore4", "waitcnt", "comment", "dpp_shr1", "writelane0", "sprev"}
+    assert sum(1 for i in g.ins if i[0] in ("dpp_shr1", "writelane0")) == 4
     g.check_banks()
-    n_valu = sum(1 for i in g.ins if i[0] in valu)
+    n_valu = sum(1 for i in g.ins if i[0] in valu | {"dpp_shr1", "writelane0"})
     inc = open(os.path.join(REPO, "ntjoin_amd", "csrc", "hash_bs_k32.inc")).read()
     assert f"#define HASH_BS_VALU_PER_CHUNK {n_valu}\n" in inc
     assert f"#define HASH_BS_VGPR_END {G.VEND}\n" in inc
@@ -78,18 +81,27 @@ def test_committed_inc_is_current(tmp_path):
     assert p.read_text() == open(os.path.join(REPO, "ntjoin_amd", "csrc", "hash_bs_k32.inc")).read()
 
 
-def test_layout_of_transpose():
-    """T / Q hold what bs_kernels.h says they hold"""
+def test_planes_in_registers():
+    """the in-register transposes: after planes_in, plane (t, beta) holds bit beta of the base at (32 lane + s) * 32 + t in bit s,
+    and QL / QH hold the strip in front of the lane's first one (previous lane's last strip; lane 0: the words in front of the chunk)"""
     rng = np.random.default_rng(9)
     codes = rng.integers(0, 4, 2 * G.CHUNK).astype(np.uint8)
-    T, Q = G.transpose_layout(codes, 2)
-    for _ in range(200):
-        c, lane, s, t, be = (int(rng.integers(0, n)) for n in (2, 64, 32, 32, 2))
-        p = c * G.CHUNK + (32 * lane + s) * 32 + t
-        assert (int(T[c, t // 2, lane, 2 * (t & 1) + be]) >> s) & 1 == (int(codes[p]) >> be) & 1
-        q = c * G.CHUNK + (32 * lane - 1) * 32 + t
-        if q >= 0:
-            assert (int(Q[c, lane, be]) >> t) & 1 == (int(codes[q]) >> be) & 1
+    packed = G.pack_chunks(codes, 2)
+    for c in (0, 1):
+        g = G.Gen(32)
+        g.planes_in()
+        vm = G.VM(packed, 0, c, c)
+        vm.run(g)
+        for _ in range(300):
+            lane, s_, t, be = (int(rng.integers(0, n)) for n in (64, 32, 32, 2))
+            p = c * G.CHUNK + (32 * lane + s_) * 32 + t
+            assert (int(vm.vr[g.W[(t, be)]][lane]) >> s_) & 1 == (int(codes[p]) >> be) & 1
+            q = c * G.CHUNK + (32 * lane - 1) * 32 + t
+            reg = (g.QL if t < 16 else g.QH)[be]
+            want = (int(codes[q]) >> be) & 1 if q >= 0 else 0
+            assert (int(vm.vr[reg][lane]) >> (t % 16)) & 1 == want
+        for be in (0, 1):  # nothing above bit 15
+            assert not (vm.vr[g.QL[be]] >> np.uint32(16)).any() and not (vm.vr[g.QH[be]] >> np.uint32(16)).any()
 
 
 @pytest.mark.parametrize("cand_per_window,w", [(10, 1000), (10, 200), (18, 500), (2, 500)])

@@ -1,6 +1,6 @@
 // bs_bench.hip -- standalone check + timing of the bit-sliced ring filter (ntjoin_amd/csrc/bs_kernels.h) on random bases.
 // Build: hipcc --offload-arch=gfx950 -O3 -I ntjoin_amd/csrc tools/bs_bench.hip -o tools/bin/bs_bench
-// Usage: bs_bench [Mbp=3000] [tt=164]   (layout kernel, filter, 4 chunks checked against the direct formula, timings)
+// Usage: bs_bench [Mbp=3000] [tt=164]   (filter straight from the packed bases, 4 chunks checked against the direct formula, timings)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -48,27 +48,20 @@ int main(int argc, char **argv)
     uint64_t x = 88172645463325252ull;
     auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
     for (auto &v : hp) v = (uint32_t)rnd();
-    uint32_t *dp, *dT, *dO;
-    uint32_t *dP;
+    uint32_t *dp, *dTail, *dO;
     CK(hipMalloc(&dp, n_words * 4));
-    CK(hipMalloc(&dT, (size_t)n_chunks * mxg::BS_T_WORDS * 4));
-    CK(hipMalloc(&dP, (size_t)n_chunks * mxg::BS_Q_WORDS * 4));
+    CK(hipMalloc(&dTail, (size_t)mxg::BS_CHUNK_WORDS * 4));
+    CK(hipMemset(dTail, 0, (size_t)mxg::BS_CHUNK_WORDS * 4));
     CK(hipMalloc(&dO, ((size_t)n_chunks * mxg::BS_OUT_WORDS + mxg::BS_OUT_PAD) * 4));
     dO += mxg::BS_OUT_PAD;
     CK(hipMemcpy(dp, hp.data(), n_words * 4, hipMemcpyHostToDevice));
+    const uint64_t tail_lo = (uint64_t)(n_chunks - 1) * mxg::BS_CHUNK_WORDS;  // the last (ragged) chunk: zero-padded copy
+    CK(hipMemcpy(dTail, dp + tail_lo, (n_words - tail_lo) * 4, hipMemcpyDeviceToDevice));
     CK(hipMemset(dO - mxg::BS_OUT_PAD, 0xAB, ((size_t)n_chunks * mxg::BS_OUT_WORDS + mxg::BS_OUT_PAD) * 4));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(mxg::k_bs_transpose, dim3(n_chunks), dim3(64), 0, 0, dp, n_words, dT, dP, 0u, n_chunks);
-    CK(hipDeviceSynchronize());
-    CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(mxg::k_bs_transpose, dim3(n_chunks), dim3(64), 0, 0, dp, n_words, dT, dP, 0u, n_chunks);
-    CK(hipEventRecord(e1));
-    CK(hipEventSynchronize(e1));
-    float ms_tr = 0;
-    CK(hipEventElapsedTime(&ms_tr, e0, e1));
-    hipLaunchKernelGGL(mxg::k_hash_bs, dim3(512), dim3(256), 0, 0, dT, dP, dO, 0u, n_chunks, tt);
+    hipLaunchKernelGGL(mxg::k_hash_bs, dim3(512), dim3(256), 0, 0, dp, dTail, dO, 0u, n_chunks, tt, n_chunks - 1);
     CK(hipDeviceSynchronize());
     CK(hipGetLastError());
     // ---- verify chunks 0, 1, the middle one and the last one
@@ -89,13 +82,12 @@ int main(int argc, char **argv)
     }
     printf("verify: %s (%llu candidates in 4 chunks)\n", bad ? "FAILED" : "ok", (unsigned long long)total);
     const double kmers = (double)n_chunks * 65536.0;
-    printf("k_bs_transpose: %.1f us (%.0f GB/s read + written)\n", ms_tr * 1e3, kmers * 0.5 / ms_tr * 1e-6);
     for (int blocks : {256, 512, 768, 1024}) {
-        hipLaunchKernelGGL(mxg::k_hash_bs, dim3(blocks), dim3(256), 0, 0, dT, dP, dO, 0u, n_chunks, tt);
+        hipLaunchKernelGGL(mxg::k_hash_bs, dim3(blocks), dim3(256), 0, 0, dp, dTail, dO, 0u, n_chunks, tt, n_chunks - 1);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
         const int reps = 5;
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mxg::k_hash_bs, dim3(blocks), dim3(256), 0, 0, dT, dP, dO, 0u, n_chunks, tt);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mxg::k_hash_bs, dim3(blocks), dim3(256), 0, 0, dp, dTail, dO, 0u, n_chunks, tt, n_chunks - 1);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms = 0;
