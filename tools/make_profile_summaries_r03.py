@@ -64,7 +64,11 @@ valu = {
     "kernel": hname, "bases_per_launch": bases_launch, "waves": hc["SQ_WAVES"], "valu_wave_instr": hc["SQ_INSTS_VALU"],
     "valu_wave_instr_per_base": hc["SQ_INSTS_VALU"] / bases_launch,
     "valu_lane_ops_per_base": hc["SQ_INSTS_VALU"] * 64.0 / bases_launch,
-    "valu_busy": hc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles),
+    "gpu_cycles_per_valu_instr_per_simd": cycles * 1024.0 / hc["SQ_INSTS_VALU"],
+    "issue_floor_cycles_per_instr": 2.0,
+    "note": "SQ_ACTIVE_INST_VALU equals the instruction count for this kernel (one count per wave instruction), so it says nothing "
+            "about busy cycles; the kernel alone on the GPU takes gpu_cycles (GRBM_GUI_ACTIVE / 8 XCDs) for valu_wave_instr / 1024 "
+            "instructions per SIMD",
     "lds_instr": hc["SQ_INSTS_LDS"], "wait_any_frac_of_wave_cycles": hc["SQ_WAIT_ANY"] / hc["SQ_WAVE_CYCLES"], "gpu_cycles": cycles,
     "source": "profiles/r03/configs2_pmc_by_kernel.json (tools/pmc_r03.sh)",
 }
