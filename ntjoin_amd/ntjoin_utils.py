@@ -282,6 +282,130 @@ def build_graph(list_mxs, weights, graph=None, black_list=None):
     return MxGraph(names, zip(g["edge_u"].tolist(), g["edge_v"].tolist()), support, g["edge_weight"].tolist())
 
 
+# ---- many independent calls at once -----------------------------------------------------------------------------------------
+# The overlap stage calls filter_minimizers and build_graph once per pair of adjacent contigs, on two lists of ~15 minimizers,
+# thousands of times per run (reference bin/ntjoin_overlap.py:28,132).  One engine, one upload and one pass of the graph-stage
+# kernels per call is all overhead at that size; the *_many forms take the calls' inputs together: every item's hashes are
+# renumbered (item << 32 | rank of the hash among the item's distinct hashes: a bijection, so items can never meet in the join),
+# the items' lists become the records of A assemblies of ONE handle, the graph stage runs once, and the results are split per
+# item.  Results are exactly those of the one-at-a-time functions (tests/test_gpu_parity.py).
+def _compose_items(items):
+    n_asm = {len(it) for it in items}
+    if len(n_asm) != 1:
+        raise ValueError("*_many: every item must hold the same number of assemblies")
+    A = n_asm.pop()
+    if len(items) >= (1 << 32):
+        raise ValueError("*_many: too many items")
+    keys = [[] for _ in range(A)]      # per assembly slot: composed keys of every item's lists, in item order
+    recs = [[] for _ in range(A)]
+    n_rec = [0] * A
+    originals, shapes = [], []
+    for i, it in enumerate(items):
+        lists_per_asm = [it[name] for name in it]
+        flat = np.fromiter((int(mx) for lists in lists_per_asm for lst in lists for mx in lst), dtype=np.uint64)
+        uniq = np.unique(flat)
+        originals.append(uniq)
+        local = (np.uint64(i) << np.uint64(32)) | np.searchsorted(uniq, flat).astype(np.uint64)
+        at = 0
+        shape = []
+        for a, lists in enumerate(lists_per_asm):
+            lens = [len(lst) for lst in lists]
+            n = int(sum(lens))
+            keys[a].append(local[at:at + n])
+            recs[a].append(np.repeat(np.arange(n_rec[a], n_rec[a] + len(lists), dtype=np.uint32), lens))
+            n_rec[a] += len(lists)
+            at += n
+            shape.append(lens)
+        shapes.append(shape)
+    cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)  # noqa: E731
+    return A, [cat(k_, np.uint64) for k_ in keys], [cat(r_, np.uint32) for r_ in recs], n_rec, originals, shapes
+
+
+def _engine_from_composed(A, keys, recs, n_rec, weights=None):
+    eng = MxEngine(k=32, w=1)
+    for a in range(A):
+        eng.add_minimizers(f"slot{a}", 1.0 if weights is None else float(weights[a]), keys[a], np.zeros(len(keys[a]), dtype=np.uint32),
+                           recs[a], [str(r) for r in range(n_rec[a])])
+    return eng
+
+
+def _by_assembly_count(items, fn, *per_item):
+    """items of 2, 3, ... assemblies are taken group by group (a handle has one number of assemblies); results in input order"""
+    out = [None] * len(items)
+    for n_asm in sorted({len(it) for it in items}):
+        idx = [i for i, it in enumerate(items) if len(it) == n_asm]
+        res = fn([items[i] for i in idx], *[[p[i] for i in idx] for p in per_item])
+        for i, r in zip(idx, res):
+            out[i] = r
+    return out
+
+
+def filter_minimizers_many(items):
+    """[filter_minimizers(item) for item in items] with one handle and one pass of the graph-stage kernels (per number of
+    assemblies among the items)"""
+    items = list(items)
+    if not items:
+        return []
+    if any(not it for it in items):
+        raise TypeError("unbound method set.intersection() needs an argument")  # what the reference raises for an empty dict
+    return _by_assembly_count(items, _filter_many_group)
+
+
+def _filter_many_group(items):
+    A, keys, recs, n_rec, _, shapes = _compose_items(items)
+    with _engine_from_composed(A, keys, recs, n_rec) as eng:
+        eng.build_graph()
+        keep = [(eng.get_mx_flags(a) & capi.MX_INALL) != 0 for a in range(A)]
+    out, at = [], [0] * A
+    for it, shape in zip(items, shapes):
+        res = {}
+        for a, (name, lens) in enumerate(zip(it, shape)):
+            lists = []
+            for lst, n in zip(it[name], lens):
+                kf = keep[a][at[a]:at[a] + n].tolist()
+                lists.append([mx for mx, k_ in zip(lst, kf) if k_])
+                at[a] += n
+            res[name] = lists
+        out.append(res)
+    return out
+
+
+def build_graph_many(items, weights):
+    """[build_graph(item, w) for item, w in zip(items, weights)] with one handle and one pass of the graph-stage kernels.
+    `weights`: one dict per item (assembly -> weight), or one dict for all items.  Every item must be filter_minimizers' output."""
+    items = list(items)
+    if not items:
+        return []
+    wts = [weights] * len(items) if isinstance(weights, dict) else list(weights)
+    return _by_assembly_count(items, _graph_many_group, wts)
+
+
+def _graph_many_group(items, wts):
+    A, keys, recs, n_rec, originals, _ = _compose_items(items)
+    with _engine_from_composed(A, keys, recs, n_rec) as eng:
+        eng.build_graph()
+        for a in range(A):
+            if not np.all((eng.get_mx_flags(a) & capi.MX_SHARED) != 0):
+                raise ValueError("build_graph_many expects filter_minimizers' output: every minimizer exactly once in every assembly "
+                                 "of its item (the reference's call site, bin/ntjoin.py:198-201)")
+        g = eng.get_graph()
+    vkey = g["vertex_hash"]
+    v_item = (vkey >> np.uint64(32)).astype(np.int64)          # vertices come in assembly 0's order: items are contiguous
+    v_first = np.searchsorted(v_item, np.arange(len(items) + 1))
+    e_item = v_item[g["edge_u"]] if len(g["edge_u"]) else np.zeros(0, dtype=np.int64)
+    graphs = []
+    for i, (it, w_i) in enumerate(zip(items, wts)):
+        names_in_order = list(it.keys())
+        v0, v1 = int(v_first[i]), int(v_first[i + 1])
+        names = [str(h) for h in originals[i][(vkey[v0:v1] & np.uint64(0xFFFFFFFF)).astype(np.int64)].tolist()]
+        sel = np.flatnonzero(e_item == i)
+        masks = g["edge_support"][sel].tolist()
+        support = [[names_in_order[b] for b in range(A) if m >> b & 1] for m in masks]
+        weight = [float(sum(w_i[nm] for nm in sup)) for sup in support]   # (calc_total_weight: sum in support order)
+        graphs.append(MxGraph(names, zip((g["edge_u"][sel] - v0).tolist(), (g["edge_v"][sel] - v0).tolist()), support, weight))
+    return graphs
+
+
 def run_indexlr(assembly, k, w, t, **kwargs):
     "Run indexlr on the given assembly with the specified k and w"
     out = f"{assembly}.k{k}.w{w}.tsv"

@@ -131,6 +131,54 @@ def test_python_mirror_functions(tmp_path):
         nu.read_minimizers(str(bad))
 
 
+def test_many_small_calls_in_one_pass():
+    """filter_minimizers_many / build_graph_many: the overlap stage's thousands of calls on two lists of ~15 minimizers
+    (reference bin/ntjoin_overlap.py:28,132) taken together -- the same results as the calls one at a time and as the oracle's
+    restatement of the reference's functions, including hashes that occur in several items, duplicates inside a list, empty
+    lists, and items of more than two assemblies"""
+    import random
+    from ntjoin_amd import ntjoin_utils as nu
+    from oracle import graph_oracle as go
+    rng = random.Random(5)
+    pool = [str(rng.getrandbits(64)) for _ in range(400)]
+    items = []
+    for i in range(60):
+        a_n = 2 if i % 9 else 3
+        base = rng.sample(pool, rng.randint(0, 25))
+        item = {}
+        for a in range(a_n):
+            lst = [m for m in base if rng.random() < 0.8] + rng.sample(pool, rng.randint(0, 4))
+            rng.shuffle(lst)
+            if lst and rng.random() < 0.15:
+                lst.insert(rng.randrange(len(lst) + 1), lst[0])     # a duplicate inside the list
+            cut = rng.randint(0, len(lst))
+            item[f"asm{a}_{i}"] = [lst[:cut], lst[cut:]] if rng.random() < 0.3 else [lst]
+        items.append(item)
+    many = nu.filter_minimizers_many(items)
+    assert len(many) == len(items)
+    for it, got in zip(items, many):
+        assert got == go.filter_minimizers(it)
+        assert list(got.keys()) == list(it.keys())
+    assert many[:5] == [nu.filter_minimizers(it) for it in items[:5]]
+    # graphs: on what the filter returned, minus duplicates (build_graph's contract: every minimizer once per assembly)
+    clean, weights = [], []
+    for got in many:
+        dup = {m for lists in got.values() for lst in lists for m in lst if sum(l.count(m) for l in lists) > 1}
+        clean.append({a: [[m for m in lst if m not in dup] for lst in lists] for a, lists in got.items()})
+        weights.append({a: float(rng.choice([1, 2, 1.5])) for a in got})
+    graphs = nu.build_graph_many(clean, weights)
+    for it, w_i, g in zip(clean, weights, graphs):
+        want_vertices, want_edges = go.build_edges(it, w_i)
+        mine = {frozenset((s, t)): (sup, w) for s, t, sup, w in g.edge_list_named()}
+        assert mine == {frozenset((s, t)): (sup, w) for s, t, sup, w in want_edges}
+        assert set(g.names) == want_vertices
+    one = nu.build_graph(clean[3], weights[3])
+    assert one.edge_list_named() == graphs[3].edge_list_named() and one.names == graphs[3].names
+    same_w = {f"slot{a}": 1.0 for a in range(2)}
+    pairs = [{"slot0": it[list(it)[0]], "slot1": it[list(it)[1]]} for it in clean if len(it) == 2][:6]
+    assert [g.edge_list_named() for g in nu.build_graph_many(pairs, same_w)] == [nu.build_graph(p, same_w).edge_list_named() for p in pairs]
+
+
 def test_array_backed_views_equal_reference_on_all_goldens():
     """read_minimizers(views=True) and Ntjoin.make_minimizer_graph(materialize="views") (what a genome-scale run uses instead of
     dicts of Python strings) hold exactly what the reference's own functions returned, for every golden case"""
