@@ -4,8 +4,8 @@ data with parts taken out: registers only, + scalar loads, + vector loads, + sto
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "ntjoin_amd", "csrc", "gen"))
-import bs_gen as G  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bs_gen_v2 as G  # noqa: E402   (the generator as it was when this was measured: planes from a pre-transposed copy)
 
 g = G.Gen(32)
 body = g.chunk()
