@@ -108,6 +108,7 @@ struct Assembly {
     std::vector<uint32_t> strip0_dense, strip0_sparse;  // [n_runs+1] exclusive prefix of strips per run
     std::vector<uint64_t> g0;                           // [n_runs+1] exclusive prefix of k-mers per run
     DevBuf d_runs, d_strip0_dense, d_strip0_sparse, d_g0, d_ctg_nk, d_ctg_rec, d_ctg_run0, d_ctg_drop;
+    DevBuf d_strip_run;  // strip of the sparse strip table -> its run (k_strip_runs)
     // k = 32 route (sketch_bs.hip): the bases transposed for the bit-sliced ring filter, its result, chunk -> first run
     bool bs_ready = false, bs_impossible = false;
     uint32_t bs_chunks = 0;

@@ -142,6 +142,7 @@ struct SparseParams {
                           // bytes per strip written and read instead of 16 -- at 3 Gbp the strip tables were 0.6 GB of HBM
                           // traffic per step)
     const uint4 *init_tab; // byte table of init_direct (make_init_tab), 256 entries
+    const uint32_t *strip_run;  // k = 32 route: the run of every strip of the assembly (k_strip_runs)
     HashTab tab;
 };
 
@@ -400,12 +401,11 @@ __global__ __launch_bounds__(256) void k_bs_count(const SparseParams p, const ui
         uint32_t len = 0;
         uint64_t b = 0;
         if (s < p.strip_hi) {
-            const uint32_t lo = find_run(p.run_strip0, p.run_lo, p.run_hi, s);
+            const uint32_t lo = p.strip_run[s];
             const Run run = p.runs[lo];
             const uint32_t j0 = (s - p.run_strip0[lo]) * S;
             len = min(S, run.n_kmers - j0);
             b = run.base_off + j0;
-            p.strip_meta[srel] = lo;
         }
         const uint32_t wave_id = vb * 4u + wv;
         // eight words are requested at a time (one dependent load per word left the kernel waiting for memory)
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(RW_WAVES * 64) void k_bs_reorder_w(const ReorderPar
         const uint32_t c = in ? p.strip_cnt[s] : 0u;
         uint32_t m_c = 0, m_k = 0, m_blo = 0, m_bhi = 0, len = 0;  // the strip's contig, first k-mer index, base offset, k-mers
         if (in) {
-            const uint32_t ri = p.strip_meta[s];
+            const uint32_t ri = p.strip_meta[p.strip_lo + s];  // (here: the assembly's strip -> run table)
             const Run run = p.runs[ri];
             const uint32_t j0 = (p.strip_lo + s - p.run_strip0[ri]) * p.S;
             const uint64_t b = run.base_off + j0;
@@ -1373,7 +1373,9 @@ __device__ __forceinline__ void defer_stretch(const GapFixParams &p, const uint4
 // most GAP_DEV_NSMALL k-mers: 23 KB per block, which fits beside the other stream's hash kernel -- blocks of 56 KB, nearly
 // all with nothing to do, waited 100-160 us for a CU with room), global scratch for the rare long ones (k_gap_post's one
 // block walks them before it ranks the stretches).  All early exits are block-uniform.
-constexpr uint32_t GAP_DEV_NSMALL = 1792;
+constexpr uint32_t GAP_DEV_NSMALL = 4096;  // (= GAP_DEV_NMAX since round 3: the filter kernel of the k = 32 route uses no LDS, so a
+                                           // 51 KB block finds room; the one-block walk of the longer stretches in k_gap_post took 45 us
+                                           // in three batches of thirteen at configs[2]; 1792 and 23 KB before)
 template <int VARIANT>
 __device__ __forceinline__ void gap_fix_one(const GapFixParams &p, const uint32_t j, const uint32_t nmax, uint64_t *lh,
                                             uint16_t *lidx0, uint16_t *lidx1, uint32_t *selbits, uint32_t *lw, uint32_t *sh,
@@ -1827,6 +1829,7 @@ struct Tables {
     const std::vector<uint64_t> *g0;
     const Run *d_runs;
     const uint32_t *d_strip0_dense, *d_strip0_sparse, *d_ctg_nk, *d_ctg_rec, *d_ctg_run0;
+    const uint32_t *d_strip_run = nullptr;  // strip (sparse table) -> run, or null (virtual contigs)
     const uint64_t *d_g0;
     const uint8_t *d_ctg_drop = nullptr;  // split load: contigs whose first minimizer is not reported (k_resolve), else null
     const std::vector<Record> *recs;  // for base accounting (may be null)
@@ -2405,11 +2408,12 @@ struct Driver {
         const bool r_wave = queue_cap && w_lds + 512 <= 65536 && env_u64("MXG_REORDER_W", 1) != 0;
         const uint32_t w_grid = std::min<uint32_t>((g.n_waves + RW_WAVES - 1) / RW_WAVES,
                                                    (uint32_t)env_u64("MXG_REORDER_W_GRID", 256 * 3));
-        if (!r_wave) bs_bitmap = nullptr;  // (a batch whose slices outgrow the LDS queues takes the rolling-hash kernel)
+        if (!r_wave || !T.d_strip_run) bs_bitmap = nullptr;  // (a batch whose slices outgrow the LDS queues takes the rolling-hash kernel)
         if (!bs_bitmap) MXG_HIP(h, sc(SC_ARENA).ensure((size_t)n_cap * 8));
         sp.arena = sc(SC_ARENA).as<uint2>();
         int rc;
         sp.init_tab = h->d_init_tab.as<uint4>();
+        sp.strip_run = T.d_strip_run;
         sp.tab = h->tab;
         if ((rc = bs_bitmap ? ev_begin(0, false) : ev_begin(batch_bases(T, g.c0, g.c1), true)) != MXG_OK) return rc;
         sp.n_tiles = g.n_blocks;
@@ -2449,7 +2453,7 @@ struct Driver {
         op.wave_tot = sp.wave_tot;
         op.wave_sup = sp.wave_sup;
         op.n_cand = sp.ctrl + 4;
-        op.strip_meta = sp.strip_meta;
+        op.strip_meta = bs_bitmap ? T.d_strip_run : sp.strip_meta;
         op.runs = sp.runs;
         op.run_strip0 = sp.run_strip0;
         op.strip_lo = sp.strip_lo;
@@ -2822,6 +2826,16 @@ struct Driver {
     }
 };
 
+// strip -> run, for every strip of the sparse strip table: block r writes run r's strips (once per assembly; the batch kernels of
+// the k = 32 route read it instead of searching run_strip0 per strip: 12-15 dependent loads per strip on a fragmented assembly)
+__global__ __launch_bounds__(256) void k_strip_runs(const uint32_t *__restrict__ run_strip0, uint32_t n_runs, uint32_t *__restrict__ strip_run)
+{
+    const uint32_t r = blockIdx.x;
+    if (r >= n_runs) return;
+    const uint32_t s0 = run_strip0[r], s1 = run_strip0[r + 1];
+    for (uint32_t s = s0 + threadIdx.x; s < s1; s += 256u) strip_run[s] = r;
+}
+
 static int prepare_tables(mxg_handle *h, Assembly *a)
 {
     if (a->tables_ready) return MXG_OK;
@@ -2848,6 +2862,13 @@ static int prepare_tables(mxg_handle *h, Assembly *a)
     if ((rc = upload(h, a->d_ctg_rec, a->ctg_rec)) != MXG_OK) return rc;
     if ((rc = upload(h, a->d_ctg_run0, a->ctg_run0)) != MXG_OK) return rc;
     if (a->any_drop && (rc = upload(h, a->d_ctg_drop, a->ctg_drop)) != MXG_OK) return rc;
+    if (n_runs) {
+        const uint32_t n_strips = a->strip0_sparse[n_runs];
+        MXG_HIP(h, a->d_strip_run.ensure((size_t)n_strips * 4 + 16));
+        hipLaunchKernelGGL(k_strip_runs, dim3((uint32_t)n_runs), dim3(256), 0, h->stream, a->d_strip0_sparse.as<uint32_t>(), (uint32_t)n_runs,
+                           a->d_strip_run.as<uint32_t>());
+        MXG_HIP(h, hipGetLastError());
+    }
     MXG_HIP(h, hipStreamSynchronize(h->stream));
     a->tables_ready = true;
     return MXG_OK;
@@ -2900,6 +2921,7 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
     T.d_runs = a->d_runs.as<Run>();
     T.d_strip0_dense = a->d_strip0_dense.as<uint32_t>();
     T.d_strip0_sparse = a->d_strip0_sparse.as<uint32_t>();
+    T.d_strip_run = a->d_strip_run.as<uint32_t>();
     T.d_ctg_nk = a->d_ctg_nk.as<uint32_t>();
     T.d_ctg_rec = a->d_ctg_rec.as<uint32_t>();
     T.d_ctg_run0 = a->d_ctg_run0.as<uint32_t>();
