@@ -1373,6 +1373,7 @@ __device__ __forceinline__ void defer_stretch(const GapFixParams &p, const uint4
 // most GAP_DEV_NSMALL k-mers: 23 KB per block, which fits beside the other stream's hash kernel -- blocks of 56 KB, nearly
 // all with nothing to do, waited 100-160 us for a CU with room), global scratch for the rare long ones (k_gap_post's one
 // block walks them before it ranks the stretches).  All early exits are block-uniform.
+constexpr uint32_t GAP_FIX_BLOCKS = 512;   // blocks of k_gap_fix (they walk the batch's stretches)
 constexpr uint32_t GAP_DEV_NSMALL = 4096;  // (= GAP_DEV_NMAX since round 3: the filter kernel of the k = 32 route uses no LDS, so a
                                            // 51 KB block finds room; the one-block walk of the longer stretches in k_gap_post took 45 us
                                            // in three batches of thirteen at configs[2]; 1792 and 23 KB before)
@@ -1474,8 +1475,10 @@ __device__ __forceinline__ void gap_fix_one(const GapFixParams &p, const uint32_
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
 {
-    const uint32_t n_g = p.ctrl[1], j = blockIdx.x;
-    if (j >= n_g || n_g > GAP_DEV_MAX || p.ctrl[0]) return;
+    // GAP_FIX_BLOCKS blocks walk the stretches (a block of 51 KB per possible stretch -- 2048, nearly all with nothing to do -- came
+    // to the CUs in three rounds: 36 us per launch beside the other stream's kernels)
+    const uint32_t n_g = p.ctrl[1];
+    if (blockIdx.x >= n_g || n_g > GAP_DEV_MAX || p.ctrl[0]) return;
     __shared__ uint64_t lh[GAP_DEV_NSMALL];
     __shared__ uint16_t lidx[2][GAP_DEV_NSMALL];
     __shared__ uint32_t selbits[GAP_DEV_NSMALL / 32];
@@ -1483,11 +1486,14 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
     __shared__ uint32_t sh[256];
     __shared__ uint32_t drop_idx;
     __shared__ uint32_t lw[GAP_DEV_NSMALL / 16 + 1024 / 16 + 4];  // the stretch's packed bases (+ k): every later read is local
-    const uint4 g = p.gaps[j];
-    if (g.z - g.y + 1u > GAP_DEV_NSMALL) return;  // k_gap_post takes the long ones
     if (threadIdx.x < 20) tab[threadIdx.x] = p.tab.e[threadIdx.x];
     __syncthreads();
-    gap_fix_one<VARIANT>(p, j, GAP_DEV_NSMALL, lh, lidx[0], lidx[1], selbits, lw, sh, tab, &drop_idx);
+    for (uint32_t j = blockIdx.x; j < n_g; j += gridDim.x) {
+        const uint4 g = p.gaps[j];
+        if (g.z - g.y + 1u <= GAP_DEV_NSMALL)  // (k_gap_post hands the longer ones to the host)
+            gap_fix_one<VARIANT>(p, j, GAP_DEV_NSMALL, lh, lidx[0], lidx[1], selbits, lw, sh, tab, &drop_idx);
+        __syncthreads();  // the work arrays are reused
+    }
 }
 
 struct GapPostParams {
@@ -2320,9 +2326,9 @@ struct Driver {
         gp.defer = reinterpret_cast<uint4 *>(h->pinned_defer) + (size_t)((ctrl_host - h->pinned_ctrl) / 16) * GAP_DEV_MAX;
         gp.tab = h->tab;
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-            hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V1_MIN>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
+            hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V1_MIN>, dim3(GAP_FIX_BLOCKS), dim3(256), 0, st, gp);
         else
-            hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V2_SUM>, dim3(GAP_DEV_MAX), dim3(256), 0, st, gp);
+            hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V2_SUM>, dim3(GAP_FIX_BLOCKS), dim3(256), 0, st, gp);
         GapPostParams pp;
         pp.ctrl = sc(SC_CTRL).as<uint32_t>();
         pp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
