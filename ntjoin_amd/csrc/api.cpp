@@ -934,17 +934,24 @@ int mxg_write_outputs(mxg_handle *h, const char *dot_path, const char *const *ts
         int rc = graph_to_host(h);  // (device -> host copies on the handle's stream: before the TSV kernels use it)
         if (rc != MXG_OK) return rc;
         int rc_dot = MXG_OK;
-        std::thread dot([&]() {
+        struct Joiner {  // (whatever happens to the TSVs, the writer thread is waited for)
+            std::thread t;
+            ~Joiner()
+            {
+                if (t.joinable()) t.join();
+            }
+        } dot{std::thread([&]() {
             try {
                 rc_dot = write_dot(h, dot_path);  // host arrays only from here on
-            } catch (const std::bad_alloc &) {
+            } catch (const std::exception &) {
                 rc_dot = MXG_ENOMEM;
             }
-        });
+        })};
         int rc_tsv = MXG_OK;
         for (size_t a = 0; a < h->asms.size() && rc_tsv == MXG_OK; ++a)
             if (tsv_paths[a]) rc_tsv = mxg_write_tsv(h, (int)a, tsv_paths[a], with_pos, with_strand, with_seq);
-        dot.join();
+        dot.t.join();
+        if (rc_dot == MXG_ENOMEM && rc_tsv == MXG_OK) return set_err(h, MXG_ENOMEM, "out of host memory writing '%s'", dot_path);
         return rc_tsv != MXG_OK ? rc_tsv : rc_dot;
     } catch (const std::bad_alloc &) {
         return set_err(h, MXG_ENOMEM, "out of host memory in mxg_write_outputs");
