@@ -25,9 +25,13 @@ A 32 x 32 transpose = 5 stages x 16 register pairs; a pair is swapped with v_lsh
 two v_xor_b32 and the left shift as a chain of v_add_u32 x, x (v_lshlrev_b32 is slow class): 1 632 instructions per chunk,
 +24 % on the filter itself.  (Until late in round 3 a pre-transposed copy of the assembly was kept instead, built by a kernel
 of its own: 0.26 B/bp of HBM and one more pass over the assembly per sketch, 0.33 ms per 3 Gbp -- as long as the filter's launch.)
-The strip in front of a lane's first one (its bases are the outgoing bases of slot 0) is the previous lane's last strip: its
-two words come over by DPP wave_shr:1 (lane 0: the two words in front of the chunk, by a scalar load), and their even / odd bits
-are separated into four registers of 16 steps each.
+The strip in front of a lane's first one (its bases are the outgoing bases of slot 0) is the previous lane's last strip: every
+lane loads those two words itself (the eight bytes in front of its 256: one global_load_dwordx2 more per chunk -- a DPP move
+and a scalar load with its wait did the same until they were found to cost more than a thousand cycles per chunk), and their
+even / odd bits are separated into four registers of 16 steps each.  The assembly's first and last chunk are read from padded
+copies (two zero words in front of chunk 0, zeros behind the last chunk's words), so nothing outside the packed array is read.
+The result words of a chunk are stored at the start of the NEXT chunk, after its words have arrived: a wait for "all but n
+loads" then never waits for a store.
 Slot s of lane L rolls the k-mers of strip 32 L + s - 1 (the strip BEFORE the one whose bits sit at position s): the
 incoming base of step t is then W[t] itself and the outgoing base is W[t] shifted up by one slot (v_add_u32 W, W) with
 the previous lane's last strip coming in at the bottom (bit t of Q: a running v_lshrrev_b32 and one v_bitop3_b32).
@@ -120,16 +124,9 @@ def to_asm(ins):
     if op == 'gload4':  # first dst register, base SGPR pair, byte offset; the lane's offset (lane * 256) is operand %[voff256]
         d = int(ins[1][1:])
         return f"global_load_dwordx4 v[{d}:{d + 3}], %[voff256], {sp(ins[2])} offset:{ins[3]}"
-    if op == 'dpp_shr1':  # dst[lane] = src[lane - 1], lane 0: 0   (two per chunk: their being slow class does not matter)
-        return f"v_mov_b32_dpp {a[0]}, {a[1]} wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-    if op == 'writelane0':  # lane 0 of dst <- SGPR
-        return f"v_writelane_b32 {a[0]}, {a[1]}, 0"
-    if op == 'sprev':  # SGPR pair <- the two packed words in front of the chunk (chunk 0: zeros); S_CB = the chunk's first word
-        d = ins[1]
-        return "\n".join([f"s_add_u32 s{d}, s{S_CB}, -8", f"s_addc_u32 s{d + 1}, s{S_CB + 1}, -1",
-                          f"s_cmp_eq_u32 s{S_C}, 0", f"s_cselect_b64 {sp(d)}, {sp(S_CB)}, {sp(d)}",
-                          f"s_load_dwordx2 {sp(d)}, {sp(d)}, 0x0", "s_waitcnt lgkmcnt(0)",
-                          f"s_cmp_eq_u32 s{S_C}, 0", f"s_cselect_b32 s{d}, 0, s{d}", f"s_cselect_b32 s{d + 1}, 0, s{d + 1}"])
+    if op == 'gload2':  # the two words in front of the lane's 64: base pair = the chunk's words - 8 bytes
+        d = int(ins[1][1:])
+        return f"global_load_dwordx2 v[{d}:{d + 1}], %[voff256], {sp(ins[2])} offset:{ins[3]}"
     if op in ('gstore4', 'gstore3', 'gstore1'):  # first data register, base SGPR pair, byte offset; lane * 128: %[voff128]
         d = int(ins[1][1:])
         n = int(op[-1])
@@ -182,14 +179,15 @@ S_P = S0 + 8
 S_O = S0 + 10
 S_TN = S0 + 12      # pair: the next chunk's words
 S_CB = S0 + 14      # pair: this chunk's words
-S_PV = S0 + 16      # pair: the two words in front of this chunk
+S_FIRST = S0 + 16   # 1 in a wave's first chunk (no results of a chunk before to store)
 S_CTAIL = S0 + 18   # the chunk whose words are taken from the copy (the assembly's last, ragged chunk)
 S_OC = S0 + 20      # 2 pairs: this chunk's OUT words - 4 bytes, this chunk's OUT words
-S_QN = S0 + 24      # (free)
+S_TQ = S0 + 24      # pair: the next chunk's words - 8 bytes
 S_TMP = S0 + 26     # pair
 S_CM = S0 + 28      # B_PLANES compare masks
 S_M16, S_M8, S_M4, S_M2, S_M1 = (S0 + 28 + B_PLANES + i for i in range(5))  # the transpose's select masks
-SEND = S_M1 + 1
+S_HD = (S_M1 + 2) & ~1   # pair (even register): the padded copy of chunk 0's words
+SEND = S_HD + 2
 
 
 class Gen:
@@ -286,8 +284,9 @@ class Gen:
         b = self.b
         FP, RP, W = self.FP, self.RP, self.W
         A, B = self.A, self.B
-        # ---- the chunk's 64 words per lane -> bit planes
+        # ---- the chunk's 64 words per lane -> bit planes; then (the loads are all back) the results of the chunk before go out
         self.planes_in()
+        e('prev_stores')
         # ---- warm-up: steps n = 0..31: the slot's own strip, i.e. the o-stream (W shifted up by one slot)
         for n in range(32):
             self.o_stream(n)
@@ -309,6 +308,8 @@ class Gen:
                 e('mov', B[1], W[(t, 1)])
             if t >= 16:  # the planes of steps t - 16 and t are dead: the next chunk's words 4 (t - 16) .. + 3 can come
                 e('gload4', f"v{W0 + 4 * (t - 16)}", S_TN, 16 * (t - 16))
+            if t == 31:  # (the running Q registers are dead since step 30: the words in front of the lane's 64 land there)
+                e('gload2', self.Qr[0], S_TQ, 0)
             if t < 31:
                 mA = self.masks(A)
                 mB = self.masks(B)
@@ -341,11 +342,11 @@ class Gen:
                     jr = (r - n) % 31
                     self.plane_update(RP[r], self.ro[jr], mA, self.ri[jr], mB)
         self.transpose_out()
-        # M[s] = the 32 positions of strip 32 lane + s - 1: slots 1..31 at bytes 0..123 of the lane's 128, slot 0 in front
-        e('gstore1', self.M[0], S_OC, 0)
-        for q in range(7):
-            e('gstore4', self.M[4 * q + 1], S_OC + 2, 16 * q)
-        e('gstore3', self.M[29], S_OC + 2, 112)
+        # M[s] = the 32 positions of strip 32 lane + s - 1: slots 1..31 at bytes 0..123 of the lane's 128, slot 0 in front.
+        # They stay in their registers (nothing touches M before the next chunk's first productive step) and are stored by
+        # the next chunk, or behind the loop.
+        self.store_ins = [('gstore1', self.M[0], S_OC, 0)] + [('gstore4', self.M[4 * q + 1], S_OC + 2, 16 * q) for q in range(7)] + \
+                         [('gstore3', self.M[29], S_OC + 2, 112)]
         self.check_banks()
         return self.ins
 
@@ -391,19 +392,15 @@ class Gen:
             e('bitop3', dst, t_, dst, f"s{sm}", tt)
 
     def planes_in(self):
-        """the lane's 64 packed words (RAW) -> the strip in front (QL, QH) and the 64 bit planes (W), in place"""
+        """the lane's 64 packed words (RAW) and the two in front of them (in the Qr registers) -> the strip in front (QL, QH)
+        and the 64 bit planes (W), in place"""
         e = self.e
-        pa, pb = self.M[0], self.M[1]   # (M is free until the first productive step)
+        pa, pb = self.Qr[0], self.Qr[1]
         # the first stage pairs strips s and s + 16, i.e. the words of loads s / 2 and s / 2 + 8: it starts as soon as nine of the
-        # sixteen loads are back and follows the others in (loads return in order), instead of waiting for the last one first
+        # sixteen loads are back and follows the others in (loads return in order; behind load j come 15 - j loads and the
+        # one of the two words in front), instead of waiting for the last one first.  No store is outstanding here.
         for k in range(0, 16, 2):
-            e('waitcnt', f'vmcnt({7 - k // 2})')
-            if k == 14:  # strip 31's words are in (and still as loaded: the last pair of the stage changes them)
-                e('sprev', S_PV)
-                e('dpp_shr1', pa, self.RAW[0][31])
-                e('dpp_shr1', pb, self.RAW[1][31])
-                e('writelane0', pa, f"s{S_PV}")
-                e('writelane0', pb, f"s{S_PV + 1}")
+            e('waitcnt', f'vmcnt({8 - k // 2 if k < 14 else 0})')
             for h_ in (0, 1):
                 self.swap_stage(self.RAW[h_], 16, S_M16, self.TT, only=k)
         for be in (0, 1):
@@ -447,25 +444,33 @@ class Gen:
         assert bad == 0, f"{bad} v_bitop3_b32 with a register bank conflict"
 
     # ---- the whole block: prologue, chunk loop ---------------------------------------------------------------
-    def address_setup(self, lines):
-        """SALU: bases of this chunk's OUT words and packed words, and of the NEXT chunk's packed words (the last chunk of a
-        wave asks for its own words again)"""
+    def next_pointers(self, lines, which):
+        """SALU: S_TN = the words of chunk s`which` (chunk 0 and the assembly's last chunk: their padded copies), S_TQ = S_TN - 8"""
         L = lines.append
-        t0, t1 = S_TMP, S_TMP + 1
+        L(f"s_mov_b32 s{which + 1}, 0")
+        L(f"s_lshl_b64 {sp(S_TN)}, {sp(which)}, 14")
+        L(f"s_add_u32 s{S_TN}, s{S_TN}, s{S_T}")
+        L(f"s_addc_u32 s{S_TN + 1}, s{S_TN + 1}, s{S_T + 1}")
+        L(f"s_cmp_eq_u32 s{which}, s{S_CTAIL}")
+        L(f"s_cselect_b64 {sp(S_TN)}, {sp(S_P)}, {sp(S_TN)}")
+        L(f"s_cmp_eq_u32 s{which}, 0")
+        L(f"s_cselect_b64 {sp(S_TN)}, {sp(S_HD)}, {sp(S_TN)}")
+        L(f"s_add_u32 s{S_TQ}, s{S_TN}, -8")
+        L(f"s_addc_u32 s{S_TQ + 1}, s{S_TN + 1}, -1")
+
+    def address_setup(self, lines):
+        """SALU at the top of the loop: the NEXT chunk's words (the last chunk of a wave asks for its own words again)"""
+        L = lines.append
+        t0 = S_TMP
         L(f"s_add_u32 s{t0}, s{S_C}, s{S_STRIDE}")
         L(f"s_cmp_lt_u32 s{t0}, s{S_N}")
         L(f"s_cselect_b32 s{t0}, s{t0}, s{S_C}")
-        L(f"s_mov_b32 s{t1}, 0")
-        # this chunk's words (for the pair in front of them) and the next chunk's (the last, ragged chunk: its padded copy)
-        L(f"s_lshl_b64 {sp(S_CB)}, {sp(S_C)}, 14")
-        L(f"s_add_u32 s{S_CB}, s{S_CB}, s{S_T}")
-        L(f"s_addc_u32 s{S_CB + 1}, s{S_CB + 1}, s{S_T + 1}")
-        L(f"s_lshl_b64 {sp(S_TN)}, {sp(t0)}, 14")
-        L(f"s_add_u32 s{S_TN}, s{S_TN}, s{S_T}")
-        L(f"s_addc_u32 s{S_TN + 1}, s{S_TN + 1}, s{S_T + 1}")
-        L(f"s_cmp_eq_u32 s{t0}, s{S_CTAIL}")
-        L(f"s_cselect_b64 {sp(S_TN)}, {sp(S_P)}, {sp(S_TN)}")
-        d = S_OC + 2  # the chunk's 2048 words; S_OC: the same minus one word (slot 0 of a lane = the word in front of its 31)
+        self.next_pointers(lines, t0)
+
+    def out_pointers(self, lines):
+        """SALU: this chunk's 2048 OUT words (S_OC + 2) and the same minus one word (slot 0 of a lane = the word in front of its 31)"""
+        L = lines.append
+        d = S_OC + 2
         L(f"s_lshl_b64 {sp(d)}, {sp(S_C)}, 13")
         L(f"s_add_u32 s{d}, s{d}, s{S_O}")
         L(f"s_addc_u32 s{d + 1}, s{d + 1}, s{S_O + 1}")
@@ -473,9 +478,9 @@ class Gen:
         L(f"s_addc_u32 s{S_OC + 1}, s{d + 1}, -1")
 
     def asm(self):
-        """the inline-asm text.  Operands: %[t] %[p] %[o] (SGPR pairs: packed bases, padded copy of the last chunk's words, OUT),
-        %[c0] first chunk of the wave, %[n] one past the last chunk, %[stride] chunks between a wave's chunks, %[tt] threshold,
-        %[ctail] the chunk read from the copy, VGPRs %[voff256] = lane * 256, %[voff128] = lane * 128"""
+        """the inline-asm text.  Operands: %[t] %[p] %[hd] %[o] (SGPR pairs: packed bases, padded copies of the last and of the first
+        chunk's words, OUT), %[c0] first chunk of the wave, %[n] one past the last chunk, %[stride] chunks between a wave's chunks,
+        %[tt] threshold, %[ctail] the last chunk, VGPRs %[voff256] = lane * 256, %[voff128] = lane * 128"""
         body = self.chunk()
         L = []
         A = L.append
@@ -486,8 +491,10 @@ class Gen:
         A(f"s_mov_b32 s{S_TT}, %[tt]")
         A(f"s_mov_b64 {sp(S_T)}, %[t]")
         A(f"s_mov_b64 {sp(S_P)}, %[p]")
+        A(f"s_mov_b64 {sp(S_HD)}, %[hd]")
         A(f"s_mov_b64 {sp(S_O)}, %[o]")
         A(f"s_mov_b32 s{S_CTAIL}, %[ctail]")
+        A(f"s_mov_b32 s{S_FIRST}, 1")
         for i in range(self.b):  # compare masks: Cm_i = all ones iff bit i of the threshold is set
             A(f"s_bfe_u32 s{S_TMP}, s{S_TT}, {hex((1 << 16) | i)}")
             A(f"s_sub_u32 s{S_CM + i}, 0, s{S_TMP}")
@@ -496,23 +503,31 @@ class Gen:
         A(f"s_cmp_ge_u32 s{S_C}, s{S_N}")
         A("s_cbranch_scc1 L_bs_end_%=")
         # prologue: the first chunk's words
-        A(f"s_lshl_b64 {sp(S_TN)}, {sp(S_C)}, 14")
-        A(f"s_add_u32 s{S_TN}, s{S_TN}, s{S_T}")
-        A(f"s_addc_u32 s{S_TN + 1}, s{S_TN + 1}, s{S_T + 1}")
-        A(f"s_cmp_eq_u32 s{S_C}, s{S_CTAIL}")
-        A(f"s_cselect_b64 {sp(S_TN)}, {sp(S_P)}, {sp(S_TN)}")
+        A(f"s_mov_b32 s{S_TMP}, s{S_C}")
+        self.next_pointers(L, S_TMP)
         for k in range(16):
             A(to_asm(('gload4', f"v{W0 + 4 * k}", S_TN, 16 * k)))
+        A(to_asm(('gload2', self.Qr[0], S_TQ, 0)))
         A("L_bs_loop_%=:")
         self.address_setup(L)
         for ins in body:
-            if ins[0] != 'comment':
+            if ins[0] == 'prev_stores':
+                A(f"s_cmp_eq_u32 s{S_FIRST}, 1")
+                A("s_cbranch_scc1 L_bs_nostore_%=")
+                for st in self.store_ins:
+                    A(to_asm(st))
+                A("L_bs_nostore_%=:")
+                A(f"s_mov_b32 s{S_FIRST}, 0")
+                self.out_pointers(L)
+            elif ins[0] != 'comment':
                 for piece in to_asm(ins).split("\n"):
                     A(piece)
         A(f"s_add_u32 s{S_C}, s{S_C}, s{S_STRIDE}")
         A(f"s_cmp_lt_u32 s{S_C}, s{S_N}")
         A("s_cbranch_scc1 L_bs_loop_%=")
-        A("s_waitcnt vmcnt(0)")  # (the requests for a chunk that does not follow)
+        for st in self.store_ins:  # the last chunk's results
+            A(to_asm(st))
+        A("s_waitcnt vmcnt(0)")  # (and the requests for a chunk that does not follow)
         A("L_bs_end_%=:")
         return L
 
@@ -551,14 +566,25 @@ class VM:
         lanes = np.arange(64)
         return [self.packed[chunk, 64 * lanes + 4 * k + j].copy() for j in range(4)]
 
+    def front_words(self, chunk):
+        """what the global_load_dwordx2 brings: the two words in front of the lane's 64 (in front of chunk 0: zeros, the padded copy)"""
+        flat = np.concatenate([np.zeros(2, dtype=np.uint32), self.packed.reshape(-1)])
+        lanes = np.arange(64)
+        at = chunk * 4096 + 64 * lanes  # (+ 2 for the pad, - 2 for "in front")
+        return [flat[at].copy(), flat[at + 1].copy()]
+
     def run(self, g):
         U = np.uint32
         for k in range(16):
             for j, wds in enumerate(self.lane_words(self.c, k)):
                 self.vr[f"v{W0 + 4 * k + j}"] = wds
+        for j, wds in enumerate(self.front_words(self.c)):
+            self.vr[f"v{int(g.Qr[0][1:]) + j}"] = wds
         pend = {}  # loads in flight: they land when the body ends (no instruction of this chunk may see them)
-        for ins in g.ins:
+        for ins in list(g.ins) + list(getattr(g, 'store_ins', [])):  # (the chunk's results go out at the start of the next chunk / behind the loop)
             op = ins[0]
+            if op == 'prev_stores':
+                continue
             if op == 'xor':
                 self.vr[ins[1]] = self.V(ins[2]) ^ self.V(ins[3])
             elif op == 'and':
@@ -578,20 +604,10 @@ class VM:
                 self.vr[ins[1]] = (self.V(ins[2]) + self.V(ins[3])).astype(U)
             elif op == 'lshr':
                 self.vr[ins[1]] = (self.V(ins[2]) >> U(ins[3])).astype(U)
-            elif op == 'dpp_shr1':
-                src = self.V(ins[2])
-                r = np.zeros(64, dtype=U)
-                r[1:] = src[:-1]
-                self.vr[ins[1]] = r
-            elif op == 'writelane0':
-                r = self.V(ins[1]).copy()
-                r[0] = self.sr[int(ins[2][1:])] & 0xFFFFFFFF
-                self.vr[ins[1]] = r
-            elif op == 'sprev':
-                flat = self.packed.reshape(-1)
-                at = self.c * 4096
-                self.sr[ins[1]] = int(flat[at - 2]) if self.c else 0
-                self.sr[ins[1] + 1] = int(flat[at - 1]) if self.c else 0
+            elif op == 'gload2':
+                d = int(ins[1][1:])
+                for j, wds in enumerate(self.front_words(self.cn)):
+                    pend[f"v{d + j}"] = wds
             elif op == 'gload4':
                 k = ins[3] // 16
                 d = int(ins[1][1:])
@@ -659,11 +675,11 @@ def out_position(c, t, lane, s):
 def emit_inc(path, k):
     g = Gen(k)
     lines = g.asm()
-    n_valu = sum(1 for i in g.ins if i[0] in ('xor', 'and', 'or', 'mov', 'bitop3', 'add', 'lshr', 'dpp_shr1', 'writelane0'))
+    n_valu = sum(1 for i in g.ins if i[0] in ('xor', 'and', 'or', 'mov', 'bitop3', 'add', 'lshr'))
     with open(path, 'w') as fh:
         fh.write(f"// GENERATED by gen/bs_gen.py (k = {k}, {B_PLANES} sum planes): the bit-sliced ring filter, chunk loop included.\n")
         fh.write(f"// {n_valu} VALU per chunk of 65 536 base positions per wave, all of them full-rate (see gen/bs_gen.py).  Do not edit.\n")
-        fh.write("// operands: [t] [p] [o] SGPR pairs (packed bases, padded copy of the last chunk, OUT), [c0] [n] [stride] [tt] [ctail] SGPRs, [voff256] VGPR = lane * 256, [voff128] = lane * 128\n")
+        fh.write("// operands: [t] [p] [hd] [o] SGPR pairs (packed bases, padded copies of the last / first chunk, OUT), [c0] [n] [stride] [tt] [ctail] SGPRs, [voff256] VGPR = lane * 256, [voff128] = lane * 128\n")
         fh.write(f"#define HASH_BS_VGPR_END {VEND}\n")
         fh.write(f"#define HASH_BS_VALU_PER_CHUNK {n_valu}\n")
         fh.write(f"#define HASH_BS_PLANES {B_PLANES}\n")

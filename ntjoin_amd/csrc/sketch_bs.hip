@@ -586,13 +586,22 @@ int bs_prepare(mxg_handle *h, Assembly *a)
     a->bs_chunks = n_chunks;
     // (+ 256 bytes behind it: the batch kernels request the words of a whole strip, up to 1024 positions + 2 words, before masking)
     MXG_HIP(h, a->d_bs_out.ensure(((size_t)n_chunks * BS_OUT_WORDS + BS_OUT_PAD) * 4 + 256));
-    // the last chunk's words, padded with zeros to a whole chunk: the filter reads whole chunks (bases behind the assembly = A)
-    MXG_HIP(h, a->d_bs_tail.ensure((size_t)BS_CHUNK_WORDS * 4));
-    MXG_HIP(h, hipMemsetAsync(a->d_bs_tail.p, 0, (size_t)BS_CHUNK_WORDS * 4, h->stream));
-    const uint64_t tail_lo = (uint64_t)(n_chunks - 1) * BS_CHUNK_WORDS;
-    if (a->packed_words > tail_lo)
-        MXG_HIP(h, hipMemcpyAsync(a->d_bs_tail.p, a->d_packed + tail_lo, (size_t)(a->packed_words - tail_lo) * 4, hipMemcpyDeviceToDevice,
-                                  h->stream));
+    // padded copies of the first and of the last chunk's words (the filter reads whole chunks and, per lane, the two words in
+    // front of its 64: zeros in front of the assembly, zeros = base A behind it): [head copy | tail copy], BS_EDGE_WORDS each
+    MXG_HIP(h, a->d_bs_tail.ensure((size_t)2 * BS_EDGE_WORDS * 4));
+    MXG_HIP(h, hipMemsetAsync(a->d_bs_tail.p, 0, (size_t)2 * BS_EDGE_WORDS * 4, h->stream));
+    {
+        uint32_t *edge = a->d_bs_tail.as<uint32_t>();
+        const uint64_t n_head = std::min<uint64_t>(a->packed_words, BS_CHUNK_WORDS);
+        MXG_HIP(h, hipMemcpyAsync(edge + 2, a->d_packed, (size_t)n_head * 4, hipMemcpyDeviceToDevice, h->stream));
+        const uint64_t tail_lo = (uint64_t)(n_chunks - 1) * BS_CHUNK_WORDS;
+        if (n_chunks > 1) {  // (one chunk: it is the first one, and the head copy is padded behind as well)
+            const uint64_t from = tail_lo - 2;  // with the two words in front
+            if (a->packed_words > from)
+                MXG_HIP(h, hipMemcpyAsync(edge + BS_EDGE_WORDS, a->d_packed + from, (size_t)std::min<uint64_t>(a->packed_words - from, BS_CHUNK_WORDS + 2) * 4,
+                                          hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
     // chunk -> first run whose k-mers end behind the chunk's first position (runs are sorted)
     std::vector<uint32_t> run0((size_t)n_chunks + 1);
     size_t r = 0;
@@ -619,8 +628,9 @@ int bs_hash(mxg_handle *h, Assembly *a, uint32_t tau_hi, hipStream_t st)
     const char *eb = getenv("MXG_BS_BLOCKS");
     const unsigned env_blocks = eb && atoi(eb) > 0 ? (unsigned)atoi(eb) : 512u;
     const uint32_t blocks = std::min<uint32_t>((uint32_t)env_blocks, (a->bs_chunks + 3u) / 4u);  // two waves per SIMD are resident (see k_hash_bs)
-    hipLaunchKernelGGL(k_hash_bs, dim3(blocks), dim3(256), 0, st, a->d_packed, a->d_bs_tail.as<uint32_t>(),
-                       a->d_bs_out.as<uint32_t>() + BS_OUT_PAD, 0u, a->bs_chunks, tt, a->bs_chunks - 1u);
+    const uint32_t *head = a->d_bs_tail.as<uint32_t>() + 2, *tail = a->bs_chunks > 1 ? head + BS_EDGE_WORDS : head;
+    hipLaunchKernelGGL(k_hash_bs, dim3(blocks), dim3(256), 0, st, a->d_packed, head, tail, a->d_bs_out.as<uint32_t>() + BS_OUT_PAD, 0u,
+                       a->bs_chunks, tt, a->bs_chunks - 1u);
     MXG_HIP(h, hipGetLastError());
     return MXG_OK;
 }

@@ -40,10 +40,14 @@ def _vm_chunk(seed, tt, c, n_chunks=3):
             want[wi] = int((ref[gi * 32: gi * 32 + 32].astype(np.uint64) << sh).sum())
     first = 1 if lo < 0 else 0
     assert np.array_equal(np.asarray(out[first:], dtype=np.uint64), want[first:])
-    # the words left in the W registers are the next chunk's (requested while this one was computed): lane L holds words 64 L ..
+    # the words left in the W registers are the next chunk's (requested while this one was computed): lane L holds words 64 L ..,
+    # and the two words in front of them are in the running-Q registers
     lanes = np.arange(64)
     for i in range(64):
         assert np.array_equal(vm.vr[f"v{G.W0 + i}"], packed[c_next, 64 * lanes + i]), i
+    flat = np.concatenate([np.zeros(2, dtype=np.uint32), packed.reshape(-1)])
+    for j in (0, 1):
+        assert np.array_equal(vm.vr[f"v{int(g.Qr[0][1:]) + j}"], flat[c_next * 4096 + 64 * lanes + j])
     return float(ref.mean())
 
 
@@ -64,11 +68,11 @@ def test_instruction_classes_and_banks():
     g.chunk()
     ops = {i[0] for i in g.ins}
     valu = {"xor", "and", "or", "mov", "bitop3", "add", "lshr"}
-    # besides them, per chunk: two DPP moves + two v_writelane (the strip in front of the lane's first) and one scalar load
-    assert ops - valu <= {"gload4", "gstore1", "gstore3", "gstore4", "waitcnt", "comment", "dpp_shr1", "writelane0", "sprev"}
-    assert sum(1 for i in g.ins if i[0] in ("dpp_shr1", "writelane0")) == 4
+    # besides them: loads, waits and the marker where the results of the chunk before are stored -- nothing of the slow class
+    assert ops - valu <= {"gload4", "gload2", "waitcnt", "comment", "prev_stores"}
+    assert {i[0] for i in g.store_ins} == {"gstore1", "gstore3", "gstore4"}
     g.check_banks()
-    n_valu = sum(1 for i in g.ins if i[0] in valu | {"dpp_shr1", "writelane0"})
+    n_valu = sum(1 for i in g.ins if i[0] in valu)
     inc = open(os.path.join(REPO, "ntjoin_amd", "csrc", "hash_bs_k32.inc")).read()
     assert f"#define HASH_BS_VALU_PER_CHUNK {n_valu}\n" in inc
     assert f"#define HASH_BS_VGPR_END {G.VEND}\n" in inc

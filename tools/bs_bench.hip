@@ -48,20 +48,22 @@ int main(int argc, char **argv)
     uint64_t x = 88172645463325252ull;
     auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
     for (auto &v : hp) v = (uint32_t)rnd();
-    uint32_t *dp, *dTail, *dO;
+    uint32_t *dp, *dEdge, *dO;
     CK(hipMalloc(&dp, n_words * 4));
-    CK(hipMalloc(&dTail, (size_t)mxg::BS_CHUNK_WORDS * 4));
-    CK(hipMemset(dTail, 0, (size_t)mxg::BS_CHUNK_WORDS * 4));
+    CK(hipMalloc(&dEdge, (size_t)2 * mxg::BS_EDGE_WORDS * 4));  // padded copies of the first and of the last chunk's words
+    CK(hipMemset(dEdge, 0, (size_t)2 * mxg::BS_EDGE_WORDS * 4));
     CK(hipMalloc(&dO, ((size_t)n_chunks * mxg::BS_OUT_WORDS + mxg::BS_OUT_PAD) * 4));
     dO += mxg::BS_OUT_PAD;
     CK(hipMemcpy(dp, hp.data(), n_words * 4, hipMemcpyHostToDevice));
     const uint64_t tail_lo = (uint64_t)(n_chunks - 1) * mxg::BS_CHUNK_WORDS;  // the last (ragged) chunk: zero-padded copy
-    CK(hipMemcpy(dTail, dp + tail_lo, (n_words - tail_lo) * 4, hipMemcpyDeviceToDevice));
+    CK(hipMemcpy(dEdge + 2, dp, (size_t)mxg::BS_CHUNK_WORDS * 4, hipMemcpyDeviceToDevice));
+    CK(hipMemcpy(dEdge + mxg::BS_EDGE_WORDS, dp + tail_lo - 2, (n_words - tail_lo + 2) * 4, hipMemcpyDeviceToDevice));
+    const uint32_t *dHead = dEdge + 2, *dTail = dEdge + mxg::BS_EDGE_WORDS + 2;
     CK(hipMemset(dO - mxg::BS_OUT_PAD, 0xAB, ((size_t)n_chunks * mxg::BS_OUT_WORDS + mxg::BS_OUT_PAD) * 4));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(mxg::k_hash_bs, dim3(512), dim3(256), 0, 0, dp, dTail, dO, 0u, n_chunks, tt, n_chunks - 1);
+    hipLaunchKernelGGL(mxg::k_hash_bs, dim3(512), dim3(256), 0, 0, dp, dHead, dTail, dO, 0u, n_chunks, tt, n_chunks - 1);
     CK(hipDeviceSynchronize());
     CK(hipGetLastError());
     // ---- verify chunks 0, 1, the middle one and the last one
@@ -83,11 +85,11 @@ int main(int argc, char **argv)
     printf("verify: %s (%llu candidates in 4 chunks)\n", bad ? "FAILED" : "ok", (unsigned long long)total);
     const double kmers = (double)n_chunks * 65536.0;
     for (int blocks : {256, 512, 768, 1024}) {
-        hipLaunchKernelGGL(mxg::k_hash_bs, dim3(blocks), dim3(256), 0, 0, dp, dTail, dO, 0u, n_chunks, tt, n_chunks - 1);
+        hipLaunchKernelGGL(mxg::k_hash_bs, dim3(blocks), dim3(256), 0, 0, dp, dHead, dTail, dO, 0u, n_chunks, tt, n_chunks - 1);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
         const int reps = 5;
-        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mxg::k_hash_bs, dim3(blocks), dim3(256), 0, 0, dp, dTail, dO, 0u, n_chunks, tt, n_chunks - 1);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mxg::k_hash_bs, dim3(blocks), dim3(256), 0, 0, dp, dHead, dTail, dO, 0u, n_chunks, tt, n_chunks - 1);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms = 0;
