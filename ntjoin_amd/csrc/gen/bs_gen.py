@@ -350,32 +350,45 @@ class Gen:
         self.check_banks()
         return self.ins
 
-    def swap_stage(self, regs, j, sm, temps, only=None):
-        """one stage of a 32 x 32 bit transpose in place: rows k, k + j (k & j == 0) exchange the bits whose index has bit j set
-        / clear:  t = ((x >> j) ^ y) & m;  y ^= t;  x ^= t << j   (m in an SGPR; the left shift = j times v_add_u32 t, t).
-        Two pairs are interleaved (their add chains are independent)."""
+    def temp_pool(self):
+        """registers that are dead while the bit planes are made and while the results are transposed back: the ring planes
+        (the warm-up makes them anew), the masks, the adder's registers and the transposes' own four -- eight per bank"""
+        return self.TT + self.FP[:7] + self.RP[:7] + self.A + self.B
+
+    def pick(self, pool, used, avoid_banks):
+        for t_ in pool:
+            if t_ not in used and bank(t_) not in avoid_banks:
+                used.add(t_)
+                return t_
+        raise RuntimeError("no temporary register of a suitable bank left")
+
+    def swap_pairs(self, pairs, j, sm, width=8):
+        """one stage of a 32 x 32 bit transpose in place on the register pairs (x, y) = rows (k, k + j): they exchange the bits
+        whose index has bit j set / clear:  t = ((x >> j) ^ y) & m;  y ^= t;  x ^= t << j   (m in an SGPR; the left shift = j
+        times v_add_u32 t, t).  `width` pairs are interleaved, so that an instruction never follows the one it depends on: a
+        chain of dependent v_add_u32 issued back to back runs at half the rate."""
         e = self.e
         tt = self.tt3(lambda a, b2, c: (a ^ b2) & c)
-        pairs = [(regs[k], regs[k + j]) for k in range(32) if not k & j]
-        if only is not None:
-            pairs = pairs[only:only + 2]
-        for i in range(0, len(pairs), 2):
-            grp2 = pairs[i:i + 2]
-            tmp = []
-            for (x, y) in grp2:
-                cands = [t_ for t_ in temps if bank(t_) != bank(y) and t_ not in tmp]
-                tmp.append(cands[0])
-            for (x, y), t_ in zip(grp2, tmp):
+        pool = self.temp_pool()
+        for i in range(0, len(pairs), width):
+            grp_ = pairs[i:i + width]
+            used = set()
+            tmp = [self.pick(pool, used, {bank(y)}) for (x, y) in grp_]
+            for (x, y), t_ in zip(grp_, tmp):
                 e('lshr', t_, x, j)
-            for (x, y), t_ in zip(grp2, tmp):
+            for (x, y), t_ in zip(grp_, tmp):
                 e('bitop3', t_, t_, y, f"s{sm}", tt)
-            for (x, y), t_ in zip(grp2, tmp):
+            for (x, y), t_ in zip(grp_, tmp):
                 e('xor', y, y, t_)
             for _ in range(j):
                 for t_ in tmp:
                     e('add', t_, t_, t_)
-            for (x, y), t_ in zip(grp2, tmp):
+            for (x, y), t_ in zip(grp_, tmp):
                 e('xor', x, x, t_)
+
+    @staticmethod
+    def stage_pairs(regs, j):
+        return [(regs[k], regs[k + j]) for k in range(32) if not k & j]
 
     def even_bits(self, dst, src, shift):
         """dst = the bits 2 i + shift of src, packed into bits 0..15 (right shifts only)"""
@@ -399,38 +412,41 @@ class Gen:
         # the first stage pairs strips s and s + 16, i.e. the words of loads s / 2 and s / 2 + 8: it starts as soon as nine of the
         # sixteen loads are back and follows the others in (loads return in order; behind load j come 15 - j loads and the
         # one of the two words in front), instead of waiting for the last one first.  No store is outstanding here.
+        p16 = [self.stage_pairs(self.RAW[h_], 16) for h_ in (0, 1)]
         for k in range(0, 16, 2):
             e('waitcnt', f'vmcnt({8 - k // 2 if k < 14 else 0})')
-            for h_ in (0, 1):
-                self.swap_stage(self.RAW[h_], 16, S_M16, self.TT, only=k)
+            self.swap_pairs(p16[0][k:k + 2] + p16[1][k:k + 2], 16, S_M16)
         for be in (0, 1):
             self.even_bits(self.QL[be], pa, be)
             self.even_bits(self.QH[be], pb, be)
-        for h_ in (0, 1):
-            for j, sm in ((8, S_M8), (4, S_M4), (2, S_M2), (1, S_M1)):
-                self.swap_stage(self.RAW[h_], j, sm, self.TT)
+        for j, sm in ((8, S_M8), (4, S_M4), (2, S_M2), (1, S_M1)):
+            self.swap_pairs(self.stage_pairs(self.RAW[0], j) + self.stage_pairs(self.RAW[1], j), j, sm)
 
-    def transpose_out(self):
+    def transpose_out(self, width=8):
         """M[t] bit s -> M[s] bit t, in place.  Stage j pairs rows k, k + j: new_k = (k & m) | ((k+j << j) & ~m),
         new_k+j = ((k >> j) & m) | (k+j & ~m), m = the bits whose index has bit j clear (an SGPR: v_bitop3_b32 with one SGPR source
-        stays fast class); the left shift is j times v_add_u32 x, x (v_lshlrev_b32 is slow class)."""
+        stays fast class); the left shift is j times v_add_u32 x, x (v_lshlrev_b32 is slow class).  `width` pairs interleaved."""
         e = self.e
         sel = self.tt3(lambda a, b2, c: a if c else b2)
+        pool = self.temp_pool()
         for j, sm in ((16, S_M16), (8, S_M8), (4, S_M4), (2, S_M2), (1, S_M1)):
-            for k in range(32):
-                if k & j:
-                    continue
-                a, bq = self.M[k], self.M[k + j]
-                t0 = self.TT[(bank(a) + 1) % 4]
-                t1 = self.TT[(bank(bq) + 1) % 4]
-                if t1 == t0:
-                    t1 = self.TT[(bank(bq) + 2) % 4]
-                e('add', t0, bq, bq)
+            pairs = self.stage_pairs(self.M, j)
+            for i in range(0, len(pairs), width):
+                grp_ = pairs[i:i + width]
+                used = set()
+                t0 = [self.pick(pool, used, {bank(a)}) for (a, bq) in grp_]
+                t1 = [self.pick(pool, used, {bank(bq)}) for (a, bq) in grp_]
+                for (a, bq), t_ in zip(grp_, t0):
+                    e('add', t_, bq, bq)
                 for _ in range(j - 1):
-                    e('add', t0, t0, t0)
-                e('lshr', t1, a, j)
-                e('bitop3', a, a, t0, f"s{sm}", sel)
-                e('bitop3', bq, t1, bq, f"s{sm}", sel)
+                    for t_ in t0:
+                        e('add', t_, t_, t_)
+                for (a, bq), t_ in zip(grp_, t1):
+                    e('lshr', t_, a, j)
+                for (a, bq), t_ in zip(grp_, t0):
+                    e('bitop3', a, a, t_, f"s{sm}", sel)
+                for (a, bq), t_ in zip(grp_, t1):
+                    e('bitop3', bq, t_, bq, f"s{sm}", sel)
 
     def check_banks(self):
         """no v_bitop3_b32 may read two VGPRs of one bank"""
