@@ -3354,9 +3354,21 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             h->stat_dense_kmers += gk;
             h->stat_batches_redone += q1 - j;
             if (j == q0) ++h->stat_sync_assemblies;
+            // (the batches that are kept may have left stretches to the host: their lists are read before anything reuses the slots)
+            std::vector<uint4> deferred;
+            for (size_t q = q0; q < j; ++q) {
+                const uint32_t nd = items[q].hc[11] == 0xFFFFFFFFu ? 0u : std::min(items[q].hc[11], GAP_DEV_MAX);
+                const uint4 *src = reinterpret_cast<const uint4 *>(h->pinned_defer) + (size_t)((items[q].hc - h->pinned_ctrl) / 16) * GAP_DEV_MAX;
+                deferred.insert(deferred.end(), src, src + nd);
+            }
             if ((rc = drv0.sparse_all(a, tabs[i], out, rp.tau_hi, rp.frac, items[j].g.c0)) != MXG_OK) return rc;
             MXG_HIP(h, hipStreamSynchronize(drv0.st));
-            a->n_mx = out.n;
+            uint64_t n_final = out.n;
+            if (!deferred.empty()) {
+                if ((rc = drv0.merge_deferred(a, tabs[i], deferred, out.n, &n_final)) != MXG_OK) return rc;
+                h->stat_deferred += deferred.size();
+            }
+            a->n_mx = n_final;
             a->has_sketch = true;
             state[i] = 2;
         } else {

@@ -62,6 +62,46 @@ def test_fuzz_sparse_path_vs_oracle(oracle):
             os.environ["MXG_SPARSE_S"] = saved
 
 
+def test_fuzz_k32_route_vs_oracle(oracle):
+    """the same at k = 32, the route ntJoin's default takes (bit-sliced filter over whole chunks of 65 536 positions, bitmap ->
+    ordered candidates, stretches on the device or left to the tile kernel): records around and beyond the chunk size, chunk
+    borders inside runs of N and inside low-complexity sequence, several chained batches, both stretch routes"""
+    from ntjoin_amd.engine import MxEngine
+    trials = int(os.environ.get("MXG_FUZZ_TRIALS", "40"))
+    rng = random.Random(int(os.environ.get("MXG_FUZZ_SEED", "3232")))
+    knobs = ("MXG_SPARSE_S", "MXG_SPARSE_BATCH_KMERS", "MXG_DEV_GAPS")
+    saved = {k_: os.environ.get(k_) for k_ in knobs}
+    try:
+        for t in range(trials):
+            w = rng.choice([150, 200, 333, 500, 1000, 2000])
+            c = rng.choice([2, 4, 8, 10, 16, 18])
+            while c / w > 0.125:
+                c //= 2
+            os.environ["MXG_SPARSE_S"] = str(rng.choice([64, 128, 320, 512]))
+            os.environ["MXG_SPARSE_BATCH_KMERS"] = str(rng.choice([40_000, 150_000, 10**9]))
+            os.environ["MXG_DEV_GAPS"] = str(rng.choice([0, 1]))
+            recs = [(f"r{i}", _rand_record(rng, rng.choice([31, 32, 33, 32 + w - 2, 32 + w - 1, 5000, 65536 - 31, 65536, 65537, 70000, 140000])))
+                    for i in range(rng.randint(1, 6))]
+            with MxEngine(k=32, w=w, cand_per_window=c) as eng:
+                eng.add_records("x", 1.0, recs)
+                eng.sketch()
+                sk = eng.get_sketch(0)
+                st = eng.stats()
+            assert st["bs_filter_bases"] == sum(len(s_) for _, s_ in recs) or st["kmers"] == 0 or not any(len(s_) >= 32 + w - 1 for _, s_ in recs) \
+                or st["bs_filter_bases"] == 0
+            for r, (rid, seq) in enumerate(recs):
+                lo, hi = int(sk["record_first"][r]), int(sk["record_first"][r + 1])
+                want = oracle.sketch(seq, 32, w, _oracle.V2_SUM)
+                got = list(zip(sk["out_hash"][lo:hi].tolist(), sk["pos"][lo:hi].tolist(), sk["forward"][lo:hi].tolist()))
+                assert got == [(h, p, f) for h, p, f, _ in want], (t, w, c, {k_: os.environ[k_] for k_ in knobs}, rid, len(seq))
+    finally:
+        for k_, v in saved.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
+
+
 def test_fuzz_graph_stage_vs_oracle(tmp_path):
     """random sketches fed through mxg_add_assembly_tsv: duplicates inside and across assemblies, empty records,
     1-6 assemblies, fractional weights -> flags, filtered lists, edges, weights and canonical .mx.dot vs the oracle"""

@@ -346,3 +346,19 @@ def test_batches_redone_one_by_one(oracle, route_knobs):
     route_knobs["MXG_GRID_BY_ESTIMATE"] = "2"
     st = _check(oracle, _records(41), 32, 200)
     assert st["retried_assemblies"] + st["batches_redone"] + st["sync_assemblies"] > 0
+
+
+def test_kept_batches_keep_their_deferred_stretches(oracle, route_knobs):
+    """batch 0 hands a long homopolymer stretch to the tile kernel, the last batch (a short-unit repeat: no candidate at all)
+    never reports the common way, so the assembly ends in the per-batch redo with batches 0 and 1 kept: the stretch batch 0
+    deferred is merged all the same (found by the k=32 fuzz test: 117 minimizers for 80 445)"""
+    route_knobs["MXG_DEV_GAPS"] = "1"
+    route_knobs["MXG_SPARSE_BATCH_KMERS"] = "150000"
+    route_knobs["MXG_SPARSE_S"] = "512"
+    rng = random.Random(44)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    recs = [("tiny", rnd(33)), ("polyA", rnd(46000) + "".join(rng.choice("Aa") for _ in range(81000)) + rnd(13000)),
+            ("plain", rnd(140000)), ("unit", ("ACGGTCA" * 10000)[:65536])]
+    st = _check(oracle, recs, 32, 1000, cand_per_window=4)
+    assert st["deferred_stretches"] >= 1
+    assert st["batches_redone"] >= 1
