@@ -138,3 +138,85 @@ def test_fuzz_graph_stage_vs_oracle(tmp_path):
         for a, nm in enumerate(names):
             uniq = {str(h) for h, f in zip(sks[a]["out_hash"].tolist(), flags[a].tolist()) if f & 1}
             assert uniq == set(state["list_mx_info"][nm].keys()), (t, a)
+
+
+def _derived_assembly(rng, base, sub):
+    """contigs cut out of `base` (some reverse-complemented, substitutions at rate `sub`, a run of N or a duplicated piece now
+    and then): shares most minimizers with it, repeats some inside itself"""
+    comp = str.maketrans("ACGTacgtN", "TGCAtgcaN")
+    recs, p, i = [], 0, 0
+    while p < len(base):
+        ln = rng.choice([40, 900, 5000, 30000, 70000, 140000])
+        seg = list(base[p:p + ln])
+        p += ln + rng.choice([0, 25, 300])
+        for q in range(len(seg)):
+            if rng.random() < sub:
+                seg[q] = rng.choice("ACGT")
+        if rng.random() < 0.3 and len(seg) > 3000:
+            a = rng.randrange(len(seg) - 2000)
+            seg[a:a + rng.choice([1, 50, 1500])] = "N" * len(seg[a:a + rng.choice([1, 50, 1500])])
+        if rng.random() < 0.3 and len(seg) > 8000:  # the same 3 kbp twice: minimizers that are not unique in the assembly
+            a, b = rng.randrange(len(seg) - 3000), rng.randrange(len(seg) - 3000)
+            seg[b:b + 3000] = seg[a:a + 3000]
+        s = "".join(seg)
+        if rng.random() < 0.5:
+            s = s.translate(comp)[::-1]
+        recs.append((f"c{i}", s))
+        i += 1
+    rng.shuffle(recs)
+    return recs
+
+
+def test_fuzz_whole_path_k32_vs_oracle(oracle, tmp_path):
+    """sketch -> uniqueness -> intersection -> edges on the device, k = 32 route, 2-4 related assemblies with low-complexity
+    stretches, N runs and repeated pieces, batches and stretch routes forced small: every record's minimizers and the canonical
+    .mx.dot against the oracle (the graph oracle reads the TSVs this engine wrote, whose records are checked first)"""
+    from ntjoin_amd.engine import MxEngine
+    from oracle import graph_oracle as go
+    trials = int(os.environ.get("MXG_FUZZ_TRIALS", "12"))
+    rng = random.Random(int(os.environ.get("MXG_FUZZ_SEED", "515")))
+    knobs = ("MXG_SPARSE_S", "MXG_SPARSE_BATCH_KMERS", "MXG_DEV_GAPS")
+    saved = {k_: os.environ.get(k_) for k_ in knobs}
+    os.chdir(tmp_path)
+    try:
+        for t in range(trials):
+            w = rng.choice([100, 200, 500, 1000])
+            c = rng.choice([4, 8, 10, 18])
+            while c / w > 0.125:
+                c //= 2
+            os.environ["MXG_SPARSE_S"] = str(rng.choice([64, 128, 320, 512]))
+            os.environ["MXG_SPARSE_BATCH_KMERS"] = str(rng.choice([60_000, 200_000, 10**9]))
+            os.environ["MXG_DEV_GAPS"] = str(rng.choice([0, 1]))
+            base = "".join(_rand_record(rng, rng.choice([20000, 70000, 140000])) for _ in range(rng.randint(1, 3)))
+            A = rng.randint(2, 4)
+            asms = [[("chr", base)]] + [_derived_assembly(rng, base, rng.choice([0.0, 0.002, 0.01])) for _ in range(A - 1)]
+            names = [f"t{t}_a{a}.fa.k32.w{w}.tsv" for a in range(A)]
+            weights = [rng.choice([1, 2, 0.5, 1.5]) for _ in range(A)]
+            fused = rng.random() < 0.5
+            with MxEngine(k=32, w=w, cand_per_window=c) as eng:
+                for nm, wt, recs in zip(names, weights, asms):
+                    eng.add_records(nm, wt, recs)
+                if fused:
+                    eng.sketch_graph()
+                else:
+                    eng.sketch()
+                for a, recs in enumerate(asms):
+                    sk = eng.get_sketch(a)
+                    for r, (rid, seq) in enumerate(recs):
+                        lo, hi = int(sk["record_first"][r]), int(sk["record_first"][r + 1])
+                        want = oracle.sketch(seq, 32, w, _oracle.V2_SUM)
+                        got = list(zip(sk["out_hash"][lo:hi].tolist(), sk["pos"][lo:hi].tolist()))
+                        assert got == [(h, p) for h, p, _, _ in want], (t, w, c, {k_: os.environ[k_] for k_ in knobs}, a, rid, len(seq))
+                    eng.write_tsv(a, names[a])
+                if not fused:
+                    eng.build_graph()
+                eng.write_dot(f"t{t}.mx.dot")
+            state = go.load_and_build(names[:-1], weights[:-1], names[-1], weights[-1])
+            got = go.canonical_dot_from_text(open(f"t{t}.mx.dot", encoding="utf-8").read())
+            assert got == go.canonical_dot_from_state(state), (t, w, c, fused, {k_: os.environ[k_] for k_ in knobs})
+    finally:
+        for k_, v in saved.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
