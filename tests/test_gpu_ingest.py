@@ -178,3 +178,34 @@ def test_gzip_fasta_input(tmp_path):
         whole = eng.get_sketch(0)
     for key in ("out_hash", "pos", "record"):
         assert np.array_equal(np.concatenate([p[key] for p in parts]), whole[key]), key
+
+
+def test_fuzz_fasta_text_three_ways(tmp_path):
+    """random FASTA text -- line widths from 1 up, LF or CRLF, with or without the final line end, empty and tiny records next to
+    records of several device tiles, lower case, N runs and IUPAC letters at random places, header lines with blanks, tabs and
+    '>' -- through the device route, the host route and the oracle's own FASTA -> TSV driver: three byte-identical files"""
+    orc = _oracle.load()
+    trials = int(os.environ.get("MXG_FUZZ_TRIALS", "25"))
+    rng = random.Random(int(os.environ.get("MXG_FUZZ_SEED", "99")))
+    for t in range(trials):
+        k, w = rng.choice([(32, 100), (32, 300), (32, 1000), (15, 10), (21, 50)])
+        recs = []
+        for i in range(rng.choice([1, 2, 5, 40, 400])):
+            n = rng.choice([0, 1, k - 1, k, k + w - 2, k + w - 1, 200, 4095, 4096, 4097, 9000, 70000])
+            alphabet = rng.choice(["ACGT", "ACGT", "ACGTacgt", "ACGTN", "ACGTRYKMn-", "ACGU", "A", "AC"])
+            s = [rng.choice(alphabet) for _ in range(n)]
+            if n > 3000 and rng.random() < 0.4:
+                a = rng.randrange(n - 2000)
+                s[a:a + rng.choice([1, 31, 32, 700, 1900])] = rng.choice("Nn") * len(s[a:a + rng.choice([1, 31, 32, 700, 1900])])
+            hdr = rng.choice([f"r{i}", f"r{i} a comment", f"r{i}\twith tab", f"r{i} > bracket", f"{i}"])
+            recs.append((hdr, "".join(s)))
+        fa = str(tmp_path / f"f{t}.fa")
+        eol = rng.choice(["\n", "\r\n"])
+        width = rng.choice([1, 7, 60, 61, 80, 4096, 100000])
+        _write_fasta(fa, recs, width=width, eol=eol, ragged=rng.random() < 0.3, final_newline=rng.random() < 0.7)
+        want = str(tmp_path / f"want{t}.tsv")
+        orc.fasta_to_tsv(fa, want, k, w)
+        for tag, env in (("dev", {}), ("host", {"MXG_HOST_INGEST": "1", "MXG_HOST_TSV": "1"})):
+            out = str(tmp_path / f"{tag}{t}.tsv")
+            _tsv_by_engine(fa, k, w, out, **env)
+            assert open(out, "rb").read() == open(want, "rb").read(), (t, tag, k, w, width, repr(eol), len(recs))
