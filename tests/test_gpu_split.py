@@ -163,3 +163,41 @@ def test_split_with_small_batches(tmp_path, monkeypatch):
         got, _, _, _ = _pieces(fa, 32, 300, 5, **kw)
         for key in whole:
             assert np.array_equal(whole[key], got[key]), (kw, key)
+
+
+def test_fuzz_split_equals_whole(tmp_path):
+    """random record sets (plain, short-unit repeats, N runs, long homopolymer stretches: the records of tests/test_gpu_fuzz.py),
+    2-9 shards, k = 32 route with batches and stretch routes forced small: the shards' sketches concatenate to the whole file's"""
+    from tests.test_gpu_fuzz import _rand_record
+    trials = int(os.environ.get("MXG_FUZZ_TRIALS", "15"))
+    rng = random.Random(int(os.environ.get("MXG_FUZZ_SEED", "808")))
+    knobs = ("MXG_SPARSE_S", "MXG_SPARSE_BATCH_KMERS", "MXG_DEV_GAPS")
+    saved = {k_: os.environ.get(k_) for k_ in knobs}
+    try:
+        for t in range(trials):
+            w = rng.choice([50, 200, 500, 1000])
+            c = rng.choice([2, 4, 10, 18])
+            while c / w > 0.125:
+                c //= 2
+            os.environ["MXG_SPARSE_S"] = str(rng.choice([64, 128, 320, 512]))
+            os.environ["MXG_SPARSE_BATCH_KMERS"] = str(rng.choice([50_000, 200_000, 10**9]))
+            os.environ["MXG_DEV_GAPS"] = str(rng.choice([0, 1]))
+            fa = str(tmp_path / f"g{t}.fa")
+            with open(fa, "w") as f:
+                for i in range(rng.randint(1, 7)):
+                    s = _rand_record(rng, rng.choice([31, 40, 1500, 20000, 65536, 70000, 140000]))
+                    f.write(f">rec{i}\n")
+                    for j in range(0, len(s), 80):
+                        f.write(s[j:j + 80] + "\n")
+            kw = {"cand_per_window": c}
+            whole = _whole(fa, 32, w, **kw)
+            n_shards = rng.randint(2, 9)
+            got, _, _, _ = _pieces(fa, 32, w, n_shards, **kw)
+            for key in whole:
+                assert np.array_equal(whole[key], got[key]), (t, key, w, c, n_shards, {k_: os.environ[k_] for k_ in knobs})
+    finally:
+        for k_, v in saved.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
