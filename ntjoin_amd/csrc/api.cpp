@@ -1,5 +1,6 @@
 // api.cpp -- extern "C" entry points of libntjoin_mx.so (declared in include/ntjoin_mx.h).
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <thread>
 
@@ -107,6 +108,7 @@ void mxg_destroy(mxg_handle *h)
         if (e) (void)hipEventDestroy(e);
     if (h->pinned_ctrl) (void)hipHostFree(h->pinned_ctrl);
     if (h->pinned_defer) (void)hipHostFree(h->pinned_defer);
+    if (h->pin_pool) (void)hipHostFree(h->pin_pool);
     if (h->pinned_gctl) (void)hipHostFree(h->pinned_gctl);
     if (h->pinned_dg) (void)hipHostFree(h->pinned_dg);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -931,8 +933,12 @@ int mxg_write_outputs(mxg_handle *h, const char *dot_path, const char *const *ts
 {
     if (!h || !dot_path || !tsv_paths) return MXG_EINVAL;
     try {
+        const bool dbg_io = getenv("MXG_DEBUG_IO") != nullptr;
+        auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now_s();
         int rc = graph_to_host(h);  // (device -> host copies on the handle's stream: before the TSV kernels use it)
         if (rc != MXG_OK) return rc;
+        const double t1 = now_s();
         int rc_dot = MXG_OK;
         struct Joiner {  // (whatever happens to the TSVs, the writer thread is waited for)
             std::thread t;
@@ -950,7 +956,11 @@ int mxg_write_outputs(mxg_handle *h, const char *dot_path, const char *const *ts
         int rc_tsv = MXG_OK;
         for (size_t a = 0; a < h->asms.size() && rc_tsv == MXG_OK; ++a)
             if (tsv_paths[a]) rc_tsv = mxg_write_tsv(h, (int)a, tsv_paths[a], with_pos, with_strand, with_seq);
+        const double t2 = now_s();
         dot.t.join();
+        if (dbg_io)
+            fprintf(stderr, "[mxg] write_outputs: graph to host %.3f s, TSVs %.3f s, then %.3f s more for the .mx.dot\n", t1 - t0, t2 - t1,
+                    now_s() - t2);
         if (rc_dot == MXG_ENOMEM && rc_tsv == MXG_OK) return set_err(h, MXG_ENOMEM, "out of host memory writing '%s'", dot_path);
         return rc_tsv != MXG_OK ? rc_tsv : rc_dot;
     } catch (const std::bad_alloc &) {

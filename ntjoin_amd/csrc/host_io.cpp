@@ -11,10 +11,12 @@
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <functional>
 #include <thread>
+#include <unordered_map>
 
 #include "mxg_internal.h"
 
@@ -952,45 +954,79 @@ struct DotText {
         }
     }
     // label line per assembly: f"{file_name}_{(contig, pos)}"  (bin/ntjoin.py:43-47)
+    // (one capacity check per line, then plain stores: the text of a 3 Gbp + 3 Gbp graph is 1.1 GB, and formatting it -- not
+    // writing it -- was what the output phase of the one-process route waited for)
     void vertices(uint64_t v0, uint64_t v1, OutBuf &o) const
     {
+        size_t fixed = 2 * 20 + 16;
+        for (uint32_t a = 0; a < A; ++a) fixed += h->asms[a]->name.size() + 16 + 20;
         for (uint64_t v = v0; v < v1; ++v) {
-            o.put('"');
-            o.put_u64(g.vhash[v]);
-            o.put("\" [label=\"", 10);
-            o.put_u64(g.vhash[v]);
+            size_t need = fixed;
+            for (uint32_t a = 0; a < A; ++a) need += rec_repr[a][g.vrec[(uint64_t)a * g.nv + v]].size();
+            o.room(need);
+            char *p = o.b.data() + o.n;
+            *p++ = '"';
+            char *d0 = p;
+            p = std::to_chars(p, p + 20, g.vhash[v]).ptr;
+            const size_t nd = (size_t)(p - d0);
+            memcpy(p, "\" [label=\"", 10);
+            p += 10;
+            memcpy(p, d0, nd);
+            p += nd;
             for (uint32_t a = 0; a < A; ++a) {
-                o.put('\n');
-                o.put(h->asms[a]->name);
-                o.put("_(", 2);
-                o.put(rec_repr[a][g.vrec[(uint64_t)a * g.nv + v]]);
-                o.put(", ", 2);
-                o.put_u64(g.vpos[(uint64_t)a * g.nv + v]);
-                o.put(')');
+                *p++ = '\n';
+                const std::string &nm = h->asms[a]->name;
+                memcpy(p, nm.data(), nm.size());
+                p += nm.size();
+                *p++ = '_';
+                *p++ = '(';
+                const std::string &rr = rec_repr[a][g.vrec[(uint64_t)a * g.nv + v]];
+                memcpy(p, rr.data(), rr.size());
+                p += rr.size();
+                *p++ = ',';
+                *p++ = ' ';
+                p = std::to_chars(p, p + 20, (uint64_t)g.vpos[(uint64_t)a * g.nv + v]).ptr;
+                *p++ = ')';
             }
-            o.put("\"]\n", 3);
+            memcpy(p, "\"]\n", 3);
+            p += 3;
+            o.n = (size_t)(p - o.b.data());
         }
     }
     void edges(uint64_t e0, uint64_t e1, OutBuf &o) const
     {
         static const char *COLOURS[10] = {"red",       "green", "blue",   "purple", "orange",
                                           "turquoise", "pink",  "yellow", "orchid", "salmon"};
+        // " [weight=W color=C]\n" is a function of the edge's support set: spelt once per set (the weight is the sum of the
+        // supporting assemblies' weights in assembly order, g.ew: repr() of a double is not cheap)
+        std::unordered_map<uint32_t, std::string> tails;
+        uint32_t last_m = 0;
+        const std::string *last_tail = nullptr;
         for (uint64_t e = e0; e < e1; ++e) {
-            o.put('"');
-            o.put_u64(g.vhash[g.eu[e]]);
-            o.put("\" --\"", 5);
-            o.put_u64(g.vhash[g.ev[e]]);
-            o.put("\" [weight=", 10);
-            o.put(py_repr_float(g.ew[e]));
-            o.put(" color=", 7);
             const uint32_t m = g.esup[e];
-            const int pc = __builtin_popcount(m);
-            const char *col;
-            if (pc == 1) col = (A > 10) ? "red" : COLOURS[__builtin_ctz(m)];
-            else if (pc == 2) col = "lightgrey";
-            else col = "black";
-            o.put(col, strlen(col));
-            o.put("]\n", 2);
+            if (!last_tail || m != last_m) {
+                auto it = tails.find(m);
+                if (it == tails.end()) {
+                    const int pc = __builtin_popcount(m);
+                    const char *col;
+                    if (pc == 1) col = (A > 10) ? "red" : COLOURS[__builtin_ctz(m)];
+                    else if (pc == 2) col = "lightgrey";
+                    else col = "black";
+                    it = tails.emplace(m, "\" [weight=" + py_repr_float(g.ew[e]) + " color=" + col + "]\n").first;
+                }
+                last_m = m;
+                last_tail = &it->second;
+            }
+            o.room(2 * 20 + 8 + last_tail->size());
+            char *p = o.b.data() + o.n;
+            *p++ = '"';
+            p = std::to_chars(p, p + 20, g.vhash[g.eu[e]]).ptr;
+            memcpy(p, "\" --\"", 5);
+            p += 5;
+            p = std::to_chars(p, p + 20, g.vhash[g.ev[e]]).ptr;
+            memcpy(p, last_tail->data(), last_tail->size());
+            p += last_tail->size();
+            o.n = (size_t)(p - o.b.data());
         }
     }
 };
@@ -1066,6 +1102,10 @@ int write_dot(mxg_handle *h, const char *path)
     if (!g.valid) return set_err(h, MXG_EINVAL, "mxg_write_dot: call mxg_build_graph first");
     FILE *f = fopen(path, "w+b");
     if (!f) return set_err(h, MXG_EIO, "cannot open '%s' for writing", path);
+    const bool dbg_io = getenv("MXG_DEBUG_IO") != nullptr;  // timings on stderr
+    auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now_s();
+    double t_wait = 0.0;
     const DotText dt(h);
     auto vertices = [&](uint64_t v0, uint64_t v1, OutBuf &o) { dt.vertices(v0, v1, o); };
     auto edges = [&](uint64_t e0, uint64_t e1, OutBuf &o) { dt.edges(e0, e1, o); };
@@ -1101,7 +1141,9 @@ int write_dot(mxg_handle *h, const char *path)
         for (uint32_t t = 0; t < T; ++t) th.emplace_back(worker, t);
         for (uint64_t c = 0; c < n_chunks && ok; ++c) {
             Slot &sl = slot_of(c);
+            const double tw0 = dbg_io ? now_s() : 0.0;
             while (!sl.full.load(std::memory_order_acquire)) std::this_thread::yield();
+            if (dbg_io) t_wait += now_s() - tw0;
             size_t done = 0;
             while (done < sl.buf.n) {
                 const ssize_t wr = write(fd, sl.buf.b.data() + done, sl.buf.n - done);
@@ -1118,6 +1160,9 @@ int write_dot(mxg_handle *h, const char *path)
     }
     ok = ok && write(fd, "}\n", 2) == 2;
     ok = (fclose(f) == 0) && ok;
+    if (dbg_io)
+        fprintf(stderr, "[mxg] write_dot: %.3f s, of which the writer waited %.3f s for formatted chunks (%u workers, %llu chunks)\n",
+                now_s() - t_begin, t_wait, T, (unsigned long long)n_chunks);
     if (!ok) return set_err(h, MXG_EIO, "write error on '%s'", path);
     return MXG_OK;
 }

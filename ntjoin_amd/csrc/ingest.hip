@@ -19,6 +19,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -222,10 +223,8 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
         ~Staging()
         {
             finish();
-            for (int b = 0; b < NB; ++b) {
-                if (buf[b]) (void)hipHostFree(buf[b]);
-                if (ev[b]) (void)hipEventDestroy(ev[b]);
-            }
+            for (int b = 0; b < NB; ++b)
+                if (ev[b]) (void)hipEventDestroy(ev[b]);  // (the buffers are the handle's: pin_pool)
             if (cs) (void)hipStreamDestroy(cs);
         }
     } sg;
@@ -233,10 +232,15 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
     hipEvent_t *sev = sg.ev;
     MXG_HIP(h, hipStreamCreateWithFlags(&sg.cs, hipStreamNonBlocking));
     hipStream_t cs = sg.cs;
-    for (int b = 0; b < NB; ++b) {
-        const hipError_t e = hipHostMalloc((void **)&stage[b], STAGE);
+    static_assert(NB * STAGE <= PIN_POOL_BYTES, "staging buffers come out of the handle's pinned pool");
+    {
+        unsigned char *pool = nullptr;
+        const hipError_t e = pin_pool_get(h, &pool);
         if (e != hipSuccess) return dev_fallback(e) ? 1 : set_err(h, MXG_EDEVICE, "pinned allocation failed: %s", hipGetErrorString(e));
-        MXG_HIP(h, hipEventCreateWithFlags(&sev[b], hipEventDisableTiming));
+        for (int b = 0; b < NB; ++b) {
+            stage[b] = pool + (size_t)b * STAGE;
+            MXG_HIP(h, hipEventCreateWithFlags(&sev[b], hipEventDisableTiming));
+        }
     }
     hipError_t uerr = hipSuccess;
     sg.uploader = std::thread([&]() {
@@ -651,6 +655,10 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
 {
     if (!a->has_sketch) return set_err(h, MXG_EINVAL, "assembly '%s' has no sketch yet (call mxg_sketch)", a->name.c_str());
     const uint32_t k = h->cfg.k;
+    const bool dbg_io = getenv("MXG_DEBUG_IO") != nullptr;  // timings on stderr
+    auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now_s();
+    double t_tables = 0, t_alloc = 0, t_dev_wait = 0, t_put = 0;
     MXG_HIP(h, hipSetDevice(h->device));
     hipStream_t st = h->stream;
     int rc;
@@ -679,7 +687,7 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
     }
     id_off[n_rec] = (uint32_t)ids.size();
     if (ids.size() >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "record ids too long");
-    DevBuf d_first, d_prefix, d_idoff, d_ids, d_len, d_off, d_tsum, d_tbase, d_total, d_recbase, d_out[2];
+    DevBuf d_first, d_prefix, d_idoff, d_ids, d_len, d_off, d_tsum, d_tbase, d_total, d_recbase;
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
         MXG_HIP(h, b.ensure(std::max<size_t>(bytes, 16)));
         if (bytes) MXG_HIP(h, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
@@ -742,6 +750,7 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
         MXG_HIP(h, hipMemsetAsync(d_off.p, 0, 8, st));
     }
     const uint64_t total = pre + total_entries;
+    t_tables = now_s() - t_begin;
     FILE *f = strcmp(path, "-") == 0 ? stdout : fopen(path, "w+b");  // (read access too: put_parallel maps the file)
     if (!f) return set_err(h, MXG_EIO, "cannot open '%s' for writing", path);
     const int ofd = fileno(f);
@@ -763,10 +772,8 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
         ~Out()
         {
             (void)hipStreamSynchronize(st);
-            for (int b = 0; b < 2; ++b) {
-                if (pin[b]) (void)hipHostFree(pin[b]);
-                if (ev[b]) (void)hipEventDestroy(ev[b]);
-            }
+            for (int b = 0; b < 2; ++b)
+                if (ev[b]) (void)hipEventDestroy(ev[b]);  // (the windows are the handle's: pin_pool, tsv_win)
             if (!closed) (void)close();
             if (!complete && f != stdout) (void)remove(path);
         }
@@ -774,20 +781,26 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
     char **pin = out.pin;
     hipEvent_t *ev = out.ev;
     bool ok = true;
-    for (int b = 0; b < 2; ++b) {
-        MXG_HIP(h, d_out[b].ensure(WIN));
-        MXG_HIP(h, hipHostMalloc((void **)&pin[b], WIN));
-        MXG_HIP(h, hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+    static_assert(2 * WIN <= PIN_POOL_BYTES, "the windows come out of the handle's pinned pool");
+    {
+        unsigned char *pool = nullptr;
+        MXG_HIP(h, pin_pool_get(h, &pool));
+        for (int b = 0; b < 2; ++b) {
+            MXG_HIP(h, h->tsv_win[b].ensure(WIN));
+            pin[b] = reinterpret_cast<char *>(pool) + (size_t)b * WIN;
+            MXG_HIP(h, hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+        }
     }
+    t_alloc = now_s() - t_begin - t_tables;
     auto enqueue = [&](uint64_t c) -> int {
         const int b = (int)(c & 1);
-        p.out = d_out[b].as<char>();
+        p.out = h->tsv_win[b].as<char>();
         p.win_lo = c * WIN;
         p.win_hi = std::min(total, p.win_lo + WIN);
         if (n) hipLaunchKernelGGL(k_tsv_entries, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, p);
         if (n_rec) hipLaunchKernelGGL(k_tsv_ids, dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, st, p);
         MXG_HIP(h, hipGetLastError());
-        MXG_HIP(h, hipMemcpyAsync(pin[b], d_out[b].p, p.win_hi - p.win_lo, hipMemcpyDeviceToHost, st));
+        MXG_HIP(h, hipMemcpyAsync(pin[b], h->tsv_win[b].p, p.win_hi - p.win_lo, hipMemcpyDeviceToHost, st));
         MXG_HIP(h, hipEventRecord(ev[b], st));
         return MXG_OK;
     };
@@ -798,10 +811,13 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
         if (c + 1 < n_win) rc = enqueue(c + 1);  // the device formats the next window while this one is written out
         if (rc != MXG_OK) break;
         const int b = (int)(c & 1);
+        const double tw0 = now_s();
         if (hipEventSynchronize(ev[b]) != hipSuccess) {
             rc = set_err(h, MXG_EDEVICE, "TSV formatting failed on the device");
             break;
         }
+        const double tw1 = now_s();
+        t_dev_wait += tw1 - tw0;
         const uint64_t bytes = std::min(total, (c + 1) * WIN) - c * WIN;
         if (f == stdout) {  // (a pipe or the shell's redirection: in order, at the descriptor's own position)
             uint64_t done = 0;
@@ -824,10 +840,14 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
             }
             ok = put_parallel(ofd, c * WIN, src, len, T);
         }
+        t_put += now_s() - tw1;
         if (!ok) break;
     }
     (void)hipStreamSynchronize(st);
     ok = out.close() && ok;
+    if (dbg_io)
+        fprintf(stderr, "[mxg] write_tsv_device %s: %.3f s = tables %.3f + buffers %.3f + waiting for the device %.3f + writing %.3f (%llu MB)\n",
+                a->name.c_str(), now_s() - t_begin, t_tables, t_alloc, t_dev_wait, t_put, (unsigned long long)(total >> 20));
     if (rc != MXG_OK) return rc;
     if (!ok) return set_err(h, MXG_EIO, "write error on '%s'", path);
     out.complete = true;

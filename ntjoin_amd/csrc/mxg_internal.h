@@ -228,11 +228,29 @@ struct mxg_handle {
     uint32_t *pinned_ctrl = nullptr;  // pinned host copies of per-assembly control blocks (pipelined sketch)
     std::vector<char> dot_part[2];    // a formatted part of the .mx.dot (mxg_dot_part_format -> mxg_dot_part_write)
     void *pinned_defer = nullptr;     // per control block: the stretches its batch left to the host (sketch.hip defer_stretch)
+    // 128 MB of pinned host memory shared by the file routes (FASTA text on its way in: 4 x 32 MB, TSV text on its way out: 2 x 64 MB)
+    // and the TSV writer's device windows: allocated on first use, kept until mxg_destroy -- a pinned allocation of this size
+    // costs 25-55 ms, and the one-process route (mxgraph) would pay it four times
+    void *pin_pool = nullptr;
+    mxg::DevBuf tsv_win[2];
 };
 
 namespace mxg {
 
 int set_err(mxg_handle *h, int code, const char *fmt, ...);
+constexpr size_t PIN_POOL_BYTES = 128ull << 20;
+inline hipError_t pin_pool_get(mxg_handle *h, unsigned char **p)
+{
+    if (!h->pin_pool) {
+        const hipError_t e = hipHostMalloc(&h->pin_pool, PIN_POOL_BYTES);
+        if (e != hipSuccess) {
+            h->pin_pool = nullptr;
+            return e;
+        }
+    }
+    *p = static_cast<unsigned char *>(h->pin_pool);
+    return hipSuccess;
+}
 // Wait for a stream by polling: hipStreamSynchronize parks the thread and its wake-up costs tens of microseconds, which
 // is a tenth of a whole sketch+graph step at 2 x 100 Mbp.  The two syncs on the hot path (end of the sketch stage, end
 // of the graph stage) poll for a bounded time, then fall back to the blocking wait.

@@ -36,6 +36,9 @@ try:
             dt = time.perf_counter() - t0
             ph = next((ln.split("mxgraph: ", 1)[1] for ln in pr.stderr.splitlines() if "device + handle" in ln), pr.stderr[-200:])
             print(f"{label}: total {dt:.3f} s | {ph}", flush=True)
+            for ln in pr.stderr.splitlines():
+                if ln.startswith("[mxg] write"):
+                    print("    " + ln, flush=True)
     for f in ("/dev/shm/mxg_o.mx.dot",):
         if os.path.exists(f):
             os.remove(f)
