@@ -119,6 +119,8 @@ int main(int argc, char **argv)
     cfg.device = device;
     cfg.host_threads = threads;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto wall = []() { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); };
+    if (getenv("MXG_DEBUG_IO")) fprintf(stderr, "[mxg] main() entered at %.3f (epoch seconds)\n", wall());
     const double t0 = now();
     mxg_handle *h = nullptr;
     if (mxg_create(&cfg, &h) != MXG_OK) {
@@ -168,6 +170,7 @@ int main(int argc, char **argv)
     }
     // every output is complete and closed; the process ends without returning tens of GB of HBM buffer by buffer first (the
     // driver reclaims them with the process: 0.1-0.2 s of a 1.3 s run at 3 Gbp + 3 Gbp)
+    if (getenv("MXG_DEBUG_IO")) fprintf(stderr, "[mxg] leaving main() at %.3f (epoch seconds)\n", wall());
     fflush(stdout);
     fflush(stderr);
     if (!getenv("MXG_CLEAN_EXIT")) _exit(0);

@@ -31,14 +31,20 @@ try:
                                        ("shm t8 no-tsv", ["--no-tsv"], "/dev/shm/mxg_o", 8), ("tmp t16 no-tsv", ["--no-tsv"], os.path.join(td, "o"), 16),
                                        ("null t8 no-tsv", ["--no-tsv"], "/dev/null", 8)):
             t0 = time.perf_counter()
+            w0 = time.time()
             pr = subprocess.run([exe, "-v", "-k32", "-w1000", f"-t{t}", "-p", prefix, "-s", fas[1], "-l", "1", "-r", "2", fas[0]] + extra,
                                 stderr=subprocess.PIPE, text=True)
             dt = time.perf_counter() - t0
+            w1 = time.time()
             ph = next((ln.split("mxgraph: ", 1)[1] for ln in pr.stderr.splitlines() if "device + handle" in ln), pr.stderr[-200:])
             print(f"{label}: total {dt:.3f} s | {ph}", flush=True)
             for ln in pr.stderr.splitlines():
                 if ln.startswith("[mxg] write"):
                     print("    " + ln, flush=True)
+                if ln.startswith("[mxg] main() entered"):
+                    print(f"    spawn -> main(): {float(ln.split()[4]) - w0:.3f} s", flush=True)
+                if ln.startswith("[mxg] leaving main()"):
+                    print(f"    end of main() -> parent has the exit status: {w1 - float(ln.split()[4]):.3f} s", flush=True)
     for f in ("/dev/shm/mxg_o.mx.dot",):
         if os.path.exists(f):
             os.remove(f)
