@@ -127,6 +127,35 @@ def whole_record_check(orc, sk, seg, r, seed, sub_seed, sub, w):
     assert sk["forward"][s0:s1].tolist() == [x[2] for x in want]
 
 
+def paths_properties(eng, g, n):
+    """what find_paths(n) returns on a graph too large for the Python oracle: every vertex on at most one path, consecutive path
+    vertices joined by an edge of weight >= n, every path inside one component, no path of a single vertex unless the
+    reference would print one (it does not: bin/ntjoin.py:163-170 keeps paths of any length, vertices without an edge of
+    weight >= n are components of their own and are skipped by the degree test), and most of the graph covered (the synthetic
+    target is the reference cut into contigs: long chains)"""
+    paths = eng.find_paths(n)
+    assert len(paths) >= (24 if n == 1 else 1000)  # n = 1: the reference's edges chain each of its 24 records; n = 3: the target's contigs
+    nv = len(g["vertex_hash"])
+    lens = np.array([len(v) for _, v in paths], dtype=np.int64)
+    verts = np.concatenate([np.asarray(v, dtype=np.int64) for _, v in paths])
+    assert verts.min() >= 0 and verts.max() < nv
+    assert len(np.unique(verts)) == len(verts)
+    ends = np.cumsum(lens)
+    a, b = verts[:-1], verts[1:]
+    inside = np.ones(len(verts) - 1, dtype=bool)
+    inside[ends[:-1] - 1] = False
+    a, b = a[inside], b[inside]
+    keep = np.asarray(g["edge_weight"]) >= n
+    eu, ev = np.asarray(g["edge_u"], dtype=np.int64)[keep], np.asarray(g["edge_v"], dtype=np.int64)[keep]
+    keys = np.sort(np.minimum(eu, ev) * nv + np.maximum(eu, ev))
+    want = np.minimum(a, b) * nv + np.maximum(a, b)
+    at = np.searchsorted(keys, want)
+    assert np.all(at < len(keys)) and np.all(keys[np.minimum(at, len(keys) - 1)] == want)
+    comp = np.array([c for c, _ in paths])
+    assert len(np.unique(comp)) <= len(comp)
+    assert len(verts) > 0.5 * nv if n == 1 else len(verts) > 0
+
+
 def _born_in_hbm(eng, cfg, which, name, weight):
     segs, n_words = cfg[which + "_segs"], cfg[which + "_words"]
     sub = synth.SUB_PER_65536 if which == "tgt" else 0
@@ -153,6 +182,9 @@ def test_configs2_whole_path_3gbp_plus_3gbp():
         for sk, segs in zip(sks, (rsegs, tsegs)):
             sketch_properties(sk, segs[:, 2], w)
             assert abs(len(sk["pos"]) / float(segs[:, 2].sum()) - 2.0 / (w + 1)) < 0.02 * 2.0 / (w + 1)
+        # the first "next" row at this size: linear paths over 4.5 M vertices (reference bin/ntjoin.py:69-176)
+        for n in (1, 3):
+            paths_properties(eng, g, n)
         # sketch stage, exact: excerpts of the long reference records (first, last, across the second sparse batch) ...
         for r, lo in ((0, 0), (0, 50_000_000), (23, int(rsegs[23][2]) - 300_000), (16, 1_000_000), (17, 77_777)):
             excerpt_check(orc, sks[0], rsegs[r], r, cfg["seed"], cfg["sub_seed"], 0, w, lo, 300_000)
