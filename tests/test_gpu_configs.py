@@ -154,6 +154,36 @@ def paths_properties(eng, g, n):
     comp = np.array([c for c, _ in paths])
     assert len(np.unique(comp)) <= len(comp)
     assert len(verts) > 0.5 * nv if n == 1 else len(verts) > 0
+    # format_path's inputs (8 f4): per record the extreme positions of its graph vertices, per assembly the runs of consecutive
+    # path vertices on one record with their position range and orientation tallies
+    for a in range(len(g["vertex_pos"])):
+        rec, pos = np.asarray(g["vertex_record"][a], dtype=np.int64), np.asarray(g["vertex_pos"][a], dtype=np.int64)
+        n_rec = int(rec.max()) + 1
+        lo = np.full(n_rec, np.iinfo(np.int64).max)
+        hi = np.full(n_rec, -1)
+        np.minimum.at(lo, rec, pos)
+        np.maximum.at(hi, rec, pos)
+        ext = eng.mx_extremes(a)
+        got = [(i, e) for i, e in enumerate(ext) if e is not None]
+        assert [i for i, _ in got] == np.flatnonzero(hi >= 0).tolist()
+        assert [e for _, e in got] == list(zip(lo[hi >= 0].tolist(), hi[hi >= 0].tolist()))
+        sg = eng.path_segments(a)
+        assert int(sg["n"].sum()) == len(verts)  # the runs tile the concatenated paths
+        first = np.asarray(sg["first"], dtype=np.int64)
+        assert np.array_equal(first, np.concatenate([[0], np.cumsum(sg["n"].astype(np.int64))[:-1]]))
+        # every run lies on one record, and its position range is the range of its vertices
+        run_of = np.repeat(np.arange(len(first)), sg["n"].astype(np.int64))
+        assert np.array_equal(rec[verts], np.asarray(sg["record"], dtype=np.int64)[run_of])
+        rmin = np.full(len(first), np.iinfo(np.int64).max)
+        rmax = np.full(len(first), -1)
+        np.minimum.at(rmin, run_of, pos[verts])
+        np.maximum.at(rmax, run_of, pos[verts])
+        assert np.array_equal(rmin, sg["min_pos"].astype(np.int64)) and np.array_equal(rmax, sg["max_pos"].astype(np.int64))
+        step = np.diff(pos[verts])
+        same_run = run_of[1:] == run_of[:-1]
+        inc = np.bincount(run_of[1:][same_run & (step > 0)], minlength=len(first))
+        dec = np.bincount(run_of[1:][same_run & (step < 0)], minlength=len(first))
+        assert np.array_equal(inc, sg["inc"].astype(np.int64)) and np.array_equal(dec, sg["dec"].astype(np.int64))
 
 
 def _born_in_hbm(eng, cfg, which, name, weight):
