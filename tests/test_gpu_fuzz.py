@@ -67,7 +67,7 @@ def test_fuzz_k32_route_vs_oracle(oracle):
     ordered candidates, stretches on the device or left to the tile kernel): records around and beyond the chunk size, chunk
     borders inside runs of N and inside low-complexity sequence, several chained batches, both stretch routes"""
     from ntjoin_amd.engine import MxEngine
-    trials = int(os.environ.get("MXG_FUZZ_TRIALS", "40"))
+    trials = int(os.environ.get("MXG_FUZZ_TRIALS", "100"))
     rng = random.Random(int(os.environ.get("MXG_FUZZ_SEED", "3232")))
     knobs = ("MXG_SPARSE_S", "MXG_SPARSE_BATCH_KMERS", "MXG_DEV_GAPS")
     saved = {k_: os.environ.get(k_) for k_ in knobs}
@@ -173,7 +173,7 @@ def test_fuzz_whole_path_k32_vs_oracle(oracle, tmp_path):
     .mx.dot against the oracle (the graph oracle reads the TSVs this engine wrote, whose records are checked first)"""
     from ntjoin_amd.engine import MxEngine
     from oracle import graph_oracle as go
-    trials = int(os.environ.get("MXG_FUZZ_TRIALS", "12"))
+    trials = int(os.environ.get("MXG_FUZZ_TRIALS", "40"))
     rng = random.Random(int(os.environ.get("MXG_FUZZ_SEED", "515")))
     knobs = ("MXG_SPARSE_S", "MXG_SPARSE_BATCH_KMERS", "MXG_DEV_GAPS")
     saved = {k_: os.environ.get(k_) for k_ in knobs}
