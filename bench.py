@@ -365,8 +365,8 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=["auto", "configs1", "configs2", "configs3", "configs4", "repeats"])
     ap.add_argument("--mbp", type=float, default=0.0, help="reference size in Mbp (default: 100 for configs1, 3000 for configs2)")
     ap.add_argument("--w", type=int, default=0, help="window size (default: 500 for configs3, else 1000)")
