@@ -122,7 +122,7 @@ def test_fuzz_paths_vs_oracle(tmp_path):
                 want = po.canonical(po.find_paths(state, n))
                 assert _canonical_gpu(eng, n) == want, (t, n, names, weights)
                 n_paths += sum(len(c) for c in want)
-    assert n_paths > trials  # the generator does produce chains
+    assert n_paths > trials // 2  # the generator does produce chains (about one per trial)
 
 
 def test_cycle_is_opened(tmp_path):
