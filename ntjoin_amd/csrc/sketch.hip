@@ -2150,7 +2150,9 @@ struct Driver {
             if (rc != MXG_OK) return rc;
             const uint32_t n_strips = hp.strip_hi - hp.strip_lo;
             dim3 grid((n_strips + 255) / 256), block(256);
-            if (h->cfg.variant == MXG_VARIANT_V1_MIN)
+            if (!n_strips) {
+                // (a batch of records without a single k-mer: nothing to hash)
+            } else if (h->cfg.variant == MXG_VARIANT_V1_MIN)
                 hipLaunchKernelGGL((k_hash_dense<S_DENSE, MXG_VARIANT_V1_MIN>), grid, block, 0, st, hp);
             else
                 hipLaunchKernelGGL((k_hash_dense<S_DENSE, MXG_VARIANT_V2_SUM>), grid, block, 0, st, hp);
@@ -3049,9 +3051,12 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
     for (uint32_t x = 0; x + 2 < n_str; ++x)
         if (!h->stream_x[x]) MXG_HIP(h, hipStreamCreateWithFlags(&h->stream_x[x], hipStreamNonBlocking));
     Driver drv0(h, 0), drv1(h, 1), drv2(h, n_str > 2 ? 2 : 1), drv3(h, n_str > 3 ? 3 : 1);
-    static const bool one_stream = getenv("MXG_ONE_STREAM") != nullptr;  // profiling: kernels of the streams do not overlap
+    // profiling (tools/pmc_r03.sh): every batch on the handle's main stream, so that no two kernels overlap.  Every batch then uses
+    // slot 0 (one scratch set, in stream order); the calls that keep one batch per assembly in flight for the stage behind them
+    // (mxg_sketch_graph, mxg_sketch_pack) need a scratch set per assembly and ignore the switch.
+    const bool one_stream = getenv("MXG_ONE_STREAM") != nullptr && !fuse_graph && !xp;
     Driver *drvs[4] = {&drv0, one_stream ? &drv0 : &drv1, one_stream ? &drv0 : &drv2, one_stream ? &drv0 : &drv3};
-    if (one_stream) n_str = 2;
+    if (one_stream) n_str = 1;
     struct Item {
         size_t asm_i;
         Driver::BatchGeom g;
@@ -3112,7 +3117,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             // stream (whatever follows the sketches on that stream then waits for the other stream's chain, which has
             // finished earlier); batches of a multi-batch assembly simply alternate
             size_t sl;
-            if (gs.size() == 1) sl = h->own_stream ? ((n - 1 - i) & 1) : (i & 1);
+            if (one_stream) sl = 0;
+            else if (gs.size() == 1) sl = h->own_stream ? ((n - 1 - i) & 1) : (i & 1);
             else sl = next_slot++ % n_str;
             Driver &drv = *drvs[sl];
             Item it;

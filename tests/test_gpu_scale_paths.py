@@ -362,3 +362,14 @@ def test_kept_batches_keep_their_deferred_stretches(oracle, route_knobs):
     st = _check(oracle, recs, 32, 1000, cand_per_window=4)
     assert st["deferred_stretches"] >= 1
     assert st["batches_redone"] >= 1
+
+
+def test_dense_batch_of_records_without_a_kmer(oracle, knobs):
+    """records shorter than k around records larger than the dense batch budget: no batch is launched with an empty grid, the
+    records without a k-mer come out with empty sketches"""
+    knobs["MXG_DENSE_BATCH_KMERS"] = "2000"
+    rng = random.Random(12)
+    recs = [("t1", "ACGT"), ("t2", "AC"), ("big", "".join(rng.choice("ACGT") for _ in range(6000))), ("t3", "A" * 31),
+            ("big2", "".join(rng.choice("ACGT") for _ in range(5000)))]
+    _check(oracle, recs, 32, 10, dense_only=True)
+    _check(oracle, recs, 32, 100, dense_only=True)
