@@ -68,3 +68,35 @@ def test_seqreader_counterpart(tmp_path):
     with pytest.raises(FileNotFoundError):
         with btllib.SeqReader(str(tmp_path / "missing.fa"), btllib.SeqReaderFlag.LONG_MODE, 2) as fin:
             list(fin)
+
+
+def test_fuzz_indexlr_iterator(oracle, tmp_path):
+    """random FASTA files (ragged lines, lower case, N runs, empty and tiny records, hundreds of records) through the Indexlr
+    counterpart at the overlap stage's parameters and others: ids, lengths and (out_hash, pos, strand) per record = the oracle"""
+    import random
+    import ntjoin_amd.indexlr as btllib
+    trials = int(os.environ.get("MXG_FUZZ_TRIALS", "20"))
+    rng = random.Random(int(os.environ.get("MXG_FUZZ_SEED", "31")))
+    for t in range(trials):
+        k, w = rng.choice([(15, 10), (15, 10), (32, 100), (21, 50), (11, 5), (32, 1000)])
+        recs = []
+        for i in range(rng.choice([1, 3, 30, 300])):
+            n = rng.choice([0, 1, k - 1, k, k + w - 2, k + w - 1, 200, 5000, 40000])
+            alphabet = rng.choice(["ACGT", "ACGT", "ACGTacgt", "ACGTN", "AC", "ACGTRYn"])
+            recs.append((f"rec{i}", "".join(rng.choice(alphabet) for _ in range(n))))
+        path = str(tmp_path / f"f{t}.fa")
+        with open(path, "w", encoding="ascii") as fh:
+            for rid, s in recs:
+                fh.write(f">{rid} comment {t}\n")
+                p = 0
+                while p < len(s):
+                    wd = rng.randint(1, 120)
+                    fh.write(s[p:p + wd] + "\n")
+                    p += wd
+        with btllib.Indexlr(path, k, w, btllib.IndexlrFlag.LONG_MODE, rng.choice([1, 2, 6])) as minimizers:
+            got = list(minimizers)
+        assert [e.id for e in got] == [rid for rid, _ in recs], (t, k, w)
+        assert [e.readlen for e in got] == [len(s) for _, s in recs], (t, k, w)
+        for e, (rid, seq) in zip(got, recs):
+            exp = oracle.sketch(seq, k, w)
+            assert [(m.out_hash, m.pos, int(m.forward)) for m in e.minimizers] == [(h, p, f) for h, p, f, _ in exp], (t, k, w, rid)
