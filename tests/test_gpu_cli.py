@@ -139,10 +139,10 @@ def test_many_small_calls_in_one_pass():
     import random
     from ntjoin_amd import ntjoin_utils as nu
     from oracle import graph_oracle as go
-    rng = random.Random(5)
+    rng = random.Random(int(os.environ.get("MXG_FUZZ_SEED", "5")))
     pool = [str(rng.getrandbits(64)) for _ in range(400)]
     items = []
-    for i in range(60):
+    for i in range(max(60, int(os.environ.get("MXG_FUZZ_TRIALS", "60")))):
         a_n = 2 if i % 9 else 3
         base = rng.sample(pool, rng.randint(0, 25))
         item = {}
