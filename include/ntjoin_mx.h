@@ -139,6 +139,8 @@ typedef struct mxg_stats {
     uint64_t sync_assemblies;  /* assemblies none of whose batches could be kept                             */
     uint64_t retried_assemblies; /* assemblies whose batches went through the streams a second time, re-sized    */
     uint64_t deferred_stretches; /* candidate-free stretches sketched apart and merged in (satellites, low complexity) */
+    uint64_t select_slices;    /* slices of 64 strips that went through k_bs_select (k = 32 route: bitmap -> selected minimizers
+                                  in one kernel; 0: count -> reorder -> resolve ran)                                           */
 } mxg_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */

@@ -941,6 +941,7 @@ int mxg_write_outputs(mxg_handle *h, const char *dot_path, const char *const *ts
         if (rc != MXG_OK) return rc;
         const double t1 = now_s();
         int rc_dot = MXG_OK;
+        std::string dot_msg;  // the writer thread's error text: the handle's message is this thread's alone until the join
         struct Joiner {  // (whatever happens to the TSVs, the writer thread is waited for)
             std::thread t;
             ~Joiner()
@@ -948,11 +949,14 @@ int mxg_write_outputs(mxg_handle *h, const char *dot_path, const char *const *ts
                 if (t.joinable()) t.join();
             }
         } dot{std::thread([&]() {
+            tl_err_sink = &dot_msg;
             try {
                 rc_dot = write_dot(h, dot_path);  // host arrays only from here on
             } catch (const std::exception &) {
                 rc_dot = MXG_ENOMEM;
+                dot_msg.clear();
             }
+            tl_err_sink = nullptr;
         })};
         int rc_tsv = MXG_OK;
         for (size_t a = 0; a < h->asms.size() && rc_tsv == MXG_OK; ++a)
@@ -962,8 +966,12 @@ int mxg_write_outputs(mxg_handle *h, const char *dot_path, const char *const *ts
         if (dbg_io)
             fprintf(stderr, "[mxg] write_outputs: graph to host %.3f s, TSVs %.3f s, then %.3f s more for the .mx.dot\n", t1 - t0, t2 - t1,
                     now_s() - t2);
-        if (rc_dot == MXG_ENOMEM && rc_tsv == MXG_OK) return set_err(h, MXG_ENOMEM, "out of host memory writing '%s'", dot_path);
-        return rc_tsv != MXG_OK ? rc_tsv : rc_dot;
+        if (rc_tsv != MXG_OK) return rc_tsv;  // (its message is the handle's)
+        if (rc_dot != MXG_OK) {
+            if (dot_msg.empty()) return set_err(h, MXG_ENOMEM, "out of host memory writing '%s'", dot_path);
+            h->err = dot_msg;
+        }
+        return rc_dot;
     } catch (const std::bad_alloc &) {
         return set_err(h, MXG_ENOMEM, "out of host memory in mxg_write_outputs");
     } catch (const std::system_error &) {
@@ -1011,6 +1019,7 @@ int mxg_get_stats(mxg_handle *h, mxg_stats *out)
     s.batches_redone = h->stat_batches_redone;
     s.sync_assemblies = h->stat_sync_assemblies;
     s.deferred_stretches = h->stat_deferred;
+    s.select_slices = h->stat_sel_slices;
     s.retried_assemblies = h->stat_retries;
     s.dense_kmers = h->stat_dense_kmers;
     s.unique = h->graph.valid ? h->stat_unique : 0;
@@ -1038,7 +1047,7 @@ int mxg_reset_timers(mxg_handle *h)
     if (rc != MXG_OK) return rc;
     h->tm = Timers();
     h->stat_candidates = h->stat_dense_kmers = h->stat_bs_bases = 0;
-    h->stat_batches_redone = h->stat_sync_assemblies = h->stat_deferred = h->stat_retries = 0;
+    h->stat_batches_redone = h->stat_sync_assemblies = h->stat_deferred = h->stat_retries = h->stat_sel_slices = 0;
     return MXG_OK;
 }
 

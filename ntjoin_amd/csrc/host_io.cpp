@@ -22,6 +22,8 @@
 
 namespace mxg {
 
+thread_local std::string *tl_err_sink = nullptr;
+
 int set_err(mxg_handle *h, int code, const char *fmt, ...)
 {
     char buf[1024];
@@ -29,7 +31,8 @@ int set_err(mxg_handle *h, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (h) h->err = buf;
+    if (tl_err_sink) *tl_err_sink = buf;  // (a helper thread of the library: its caller decides what the handle reports)
+    else if (h) h->err = buf;
     return code;
 }
 
@@ -842,7 +845,7 @@ struct OutBuf {
     std::vector<char> b;
     size_t n = 0;
     bool ok = true;
-    explicit OutBuf(FILE *f_) : f(f_), b(1 << 22) {}
+    explicit OutBuf(FILE *f_, size_t cap = (size_t)1 << 22) : f(f_), b(cap) {}
     inline void room(size_t need)
     {
         if (!f) {  // memory only: grows (the parallel .mx.dot writer formats chunks into such buffers)
@@ -1041,16 +1044,22 @@ int dot_part_format(mxg_handle *h, uint32_t part, uint32_t n_parts, uint64_t byt
     if (!g.valid || !g.host_valid) return set_err(h, MXG_EINVAL, "mxg_dot_part_format: no graph on the host");
     if (n_parts == 0 || part >= n_parts) return set_err(h, MXG_EINVAL, "mxg_dot_part_format: part out of range");
     const DotText dt(h);
-    const uint32_t T = std::min(64u, std::max(1u, host_threads(h)));
     for (int seg = 0; seg < 2; ++seg) {
         const uint64_t n = seg ? g.ne : g.nv, lo = n * part / n_parts, hi = n * (part + 1) / n_parts;
+        // one worker per 16 Ki items at most, buffers sized for their share (they grow if a line is longer than the guess)
+        const uint32_t T = (uint32_t)std::min<uint64_t>(std::min(64u, std::max(1u, host_threads(h))), std::max<uint64_t>(1, (hi - lo) >> 14));
         std::vector<OutBuf> bufs;
         bufs.reserve(T);
-        for (uint32_t t = 0; t < T; ++t) bufs.emplace_back(nullptr);
+        for (uint32_t t = 0; t < T; ++t) bufs.emplace_back(nullptr, (size_t)((hi - lo) / T + 1) * (seg ? 80 : 224) + 4096);
+        std::atomic<bool> failed{false};
         auto work = [&](uint32_t t) {
-            const uint64_t a = lo + (hi - lo) * t / T, b = lo + (hi - lo) * (t + 1) / T;
-            bufs[t].n = 0;
-            if (seg) dt.edges(a, b, bufs[t]); else dt.vertices(a, b, bufs[t]);
+            try {
+                const uint64_t a = lo + (hi - lo) * t / T, b = lo + (hi - lo) * (t + 1) / T;
+                bufs[t].n = 0;
+                if (seg) dt.edges(a, b, bufs[t]); else dt.vertices(a, b, bufs[t]);
+            } catch (...) {
+                failed = true;
+            }
         };
         {
             std::vector<std::thread> th;
@@ -1058,6 +1067,7 @@ int dot_part_format(mxg_handle *h, uint32_t part, uint32_t n_parts, uint64_t byt
             work(0);
             for (auto &x : th) x.join();
         }
+        if (failed) return set_err(h, MXG_ENOMEM, "out of host memory formatting a part of the .mx.dot");
         size_t total = 0;
         for (auto &b : bufs) total += b.n;
         h->dot_part[seg].resize(total);
@@ -1112,28 +1122,33 @@ int write_dot(mxg_handle *h, const char *path)
     // ~200 bytes per vertex and ~75 per edge (1.2 GB at 3 Gbp + 3 Gbp).  `host_threads` workers format chunks of 16 Ki items
     // into memory (two buffers each); this thread writes the chunks out in order AS THEY COMPLETE, so formatting and the
     // (serial: one file) copy into the page cache overlap -- formatting rounds alternating with writing rounds took their sum.
-    const uint32_t T = std::min(64u, std::max(1u, host_threads(h)));
     constexpr uint64_t CH = 1u << 14;
     const uint64_t v_chunks = (g.nv + CH - 1) / CH, e_chunks = (g.ne + CH - 1) / CH, n_chunks = v_chunks + e_chunks;
+    // (no more workers than chunks: a small graph -- the overlap stage's calls, the tests -- does not pay for 64 threads and buffers)
+    const uint32_t T = (uint32_t)std::min<uint64_t>(std::min(64u, std::max(1u, host_threads(h))), std::max<uint64_t>(1, n_chunks));
     struct Slot {
-        OutBuf buf{nullptr};
+        OutBuf buf{nullptr, CH * 64};
         std::atomic<int> full{0};
     };
     std::vector<Slot> slots(2 * (size_t)T);
-    for (auto &sl : slots) sl.buf.b.resize(CH * 64);
     bool ok = fwrite("graph G {\n", 1, 10, f) == 10;
     ok = fflush(f) == 0 && ok;
     const int fd = fileno(f);
-    std::atomic<bool> stop{false};
+    std::atomic<bool> stop{false}, failed{false};
     auto slot_of = [&](uint64_t c) -> Slot & { return slots[(size_t)(c % T) * 2 + (size_t)((c / T) & 1)]; };
     auto worker = [&](uint32_t t) {
-        for (uint64_t c = t; c < n_chunks && !stop; c += T) {
-            Slot &sl = slot_of(c);
-            while (sl.full.load(std::memory_order_acquire) && !stop) std::this_thread::yield();
-            sl.buf.n = 0;
-            if (c < v_chunks) vertices(c * CH, std::min<uint64_t>(g.nv, (c + 1) * CH), sl.buf);
-            else edges((c - v_chunks) * CH, std::min<uint64_t>(g.ne, (c - v_chunks + 1) * CH), sl.buf);
-            sl.full.store(1, std::memory_order_release);
+        try {
+            for (uint64_t c = t; c < n_chunks && !stop; c += T) {
+                Slot &sl = slot_of(c);
+                while (sl.full.load(std::memory_order_acquire) && !stop) std::this_thread::yield();
+                sl.buf.n = 0;
+                if (c < v_chunks) vertices(c * CH, std::min<uint64_t>(g.nv, (c + 1) * CH), sl.buf);
+                else edges((c - v_chunks) * CH, std::min<uint64_t>(g.ne, (c - v_chunks + 1) * CH), sl.buf);
+                sl.full.store(1, std::memory_order_release);
+            }
+        } catch (...) {  // (a buffer could not grow: the writer below stops waiting, the call reports MXG_ENOMEM)
+            failed = true;
+            stop = true;
         }
     };
     {
@@ -1142,7 +1157,8 @@ int write_dot(mxg_handle *h, const char *path)
         for (uint64_t c = 0; c < n_chunks && ok; ++c) {
             Slot &sl = slot_of(c);
             const double tw0 = dbg_io ? now_s() : 0.0;
-            while (!sl.full.load(std::memory_order_acquire)) std::this_thread::yield();
+            while (!sl.full.load(std::memory_order_acquire) && !stop) std::this_thread::yield();
+            if (stop) break;
             if (dbg_io) t_wait += now_s() - tw0;
             size_t done = 0;
             while (done < sl.buf.n) {
@@ -1158,11 +1174,12 @@ int write_dot(mxg_handle *h, const char *path)
         if (!ok) stop = true;
         for (auto &x : th) x.join();
     }
-    ok = ok && write(fd, "}\n", 2) == 2;
+    ok = ok && !failed && write(fd, "}\n", 2) == 2;
     ok = (fclose(f) == 0) && ok;
     if (dbg_io)
         fprintf(stderr, "[mxg] write_dot: %.3f s, of which the writer waited %.3f s for formatted chunks (%u workers, %llu chunks)\n",
                 now_s() - t_begin, t_wait, T, (unsigned long long)n_chunks);
+    if (failed) return set_err(h, MXG_ENOMEM, "out of host memory formatting '%s'", path);
     if (!ok) return set_err(h, MXG_EIO, "write error on '%s'", path);
     return MXG_OK;
 }

@@ -10,7 +10,16 @@
 #include <cstring>
 #include <string>
 
+#include <sys/stat.h>
+
 #include "ntjoin_mx.h"
+
+// a partial output is removed only when its name is a regular file: a FIFO, /dev/stdout or a process substitution is not ours to unlink
+static void remove_partial(const char *path)
+{
+    struct stat sb;
+    if (strcmp(path, "-") != 0 && lstat(path, &sb) == 0 && S_ISREG(sb.st_mode)) remove(path);
+}
 
 static void usage(FILE *f)
 {
@@ -111,7 +120,7 @@ int main(int argc, char **argv)
     if (a < 0 || (rc = mxg_sketch(h, a)) != MXG_OK || (t3 = now(), rc = mxg_write_tsv(h, a, out, with_pos, with_strand, with_seq)) != MXG_OK) {
         fprintf(stderr, "indexlr: %s\n", mxg_last_error(h));
         mxg_destroy(h);
-        if (strcmp(out, "-") != 0) remove(out);  // leave no partial output behind
+        remove_partial(out);  // leave no partial output behind
         return 1;
     }
     if (verbose) {

@@ -755,12 +755,19 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
     if (!f) return set_err(h, MXG_EIO, "cannot open '%s' for writing", path);
     const int ofd = fileno(f);
     fflush(f);
+    // a regular file takes the windows in parallel parts at absolute offsets (pwrite); anything else -- a FIFO, /dev/stdout, a
+    // process substitution -- has no offsets: it is written in order at the descriptor's own position, and is never removed
+    struct stat sb;
+    const bool regular = f != stdout && fstat(ofd, &sb) == 0 && S_ISREG(sb.st_mode);
+    // (the NAME may still be a symbolic link to a regular file -- /dev/stdout redirected into one -- and is then left alone too)
+    const bool removable = regular && lstat(path, &sb) == 0 && S_ISREG(sb.st_mode);
     constexpr uint64_t WIN = 64ull << 20;
     // the file, the pinned windows and their events are released on every way out; a file left incomplete is removed
     struct Out {
         FILE *f;
         const char *path;
         hipStream_t st;
+        bool removable;
         char *pin[2] = {nullptr, nullptr};
         hipEvent_t ev[2] = {nullptr, nullptr};
         bool complete = false, closed = false;
@@ -775,9 +782,9 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
             for (int b = 0; b < 2; ++b)
                 if (ev[b]) (void)hipEventDestroy(ev[b]);  // (the windows are the handle's: pin_pool, tsv_win)
             if (!closed) (void)close();
-            if (!complete && f != stdout) (void)remove(path);
+            if (!complete && removable) (void)remove(path);  // (only a regular file this call created or truncated)
         }
-    } out{f, path, st};
+    } out{f, path, st, removable};
     char **pin = out.pin;
     hipEvent_t *ev = out.ev;
     bool ok = true;
@@ -819,7 +826,7 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
         const double tw1 = now_s();
         t_dev_wait += tw1 - tw0;
         const uint64_t bytes = std::min(total, (c + 1) * WIN) - c * WIN;
-        if (f == stdout) {  // (a pipe or the shell's redirection: in order, at the descriptor's own position)
+        if (!regular) {  // (a pipe, a FIFO, a device or the shell's redirection: in order, at the descriptor's own position)
             uint64_t done = 0;
             while (done < bytes) {
                 const ssize_t wr = write(ofd, pin[b] + done, bytes - done);

@@ -26,6 +26,16 @@ struct Run {
     uint32_t pos0;      // contig-local base position of the run's first base
 };
 
+// a run as k_bs_select (sketch_bs.hip) reads it: one aligned 32-byte entry where Run + the strip prefix + the contig's k-mer
+// count are three dependent table reads (strip0 belongs to the assembly's sparse strip length)
+struct alignas(32) RunX {
+    uint64_t base_off;
+    uint32_t n_kmers, contig, kidx0;
+    uint32_t strip0;    // strips (of the sparse strip table) in front of the run
+    uint32_t nk;        // valid k-mers of the run's contig
+    uint32_t pad;
+};
+
 struct HashTab {  // ntHash step table, entry (out*4+in), out==4: warm-up step with no outgoing base
     // x,y = low/high word of  srol^k(SEED[out]) ^ SEED[in]            (forward update term)
     // z,w = low/high word of  SEED[comp(out)] ^ srol^k(SEED[comp(in)]) (reverse update term, before sror)
@@ -109,10 +119,12 @@ struct Assembly {
     std::vector<uint64_t> g0;                           // [n_runs+1] exclusive prefix of k-mers per run
     DevBuf d_runs, d_strip0_dense, d_strip0_sparse, d_g0, d_ctg_nk, d_ctg_rec, d_ctg_run0, d_ctg_drop;
     DevBuf d_strip_run;  // strip of the sparse strip table -> its run (k_strip_runs)
+    DevBuf d_runx;       // RunX per run
     // k = 32 route (sketch_bs.hip): the bases transposed for the bit-sliced ring filter, its result, chunk -> first run
     bool bs_ready = false, bs_impossible = false;
     uint32_t bs_chunks = 0;
-    DevBuf d_bs_tail, d_bs_out, d_bs_run0;  // k = 32 route: padded copy of the last chunk's words, the filter's bitmap, chunk -> run
+    DevBuf d_bs_tail, d_bs_out;  // k = 32 route: padded copies of the first / last chunk's words, the filter's bitmap
+    uint32_t sel_H = 0, sel_H_S = 0, sel_H_w = 0;  // k_bs_select: halo strips (0: the route does not take this run table) for (S, w)
     // sketch (device, ordered by (record,pos)) + lazily filled host mirror
     bool has_sketch = false;
     uint64_t n_mx = 0;
@@ -208,6 +220,7 @@ struct mxg_handle {
     mxg::DevBuf d_init_tab;  // byte table of the direct hash formula (256 x 16 B), built by the first sketch
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
     uint64_t stat_bs_bases = 0;  // bases the bit-sliced filter (k = 32 route) has covered
+    uint64_t stat_sel_slices = 0;  // slices enqueued through k_bs_select
     bool pj_overflowed = false;  // graph stage: the partitioned join overflowed once (build_graph then starts with the global table)
     uint64_t stat_retries = 0;   // assemblies enqueued a second time (their batches did not all end the common way)
     uint64_t stat_deferred = 0;  // candidate-free stretches the device route handed to the host
@@ -238,6 +251,8 @@ struct mxg_handle {
 namespace mxg {
 
 int set_err(mxg_handle *h, int code, const char *fmt, ...);
+// a helper thread of the library points this at a string of its own: set_err then leaves the handle's message alone (host_io.cpp)
+extern thread_local std::string *tl_err_sink;
 constexpr size_t PIN_POOL_BYTES = 128ull << 20;
 inline hipError_t pin_pool_get(mxg_handle *h, unsigned char **p)
 {

@@ -16,7 +16,16 @@
 
 #include <unistd.h>
 
+#include <sys/stat.h>
+
 #include "ntjoin_mx.h"
+
+// a partial output is removed only when its name is a regular file: a FIFO, /dev/stdout or a process substitution is not ours to unlink
+static void remove_partial(const char *path)
+{
+    struct stat sb;
+    if (strcmp(path, "-") != 0 && lstat(path, &sb) == 0 && S_ISREG(sb.st_mode)) remove(path);
+}
 
 static void usage(FILE *f)
 {
@@ -152,9 +161,9 @@ int main(int argc, char **argv)
     std::vector<const char *> tsv_ptrs;
     for (auto &t : tsvs) tsv_ptrs.push_back(no_tsv ? nullptr : t.c_str());
     if (mxg_write_outputs(h, dot.c_str(), tsv_ptrs.data(), 1, 0, 1) != MXG_OK) {
-        remove(dot.c_str());
+        remove_partial(dot.c_str());
         if (!no_tsv)
-            for (auto &t : tsvs) remove(t.c_str());  // leave no partial output behind
+            for (auto &t : tsvs) remove_partial(t.c_str());  // leave no partial output behind
         return fail("writing the outputs");
     }
     const double t5 = now();

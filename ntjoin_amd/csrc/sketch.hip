@@ -1095,10 +1095,11 @@ struct EmitParams {
     // the selected candidates laid out per k_resolve block (ResolveParams::cs_*): replaces sel / ch / ck / cc
     const uint64_t *cs_h;
     const uint32_t *cs_k, *cs_c;
-    // entries per producer block in the cs_* arrays (RK behind k_resolve; k_bs_resolve has its own) and, behind k_bs_resolve,
-    // the number of entries to walk (blocks x rk: the candidate count in *n_ptr is then only reported)
+    const uint4 *cs_aos;   // ... or (behind k_bs_select) as ONE array of {hash lo, hash hi, k-mer index, contig}: cs_h is then only a flag
+    // entries per producer block in the cs_* arrays (RK behind k_resolve; a slice of k_bs_select has its own) and, behind
+    // k_bs_select, the number of entries to walk (slices x rk: the candidate count in *n_ptr is then only reported)
     uint32_t rk, n_fixed;
-    const uint32_t *cand_spread;  // k_bs_resolve's candidate counters (64, 32 words apart) or null: then *n_ptr is the count
+    const uint32_t *cand_spread;  // k_bs_select's candidate counters (64, 32 words apart) or null: then *n_ptr is the count
 };
 
 // number of keys < key in the sorted array keys[0..n)
@@ -1125,7 +1126,8 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
         return;
     }
     // stretches sketched on the device: count, their minimizers, "could not be finished here" (the host then redoes the batch)
-    const uint32_t flag = p.dev_gaps ? p.ovf[6] : 0u;
+    // (k_bs_select raises it too: slices beyond their queues / regions, more selected candidates than a slice's room)
+    const uint32_t flag = (p.dev_gaps || p.n_fixed) ? p.ovf[6] : 0u;
     const uint32_t n_g = p.dev_gaps && !flag && n_g_raw <= GAP_DEV_MAX ? n_g_raw : 0u;
     const uint32_t nB = n_g ? p.ovf[7] : 0u;
     const uint64_t obase = p.out_base + (p.base_in ? *p.base_in : 0ull), limit = p.out_limit;
@@ -1141,7 +1143,14 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
         uint32_t below = 0;  // minimizers of block b in front of the stretch
         for (uint32_t e = lane; e < cb; e += 64u) {
             const uint32_t src = b * RKe + e;
-            below += ((((uint64_t)p.cs_c[src] << 32) | p.cs_k[src]) < key) ? 1u : 0u;
+            uint32_t ec, ek;
+            if (p.cs_aos) {
+                const uint4 q = p.cs_aos[src];
+                ek = q.z; ec = q.w;
+            } else {
+                ec = p.cs_c[src]; ek = p.cs_k[src];
+            }
+            below += ((((uint64_t)ec << 32) | ek) < key) ? 1u : 0u;
         }
         const uint64_t o0 = obase + count_prefix(p.cnt256, p.sel_sup, b) + wave_sum_u32(below) + p.s_off[r];
         if (lane < p.r_cnt[g] && o0 + lane < limit) {
@@ -1185,6 +1194,10 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
                 if (threadIdx.x == 0) {
                     p.n_sel[0] = all;
                     p.n_sel[1] = 0;
+                    if (p.cand_spread) {  // (ctrl[4..5]: the candidate count, where the other route's reorder kernel leaves it)
+                        p.n_sel[2] = n_report;
+                        p.n_sel[3] = 0;
+                    }
                     if (p.n_out) *p.n_out = (uint32_t)(obase + total);
                     if (p.base_out) *p.base_out = obase + total;
                 }
@@ -1221,9 +1234,16 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
             for (uint32_t st = ECB / 2; st > 0; st >>= 1)
                 if (spre[u + st] <= r) u += st;
             const uint32_t src = (tile * ECB + u) * RKe + (r - spre[u]);
-            hsh = p.cs_h[src];
-            kx = p.cs_k[src];
-            ctg = p.cs_c[src];
+            if (p.cs_aos) {
+                const uint4 q = p.cs_aos[src];
+                hsh = ((uint64_t)q.y << 32) | q.x;
+                kx = q.z;
+                ctg = q.w;
+            } else {
+                hsh = p.cs_h[src];
+                kx = p.cs_k[src];
+                ctg = p.cs_c[src];
+            }
         } else {
             const uint32_t i = tile * TILE + picked[r];
             hsh = p.ch[i];
@@ -2081,6 +2101,7 @@ struct Driver {
         ep.cs_h = fused ? sc(SC_CS_H).as<uint64_t>() : nullptr;  // (the sparse path's k_resolve laid the selected ones out per block)
         ep.cs_k = fused ? sc(SC_CS_K).as<uint32_t>() : nullptr;
         ep.cs_c = fused ? sc(SC_CS_C).as<uint32_t>() : nullptr;
+        ep.cs_aos = fused && n_fixed ? sc(SC_CS_H).as<uint4>() : nullptr;  // (n_fixed: the batch went through k_bs_select)
         ep.base_in = io ? io->base_in : nullptr;
         ep.base_out = io ? io->base_out : nullptr;
         ep.dev_gaps = io && io->dev_gaps ? 1u : 0u;
@@ -2524,105 +2545,63 @@ struct Driver {
     }
 
     // ---- k = 32 route (sketch_bs.hip): the assembly's filter bitmap is in a->d_bs_out (bs_hash, enqueued by the caller on
-    // some stream this one has been made to wait for); one batch = k_bs_resolve over the batch's chunks -> stretches -> emit.
-    struct BsGeom {
-        uint32_t chunk_lo, n_blocks, rk, halo_l, halo_r, max_cand;
-        bool ok;
-    };
-    BsGeom bs_geom(const Tables &T, const BatchGeom &g, double frac) const
+    // some stream this one has been made to wait for); one batch = k_bs_select over the batch's strips -> stretches -> emit.
+    BsSelGeom sel_geom(const Assembly *a, const BatchGeom &g, double frac) const
     {
-        BsGeom b{};
-        const uint32_t w = h->cfg.w;
-        const Run &r0 = (*T.runs)[g.r_lo], &r1 = (*T.runs)[g.r_hi - 1];
-        const uint64_t pos_lo = r0.base_off, pos_hi = r1.base_off + r1.n_kmers;  // first positions of the batch's k-mers
-        b.chunk_lo = (uint32_t)((pos_lo + 32) / BS_CHUNK);
-        b.n_blocks = (uint32_t)((pos_hi - 1 + 32) / BS_CHUNK) - b.chunk_lo + 1;
-        b.halo_l = (w - 1 + BSR_HALO_LANE - 1) / BSR_HALO_LANE;
-        b.halo_r = (GAP_DEV_NMAX + w + BSR_HALO_LANE - 1) / BSR_HALO_LANE;
-        const double range = (double)BS_CHUNK + (double)(b.halo_l + b.halo_r) * BSR_HALO_LANE;
-        // raw candidates of a block's range: what passes the ring test (the top-bits sum lets ~2 % more through than tau)
-        const double raw = range * frac * 1.05;
-        uint32_t mc = (uint32_t)(raw * 1.25 + 6.0 * std::sqrt(raw) + 128.0);
-        mc = std::max<uint32_t>(mc, (uint32_t)((range / 32 + 8) / 4) + 1);  // (the position-order bitmap lies over the candidates)
-        b.max_cand = (mc + 255u) / 256u * 256u;
-        const double sel = (double)BS_CHUNK * 2.0 / (double)(w + 1);
-        b.rk = ((uint32_t)(sel * 1.5 + 6.0 * std::sqrt(sel) + 96.0) + 63u) / 64u * 64u;
-        b.ok = b.max_cand <= 3072 && (uint64_t)b.n_blocks * b.rk < (1ull << 31) && b.halo_l + b.halo_r <= 12;
-        return b;
+        return bs_select_geom(a->S_sparse, a->sel_H, h->cfg.w, frac, g.n_strips, (uint32_t)env_u64("MXG_SEL_QCAP", 0));
     }
-    int enqueue_bs(Assembly *a, const Tables &T, const BatchGeom &g, const BsGeom &b, uint32_t tau_hi, OutArrays &out,
-                   uint32_t *ctrl_host, const ChainIO *io)
+    int enqueue_sel(Assembly *a, const Tables &T, const BatchGeom &g, const BsSelGeom &b, uint32_t tau_hi, OutArrays &out,
+                    uint32_t *ctrl_host, const ChainIO *io)
     {
         int rc;
         MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
         n_wave_sup = 0;
-        const size_t ctrl_bytes = ((size_t)CTRL_WORDS + sup_words(b.n_blocks) + 64 * 32) * 4;  // + the candidate counters
+        const size_t ctrl_bytes = ((size_t)CTRL_WORDS + sup_words(b.n_slices) + 64 * 32) * 4;  // + the candidate counters
         MXG_HIP(h, sc(SC_CTRL).ensure(ctrl_bytes));
-        MXG_HIP(h, sc(SC_CNT256).ensure((size_t)b.n_blocks * 4 + 64));
-        const size_t n_ent = (size_t)b.n_blocks * b.rk;
-        MXG_HIP(h, sc(SC_CS_H).ensure(n_ent * 8));
-        MXG_HIP(h, sc(SC_CS_K).ensure(n_ent * 4));
-        MXG_HIP(h, sc(SC_CS_C).ensure(n_ent * 4));
+        MXG_HIP(h, sc(SC_CNT256).ensure((size_t)b.n_slices * 4 + 64));
+        const size_t n_ent = (size_t)b.n_slices * b.rk;
+        MXG_HIP(h, sc(SC_CS_H).ensure(n_ent * 16));  // (one 16-byte entry per selected candidate: EmitParams::cs_aos)
+        // regions for the slices that outgrow their LDS queue (SC_CAND_H / SC_CAND_K: this route has no candidate arrays)
+        const size_t ovf_ent = (size_t)b.n_ovf * (b.ovf_cap + 2 * SEL_PAD);
+        MXG_HIP(h, sc(SC_CAND_H).ensure(ovf_ent * 8));
+        MXG_HIP(h, sc(SC_CAND_K).ensure(ovf_ent * 4));
         MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, ctrl_bytes, st));
         if ((rc = ev_begin(0, false, fine ? 3 : 1)) != MXG_OK) return rc;
-        BsResolveParams bp{};
-        bp.out = a->d_bs_out.as<uint32_t>() + 4;  // (BS_OUT_PAD)
-        bp.n_chunks = a->bs_chunks;
+        BsSelParams bp{};
+        bp.bm = a->d_bs_out.as<uint32_t>() + 4;  // (BS_OUT_PAD)
         bp.packed = a->d_packed;
-        bp.n_words = a->packed_words;
-        bp.runs = T.d_runs;
-        bp.chunk_run0 = a->d_bs_run0.as<uint32_t>();
-        bp.ctg_nk = T.d_ctg_nk;
+        bp.runx = a->d_runx.as<RunX>();
+        bp.strip_run = T.d_strip_run;
         bp.ctg_drop = T.d_ctg_drop;
-        bp.init_tab = h->d_init_tab.as<uint4>();
-        bp.tab = h->tab;
-        bp.run_lo = g.r_lo;
-        bp.run_hi = g.r_hi;
-        bp.ctg_lo = (uint32_t)g.c0;
-        bp.ctg_hi = (uint32_t)g.c1;
-        bp.chunk_lo = b.chunk_lo;
-        bp.k = h->cfg.k;
+        bp.ptab = h->d_init_tab.as<uint4>() + 256;
+        bp.n_strips_asm = (*T.strip0_sparse)[T.runs->size()];
+        bp.strip_lo = g.strip_lo;
+        bp.strip_hi = g.strip_hi;
+        bp.S = a->S_sparse;
+        bp.H = b.H;
+        bp.T = b.T;
+        bp.n_slices = b.n_slices;
         bp.w = h->cfg.w;
         bp.tau = (uint64_t)tau_hi << 32;
-        bp.halo_l = b.halo_l;
-        bp.halo_r = b.halo_r;
-        bp.max_cand = b.max_cand;
+        bp.qcap = b.qcap;
+        bp.ovf_h = sc(SC_CAND_H).as<uint64_t>();
+        bp.ovf_e = sc(SC_CAND_K).as<uint32_t>();
+        bp.ovf_cap = b.ovf_cap;
+        bp.n_ovf = b.n_ovf;
+        bp.ovf_next = sc(SC_CTRL).as<uint32_t>() + 12;
         bp.rk = b.rk;
-        bp.cs_h = sc(SC_CS_H).as<uint64_t>();
-        bp.cs_k = sc(SC_CS_K).as<uint32_t>();
-        bp.cs_c = sc(SC_CS_C).as<uint32_t>();
+        bp.cs = sc(SC_CS_H).as<uint4>();
         bp.cnt = sc(SC_CNT256).as<uint32_t>();
         bp.sup = sel_sup(0);
         bp.gaps = sc(SC_GAPS).as<uint4>();
         bp.gap_cap = GAP_CAP;
         bp.ctrl = sc(SC_CTRL).as<uint32_t>();
-        bp.cand_spread = sel_sup(0) + sup_words(b.n_blocks);
-        bp.ablate = (uint32_t)env_u64("MXG_BSR_ABLATE", 0);  // (profiling only)
-        bp.dbg = nullptr;
-        if (env_u64("MXG_BSR_DBG", 0)) {  // (profiling only: cycle stamps of the phases, printed for one launch)
-            MXG_HIP(h, h->dbg_buf.ensure((size_t)b.n_blocks * 16 * 8));
-            bp.dbg = h->dbg_buf.as<unsigned long long>();
-            MXG_HIP(h, hipMemsetAsync(h->dbg_buf.p, 0, (size_t)b.n_blocks * 16 * 8, st));
-            h->dbg_blocks = b.n_blocks;
-        }
-        launch_bs_resolve(bp, b.n_blocks, st);
-        MXG_HIP(h, hipGetLastError());
-        if (bp.dbg) {
-            MXG_HIP(h, hipStreamSynchronize(st));
-            std::vector<unsigned long long> v((size_t)b.n_blocks * 16);
-            MXG_HIP(h, hipMemcpy(v.data(), bp.dbg, v.size() * 8, hipMemcpyDeviceToHost));
-            double acc[9] = {0};
-            unsigned long long t_min = ~0ull, t_max = 0;
-            for (uint32_t q = 0; q < b.n_blocks; ++q) {
-                for (int k = 1; k <= 8; ++k) acc[k] += (double)(v[q * 16 + k] - v[q * 16 + k - 1]);
-                t_min = std::min(t_min, v[q * 16]);
-                t_max = std::max(t_max, v[q * 16 + 8]);
-            }
-            fprintf(stderr, "k_bs_resolve phases (mean ticks per block, %u blocks): issue %.0f | to LDS + window %.0f | scatter %.0f | enumerate %.0f | hash %.0f | resolve %.0f | leading %.0f | counts %.0f ; kernel span %.0f ticks\n",
-                    b.n_blocks, acc[1] / b.n_blocks, acc[2] / b.n_blocks, acc[3] / b.n_blocks, acc[4] / b.n_blocks, acc[5] / b.n_blocks,
-                    acc[6] / b.n_blocks, acc[7] / b.n_blocks, acc[8] / b.n_blocks, (double)(t_max - t_min));
-        }
-        if ((rc = enqueue_dev_gaps(a, T, ctrl_host)) != MXG_OK) return rc;
+        bp.cand_spread = sel_sup(0) + sup_words(b.n_slices);
+        bp.ablate = (uint32_t)env_u64("MXG_SEL_ABLATE", 0);  // (profiling only: stop every slice after phase n)
+        if ((rc = launch_bs_select(h, bp, b, st)) != MXG_OK) return rc;
+        h->stat_sel_slices += b.n_slices;
+        const bool dev = io && io->dev_gaps;
+        if (dev && (rc = enqueue_dev_gaps(a, T, ctrl_host)) != MXG_OK) return rc;
         if ((rc = ev_next(4)) != MXG_OK) return rc;
         if (io && io->wait) MXG_HIP(h, hipStreamWaitEvent(st, io->wait, 0));
         rc = emit(a->d_packed, T, (uint32_t)n_ent, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host, io, b.rk,
@@ -2871,6 +2850,12 @@ static int prepare_tables(mxg_handle *h, Assembly *a)
     if ((rc = upload(h, a->d_ctg_run0, a->ctg_run0)) != MXG_OK) return rc;
     if (a->any_drop && (rc = upload(h, a->d_ctg_drop, a->ctg_drop)) != MXG_OK) return rc;
     if (n_runs) {
+        std::vector<RunX> rx(n_runs);
+        for (size_t r = 0; r < n_runs; ++r) {
+            const Run &q = a->runs[r];
+            rx[r] = RunX{q.base_off, q.n_kmers, q.contig, q.kidx0, a->strip0_sparse[r], a->ctg_nk[q.contig], 0u};
+        }
+        if ((rc = upload(h, a->d_runx, rx)) != MXG_OK) return rc;
         const uint32_t n_strips = a->strip0_sparse[n_runs];
         MXG_HIP(h, a->d_strip_run.ensure((size_t)n_strips * 4 + 16));
         hipLaunchKernelGGL(k_strip_runs, dim3((uint32_t)n_runs), dim3(256), 0, h->stream, a->d_strip0_sparse.as<uint32_t>(), (uint32_t)n_runs,
@@ -3015,7 +3000,7 @@ __global__ __launch_bounds__(256) void k_pack_slot_dev(const uint64_t *__restric
         return;
     }
     const uint64_t n = *n_ptr;
-    const bool ok = ctrl[0] == 0 && ctrl[1] == 0 && (ctrl[4] | ctrl[5]) != 0 && n <= cap && n <= out_cap;
+    const bool ok = ctrl[0] == 0 && ctrl[1] == 0 && ctrl[6] == 0 && (ctrl[4] | ctrl[5]) != 0 && n <= cap && n <= out_cap;
     if (i == 0) *header = ok ? (long long)n : -1ll;
     if (!ok || i >= n) return;
     reinterpret_cast<uint64_t *>(region)[i] = hash[i];
@@ -3066,7 +3051,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         bool bs;       // went through the k = 32 route (no candidate arrays to finish from)
     };
     const bool bs_env = env_u64("MXG_BS", 1) != 0;
-    const bool bs_fused = env_u64("MXG_BS_FUSED", 0) != 0;  // k_bs_resolve instead of count -> reorder -> resolve
+    const bool bs_select = env_u64("MXG_BS_SELECT", 1) != 0;  // k_bs_select instead of count -> reorder -> resolve
     std::vector<Tables> tabs(n);
     std::vector<int> state(n, 0);  // 0 = synchronous path, 1 = enqueued, 2 = done
     std::vector<SparsePlan> plans(n);
@@ -3092,19 +3077,27 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             c0 = g.c1;
         }
         if (gs.empty() || (chain_modes && gs.size() > 1) || items.size() + gs.size() >= PINNED_SLOTS - 1) return MXG_OK;
-        // the k = 32 route: the bit-sliced filter over the whole assembly, then one k_bs_resolve per batch (sketch_bs.hip)
+        // the k = 32 route: the bit-sliced filter over the whole assembly, then one k_bs_select per batch (sketch_bs.hip); a second
+        // attempt (a batch did not end the common way: slices beyond their queues, stretches beyond the device route) and run
+        // tables with short runs between invalid bases take count -> reorder -> resolve behind the same bitmap
         bool use_bs = bs_env && bs_possible(h, list[i]);
-        bool fused_ok = use_bs && bs_fused && plans[i].dev_gaps && !chain_modes && h->cfg.w >= 256 && h->cfg.w <= GAP_DEV_NMAX / 2;
-        std::vector<Driver::BsGeom> bgs;
+        bool sel_ok = use_bs && bs_select && attempt == 0;
+        std::vector<BsSelGeom> bgs;
         if (use_bs) {
             if ((rc = bs_prepare(h, list[i])) != MXG_OK) return rc;
             use_bs = list[i]->bs_ready;
-            for (size_t b = 0; use_bs && fused_ok && b < gs.size(); ++b) {
-                bgs.push_back(drv0.bs_geom(tabs[i], gs[b], plans[i].frac));
-                fused_ok = bgs.back().ok;
+            Assembly *a = list[i];
+            if (use_bs && sel_ok && (a->sel_H_S != a->S_sparse || a->sel_H_w != h->cfg.w)) {
+                a->sel_H = bs_select_halo(a, a->S_sparse, h->cfg.w);
+                a->sel_H_S = a->S_sparse;
+                a->sel_H_w = h->cfg.w;
+            }
+            for (size_t b = 0; use_bs && sel_ok && b < gs.size(); ++b) {
+                bgs.push_back(drv0.sel_geom(a, gs[b], plans[i].frac));
+                sel_ok = bgs.back().ok;
             }
         }
-        fused_ok = fused_ok && use_bs;
+        sel_ok = sel_ok && use_bs;
         hipEvent_t ev_hash = nullptr;
         hipStream_t st_hash = nullptr;
         OutArrays out{&list[i]->d_hash, &list[i]->d_pos, &list[i]->d_rec, &list[i]->d_fwd, 0};
@@ -3126,7 +3119,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             it.g = gs[b];
             it.slot = (int)sl;
             it.n_cap = 0;
-            it.bs = fused_ok;
+            it.bs = sel_ok;
             if (use_bs && attempt > 0) {
                 // (the bitmap of the first attempt is still there, and every stream has been waited for)
             } else if (use_bs && b == 0) {  // the filter, once per assembly, on the first batch's stream
@@ -3169,8 +3162,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
                 drv.n_out = h->d_nmx.as<uint32_t>() + i;
             }
-            if (fused_ok) {
-                if ((rc = drv.enqueue_bs(list[i], tabs[i], it.g, bgs[b], plans[i].tau_hi, out, it.hc, &io)) != MXG_OK) return rc;
+            if (sel_ok) {
+                if ((rc = drv.enqueue_sel(list[i], tabs[i], it.g, bgs[b], plans[i].tau_hi, out, it.hc, &io)) != MXG_OK) return rc;
             } else if ((rc = drv.enqueue_sparse(list[i], tabs[i], it.g, drv.default_wave_cap(list[i]->S_sparse, plans[i].frac),
                                                 plans[i].tau_hi, out, it.hc, &it.n_cap, &io, list[i]->cand_hints[b],
                                                 use_bs ? list[i]->d_bs_out.as<uint32_t>() + 4 : nullptr)) != MXG_OK)
@@ -3261,7 +3254,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             const uint64_t t = (uint64_t)c[6] | ((uint64_t)c[7] << 32);
             const bool dev = plans[i].dev_gaps && !chain_modes;
             // (not the device route: any stretch sends the batch to the general route below)
-            good = good && c[0] == 0 && c[3] == 0 && c[4] != 0 && c[4] != 0xFFFFFFFFu && (dev || c[1] == 0);
+            // (a batch without any candidate: k_bs_select reports its contigs as stretches; the other route leaves it to the host)
+            good = good && c[0] == 0 && c[3] == 0 && (c[4] != 0 || items[q].bs) && c[4] != 0xFFFFFFFFu && (dev || c[1] == 0);
             total += t;
             n_cand += c[4];
             gap_kmers += c[10] == 0xFFFFFFFFu ? 0 : c[10];
@@ -3339,7 +3333,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             for (; j < q1; ++j) {
                 const uint32_t *c = items[j].hc;
                 const uint64_t t = (uint64_t)c[6] | ((uint64_t)c[7] << 32), ob = (uint64_t)c[8] | ((uint64_t)c[9] << 32);
-                const bool ok = c[0] == 0 && c[3] == 0 && c[4] != 0 && c[4] != 0xFFFFFFFFu && (dev || c[1] == 0) && ob == offset &&
+                const bool ok = c[0] == 0 && c[3] == 0 && (c[4] != 0 || items[j].bs) && c[4] != 0xFFFFFFFFu && (dev || c[1] == 0) && ob == offset &&
                                 offset + t <= cap;
                 if (!ok) break;
                 offset += t;

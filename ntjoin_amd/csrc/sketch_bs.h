@@ -1,5 +1,5 @@
 // sketch_bs.h -- the k = 32 route of the sketch stage: bit-sliced ring filter (bs_kernels.h) + one kernel that turns its
-// candidate bitmap into minimizers (exact hashes, window decision, candidate-free stretches).  Launchers for sketch.hip.
+// candidate bitmap into selected minimizers (exact hashes, window decision, candidate-free stretches).  Launchers for sketch.hip.
 #pragma once
 #include "mxg_internal.h"
 
@@ -9,48 +9,59 @@ namespace mxg {
 #define MXG_BS_CHUNK_DEFINED
 constexpr uint32_t BS_CHUNK = 65536;      // base positions per chunk of the bit-sliced filter (bs_kernels.h)
 #endif
-constexpr uint32_t BSR_THREADS = 1024;   // 16 waves per chunk: the block is a chain of short dependent phases, parallel slack hides them
-constexpr uint32_t BSR_RUNS = 96;        // runs of the run table a block keeps in LDS (more overlap its range: host redo)
-constexpr uint32_t BSR_HALO_LANE = 1024; // base positions per halo unit (one lane of a chunk)
 
-struct BsResolveParams {
-    // the filter's result for the whole assembly, the assembly's bases and tables
-    const uint32_t *out;       // the filter's bitmap: bit p = position p (bs_kernels.h)
-    uint32_t n_chunks;
+// k_bs_select: one WAVE per slice of 64 consecutive strips of the assembly's strip table (lane = strip): H halo strips, T own
+// strips, H halo strips (T + 2 H = 64).  The slice's candidates never leave the wave's LDS: bits -> queue -> exact hashes ->
+// window decision -> the selected ones, laid out per slice for k_emit (the layout k_resolve writes per block of 256 candidates).
+constexpr uint32_t SEL_PAD = 8;          // sentinel entries on either side of a wave's candidate list (the scans look at eight at a time)
+constexpr uint32_t SEL_REQ = 8;          // stretches per slice whose end lies behind the slice's strips (found by walking on)
+constexpr uint32_t SEL_MAX_H = 12;       // largest halo (strips) the route takes: 40 own strips per slice
+
+struct BsSelParams {
+    const uint32_t *bm;          // the filter's bitmap: bit p = base position p of the packed array (bs_kernels.h)
     const uint32_t *packed;
-    uint64_t n_words;
-    const Run *runs;
-    const uint32_t *chunk_run0;  // [n_chunks + 1] first run whose k-mers end behind the chunk's first position
-    const uint32_t *ctg_nk;
+    const RunX *runx;            // [n_runs] the run table as this kernel reads it
+    const uint32_t *strip_run;   // [n_strips_asm] the run of every strip (k_strip_runs)
     const uint8_t *ctg_drop;     // see ResolveParams::ctg_drop (sketch.hip); may be null
-    const uint4 *init_tab;       // byte table of the direct hash formula (make_init_tab)
-    HashTab tab;
-    // the batch: contigs [ctg_lo, ctg_hi) = runs [run_lo, run_hi); one block per chunk from chunk_lo on
-    uint32_t run_lo, run_hi, ctg_lo, ctg_hi;
-    uint32_t chunk_lo;
-    uint32_t k, w;
+    const uint4 *ptab;           // position tables of the direct hash formula (make_init_tab, entries 256..: 2048 x 16 B)
+    uint32_t n_strips_asm;       // strips of the whole assembly (halo strips may lie outside the batch)
+    uint32_t strip_lo, strip_hi; // the batch's strips: every one of them is an own strip of exactly one slice
+    uint32_t S, H, T;            // k-mers per strip, halo strips on either side, own strips per slice
+    uint32_t n_slices;
+    uint32_t w;
     uint64_t tau;
-    uint32_t halo_l, halo_r;     // halo in units of BSR_HALO_LANE positions
-    uint32_t max_cand;           // candidates a block can hold (dynamic LDS is sized for it)
-    // results: the selected candidates of block b from entry b * rk on + two-level counts (k_emit), stretches (k_gap_fix)
+    uint32_t qcap;               // raw candidates a wave's LDS queue holds
+    // a slice with more raw candidates than qcap works in one of n_ovf global-memory regions of ovf_cap entries (a wave's
+    // worst case: 64 S) instead; no region left: the host redoes the batch (ctrl[6])
+    uint64_t *ovf_h;
+    uint32_t *ovf_e;
+    uint32_t ovf_cap, n_ovf;
+    uint32_t *ovf_next;          // ticket counter of the regions (zeroed with the control block)
+    // results: the selected candidates of slice s from entry s * rk on + two-level counts (k_emit), stretches (k_gap_fix)
     uint32_t rk;
-    uint64_t *cs_h;
-    uint32_t *cs_k, *cs_c;
+    uint4 *cs;                   // {hash lo, hash hi, k-mer index, contig}
     uint32_t *cnt, *sup;
     uint4 *gaps;
     uint32_t gap_cap;
-    uint32_t ablate;             // (profiling builds: stop after phase n; 0 = run)
-    unsigned long long *dbg;     // (profiling: 16 cycle stamps per block, or null)
-    uint32_t *cand_spread;       // 64 counters, 32 words apart: the blocks' own candidates (k_emit adds them up for the report)
+    uint32_t *cand_spread;       // 64 counters, 32 words apart: the slices' own candidates (k_emit adds them up for the report)
     uint32_t *ctrl;              // [1] stretches, [6] "the host must redo this batch"
+    uint32_t ablate;             // (profiling builds: every slice stops after phase n; 0 = run)
 };
 
-size_t bs_resolve_lds(const BsResolveParams &p);
-void launch_bs_resolve(const BsResolveParams &p, uint32_t n_blocks, hipStream_t st);
+struct BsSelGeom {
+    uint32_t H, T, n_slices, rk, qcap, waves, ovf_cap, n_ovf;
+    size_t lds;
+    bool ok;
+};
+// halo (strips on either side of a slice's own strips) that gives every own candidate w k-mers of its contig on either side --
+// or the contig's end -- whatever the run table looks like; 0: more than SEL_MAX_H strips (short runs between invalid bases)
+uint32_t bs_select_halo(const Assembly *a, uint32_t S, uint32_t w);
+BsSelGeom bs_select_geom(uint32_t S, uint32_t H, uint32_t w, double frac, uint32_t n_strips, uint32_t qcap_force);
+int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hipStream_t st);
 
 // layout + filter (per assembly)
 bool bs_possible(const mxg_handle *h, const Assembly *a);
-int bs_prepare(mxg_handle *h, Assembly *a);                                  // T / Q / chunk_run0, once per assembly
+int bs_prepare(mxg_handle *h, Assembly *a);                                  // padded edge chunks, once per assembly
 int bs_hash(mxg_handle *h, Assembly *a, uint32_t tau_hi, hipStream_t st);    // the filter over the whole assembly -> a->d_bs_out
 
 }  // namespace mxg

@@ -3,16 +3,20 @@
 //   k_hash_bs       (bs_kernels.h)  the bit-sliced ring filter over the whole assembly, straight from the 2-bit packed bases (bit
 //                                   planes are made in registers): one bit per base position, "the 32-mer starting here may have
 //                                   canonical hash < tau" (a superset)
-//   k_bs_resolve    (here)          one block per chunk of 65 536 positions: the filter's bits of the chunk and of a halo on
-//                                   either side -> candidates in position order -> valid ones (run table) with their exact
-//                                   64-bit hashes < tau -> the window decision of k_resolve (sketch.hip) on the block's own
-//                                   candidates, with every neighbour it can need inside the halo -> the selected ones laid
-//                                   out per block for k_emit, candidate-free stretches for k_gap_fix.
-// The halo: w - 1 k-mers to the left (the window decision), the longest stretch the device route sketches (GAP_DEV_NMAX) plus
-// w to the right (a stretch is reported by the candidate in front of it and must end inside the block's range; a longer one
-// sends the batch to the general route, as it does in sketch.hip).  A block whose range the run table describes in more than
-// BSR_RUNS runs, or that finds more candidates than its LDS holds, also sends the batch there (ctrl[6]).
+//   k_bs_select     (here)          one WAVE per slice of 64 consecutive strips (lane = strip: H halo strips, T own strips, H halo
+//                                   strips): the strips' bits of the bitmap -> the wave's LDS queue in position order -> exact 64-bit
+//                                   hashes (position tables), entries >= tau dropped -> the window decision of k_resolve
+//                                   (sketch.hip: L + R + 1 >= w) on the slice's OWN candidates, whose every possible neighbour
+//                                   lies in the halo -> the selected ones laid out per slice for k_emit, candidate-free stretches
+//                                   for k_gap_fix.  Nothing is counted, ordered or exchanged between slices: the candidates of the
+//                                   assembly never exist as one array (k_bs_count / k_bs_reorder_w / k_resolve of sketch.hip remain
+//                                   the route for what this kernel does not take).
+// The halo: H strips hold at least w k-mers of the own strips' contig on either side, or reach that contig's end
+// (bs_select_halo checks it against the run table).  So an own candidate sees every candidate within w - 1 k-mers, and one that
+// has no candidate of its contig behind it inside the slice is followed by a candidate-free stretch of >= w k-mers for
+// certain: where that stretch ends is found by walking on through the strips behind the slice (stretch_end).
 #include <algorithm>
+#include <cmath>
 
 #include "bs_kernels.h"
 #include "nthash_dev.h"
@@ -23,544 +27,533 @@ namespace mxg {
 
 namespace {
 
-__device__ __forceinline__ uint32_t lds_base2(const uint32_t *pk, uint32_t rel)  // 16 bases from LDS words, any alignment
+// canonical hash (fwd + rev) of the 32-mer at base index b: position tables ptab[j][v] = {srol^{4(7-j)} f4[v], srol^{4j} r4[v]}
+// (init_pos of nthash_dev.h at k = 32: 8 lookups, 32 XORs, no rotation)
+// three consecutive words from a 4-byte aligned address in ONE request (the address unit is what this kernel keeps busiest)
+struct __attribute__((packed, aligned(4))) Words3 {
+    uint32_t w0, w1, w2;
+};
+struct __attribute__((packed, aligned(4))) Words4 {
+    uint32_t w0, w1, w2, w3;
+};
+__device__ __forceinline__ uint64_t hash32_words(const uint32_t w0, const uint32_t w1, const uint32_t w2, const uint32_t sh, const uint4 *ptab)
 {
-    const uint32_t wi = rel >> 4, sh = (rel & 15u) * 2u;
-    return __builtin_amdgcn_alignbit(pk[wi + 1], pk[wi], sh);
-}
-
-// canonical hash (fwd + rev) of the 32-mer at LDS base index rel: half position tables (init32_half, nthash_dev.h:
-// half[j][v] = {srol^{4(3-j)} f4[v], srol^{4j} r4[v]}; bytes 0..3 and 4..7 of the k-mer through the same four tables, joined by
-// two rotations by 16) -- 16 KB of LDS where the full position tables take 32 KB and a second block per CU
-__device__ __forceinline__ uint64_t hash32_lds(const uint32_t *pk, uint32_t rel, const uint4 *half)
-{
-    const uint32_t wi = rel >> 4, sh = (rel & 15u) * 2u;
-    const uint32_t w0 = pk[wi], w1 = pk[wi + 1], w2 = pk[wi + 2];
     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-    uint4 a = make_uint4(0u, 0u, 0u, 0u), c = make_uint4(0u, 0u, 0u, 0u);
+    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) {
-        const uint4 e0 = half[u * 256u + ((lo >> (8 * u)) & 255u)];
-        const uint4 e1 = half[u * 256u + ((hi >> (8 * u)) & 255u)];
-        a.x ^= e0.x; a.y ^= e0.y; a.z ^= e0.z; a.w ^= e0.w;
-        c.x ^= e1.x; c.y ^= e1.y; c.z ^= e1.z; c.w ^= e1.w;
+        const uint4 e0 = ptab[u * 256u + ((lo >> (8 * u)) & 255u)];
+        const uint4 e1 = ptab[(4u + u) * 256u + ((hi >> (8 * u)) & 255u)];
+        acc.x ^= e0.x ^ e1.x; acc.y ^= e0.y ^ e1.y; acc.z ^= e0.z ^ e1.z; acc.w ^= e0.w ^ e1.w;
     }
-    srol16(a.x, a.y);
-    srol16(c.z, c.w);
-    return (((uint64_t)(a.y ^ c.y) << 32) | (a.x ^ c.x)) + (((uint64_t)(a.w ^ c.w) << 32) | (a.z ^ c.z));
+    return (((uint64_t)acc.y << 32) | acc.x) + (((uint64_t)acc.w << 32) | acc.z);
+}
+__device__ __forceinline__ uint64_t hash32_pos(const uint32_t *__restrict__ packed, const uint64_t b, const uint4 *ptab)
+{
+    const Words3 v = *reinterpret_cast<const Words3 *>(packed + (b >> 4));
+    return hash32_words(v.w0, v.w1, v.w2, ((uint32_t)b & 15u) * 2u, ptab);
 }
 
-// exclusive prefix of v over the block's threads (16 waves); total = the block's sum.  sh: 40 words; two barriers; a following
-// call may start at once.  (block_exclusive of scan_kernels.h has every thread walk the 16 wave totals: ~120 instructions per
-// wave where this takes ~40, and the kernel is bound by instruction issue.)
-__device__ __forceinline__ uint32_t bsr_scan(uint32_t v, uint32_t *sh, uint32_t &total)
+// the bits of k-mers [32 j, 32 j + 32) of a strip of len k-mers whose first k-mer is base position b (sh = b % 32): LSB first
+__device__ __forceinline__ uint32_t sel_bits(const uint32_t w_lo, const uint32_t w_hi, const uint32_t sh, const uint32_t len, const uint32_t j)
 {
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t incl = wave_inclusive_u32(v, lane);
-    if (lane == 63u) sh[wv] = incl;
-    __syncthreads();
-    if (wv == 0 && lane < 16u) {
-        const uint32_t x = sh[lane];
-        uint32_t inc = x;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 16);
-            if (lane >= (uint32_t)o) inc += t;
-        }
-        sh[16u + lane] = inc - x;
-        if (lane == 15u) sh[32] = inc;
-    }
-    __syncthreads();
-    total = sh[32];
-    return sh[16u + wv] + incl - v;
-}
-// the same for one flag per thread (rank inside the wave from the ballot)
-__device__ __forceinline__ uint32_t bsr_scan_flag(bool f, uint32_t *sh, uint32_t &total)
-{
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint64_t m = __ballot(f);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    if (lane == 0u) sh[wv] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (wv == 0 && lane < 16u) {
-        const uint32_t x = sh[lane];
-        uint32_t inc = x;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 16);
-            if (lane >= (uint32_t)o) inc += t;
-        }
-        sh[16u + lane] = inc - x;
-        if (lane == 15u) sh[32] = inc;
-    }
-    __syncthreads();
-    total = sh[32];
-    return sh[16u + wv] + rank;
+    const uint32_t bits = __builtin_amdgcn_alignbit(w_hi, w_lo, sh);
+    const uint32_t k0 = 32u * j;
+    const uint32_t nvalid = len > k0 ? min(len - k0, 32u) : 0u;
+    return bits & (nvalid >= 32u ? 0xFFFFFFFFu : ((1u << nvalid) - 1u));
 }
 
-constexpr uint32_t BSR_PAD = 4;  // sentinel entries on either side of the candidates (the scans look at four at a time)
-struct BsLds {
-    uint4 *btab;        // [1024] half position tables of the direct hash formula
-    uint32_t *pk;       // packed words of the block's range (+ 3)
-    uint32_t *nat;      // position-order bitmap of the range: word g = strip g (32 positions); lies over cand (dead before)
-    uint32_t *posl;     // candidates: position relative to the range start
-    uint4 *cand;        // candidates of the range in order: {k-mer index, contig, hash lo, hash hi}; [-PAD, n + PAD)
-    uint32_t *cnk;      // ... the k-mer count of the candidate's contig
-    Run *runs;          // [BSR_RUNS]
-    uint32_t *rnk;      // [BSR_RUNS] k-mer count of the run's contig
-    uint32_t *sh;       // [256 + 8] scan scratch
+// a strip of the assembly's strip table as its lane holds it
+struct StripRegs {
+    uint64_t b;                // base position of its first k-mer
+    uint32_t len, cg, k0, nk;  // k-mers, contig (~0: no strip), contig-local index of the first k-mer, k-mers of the contig
 };
+__device__ __forceinline__ StripRegs strip_of(const BsSelParams &p, const bool in, const uint32_t s, const uint32_t ri)
+{
+    StripRegs r;
+    r.b = 0; r.len = 0; r.cg = 0xFFFFFFFFu; r.k0 = 0; r.nk = 0;
+    if (in) {
+        const RunX run = p.runx[ri];  // (32 bytes, aligned: two requests)
+        const uint32_t j0 = (s - run.strip0) * p.S;
+        r.len = min(p.S, run.n_kmers - j0);
+        r.b = run.base_off + j0;
+        r.cg = run.contig;
+        r.k0 = run.kidx0 + j0;
+        r.nk = run.nk;
+    }
+    return r;
+}
+__device__ __forceinline__ StripRegs load_strip(const BsSelParams &p, const int64_t s64)
+{
+    const bool in = s64 >= 0 && s64 < (int64_t)p.n_strips_asm;
+    const uint32_t s = in ? (uint32_t)s64 : 0u;
+    return strip_of(p, in, s, in ? p.strip_run[s] : 0u);
+}
+
+__device__ __forceinline__ void sel_push_gap(const BsSelParams &p, uint32_t c, uint32_t lo, uint32_t hi, uint32_t hint)
+{
+    const uint32_t idx = atomicAdd(&p.ctrl[1], 1u);
+    if (idx < p.gap_cap) p.gaps[idx] = make_uint4(c, lo, hi, hint);
+}
+
+// The whole wave: contig c has no candidate from k-mer k_from up to the end of the strips the slice holds, and goes on behind
+// them.  Walk on, 64 strips at a time, to the contig's first real candidate (exact hash < tau) or its end.  -> last k-mer of the stretch
+__device__ __forceinline__ uint32_t stretch_end(const BsSelParams &p, const uint4 *ptab, const uint32_t lane, int64_t s_next, const uint32_t c,
+                                                const uint32_t nk)
+{
+    const uint32_t nwords = (p.S + 31u) / 32u;
+    for (;; s_next += 64) {
+        const StripRegs r = load_strip(p, s_next + lane);
+        const bool stop = r.cg != c;  // (behind the assembly's last strip: cg = ~0)
+        uint32_t kfound = 0xFFFFFFFFu;
+        if (!stop) {
+            const uint32_t *bw = p.bm + (r.b >> 5);
+            const uint32_t sh = (uint32_t)r.b & 31u;
+            uint32_t w0 = bw[0];
+            for (uint32_t j = 0; j < nwords && kfound == 0xFFFFFFFFu; ++j) {
+                const uint32_t w1 = bw[j + 1u];
+                uint32_t bits = sel_bits(w0, w1, sh, r.len, j);
+                w0 = w1;
+                for (; bits; bits &= bits - 1u) {
+                    const uint32_t ju = 32u * j + (uint32_t)__builtin_ctz(bits);
+                    if (hash32_pos(p.packed, r.b + ju, ptab) < p.tau) {
+                        kfound = r.k0 + ju;
+                        break;
+                    }
+                }
+            }
+        }
+        const uint64_t mf = __ballot(kfound != 0xFFFFFFFFu), ms = __ballot(stop);
+        const uint64_t ev = mf | ms;
+        if (ev) {
+            const int first = __builtin_ctzll(ev);
+            if ((mf >> first) & 1ull) return (uint32_t)__builtin_amdgcn_readlane((int)kfound, first) - 1u;
+            return nk - 1u;
+        }
+    }
+}
+
+constexpr uint32_t SEL_SI = 6;  // per-strip words a wave keeps in LDS: base position (2), contig, first k-mer, contig's k-mers, fold base
+
+// bytes of LDS per wave (a multiple of 16): hashes | coordinates (raw queue before) | strip info | requests | counters
+__host__ __device__ inline uint32_t sel_wave_lds(uint32_t qcap)
+{
+    return (qcap + 2u * SEL_PAD) * 12u + SEL_SI * 64u * 4u + SEL_REQ * 16u + 16u;
+}
+
+// What a wave knows about its slice while it works on it
+struct SelCtx {
+    const uint4 *ptab;
+    uint32_t *si;      // strip info (LDS)
+    uint4 *req;        // stretches that end behind the slice (LDS)
+    uint32_t *misc;    // [0] number of requests
+    uint32_t lane, sl, own_end;
+    int64_t s_first;
+    uint32_t nreal, own_lo, own_hi;  // the list: real candidates, the own ones among them [own_lo, own_hi)
+};
+
+// The candidate list of a slice: the wave's LDS, or -- GLOB -- a region of global memory for a slice whose raw candidates
+// outgrow the queue; entries -SEL_PAD .. cap + SEL_PAD - 1 of
+//   le   before the hashes: raw queue, item = strip lane | k-mer of the strip << 6
+//        behind them: e = (folded coordinate << 6) | strip lane of the real candidates (real: hash < tau), in order
+//   lh   their hashes
+// folded coordinate: position on one axis on which the slice's k-mers lie in order, k-mers of one contig at their distances
+// and contigs >= w apart -- "same contig and within w - 1 k-mers" is one subtraction and one compare (on e itself: strip lanes
+// rise with the coordinate, so e_a - e_b = 64 (x_a - x_b) + (lane_a - lane_b) and x_a - x_b = (e_a - e_b) >> 6).
+template <bool GLOB>
+__device__ __forceinline__ void sel_sync()
+{
+    if (GLOB) __threadfence_block();
+    else __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave complete in order)
+}
+
+// bits -> raw queue -> exact hashes -> the real candidates at the front of the list, in order (+ sentinels)
+template <int NWC, bool GLOB>
+__device__ __forceinline__ void sel_collect(const BsSelParams &p, SelCtx &c, uint64_t *lh, uint32_t *le, const uint32_t cap, const StripRegs &sr,
+                                            const uint32_t (&wd)[NWC], const uint32_t at0, const uint32_t tot)
+{
+    const uint32_t lane = c.lane, H = p.H;
+    const uint32_t nwords = (p.S + 31u) / 32u;
+    const uint32_t qn = min(tot, cap);
+    {
+        uint32_t at = at0;
+        const uint32_t sh = (uint32_t)sr.b & 31u;
+#pragma unroll
+        for (uint32_t j = 0; j + 1 < (uint32_t)NWC; ++j) {
+            if (j < nwords) {
+                uint32_t bits = sel_bits(wd[j], wd[j + 1], sh, sr.len, j);
+                const uint32_t item0 = lane | ((32u * j) << 6);
+                for (; bits; bits &= bits - 1u, ++at) {
+                    const uint32_t t = (uint32_t)__builtin_ctz(bits);
+                    if (at < qn) le[at] = item0 + (t << 6);
+                }
+            }
+        }
+    }
+    const uint32_t *s_blo = c.si, *s_bhi = c.si + 64, *s_f = c.si + 320;
+    sel_sync<GLOB>();
+    c.nreal = c.own_lo = c.own_hi = 0;
+    if (p.ablate == 2) return;  // (profiling)
+    uint32_t nreal = 0, own_lo = 0, own_hi = 0;
+    for (uint32_t q0 = 0; q0 < qn; q0 += 64u) {
+        const uint32_t q = q0 + lane;
+        const bool act = q < qn;
+        const uint32_t item = act ? le[q] : 0u;
+        const uint32_t l2 = item & 63u, ju = item >> 6;
+        const uint64_t b = (((uint64_t)s_bhi[l2] << 32) | s_blo[l2]) + ju;
+        uint64_t h = ~0ull;
+        if (act) h = hash32_pos(p.packed, b, c.ptab);
+        const bool real = act && h < p.tau;
+        const uint64_t m = __ballot(real);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (real) {  // (in place: an entry lands at or in front of the item it came from, and the round's items have all been read)
+            le[nreal + rank] = ((s_f[l2] + ju) << 6) | l2;
+            lh[nreal + rank] = h;
+        }
+        own_lo += (uint32_t)__popcll(__ballot(real && l2 < H));
+        own_hi += (uint32_t)__popcll(__ballot(real && l2 < c.own_end));
+        nreal += (uint32_t)__popcll(m);
+    }
+    if (lane < SEL_PAD) {  // sentinels: out of every scan's reach (the folded coordinates start at 2 w), hashes that never block
+        le[-1 - (int)lane] = 0u;
+        lh[-1 - (int)lane] = ~0ull;
+        le[nreal + lane] = 0xFFFFFFFFu;
+        lh[nreal + lane] = ~0ull;
+    }
+    sel_sync<GLOB>();
+    c.nreal = nreal; c.own_lo = own_lo; c.own_hi = own_hi;
+}
+
+// the window decision (k_resolve's, sketch.hip) on the own candidates, stretch detection, the selected ones out in order
+template <bool GLOB>
+__device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, const uint64_t *lh, const uint32_t *le, const StripRegs &sr,
+                                           const uint32_t f, bool &flag)
+{
+    const uint32_t lane = c.lane, sl = c.sl, H = p.H, w = p.w, wm1 = w - 1u, nreal = c.nreal;
+    const uint32_t lim = 64u * wm1 + 63u;  // e-distance: within w - 1 k-mers
+    const uint32_t *s_c = c.si + 128, *s_k0 = c.si + 192, *s_nk = c.si + 256, *s_f = c.si + 320;
+    // the contig that leaves the slice at its far end (none: ~0) -- every other contig of the slice ends inside it
+    const uint32_t cov_c = (uint32_t)__builtin_amdgcn_readlane((int)sr.cg, 63);
+    const uint32_t cov_kend = (uint32_t)__builtin_amdgcn_readlane((int)(sr.k0 + sr.len), 63);
+    const uint32_t cov_nk = (uint32_t)__builtin_amdgcn_readlane((int)sr.nk, 63);
+    const bool cov_open = cov_c != 0xFFFFFFFFu && cov_kend < cov_nk;
+    // a stretch from k_from on, reported by the candidate (or contig start) in front of it; the next real candidate is entry nx
+    auto report = [&](uint32_t cg, uint32_t k_from, uint32_t nk, uint32_t nx) {
+        bool same = false;
+        uint32_t k2 = 0;
+        if (nx < nreal) {
+            const uint32_t e2 = le[nx], l2 = e2 & 63u;
+            same = s_c[l2] == cg;
+            k2 = s_k0[l2] + ((e2 >> 6) - s_f[l2]);
+        }
+        if (same) {
+            if (k2 - k_from >= w) sel_push_gap(p, cg, k_from, k2 - 1u, sl * p.rk);
+        } else if (nk - k_from >= w) {
+            if (!(cov_open && cg == cov_c)) {
+                sel_push_gap(p, cg, k_from, nk - 1u, sl * p.rk);
+            } else {  // the stretch's end lies behind the slice: the wave walks there (below)
+                const uint32_t at = atomicAdd(&c.misc[0], 1u);
+                if (at < SEL_REQ) c.req[at] = make_uint4(cg, k_from, nk, 0u);
+            }
+        }
+    };
+    // L = k-mers on the left with hash >= this one's (ties: the rightmost of equals wins), R = on the right with hash > this
+    // one's, both capped by the window and the contig: a window of w k-mers in which this k-mer is the rightmost minimum exists
+    // iff L + R + 1 >= w.  Eight neighbours per step, requested at once and decided with selects -- as branches per neighbour
+    // (what the compiler makes of short-circuit conditions) each one cost two dependent LDS round trips.  Distances are taken on
+    // e itself (see above); the right scan runs only for candidates the left scan left room for, as far as that room needs.
+    uint32_t n_sel = 0;
+    for (uint32_t i0 = c.own_lo; i0 < c.own_hi; i0 += 64u) {
+        const bool live = i0 + lane < c.own_hi;
+        const uint32_t i = live ? i0 + lane : i0;
+        const uint32_t e = le[i], l1 = e & 63u;
+        const uint64_t h = lh[i];
+        const uint32_t kx = s_k0[l1] + ((e >> 6) - s_f[l1]), cg = s_c[l1], nk = s_nk[l1];
+        uint32_t dl = 0xFFFFFFFFu;
+        bool ldone = !live;
+        for (uint32_t t = 1; !ldone; t += SEL_PAD) {
+            uint32_t ae[SEL_PAD];
+            uint64_t ah[SEL_PAD];
+#pragma unroll
+            for (uint32_t u = 0; u < SEL_PAD; ++u) {
+                ae[u] = le[(int)i - (int)t - (int)u];
+                ah[u] = lh[(int)i - (int)t - (int)u];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < SEL_PAD; ++u) {
+                const uint32_t d = e - ae[u];
+                const bool stop = d > lim, lt = ah[u] < h;
+                dl = (!ldone & !stop & lt) ? d : dl;
+                ldone = ldone | stop | lt;
+            }
+        }
+        const uint32_t L = dl != 0xFFFFFFFFu ? (dl >> 6) - 1u : min(kx, wm1);
+        const uint32_t R0 = min(nk - 1u - kx, wm1);
+        bool s = live && (L + R0 + 1u >= w);
+        const uint32_t need = 64u * (wm1 - min(L, wm1)) + 63u;  // blocked by a smaller-or-equal hash within this e-distance
+        bool rdone = !(s && L < wm1);
+        for (uint32_t t = 1; !rdone; t += SEL_PAD) {
+            uint32_t be[SEL_PAD];
+            uint64_t bh[SEL_PAD];
+#pragma unroll
+            for (uint32_t u = 0; u < SEL_PAD; ++u) {
+                be[u] = le[i + t + u];
+                bh[u] = lh[i + t + u];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < SEL_PAD; ++u) {
+                const uint32_t d = be[u] - e;
+                const bool stop = d > need, lq = bh[u] <= h;
+                s = (!rdone & !stop & lq) ? false : s;
+                rdone = rdone | stop | lq;
+            }
+        }
+        // a piece of a record that starts with the halo of the shard before it: see k_resolve
+        if (p.ctg_drop && s && kx <= wm1 && L == kx && p.ctg_drop[cg]) s = false;
+        const uint64_t bm = __ballot(s);
+        if (s) {
+            const uint32_t dst = n_sel + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            if (dst < p.rk) p.cs[(size_t)sl * p.rk + dst] = make_uint4((uint32_t)h, (uint32_t)(h >> 32), kx, cg);
+        }
+        n_sel += (uint32_t)__popcll(bm);
+        // candidate-free stretches: the candidate in front of a stretch reports it
+        if (live && le[i + 1u] - e >= 64u * (w + 1u)) report(cg, kx + 1u, nk, i + 1u);
+    }
+    // ... and a contig's first k-mer reports the stretch in front of the contig's first candidate (contigs without any: all of it)
+    if (lane >= H && lane < c.own_end && sr.len && sr.k0 == 0) {
+        uint32_t lo = 0, hi = nreal;  // first real candidate at or behind this strip
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((le[mid] >> 6) < f) lo = mid + 1u; else hi = mid;
+        }
+        report(sr.cg, 0u, sr.nk, lo);
+    }
+    sel_sync<GLOB>();
+    if (lane == 0) {
+        if (n_sel > p.rk) flag = true;
+        count_publish(p.cnt, p.sup, sl, min(n_sel, p.rk));
+    }
+    // ---- stretches that end behind the slice
+    const uint32_t n_req = c.misc[0];
+    if (n_req) {
+        if (n_req > SEL_REQ) flag = true;
+        for (uint32_t r = 0; r < min(n_req, SEL_REQ); ++r) {
+            const uint4 rq = c.req[r];
+            const uint32_t k_end = stretch_end(p, c.ptab, lane, c.s_first + 64, rq.x, rq.z);
+            if (lane == 0 && k_end + 1u - rq.y >= w) sel_push_gap(p, rq.x, rq.y, k_end, sl * p.rk);
+        }
+        sel_sync<GLOB>();
+        if (lane == 0) c.misc[0] = 0;
+    }
+}
 
 }  // namespace
 
-// LDS of a block: half position tables | cand | posl | cnk | pk | runs | rnk | scan scratch; the position-order bitmap lies over cand
-// (it is dead before that is written), which max_cand must be large enough for (the host sizes max_cand)
-static __host__ __device__ inline uint32_t bsr_range_cap(const BsResolveParams &p) { return BS_CHUNK + (p.halo_l + p.halo_r) * BSR_HALO_LANE; }
-size_t bs_resolve_lds(const BsResolveParams &p)
+// NWC = bitmap words a lane keeps of its strip: S / 32 rounded up + 1, as whole 16-byte requests
+template <int NWC>
+__global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
 {
-    const size_t rc = bsr_range_cap(p);
-    return 1024 * 16 + ((size_t)p.max_cand + 2 * BSR_PAD) * 16 + (size_t)p.max_cand * 8 + (rc / 16 + 8) * 4 + BSR_RUNS * (sizeof(Run) + 4) +
-           (256 + 8) * 4;
-}
-
-// (profiling builds: the block stops after phase n but still reports, so that the batch ends the common way)
-#define BSR_STAMP(k)                                                    \
-    if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 16u + (k)] = __builtin_readcyclecounter();
-#define BSR_ABLATE(n)                                                   \
-    if (p.ablate == (n)) {                                              \
-        if (threadIdx.x == 0) {                                         \
-            count_publish(p.cnt, p.sup, blockIdx.x, 0u);                \
-            atomicAdd(&p.cand_spread[(blockIdx.x & 63u) * 32u], 1u);    \
-        }                                                               \
-        return;                                                         \
-    }
-
-__global__ __launch_bounds__(BSR_THREADS, 8) void k_bs_resolve(const BsResolveParams p)
-{
-    extern __shared__ uint4 lds_raw[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t c = p.chunk_lo + blockIdx.x;  // the chunk whose OUT words this block owns
-    // positions: the chunk's OUT words cover strips -1 .. 2046 of the chunk
-    const int64_t core_lo = (int64_t)c * BS_CHUNK - 32, core_hi = core_lo + BS_CHUNK;
-    const int64_t n_pos = (int64_t)p.n_chunks * BS_CHUNK;
-    const int64_t range_lo = std::max<int64_t>(0, core_lo - (int64_t)p.halo_l * BSR_HALO_LANE);
-    const int64_t range_hi = std::min<int64_t>(n_pos, core_hi + (int64_t)p.halo_r * BSR_HALO_LANE);
-    const uint32_t n_strips = (uint32_t)((range_hi - range_lo) >> 5);  // (range_lo, range_hi are multiples of 32)
-    const uint32_t range_cap = bsr_range_cap(p);
-    // ---- LDS carving (see bs_resolve_lds)
-    BsLds L;
-    unsigned char *bp = reinterpret_cast<unsigned char *>(lds_raw);
-    L.btab = reinterpret_cast<uint4 *>(bp); bp += 1024 * 16;
-    L.nat = reinterpret_cast<uint32_t *>(bp);
-    L.cand = reinterpret_cast<uint4 *>(bp) + BSR_PAD; bp += ((size_t)p.max_cand + 2 * BSR_PAD) * 16;
-    L.posl = reinterpret_cast<uint32_t *>(bp); bp += (size_t)p.max_cand * 4;
-    L.cnk = reinterpret_cast<uint32_t *>(bp); bp += (size_t)p.max_cand * 4;
-    L.pk = reinterpret_cast<uint32_t *>(bp); bp += (range_cap / 16 + 8) * 4;
-    L.runs = reinterpret_cast<Run *>(bp); bp += BSR_RUNS * sizeof(Run);
-    L.rnk = reinterpret_cast<uint32_t *>(bp); bp += BSR_RUNS * 4;
-    L.sh = reinterpret_cast<uint32_t *>(bp);
-    __shared__ uint32_t s_nwin, s_flag, s_nraw, s_ncand;
-    __shared__ uint32_t s_klo_ctg, s_klo, s_khi_ctg, s_khi;  // the contig cut by the range's start / end and its k-mer there
-    if (tid == 0) { s_flag = 0; s_nwin = 0; }
-    BSR_STAMP(0)
-    // ---- loads.  Everything the block reads from global memory is requested at once, by role: wave 0 = the chunk's own 64
-    // lanes of OUT words, the first threads of wave 1 = the halo lanes (the last lanes of the chunks before, the first of the
-    // chunks behind), every thread a share of the packed bases and of the position tables, the first BSR_RUNS + 32 a run.
-    const uint32_t rc = (uint32_t)(range_lo / BS_CHUNK);
-    const uint32_t run0_c = p.chunk_run0[rc];
-    uint4 bt0;  // half tables (see init32_half): entry tid = table tid / 256, byte value tid % 256
-    {
-        const uint32_t j = tid >> 8, vb = tid & 255u;
-        const uint4 f = p.init_tab[256u + (j + 4u) * 256u + vb], r = p.init_tab[256u + j * 256u + vb];
-        bt0 = make_uint4(f.x, f.y, r.z, r.w);
-    }
-    const uint64_t w0 = (uint64_t)range_lo >> 4;            // (a multiple of 2: range_lo is a multiple of 32)
-    const uint32_t nw = (uint32_t)((range_hi - range_lo) >> 4) + 3u;
-    const int64_t strip0 = range_lo >> 5;
-    // the filter's words of the range: a plain bitmap, word = strip (32 positions)
-    constexpr uint32_t NWV3 = (3072u + BSR_THREADS - 1u) / BSR_THREADS;  // n_strips <= (65536 + 32 * 1024) / 32
-    uint32_t natw[NWV3];
+    static_assert(NWC % 4 == 0, "the strips' bitmap words are requested four at a time");
+    extern __shared__ uint4 sel_lds[];
+    uint4 *ptab = sel_lds;
+    for (uint32_t i = threadIdx.x; i < 2048u; i += blockDim.x) ptab[i] = p.ptab[i];
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    unsigned char *wb = reinterpret_cast<unsigned char *>(sel_lds + 2048) + (size_t)wib * sel_wave_lds(p.qcap);
+    uint64_t *lh = reinterpret_cast<uint64_t *>(wb);
+    uint32_t *le = reinterpret_cast<uint32_t *>(lh + p.qcap + 2u * SEL_PAD);
+    SelCtx c;
+    c.ptab = ptab;
+    c.si = le + p.qcap + 2u * SEL_PAD;
+    c.req = reinterpret_cast<uint4 *>(c.si + SEL_SI * 64u);
+    c.misc = reinterpret_cast<uint32_t *>(c.req + SEL_REQ);
+    c.lane = lane;
+    c.nreal = c.own_lo = c.own_hi = 0;
+    if (lane == 0) c.misc[0] = 0;
+    __syncthreads();
+    const uint32_t S = p.S, H = p.H, T = p.T, w = p.w;
+    const uint32_t nwords = (S + 31u) / 32u;
+    const uint32_t stride = gridDim.x * nwv;
+    uint32_t own_cands = 0, touch = 0;
+    uint32_t region = 0xFFFFFFFFu;  // this wave's region of global memory, once it has needed one
+    bool flag = false;
+    uint32_t sl = blockIdx.x * nwv + wib;
+    // a slice's strips are looked up one slice ahead: the strip -> run table while the slice before is being set up, the run
+    // itself while that slice's candidates are being decided (nothing there waits for memory)
+    auto first_strip = [&](uint32_t q) { return (int64_t)(p.strip_lo + q * T) - (int64_t)H; };
+    StripRegs sr = sl < p.n_slices ? load_strip(p, first_strip(sl) + lane) : StripRegs{0, 0, 0xFFFFFFFFu, 0, 0};
+    for (; sl < p.n_slices; sl += stride) {
+        const uint32_t s_own0 = p.strip_lo + sl * T;
+        c.sl = sl;
+        c.s_first = first_strip(sl);
+        c.own_end = H + min(T, p.strip_hi - s_own0);  // lanes [H, own_end) hold the slice's own strips
+        const uint32_t sl_n = sl + stride;
+        const int64_t sn64 = first_strip(sl_n) + lane;
+        const bool in_n = sl_n < p.n_slices && sn64 >= 0 && sn64 < (int64_t)p.n_strips_asm;
+        const uint32_t s_n = in_n ? (uint32_t)sn64 : 0u;
+        const uint32_t ri_n = in_n ? p.strip_run[s_n] : 0u;
+        // the strip's words of the bitmap, four per request
+        uint32_t wd[NWC];
+        {
+            const Words4 *bw = reinterpret_cast<const Words4 *>(p.bm + (sr.b >> 5));
 #pragma unroll
-    for (uint32_t u = 0; u < NWV3; ++u) {
-        const uint32_t g = tid + u * BSR_THREADS;
-        natw[u] = g < n_strips ? p.out[strip0 + g] : 0u;
-    }
-    // the packed words of the range, four per load
-    constexpr uint32_t PKV = (1536u + BSR_THREADS - 1u) / BSR_THREADS;
-    uint4 pkv[PKV];
+            for (uint32_t u = 0; u < (uint32_t)NWC / 4u; ++u) {
+                Words4 v{0u, 0u, 0u, 0u};
+                if (sr.len && 4u * u <= nwords) v = bw[u];
+                wd[4 * u] = v.w0; wd[4 * u + 1] = v.w1; wd[4 * u + 2] = v.w2; wd[4 * u + 3] = v.w3;
+            }
+        }
+        // ... and the first and last word of its packed bases: a strip is shorter than a cache line, so these requests bring every
+        // line the slice's candidates will be hashed from on their way while the bitmap words travel (the candidates' own requests
+        // then meet them in L2; without this every round of 64 candidates waited for HBM).  `touch` keeps the loads alive.
+        if (sr.len) touch ^= p.packed[sr.b >> 4] ^ p.packed[(sr.b + sr.len + 31u) >> 4];
+        // fold: k-mers of one contig at their distances, a contig border = w more; the first strip starts at 2 w
+        const uint32_t len_p = (uint32_t)__shfl_up((int)sr.len, 1, 64), cg_p = (uint32_t)__shfl_up((int)sr.cg, 1, 64);
+        const uint32_t f = wave_inclusive_u32(lane ? len_p + (sr.cg != cg_p ? w : 0u) : 2u * w, lane);
+        c.si[lane] = (uint32_t)sr.b;
+        c.si[64u + lane] = (uint32_t)(sr.b >> 32);
+        c.si[128u + lane] = sr.cg;
+        c.si[192u + lane] = sr.k0;
+        c.si[256u + lane] = sr.nk;
+        c.si[320u + lane] = f;
+        uint32_t cnt = 0;
+        {
+            const uint32_t sh = (uint32_t)sr.b & 31u;
 #pragma unroll
-    for (uint32_t u = 0; u < PKV; ++u) {
-        const uint32_t i = (tid + u * BSR_THREADS) * 4u;
-        pkv[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (i < nw) {
-            const uint64_t wq = w0 + i;
-            if (wq + 4 <= p.n_words) {
-                const uint2 lo = *reinterpret_cast<const uint2 *>(p.packed + wq), hi = *reinterpret_cast<const uint2 *>(p.packed + wq + 2);
-                pkv[u] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            for (uint32_t j = 0; j + 1 < (uint32_t)NWC; ++j)
+                if (j < nwords) cnt += (uint32_t)__popc(sel_bits(wd[j], wd[j + 1], sh, sr.len, j));
+        }
+        const uint32_t incl = wave_inclusive_u32(cnt, lane);
+        const uint32_t tot = (uint32_t)__shfl((int)incl, 63, 64);
+        StripRegs sr_n;
+        if (p.ablate == 1) {  // (profiling)
+            if (lane == 0) count_publish(p.cnt, p.sup, sl, 0u);
+            own_cands += tot != 0;
+            sr_n = strip_of(p, in_n, s_n, ri_n);
+        } else if (tot <= p.qcap) {
+            sel_collect<NWC, false>(p, c, lh + SEL_PAD, le + SEL_PAD, p.qcap, sr, wd, incl - cnt, tot);
+            sr_n = strip_of(p, in_n, s_n, ri_n);
+            if (p.ablate == 2 || p.ablate == 3) {
+                if (lane == 0) count_publish(p.cnt, p.sup, sl, 0u);
+                own_cands += 1u;
             } else {
-                if (wq < p.n_words) pkv[u].x = p.packed[wq];
-                if (wq + 1 < p.n_words) pkv[u].y = p.packed[wq + 1];
-                if (wq + 2 < p.n_words) pkv[u].z = p.packed[wq + 2];
+                sel_decide<false>(p, c, lh + SEL_PAD, le + SEL_PAD, sr, f, flag);
             }
-        }
-    }
-    // run window: the runs that overlap the range, of this batch only; every thread looks at one run
-    uint32_t r_first = std::max(run0_c, p.run_lo);
-    Run my_run{};
-    const bool my_run_on = tid < BSR_RUNS + 32u && r_first + tid < p.run_hi;
-    if (my_run_on) my_run = p.runs[r_first + tid];
-    const uint32_t my_nk = my_run_on ? p.ctg_nk[my_run.contig] : 0u;
-    uint64_t beyond_off = ~0ull;  // does the run behind the ones looked at still start inside the range?
-    if (tid == 0 && r_first + BSR_RUNS + 32u < p.run_hi) beyond_off = p.runs[r_first + BSR_RUNS + 32u].base_off;
-    BSR_STAMP(1)
-    // ---- into LDS
-    L.btab[tid] = bt0;
-#pragma unroll
-    for (uint32_t u = 0; u < PKV; ++u) {
-        const uint32_t i = (tid + u * BSR_THREADS) * 4u;
-        if (i < nw) {
-            L.pk[i] = pkv[u].x; L.pk[i + 1] = pkv[u].y; L.pk[i + 2] = pkv[u].z; L.pk[i + 3] = pkv[u].w;
-        }
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < NWV3; ++u) {
-        const uint32_t g = tid + u * BSR_THREADS;
-        if (g < n_strips) L.nat[g] = natw[u];
-    }
-    {
-        // (chunk_run0 is exact for a chunk's first position; the range starts behind it: the runs that end before it are
-        // skipped here)
-        bool in = false;
-        const Run &run = my_run;
-        if (my_run_on) in = (int64_t)(run.base_off + run.n_kmers) > range_lo && (int64_t)run.base_off < range_hi;
-        // runs are sorted by position: the overlapping ones are consecutive
-        const uint64_t mb = __ballot(in);
-        constexpr uint32_t NWV = BSR_THREADS / 64u;
-        __shared__ uint32_t s_cnt[NWV], s_first[NWV];
-        if (lane == 0) {
-            s_cnt[tid >> 6] = (uint32_t)__popcll(mb);
-            s_first[tid >> 6] = mb ? (uint32_t)__builtin_ctzll(mb) + (tid & ~63u) : 0xFFFFFFFFu;
-        }
-        __syncthreads();
-        uint32_t first = 0xFFFFFFFFu, total = 0;
-#pragma unroll
-        for (uint32_t u = 0; u < 3u && u < NWV; ++u) {  // (the runs looked at sit in the first BSR_RUNS + 32 threads)
-            first = std::min(first, s_first[u]);
-            total += s_cnt[u];
-        }
-        if (in) {
-            const uint32_t at = tid - first;
-            if (at < BSR_RUNS) {
-                L.runs[at] = run;
-                L.rnk[at] = my_nk;
-            }
-        }
-        if (tid == 0) {
-            s_nwin = std::min(total, BSR_RUNS);
-            // more runs than one pass of the block sees (or than the window holds): the general route takes the batch
-            if (total > BSR_RUNS || (int64_t)std::min<uint64_t>(beyond_off, (uint64_t)INT64_MAX) < range_hi) s_flag = 1;
-        }
-    }
-    __syncthreads();
-    BSR_STAMP(2)
-    BSR_ABLATE(1)
-    const uint32_t n_win = s_nwin;
-    BSR_STAMP(3)
-    BSR_ABLATE(2)
-    // ---- positions of the set bits, in order: thread t takes the strips [4 t, 4 t + 4)
-    {
-        uint32_t wd[4], cnt = 0;
-#pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-            const uint32_t g = 4u * tid + u;
-            wd[u] = g < n_strips ? L.nat[g] : 0u;
-            cnt += (uint32_t)__popc(wd[u]);
-        }
-        uint32_t total;
-        uint32_t at = bsr_scan(cnt, L.sh, total);
-        if (tid == 0) {
-            s_nraw = std::min(total, p.max_cand);
-            if (total > p.max_cand) s_flag = 1;
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-            uint32_t word = wd[u];
-            while (word) {
-                const uint32_t t = (uint32_t)__builtin_ctz(word);
-                word &= word - 1u;
-                if (at < p.max_cand) L.posl[at] = (4u * tid + u) * 32u + t;
-                ++at;
-            }
-        }
-    }
-    __syncthreads();
-    BSR_STAMP(4)
-    BSR_ABLATE(3)
-    const uint32_t n_raw = s_nraw;
-    // ---- valid ones with their exact hashes; thread t takes the raw candidates [t * ipt, (t + 1) * ipt)
-    constexpr uint32_t IPT_MAX = 3072u / BSR_THREADS;  // max_cand <= 3072
-    const uint32_t ipt = (n_raw + BSR_THREADS - 1u) / BSR_THREADS;
-    uint64_t vh[IPT_MAX];
-    uint32_t vk[IPT_MAX], vc[IPT_MAX], vp[IPT_MAX], vn[IPT_MAX];
-    uint32_t keep = 0;
-#pragma unroll
-    for (uint32_t u = 0; u < IPT_MAX; ++u) {
-        const uint32_t i = tid * ipt + u;
-        vh[u] = 0; vk[u] = 0; vc[u] = 0; vp[u] = 0; vn[u] = 0;
-        if (u < ipt && i < n_raw) {
-            const uint32_t rel = L.posl[i];
-            vp[u] = rel;
-            const uint64_t pos = (uint64_t)range_lo + rel;
-            // the run holding the position: last run of the window with base_off <= pos
-            uint32_t lo = 0, hi = n_win;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (L.runs[mid].base_off <= pos) lo = mid + 1; else hi = mid;
-            }
-            if (lo > 0) {
-                const Run &run = L.runs[lo - 1];
-                if (pos - run.base_off < run.n_kmers) {
-                    const uint64_t h = hash32_lds(L.pk, rel, L.btab);
-                    if (h < p.tau) {
-                        vh[u] = h;
-                        vk[u] = run.kidx0 + (uint32_t)(pos - run.base_off);
-                        vc[u] = run.contig;
-                        vn[u] = L.rnk[lo - 1];
-                        keep |= 1u << u;
-                    }
-                }
-            }
-        }
-    }
-    {
-        uint32_t total;
-        uint32_t at = bsr_scan((uint32_t)__popc(keep), L.sh, total);
-        if (tid == 0) s_ncand = total;
-        // (behind the scan's barriers the bitmap and the raw positions are dead: cand / posl / cnk may be written)
-#pragma unroll
-        for (uint32_t u = 0; u < IPT_MAX; ++u)
-            if ((keep >> u) & 1u) {
-                L.cand[at] = make_uint4(vk[u], vc[u], (uint32_t)vh[u], (uint32_t)(vh[u] >> 32));
-                L.posl[at] = vp[u];  // (position relative to the range, at the candidate's new index)
-                L.cnk[at] = vn[u];
-                ++at;
-            }
-    }
-    // the k-mer index at which the range cuts a contig (first / last run of the window)
-    if (tid == 0) {
-        s_klo_ctg = 0xFFFFFFFFu; s_klo = 0; s_khi_ctg = 0xFFFFFFFFu; s_khi = 0;
-        if (n_win) {
-            const Run &a = L.runs[0];
-            const uint32_t kl = (int64_t)a.base_off >= range_lo ? a.kidx0 : a.kidx0 + (uint32_t)(range_lo - (int64_t)a.base_off);
-            if (kl > 0) { s_klo_ctg = a.contig; s_klo = kl; }
-            const Run &b = L.runs[n_win - 1];
-            const uint32_t kh = b.kidx0 + (uint32_t)std::min<int64_t>(b.n_kmers, range_hi - (int64_t)b.base_off) - 1u;
-            if (kh + 1u < L.rnk[n_win - 1]) { s_khi_ctg = b.contig; s_khi = kh; }
-        }
-    }
-    __syncthreads();
-    BSR_STAMP(5)
-    BSR_ABLATE(4)
-    const uint32_t n_c = s_ncand;
-    if (tid < BSR_PAD) {  // sentinels: a contig no candidate has
-        L.cand[-1 - (int)tid] = make_uint4(0u, 0xFFFFFFFFu, 0u, 0u);
-        L.cand[n_c + tid] = make_uint4(0u, 0xFFFFFFFFu, 0u, 0u);
-    }
-    __syncthreads();
-    const uint32_t w = p.w, wm1 = w - 1u;
-    // (chunk 0: positions -32..-1 do not exist)
-    const uint32_t core_rel_lo = (uint32_t)(std::max(core_lo, range_lo) - range_lo);
-    const uint32_t core_rel_hi = (uint32_t)(std::min(core_hi, range_hi) - range_lo);
-    // ---- the window decision on the block's own candidates: k_resolve's scans (sketch.hip), everything in LDS.  Pass 1: every
-    // candidate looks at its four neighbours on either side (one ds_read_b128 each), which decides four in five; pass 2: the
-    // undecided ones, laid end to end, walk on four neighbours at a time with full waves.  The flags go to LDS (the raw
-    // position list is dead: its first bytes are reused); the selected ones then leave in order.
-    uint8_t *selb = reinterpret_cast<uint8_t *>(L.pk);            // [max_cand] 0 / 1 (the packed words are dead behind the hashes)
-    uint32_t *undl = reinterpret_cast<uint32_t *>(L.pk) + (p.max_cand / 4u + 4u);  // undecided candidates: index | state
-    uint32_t n_own = 0;
-    auto scan_left = [&](uint32_t i, uint32_t kx, uint32_t cg, uint64_t h, uint32_t t0, uint32_t &Ld, bool &done, bool one) {
-        for (uint32_t t = t0; !done; t += 4) {
-#pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
-                const uint4 e = L.cand[(int)i - (int)t - (int)u];
-                const uint32_t d = kx - e.x;
-                const bool stop = e.y != cg || d > wm1;
-                const bool hit = !stop && ((((uint64_t)e.w << 32) | e.z) < h);
-                Ld = (!done && hit) ? d - 1u : Ld;
-                done = done || stop || hit;
-            }
-            if (one) break;
-        }
-    };
-    auto scan_right = [&](uint32_t i, uint32_t kx, uint32_t cg, uint64_t h, uint32_t need, uint32_t t0, bool &sel, bool &done, bool one) {
-        for (uint32_t t = t0; !done; t += 4) {
-#pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {
-                const uint4 e = L.cand[i + t + u];
-                const uint32_t d = e.x - kx;
-                const bool stop = e.y != cg || d > need;
-                const bool hit = !stop && ((((uint64_t)e.w << 32) | e.z) <= h);
-                sel = (!done && hit) ? false : sel;
-                done = done || stop || hit;
-            }
-            if (one) break;
-        }
-    };
-    for (uint32_t i0 = 0; i0 < n_c; i0 += BSR_THREADS) {  // (one round unless max_cand > 1024)
-        const uint32_t i = i0 + tid;
-        bool undecided = false;
-        uint32_t st_word = 0;
-        if (i < n_c) {
-            bool sel = false;
-            const uint32_t rel = L.posl[i];
-            if (rel >= core_rel_lo && rel < core_rel_hi) {  // (a halo candidate: its own block decides it)
-                ++n_own;
-                const uint4 me = L.cand[i];
-                const uint64_t h = ((uint64_t)me.w << 32) | me.z;
-                const uint32_t kx = me.x, cg = me.y, nk = L.cnk[i];
-                // is everything this candidate can need inside the range?
-                const uint32_t need_lo = kx > wm1 ? kx - wm1 : 0u, need_hi = std::min(nk - 1u, kx + wm1);
-                if ((cg == s_klo_ctg && need_lo < s_klo) || (cg == s_khi_ctg && need_hi > s_khi)) {
-                    s_flag = 1;
-                } else {
-                    uint32_t Ld = std::min(kx, wm1);
-                    bool ldone = false;
-                    scan_left(i, kx, cg, h, 1u, Ld, ldone, true);
-                    if (!ldone) {
-                        undecided = true;  // (left scan unfinished)
-                    } else {
-                        const uint32_t Rd = std::min(nk - 1u - kx, wm1);
-                        sel = Ld + Rd + 1u >= w;
-                        const uint32_t need = wm1 - std::min(Ld, wm1);
-                        bool rdone = !(sel && need > 0);
-                        scan_right(i, kx, cg, h, need, 1u, sel, rdone, true);
-                        if (!rdone) {
-                            undecided = true;
-                            st_word = 0x80000000u | (Ld << 16);  // (left part known: Ld < 2^15 as w <= 2048)
-                        } else {
-                            if (p.ctg_drop && sel && kx <= wm1 && Ld == kx && p.ctg_drop[cg]) sel = false;
-                            if (h == 0xFFFFFFFFFFFFFFFFull) sel = false;
-                        }
-                    }
-                    // candidate-free stretches behind this candidate (the candidate in front of a stretch reports it)
-                    const uint4 nxt = L.cand[i + 1u];
-                    if (nxt.y == cg) {
-                        if (nxt.x - kx - 1u >= w) {
-                            const uint32_t idx = atomicAdd(&p.ctrl[1], 1u);
-                            if (idx < p.gap_cap) p.gaps[idx] = make_uint4(cg, kx + 1u, nxt.x - 1u, blockIdx.x * p.rk);
-                        }
-                    } else if (nk - 1u - kx >= w) {
-                        // no further candidate of the contig in the range: the stretch runs to the contig's end -- unless the
-                        // contig goes on behind the range, where its next candidate hides: then the stretch is longer than the
-                        // device route takes
-                        if (cg == s_khi_ctg) s_flag = 1;
-                        else {
-                            const uint32_t idx = atomicAdd(&p.ctrl[1], 1u);
-                            if (idx < p.gap_cap) p.gaps[idx] = make_uint4(cg, kx + 1u, nk - 1u, blockIdx.x * p.rk);
-                        }
-                    }
-                }
-            }
-            selb[i] = sel ? 1 : 0;
-        }
-        uint32_t n_und;
-        const uint32_t ua = bsr_scan_flag(undecided, L.sh, n_und);
-        if (undecided) undl[ua] = i | st_word;  // (i < 2^15)
-        __syncthreads();
-        for (uint32_t q = tid; q < n_und; q += BSR_THREADS) {  // pass 2
-            const uint32_t wd = undl[q], ii = wd & 0x7FFFu;
-            const uint4 me = L.cand[ii];
-            const uint64_t h = ((uint64_t)me.w << 32) | me.z;
-            const uint32_t kx = me.x, cg = me.y, nk = L.cnk[ii];
-            uint32_t Ld;
-            if (wd & 0x80000000u) {
-                Ld = (wd >> 16) & 0x7FFFu;
-            } else {
-                Ld = std::min(kx, wm1);
-                bool ldone = false;
-                scan_left(ii, kx, cg, h, 5u, Ld, ldone, false);
-            }
-            const uint32_t Rd = std::min(nk - 1u - kx, wm1);
-            bool sel = Ld + Rd + 1u >= w;
-            const uint32_t need = wm1 - std::min(Ld, wm1);
-            bool rdone = !(sel && need > 0);
-            scan_right(ii, kx, cg, h, need, (wd & 0x80000000u) ? 5u : 1u, sel, rdone, false);
-            if (p.ctg_drop && sel && kx <= wm1 && Ld == kx && p.ctg_drop[cg]) sel = false;
-            if (h == 0xFFFFFFFFFFFFFFFFull) sel = false;
-            selb[ii] = sel ? 1 : 0;
-        }
-        __syncthreads();
-    }
-    // the selected ones, in order
-    uint32_t out_at = 0;
-    for (uint32_t i0 = 0; i0 < n_c; i0 += BSR_THREADS) {
-        const uint32_t i = i0 + tid;
-        const bool sel = i < n_c && selb[i];
-        uint32_t tot;
-        const uint32_t at = out_at + bsr_scan_flag(sel, L.sh, tot);
-        out_at += tot;
-        if (sel && at < p.rk) {
-            const uint4 me = L.cand[i];
-            const size_t dst = (size_t)blockIdx.x * p.rk + at;
-            p.cs_h[dst] = ((uint64_t)me.w << 32) | me.z;
-            p.cs_k[dst] = me.x;
-            p.cs_c[dst] = me.y;
-        }
-    }
-    BSR_STAMP(6)
-    BSR_ABLATE(5)
-    // ---- stretches in front of a contig's first candidate, and contigs without any: reported by the block whose own
-    // positions hold the contig's first k-mer
-    for (uint32_t r = tid; r < n_win; r += BSR_THREADS) {
-        const Run &run = L.runs[r];
-        if (run.kidx0 != 0) continue;
-        const int64_t rel64 = (int64_t)run.base_off - range_lo;
-        if (rel64 < (int64_t)core_rel_lo || rel64 >= (int64_t)core_rel_hi) continue;
-        const uint32_t cg = run.contig, nk = L.rnk[r];
-        // first candidate at or behind the contig's first position
-        uint32_t lo = 0, hi = n_c;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((int64_t)L.posl[mid] < rel64) lo = mid + 1; else hi = mid;
-        }
-        uint32_t khi = 0;
-        bool push = false;
-        const uint4 e = L.cand[lo];  // (index n_c: a sentinel)
-        if (e.y == cg) {
-            if (e.x >= w) { push = true; khi = e.x - 1u; }
-        } else if (cg == s_khi_ctg) {
-            s_flag = 1;  // the contig leaves the range without a candidate
         } else {
-            push = true; khi = nk - 1u;  // no candidate at all (eligible: nk >= w)
+            if (region == 0xFFFFFFFFu) {
+                uint32_t r = 0;
+                if (lane == 0) r = atomicAdd(p.ovf_next, 1u);
+                region = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+            }
+            sr_n = strip_of(p, in_n, s_n, ri_n);
+            if (region < p.n_ovf) {
+                const size_t o = (size_t)region * (p.ovf_cap + 2u * SEL_PAD) + SEL_PAD;
+                sel_collect<NWC, true>(p, c, p.ovf_h + o, p.ovf_e + o, p.ovf_cap, sr, wd, incl - cnt, tot);
+                sel_decide<true>(p, c, p.ovf_h + o, p.ovf_e + o, sr, f, flag);
+            } else {  // no region left: the host redoes the batch
+                flag = true;
+                c.own_lo = c.own_hi = 0;
+                if (lane == 0) count_publish(p.cnt, p.sup, sl, 0u);
+            }
         }
-        if (push) {
-            const uint32_t idx = atomicAdd(&p.ctrl[1], 1u);
-            if (idx < p.gap_cap) p.gaps[idx] = make_uint4(cg, 0u, khi, blockIdx.x * p.rk);
-        }
+        own_cands += c.own_hi - c.own_lo;
+        __builtin_amdgcn_wave_barrier();  // the next slice reuses the wave's LDS
+        sr = sr_n;
     }
-    BSR_STAMP(7)
-    // ---- counts: selected (two-level, for k_emit), own candidates (statistics: 64 counters on their own lines, summed by
-    // k_emit's reporting tile -- one counter for all blocks cost 70 us per launch in same-address atomics)
-    {
-        const uint32_t own_w = wave_sum_u32(n_own);
-        __shared__ uint32_t s_own[BSR_THREADS / 64];
-        if (lane == 0) s_own[tid >> 6] = own_w;
-        __syncthreads();
-        if (tid == 0) {
-            if (out_at > p.rk) s_flag = 1;
-            count_publish(p.cnt, p.sup, blockIdx.x, std::min(out_at, p.rk));
-            uint32_t own = 0;
-            for (uint32_t u = 0; u < BSR_THREADS / 64; ++u) own += s_own[u];
-            if (own) atomicAdd(&p.cand_spread[(blockIdx.x & 63u) * 32u], own);
-            if (s_flag) p.ctrl[6] = 1;
-        }
+    const uint32_t own_w = own_cands;  // (wave-uniform)
+    if (touch == 0x9E3779B9u && p.w == 0) p.ctrl[15] = touch;  // (never: the words requested ahead are not used for anything)
+    if (lane == 0) {
+        if (own_w) atomicAdd(&p.cand_spread[((blockIdx.x * nwv + wib) & 63u) * 32u], own_w);
+        if (flag) p.ctrl[6] = 1;
     }
-    BSR_STAMP(8)
 }
 
-void launch_bs_resolve(const BsResolveParams &p, uint32_t n_blocks, hipStream_t st)
+size_t bs_select_lds(uint32_t qcap, uint32_t waves) { return (size_t)2048 * 16 + (size_t)waves * sel_wave_lds(qcap); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_bs_select: geometry + launch
+// ---------------------------------------------------------------------------------------------------------------
+// Smallest H such that every H consecutive strips of one contig that do not hold the contig's last strip hold >= w k-mers: then
+// the H strips on either side of a slice's own strips give every own candidate w k-mers of its contig -- or the contig's end.
+// Only a run's last strip is shorter than S, so contigs of one run need H = ceil(w / S) and nothing else; the others are walked
+// strip by strip around their run ends (the inside of a long run is skipped).
+uint32_t bs_select_halo(const Assembly *a, uint32_t S, uint32_t w)
 {
-    hipLaunchKernelGGL(k_bs_resolve, dim3(n_blocks), dim3(BSR_THREADS), bs_resolve_lds(p), st, p);
+    const uint32_t H0 = (w + S - 1) / S;
+    if (H0 > SEL_MAX_H) return 0;
+    uint32_t H = H0;
+    std::vector<uint32_t> lens;
+    for (size_t c = 0; c + 1 < a->ctg_run0.size(); ++c) {
+        const uint32_t r0 = a->ctg_run0[c], r1 = a->ctg_run0[c + 1];
+        if (r1 - r0 < 2) continue;
+        // the contig's strips, the inside of long runs cut down to 2 * SEL_MAX_H full strips (windows there hold H S >= w k-mers)
+        lens.clear();
+        for (uint32_t r = r0; r < r1; ++r) {
+            const uint32_t nk = a->runs[r].n_kmers, n_full = nk / S, last = nk - n_full * S;
+            for (uint32_t q = 0; q < std::min<uint32_t>(n_full, 2 * SEL_MAX_H); ++q) lens.push_back(S);
+            if (last) lens.push_back(last);
+        }
+        if (lens.size() < 2) continue;
+        lens.pop_back();  // (the contig's last strip: a window holding it reaches the contig's end)
+        for (;;) {
+            bool ok = true;
+            uint64_t sum = 0;
+            for (size_t q = 0; q < lens.size(); ++q) {
+                sum += lens[q];
+                if (q >= H) sum -= lens[q - H];
+                if (q + 1 >= H && sum < w) {
+                    ok = false;
+                    break;
+                }
+            }
+            if (ok) break;
+            if (++H > SEL_MAX_H) return 0;
+        }
+    }
+    return H;
+}
+
+BsSelGeom bs_select_geom(uint32_t S, uint32_t H, uint32_t w, double frac, uint32_t n_strips, uint32_t qcap_force)
+{
+    BsSelGeom g{};
+    g.ok = false;
+    if (H == 0 || 2 * H >= 64 || S > 1024 || n_strips == 0) return g;
+    g.H = H;
+    g.T = 64 - 2 * H;
+    g.n_slices = (n_strips + g.T - 1) / g.T;
+    // raw candidates of a slice: what passes the ring test (the top-bits sum lets ~2 % more through than tau)
+    const double raw = 64.0 * S * frac * 1.03;
+    g.qcap = ((uint32_t)(raw * 1.3 + 6.0 * std::sqrt(raw) + 32.0) + 63u) / 64u * 64u;
+    if (qcap_force) g.qcap = std::max<uint32_t>(64u, (qcap_force + 63u) / 64u * 64u);  // (test knob: slices that outgrow their queue)
+    g.qcap = std::min<uint32_t>(g.qcap, 64u * S);
+    const double sel = (double)g.T * S * 2.0 / (double)(w + 1);
+    g.rk = ((uint32_t)(sel * 1.3 + 6.0 * std::sqrt(sel) + 24.0) + 31u) / 32u * 32u;
+    // as many waves per block as fit beside the 32 KB of position tables in the CU's 160 KB of LDS (one block per CU)
+    const size_t budget = 160 * 1024 - 2048 * 16 - 1024;
+    g.waves = (uint32_t)std::min<size_t>(16, budget / sel_wave_lds(g.qcap));
+    g.ovf_cap = 64u * S;
+    g.n_ovf = 1024;
+    g.lds = bs_select_lds(g.qcap, g.waves);
+    g.ok = g.waves >= 4 && (uint64_t)g.n_slices * g.rk < (1ull << 31);
+    return g;
+}
+
+int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hipStream_t st)
+{
+    const uint32_t nwc = (p.S + 31u) / 32u + 1u;
+    const uint32_t blocks = std::min<uint32_t>((g.n_slices + g.waves - 1) / g.waves, 256u);
+    const dim3 grid(blocks), block(g.waves * 64u);
+    static bool attr_set = false;
+    if (!attr_set) {  // (more than 64 KB of dynamic LDS must be asked for)
+        MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<36>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    if (nwc <= 12) hipLaunchKernelGGL(k_bs_select<12>, grid, block, g.lds, st, p);
+    else if (nwc <= 20) hipLaunchKernelGGL(k_bs_select<20>, grid, block, g.lds, st, p);
+    else hipLaunchKernelGGL(k_bs_select<36>, grid, block, g.lds, st, p);
+    MXG_HIP(h, hipGetLastError());
+    return MXG_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -586,39 +579,35 @@ int bs_prepare(mxg_handle *h, Assembly *a)
     a->bs_chunks = n_chunks;
     // (+ 256 bytes behind it: the batch kernels request the words of a whole strip, up to 1024 positions + 2 words, before masking)
     MXG_HIP(h, a->d_bs_out.ensure(((size_t)n_chunks * BS_OUT_WORDS + BS_OUT_PAD) * 4 + 256));
-    // padded copies of the first and of the last chunk's words (the filter reads whole chunks and, per lane, the two words in
-    // front of its 64: zeros in front of the assembly, zeros = base A behind it): [head copy | tail copy], BS_EDGE_WORDS each
+    // padded copies of the first and of the last chunk's words (k_bs_edges fills them in front of every filter launch)
     MXG_HIP(h, a->d_bs_tail.ensure((size_t)2 * BS_EDGE_WORDS * 4));
-    MXG_HIP(h, hipMemsetAsync(a->d_bs_tail.p, 0, (size_t)2 * BS_EDGE_WORDS * 4, h->stream));
-    {
-        uint32_t *edge = a->d_bs_tail.as<uint32_t>();
-        const uint64_t n_head = std::min<uint64_t>(a->packed_words, BS_CHUNK_WORDS);
-        MXG_HIP(h, hipMemcpyAsync(edge + 2, a->d_packed, (size_t)n_head * 4, hipMemcpyDeviceToDevice, h->stream));
-        const uint64_t tail_lo = (uint64_t)(n_chunks - 1) * BS_CHUNK_WORDS;
-        if (n_chunks > 1) {  // (one chunk: it is the first one, and the head copy is padded behind as well)
-            const uint64_t from = tail_lo - 2;  // with the two words in front
-            if (a->packed_words > from)
-                MXG_HIP(h, hipMemcpyAsync(edge + BS_EDGE_WORDS, a->d_packed + from, (size_t)std::min<uint64_t>(a->packed_words - from, BS_CHUNK_WORDS + 2) * 4,
-                                          hipMemcpyDeviceToDevice, h->stream));
-        }
-    }
-    // chunk -> first run whose k-mers end behind the chunk's first position (runs are sorted)
-    std::vector<uint32_t> run0((size_t)n_chunks + 1);
-    size_t r = 0;
-    for (uint32_t c = 0; c <= n_chunks; ++c) {
-        const uint64_t p0 = (uint64_t)c * BS_CHUNK;
-        while (r < a->runs.size() && a->runs[r].base_off + a->runs[r].n_kmers <= p0) ++r;
-        run0[c] = (uint32_t)r;
-    }
-    MXG_HIP(h, a->d_bs_run0.ensure(run0.size() * 4));
-    MXG_HIP(h, hipMemcpyAsync(a->d_bs_run0.p, run0.data(), run0.size() * 4, hipMemcpyHostToDevice, h->stream));
     MXG_HIP(h, hipStreamSynchronize(h->stream));
     a->bs_ready = true;
     return MXG_OK;
 }
 
+// The filter reads whole chunks and, per lane, the two words in front of its 64: the assembly's first and last chunk are read from
+// padded copies [head copy | tail copy], BS_EDGE_WORDS each -- zeros in front of the assembly, zeros (= base A) behind it.  Made
+// anew for every sketch: a borrowed packed buffer (mxg_add_assembly_packed_device) may have been refilled since the last one.
+__global__ __launch_bounds__(256) void k_bs_edges(const uint32_t *__restrict__ packed, uint64_t packed_words, uint32_t n_chunks,
+                                                  uint32_t *__restrict__ edge)
+{
+    const uint64_t n_head = min(packed_words, (uint64_t)BS_CHUNK_WORDS);
+    const uint64_t from = (uint64_t)(n_chunks - 1) * BS_CHUNK_WORDS - 2;  // (the tail copy: with the two words in front; n_chunks > 1)
+    for (uint32_t i = threadIdx.x; i < BS_EDGE_WORDS; i += 256u) {
+        uint32_t v = 0;
+        if (blockIdx.x == 0) {
+            if (i >= 2u && i - 2u < n_head) v = packed[i - 2u];
+        } else if (n_chunks > 1 && i < BS_CHUNK_WORDS + 2u && from + i < packed_words) {
+            v = packed[from + i];
+        }
+        edge[blockIdx.x * BS_EDGE_WORDS + i] = v;
+    }
+}
+
 int bs_hash(mxg_handle *h, Assembly *a, uint32_t tau_hi, hipStream_t st)
 {
+    hipLaunchKernelGGL(k_bs_edges, dim3(2), dim3(256), 0, st, a->d_packed, a->packed_words, a->bs_chunks, a->d_bs_tail.as<uint32_t>());
     // tau = T * 2^33 with T = tau_hi / 2 on the top ring; the filter compares the top HASH_BS_PLANES bits of F + R with
     // tt = (T - 1) >> (31 - planes) (gen/bs_gen.py: reference_bits)
     const uint32_t T = tau_hi >> 1;

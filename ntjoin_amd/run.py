@@ -27,7 +27,7 @@ def parse_arguments(argv=None):
     parser.add_argument("-G", required=False, default=0, type=int, help="downstream only: largest gap allowed, 0 = unlimited")
     # flags of the stages behind the graph build: accepted so that the reference's command line parses, otherwise unused here
     parser.add_argument("--mkt", action="store_true")
-    parser.add_argument("-m", type=int, default=50, required=False)
+    parser.add_argument("-m", type=int, default=90, required=False)
     parser.add_argument("-t", type=int, default=1)
     parser.add_argument("--agp", action="store_true")
     parser.add_argument("--no_cut", action="store_true")

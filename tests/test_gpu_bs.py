@@ -1,10 +1,11 @@
-"""GPU tests of the k = 32 route of the sketch stage (csrc/bs_kernels.h, sketch_bs.hip, k_bs_count / k_bs_reorder_w):
+"""GPU tests of the k = 32 route of the sketch stage (csrc/bs_kernels.h, sketch_bs.hip: k_bs_select; k_bs_count / k_bs_reorder_w):
 
   * the generated filter kernel against the direct ring formula on random bases (standalone binary built with the library:
     layout kernel + filter over whole chunks, ragged tail, first / middle / last chunks compared word for word);
-  * the three routes of the library -- bit-sliced filter + batch kernels (default), bit-sliced filter + the fused resolve kernel
-    (MXG_BS_FUSED=1), the rolling-hash kernel (MXG_BS=0) -- against the CPU oracle on the same records, bit for bit, with the
-    statistics saying which route ran;
+  * the three routes of the library -- bit-sliced filter + the slice kernel k_bs_select (default), bit-sliced filter + the batch
+    kernels count -> reorder -> resolve (MXG_BS_SELECT=0), the rolling-hash kernel (MXG_BS=0) -- against the CPU oracle on the
+    same records, bit for bit, with the statistics saying which route ran;
+  * slices that outgrow their LDS queue (MXG_SEL_QCAP) work in global memory, and a batch without a region left is redone;
   * inputs the filter does not take (k != 32, the min(fwd, rev) variant) still go the old way.
 """
 import os
@@ -18,7 +19,7 @@ from tests.test_gpu_scale_paths import _check, _records
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUTE_KNOBS = ("MXG_BS", "MXG_BS_FUSED", "MXG_SPARSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S", "MXG_DEV_GAPS")
+ROUTE_KNOBS = ("MXG_BS", "MXG_BS_SELECT", "MXG_SEL_QCAP", "MXG_SPARSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S", "MXG_DEV_GAPS")
 
 
 @pytest.fixture
@@ -52,13 +53,56 @@ def test_three_routes_agree_with_the_oracle(oracle, env, seed, w):
     st = _check(oracle, recs, 32, w)
     assert st["bs_filter_bases"] == _bases(recs), "the k = 32 route did not run"
     assert st["candidates"] > 0
-    env["MXG_BS_FUSED"] = "1"
+    env["MXG_BS_SELECT"] = "0"
     st = _check(oracle, recs, 32, w)
     assert st["bs_filter_bases"] == _bases(recs)
-    env["MXG_BS_FUSED"] = "0"
+    env["MXG_BS_SELECT"] = "1"
     env["MXG_BS"] = "0"
     st = _check(oracle, recs, 32, w)
     assert st["bs_filter_bases"] == 0
+
+
+@pytest.mark.parametrize("S,w", [(320, 1000), (64, 200), (128, 500), (512, 1000), (1024, 777)])
+def test_select_route_runs_and_agrees(oracle, env, S, w):
+    """k_bs_select on records with N runs, low-complexity islands and short records, strips of every template size"""
+    env["MXG_SPARSE_S"] = str(S)
+    env["MXG_BS"] = "1"
+    env["MXG_BS_SELECT"] = "1"
+    st = _check(oracle, _records(100 + S), 32, w)
+    assert st["select_slices"] > 0, "k_bs_select did not run"
+    env["MXG_DEV_GAPS"] = "1"      # candidate-free stretches stay on the device: few candidates per window make many
+    st = _check(oracle, _records(200 + S), 32, w, cand_per_window=3)
+    assert st["select_slices"] > 0
+    env["MXG_SPARSE_BATCH_KMERS"] = "50000"
+    st = _check(oracle, _records(300 + S), 32, w, cand_per_window=5)
+    assert st["select_slices"] > 0
+
+
+def test_select_slices_beyond_their_queue(oracle, env):
+    """MXG_SEL_QCAP=64: nearly every slice has more raw candidates than its LDS queue holds and works in a region of global
+    memory; the results do not change"""
+    env["MXG_SPARSE_S"] = "320"
+    env["MXG_SEL_QCAP"] = "64"
+    env["MXG_DEV_GAPS"] = "1"
+    st = _check(oracle, _records(51), 32, 1000)
+    assert st["select_slices"] > 0
+    st = _check(oracle, _records(52), 32, 300, cand_per_window=12)
+    assert st["select_slices"] > 0
+
+
+def test_select_stretch_ends_behind_the_slice(oracle, env):
+    """candidate-free stretches far longer than a slice's halo (a satellite-like array, a homopolymer, a contig without any
+    candidate): the reporting slice walks on to the stretch's end"""
+    rng = random.Random(5)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    unit = rnd(171)
+    recs = [("sat", rnd(30000) + unit * 400 + rnd(30000)), ("polyA", rnd(5000) + "A" * 90000 + rnd(2000)),
+            ("unit7", ("ACGGTCA" * 20000)[:100000]), ("plain", rnd(200000)), ("polyT_end", rnd(3000) + "T" * 50000)]
+    env["MXG_SPARSE_S"] = "320"
+    env["MXG_DEV_GAPS"] = "1"
+    for c in (2, 10):
+        st = _check(oracle, recs, 32, 1000, cand_per_window=c)
+        assert st["select_slices"] > 0
 
 
 def test_many_batches_and_overflow_on_the_bs_route(oracle, env):

@@ -42,6 +42,39 @@ def test_indexlr_glued_options_and_o(tmp_path):
     assert len(fields) == 3 and fields[2] in "+-"
 
 
+def test_indexlr_o_into_a_fifo_and_dev_stdout(tmp_path):
+    """-o names something that is not a regular file (a FIFO a consumer reads, /dev/stdout): the text is written in order at
+    the descriptor's own position (no pwrite), and the name is never unlinked -- not even when the run fails"""
+    import threading
+    want = open(os.path.join(GOLDEN, "cases", "f-f_w100_config1", "ref.fa.k32.w100.tsv"), "rb").read()
+    fifo = tmp_path / "out.fifo"
+    os.mkfifo(fifo)
+    got = {}
+
+    def reader():
+        with open(fifo, "rb") as fh:
+            got["data"] = fh.read()
+    t = threading.Thread(target=reader)
+    t.start()
+    subprocess.check_call([INDEXLR, os.path.join(FASTA, "ref.fa"), "--seq", "--long", "--pos", "-k32", "-w100", "-o", str(fifo)])
+    t.join(timeout=60)
+    assert got.get("data") == want
+    assert os.path.exists(fifo) and not os.path.isfile(fifo)
+    r = subprocess.run([INDEXLR, os.path.join(FASTA, "ref.fa"), "--seq", "--long", "--pos", "-k32", "-w100", "-o", "/dev/stdout"],
+                       check=True, capture_output=True)
+    assert r.stdout == want
+    assert os.path.islink("/dev/stdout")
+    # a failing run leaves the FIFO in place (a reader must be there for the open to return)
+    t = threading.Thread(target=reader)
+    t.start()
+    r = subprocess.run([INDEXLR, str(tmp_path / "missing.fa"), "-k32", "-w100", "-o", str(fifo)], capture_output=True)
+    if t.is_alive():  # (the run failed before it opened the FIFO: release the reader)
+        with open(fifo, "wb"):
+            pass
+    t.join(timeout=60)
+    assert r.returncode != 0 and os.path.exists(fifo)
+
+
 def test_indexlr_failure_is_loud(tmp_path):
     r = subprocess.run([INDEXLR, "-k", "32", "-w", "100", str(tmp_path / "missing.fa")], capture_output=True)
     assert r.returncode != 0 and r.stdout == b"" and b"cannot open" in r.stderr

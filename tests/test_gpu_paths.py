@@ -8,6 +8,7 @@ import pytest
 
 from oracle import graph_oracle as go
 from oracle import paths_oracle as po
+from tests import _path_literals
 from tests.conftest import GOLDEN, golden_cases, load_case
 
 pytestmark = pytest.mark.gpu
@@ -275,6 +276,38 @@ def test_format_paths_match_reference_goldens(name):
                 nj.close()
             key = lambda nodes: tuple(tuple(x) for x in nodes)
             assert sorted(map(key, got)) == sorted(map(key, want)), (name, n)
+    finally:
+        os.chdir(cwd)
+
+
+@pytest.mark.parametrize("name", sorted(_path_literals.EXPECTED))
+def test_path_strings_the_reference_tests_assert(name):
+    """reference tests/ntjoin_test.py:85,97,104,111,120,133,148,157,165: the path strings (contig, orientation, cut coordinates,
+    gap sizes) built from Ntjoin.find_paths + format_paths on the GPU, against the literals typed in from the reference's test file"""
+    import argparse
+    import contextlib
+    import io
+    from ntjoin_amd.ntjoin import Ntjoin
+    n, expected = _path_literals.EXPECTED[name]
+    case = load_case(name)
+    meta, fa = case["meta"], case["reference"]["format_args"]
+    lengths = _fasta_lengths(os.path.join(GOLDEN, "fasta", meta["target"]["fasta"]))
+    cwd = os.getcwd()
+    os.chdir(os.path.join(GOLDEN, "cases", name))
+    try:
+        args = argparse.Namespace(FILES=[r["tsv"] for r in meta["refs"]], s=meta["target"]["tsv"], l=meta["target"]["weight"],
+                                  p="/tmp/mxg_lit_" + name, k=meta["k"], n=n, t=1)
+        nj = Ntjoin(args, variant=meta["variant"])
+        try:
+            nj.weights_list = [r["weight"] for r in meta["refs"]]
+            with contextlib.redirect_stdout(io.StringIO()):
+                nj.load_minimizers_scaffold()
+                nj.make_minimizer_graph(materialize=False)
+                nj.find_paths()
+            got = {_path_literals.path_string(nodes) for nodes in nj.format_paths(lengths, g=fa["g"], G=fa["G"], m=fa["m"])}
+        finally:
+            nj.close()
+        assert got == expected
     finally:
         os.chdir(cwd)
 

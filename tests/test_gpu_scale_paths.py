@@ -273,7 +273,7 @@ def _repeat_rich_numpy(seed, n_rec, rec_len):
 
 @pytest.fixture
 def route_knobs(dev_knobs):
-    saved = {k: os.environ.get(k) for k in ("MXG_GAP_BUDGET", "MXG_GRID_BY_ESTIMATE", "MXG_STRETCH_DENSE")}
+    saved = {k: os.environ.get(k) for k in ("MXG_GAP_BUDGET", "MXG_GRID_BY_ESTIMATE", "MXG_STRETCH_DENSE", "MXG_BS_SELECT")}
     yield dev_knobs
     for k, v in saved.items():
         if v is None:
@@ -344,6 +344,7 @@ def test_batches_redone_one_by_one(oracle, route_knobs):
     route_knobs["MXG_DEV_GAPS"] = "1"
     route_knobs["MXG_SPARSE_BATCH_KMERS"] = "150000"
     route_knobs["MXG_GRID_BY_ESTIMATE"] = "2"
+    route_knobs["MXG_BS_SELECT"] = "0"   # (grids sized by an estimate exist on the count -> reorder -> resolve route only)
     st = _check(oracle, _records(41), 32, 200)
     assert st["retried_assemblies"] + st["batches_redone"] + st["sync_assemblies"] > 0
 
@@ -360,7 +361,7 @@ def test_kept_batches_keep_their_deferred_stretches(oracle, route_knobs):
     recs = [("tiny", rnd(33)), ("polyA", rnd(46000) + "".join(rng.choice("Aa") for _ in range(81000)) + rnd(13000)),
             ("plain", rnd(140000)), ("unit", ("ACGGTCA" * 10000)[:65536])]
     st = _check(oracle, recs, 32, 1000, cand_per_window=4)
-    if not os.environ.get("MXG_BS_FUSED") and os.environ.get("MXG_BS", "1") != "0":  # (the default route's bookkeeping)
+    if os.environ.get("MXG_BS_SELECT") == "0" and os.environ.get("MXG_BS", "1") != "0":  # (the default route's bookkeeping)
         assert st["deferred_stretches"] >= 1
         assert st["batches_redone"] >= 1
 

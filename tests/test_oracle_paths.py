@@ -5,6 +5,7 @@ import pytest
 
 from oracle import graph_oracle as go
 from oracle import paths_oracle as po
+from tests import _path_literals
 from tests.conftest import GOLDEN, golden_cases, load_case
 
 CASES = [m["name"] for m in golden_cases()]
@@ -70,3 +71,23 @@ def test_format_path_oracle_matches_reference(name):
                for comp in po.find_paths(state, int(n)) for p in comp]
         key = lambda nodes: tuple(tuple(x) for x in nodes)
         assert sorted(map(key, got)) == sorted(map(key, want)), (name, n)
+
+
+@pytest.mark.parametrize("name", sorted(_path_literals.EXPECTED))
+def test_path_strings_the_reference_tests_assert(name):
+    """the literals of reference tests/ntjoin_test.py (contig, orientation, cut coordinates, gap sizes) from the oracle's
+    find_paths + format_path, and from what the reference itself returned for the case (goldens)"""
+    n, expected = _path_literals.EXPECTED[name]
+    case = load_case(name)
+    meta, ref = case["meta"], case["reference"]
+    assert {_path_literals.path_string(nodes) for nodes in ref["format_by_n"][str(n)]} == expected
+    state = _state(meta)
+    target = meta["target"]["tsv"]
+    lengths = _fasta_lengths(os.path.join(GOLDEN, "fasta", meta["target"]["fasta"]))
+    fa = ref["format_args"]
+    filt = dict(state)
+    if not n <= min(state["weights"].values()):
+        filt["edges"] = [e for e in state["edges"] if not e[3] < n]
+    got = {_path_literals.path_string(po.format_path(filt, p, target, lengths, meta["k"], fa["g"], fa["G"], fa["m"]))
+           for comp in po.find_paths(state, n) for p in comp}
+    assert got == expected
