@@ -31,7 +31,7 @@ struct Run {
 struct alignas(32) RunX {
     uint64_t base_off;
     uint32_t n_kmers, contig, kidx0;
-    uint32_t strip0;    // strips (of the sparse strip table) in front of the run
+    uint32_t strip0S;   // (strips of the sparse strip table in front of the run) x (k-mers per strip), mod 2^32
     uint32_t nk;        // valid k-mers of the run's contig
     uint32_t pad;
 };

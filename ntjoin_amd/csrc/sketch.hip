@@ -2566,7 +2566,9 @@ struct Driver {
         MXG_HIP(h, sc(SC_CAND_H).ensure(ovf_ent * 8));
         MXG_HIP(h, sc(SC_CAND_K).ensure(ovf_ent * 4));
         MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, ctrl_bytes, st));
-        if ((rc = ev_begin(0, false, fine ? 3 : 1)) != MXG_OK) return rc;
+        // (fine timing: the slice kernel is booked where the other route books count + reorder, the stretch kernels where it books
+        // resolve + stretches)
+        if ((rc = ev_begin(0, false, fine ? 2 : 1)) != MXG_OK) return rc;
         BsSelParams bp{};
         bp.bm = a->d_bs_out.as<uint32_t>() + 4;  // (BS_OUT_PAD)
         bp.packed = a->d_packed;
@@ -2601,6 +2603,7 @@ struct Driver {
         if ((rc = launch_bs_select(h, bp, b, st)) != MXG_OK) return rc;
         h->stat_sel_slices += b.n_slices;
         const bool dev = io && io->dev_gaps;
+        if ((rc = ev_next(3)) != MXG_OK) return rc;
         if (dev && (rc = enqueue_dev_gaps(a, T, ctrl_host)) != MXG_OK) return rc;
         if ((rc = ev_next(4)) != MXG_OK) return rc;
         if (io && io->wait) MXG_HIP(h, hipStreamWaitEvent(st, io->wait, 0));
@@ -2853,7 +2856,7 @@ static int prepare_tables(mxg_handle *h, Assembly *a)
         std::vector<RunX> rx(n_runs);
         for (size_t r = 0; r < n_runs; ++r) {
             const Run &q = a->runs[r];
-            rx[r] = RunX{q.base_off, q.n_kmers, q.contig, q.kidx0, a->strip0_sparse[r], a->ctg_nk[q.contig], 0u};
+            rx[r] = RunX{q.base_off, q.n_kmers, q.contig, q.kidx0, a->strip0_sparse[r] * a->S_sparse, a->ctg_nk[q.contig], 0u};
         }
         if ((rc = upload(h, a->d_runx, rx)) != MXG_OK) return rc;
         const uint32_t n_strips = a->strip0_sparse[n_runs];
@@ -2941,6 +2944,7 @@ struct SparsePlan {
     bool dev_gaps;
     double frac;
     uint32_t tau_hi;
+    uint64_t gap_kmers;    // device route: k-mers that hold ~GAP_DEV_MAX / 2 expected stretches (0: not the device route)
     uint64_t batch_kmers;  // device route: batches small enough for ~GAP_DEV_MAX / 2 expected stretches (0: the default size;
                            // a quarter until round 3: on repeat-rich sequence, whose batches this limit cuts, half as many batches
                            // are 20 % faster, and a batch that overflows all the same is re-sized and enqueued again)
@@ -2959,10 +2963,12 @@ static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
     sp.tau_hi = std::max(2u, (uint32_t)std::min<double>(4294967294.0, sp.frac * 4294967296.0) & ~1u);
     sp.sparse = !(h->cfg.flags & MXG_FLAG_DENSE_ONLY) && sp.frac <= 0.125;
     sp.batch_kmers = 0;
+    sp.gap_kmers = 0;
     if (sp.dev_gaps) {  // a candidate is followed by a stretch with probability e^-c
         // (a->gap_rate_hint: what earlier sketches of this assembly met, 25 % on top)
         const double per_kmer = std::max(sp.frac * std::exp(-(double)c), a->gap_rate_hint * 1.25);
         const double lim = (double)env_u64("MXG_GAP_BUDGET", GAP_DEV_MAX / 2) / std::max(per_kmer, 1e-30);  // expected stretches per batch
+        sp.gap_kmers = (uint64_t)std::min<double>(std::max<double>(lim, (double)(1u << 20)), 9e18);
         if (lim < (double)SPARSE_BATCH_KMERS) sp.batch_kmers = std::max<uint64_t>((uint64_t)lim, 1u << 20);
     }
     return sp;
@@ -3068,21 +3074,11 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         state[i] = 0;
         plans[i] = sparse_plan(h, list[i]);
         if (!plans[i].sparse || i >= MXG_MAX_ASSEMBLIES) return MXG_OK;
-        std::vector<Driver::BatchGeom> gs;
-        const size_t n_ctg = tabs[i].ctg_rec->size();
-        for (size_t c0 = 0; c0 < n_ctg;) {
-            Driver::BatchGeom g;
-            drv0.batch_geom(tabs[i], c0, g, plans[i].batch_kmers);
-            gs.push_back(g);
-            c0 = g.c1;
-        }
-        if (gs.empty() || (chain_modes && gs.size() > 1) || items.size() + gs.size() >= PINNED_SLOTS - 1) return MXG_OK;
         // the k = 32 route: the bit-sliced filter over the whole assembly, then one k_bs_select per batch (sketch_bs.hip); a second
         // attempt (a batch did not end the common way: slices beyond their queues, stretches beyond the device route) and run
         // tables with short runs between invalid bases take count -> reorder -> resolve behind the same bitmap
         bool use_bs = bs_env && bs_possible(h, list[i]);
         bool sel_ok = use_bs && bs_select && attempt == 0;
-        std::vector<BsSelGeom> bgs;
         if (use_bs) {
             if ((rc = bs_prepare(h, list[i])) != MXG_OK) return rc;
             use_bs = list[i]->bs_ready;
@@ -3092,11 +3088,36 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 a->sel_H_S = a->S_sparse;
                 a->sel_H_w = h->cfg.w;
             }
-            for (size_t b = 0; use_bs && sel_ok && b < gs.size(); ++b) {
-                bgs.push_back(drv0.sel_geom(a, gs[b], plans[i].frac));
-                sel_ok = bgs.back().ok;
-            }
+            sel_ok = sel_ok && use_bs && a->sel_H != 0;
         }
+        // k_bs_select has no candidate arrays to size: its batches are as large as the stretch budget and 32-bit k-mer counts allow
+        // (an assembly of 3 Gbp: two batches, ten launches in all, where the other route cuts seven)
+        std::vector<Driver::BatchGeom> gs;
+        std::vector<BsSelGeom> bgs;
+        const size_t n_ctg = tabs[i].ctg_rec->size();
+        for (int pass = sel_ok ? 0 : 1; pass < 2; ++pass) {
+            uint64_t budget = plans[i].batch_kmers;
+            if (pass == 0) {
+                const uint64_t big = env_u64("MXG_SEL_BATCH_KMERS", 2040ull << 20);
+                budget = std::min<uint64_t>(plans[i].gap_kmers ? plans[i].gap_kmers : big, big);
+                if (getenv("MXG_SPARSE_BATCH_KMERS")) budget = std::min<uint64_t>(budget, SPARSE_BATCH_KMERS);  // (test knob)
+            }
+            gs.clear();
+            bgs.clear();
+            for (size_t c0 = 0; c0 < n_ctg;) {
+                Driver::BatchGeom g;
+                drv0.batch_geom(tabs[i], c0, g, budget);
+                gs.push_back(g);
+                c0 = g.c1;
+            }
+            if (pass == 1) break;
+            for (size_t b = 0; sel_ok && b < gs.size(); ++b) {
+                bgs.push_back(drv0.sel_geom(list[i], gs[b], plans[i].frac));
+                sel_ok = bgs.back().ok && gs[b].nk < (1ull << 31);
+            }
+            if (sel_ok) break;
+        }
+        if (gs.empty() || (chain_modes && gs.size() > 1) || items.size() + gs.size() >= PINNED_SLOTS - 1) return MXG_OK;
         sel_ok = sel_ok && use_bs;
         hipEvent_t ev_hash = nullptr;
         hipStream_t st_hash = nullptr;

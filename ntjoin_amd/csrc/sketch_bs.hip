@@ -68,13 +68,14 @@ struct StripRegs {
     uint64_t b;                // base position of its first k-mer
     uint32_t len, cg, k0, nk;  // k-mers, contig (~0: no strip), contig-local index of the first k-mer, k-mers of the contig
 };
-__device__ __forceinline__ StripRegs strip_of(const BsSelParams &p, const bool in, const uint32_t s, const uint32_t ri)
+// sS = the strip's index x S (mod 2^32): the wave's first strip x S is scalar work, lane x S is computed once per kernel
+__device__ __forceinline__ StripRegs strip_of(const BsSelParams &p, const bool in, const uint32_t sS, const uint32_t ri)
 {
     StripRegs r;
     r.b = 0; r.len = 0; r.cg = 0xFFFFFFFFu; r.k0 = 0; r.nk = 0;
     if (in) {
-        const RunX run = p.runx[ri];  // (32 bytes, aligned: two requests)
-        const uint32_t j0 = (s - run.strip0) * p.S;
+        const RunX run = p.runx[ri];  // (32 bytes, aligned)
+        const uint32_t j0 = sS - run.strip0S;  // k-mers of the run in front of the strip (the true value is below 2^32)
         r.len = min(p.S, run.n_kmers - j0);
         r.b = run.base_off + j0;
         r.cg = run.contig;
@@ -87,7 +88,20 @@ __device__ __forceinline__ StripRegs load_strip(const BsSelParams &p, const int6
 {
     const bool in = s64 >= 0 && s64 < (int64_t)p.n_strips_asm;
     const uint32_t s = in ? (uint32_t)s64 : 0u;
-    return strip_of(p, in, s, in ? p.strip_run[s] : 0u);
+    return strip_of(p, in, s * p.S, in ? p.strip_run[s] : 0u);
+}
+
+// inclusive prefix sum over the wave's 64 lanes in six DPP additions (row shifts inside the rows of 16 lanes, then the rows' last
+// lanes broadcast to the rows behind them); the shuffle version of scan_kernels.h takes an LDS-crossbar round trip per step
+__device__ __forceinline__ uint32_t wave_inclusive_dpp(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
+    return v;
 }
 
 __device__ __forceinline__ void sel_push_gap(const BsSelParams &p, uint32_t c, uint32_t lo, uint32_t hi, uint32_t hint)
@@ -168,26 +182,20 @@ __device__ __forceinline__ void sel_sync()
 }
 
 // bits -> raw queue -> exact hashes -> the real candidates at the front of the list, in order (+ sentinels)
-template <int NWC, bool GLOB>
-__device__ __forceinline__ void sel_collect(const BsSelParams &p, SelCtx &c, uint64_t *lh, uint32_t *le, const uint32_t cap, const StripRegs &sr,
-                                            const uint32_t (&wd)[NWC], const uint32_t at0, const uint32_t tot)
+// bt[j]: the strip's bits of k-mers [32 j, 32 j + 32), LSB first (words beyond the strip: 0)
+template <int NB, bool GLOB>
+__device__ __forceinline__ void sel_collect(const BsSelParams &p, SelCtx &c, uint64_t *lh, uint32_t *le, const uint32_t cap,
+                                            const uint32_t (&bt)[NB], const uint32_t at0, const uint32_t tot)
 {
     const uint32_t lane = c.lane, H = p.H;
-    const uint32_t nwords = (p.S + 31u) / 32u;
-    const uint32_t qn = min(tot, cap);
+    const uint32_t qn = min(tot, cap);  // (tot <= cap: the caller chose the list for it)
     {
         uint32_t at = at0;
-        const uint32_t sh = (uint32_t)sr.b & 31u;
 #pragma unroll
-        for (uint32_t j = 0; j + 1 < (uint32_t)NWC; ++j) {
-            if (j < nwords) {
-                uint32_t bits = sel_bits(wd[j], wd[j + 1], sh, sr.len, j);
-                const uint32_t item0 = lane | ((32u * j) << 6);
-                for (; bits; bits &= bits - 1u, ++at) {
-                    const uint32_t t = (uint32_t)__builtin_ctz(bits);
-                    if (at < qn) le[at] = item0 + (t << 6);
-                }
-            }
+        for (uint32_t j = 0; j < (uint32_t)NB; ++j) {
+            uint32_t bits = bt[j];
+            const uint32_t item0 = lane | ((32u * j) << 6);
+            for (; bits; bits &= bits - 1u, ++at) le[at] = item0 + ((uint32_t)__builtin_ctz(bits) << 6);
         }
     }
     const uint32_t *s_blo = c.si, *s_bhi = c.si + 64, *s_f = c.si + 320;
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     __syncthreads();
     const uint32_t S = p.S, H = p.H, T = p.T, w = p.w;
     const uint32_t nwords = (S + 31u) / 32u;
-    const uint32_t stride = gridDim.x * nwv;
+    const uint32_t stride = gridDim.x * nwv, laneS = lane * S;
     uint32_t own_cands = 0, touch = 0;
     uint32_t region = 0xFFFFFFFFu;  // this wave's region of global memory, once it has needed one
     bool flag = false;
@@ -391,6 +399,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         const bool in_n = sl_n < p.n_slices && sn64 >= 0 && sn64 < (int64_t)p.n_strips_asm;
         const uint32_t s_n = in_n ? (uint32_t)sn64 : 0u;
         const uint32_t ri_n = in_n ? p.strip_run[s_n] : 0u;
+        const uint32_t sS_n = (uint32_t)(sn64 - lane) * S + laneS;  // (wrong only where in_n is false)
         // the strip's words of the bitmap, four per request
         uint32_t wd[NWC];
         {
@@ -407,31 +416,44 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         // then meet them in L2; without this every round of 64 candidates waited for HBM).  `touch` keeps the loads alive.
         if (sr.len) touch ^= p.packed[sr.b >> 4] ^ p.packed[(sr.b + sr.len + 31u) >> 4];
         // fold: k-mers of one contig at their distances, a contig border = w more; the first strip starts at 2 w
-        const uint32_t len_p = (uint32_t)__shfl_up((int)sr.len, 1, 64), cg_p = (uint32_t)__shfl_up((int)sr.cg, 1, 64);
-        const uint32_t f = wave_inclusive_u32(lane ? len_p + (sr.cg != cg_p ? w : 0u) : 2u * w, lane);
+        // (wave_shr:1: the lane in front; lane 0 keeps `old`)
+        const uint32_t len_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sr.len, 0x138, 0xf, 0xf, false);
+        const uint32_t cg_p = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)sr.cg, 0x138, 0xf, 0xf, false);
+        const uint32_t f = wave_inclusive_dpp(lane ? len_p + (sr.cg != cg_p ? w : 0u) : 2u * w);
         c.si[lane] = (uint32_t)sr.b;
         c.si[64u + lane] = (uint32_t)(sr.b >> 32);
         c.si[128u + lane] = sr.cg;
         c.si[192u + lane] = sr.k0;
         c.si[256u + lane] = sr.nk;
         c.si[320u + lane] = f;
+        // the strip's bits, word by word (k-mers [32 j, 32 j + 32), LSB first): shifted into place, cut at the strip's length --
+        // positions whose 32-mer crosses the run's end are set in the bitmap (the filter sees bases, not runs).  When every strip
+        // of the slice is whole (nearly always) nothing needs cutting.
+        uint32_t bt[NWC - 1];
         uint32_t cnt = 0;
         {
             const uint32_t sh = (uint32_t)sr.b & 31u;
+            const bool whole = (S & 31u) == 0 && __ballot(sr.len != 0 && sr.len != S) == 0;
+            if (whole) {
 #pragma unroll
-            for (uint32_t j = 0; j + 1 < (uint32_t)NWC; ++j)
-                if (j < nwords) cnt += (uint32_t)__popc(sel_bits(wd[j], wd[j + 1], sh, sr.len, j));
+                for (uint32_t j = 0; j + 1 < (uint32_t)NWC; ++j) bt[j] = j < nwords ? __builtin_amdgcn_alignbit(wd[j + 1], wd[j], sh) : 0u;
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j + 1 < (uint32_t)NWC; ++j) bt[j] = j < nwords ? sel_bits(wd[j], wd[j + 1], sh, sr.len, j) : 0u;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j + 1 < (uint32_t)NWC; ++j) cnt += (uint32_t)__popc(bt[j]);
         }
-        const uint32_t incl = wave_inclusive_u32(cnt, lane);
-        const uint32_t tot = (uint32_t)__shfl((int)incl, 63, 64);
+        const uint32_t incl = wave_inclusive_dpp(cnt);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         StripRegs sr_n;
         if (p.ablate == 1) {  // (profiling)
             if (lane == 0) count_publish(p.cnt, p.sup, sl, 0u);
             own_cands += tot != 0;
-            sr_n = strip_of(p, in_n, s_n, ri_n);
+            sr_n = strip_of(p, in_n, sS_n, ri_n);
         } else if (tot <= p.qcap) {
-            sel_collect<NWC, false>(p, c, lh + SEL_PAD, le + SEL_PAD, p.qcap, sr, wd, incl - cnt, tot);
-            sr_n = strip_of(p, in_n, s_n, ri_n);
+            sel_collect<NWC - 1, false>(p, c, lh + SEL_PAD, le + SEL_PAD, p.qcap, bt, incl - cnt, tot);
+            sr_n = strip_of(p, in_n, sS_n, ri_n);
             if (p.ablate == 2 || p.ablate == 3) {
                 if (lane == 0) count_publish(p.cnt, p.sup, sl, 0u);
                 own_cands += 1u;
@@ -444,10 +466,10 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
                 if (lane == 0) r = atomicAdd(p.ovf_next, 1u);
                 region = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
             }
-            sr_n = strip_of(p, in_n, s_n, ri_n);
+            sr_n = strip_of(p, in_n, sS_n, ri_n);
             if (region < p.n_ovf) {
                 const size_t o = (size_t)region * (p.ovf_cap + 2u * SEL_PAD) + SEL_PAD;
-                sel_collect<NWC, true>(p, c, p.ovf_h + o, p.ovf_e + o, p.ovf_cap, sr, wd, incl - cnt, tot);
+                sel_collect<NWC - 1, true>(p, c, p.ovf_h + o, p.ovf_e + o, p.ovf_cap, bt, incl - cnt, tot);
                 sel_decide<true>(p, c, p.ovf_h + o, p.ovf_e + o, sr, f, flag);
             } else {  // no region left: the host redoes the batch
                 flag = true;
