@@ -46,6 +46,7 @@ sys.path.insert(0, REPO)
 
 K = 32
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+PROFILE_ROUND = "r04"   # profiles/<round>/: the committed rocprofv3 summaries static figures are quoted from
 ALG_BYTES_PER_BASE_HASH = 0.25   # hash kernel: one 2-bit packed base read per base
 ALG_BYTES_PER_MINIMIZER = 70.0   # whole path: sketch tuple + uniqueness + intersection + edge build
 
@@ -331,7 +332,7 @@ def dry_run(args):
         # same workload when there is one (a rank's own two shares are different stretches of the genome: its own graph says nothing)
         frac = 0.75
         try:
-            one = json.loads(open(os.path.join(REPO, "profiles", "r03", f"bench_{wl}.json")).read().strip().splitlines()[-1])
+            one = json.loads(open(os.path.join(REPO, "profiles", PROFILE_ROUND, f"bench_{wl}.json")).read().strip().splitlines()[-1])
             frac = one["config"]["vertices"] * len(asms) / max(one["config"]["minimizers"], 1)
         except Exception:
             pass
@@ -341,8 +342,8 @@ def dry_run(args):
         sent = {"items": int(16 * m * out_frac), "verdicts": int(8 * m * out_frac), "adjacency_messages": int(2 * 16 * shared * out_frac)}  # one message to each end point's owner
         per_link = sum(sent.values()) / (N - 1)
         ranks.append({"rank": r, "bases": int(st["bases"]), "minimizers": m, "sketch_ms": round(t_sk, 3), "graph_stage_on_own_minimizers_ms": round(t_gr, 3),
-                      "kernel_ms_per_step": {"filter": round(st["ms_hash"] / args.steps, 3), "count+reorder": round(st["ms_reorder"] / args.steps, 3),
-                                             "resolve+stretches": round(st["ms_resolve_kernel"] / args.steps, 3), "emit": round(st["ms_emit"] / args.steps, 3),
+                      "kernel_ms_per_step": {"filter": round(st["ms_hash"] / args.steps, 3), "select (or count+reorder)": round(st["ms_reorder"] / args.steps, 3),
+                                             "stretches (+resolve)": round(st["ms_resolve_kernel"] / args.steps, 3), "emit": round(st["ms_emit"] / args.steps, 3),
                                              "join": round(st["ms_join"] / args.steps, 3), "vertices": round(st["ms_vertices"] / args.steps, 3),
                                              "edges": round(st["ms_edges"] / args.steps, 3)},
                       "bytes_sent_per_step": sent, "exchange_ms_at_link_rate": round(per_link / (XGMI_LINK_GBS * 1e9) * 1e3, 3)})
@@ -529,7 +530,7 @@ def main():
         step_gbs = step_alg_bytes / (ms_step * 1e-3) / 1e9
         # PMC traffic of the hash kernel: only quoted when the committed counters were collected on THIS workload
         traffic, traffic_src, tj_commit = None, None, None
-        tpath = os.path.join(REPO, "profiles", "r03", "hbm_traffic.json")
+        tpath = os.path.join(REPO, "profiles", PROFILE_ROUND, "hbm_traffic.json")
         if os.path.exists(tpath) and bs_route():
             try:
                 tj = json.load(open(tpath))
@@ -538,9 +539,9 @@ def main():
                     if tj.get("kernel_sources_digest") == kernel_sources_digest():
                         traffic = round(tj["k_hash_bytes_per_base"] * st["hash_kernel_bases"] / launches)
                         traffic_src = ("static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload at commit "
-                                       f"{tj.get('commit', '?')}, profiles/r03/hbm_traffic.json")
+                                       f"{tj.get('commit', '?')}, profiles/" + PROFILE_ROUND + "/hbm_traffic.json")
                     else:
-                        traffic_src = (f"stale: profiles/r03/hbm_traffic.json was captured at commit {tj.get('commit', '?')} and the "
+                        traffic_src = (f"stale: profiles/" + PROFILE_ROUND + "/hbm_traffic.json was captured at commit {tj.get('commit', '?')} and the "
                                        "kernel sources have changed since; not quoted")
             except Exception:
                 traffic = None
@@ -607,16 +608,78 @@ def main():
                 step(eng2)
             s2 = eng2.stats()
             bs = bs_route()
+            sel = s2.get("select_slices", 0) > 0   # k_bs_select ran (its time is booked where the other route books count + reorder)
             ker = {"k_hash_bs" if bs else "k_hash_sparse": s2["ms_hash"] / nk,
-                   "k_bs_count+k_bs_reorder_w" if bs else "k_reorder_w": s2["ms_reorder"] / nk,
-                   "k_resolve+k_gap_fix+k_gap_post": s2["ms_resolve_kernel"] / nk, "k_emit": s2["ms_emit"] / nk, "join (k_pj_* / k_insert+k_flags)": s2["ms_join"] / nk,
+                   ("k_bs_select" if sel else "k_bs_count+k_bs_reorder_w") if bs else "k_reorder_w": s2["ms_reorder"] / nk,
+                   "k_gap_fix+k_gap_post" if sel else "k_resolve+k_gap_fix+k_gap_post": s2["ms_resolve_kernel"] / nk,
+                   "k_emit": s2["ms_emit"] / nk, "join (k_pj_* / k_insert+k_flags)": s2["ms_join"] / nk,
                    "k_vertices+k_adjacency": s2["ms_vertices"] / nk, "k_edge_flags+k_edges": s2["ms_edges"] / nk}
             tot = sum(ker.values()) or 1.0
             out["kernels"] = {"ms_per_step": {k_: round(v, 4) for k_, v in ker.items()},
                               "share": {k_: round(v / tot, 4) for k_, v in ker.items()},
                               "note": "HIP-event pair per kernel on a second handle (3 steps after the timed region); "
                                       "spans of the two streams may overlap when the assemblies are pipelined"}
+            # the first step of a FRESH handle in a warm process (what a one-shot caller of the library pays: buffers, tables, no
+            # hints from earlier steps; the code objects are loaded and the driver has released nothing yet)
+            torch.cuda.synchronize()
+            eng3 = MxEngine(k=K, w=W, device=local_rank, cand_per_window=args.cand)
+            for (name, weight, segs, _, _, _), d in zip(asms, keep):
+                eng3.add_packed_device(name, weight, d.data_ptr(), segs[:, 0], segs[:, 2])
+            torch.cuda.synchronize()
+            t1s = time.perf_counter()
+            step(eng3)
+            torch.cuda.synchronize()
+            one_ms = (time.perf_counter() - t1s) * 1e3
+            s3 = eng3.stats()
+            out["one_shot"] = {"ms": round(one_ms, 3), "value": round(bases_total / (one_ms * 1e-3) / 1e9, 2), "unit": "Gbp/s",
+                               "vs_steady_state": round(one_ms / ms_step, 2),
+                               "assemblies_enqueued_twice": int(s3["retried_assemblies"]), "batches_redone": int(s3["batches_redone"]),
+                               "what": "first sketch + graph step of a fresh handle on the same resident bases, timed after the steady-state "
+                                       "region in the same process (code objects loaded); `fallbacks.first_step_of_the_handle` is the very first "
+                                       "step of the process"}
+            eng3.close()
             eng2.close()
+            # every kernel group against the HBM roof: algorithmic bytes where SURVEY.md 8(d) defines them (0.25 B per base for the
+            # kernel that reads the bases; per minimizer 16 B tuple written, 18 B uniqueness + intersection, 36 B edge build), the
+            # counter traffic of the committed PMC passes when they are of these kernel sources, the time of the pass above
+            mx = float(st["minimizers"])
+            alg = {"filter": ALG_BYTES_PER_BASE_HASH * bases_total, "emit": 16.0 * mx, "join": 18.0 * mx, "graph": 36.0 * mx}
+            groups = [("k_hash_bs" if bs else "k_hash_sparse", "filter", ("k_hash_bs", "k_hash_sparse")),
+                      (("k_bs_select" if sel else "k_bs_count+k_bs_reorder_w") if bs else "k_reorder_w", None, ("k_bs_select", "k_bs_count", "k_bs_reorder_w", "k_reorder")),
+                      ("k_gap_fix+k_gap_post" if sel else "k_resolve+k_gap_fix+k_gap_post", None, ("k_resolve", "k_gap_fix", "k_gap_post")),
+                      ("k_emit", "emit", ("k_emit",)),
+                      ("join (k_pj_* / k_insert+k_flags)", "join", ("k_pj", "k_flags", "k_insert")),
+                      ("k_vertices+k_adjacency", "graph", ("k_vertices", "k_adjacency", "k_block_prefix", "k_edge_flags", "k_edges")),
+                      ("k_edge_flags+k_edges", None, ())]
+            pmc = {}
+            try:
+                tj = json.load(open(os.path.join(REPO, "profiles", PROFILE_ROUND, "hbm_traffic.json")))
+                if tj.get("workload") == wl and tj.get("kernel_sources_digest") == kernel_sources_digest():
+                    pmc = {r["kernel"]: r["bytes_per_step"] for r in tj.get("per_kernel", [])}
+            except Exception:
+                pmc = {}
+            rbk = []
+            for label_k, alg_key, names in groups:
+                ms_k = ker.get(label_k, 0.0)
+                if alg_key == "graph":
+                    ms_k += ker.get("k_edge_flags+k_edges", 0.0)
+                if label_k == "k_edge_flags+k_edges":
+                    continue
+                pb = sum(v for k_, v in pmc.items() if any(nm in k_ for nm in names)) if pmc else None
+                ab = alg.get(alg_key) if alg_key else 0.0
+                rbk.append({"kernels": label_k + (" + k_edge_flags+k_edges" if alg_key == "graph" else ""), "ms_per_step": round(ms_k, 4),
+                            "alg_bytes_per_step": int(ab),
+                            "alg_frac_of_hbm_peak": round(ab / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_k > 0 else None,
+                            "pmc_bytes_per_step": int(pb) if pb else None,
+                            "pmc_frac_of_hbm_peak": round(pb / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if pb and ms_k > 0 else None})
+            out["roofline_by_kernel"] = {"rows": rbk, "peak_gbs": HBM_PEAK_GBS,
+                                         "note": "ms: HIP-event pair per kernel group (the `kernels` pass); alg bytes: SURVEY.md 8(d) -- none are "
+                                                 "defined for turning the filter's bitmap into selected candidates or for candidate-free "
+                                                 "stretches; pmc bytes: FETCH_SIZE x 2 + WRITE_SIZE of profiles/" + PROFILE_ROUND +
+                                                 "/hbm_traffic.json when it was captured at these kernel sources, else null"}
+            big = max(rbk, key=lambda r: r["ms_per_step"])
+            out["roofline"]["largest_time_consumer"] = {"kernels": big["kernels"], "ms_per_step": big["ms_per_step"],
+                                                        "see": "roofline_by_kernel"}
         asms_host = None
         if not multi and not (args.no_cpu_baseline and args.no_end_to_end):
             asms_host = [(d.cpu().numpy().view(np.uint32), st_, ln_) for d, st_, ln_ in host_layout]

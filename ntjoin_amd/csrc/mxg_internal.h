@@ -3,9 +3,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -60,6 +62,9 @@ struct DevBuf {
     hipError_t ensure(size_t need)
     {
         if (need <= bytes) return hipSuccess;
+        static const bool dbg = getenv("MXG_DEBUG_ALLOC") != nullptr;  // (diagnostics: what a handle's first step allocates)
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t had = bytes;
         release();
         size_t want = need + need / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
@@ -68,6 +73,9 @@ struct DevBuf {
             return e;
         }
         bytes = want;
+        if (dbg)
+            fprintf(stderr, "[mxg] alloc %.1f MB (had %.1f MB): %.3f ms\n", want / 1048576.0, had / 1048576.0,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         return hipSuccess;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }

@@ -3113,7 +3113,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             if (pass == 1) break;
             for (size_t b = 0; sel_ok && b < gs.size(); ++b) {
                 bgs.push_back(drv0.sel_geom(list[i], gs[b], plans[i].frac));
-                sel_ok = bgs.back().ok && gs[b].nk < (1ull << 31);
+                sel_ok = bgs.back().ok;  // (strips and selected entries are counted in 32 bits: bs_select_geom checks them)
             }
             if (sel_ok) break;
         }

@@ -381,22 +381,24 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     const uint32_t S = p.S, H = p.H, T = p.T, w = p.w;
     const uint32_t nwords = (S + 31u) / 32u;
     const uint32_t stride = gridDim.x * nwv, laneS = lane * S;
-    uint32_t own_cands = 0, touch = 0;
+    uint32_t own_cands = 0, touch = 0, pend_a = 0, pend_b = 0, pend_c = 0;
     uint32_t region = 0xFFFFFFFFu;  // this wave's region of global memory, once it has needed one
-    bool flag = false;
+    bool flag = false, first = true;
+    // (a wave takes every stride-th slice; runs of consecutive slices per wave measured 4 % slower)
     uint32_t sl = blockIdx.x * nwv + wib;
+    const uint32_t sl_end = p.n_slices;
     // a slice's strips are looked up one slice ahead: the strip -> run table while the slice before is being set up, the run
     // itself while that slice's candidates are being decided (nothing there waits for memory)
     auto first_strip = [&](uint32_t q) { return (int64_t)(p.strip_lo + q * T) - (int64_t)H; };
-    StripRegs sr = sl < p.n_slices ? load_strip(p, first_strip(sl) + lane) : StripRegs{0, 0, 0xFFFFFFFFu, 0, 0};
-    for (; sl < p.n_slices; sl += stride) {
+    StripRegs sr = sl < sl_end ? load_strip(p, first_strip(sl) + lane) : StripRegs{0, 0, 0xFFFFFFFFu, 0, 0};
+    for (; sl < sl_end; sl += stride) {
         const uint32_t s_own0 = p.strip_lo + sl * T;
         c.sl = sl;
         c.s_first = first_strip(sl);
         c.own_end = H + min(T, p.strip_hi - s_own0);  // lanes [H, own_end) hold the slice's own strips
         const uint32_t sl_n = sl + stride;
         const int64_t sn64 = first_strip(sl_n) + lane;
-        const bool in_n = sl_n < p.n_slices && sn64 >= 0 && sn64 < (int64_t)p.n_strips_asm;
+        const bool in_n = sl_n < sl_end && sn64 >= 0 && sn64 < (int64_t)p.n_strips_asm;
         const uint32_t s_n = in_n ? (uint32_t)sn64 : 0u;
         const uint32_t ri_n = in_n ? p.strip_run[s_n] : 0u;
         const uint32_t sS_n = (uint32_t)(sn64 - lane) * S + laneS;  // (wrong only where in_n is false)
@@ -413,8 +415,10 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         }
         // ... and the first and last word of its packed bases: a strip is shorter than a cache line, so these requests bring every
         // line the slice's candidates will be hashed from on their way while the bitmap words travel (the candidates' own requests
-        // then meet them in L2; without this every round of 64 candidates waited for HBM).  `touch` keeps the loads alive.
-        if (sr.len) touch ^= p.packed[sr.b >> 4] ^ p.packed[(sr.b + sr.len + 31u) >> 4];
+        // then meet them in L2; without this every round of 64 candidates waited for HBM).  `touch` keeps the loads alive.  Only for
+        // a wave's first slice: the lines of every later one are asked for while the slice before it is being decided (below).
+        if (first && sr.len) touch ^= p.packed[sr.b >> 4] ^ p.packed[(sr.b + sr.len + 31u) >> 4];
+        touch ^= pend_a ^ pend_b ^ pend_c;  // (what the round before asked for ahead)
         // fold: k-mers of one contig at their distances, a contig border = w more; the first strip starts at 2 w
         // (wave_shr:1: the lane in front; lane 0 keeps `old`)
         const uint32_t len_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sr.len, 0x138, 0xf, 0xf, false);
@@ -446,14 +450,25 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         }
         const uint32_t incl = wave_inclusive_dpp(cnt);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        StripRegs sr_n;
+        // the next slice's strips (their run indices have arrived while this slice's bitmap words travelled), and -- once this
+        // slice's candidates are hashed -- one word of every cache line of its bitmap words and packed bases: they travel while
+        // this slice's candidates are decided, which asks nothing of memory
+        const StripRegs sr_n = strip_of(p, in_n, sS_n, ri_n);
+        auto ask_ahead = [&]() {  // (the words are looked at -- folded into `touch` -- only in the next round of the loop: no wait here)
+            pend_a = pend_b = pend_c = 0;
+            if (sr_n.len) {
+                pend_a = p.bm[sr_n.b >> 5];
+                pend_b = p.packed[sr_n.b >> 4];
+                pend_c = p.packed[(sr_n.b + sr_n.len + 31u) >> 4];
+            }
+        };
         if (p.ablate == 1) {  // (profiling)
             if (lane == 0) count_publish(p.cnt, p.sup, sl, 0u);
             own_cands += tot != 0;
-            sr_n = strip_of(p, in_n, sS_n, ri_n);
+            ask_ahead();
         } else if (tot <= p.qcap) {
             sel_collect<NWC - 1, false>(p, c, lh + SEL_PAD, le + SEL_PAD, p.qcap, bt, incl - cnt, tot);
-            sr_n = strip_of(p, in_n, sS_n, ri_n);
+            ask_ahead();
             if (p.ablate == 2 || p.ablate == 3) {
                 if (lane == 0) count_publish(p.cnt, p.sup, sl, 0u);
                 own_cands += 1u;
@@ -466,7 +481,6 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
                 if (lane == 0) r = atomicAdd(p.ovf_next, 1u);
                 region = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
             }
-            sr_n = strip_of(p, in_n, sS_n, ri_n);
             if (region < p.n_ovf) {
                 const size_t o = (size_t)region * (p.ovf_cap + 2u * SEL_PAD) + SEL_PAD;
                 sel_collect<NWC - 1, true>(p, c, p.ovf_h + o, p.ovf_e + o, p.ovf_cap, bt, incl - cnt, tot);
@@ -480,6 +494,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         own_cands += c.own_hi - c.own_lo;
         __builtin_amdgcn_wave_barrier();  // the next slice reuses the wave's LDS
         sr = sr_n;
+        first = false;
     }
     const uint32_t own_w = own_cands;  // (wave-uniform)
     if (touch == 0x9E3779B9u && p.w == 0) p.ctrl[15] = touch;  // (never: the words requested ahead are not used for anything)

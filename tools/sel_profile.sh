@@ -7,10 +7,10 @@ run() {
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d.get('kernels',{}).get('ms_per_step',{})
-print('$1', 'ms/step', d['ms_per_step'], 'select+stretches', k.get('k_bs_select+k_gap_fix+k_gap_post', k.get('k_resolve+k_gap_fix+k_gap_post')), 'emit', k.get('k_emit'), 'filter', k.get('k_hash_bs'), 'first', (d['fallbacks'].get('first_step_of_the_handle') or {}).get('ms'))
+print('$1', 'ms/step', d['ms_per_step'], {a.split(' ')[0]: b for a, b in k.items()}, 'first', (d['fallbacks'].get('first_step_of_the_handle') or {}).get('ms'))
 "
 }
 for a in 0 1 2 3; do MXG_SEL_ABLATE=$a run "ablate=$a"; done
-for b in 1073741824 2147000000; do MXG_SPARSE_BATCH_KMERS=$b run "batch_kmers=$b"; done
+for b in 536870912 1073741824; do MXG_SEL_BATCH_KMERS=$b run "batch_kmers=$b"; done
 for s in 256 512; do MXG_SPARSE_S=$s run "S=$s"; done
 MXG_BS_SELECT=0 run "old route"
