@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libntjoin_mx.so")
+# MXG_LIB_DIR: another build of the same sources (the sanitizer builds of csrc/Makefile: lib_asan, lib_tsan)
+LIB_PATH = os.path.join(os.environ.get("MXG_LIB_DIR") or os.path.join(_HERE, "lib"), "libntjoin_mx.so")
 
 MXG_OK, MXG_EINVAL, MXG_EIO, MXG_ENOMEM, MXG_EDEVICE, MXG_ELIMIT = 0, -1, -2, -3, -4, -5
 VARIANT_V2_SUM, VARIANT_V1_MIN = 0, 1

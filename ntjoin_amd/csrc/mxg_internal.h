@@ -132,6 +132,7 @@ struct Assembly {
     bool bs_ready = false, bs_impossible = false;
     uint32_t bs_chunks = 0;
     DevBuf d_bs_tail, d_bs_out;  // k = 32 route: padded copies of the first / last chunk's words, the filter's bitmap
+    bool sel_again = false;  // the second attempt of an assembly's batches may take k_bs_select again (only the stretch budget failed)
     uint32_t sel_H = 0, sel_H_S = 0, sel_H_w = 0;  // k_bs_select: halo strips (0: the route does not take this run table) for (S, w)
     // sketch (device, ordered by (record,pos)) + lazily filled host mirror
     bool has_sketch = false;

@@ -53,7 +53,7 @@ enum Scratch {
     SC_G_REC, SC_G_FWD, SC_V_RUNS, SC_V_STRIP0, SC_V_G0, SC_V_NK, SC_V_REC, SC_V_RUN0, SC_V_DROP, SC_CNT256, SC_WAVE_TOT,
     SC_GR_HASH, SC_GR_POS, SC_GR_REC, SC_GR_CNT, SC_GR_KEY, SC_GD_HASH, SC_GD_POS, SC_GD_REC,  // device-side stretch fix-up
     SC_CS_H, SC_CS_K, SC_CS_C,  // selected candidates per k_resolve block
-    SC_GB_WORK,                 // work arrays of the long stretches (k_gap_post)
+    SC_GB_WORK,                 // (unused)
     SC_COUNT
 };
 static_assert(SC_COUNT <= 40, "scratch pool too small");
@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
                     p.host_ctrl[w] = w == 1 ? n_g_raw : w == 2 ? all : w == 3 ? flag : w == 4 ? n_report : w == 5 ? nB
                                    : w == 6 ? (uint32_t)total : w == 7 ? (uint32_t)(total >> 32)
                                    : w == 8 ? (uint32_t)obase : w == 9 ? (uint32_t)(obase >> 32)
-                                   : (w == 10 && p.dev_gaps) ? p.ovf[10] : (w == 11 && p.dev_gaps && !flag) ? p.ovf[11] : 0u;
+                                   : (w == 10 && p.dev_gaps) ? p.ovf[10] : (w == 11 && p.dev_gaps && !flag) ? p.ovf[11] : w == 12 ? p.ovf[13] : 0u;
                 }
             }
         }
@@ -1510,8 +1510,13 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
     __syncthreads();
     for (uint32_t j = blockIdx.x; j < n_g; j += gridDim.x) {
         const uint4 g = p.gaps[j];
-        if (g.z - g.y + 1u <= GAP_DEV_NSMALL)  // (k_gap_post hands the longer ones to the host)
+        if (g.z - g.y + 1u <= GAP_DEV_NSMALL) {
             gap_fix_one<VARIANT>(p, j, GAP_DEV_NSMALL, lh, lidx[0], lidx[1], selbits, lw, sh, tab, &drop_idx);
+        } else if (threadIdx.x == 0) {  // longer than the block's arrays: left to the host (it contributes no minimizer here)
+            p.r_key[j] = ((uint64_t)g.x << 32) | g.y;
+            p.r_cnt[j] = 0;
+            defer_stretch(p, g);
+        }
         __syncthreads();  // the work arrays are reused
     }
 }
@@ -1521,120 +1526,74 @@ struct GapPostParams {
     const uint32_t *r_cnt; const uint64_t *r_key;
     // the stretches in (contig, first k-mer) order: key, minimizers in the stretches before it ([n] = all), index of its region
     uint64_t *s_key; uint32_t *s_off, *s_src;
-    GapFixParams fx;     // the long stretches (more than GAP_DEV_NSMALL k-mers) are sketched here, one after the other,
-    uint32_t *big_work;  // with these GAP_BIG_WORK_WORDS words of global memory in place of k_gap_fix's LDS arrays
 };
-constexpr uint32_t GAP_BIG_WORK_WORDS = GAP_DEV_NMAX * 2 + GAP_DEV_NMAX + GAP_DEV_NMAX / 32 + (GAP_DEV_NMAX / 16 + 1024 / 16 + 4);
-constexpr uint32_t GAP_BIG_LIST = 4;   // long stretches per batch walked by k_gap_post, ~30 us each (more: all left to the host)
 
-// (256 threads: a single block of 1024 had to wait for sixteen free wave slots on one CU while the other stream's hash kernel
-// held them all -- 23 us per launch under rocprofv3 for a microsecond of work)
-constexpr uint32_t GPB = 256;
-template <int VARIANT>
+// The batch's stretches ranked by (contig, first k-mer): every stretch counts the stretches with a smaller key -- its rank (the
+// keys are distinct) -- and, in the same pass, the minimizers those hold -- its offset: nothing is scanned, no block waits for
+// another.  A block takes 64 stretches, four threads each (a quarter of the other keys per thread), the other stretches' keys
+// and counts pass through 6 KB of LDS 512 at a time (a block that wants more LDS than k_bs_select leaves free on a CU waits for
+// one of its blocks to end).  One block of 256 threads ranking everything took 48 us for 950 stretches (a third of the batch's
+// emit + stretch time at 2 x 10^9 k-mers per batch).
+constexpr uint32_t GPB = 256, GP_PER = 64;
+constexpr uint32_t GAP_POST_BLOCKS = GAP_DEV_MAX / GP_PER;
 __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
 {
-    __shared__ uint64_t keys[512];
-    __shared__ uint32_t sh[256];
-    __shared__ uint4 tab[20];
-    __shared__ uint32_t big_list[GAP_BIG_LIST], n_big, drop_idx;
+    constexpr uint32_t CH = 512;
+    __shared__ uint64_t keys[CH];
+    __shared__ uint32_t cnts[CH];
+    __shared__ uint32_t part_rank[GPB], part_off[GPB];
     const uint32_t n_g = p.ctrl[1];
     if (n_g == 0 || n_g > GAP_DEV_MAX || p.ctrl[0]) {
-        if (threadIdx.x == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
             p.ctrl[7] = 0;
             if (n_g > GAP_DEV_MAX) p.ctrl[6] = 1;
         }
         return;
     }
-    // the long stretches first (about one batch in two has one at 10 candidates per window)
-    if (threadIdx.x == 0) n_big = 0;
-    if (threadIdx.x < 20) tab[threadIdx.x] = p.fx.tab.e[threadIdx.x];
-    __syncthreads();
-    for (uint32_t j = threadIdx.x; j < n_g; j += GPB) {
-        const uint4 g = p.fx.gaps[j];
-        if (g.z - g.y + 1u > GAP_DEV_NSMALL && g.z - g.y + 1u <= GAP_DEV_NMAX) atomicAdd(&n_big, 1u);
-    }
-    __syncthreads();
-    // up to GAP_BIG_LIST long stretches are walked here (random sequence: about one batch in two has one); a batch with more
-    // of them is repeat-rich sequence, whose long stretches all go to the host's tile kernel
-    const bool walk = n_big <= GAP_BIG_LIST;
-    __syncthreads();
-    if (threadIdx.x == 0) n_big = 0;
-    __syncthreads();
-    for (uint32_t j = threadIdx.x; j < n_g; j += GPB) {
-        const uint4 g = p.fx.gaps[j];
-        if (g.z - g.y + 1u > GAP_DEV_NSMALL) {
-            if (walk && g.z - g.y + 1u <= GAP_DEV_NMAX) {
-                big_list[atomicAdd(&n_big, 1u)] = j;
-            } else {
-                p.fx.r_key[j] = ((uint64_t)g.x << 32) | g.y;
-                p.fx.r_cnt[j] = 0;
-                defer_stretch(p.fx, g);
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t nb = n_big;
-    for (uint32_t q = 0; q < min(nb, GAP_BIG_LIST); ++q) {
-        uint64_t *lh = reinterpret_cast<uint64_t *>(p.big_work);
-        uint16_t *lidx0 = reinterpret_cast<uint16_t *>(p.big_work + GAP_DEV_NMAX * 2), *lidx1 = lidx0 + GAP_DEV_NMAX;
-        uint32_t *selbits = p.big_work + GAP_DEV_NMAX * 3, *lw = selbits + GAP_DEV_NMAX / 32;
-        gap_fix_one<VARIANT>(p.fx, big_list[q], GAP_DEV_NMAX, lh, lidx0, lidx1, selbits, lw, sh, tab, &drop_idx);
-        __threadfence();
-        __syncthreads();  // (the work arrays are reused; what this block wrote to global memory is read below)
-    }
-    // rank by counting (the keys (contig, first k-mer) are distinct), 512 keys at a time through 4 KB of LDS: with all
-    // GAP_DEV_MAX keys in LDS (16 KB) the block often waited tens of microseconds for a CU with that much room.  Every
-    // thread asks for its keys AND their stretches' counts at once; with at most CH stretches (the usual case) the counts
-    // reach their ranks through LDS, so that nothing written here is read back from global memory.
-    constexpr uint32_t PERK = GAP_DEV_MAX / GPB, CH = 512;
-    __shared__ uint32_t cnt_sorted[CH];
-    uint64_t mine[PERK];
-    uint32_t rank[PERK], mcnt[PERK];
-#pragma unroll
-    for (uint32_t u = 0; u < PERK; ++u) {
-        const uint32_t i = threadIdx.x + u * GPB;
-        mine[u] = i < n_g ? p.r_key[i] : ~0ull;
-        mcnt[u] = i < n_g ? p.r_cnt[i] : 0u;
-        rank[u] = 0;
-    }
+    if (blockIdx.x * GP_PER >= n_g) return;
+    const uint32_t i = blockIdx.x * GP_PER + (threadIdx.x & (GP_PER - 1u)), quarter = threadIdx.x / GP_PER;
+    const bool on = i < n_g;
+    const uint64_t mine = on ? p.r_key[i] : ~0ull;
+    uint32_t rank = 0, off = 0, total = 0;
     for (uint32_t c0 = 0; c0 < n_g; c0 += CH) {
         const uint32_t cn = min(CH, n_g - c0);
         __syncthreads();
-        for (uint32_t q = threadIdx.x; q < cn; q += GPB) keys[q] = p.r_key[c0 + q];
-        __syncthreads();
-#pragma unroll
-        for (uint32_t u = 0; u < PERK; ++u)
-            if (threadIdx.x + u * GPB < n_g)
-                for (uint32_t q = 0; q < cn; ++q) rank[u] += keys[q] < mine[u] ? 1u : 0u;
-    }
-    const bool small = n_g <= CH;
-#pragma unroll
-    for (uint32_t u = 0; u < PERK; ++u) {
-        const uint32_t i = threadIdx.x + u * GPB;
-        if (i < n_g) {
-            p.s_key[rank[u]] = mine[u];
-            p.s_src[rank[u]] = i;
-            if (small) cnt_sorted[rank[u]] = mcnt[u];
+        for (uint32_t q = threadIdx.x; q < cn; q += GPB) {
+            keys[q] = p.r_key[c0 + q];
+            cnts[q] = p.r_cnt[c0 + q];
         }
+        __syncthreads();
+        const uint32_t q_lo = cn * quarter / 4u, q_hi = cn * (quarter + 1u) / 4u;
+        for (uint32_t q = q_lo; q < q_hi; ++q) {
+            const bool less = keys[q] < mine;
+            rank += less ? 1u : 0u;
+            off += less ? cnts[q] : 0u;
+        }
+        if (blockIdx.x == 0)
+            for (uint32_t q = threadIdx.x; q < cn; q += GPB) total += cnts[q];
     }
-    if (!small) __threadfence();
+    part_rank[threadIdx.x] = rank;
+    part_off[threadIdx.x] = off;
     __syncthreads();
-    constexpr uint32_t PER = GAP_DEV_MAX / GPB;
-    uint32_t c[PER], tot = 0;
-    for (uint32_t u = 0; u < PER; ++u) {
-        const uint32_t r = threadIdx.x * PER + u;
-        c[u] = r < n_g ? (small ? cnt_sorted[r] : p.r_cnt[p.s_src[r]]) : 0u;
-        tot += c[u];
+    if (quarter == 0 && on) {
+        const uint32_t t = threadIdx.x;
+        const uint32_t r = part_rank[t] + part_rank[t + GP_PER] + part_rank[t + 2u * GP_PER] + part_rank[t + 3u * GP_PER];
+        p.s_key[r] = mine;
+        p.s_src[r] = i;
+        p.s_off[r] = part_off[t] + part_off[t + GP_PER] + part_off[t + 2u * GP_PER] + part_off[t + 3u * GP_PER];
     }
-    uint32_t run = block_exclusive<GPB / 64>(tot, sh);
-    for (uint32_t u = 0; u < PER; ++u) {
-        const uint32_t r = threadIdx.x * PER + u;
-        if (r < n_g) p.s_off[r] = run;
-        run += c[u];
-    }
-    if (threadIdx.x == 0) {
-        p.ctrl[7] = sh[255];
-        p.s_off[n_g] = sh[255];
+    if (blockIdx.x == 0) {  // the sum of all counts
+        __syncthreads();
+        part_rank[threadIdx.x] = total;
+        __syncthreads();
+        for (uint32_t st = GPB / 2; st > 0; st >>= 1) {
+            if (threadIdx.x < st) part_rank[threadIdx.x] += part_rank[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            p.ctrl[7] = part_rank[0];
+            p.s_off[n_g] = part_rank[0];
+        }
     }
 }
 
@@ -2359,13 +2318,7 @@ struct Driver {
         pp.s_key = sc(SC_GD_HASH).as<uint64_t>();
         pp.s_off = sc(SC_GD_POS).as<uint32_t>();
         pp.s_src = sc(SC_GD_REC).as<uint32_t>();
-        pp.fx = gp;
-        MXG_HIP(h, sc(SC_GB_WORK).ensure((size_t)GAP_BIG_WORK_WORDS * 4));
-        pp.big_work = sc(SC_GB_WORK).as<uint32_t>();
-        if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-            hipLaunchKernelGGL(k_gap_post<MXG_VARIANT_V1_MIN>, dim3(1), dim3(GPB), 0, st, pp);
-        else
-            hipLaunchKernelGGL(k_gap_post<MXG_VARIANT_V2_SUM>, dim3(1), dim3(GPB), 0, st, pp);
+        hipLaunchKernelGGL(k_gap_post, dim3(GAP_POST_BLOCKS), dim3(GPB), 0, st, pp);
         MXG_HIP(h, hipGetLastError());
         return MXG_OK;
     }
@@ -3078,7 +3031,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         // attempt (a batch did not end the common way: slices beyond their queues, stretches beyond the device route) and run
         // tables with short runs between invalid bases take count -> reorder -> resolve behind the same bitmap
         bool use_bs = bs_env && bs_possible(h, list[i]);
-        bool sel_ok = use_bs && bs_select && attempt == 0;
+        bool sel_ok = use_bs && bs_select && (attempt == 0 || list[i]->sel_again);
         if (use_bs) {
             if ((rc = bs_prepare(h, list[i])) != MXG_OK) return rc;
             use_bs = list[i]->bs_ready;
@@ -3330,7 +3283,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             a->n_mx = out.n;
             a->has_sketch = true;
             state[i] = 2;
-        } else if (q1 - q0 > 1 && !chain_modes && !final) {
+        } else if ((q1 - q0 > 1 || (items[q0].bs && plans[i].dev_gaps)) && !chain_modes && !final) {
             // several batches, first attempt: once more through the streams (a few ms per Gbp; the synchronous route costs
             // ten times that), with batches sized for the stretch density just seen (gap_rate_hint, above), every grid sized by
             // the batch's own candidate count where it reported one, and slices as large as the largest wave asked for
@@ -3338,6 +3291,11 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 const uint32_t *c = items[q].hc;
                 if (c[0] != 0 && c[0] != 0xFFFFFFFFu) h->arena_cap_hint = std::max<uint64_t>(h->arena_cap_hint, (uint64_t)c[0] + 64);
             }
+            // (k_bs_select again unless the slice kernel itself gave up somewhere -- a slice beyond its queue with no region left,
+            // more selected candidates than a slice's room: word 12 -- and not merely more stretches than a batch holds)
+            a->sel_again = true;
+            for (size_t q = q0; q < q1; ++q)
+                if (items[q].bs && items[q].hc[12] != 0) a->sel_again = false;
             a->cand_hints.clear();  // (the batches will be cut differently)
             a->cand_hint = 0xFFFFFFFEu;
             a->full_grid_once = true;

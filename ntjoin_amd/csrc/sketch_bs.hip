@@ -500,7 +500,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     if (touch == 0x9E3779B9u && p.w == 0) p.ctrl[15] = touch;  // (never: the words requested ahead are not used for anything)
     if (lane == 0) {
         if (own_w) atomicAdd(&p.cand_spread[((blockIdx.x * nwv + wib) & 63u) * 32u], own_w);
-        if (flag) p.ctrl[6] = 1;
+        if (flag) p.ctrl[6] = p.ctrl[13] = 1;  // ([13]: it was this kernel that gave up)
     }
 }
 

@@ -9,6 +9,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, "tests", "golden")
+# the CLIs under test: MXG_BIN_DIR points at another build of them (the sanitizer builds of ntjoin_amd/csrc/Makefile)
+BIN_DIR = os.environ.get("MXG_BIN_DIR") or os.path.join(REPO, "ntjoin_amd", "bin")
 
 
 def pytest_configure(config):

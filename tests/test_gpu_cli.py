@@ -7,10 +7,10 @@ import subprocess
 import pytest
 
 from oracle import graph_oracle as go
-from tests.conftest import GOLDEN, REPO, load_case
+from tests.conftest import BIN_DIR, GOLDEN, REPO, load_case
 
 pytestmark = pytest.mark.gpu
-INDEXLR = os.path.join(REPO, "ntjoin_amd", "bin", "indexlr")
+INDEXLR = os.path.join(BIN_DIR, "indexlr")
 FASTA = os.path.join(GOLDEN, "fasta")
 
 
@@ -125,7 +125,7 @@ def test_one_process_route_is_byte_identical_to_the_two_process_route(tmp_path, 
 
 
 def test_mxgraph_cli_failures_are_loud(tmp_path):
-    exe = os.path.join(REPO, "ntjoin_amd", "bin", "mxgraph")
+    exe = os.path.join(BIN_DIR, "mxgraph")
     fa = tmp_path / "a.fa"
     fa.write_text(">x\n" + "ACGT" * 100 + "\n")
     r = subprocess.run([exe, "-k", "32", "-w", "10", "-s", str(fa), "-r", "1 2", str(fa)], capture_output=True, text=True)

@@ -8,7 +8,7 @@ import sys
 
 import pytest
 
-from tests.conftest import REPO
+from tests.conftest import BIN_DIR, REPO
 
 pytestmark = pytest.mark.gpu
 
@@ -118,7 +118,7 @@ def test_run_dist_ranks_on_one_gpu(tmp_path, world, split):
     one.mkdir()
     for a in asms:
         shutil.copy(os.path.join(fasta_dir, a["fasta"]), one / a["fasta"])
-    subprocess.check_call([os.path.join(REPO, "ntjoin_amd", "bin", "mxgraph"), "-k", str(meta["k"]), "-w", str(meta["w"]), "-p", "out",
+    subprocess.check_call([os.path.join(BIN_DIR, "mxgraph"), "-k", str(meta["k"]), "-w", str(meta["w"]), "-p", "out",
                            "-s", meta["target"]["fasta"], "-l", str(meta["target"]["weight"]), "-r",
                            " ".join(str(a["weight"]) for a in meta["refs"])] + [a["fasta"] for a in meta["refs"]], cwd=one)
     assert filecmp.cmp(str(tmp_path / "out.mx.dot"), str(one / "out.mx.dot"), shallow=False)

@@ -12,7 +12,7 @@ import pytest
 
 from ntjoin_amd.engine import MxEngine
 from tests import _oracle
-from tests.conftest import REPO
+from tests.conftest import BIN_DIR, REPO
 
 pytestmark = pytest.mark.gpu
 
@@ -106,7 +106,7 @@ def test_cli_threads_and_strand_column(tmp_path):
     orc = _oracle.load()
     fa = str(tmp_path / "m.fa")
     _write_fasta(fa, _messy_records(9), width=80)
-    exe = os.path.join(REPO, "ntjoin_amd", "bin", "indexlr")
+    exe = os.path.join(BIN_DIR, "indexlr")
     want = str(tmp_path / "want.tsv")
     orc.fasta_to_tsv(fa, want, 32, 100)
     for t in ("1", "4", "48"):
@@ -163,7 +163,7 @@ def test_gzip_fasta_input(tmp_path):
         dst.write(src.read())
     want = str(tmp_path / "want.tsv")
     orc.fasta_to_tsv(fa, want, 32, 100)
-    exe = os.path.join(REPO, "ntjoin_amd", "bin", "indexlr")
+    exe = os.path.join(BIN_DIR, "indexlr")
     out = subprocess.run([exe, "--seq", "--long", "--pos", "-k32", "-w100", "-t2", gz], capture_output=True, check=True).stdout
     assert out == open(want, "rb").read()
     parts = []

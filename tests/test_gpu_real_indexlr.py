@@ -8,10 +8,10 @@ import subprocess
 
 import pytest
 
-from tests.conftest import GOLDEN, REPO
+from tests.conftest import BIN_DIR, GOLDEN, REPO
 
 pytestmark = pytest.mark.gpu
-OURS = os.path.join(REPO, "ntjoin_amd", "bin", "indexlr")
+OURS = os.path.join(BIN_DIR, "indexlr")
 
 
 def _real_indexlr():
