@@ -563,6 +563,7 @@ def main():
                                        ("graph stage partitioned by hash range (RCCL all-to-all)" if graph_mode == "partitioned"
                                         else "RCCL all-gather of sketches, graph of the union on every rank"))},
             "kernel_sources_digest": kernel_sources_digest(),
+            "knobs_in_force": eng.knobs(),  # MXG_* environment switches the handle read and found set ("" = library defaults)
             "resident_input": "2-bit packed bases (0.25 B/bp) as handed over through mxg_add_assembly_packed_device*; every step reads them as they are",
             "step_ms_min_max": [round(min(step_times) * 1e3, 4), round(max(step_times) * 1e3, 4)],
             "roofline": {"bound": "hbm",

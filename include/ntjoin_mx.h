@@ -424,6 +424,11 @@ int mxg_synth_write_fasta(const char *path, const uint32_t *packed, const uint64
 /* ---- introspection ----------------------------------------------------------------------------- */
 int mxg_get_stats(mxg_handle *h, mxg_stats *out);
 int mxg_reset_timers(mxg_handle *h);
+/* The environment knobs (README: MXG_* tuning / test / profiling switches) this handle has read and found SET, as
+   "NAME=value NAME=value ..." sorted by name.  A knob is parsed once per handle, at its first use, so this is what the
+   handle really ran with.  Returns the text's length; writes at most cap - 1 bytes + NUL (buf may be NULL).  No reference
+   counterpart (bench.py records it next to every number). */
+size_t mxg_knobs(mxg_handle *h, char *buf, size_t cap);
 
 #ifdef __cplusplus
 }

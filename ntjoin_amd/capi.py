@@ -21,7 +21,7 @@ SYMBOLS = [
     "mxg_sketch", "mxg_sketch_graph", "mxg_get_sketch", "mxg_get_sketch_device", "mxg_compute_strands", "mxg_set_sketch_device",
     "mxg_pack_sketch_device", "mxg_set_sketch_gathered", "mxg_set_sketch_gathered_strided", "mxg_write_tsv",
     "mxg_build_graph", "mxg_get_mx_flags", "mxg_get_graph", "mxg_find_paths", "mxg_path_segments", "mxg_mx_extremes", "mxg_dg_owner_counts", "mxg_dg_pack_items", "mxg_dg_set_items", "mxg_dg_vertices", "mxg_dg_item_results", "mxg_dg_msg_counts", "mxg_dg_pack_msgs", "mxg_dg_edges", "mxg_dg_pack_slots", "mxg_dg_owner_slots", "mxg_dg_slot_results", "mxg_dg_pack_msg_slots", "mxg_dg_edges_slots", "mxg_write_dot", "mxg_write_outputs", "mxg_dot_part_format", "mxg_dot_part_write",
-    "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers",
+    "mxg_py_repr_double", "mxg_py_repr_str", "mxg_get_stats", "mxg_reset_timers", "mxg_knobs",
     "mxg_synth_fill_packed_device", "mxg_synth_fill_packed_host", "mxg_synth_write_fasta",
     "mxg_plan_split", "mxg_add_assembly_packed_device_pieces", "mxg_dg_last_shared", "mxg_dg_set_ghosts",
 ]
@@ -198,6 +198,8 @@ def load():
     L.mxg_py_repr_str.restype = C.c_size_t
     L.mxg_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mxg_reset_timers.argtypes = [vp]
+    L.mxg_knobs.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.mxg_knobs.restype = C.c_size_t
     L.mxg_synth_fill_packed_device.argtypes = [vp, u64, vp, u64, u64, u64, C.c_uint32, i32]
     L.mxg_synth_fill_packed_host.argtypes = [vp, u64, vp, u64, u64, u64, C.c_uint32, C.c_uint32]
     L.mxg_synth_write_fasta.argtypes = [cp, vp, vp, vp, u64, cp, C.c_uint32, C.c_uint32]

@@ -152,7 +152,7 @@ int mxg_add_assembly_fasta(mxg_handle *h, const char *name, double weight, const
     if (!fasta_path) return commit(h, a, set_err(h, MXG_EINVAL, "fasta_path is NULL"));
     try {
         // regular files: raw text to HBM, classified and packed there (ingest.hip); MXG_HOST_INGEST=1 keeps the host parser
-        rc = getenv("MXG_HOST_INGEST") ? 1 : load_fasta_device(h, a, fasta_path, host_threads(h));
+        rc = knob_set(h, "MXG_HOST_INGEST") ? 1 : load_fasta_device(h, a, fasta_path, host_threads(h));
         if (rc == 1) {
             Assembly *fresh;
             delete a;
@@ -1038,6 +1038,20 @@ int mxg_get_stats(mxg_handle *h, mxg_stats *out)
     s.ms_edges = h->tm.ms_edges;
     *out = s;
     return MXG_OK;
+}
+
+size_t mxg_knobs(mxg_handle *h, char *buf, size_t cap)
+{
+    if (!h) return 0;
+    std::string r;
+    for (const auto &kv : h->knobs)  // (a std::map: sorted by name)
+        if (kv.second.set) r += (r.empty() ? "" : " ") + kv.first + "=" + kv.second.raw;
+    if (buf && cap) {
+        const size_t n = std::min(r.size(), cap - 1);
+        memcpy(buf, r.data(), n);
+        buf[n] = 0;
+    }
+    return r.size();
 }
 
 int mxg_reset_timers(mxg_handle *h)

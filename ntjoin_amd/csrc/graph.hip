@@ -846,14 +846,14 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
     const uint32_t mask = cap - 1;
     const uint32_t full = (A == 32) ? 0xFFFFFFFFu : ((1u << A) - 1u);
     // the join: LDS tables per hash partition (the whole-stage call, up to PJ_MAX_P partitions of <= 1280 records), else
-    // the global table.  MXG_GRAPH_JOIN=global|lds and MXG_PJ_FORCE_FAIL=1 are test knobs (read per call).
+    // the global table.  MXG_GRAPH_JOIN=global|lds and MXG_PJ_FORCE_FAIL=1 are test knobs (knob_*: as the handle first saw them).
     uint32_t P = 256;
     while ((uint64_t)P * 1280 < N) P <<= 1;
-    const char *join_env = getenv("MXG_GRAPH_JOIN");
+    const char *join_env = knob_raw(h, "MXG_GRAPH_JOIN");
     // beyond PJ_MAX_P partitions of <= 1280 records: two levels -- P1 coarse partitions, each sorted into 256 sub-partitions
     // (MXG_PJ_TWO_LEVEL=1 forces them on small inputs: test knob)
     uint32_t P1 = 0, cap1 = 0, rows2 = 0;
-    if (P > PJ_MAX_P || (getenv("MXG_PJ_TWO_LEVEL") && atoi(getenv("MXG_PJ_TWO_LEVEL")))) {
+    if (P > PJ_MAX_P || knob_u64(h, "MXG_PJ_TWO_LEVEL", 0)) {
         P = 256;
         P1 = 2;
         while ((uint64_t)P1 * P * 1000 < N) P1 <<= 1;
@@ -865,7 +865,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
     // (k_pj_join's verdict word carries the index of the key's minimizer in assembly 0 above three flag bits: < 2^29)
     const bool pj = mode == GRAPH_FULL && !global_table && (P1 == 0 || two_level) && P <= PJ_MAX_P &&
                     (uint64_t)n_of[0] < (1ull << 29) && !(join_env && !strcmp(join_env, "global"));
-    const uint32_t pj_force_fail = getenv("MXG_PJ_FORCE_FAIL") && atoi(getenv("MXG_PJ_FORCE_FAIL")) ? 1u : 0u;
+    const uint32_t pj_force_fail = knob_u64(h, "MXG_PJ_FORCE_FAIL", 0) ? 1u : 0u;
 
     if (!pj) MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * sizeof(Slot)));  // (the partitioned join keeps its N records here)
     // global table: slot -> vertex id; partitioned join: assembly 0's shared mask (8 B per 64 minimizers) + block prefix

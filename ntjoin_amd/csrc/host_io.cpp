@@ -36,6 +36,34 @@ int set_err(mxg_handle *h, int code, const char *fmt, ...)
     return code;
 }
 
+static const mxg_handle::Knob &knob_of(const mxg_handle *h, const char *name)
+{
+    auto &m = const_cast<mxg_handle *>(h)->knobs;  // (a cache: filling it does not change what the handle does)
+    auto it = m.find(name);
+    if (it == m.end()) {
+        mxg_handle::Knob k;
+        const char *e = getenv(name);
+        if (e && *e) {
+            k.set = true;
+            k.raw = e;
+            k.value = strtoull(e, nullptr, 10);
+        }
+        it = m.emplace(name, k).first;
+    }
+    return it->second;
+}
+uint64_t knob_u64(const mxg_handle *h, const char *name, uint64_t dflt)
+{
+    const mxg_handle::Knob &k = knob_of(h, name);
+    return k.set ? k.value : dflt;
+}
+bool knob_set(const mxg_handle *h, const char *name) { return knob_of(h, name).set; }
+const char *knob_raw(const mxg_handle *h, const char *name)
+{
+    const mxg_handle::Knob &k = knob_of(h, name);
+    return k.set ? k.raw.c_str() : nullptr;
+}
+
 // ---- ntHash constants ---------------------------------------------------
 static const uint64_t SEED[4] = {0x3c8bfbb395c60474ULL, 0x3193c18562a02b4cULL, 0x20323ed082572324ULL,
                                  0x295549f54be24456ULL};  // A C G T
@@ -885,7 +913,7 @@ int write_tsv(mxg_handle *h, Assembly *a, const char *path, int with_pos, int wi
     // Text formatted on the device (ingest.hip) unless the k-mer column must come from text kept on the HOST (records
     // handed over in buffers, sharded loads) or nothing on the device can spell the k-mers.  MXG_HOST_TSV=1: host writer.
     const bool whole = a->shard_lo == 0 && a->shard_hi >= a->recs.size();
-    if (a->has_sketch && !a->has_text && whole && h->cfg.k <= 200 && !getenv("MXG_HOST_TSV") &&
+    if (a->has_sketch && !a->has_text && whole && h->cfg.k <= 200 && !knob_set(h, "MXG_HOST_TSV") &&
         (!with_seq || a->text_on_device || (a->has_bases && a->d_packed && !a->foreign_sketch)))
         return write_tsv_device(h, a, path, with_pos, with_strand, with_seq);
     int rc = sync_sketch_to_host(h, a);

@@ -359,8 +359,7 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
     }
     MXG_HIP(h, hipMemsetAsync(a->d_packed_own.p, 0, a->packed_words * 4, st));
     // changes between valid and invalid bases inside the tiles; MXG_INGEST_EV_CAP: test knob
-    const char *ev_env = getenv("MXG_INGEST_EV_CAP");
-    const uint32_t EV_CAP = ev_env && *ev_env ? (uint32_t)std::max(1, atoi(ev_env)) : 4u << 20;
+    const uint32_t EV_CAP = (uint32_t)std::max<uint64_t>(1, knob_u64(h, "MXG_INGEST_EV_CAP", 4u << 20));
     std::vector<uint8_t> fv(n_items), lv(n_items);
     std::vector<IngEvent> events;
     if (n_items) {

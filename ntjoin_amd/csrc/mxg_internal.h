@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -243,6 +244,14 @@ struct mxg_handle {
     mxg::DevBuf g_keys, g_cnt, g_vid, g_ctl, g_vhash, g_vpos, g_vrec, g_fv, g_frec, g_nxt, g_prv, g_eflag,
         g_ebs, g_eu, g_ev, g_esup, g_ew;  // indexed by mxg::Scratch (sketch.hip) / graph.hip's own enum
     uint64_t arena_cap_hint = 0;
+    // environment knobs (README: tuning / test / profiling switches), each parsed ONCE per handle, at its first use: what a
+    // handle ran with is what mxg_knobs reports, whatever the environment says later
+    struct Knob {
+        bool set = false;
+        uint64_t value = 0;
+        std::string raw;
+    };
+    std::map<std::string, Knob> knobs;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_g[2] = {nullptr, nullptr};  // MXG_FLAG_TIMING_FINE: after the join, after vertices + adjacency
     uint64_t *pinned_dg = nullptr;    // dgraph.hip: pinned copy of the per-destination counters
@@ -260,6 +269,10 @@ struct mxg_handle {
 namespace mxg {
 
 int set_err(mxg_handle *h, int code, const char *fmt, ...);
+// environment knob `name` as the handle first saw it (host_io.cpp): its value, or dflt when it is unset / empty
+uint64_t knob_u64(const mxg_handle *h, const char *name, uint64_t dflt);
+bool knob_set(const mxg_handle *h, const char *name);
+const char *knob_raw(const mxg_handle *h, const char *name);  // the text it was set to, or nullptr
 // a helper thread of the library points this at a string of its own: set_err then leaves the handle's message alone (host_io.cpp)
 extern thread_local std::string *tl_err_sink;
 constexpr size_t PIN_POOL_BYTES = 128ull << 20;

@@ -1754,10 +1754,10 @@ constexpr int S_DENSE = 128;
 // long strips spread a wave's loads over more cache lines and leave fewer waves per SIMD on small inputs.  Measured on
 // MI355X (tools/sweep_S.sh, sketch+graph, k=32 w=1000): 2 x 100 Mbp 569 / 578 / 584 / 588 / 556 Gbp/s and 2 x 1 Gbp
 // 659 / 675 / 683 / 689 / 581 Gbp/s at S = 192 / 256 / 320 / 384 / 512; the hash kernel alone is fastest at 192-256.
-static uint32_t choose_sparse_S(uint64_t total_kmers)
+static uint32_t choose_sparse_S(const mxg_handle *h, uint64_t total_kmers)
 {
-    const char *e = getenv("MXG_SPARSE_S");
-    if (e && atoi(e) >= 16) return std::min(1024, (atoi(e) + 15) / 16 * 16);
+    const uint64_t e = knob_u64(h, "MXG_SPARSE_S", 0);
+    if (e >= 16) return (uint32_t)std::min<uint64_t>(1024, (e + 15) / 16 * 16);
     const uint64_t lanes = 1024ull * 64;  // SIMDs x lanes
     // small inputs: keep at least ~4 waves per SIMD in flight
     uint64_t S = (total_kmers + lanes * 4 - 1) / (lanes * 4);
@@ -1766,13 +1766,9 @@ static uint32_t choose_sparse_S(uint64_t total_kmers)
 }
 // batch sizes (whole records; a single record may exceed them).  Test knobs (environment, read per call):
 // MXG_DENSE_BATCH_KMERS / MXG_SPARSE_BATCH_KMERS shrink the batches, MXG_WAVE_CAP forces the arena-overflow retry.
-static uint64_t env_u64(const char *name, uint64_t dflt)
-{
-    const char *e = getenv(name);
-    return (e && *e) ? strtoull(e, nullptr, 10) : dflt;
-}
-#define DENSE_BATCH_KMERS env_u64("MXG_DENSE_BATCH_KMERS", 96ull << 20)    /* dense arena = 16 B per k-mer */
-#define SPARSE_BATCH_KMERS env_u64("MXG_SPARSE_BATCH_KMERS", 512ull << 20) /* < 2^31 k-mers per batch; measured on MI355X
+static uint64_t env_u64(const mxg_handle *h, const char *name, uint64_t dflt) { return knob_u64(h, name, dflt); }
+#define DENSE_BATCH_KMERS env_u64(h, "MXG_DENSE_BATCH_KMERS", 96ull << 20)    /* dense arena = 16 B per k-mer */
+#define SPARSE_BATCH_KMERS env_u64(h, "MXG_SPARSE_BATCH_KMERS", 512ull << 20) /* < 2^31 k-mers per batch; measured on MI355X
    (3 Gbp + 3 Gbp, k=32 w=1000): 985 / 968 / 931 Gbp/s at 512 Mi / 1 Gi / 2040 Mi k-mers per batch */
 constexpr uint32_t GAP_CAP = 1u << 20;
 
@@ -1962,7 +1958,7 @@ struct Driver {
             hipLaunchKernelGGL((k_resolve<true, true, 2>), dim3(blocks), dim3(RK), 0, st, rp);
         else if (abl == 3)
             hipLaunchKernelGGL((k_resolve<true, true, 3>), dim3(blocks), dim3(RK), 0, st, rp);
-        else if (env_u64("MXG_RH", few_cand ? 32 : 64) == 32)  // halo of 32 candidates: enough for <= 12 per window (976 -> 985 Gbp/s)
+        else if (env_u64(h, "MXG_RH", few_cand ? 32 : 64) == 32)  // halo of 32 candidates: enough for <= 12 per window (976 -> 985 Gbp/s)
             hipLaunchKernelGGL((k_resolve<true, true, 0, 32>), dim3(blocks), dim3(RK), 0, st, rp);
         else
             hipLaunchKernelGGL((k_resolve<true, true>), dim3(blocks), dim3(RK), 0, st, rp);
@@ -2261,7 +2257,7 @@ struct Driver {
         uint64_t wave_cap = (uint64_t)(2.0 * expect + 6.0 * std::sqrt(expect)) + 64;
         wave_cap = std::max<uint64_t>(wave_cap, h->arena_cap_hint);
         wave_cap = std::min<uint64_t>(wave_cap, 64ull * S);  // a wave can never produce more
-        if (h->arena_cap_hint == 0) wave_cap = env_u64("MXG_WAVE_CAP", wave_cap);  // test knob
+        if (h->arena_cap_hint == 0) wave_cap = env_u64(h, "MXG_WAVE_CAP", wave_cap);  // test knob
         return wave_cap;
     }
     // Enqueue one batch completely (hash -> order -> resolve+count -> speculative emit at out.n); the last kernel writes
@@ -2271,7 +2267,7 @@ struct Driver {
     uint32_t sparse_grid(uint32_t n_tiles, uint64_t nk) const
     {
         (void)nk;
-        const uint64_t bpc = env_u64("MXG_HASH_BPC", 0);
+        const uint64_t bpc = env_u64(h, "MXG_HASH_BPC", 0);
         if (bpc == 0 || n_tiles <= 256 * bpc) return n_tiles;
         const uint32_t rounds = (uint32_t)std::max<uint64_t>(1, (n_tiles + 128 * bpc) / (256 * bpc));  // nearest
         return (n_tiles + rounds - 1) / rounds;
@@ -2334,7 +2330,7 @@ struct Driver {
             TimingGuard(bool &t_, bool now) : t(t_), saved(t_) { t = now; }
             ~TimingGuard() { t = saved; }
         };
-        const uint64_t t_sample = timing && !fine && io ? env_u64("MXG_TIMING_SAMPLE", 1) : 1;
+        const uint64_t t_sample = timing && !fine && io ? env_u64(h, "MXG_TIMING_SAMPLE", 1) : 1;
         TimingGuard timing_guard(timing, timing && (t_sample <= 1 || (h->timing_batches++ % t_sample) == 0));
         const uint32_t S = a->S_sparse;
         few_cand = (double)tau_hi / 4294967296.0 * (double)h->cfg.w <= 12.5;
@@ -2365,11 +2361,11 @@ struct Driver {
         sp.strip_hi = g.strip_hi;
         sp.k = h->cfg.k;
         sp.S = S;
-        sp.five = env_u64("MXG_HASH_FIVE", 1) != 0 ? 1u : 0u;
+        sp.five = env_u64(h, "MXG_HASH_FIVE", 1) != 0 ? 1u : 0u;
         // MXG_RING_SLACK=<percent> (test knob): the ring filter captures up to that many percent more k-mers than have
         // hash < tau, i.e. entries that k_reorder finds to be >= tau and k_resolve must treat as absent.  On real runs
         // such entries occur about once per 10^9 k-mers, so the tests force them.
-        const uint32_t ring_slack = (uint32_t)env_u64("MXG_RING_SLACK", 0);  // read per call, like the other knobs
+        const uint32_t ring_slack = (uint32_t)env_u64(h, "MXG_RING_SLACK", 0);  // read per call, like the other knobs
         sp.tau_hi = ring_slack ? (uint32_t)std::min<uint64_t>(0x7FFFFFFEull, (uint64_t)tau_hi * (100 + ring_slack) / 100) & ~1u
                                : tau_hi;
         sp.wave_cap = (uint32_t)wave_cap;
@@ -2383,13 +2379,13 @@ struct Driver {
         const uint32_t queue_cap = sp.wave_cap <= 8192 ? sp.wave_cap : 0;
         const size_t q_lds = (size_t)queue_cap * 4;
         // slices per block (MXG_REORDER_G): the block's byte table is loaded once for all of them
-        const uint32_t r_g = (uint32_t)std::max<uint64_t>(1, env_u64("MXG_REORDER_G", 1));
+        const uint32_t r_g = (uint32_t)std::max<uint64_t>(1, env_u64(h, "MXG_REORDER_G", 1));
         const uint32_t r_grid = (g.n_waves + r_g - 1) / r_g;
         // one wave per slice + position tables when the queues of a block fit beside the 32 KB of tables
         const size_t w_lds = (size_t)2048 * 16 + (size_t)RW_WAVES * queue_cap * 4;
-        const bool r_wave = queue_cap && w_lds + 512 <= 65536 && env_u64("MXG_REORDER_W", 1) != 0;
+        const bool r_wave = queue_cap && w_lds + 512 <= 65536 && env_u64(h, "MXG_REORDER_W", 1) != 0;
         const uint32_t w_grid = std::min<uint32_t>((g.n_waves + RW_WAVES - 1) / RW_WAVES,
-                                                   (uint32_t)env_u64("MXG_REORDER_W_GRID", 256 * 3));
+                                                   (uint32_t)env_u64(h, "MXG_REORDER_W_GRID", 256 * 3));
         if (!r_wave || !T.d_strip_run) bs_bitmap = nullptr;  // (a batch whose slices outgrow the LDS queues takes the rolling-hash kernel)
         if (!bs_bitmap) MXG_HIP(h, sc(SC_ARENA).ensure((size_t)n_cap * 8));
         sp.arena = sc(SC_ARENA).as<uint2>();
@@ -2408,7 +2404,7 @@ struct Driver {
         // 24 KB: 1285-1308 Gbp/s against 1304-1331; none: 1257).  It also keeps the other stream's kernels from moving in
         // beside this one, which costs both more than it gains.  Small inputs (cache-resident) keep full occupancy.  At
         // k = 32 the first 16 KB of it hold init32_half's tables.
-        size_t pad = (size_t)env_u64("MXG_HASH_LDS", g.nk >= (256ull << 20) ? 18000 : 0);
+        size_t pad = (size_t)env_u64(h, "MXG_HASH_LDS", g.nk >= (256ull << 20) ? 18000 : 0);
         if (sp.five && sp.k == 32) pad = std::max<size_t>(pad, 16384);
         if (bs_bitmap)  // (k = 32 route: the filter has run over the whole assembly; only its bits are turned into entries)
             hipLaunchKernelGGL(k_bs_count, dim3(g.n_blocks), block, 0, st, sp, bs_bitmap);
@@ -2453,7 +2449,7 @@ struct Driver {
             hipLaunchKernelGGL(k_bs_reorder_w<MXG_VARIANT_V2_SUM>, dim3(w_grid), dim3(RW_WAVES * 64), w_lds, st, op);
         else if (r_wave && h->cfg.variant == MXG_VARIANT_V1_MIN)
             hipLaunchKernelGGL(k_reorder_w<MXG_VARIANT_V1_MIN>, dim3(w_grid), dim3(RW_WAVES * 64), w_lds, st, op);
-        else if (r_wave && !getenv("MXG_ABLATE_REORDER"))
+        else if (r_wave && !knob_set(h, "MXG_ABLATE_REORDER"))
             hipLaunchKernelGGL(k_reorder_w<MXG_VARIANT_V2_SUM>, dim3(w_grid), dim3(RW_WAVES * 64), w_lds, st, op);
         else if (h->cfg.variant == MXG_VARIANT_V1_MIN)
             hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V1_MIN>, dim3(r_grid), dim3(RB), q_lds, st, op);
@@ -2462,7 +2458,7 @@ struct Driver {
             static const int rabl = getenv("MXG_ABLATE_REORDER") ? atoi(getenv("MXG_ABLATE_REORDER")) : 0;  // profiling only
             if (rabl == 1)
                 hipLaunchKernelGGL((k_reorder<MXG_VARIANT_V2_SUM, 1>), dim3(r_grid), dim3(RB), q_lds, st, op);
-            else if (env_u64("MXG_RB", few_cand ? 256 : RB) == 256)  // ~205 candidates per slice at 10 per window: one pass of 256 threads
+            else if (env_u64(h, "MXG_RB", few_cand ? 256 : RB) == 256)  // ~205 candidates per slice at 10 per window: one pass of 256 threads
                 hipLaunchKernelGGL((k_reorder<MXG_VARIANT_V2_SUM, 0, 256>), dim3(r_grid), dim3(256), q_lds, st, op);
             else
                 hipLaunchKernelGGL(k_reorder<MXG_VARIANT_V2_SUM>, dim3(r_grid), dim3(RB), q_lds, st, op);
@@ -2472,7 +2468,7 @@ struct Driver {
         // (no gap, no overflow) the batch then needs a single host sync
         if ((rc = ev_next(3)) != MXG_OK) return rc;
         grid_cand = 0;
-        if (const uint64_t by_est = io ? env_u64("MXG_GRID_BY_ESTIMATE", 1) : 0) {
+        if (const uint64_t by_est = io ? env_u64(h, "MXG_GRID_BY_ESTIMATE", 1) : 0) {
             // (min(fwd, rev) < tau: either strand may pass)
             const uint64_t expect = (uint64_t)((double)g.nk * (double)sp.tau_hi / 4294967296.0) *
                                     (h->cfg.variant == MXG_VARIANT_V1_MIN ? 2u : 1u);
@@ -2501,7 +2497,7 @@ struct Driver {
     // some stream this one has been made to wait for); one batch = k_bs_select over the batch's strips -> stretches -> emit.
     BsSelGeom sel_geom(const Assembly *a, const BatchGeom &g, double frac) const
     {
-        return bs_select_geom(a->S_sparse, a->sel_H, h->cfg.w, frac, g.n_strips, (uint32_t)env_u64("MXG_SEL_QCAP", 0));
+        return bs_select_geom(a->S_sparse, a->sel_H, h->cfg.w, frac, g.n_strips, (uint32_t)env_u64(h, "MXG_SEL_QCAP", 0));
     }
     int enqueue_sel(Assembly *a, const Tables &T, const BatchGeom &g, const BsSelGeom &b, uint32_t tau_hi, OutArrays &out,
                     uint32_t *ctrl_host, const ChainIO *io)
@@ -2552,7 +2548,7 @@ struct Driver {
         bp.gap_cap = GAP_CAP;
         bp.ctrl = sc(SC_CTRL).as<uint32_t>();
         bp.cand_spread = sel_sup(0) + sup_words(b.n_slices);
-        bp.ablate = (uint32_t)env_u64("MXG_SEL_ABLATE", 0);  // (profiling only: stop every slice after phase n)
+        bp.ablate = (uint32_t)env_u64(h, "MXG_SEL_ABLATE", 0);  // (profiling only: stop every slice after phase n)
         if ((rc = launch_bs_select(h, bp, b, st)) != MXG_OK) return rc;
         h->stat_sel_slices += b.n_slices;
         const bool dev = io && io->dev_gaps;
@@ -2697,7 +2693,7 @@ struct Driver {
         int rc;
         uint64_t n_gap_mx = 0;
         *n_out = n;
-        if (h->cfg.w <= ST_WMAX && !getenv("MXG_STRETCH_DENSE")) {
+        if (h->cfg.w <= ST_WMAX && !knob_set(h, "MXG_STRETCH_DENSE")) {
             if ((rc = sketch_stretches(a, T, gaps, &n_gap_mx)) != MXG_OK) return rc;
             for (const uint4 &g : gaps) h->stat_dense_kmers += g.z - g.y + 1u;
         } else if ((rc = process_gaps(a, T, gaps, &n_gap_mx)) != MXG_OK) {  // (dense_all counts its k-mers itself)
@@ -2786,7 +2782,7 @@ static int prepare_tables(mxg_handle *h, Assembly *a)
     if (n_runs >= (1ull << 31)) return set_err(h, MXG_ELIMIT, "too many valid runs (%zu)", n_runs);
     bool ovf = false;
     build_strip_tables(a->runs, S_DENSE, a->strip0_dense, &ovf);
-    a->S_sparse = choose_sparse_S(a->total_kmers);
+    a->S_sparse = choose_sparse_S(h, a->total_kmers);
     build_strip_tables(a->runs, (int)a->S_sparse, a->strip0_sparse, &ovf);
     if (ovf) return set_err(h, MXG_ELIMIT, "too many strips");
     a->g0.resize(n_runs + 1);
@@ -2905,12 +2901,11 @@ struct SparsePlan {
 static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
 {
     SparsePlan sp;
-    const uint64_t big = env_u64("MXG_DEV_GAPS_MIN_KMERS", 256ull << 20);
+    const uint64_t big = env_u64(h, "MXG_DEV_GAPS_MIN_KMERS", 256ull << 20);
     sp.dev_gaps = a && a->total_kmers >= big && h->cfg.w <= GAP_DEV_NMAX / 2;
-    const char *e = getenv("MXG_DEV_GAPS");
-    if (e && *e) sp.dev_gaps = atoi(e) != 0 && h->cfg.w <= GAP_DEV_NMAX / 2;
+    if (knob_set(h, "MXG_DEV_GAPS")) sp.dev_gaps = knob_u64(h, "MXG_DEV_GAPS", 0) != 0 && h->cfg.w <= GAP_DEV_NMAX / 2;
     // measured on MI355X (3 Gbp + 3 Gbp, w=1000, batches of 512 Mi k-mers): 941 / 985 / 945 / 897 Gbp/s at c = 8 / 10 / 12 / 14
-    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : (sp.dev_gaps ? (uint32_t)env_u64("MXG_DEV_CAND", 10) : 18u);
+    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : (sp.dev_gaps ? (uint32_t)env_u64(h, "MXG_DEV_CAND", 10) : 18u);
     sp.frac = (double)c / (double)h->cfg.w;
     // even: the threshold then falls on the top 31-bit ring of the hash, which is all the sparse kernel rolls
     sp.tau_hi = std::max(2u, (uint32_t)std::min<double>(4294967294.0, sp.frac * 4294967296.0) & ~1u);
@@ -2920,7 +2915,7 @@ static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
     if (sp.dev_gaps) {  // a candidate is followed by a stretch with probability e^-c
         // (a->gap_rate_hint: what earlier sketches of this assembly met, 25 % on top)
         const double per_kmer = std::max(sp.frac * std::exp(-(double)c), a->gap_rate_hint * 1.25);
-        const double lim = (double)env_u64("MXG_GAP_BUDGET", GAP_DEV_MAX / 2) / std::max(per_kmer, 1e-30);  // expected stretches per batch
+        const double lim = (double)env_u64(h, "MXG_GAP_BUDGET", GAP_DEV_MAX / 2) / std::max(per_kmer, 1e-30);  // expected stretches per batch
         sp.gap_kmers = (uint64_t)std::min<double>(std::max<double>(lim, (double)(1u << 20)), 9e18);
         if (lim < (double)SPARSE_BATCH_KMERS) sp.batch_kmers = std::max<uint64_t>((uint64_t)lim, 1u << 20);
     }
@@ -2991,14 +2986,14 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
     // (emit, stretch fix-up) has another batch's hash kernel to run beside.  Two are enough: measured on MI355X at 3 Gbp +
     // 3 Gbp, 1072 / 1076 / 1046 Gbp/s with 2 / 3 / 4 streams -- the sum of the kernels' own times (9 ms per step under
     // rocprofv3) already overlaps into 5.6 ms of wall time
-    uint32_t n_str = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(2, env_u64("MXG_STREAMS", 2)));
+    uint32_t n_str = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(2, env_u64(h, "MXG_STREAMS", 2)));
     for (uint32_t x = 0; x + 2 < n_str; ++x)
         if (!h->stream_x[x]) MXG_HIP(h, hipStreamCreateWithFlags(&h->stream_x[x], hipStreamNonBlocking));
     Driver drv0(h, 0), drv1(h, 1), drv2(h, n_str > 2 ? 2 : 1), drv3(h, n_str > 3 ? 3 : 1);
     // profiling (tools/pmc_r03.sh): every batch on the handle's main stream, so that no two kernels overlap.  Every batch then uses
     // slot 0 (one scratch set, in stream order); the calls that keep one batch per assembly in flight for the stage behind them
     // (mxg_sketch_graph, mxg_sketch_pack) need a scratch set per assembly and ignore the switch.
-    const bool one_stream = getenv("MXG_ONE_STREAM") != nullptr && !fuse_graph && !xp;
+    const bool one_stream = knob_set(h, "MXG_ONE_STREAM") && !fuse_graph && !xp;
     Driver *drvs[4] = {&drv0, one_stream ? &drv0 : &drv1, one_stream ? &drv0 : &drv2, one_stream ? &drv0 : &drv3};
     if (one_stream) n_str = 1;
     struct Item {
@@ -3009,8 +3004,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         uint32_t *hc;  // pinned control block
         bool bs;       // went through the k = 32 route (no candidate arrays to finish from)
     };
-    const bool bs_env = env_u64("MXG_BS", 1) != 0;
-    const bool bs_select = env_u64("MXG_BS_SELECT", 1) != 0;  // k_bs_select instead of count -> reorder -> resolve
+    const bool bs_env = env_u64(h, "MXG_BS", 1) != 0;
+    const bool bs_select = env_u64(h, "MXG_BS_SELECT", 1) != 0;  // k_bs_select instead of count -> reorder -> resolve
     std::vector<Tables> tabs(n);
     std::vector<int> state(n, 0);  // 0 = synchronous path, 1 = enqueued, 2 = done
     std::vector<SparsePlan> plans(n);
@@ -3051,9 +3046,9 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         for (int pass = sel_ok ? 0 : 1; pass < 2; ++pass) {
             uint64_t budget = plans[i].batch_kmers;
             if (pass == 0) {
-                const uint64_t big = env_u64("MXG_SEL_BATCH_KMERS", 2040ull << 20);
+                const uint64_t big = env_u64(h, "MXG_SEL_BATCH_KMERS", 2040ull << 20);
                 budget = std::min<uint64_t>(plans[i].gap_kmers ? plans[i].gap_kmers : big, big);
-                if (getenv("MXG_SPARSE_BATCH_KMERS")) budget = std::min<uint64_t>(budget, SPARSE_BATCH_KMERS);  // (test knob)
+                if (knob_set(h, "MXG_SPARSE_BATCH_KMERS")) budget = std::min<uint64_t>(budget, SPARSE_BATCH_KMERS);  // (test knob)
             }
             gs.clear();
             bgs.clear();
@@ -3234,7 +3229,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             n_cand += c[4];
             gap_kmers += c[10] == 0xFFFFFFFFu ? 0 : c[10];
         }
-        if (!(good && total <= cap) && getenv("MXG_DEBUG_BATCH")) {  // (diagnostics: the reports of an assembly's batches)
+        if (!(good && total <= cap) && knob_set(h, "MXG_DEBUG_BATCH")) {  // (diagnostics: the reports of an assembly's batches)
             for (size_t q = q0; q < q1; ++q) {
                 const uint32_t *c = items[q].hc;
                 fprintf(stderr, "[mxg] asm %zu batch %zu: ovf %u gaps %u sel %u flag %u cand %u nB %u total %u obase %u gapk %u (cap %llu)\n", i,

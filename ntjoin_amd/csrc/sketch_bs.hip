@@ -651,8 +651,7 @@ int bs_hash(mxg_handle *h, Assembly *a, uint32_t tau_hi, hipStream_t st)
     const uint32_t tt = T ? (T - 1u) >> (31 - HASH_BS_PLANES) : 0u;
     // (alone on the GPU 1024 blocks over the 512 resident ones even out the tail: 478 us against 500 us at 3 Gbp; beside the other
     // stream's kernels the step is the same or better with 512.  MXG_BS_BLOCKS: sweep knob)
-    const char *eb = getenv("MXG_BS_BLOCKS");
-    const unsigned env_blocks = eb && atoi(eb) > 0 ? (unsigned)atoi(eb) : 512u;
+    const unsigned env_blocks = (unsigned)std::max<uint64_t>(1, knob_u64(h, "MXG_BS_BLOCKS", 512));
     const uint32_t blocks = std::min<uint32_t>((uint32_t)env_blocks, (a->bs_chunks + 3u) / 4u);  // two waves per SIMD are resident (see k_hash_bs)
     const uint32_t *head = a->d_bs_tail.as<uint32_t>() + 2, *tail = a->bs_chunks > 1 ? head + BS_EDGE_WORDS : head;
     hipLaunchKernelGGL(k_hash_bs, dim3(blocks), dim3(256), 0, st, a->d_packed, head, tail, a->d_bs_out.as<uint32_t>() + BS_OUT_PAD, 0u,

@@ -353,5 +353,11 @@ class MxEngine:
         self._check(self._lib.mxg_get_stats(self._h, C.byref(s)))
         return {f: getattr(s, f) for f, _ in capi.Stats._fields_ if f not in ("struct_size", "reserved")}
 
+    def knobs(self):
+        """the MXG_* environment knobs this handle has read and found set: 'NAME=value ...' (parsed once per handle)"""
+        buf = C.create_string_buffer(4096)
+        self._lib.mxg_knobs(self._h, buf, 4096)
+        return buf.value.decode()
+
     def reset_timers(self):
         self._check(self._lib.mxg_reset_timers(self._h))

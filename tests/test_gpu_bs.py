@@ -140,3 +140,27 @@ def test_run_borders_and_short_records(oracle, env):
     recs.append(("long", "".join(rng.choice("ACGT") for _ in range(150000))))
     st = _check(oracle, recs, 32, 200)
     assert st["bs_filter_bases"] > 0 or os.environ.get("MXG_BS") == "0"  # (MXG_BS=0: the rolling-hash route is under test)
+
+
+def test_knobs_are_read_once_per_handle_and_reported(oracle, env):
+    """mxg_knobs: the MXG_* switches a handle read and found set, as it first saw them (a later change of the environment does
+    not reach a handle that has already run)"""
+    from ntjoin_amd.engine import MxEngine
+    env["MXG_SPARSE_S"] = "128"
+    env["MXG_BS_SELECT"] = "0"
+    recs = _records(61)
+    with MxEngine(k=32, w=200) as eng:
+        eng.add_records("x", 1.0, recs)
+        eng.sketch()
+        first = eng.get_sketch(0)["out_hash"].copy()
+        kn = dict(kv.split("=", 1) for kv in eng.knobs().split())
+        assert kn.get("MXG_SPARSE_S") == "128" and kn.get("MXG_BS_SELECT") == "0"
+        assert eng.stats()["select_slices"] == 0
+        env["MXG_BS_SELECT"] = "1"     # too late for this handle
+        eng.sketch()
+        assert eng.stats()["select_slices"] == 0
+        assert (eng.get_sketch(0)["out_hash"] == first).all()
+    with MxEngine(k=32, w=200) as eng:
+        eng.add_records("x", 1.0, recs)
+        eng.sketch()
+        assert eng.stats()["select_slices"] > 0 and "MXG_BS_SELECT=1" in eng.knobs()
