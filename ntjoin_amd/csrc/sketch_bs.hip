@@ -582,11 +582,13 @@ int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hi
     static bool attr_set = false;
     if (!attr_set) {  // (more than 64 KB of dynamic LDS must be asked for)
         MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<36>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     if (nwc <= 12) hipLaunchKernelGGL(k_bs_select<12>, grid, block, g.lds, st, p);
+    else if (nwc <= 16) hipLaunchKernelGGL(k_bs_select<16>, grid, block, g.lds, st, p);
     else if (nwc <= 20) hipLaunchKernelGGL(k_bs_select<20>, grid, block, g.lds, st, p);
     else hipLaunchKernelGGL(k_bs_select<36>, grid, block, g.lds, st, p);
     MXG_HIP(h, hipGetLastError());
