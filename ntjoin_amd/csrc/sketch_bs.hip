@@ -381,9 +381,9 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     const uint32_t S = p.S, H = p.H, T = p.T, w = p.w;
     const uint32_t nwords = (S + 31u) / 32u;
     const uint32_t stride = gridDim.x * nwv, laneS = lane * S;
-    uint32_t own_cands = 0, touch = 0, pend_a = 0, pend_b = 0, pend_c = 0;
+    uint32_t own_cands = 0;
     uint32_t region = 0xFFFFFFFFu;  // this wave's region of global memory, once it has needed one
-    bool flag = false, first = true;
+    bool flag = false;
     // (a wave takes every stride-th slice; runs of consecutive slices per wave measured 4 % slower)
     uint32_t sl = blockIdx.x * nwv + wib;
     const uint32_t sl_end = p.n_slices;
@@ -413,12 +413,6 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
                 wd[4 * u] = v.w0; wd[4 * u + 1] = v.w1; wd[4 * u + 2] = v.w2; wd[4 * u + 3] = v.w3;
             }
         }
-        // ... and the first and last word of its packed bases: a strip is shorter than a cache line, so these requests bring every
-        // line the slice's candidates will be hashed from on their way while the bitmap words travel (the candidates' own requests
-        // then meet them in L2; without this every round of 64 candidates waited for HBM).  `touch` keeps the loads alive.  Only for
-        // a wave's first slice: the lines of every later one are asked for while the slice before it is being decided (below).
-        if (first && sr.len) touch ^= p.packed[sr.b >> 4] ^ p.packed[(sr.b + sr.len + 31u) >> 4];
-        touch ^= pend_a ^ pend_b ^ pend_c;  // (what the round before asked for ahead)
         // fold: k-mers of one contig at their distances, a contig border = w more; the first strip starts at 2 w
         // (wave_shr:1: the lane in front; lane 0 keeps `old`)
         const uint32_t len_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sr.len, 0x138, 0xf, 0xf, false);
@@ -450,25 +444,15 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         }
         const uint32_t incl = wave_inclusive_dpp(cnt);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        // the next slice's strips (their run indices have arrived while this slice's bitmap words travelled), and -- once this
-        // slice's candidates are hashed -- one word of every cache line of its bitmap words and packed bases: they travel while
-        // this slice's candidates are decided, which asks nothing of memory
+        // the next slice's strips: their run indices have arrived while this slice's bitmap words travelled.  (Asking ahead for the
+        // next slice's bitmap and base lines as well, or touching this slice's base lines while the bitmap words travel, was
+        // measured: 1.6 x the kernel's HBM traffic -- the waves of an XCD hold more lines than its L2 -- for no time at all.)
         const StripRegs sr_n = strip_of(p, in_n, sS_n, ri_n);
-        auto ask_ahead = [&]() {  // (the words are looked at -- folded into `touch` -- only in the next round of the loop: no wait here)
-            pend_a = pend_b = pend_c = 0;
-            if (sr_n.len) {
-                pend_a = p.bm[sr_n.b >> 5];
-                pend_b = p.packed[sr_n.b >> 4];
-                pend_c = p.packed[(sr_n.b + sr_n.len + 31u) >> 4];
-            }
-        };
         if (p.ablate == 1) {  // (profiling)
             if (lane == 0) count_publish(p.cnt, p.sup, sl, 0u);
             own_cands += tot != 0;
-            ask_ahead();
         } else if (tot <= p.qcap) {
             sel_collect<NWC - 1, false>(p, c, lh + SEL_PAD, le + SEL_PAD, p.qcap, bt, incl - cnt, tot);
-            ask_ahead();
             if (p.ablate == 2 || p.ablate == 3) {
                 if (lane == 0) count_publish(p.cnt, p.sup, sl, 0u);
                 own_cands += 1u;
@@ -494,10 +478,8 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         own_cands += c.own_hi - c.own_lo;
         __builtin_amdgcn_wave_barrier();  // the next slice reuses the wave's LDS
         sr = sr_n;
-        first = false;
     }
     const uint32_t own_w = own_cands;  // (wave-uniform)
-    if (touch == 0x9E3779B9u && p.w == 0) p.ctrl[15] = touch;  // (never: the words requested ahead are not used for anything)
     if (lane == 0) {
         if (own_w) atomicAdd(&p.cand_spread[((blockIdx.x * nwv + wib) & 63u) * 32u], own_w);
         if (flag) p.ctrl[6] = p.ctrl[13] = 1;  // ([13]: it was this kernel that gave up)

@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 
 from .dist import allgather_inplace, concat_tsv_parts
-from .engine import MxEngine
+from .engine import MxEngine, MxError
 
 
 def main(argv=None):
@@ -81,17 +81,41 @@ def main(argv=None):
             eng.build_graph()
             # every rank holds the whole graph: each formats 1/world of the .mx.dot text and writes it at its own place
             # (the sizes travel in one small all-gather); rank 0 alone took world times as long for the same bytes
+            # A rank that fails (out of memory while formatting, a write error) must not leave the others waiting in the next
+            # collective, nor a file with holes behind: the sizes travel with a status word (-1 = failed), the writes are followed
+            # by an all-reduce of the return codes, and on any failure rank 0 removes the file and every rank exits non-zero.
+            # (all ranks write ONE file at their own offsets: the prefix must lie on a file system they share coherently --
+            # one host, or a cluster file system; otherwise gather the parts to rank 0.)
             dot = args.prefix + ".mx.dot"
-            vb, eb = eng.dot_part_format(rank, world)
+            try:
+                vb, eb = eng.dot_part_format(rank, world)
+            except (MxError, MemoryError) as exc:
+                print(f"ntjoin_amd.run_dist: rank {rank}: {exc}", file=sys.stderr, flush=True)
+                vb, eb = -1, -1
             sizes = torch.empty((world, 2), dtype=torch.int64, device=tdev)
             dist.all_gather_into_tensor(sizes.view(-1), torch.tensor([vb, eb], dtype=torch.int64, device=tdev))
             sizes = sizes.cpu().numpy()
+            if (sizes < 0).any():
+                dist.barrier()
+                return 1
             if rank == 0 and os.path.exists(dot):
                 os.remove(dot)                                   # (nobody truncates once the writing has begun)
             dist.barrier()
             v_off = 10 + int(sizes[:rank, 0].sum())
             e_off = 10 + int(sizes[:, 0].sum()) + int(sizes[:rank, 1].sum())
-            eng.dot_part_write(dot, v_off, e_off, rank == 0, rank == world - 1)
+            bad = 0
+            try:
+                eng.dot_part_write(dot, v_off, e_off, rank == 0, rank == world - 1)
+            except (MxError, OSError) as exc:
+                print(f"ntjoin_amd.run_dist: rank {rank}: {exc}", file=sys.stderr, flush=True)
+                bad = 1
+            status = torch.tensor([bad], dtype=torch.int32, device=tdev)
+            dist.all_reduce(status, op=dist.ReduceOp.MAX)
+            if int(status.item()):
+                if rank == 0 and os.path.exists(dot):
+                    os.remove(dot)
+                dist.barrier()
+                return 1
             if rank == 0:
                 st = eng.stats()
                 print(f"ntjoin_amd.run_dist: {world} GPU(s), {st['minimizers']} minimizers, {st['vertices']} vertices, "
