@@ -541,7 +541,7 @@ def main():
                         traffic_src = ("static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this workload at commit "
                                        f"{tj.get('commit', '?')}, profiles/" + PROFILE_ROUND + "/hbm_traffic.json")
                     else:
-                        traffic_src = (f"stale: profiles/" + PROFILE_ROUND + "/hbm_traffic.json was captured at commit {tj.get('commit', '?')} and the "
+                        traffic_src = (f"stale: profiles/{PROFILE_ROUND}/hbm_traffic.json was captured at commit {tj.get('commit', '?')} and the "
                                        "kernel sources have changed since; not quoted")
             except Exception:
                 traffic = None
