@@ -104,10 +104,25 @@ __device__ __forceinline__ uint32_t wave_inclusive_dpp(uint32_t v)
     return v;
 }
 
-__device__ __forceinline__ void sel_push_gap(const BsSelParams &p, uint32_t c, uint32_t lo, uint32_t hi, uint32_t hint)
+// The kernel's own argument block, through a pointer the compiler cannot see through: the fields only the rare paths need
+// (stretches, the global-memory regions, the final report) are then read where they are used -- one scalar load each -- instead of
+// sitting in scalar registers for the whole kernel, where, with the rest of its loop-invariant values, they spilled into vector
+// lanes (v_readlane / v_writelane: a tenth of the slice loop's vector instructions).
+__device__ __forceinline__ const BsSelParams *sel_rare_params()
 {
-    const uint32_t idx = atomicAdd(&p.ctrl[1], 1u);
-    if (idx < p.gap_cap) p.gaps[idx] = make_uint4(c, lo, hi, hint);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const void *q = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return static_cast<const BsSelParams *>(q);
+#else
+    return nullptr;  // (host pass of the compiler: never called)
+#endif
+}
+__device__ __forceinline__ void sel_push_gap(const BsSelParams &, uint32_t c, uint32_t lo, uint32_t hi, uint32_t hint)
+{
+    const BsSelParams *q = sel_rare_params();
+    const uint32_t idx = atomicAdd(&q->ctrl[1], 1u);
+    if (idx < q->gap_cap) q->gaps[idx] = make_uint4(c, lo, hi, hint);
 }
 
 // The whole wave: contig c has no candidate from k-mer k_from up to the end of the strips the slice holds, and goes on behind
@@ -162,6 +177,7 @@ struct SelCtx {
     uint4 *req;        // stretches that end behind the slice (LDS)
     uint32_t *misc;    // [0] number of requests
     uint32_t lane, sl, own_end;
+    bool has_drop;     // pieces of records cut between shards are loaded (ctg_drop)
     int64_t s_first;
     uint32_t nreal, own_lo, own_hi;  // the list: real candidates, the own ones among them [own_lo, own_hi)
 };
@@ -238,6 +254,7 @@ __device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, cons
                                            const uint32_t f, bool &flag)
 {
     const uint32_t lane = c.lane, sl = c.sl, H = p.H, w = p.w, wm1 = w - 1u, nreal = c.nreal;
+    const bool has_drop = c.has_drop;
     const uint32_t lim = 64u * wm1 + 63u;  // e-distance: within w - 1 k-mers
     const uint32_t *s_c = c.si + 128, *s_k0 = c.si + 192, *s_nk = c.si + 256, *s_f = c.si + 320;
     // the contig that leaves the slice at its far end (none: ~0) -- every other contig of the slice ends inside it
@@ -317,7 +334,7 @@ __device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, cons
             }
         }
         // a piece of a record that starts with the halo of the shard before it: see k_resolve
-        if (p.ctg_drop && s && kx <= wm1 && L == kx && p.ctg_drop[cg]) s = false;
+        if (has_drop && s && kx <= wm1 && L == kx && sel_rare_params()->ctg_drop[cg]) s = false;
         const uint64_t bm = __ballot(s);
         if (s) {
             const uint32_t dst = n_sel + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
@@ -375,6 +392,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     c.req = reinterpret_cast<uint4 *>(c.si + SEL_SI * 64u);
     c.misc = reinterpret_cast<uint32_t *>(c.req + SEL_REQ);
     c.lane = lane;
+    c.has_drop = p.ctg_drop != nullptr;
     c.nreal = c.own_lo = c.own_hi = 0;
     if (lane == 0) c.misc[0] = 0;
     __syncthreads();
@@ -460,15 +478,17 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
                 sel_decide<false>(p, c, lh + SEL_PAD, le + SEL_PAD, sr, f, flag);
             }
         } else {
+            const BsSelParams *q = sel_rare_params();
             if (region == 0xFFFFFFFFu) {
                 uint32_t r = 0;
-                if (lane == 0) r = atomicAdd(p.ovf_next, 1u);
+                if (lane == 0) r = atomicAdd(q->ovf_next, 1u);
                 region = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
             }
-            if (region < p.n_ovf) {
-                const size_t o = (size_t)region * (p.ovf_cap + 2u * SEL_PAD) + SEL_PAD;
-                sel_collect<NWC - 1, true>(p, c, p.ovf_h + o, p.ovf_e + o, p.ovf_cap, bt, incl - cnt, tot);
-                sel_decide<true>(p, c, p.ovf_h + o, p.ovf_e + o, sr, f, flag);
+            if (region < q->n_ovf) {
+                const uint32_t ocap = q->ovf_cap;
+                const size_t o = (size_t)region * (ocap + 2u * SEL_PAD) + SEL_PAD;
+                sel_collect<NWC - 1, true>(p, c, q->ovf_h + o, q->ovf_e + o, ocap, bt, incl - cnt, tot);
+                sel_decide<true>(p, c, q->ovf_h + o, q->ovf_e + o, sr, f, flag);
             } else {  // no region left: the host redoes the batch
                 flag = true;
                 c.own_lo = c.own_hi = 0;
@@ -481,8 +501,9 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     }
     const uint32_t own_w = own_cands;  // (wave-uniform)
     if (lane == 0) {
-        if (own_w) atomicAdd(&p.cand_spread[((blockIdx.x * nwv + wib) & 63u) * 32u], own_w);
-        if (flag) p.ctrl[6] = p.ctrl[13] = 1;  // ([13]: it was this kernel that gave up)
+        const BsSelParams *q = sel_rare_params();
+        if (own_w) atomicAdd(&q->cand_spread[((blockIdx.x * nwv + wib) & 63u) * 32u], own_w);
+        if (flag) q->ctrl[6] = q->ctrl[13] = 1;  // ([13]: it was this kernel that gave up)
     }
 }
 

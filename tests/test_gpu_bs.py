@@ -142,6 +142,30 @@ def test_run_borders_and_short_records(oracle, env):
     assert st["bs_filter_bases"] > 0 or os.environ.get("MXG_BS") == "0"  # (MXG_BS=0: the rolling-hash route is under test)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_select_halo_where_runs_meet(oracle, env, seed):
+    """records made of many valid runs between N gaps, run lengths just under / at / over whole strips and just under / over a
+    window: the halo of a slice (strips on either side of its own ones) must still hold w k-mers of the contig where a run's
+    short last strip falls into it (bs_select_halo), or the route must decline the assembly -- either way the sketch is the
+    oracle's"""
+    rng = random.Random(seed)
+    S, w, k = 320, 1000, 32
+    env["MXG_SPARSE_S"] = str(S)
+    env["MXG_DEV_GAPS"] = "1"
+    recs = []
+    for r in range(6):
+        parts = []
+        for _ in range(rng.randrange(8, 40)):
+            n_kmers = rng.choice([S - 1, S, S + 1, 2 * S - 1, 2 * S + 3, 3 * S, w - 2, w, w + 1, 5, 40, 4 * S + 7, rng.randrange(1, 6000)])
+            parts.append("".join(rng.choice("ACGT") for _ in range(n_kmers + k - 1)))
+            parts.append("N" * rng.choice([1, 1, 2, 31, 32, 33, 100]))
+        recs.append((f"r{r}", "".join(parts)))
+    recs.append(("plain", "".join(rng.choice("ACGT") for _ in range(120000))))
+    st = _check(oracle, recs, k, w)
+    st2 = _check(oracle, recs, k, w, cand_per_window=4)
+    assert st["bs_filter_bases"] > 0 and st2["bs_filter_bases"] > 0
+
+
 def test_knobs_are_read_once_per_handle_and_reported(oracle, env):
     """mxg_knobs: the MXG_* switches a handle read and found set, as it first saw them (a later change of the environment does
     not reach a handle that has already run)"""
