@@ -693,7 +693,11 @@ def main():
                           f"({cb['bases'] / 1e6:.0f} Mbp, {100 * cb['frac']:.0f} % of the step's workload): C restatement of "
                           f"`indexlr -t {cb['cores']}` (records chunked, one worker per core: {cb['t_sketch']:.2f} s) + C restatement of "
                           f"read_minimizers/filter_minimizers/build_graph on arrays, 1 thread like the reference ({cb['t_graph']:.2f} s)",
-                "seconds": round(cb["seconds"], 3)}
+                "seconds": round(cb["seconds"], 3),
+                "reference_python_graph_stage": "what users run today behind indexlr: the reference's own read_minimizers + "
+                                                "filter_minimizers + build_graph in Python take ~5.7 + 0.57 us per minimizer (SURVEY.md "
+                                                "section 6, measured once in the build container on the reference's code: ~75 s for "
+                                                "this workload's 12 M minimizers, 0.08 Gbp/s for the graph stage alone)"}
             if cb["frac"] >= 1.0:  # whole workload: same inputs -> same counts (bit-exact parity lives in tests/)
                 out["parity_counts_match_cpu"] = bool(cb["minimizers"] == st["minimizers"] and
                                                       cb["vertices"] == st["vertices"] and cb["edges"] == st["edges"])

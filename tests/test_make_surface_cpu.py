@@ -31,6 +31,26 @@ def test_assemble_delegates_with_our_indexlr_first_on_path(tmp_path):
         assert want in args, (want, args)
 
 
+def test_assemble_forwards_the_downstream_variables_by_name(tmp_path):
+    """the variables of the stages behind the graph (reference ntJoin:36-77: g, G, m, mkt, agp, no_cut, overlap, overlap_k,
+    overlap_w, overlap_g, assemble_t) reach the reference's make explicitly when given, and are left to its defaults when not"""
+    stub = tmp_path / "ntJoin"
+    _stub(stub, 'for a in "$@"; do echo "arg=$a" >> "$PWD/seen.txt"; done\n')
+    given = ["g=30", "G=500", "m=80", "mkt=True", "agp=True", "no_cut=True", "overlap=False", "overlap_k=17", "overlap_w=12",
+             "overlap_g=25", "assemble_t=3"]
+    subprocess.check_call(["make", "-f", MK, "assemble", "target=scaf.fa", "references=r1.fa", "reference_weights=2", f"ntjoin={stub}"] + given,
+                          cwd=tmp_path, env={k: v for k, v in os.environ.items() if k not in ("MAKEFLAGS", "MFLAGS")})
+    args = [l[4:] for l in (tmp_path / "seen.txt").read_text().splitlines()]
+    for want in given:
+        assert want in args, (want, args)
+    os.remove(tmp_path / "seen.txt")
+    subprocess.check_call(["make", "-f", MK, "assemble", "target=scaf.fa", "references=r1.fa", "reference_weights=2", f"ntjoin={stub}"],
+                          cwd=tmp_path)
+    args = [l[4:] for l in (tmp_path / "seen.txt").read_text().splitlines()]
+    assert not any(a.split("=")[0] in ("g", "G", "m", "mkt", "agp", "no_cut", "overlap", "overlap_k", "overlap_w", "overlap_g", "assemble_t")
+                   for a in args), args
+
+
 def test_assemble_without_reference_path_is_an_error(tmp_path):
     r = subprocess.run(["make", "-f", MK, "assemble", "target=a.fa", "references=b.fa", "reference_weights=2"], cwd=tmp_path,
                        capture_output=True, text=True)
