@@ -1758,6 +1758,10 @@ static uint32_t choose_sparse_S(const mxg_handle *h, uint64_t total_kmers)
 {
     const uint64_t e = knob_u64(h, "MXG_SPARSE_S", 0);
     if (e >= 16) return (uint32_t)std::min<uint64_t>(1024, (e + 15) / 16 * 16);
+    // the k = 32 route's slice kernel wants w k-mers in a few strips (sketch_bs.h: SEL_MAX_H), whatever the input's size
+    if (h->cfg.k == 32 && h->cfg.variant == MXG_VARIANT_V2_SUM && h->cfg.w > 64 * SEL_MAX_H &&
+        knob_u64(h, "MXG_BS", 1) != 0 && knob_u64(h, "MXG_BS_SELECT", 1) != 0)
+        return 320;
     const uint64_t lanes = 1024ull * 64;  // SIMDs x lanes
     // small inputs: keep at least ~4 waves per SIMD in flight
     uint64_t S = (total_kmers + lanes * 4 - 1) / (lanes * 4);

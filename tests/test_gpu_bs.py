@@ -78,6 +78,15 @@ def test_select_route_runs_and_agrees(oracle, env, S, w):
     assert st["select_slices"] > 0
 
 
+@pytest.mark.parametrize("w", [1000, 2500, 200])
+def test_select_route_is_the_default_for_small_inputs(oracle, env, w):
+    """no strip-length knob: an input of a few hundred kbp takes the same route as a genome (strips long enough for the
+    slice kernel's halo at any w it covers)"""
+    env.pop("MXG_SPARSE_S", None)
+    st = _check(oracle, _records(400 + w), 32, w)
+    assert st["select_slices"] > 0
+
+
 def test_select_slices_beyond_their_queue(oracle, env):
     """MXG_SEL_QCAP=64: nearly every slice has more raw candidates than its LDS queue holds and works in a region of global
     memory; the results do not change"""
