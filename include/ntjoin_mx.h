@@ -132,7 +132,9 @@ typedef struct mxg_stats {
     double ms_vertices;        /* vertex ids + adjacency arrays                                  */
     double ms_edges;           /* edge flags + edge compaction                                   */
     uint64_t bs_filter_bases;  /* bases covered by the bit-sliced filter (k = 32 route; 0: the rolling-hash kernel ran) */
-    double reserved[1];
+    uint64_t graph_join;       /* the last mxg_build_graph's join: 1 = LDS tables per hash partition, 2 = the same behind coarse
+                                  partitions (two levels), 3 = one global table; | 0x100: coarse partitions re-sized and the join
+                                  redone, | 0x200: the LDS join gave up and the global table ran (a slot that was reserved)     */
     /* what the common route (every batch enqueued once, one host sync) could not finish: candidate floods beyond the estimate,
        stretches the device route cannot hold, output beyond its bound.  Such batches are redone one by one behind the good ones */
     uint64_t batches_redone;   /* batches redone through the synchronous route                               */

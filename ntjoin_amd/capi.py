@@ -75,7 +75,7 @@ class Stats(C.Structure):
                 ("ms_graph", C.c_double), ("launches_hash", C.c_uint64), ("hash_kernel_bases", C.c_uint64),
                 ("ms_reorder", C.c_double), ("ms_resolve_kernel", C.c_double), ("ms_emit", C.c_double),
                 ("ms_join", C.c_double), ("ms_vertices", C.c_double), ("ms_edges", C.c_double),
-                ("bs_filter_bases", C.c_uint64), ("reserved", C.c_double * 1),
+                ("bs_filter_bases", C.c_uint64), ("graph_join", C.c_uint64),
                 ("batches_redone", C.c_uint64), ("sync_assemblies", C.c_uint64), ("retried_assemblies", C.c_uint64), ("deferred_stretches", C.c_uint64),
                 ("select_slices", C.c_uint64)]
 

@@ -1020,6 +1020,7 @@ int mxg_get_stats(mxg_handle *h, mxg_stats *out)
     s.sync_assemblies = h->stat_sync_assemblies;
     s.deferred_stretches = h->stat_deferred;
     s.select_slices = h->stat_sel_slices;
+    s.graph_join = h->stat_graph_join;
     s.retried_assemblies = h->stat_retries;
     s.dense_kmers = h->stat_dense_kmers;
     s.unique = h->graph.valid ? h->stat_unique : 0;

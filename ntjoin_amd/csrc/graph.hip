@@ -57,6 +57,7 @@ struct AsmSet {
     uint32_t *slot[MXG_MAX_ASSEMBLIES];
     uint8_t *flags[MXG_MAX_ASSEMBLIES];
     uint8_t *shared[MXG_MAX_ASSEMBLIES];
+    uint64_t *fol;                              // partitioned join: bit t of word 4 b + q = minimizer 64 q + t of block b is a follower
 };
 
 __device__ __forceinline__ uint32_t asm_n(const AsmSet &p, uint32_t a)
@@ -148,6 +149,23 @@ __device__ __forceinline__ uint32_t pj_part(uint64_t key, uint32_t pmask)
     return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 44) & pmask;  // (the slot inside the table uses bits 32..42)
 }
 
+// Runs of equal hashes in sketch order -- a tandem array leaves the same minimizer once per unit: tens of thousands of copies of
+// one key in a satellite-rich genome, all in one partition, all for one block of k_pj_join -- go through the join as ONE
+// record: the run's first minimizer (the leader), marked "more than once in its assembly" (PJ_REC_DUP in the record's
+// assembly word).  The others (followers) are left out of the records; k_flags_pj gives them their verdict (not unique, not
+// shared, in every assembly iff the leader's key is).  Called by whole waves (lane = 64 consecutive minimizers of one block).
+constexpr uint32_t PJ_REC_DUP = 0x80000000u;
+__device__ __forceinline__ uint32_t pj_run_role(const uint64_t *hp, uint32_t i, uint32_t n, uint64_t key, bool live)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t prev = __shfl_up(key, 1), next = __shfl_down(key, 1);
+    if (live && lane == 0 && i > 0) prev = hp[i - 1];
+    if (live && lane == 63 && i + 1 < n) next = hp[i + 1];
+    const bool fol = live && i > 0 && prev == key;
+    const bool lead = live && !fol && i + 1 < n && next == key;
+    return (fol ? 1u : 0u) | (lead ? 2u : 0u);
+}
+
 constexpr uint32_t PJ_BT = 1024;   // threads of a bucketing block (4 items each): 16 waves hide the latency of its passes
 __global__ __launch_bounds__(PJ_BT) void k_pj_bucket(const AsmSet p, uint32_t nb, uint32_t pmask, uint32_t *M, uint4 *recs,
                                                    uint32_t *sup, uint32_t n_sup)
@@ -168,26 +186,27 @@ __global__ __launch_bounds__(PJ_BT) void k_pj_bucket(const AsmSet p, uint32_t nb
     uint32_t *sp0 = p.slot[a0];
     const uint32_t n0 = asm_n(p, a0), ib0 = (blk0 - p.bstart[a0]) * 256u;
     uint64_t key[U];
-    uint32_t live = 0;  // bit u: item u of this thread exists
+    uint32_t live = 0, dupm = 0;  // bit u: item u of this thread exists (and is no follower) / leads a run of equal hashes
 #pragma unroll
     for (uint32_t u = 0; u < U; ++u) {
         const uint32_t blk = blk0 + u * BPU + sub;
         key[u] = 0;
         if (blk >= nb) continue;
-        if (one) {
-            const uint32_t i = ib0 + (u * BPU + sub) * 256u + t256;
-            if (i < n0) {
-                key[u] = hp0[i];
-                live |= 1u << u;
-            }
-        } else {
+        const uint64_t *hp = hp0;
+        uint32_t i = ib0 + (u * BPU + sub) * 256u + t256, n = n0;
+        if (!one) {
             const uint32_t a = asm_of_block(p, blk);
-            const uint32_t i = (blk - p.bstart[a]) * 256u + t256;
-            if (i < asm_n(p, a)) {
-                key[u] = p.hash[a][i];
-                live |= 1u << u;
-            }
+            hp = p.hash[a];
+            i = (blk - p.bstart[a]) * 256u + t256;
+            n = asm_n(p, a);
         }
+        const bool lv = i < n;
+        if (lv) key[u] = hp[i];
+        const uint32_t role = pj_run_role(hp, i, n, key[u], lv);
+        const uint64_t fb = __ballot(role & 1u);
+        if ((threadIdx.x & 63u) == 0) p.fol[(size_t)blk * 4u + ((threadIdx.x >> 6) & 3u)] = fb;
+        if (lv && !(role & 1u)) live |= 1u << u;
+        if (role & 2u) dupm |= 1u << u;
     }
     for (uint32_t b = threadIdx.x; b <= pmask; b += PJ_BT) hist[b] = 0;
     __syncthreads();
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(PJ_BT) void k_pj_bucket(const AsmSet p, uint32_t nb
         }
         const uint32_t b = pj_part(key[u], pmask);
         const uint32_t pos = j * PJ_IPB + start[b] + atomicAdd(&hist[b], 1u);
-        recs[pos] = make_uint4((uint32_t)key[u], (uint32_t)(key[u] >> 32), i, a);  // (the record knows whose it is: k_pj_join
+        recs[pos] = make_uint4((uint32_t)key[u], (uint32_t)(key[u] >> 32), i, a | (((dupm >> u) & 1u) ? PJ_REC_DUP : 0u));  // (the record knows whose it is: k_pj_join
         (void)sp;                                                                   //  sends the verdict straight to slot[a][i])
     }
 }
@@ -315,21 +334,27 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
             };
             uint32_t last_a = 0, last_i = 0;  // assembly / item of the record insert() looked at last
             auto insert_rec = [&](const uint4 rec) {   // pass 0; also the lookup of pass 1
-                last_a = rec.w;
+                last_a = rec.w & ~PJ_REC_DUP;
                 last_i = rec.z;
                 const uint32_t s = pj_slot(keys, ((uint64_t)rec.y << 32) | rec.x);
                 if (pass == 0) {
-                    const uint32_t bit = 1u << rec.w;
+                    const uint32_t bit = 1u << last_a;
                     if (s > PJ_T) failed = 1;
                     else {
                         // (a key of huge multiplicity -- a satellite's minimizer -- brings tens of thousands of records to one
                         // slot: once its state says "seen twice here" there is nothing left to record, and no atomic to queue for)
                         const uint32_t cur = seen[s], dcur = NARROW ? cur >> 16 : dup[s];
                         if (!((cur & bit) && (dcur & bit))) {
-                            if (atomicOr(&seen[s], bit) & bit) {  // second occurrence in this assembly
+                            if (rec.w & PJ_REC_DUP) {  // the leader of a run of equal hashes: its followers are not among the records
+                                if (NARROW) atomicOr(&seen[s], bit | (bit << 16));
+                                else {
+                                    atomicOr(&seen[s], bit);
+                                    atomicOr(&dup[s], bit);
+                                }
+                            } else if (atomicOr(&seen[s], bit) & bit) {  // second occurrence in this assembly
                                 if (NARROW) atomicOr(&seen[s], bit << 16); else atomicOr(&dup[s], bit);
                             }
-                            if (rec.w == 0) item0[s] = rec.z;  // (a key that occurs twice in assembly 0 is not shared: never read)
+                            if (last_a == 0) item0[s] = rec.z;  // (a key that occurs twice in assembly 0 is not shared: never read)
                         }
                     }
                 }
@@ -413,10 +438,14 @@ __global__ __launch_bounds__(PJ_BT) void k_pj1_scatter(const AsmSet p, uint32_t 
         ia[u] = ii[u] = 0;
         if (blk >= nb) continue;
         const uint32_t a = asm_of_block(p, blk);
-        const uint32_t i = (blk - p.bstart[a]) * 256u + t256;
-        if (i < asm_n(p, a)) {
-            key[u] = p.hash[a][i];
-            ia[u] = a;
+        const uint32_t i = (blk - p.bstart[a]) * 256u + t256, n = asm_n(p, a);
+        const bool lv = i < n;
+        if (lv) key[u] = p.hash[a][i];
+        const uint32_t role = pj_run_role(p.hash[a], i, n, key[u], lv);  // (followers travel with their run's leader)
+        const uint64_t fb = __ballot(role & 1u);
+        if ((threadIdx.x & 63u) == 0) p.fol[(size_t)blk * 4u + ((threadIdx.x >> 6) & 3u)] = fb;
+        if (lv && !(role & 1u)) {
+            ia[u] = a | ((role & 2u) ? PJ_REC_DUP : 0u);
             ii[u] = i;
             live |= 1u << u;
         }
@@ -439,21 +468,31 @@ __global__ __launch_bounds__(PJ_BT) void k_pj1_scatter(const AsmSet p, uint32_t 
         const uint32_t b = pj1_part(key[u], p1mask);
         const uint32_t pos = start[b] + atomicAdd(&hist[b], 1u);
         if (pos < cap1) recs1[(size_t)b * cap1 + pos] = make_uint4((uint32_t)key[u], (uint32_t)(key[u] >> 32), ii[u], ia[u]);
-        else p.slot[ia[u]][ii[u]] = 0;  // beyond the capacity: no verdict will come (the cursor says so, k_pj_join reports it and
+        else p.slot[ia[u] & ~PJ_REC_DUP][ii[u]] = 0;  // beyond the capacity: no verdict will come (the cursor says so, k_pj_join reports it and
                                         // the host redoes the stage with the global table); leave a harmless one behind
     }
 }
 
 // level 2: block (j, c) sorts records [j * 4096, (j + 1) * 4096) of coarse partition c by sub-partition (hash bits 44..) inside
 // their region of recs2, writes its row of M and tells every minimizer where its record went (slot[a][i], read by k_flags_pj)
+//
+// A coarse partition that holds far more records than the mean (skew_lim) holds a key of huge multiplicity (hash partitions of
+// distinct keys differ by a fraction of a percent): a satellite's minimizer whose copies are not neighbours in sketch order
+// (those travel as one record already, pj_run_role), 10^5 records that would all meet in ONE block of k_pj_join.  The blocks of
+// such a partition first collapse what is equal among their 4096 records: records of one (key, assembly) elect one of them,
+// which goes on marked PJ_REC_DUP; the others leave a reference to it as their verdict (PJ_VERDICT_REF, followed by k_flags_pj)
+// and drop out.
+constexpr uint32_t PJ_VERDICT_REF = 2u;  // low bits of a verdict word that is no verdict (SHARED without UNIQUE cannot be):
+                                         // the upper bits name a minimizer of the same assembly whose verdict holds for this one
 __global__ __launch_bounds__(PJ_BT) void k_pj2_bucket(const AsmSet p, const uint4 *__restrict__ recs1, const uint32_t *__restrict__ cursor,
-                                                    uint32_t cap1, uint32_t rows2, uint32_t pmask, uint32_t *M, uint4 *recs2)
+                                                    uint32_t cap1, uint32_t rows2, uint32_t pmask, uint32_t *M, uint4 *recs2,
+                                                    uint32_t skew_lim)
 {
     extern __shared__ uint32_t pj_lds[];
     uint32_t *hist = pj_lds, *start = pj_lds + pmask + 1;
     __shared__ uint32_t sh[256];
     const uint32_t j = blockIdx.x, c = blockIdx.y;
-    const uint32_t n_c = min(cursor[c * PJ1_CS], cap1);
+    const uint32_t n_all = cursor[c * PJ1_CS], n_c = min(n_all, cap1);
     if (j * PJ_IPB >= n_c) return;  // (block-uniform) nothing of this coarse partition in this region
     constexpr uint32_t U = PJ_IPB / PJ_BT;
     const size_t base = (size_t)c * cap1 + (size_t)j * PJ_IPB;
@@ -466,6 +505,57 @@ __global__ __launch_bounds__(PJ_BT) void k_pj2_bucket(const AsmSet p, const uint
         if (j * PJ_IPB + q < n_c) {
             rec[u] = recs1[base + q];
             live |= 1u << u;
+        }
+    }
+    if (n_all > skew_lim) {  // (block-uniform)
+        __shared__ unsigned long long skey[PJ_IPB];
+        __shared__ uint32_t sitem[PJ_IPB];
+        __shared__ uint8_t sasm[PJ_IPB];
+        __shared__ uint32_t stab[PJ_IPB];      // 2 x 4096 slots of 16 bits: the record number of the slot's (key, assembly)
+        __shared__ uint32_t sdup[PJ_IPB / 32];
+        for (uint32_t q = threadIdx.x; q < PJ_IPB; q += PJ_BT) stab[q] = 0xFFFFFFFFu;
+        for (uint32_t q = threadIdx.x; q < PJ_IPB / 32; q += PJ_BT) sdup[q] = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t q = u * PJ_BT + threadIdx.x;
+            skey[q] = ((unsigned long long)rec[u].y << 32) | rec[u].x;
+            sitem[q] = rec[u].z;
+            sasm[q] = (uint8_t)(rec[u].w & 0xFFu);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            if (!((live >> u) & 1u)) continue;
+            const uint32_t q = u * PJ_BT + threadIdx.x;
+            const unsigned long long key = skey[q];
+            const uint32_t a = rec[u].w & 0xFFu;
+            uint32_t hsl = (uint32_t)(((key + a) * 0x9E3779B97F4A7C15ull) >> 40) & (2u * PJ_IPB - 1u);
+            uint32_t rep = q;
+            for (;;) {
+                const uint32_t sft = (hsl & 1u) * 16u;
+                const uint32_t word = stab[hsl >> 1], cur = (word >> sft) & 0xFFFFu;
+                if (cur == 0xFFFFu) {
+                    const uint32_t want = (word & ~(0xFFFFu << sft)) | (q << sft);
+                    if (atomicCAS(&stab[hsl >> 1], word, want) == word) break;  // this record stands for its (key, assembly)
+                    continue;                                                    // (the word changed: look again)
+                }
+                if (skey[cur] == key && sasm[cur] == a) {
+                    rep = cur;
+                    break;
+                }
+                hsl = (hsl + 1u) & (2u * PJ_IPB - 1u);
+            }
+            if (rep != q) {
+                atomicOr(&sdup[rep >> 5], 1u << (rep & 31u));
+                p.slot[a][rec[u].z] = (sitem[rep] << 3) | PJ_VERDICT_REF;
+                live &= ~(1u << u);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t q = u * PJ_BT + threadIdx.x;
+            if ((sdup[q >> 5] >> (q & 31u)) & 1u) rec[u].w |= PJ_REC_DUP;
         }
     }
     for (uint32_t b = threadIdx.x; b <= pmask; b += PJ_BT) hist[b] = 0;
@@ -512,12 +602,36 @@ __global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, uint32_t *cnt,
         nxt[(size_t)(p.n_asm + a) * nvs + i] = NONE32;
     }
     bool sh = false;
-    if (i < asm_n(p, a)) {
-        const uint32_t v = p.slot[a][i];  // the verdict k_pj_join left here
-        sh = (v & MXG_MX_SHARED) != 0;
-        p.flags[a][i] = (uint8_t)(v & 7u);
-        p.shared[a][i] = sh ? 1 : 0;
-        p.slot[a][i] = v >> 3;
+    {
+        // the verdict k_pj_join left here (k_vertices_pj reads the word's upper part) -- a follower (pj_run_role) has none: its
+        // run's leader, the last minimizer in front of it that is no follower, says whether the key is in every assembly
+        const bool in = i < asm_n(p, a);
+        const uint32_t lane = threadIdx.x & 63u, w0 = blockIdx.x * 4u + (threadIdx.x >> 6);
+        const uint64_t fb = p.fol[w0];
+        const bool isf = in && ((fb >> lane) & 1ull);
+        uint64_t m = ~fb & ((2ull << lane) - 1ull);  // (lane 63: the shift wraps to 0, the mask to all ones)
+        uint32_t wq = w0;
+        if (__ballot(isf && m == 0)) {  // the run began in front of this wave's 64: one walk back for the wave, ending inside
+            uint64_t mp;                // the assembly (its first minimizer follows nobody)
+            uint32_t wp = w0;
+            do mp = ~p.fol[--wp]; while (mp == 0);
+            if (m == 0) {
+                m = mp;
+                wq = wp;
+            }
+        }
+        if (in) {
+            uint32_t v = p.slot[a][isf ? (wq - p.bstart[a] * 4u) * 64u + 63u - (uint32_t)__clzll(m) : i];
+            bool other = isf;
+            if ((v & 7u) == PJ_VERDICT_REF) {  // (k_pj2_bucket: the record was one of many of its key; the one it names went on)
+                v = p.slot[a][v >> 3];
+                other = true;
+            }
+            if (other) v &= MXG_MX_INALL;  // more than once in this assembly: neither unique nor shared
+            sh = (v & MXG_MX_SHARED) != 0;
+            p.flags[a][i] = (uint8_t)(v & 7u);
+            p.shared[a][i] = sh ? 1 : 0;
+        }
     }
     const uint64_t bm = __ballot(sh);
     if (a == 0 && (threadIdx.x & 63u) == 0) mask0[(blockIdx.x - p.bstart[0]) * 4u + (threadIdx.x >> 6)] = bm;
@@ -636,7 +750,7 @@ __global__ __launch_bounds__(256) void k_vertices_pj(const VertexPjParams p)
     if (!f) return;
     uint32_t v = r;
     if (a) {
-        const uint32_t i0 = p.as.slot[a][i], w = i0 >> 6;
+        const uint32_t i0 = p.as.slot[a][i] >> 3, w = i0 >> 6;  // (the verdict word: flags in its three low bits)
         const uint64_t *m = p.mask0 + (w & ~3u);
         v = p.bpref0[i0 >> 8] + (uint32_t)__popcll(p.mask0[w] & ((1ull << (i0 & 63u)) - 1ull));
         for (uint32_t q = 0; q < (w & 3u); ++q) v += (uint32_t)__popcll(m[q]);
@@ -796,7 +910,7 @@ __global__ __launch_bounds__(256) void k_count_unique(const uint8_t *__restrict_
 // gb (fused sketch+graph call, GRAPH_FULL only): the sketches are still being computed on the stream; sizes are the
 // bounds gb->n_bound[a], the kernels read the counts from gb->n_ptr[a] on the device.
 static constexpr int CTL_PJ_FAIL = 34;  // pinned control block: a partition's table overflowed (k_pj_join)
-static constexpr int RC_RETRY_GLOBAL = 1;
+static constexpr int RC_RETRY_GLOBAL = 1, RC_RETRY_PJ = 2;
 
 static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, const GraphBounds *gb, bool global_table);
 
@@ -804,11 +918,22 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, co
 {
     // (a handle whose minimizers once overflowed a partition -- a key of huge multiplicity: satellite arrays -- goes straight to
     // the global table afterwards: the same assemblies would overflow again)
+    h->stat_graph_join = 0;
+    uint64_t how = 0;
     int rc = build_graph_impl(h, mode, d_msgs, n_msgs, gb, h->pj_overflowed);
+    // (a coarse partition outgrew its capacity -- hash skew: a key of large multiplicity -- while the tables held: once more with
+    // the capacity the cursors ask for, which the handle keeps)
+    if (rc == RC_RETRY_PJ) {
+        how |= 0x100;
+        rc = build_graph_impl(h, mode, d_msgs, n_msgs, gb, false);
+    }
+    if (rc == RC_RETRY_PJ) rc = RC_RETRY_GLOBAL;
     if (rc == RC_RETRY_GLOBAL) {
+        how |= 0x200;
         h->pj_overflowed = true;
         rc = build_graph_impl(h, mode, d_msgs, n_msgs, gb, true);
     }
+    h->stat_graph_join |= how;
     return rc;
 }
 
@@ -857,22 +982,31 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         P = 256;
         P1 = 2;
         while ((uint64_t)P1 * P * 1000 < N) P1 <<= 1;
-        const uint64_t c1 = (N / P1) + (N / P1) / 4 + 4096;  // 25 % above the mean (hash skew: keys of huge multiplicity)
+        uint64_t c1 = (N / P1) + (N / P1) / 4 + 4096;  // 25 % above the mean (hash skew: keys of large multiplicity)
+        if (h->pj_cap1_P1 == P1) c1 = std::max<uint64_t>(c1, h->pj_cap1_need);  // (what an earlier call's cursors asked for)
         cap1 = (uint32_t)((c1 + PJ_IPB - 1) / PJ_IPB * PJ_IPB);
         rows2 = cap1 / PJ_IPB;
     }
     const bool two_level = P1 != 0 && P1 <= 4096 && (uint64_t)P1 * cap1 < (1ull << 32) && (uint64_t)P1 * P * (PJ_T + 1) < (1ull << 29);
-    // (k_pj_join's verdict word carries the index of the key's minimizer in assembly 0 above three flag bits: < 2^29)
+    // (k_pj_join's verdict word carries the index of the key's minimizer in assembly 0 above three flag bits, k_pj2_bucket's
+    // reference that of a minimizer of the same assembly: < 2^29)
+    uint64_t n_max = 0;
+    for (uint32_t a = 0; a < A; ++a) n_max = std::max(n_max, n_of[a]);
     const bool pj = mode == GRAPH_FULL && !global_table && (P1 == 0 || two_level) && P <= PJ_MAX_P &&
-                    (uint64_t)n_of[0] < (1ull << 29) && !(join_env && !strcmp(join_env, "global"));
+                    n_max < (1ull << 29) && !(join_env && !strcmp(join_env, "global"));
     const uint32_t pj_force_fail = knob_u64(h, "MXG_PJ_FORCE_FAIL", 0) ? 1u : 0u;
 
+    if (!resume) h->stat_graph_join = pj ? (two_level ? 2 : 1) : 3;
     if (!pj) MXG_HIP(h, h->g_keys.ensure(((size_t)cap + 1) * sizeof(Slot)));  // (the partitioned join keeps its N records here)
     // global table: slot -> vertex id; partitioned join: assembly 0's shared mask (8 B per 64 minimizers) + block prefix
+    // (+ partitioned join: one "follower" bit per minimizer of every assembly, pj_run_role)
     const size_t nb0 = (size_t)((n_of[0] + 255) / 256);
-    MXG_HIP(h, h->g_vid.ensure(pj ? nb0 * 4 * 8 + nb0 * 4 + 64 : ((size_t)cap + 1) * 4));
+    size_t nb_all = 0;
+    for (uint32_t a = 0; a < A; ++a) nb_all += (size_t)((n_of[a] + 255) / 256);
+    MXG_HIP(h, h->g_vid.ensure(pj ? (nb0 + nb_all) * 4 * 8 + nb0 * 4 + 64 : ((size_t)cap + 1) * 4));
     uint64_t *const pj_mask0 = h->g_vid.as<uint64_t>();
-    uint32_t *const pj_bpref0 = reinterpret_cast<uint32_t *>(pj_mask0 + nb0 * 4);
+    uint64_t *const pj_fol = pj_mask0 + nb0 * 4;
+    uint32_t *const pj_bpref0 = reinterpret_cast<uint32_t *>(pj_fol + nb_all * 4);
     MXG_HIP(h, h->g_ctl.ensure(CTL_WORDS * 8));
     if (pj) {
         // (nothing to clear: every word of M and of the record regions that is read is written by this call)
@@ -884,6 +1018,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
     AsmSet as_all;
     as_all.n_asm = A;
     as_all.full = full;
+    as_all.fol = pj ? pj_fol : nullptr;
     uint32_t nb = 0;
     for (uint32_t a = 0; a < A; ++a) {
         Assembly *as = h->asms[a];
@@ -936,8 +1071,9 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         uint4 *recs1 = h->g_recs1.as<uint4>(), *recs2 = h->g_keys.as<uint4>();
         hipLaunchKernelGGL(k_pj1_scatter, dim3(n_rows1), dim3(PJ_BT), (size_t)P1 * 8, h->stream, as_all, nb, P1 - 1, cap1, cursor, recs1,
                            fsup, n_fsup + n_esup);
+        const uint32_t skew_lim = (uint32_t)std::min<uint64_t>(N / P1 + N / P1 / 32 + 2048, 0xFFFFFFFFull);  // 3 % above the mean
         hipLaunchKernelGGL(k_pj2_bucket, dim3(rows2, P1), dim3(PJ_BT), (size_t)P * 8, h->stream, as_all, recs1, cursor, cap1, rows2, P - 1, M,
-                           recs2);
+                           recs2, knob_u64(h, "MXG_PJ_SKEW", 0) ? 0u : skew_lim);
         if (A <= 16)
             hipLaunchKernelGGL(k_pj_join<true>, dim3(P1 * P), dim3(256), 0, h->stream, recs2, M, P, 0u, hctl + CTL_PJ_FAIL, pj_force_fail,
                                cursor, cap1, rows2, as_all);
@@ -1085,7 +1221,21 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
     }
     if (timing) MXG_HIP(h, hipEventRecord(h->ev1, h->stream));
     MXG_HIP(h, stream_wait(h->stream));  // the stage's only sync; results stay in HBM
-    if (pj && hctl[CTL_PJ_FAIL]) return RC_RETRY_GLOBAL;  // a partition outgrew its LDS table: redo with the global table
+    if (pj && hctl[CTL_PJ_FAIL]) {  // a partition outgrew its LDS table: redo with the global table
+        if (two_level && !pj_force_fail) {  // ... unless it was a coarse partition's capacity, and only that
+            std::vector<uint32_t> cur((size_t)P1 * PJ1_CS);
+            const uint32_t *d_cur = h->g_part.as<uint32_t>() + (size_t)P1 * rows2 * (P + 1);
+            MXG_HIP(h, hipMemcpy(cur.data(), d_cur, cur.size() * 4, hipMemcpyDeviceToHost));
+            uint32_t mx = 0;
+            for (uint32_t c = 0; c < P1; ++c) mx = std::max(mx, cur[(size_t)c * PJ1_CS]);
+            if (mx > cap1 && (h->pj_cap1_P1 != P1 || h->pj_cap1_need < mx)) {
+                h->pj_cap1_P1 = P1;
+                h->pj_cap1_need = (uint64_t)mx + mx / 8 + 4096;
+                return RC_RETRY_PJ;
+            }
+        }
+        return RC_RETRY_GLOBAL;
+    }
     const uint64_t nv = hctl[0];
     for (uint32_t a = 1; a < A; ++a)
         if (hctl[a] != nv)

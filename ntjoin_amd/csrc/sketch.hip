@@ -1055,7 +1055,9 @@ __global__ __launch_bounds__(256) void k_count_n(const uint8_t *__restrict__ sel
 }
 
 constexpr uint32_t GAP_DEV_MAX = 2048;  // stretches per batch the device route holds (defined here: k_emit places them)
-constexpr uint32_t GAP_DEV_REG = 64;    // minimizers per stretch
+constexpr uint32_t GAP_DEV_REG = 4096;  // minimizers per stretch (= GAP_DEV_NMAX: whatever a stretch of that length holds.  64 until
+                                        // round 4: a di- or trinucleotide run longer than w reports every second or third k-mer,
+                                        // and each such stretch went to the host and through the dense kernels)
 constexpr uint32_t EMIT_COMPACT_BLOCKS = 16;  // k_resolve blocks per k_emit tile on the sparse path (a power of two)
 struct EmitParams {
     const uint8_t *sel;
@@ -1153,11 +1155,12 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
             below += ((((uint64_t)ec << 32) | ek) < key) ? 1u : 0u;
         }
         const uint64_t o0 = obase + count_prefix(p.cnt256, p.sel_sup, b) + wave_sum_u32(below) + p.s_off[r];
-        if (lane < p.r_cnt[g] && o0 + lane < limit) {
-            const size_t at = (size_t)g * GAP_DEV_REG + lane;
-            p.o_hash[o0 + lane] = p.r_hash[at];
-            p.o_pos[o0 + lane] = p.r_pos[at];
-            p.o_rec[o0 + lane] = p.r_rec[at];
+        const uint32_t rc = p.r_cnt[g];
+        for (uint32_t e = lane; e < rc && o0 + e < limit; e += 64u) {
+            const size_t at = (size_t)g * GAP_DEV_REG + e;
+            p.o_hash[o0 + e] = p.r_hash[at];
+            p.o_pos[o0 + e] = p.r_pos[at];
+            p.o_rec[o0 + e] = p.r_rec[at];
         }
         return;
     }
@@ -1415,31 +1418,54 @@ __device__ __forceinline__ void gap_fix_one(const GapFixParams &p, const uint32_
         const uint32_t mid = (lo + hi) >> 1;
         if (p.runs[mid].kidx0 <= klo) lo = mid; else hi = mid;
     }
-    const Run run = p.runs[lo];
-    if (n > nmax || n < w || khi >= run.kidx0 + run.n_kmers) {
+    // (a stretch may run across invalid bases: its k-mers are the valid ones of several runs, its bases one range of the packed
+    // array with the invalid ones in it -- taken as long as the range fits the block's words)
+    const uint32_t r_end = p.ctg_run0[c + 1];
+    uint32_t rl = lo;  // the run holding k_hi
+    while (rl + 1 < r_end && khi >= p.runs[rl].kidx0 + p.runs[rl].n_kmers) ++rl;
+    const Run run = p.runs[lo], runl = p.runs[rl];
+    const uint64_t b_glob = run.base_off + (klo - run.kidx0);
+    const uint64_t bspan = runl.base_off + (khi - runl.kidx0) + k - b_glob;  // bases from the first k-mer's first to the last one's last
+    if (n > nmax || n < w || khi >= runl.kidx0 + runl.n_kmers || bspan > (uint64_t)nmax + 1024u) {
         if (threadIdx.x == 0) defer_stretch(p, gp);
         return;
     }
     for (uint32_t i = threadIdx.x; i < nmax / 32; i += 256) selbits[i] = 0;
     if (threadIdx.x == 0) *drop_idx = 0xFFFFFFFFu;
     __syncthreads();
-    const uint64_t b_glob = run.base_off + (klo - run.kidx0);
     {
-        const uint32_t n_words = (uint32_t)(((b_glob & 15u) + n + k + 15u) / 16u) + 1u;  // <= the size of lw: n <= NMAX, k <= 1024
+        const uint32_t n_words = (uint32_t)(((b_glob & 15u) + bspan + 15u) / 16u) + 1u;  // <= the size of lw: bspan <= NMAX + 1024
         for (uint32_t q = threadIdx.x; q < n_words; q += 256) lw[q] = p.packed[(b_glob >> 4) + q];
     }
     __syncthreads();
     const uint64_t b = b_glob & 15u;  // base index inside lw
     const uint32_t per = (n + 255u) / 256u, i0 = threadIdx.x * per, i1 = min(i0 + per, n);
-    if (i0 < n) {  // exact hashes: the direct formula once, then rolling
+    // the run of a k-mer of the stretch, walking on from the run the caller is in
+    auto seek = [&](uint32_t &rr, Run &cr, uint32_t kk) {
+        while (kk >= cr.kidx0 + cr.n_kmers) cr = p.runs[++rr];
+    };
+    if (i0 < n) {  // exact hashes: the direct formula once (and once more behind invalid bases), then rolling
+        uint32_t rr = lo, kk = klo + i0;
+        Run cr = run;
+        seek(rr, cr, kk);
+        uint64_t bb = cr.base_off + (kk - cr.kidx0) - b_glob + b;  // the k-mer's first base inside lw
         H2 h = {0u, 0u, 0u, 0u};
-        warm_up(h, lw, b + i0, k, tab);  // (k rolling steps: no byte table in this kernel's LDS)
+        warm_up(h, lw, bb, k, tab);  // (k rolling steps: no byte table in this kernel's LDS)
         lh[i0] = canonical<VARIANT>(h);
         for (uint32_t i = i0 + 1; i < i1; ++i) {
-            const uint64_t go = b + i - 1, gi = go + k;
-            const uint32_t o = (lw[go >> 4] >> (2u * ((uint32_t)go & 15u))) & 3u;
-            const uint32_t in = (lw[gi >> 4] >> (2u * ((uint32_t)gi & 15u))) & 3u;
-            nt_step(h, tab[o * 4u + in]);
+            ++kk;
+            if (kk == cr.kidx0 + cr.n_kmers) {  // the next valid k-mer begins behind invalid bases
+                cr = p.runs[++rr];
+                bb = cr.base_off - b_glob + b;
+                h = {0u, 0u, 0u, 0u};
+                warm_up(h, lw, bb, k, tab);
+            } else {
+                const uint64_t go = bb, gi = go + k;
+                const uint32_t o = (lw[go >> 4] >> (2u * ((uint32_t)go & 15u))) & 3u;
+                const uint32_t in = (lw[gi >> 4] >> (2u * ((uint32_t)gi & 15u))) & 3u;
+                nt_step(h, tab[o * 4u + in]);
+                ++bb;
+            }
             lh[i] = canonical<VARIANT>(h);
         }
     }
@@ -1483,11 +1509,14 @@ __device__ __forceinline__ void gap_fix_one(const GapFixParams &p, const uint32_
     }
     if (threadIdx.x == 0) p.r_cnt[j] = total;
     const uint32_t rec = p.ctg_rec[c];
+    uint32_t rr = lo;
+    Run cr = run;
     for (uint32_t i = i0; i < i1 && i0 < n; ++i)
         if ((selbits[i >> 5] >> (i & 31u)) & 1u) {
             const size_t at = (size_t)j * GAP_DEV_REG + o++;
+            seek(rr, cr, klo + i);
             p.r_hash[at] = ext_hash(lh[i], p.mult);
-            p.r_pos[at] = run.pos0 + (klo + i - run.kidx0);
+            p.r_pos[at] = cr.pos0 + (klo + i - cr.kidx0);
             p.r_rec[at] = rec;
         }
 }
@@ -2697,6 +2726,20 @@ struct Driver {
         int rc;
         uint64_t n_gap_mx = 0;
         *n_out = n;
+        if (knob_set(h, "MXG_DEBUG_BATCH")) {  // (diagnostics: what the device route handed over, by length)
+            uint32_t hist[33] = {0};
+            for (const uint4 &g : gaps) {
+                uint32_t len = g.z - g.y + 1u, b = 0;
+                while ((2u << b) <= len) ++b;
+                ++hist[b];
+            }
+            fprintf(stderr, "[mxg] %s: %zu stretches handed over, by length:", a->name.c_str(), gaps.size());
+            for (uint32_t b = 0; b < 33; ++b)
+                if (hist[b]) fprintf(stderr, " 2^%u: %u", b, hist[b]);
+            for (size_t q = 0; q < gaps.size() && q < 6; ++q)
+                fprintf(stderr, " | contig %u k-mers %u..%u", gaps[q].x, gaps[q].y, gaps[q].z);
+            fprintf(stderr, "\n");
+        }
         if (h->cfg.w <= ST_WMAX && !knob_set(h, "MXG_STRETCH_DENSE")) {
             if ((rc = sketch_stretches(a, T, gaps, &n_gap_mx)) != MXG_OK) return rc;
             for (const uint4 &g : gaps) h->stat_dense_kmers += g.z - g.y + 1u;

@@ -114,6 +114,25 @@ def test_select_stretch_ends_behind_the_slice(oracle, env):
         assert st["select_slices"] > 0
 
 
+def test_low_complexity_stretches_stay_on_the_device(oracle, env):
+    """di- and trinucleotide runs longer than a window: every second / third k-mer of the run is a minimizer (the rightmost of
+    equal hashes wins each time the window moves on) -- hundreds per candidate-free stretch, all of them through k_gap_fix"""
+    rng = random.Random(8)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    recs = [("di", rnd(20000) + "AC" * 900 + rnd(7000) + "AT" * 1400 + rnd(9000)),
+            ("tri", rnd(3000) + "GGC" * 800 + rnd(30000) + "GGC" * 1000 + rnd(100)),
+            ("plain", rnd(150000)), ("di_end", rnd(9000) + "TG" * 1200),
+            # invalid bases inside the stretch: its k-mers come from two or three valid runs
+            ("di_n", rnd(12000) + "AC" * 500 + "N" + "AC" * 600 + rnd(8000) + "AT" * 450 + "N" * 20 + "AT" * 450 + "N" * 300 + "AT" * 300
+             + rnd(5000)),
+            ("tri_n", rnd(700) + "N" * 5 + "GGC" * 700 + "NN" + rnd(40000))]
+    env["MXG_DEV_GAPS"] = "1"
+    for w in (1000, 600):
+        st = _check(oracle, recs, 32, w)
+        assert st["select_slices"] > 0
+        assert st["deferred_stretches"] == 0, st["deferred_stretches"]
+
+
 def test_many_batches_and_overflow_on_the_bs_route(oracle, env):
     env["MXG_SPARSE_BATCH_KMERS"] = "30000"
     st = _check(oracle, _records(21), 32, 200)

@@ -24,9 +24,10 @@ def _three_ways(monkeypatch, build):
     res = []
     # default (LDS tables per hash partition), the global table, the fallback after a failed LDS join, and the two-level LDS
     # join that genome-scale inputs (> 5 M minimizers) take, forced here
+    # (MXG_PJ_SKEW=1: every block of the second level collapses equal records, as the blocks of a skewed partition do)
     for env in ({}, {"MXG_GRAPH_JOIN": "global"}, {"MXG_PJ_FORCE_FAIL": "1"}, {"MXG_PJ_TWO_LEVEL": "1"},
-                {"MXG_PJ_TWO_LEVEL": "1", "MXG_PJ_FORCE_FAIL": "1"}):
-        for key in ("MXG_GRAPH_JOIN", "MXG_PJ_FORCE_FAIL", "MXG_PJ_TWO_LEVEL"):
+                {"MXG_PJ_TWO_LEVEL": "1", "MXG_PJ_FORCE_FAIL": "1"}, {"MXG_PJ_TWO_LEVEL": "1", "MXG_PJ_SKEW": "1"}):
+        for key in ("MXG_GRAPH_JOIN", "MXG_PJ_FORCE_FAIL", "MXG_PJ_TWO_LEVEL", "MXG_PJ_SKEW"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
@@ -141,9 +142,12 @@ def test_joins_agree_beyond_256_regions(monkeypatch):
     _three_ways(monkeypatch, build)
 
 
-def test_two_level_join_coarse_partition_overflow_falls_back(monkeypatch):
-    """one key 400 000 times among 900 000 minimizers: its coarse partition outgrows the capacity reserved for it (25 % above
-    the mean); the stage must notice and redo itself with the global table -- same result as asking for that table directly"""
+@pytest.mark.parametrize("adjacent", [True, False])
+def test_two_level_join_one_key_400000_times(monkeypatch, adjacent):
+    """one key 400 000 times among 900 000 minimizers.  In one run (a tandem array): the run travels as one record and nothing
+    overflows.  Scattered among the others: the key's coarse partition outgrows the capacity reserved for it (25 % above the
+    mean); the stage notices, sizes the partitions by what the cursors counted and runs the join again.  Either way the result
+    is the global table's."""
     from ntjoin_amd.engine import MxEngine
     rng = np.random.default_rng(9)
     base = rng.integers(0, 2**63, size=500_000, dtype=np.int64).astype(np.uint64)
@@ -152,7 +156,14 @@ def test_two_level_join_coarse_partition_overflow_falls_back(monkeypatch):
         r = np.random.default_rng(seed)
         hs = base.copy()
         r.shuffle(hs)
-        hs = np.concatenate([hs, np.full(heavy, base[7], dtype=np.uint64)])
+        if adjacent:
+            hs = np.concatenate([hs, np.full(heavy, base[7], dtype=np.uint64)])
+        elif heavy:
+            out = np.empty(hs.size + heavy, dtype=np.uint64)  # every other minimizer of the first 800 000 is the heavy key
+            out[:2 * heavy:2] = base[7]
+            out[1:2 * heavy:2] = hs[:heavy]
+            out[2 * heavy:] = hs[heavy:]
+            hs = out
         rec = np.sort(r.integers(0, 16, size=hs.size)).astype(np.uint32)
         return hs, np.arange(hs.size, dtype=np.uint32), rec, [f"c{i}" for i in range(16)]
 
@@ -167,10 +178,81 @@ def test_two_level_join_coarse_partition_overflow_falls_back(monkeypatch):
             for i, (hs, pos, rec, ids) in enumerate(sets):
                 eng.add_minimizers(f"a{i}", float(i + 1), hs, pos, rec, ids)
             eng.build_graph()
-            assert eng.stats()["vertices"] == 499_999
+            st = eng.stats()
+            assert st["vertices"] == 499_999
+            if "MXG_PJ_TWO_LEVEL" in env:
+                assert st["graph_join"] == (2 if adjacent else 2 | 0x100), hex(st["graph_join"])
+                eng.build_graph()  # the handle remembers the capacity: no second attempt
+                assert eng.stats()["graph_join"] == 2
+            else:
+                assert st["graph_join"] == 3
             res.append(_graph_state(eng, 2))
     for key in res[0]:
         assert np.array_equal(res[0][key], res[1][key]), key
+
+
+def _flag_truth(sets):
+    """UNIQUE / SHARED / INALL per minimizer from numpy (ntjoin_utils.py:152-193: seen once here; once everywhere; everywhere)"""
+    cnt = []
+    for hs, *_ in sets:
+        u, c = np.unique(hs, return_counts=True)
+        cnt.append(dict(zip(u.tolist(), c.tolist())))
+    out = []
+    for a, (hs, *_) in enumerate(sets):
+        fl = np.zeros(hs.size, np.uint8)
+        for i, hv in enumerate(hs.tolist()):
+            cs = [c.get(hv, 0) for c in cnt]
+            inall = all(cs)
+            fl[i] = (1 if cs[a] == 1 else 0) | (2 if inall and max(cs) == 1 else 0) | (4 if inall else 0)
+        out.append(fl)
+    return out
+
+
+def test_joins_agree_on_runs_of_equal_hashes(monkeypatch):
+    """runs of equal hashes in sketch order (what a tandem array leaves): lengths 2 ... 5000, across waves, 256-blocks and
+    bucketing regions, at an assembly's first and last minimizer, one run right behind another, of keys that the other
+    assemblies hold once / not at all / also as a run, and of the key 2^64 - 1; flags against numpy as well"""
+    from ntjoin_amd.engine import MxEngine
+    rng = np.random.default_rng(21)
+    base = rng.integers(0, 2**63, size=30000, dtype=np.int64).astype(np.uint64)
+    base[5] = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def mk(seed, runs, first_run=0, last_run=0):
+        r = np.random.default_rng(seed)
+        hs = base[r.random(base.size) >= 0.03].copy()
+        r.shuffle(hs)
+        parts, at = [], 0
+        if first_run:
+            parts.append(np.full(first_run, base[1], dtype=np.uint64))
+        for j, (key, ln) in enumerate(runs):
+            step = int(r.integers(1, 900))
+            parts.append(hs[at:at + step])
+            at += step
+            parts.append(np.full(ln, base[key], dtype=np.uint64))
+            if j % 3 == 0:  # a second run right behind the first
+                parts.append(np.full(1 + ln // 2, base[key + 1], dtype=np.uint64))
+        parts.append(hs[at:])
+        if last_run:
+            parts.append(np.full(last_run, base[2], dtype=np.uint64))
+        hs = np.concatenate(parts)
+        rec = np.sort(r.integers(0, 9, size=hs.size)).astype(np.uint32)
+        return hs, np.arange(hs.size, dtype=np.uint32), rec, [f"c{i}" for i in range(9)]
+
+    lens = [2, 3, 63, 64, 65, 127, 129, 255, 256, 257, 700, 5000, 2, 2, 70, 70]
+    sets = [mk(1, [(10 + 2 * j, ln) for j, ln in enumerate(lens)], first_run=300, last_run=2),
+            mk(2, [(10 + 2 * j, 1 + ln % 7) for j, ln in enumerate(lens)] + [(5, 80)], last_run=400),
+            mk(3, [(5, 3), (200, 4100), (12, 1)], first_run=2)]
+    truth = _flag_truth(sets)
+
+    def build():
+        with MxEngine(k=32, w=1000) as eng:
+            for i, (hs, pos, rec, ids) in enumerate(sets):
+                eng.add_minimizers(f"a{i}", float(i + 1), hs, pos, rec, ids)
+            eng.build_graph()
+            for a in range(len(sets)):
+                assert np.array_equal(eng.get_mx_flags(a), truth[a]), a
+            return _graph_state(eng, len(sets))
+    _three_ways(monkeypatch, build)
 
 
 @pytest.mark.parametrize("n_asm", [16, 17, 32])

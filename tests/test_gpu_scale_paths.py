@@ -283,12 +283,20 @@ def route_knobs(dev_knobs):
 
 
 def test_stretches_left_to_the_tile_kernel(oracle, route_knobs):
-    """satellite arrays and low-complexity runs: candidate-free stretches longer than the device route's 4096 k-mers, stretches
-    with hundreds of minimizers in a row (every window of a homopolymer reports its last k-mer), stretches across N gaps --
-    handed to k_stretch_tiles and merged into the sketch; the same through the dense pipeline (MXG_STRETCH_DENSE=1)"""
+    """candidate-free stretches longer than the device route's 4096 k-mers (homopolymers, short-unit arrays, some of them
+    across N gaps) -- handed to k_stretch_tiles and merged into the sketch; the same through the dense pipeline
+    (MXG_STRETCH_DENSE=1).  (Stretches of up to 4096 k-mers stay with k_gap_fix, however many minimizers they hold and
+    whatever invalid bases they cross: the repeat-rich records are full of them.)"""
     route_knobs["MXG_DEV_GAPS"] = "1"
     route_knobs["MXG_SPARSE_BATCH_KMERS"] = "600000"
+    import random
+    rng = random.Random(17)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
     recs = _repeat_rich_numpy(3, 4, 700_000)
+    recs += [("long_a", rnd(4000) + "A" * 9000 + rnd(30000) + "AC" * 3500 + rnd(2000)),
+             ("long_n", rnd(9000) + "TTG" * 1500 + "N" * 7 + "TTG" * 1500 + rnd(20000) + "C" * 5000 + "N" + "C" * 4000 + rnd(800)),
+             ("unit7", rnd(600) + "ACGGTCA" * 3000), ("unit5_start", "GATTA" * 2500 + rnd(12000)),
+             ("long_b", rnd(100) + "GA" * 2600 + rnd(60000) + "T" * 4700 + rnd(3000) + "AGC" * 2000 + rnd(10))]
     st = _check(oracle, recs, 32, 500, cand_per_window=10)
     assert st["deferred_stretches"] > 5 and st["batches_redone"] == 0 and st["sync_assemblies"] == 0
     st2 = _check(oracle, recs, 32, 200, cand_per_window=6)
