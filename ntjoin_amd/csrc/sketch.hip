@@ -1396,7 +1396,7 @@ __device__ __forceinline__ void defer_stretch(const GapFixParams &p, const uint4
 // most GAP_DEV_NSMALL k-mers: 23 KB per block, which fits beside the other stream's hash kernel -- blocks of 56 KB, nearly
 // all with nothing to do, waited 100-160 us for a CU with room), global scratch for the rare long ones (k_gap_post's one
 // block walks them before it ranks the stretches).  All early exits are block-uniform.
-constexpr uint32_t GAP_FIX_BLOCKS = 512;   // blocks of k_gap_fix (they walk the batch's stretches)
+constexpr uint32_t GAP_FIX_BLOCKS = 768;   // blocks of k_gap_fix (they walk the batch's stretches): three of 51 KB per CU (tools/sweep_gap_blocks.sh)
 constexpr uint32_t GAP_DEV_NSMALL = 4096;  // (= GAP_DEV_NMAX since round 3: the filter kernel of the k = 32 route uses no LDS, so a
                                            // 51 KB block finds room; the one-block walk of the longer stretches in k_gap_post took 45 us
                                            // in three batches of thirteen at configs[2]; 1792 and 23 KB before)
@@ -2336,10 +2336,11 @@ struct Driver {
         // the batch's slice of the pinned list of deferred stretches goes with its pinned control block
         gp.defer = reinterpret_cast<uint4 *>(h->pinned_defer) + (size_t)((ctrl_host - h->pinned_ctrl) / 16) * GAP_DEV_MAX;
         gp.tab = h->tab;
+        const uint32_t gf_blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64(h, "MXG_GAP_FIX_BLOCKS", GAP_FIX_BLOCKS), 1), GAP_DEV_MAX);
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
-            hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V1_MIN>, dim3(GAP_FIX_BLOCKS), dim3(256), 0, st, gp);
+            hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V1_MIN>, dim3(gf_blocks), dim3(256), 0, st, gp);
         else
-            hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V2_SUM>, dim3(GAP_FIX_BLOCKS), dim3(256), 0, st, gp);
+            hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V2_SUM>, dim3(gf_blocks), dim3(256), 0, st, gp);
         GapPostParams pp;
         pp.ctrl = sc(SC_CTRL).as<uint32_t>();
         pp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
