@@ -1054,10 +1054,13 @@ __global__ __launch_bounds__(256) void k_count_n(const uint8_t *__restrict__ sel
     if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
 }
 
-constexpr uint32_t GAP_DEV_MAX = 2048;  // stretches per batch the device route holds (defined here: k_emit places them)
-constexpr uint32_t GAP_DEV_REG = 4096;  // minimizers per stretch (= GAP_DEV_NMAX: whatever a stretch of that length holds.  64 until
-                                        // round 4: a di- or trinucleotide run longer than w reports every second or third k-mer,
-                                        // and each such stretch went to the host and through the dense kernels)
+constexpr uint32_t GAP_DEV_MAX = 4096;  // stretches per batch the device route holds (defined here: k_emit places them)
+// Their minimizers wait in one pool per batch, each stretch's in a region of the size it needs (k_gap_fix reserves it with one
+// add to ctrl[14]; r_start[stretch]).  Until round 4 every stretch had a region of 64 entries: a di- or trinucleotide run longer
+// than w reports every second or third k-mer, and each such stretch went to the host and through the dense kernels.  A pool that
+// runs out (a batch whose stretches hold more than four million minimizers) hands the stretch to the host like any other it
+// cannot keep.
+constexpr uint32_t GAP_DEV_POOL = 4u << 20;
 constexpr uint32_t EMIT_COMPACT_BLOCKS = 16;  // k_resolve blocks per k_emit tile on the sparse path (a power of two)
 struct EmitParams {
     const uint8_t *sel;
@@ -1093,7 +1096,7 @@ struct EmitParams {
     uint32_t n_tiles;      // tiles of the candidate array = blocks that emit; blocks beyond them place stretches (dev_gaps)
     const uint64_t *s_key; const uint32_t *s_off, *s_src;
     const uint4 *gaps;
-    const uint64_t *r_hash; const uint32_t *r_pos, *r_rec, *r_cnt;
+    const uint64_t *r_hash; const uint32_t *r_pos, *r_rec, *r_cnt, *r_start;
     // the selected candidates laid out per k_resolve block (ResolveParams::cs_*): replaces sel / ch / ck / cc
     const uint64_t *cs_h;
     const uint32_t *cs_k, *cs_c;
@@ -1157,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
         const uint64_t o0 = obase + count_prefix(p.cnt256, p.sel_sup, b) + wave_sum_u32(below) + p.s_off[r];
         const uint32_t rc = p.r_cnt[g];
         for (uint32_t e = lane; e < rc && o0 + e < limit; e += 64u) {
-            const size_t at = (size_t)g * GAP_DEV_REG + e;
+            const size_t at = (size_t)p.r_start[g] + e;
             p.o_hash[o0 + e] = p.r_hash[at];
             p.o_pos[o0 + e] = p.r_pos[at];
             p.o_rec[o0 + e] = p.r_rec[at];
@@ -1257,7 +1260,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     // A few hundred stretches among a million minimizers: almost every tile lies between two neighbouring stretches, so the
     // tile's first and last key are searched once and only a tile that straddles a stretch searches per minimizer.
     // (up to EK stretch keys are copied to LDS in one round trip: the searches then do not walk through L2)
-    constexpr uint32_t EK = 1024;
+    constexpr uint32_t EK = 2048;
     __shared__ uint64_t skeys[EK];
     __shared__ uint32_t lb_edge[2];
     const uint64_t *keys = p.s_key;
@@ -1359,8 +1362,8 @@ __global__ __launch_bounds__(256) void k_merge(const MergeParams p)
 //   k_gap_post   one block: ranks the stretches by (contig, first k-mer); sorted keys + minimizers before each stretch
 //   k_emit       (runs after them) writes the batch's own minimizers straight to their final places, shifted by the
 //                stretch minimizers before each; a few extra blocks put the stretches' minimizers in between; reports
-// Anything this route cannot hold -- more than GAP_DEV_MAX stretches, a stretch longer than GAP_DEV_NMAX k-mers or cut by
-// invalid bases, more than GAP_DEV_REG minimizers in one stretch (low-complexity sequence) -- is left out here: more than
+// Anything this route cannot hold -- more than GAP_DEV_MAX stretches, a stretch longer than GAP_DEV_NMAX k-mers or with more
+// invalid bases inside than the block's words take, minimizers beyond the batch's pool -- is left out here: more than
 // GAP_DEV_MAX stretches raise ctrl[6] and the host redoes the batch; single stretches are handed to the host (defer_stretch).
 constexpr uint32_t GAP_DEV_NMAX = 4096;
 
@@ -1374,16 +1377,17 @@ struct GapFixParams {
     const uint4 *init_tab;
     uint32_t k, w;
     uint64_t mult;
-    uint64_t *r_hash;    // [GAP_DEV_MAX][GAP_DEV_REG]
+    uint64_t *r_hash;    // [GAP_DEV_POOL]
     uint32_t *r_pos, *r_rec;
     uint32_t *r_cnt;     // [GAP_DEV_MAX]
+    uint32_t *r_start;   // [GAP_DEV_MAX] the stretch's region of the pool
     uint64_t *r_key;     // [GAP_DEV_MAX] contig << 32 | k_lo
     uint4 *defer;        // [GAP_DEV_MAX] (pinned host memory) stretches left to the host: ctrl[11] of them
     HashTab tab;
 };
 
-// A stretch this route cannot hold (longer than GAP_DEV_NMAX k-mers, cut by invalid bases, more than GAP_DEV_REG minimizers:
-// satellite arrays, low-complexity runs) contributes nothing here; the host sketches it afterwards through the dense pipeline
+// A stretch this route cannot hold (longer than GAP_DEV_NMAX k-mers: satellite arrays, long low-complexity runs; too many
+// invalid bases inside; the pool used up) contributes nothing here; the host sketches it afterwards through the dense pipeline
 // and merges its minimizers into the assembly's sketch (Driver::merge_deferred).  One thread of the block calls this.
 __device__ __forceinline__ void defer_stretch(const GapFixParams &p, const uint4 gp)
 {
@@ -1503,17 +1507,24 @@ __device__ __forceinline__ void gap_fix_one(const GapFixParams &p, const uint32_
     uint32_t o = block_exclusive_256(cnt, sh);
     const uint32_t total = sh[255];
     if (threadIdx.x == 0) atomicAdd(&p.ctrl[10], n);
-    if (total > GAP_DEV_REG) {
+    if (threadIdx.x == 0) sh[0] = total ? atomicAdd(&p.ctrl[14], total) : 0u;  // (sh: the scan is done with it)
+    __syncthreads();
+    const uint32_t region = sh[0];
+    __syncthreads();
+    if (region + total > GAP_DEV_POOL) {  // (block-uniform)
         if (threadIdx.x == 0) defer_stretch(p, gp);
         return;
     }
-    if (threadIdx.x == 0) p.r_cnt[j] = total;
+    if (threadIdx.x == 0) {
+        p.r_cnt[j] = total;
+        p.r_start[j] = region;
+    }
     const uint32_t rec = p.ctg_rec[c];
     uint32_t rr = lo;
     Run cr = run;
     for (uint32_t i = i0; i < i1 && i0 < n; ++i)
         if ((selbits[i >> 5] >> (i & 31u)) & 1u) {
-            const size_t at = (size_t)j * GAP_DEV_REG + o++;
+            const size_t at = (size_t)region + o++;
             seek(rr, cr, klo + i);
             p.r_hash[at] = ext_hash(lh[i], p.mult);
             p.r_pos[at] = cr.pos0 + (klo + i - cr.kidx0);
@@ -2102,7 +2113,7 @@ struct Driver {
         ep.s_off = ep.s_src = nullptr;
         ep.gaps = nullptr;
         ep.r_hash = nullptr;
-        ep.r_pos = ep.r_rec = ep.r_cnt = nullptr;
+        ep.r_pos = ep.r_rec = ep.r_cnt = ep.r_start = nullptr;
         uint32_t grid = ep.n_tiles;
         if (ep.dev_gaps) {
             ep.s_key = sc(SC_GD_HASH).as<uint64_t>();
@@ -2113,6 +2124,7 @@ struct Driver {
             ep.r_pos = sc(SC_GR_POS).as<uint32_t>();
             ep.r_rec = sc(SC_GR_REC).as<uint32_t>();
             ep.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
+            ep.r_start = ep.r_cnt + GAP_DEV_MAX;
             grid += GAP_DEV_MAX / 4;
         }
         hipLaunchKernelGGL(k_emit, dim3(grid), dim3(256), 0, st, ep);
@@ -2308,10 +2320,10 @@ struct Driver {
     // stretches sketched on the device, one block each (results wait in their regions for k_gap_post): reads SC_GAPS / ctrl[1]
     int enqueue_dev_gaps(Assembly *a, const Tables &T, const uint32_t *ctrl_host)
     {
-        MXG_HIP(h, sc(SC_GR_HASH).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 8));
-        MXG_HIP(h, sc(SC_GR_POS).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
-        MXG_HIP(h, sc(SC_GR_REC).ensure((size_t)GAP_DEV_MAX * GAP_DEV_REG * 4));
-        MXG_HIP(h, sc(SC_GR_CNT).ensure((size_t)GAP_DEV_MAX * 4));
+        MXG_HIP(h, sc(SC_GR_HASH).ensure((size_t)GAP_DEV_POOL * 8));
+        MXG_HIP(h, sc(SC_GR_POS).ensure((size_t)GAP_DEV_POOL * 4));
+        MXG_HIP(h, sc(SC_GR_REC).ensure((size_t)GAP_DEV_POOL * 4));
+        MXG_HIP(h, sc(SC_GR_CNT).ensure((size_t)GAP_DEV_MAX * 8));  // counts, then the regions' starts
         MXG_HIP(h, sc(SC_GR_KEY).ensure((size_t)GAP_DEV_MAX * 8));
         MXG_HIP(h, sc(SC_GD_HASH).ensure((size_t)(GAP_DEV_MAX + 1) * 8));  // the stretches in order: key,
         MXG_HIP(h, sc(SC_GD_POS).ensure((size_t)(GAP_DEV_MAX + 1) * 4));   // minimizers before,
@@ -2332,6 +2344,7 @@ struct Driver {
         gp.r_pos = sc(SC_GR_POS).as<uint32_t>();
         gp.r_rec = sc(SC_GR_REC).as<uint32_t>();
         gp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
+        gp.r_start = gp.r_cnt + GAP_DEV_MAX;
         gp.r_key = sc(SC_GR_KEY).as<uint64_t>();
         // the batch's slice of the pinned list of deferred stretches goes with its pinned control block
         gp.defer = reinterpret_cast<uint4 *>(h->pinned_defer) + (size_t)((ctrl_host - h->pinned_ctrl) / 16) * GAP_DEV_MAX;
@@ -3094,7 +3107,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         for (int pass = sel_ok ? 0 : 1; pass < 2; ++pass) {
             uint64_t budget = plans[i].batch_kmers;
             if (pass == 0) {
-                const uint64_t big = env_u64(h, "MXG_SEL_BATCH_KMERS", 2040ull << 20);
+                const uint64_t big = env_u64(h, "MXG_SEL_BATCH_KMERS", 3600ull << 20);  // (k-mers of a batch are counted in 32 bits)
                 budget = std::min<uint64_t>(plans[i].gap_kmers ? plans[i].gap_kmers : big, big);
                 if (knob_set(h, "MXG_SPARSE_BATCH_KMERS")) budget = std::min<uint64_t>(budget, SPARSE_BATCH_KMERS);  // (test knob)
             }
