@@ -150,19 +150,19 @@ __device__ __forceinline__ uint32_t pj_part(uint64_t key, uint32_t pmask)
 }
 
 // Runs of equal hashes in sketch order -- a tandem array leaves the same minimizer once per unit: tens of thousands of copies of
-// one key in a satellite-rich genome, all in one partition, all for one block of k_pj_join -- go through the join as ONE
-// record: the run's first minimizer (the leader), marked "more than once in its assembly" (PJ_REC_DUP in the record's
-// assembly word).  The others (followers) are left out of the records; k_flags_pj gives them their verdict (not unique, not
-// shared, in every assembly iff the leader's key is).  Called by whole waves (lane = 64 consecutive minimizers of one block).
+// one key in a satellite-rich genome, all in one partition, all for one block of k_pj_join -- go through the join as one
+// record per wave they touch: the first of the run's minimizers among the wave's 64 (the leader), marked "more than once in
+// its assembly" (PJ_REC_DUP in the record's assembly word).  The others (followers) are left out of the records; k_flags_pj
+// gives them their verdict (not unique, not shared, in every assembly iff the leader's key is).  A run that crosses into the
+// next wave starts again there: its parts meet in the join like any two records of one key.  Called by whole waves (lane = 64
+// consecutive minimizers of one block).
 constexpr uint32_t PJ_REC_DUP = 0x80000000u;
-__device__ __forceinline__ uint32_t pj_run_role(const uint64_t *hp, uint32_t i, uint32_t n, uint64_t key, bool live)
+__device__ __forceinline__ uint32_t pj_run_role(uint32_t i, uint32_t n, uint64_t key, bool live)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    uint64_t prev = __shfl_up(key, 1), next = __shfl_down(key, 1);
-    if (live && lane == 0 && i > 0) prev = hp[i - 1];
-    if (live && lane == 63 && i + 1 < n) next = hp[i + 1];
-    const bool fol = live && i > 0 && prev == key;
-    const bool lead = live && !fol && i + 1 < n && next == key;
+    const uint64_t prev = __shfl_up(key, 1), next = __shfl_down(key, 1);
+    const bool fol = live && lane > 0 && prev == key;
+    const bool lead = live && !fol && lane < 63 && i + 1 < n && next == key;
     return (fol ? 1u : 0u) | (lead ? 2u : 0u);
 }
 
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(PJ_BT) void k_pj_bucket(const AsmSet p, uint32_t nb
         }
         const bool lv = i < n;
         if (lv) key[u] = hp[i];
-        const uint32_t role = pj_run_role(hp, i, n, key[u], lv);
+        const uint32_t role = pj_run_role(i, n, key[u], lv);
         const uint64_t fb = __ballot(role & 1u);
         if ((threadIdx.x & 63u) == 0) p.fol[(size_t)blk * 4u + ((threadIdx.x >> 6) & 3u)] = fb;
         if (lv && !(role & 1u)) live |= 1u << u;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(PJ_BT) void k_pj1_scatter(const AsmSet p, uint32_t 
         const uint32_t i = (blk - p.bstart[a]) * 256u + t256, n = asm_n(p, a);
         const bool lv = i < n;
         if (lv) key[u] = p.hash[a][i];
-        const uint32_t role = pj_run_role(p.hash[a], i, n, key[u], lv);  // (followers travel with their run's leader)
+        const uint32_t role = pj_run_role(i, n, key[u], lv);  // (followers travel with their run's leader)
         const uint64_t fb = __ballot(role & 1u);
         if ((threadIdx.x & 63u) == 0) p.fol[(size_t)blk * 4u + ((threadIdx.x >> 6) & 3u)] = fb;
         if (lv && !(role & 1u)) {
@@ -603,31 +603,24 @@ __global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, uint32_t *cnt,
     }
     bool sh = false;
     {
-        // the verdict k_pj_join left here (k_vertices_pj reads the word's upper part) -- a follower (pj_run_role) has none: its
-        // run's leader, the last minimizer in front of it that is no follower, says whether the key is in every assembly
+        // the verdict k_pj_join left here (k_vertices_pj reads the word's upper part) -- or a reference to the minimizer that
+        // went on for this one (k_pj2_bucket); a follower (pj_run_role) has neither: its leader, the last lane in front of it
+        // that is no follower, says whether the key is in every assembly
         const bool in = i < asm_n(p, a);
-        const uint32_t lane = threadIdx.x & 63u, w0 = blockIdx.x * 4u + (threadIdx.x >> 6);
-        const uint64_t fb = p.fol[w0];
-        const bool isf = in && ((fb >> lane) & 1ull);
-        uint64_t m = ~fb & ((2ull << lane) - 1ull);  // (lane 63: the shift wraps to 0, the mask to all ones)
-        uint32_t wq = w0;
-        if (__ballot(isf && m == 0)) {  // the run began in front of this wave's 64: one walk back for the wave, ending inside
-            uint64_t mp;                // the assembly (its first minimizer follows nobody)
-            uint32_t wp = w0;
-            do mp = ~p.fol[--wp]; while (mp == 0);
-            if (m == 0) {
-                m = mp;
-                wq = wp;
-            }
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint64_t fb = p.fol[blockIdx.x * 4u + (threadIdx.x >> 6)];
+        const bool isf = (fb >> lane) & 1ull;
+        uint32_t v = in && !isf ? p.slot[a][i] : 0u;
+        bool other = isf;
+        if ((v & 7u) == PJ_VERDICT_REF) {
+            v = p.slot[a][v >> 3];
+            other = true;
         }
+        const uint32_t lead = 63u - (uint32_t)__clzll(~fb & ((2ull << lane) - 1ull));  // (lane 0 follows nobody; lane 63: the
+        const uint32_t vl = __shfl(v, lead);                                            //  shift wraps to 0, the mask to all ones)
+        if (isf) v = vl;
+        if (other) v &= MXG_MX_INALL;  // more than once in this assembly: neither unique nor shared
         if (in) {
-            uint32_t v = p.slot[a][isf ? (wq - p.bstart[a] * 4u) * 64u + 63u - (uint32_t)__clzll(m) : i];
-            bool other = isf;
-            if ((v & 7u) == PJ_VERDICT_REF) {  // (k_pj2_bucket: the record was one of many of its key; the one it names went on)
-                v = p.slot[a][v >> 3];
-                other = true;
-            }
-            if (other) v &= MXG_MX_INALL;  // more than once in this assembly: neither unique nor shared
             sh = (v & MXG_MX_SHARED) != 0;
             p.flags[a][i] = (uint8_t)(v & 7u);
             p.shared[a][i] = sh ? 1 : 0;
