@@ -1061,6 +1061,7 @@ constexpr uint32_t GAP_DEV_MAX = 4096;  // stretches per batch the device route 
 // runs out (a batch whose stretches hold more than four million minimizers) hands the stretch to the host like any other it
 // cannot keep.
 constexpr uint32_t GAP_DEV_POOL = 4u << 20;
+constexpr uint32_t GAP_DEFER_MAX = 1024;  // stretches per batch that can be handed to the host (a batch's slice of a pinned array)
 constexpr uint32_t EMIT_COMPACT_BLOCKS = 16;  // k_resolve blocks per k_emit tile on the sparse path (a power of two)
 struct EmitParams {
     const uint8_t *sel;
@@ -1382,7 +1383,7 @@ struct GapFixParams {
     uint32_t *r_cnt;     // [GAP_DEV_MAX]
     uint32_t *r_start;   // [GAP_DEV_MAX] the stretch's region of the pool
     uint64_t *r_key;     // [GAP_DEV_MAX] contig << 32 | k_lo
-    uint4 *defer;        // [GAP_DEV_MAX] (pinned host memory) stretches left to the host: ctrl[11] of them
+    uint4 *defer;        // [GAP_DEFER_MAX] (pinned host memory) stretches left to the host: ctrl[11] of them
     HashTab tab;
 };
 
@@ -1392,7 +1393,7 @@ struct GapFixParams {
 __device__ __forceinline__ void defer_stretch(const GapFixParams &p, const uint4 gp)
 {
     const uint32_t at = atomicAdd(&p.ctrl[11], 1u);
-    if (at < GAP_DEV_MAX) p.defer[at] = gp;
+    if (at < GAP_DEFER_MAX) p.defer[at] = gp;
     else p.ctrl[6] = 1;
 }
 
@@ -1893,7 +1894,7 @@ constexpr uint32_t PINNED_SLOTS = 1024;
 static int ensure_pinned_ctrl(mxg_handle *h)
 {
     if (!h->pinned_ctrl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_ctrl, (size_t)PINNED_SLOTS * 64));
-    if (!h->pinned_defer) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_defer, (size_t)PINNED_SLOTS * GAP_DEV_MAX * 16));
+    if (!h->pinned_defer) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_defer, (size_t)PINNED_SLOTS * GAP_DEFER_MAX * 16));
     return MXG_OK;
 }
 
@@ -2347,7 +2348,7 @@ struct Driver {
         gp.r_start = gp.r_cnt + GAP_DEV_MAX;
         gp.r_key = sc(SC_GR_KEY).as<uint64_t>();
         // the batch's slice of the pinned list of deferred stretches goes with its pinned control block
-        gp.defer = reinterpret_cast<uint4 *>(h->pinned_defer) + (size_t)((ctrl_host - h->pinned_ctrl) / 16) * GAP_DEV_MAX;
+        gp.defer = reinterpret_cast<uint4 *>(h->pinned_defer) + (size_t)((ctrl_host - h->pinned_ctrl) / 16) * GAP_DEFER_MAX;
         gp.tab = h->tab;
         const uint32_t gf_blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64(h, "MXG_GAP_FIX_BLOCKS", GAP_FIX_BLOCKS), 1), GAP_DEV_MAX);
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
@@ -3307,8 +3308,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             // stretches the device route left to the host (too long, too many minimizers, invalid bases inside)
             std::vector<uint4> deferred;
             for (size_t q = q0; q < q1 && !chain_modes; ++q) {
-                const uint32_t nd = items[q].hc[11] == 0xFFFFFFFFu ? 0u : std::min(items[q].hc[11], GAP_DEV_MAX);
-                const uint4 *src = reinterpret_cast<const uint4 *>(h->pinned_defer) + (size_t)((items[q].hc - h->pinned_ctrl) / 16) * GAP_DEV_MAX;
+                const uint32_t nd = items[q].hc[11] == 0xFFFFFFFFu ? 0u : std::min(items[q].hc[11], GAP_DEFER_MAX);
+                const uint4 *src = reinterpret_cast<const uint4 *>(h->pinned_defer) + (size_t)((items[q].hc - h->pinned_ctrl) / 16) * GAP_DEFER_MAX;
                 deferred.insert(deferred.end(), src, src + nd);
             }
             uint64_t n_final = total;
@@ -3392,8 +3393,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             // (the batches that are kept may have left stretches to the host: their lists are read before anything reuses the slots)
             std::vector<uint4> deferred;
             for (size_t q = q0; q < j; ++q) {
-                const uint32_t nd = items[q].hc[11] == 0xFFFFFFFFu ? 0u : std::min(items[q].hc[11], GAP_DEV_MAX);
-                const uint4 *src = reinterpret_cast<const uint4 *>(h->pinned_defer) + (size_t)((items[q].hc - h->pinned_ctrl) / 16) * GAP_DEV_MAX;
+                const uint32_t nd = items[q].hc[11] == 0xFFFFFFFFu ? 0u : std::min(items[q].hc[11], GAP_DEFER_MAX);
+                const uint4 *src = reinterpret_cast<const uint4 *>(h->pinned_defer) + (size_t)((items[q].hc - h->pinned_ctrl) / 16) * GAP_DEFER_MAX;
                 deferred.insert(deferred.end(), src, src + nd);
             }
             if ((rc = drv0.sparse_all(a, tabs[i], out, rp.tau_hi, rp.frac, items[j].g.c0)) != MXG_OK) return rc;
