@@ -103,6 +103,8 @@ void mxg_destroy(mxg_handle *h)
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_bs) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_sel_done)
+        if (e) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (hipEvent_t e : h->ev_g)

@@ -2598,6 +2598,7 @@ struct Driver {
         bp.cand_spread = sel_sup(0) + sup_words(b.n_slices);
         bp.ablate = (uint32_t)env_u64(h, "MXG_SEL_ABLATE", 0);  // (profiling only: stop every slice after phase n)
         if ((rc = launch_bs_select(h, bp, b, st)) != MXG_OK) return rc;
+        if (h->ev_sel_done[slot]) MXG_HIP(h, hipEventRecord(h->ev_sel_done[slot], st));  // (the next assembly's filter may start here)
         h->stat_sel_slices += b.n_slices;
         const bool dev = io && io->dev_gaps;
         if ((rc = ev_next(3)) != MXG_OK) return rc;
@@ -3075,6 +3076,10 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
     std::vector<size_t> item0(n + 1, 0);
     size_t last_on_slot[4] = {(size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
     size_t n_enq = 0, next_slot = 0;
+    int last_sel_slot = -1;  // the stream slot the last slice kernel of this call went to
+    const bool stagger = knob_u64(h, "MXG_STAGGER", 1) != 0;
+    for (int q = 0; q < 4; ++q)
+        if (!h->ev_sel_done[q]) MXG_HIP(h, hipEventCreateWithFlags(&h->ev_sel_done[q], hipEventDisableTiming));
     const bool chain_modes = fuse_graph || xp;  // (these two need one batch per assembly)
     // the batches of assembly i -> the streams (attempt 0; attempt 1: once more for an assembly whose batches did not all end
     // the common way, now sized by what the first attempt saw: stretch density, candidate counts, slice capacity)
@@ -3155,6 +3160,13 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 // (the bitmap of the first attempt is still there, and every stream has been waited for)
             } else if (use_bs && b == 0) {  // the filter, once per assembly, on the first batch's stream
                 st_hash = drv.st;
+                // ... behind the slice kernel of the assembly before it when that runs on another stream: each of the two fills
+                // the register file, side by side they only take turns; the tails behind the slice kernel (stretches, emit)
+                // leave room.  Assemblies too small to fill the GPU run free.  (MXG_STAGGER=0: the streams run free -- the step takes the same time within the noise of a run,
+                // tools/stagger_try.sh, but a filter that shares the GPU with a slice kernel takes 0.63 ms instead of 0.44, and
+                // neither kernel's time says anything about the kernel any more)
+                if (stagger && !one_stream && last_sel_slot >= 0 && drvs[last_sel_slot] != &drv && list[i]->total_kmers >= (256ull << 20))
+                    MXG_HIP(h, hipStreamWaitEvent(drv.st, h->ev_sel_done[last_sel_slot], 0));
                 if ((rc = drv.ev_begin(list[i]->total_bases, true)) != MXG_OK) return rc;
                 if ((rc = bs_hash(h, list[i], plans[i].tau_hi, drv.st)) != MXG_OK) return rc;
                 h->stat_bs_bases += list[i]->total_bases;
@@ -3195,6 +3207,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             }
             if (sel_ok) {
                 if ((rc = drv.enqueue_sel(list[i], tabs[i], it.g, bgs[b], plans[i].tau_hi, out, it.hc, &io)) != MXG_OK) return rc;
+                last_sel_slot = (int)sl;
             } else if ((rc = drv.enqueue_sparse(list[i], tabs[i], it.g, drv.default_wave_cap(list[i]->S_sparse, plans[i].frac),
                                                 plans[i].tau_hi, out, it.hc, &it.n_cap, &io, list[i]->cand_hints[b],
                                                 use_bs ? list[i]->d_bs_out.as<uint32_t>() + 4 : nullptr)) != MXG_OK)
