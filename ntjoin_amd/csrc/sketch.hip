@@ -3162,10 +3162,11 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 st_hash = drv.st;
                 // ... behind the slice kernel of the assembly before it when that runs on another stream: each of the two fills
                 // the register file, side by side they only take turns; the tails behind the slice kernel (stretches, emit)
-                // leave room.  Assemblies too small to fill the GPU run free.  (MXG_STAGGER=0: the streams run free -- the step takes the same time within the noise of a run,
-                // tools/stagger_try.sh, but a filter that shares the GPU with a slice kernel takes 0.63 ms instead of 0.44, and
-                // neither kernel's time says anything about the kernel any more)
-                if (stagger && !one_stream && last_sel_slot >= 0 && drvs[last_sel_slot] != &drv && list[i]->total_kmers >= (256ull << 20))
+                // leave room.  Only for assemblies of 2^31 k-mers and more: there the free-running streams gain 1 % of the step
+                // (3.20 against 3.24 ms at 3 Gbp + 3 Gbp, tools/stagger_try.sh) and a filter that shares the GPU with a slice
+                // kernel takes 0.64 ms instead of 0.44 -- neither kernel's time says anything about the kernel any more; at
+                // 1 Gbp + 1 Gbp, where the tails weigh more, running free is 6 % faster and stays.  (MXG_STAGGER=0: never)
+                if (stagger && !one_stream && last_sel_slot >= 0 && drvs[last_sel_slot] != &drv && list[i]->total_kmers >= (1ull << 31))
                     MXG_HIP(h, hipStreamWaitEvent(drv.st, h->ev_sel_done[last_sel_slot], 0));
                 if ((rc = drv.ev_begin(list[i]->total_bases, true)) != MXG_OK) return rc;
                 if ((rc = bs_hash(h, list[i], plans[i].tau_hi, drv.st)) != MXG_OK) return rc;
