@@ -628,11 +628,16 @@ def main():
                 eng3.add_packed_device(name, weight, d.data_ptr(), segs[:, 0], segs[:, 2])
             torch.cuda.synchronize()
             t1s = time.perf_counter()
-            step(eng3)
+            eng3.sketch(-2)
+            torch.cuda.synchronize()
+            t1g = time.perf_counter()
+            eng3.build_graph()
             torch.cuda.synchronize()
             one_ms = (time.perf_counter() - t1s) * 1e3
             s3 = eng3.stats()
             out["one_shot"] = {"ms": round(one_ms, 3), "value": round(bases_total / (one_ms * 1e-3) / 1e9, 2), "unit": "Gbp/s",
+                               "sketch_ms": round((t1g - t1s) * 1e3, 3), "graph_ms": round(one_ms - (t1g - t1s) * 1e3, 3),
+                               "graph_join": hex(int(s3.get("graph_join", 0))),
                                "vs_steady_state": round(one_ms / ms_step, 2),
                                "assemblies_enqueued_twice": int(s3["retried_assemblies"]), "batches_redone": int(s3["batches_redone"]),
                                "what": "first sketch + graph step of a fresh handle on the same resident bases, timed after the steady-state "
