@@ -1382,6 +1382,7 @@ struct GapFixParams {
     uint32_t *r_pos, *r_rec;
     uint32_t *r_cnt;     // [GAP_DEV_MAX]
     uint32_t *r_start;   // [GAP_DEV_MAX] the stretch's region of the pool
+    uint32_t pool;       // entries of the pool (GAP_DEV_POOL; MXG_GAP_POOL: test knob)
     uint64_t *r_key;     // [GAP_DEV_MAX] contig << 32 | k_lo
     uint4 *defer;        // [GAP_DEFER_MAX] (pinned host memory) stretches left to the host: ctrl[11] of them
     HashTab tab;
@@ -1512,7 +1513,7 @@ __device__ __forceinline__ void gap_fix_one(const GapFixParams &p, const uint32_
     __syncthreads();
     const uint32_t region = sh[0];
     __syncthreads();
-    if (region + total > GAP_DEV_POOL) {  // (block-uniform)
+    if (region + total > p.pool) {  // (block-uniform)
         if (threadIdx.x == 0) defer_stretch(p, gp);
         return;
     }
@@ -2346,6 +2347,7 @@ struct Driver {
         gp.r_rec = sc(SC_GR_REC).as<uint32_t>();
         gp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
         gp.r_start = gp.r_cnt + GAP_DEV_MAX;
+        gp.pool = (uint32_t)std::min<uint64_t>(env_u64(h, "MXG_GAP_POOL", GAP_DEV_POOL), GAP_DEV_POOL);
         gp.r_key = sc(SC_GR_KEY).as<uint64_t>();
         // the batch's slice of the pinned list of deferred stretches goes with its pinned control block
         gp.defer = reinterpret_cast<uint4 *>(h->pinned_defer) + (size_t)((ctrl_host - h->pinned_ctrl) / 16) * GAP_DEFER_MAX;

@@ -19,7 +19,7 @@ from tests.test_gpu_scale_paths import _check, _records
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUTE_KNOBS = ("MXG_BS", "MXG_BS_SELECT", "MXG_SEL_QCAP", "MXG_SPARSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S", "MXG_DEV_GAPS")
+ROUTE_KNOBS = ("MXG_GAP_POOL", "MXG_BS", "MXG_BS_SELECT", "MXG_SEL_QCAP", "MXG_SPARSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S", "MXG_DEV_GAPS")
 
 
 @pytest.fixture
@@ -131,6 +131,15 @@ def test_low_complexity_stretches_stay_on_the_device(oracle, env):
         st = _check(oracle, recs, 32, w)
         assert st["select_slices"] > 0
         assert st["deferred_stretches"] == 0, st["deferred_stretches"]
+    # a pool of 300 entries: the stretches that find it used up go to the host and through the tile kernel, same sketch
+    env["MXG_GAP_POOL"] = "300"
+    st = _check(oracle, recs, 32, 1000)
+    assert st["deferred_stretches"] > 0
+    env.pop("MXG_GAP_POOL")
+    # more invalid bases inside a stretch than the block's words take: handed over as well
+    recs2 = [("wide_n", rnd(6000) + "AT" * 900 + "N" * 3000 + "AT" * 900 + rnd(9000)), ("plain", rnd(90000))]
+    st = _check(oracle, recs2, 32, 1000)
+    assert st["deferred_stretches"] > 0
 
 
 def test_many_batches_and_overflow_on_the_bs_route(oracle, env):
