@@ -1064,6 +1064,7 @@ constexpr uint32_t GAP_DEV_POOL = 4u << 20;
 constexpr uint32_t GAP_DEFER_MAX = 1024;  // stretches per batch that can be handed to the host (a batch's slice of a pinned array)
 constexpr uint32_t EMIT_COMPACT_BLOCKS = 16;  // k_resolve blocks per k_emit tile on the sparse path (a power of two)
 struct EmitParams {
+    uint32_t ecb;        // compact mode: blocks (slices) of selected candidates per tile, a power of two <= 64
     const uint8_t *sel;
     const uint64_t *ch;
     const uint32_t *ck, *cc;
@@ -1170,7 +1171,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     }
     // compact mode (the sparse path: k_resolve laid the selected candidates out per block): a tile = ECB blocks of k_resolve,
     // ~400 minimizers; flag mode (dense path): a tile = TILE candidates
-    constexpr uint32_t ECB = EMIT_COMPACT_BLOCKS;
+    const uint32_t ECB = p.ecb;  // (16 behind k_resolve's blocks of 256 candidates; the slices of k_bs_select hold ~18 each: 32 or 64)
     const uint32_t tile = blockIdx.x - n_place;
     const uint32_t span = p.cs_h ? ECB * RKe : (uint32_t)TILE;
     if ((uint64_t)tile * span >= n) return;  // whole tile beyond the candidates
@@ -1178,7 +1179,7 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     const uint32_t fl = p.cs_h ? 0u : load_flags4(p.sel, base, n);
     uint32_t c = count_flags4(fl);
     uint32_t before;
-    __shared__ uint32_t spre[ECB + 1];  // compact mode: the selected counts of the tile's blocks as a prefix
+    __shared__ uint32_t spre[64 + 1];  // compact mode: the selected counts of the tile's blocks as a prefix
     if (p.bsum) {
         before = p.bsum[tile];
     } else {
@@ -1237,7 +1238,6 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     auto item = [&](uint32_t r, uint64_t &hsh, uint32_t &kx, uint32_t &ctg) {  // minimizer r of the tile
         if (p.cs_h) {
             uint32_t u = 0;  // the block holding it: last u with spre[u] <= r
-#pragma unroll
             for (uint32_t st = ECB / 2; st > 0; st >>= 1)
                 if (spre[u + st] <= r) u += st;
             const uint32_t src = (tile * ECB + u) * RKe + (r - spre[u]);
@@ -2067,6 +2067,7 @@ struct Driver {
         uint64_t *base_out = nullptr;
         bool dev_gaps = false;
         hipEvent_t wait = nullptr;  // recorded behind the previous batch of the assembly when that ran on the other stream
+        uint32_t ecb = 0;           // slices per k_emit tile behind k_bs_select (0: the default)
     };
     int emit(const uint32_t *d_packed, const Tables &T, uint32_t n_cap, DevBuf &oh, DevBuf &op, DevBuf &orc, DevBuf &of,
              uint64_t out_base, bool fused = false, uint32_t *host_ctrl = nullptr, const ChainIO *io = nullptr,
@@ -2110,7 +2111,12 @@ struct Driver {
         ep.n_fixed = n_fixed;
         ep.cand_spread = cand_spread;
         const uint32_t n_grid = n_fixed ? n_fixed : (grid_cand ? std::min(grid_cand, n_cap) : n_cap);
-        ep.n_tiles = fused ? (n_grid + EMIT_COMPACT_BLOCKS * rk - 1) / (EMIT_COMPACT_BLOCKS * rk) : (n_grid + TILE - 1) / TILE;
+        ep.ecb = EMIT_COMPACT_BLOCKS;
+        if (rk < RK) {  // the slices of k_bs_select: ~18 minimizers each
+            const uint64_t e = env_u64(h, "MXG_EMIT_ECB", io && io->ecb ? io->ecb : 16);
+            ep.ecb = e >= 64 ? 64u : e >= 32 ? 32u : 16u;
+        }
+        ep.n_tiles = fused ? (n_grid + ep.ecb * rk - 1) / (ep.ecb * rk) : (n_grid + TILE - 1) / TILE;
         ep.s_key = nullptr;
         ep.s_off = ep.s_src = nullptr;
         ep.gaps = nullptr;
@@ -2958,6 +2964,7 @@ struct SparsePlan {
     bool dev_gaps;
     double frac;
     uint32_t tau_hi;
+    double gap_rate;       // device route: expected candidate-free stretches per k-mer (prior, or what earlier sketches met)
     uint64_t gap_kmers;    // device route: k-mers that hold ~GAP_DEV_MAX / 2 expected stretches (0: not the device route)
     uint64_t batch_kmers;  // device route: batches small enough for ~GAP_DEV_MAX / 2 expected stretches (0: the default size;
                            // a quarter until round 3: on repeat-rich sequence, whose batches this limit cuts, half as many batches
@@ -2977,9 +2984,11 @@ static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
     sp.sparse = !(h->cfg.flags & MXG_FLAG_DENSE_ONLY) && sp.frac <= 0.125;
     sp.batch_kmers = 0;
     sp.gap_kmers = 0;
+    sp.gap_rate = 0;
     if (sp.dev_gaps) {  // a candidate is followed by a stretch with probability e^-c
         // (a->gap_rate_hint: what earlier sketches of this assembly met, 25 % on top)
         const double per_kmer = std::max(sp.frac * std::exp(-(double)c), a->gap_rate_hint * 1.25);
+        sp.gap_rate = per_kmer;
         const double lim = (double)env_u64(h, "MXG_GAP_BUDGET", GAP_DEV_MAX / 2) / std::max(per_kmer, 1e-30);  // expected stretches per batch
         sp.gap_kmers = (uint64_t)std::min<double>(std::max<double>(lim, (double)(1u << 20)), 9e18);
         if (lim < (double)SPARSE_BATCH_KMERS) sp.batch_kmers = std::max<uint64_t>((uint64_t)lim, 1u << 20);
@@ -3190,6 +3199,10 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             memset(it.hc, 0xFF, 64);
             Driver::ChainIO io;
             io.dev_gaps = plans[i].dev_gaps && !chain_modes;
+            // tiles of 32 slices in k_emit (0.18 against 0.21 ms per step at 3 Gbp + 3 Gbp) unless stretches are so dense that
+            // most tiles of that size would hold one (the tile then searches the stretch keys per minimizer: repeat-rich
+            // sequence is 2 % slower with 32, 6 % with 64; tools/sweep_emit_ecb.sh)
+            io.ecb = plans[i].gap_rate * 32.0 * 64.0 * list[i]->S_sparse < 0.5 ? 32u : 16u;
             uint64_t *chain = h->d_chain.as<uint64_t>();
             io.base_in = b == 0 ? nullptr : chain + (items.size() - 1);
             io.base_out = gs.size() > 1 ? chain + items.size() : nullptr;
