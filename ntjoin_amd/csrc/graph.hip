@@ -414,6 +414,167 @@ __global__ __launch_bounds__(256) void k_pj_join(uint4 *recs, const uint32_t *__
 }
 
 
+// The two-level join's partitions by PERSISTENT blocks, three partitions in flight per block: while the records of partition k
+// are inserted and judged, the records of partition k + 1 are on their way (requested as soon as its segments were laid out) and
+// so are the segment bounds of partition k + 2 -- a block of k_pj_join spends most of its ~16 us waiting for exactly these two
+// round trips, one behind the other, and the tables' 32 KB keep more blocks from hiding them.  For partitions of at most 256
+// regions (rows2; always, unless a skewed coarse partition was re-sized); same tables, same verdicts as k_pj_join.
+template <bool NARROW>
+__global__ __launch_bounds__(256) void k_pj_join_pipe(uint4 *recs, const uint32_t *__restrict__ M, uint32_t P, uint32_t n_parts,
+                                                      uint64_t *host_fail, uint32_t force_fail, const uint32_t *__restrict__ cursor,
+                                                      uint32_t cap1, uint32_t rows2, const AsmSet p)
+{
+    const uint32_t full = p.full;
+    __shared__ unsigned long long keys[PJ_T + 1];
+    __shared__ uint32_t seen[PJ_T + 1], dup[NARROW ? 1 : PJ_T + 1];
+    __shared__ uint32_t item0[PJ_T + 1];
+    __shared__ uint32_t seg_off[2][257], seg_rec[2][256], sh[256];
+    __shared__ uint32_t failed;
+    constexpr uint32_t QC = 4;
+    uint4 rn[QC];                    // the first QC records per thread of the partition whose segments were laid out last
+    uint32_t tot_n = 0;              // ... and how many records it has
+    uint32_t lo_nn = 0, len_nn = 0;  // segment of this thread's region in the partition after that one
+    auto bounds = [&](uint32_t part, uint32_t &lo, uint32_t &len) {  // (requests only: nothing waits here)
+        lo = len = 0;
+        if (part < n_parts && threadIdx.x < rows2) {
+            const uint32_t c = part / P, b = part % P;
+            const uint32_t *row = M + ((size_t)c * rows2 + threadIdx.x) * (P + 1);
+            lo = row[b];
+            len = row[b + 1];  // (the end: the length is taken where the values are used)
+        }
+    };
+    auto lay_out = [&](uint32_t part, uint32_t buf, uint32_t lo, uint32_t end) {  // segments end to end; first records requested
+        const uint32_t c = part < n_parts ? part / P : 0u;
+        const uint32_t len = end - lo;
+        const uint32_t off = block_exclusive_256(len, sh);
+        seg_off[buf][threadIdx.x] = off;
+        seg_rec[buf][threadIdx.x] = c * cap1 + threadIdx.x * PJ_IPB + lo;
+        const uint32_t total = sh[255];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t it = 0; it < QC; ++it) {
+            const uint32_t q = threadIdx.x + it * 256u;
+            rn[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (q < total) {
+                uint32_t l = 0, h = 256;
+                while (h - l > 1) {
+                    const uint32_t m = (l + h) >> 1;
+                    if (seg_off[buf][m] <= q) l = m; else h = m;
+                }
+                rn[it] = recs[seg_rec[buf][l] + (q - seg_off[buf][l])];
+            }
+        }
+        return total;
+    };
+    const uint32_t first = blockIdx.x, stride = gridDim.x;
+    {
+        uint32_t lo, end;
+        bounds(first, lo, end);
+        bounds(first + stride, lo_nn, len_nn);
+        tot_n = lay_out(first, 0u, lo, end);
+    }
+    uint32_t k = 0;
+    for (uint32_t part = first; part < n_parts; part += stride, ++k) {
+        // this partition's records are in rn (requested one iteration ago); move on the two prefetches
+        uint4 rc[QC];
+#pragma unroll
+        for (uint32_t it = 0; it < QC; ++it) rc[it] = rn[it];
+        const uint32_t total = tot_n, buf = k & 1u;
+        {
+            const uint32_t lo = lo_nn, end = len_nn;
+            bounds(part + 2u * stride, lo_nn, len_nn);
+            tot_n = lay_out(part + stride, buf ^ 1u, lo, end);  // (a partition beyond the last: no segments, no requests)
+        }
+        for (uint32_t s = threadIdx.x; s <= PJ_T; s += 256) {
+            keys[s] = HT_EMPTY;
+            seen[s] = 0;
+            if (!NARROW) dup[s] = 0;
+        }
+        if (threadIdx.x == 0) {
+            failed = force_fail;
+            const uint32_t c = part / P;
+            if (part % P == 0 && cursor[c * PJ1_CS] > cap1) *host_fail = 1;  // the coarse partition overflowed: global table
+        }
+        __syncthreads();
+        auto locate = [&](uint32_t q) {
+            uint32_t l = 0, h = 256;
+            while (h - l > 1) {
+                const uint32_t m = (l + h) >> 1;
+                if (seg_off[buf][m] <= q) l = m; else h = m;
+            }
+            return seg_rec[buf][l] + (q - seg_off[buf][l]);
+        };
+        auto insert_rec = [&](const uint4 rec, bool record) {
+            const uint32_t a = rec.w & ~PJ_REC_DUP;
+            const uint32_t s = pj_slot(keys, ((uint64_t)rec.y << 32) | rec.x);
+            if (record) {
+                const uint32_t bit = 1u << a;
+                if (s > PJ_T) failed = 1;
+                else {
+                    const uint32_t cur = seen[s], dcur = NARROW ? cur >> 16 : dup[s];
+                    if (!((cur & bit) && (dcur & bit))) {
+                        if (rec.w & PJ_REC_DUP) {
+                            if (NARROW) atomicOr(&seen[s], bit | (bit << 16));
+                            else {
+                                atomicOr(&seen[s], bit);
+                                atomicOr(&dup[s], bit);
+                            }
+                        } else if (atomicOr(&seen[s], bit) & bit) {
+                            if (NARROW) atomicOr(&seen[s], bit << 16); else atomicOr(&dup[s], bit);
+                        }
+                        if (a == 0) item0[s] = rec.z;
+                    }
+                }
+            }
+            return s;
+        };
+        uint32_t sc[QC];
+#pragma unroll
+        for (uint32_t it = 0; it < QC; ++it)
+            if (threadIdx.x + it * 256u < total) sc[it] = insert_rec(rc[it], true);
+        constexpr uint32_t TU = 8;
+        for (uint32_t q0 = threadIdx.x + QC * 256u; q0 < total; q0 += 256u * TU) {  // (a key of huge multiplicity: see k_pj_join)
+            uint4 rv[TU];
+#pragma unroll
+            for (uint32_t u = 0; u < TU; ++u) {
+                const uint32_t q = q0 + u * 256u;
+                rv[u] = q < total ? recs[locate(q)] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < TU; ++u)
+                if (q0 + u * 256u < total) insert_rec(rv[u], true);
+        }
+        __syncthreads();
+        const bool bad = failed != 0;
+        if (bad && threadIdx.x == 0) *host_fail = 1;
+        auto finish = [&](const uint4 rec, uint32_t s) {
+            const uint32_t a = rec.w & ~PJ_REC_DUP;
+            uint32_t fl = 0;
+            if (!bad) {
+                const uint32_t sn = seen[s] & full, d = (NARROW ? seen[s] >> 16 : dup[s]) & full;
+                const bool inall = sn == full;
+                fl = (!(d & (1u << a)) ? MXG_MX_UNIQUE : 0u) | ((inall && d == 0) ? MXG_MX_SHARED : 0u) | (inall ? MXG_MX_INALL : 0u);
+            }
+            p.slot[a][rec.z] = ((fl & MXG_MX_SHARED) ? item0[s] << 3 : 0u) | fl;
+        };
+#pragma unroll
+        for (uint32_t it = 0; it < QC; ++it)
+            if (threadIdx.x + it * 256u < total) finish(rc[it], bad ? 0u : sc[it]);
+        for (uint32_t q0 = threadIdx.x + QC * 256u; q0 < total; q0 += 256u * TU) {
+            uint4 rv[TU];
+#pragma unroll
+            for (uint32_t u = 0; u < TU; ++u) {
+                const uint32_t q = q0 + u * 256u;
+                rv[u] = q < total ? recs[locate(q)] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < TU; ++u)
+                if (q0 + u * 256u < total) finish(rv[u], bad ? 0u : insert_rec(rv[u], false));
+        }
+        __syncthreads();  // the table is cleared for the next partition
+    }
+}
+
 // level 1 of the two-level join: 4096 minimizers per block (the same item order as k_pj_bucket), LDS histogram over P1
 // coarse partitions (hash bits 52..63), ONE device-scope add per non-empty (block, partition) bin reserves the bin's place
 // in the partition (4096 / P1 records per add; the cursors sit on their own lines), then the records are dealt out.
@@ -493,7 +654,11 @@ __global__ __launch_bounds__(PJ_BT) void k_pj2_bucket(const AsmSet p, const uint
     __shared__ uint32_t sh[256];
     const uint32_t j = blockIdx.x, c = blockIdx.y;
     const uint32_t n_all = cursor[c * PJ1_CS], n_c = min(n_all, cap1);
-    if (j * PJ_IPB >= n_c) return;  // (block-uniform) nothing of this coarse partition in this region
+    if (j * PJ_IPB >= n_c) {  // (block-uniform) nothing of this coarse partition in this region: an empty row (k_pj_join_pipe
+        uint32_t *row = M + ((size_t)c * rows2 + j) * (pmask + 2);  // reads every row of the partition without asking the cursor)
+        for (uint32_t b = threadIdx.x; b <= pmask + 1; b += PJ_BT) row[b] = 0;
+        return;
+    }
     constexpr uint32_t U = PJ_IPB / PJ_BT;
     const size_t base = (size_t)c * cap1 + (size_t)j * PJ_IPB;
     uint4 rec[U];
@@ -1067,7 +1232,16 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         const uint32_t skew_lim = (uint32_t)std::min<uint64_t>(N / P1 + N / P1 / 32 + 2048, 0xFFFFFFFFull);  // 3 % above the mean
         hipLaunchKernelGGL(k_pj2_bucket, dim3(rows2, P1), dim3(PJ_BT), (size_t)P * 8, h->stream, as_all, recs1, cursor, cap1, rows2, P - 1, M,
                            recs2, knob_u64(h, "MXG_PJ_SKEW", 0) ? 0u : skew_lim);
-        if (A <= 16)
+        const uint64_t pipe_blocks = knob_u64(h, "MXG_PJ_PIPE", 1024);  // (0: one block per partition, k_pj_join)
+        if (pipe_blocks && rows2 <= 256) {
+            const uint32_t nblk = (uint32_t)std::min<uint64_t>(pipe_blocks, (uint64_t)P1 * P);
+            if (A <= 16)
+                hipLaunchKernelGGL(k_pj_join_pipe<true>, dim3(nblk), dim3(256), 0, h->stream, recs2, M, P, P1 * P, hctl + CTL_PJ_FAIL,
+                                   pj_force_fail, cursor, cap1, rows2, as_all);
+            else
+                hipLaunchKernelGGL(k_pj_join_pipe<false>, dim3(nblk), dim3(256), 0, h->stream, recs2, M, P, P1 * P, hctl + CTL_PJ_FAIL,
+                                   pj_force_fail, cursor, cap1, rows2, as_all);
+        } else if (A <= 16)
             hipLaunchKernelGGL(k_pj_join<true>, dim3(P1 * P), dim3(256), 0, h->stream, recs2, M, P, 0u, hctl + CTL_PJ_FAIL, pj_force_fail,
                                cursor, cap1, rows2, as_all);
         else
