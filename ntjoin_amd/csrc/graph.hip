@@ -894,6 +894,22 @@ __global__ __launch_bounds__(256) void k_vertices_pj(const VertexPjParams p)
     const uint32_t blk = blockIdx.x - p.as.bstart[a], nblk = p.as.bstart[a + 1] - p.as.bstart[a];
     const uint32_t i = blk * 256u + threadIdx.x;
     const bool f = i < asm_n(p.as, a) && p.as.shared[a][i];
+    // (what the minimizer brings along first: its loads -- for a > 0 the chain verdict word -> mask words -> vertex id -- do not
+    // need its rank, and the block's prefix below is two dependent round trips every thread would otherwise wait for first)
+    uint32_t v0 = 0, rec = 0, pos = 0;
+    uint64_t hsh = 0;
+    if (f) {
+        if (a) {
+            const uint32_t i0 = p.as.slot[a][i] >> 3, w = i0 >> 6;  // (the verdict word: flags in its three low bits)
+            const uint64_t *m = p.mask0 + (w & ~3u);
+            v0 = p.bpref0[i0 >> 8] + (uint32_t)__popcll(p.mask0[w] & ((1ull << (i0 & 63u)) - 1ull));
+            for (uint32_t q = 0; q < (w & 3u); ++q) v0 += (uint32_t)__popcll(m[q]);
+        } else {
+            hsh = p.as.hash[0][i];
+        }
+        rec = p.rec[a][i];
+        pos = p.pos[a][i];
+    }
     if (threadIdx.x < 64) {
         const uint32_t *cnt = p.cnt + p.as.bstart[a], *sup = p.sup + sup_start(p.as, a);
         const uint32_t bef = count_prefix(cnt, sup, blk);
@@ -906,18 +922,10 @@ __global__ __launch_bounds__(256) void k_vertices_pj(const VertexPjParams p)
     __syncthreads();
     const uint32_t r = sh_before + block_exclusive_256(f ? 1u : 0u, sh);
     if (!f) return;
-    uint32_t v = r;
-    if (a) {
-        const uint32_t i0 = p.as.slot[a][i] >> 3, w = i0 >> 6;  // (the verdict word: flags in its three low bits)
-        const uint64_t *m = p.mask0 + (w & ~3u);
-        v = p.bpref0[i0 >> 8] + (uint32_t)__popcll(p.mask0[w] & ((1ull << (i0 & 63u)) - 1ull));
-        for (uint32_t q = 0; q < (w & 3u); ++q) v += (uint32_t)__popcll(m[q]);
-    } else {
-        p.vhash[v] = p.as.hash[0][i];
-    }
+    const uint32_t v = a ? v0 : r;
+    if (!a) p.vhash[v] = hsh;
     const size_t o = (size_t)a * p.nvs;
-    const uint32_t rec = p.rec[a][i];
-    p.vpos[o + v] = p.pos[a][i];
+    p.vpos[o + v] = pos;
     p.vrec[o + v] = rec;
     p.fv[o + r] = v;
     p.frec[o + r] = rec;
@@ -994,6 +1002,19 @@ __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_it
     __shared__ uint32_t sh[256];
     const uint32_t item = blockIdx.x * 256u + threadIdx.x;  // (one per thread: see k_vertices)
     const bool f = item < n_items && p.eflag[item];
+    // (the edge itself first: its chain of loads -- vertex, successor, the other assemblies' adjacency -- does not need the edge's
+    // place, and the block's prefix below is two dependent round trips every thread would otherwise wait for before starting)
+    uint32_t u = 0, v = 0, m = 0;
+    double wsum = 0.0;
+    if (f) {
+        const uint32_t a = item / p.nv, r = item % p.nv;
+        u = p.fv[(size_t)a * p.nv + r];
+        v = p.nxt[(size_t)a * p.nv + u];
+        m = edge_mask(p, u, v);
+        // python: sum(weights[f] for f in support) -- int 0 start, then float adds in support (= assembly) order
+        for (uint32_t b = 0; b < p.n_asm; ++b)
+            if (m & (1u << b)) wsum = wsum + p.weights[b];
+    }
     __shared__ uint32_t sh_before;
     if (threadIdx.x < 64) {
         const uint32_t bef = count_prefix(p.bsum, p.bsuper, blockIdx.x);
@@ -1010,14 +1031,6 @@ __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_it
     __syncthreads();
     const uint32_t e = sh_before + block_exclusive_256(f ? 1u : 0u, sh);
     if (!f) return;
-    const uint32_t a = item / p.nv, r = item % p.nv;
-    const uint32_t u = p.fv[(size_t)a * p.nv + r];
-    const uint32_t v = p.nxt[(size_t)a * p.nv + u];
-    const uint32_t m = edge_mask(p, u, v);
-    // python: sum(weights[f] for f in support) -- int 0 start, then float adds in support (= assembly) order
-    double wsum = 0.0;
-    for (uint32_t b = 0; b < p.n_asm; ++b)
-        if (m & (1u << b)) wsum = wsum + p.weights[b];
     p.eu[e] = u;
     p.ev[e] = v;
     p.esup[e] = m;
