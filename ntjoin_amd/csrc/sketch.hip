@@ -3198,7 +3198,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             it.hc = h->pinned_ctrl + 16 * items.size();
             memset(it.hc, 0xFF, 64);
             Driver::ChainIO io;
-            io.dev_gaps = plans[i].dev_gaps && !chain_modes;
+            io.dev_gaps = plans[i].dev_gaps;
             // tiles of 32 slices in k_emit (0.18 against 0.21 ms per step at 3 Gbp + 3 Gbp) unless stretches are so dense that
             // most tiles of that size would hold one (the tile then searches the stretch keys per minimizer: repeat-rich
             // sequence is 2 % slower with 32, 6 % with 64; tools/sweep_emit_ecb.sh)
@@ -3312,7 +3312,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         for (size_t q = q0; q < q1; ++q) {
             const uint32_t *c = items[q].hc;
             const uint64_t t = (uint64_t)c[6] | ((uint64_t)c[7] << 32);
-            const bool dev = plans[i].dev_gaps && !chain_modes;
+            // (the one-call modes have already used the counts on the device: a stretch handed to the host undoes them)
+            const bool dev = plans[i].dev_gaps && !(chain_modes && c[11] != 0 && c[11] != 0xFFFFFFFFu);
             // (not the device route: any stretch sends the batch to the general route below)
             // (a batch without any candidate: k_bs_select reports its contigs as stretches; the other route leaves it to the host)
             good = good && c[0] == 0 && c[3] == 0 && (c[4] != 0 || items[q].bs) && c[4] != 0xFFFFFFFFu && (dev || c[1] == 0);

@@ -68,6 +68,33 @@ def test_fused_on_synthetic_genome(kw):
         assert e1.stats()["vertices"] > 10000
 
 
+@pytest.mark.parametrize("cand", [10, 3])
+def test_fused_with_stretches_on_the_device(monkeypatch, cand):
+    """the stretches stay on the device in the one-call mode too (MXG_DEV_GAPS=1: as on genome-scale input): one host sync,
+    nothing redone; a stretch the device route hands to the host (a homopolymer of 9000) sends the call the long way round"""
+    import random
+    from ntjoin_amd import synth
+    from ntjoin_amd.engine import MxEngine
+    monkeypatch.setenv("MXG_DEV_GAPS", "1")
+    ref, tgt = synth.config2(seed=6, n_bases=20_000_000)
+    for extra in (False, True):
+        with MxEngine(k=32, w=1000, cand_per_window=cand) as e1, MxEngine(k=32, w=1000, cand_per_window=cand) as e2:
+            for e in (e1, e2):
+                _packed(e, "ref", 2.0, ref)
+                _packed(e, "tgt", 1.0, tgt)
+                if extra:
+                    rng = random.Random(3)
+                    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+                    e.add_records("odd", 1.5, [("x", (rnd(30000) + "A" * 9000 + rnd(30000)).encode())])
+            e1.sketch_graph()
+            e2.sketch(-2)
+            e2.build_graph()
+            _same(e1, e2, 3 if extra else 2)
+            st = e1.stats()
+            if not extra and cand == 10:  # (3 candidates per window: more stretches than one batch holds, and the call needs one batch)
+                assert st["batches_redone"] == 0 and st["sync_assemblies"] == 0 and st["deferred_stretches"] == 0, st
+
+
 def test_fused_after_arena_overflow(monkeypatch):
     from ntjoin_amd import synth
     from ntjoin_amd.engine import MxEngine
