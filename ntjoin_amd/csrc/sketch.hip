@@ -3177,8 +3177,11 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 // (3.20 against 3.24 ms at 3 Gbp + 3 Gbp, tools/stagger_try.sh) and a filter that shares the GPU with a slice
                 // kernel takes 0.64 ms instead of 0.44 -- neither kernel's time says anything about the kernel any more; at
                 // 1 Gbp + 1 Gbp, where the tails weigh more, running free is 6 % faster and stays.  (MXG_STAGGER=0: never)
+                hipEvent_t behind = nullptr;
                 if (stagger && !one_stream && last_sel_slot >= 0 && drvs[last_sel_slot] != &drv && list[i]->total_kmers >= (1ull << 31))
-                    MXG_HIP(h, hipStreamWaitEvent(drv.st, h->ev_sel_done[last_sel_slot], 0));
+                    behind = h->ev_sel_done[last_sel_slot];
+                if ((rc = bs_edges(h, list[i], drv.st)) != MXG_OK) return rc;  // (the two blocks that copy the edge chunks need not wait)
+                if (behind) MXG_HIP(h, hipStreamWaitEvent(drv.st, behind, 0));
                 if ((rc = drv.ev_begin(list[i]->total_bases, true)) != MXG_OK) return rc;
                 if ((rc = bs_hash(h, list[i], plans[i].tau_hi, drv.st)) != MXG_OK) return rc;
                 h->stat_bs_bases += list[i]->total_bases;

@@ -62,6 +62,7 @@ int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hi
 // layout + filter (per assembly)
 bool bs_possible(const mxg_handle *h, const Assembly *a);
 int bs_prepare(mxg_handle *h, Assembly *a);                                  // padded edge chunks, once per assembly
+int bs_edges(mxg_handle *h, Assembly *a, hipStream_t st);                    // the padded copies of the first and last chunk's words (before every filter launch)
 int bs_hash(mxg_handle *h, Assembly *a, uint32_t tau_hi, hipStream_t st);    // the filter over the whole assembly -> a->d_bs_out
 
 }  // namespace mxg

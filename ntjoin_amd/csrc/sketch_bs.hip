@@ -647,9 +647,15 @@ __global__ __launch_bounds__(256) void k_bs_edges(const uint32_t *__restrict__ p
     }
 }
 
-int bs_hash(mxg_handle *h, Assembly *a, uint32_t tau_hi, hipStream_t st)
+int bs_edges(mxg_handle *h, Assembly *a, hipStream_t st)
 {
     hipLaunchKernelGGL(k_bs_edges, dim3(2), dim3(256), 0, st, a->d_packed, a->packed_words, a->bs_chunks, a->d_bs_tail.as<uint32_t>());
+    MXG_HIP(h, hipGetLastError());
+    return MXG_OK;
+}
+
+int bs_hash(mxg_handle *h, Assembly *a, uint32_t tau_hi, hipStream_t st)
+{
     // tau = T * 2^33 with T = tau_hi / 2 on the top ring; the filter compares the top HASH_BS_PLANES bits of F + R with
     // tt = (T - 1) >> (31 - planes) (gen/bs_gen.py: reference_bits)
     const uint32_t T = tau_hi >> 1;
