@@ -575,6 +575,10 @@ def main():
                          "alg_bytes_per_base": ALG_BYTES_PER_BASE_HASH, "alg_bytes_per_launch": int(bytes_per_launch),
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(st["launches_hash"]),
                          "timed": "HIP-event pair around every launch of the kernel inside the timed region, on the launch stream",
+                         "streams": ("free-running (MXG_STAGGER=0): this kernel shares the GPU with the other assembly's slice kernel"
+                                     if os.environ.get("MXG_STAGGER") == "0" else
+                                     "an assembly of 2^31 k-mers or more starts its filter behind the slice kernel of the assembly before it, so "
+                                     "the kernel's time is its own (MXG_STAGGER=0: free-running streams, the step ~2 % shorter, kernel times shared)"),
                          "min_traffic_bytes_per_base": 0.25 + 0.25 / 32 + 0.125,
                          "min_traffic_note": "what this formulation must move: 2 bits per base (bit planes) + 1/32 of that (the "
                                              "strips' predecessors) read, 1 bit per position (the candidate bitmap) written",
