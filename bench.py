@@ -363,6 +363,54 @@ def dry_run(args):
     return 0
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here -- one process per GPU, the environment torchrun
+    would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT on 127.0.0.1 with a free port) -- hand rank 0's
+    stdout through (its last line is the JSON line), drop the other ranks' stdout, keep everybody's stderr, and end with a
+    non-zero status as soon as any rank does (the others are then stopped: a rank waiting in a collective for a dead one would
+    hang the run).  The driver's own `python -m torch.distributed.run ... bench.py --gpus N` takes the other branch (WORLD_SIZE set)."""
+    import signal
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MXG_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL, start_new_session=True))
+    rc = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                c = procs[r].poll()
+                if c is not None:
+                    live.discard(r)
+                    if c != 0 and rc == 0:
+                        rc = c if c > 0 else 1
+                        print(f"bench.py: rank {r} ended with status {c}; stopping the other ranks", file=sys.stderr, flush=True)
+            if rc:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)   # the exact process groups started above
+                except ProcessLookupError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -384,6 +432,8 @@ def main():
     args = ap.parse_args()
     if args.dry:
         return dry_run(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -394,8 +444,9 @@ def main():
     if os.environ.get("MXG_BENCH_ONE_DEVICE") == "1":  # testing: several ranks share GPU 0 (with MXG_BENCH_BACKEND=gloo)
         local_rank = 0
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N ...")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    if os.environ.get("MXG_BENCH_KILL_RANK") == str(rank) and world > 1:  # testing: a rank that dies before the rendezvous
+        sys.exit(f"bench.py: rank {rank} told to fail (MXG_BENCH_KILL_RANK)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -507,6 +558,28 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
     bases_total = float(bases_job)  # the whole job's bases: every rank sketched 1/world of every assembly
+    dist_info = None
+    if multi:
+        # "did the communicator really hold N ranks on N devices": a sum of ones over the backend's all-reduce, and every rank's
+        # device (index + PCI bus id) gathered through the same communicator
+        ones = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(ones)
+        pr = torch.cuda.get_device_properties(local_rank)
+        mine = torch.tensor([local_rank, getattr(pr, "pci_bus_id", -1), getattr(pr, "pci_device_id", -1)], dtype=torch.int64, device="cuda")
+        devs = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(devs, mine)
+        be = dist.get_backend()
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version()) if be == "nccl" else None
+        except Exception:
+            rccl = None
+        dist_info = {"world": world, "backend": be + (" (= RCCL on ROCm)" if be == "nccl" else " (test backend: ranks may share one GPU)"),
+                     "rccl_version": rccl, "communicator_ranks": dist.get_world_size(), "allreduce_of_ones": int(ones[0]),
+                     "devices_by_rank": [[int(v) for v in d.tolist()] for d in devs],
+                     "distinct_devices": len({tuple(int(v) for v in d.tolist()) for d in devs}),
+                     "launched_by": "bench.py itself (python bench.py --gpus N)" if os.environ.get("MXG_BENCH_SELF_LAUNCHED") == "1"
+                                    else "an external launcher (torch.distributed.run)",
+                     "graph_route": graph_mode}
 
     st = eng.stats()
     if union is not None and graph_mode == "partitioned":
@@ -562,6 +635,7 @@ def main():
                                         "with a w-k-mer halo), ") +
                                        ("graph stage partitioned by hash range (RCCL all-to-all)" if graph_mode == "partitioned"
                                         else "RCCL all-gather of sketches, graph of the union on every rank"))},
+            "distributed": dist_info,
             "kernel_sources_digest": kernel_sources_digest(),
             "knobs_in_force": eng.knobs(),  # MXG_* environment switches the handle read and found set ("" = library defaults)
             "resident_input": "2-bit packed bases (0.25 B/bp) as handed over through mxg_add_assembly_packed_device*; every step reads them as they are",
@@ -749,4 +823,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

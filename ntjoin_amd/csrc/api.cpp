@@ -143,6 +143,8 @@ static int commit(mxg_handle *h, Assembly *a, int rc)
     h->asms.push_back(a);
     h->graph.valid = false;
     h->pj_overflowed = false;
+    h->pj_cap1_P1 = 0;
+    h->pj_cap1_need = 0;
     return (int)h->asms.size() - 1;
 }
 

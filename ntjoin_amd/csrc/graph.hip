@@ -1091,6 +1091,16 @@ int build_graph(mxg_handle *h, int mode, const void *d_msgs, uint64_t n_msgs, co
     // the global table afterwards: the same assemblies would overflow again)
     h->stat_graph_join = 0;
     uint64_t how = 0;
+    // what the handle learnt from an overflow (start with the global table; a coarse partition's capacity) holds for the sketches it
+    // was learnt on: other sketches -- new assemblies, a borrowed buffer refilled and sketched again -- start with the defaults
+    uint64_t sig = 0x9E3779B97F4A7C15ull * (h->asms.size() + 1);
+    for (const Assembly *a : h->asms) sig = (sig ^ a->n_mx) * 0x100000001B3ull;
+    if (!gb && (h->pj_overflowed || h->pj_cap1_P1) && h->pj_learnt_sig != sig) {
+        h->pj_overflowed = false;
+        h->pj_cap1_P1 = 0;
+        h->pj_cap1_need = 0;
+    }
+    if (!gb) h->pj_learnt_sig = sig;
     int rc = build_graph_impl(h, mode, d_msgs, n_msgs, gb, h->pj_overflowed);
     // (a coarse partition outgrew its capacity -- hash skew: a key of large multiplicity -- while the tables held: once more with
     // the capacity the cursors ask for, which the handle keeps)

@@ -235,6 +235,7 @@ struct mxg_handle {
     uint64_t stat_graph_join = 0; // mxg_stats::graph_join
     uint32_t pj_cap1_P1 = 0;     // two-level join: coarse partitions and the records one of them must hold, as an earlier call's
     uint64_t pj_cap1_need = 0;   // cursors reported them (a key of large multiplicity skews the partitions)
+    uint64_t pj_learnt_sig = 0;  // the sketches (count and sizes) the three fields around this one were learnt on
     bool pj_overflowed = false;  // graph stage: the partitioned join overflowed once (build_graph then starts with the global table)
     uint64_t stat_retries = 0;   // assemblies enqueued a second time (their batches did not all end the common way)
     uint64_t stat_deferred = 0;  // candidate-free stretches the device route handed to the host
@@ -243,6 +244,7 @@ struct mxg_handle {
     mxg::DevBuf scratch[4][40];  // indexed by mxg::Scratch (sketch.hip): one set per in-flight sketch driver (= stream)
     std::vector<mxg::Assembly *> pend_list;  // mxg_sketch_pack in flight: assemblies and how each was enqueued
     std::vector<int> pend_state;
+    std::vector<unsigned char> pend_dev;     // ... and whether its stretches went the device route (sketch_finish accepts those)
     mxg::DevBuf g_part;     // partitioned join (graph.hip): partition offsets of every bucketing block
     mxg::DevBuf g_recs1;    // two-level join: the coarse partitions' records
     mxg::DevBuf g_keys, g_cnt, g_vid, g_ctl, g_vhash, g_vpos, g_vrec, g_fv, g_frec, g_nxt, g_prv, g_eflag,

@@ -2553,7 +2553,7 @@ struct Driver {
     // some stream this one has been made to wait for); one batch = k_bs_select over the batch's strips -> stretches -> emit.
     BsSelGeom sel_geom(const Assembly *a, const BatchGeom &g, double frac) const
     {
-        return bs_select_geom(a->S_sparse, a->sel_H, h->cfg.w, frac, g.n_strips, (uint32_t)env_u64(h, "MXG_SEL_QCAP", 0));
+        return bs_select_geom(a->S_sparse, a->sel_H, h->cfg.w, frac, g.n_strips, (uint32_t)env_u64(h, "MXG_SEL_QCAP", 0), (uint32_t)env_u64(h, "MXG_SEL_RK", 0));
     }
     int enqueue_sel(Assembly *a, const Tables &T, const BatchGeom &g, const BsSelGeom &b, uint32_t tau_hi, OutArrays &out,
                     uint32_t *ctrl_host, const ChainIO *io)
@@ -3020,7 +3020,8 @@ int sketch_assembly(mxg_handle *h, Assembly *a)
 __global__ __launch_bounds__(256) void k_pack_slot_dev(const uint64_t *__restrict__ hash, const uint32_t *__restrict__ pos,
                                                        const uint32_t *__restrict__ rec, const uint32_t *__restrict__ n_ptr,
                                                        const uint32_t *__restrict__ ctrl, uint64_t out_cap, uint64_t cap,
-                                                       long long fixed, long long *header, unsigned char *__restrict__ region)
+                                                       long long fixed, long long *header, unsigned char *__restrict__ region,
+                                                       uint32_t dev_gaps)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (fixed != -2) {  // the host already knows: empty assembly (0) or not through the one-batch pipeline (-1)
@@ -3028,7 +3029,10 @@ __global__ __launch_bounds__(256) void k_pack_slot_dev(const uint64_t *__restric
         return;
     }
     const uint64_t n = *n_ptr;
-    const bool ok = ctrl[0] == 0 && ctrl[1] == 0 && ctrl[6] == 0 && (ctrl[4] | ctrl[5]) != 0 && n <= cap && n <= out_cap;
+    // the same predicate as sketch_finish's (batch_ended_well): no arena overflow, no flag from the stretch kernels (word 6) or from
+    // the slice kernel (word 13: a slice gave up), stretches either absent or -- on the device route -- all placed (none deferred)
+    const bool ok = ctrl[0] == 0 && ctrl[6] == 0 && ctrl[13] == 0 && (dev_gaps ? ctrl[11] == 0 : ctrl[1] == 0) && (ctrl[4] | ctrl[5]) != 0 &&
+                    n <= cap && n <= out_cap;
     if (i == 0) *header = ok ? (long long)n : -1ll;
     if (!ok || i >= n) return;
     reinterpret_cast<uint64_t *>(region)[i] = hash[i];
@@ -3273,12 +3277,14 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             hipLaunchKernelGGL(k_pack_slot_dev, dim3(grid), dim3(256), 0, h->stream, a->d_hash.as<uint64_t>(),
                                a->d_pos.as<uint32_t>(), a->d_rec.as<uint32_t>(), h->d_nmx.as<uint32_t>() + i,
                                drvs[slot_of[i]]->sc(SC_CTRL).as<uint32_t>(), out_cap, cap, fixed,
-                               reinterpret_cast<long long *>(base) + i, base + off);
+                               reinterpret_cast<long long *>(base) + i, base + off, plans[i].dev_gaps ? 1u : 0u);
             off += 16 * cap;
         }
         MXG_HIP(h, hipGetLastError());
         h->pend_list.assign(list, list + n);
         h->pend_state = state;
+        h->pend_dev.assign(n, 0);
+        for (size_t i = 0; i < n; ++i) h->pend_dev[i] = plans[i].dev_gaps ? 1 : 0;
         return MXG_OK;
     }
     bool fused = false;
@@ -3319,7 +3325,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             const bool dev = plans[i].dev_gaps && !(chain_modes && c[11] != 0 && c[11] != 0xFFFFFFFFu);
             // (not the device route: any stretch sends the batch to the general route below)
             // (a batch without any candidate: k_bs_select reports its contigs as stretches; the other route leaves it to the host)
-            good = good && c[0] == 0 && c[3] == 0 && (c[4] != 0 || items[q].bs) && c[4] != 0xFFFFFFFFu && (dev || c[1] == 0);
+            good = good && c[0] == 0 && c[3] == 0 && c[12] == 0 && (c[4] != 0 || items[q].bs) && c[4] != 0xFFFFFFFFu && (dev || c[1] == 0);
             total += t;
             n_cand += c[4];
             gap_kmers += c[10] == 0xFFFFFFFFu ? 0 : c[10];
@@ -3402,7 +3408,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             for (; j < q1; ++j) {
                 const uint32_t *c = items[j].hc;
                 const uint64_t t = (uint64_t)c[6] | ((uint64_t)c[7] << 32), ob = (uint64_t)c[8] | ((uint64_t)c[9] << 32);
-                const bool ok = c[0] == 0 && c[3] == 0 && (c[4] != 0 || items[j].bs) && c[4] != 0xFFFFFFFFu && (dev || c[1] == 0) && ob == offset &&
+                const bool ok = c[0] == 0 && c[3] == 0 && c[12] == 0 && (c[4] != 0 || items[j].bs) && c[4] != 0xFFFFFFFFu && (dev || c[1] == 0) && ob == offset &&
                                 offset + t <= cap;
                 if (!ok) break;
                 offset += t;
@@ -3489,8 +3495,10 @@ int sketch_finish(mxg_handle *h)
     MXG_HIP(h, stream_wait(h->stream2));
     std::vector<Assembly *> list;
     std::vector<int> state;
+    std::vector<unsigned char> devg;
     list.swap(h->pend_list);
     state.swap(h->pend_state);
+    devg.swap(h->pend_dev);
     int rc;
     size_t q = 0;  // (one item per enqueued assembly, in order)
     for (size_t i = 0; i < list.size(); ++i) {
@@ -3499,7 +3507,11 @@ int sketch_finish(mxg_handle *h)
             const uint32_t *c = h->pinned_ctrl + 16 * q++;
             const uint64_t total = (uint64_t)c[6] | ((uint64_t)c[7] << 32), n_cand = c[4];
             const uint64_t cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
-            if (c[0] == 0 && c[1] == 0 && n_cand > 0 && c[4] != 0xFFFFFFFFu && total <= cap) {
+            // evaluate()'s `good` for a one-call mode, and what k_pack_slot_dev checked on the device: word 3 = the stretch kernels'
+            // flag, word 12 = the slice kernel gave up on a slice (its output is then truncated), stretches absent or all placed on
+            // the device (word 11 = handed to the host: the counts the pack kernel used would be without them)
+            const bool dev = i < devg.size() && devg[i] && c[11] == 0;
+            if (c[0] == 0 && c[3] == 0 && c[12] == 0 && (dev || c[1] == 0) && n_cand > 0 && c[4] != 0xFFFFFFFFu && total <= cap) {
                 a->n_mx = total;
                 a->has_sketch = true;
                 h->stat_candidates += n_cand;

@@ -56,7 +56,7 @@ struct BsSelGeom {
 // halo (strips on either side of a slice's own strips) that gives every own candidate w k-mers of its contig on either side --
 // or the contig's end -- whatever the run table looks like; 0: more than SEL_MAX_H strips (short runs between invalid bases)
 uint32_t bs_select_halo(const Assembly *a, uint32_t S, uint32_t w);
-BsSelGeom bs_select_geom(uint32_t S, uint32_t H, uint32_t w, double frac, uint32_t n_strips, uint32_t qcap_force);
+BsSelGeom bs_select_geom(uint32_t S, uint32_t H, uint32_t w, double frac, uint32_t n_strips, uint32_t qcap_force, uint32_t rk_force = 0);
 int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hipStream_t st);
 
 // layout + filter (per assembly)

@@ -17,6 +17,7 @@
 // certain: where that stretch ends is found by walking on through the strips behind the slice (stretch_end).
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 
 #include "bs_kernels.h"
 #include "nthash_dev.h"
@@ -552,7 +553,7 @@ uint32_t bs_select_halo(const Assembly *a, uint32_t S, uint32_t w)
     return H;
 }
 
-BsSelGeom bs_select_geom(uint32_t S, uint32_t H, uint32_t w, double frac, uint32_t n_strips, uint32_t qcap_force)
+BsSelGeom bs_select_geom(uint32_t S, uint32_t H, uint32_t w, double frac, uint32_t n_strips, uint32_t qcap_force, uint32_t rk_force)
 {
     BsSelGeom g{};
     g.ok = false;
@@ -567,6 +568,7 @@ BsSelGeom bs_select_geom(uint32_t S, uint32_t H, uint32_t w, double frac, uint32
     g.qcap = std::min<uint32_t>(g.qcap, 64u * S);
     const double sel = (double)g.T * S * 2.0 / (double)(w + 1);
     g.rk = ((uint32_t)(sel * 1.3 + 6.0 * std::sqrt(sel) + 24.0) + 31u) / 32u * 32u;
+    if (rk_force) g.rk = std::max<uint32_t>(4u, rk_force);  // (test knob: slices with more selected candidates than their room -- the kernel then gives the slice up)
     // as many waves per block as fit beside the 32 KB of position tables in the CU's 160 KB of LDS (one block per CU)
     const size_t budget = 160 * 1024 - 2048 * 16 - 1024;
     g.waves = (uint32_t)std::min<size_t>(16, budget / sel_wave_lds(g.qcap));
@@ -582,13 +584,21 @@ int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hi
     const uint32_t nwc = (p.S + 31u) / 32u + 1u;
     const uint32_t blocks = std::min<uint32_t>((g.n_slices + g.waves - 1) / g.waves, 256u);
     const dim3 grid(blocks), block(g.waves * 64u);
-    static bool attr_set = false;
-    if (!attr_set) {  // (more than 64 KB of dynamic LDS must be asked for)
-        MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<36>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    // more than 64 KB of dynamic LDS must be asked for, and the attribute belongs to the (function, device) pair: once per
+    // DEVICE, whichever handle or thread comes first (handles on several GPUs of one process, handles made by several threads)
+    static std::mutex attr_mutex;
+    constexpr int MXG_MAX_DEVICES = 64;
+    static bool attr_set[MXG_MAX_DEVICES] = {};
+    {
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        const int dev = h->device;
+        if (dev < 0 || dev >= MXG_MAX_DEVICES || !attr_set[dev]) {
+            MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<36>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (dev >= 0 && dev < MXG_MAX_DEVICES) attr_set[dev] = true;
+        }
     }
     if (nwc <= 12) hipLaunchKernelGGL(k_bs_select<12>, grid, block, g.lds, st, p);
     else if (nwc <= 16) hipLaunchKernelGGL(k_bs_select<16>, grid, block, g.lds, st, p);

@@ -19,7 +19,7 @@ from tests.test_gpu_scale_paths import _check, _records
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUTE_KNOBS = ("MXG_GAP_POOL", "MXG_BS", "MXG_BS_SELECT", "MXG_SEL_QCAP", "MXG_SPARSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S", "MXG_DEV_GAPS")
+ROUTE_KNOBS = ("MXG_GAP_POOL", "MXG_BS", "MXG_BS_SELECT", "MXG_SEL_QCAP", "MXG_SEL_RK", "MXG_SPARSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S", "MXG_DEV_GAPS")
 
 
 @pytest.fixture
@@ -97,6 +97,17 @@ def test_select_slices_beyond_their_queue(oracle, env):
     assert st["select_slices"] > 0
     st = _check(oracle, _records(52), 32, 300, cand_per_window=12)
     assert st["select_slices"] > 0
+
+
+@pytest.mark.parametrize("dev_gaps", ["0", "1"])
+def test_select_slice_that_gives_up_is_redone(oracle, env, dev_gaps):
+    """MXG_SEL_RK=4: a slice has room for four selected candidates, so nearly every slice gives up (its output would be
+    truncated); the kernel's flag sends the batch through the other route, with and without the device's stretch route"""
+    env["MXG_SPARSE_S"] = "320"
+    env["MXG_SEL_RK"] = "4"
+    env["MXG_DEV_GAPS"] = dev_gaps
+    _check(oracle, _records(61), 32, 1000)
+    _check(oracle, _records(62), 32, 300, cand_per_window=12)
 
 
 def test_select_stretch_ends_behind_the_slice(oracle, env):

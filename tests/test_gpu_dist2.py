@@ -47,7 +47,12 @@ def test_four_and_eight_ranks_on_one_gpu(world, config3):
     assert out.stdout.count("DIST2 OK") == world, out.stdout[-3000:]
 
 
-@pytest.mark.parametrize("knob", [{"MXG_TEST_CAND": "2"}, {"MXG_WAVE_CAP": "8"}])
+@pytest.mark.parametrize("knob", [{"MXG_TEST_CAND": "2"}, {"MXG_WAVE_CAP": "8"},
+                                  # the slice kernel gives slices up (room for 4 selected candidates per slice; w = 500 so that the
+                                  # sparse route runs at all): its flag alone must keep the truncated sketch from being accepted
+                                  {"MXG_SEL_RK": "4", "MXG_TEST_CONFIG3": "1"},
+                                  # stretches everywhere AND on the device route: the pack kernel accepts what k_gap_fix placed
+                                  {"MXG_TEST_CAND": "3", "MXG_TEST_CONFIG3": "1", "MXG_DEV_GAPS": "1"}])
 def test_union_step_when_sketches_leave_the_common_case(knob):
     """mxg_sketch_pack with sketches that do not end the common way on the device -- candidate-free stretches everywhere
     (2 candidates per window) / every wave overflowing its arena slice: their slots travel as -1, every rank falls back
@@ -83,6 +88,36 @@ def test_bench_two_ranks_on_one_gpu(mode):
 
 
 _BENCH_COUNTS = {}
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher in front (what a driver that only knows the one-GPU command line would run):
+    bench.py starts the two ranks itself, rank 0 prints the one JSON line, and the line says what the communicator held"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MXG_BENCH_BACKEND="gloo", MXG_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mbp", "5",
+           "--no-cpu-baseline", "--no-end-to-end"]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]                       # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["vertices"] > 0
+    di = d["distributed"]
+    assert di["world"] == 2 and di["communicator_ranks"] == 2 and di["allreduce_of_ones"] == 2
+    assert "bench.py itself" in di["launched_by"] and len(di["devices_by_rank"]) == 2
+
+
+def test_bench_own_ranks_fail_loudly():
+    """a rank that dies takes the run down with a non-zero status instead of leaving the others in a collective"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MXG_BENCH_BACKEND="gloo", MXG_BENCH_ONE_DEVICE="1", MXG_BENCH_KILL_RANK="1")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mbp", "5",
+           "--no-cpu-baseline", "--no-end-to-end"]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
 @pytest.mark.parametrize("world,split", [(3, True), (2, False)])

@@ -10,12 +10,9 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 for n in 1 2 4 8; do
   [ "$n" -le "$n_gpu" ] || { echo "{\"n_gpus\": $n, \"skipped\": \"the node has $n_gpu GPU(s)\"}"; continue; }
   out=gpurun_out/scale/bench_n$n.json
-  if [ "$n" -eq 1 ]; then
-    timeout 1500 python bench.py --gpus 1 --steps $steps --warmup $warm --no-end-to-end > $out 2> gpurun_out/scale/bench_n$n.err
-  else
-    timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29600 + n)) \
-        bench.py --gpus $n --steps $steps --warmup $warm > $out 2> gpurun_out/scale/bench_n$n.err
-  fi
+  # bench.py starts its own N ranks when no launcher did (WORLD_SIZE unset): the same line for every N
+  extra=""; [ "$n" -eq 1 ] && extra="--no-end-to-end"
+  timeout 1500 python bench.py --gpus $n --steps $steps --warmup $warm $extra > $out 2> gpurun_out/scale/bench_n$n.err
   grep '^{' $out | tail -1
   [ -f profiles/r04/bench_dry$n.json ] && python - "$n" <<'PY'
 import json, sys
