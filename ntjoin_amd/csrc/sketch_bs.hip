@@ -295,6 +295,9 @@ __device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, cons
         const uint32_t e = le[i], l1 = e & 63u;
         const uint64_t h = lh[i];
         const uint32_t kx = s_k0[l1] + ((e >> 6) - s_f[l1]), cg = s_c[l1], nk = s_nk[l1];
+        // (no running "done" flag inside a step: the neighbours lie at rising distances, so the nearest one with a smaller hash is
+        // the one at the SMALLEST distance among those with a smaller hash -- a minimum, which needs no order and no mask
+        // arithmetic in scalar registers; the step's farthest neighbour says whether the window's end has been passed)
         uint32_t dl = 0xFFFFFFFFu;
         bool ldone = !live;
         for (uint32_t t = 1; !ldone; t += SEL_PAD) {
@@ -305,15 +308,13 @@ __device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, cons
                 ae[u] = le[(int)i - (int)t - (int)u];
                 ah[u] = lh[(int)i - (int)t - (int)u];
             }
+            uint32_t dmin = 0xFFFFFFFFu;
 #pragma unroll
-            for (uint32_t u = 0; u < SEL_PAD; ++u) {
-                const uint32_t d = e - ae[u];
-                const bool stop = d > lim, lt = ah[u] < h;
-                dl = (!ldone & !stop & lt) ? d : dl;
-                ldone = ldone | stop | lt;
-            }
+            for (uint32_t u = 0; u < SEL_PAD; ++u) dmin = min(dmin, ah[u] < h ? e - ae[u] : 0xFFFFFFFFu);
+            dl = dmin;
+            ldone = dmin <= lim || e - ae[SEL_PAD - 1] > lim;
         }
-        const uint32_t L = dl != 0xFFFFFFFFu ? (dl >> 6) - 1u : min(kx, wm1);
+        const uint32_t L = dl <= lim ? (dl >> 6) - 1u : min(kx, wm1);
         const uint32_t R0 = min(nk - 1u - kx, wm1);
         bool s = live && (L + R0 + 1u >= w);
         const uint32_t need = 64u * (wm1 - min(L, wm1)) + 63u;  // blocked by a smaller-or-equal hash within this e-distance
@@ -326,13 +327,12 @@ __device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, cons
                 be[u] = le[i + t + u];
                 bh[u] = lh[i + t + u];
             }
+            uint32_t dmin = 0xFFFFFFFFu;
 #pragma unroll
-            for (uint32_t u = 0; u < SEL_PAD; ++u) {
-                const uint32_t d = be[u] - e;
-                const bool stop = d > need, lq = bh[u] <= h;
-                s = (!rdone & !stop & lq) ? false : s;
-                rdone = rdone | stop | lq;
-            }
+            for (uint32_t u = 0; u < SEL_PAD; ++u) dmin = min(dmin, bh[u] <= h ? be[u] - e : 0xFFFFFFFFu);
+            const bool blocked = dmin <= need;
+            s = blocked ? false : s;
+            rdone = blocked || be[SEL_PAD - 1] - e > need;
         }
         // a piece of a record that starts with the halo of the shard before it: see k_resolve
         if (has_drop && s && kx <= wm1 && L == kx && sel_rare_params()->ctg_drop[cg]) s = false;
