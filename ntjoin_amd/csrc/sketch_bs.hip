@@ -220,24 +220,41 @@ __device__ __forceinline__ void sel_collect(const BsSelParams &p, SelCtx &c, uin
     c.nreal = c.own_lo = c.own_hi = 0;
     if (p.ablate == 2) return;  // (profiling)
     uint32_t nreal = 0, own_lo = 0, own_hi = 0;
-    for (uint32_t q0 = 0; q0 < qn; q0 += 64u) {
-        const uint32_t q = q0 + lane;
-        const bool act = q < qn;
-        const uint32_t item = act ? le[q] : 0u;
-        const uint32_t l2 = item & 63u, ju = item >> 6;
-        const uint64_t b = (((uint64_t)s_bhi[l2] << 32) | s_blo[l2]) + ju;
-        uint64_t h = ~0ull;
-        if (act) h = hash32_pos(p.packed, b, c.ptab);
-        const bool real = act && h < p.tau;
-        const uint64_t m = __ballot(real);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (real) {  // (in place: an entry lands at or in front of the item it came from, and the round's items have all been read)
-            le[nreal + rank] = ((s_f[l2] + ju) << 6) | l2;
-            lh[nreal + rank] = h;
+    // four rounds of 64 candidates at a time: the rounds' packed bases are all requested before the first round's table lookups,
+    // so a slice waits once for them, not once per round (a round's request depends on nothing but the queue)
+    constexpr uint32_t NR = 4;
+    for (uint32_t q0 = 0; q0 < qn; q0 += 64u * NR) {
+        uint32_t item[NR];
+        Words3 wv[NR];
+        uint32_t shv[NR];
+#pragma unroll
+        for (uint32_t r = 0; r < NR; ++r) {
+            const uint32_t q = q0 + 64u * r + lane;
+            const bool act = q < qn;
+            item[r] = act ? le[q] : 0u;
+            const uint32_t l2 = item[r] & 63u;
+            const uint64_t b = (((uint64_t)s_bhi[l2] << 32) | s_blo[l2]) + (item[r] >> 6);
+            wv[r] = Words3{0u, 0u, 0u};
+            if (act) wv[r] = *reinterpret_cast<const Words3 *>(p.packed + (b >> 4));
+            shv[r] = ((uint32_t)b & 15u) * 2u;
         }
-        own_lo += (uint32_t)__popcll(__ballot(real && l2 < H));
-        own_hi += (uint32_t)__popcll(__ballot(real && l2 < c.own_end));
-        nreal += (uint32_t)__popcll(m);
+#pragma unroll
+        for (uint32_t r = 0; r < NR; ++r) {
+            if (q0 + 64u * r >= qn) break;  // (wave-uniform)
+            const bool act = q0 + 64u * r + lane < qn;
+            const uint32_t l2 = item[r] & 63u, ju = item[r] >> 6;
+            const uint64_t h = act ? hash32_words(wv[r].w0, wv[r].w1, wv[r].w2, shv[r], c.ptab) : ~0ull;
+            const bool real = act && h < p.tau;
+            const uint64_t m = __ballot(real);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (real) {  // (in place: an entry lands at or in front of the item it came from, and the batch's items have all been read)
+                le[nreal + rank] = ((s_f[l2] + ju) << 6) | l2;
+                lh[nreal + rank] = h;
+            }
+            own_lo += (uint32_t)__popcll(__ballot(real && l2 < H));
+            own_hi += (uint32_t)__popcll(__ballot(real && l2 < c.own_end));
+            nreal += (uint32_t)__popcll(m);
+        }
     }
     if (lane < SEL_PAD) {  // sentinels: out of every scan's reach (the folded coordinates start at 2 w), hashes that never block
         le[-1 - (int)lane] = 0u;
@@ -295,10 +312,12 @@ __device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, cons
         const uint32_t e = le[i], l1 = e & 63u;
         const uint64_t h = lh[i];
         const uint32_t kx = s_k0[l1] + ((e >> 6) - s_f[l1]), cg = s_c[l1], nk = s_nk[l1];
-        // (no running "done" flag inside a step: the neighbours lie at rising distances, so the nearest one with a smaller hash is
-        // the one at the SMALLEST distance among those with a smaller hash -- a minimum, which needs no order and no mask
-        // arithmetic in scalar registers; the step's farthest neighbour says whether the window's end has been passed)
-        uint32_t dl = 0xFFFFFFFFu;
+        // (no running "done" flag inside a step, and no distances: on the left the nearest neighbour with a smaller hash is the one
+        // with the LARGEST e among those with a smaller hash -- a maximum, which needs no order and no mask arithmetic in scalar
+        // registers -- and it lies inside the window iff that e >= e - lim; the step's farthest neighbour says whether the
+        // window's end has been passed.  Two and a half vector instructions per neighbour: compare, select, half a max3.)
+        const uint32_t e_lo = e - lim;  // (e >= 128 w > lim: the folded coordinates start at 2 w)
+        uint32_t al = 0u;
         bool ldone = !live;
         for (uint32_t t = 1; !ldone; t += SEL_PAD) {
             uint32_t ae[SEL_PAD];
@@ -308,16 +327,17 @@ __device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, cons
                 ae[u] = le[(int)i - (int)t - (int)u];
                 ah[u] = lh[(int)i - (int)t - (int)u];
             }
-            uint32_t dmin = 0xFFFFFFFFu;
-#pragma unroll
-            for (uint32_t u = 0; u < SEL_PAD; ++u) dmin = min(dmin, ah[u] < h ? e - ae[u] : 0xFFFFFFFFu);
-            dl = dmin;
-            ldone = dmin <= lim || e - ae[SEL_PAD - 1] > lim;
+            static_assert(SEL_PAD == 8, "the scans look at eight neighbours per step");
+            const uint32_t c0 = ah[0] < h ? ae[0] : 0u, c1 = ah[1] < h ? ae[1] : 0u, c2 = ah[2] < h ? ae[2] : 0u, c3 = ah[3] < h ? ae[3] : 0u;
+            const uint32_t c4 = ah[4] < h ? ae[4] : 0u, c5 = ah[5] < h ? ae[5] : 0u, c6 = ah[6] < h ? ae[6] : 0u, c7 = ah[7] < h ? ae[7] : 0u;
+            al = max(max(max(c0, c1), c2), max(max(max(c3, c4), c5), max(c6, c7)));
+            ldone = al >= e_lo || ae[SEL_PAD - 1] < e_lo;
         }
-        const uint32_t L = dl <= lim ? (dl >> 6) - 1u : min(kx, wm1);
+        const uint32_t L = al >= e_lo ? ((e - al) >> 6) - 1u : min(kx, wm1);
         const uint32_t R0 = min(nk - 1u - kx, wm1);
         bool s = live && (L + R0 + 1u >= w);
-        const uint32_t need = 64u * (wm1 - min(L, wm1)) + 63u;  // blocked by a smaller-or-equal hash within this e-distance
+        // blocked by a smaller-or-equal hash at an e up to this one (e < 2^31: the folded axis of a slice is short)
+        const uint32_t e_hi = e + 64u * (wm1 - min(L, wm1)) + 63u;
         bool rdone = !(s && L < wm1);
         for (uint32_t t = 1; !rdone; t += SEL_PAD) {
             uint32_t be[SEL_PAD];
@@ -327,12 +347,13 @@ __device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, cons
                 be[u] = le[i + t + u];
                 bh[u] = lh[i + t + u];
             }
-            uint32_t dmin = 0xFFFFFFFFu;
-#pragma unroll
-            for (uint32_t u = 0; u < SEL_PAD; ++u) dmin = min(dmin, bh[u] <= h ? be[u] - e : 0xFFFFFFFFu);
-            const bool blocked = dmin <= need;
+            const uint32_t n = 0xFFFFFFFFu;
+            const uint32_t c0 = bh[0] <= h ? be[0] : n, c1 = bh[1] <= h ? be[1] : n, c2 = bh[2] <= h ? be[2] : n, c3 = bh[3] <= h ? be[3] : n;
+            const uint32_t c4 = bh[4] <= h ? be[4] : n, c5 = bh[5] <= h ? be[5] : n, c6 = bh[6] <= h ? be[6] : n, c7 = bh[7] <= h ? be[7] : n;
+            const uint32_t bl = min(min(min(c0, c1), c2), min(min(min(c3, c4), c5), min(c6, c7)));
+            const bool blocked = bl <= e_hi;
             s = blocked ? false : s;
-            rdone = blocked || be[SEL_PAD - 1] - e > need;
+            rdone = blocked || be[SEL_PAD - 1] > e_hi;
         }
         // a piece of a record that starts with the halo of the shard before it: see k_resolve
         if (has_drop && s && kx <= wm1 && L == kx && sel_rare_params()->ctg_drop[cg]) s = false;
