@@ -37,16 +37,51 @@ struct __attribute__((packed, aligned(4))) Words3 {
 struct __attribute__((packed, aligned(4))) Words4 {
     uint32_t w0, w1, w2, w3;
 };
+// byte B of x, times 16 (the byte offset of a 16-byte table entry): one SDWA shift instead of a field extract and a shift
+template <int B>
+__device__ __forceinline__ uint32_t byte_x16(const uint32_t x)
+{
+    uint32_t r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(B >= 0 && B < 4, "byte of a word");
+    if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(4u), "v"(x));
+    else if (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(4u), "v"(x));
+    else if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(4u), "v"(x));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(4u), "v"(x));
+#else
+    r = ((x >> (8 * B)) & 255u) << 4;
+#endif
+    return r;
+}
+__device__ __forceinline__ uint32_t xor3(const uint32_t a, const uint32_t b, const uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // (one v_bitop3_b32; the compiler makes two v_xor_b32 of a ^ b ^ c)
+#else
+    return a ^ b ^ c;
+#endif
+}
 __device__ __forceinline__ uint64_t hash32_words(const uint32_t w0, const uint32_t w1, const uint32_t w2, const uint32_t sh, const uint4 *ptab)
 {
     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {
-        const uint4 e0 = ptab[u * 256u + ((lo >> (8 * u)) & 255u)];
-        const uint4 e1 = ptab[(4u + u) * 256u + ((hi >> (8 * u)) & 255u)];
-        acc.x ^= e0.x ^ e1.x; acc.y ^= e0.y ^ e1.y; acc.z ^= e0.z ^ e1.z; acc.w ^= e0.w ^ e1.w;
-    }
+    // the tables lie at offset 0 of the block's LDS (k_bs_select checks it), so an entry's address is its byte offset: the
+    // table's 4096 j goes into the instruction's offset field, and nothing is added (through a generic pointer the compiler adds
+    // the -- zero -- address of the dynamic LDS symbol to every one of them)
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)ptab;
+    typedef const uint4 __attribute__((address_space(3))) *lds_u4;
+    auto ent = [&](const uint32_t j, const uint32_t off) { return *(lds_u4)(uintptr_t)(off + j * 4096u); };
+#else
+    auto ent = [&](const uint32_t j, const uint32_t off) { return ptab[j * 256u + off / 16u]; };  // (host pass of the compiler: never called)
+#endif
+    const uint4 a0 = ent(0, byte_x16<0>(lo)), b0 = ent(4, byte_x16<0>(hi));
+    uint4 acc = make_uint4(a0.x ^ b0.x, a0.y ^ b0.y, a0.z ^ b0.z, a0.w ^ b0.w);
+    const uint4 a1 = ent(1, byte_x16<1>(lo)), b1 = ent(5, byte_x16<1>(hi));
+    acc = make_uint4(xor3(acc.x, a1.x, b1.x), xor3(acc.y, a1.y, b1.y), xor3(acc.z, a1.z, b1.z), xor3(acc.w, a1.w, b1.w));
+    const uint4 a2 = ent(2, byte_x16<2>(lo)), b2 = ent(6, byte_x16<2>(hi));
+    acc = make_uint4(xor3(acc.x, a2.x, b2.x), xor3(acc.y, a2.y, b2.y), xor3(acc.z, a2.z, b2.z), xor3(acc.w, a2.w, b2.w));
+    const uint4 a3 = ent(3, byte_x16<3>(lo)), b3 = ent(7, byte_x16<3>(hi));
+    acc = make_uint4(xor3(acc.x, a3.x, b3.x), xor3(acc.y, a3.y, b3.y), xor3(acc.z, a3.z, b3.z), xor3(acc.w, a3.w, b3.w));
     return (((uint64_t)acc.y << 32) | acc.x) + (((uint64_t)acc.w << 32) | acc.z);
 }
 __device__ __forceinline__ uint64_t hash32_pos(const uint32_t *__restrict__ packed, const uint64_t b, const uint4 *ptab)
@@ -83,6 +118,19 @@ __device__ __forceinline__ StripRegs strip_of(const BsSelParams &p, const bool i
         r.k0 = run.kidx0 + j0;
         r.nk = run.nk;
     }
+    return r;
+}
+// the same from a run entry that was requested earlier, whatever `in` says (the entry of a clamped index): nothing here waits for
+// memory under a condition, so the compiler places the wait where the values are first used, not behind the request
+__device__ __forceinline__ StripRegs strip_from_run(const BsSelParams &p, const bool in, const uint32_t sS, const RunX &run)
+{
+    const uint32_t j0 = sS - run.strip0S;
+    StripRegs r;
+    r.len = in ? min(p.S, run.n_kmers - j0) : 0u;
+    r.b = in ? run.base_off + j0 : 0ull;
+    r.cg = in ? run.contig : 0xFFFFFFFFu;
+    r.k0 = in ? run.kidx0 + j0 : 0u;
+    r.nk = in ? run.nk : 0u;
     return r;
 }
 __device__ __forceinline__ StripRegs load_strip(const BsSelParams &p, const int64_t s64)
@@ -403,6 +451,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     static_assert(NWC % 4 == 0, "the strips' bitmap words are requested four at a time");
     extern __shared__ uint4 sel_lds[];
     uint4 *ptab = sel_lds;
+    if ((uint32_t)(uintptr_t)sel_lds != 0u) __builtin_trap();  // (hash32_words reads the tables at LDS offset 0: no static LDS in this kernel)
     for (uint32_t i = threadIdx.x; i < 2048u; i += blockDim.x) ptab[i] = p.ptab[i];
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     unsigned char *wb = reinterpret_cast<unsigned char *>(sel_lds + 2048) + (size_t)wib * sel_wave_lds(p.qcap);
@@ -416,13 +465,16 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     c.lane = lane;
     c.has_drop = p.ctg_drop != nullptr;
     c.nreal = c.own_lo = c.own_hi = 0;
-    if (lane == 0) c.misc[0] = 0;
+    if (lane == 0) {
+        c.misc[0] = 0;
+        c.misc[1] = 0xFFFFFFFFu;  // this wave's region of global memory, once it has needed one (kept in LDS: a loop-carried scalar
+                                  // for a path one slice in 10^5 takes cost every slice a wait -- the compiler's phi of it)
+    }
     __syncthreads();
     const uint32_t S = p.S, H = p.H, T = p.T, w = p.w;
     const uint32_t nwords = (S + 31u) / 32u;
     const uint32_t stride = gridDim.x * nwv, laneS = lane * S;
     uint32_t own_cands = 0;
-    uint32_t region = 0xFFFFFFFFu;  // this wave's region of global memory, once it has needed one
     bool flag = false;
     // (a wave takes every stride-th slice; runs of consecutive slices per wave measured 4 % slower)
     uint32_t sl = blockIdx.x * nwv + wib;
@@ -440,7 +492,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         const int64_t sn64 = first_strip(sl_n) + lane;
         const bool in_n = sl_n < sl_end && sn64 >= 0 && sn64 < (int64_t)p.n_strips_asm;
         const uint32_t s_n = in_n ? (uint32_t)sn64 : 0u;
-        const uint32_t ri_n = in_n ? p.strip_run[s_n] : 0u;
+        const uint32_t ri_n = p.strip_run[s_n];  // (unconditional, from a clamped index: a request under a condition is waited for at once)
         const uint32_t sS_n = (uint32_t)(sn64 - lane) * S + laneS;  // (wrong only where in_n is false)
         // the strip's words of the bitmap, four per request
         uint32_t wd[NWC];
@@ -487,7 +539,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         // the next slice's strips: their run indices have arrived while this slice's bitmap words travelled.  (Asking ahead for the
         // next slice's bitmap and base lines as well, or touching this slice's base lines while the bitmap words travel, was
         // measured: 1.6 x the kernel's HBM traffic -- the waves of an XCD hold more lines than its L2 -- for no time at all.)
-        const StripRegs sr_n = strip_of(p, in_n, sS_n, ri_n);
+        const RunX run_n = p.runx[ri_n];  // (in flight until the end of the slice)
         if (p.ablate == 1) {  // (profiling)
             if (lane == 0) count_publish(p.cnt, p.sup, sl, 0u);
             own_cands += tot != 0;
@@ -501,11 +553,9 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
             }
         } else {
             const BsSelParams *q = sel_rare_params();
-            if (region == 0xFFFFFFFFu) {
-                uint32_t r = 0;
-                if (lane == 0) r = atomicAdd(q->ovf_next, 1u);
-                region = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-            }
+            if (lane == 0 && c.misc[1] == 0xFFFFFFFFu) c.misc[1] = atomicAdd(q->ovf_next, 1u);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t region = c.misc[1];
             if (region < q->n_ovf) {
                 const uint32_t ocap = q->ovf_cap;
                 const size_t o = (size_t)region * (ocap + 2u * SEL_PAD) + SEL_PAD;
@@ -519,7 +569,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         }
         own_cands += c.own_hi - c.own_lo;
         __builtin_amdgcn_wave_barrier();  // the next slice reuses the wave's LDS
-        sr = sr_n;
+        sr = strip_from_run(p, in_n, sS_n, run_n);
     }
     const uint32_t own_w = own_cands;  // (wave-uniform)
     if (lane == 0) {
