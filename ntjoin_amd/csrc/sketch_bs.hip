@@ -445,10 +445,14 @@ __device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, cons
 }  // namespace
 
 // NWC = bitmap words a lane keeps of its strip: S / 32 rounded up + 1, as whole 16-byte requests
-template <int NWC>
+// NWX = the strip's words of bits when they are known where the kernel is compiled (S = 32 NWX: the default strip of 320 k-mers
+// has its own instance), else 0: "word j belongs to the strip" is then no select per word on a mask kept in scalar registers
+template <int NWC, int NWX>
 __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
 {
     static_assert(NWC % 4 == 0, "the strips' bitmap words are requested four at a time");
+    static_assert(NWX < NWC, "one word more than the strip's bits is read (the bits are shifted into place)");
+    constexpr int NB = NWX ? NWX : NWC - 1;  // words of bits a lane keeps
     extern __shared__ uint4 sel_lds[];
     uint4 *ptab = sel_lds;
     if ((uint32_t)(uintptr_t)sel_lds != 0u) __builtin_trap();  // (hash32_words reads the tables at LDS offset 0: no static LDS in this kernel)
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     }
     __syncthreads();
     const uint32_t S = p.S, H = p.H, T = p.T, w = p.w;
-    const uint32_t nwords = (S + 31u) / 32u;
+    const uint32_t nwords = NWX ? (uint32_t)NWX : (S + 31u) / 32u;
     const uint32_t stride = gridDim.x * nwv, laneS = lane * S;
     uint32_t own_cands = 0;
     bool flag = false;
@@ -481,6 +485,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     const uint32_t sl_end = p.n_slices;
     // a slice's strips are looked up one slice ahead: the strip -> run table while the slice before is being set up, the run
     // itself while that slice's candidates are being decided (nothing there waits for memory)
+    // (strips are counted in 32 bits, bs_select_geom: a first strip "in front of the assembly" wraps to a number no assembly has)
     auto first_strip = [&](uint32_t q) { return (int64_t)(p.strip_lo + q * T) - (int64_t)H; };
     StripRegs sr = sl < sl_end ? load_strip(p, first_strip(sl) + lane) : StripRegs{0, 0, 0xFFFFFFFFu, 0, 0};
     for (; sl < sl_end; sl += stride) {
@@ -489,11 +494,11 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         c.s_first = first_strip(sl);
         c.own_end = H + min(T, p.strip_hi - s_own0);  // lanes [H, own_end) hold the slice's own strips
         const uint32_t sl_n = sl + stride;
-        const int64_t sn64 = first_strip(sl_n) + lane;
-        const bool in_n = sl_n < sl_end && sn64 >= 0 && sn64 < (int64_t)p.n_strips_asm;
-        const uint32_t s_n = in_n ? (uint32_t)sn64 : 0u;
+        const uint32_t sn32 = p.strip_lo + sl_n * T - H + lane;
+        const bool in_n = sl_n < sl_end && sn32 < p.n_strips_asm;
+        const uint32_t s_n = in_n ? sn32 : 0u;
         const uint32_t ri_n = p.strip_run[s_n];  // (unconditional, from a clamped index: a request under a condition is waited for at once)
-        const uint32_t sS_n = (uint32_t)(sn64 - lane) * S + laneS;  // (wrong only where in_n is false)
+        const uint32_t sS_n = (sn32 - lane) * S + laneS;  // (wrong only where in_n is false)
         // the strip's words of the bitmap, four per request
         uint32_t wd[NWC];
         {
@@ -519,20 +524,20 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         // the strip's bits, word by word (k-mers [32 j, 32 j + 32), LSB first): shifted into place, cut at the strip's length --
         // positions whose 32-mer crosses the run's end are set in the bitmap (the filter sees bases, not runs).  When every strip
         // of the slice is whole (nearly always) nothing needs cutting.
-        uint32_t bt[NWC - 1];
+        uint32_t bt[NB];
         uint32_t cnt = 0;
         {
             const uint32_t sh = (uint32_t)sr.b & 31u;
-            const bool whole = (S & 31u) == 0 && __ballot(sr.len != 0 && sr.len != S) == 0;
+            const bool whole = (NWX || (S & 31u) == 0) && __ballot(sr.len != 0 && sr.len != S) == 0;
             if (whole) {
 #pragma unroll
-                for (uint32_t j = 0; j + 1 < (uint32_t)NWC; ++j) bt[j] = j < nwords ? __builtin_amdgcn_alignbit(wd[j + 1], wd[j], sh) : 0u;
+                for (uint32_t j = 0; j < (uint32_t)NB; ++j) bt[j] = j < nwords ? __builtin_amdgcn_alignbit(wd[j + 1], wd[j], sh) : 0u;
             } else {
 #pragma unroll
-                for (uint32_t j = 0; j + 1 < (uint32_t)NWC; ++j) bt[j] = j < nwords ? sel_bits(wd[j], wd[j + 1], sh, sr.len, j) : 0u;
+                for (uint32_t j = 0; j < (uint32_t)NB; ++j) bt[j] = j < nwords ? sel_bits(wd[j], wd[j + 1], sh, sr.len, j) : 0u;
             }
 #pragma unroll
-            for (uint32_t j = 0; j + 1 < (uint32_t)NWC; ++j) cnt += (uint32_t)__popc(bt[j]);
+            for (uint32_t j = 0; j < (uint32_t)NB; ++j) cnt += (uint32_t)__popc(bt[j]);
         }
         const uint32_t incl = wave_inclusive_dpp(cnt);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
             if (lane == 0) count_publish(p.cnt, p.sup, sl, 0u);
             own_cands += tot != 0;
         } else if (tot <= p.qcap) {
-            sel_collect<NWC - 1, false>(p, c, lh + SEL_PAD, le + SEL_PAD, p.qcap, bt, incl - cnt, tot);
+            sel_collect<NB, false>(p, c, lh + SEL_PAD, le + SEL_PAD, p.qcap, bt, incl - cnt, tot);
             if (p.ablate == 2 || p.ablate == 3) {
                 if (lane == 0) count_publish(p.cnt, p.sup, sl, 0u);
                 own_cands += 1u;
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
             if (region < q->n_ovf) {
                 const uint32_t ocap = q->ovf_cap;
                 const size_t o = (size_t)region * (ocap + 2u * SEL_PAD) + SEL_PAD;
-                sel_collect<NWC - 1, true>(p, c, q->ovf_h + o, q->ovf_e + o, ocap, bt, incl - cnt, tot);
+                sel_collect<NB, true>(p, c, q->ovf_h + o, q->ovf_e + o, ocap, bt, incl - cnt, tot);
                 sel_decide<true>(p, c, q->ovf_h + o, q->ovf_e + o, sr, f, flag);
             } else {  // no region left: the host redoes the batch
                 flag = true;
@@ -664,17 +669,19 @@ int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hi
         std::lock_guard<std::mutex> lock(attr_mutex);
         const int dev = h->device;
         if (dev < 0 || dev >= MXG_MAX_DEVICES || !attr_set[dev]) {
-            MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            MXG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bs_select<36>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            const void *fns[] = {reinterpret_cast<const void *>(&k_bs_select<12, 10>), reinterpret_cast<const void *>(&k_bs_select<8, 0>),
+                                 reinterpret_cast<const void *>(&k_bs_select<12, 0>), reinterpret_cast<const void *>(&k_bs_select<16, 0>),
+                                 reinterpret_cast<const void *>(&k_bs_select<20, 0>), reinterpret_cast<const void *>(&k_bs_select<36, 0>)};
+            for (const void *f : fns) MXG_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (dev >= 0 && dev < MXG_MAX_DEVICES) attr_set[dev] = true;
         }
     }
-    if (nwc <= 12) hipLaunchKernelGGL(k_bs_select<12>, grid, block, g.lds, st, p);
-    else if (nwc <= 16) hipLaunchKernelGGL(k_bs_select<16>, grid, block, g.lds, st, p);
-    else if (nwc <= 20) hipLaunchKernelGGL(k_bs_select<20>, grid, block, g.lds, st, p);
-    else hipLaunchKernelGGL(k_bs_select<36>, grid, block, g.lds, st, p);
+    if (p.S == 320u) hipLaunchKernelGGL((k_bs_select<12, 10>), grid, block, g.lds, st, p);
+    else if (nwc <= 8) hipLaunchKernelGGL((k_bs_select<8, 0>), grid, block, g.lds, st, p);
+    else if (nwc <= 12) hipLaunchKernelGGL((k_bs_select<12, 0>), grid, block, g.lds, st, p);
+    else if (nwc <= 16) hipLaunchKernelGGL((k_bs_select<16, 0>), grid, block, g.lds, st, p);
+    else if (nwc <= 20) hipLaunchKernelGGL((k_bs_select<20, 0>), grid, block, g.lds, st, p);
+    else hipLaunchKernelGGL((k_bs_select<36, 0>), grid, block, g.lds, st, p);
     MXG_HIP(h, hipGetLastError());
     return MXG_OK;
 }
