@@ -46,7 +46,7 @@ sys.path.insert(0, REPO)
 
 K = 32
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r04"   # profiles/<round>/: the committed rocprofv3 summaries static figures are quoted from
+PROFILE_ROUND = "r05"   # profiles/<round>/: the committed rocprofv3 summaries static figures are quoted from
 ALG_BYTES_PER_BASE_HASH = 0.25   # hash kernel: one 2-bit packed base read per base
 ALG_BYTES_PER_MINIMIZER = 70.0   # whole path: sketch tuple + uniqueness + intersection + edge build
 
@@ -132,6 +132,53 @@ def valu_model(bases_per_launch, avg_ms):
             "frac_of_issue_bound": round(bound_ms / avg_ms, 4) if avg_ms > 0 else None,
             "model": f"instructions x chunks / {SIMDS} SIMDs x {ISSUE_CYCLES:g} cycles / {CLOCK_HZ / 1e9:g} GHz; the instruction count is "
                      "static (generated code: ntjoin_amd/csrc/gen/bs_gen.py), the launch time is this run's"}
+
+
+SELECT_ISSUE_CYCLES = 4.0  # what a wave64 VALU instruction of k_bs_select's mix occupies its SIMD for: SQ_ACTIVE_INST_VALU x 4 cycles /
+                           # SQ_INSTS_VALU = 4.00 in every PMC pass of the kernel (compares, shifts, DPP, selects: profiles/ubench/README.md)
+ALG_BYTES_PER_MINIMIZER_TUPLE = 16.0  # the (hash, pos, record) tuple a selected minimizer is written as
+
+
+def committed_kernel_stats(wl):
+    """rocprofv3 --kernel-trace --stats summary of this workload committed under profiles/<round>/ -> [(kernel, total ns, avg ns, calls)]
+    of the step's kernels, largest first (the generator k_synth and the runtime's fill / copy kernels are not part of a step)"""
+    import csv
+    path = os.path.join(REPO, "profiles", PROFILE_ROUND, f"{wl}_kernel_stats.csv")
+    rows = []
+    try:
+        with open(path, newline="") as fh:
+            for r in csv.DictReader(fh):
+                name = r["Name"].split("(")[0].replace("void ", "").replace("mxg::", "")
+                if name.startswith("k_synth") or name.startswith("__amd_rocclr") or name.startswith("k_strip_runs"):
+                    continue
+                rows.append((name, float(r["TotalDurationNs"]), float(r["AverageNs"]), int(r["Calls"])))
+    except (OSError, KeyError, ValueError):
+        return None, path
+    rows.sort(key=lambda x: -x[1])
+    return rows, path
+
+
+def select_valu_model(launch_ms, slices_per_launch):
+    """k_bs_select against VALU issue: wave64 instructions per slice from the committed PMC passes of the kernel at these sources
+    (profiles/<round>/configs2_select_pmc.json, made by tools/pmc_sel.sh), this run's launch time"""
+    path = os.path.join(REPO, "profiles", PROFILE_ROUND, "configs2_select_pmc.json")
+    try:
+        pj = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if pj.get("kernel_sources_digest") != kernel_sources_digest():
+        return {"kernel": "k_bs_select", "stale": f"profiles/{PROFILE_ROUND}/configs2_select_pmc.json was captured at commit {pj.get('commit', '?')} "
+                                                  "and the kernel sources have changed since; not quoted"}
+    per = pj["per_slice"]
+    bound_ms = per["valu"] * slices_per_launch / SIMDS * SELECT_ISSUE_CYCLES / CLOCK_HZ * 1e3
+    return {"kernel": "k_bs_select", "wave64_instr_per_slice": per, "slices_per_launch": int(slices_per_launch),
+            "cycles_per_valu_instr_measured": pj.get("cycles_per_valu_instr"), "lds_bank_conflict_cycles_per_slice": pj.get("lds_bank_conflict_cycles_per_slice"),
+            "wait_any_frac_of_wave_cycles": pj.get("wait_any_frac"), "waves_per_simd": pj.get("waves_per_simd"),
+            "valu_issue_bound_ms": round(bound_ms, 4), "avg_launch_ms": round(launch_ms, 4),
+            "frac_of_issue_bound": round(bound_ms / launch_ms, 4) if launch_ms > 0 else None,
+            "source": f"profiles/{PROFILE_ROUND}/configs2_select_pmc.json (commit {pj.get('commit', '?')})",
+            "model": f"VALU instructions per slice x slices / {SIMDS} SIMDs x {SELECT_ISSUE_CYCLES:g} cycles / {CLOCK_HZ / 1e9:g} GHz: the kernel's "
+                     "instruction mix issues at 4 cycles per wave64 instruction (PMC), not at the 2 of the filter's fast-class stream"}
 
 
 def workload_tables(name, mbp, w, seed=1):
@@ -640,24 +687,7 @@ def main():
             "knobs_in_force": eng.knobs(),  # MXG_* environment switches the handle read and found set ("" = library defaults)
             "resident_input": "2-bit packed bases (0.25 B/bp) as handed over through mxg_add_assembly_packed_device*; every step reads them as they are",
             "step_ms_min_max": [round(min(step_times) * 1e3, 4), round(max(step_times) * 1e3, 4)],
-            "roofline": {"bound": "hbm",
-                         "kernel": ("k_hash_bs (bit-sliced ntHash top rings + candidate filter, one launch per assembly)" if bs_route()
-                                    else "k_hash_sparse (ntHash fwd/rc rings + candidate filter)"),
-                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_commit": tj_commit,
-                         "alg_bytes_per_base": ALG_BYTES_PER_BASE_HASH, "alg_bytes_per_launch": int(bytes_per_launch),
-                         "avg_launch_ms": round(avg_ms, 4), "launches": int(st["launches_hash"]),
-                         "timed": "HIP-event pair around every launch of the kernel inside the timed region, on the launch stream",
-                         "streams": ("free-running (MXG_STAGGER=0): this kernel shares the GPU with the other assembly's slice kernel"
-                                     if os.environ.get("MXG_STAGGER") == "0" else
-                                     "an assembly of 2^31 k-mers or more starts its filter behind the slice kernel of the assembly before it, so "
-                                     "the kernel's time is its own (MXG_STAGGER=0: free-running streams, the step ~2 % shorter, kernel times shared)"),
-                         "min_traffic_bytes_per_base": 0.25 + 0.25 / 32 + 0.125,
-                         "min_traffic_note": "what this formulation must move: 2 bits per base (bit planes) + 1/32 of that (the "
-                                             "strips' predecessors) read, 1 bit per position (the candidate bitmap) written",
-                         "bases_per_launch": int(st["hash_kernel_bases"] / launches),
-                         "share_of_step_time": round(st["ms_hash"] * t_scale / args.steps / ms_step, 4)},
+            "roofline": None,  # (filled below: the dominant kernel of the step)
             "valu": valu_model(st["hash_kernel_bases"] / launches, avg_ms) if bs_route() else None,
             "step_roofline": {"bound": "hbm", "alg_bytes_per_step": int(step_alg_bytes),
                               "formula": "0.25 B x bases + 70 B x minimizers (SURVEY.md 8d)",
@@ -675,6 +705,90 @@ def main():
                           "first_step_of_the_handle": cold,
                           "note": "counted over the timed steps (warm: the candidate counts of the warm-up steps size the grids)"},
         }
+        # ---- the roofline object: the step's dominant kernel, and the two kernels that together turn bases into minimizer tuples
+        filter_obj = {"bound": "hbm",
+                      "kernel": ("k_hash_bs (bit-sliced ntHash top rings + candidate filter, one launch per assembly)" if bs_route()
+                                 else "k_hash_sparse (ntHash fwd/rc rings + candidate filter)"),
+                      "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                      "traffic_commit": tj_commit,
+                      "alg_bytes_per_base": ALG_BYTES_PER_BASE_HASH, "alg_bytes_per_launch": int(bytes_per_launch),
+                      "avg_launch_ms": round(avg_ms, 4), "launches": int(st["launches_hash"]),
+                      "timed": "HIP-event pair around every launch of the kernel inside the timed region, on the launch stream",
+                      "streams": ("free-running (MXG_STAGGER=0): this kernel shares the GPU with the other assembly's slice kernel"
+                                  if os.environ.get("MXG_STAGGER") == "0" else
+                                  "an assembly of 2^31 k-mers or more starts its filter behind the slice kernel of the assembly before it, so "
+                                  "the kernel's time is its own (MXG_STAGGER=0: free-running streams, the step ~2 % shorter, kernel times shared)"),
+                      "min_traffic_bytes_per_base": 0.25 + 0.25 / 32 + 0.125,
+                      "min_traffic_note": "what this formulation must move: 2 bits per base (bit planes) + 1/32 of that (the "
+                                          "strips' predecessors) read, 1 bit per position (the candidate bitmap) written",
+                      "bases_per_launch": int(st["hash_kernel_bases"] / launches),
+                      "share_of_step_time": round(st["ms_hash"] * t_scale / args.steps / ms_step, 4)}
+        roof = filter_obj
+        sel_ran = bs_route() and st.get("select_slices", 0) > 0 and not multi
+        if sel_ran:
+            # k_bs_select: one launch per assembly and step (a span of its own in the timed region); SURVEY.md 8(d) prices what it
+            # produces at the 16-byte tuple per selected minimizer -- bitmap -> candidates -> window decision has no bytes of its own
+            n_asm = len(asms)
+            sel_launches = args.steps * n_asm
+            sel_ms_step = st["ms_reorder"] / args.steps
+            sel_launch_ms = st["ms_reorder"] / max(sel_launches, 1)
+            mx_launch = float(st["minimizers"]) / n_asm
+            sel_bytes = ALG_BYTES_PER_MINIMIZER_TUPLE * mx_launch
+            sel_ach = sel_bytes / (sel_launch_ms * 1e-3) / 1e9 if sel_launch_ms > 0 else 0.0
+            sel_traffic = None
+            try:
+                tj2 = json.load(open(tpath))
+                if tj2.get("workload") == wl and tj2.get("kernel_sources_digest") == kernel_sources_digest():
+                    row = next(r for r in tj2.get("per_kernel", []) if "k_bs_select" in r["kernel"])
+                    sel_traffic = int(row["bytes_per_step"] / row["launches_per_step"])
+            except Exception:
+                sel_traffic = None
+            select_obj = {"bound": "hbm", "kernel": "k_bs_select (the filter's bitmap -> exact hashes -> window decision -> selected minimizers, one launch per assembly)",
+                          "achieved": round(sel_ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sel_ach / HBM_PEAK_GBS, 6),
+                          "traffic": sel_traffic,
+                          "traffic_source": (f"static: profiles/{PROFILE_ROUND}/hbm_traffic.json (counter passes at these kernel sources; the correction "
+                                             "of each counter for this kernel's access patterns: profiles/" + PROFILE_ROUND + "/traffic_calibration.json)")
+                                            if sel_traffic else None,
+                          "alg_bytes_per_minimizer": ALG_BYTES_PER_MINIMIZER_TUPLE, "alg_bytes_per_launch": int(sel_bytes),
+                          "alg_note": "SURVEY.md 8(d) defines bytes for what this kernel produces (the 16-byte minimizer tuple), none for what it "
+                                      "reads (bitmap, packed bases of the candidates): the fraction says how far an instruction-bound kernel is "
+                                      "from the roof of the little it must write; what bounds it is in valu_by_kernel",
+                          "avg_launch_ms": round(sel_launch_ms, 4), "launches": int(sel_launches),
+                          "timed": "HIP-event pair around every launch of the kernel inside the timed region, on the launch stream",
+                          "minimizers_per_launch": int(mx_launch), "slices_per_launch": int(st["select_slices"] / max(sel_launches, 1)),
+                          "share_of_step_time": round(sel_ms_step / ms_step, 4)}
+            # which of the two is the step's largest consumer: the committed rocprofv3 stats of this workload say (total duration)
+            stats, spath = committed_kernel_stats(wl)
+            dom, dom_src = None, None
+            if stats:
+                dom = stats[0][0]
+                tot_ns = sum(r[1] for r in stats)
+                dom_src = (f"{os.path.relpath(spath, REPO)}: " + ", ".join(f"{r[0]} {100 * r[1] / tot_ns:.1f} %" for r in stats[:3]) +
+                           " of the step's kernel time")
+            live_dom = "k_bs_select" if sel_ms_step > st["ms_hash"] * t_scale / args.steps else "k_hash_bs"
+            if dom is None or not (dom.startswith("k_bs_select") or dom.startswith("k_hash_bs")):
+                dom, dom_src = live_dom, "this run's event pairs (no committed rocprofv3 stats of this workload)"
+            roof = dict(select_obj if dom.startswith("k_bs_select") else filter_obj)
+            roof["dominant_by"] = dom_src
+            roof["dominant_in_this_run"] = live_dom
+            pair_bytes = ALG_BYTES_PER_BASE_HASH * bases_total + ALG_BYTES_PER_MINIMIZER_TUPLE * float(st["minimizers"])
+            pair_ms = st["ms_hash"] * t_scale / args.steps + sel_ms_step
+            pair_gbs = pair_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+            roof["sketch_pair"] = {"kernels": "k_hash_bs + k_bs_select", "alg_bytes_per_step": int(pair_bytes),
+                                   "formula": "0.25 B x bases + 16 B x minimizers: together the two kernels do what SURVEY.md 8(d) prices so",
+                                   "ms_per_step": round(pair_ms, 4), "achieved": round(pair_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(pair_gbs / HBM_PEAK_GBS, 6)}
+            roof["other_kernel"] = filter_obj if dom.startswith("k_bs_select") else select_obj
+        out["roofline"] = roof
+        vbk = {}
+        if out.get("valu"):
+            vbk["k_hash_bs"] = out["valu"]
+        if sel_ran:
+            sm = select_valu_model(select_obj["avg_launch_ms"], select_obj["slices_per_launch"])
+            if sm:
+                vbk["k_bs_select"] = sm
+        out["valu_by_kernel"] = vbk or None
         if not multi and not args.no_kernels:
             # per-kernel GPU time: a second handle on the same bases with one event pair per kernel (a few steps)
             eng2 = MxEngine(k=K, w=W, device=local_rank, timing_fine=True, cand_per_window=args.cand)

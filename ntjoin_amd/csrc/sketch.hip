@@ -1801,14 +1801,18 @@ static uint32_t choose_sparse_S(const mxg_handle *h, uint64_t total_kmers)
     const uint64_t e = knob_u64(h, "MXG_SPARSE_S", 0);
     if (e >= 16) return (uint32_t)std::min<uint64_t>(1024, (e + 15) / 16 * 16);
     // the k = 32 route's slice kernel wants w k-mers in a few strips (sketch_bs.h: SEL_MAX_H), whatever the input's size
-    if (h->cfg.k == 32 && h->cfg.variant == MXG_VARIANT_V2_SUM && h->cfg.w > 64 * SEL_MAX_H &&
-        knob_u64(h, "MXG_BS", 1) != 0 && knob_u64(h, "MXG_BS_SELECT", 1) != 0)
-        return 320;
+    const bool sel_route = h->cfg.k == 32 && h->cfg.variant == MXG_VARIANT_V2_SUM && knob_u64(h, "MXG_BS", 1) != 0 &&
+                           knob_u64(h, "MXG_BS_SELECT", 1) != 0;
+    if (sel_route && h->cfg.w > 64 * SEL_MAX_H) return 320;
     const uint64_t lanes = 1024ull * 64;  // SIMDs x lanes
     // small inputs: keep at least ~4 waves per SIMD in flight
     uint64_t S = (total_kmers + lanes * 4 - 1) / (lanes * 4);
     S = (S + 15) / 16 * 16;
-    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(S, 64), 320);
+    S = std::min<uint64_t>(std::max<uint64_t>(S, 64), 320);
+    // the slice kernel's work goes with the candidates of a slice (64 strips x S x c / w): shorter windows, shorter strips.  Measured at
+    // w = 500 on configs[3] (tools/sweep_c3.sh; 12 Gbp, Gbp/s at S = 160 / 192 / 224 / 256 / 320): 1227 / 1313 / 1283 / 1256 / 1290
+    if (sel_route && h->cfg.w >= 400 && S > 192) S = h->cfg.w >= 600 ? 256 : 192;
+    return (uint32_t)S;
 }
 // batch sizes (whole records; a single record may exceed them).  Test knobs (environment, read per call):
 // MXG_DENSE_BATCH_KMERS / MXG_SPARSE_BATCH_KMERS shrink the batches, MXG_WAVE_CAP forces the arena-overflow retry.
@@ -2573,7 +2577,8 @@ struct Driver {
         MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, ctrl_bytes, st));
         // (fine timing: the slice kernel is booked where the other route books count + reorder, the stretch kernels where it books
         // resolve + stretches)
-        if ((rc = ev_begin(0, false, fine ? 2 : 1)) != MXG_OK) return rc;
+        // (the slice kernel has a span of its own in either timing mode: bench.py's roofline object times it inside the timed region)
+        if ((rc = ev_begin(0, false, 2)) != MXG_OK) return rc;
         BsSelParams bp{};
         bp.bm = a->d_bs_out.as<uint32_t>() + 4;  // (BS_OUT_PAD)
         bp.packed = a->d_packed;
@@ -2609,6 +2614,9 @@ struct Driver {
         if (h->ev_sel_done[slot]) MXG_HIP(h, hipEventRecord(h->ev_sel_done[slot], st));  // (the next assembly's filter may start here)
         h->stat_sel_slices += b.n_slices;
         const bool dev = io && io->dev_gaps;
+        if (timing && !fine) {  // the rest of the batch (stretches, emit) as one span
+            if ((rc = ev_end()) != MXG_OK || (rc = ev_begin(0, false, 1)) != MXG_OK) return rc;
+        }
         if ((rc = ev_next(3)) != MXG_OK) return rc;
         if (dev && (rc = enqueue_dev_gaps(a, T, ctrl_host)) != MXG_OK) return rc;
         if ((rc = ev_next(4)) != MXG_OK) return rc;
@@ -2977,7 +2985,10 @@ static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
     sp.dev_gaps = a && a->total_kmers >= big && h->cfg.w <= GAP_DEV_NMAX / 2;
     if (knob_set(h, "MXG_DEV_GAPS")) sp.dev_gaps = knob_u64(h, "MXG_DEV_GAPS", 0) != 0 && h->cfg.w <= GAP_DEV_NMAX / 2;
     // measured on MI355X (3 Gbp + 3 Gbp, w=1000, batches of 512 Mi k-mers): 941 / 985 / 945 / 897 Gbp/s at c = 8 / 10 / 12 / 14
-    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window : (sp.dev_gaps ? (uint32_t)env_u64(h, "MXG_DEV_CAND", 10) : 18u);
+    // (w = 500, configs[3], S = 192: 1256 / 1313 / 1342 / 1259 Gbp/s at c = 9 / 10 / 11 / 12 -- candidates are twice as dense as at
+    // w = 1000, so are the stretches at a given c, and the stretch kernels' share grows: one candidate more per window pays)
+    const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window
+                                              : (sp.dev_gaps ? (uint32_t)env_u64(h, "MXG_DEV_CAND", h->cfg.w < 700 ? 11 : 10) : 18u);
     sp.frac = (double)c / (double)h->cfg.w;
     // even: the threshold then falls on the top 31-bit ring of the hash, which is all the sparse kernel rolls
     sp.tau_hi = std::max(2u, (uint32_t)std::min<double>(4294967294.0, sp.frac * 4294967296.0) & ~1u);

@@ -669,7 +669,8 @@ int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hi
         std::lock_guard<std::mutex> lock(attr_mutex);
         const int dev = h->device;
         if (dev < 0 || dev >= MXG_MAX_DEVICES || !attr_set[dev]) {
-            const void *fns[] = {reinterpret_cast<const void *>(&k_bs_select<12, 10>), reinterpret_cast<const void *>(&k_bs_select<8, 0>),
+            const void *fns[] = {reinterpret_cast<const void *>(&k_bs_select<12, 10>), reinterpret_cast<const void *>(&k_bs_select<8, 6>),
+                                 reinterpret_cast<const void *>(&k_bs_select<8, 0>),
                                  reinterpret_cast<const void *>(&k_bs_select<12, 0>), reinterpret_cast<const void *>(&k_bs_select<16, 0>),
                                  reinterpret_cast<const void *>(&k_bs_select<20, 0>), reinterpret_cast<const void *>(&k_bs_select<36, 0>)};
             for (const void *f : fns) MXG_HIP(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -677,6 +678,7 @@ int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hi
         }
     }
     if (p.S == 320u) hipLaunchKernelGGL((k_bs_select<12, 10>), grid, block, g.lds, st, p);
+    else if (p.S == 192u) hipLaunchKernelGGL((k_bs_select<8, 6>), grid, block, g.lds, st, p);
     else if (nwc <= 8) hipLaunchKernelGGL((k_bs_select<8, 0>), grid, block, g.lds, st, p);
     else if (nwc <= 12) hipLaunchKernelGGL((k_bs_select<12, 0>), grid, block, g.lds, st, p);
     else if (nwc <= 16) hipLaunchKernelGGL((k_bs_select<16, 0>), grid, block, g.lds, st, p);
