@@ -136,6 +136,7 @@ static int new_assembly(mxg_handle *h, const char *name, double weight, Assembly
 
 static int commit(mxg_handle *h, Assembly *a, int rc)
 {
+    if (rc == MXG_OK) rc = upload_packed(h, a);  // (bases parsed on the host: resident in HBM from here on, like the other routes')
     if (rc != MXG_OK) {
         delete a;
         return rc;

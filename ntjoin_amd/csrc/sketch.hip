@@ -1054,7 +1054,10 @@ __global__ __launch_bounds__(256) void k_count_n(const uint8_t *__restrict__ sel
     if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
 }
 
-constexpr uint32_t GAP_DEV_MAX = 4096;  // stretches per batch the device route holds (defined here: k_emit places them)
+constexpr uint32_t GAP_DEV_MAX = 4096;  // stretches per batch the device route holds at least (defined here: k_emit places them);
+// a batch's real capacity (`gcap` below) grows with its assembly up to GAP_DEV_CAP_MAX: repeat-rich genomes hold thirty times the
+// stretches of i.i.d. sequence, and a first sketch -- no density is known yet -- must not run out of room and go round again
+constexpr uint32_t GAP_DEV_CAP_MAX = 65536;
 // Their minimizers wait in one pool per batch, each stretch's in a region of the size it needs (k_gap_fix reserves it with one
 // add to ctrl[14]; r_start[stretch]).  Until round 4 every stretch had a region of 64 entries: a di- or trinucleotide run longer
 // than w reports every second or third k-mer, and each such stretch went to the host and through the dense kernels.  A pool that
@@ -1095,6 +1098,7 @@ struct EmitParams {
     // GAP_DEV_MAX / 4 extra blocks at the end of the grid, one wave per stretch, put the stretches' minimizers between them:
     // stretch r goes to base + (own minimizers before it) + s_off[r].  No staging copy, no merge pass.
     uint32_t dev_gaps;
+    uint32_t gcap, n_place; // stretches the batch's arrays hold; blocks at the front of the grid that place them (four each)
     uint32_t n_tiles;      // tiles of the candidate array = blocks that emit; blocks beyond them place stretches (dev_gaps)
     const uint64_t *s_key; const uint32_t *s_off, *s_src;
     const uint4 *gaps;
@@ -1134,18 +1138,19 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     }
     // stretches sketched on the device: count, their minimizers, "could not be finished here" (the host then redoes the batch)
     // (k_bs_select raises it too: slices beyond their queues / regions, more selected candidates than a slice's room)
-    const uint32_t flag = (p.dev_gaps || p.n_fixed) ? p.ovf[6] : 0u;
-    const uint32_t n_g = p.dev_gaps && !flag && n_g_raw <= GAP_DEV_MAX ? n_g_raw : 0u;
+    // (... and more stretches than this launch has blocks to place them: the grid follows what earlier sketches of the assembly met)
+    const uint32_t flag = ((p.dev_gaps || p.n_fixed) ? p.ovf[6] : 0u) | ((p.dev_gaps && n_g_raw > 4u * p.n_place && n_g_raw <= p.gcap) ? 1u : 0u);
+    const uint32_t n_g = p.dev_gaps && !flag && n_g_raw <= p.gcap ? n_g_raw : 0u;
     const uint32_t nB = n_g ? p.ovf[7] : 0u;
     const uint64_t obase = p.out_base + (p.base_in ? *p.base_in : 0ull), limit = p.out_limit;
-    const uint32_t n_place = p.dev_gaps ? GAP_DEV_MAX / 4u : 0u;  // the grid's FIRST blocks: they start at once
+    const uint32_t n_place = p.dev_gaps ? p.n_place : 0u;  // the grid's FIRST blocks: they start at once
     if (blockIdx.x < n_place) {  // placement of the stretches' minimizers: one wave per stretch
         const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
         if (r >= n_g) return;
         const uint32_t g = p.s_src[r];
         const uint64_t key = p.s_key[r];
         const uint32_t nblk = (n + RKe - 1u) / RKe;
-        const uint32_t b = min(p.gaps[g].w / RKe, nblk - 1u);  // the block of the candidate that reported the stretch
+        const uint32_t b = min((p.gaps[g].w & ~SEL_GAP_DROP) / RKe, nblk - 1u);  // the block of the candidate that reported the stretch
         const uint32_t cb = p.cnt256[b];
         uint32_t below = 0;  // minimizers of block b in front of the stretch
         for (uint32_t e = lane; e < cb; e += 64u) {
@@ -1383,6 +1388,7 @@ struct GapFixParams {
     uint32_t *r_cnt;     // [GAP_DEV_MAX]
     uint32_t *r_start;   // [GAP_DEV_MAX] the stretch's region of the pool
     uint32_t pool;       // entries of the pool (GAP_DEV_POOL; MXG_GAP_POOL: test knob)
+    uint32_t gcap;       // stretches the per-stretch arrays hold
     uint64_t *r_key;     // [GAP_DEV_MAX] contig << 32 | k_lo
     uint4 *defer;        // [GAP_DEFER_MAX] (pinned host memory) stretches left to the host: ctrl[11] of them
     HashTab tab;
@@ -1495,7 +1501,8 @@ __device__ __forceinline__ void gap_fix_one(const GapFixParams &p, const uint32_
         __syncthreads();
     }
     const uint32_t span = 1u << J;
-    const bool drop = klo == 0 && p.ctg_drop && p.ctg_drop[c];
+    // (... or the piece of a long stretch that starts with the last window of the piece before it: sel_push_gap, sketch_bs.hip)
+    const bool drop = (klo == 0 && p.ctg_drop && p.ctg_drop[c]) || (gp.w & SEL_GAP_DROP) != 0;
     for (uint32_t s = threadIdx.x; s + w <= n; s += 256) {
         const uint32_t a = best(lidxc(cur)[s], lidxc(cur)[s + w - span]);
         if (lh[a] != 0xFFFFFFFFFFFFFFFFull) atomicOr(&selbits[a >> 5], 1u << (a & 31u));  // btllib never reports 2^64-1
@@ -1540,7 +1547,7 @@ __global__ __launch_bounds__(256) void k_gap_fix(const GapFixParams p)
     // GAP_FIX_BLOCKS blocks walk the stretches (a block of 51 KB per possible stretch -- 2048, nearly all with nothing to do -- came
     // to the CUs in three rounds: 36 us per launch beside the other stream's kernels)
     const uint32_t n_g = p.ctrl[1];
-    if (blockIdx.x >= n_g || n_g > GAP_DEV_MAX || p.ctrl[0]) return;
+    if (blockIdx.x >= n_g || n_g > p.gcap || p.ctrl[0]) return;
     __shared__ uint64_t lh[GAP_DEV_NSMALL];
     __shared__ uint16_t lidx[2][GAP_DEV_NSMALL];
     __shared__ uint32_t selbits[GAP_DEV_NSMALL / 32];
@@ -1568,6 +1575,7 @@ struct GapPostParams {
     const uint32_t *r_cnt; const uint64_t *r_key;
     // the stretches in (contig, first k-mer) order: key, minimizers in the stretches before it ([n] = all), index of its region
     uint64_t *s_key; uint32_t *s_off, *s_src;
+    uint32_t gcap;   // stretches the arrays hold
 };
 
 // The batch's stretches ranked by (contig, first k-mer): every stretch counts the stretches with a smaller key -- its rank (the
@@ -1577,7 +1585,6 @@ struct GapPostParams {
 // one of its blocks to end).  One block of 256 threads ranking everything took 48 us for 950 stretches (a third of the batch's
 // emit + stretch time at 2 x 10^9 k-mers per batch).
 constexpr uint32_t GPB = 256, GP_PER = 64;
-constexpr uint32_t GAP_POST_BLOCKS = GAP_DEV_MAX / GP_PER;
 __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
 {
     constexpr uint32_t CH = 512;
@@ -1585,10 +1592,10 @@ __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
     __shared__ uint32_t cnts[CH];
     __shared__ uint32_t part_rank[GPB], part_off[GPB];
     const uint32_t n_g = p.ctrl[1];
-    if (n_g == 0 || n_g > GAP_DEV_MAX || p.ctrl[0]) {
+    if (n_g == 0 || n_g > p.gcap || p.ctrl[0]) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             p.ctrl[7] = 0;
-            if (n_g > GAP_DEV_MAX) p.ctrl[6] = 1;
+            if (n_g > p.gcap) p.ctrl[6] = 1;
         }
         return;
     }
@@ -1914,6 +1921,14 @@ struct Driver {
         fine = (h_->cfg.flags & MXG_FLAG_TIMING_FINE) != 0;
     }
     DevBuf &sc(int i) { return h->scratch[slot][i]; }
+    // stretches the device route's per-stretch arrays hold for the batch being enqueued, and the blocks at the front of k_emit's
+    // grid that place them, four stretches each (see gap_capacity)
+    uint32_t gcap = GAP_DEV_MAX, n_place = GAP_DEV_MAX / 4;
+    void set_gaps(uint32_t cap, uint32_t place)
+    {
+        gcap = cap;
+        n_place = place;
+    }
 
     // SC_CTRL holds the control block (16 words) followed by the two super-count arrays of the batch (scan_kernels.h):
     // per hash-kernel wave, then per k_resolve block; ctrl_bytes() of it are zeroed by the batch's one memset
@@ -2111,6 +2126,8 @@ struct Driver {
         ep.base_in = io ? io->base_in : nullptr;
         ep.base_out = io ? io->base_out : nullptr;
         ep.dev_gaps = io && io->dev_gaps ? 1u : 0u;
+        ep.gcap = gcap;
+        ep.n_place = n_place;
         ep.rk = rk;
         ep.n_fixed = n_fixed;
         ep.cand_spread = cand_spread;
@@ -2136,8 +2153,8 @@ struct Driver {
             ep.r_pos = sc(SC_GR_POS).as<uint32_t>();
             ep.r_rec = sc(SC_GR_REC).as<uint32_t>();
             ep.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
-            ep.r_start = ep.r_cnt + GAP_DEV_MAX;
-            grid += GAP_DEV_MAX / 4;
+            ep.r_start = ep.r_cnt + gcap;
+            grid += n_place;
         }
         hipLaunchKernelGGL(k_emit, dim3(grid), dim3(256), 0, st, ep);
         MXG_HIP(h, hipGetLastError());
@@ -2335,11 +2352,11 @@ struct Driver {
         MXG_HIP(h, sc(SC_GR_HASH).ensure((size_t)GAP_DEV_POOL * 8));
         MXG_HIP(h, sc(SC_GR_POS).ensure((size_t)GAP_DEV_POOL * 4));
         MXG_HIP(h, sc(SC_GR_REC).ensure((size_t)GAP_DEV_POOL * 4));
-        MXG_HIP(h, sc(SC_GR_CNT).ensure((size_t)GAP_DEV_MAX * 8));  // counts, then the regions' starts
-        MXG_HIP(h, sc(SC_GR_KEY).ensure((size_t)GAP_DEV_MAX * 8));
-        MXG_HIP(h, sc(SC_GD_HASH).ensure((size_t)(GAP_DEV_MAX + 1) * 8));  // the stretches in order: key,
-        MXG_HIP(h, sc(SC_GD_POS).ensure((size_t)(GAP_DEV_MAX + 1) * 4));   // minimizers before,
-        MXG_HIP(h, sc(SC_GD_REC).ensure((size_t)(GAP_DEV_MAX + 1) * 4));   // region
+        MXG_HIP(h, sc(SC_GR_CNT).ensure((size_t)gcap * 8));  // counts, then the regions' starts
+        MXG_HIP(h, sc(SC_GR_KEY).ensure((size_t)gcap * 8));
+        MXG_HIP(h, sc(SC_GD_HASH).ensure((size_t)(gcap + 1) * 8));  // the stretches in order: key,
+        MXG_HIP(h, sc(SC_GD_POS).ensure((size_t)(gcap + 1) * 4));   // minimizers before,
+        MXG_HIP(h, sc(SC_GD_REC).ensure((size_t)(gcap + 1) * 4));   // region
         GapFixParams gp;
         gp.gaps = sc(SC_GAPS).as<uint4>();
         gp.ctrl = sc(SC_CTRL).as<uint32_t>();
@@ -2356,13 +2373,14 @@ struct Driver {
         gp.r_pos = sc(SC_GR_POS).as<uint32_t>();
         gp.r_rec = sc(SC_GR_REC).as<uint32_t>();
         gp.r_cnt = sc(SC_GR_CNT).as<uint32_t>();
-        gp.r_start = gp.r_cnt + GAP_DEV_MAX;
+        gp.r_start = gp.r_cnt + gcap;
+        gp.gcap = gcap;
         gp.pool = (uint32_t)std::min<uint64_t>(env_u64(h, "MXG_GAP_POOL", GAP_DEV_POOL), GAP_DEV_POOL);
         gp.r_key = sc(SC_GR_KEY).as<uint64_t>();
         // the batch's slice of the pinned list of deferred stretches goes with its pinned control block
         gp.defer = reinterpret_cast<uint4 *>(h->pinned_defer) + (size_t)((ctrl_host - h->pinned_ctrl) / 16) * GAP_DEFER_MAX;
         gp.tab = h->tab;
-        const uint32_t gf_blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64(h, "MXG_GAP_FIX_BLOCKS", GAP_FIX_BLOCKS), 1), GAP_DEV_MAX);
+        const uint32_t gf_blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64(h, "MXG_GAP_FIX_BLOCKS", GAP_FIX_BLOCKS), 1), gcap);
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
             hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V1_MIN>, dim3(gf_blocks), dim3(256), 0, st, gp);
         else
@@ -2374,7 +2392,9 @@ struct Driver {
         pp.s_key = sc(SC_GD_HASH).as<uint64_t>();
         pp.s_off = sc(SC_GD_POS).as<uint32_t>();
         pp.s_src = sc(SC_GD_REC).as<uint32_t>();
-        hipLaunchKernelGGL(k_gap_post, dim3(GAP_POST_BLOCKS), dim3(GPB), 0, st, pp);
+        pp.gcap = gcap;
+        // (blocks beyond the stretches there are leave at once: the grid follows what the launch may meet, like k_emit's placing blocks)
+        hipLaunchKernelGGL(k_gap_post, dim3(std::max(1u, std::min(gcap, 4u * n_place) / GP_PER)), dim3(GPB), 0, st, pp);
         MXG_HIP(h, hipGetLastError());
         return MXG_OK;
     }
@@ -2607,6 +2627,8 @@ struct Driver {
         bp.sup = sel_sup(0);
         bp.gaps = sc(SC_GAPS).as<uint4>();
         bp.gap_cap = GAP_CAP;
+        // (pieces only where the host's route for what k_gap_fix hands over knows them: the tile kernel)
+        bp.gap_nmax = (io && io->dev_gaps && h->cfg.w <= ST_WMAX && !knob_set(h, "MXG_STRETCH_DENSE") && !knob_set(h, "MXG_GAP_WHOLE")) ? GAP_DEV_NMAX : 0u;
         bp.ctrl = sc(SC_CTRL).as<uint32_t>();
         bp.cand_spread = sel_sup(0) + sup_words(b.n_slices);
         bp.ablate = (uint32_t)env_u64(h, "MXG_SEL_ABLATE", 0);  // (profiling only: stop every slice after phase n)
@@ -2692,7 +2714,10 @@ struct Driver {
             const uint32_t n = g.z - g.y + 1u;
             if (n < w) continue;  // (no window inside)
             const uint32_t n_win = n - w + 1u;
-            for (uint32_t t0 = 0; t0 < n_win; t0 += ST_WIN) tiles.push_back(StretchTile{g.x, g.y, t0, std::min(ST_WIN, n_win - t0)});
+            // (a piece of a long stretch whose first window is the piece before's last: its tiles start at the second window, and the
+            // first tile leaves out the arg-min of the window in front of it like every tile behind another)
+            for (uint32_t t0 = (g.w & SEL_GAP_DROP) ? 1u : 0u; t0 < n_win; t0 += ST_WIN)
+                tiles.push_back(StretchTile{g.x, g.y, t0, std::min(ST_WIN, n_win - t0)});
         }
         *n_gap_mx = 0;
         if (tiles.empty()) return MXG_OK;
@@ -2899,6 +2924,20 @@ static int prepare_tables(mxg_handle *h, Assembly *a)
 }
 
 // uploads / tables / output capacity for one assembly; *empty = nothing eligible (the sketch is empty)
+// The packed bases of an assembly that was parsed on the host go to HBM -- when the assembly is added (api.cpp: commit), so that
+// a sketch starts from resident bases whatever route loaded them (the first sketch used to carry this copy: 10 ms per Gbp).
+int upload_packed(mxg_handle *h, Assembly *a)
+{
+    if (a->d_packed || !a->has_bases || a->h_packed.empty()) return MXG_OK;
+    MXG_HIP(h, hipSetDevice(h->device));
+    MXG_HIP(h, a->d_packed_own.ensure(a->h_packed.size() * 4));
+    MXG_HIP(h, hipMemcpyAsync(a->d_packed_own.p, a->h_packed.data(), a->h_packed.size() * 4, hipMemcpyHostToDevice, h->stream));
+    MXG_HIP(h, hipStreamSynchronize(h->stream));
+    a->d_packed = a->d_packed_own.as<uint32_t>();
+    std::vector<uint32_t>().swap(a->h_packed);  // refetched from HBM on demand (mxg_write_tsv without text)
+    return MXG_OK;
+}
+
 static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
 {
     if (!a->has_bases) return set_err(h, MXG_EINVAL, "assembly '%s' has no bases to sketch", a->name.c_str());
@@ -2913,14 +2952,8 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
     a->n_mx = 0;
     *empty = false;
 
-    if (!a->d_packed) {  // bases to HBM
-        MXG_HIP(h, a->d_packed_own.ensure(a->h_packed.size() * 4));
-        MXG_HIP(h, hipMemcpyAsync(a->d_packed_own.p, a->h_packed.data(), a->h_packed.size() * 4,
-                                  hipMemcpyHostToDevice, h->stream));
-        MXG_HIP(h, hipStreamSynchronize(h->stream));
-        a->d_packed = a->d_packed_own.as<uint32_t>();
-        std::vector<uint32_t>().swap(a->h_packed);  // refetched from HBM on demand (mxg_write_tsv without text)
-    }
+    int rc0 = upload_packed(h, a);  // (bases to HBM: the loaders do it when the assembly is added; here for whatever did not)
+    if (rc0 != MXG_OK) return rc0;
     if (a->runs.empty()) {  // nothing eligible: empty sketch
         a->has_sketch = true;
         *empty = true;
@@ -2952,8 +2985,10 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
     T.d_g0 = a->d_g0.as<uint64_t>();
     T.d_ctg_drop = a->any_drop ? a->d_ctg_drop.as<uint8_t>() : nullptr;
     T.recs = &a->recs;
-    // output capacity estimate: density 2/(w+1) per k-mer plus slack; grown on demand
-    uint64_t cap = (uint64_t)(3.0 * (double)a->total_kmers / (double)(w + 1)) + 4096;
+    // output capacity estimate: density 2/(w+1) per k-mer plus slack; grown on demand.  (Two and a half times the i.i.d. density:
+    // low-complexity runs report every second or third k-mer -- bench.py's repeat-rich Gbp holds 3.8 M minimizers where i.i.d.
+    // sequence holds 2.0 M, and a first sketch that outgrew arrays sized for 3.0 M was redone whole: 17 bytes per entry.)
+    uint64_t cap = (uint64_t)(5.0 * (double)a->total_kmers / (double)(w + 1)) + 4096;
     MXG_HIP(h, a->d_hash.ensure(cap * 8));
     MXG_HIP(h, a->d_pos.ensure(cap * 4));
     MXG_HIP(h, a->d_rec.ensure(cap * 4));
@@ -2967,9 +3002,23 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
 // run with c = 10 (about 450 stretches per 10^9 k-mers at w = 1000); small ones keep c = 18, where a stretch (then handled by the
 // host-driven route) turns up once per ~4 x 10^9 k-mers, and save the three extra launches per batch.
 // mxg_config.cand_per_window fixes c; MXG_DEV_GAPS=0|1 forces the route (test / profiling knobs, read per call).
+// Capacity of the device route's per-stretch arrays for a batch of an assembly: a power of two between GAP_DEV_MAX and
+// GAP_DEV_CAP_MAX, thirty times what i.i.d. sequence of the assembly's size holds at ten candidates per window (repeat-rich
+// genomes: satellite arrays, low-complexity runs -- 13 stretches per Mbp on bench.py's repeat-rich workload against 0.45), or two
+// and a half times what earlier sketches of the assembly met.  MXG_GAP_DEV_CAP: test knob.
+static uint32_t gap_capacity(const mxg_handle *h, const Assembly *a)
+{
+    const uint64_t forced = knob_u64(h, "MXG_GAP_DEV_CAP", 0);
+    double want = forced ? (double)forced : std::max(32e-6, 2.5 * (a ? a->gap_rate_hint : 0.0)) * (double)(a ? a->total_kmers : 0);
+    uint32_t cap = GAP_DEV_MAX;
+    while (cap < GAP_DEV_CAP_MAX && (double)cap < want) cap *= 2;
+    return forced ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(forced, 64), GAP_DEV_CAP_MAX) : cap;
+}
+
 struct SparsePlan {
     bool sparse;
     bool dev_gaps;
+    uint32_t gcap;         // device route: stretches a batch's arrays hold (gap_capacity)
     double frac;
     uint32_t tau_hi;
     double gap_rate;       // device route: expected candidate-free stretches per k-mer (prior, or what earlier sketches met)
@@ -2996,11 +3045,12 @@ static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
     sp.batch_kmers = 0;
     sp.gap_kmers = 0;
     sp.gap_rate = 0;
+    sp.gcap = gap_capacity(h, a);
     if (sp.dev_gaps) {  // a candidate is followed by a stretch with probability e^-c
         // (a->gap_rate_hint: what earlier sketches of this assembly met, 25 % on top)
         const double per_kmer = std::max(sp.frac * std::exp(-(double)c), a->gap_rate_hint * 1.25);
         sp.gap_rate = per_kmer;
-        const double lim = (double)env_u64(h, "MXG_GAP_BUDGET", GAP_DEV_MAX / 2) / std::max(per_kmer, 1e-30);  // expected stretches per batch
+        const double lim = (double)env_u64(h, "MXG_GAP_BUDGET", sp.gcap / 2) / std::max(per_kmer, 1e-30);  // expected stretches per batch
         sp.gap_kmers = (uint64_t)std::min<double>(std::max<double>(lim, (double)(1u << 20)), 9e18);
         if (lim < (double)SPARSE_BATCH_KMERS) sp.batch_kmers = std::max<uint64_t>((uint64_t)lim, 1u << 20);
     }
@@ -3217,6 +3267,12 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             memset(it.hc, 0xFF, 64);
             Driver::ChainIO io;
             io.dev_gaps = plans[i].dev_gaps;
+            {   // placing blocks for twice the stretches the plan expects of this batch (+ 256), at most for all the arrays hold; a
+                // batch that meets more than its launch can place reports so and is enqueued again with the density it met
+                const double expect = plans[i].gap_rate * (double)it.g.nk;
+                const uint32_t place4 = (uint32_t)std::min<double>((double)plans[i].gcap, 2.0 * expect + 256.0);
+                drv.set_gaps(plans[i].gcap, list[i]->gap_rate_hint > 0 ? (place4 + 3u) / 4u : plans[i].gcap / 4u);
+            }
             // tiles of 32 slices in k_emit (0.18 against 0.21 ms per step at 3 Gbp + 3 Gbp) unless stretches are so dense that
             // most tiles of that size would hold one (the tile then searches the stretch keys per minimizer: repeat-rich
             // sequence is 2 % slower with 32, 6 % with 64; tools/sweep_emit_ecb.sh)

@@ -15,6 +15,7 @@ constexpr uint32_t BS_CHUNK = 65536;      // base positions per chunk of the bit
 // window decision -> the selected ones, laid out per slice for k_emit (the layout k_resolve writes per block of 256 candidates).
 constexpr uint32_t SEL_PAD = 8;          // sentinel entries on either side of a wave's candidate list (the scans look at eight at a time)
 constexpr uint32_t SEL_REQ = 8;          // stretches per slice whose end lies behind the slice's strips (found by walking on)
+constexpr uint32_t SEL_GAP_DROP = 0x80000000u;  // in a reported stretch's fourth word (the reporting slice's first entry): "leave the first window's arg-min out"
 constexpr uint32_t SEL_MAX_H = 12;       // largest halo (strips) the route takes: 40 own strips per slice
 
 struct BsSelParams {
@@ -43,6 +44,7 @@ struct BsSelParams {
     uint32_t *cnt, *sup;
     uint4 *gaps;
     uint32_t gap_cap;
+    uint32_t gap_nmax;           // k-mers of the longest stretch reported in one piece (0: any); see sel_push_gap
     uint32_t *cand_spread;       // 64 counters, 32 words apart: the slices' own candidates (k_emit adds them up for the report)
     uint32_t *ctrl;              // [1] stretches, [6] "the host must redo this batch"
     uint32_t ablate;             // (profiling builds: every slice stops after phase n; 0 = run)

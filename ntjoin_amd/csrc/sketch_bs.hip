@@ -167,11 +167,23 @@ __device__ __forceinline__ const BsSelParams *sel_rare_params()
     return nullptr;  // (host pass of the compiler: never called)
 #endif
 }
+// A stretch longer than the stretch kernel holds (gap_nmax k-mers) is reported in pieces that overlap by one window: a piece after
+// the first starts with the last window of the piece before it and is marked (SEL_GAP_DROP) to leave that window's arg-min out --
+// the arg-min moves right with the window, so that is the only minimizer the two pieces can share (k_gap_fix's drop_idx; what
+// k_stretch_tiles does between its tiles).  gap_nmax = 0: stretches are reported whole.
 __device__ __forceinline__ void sel_push_gap(const BsSelParams &, uint32_t c, uint32_t lo, uint32_t hi, uint32_t hint)
 {
     const BsSelParams *q = sel_rare_params();
-    const uint32_t idx = atomicAdd(&q->ctrl[1], 1u);
-    if (idx < q->gap_cap) q->gaps[idx] = make_uint4(c, lo, hi, hint);
+    const uint32_t nmax = q->gap_nmax, w = q->w;
+    uint32_t s = lo, flag = 0u;
+    for (;;) {
+        const uint32_t e = nmax && hi - s >= nmax ? s + nmax - 1u : hi;
+        const uint32_t idx = atomicAdd(&q->ctrl[1], 1u);
+        if (idx < q->gap_cap) q->gaps[idx] = make_uint4(c, s, e, hint | flag);
+        if (e == hi) break;
+        s = e - w + 1u;  // (the piece's last window; the next piece's own windows start one k-mer behind it)
+        flag = SEL_GAP_DROP;
+    }
 }
 
 // The whole wave: contig c has no candidate from k-mer k_from up to the end of the strips the slice holds, and goes on behind

@@ -19,7 +19,7 @@ from tests.test_gpu_scale_paths import _check, _records
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUTE_KNOBS = ("MXG_GAP_POOL", "MXG_BS", "MXG_BS_SELECT", "MXG_SEL_QCAP", "MXG_SEL_RK", "MXG_SPARSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S", "MXG_DEV_GAPS")
+ROUTE_KNOBS = ("MXG_GAP_POOL", "MXG_BS", "MXG_BS_SELECT", "MXG_SEL_QCAP", "MXG_SEL_RK", "MXG_GAP_WHOLE", "MXG_GAP_DEV_CAP", "MXG_SPARSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S", "MXG_DEV_GAPS")
 
 
 @pytest.fixture
@@ -151,6 +151,35 @@ def test_low_complexity_stretches_stay_on_the_device(oracle, env):
     recs2 = [("wide_n", rnd(6000) + "AT" * 900 + "N" * 3000 + "AT" * 900 + rnd(9000)), ("plain", rnd(90000))]
     st = _check(oracle, recs2, 32, 1000)
     assert st["deferred_stretches"] > 0
+
+
+def test_long_stretches_are_reported_in_pieces(oracle, env):
+    """candidate-free stretches longer than k_gap_fix's 4096 k-mers (a homopolymer of 90 kb, a satellite-like array, dinucleotide
+    runs, one of them across N): the slice kernel reports them in pieces that overlap by one window, every piece after the first
+    leaving out the arg-min of the window it shares with the piece before it -- nothing goes to the host.  Then with a stretch
+    pool of 300 entries: pieces that find the pool used up are handed over, marked pieces among them (the tile kernel starts those
+    at their second window), same sketch."""
+    rng = random.Random(23)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    unit = rnd(171)
+    recs = [("polyA", rnd(5000) + "A" * 90000 + rnd(2000)), ("sat", rnd(30000) + unit * 300 + rnd(30000)),
+            ("di", rnd(800) + "AC" * 9000 + rnd(7000) + "TG" * 2300 + "N" * 3 + "TG" * 2500 + rnd(900)),
+            ("unit7_whole", ("ACGGTCA" * 6000)[:40000]), ("plain", rnd(120000)), ("polyT_end", rnd(3000) + "T" * 20000)]
+    env["MXG_SPARSE_S"] = "320"
+    env["MXG_DEV_GAPS"] = "1"
+    for w, c in ((1000, 10), (2048, 10), (300, 4), (1000, 2)):
+        st = _check(oracle, recs, 32, w, cand_per_window=c)
+        assert st["select_slices"] > 0 and st["deferred_stretches"] == 0, (w, c, st["deferred_stretches"])
+    env["MXG_GAP_POOL"] = "300"
+    st = _check(oracle, recs, 32, 1000, cand_per_window=10)
+    assert st["deferred_stretches"] > 3
+    env.pop("MXG_GAP_POOL")
+    env["MXG_GAP_WHOLE"] = "1"      # the long ones whole, to the host: rounds 3 and 4
+    st = _check(oracle, recs, 32, 1000, cand_per_window=10)
+    assert st["deferred_stretches"] > 3
+    env.pop("MXG_GAP_WHOLE")
+    env["MXG_GAP_DEV_CAP"] = "64"   # more stretches than the arrays hold: the batch is enqueued again, then redone
+    _check(oracle, recs + [(f"x{i}", rnd(9000)) for i in range(40)], 32, 1000, cand_per_window=2)
 
 
 def test_many_batches_and_overflow_on_the_bs_route(oracle, env):
