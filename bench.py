@@ -410,6 +410,31 @@ def dry_run(args):
     return 0
 
 
+def repeat_rich_side_run(cand):
+    """What random genomes lack, beside the headline: `--workload repeats` (1 Gbp + derived target; repeat families, satellite
+    arrays, low-complexity runs, N gaps) and i.i.d. sequence of the same size, each in a process of its own -- steady state and
+    the first step of the handle, which every CLI run is."""
+    def run(extra):
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-end-to-end", "--no-kernels",
+               "--no-repeats", "--cand", str(cand)] + extra
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            return json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:  # (a side measurement: the headline does not depend on it)
+            return {"error": repr(e)[:200]}
+    rep, iid = run(["--workload", "repeats"]), run(["--workload", "configs2", "--mbp", "1000"])
+    if "error" in rep or "error" in iid:
+        return {"error": rep.get("error") or iid.get("error")}
+    first = rep["fallbacks"]["first_step_of_the_handle"] or {}
+    return {"workload": rep["config"]["workload"], "value": rep["value"], "unit": "Gbp/s", "ms_per_step": rep["ms_per_step"],
+            "iid_same_size_value": iid["value"], "iid_same_size_ms_per_step": iid["ms_per_step"],
+            "slower_than_iid": round(iid["value"] / rep["value"], 3) if rep["value"] else None,
+            "first_step_of_the_handle": first, "first_step_iid_ms": (iid["fallbacks"]["first_step_of_the_handle"] or {}).get("ms"),
+            "per_step": {k_: rep["fallbacks"][k_] for k_ in ("dense_kmers_per_step", "batches_redone_per_step", "assemblies_redone_whole_per_step",
+                                                            "assemblies_enqueued_twice_per_step", "stretches_sketched_apart_per_step")},
+            "what": "bench.py --workload repeats / --workload configs2 --mbp 1000, 10 steps each in processes of their own (never `value`)"}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks here -- one process per GPU, the environment torchrun
     would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT on 127.0.0.1 with a free port) -- hand rank 0's
@@ -469,6 +494,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel breakdown pass")
+    ap.add_argument("--no-repeats", action="store_true", help="skip the repeat-rich side measurement of the default line")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall-time budget of the cpu_baseline sample")
     ap.add_argument("--e2e-mbp", type=float, default=0.0, help="end-to-end sample: Mbp per assembly (0 = the whole workload)")
     ap.add_argument("--cand", type=int, default=0, help="candidates per window for the sparse path (0 = library default)")
@@ -924,6 +950,8 @@ def main():
                     "settle_s_before_each_route": E2E_SETTLE_S}
             finally:
                 shutil.rmtree(td, ignore_errors=True)
+        if not multi and args.workload == "auto" and not args.no_repeats and not args.mbp:
+            out["repeat_rich"] = repeat_rich_side_run(args.cand)
         result_line = json.dumps(out)
     if multi:
         dist.barrier()

@@ -50,6 +50,8 @@ extern "C" {
 #define MXG_FLAG_DROP_SEQ 0x2u    /* do not keep FASTA text on the host (mxg_write_tsv then decodes k-mers from the packed bases: upper-case) */
 #define MXG_FLAG_TIMING 0x4u      /* bracket each kernel family with HIP events (read back through mxg_stats) */
 #define MXG_FLAG_TIMING_FINE 0x8u /* ... one event pair per kernel (profiling; fills the per-kernel fields of mxg_stats) */
+#define MXG_FLAG_ONE_SHOT 0x10u   /* the handle sketches once and writes its outputs once (the CLIs): mxg_write_outputs returns the bases, the
+                                     text and the scratch buffers to the driver as soon as the TSVs are written, beside the .mx.dot writer */
 
 #define MXG_MAX_ASSEMBLIES 32
 

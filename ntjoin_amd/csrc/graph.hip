@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <system_error>
+#include <thread>
 
 #include "mxg_internal.h"
 #include "scan_kernels.h"
@@ -1463,6 +1465,28 @@ int graph_to_host(mxg_handle *h)
     MXG_HIP(h, hipSetDevice(h->device));
     const size_t anv = (size_t)g.n_asm * g.nv;
     int rc;
+    // the host mirrors (a quarter of a gigabyte at 3 Gbp + 3 Gbp) are sized -- zero-filled, i.e. their pages are touched -- by one
+    // thread per array before the copies are issued: one thread doing it in front of each copy took 30 of this function's 47 ms
+    {
+        std::vector<std::thread> th;
+        auto sized = [](auto &v, size_t n) {  // (out of memory in a helper: the copy below sizes the array in this thread and reports)
+            try {
+                v.resize(n);
+            } catch (const std::bad_alloc &) {
+            }
+        };
+        try {
+            th.emplace_back([&] { sized(g.vhash, g.nv); });
+            th.emplace_back([&] { sized(g.vpos, anv); });
+            th.emplace_back([&] { sized(g.vrec, anv); });
+            th.emplace_back([&] { sized(g.eu, g.ne); });
+            th.emplace_back([&] { sized(g.ev, g.ne); });
+            th.emplace_back([&] { sized(g.esup, g.ne); });
+            sized(g.ew, g.ne);
+        } catch (const std::system_error &) {  // (no thread to be had: the copies below size what is left)
+        }
+        for (auto &t : th) t.join();
+    }
     if ((rc = d2h(h, g.vhash, h->g_vhash.p, g.nv)) != MXG_OK) return rc;
     g.vpos.resize(anv);
     g.vrec.resize(anv);

@@ -169,6 +169,10 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
 {
     const uint32_t k = h->cfg.k, w = h->cfg.w;
     n_threads = std::max(1u, std::min(n_threads, 64u));
+    const bool dbg_io = getenv("MXG_DEBUG_IO") != nullptr;  // phase timings on stderr
+    auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tp0 = now_s();
+    double tp_alloc = 0, tp_hdr = 0, tp_up = 0, tp_count = 0, tp_pack = 0;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return set_err(h, MXG_EIO, "cannot open FASTA '%s'", path);
     struct stat sb;
@@ -207,6 +211,7 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
         if (e != hipSuccess) return dev_fallback(e) ? 1 : set_err(h, MXG_EDEVICE, "device allocation failed: %s", hipGetErrorString(e));
     }
     unsigned char *d_text = a->d_text.as<unsigned char>();
+    tp_alloc = now_s() - tp0;
     constexpr uint64_t STAGE = 32ull << 20;
     constexpr int NB = 4;
     // staging resources + the uploader thread: joined and released on every way out of this function (an exception thrown
@@ -323,7 +328,9 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
         if ((e = hipMemcpyAsync(d_items.p, items.data(), n_items * sizeof(IngItem), hipMemcpyHostToDevice, st)) != hipSuccess)
             return set_err(h, MXG_EDEVICE, "upload failed: %s", hipGetErrorString(e));
     }
+    tp_hdr = now_s() - tp0;
     sg.finish();  // the text is in HBM
+    tp_up = now_s() - tp0;
     if (uerr != hipSuccess) return set_err(h, MXG_EDEVICE, "text upload failed: %s", hipGetErrorString(uerr));
     std::vector<uint32_t> cnt(n_items);
     if (n_items) {
@@ -333,6 +340,7 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
         MXG_HIP(h, hipMemcpyAsync(cnt.data(), d_cnt.p, n_items * 4, hipMemcpyDeviceToHost, st));
         MXG_HIP(h, hipStreamSynchronize(st));
     }
+    tp_count = now_s() - tp0;
     // ---- (3) record lengths, packed layout (every record starts at a multiple of 16 bases) ----
     std::vector<uint64_t> pbase(n_items);
     uint64_t cur = 0;
@@ -388,6 +396,7 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
         }
     }
     a->d_packed = a->d_packed_own.as<uint32_t>();
+    tp_pack = now_s() - tp0;
     // ---- the run table: maximal stretches of valid bases holding at least one k-mer ----
     size_t ev_i = 0;
     for (size_t r = 0; r < n_rec; ++r) {
@@ -440,6 +449,10 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
     a->text_on_device = true;
     a->text_bytes = fsz;
     a->ing_item0.assign(rec_item0.begin(), rec_item0.end());
+    if (dbg_io)
+        fprintf(stderr, "[mxg] load_fasta_device %s: %.3f s = open + map + text buffer %.3f, headers + items (beside the upload) until %.3f, "
+                        "upload done at %.3f, base counts at %.3f, packed at %.3f, run table at %.3f (%.2f GB)\n", path, now_s() - tp0,
+                tp_alloc, tp_hdr, tp_up, tp_count, tp_pack, now_s() - tp0, fsz / 1e9);
     if (h->cfg.flags & MXG_FLAG_DROP_SEQ) {  // the caller does not want the text kept: k-mers are then printed from the packed bases
         a->d_text.release();
         a->d_ing_items.release();

@@ -127,6 +127,7 @@ int main(int argc, char **argv)
     cfg.variant = variant;
     cfg.device = device;
     cfg.host_threads = threads;
+    if (!getenv("MXG_KEEP_BUFFERS")) cfg.flags |= MXG_FLAG_ONE_SHOT;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto wall = []() { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); };
     if (getenv("MXG_DEBUG_IO")) fprintf(stderr, "[mxg] main() entered at %.3f (epoch seconds)\n", wall());

@@ -39,7 +39,7 @@ try:
             ph = next((ln.split("mxgraph: ", 1)[1] for ln in pr.stderr.splitlines() if "device + handle" in ln), pr.stderr[-200:])
             print(f"{label}: total {dt:.3f} s | {ph}", flush=True)
             for ln in pr.stderr.splitlines():
-                if ln.startswith("[mxg] write") or ln.startswith("[mxg] statistics"):
+                if ln.startswith("[mxg] write") or ln.startswith("[mxg] statistics") or ln.startswith("[mxg] load_fasta"):
                     print("    " + ln, flush=True)
                 if ln.startswith("[mxg] main() entered"):
                     print(f"    spawn -> main(): {float(ln.split()[4]) - w0:.3f} s", flush=True)
