@@ -134,8 +134,9 @@ def valu_model(bases_per_launch, avg_ms):
                      "static (generated code: ntjoin_amd/csrc/gen/bs_gen.py), the launch time is this run's"}
 
 
-SELECT_ISSUE_CYCLES = 4.0  # what a wave64 VALU instruction of k_bs_select's mix occupies its SIMD for: SQ_ACTIVE_INST_VALU x 4 cycles /
-                           # SQ_INSTS_VALU = 4.00 in every PMC pass of the kernel (compares, shifts, DPP, selects: profiles/ubench/README.md)
+SELECT_ISSUE_CYCLES = 4.0  # what a wave64 VALU instruction of k_bs_select's mix (compares, shifts, selects, DPP, SDWA) occupies its SIMD
+                           # for: the instruction classes measured one at a time in profiles/ubench/README.md -- anything outside the
+                           # filter's full-rate class keeps the stream at ~4 cycles per instruction
 ALG_BYTES_PER_MINIMIZER_TUPLE = 16.0  # the (hash, pos, record) tuple a selected minimizer is written as
 
 
@@ -177,8 +178,9 @@ def select_valu_model(launch_ms, slices_per_launch):
             "valu_issue_bound_ms": round(bound_ms, 4), "avg_launch_ms": round(launch_ms, 4),
             "frac_of_issue_bound": round(bound_ms / launch_ms, 4) if launch_ms > 0 else None,
             "source": f"profiles/{PROFILE_ROUND}/configs2_select_pmc.json (commit {pj.get('commit', '?')})",
+            "gpu_cycles_per_valu_instr_per_simd_in_the_pmc_pass": pj.get("gpu_cycles_per_valu_instr_per_simd"),
             "model": f"VALU instructions per slice x slices / {SIMDS} SIMDs x {SELECT_ISSUE_CYCLES:g} cycles / {CLOCK_HZ / 1e9:g} GHz: the kernel's "
-                     "instruction mix issues at 4 cycles per wave64 instruction (PMC), not at the 2 of the filter's fast-class stream"}
+                     "instruction mix issues at 4 cycles per wave64 instruction (profiles/ubench), not at the 2 of the filter's fast-class stream"}
 
 
 def workload_tables(name, mbp, w, seed=1):

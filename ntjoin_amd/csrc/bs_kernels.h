@@ -14,7 +14,10 @@
 
 #include <cstdint>
 
-#include "hash_bs_k32.inc"
+#ifndef HASH_BS_INC_FILE  // (tools/bs_ablate.sh builds tools/bs_bench.hip against timing variants of the generated code)
+#define HASH_BS_INC_FILE "hash_bs_k32.inc"
+#endif
+#include HASH_BS_INC_FILE
 
 namespace mxg {
 

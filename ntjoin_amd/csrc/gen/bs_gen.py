@@ -191,8 +191,11 @@ SEND = S_HD + 2
 
 
 class Gen:
-    def __init__(self, k=32, b_planes=B_PLANES):
+    def __init__(self, k=32, b_planes=B_PLANES, ablate=()):
+        """ablate (timing experiments only, tools/bs_ablate.sh -- the results are wrong on purpose): 'loads' = no vector loads in the
+        chunk loop (every chunk works on the first one's words) and no waits for them, 'stores' = no result stores"""
         assert k == 32, "strips of 32 k-mers: k = 32 only (other k: k_hash_sparse)"
+        self.ablate = set(ablate)
         self.k = k
         self.b = b_planes
         self.ins = []
@@ -531,17 +534,20 @@ class Gen:
                 A(f"s_cmp_eq_u32 s{S_FIRST}, 1")
                 A("s_cbranch_scc1 L_bs_nostore_%=")
                 for st in self.store_ins:
-                    A(to_asm(st))
+                    if 'stores' not in self.ablate:
+                        A(to_asm(st))
                 A("L_bs_nostore_%=:")
                 A(f"s_mov_b32 s{S_FIRST}, 0")
                 self.out_pointers(L)
+            elif ins[0] in ('gload4', 'gload2', 'waitcnt') and 'loads' in self.ablate:
+                continue
             elif ins[0] != 'comment':
                 for piece in to_asm(ins).split("\n"):
                     A(piece)
         A(f"s_add_u32 s{S_C}, s{S_C}, s{S_STRIDE}")
         A(f"s_cmp_lt_u32 s{S_C}, s{S_N}")
         A("s_cbranch_scc1 L_bs_loop_%=")
-        for st in self.store_ins:  # the last chunk's results
+        for st in self.store_ins:  # the last chunk's results (kept in every ablation: something must depend on the work)
             A(to_asm(st))
         A("s_waitcnt vmcnt(0)")  # (and the requests for a chunk that does not follow)
         A("L_bs_end_%=:")
@@ -688,8 +694,8 @@ def out_position(c, t, lane, s):
     return c * CHUNK + (32 * lane + s - 1) * 32 + t
 
 
-def emit_inc(path, k):
-    g = Gen(k)
+def emit_inc(path, k, ablate=()):
+    g = Gen(k, ablate=ablate)
     lines = g.asm()
     n_valu = sum(1 for i in g.ins if i[0] in ('xor', 'and', 'or', 'mov', 'bitop3', 'add', 'lshr'))
     with open(path, 'w') as fh:
@@ -711,6 +717,7 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('-k', type=int, default=32)
     ap.add_argument('-o', default='hash_bs_k32.inc')
+    ap.add_argument('--ablate', default='', help="comma-separated: loads, stores (timing experiments: tools/bs_ablate.sh)")
     a = ap.parse_args()
-    n, nv = emit_inc(a.o, a.k)
+    n, nv = emit_inc(a.o, a.k, tuple(x for x in a.ablate.split(',') if x))
     print(f"{a.o}: {n} lines, {nv} VALU per chunk", file=sys.stderr)
