@@ -1,0 +1,53 @@
+"""bench.py without a GPU: the launcher of `python bench.py --gpus N` (ranks started, failures reported, no JSON line from a failed
+run) and the helpers that read the committed profiles."""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_own_launcher_reports_a_failed_rank():
+    """no GPU here: every rank ends with "bench.py needs a GPU"; the launcher must come back with a non-zero status, say which
+    rank failed, and print no JSON line"""
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=REPO, env=_clean_env(),
+                         capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():   # (on a GPU box this test has nothing to say: tests/test_gpu_dist2.py runs the launcher for real)
+        return
+    assert out.returncode != 0
+    assert "ended with status" in out.stderr and "needs a GPU" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_rank_count_must_match():
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "1"], cwd=REPO,
+                         env=_clean_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "must agree" in (out.stderr + out.stdout)
+
+
+def test_committed_profiles_are_readable():
+    """what bench.py quotes from profiles/<round>/: the kernel stats name the step's kernels (largest first) and the slice kernel's
+    PMC summary has the fields the valu_by_kernel entry is made of"""
+    sys.path.insert(0, REPO)
+    import bench
+    rows, path = bench.committed_kernel_stats("configs2")
+    if rows is None:   # (no profile of this round committed yet)
+        assert not os.path.exists(path)
+        return
+    names = [r[0] for r in rows]
+    assert any(n.startswith("k_hash_bs") for n in names) and any(n.startswith("k_bs_select") for n in names)
+    assert rows == sorted(rows, key=lambda r: -r[1]) and not any(n.startswith("k_synth") for n in names)
+    sp = os.path.join(REPO, "profiles", bench.PROFILE_ROUND, "configs2_select_pmc.json")
+    if os.path.exists(sp):
+        pj = json.load(open(sp))
+        assert pj["per_slice"]["valu"] > 0 and pj["per_slice"]["salu"] > 0 and pj["slices_per_launch"] > 0
+        m = bench.select_valu_model(0.5, pj["slices_per_launch"])
+        assert m is not None and ("stale" in m or 0 < m["frac_of_issue_bound"] < 1.5)
