@@ -370,7 +370,7 @@ def test_configs3_full_size_target_and_three_references_w500():
         eng.build_graph()
         st = eng.stats()
         assert st["bases"] > 11_900_000_000 and st["minimizers"] > 47_000_000
-        assert st["bs_filter_bases"] == st["bases"]  # the k = 32 route took every assembly
+        assert st["bs_filter_bases"] == st["bases"] or os.environ.get("MXG_BS") == "0"   # (MXG_BS=0: the rolling-hash route is under test at size)  # the k = 32 route took every assembly
         weights = [a[1] for a in asms]
         assert weights == [2.0, 2.0, 2.0, 1.0]
         sks, g = check_graph_against_numpy(eng, weights)
@@ -403,7 +403,7 @@ def test_configs4_full_size_40gbp_on_one_gpu():
         eng.build_graph()
         st = eng.stats()
         assert st["bases"] > 39_000_000_000 and st["kmers"] > (1 << 32) * 9
-        assert st["bs_filter_bases"] == st["bases"]
+        assert st["bs_filter_bases"] == st["bases"] or os.environ.get("MXG_BS") == "0"   # (MXG_BS=0: the rolling-hash route is under test at size)
         assert st["minimizers"] > 78_000_000
         sks, g = check_graph_against_numpy(eng, [a[1] for a in asms])
         assert len(g["vertex_hash"]) > 25_000_000 and len(g["edge_u"]) > 25_000_000
