@@ -2633,7 +2633,9 @@ struct Driver {
         bp.cand_spread = sel_sup(0) + sup_words(b.n_slices);
         bp.ablate = (uint32_t)env_u64(h, "MXG_SEL_ABLATE", 0);  // (profiling only: stop every slice after phase n)
         if ((rc = launch_bs_select(h, bp, b, st)) != MXG_OK) return rc;
-        if (h->ev_sel_done[slot]) MXG_HIP(h, hipEventRecord(h->ev_sel_done[slot], st));  // (the next assembly's filter may start here)
+        // (the next assembly's filter may start here; MXG_STAGGER=2, an experiment: behind this batch's emit instead, below)
+        const bool late = knob_u64(h, "MXG_STAGGER", 1) == 2;
+        if (h->ev_sel_done[slot] && !late) MXG_HIP(h, hipEventRecord(h->ev_sel_done[slot], st));
         h->stat_sel_slices += b.n_slices;
         const bool dev = io && io->dev_gaps;
         if (timing && !fine) {  // the rest of the batch (stretches, emit) as one span
@@ -2646,6 +2648,7 @@ struct Driver {
         rc = emit(a->d_packed, T, (uint32_t)n_ent, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host, io, b.rk,
                   (uint32_t)n_ent, bp.cand_spread);
         if (rc != MXG_OK) return rc;
+        if (h->ev_sel_done[slot] && late) MXG_HIP(h, hipEventRecord(h->ev_sel_done[slot], st));
         return ev_end();
     }
 
