@@ -481,6 +481,11 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     c.lane = lane;
     c.has_drop = p.ctg_drop != nullptr;
     c.nreal = c.own_lo = c.own_hi = 0;
+    // the block's slices are handed out to its waves one by one (a ticket counter in LDS behind the waves' areas): a wave's 41
+    // slices of its own differ by +-4 % in time from wave to wave and the launch waits for the slowest of 4096 (PMC, round 5: a
+    // wave lived 0.82 of the launch on average); the block's 650 slices differ by +-1 % from block to block
+    uint32_t *blk_ticket = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(sel_lds + 2048) + (size_t)nwv * sel_wave_lds(p.qcap));
+    if (threadIdx.x == 0) *blk_ticket = nwv;  // (tickets 0 .. nwv - 1: the waves' first slices)
     if (lane == 0) {
         c.misc[0] = 0;
         c.misc[1] = 0xFFFFFFFFu;  // this wave's region of global memory, once it has needed one (kept in LDS: a loop-carried scalar
@@ -492,20 +497,24 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     const uint32_t stride = gridDim.x * nwv, laneS = lane * S;
     uint32_t own_cands = 0;
     bool flag = false;
-    // (a wave takes every stride-th slice; runs of consecutive slices per wave measured 4 % slower)
-    uint32_t sl = blockIdx.x * nwv + wib;
+    // (ticket t of the block = slice (t / waves) x stride + block x waves + t % waves: the slices a block's waves took in turn when
+    // every wave had every stride-th slice; runs of consecutive slices per wave measured 4 % slower)
+    auto slice_of = [&](uint32_t t) { return (t / nwv) * stride + blockIdx.x * nwv + (t % nwv); };
+    uint32_t sl = slice_of(wib);
     const uint32_t sl_end = p.n_slices;
     // a slice's strips are looked up one slice ahead: the strip -> run table while the slice before is being set up, the run
     // itself while that slice's candidates are being decided (nothing there waits for memory)
     // (strips are counted in 32 bits, bs_select_geom: a first strip "in front of the assembly" wraps to a number no assembly has)
     auto first_strip = [&](uint32_t q) { return (int64_t)(p.strip_lo + q * T) - (int64_t)H; };
     StripRegs sr = sl < sl_end ? load_strip(p, first_strip(sl) + lane) : StripRegs{0, 0, 0xFFFFFFFFu, 0, 0};
-    for (; sl < sl_end; sl += stride) {
+    while (sl < sl_end) {
+        uint32_t tk = 0;
+        if (lane == 0) tk = atomicAdd(blk_ticket, 1u);
+        const uint32_t sl_n = slice_of((uint32_t)__builtin_amdgcn_readfirstlane((int)tk));  // the wave's next slice
         const uint32_t s_own0 = p.strip_lo + sl * T;
         c.sl = sl;
         c.s_first = first_strip(sl);
         c.own_end = H + min(T, p.strip_hi - s_own0);  // lanes [H, own_end) hold the slice's own strips
-        const uint32_t sl_n = sl + stride;
         const uint32_t sn32 = p.strip_lo + sl_n * T - H + lane;
         const bool in_n = sl_n < sl_end && sn32 < p.n_strips_asm;
         const uint32_t s_n = in_n ? sn32 : 0u;
@@ -587,6 +596,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
         own_cands += c.own_hi - c.own_lo;
         __builtin_amdgcn_wave_barrier();  // the next slice reuses the wave's LDS
         sr = strip_from_run(p, in_n, sS_n, run_n);
+        sl = sl_n;
     }
     const uint32_t own_w = own_cands;  // (wave-uniform)
     if (lane == 0) {
@@ -596,7 +606,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     }
 }
 
-size_t bs_select_lds(uint32_t qcap, uint32_t waves) { return (size_t)2048 * 16 + (size_t)waves * sel_wave_lds(qcap); }
+size_t bs_select_lds(uint32_t qcap, uint32_t waves) { return (size_t)2048 * 16 + (size_t)waves * sel_wave_lds(qcap) + 16; }  // (+ the block's ticket counter)
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_bs_select: geometry + launch
