@@ -137,6 +137,38 @@ def test_mxgraph_cli_failures_are_loud(tmp_path):
     assert r.returncode == 2
 
 
+def test_mxgraph_worker_and_parent(tmp_path):
+    """mxgraph does its work in a child and leaves as soon as the child reports its outputs complete (the driver's teardown of the
+    child is nobody's wait): same bytes and the same statuses as in one process (MXG_NO_DETACH=1), output pipes released at once, a
+    worker that dies without a word reported by its status"""
+    import signal
+    import time
+    from tests.conftest import GOLDEN, load_case
+    meta = load_case("f-f_w100_config1")["meta"]
+    fasta_dir = os.path.join(GOLDEN, "fasta")
+    exe = os.path.join(BIN_DIR, "mxgraph")
+    outs = {}
+    for mode, env in (("detached", {}), ("one", {"MXG_NO_DETACH": "1"})):
+        d = tmp_path / mode
+        d.mkdir()
+        fas = []
+        for a in meta["refs"] + [meta["target"]]:
+            shutil.copy(os.path.join(fasta_dir, a["fasta"]), d / a["fasta"])
+            fas.append(a["fasta"])
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "-v", "-k", str(meta["k"]), "-w", str(meta["w"]), "-p", "out", "-s", fas[-1], "-l", str(meta["target"]["weight"]),
+                            "-r", " ".join(str(a["weight"]) for a in meta["refs"])] + fas[:-1], cwd=d, env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "vertices" in r.stderr, r.stderr[-500:]     # (-v statistics arrive before the parent leaves)
+        outs[mode] = {f: (d / f).read_bytes() for f in ["out.mx.dot"] + [a["tsv"] for a in meta["refs"] + [meta["target"]]]}
+        assert time.perf_counter() - t0 < 120
+    assert outs["detached"] == outs["one"]
+    # a worker killed before it reports: the parent returns 128 + signal (MXG_TEST_WORKER_SIGNAL: the worker raises it at its start)
+    r = subprocess.run([exe, "-k", "32", "-w", "10", "-s", "x.fa", "-r", "1", "y.fa"], cwd=tmp_path,
+                       env=dict(os.environ, MXG_TEST_WORKER_SIGNAL=str(int(signal.SIGKILL))), capture_output=True, text=True, timeout=60)
+    assert r.returncode == 128 + int(signal.SIGKILL)
+
+
 def test_python_mirror_functions(tmp_path):
     """read_minimizers / filter_minimizers / build_graph counterparts return what the reference's returned"""
     from ntjoin_amd import ntjoin_utils as nu

@@ -7,6 +7,7 @@ kind=${1:-asan}; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 rt=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.${kind}-x86_64.so)
 [ -f "$root/ntjoin_amd/lib_$kind/libntjoin_mx.so" ] || make -C "$root/ntjoin_amd/csrc" $kind || exit 1
+export MXG_NO_DETACH=1  # (mxgraph in one process: a sanitizer report comes with the real exit of the process that did the work)
 export MXG_LIB_DIR=$root/ntjoin_amd/lib_$kind MXG_BIN_DIR=$root/ntjoin_amd/bin_$kind
 # (tsan: the uninstrumented HIP / HSA runtimes are suppressed, tools/tsan.supp; a race in this library's own code still ends the
 # process that shows it with status 66, which fails the test that started it)
