@@ -179,6 +179,14 @@ def test_bench_named_workloads_scaled_down(world, workload, mbp, graph):
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
                    "--master-port", str(_free_port())] + common
         out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+        if out.returncode != 0 and n > 1:
+            # eight processes opening one GPU right behind a test that held 100 GB of it: the driver is still releasing that memory and a
+            # rank's start-up can outlast the rendezvous (seen once in a full-suite run, never alone) -- once more from a quiet device
+            import time
+            sys.stderr.write("first attempt failed:\n" + out.stderr[-1500:] + "\n")
+            time.sleep(10)
+            cmd[cmd.index("--master-port") + 1] = str(_free_port())
+            out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     many = run(world)
