@@ -436,3 +436,40 @@ def test_configs4_full_size_40gbp_on_one_gpu():
                 kmer = synth.segment_codes((0, src, K, int(seg[3])), cfg["seed"], sub_seed, sub)
                 _, oh, fw, ok = orc.kmer_hashes(synth.to_ascii(kmer), K)
                 assert ok[0] and int(oh[0]) == int(sk["out_hash"][i]) and int(fw[0]) == int(sk["forward"][i])
+
+
+@pytest.mark.parametrize("w", [1000, 500])
+def test_fallback_routes_agree_with_the_default_route_at_1_gbp(w):
+    """the routes that real input can send a batch down -- behind the filter's bitmap the batch kernels instead of the slice kernel
+    (MXG_BS_SELECT=0: second attempts, run tables with short runs), the rolling-hash filter (MXG_BS=0: other k, caller's layouts) --
+    on bench.py's configs[2] workload at 1 Gbp + 1 Gbp: every array of both sketches and the graph's counts equal the default
+    route's, bit for bit.  (The same routes pass the whole config-size suite: profiles/r05/configs_select_off.txt, configs_bs_off.txt.)"""
+    saved = {k_: os.environ.get(k_) for k_ in ("MXG_BS_SELECT", "MXG_BS")}
+    res = {}
+    try:
+        for route, env in (("default", {}), ("batch kernels", {"MXG_BS_SELECT": "0"}), ("rolling hash", {"MXG_BS": "0"})):
+            for k_ in saved:
+                os.environ.pop(k_, None)
+            os.environ.update(env)
+            with MxEngine(k=K, w=w) as eng:
+                _bench_workload(eng, "configs2", 1000.0, w)
+                eng.sketch(-2)
+                eng.build_graph()
+                st = eng.stats()
+                sks = [eng.get_sketch(a) for a in range(2)]
+                res[route] = ([{f: sk[f].copy() for f in ("out_hash", "pos", "record")} for sk in sks], st["vertices"], st["edges"])
+                assert (st["select_slices"] > 0) == (route == "default") and (st["bs_filter_bases"] > 0) == (route != "rolling hash")
+    finally:
+        for k_, v in saved.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
+    ref = res["default"]
+    assert ref[1] > 500_000 and ref[2] > 500_000
+    for route in ("batch kernels", "rolling hash"):
+        got = res[route]
+        assert got[1:] == ref[1:], route
+        for a in range(2):
+            for f in ("out_hash", "pos", "record"):
+                assert np.array_equal(got[0][a][f], ref[0][a][f]), (route, a, f)
