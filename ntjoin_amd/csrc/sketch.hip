@@ -38,6 +38,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <type_traits>
 
 #include "mxg_internal.h"
@@ -2583,6 +2584,7 @@ struct Driver {
                     uint32_t *ctrl_host, const ChainIO *io)
     {
         int rc;
+        if ((rc = flush_emit(nullptr)) != MXG_OK) return rc;  // (this driver's scratch is about to be reused)
         MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
         n_wave_sup = 0;
         const size_t ctrl_bytes = ((size_t)CTRL_WORDS + sup_words(b.n_slices) + 64 * 32) * 4;  // + the candidate counters
@@ -2643,6 +2645,33 @@ struct Driver {
         }
         if ((rc = ev_next(3)) != MXG_OK) return rc;
         if (dev && (rc = enqueue_dev_gaps(a, T, ctrl_host)) != MXG_OK) return rc;
+        if (defer_emit && io && !io->wait && !io->base_in && !io->base_out) {
+            // the emit is held back (flush_emit): the caller enqueues it behind the NEXT assembly's slice kernel -- enqueued here it
+            // would start when that assembly's filter lets go of the GPU and land on its slice kernel, whose blocks need whole CUs
+            // (rocprofv3, round 5: 529 us for the target's launch against 450 for the reference's) -- so that it runs beside that
+            // assembly's stretch kernels instead, which leave the GPU idle
+            if ((rc = ev_end()) != MXG_OK) return rc;
+            const Tables *Tp = &T;
+            DevBuf *oh = out.hash, *op = out.pos, *orc = out.rec, *of = out.fwd;
+            const uint64_t on = out.n;
+            const ChainIO ioc = *io;
+            const uint32_t rk = b.rk, gc = gcap, np = n_place;
+            uint32_t *const no = n_out;
+            const uint32_t *cs = bp.cand_spread;
+            pending_emit = [=](hipEvent_t behind) -> int {
+                int rc2;
+                if (behind) MXG_HIP(h, hipStreamWaitEvent(st, behind, 0));
+                if ((rc2 = ev_begin(0, false, fine ? 4 : 1)) != MXG_OK) return rc2;
+                const uint32_t gc0 = gcap, np0 = n_place;
+                uint32_t *const no0 = n_out;
+                gcap = gc; n_place = np; n_out = no;
+                rc2 = emit(a->d_packed, *Tp, (uint32_t)n_ent, *oh, *op, *orc, *of, on, true, ctrl_host, &ioc, rk, (uint32_t)n_ent, cs);
+                gcap = gc0; n_place = np0; n_out = no0;
+                if (rc2 != MXG_OK) return rc2;
+                return ev_end();
+            };
+            return MXG_OK;
+        }
         if ((rc = ev_next(4)) != MXG_OK) return rc;
         if (io && io->wait) MXG_HIP(h, hipStreamWaitEvent(st, io->wait, 0));
         rc = emit(a->d_packed, T, (uint32_t)n_ent, *out.hash, *out.pos, *out.rec, *out.fwd, out.n, true, ctrl_host, io, b.rk,
@@ -2650,6 +2679,16 @@ struct Driver {
         if (rc != MXG_OK) return rc;
         if (h->ev_sel_done[slot] && late) MXG_HIP(h, hipEventRecord(h->ev_sel_done[slot], st));
         return ev_end();
+    }
+    // the emit enqueue_sel held back, now: behind `behind` (an event of another stream) if given
+    std::function<int(hipEvent_t)> pending_emit;
+    bool defer_emit = false;
+    int flush_emit(hipEvent_t behind)
+    {
+        if (!pending_emit) return MXG_OK;
+        auto f = std::move(pending_emit);
+        pending_emit = nullptr;
+        return f(behind);
     }
 
     // Second half of a sparse batch, after the host has read the control block `ctrl` of a run that did not overflow:
@@ -3157,6 +3196,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
     size_t n_enq = 0, next_slot = 0;
     int last_sel_slot = -1;  // the stream slot the last slice kernel of this call went to
     const bool stagger = knob_u64(h, "MXG_STAGGER", 1) != 0;
+    const bool defer_emits = knob_u64(h, "MXG_DEFER_EMIT", 0) != 0 && knob_u64(h, "MXG_STAGGER", 1) == 1;
     for (int q = 0; q < 4; ++q)
         if (!h->ev_sel_done[q]) MXG_HIP(h, hipEventCreateWithFlags(&h->ev_sel_done[q], hipEventDisableTiming));
     const bool chain_modes = fuse_graph || xp;  // (these two need one batch per assembly)
@@ -3299,7 +3339,11 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 drv.n_out = h->d_nmx.as<uint32_t>() + i;
             }
             if (sel_ok) {
+                drv.defer_emit = defer_emits && !chain_modes && gs.size() == 1 && !one_stream;
                 if ((rc = drv.enqueue_sel(list[i], tabs[i], it.g, bgs[b], plans[i].tau_hi, out, it.hc, &io)) != MXG_OK) return rc;
+                // the emits other drivers hold back (the assembly before this one): behind this slice kernel
+                for (Driver *od : drvs)
+                    if (od != &drv && (rc = od->flush_emit(h->ev_sel_done[sl])) != MXG_OK) return rc;
                 last_sel_slot = (int)sl;
             } else if ((rc = drv.enqueue_sparse(list[i], tabs[i], it.g, drv.default_wave_cap(list[i]->S_sparse, plans[i].frac),
                                                 plans[i].tau_hi, out, it.hc, &it.n_cap, &io, list[i]->cand_hints[b],
@@ -3323,6 +3367,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         if ((rc = enqueue_asm(i, 0)) != MXG_OK) return rc;
         if (state[i] == 1) ++n_enq;
     }
+    for (Driver *od : drvs)  // (the last assembly's emit, held back for an assembly that did not come)
+        if ((rc = od->flush_emit(nullptr)) != MXG_OK) return rc;
     item0[n] = items.size();
     for (size_t i = n; i-- > 0;)
         if (state[i] != 1) item0[i] = item0[i + 1];  // (assemblies without items: empty range)
@@ -3529,6 +3575,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             if (state[i] == 3) again.push_back(i);
         for (size_t i : again)
             if ((rc = enqueue_asm(i, 1)) != MXG_OK) return rc;
+        for (Driver *od : drvs)
+            if ((rc = od->flush_emit(nullptr)) != MXG_OK) return rc;
         if (!again.empty()) {
             MXG_HIP(h, stream_wait(h->stream));
             MXG_HIP(h, stream_wait(h->stream2));
