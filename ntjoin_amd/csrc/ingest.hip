@@ -23,7 +23,6 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
-#include <system_error>
 #include <thread>
 
 #include "mxg_internal.h"
@@ -192,21 +191,10 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
     close(fd);
     if (txt == MAP_FAILED) return 1;
     (void)madvise(const_cast<unsigned char *>(txt), fsz, MADV_SEQUENTIAL);
-    // (the mapping of a 3 GB file takes the kernel 15-20 ms to take down again, page-table entry by entry: a thread of its own does
-    // that while the caller goes on to the next file -- 0.04 s of the one-process route's 0.24 s of loading at 3 Gbp + 3 Gbp)
     struct Unmap {
         const unsigned char *p;
         uint64_t n;
-        ~Unmap()
-        {
-            unsigned char *q = const_cast<unsigned char *>(p);
-            const uint64_t len = n;
-            try {
-                std::thread([q, len]() { munmap(q, len); }).detach();
-            } catch (const std::system_error &) {
-                munmap(q, len);
-            }
-        }
+        ~Unmap() { munmap(const_cast<unsigned char *>(p), n); }
     } unmap{txt, fsz};
     MXG_HIP(h, hipSetDevice(h->device));
 
