@@ -19,6 +19,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <sys/prctl.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 
@@ -225,6 +226,7 @@ int main(int argc, char **argv)
     if (getenv("MXG_NO_DETACH") || pipe(fds) != 0) return run(argc, argv);
     fflush(stdout);
     fflush(stderr);
+    const pid_t parent_pid = getpid();
     const pid_t pid = fork();  // (before anything touches the GPU: a HIP context does not survive a fork)
     if (pid < 0) {
         close(fds[0]);
@@ -232,6 +234,10 @@ int main(int argc, char **argv)
         return run(argc, argv);
     }
     if (pid == 0) {  // the worker
+        // (it lives and dies with the process the user started: a parent that is killed takes it along -- after the parent has left
+        // in the regular way, the signal finds the worker with nothing left to do but hand its memory back)
+        prctl(PR_SET_PDEATHSIG, SIGTERM);
+        if (getppid() != parent_pid) _exit(143);
         close(fds[0]);
         g_done_fd = fds[1];
         if (const char *sig = getenv("MXG_TEST_WORKER_SIGNAL")) raise(atoi(sig));  // (test knob: a worker that dies without a word)
