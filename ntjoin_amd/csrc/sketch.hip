@@ -3196,7 +3196,10 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
     size_t n_enq = 0, next_slot = 0;
     int last_sel_slot = -1;  // the stream slot the last slice kernel of this call went to
     const bool stagger = knob_u64(h, "MXG_STAGGER", 1) != 0;
-    const bool defer_emits = knob_u64(h, "MXG_DEFER_EMIT", 0) != 0 && knob_u64(h, "MXG_STAGGER", 1) == 1;
+    // (an assembly's k_emit behind the NEXT assembly's slice kernel, beside that assembly's stretch kernels: enqueued in its own
+    // place it starts when the next filter lets go of the GPU and lands on the next slice kernel, whose blocks need whole CUs --
+    // 529 us for the target's launch against 450 for the reference's under rocprofv3; MXG_DEFER_EMIT=0: in its own place)
+    const bool defer_emits = knob_u64(h, "MXG_DEFER_EMIT", 1) != 0 && knob_u64(h, "MXG_STAGGER", 1) == 1;
     for (int q = 0; q < 4; ++q)
         if (!h->ev_sel_done[q]) MXG_HIP(h, hipEventCreateWithFlags(&h->ev_sel_done[q], hipEventDisableTiming));
     const bool chain_modes = fuse_graph || xp;  // (these two need one batch per assembly)
