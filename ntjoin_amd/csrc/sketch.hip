@@ -1581,14 +1581,15 @@ struct GapPostParams {
 
 // The batch's stretches ranked by (contig, first k-mer): every stretch counts the stretches with a smaller key -- its rank (the
 // keys are distinct) -- and, in the same pass, the minimizers those hold -- its offset: nothing is scanned, no block waits for
-// another.  A block takes 64 stretches, four threads each (a quarter of the other keys per thread), the other stretches' keys
+// another.  A block takes 16 stretches, sixteen threads each (a sixteenth of the other keys per thread), the other stretches' keys
 // and counts pass through 6 KB of LDS 512 at a time (a block that wants more LDS than k_bs_select leaves free on a CU waits for
 // one of its blocks to end).  One block of 256 threads ranking everything took 48 us for 950 stretches (a third of the batch's
 // emit + stretch time at 2 x 10^9 k-mers per batch).
-constexpr uint32_t GPB = 256, GP_PER = 64;
+constexpr uint32_t GPB = 256, GP_PER = 16, GP_PARTS = GPB / GP_PER;  // (64 stretches x 4 threads until round 5: 30 us for 3000 stretches)
 __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
 {
     constexpr uint32_t CH = 512;
+    static_assert(CH % GP_PARTS == 0, "a chunk of keys is dealt out evenly");
     __shared__ uint64_t keys[CH];
     __shared__ uint32_t cnts[CH];
     __shared__ uint32_t part_rank[GPB], part_off[GPB];
@@ -1601,20 +1602,21 @@ __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
         return;
     }
     if (blockIdx.x * GP_PER >= n_g) return;
-    const uint32_t i = blockIdx.x * GP_PER + (threadIdx.x & (GP_PER - 1u)), quarter = threadIdx.x / GP_PER;
+    const uint32_t i = blockIdx.x * GP_PER + (threadIdx.x & (GP_PER - 1u)), part = threadIdx.x / GP_PER;
     const bool on = i < n_g;
     const uint64_t mine = on ? p.r_key[i] : ~0ull;
     uint32_t rank = 0, off = 0, total = 0;
     for (uint32_t c0 = 0; c0 < n_g; c0 += CH) {
         const uint32_t cn = min(CH, n_g - c0);
         __syncthreads();
-        for (uint32_t q = threadIdx.x; q < cn; q += GPB) {
-            keys[q] = p.r_key[c0 + q];
-            cnts[q] = p.r_cnt[c0 + q];
+        for (uint32_t q = threadIdx.x; q < CH; q += GPB) {  // (beyond the stretches: keys no stretch lies behind)
+            keys[q] = q < cn ? p.r_key[c0 + q] : ~0ull;
+            cnts[q] = q < cn ? p.r_cnt[c0 + q] : 0u;
         }
         __syncthreads();
-        const uint32_t q_lo = cn * quarter / 4u, q_hi = cn * (quarter + 1u) / 4u;
-        for (uint32_t q = q_lo; q < q_hi; ++q) {
+        // a thread's share is strided by the threads of its stretch: the 16 stretches of a part read the same word (one broadcast)
+#pragma unroll 8
+        for (uint32_t q = part; q < CH; q += GP_PARTS) {
             const bool less = keys[q] < mine;
             rank += less ? 1u : 0u;
             off += less ? cnts[q] : 0u;
@@ -1625,12 +1627,17 @@ __global__ __launch_bounds__(GPB) void k_gap_post(const GapPostParams p)
     part_rank[threadIdx.x] = rank;
     part_off[threadIdx.x] = off;
     __syncthreads();
-    if (quarter == 0 && on) {
+    if (part == 0 && on) {
         const uint32_t t = threadIdx.x;
-        const uint32_t r = part_rank[t] + part_rank[t + GP_PER] + part_rank[t + 2u * GP_PER] + part_rank[t + 3u * GP_PER];
+        uint32_t r = 0, o = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < GP_PARTS; ++u) {
+            r += part_rank[t + u * GP_PER];
+            o += part_off[t + u * GP_PER];
+        }
         p.s_key[r] = mine;
         p.s_src[r] = i;
-        p.s_off[r] = part_off[t] + part_off[t + GP_PER] + part_off[t + 2u * GP_PER] + part_off[t + 3u * GP_PER];
+        p.s_off[r] = o;
     }
     if (blockIdx.x == 0) {  // the sum of all counts
         __syncthreads();
