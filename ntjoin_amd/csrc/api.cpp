@@ -4,6 +4,8 @@
 #include <new>
 #include <thread>
 
+#include <sys/mman.h>
+
 #include "mxg_internal.h"
 
 using namespace mxg;
@@ -111,7 +113,9 @@ void mxg_destroy(mxg_handle *h)
         if (e) (void)hipEventDestroy(e);
     if (h->pinned_ctrl) (void)hipHostFree(h->pinned_ctrl);
     if (h->pinned_defer) (void)hipHostFree(h->pinned_defer);
-    if (h->pin_pool) (void)hipHostFree(h->pin_pool);
+    pin_pool_release(h);
+    for (auto &m : h->kept_maps) munmap(m.first, m.second);
+    h->kept_maps.clear();
     if (h->pinned_gctl) (void)hipHostFree(h->pinned_gctl);
     if (h->pinned_dg) (void)hipHostFree(h->pinned_dg);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);

@@ -24,6 +24,83 @@ namespace mxg {
 
 thread_local std::string *tl_err_sink = nullptr;
 
+// ---- the handle's pinned pool (mxg_internal.h) ----
+// MXG_PIN_MALLOC=1: one hipHostMalloc of the whole pool, as up to round 5 (A/B knob; also what happens when registering fails)
+static hipError_t pin_pool_malloc(mxg_handle *h)
+{
+    void *q = nullptr;
+    const hipError_t e = hipHostMalloc(&q, PIN_POOL_BYTES);
+    if (e != hipSuccess) {
+        h->pin_state = 3;
+        h->pin_err = e;
+        return e;
+    }
+    h->pin_pool = q;
+    h->pin_registered = false;
+    h->pin_ready = PIN_PIECES;
+    h->pin_state = 2;
+    return hipSuccess;
+}
+hipError_t pin_pool_start(mxg_handle *h)
+{
+    if (h->pin_state.load() == 3) {  // registering failed: the pieces go back and the pool is taken in one allocation (nobody is
+        pin_pool_release(h);         // using a piece: a failed wait ends the operation that waited)
+        (void)hipGetLastError();
+        return pin_pool_malloc(h);
+    }
+    if (h->pin_state.load() != 0) return hipSuccess;
+    if (getenv("MXG_PIN_MALLOC")) return pin_pool_malloc(h);
+    void *m = mmap(nullptr, PIN_POOL_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return pin_pool_malloc(h);
+    h->pin_pool = m;
+    h->pin_registered = true;
+    h->pin_ready = 0;
+    h->pin_state = 1;
+    try {
+        h->pin_thread = std::thread([h]() {
+            hipError_t e = hipSetDevice(h->device);
+            for (uint32_t b = 0; b < PIN_PIECES && e == hipSuccess; ++b) {
+                e = hipHostRegister(static_cast<char *>(h->pin_pool) + (size_t)b * PIN_PIECE_BYTES, PIN_PIECE_BYTES, hipHostRegisterDefault);
+                if (e == hipSuccess) h->pin_ready.store(b + 1, std::memory_order_release);
+            }
+            h->pin_err = e;
+            h->pin_state.store(e == hipSuccess ? 2 : 3, std::memory_order_release);
+        });
+    } catch (...) {  // no thread to be had
+        munmap(m, PIN_POOL_BYTES);
+        h->pin_pool = nullptr;
+        h->pin_registered = false;
+        h->pin_state = 0;
+        return pin_pool_malloc(h);
+    }
+    return hipSuccess;
+}
+hipError_t pin_pool_wait(mxg_handle *h, uint32_t pieces)
+{
+    pieces = std::min(pieces, PIN_PIECES);
+    while (h->pin_ready.load(std::memory_order_acquire) < pieces && h->pin_state.load(std::memory_order_acquire) == 1)
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    if (h->pin_ready.load(std::memory_order_acquire) >= pieces) return hipSuccess;
+    return h->pin_err != hipSuccess ? h->pin_err : hipErrorUnknown;  // (state 3: the next pin_pool_start allocates in one piece)
+}
+void pin_pool_release(mxg_handle *h)
+{
+    if (h->pin_thread.joinable()) h->pin_thread.join();
+    if (h->pin_pool) {
+        if (h->pin_registered) {
+            for (uint32_t b = 0; b < h->pin_ready.load(); ++b)
+                (void)hipHostUnregister(static_cast<char *>(h->pin_pool) + (size_t)b * PIN_PIECE_BYTES);
+            munmap(h->pin_pool, PIN_POOL_BYTES);
+        } else {
+            (void)hipHostFree(h->pin_pool);
+        }
+    }
+    h->pin_pool = nullptr;
+    h->pin_registered = false;
+    h->pin_ready = 0;
+    h->pin_state = 0;
+}
+
 int set_err(mxg_handle *h, int code, const char *fmt, ...)
 {
     char buf[1024];

@@ -172,7 +172,7 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
     const bool dbg_io = getenv("MXG_DEBUG_IO") != nullptr;  // phase timings on stderr
     auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tp0 = now_s();
-    double tp_alloc = 0, tp_hdr = 0, tp_up = 0, tp_count = 0, tp_pack = 0;
+    double tp_alloc = 0, tp_pool = 0, tp_hdr = 0, tp_up = 0, tp_count = 0, tp_pack = 0;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return set_err(h, MXG_EIO, "cannot open FASTA '%s'", path);
     struct stat sb;
@@ -191,11 +191,24 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
     close(fd);
     if (txt == MAP_FAILED) return 1;
     (void)madvise(const_cast<unsigned char *>(txt), fsz, MADV_SEQUENTIAL);
+    // (taking a 3 GB mapping apart costs ~25 ms: a handle that runs once -- MXG_FLAG_ONE_SHOT, the CLI -- leaves it to
+    // mxg_destroy or, as mxgraph does, to the end of a process nobody waits for)
     struct Unmap {
         const unsigned char *p;
         uint64_t n;
-        ~Unmap() { munmap(const_cast<unsigned char *>(p), n); }
-    } unmap{txt, fsz};
+        mxg_handle *keep;
+        ~Unmap()
+        {
+            if (keep) {
+                try {
+                    keep->kept_maps.emplace_back(const_cast<unsigned char *>(p), (size_t)n);
+                    return;
+                } catch (...) {
+                }
+            }
+            munmap(const_cast<unsigned char *>(p), n);
+        }
+    } unmap{txt, fsz, (h->cfg.flags & MXG_FLAG_ONE_SHOT) && !getenv("MXG_UNMAP_EARLY") ? h : nullptr};
     MXG_HIP(h, hipSetDevice(h->device));
 
     // ---- (2) raw text -> HBM through pinned staging buffers, started first so that it overlaps the header scan ----
@@ -239,9 +252,14 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
     hipStream_t cs = sg.cs;
     static_assert(NB * STAGE <= PIN_POOL_BYTES, "staging buffers come out of the handle's pinned pool");
     {
-        unsigned char *pool = nullptr;
-        const hipError_t e = pin_pool_get(h, &pool);
+        // (the pool is pinned piece by piece by a thread of the handle; a staging buffer = a piece: the upload starts with the first)
+        static_assert(STAGE == PIN_PIECE_BYTES && NB <= (int)PIN_PIECES, "a staging buffer is one piece of the pinned pool");
+        hipError_t e = pin_pool_start(h);
+        if (e == hipSuccess) e = pin_pool_wait(h, 1);
+        if (e != hipSuccess && (e = pin_pool_start(h)) == hipSuccess) e = pin_pool_wait(h, 1);  // (registering failed: one allocation)
         if (e != hipSuccess) return dev_fallback(e) ? 1 : set_err(h, MXG_EDEVICE, "pinned allocation failed: %s", hipGetErrorString(e));
+        unsigned char *pool = static_cast<unsigned char *>(h->pin_pool);
+        tp_pool = now_s() - tp0;
         for (int b = 0; b < NB; ++b) {
             stage[b] = pool + (size_t)b * STAGE;
             MXG_HIP(h, hipEventCreateWithFlags(&sev[b], hipEventDisableTiming));
@@ -252,10 +270,16 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
         (void)hipSetDevice(h->device);
         const uint32_t T = std::max(1u, n_threads - 1u);
         uint64_t c = 0;
+        uint32_t ring = NB;  // staging buffers in use: all of them, unless pinning stopped part of the way (then what is pinned: >= 1)
+        bool used[NB] = {false, false, false, false};
         for (uint64_t off = 0; off < fsz && uerr == hipSuccess; off += STAGE, ++c) {
-            const int b = (int)(c % NB);
+            if (c < ring && pin_pool_wait(h, (uint32_t)c + 1u) != hipSuccess)  // (its piece of the pool may still be on its way)
+                ring = std::max(1u, std::min((uint32_t)c, h->pin_ready.load()));
+            const int b = (int)(c % ring);
+            if (used[b]) uerr = hipEventSynchronize(sev[b]);
+            used[b] = true;
+            if (uerr != hipSuccess) break;
             const uint64_t n = std::min(STAGE, fsz - off);
-            if (c >= NB) uerr = hipEventSynchronize(sev[b]);
             try {
                 parallel_for(T, [&](uint32_t t) {
                     const uint64_t lo = n * t / T, hi = n * (t + 1) / T;
@@ -450,9 +474,9 @@ int load_fasta_device(mxg_handle *h, Assembly *a, const char *path, uint32_t n_t
     a->text_bytes = fsz;
     a->ing_item0.assign(rec_item0.begin(), rec_item0.end());
     if (dbg_io)
-        fprintf(stderr, "[mxg] load_fasta_device %s: %.3f s = open + map + text buffer %.3f, headers + items (beside the upload) until %.3f, "
-                        "upload done at %.3f, base counts at %.3f, packed at %.3f, run table at %.3f (%.2f GB)\n", path, now_s() - tp0,
-                tp_alloc, tp_hdr, tp_up, tp_count, tp_pack, now_s() - tp0, fsz / 1e9);
+        fprintf(stderr, "[mxg] load_fasta_device %s: %.3f s = open + map + text buffer %.3f, first pinned buffer at %.3f, headers + items (beside the "
+                        "upload) until %.3f, upload done at %.3f, base counts at %.3f, packed at %.3f, run table at %.3f (%.2f GB)\n", path, now_s() - tp0,
+                tp_alloc, tp_pool, tp_hdr, tp_up, tp_count, tp_pack, now_s() - tp0, fsz / 1e9);
     if (h->cfg.flags & MXG_FLAG_DROP_SEQ) {  // the caller does not want the text kept: k-mers are then printed from the packed bases
         a->d_text.release();
         a->d_ing_items.release();
@@ -800,7 +824,7 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
     char **pin = out.pin;
     hipEvent_t *ev = out.ev;
     bool ok = true;
-    static_assert(2 * WIN <= PIN_POOL_BYTES, "the windows come out of the handle's pinned pool");
+    static_assert(2 * WIN <= PIN_POOL_BYTES && WIN % PIN_PIECE_BYTES == 0, "the windows come out of the handle's pinned pool, whole pieces each");
     {
         unsigned char *pool = nullptr;
         MXG_HIP(h, pin_pool_get(h, &pool));
@@ -819,7 +843,10 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
         if (n) hipLaunchKernelGGL(k_tsv_entries, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, p);
         if (n_rec) hipLaunchKernelGGL(k_tsv_ids, dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, st, p);
         MXG_HIP(h, hipGetLastError());
-        MXG_HIP(h, hipMemcpyAsync(pin[b], h->tsv_win[b].p, p.win_hi - p.win_lo, hipMemcpyDeviceToHost, st));
+        // (the pool is pinned in pieces, each registered with HIP on its own: no copy may reach across two of them)
+        for (uint64_t done = 0, n = p.win_hi - p.win_lo; done < n; done += PIN_PIECE_BYTES)
+            MXG_HIP(h, hipMemcpyAsync(pin[b] + done, h->tsv_win[b].as<char>() + done, std::min<uint64_t>(PIN_PIECE_BYTES, n - done),
+                                      hipMemcpyDeviceToHost, st));
         MXG_HIP(h, hipEventRecord(ev[b], st));
         return MXG_OK;
     };

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdint>
@@ -11,6 +12,8 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "ntjoin_mx.h"
@@ -269,6 +272,14 @@ struct mxg_handle {
     // and the TSV writer's device windows: allocated on first use, kept until mxg_destroy -- a pinned allocation of this size
     // costs 25-55 ms, and the one-process route (mxgraph) would pay it four times
     void *pin_pool = nullptr;
+    // ... and pinning is what costs: the pool is ordinary memory that a thread of the handle registers with HIP in four pieces of
+    // 32 MB (pin_pool_start), so the first file's upload starts when the first staging buffer is pinned (~7 ms), not the last (~29 ms)
+    std::thread pin_thread;
+    std::atomic<uint32_t> pin_ready{0};   // pieces registered so far
+    std::atomic<int> pin_state{0};        // 0 no pool, 1 the thread is at work, 2 done, 3 failed (pin_err)
+    hipError_t pin_err = hipSuccess;
+    bool pin_registered = false;          // the pool is mmap'ed memory registered piece by piece (else: hipHostMalloc)
+    std::vector<std::pair<void *, size_t>> kept_maps;  // MXG_FLAG_ONE_SHOT: file mappings left for mxg_destroy / the process's end
     mxg::DevBuf tsv_win[2];
 };
 
@@ -282,15 +293,18 @@ const char *knob_raw(const mxg_handle *h, const char *name);  // the text it was
 // a helper thread of the library points this at a string of its own: set_err then leaves the handle's message alone (host_io.cpp)
 extern thread_local std::string *tl_err_sink;
 constexpr size_t PIN_POOL_BYTES = 128ull << 20;
-inline hipError_t pin_pool_get(mxg_handle *h, unsigned char **p)
+constexpr size_t PIN_PIECE_BYTES = 32ull << 20;
+constexpr uint32_t PIN_PIECES = (uint32_t)(PIN_POOL_BYTES / PIN_PIECE_BYTES);
+// host_io.cpp: starts the pool (no-op when there is one); waits until `pieces` pieces from the pool's start are pinned
+hipError_t pin_pool_start(mxg_handle *h);
+hipError_t pin_pool_wait(mxg_handle *h, uint32_t pieces);
+void pin_pool_release(mxg_handle *h);
+inline hipError_t pin_pool_get(mxg_handle *h, unsigned char **p)  // the whole pool
 {
-    if (!h->pin_pool) {
-        const hipError_t e = hipHostMalloc(&h->pin_pool, PIN_POOL_BYTES);
-        if (e != hipSuccess) {
-            h->pin_pool = nullptr;
-            return e;
-        }
-    }
+    hipError_t e = pin_pool_start(h);
+    if (e == hipSuccess) e = pin_pool_wait(h, PIN_PIECES);
+    if (e != hipSuccess && (e = pin_pool_start(h)) == hipSuccess) e = pin_pool_wait(h, PIN_PIECES);  // (once more, in one allocation)
+    if (e != hipSuccess) return e;
     *p = static_cast<unsigned char *>(h->pin_pool);
     return hipSuccess;
 }
