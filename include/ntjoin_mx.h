@@ -51,7 +51,9 @@ extern "C" {
 #define MXG_FLAG_TIMING 0x4u      /* bracket each kernel family with HIP events (read back through mxg_stats) */
 #define MXG_FLAG_TIMING_FINE 0x8u /* ... one event pair per kernel (profiling; fills the per-kernel fields of mxg_stats) */
 #define MXG_FLAG_ONE_SHOT 0x10u   /* the handle sketches once and writes its outputs once (the CLIs): mxg_write_outputs returns the bases, the
-                                     text and the scratch buffers to the driver as soon as the TSVs are written, beside the .mx.dot writer */
+                                     text and the scratch buffers to the driver as soon as the TSVs are written, beside the .mx.dot writer;
+                                     mxg_add_assembly_fasta leaves the file's mapping in place until mxg_destroy (or the process's end:
+                                     taking 3 GB of page table apart costs ~25 ms per file) */
 
 #define MXG_MAX_ASSEMBLIES 32
 
