@@ -57,7 +57,8 @@ hipError_t pin_pool_start(mxg_handle *h)
     h->pin_ready = 0;
     h->pin_state = 1;
     try {
-        h->pin_thread = std::thread([h]() {
+        // (detached: a one-shot process ends without joining anybody; pin_pool_release waits for pin_state to leave 1)
+        std::thread([h]() {
             hipError_t e = hipSetDevice(h->device);
             for (uint32_t b = 0; b < PIN_PIECES && e == hipSuccess; ++b) {
                 e = hipHostRegister(static_cast<char *>(h->pin_pool) + (size_t)b * PIN_PIECE_BYTES, PIN_PIECE_BYTES, hipHostRegisterDefault);
@@ -65,7 +66,7 @@ hipError_t pin_pool_start(mxg_handle *h)
             }
             h->pin_err = e;
             h->pin_state.store(e == hipSuccess ? 2 : 3, std::memory_order_release);
-        });
+        }).detach();
     } catch (...) {  // no thread to be had
         munmap(m, PIN_POOL_BYTES);
         h->pin_pool = nullptr;
@@ -85,7 +86,7 @@ hipError_t pin_pool_wait(mxg_handle *h, uint32_t pieces)
 }
 void pin_pool_release(mxg_handle *h)
 {
-    if (h->pin_thread.joinable()) h->pin_thread.join();
+    while (h->pin_state.load(std::memory_order_acquire) == 1) std::this_thread::sleep_for(std::chrono::microseconds(100));
     if (h->pin_pool) {
         if (h->pin_registered) {
             for (uint32_t b = 0; b < h->pin_ready.load(); ++b)

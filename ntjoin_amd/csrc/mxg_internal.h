@@ -272,9 +272,8 @@ struct mxg_handle {
     // and the TSV writer's device windows: allocated on first use, kept until mxg_destroy -- a pinned allocation of this size
     // costs 25-55 ms, and the one-process route (mxgraph) would pay it four times
     void *pin_pool = nullptr;
-    // ... and pinning is what costs: the pool is ordinary memory that a thread of the handle registers with HIP in four pieces of
+    // ... and pinning is what costs: the pool is ordinary memory that a (detached) thread of the handle registers with HIP in four pieces of
     // 32 MB (pin_pool_start), so the first file's upload starts when the first staging buffer is pinned (~7 ms), not the last (~29 ms)
-    std::thread pin_thread;
     std::atomic<uint32_t> pin_ready{0};   // pieces registered so far
     std::atomic<int> pin_state{0};        // 0 no pool, 1 the thread is at work, 2 done, 3 failed (pin_err)
     hipError_t pin_err = hipSuccess;
