@@ -124,6 +124,38 @@ def test_one_process_route_is_byte_identical_to_the_two_process_route(tmp_path, 
     assert os.path.getsize(outs["True"] / "out.mx.dot") > 100
 
 
+def test_mxgraph_file_route_knobs_give_the_same_bytes(tmp_path):
+    """the one-process route's file handling, old and new: the pinned pool registered in pieces (default) or taken in one
+    allocation (MXG_PIN_MALLOC=1), the FASTA mappings left to the end of the process (default for the one-shot handle) or taken
+    apart at once (MXG_UNMAP_EARLY=1), buffers kept (MXG_KEEP_BUFFERS=1), a clean exit through mxg_destroy (MXG_CLEAN_EXIT=1):
+    the same TSVs and the same .mx.dot; a file of several staging buffers (> 4 x 32 MB) goes through the ring of pieces"""
+    import numpy as np
+    rng = np.random.default_rng(17)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    fa_r, fa_t = tmp_path / "r.fa", tmp_path / "t.fa"
+    with open(fa_r, "wb") as fr, open(fa_t, "wb") as ft:
+        for i in range(70):   # 70 x 2.3 Mbp = 163 MB of text: five staging buffers and a bit
+            seq = lut[rng.integers(0, 4, size=2_300_000, dtype=np.uint8)]
+            lines = np.full((23_000, 101), ord("\n"), dtype=np.uint8)
+            lines[:, :100] = seq.reshape(23_000, 100)
+            fr.write(f">chr{i}\n".encode() + lines.tobytes())
+            if i % 2 == 0:   # the target: a few contigs of every other record
+                for c in range(3):
+                    ft.write(f">ctg{i}_{c}\n".encode() + seq[c * 700_000:c * 700_000 + 650_000].tobytes() + b"\n")
+    exe = os.path.join(BIN_DIR, "mxgraph")
+    outs = {}
+    for tag, env in (("default", {}), ("malloc", {"MXG_PIN_MALLOC": "1"}), ("unmap", {"MXG_UNMAP_EARLY": "1"}),
+                     ("keep", {"MXG_KEEP_BUFFERS": "1"}), ("clean", {"MXG_CLEAN_EXIT": "1", "MXG_NO_DETACH": "1"})):
+        subprocess.run([exe, "-k32", "-w1000", "-t4", "-p", str(tmp_path / tag), "-s", str(fa_t), "-r", "2", str(fa_r)], check=True,
+                       env=dict(os.environ, **env))
+        outs[tag] = tuple(open(f, "rb").read() for f in (str(tmp_path / tag) + ".mx.dot", str(fa_r) + ".k32.w1000.tsv", str(fa_t) + ".k32.w1000.tsv"))
+        os.remove(str(fa_r) + ".k32.w1000.tsv")
+        os.remove(str(fa_t) + ".k32.w1000.tsv")
+    assert len(outs["default"][0]) > 10_000 and len(outs["default"][1]) > 1_000_000
+    for tag in outs:
+        assert outs[tag] == outs["default"], tag
+
+
 def test_mxgraph_cli_failures_are_loud(tmp_path):
     exe = os.path.join(BIN_DIR, "mxgraph")
     fa = tmp_path / "a.fa"
