@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void k_dg_pack_msg_slots(const uint32_t *__res
 }
 
 __global__ __launch_bounds__(256) void k_apply_msg_slots(const unsigned char *__restrict__ recv, uint32_t world, uint32_t M,
-                                                         uint32_t nvs, uint32_t *nxt, uint32_t *prv, uint32_t *ovf)
+                                                         uint32_t nvs, uint32_t *adj, uint32_t *ovf)
 {
     const uint64_t o = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (o >= (uint64_t)world * M) return;
@@ -738,8 +738,7 @@ __global__ __launch_bounds__(256) void k_apply_msg_slots(const unsigned char *__
     if (raw > M && idx == 0) *ovf = 1;
     if (idx >= min(raw, (unsigned long long)M)) return;
     const uint4 m = reinterpret_cast<const uint4 *>(recv + (size_t)src * stride + 64)[idx];
-    uint32_t *dst = (m.x >> 8) ? prv : nxt;
-    dst[(size_t)(m.x & 255u) * nvs + m.y] = m.z;
+    adj[((size_t)(m.x & 255u) * nvs + m.y) * 2u + ((m.x >> 8) ? 1u : 0u)] = m.z;  // (graph.hip: adj[a][u] = {successor, predecessor})
 }
 
 // sender: assembly a's minimizers into the slots of d_send (headers zeroed by the caller)
@@ -884,7 +883,7 @@ int dg_edges_slots(mxg_handle *h, const void *d_recv, uint32_t world, uint32_t M
         if (tot)
             hipLaunchKernelGGL(k_apply_msg_slots, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, h->stream,
                                static_cast<const unsigned char *>(d_recv), world, M, (uint32_t)nvs, h->g_nxt.as<uint32_t>(),
-                               h->g_nxt.as<uint32_t>() + anv, ovf);
+                               ovf);
         MXG_HIP(h, hipGetLastError());
     }
     int rc = build_graph(h, GRAPH_DG_EDGES_APPLIED);

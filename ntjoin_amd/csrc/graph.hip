@@ -8,8 +8,8 @@
 // a `seen` and a `dup` bit per assembly.  A hash survives iff seen == all assemblies and dup == 0, i.e. it
 // occurs exactly once in every assembly.  Survivors get dense vertex ids (rank in the first assembly's
 // order).  Because each survivor occurs once per assembly, a vertex has at most one successor and one
-// predecessor per assembly: adjacency is two dense arrays nxt[a][v], prv[a][v]; the support mask of edge
-// {u,v} is read off those arrays and the edge is emitted once, by the first assembly (reference order:
+// predecessor per assembly: adjacency is one dense array adj[a][v] = {successor, predecessor}; the support mask of edge
+// {u,v} is read off that array and the edge is emitted once, by the first assembly (reference order:
 // refs in CLI order, then target) that contains it, in that assembly's first-seen orientation --
 // the same (s,t) the reference's `edges[s][t]` dictionary keeps (bin/ntjoin_utils.py:101-108).
 #include <algorithm>
@@ -757,17 +757,11 @@ __global__ __launch_bounds__(PJ_BT) void k_pj2_bucket(const AsmSet p, const uint
 }
 
 // k_flags for the partitioned join: the table state of minimizer i sits in recs[slot[a][i]]
-// (also clears this item's cells of the adjacency arrays nxt[A][nvs] | prv[A][nvs]: saves the fill launch)
 // mask0[w]: which of minimizers 64 w .. 64 w + 63 of assembly 0 are shared (k_vertices_pj ranks by it)
-__global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, uint32_t *cnt, uint32_t *sup, uint32_t *nxt, uint32_t nvs,
-                                                  uint64_t *mask0)
+__global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, uint32_t *cnt, uint32_t *sup, uint64_t *mask0)
 {
     const uint32_t a = asm_of_block(p, blockIdx.x);
     const uint32_t i = (blockIdx.x - p.bstart[a]) * 256u + threadIdx.x;
-    if (i < nvs) {
-        nxt[(size_t)a * nvs + i] = NONE32;
-        nxt[(size_t)(p.n_asm + a) * nvs + i] = NONE32;
-    }
     bool sh = false;
     {
         // the verdict k_pj_join left here (k_vertices_pj reads the word's upper part) -- or a reference to the minimizer that
@@ -933,28 +927,28 @@ __global__ __launch_bounds__(256) void k_vertices_pj(const VertexPjParams p)
     p.frec[o + r] = rec;
 }
 
-// blockIdx.y = assembly; all arrays are [A][stride]
+// blockIdx.y = assembly; all arrays are [A][stride].  adj[a][u] = {successor, predecessor} of vertex u in assembly a's filtered
+// order (NONE32: none) -- one 8-byte entry, so that the kernels that ask "is v next to u in assembly b" touch one sector per
+// (b, u), not two.  Every vertex occurs exactly once in every assembly's filtered list (a shared minimizer is unique in each
+// assembly), so the thread of position r writes the whole entry of its vertex: nothing has to be cleared beforehand.
 __global__ __launch_bounds__(256) void k_adjacency(const uint32_t *__restrict__ fv0, const uint32_t *__restrict__ frec0,
-                                                   const uint64_t *__restrict__ nv_ptr, uint32_t *__restrict__ nxt0,
-                                                   uint32_t *__restrict__ prv0, uint32_t stride)
+                                                   const uint64_t *__restrict__ nv_ptr, uint2 *__restrict__ adj0, uint32_t stride)
 {
     const uint32_t nv = (uint32_t)*nv_ptr;  // number of shared minimizers, still in HBM (no host sync before this stage)
     const size_t o = (size_t)blockIdx.y * stride;
     const uint32_t *fv = fv0 + o, *frec = frec0 + o;
-    uint32_t *nxt = nxt0 + o, *prv = prv0 + o;
-    uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r + 1 >= nv) return;
-    if (frec[r] == frec[r + 1]) {  // consecutive surviving minimizers of the same contig (ntjoin_utils.py:98-99)
-        uint32_t u = fv[r], v = fv[r + 1];
-        nxt[u] = v;
-        prv[v] = u;
-    }
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= nv) return;
+    const uint32_t rec = frec[r];
+    // consecutive surviving minimizers of the same contig (ntjoin_utils.py:98-99)
+    const uint32_t nx = (r + 1 < nv && frec[r + 1] == rec) ? fv[r + 1] : NONE32;
+    const uint32_t pv = (r > 0 && frec[r - 1] == rec) ? fv[r - 1] : NONE32;
+    adj0[o + fv[r]] = make_uint2(nx, pv);
 }
 
 struct EdgeParams {
     const uint32_t *fv;   // [A][nv]   (nv = stride = upper bound of the vertex count; the count itself is *nv_ptr)
-    const uint32_t *nxt;  // [A][nv]
-    const uint32_t *prv;  // [A][nv]
+    const uint2 *adj;     // [A][nv]: {successor, predecessor} (k_adjacency)
     const uint64_t *nv_ptr;
     uint32_t nv, n_asm;
     uint8_t *eflag;       // [A*nv]
@@ -971,13 +965,15 @@ __device__ __forceinline__ uint32_t edge_mask(const EdgeParams &p, uint32_t u, u
 {
     uint32_t m = 0;
     for (uint32_t b = 0; b < p.n_asm; ++b) {
-        size_t o = (size_t)b * p.nv + u;
-        if (p.nxt[o] == v || p.prv[o] == v) m |= 1u << b;
+        const uint2 q = p.adj[(size_t)b * p.nv + u];
+        if (q.x == v || q.y == v) m |= 1u << b;
     }
     return m;
 }
 
 // item = a*nv + r : the pair (filtered[a][r], filtered[a][r+1]); flagged iff assembly a is the first supporter
+// (up to eight assemblies the flag byte IS the edge's support mask: k_edges then has nothing to look up again -- 2 A random
+// reads per edge less)
 __global__ __launch_bounds__(256) void k_edge_flags(const EdgeParams p)
 {
     uint64_t item = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -987,10 +983,10 @@ __global__ __launch_bounds__(256) void k_edge_flags(const EdgeParams p)
         uint32_t r = (uint32_t)(item % p.nv);
         if (r < (uint32_t)*p.nv_ptr) {  // (beyond it: not a vertex)
             uint32_t u = p.fv[(size_t)a * p.nv + r];
-            uint32_t v = p.nxt[(size_t)a * p.nv + u];
+            uint32_t v = p.adj[(size_t)a * p.nv + u].x;
             if (v != NONE32) {
                 uint32_t m = edge_mask(p, u, v);
-                f = ((uint32_t)__builtin_ctz(m) == a) ? 1 : 0;
+                f = ((uint32_t)__builtin_ctz(m) == a) ? (p.n_asm <= 8u ? (uint8_t)m : (uint8_t)1) : (uint8_t)0;
             }
         }
         p.eflag[item] = f;
@@ -1003,7 +999,8 @@ __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_it
 {
     __shared__ uint32_t sh[256];
     const uint32_t item = blockIdx.x * 256u + threadIdx.x;  // (one per thread: see k_vertices)
-    const bool f = item < n_items && p.eflag[item];
+    const uint32_t fb = item < n_items ? p.eflag[item] : 0u;
+    const bool f = fb != 0;
     // (the edge itself first: its chain of loads -- vertex, successor, the other assemblies' adjacency -- does not need the edge's
     // place, and the block's prefix below is two dependent round trips every thread would otherwise wait for before starting)
     uint32_t u = 0, v = 0, m = 0;
@@ -1011,8 +1008,8 @@ __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_it
     if (f) {
         const uint32_t a = item / p.nv, r = item % p.nv;
         u = p.fv[(size_t)a * p.nv + r];
-        v = p.nxt[(size_t)a * p.nv + u];
-        m = edge_mask(p, u, v);
+        v = p.adj[(size_t)a * p.nv + u].x;
+        m = p.n_asm <= 8u ? fb : edge_mask(p, u, v);
         // python: sum(weights[f] for f in support) -- int 0 start, then float adds in support (= assembly) order
         for (uint32_t b = 0; b < p.n_asm; ++b)
             if (m & (1u << b)) wsum = wsum + p.weights[b];
@@ -1040,15 +1037,13 @@ __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_it
 }
 
 // distributed graph, owner side (dgraph.hip): adjacency arrives as messages {kind << 8 | assembly, local vertex, other
-// vertex (global id), 0}: kind 0 sets nxt[a][local], kind 1 sets prv[a][local]
-__global__ __launch_bounds__(256) void k_apply_msgs(const uint4 *__restrict__ msgs, uint64_t n, uint32_t stride, uint32_t *nxt,
-                                                    uint32_t *prv)
+// vertex (global id), 0}: kind 0 sets the successor, kind 1 the predecessor of adj[a][local] (the array was filled with NONE32)
+__global__ __launch_bounds__(256) void k_apply_msgs(const uint4 *__restrict__ msgs, uint64_t n, uint32_t stride, uint32_t *adj)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint4 m = msgs[i];
-    uint32_t *dst = (m.x >> 8) ? prv : nxt;
-    dst[(size_t)(m.x & 255u) * stride + m.y] = m.z;
+    adj[((size_t)(m.x & 255u) * stride + m.y) * 2u + ((m.x >> 8) ? 1u : 0u)] = m.z;
 }
 
 __global__ __launch_bounds__(256) void k_iota_rows(uint32_t *a, uint32_t stride)  // a[row][i] = i
@@ -1272,9 +1267,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         else
             hipLaunchKernelGGL(k_pj_join<false>, dim3(P1 * P), dim3(256), 0, h->stream, recs2, M, P, 0u, hctl + CTL_PJ_FAIL, pj_force_fail,
                                cursor, cap1, rows2, as_all);
-        MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4 + 16));  // nxt[A][nvs] followed by prv[A][nvs], cleared by k_flags_pj
-        hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, cnt, fsup, h->g_nxt.as<uint32_t>(), (uint32_t)nvs,
-                           pj_mask0);
+        hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, cnt, fsup, pj_mask0);
     } else if (nb && !resume && pj) {
         const uint32_t n_rows = (nb + PJ_IPB / 256 - 1) / (PJ_IPB / 256);  // bucketing blocks = record regions = rows of M
         MXG_HIP(h, h->g_part.ensure((size_t)n_rows * (P + 1) * 4));
@@ -1289,9 +1282,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         else
             hipLaunchKernelGGL(k_pj_join<false>, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, hctl + CTL_PJ_FAIL, pj_force_fail, nullptr,
                                0u, 0u, as_all);
-        MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4 + 16));  // nxt[A][nvs] followed by prv[A][nvs], cleared by k_flags_pj
-        hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, cnt, fsup, h->g_nxt.as<uint32_t>(), (uint32_t)nvs,
-                           pj_mask0);
+        hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, cnt, fsup, pj_mask0);
     } else if (nb && !resume) {
         hipLaunchKernelGGL(k_insert, dim3(nb), dim3(256), 0, h->stream, as_all, h->g_keys.as<Slot>(), mask, cap, fsup,
                            n_fsup + n_esup);
@@ -1306,9 +1297,8 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         MXG_HIP(h, h->g_vrec.ensure(anv * 4));
         MXG_HIP(h, h->g_fv.ensure(anv * 4));
         MXG_HIP(h, h->g_frec.ensure(anv * 4));
-        MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4));  // nxt[A][nvs] followed by prv[A][nvs]: one fill
-        if ((mode == GRAPH_FULL && !pj) || mode == GRAPH_DG_EDGES) MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));
-        uint32_t *const d_prv = h->g_nxt.as<uint32_t>() + anv;
+        MXG_HIP(h, h->g_nxt.ensure(2 * anv * 4));  // adj[A][nvs] = {successor, predecessor}: k_adjacency writes every entry that is read;
+        if (mode == GRAPH_DG_EDGES) MXG_HIP(h, hipMemsetAsync(h->g_nxt.p, 0xFF, 2 * anv * 4, h->stream));  // messages set single words
         if (pj && nb && !resume) {
             VertexPjParams vp;
             vp.as = as_all;
@@ -1367,11 +1357,11 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         }
         if (mode == GRAPH_FULL) {
             hipLaunchKernelGGL(k_adjacency, dim3((uint32_t)((nvs + 255) / 256), A), dim3(256), 0, h->stream,
-                               h->g_fv.as<uint32_t>(), h->g_frec.as<uint32_t>(), ctl, h->g_nxt.as<uint32_t>(), d_prv, (uint32_t)nvs);
+                               h->g_fv.as<uint32_t>(), h->g_frec.as<uint32_t>(), ctl, h->g_nxt.as<uint2>(), (uint32_t)nvs);
         } else {  // second half on the owner: every local vertex is an item (fv = identity), adjacency from messages
             if (n_msgs && mode == GRAPH_DG_EDGES)
                 hipLaunchKernelGGL(k_apply_msgs, dim3((uint32_t)((n_msgs + 255) / 256)), dim3(256), 0, h->stream,
-                                   static_cast<const uint4 *>(d_msgs), n_msgs, (uint32_t)nvs, h->g_nxt.as<uint32_t>(), d_prv);
+                                   static_cast<const uint4 *>(d_msgs), n_msgs, (uint32_t)nvs, h->g_nxt.as<uint32_t>());
             hipLaunchKernelGGL(k_iota_rows, dim3((uint32_t)((nvs + 255) / 256), A), dim3(256), 0, h->stream,
                                h->g_fv.as<uint32_t>(), (uint32_t)nvs);
         }
@@ -1386,8 +1376,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         MXG_HIP(h, h->g_ew.ensure((size_t)n_items * 8));
         EdgeParams ep;
         ep.fv = h->g_fv.as<uint32_t>();
-        ep.nxt = h->g_nxt.as<uint32_t>();
-        ep.prv = d_prv;
+        ep.adj = h->g_nxt.as<uint2>();
         ep.nv_ptr = ctl;
         ep.nv = (uint32_t)nvs;
         ep.n_asm = A;
