@@ -130,6 +130,7 @@ struct Assembly {
     std::vector<uint32_t> strip0_dense, strip0_sparse;  // [n_runs+1] exclusive prefix of strips per run
     std::vector<uint64_t> g0;                           // [n_runs+1] exclusive prefix of k-mers per run
     DevBuf d_runs, d_strip0_dense, d_strip0_sparse, d_g0, d_ctg_nk, d_ctg_rec, d_ctg_run0, d_ctg_drop;
+    DevBuf d_ctg_info;  // uint4 per contig {first run, runs, first run's pos0, record}: what k_emit needs of a contig in one read
     DevBuf d_strip_run;  // strip of the sparse strip table -> its run (k_strip_runs)
     DevBuf d_runx;       // RunX per run
     // k = 32 route (sketch_bs.hip): the bases transposed for the bit-sliced ring filter, its result, chunk -> first run

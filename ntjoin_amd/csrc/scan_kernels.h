@@ -159,7 +159,15 @@ __device__ __forceinline__ uint32_t count_prefix(const uint32_t *__restrict__ cn
     const uint32_t v0 = b0 < q ? cnt[b0] : 0u, v1 = b0 + 64u < q ? cnt[b0 + 64u] : 0u;
     const uint32_t v2 = b0 + 128u < q ? cnt[b0 + 128u] : 0u, v3 = b0 + 192u < q ? cnt[b0 + 192u] : 0u;
     uint32_t acc = s0 + v0 + v1 + v2 + v3;
-    for (uint32_t i = lane + 64u; i < ns; i += 64) acc += sup[i * SUP_STRIDE];  // > 16384 producer blocks only
+    // > 16384 producer blocks only (the slices of a 3 Gbp assembly: up to 650 super-counts): four loads issued together per
+    // round -- one after the other they were up to ten dependent round trips in front of everything a block of k_emit does
+    for (uint32_t i = lane + 64u; i < ns; i += 256u) {
+        const uint32_t t0 = sup[i * SUP_STRIDE];
+        const uint32_t t1 = i + 64u < ns ? sup[(i + 64u) * SUP_STRIDE] : 0u;
+        const uint32_t t2 = i + 128u < ns ? sup[(i + 128u) * SUP_STRIDE] : 0u;
+        const uint32_t t3 = i + 192u < ns ? sup[(i + 192u) * SUP_STRIDE] : 0u;
+        acc += (t0 + t1) + (t2 + t3);
+    }
     return wave_sum_u32(acc);
 }
 

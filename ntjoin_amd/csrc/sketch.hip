@@ -1083,6 +1083,8 @@ struct EmitParams {
                            // no copy on the stream, the host reads it after the stream has drained
     const Run *runs;
     const uint32_t *ctg_run0, *ctg_rec;
+    const uint4 *ctg_info; // {first run, runs, first run's pos0, record} per contig, or null (virtual contigs): ctg_run0 -> runs -> ctg_rec
+                           // are three dependent round trips per minimizer; a contig of one run (no N inside) needs only this entry
     uint64_t mult;         // 1 ^ (k * MULTISEED)
     uint64_t out_base;     // where this batch starts in the output arrays
     uint64_t out_limit;    // capacity of the output arrays (entries at or beyond it are dropped: speculative emit)
@@ -1181,6 +1183,18 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     const uint32_t tile = blockIdx.x - n_place;
     const uint32_t span = p.cs_h ? ECB * RKe : (uint32_t)TILE;
     if ((uint64_t)tile * span >= n) return;  // whole tile beyond the candidates
+    // (the stretch keys this block will search in are requested before anything else: they go to LDS further down, and their round
+    // trip passes under those of the block's offset)
+    constexpr uint32_t EK = 2048;
+    uint64_t kreg[EK / 256];
+    const bool keys_in_lds = n_g && n_g <= EK;
+    if (keys_in_lds) {
+#pragma unroll
+        for (uint32_t u = 0; u < EK / 256; ++u) {
+            const uint32_t q = threadIdx.x + u * 256u;
+            kreg[u] = q < n_g ? p.s_key[q] : 0ull;
+        }
+    }
     uint32_t base = tile * TILE + threadIdx.x * TILE_PER_THREAD;
     const uint32_t fl = p.cs_h ? 0u : load_flags4(p.sel, base, n);
     uint32_t c = count_flags4(fl);
@@ -1267,12 +1281,15 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
     // A few hundred stretches among a million minimizers: almost every tile lies between two neighbouring stretches, so the
     // tile's first and last key are searched once and only a tile that straddles a stretch searches per minimizer.
     // (up to EK stretch keys are copied to LDS in one round trip: the searches then do not walk through L2)
-    constexpr uint32_t EK = 2048;
     __shared__ uint64_t skeys[EK];
     __shared__ uint32_t lb_edge[2];
     const uint64_t *keys = p.s_key;
-    if (n_g && n_g <= EK) {
-        for (uint32_t q = threadIdx.x; q < n_g; q += 256u) skeys[q] = p.s_key[q];
+    if (keys_in_lds) {
+#pragma unroll
+        for (uint32_t u = 0; u < EK / 256; ++u) {
+            const uint32_t q = threadIdx.x + u * 256u;
+            if (q < n_g) skeys[q] = kreg[u];
+        }
         keys = skeys;
         __syncthreads();
     }
@@ -1295,14 +1312,26 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
         }
         if (o >= limit) continue;  // (speculative emit into arrays sized by an estimate)
         // contig-local valid-k-mer index -> base position, through the contig's run table
-        uint32_t lo = p.ctg_run0[ctg], hi = p.ctg_run0[ctg + 1];
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (p.runs[mid].kidx0 <= kx) lo = mid; else hi = mid;
+        uint32_t lo, hi, pos0, kidx0 = 0u, rec;
+        if (p.ctg_info) {
+            const uint4 ci = p.ctg_info[ctg];
+            lo = ci.x; hi = ci.x + ci.y; pos0 = ci.z; rec = ci.w;
+        } else {
+            lo = p.ctg_run0[ctg]; hi = p.ctg_run0[ctg + 1];
+            rec = p.ctg_rec[ctg];
+            pos0 = 0u;
+        }
+        if (hi - lo > 1 || !p.ctg_info) {
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (p.runs[mid].kidx0 <= kx) lo = mid; else hi = mid;
+            }
+            pos0 = p.runs[lo].pos0;
+            kidx0 = p.runs[lo].kidx0;
         }
         p.o_hash[o] = ext_hash(hsh, p.mult);  // (the strand byte is filled lazily by k_strand, only when somebody asks for it)
-        p.o_pos[o] = p.runs[lo].pos0 + (kx - p.runs[lo].kidx0);
-        p.o_rec[o] = p.ctg_rec[ctg];
+        p.o_pos[o] = pos0 + (kx - kidx0);
+        p.o_rec[o] = rec;
     }
 }
 
@@ -1875,6 +1904,7 @@ struct Tables {
     const std::vector<uint64_t> *g0;
     const Run *d_runs;
     const uint32_t *d_strip0_dense, *d_strip0_sparse, *d_ctg_nk, *d_ctg_rec, *d_ctg_run0;
+    const uint4 *d_ctg_info = nullptr;      // EmitParams::ctg_info, or null (virtual contigs)
     const uint32_t *d_strip_run = nullptr;  // strip (sparse table) -> run, or null (virtual contigs)
     const uint64_t *d_g0;
     const uint8_t *d_ctg_drop = nullptr;  // split load: contigs whose first minimizer is not reported (k_resolve), else null
@@ -2119,6 +2149,7 @@ struct Driver {
         ep.runs = T.d_runs;
         ep.ctg_run0 = T.d_ctg_run0;
         ep.ctg_rec = T.d_ctg_rec;
+        ep.ctg_info = T.d_ctg_info;
         ep.mult = 1ull ^ ((uint64_t)h->cfg.k * 0x90b45d39fb6da1faull);
         (void)d_packed;
         ep.out_base = out_base;
@@ -2953,6 +2984,14 @@ static int prepare_tables(mxg_handle *h, Assembly *a)
     if ((rc = upload(h, a->d_ctg_nk, a->ctg_nk)) != MXG_OK) return rc;
     if ((rc = upload(h, a->d_ctg_rec, a->ctg_rec)) != MXG_OK) return rc;
     if ((rc = upload(h, a->d_ctg_run0, a->ctg_run0)) != MXG_OK) return rc;
+    {
+        std::vector<uint4> ci(a->ctg_rec.size());
+        for (size_t c = 0; c < ci.size(); ++c) {
+            const uint32_t r0 = a->ctg_run0[c], r1 = a->ctg_run0[c + 1];
+            ci[c] = make_uint4(r0, r1 - r0, r1 > r0 ? a->runs[r0].pos0 : 0u, a->ctg_rec[c]);
+        }
+        if ((rc = upload(h, a->d_ctg_info, ci)) != MXG_OK) return rc;
+    }
     if (a->any_drop && (rc = upload(h, a->d_ctg_drop, a->ctg_drop)) != MXG_OK) return rc;
     if (n_runs) {
         std::vector<RunX> rx(n_runs);
@@ -3031,6 +3070,7 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
     T.d_ctg_nk = a->d_ctg_nk.as<uint32_t>();
     T.d_ctg_rec = a->d_ctg_rec.as<uint32_t>();
     T.d_ctg_run0 = a->d_ctg_run0.as<uint32_t>();
+    T.d_ctg_info = a->d_ctg_info.as<uint4>();
     T.d_g0 = a->d_g0.as<uint64_t>();
     T.d_ctg_drop = a->any_drop ? a->d_ctg_drop.as<uint8_t>() : nullptr;
     T.recs = &a->recs;
