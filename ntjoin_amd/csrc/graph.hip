@@ -767,11 +767,14 @@ __global__ __launch_bounds__(256) void k_flags_pj(const AsmSet p, uint32_t *cnt,
         // the verdict k_pj_join left here (k_vertices_pj reads the word's upper part) -- or a reference to the minimizer that
         // went on for this one (k_pj2_bucket); a follower (pj_run_role) has neither: its leader, the last lane in front of it
         // that is no follower, says whether the key is in every assembly
+        // (the verdict word is requested beside the follower bits, not behind them: a follower's word -- never written, whatever
+        // the buffer held -- is read and dropped)
         const bool in = i < asm_n(p, a);
         const uint32_t lane = threadIdx.x & 63u;
         const uint64_t fb = p.fol[blockIdx.x * 4u + (threadIdx.x >> 6)];
+        const uint32_t v_raw = in ? p.slot[a][i] : 0u;
         const bool isf = (fb >> lane) & 1ull;
-        uint32_t v = in && !isf ? p.slot[a][i] : 0u;
+        uint32_t v = isf ? 0u : v_raw;
         bool other = isf;
         if ((v & 7u) == PJ_VERDICT_REF) {
             v = p.slot[a][v >> 3];
@@ -889,22 +892,22 @@ __global__ __launch_bounds__(256) void k_vertices_pj(const VertexPjParams p)
     const uint32_t a = asm_of_block(p.as, blockIdx.x);
     const uint32_t blk = blockIdx.x - p.as.bstart[a], nblk = p.as.bstart[a + 1] - p.as.bstart[a];
     const uint32_t i = blk * 256u + threadIdx.x;
-    const bool f = i < asm_n(p.as, a) && p.as.shared[a][i];
     // (what the minimizer brings along first: its loads -- for a > 0 the chain verdict word -> mask words -> vertex id -- do not
-    // need its rank, and the block's prefix below is two dependent round trips every thread would otherwise wait for first)
-    uint32_t v0 = 0, rec = 0, pos = 0;
-    uint64_t hsh = 0;
-    if (f) {
-        if (a) {
-            const uint32_t i0 = p.as.slot[a][i] >> 3, w = i0 >> 6;  // (the verdict word: flags in its three low bits)
-            const uint64_t *m = p.mask0 + (w & ~3u);
-            v0 = p.bpref0[i0 >> 8] + (uint32_t)__popcll(p.mask0[w] & ((1ull << (i0 & 63u)) - 1ull));
-            for (uint32_t q = 0; q < (w & 3u); ++q) v0 += (uint32_t)__popcll(m[q]);
-        } else {
-            hsh = p.as.hash[0][i];
-        }
-        rec = p.rec[a][i];
-        pos = p.pos[a][i];
+    // need its rank, and the block's prefix below is two dependent round trips every thread would otherwise wait for first.
+    // The shared flag, the verdict word, record, position and hash are requested together, whether the minimizer is shared or
+    // not (three in four are): one round trip where the flag came first and the rest behind it.)
+    const bool in = i < asm_n(p.as, a);
+    const uint8_t shf = in ? p.as.shared[a][i] : (uint8_t)0;
+    const uint32_t vw = in && a ? p.as.slot[a][i] : 0u;  // (the verdict word: flags in its three low bits)
+    const uint32_t rec = in ? p.rec[a][i] : 0u, pos = in ? p.pos[a][i] : 0u;
+    const uint64_t hsh = in && !a ? p.as.hash[0][i] : 0ull;
+    const bool f = shf != 0;
+    uint32_t v0 = 0;
+    if (f && a) {
+        const uint32_t i0 = vw >> 3, w = i0 >> 6;
+        const uint64_t *m = p.mask0 + (w & ~3u);
+        v0 = p.bpref0[i0 >> 8] + (uint32_t)__popcll(p.mask0[w] & ((1ull << (i0 & 63u)) - 1ull));
+        for (uint32_t q = 0; q < (w & 3u); ++q) v0 += (uint32_t)__popcll(m[q]);
     }
     if (threadIdx.x < 64) {
         const uint32_t *cnt = p.cnt + p.as.bstart[a], *sup = p.sup + sup_start(p.as, a);
@@ -982,12 +985,23 @@ __global__ __launch_bounds__(256) void k_edge_flags(const EdgeParams p)
         uint32_t a = (uint32_t)(item / p.nv);
         uint32_t r = (uint32_t)(item % p.nv);
         if (r < (uint32_t)*p.nv_ptr) {  // (beyond it: not a vertex)
-            uint32_t u = p.fv[(size_t)a * p.nv + r];
-            uint32_t v = p.adj[(size_t)a * p.nv + u].x;
-            if (v != NONE32) {
-                uint32_t m = edge_mask(p, u, v);
-                f = ((uint32_t)__builtin_ctz(m) == a) ? (p.n_asm <= 8u ? (uint8_t)m : (uint8_t)1) : (uint8_t)0;
+            const uint32_t u = p.fv[item];
+            // (up to four assemblies: their entries of u are requested together with this assembly's own -- the successor is
+            // then one of them -- instead of behind it)
+            uint32_t v, m = 0;
+            if (p.n_asm <= 4u) {
+                uint2 q[4];
+#pragma unroll
+                for (uint32_t b = 0; b < 4u; ++b) q[b] = b < p.n_asm ? p.adj[(size_t)b * p.nv + u] : make_uint2(NONE32, NONE32);
+                v = a == 0 ? q[0].x : a == 1 ? q[1].x : a == 2 ? q[2].x : q[3].x;
+#pragma unroll
+                for (uint32_t b = 0; b < 4u; ++b)
+                    if (b < p.n_asm && (q[b].x == v || q[b].y == v)) m |= 1u << b;
+            } else {
+                v = p.adj[(size_t)a * p.nv + u].x;
+                if (v != NONE32) m = edge_mask(p, u, v);
             }
+            if (v != NONE32) f = ((uint32_t)__builtin_ctz(m) == a) ? (p.n_asm <= 8u ? (uint8_t)m : (uint8_t)1) : (uint8_t)0;
         }
         p.eflag[item] = f;
     }
@@ -1006,8 +1020,8 @@ __global__ __launch_bounds__(256) void k_edges(const EdgeParams p, uint32_t n_it
     uint32_t u = 0, v = 0, m = 0;
     double wsum = 0.0;
     if (f) {
-        const uint32_t a = item / p.nv, r = item % p.nv;
-        u = p.fv[(size_t)a * p.nv + r];
+        const uint32_t a = item / p.nv;
+        u = p.fv[item];  // (fv is [A][nv] like the items; behind the flag: with many assemblies few items are edges)
         v = p.adj[(size_t)a * p.nv + u].x;
         m = p.n_asm <= 8u ? fb : edge_mask(p, u, v);
         // python: sum(weights[f] for f in support) -- int 0 start, then float adds in support (= assembly) order
