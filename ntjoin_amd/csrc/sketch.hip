@@ -2618,6 +2618,19 @@ struct Driver {
     {
         return bs_select_geom(a->S_sparse, a->sel_H, h->cfg.w, frac, g.n_strips, (uint32_t)env_u64(h, "MXG_SEL_QCAP", 0), (uint32_t)env_u64(h, "MXG_SEL_RK", 0));
     }
+    // The slice kernel's control block cleared ahead of the filter that precedes it on this stream (the filter does not touch it):
+    // filter and slice kernel then follow one another without a fill between them (two idle spells of ~6 us per assembly).
+    bool ctrl_cleared = false;
+    int clear_sel_ctrl(const BsSelGeom &b)
+    {
+        int rc;
+        if ((rc = flush_emit(nullptr)) != MXG_OK) return rc;  // (this driver's scratch is about to be reused)
+        const size_t ctrl_bytes = ((size_t)CTRL_WORDS + sup_words(b.n_slices) + 64 * 32) * 4;
+        MXG_HIP(h, sc(SC_CTRL).ensure(ctrl_bytes));
+        MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, ctrl_bytes, st));
+        ctrl_cleared = true;
+        return MXG_OK;
+    }
     int enqueue_sel(Assembly *a, const Tables &T, const BatchGeom &g, const BsSelGeom &b, uint32_t tau_hi, OutArrays &out,
                     uint32_t *ctrl_host, const ChainIO *io)
     {
@@ -2634,7 +2647,8 @@ struct Driver {
         const size_t ovf_ent = (size_t)b.n_ovf * (b.ovf_cap + 2 * SEL_PAD);
         MXG_HIP(h, sc(SC_CAND_H).ensure(ovf_ent * 8));
         MXG_HIP(h, sc(SC_CAND_K).ensure(ovf_ent * 4));
-        MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, ctrl_bytes, st));
+        if (!ctrl_cleared) MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, ctrl_bytes, st));
+        ctrl_cleared = false;
         // (fine timing: the slice kernel is booked where the other route books count + reorder, the stretch kernels where it books
         // resolve + stretches)
         // (the slice kernel has a span of its own in either timing mode: bench.py's roofline object times it inside the timed region)
@@ -3338,6 +3352,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 hipEvent_t behind = nullptr;
                 if (stagger && !one_stream && last_sel_slot >= 0 && drvs[last_sel_slot] != &drv && list[i]->total_kmers >= (1ull << 31))
                     behind = h->ev_sel_done[last_sel_slot];
+                if (sel_ok && knob_u64(h, "MXG_CLEAR_AHEAD", 1) && (rc = drv.clear_sel_ctrl(bgs[b])) != MXG_OK) return rc;
                 if ((rc = bs_edges(h, list[i], drv.st)) != MXG_OK) return rc;  // (the two blocks that copy the edge chunks need not wait)
                 if (behind) MXG_HIP(h, hipStreamWaitEvent(drv.st, behind, 0));
                 if ((rc = drv.ev_begin(list[i]->total_bases, true)) != MXG_OK) return rc;
