@@ -4,6 +4,7 @@
 # streaming read only).  One counter group per rocprofv3 pass.   usage (GPU box): tools/pmc_calib.sh [round]   -> gpurun_out/<round>/traffic_calibration.json
 round=${1:-r05}
 bin=$GRAFT_REPO_ROOT/tools/bin/ubench_traffic
+mkdir -p $(dirname $bin)
 [ -x $bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $bin $GRAFT_REPO_ROOT/tools/ubench_traffic.hip || exit 1
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/$round
