@@ -102,42 +102,56 @@ def test_fuzz_k32_route_vs_oracle(oracle):
                 os.environ[k_] = v
 
 
+def _graph_trial(rng, t, A):
+    """one random set of A sketches through mxg_add_assembly_tsv against the graph oracle"""
+    from ntjoin_amd.engine import MxEngine
+    from oracle import graph_oracle as go
+    universe = [rng.getrandbits(64) for _ in range(rng.choice([5, 30, 200, 2000]))]
+    names, weights = [], []
+    for a in range(A):
+        name = f"t{t}_asm{a}.k32.w10.tsv"
+        with open(name, "w", encoding="ascii") as fh:
+            for r in range(rng.randint(1, 12)):
+                n = rng.choice([0, 0, 1, 2, 5, 40, 300])
+                picks = [rng.choice(universe) for _ in range(n)] if rng.random() < 0.5 else \
+                    rng.sample(universe, min(n, len(universe)))
+                pos = sorted(rng.sample(range(10 ** 6), len(picks)))
+                fh.write(f"ctg{r}\t" + " ".join(f"{h}:{p}:ACGT" for h, p in zip(picks, pos)) + "\n")
+        names.append(name)
+        weights.append(rng.choice([1, 2, 0.5, 1.5, 0.1, 3]))
+    with MxEngine(k=32, w=10) as eng:
+        for nm, wt in zip(names, weights):
+            eng.add_tsv(nm, wt, nm)
+        eng.build_graph()
+        eng.write_dot(f"t{t}.mx.dot")
+        flags = [eng.get_mx_flags(a) for a in range(A)]
+        sks = [eng.get_sketch(a) for a in range(A)]
+    state = go.load_and_build(names[:-1], weights[:-1], names[-1], weights[-1])
+    got = go.canonical_dot_from_text(open(f"t{t}.mx.dot", encoding="utf-8").read())
+    assert got == go.canonical_dot_from_state(state), (t, A)
+    for a, nm in enumerate(names):
+        uniq = {str(h) for h, f in zip(sks[a]["out_hash"].tolist(), flags[a].tolist()) if f & 1}
+        assert uniq == set(state["list_mx_info"][nm].keys()), (t, A, a)
+
+
 def test_fuzz_graph_stage_vs_oracle(tmp_path):
     """random sketches fed through mxg_add_assembly_tsv: duplicates inside and across assemblies, empty records,
     1-6 assemblies, fractional weights -> flags, filtered lists, edges, weights and canonical .mx.dot vs the oracle"""
-    from ntjoin_amd.engine import MxEngine
-    from oracle import graph_oracle as go
     trials = int(os.environ.get("MXG_FUZZ_TRIALS", "60"))
     rng = random.Random(77)
     os.chdir(tmp_path)
     for t in range(trials):
-        A = rng.randint(1, 6)
-        universe = [rng.getrandbits(64) for _ in range(rng.choice([5, 30, 200, 2000]))]
-        names, weights = [], []
-        for a in range(A):
-            name = f"t{t}_asm{a}.k32.w10.tsv"
-            with open(name, "w", encoding="ascii") as fh:
-                for r in range(rng.randint(1, 12)):
-                    n = rng.choice([0, 0, 1, 2, 5, 40, 300])
-                    picks = [rng.choice(universe) for _ in range(n)] if rng.random() < 0.5 else \
-                        rng.sample(universe, min(n, len(universe)))
-                    pos = sorted(rng.sample(range(10 ** 6), len(picks)))
-                    fh.write(f"ctg{r}\t" + " ".join(f"{h}:{p}:ACGT" for h, p in zip(picks, pos)) + "\n")
-            names.append(name)
-            weights.append(rng.choice([1, 2, 0.5, 1.5, 0.1, 3]))
-        with MxEngine(k=32, w=10) as eng:
-            for nm, wt in zip(names, weights):
-                eng.add_tsv(nm, wt, nm)
-            eng.build_graph()
-            eng.write_dot(f"t{t}.mx.dot")
-            flags = [eng.get_mx_flags(a) for a in range(A)]
-            sks = [eng.get_sketch(a) for a in range(A)]
-        state = go.load_and_build(names[:-1], weights[:-1], names[-1], weights[-1])
-        got = go.canonical_dot_from_text(open(f"t{t}.mx.dot", encoding="utf-8").read())
-        assert got == go.canonical_dot_from_state(state), t
-        for a, nm in enumerate(names):
-            uniq = {str(h) for h, f in zip(sks[a]["out_hash"].tolist(), flags[a].tolist()) if f & 1}
-            assert uniq == set(state["list_mx_info"][nm].keys()), (t, a)
+        _graph_trial(rng, t, rng.randint(1, 6))
+
+
+@pytest.mark.parametrize("n_asm", [4, 5, 8, 9, 13])
+def test_fuzz_graph_stage_by_number_of_assemblies(tmp_path, n_asm):
+    """the edge kernels know three cases -- up to four assemblies (their adjacency entries of a vertex requested together), up to
+    eight (an edge's support mask travels in its flag byte), more (the mask is looked up again): each against the oracle"""
+    rng = random.Random(1000 + n_asm)
+    os.chdir(tmp_path)
+    for t in range(int(os.environ.get("MXG_FUZZ_TRIALS", "60")) // 6):
+        _graph_trial(rng, t, n_asm)
 
 
 def _derived_assembly(rng, base, sub):
