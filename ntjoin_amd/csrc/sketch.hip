@@ -3352,7 +3352,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 hipEvent_t behind = nullptr;
                 if (stagger && !one_stream && last_sel_slot >= 0 && drvs[last_sel_slot] != &drv && list[i]->total_kmers >= (1ull << 31))
                     behind = h->ev_sel_done[last_sel_slot];
-                if (sel_ok && knob_u64(h, "MXG_CLEAR_AHEAD", 1) && (rc = drv.clear_sel_ctrl(bgs[b])) != MXG_OK) return rc;
+                if (sel_ok && (rc = drv.clear_sel_ctrl(bgs[b])) != MXG_OK) return rc;
                 if ((rc = bs_edges(h, list[i], drv.st)) != MXG_OK) return rc;  // (the two blocks that copy the edge chunks need not wait)
                 if (behind) MXG_HIP(h, hipStreamWaitEvent(drv.st, behind, 0));
                 if ((rc = drv.ev_begin(list[i]->total_bases, true)) != MXG_OK) return rc;
