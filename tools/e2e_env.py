@@ -47,7 +47,7 @@ try:
             ph = next((ln.split("mxgraph: ", 1)[1] for ln in pr.stderr.splitlines() if "device + handle" in ln), pr.stderr[-300:])
             print(f"{label}: total {dt:.3f} s = {bases / dt / 1e9:.2f} Gbp/s | {ph}", flush=True)
             for ln in pr.stderr.splitlines():
-                if ln.startswith("[mxg] load_fasta") or ln.startswith("[mxg] write_outputs: graph"):
+                if ln.startswith("[mxg] load_fasta") or ln.startswith("[mxg] write_outputs: graph") or ln.startswith("[mxg] write_tsv_device") or ln.startswith("[mxg] write_dot"):
                     print("    " + ln, flush=True)
 finally:
     if not keep:
