@@ -704,6 +704,7 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
     std::vector<uint32_t> h_rec(n);
     if (n) MXG_HIP(h, hipMemcpyAsync(h_rec.data(), a->d_rec.p, n * 4, hipMemcpyDeviceToHost, st));
     MXG_HIP(h, hipStreamSynchronize(st));
+    const double t_rec = now_s() - t_begin;  // (the record column on the host)
     std::vector<uint64_t> rec_first(n_rec + 1, 0);
     for (uint64_t i = 0; i < n; ++i) rec_first[h_rec[i] + 1]++;
     for (uint64_t r = 0; r < n_rec; ++r) rec_first[r + 1] += rec_first[r];
@@ -723,6 +724,7 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
     }
     id_off[n_rec] = (uint32_t)ids.size();
     if (ids.size() >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "record ids too long");
+    const double t_host = now_s() - t_begin - t_rec;  // (the record tables)
     DevBuf d_first, d_prefix, d_idoff, d_ids, d_len, d_off, d_tsum, d_tbase, d_total, d_recbase;
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
         MXG_HIP(h, b.ensure(std::max<size_t>(bytes, 16)));
@@ -772,6 +774,7 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
         p.rec_item0 = d_item0.as<uint64_t>();
     }
     uint64_t total_entries = 0;
+    const double t_up = now_s() - t_begin - t_rec - t_host;  // (their upload, the arrays of the lengths)
     if (n) {
         hipLaunchKernelGGL(k_tsv_len, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, p);
         hipLaunchKernelGGL(k_tsv_tile_sum, dim3(n_tiles), dim3(256), 0, st, d_len.as<uint8_t>(), n, d_tsum.as<uint32_t>());
@@ -892,8 +895,9 @@ int write_tsv_device(mxg_handle *h, Assembly *a, const char *path, int with_pos,
     (void)hipStreamSynchronize(st);
     ok = out.close() && ok;
     if (dbg_io)
-        fprintf(stderr, "[mxg] write_tsv_device %s: %.3f s = tables %.3f + buffers %.3f + waiting for the device %.3f + writing %.3f (%llu MB)\n",
-                a->name.c_str(), now_s() - t_begin, t_tables, t_alloc, t_dev_wait, t_put, (unsigned long long)(total >> 20));
+        fprintf(stderr, "[mxg] write_tsv_device %s: %.3f s = tables %.3f (record column to the host %.3f, record tables %.3f, uploads + allocations %.3f, lengths + offsets %.3f) + buffers %.3f + waiting for the device %.3f + writing %.3f (%llu MB)\n",
+                a->name.c_str(), now_s() - t_begin, t_tables, t_rec, t_host, t_up, t_tables - t_rec - t_host - t_up, t_alloc, t_dev_wait, t_put,
+                (unsigned long long)(total >> 20));
     if (rc != MXG_OK) return rc;
     if (!ok) return set_err(h, MXG_EIO, "write error on '%s'", path);
     out.complete = true;
