@@ -43,8 +43,10 @@ static hipError_t pin_pool_malloc(mxg_handle *h)
 }
 hipError_t pin_pool_start(mxg_handle *h)
 {
-    if (h->pin_state.load() == 3) {  // registering failed: the pieces go back and the pool is taken in one allocation (nobody is
-        pin_pool_release(h);         // using a piece: a failed wait ends the operation that waited)
+    if (h->pin_state.load() == 3) {  // registering failed: the pieces go back and the pool is taken in one allocation.  The
+        (void)hipSetDevice(h->device);  // operation that waited for the missing piece has ended, but copies it issued out of the
+        (void)hipDeviceSynchronize();   // pieces that DID arrive may still be in flight: they end before their pages go away
+        pin_pool_release(h);
         (void)hipGetLastError();
         return pin_pool_malloc(h);
     }

@@ -142,6 +142,7 @@ struct Assembly {
     // sketch (device, ordered by (record,pos)) + lazily filled host mirror
     bool has_sketch = false;
     uint64_t n_mx = 0;
+    uint64_t n_mx_seen = 0;  // the largest sketch an earlier mxg_sketch* of this assembly ended with (sizes the fused graph stage)
     DevBuf d_hash, d_pos, d_rec, d_fwd, d_rec_base;
     bool fwd_valid = false;  // d_fwd filled (lazily: k_strand)
     bool foreign_sketch = false;  // sketch holds minimizers of records this handle has no bases for (gathered / imported)

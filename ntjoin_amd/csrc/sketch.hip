@@ -2433,7 +2433,7 @@ struct Driver {
         pp.s_src = sc(SC_GD_REC).as<uint32_t>();
         pp.gcap = gcap;
         // (blocks beyond the stretches there are leave at once: the grid follows what the launch may meet, like k_emit's placing blocks)
-        hipLaunchKernelGGL(k_gap_post, dim3(std::max(1u, std::min(gcap, 4u * n_place) / GP_PER)), dim3(GPB), 0, st, pp);
+        hipLaunchKernelGGL(k_gap_post, dim3(std::max(1u, (std::min(gcap, 4u * n_place) + GP_PER - 1u) / GP_PER)), dim3(GPB), 0, st, pp);  // (rounded UP: 4 * n_place is any number once the placing blocks follow the density met)
         MXG_HIP(h, hipGetLastError());
         return MXG_OK;
     }
@@ -3051,6 +3051,7 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
     a->foreign_sketch = false;
     a->flags_valid = false;
     h->graph.valid = false;
+    a->n_mx_seen = std::max(a->n_mx_seen, a->n_mx);
     a->n_mx = 0;
     *empty = false;
 
@@ -3185,7 +3186,7 @@ __global__ __launch_bounds__(256) void k_pack_slot_dev(const uint64_t *__restric
                                                        const uint32_t *__restrict__ rec, const uint32_t *__restrict__ n_ptr,
                                                        const uint32_t *__restrict__ ctrl, uint64_t out_cap, uint64_t cap,
                                                        long long fixed, long long *header, unsigned char *__restrict__ region,
-                                                       uint32_t dev_gaps)
+                                                       uint32_t dev_gaps, uint32_t place4)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (fixed != -2) {  // the host already knows: empty assembly (0) or not through the one-batch pipeline (-1)
@@ -3194,8 +3195,10 @@ __global__ __launch_bounds__(256) void k_pack_slot_dev(const uint64_t *__restric
     }
     const uint64_t n = *n_ptr;
     // the same predicate as sketch_finish's (batch_ended_well): no arena overflow, no flag from the stretch kernels (word 6) or from
-    // the slice kernel (word 13: a slice gave up), stretches either absent or -- on the device route -- all placed (none deferred)
-    const bool ok = ctrl[0] == 0 && ctrl[6] == 0 && ctrl[13] == 0 && (dev_gaps ? ctrl[11] == 0 : ctrl[1] == 0) && (ctrl[4] | ctrl[5]) != 0 &&
+    // the slice kernel (word 13: a slice gave up), stretches either absent or -- on the device route -- all placed (none deferred,
+    // and no more of them than k_emit's launch had placing blocks for: k_emit then places none and tells the host through ITS
+    // word 3 only, which this kernel does not see)
+    const bool ok = ctrl[0] == 0 && ctrl[6] == 0 && ctrl[13] == 0 && (dev_gaps ? (ctrl[11] == 0 && ctrl[1] <= place4) : ctrl[1] == 0) && (ctrl[4] | ctrl[5]) != 0 &&
                     n <= cap && n <= out_cap;
     if (i == 0) *header = ok ? (long long)n : -1ll;
     if (!ok || i >= n) return;
@@ -3245,6 +3248,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         uint32_t n_cap;
         uint32_t *hc;  // pinned control block
         bool bs;       // went through the k = 32 route (no candidate arrays to finish from)
+        uint32_t place4 = 0;  // stretches the batch's k_emit launch has placing blocks for (4 * n_place)
     };
     const bool bs_env = env_u64(h, "MXG_BS", 1) != 0;
     const bool bs_select = env_u64(h, "MXG_BS_SELECT", 1) != 0;  // k_bs_select instead of count -> reorder -> resolve
@@ -3380,6 +3384,9 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 const double expect = plans[i].gap_rate * (double)it.g.nk;
                 const uint32_t place4 = (uint32_t)std::min<double>((double)plans[i].gcap, 2.0 * expect + 256.0);
                 drv.set_gaps(plans[i].gcap, list[i]->gap_rate_hint > 0 ? (place4 + 3u) / 4u : plans[i].gcap / 4u);
+                if (const uint64_t forced = knob_u64(h, "MXG_GAP_PLACE", 0))  // test knob: placing blocks for this many stretches
+                    drv.set_gaps(plans[i].gcap, (uint32_t)std::min<uint64_t>((forced + 3u) / 4u, plans[i].gcap / 4u));
+                it.place4 = 4u * drv.n_place;
             }
             // tiles of 32 slices in k_emit (0.18 against 0.21 ms per step at 3 Gbp + 3 Gbp) unless stretches are so dense that
             // most tiles of that size would hold one (the tile then searches the stretch keys per minimizer: repeat-rich
@@ -3458,7 +3465,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             hipLaunchKernelGGL(k_pack_slot_dev, dim3(grid), dim3(256), 0, h->stream, a->d_hash.as<uint64_t>(),
                                a->d_pos.as<uint32_t>(), a->d_rec.as<uint32_t>(), h->d_nmx.as<uint32_t>() + i,
                                drvs[slot_of[i]]->sc(SC_CTRL).as<uint32_t>(), out_cap, cap, fixed,
-                               reinterpret_cast<long long *>(base) + i, base + off, plans[i].dev_gaps ? 1u : 0u);
+                               reinterpret_cast<long long *>(base) + i, base + off, plans[i].dev_gaps ? 1u : 0u,
+                               state[i] == 1 ? items[item0[i]].place4 : 0u);
             off += 16 * cap;
         }
         MXG_HIP(h, hipGetLastError());
@@ -3481,7 +3489,10 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             for (size_t i = 0; i < n; ++i) {
                 Assembly *a = list[i];
                 const uint64_t cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
-                gb.n_bound[i] = std::min<uint64_t>(cap, (uint64_t)(2.3 * (double)a->total_kmers / (double)(h->cfg.w + 1)) + 2048);
+                // (2 per window on i.i.d. sequence; repeat-rich sequence reaches ~3.8: what an earlier sketch of the assembly ended
+                // with, 10 % on top, so that the fused graph survives on exactly the inputs the output arrays were widened for)
+                const uint64_t iid = (uint64_t)(2.3 * (double)a->total_kmers / (double)(h->cfg.w + 1)) + 2048;
+                gb.n_bound[i] = std::min<uint64_t>(cap, std::max<uint64_t>(iid, a->n_mx_seen + a->n_mx_seen / 10 + 2048));
                 gb.n_ptr[i] = h->d_nmx.as<uint32_t>() + i;
             }
             fused = build_graph(h, GRAPH_FULL, nullptr, 0, &gb) == MXG_OK;  // (its sync is this call's sync)

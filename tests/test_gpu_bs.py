@@ -182,6 +182,24 @@ def test_long_stretches_are_reported_in_pieces(oracle, env):
     _check(oracle, recs + [(f"x{i}", rnd(9000)) for i in range(40)], 32, 1000, cand_per_window=2)
 
 
+def test_stretch_counts_around_the_rank_kernels_last_block(oracle, env):
+    """k_gap_post ranks sixteen stretches per block: with per-stretch arrays (and placing blocks) for a number of stretches that is
+    no multiple of sixteen, a batch whose stretch count falls into the last, partial block must still have every stretch ranked
+    (the grid rounded down until round 6: those stretches' minimizers landed at stale offsets).  A sweep of record lengths
+    walks the count through 50 ... 90 stretches against arrays for 72: counts beyond 72 are enqueued again / redone, all others
+    are placed on the device."""
+    env["MXG_DEV_GAPS"] = "1"
+    env["MXG_GAP_DEV_CAP"] = "72"
+    rng = random.Random(66)
+    placed = 0
+    for L in range(60000, 124000, 2000):
+        rec = [("r%d" % L, "".join(rng.choice("ACGT") for _ in range(L)))]
+        st = _check(oracle, rec, 32, 200, cand_per_window=3)
+        assert st["select_slices"] > 0
+        placed += 1 if st["batches_redone"] == 0 and st["retried_assemblies"] == 0 else 0
+    assert placed >= 4, placed      # (the sweep did reach counts the device route keeps)
+
+
 def test_many_batches_and_overflow_on_the_bs_route(oracle, env):
     env["MXG_SPARSE_BATCH_KMERS"] = "30000"
     st = _check(oracle, _records(21), 32, 200)

@@ -52,7 +52,10 @@ def test_four_and_eight_ranks_on_one_gpu(world, config3):
                                   # sparse route runs at all): its flag alone must keep the truncated sketch from being accepted
                                   {"MXG_SEL_RK": "4", "MXG_TEST_CONFIG3": "1"},
                                   # stretches everywhere AND on the device route: the pack kernel accepts what k_gap_fix placed
-                                  {"MXG_TEST_CAND": "3", "MXG_TEST_CONFIG3": "1", "MXG_DEV_GAPS": "1"}])
+                                  {"MXG_TEST_CAND": "3", "MXG_TEST_CONFIG3": "1", "MXG_DEV_GAPS": "1"},
+                                  # ... and more stretches than k_emit's launch had placing blocks for (it then places none and says
+                                  # so to the host only): the pack kernel must see that too, or peers build on a truncated slot
+                                  {"MXG_TEST_CAND": "3", "MXG_TEST_CONFIG3": "1", "MXG_DEV_GAPS": "1", "MXG_GAP_PLACE": "8"}])
 def test_union_step_when_sketches_leave_the_common_case(knob):
     """mxg_sketch_pack with sketches that do not end the common way on the device -- candidate-free stretches everywhere
     (2 candidates per window) / every wave overflowing its arena slice: their slots travel as -1, every rank falls back
