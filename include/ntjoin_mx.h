@@ -147,6 +147,8 @@ typedef struct mxg_stats {
     uint64_t deferred_stretches; /* candidate-free stretches sketched apart and merged in (satellites, low complexity) */
     uint64_t select_slices;    /* slices of 64 strips that went through k_bs_select (k = 32 route: bitmap -> selected minimizers
                                   in one kernel; 0: count -> reorder -> resolve ran)                                           */
+    uint64_t slice_stretches;  /* candidate-free stretches (>= w k-mers without a candidate) that k_sel_stretch was handed: sketched
+                                  one wave per slice right behind k_bs_select, their minimizers put into the slice's row            */
 } mxg_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------------------- */

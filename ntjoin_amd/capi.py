@@ -77,7 +77,7 @@ class Stats(C.Structure):
                 ("ms_join", C.c_double), ("ms_vertices", C.c_double), ("ms_edges", C.c_double),
                 ("bs_filter_bases", C.c_uint64), ("graph_join", C.c_uint64),
                 ("batches_redone", C.c_uint64), ("sync_assemblies", C.c_uint64), ("retried_assemblies", C.c_uint64), ("deferred_stretches", C.c_uint64),
-                ("select_slices", C.c_uint64)]
+                ("select_slices", C.c_uint64), ("slice_stretches", C.c_uint64)]
 
 
 _lib = None

@@ -1051,6 +1051,7 @@ int mxg_get_stats(mxg_handle *h, mxg_stats *out)
     s.sync_assemblies = h->stat_sync_assemblies;
     s.deferred_stretches = h->stat_deferred;
     s.select_slices = h->stat_sel_slices;
+    s.slice_stretches = h->stat_slice_stretches;
     s.graph_join = h->stat_graph_join;
     s.retried_assemblies = h->stat_retries;
     s.dense_kmers = h->stat_dense_kmers;
@@ -1093,7 +1094,7 @@ int mxg_reset_timers(mxg_handle *h)
     if (rc != MXG_OK) return rc;
     h->tm = Timers();
     h->stat_candidates = h->stat_dense_kmers = h->stat_bs_bases = 0;
-    h->stat_batches_redone = h->stat_sync_assemblies = h->stat_deferred = h->stat_retries = h->stat_sel_slices = 0;
+    h->stat_batches_redone = h->stat_sync_assemblies = h->stat_deferred = h->stat_retries = h->stat_sel_slices = h->stat_slice_stretches = 0;
     return MXG_OK;
 }
 

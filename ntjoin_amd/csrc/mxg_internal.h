@@ -236,6 +236,7 @@ struct mxg_handle {
     uint64_t stat_candidates = 0, stat_dense_kmers = 0, stat_unique = 0;
     uint64_t stat_bs_bases = 0;  // bases the bit-sliced filter (k = 32 route) has covered
     uint64_t stat_sel_slices = 0;  // slices enqueued through k_bs_select
+    uint64_t stat_slice_stretches = 0;  // candidate-free stretches handed to k_sel_stretch
     hipEvent_t ev_sel_done[4] = {nullptr, nullptr, nullptr, nullptr};  // recorded behind every slice kernel, per stream slot
     uint64_t stat_graph_join = 0; // mxg_stats::graph_join
     uint32_t pj_cap1_P1 = 0;     // two-level join: coarse partitions and the records one of them must hold, as an earlier call's

@@ -1234,7 +1234,8 @@ __global__ __launch_bounds__(256) void k_emit(const EmitParams p)
                     p.host_ctrl[w] = w == 1 ? n_g_raw : w == 2 ? all : w == 3 ? flag : w == 4 ? n_report : w == 5 ? nB
                                    : w == 6 ? (uint32_t)total : w == 7 ? (uint32_t)(total >> 32)
                                    : w == 8 ? (uint32_t)obase : w == 9 ? (uint32_t)(obase >> 32)
-                                   : (w == 10 && p.dev_gaps) ? p.ovf[10] : (w == 11 && p.dev_gaps && !flag) ? p.ovf[11] : w == 12 ? p.ovf[13] : 0u;
+                                   : (w == 10 && p.dev_gaps) ? p.ovf[10] : (w == 11 && p.dev_gaps && !flag) ? p.ovf[11] : w == 12 ? p.ovf[13]
+                                   : (w == 15 && p.n_fixed) ? p.ovf[15] : 0u;  // ([15]: the stretches k_sel_stretch was asked for)
                 }
             }
         }
@@ -1962,11 +1963,13 @@ struct Driver {
     // stretches the device route's per-stretch arrays hold for the batch being enqueued, and the blocks at the front of k_emit's
     // grid that place them, four stretches each (see gap_capacity)
     uint32_t gcap = GAP_DEV_MAX, n_place = GAP_DEV_MAX / 4;
-    void set_gaps(uint32_t cap, uint32_t place)
+    void set_gaps(uint32_t cap, uint32_t place, double expect = -1.0)
     {
         gcap = cap;
         n_place = place;
+        gap_expect = expect;
     }
+    double gap_expect = -1.0;  // stretches the plan expects of the batch for the stretch kernels (< 0: not known)
 
     // SC_CTRL holds the control block (16 words) followed by the two super-count arrays of the batch (scan_kernels.h):
     // per hash-kernel wave, then per k_resolve block; ctrl_bytes() of it are zeroed by the batch's one memset
@@ -2419,7 +2422,10 @@ struct Driver {
         // the batch's slice of the pinned list of deferred stretches goes with its pinned control block
         gp.defer = reinterpret_cast<uint4 *>(h->pinned_defer) + (size_t)((ctrl_host - h->pinned_ctrl) / 16) * GAP_DEFER_MAX;
         gp.tab = h->tab;
-        const uint32_t gf_blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64(h, "MXG_GAP_FIX_BLOCKS", GAP_FIX_BLOCKS), 1), gcap);
+        // (no more blocks than the launch expects stretches -- what k_emit has placing blocks for: a block of 51 KB that finds
+        // nothing to do still has to be brought to a CU, 22 us for 768 of them behind k_sel_stretch, which leaves few stretches over)
+        const uint32_t gf_blocks = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(std::max<uint64_t>(env_u64(h, "MXG_GAP_FIX_BLOCKS", GAP_FIX_BLOCKS), 1), gcap),
+                                                                gap_expect >= 0.0 ? std::max<uint64_t>(32, (uint64_t)(2.0 * gap_expect) + 16) : 4ull * n_place);
         if (h->cfg.variant == MXG_VARIANT_V1_MIN)
             hipLaunchKernelGGL(k_gap_fix<MXG_VARIANT_V1_MIN>, dim3(gf_blocks), dim3(256), 0, st, gp);
         else
@@ -2625,7 +2631,7 @@ struct Driver {
     {
         int rc;
         if ((rc = flush_emit(nullptr)) != MXG_OK) return rc;  // (this driver's scratch is about to be reused)
-        const size_t ctrl_bytes = ((size_t)CTRL_WORDS + sup_words(b.n_slices) + 64 * 32) * 4;
+        const size_t ctrl_bytes = ((size_t)CTRL_WORDS + sup_words(b.n_slices) + 2 * 64 * 32) * 4;
         MXG_HIP(h, sc(SC_CTRL).ensure(ctrl_bytes));
         MXG_HIP(h, hipMemsetAsync(sc(SC_CTRL).p, 0, ctrl_bytes, st));
         ctrl_cleared = true;
@@ -2638,7 +2644,7 @@ struct Driver {
         if ((rc = flush_emit(nullptr)) != MXG_OK) return rc;  // (this driver's scratch is about to be reused)
         MXG_HIP(h, sc(SC_GAPS).ensure((size_t)GAP_CAP * 16));
         n_wave_sup = 0;
-        const size_t ctrl_bytes = ((size_t)CTRL_WORDS + sup_words(b.n_slices) + 64 * 32) * 4;  // + the candidate counters
+        const size_t ctrl_bytes = ((size_t)CTRL_WORDS + sup_words(b.n_slices) + 2 * 64 * 32) * 4;  // + the candidate counters
         MXG_HIP(h, sc(SC_CTRL).ensure(ctrl_bytes));
         MXG_HIP(h, sc(SC_CNT256).ensure((size_t)b.n_slices * 4 + 64));
         const size_t n_ent = (size_t)b.n_slices * b.rk;
@@ -2680,16 +2686,45 @@ struct Driver {
         bp.cnt = sc(SC_CNT256).as<uint32_t>();
         bp.sup = sel_sup(0);
         bp.gaps = sc(SC_GAPS).as<uint4>();
-        bp.gap_cap = GAP_CAP;
+        // (the upper part of the stretch array holds the requests for k_sel_stretch, two entries each)
+        bp.gap_cap = GAP_CAP - SEL_IREQ_CAP;
+        bp.ireq = sc(SC_GAPS).as<uint4>() + bp.gap_cap;
+        bp.ireq_cap = SEL_IREQ_CAP - 8u;  // (k_sel_stretch reads eight entries from any request on)
         // (pieces only where the host's route for what k_gap_fix hands over knows them: the tile kernel)
         bp.gap_nmax = (io && io->dev_gaps && h->cfg.w <= ST_WMAX && !knob_set(h, "MXG_STRETCH_DENSE") && !knob_set(h, "MXG_GAP_WHOLE")) ? GAP_DEV_NMAX : 0u;
         bp.ctrl = sc(SC_CTRL).as<uint32_t>();
         bp.cand_spread = sel_sup(0) + sup_words(b.n_slices);
         bp.ablate = (uint32_t)env_u64(h, "MXG_SEL_ABLATE", 0);  // (profiling only: stop every slice after phase n)
+        // the stretches between two candidates of a slice go to k_sel_stretch (MXG_SEL_INLINE=0: all stretches through k_gap_fix)
+        bp.inl_amax = knob_u64(h, "MXG_SEL_INLINE", 1) && b.n_slices < (1u << 24) ? bs_select_inline_amax(h->cfg.w) : 0u;
         if ((rc = launch_bs_select(h, bp, b, st)) != MXG_OK) return rc;
         // (the next assembly's filter may start here; MXG_STAGGER=2, an experiment: behind this batch's emit instead, below)
         const bool late = knob_u64(h, "MXG_STAGGER", 1) == 2;
         if (h->ev_sel_done[slot] && !late) MXG_HIP(h, hipEventRecord(h->ev_sel_done[slot], st));
+        if (bp.inl_amax) {
+            SelStretchParams sp{};
+            sp.packed = bp.packed;
+            sp.runs = T.d_runs;
+            sp.ctg_run0 = T.d_ctg_run0;
+            sp.ctg_drop = T.d_ctg_drop;
+            sp.byte_tab = h->d_init_tab.as<uint4>();
+            sp.tab = h->tab;
+            sp.w = bp.w;
+            sp.amax = bp.inl_amax;
+            sp.rk = bp.rk;
+            sp.cs = bp.cs;
+            sp.cnt = bp.cnt;
+            sp.sup = bp.sup;
+            sp.ireq = bp.ireq;
+            sp.ireq_cap = bp.ireq_cap;
+            sp.ctrl = bp.ctrl;
+            sp.tickets = bp.cand_spread + 64 * 32;
+            sp.ablate = (uint32_t)env_u64(h, "MXG_SST_ABLATE", 0);
+            sp.gaps = bp.gaps;
+            sp.gap_cap = bp.gap_cap;
+            sp.gap_nmax = bp.gap_nmax;
+            if ((rc = launch_sel_stretch(h, sp, st)) != MXG_OK) return rc;
+        }
         h->stat_sel_slices += b.n_slices;
         const bool dev = io && io->dev_gaps;
         if (timing && !fine) {  // the rest of the batch (stretches, emit) as one span
@@ -2759,8 +2794,8 @@ struct Driver {
         if (n_cand == 0) {  // no candidate at all: every contig of the batch is one stretch
             for (size_t c = c0; c < c1; ++c) gaps.push_back(make_uint4((uint32_t)c, 0, (*T.ctg_nk)[c] - 1, 0));
             n_gaps = (uint32_t)gaps.size();
-        } else if (n_gaps > GAP_CAP) {
-            return set_err(h, MXG_ELIMIT, "more than %u candidate-free stretches in one batch; rerun with MXG_FLAG_DENSE_ONLY", GAP_CAP);
+        } else if (n_gaps > GAP_CAP - SEL_IREQ_CAP) {  // (behind k_bs_select the array's upper part holds k_sel_stretch's requests)
+            return set_err(h, MXG_ELIMIT, "more than %u candidate-free stretches in one batch; rerun with MXG_FLAG_DENSE_ONLY", GAP_CAP - SEL_IREQ_CAP);
         } else if (n_gaps) {
             gaps.resize(n_gaps);
             MXG_HIP(h, hipMemcpyAsync(gaps.data(), sc(SC_GAPS).p, (size_t)n_gaps * 16, hipMemcpyDeviceToHost, st));
@@ -3152,7 +3187,12 @@ static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
     sp.gcap = gap_capacity(h, a);
     if (sp.dev_gaps) {  // a candidate is followed by a stretch with probability e^-c
         // (a->gap_rate_hint: what earlier sketches of this assembly met, 25 % on top)
-        const double per_kmer = std::max(sp.frac * std::exp(-(double)c), a->gap_rate_hint * 1.25);
+        // (behind k_sel_stretch only what that kernel does not take reaches the stretch kernels: on plain sequence next to nothing)
+        const bool inl = h->cfg.k == 32 && h->cfg.variant == MXG_VARIANT_V2_SUM && knob_u64(h, "MXG_BS", 1) != 0 &&
+                         knob_u64(h, "MXG_BS_SELECT", 1) != 0 && knob_u64(h, "MXG_SEL_INLINE", 1) != 0;
+        // (... and once a sketch of the assembly has reported, what it met counts, not the prior)
+        const double per_kmer = inl && a->gap_rate_hint > 0 ? std::max(a->gap_rate_hint * 1.25, 1e-9)
+                                                            : std::max(sp.frac * std::exp(-(double)c) * (inl ? 0.02 : 1.0), a->gap_rate_hint * 1.25);
         sp.gap_rate = per_kmer;
         const double lim = (double)env_u64(h, "MXG_GAP_BUDGET", sp.gcap / 2) / std::max(per_kmer, 1e-30);  // expected stretches per batch
         sp.gap_kmers = (uint64_t)std::min<double>(std::max<double>(lim, (double)(1u << 20)), 9e18);
@@ -3383,7 +3423,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 // batch that meets more than its launch can place reports so and is enqueued again with the density it met
                 const double expect = plans[i].gap_rate * (double)it.g.nk;
                 const uint32_t place4 = (uint32_t)std::min<double>((double)plans[i].gcap, 2.0 * expect + 256.0);
-                drv.set_gaps(plans[i].gcap, list[i]->gap_rate_hint > 0 ? (place4 + 3u) / 4u : plans[i].gcap / 4u);
+                drv.set_gaps(plans[i].gcap, list[i]->gap_rate_hint > 0 ? (place4 + 3u) / 4u : plans[i].gcap / 4u,
+                             list[i]->gap_rate_hint > 0 ? expect : -1.0);
                 if (const uint64_t forced = knob_u64(h, "MXG_GAP_PLACE", 0))  // test knob: placing blocks for this many stretches
                     drv.set_gaps(plans[i].gcap, (uint32_t)std::min<uint64_t>((forced + 3u) / 4u, plans[i].gcap / 4u));
                 it.place4 = 4u * drv.n_place;
@@ -3521,6 +3562,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             total += t;
             n_cand += c[4];
             gap_kmers += c[10] == 0xFFFFFFFFu ? 0 : c[10];
+            if (items[q].bs && c[15] != 0xFFFFFFFFu) h->stat_slice_stretches += c[15];
         }
         if (!(good && total <= cap) && knob_set(h, "MXG_DEBUG_BATCH")) {  // (diagnostics: the reports of an assembly's batches)
             for (size_t q = q0; q < q1; ++q) {
@@ -3533,7 +3575,8 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         // far more of them than the i.i.d. estimate (satellite arrays, low-complexity runs)
         for (size_t q = q0; q < q1; ++q) {
             const uint32_t *c = items[q].hc;
-            if (c[1] != 0xFFFFFFFFu && items[q].g.nk) a->gap_rate_hint = std::max(a->gap_rate_hint, (double)c[1] / (double)items[q].g.nk);
+            // (1e-12: "a sketch has reported" -- an assembly whose stretches all went through k_sel_stretch leaves none over)
+            if (c[1] != 0xFFFFFFFFu && items[q].g.nk) a->gap_rate_hint = std::max({a->gap_rate_hint, (double)c[1] / (double)items[q].g.nk, 1e-12});
         }
         if (good && total <= cap) {
             // stretches the device route left to the host (too long, too many minimizers, invalid bases inside)

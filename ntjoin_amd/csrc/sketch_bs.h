@@ -17,6 +17,12 @@ constexpr uint32_t SEL_PAD = 8;          // sentinel entries on either side of a
 constexpr uint32_t SEL_REQ = 8;          // stretches per slice whose end lies behind the slice's strips (found by walking on)
 constexpr uint32_t SEL_GAP_DROP = 0x80000000u;  // in a reported stretch's fourth word (the reporting slice's first entry): "leave the first window's arg-min out"
 constexpr uint32_t SEL_MAX_H = 12;       // largest halo (strips) the route takes: 40 own strips per slice
+// k_sel_stretch (round 6): the candidate-free stretches that lie between two candidates of one slice are sketched by a kernel of
+// their own right behind the slice kernel, one wave per slice that has any, and their minimizers put into the slice's row
+constexpr uint32_t SEL_INL_R = 4;        // windows per lane in one piece of a stretch: a piece has at most 64 R windows
+constexpr uint32_t SEL_INL_PIECES = 6;   // pieces per stretch; longer stretches go to k_gap_fix
+constexpr uint32_t SEL_INL_TMP = 128;    // minimizers of one stretch (more: k_gap_fix)
+constexpr uint32_t SEL_IREQ_CAP = 1u << 18;  // requests per batch (the upper part of the stretch array)
 
 struct BsSelParams {
     const uint32_t *bm;          // the filter's bitmap: bit p = base position p of the packed array (bs_kernels.h)
@@ -48,7 +54,35 @@ struct BsSelParams {
     uint32_t *cand_spread;       // 64 counters, 32 words apart: the slices' own candidates (k_emit adds them up for the report)
     uint32_t *ctrl;              // [1] stretches, [6] "the host must redo this batch"
     uint32_t ablate;             // (profiling builds: every slice stops after phase n; 0 = run)
+    // inl_amax != 0: a slice's stretches become requests for k_sel_stretch, {contig, first, last k-mer, slice | number in the
+    // slice << 24 | stretches of the slice << 27}, the slice's requests next to one another; ctrl[15] counts them (0: every
+    // stretch goes straight to k_gap_fix)
+    uint32_t inl_amax;
+    uint4 *ireq;
+    uint32_t ireq_cap;
 };
+
+struct SelStretchParams {
+    const uint32_t *packed;
+    const Run *runs;
+    const uint32_t *ctg_run0;
+    const uint8_t *ctg_drop;     // see ResolveParams::ctg_drop (sketch.hip); may be null
+    const uint4 *byte_tab;       // make_init_tab's first 256 entries (init_direct)
+    HashTab tab;                 // the terms of an ntHash step
+    uint32_t w, amax, rk;
+    uint4 *cs;                   // the slices' rows (k_bs_select) and their two-level counts
+    uint32_t *cnt, *sup;
+    const uint4 *ireq;
+    uint32_t ireq_cap;
+    uint32_t *ctrl;              // [15] requests, [1] stretches (what does not fit here goes on to k_gap_fix)
+    uint32_t *tickets;           // 64 counters, 32 words apart, zero: request 64 t + c is handed out by ticket t of counter c
+    uint4 *gaps;
+    uint32_t gap_cap, gap_nmax;
+    uint32_t ablate;             // (profiling only, MXG_SST_ABLATE: 1 no rolls, 2 no first hash, 4 no window scans, 8 nothing per request)
+};
+// the longest piece the window w allows (sketch_bs.hip: stretch_sketch); 0: no stretch is taken this way
+uint32_t bs_select_inline_amax(uint32_t w);
+int launch_sel_stretch(mxg_handle *h, const SelStretchParams &p, hipStream_t st);
 
 struct BsSelGeom {
     uint32_t H, T, n_slices, rk, qcap, waves, ovf_cap, n_ovf;

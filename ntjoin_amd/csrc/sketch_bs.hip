@@ -61,7 +61,8 @@ __device__ __forceinline__ uint32_t xor3(const uint32_t a, const uint32_t b, con
     return a ^ b ^ c;
 #endif
 }
-__device__ __forceinline__ uint64_t hash32_words(const uint32_t w0, const uint32_t w1, const uint32_t w2, const uint32_t sh, const uint4 *ptab)
+// {forward lo, hi, reverse lo, hi}: the state nt_step (nthash_dev.h) rolls on
+__device__ __forceinline__ uint4 hash32_state(const uint32_t w0, const uint32_t w1, const uint32_t w2, const uint32_t sh, const uint4 *ptab)
 {
     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
     // the tables lie at offset 0 of the block's LDS (k_bs_select checks it), so an entry's address is its byte offset: the
@@ -82,6 +83,11 @@ __device__ __forceinline__ uint64_t hash32_words(const uint32_t w0, const uint32
     acc = make_uint4(xor3(acc.x, a2.x, b2.x), xor3(acc.y, a2.y, b2.y), xor3(acc.z, a2.z, b2.z), xor3(acc.w, a2.w, b2.w));
     const uint4 a3 = ent(3, byte_x16<3>(lo)), b3 = ent(7, byte_x16<3>(hi));
     acc = make_uint4(xor3(acc.x, a3.x, b3.x), xor3(acc.y, a3.y, b3.y), xor3(acc.z, a3.z, b3.z), xor3(acc.w, a3.w, b3.w));
+    return acc;
+}
+__device__ __forceinline__ uint64_t hash32_words(const uint32_t w0, const uint32_t w1, const uint32_t w2, const uint32_t sh, const uint4 *ptab)
+{
+    const uint4 acc = hash32_state(w0, w1, w2, sh, ptab);
     return (((uint64_t)acc.y << 32) | acc.x) + (((uint64_t)acc.w << 32) | acc.z);
 }
 __device__ __forceinline__ uint64_t hash32_pos(const uint32_t *__restrict__ packed, const uint64_t b, const uint4 *ptab)
@@ -171,19 +177,23 @@ __device__ __forceinline__ const BsSelParams *sel_rare_params()
 // the first starts with the last window of the piece before it and is marked (SEL_GAP_DROP) to leave that window's arg-min out --
 // the arg-min moves right with the window, so that is the only minimizer the two pieces can share (k_gap_fix's drop_idx; what
 // k_stretch_tiles does between its tiles).  gap_nmax = 0: stretches are reported whole.
-__device__ __forceinline__ void sel_push_gap(const BsSelParams &, uint32_t c, uint32_t lo, uint32_t hi, uint32_t hint)
+__device__ __forceinline__ void push_gap(uint4 *gaps, uint32_t gap_cap, uint32_t *ctrl, uint32_t nmax, uint32_t w, uint32_t c, uint32_t lo,
+                                         uint32_t hi, uint32_t hint)
 {
-    const BsSelParams *q = sel_rare_params();
-    const uint32_t nmax = q->gap_nmax, w = q->w;
     uint32_t s = lo, flag = 0u;
     for (;;) {
         const uint32_t e = nmax && hi - s >= nmax ? s + nmax - 1u : hi;
-        const uint32_t idx = atomicAdd(&q->ctrl[1], 1u);
-        if (idx < q->gap_cap) q->gaps[idx] = make_uint4(c, s, e, hint | flag);
+        const uint32_t idx = atomicAdd(&ctrl[1], 1u);
+        if (idx < gap_cap) gaps[idx] = make_uint4(c, s, e, hint | flag);
         if (e == hi) break;
         s = e - w + 1u;  // (the piece's last window; the next piece's own windows start one k-mer behind it)
         flag = SEL_GAP_DROP;
     }
+}
+__device__ __forceinline__ void sel_push_gap(const BsSelParams &, uint32_t c, uint32_t lo, uint32_t hi, uint32_t hint)
+{
+    const BsSelParams *q = sel_rare_params();
+    push_gap(q->gaps, q->gap_cap, q->ctrl, q->gap_nmax, q->w, c, lo, hi, hint);
 }
 
 // The whole wave: contig c has no candidate from k-mer k_from up to the end of the strips the slice holds, and goes on behind
@@ -228,7 +238,7 @@ constexpr uint32_t SEL_SI = 6;  // per-strip words a wave keeps in LDS: base pos
 // bytes of LDS per wave (a multiple of 16): hashes | coordinates (raw queue before) | strip info | requests | counters
 __host__ __device__ inline uint32_t sel_wave_lds(uint32_t qcap)
 {
-    return (qcap + 2u * SEL_PAD) * 12u + SEL_SI * 64u * 4u + SEL_REQ * 16u + 16u;
+    return (qcap + 2u * SEL_PAD) * 12u + SEL_SI * 64u * 4u + SEL_REQ * 16u + SEL_REQ * 16u + 16u;
 }
 
 // What a wave knows about its slice while it works on it
@@ -236,7 +246,7 @@ struct SelCtx {
     const uint4 *ptab;
     uint32_t *si;      // strip info (LDS)
     uint4 *req;        // stretches that end behind the slice (LDS)
-    uint32_t *misc;    // [0] number of requests
+    uint32_t *misc;    // [0] number of requests, [1] the wave's overflow region, [2] number of stretches to sketch here
     uint32_t lane, sl, own_end;
     bool has_drop;     // pieces of records cut between shards are loaded (ctg_drop)
     int64_t s_first;
@@ -341,6 +351,13 @@ __device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, cons
     const uint32_t cov_nk = (uint32_t)__builtin_amdgcn_readlane((int)sr.nk, 63);
     const bool cov_open = cov_c != 0xFFFFFFFFu && cov_kend < cov_nk;
     // a stretch from k_from on, reported by the candidate (or contig start) in front of it; the next real candidate is entry nx
+    // a stretch of the slice: into the wave's list for k_sel_stretch (no room there, or that kernel is off: straight to k_gap_fix)
+    // (where the list's entries go is decided when the slice is done: one branch here, no parameter read)
+    auto push_req = [&](uint32_t cg, uint32_t lo, uint32_t hi) {
+        const uint32_t q = atomicAdd(&c.misc[2], 1u);
+        if (q < SEL_REQ) reinterpret_cast<uint4 *>(c.misc + 4)[q] = make_uint4(cg, lo, hi, 0u);
+        else sel_push_gap(p, cg, lo, hi, sl * p.rk);
+    };
     auto report = [&](uint32_t cg, uint32_t k_from, uint32_t nk, uint32_t nx) {
         bool same = false;
         uint32_t k2 = 0;
@@ -350,10 +367,10 @@ __device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, cons
             k2 = s_k0[l2] + ((e2 >> 6) - s_f[l2]);
         }
         if (same) {
-            if (k2 - k_from >= w) sel_push_gap(p, cg, k_from, k2 - 1u, sl * p.rk);
+            if (k2 - k_from >= w) push_req(cg, k_from, k2 - 1u);
         } else if (nk - k_from >= w) {
             if (!(cov_open && cg == cov_c)) {
-                sel_push_gap(p, cg, k_from, nk - 1u, sl * p.rk);
+                push_req(cg, k_from, nk - 1u);
             } else {  // the stretch's end lies behind the slice: the wave walks there (below)
                 const uint32_t at = atomicAdd(&c.misc[0], 1u);
                 if (at < SEL_REQ) c.req[at] = make_uint4(cg, k_from, nk, 0u);
@@ -447,10 +464,31 @@ __device__ __forceinline__ void sel_decide(const BsSelParams &p, SelCtx &c, cons
         for (uint32_t r = 0; r < min(n_req, SEL_REQ); ++r) {
             const uint4 rq = c.req[r];
             const uint32_t k_end = stretch_end(p, c.ptab, lane, c.s_first + 64, rq.x, rq.z);
-            if (lane == 0 && k_end + 1u - rq.y >= w) sel_push_gap(p, rq.x, rq.y, k_end, sl * p.rk);
+            if (lane == 0 && k_end + 1u - rq.y >= w) push_req(rq.x, rq.y, k_end);
         }
         sel_sync<GLOB>();
         if (lane == 0) c.misc[0] = 0;
+    }
+    // ---- the slice's stretches leave for k_sel_stretch together (one reservation; each says which of how many it is, so that ONE
+    // wave of that kernel takes all of a slice's stretches -- they go into one row)
+    if (__builtin_expect(c.misc[2] != 0u, 0)) {
+        const BsSelParams *pr = sel_rare_params();
+        const uint32_t n_i = min(c.misc[2], SEL_REQ);
+        const bool to_kernel = pr->inl_amax != 0u;  // (else: every stretch straight to k_gap_fix)
+        uint32_t base = 0xFFFFFFFFu - SEL_REQ;
+        if (to_kernel && lane == 0) base = atomicAdd(&pr->ctrl[15], n_i);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        uint32_t ln = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(ln));  // (the lane's place among the requests is computed HERE: hoisted out of the slice loop it took a register there)
+#endif
+        if (ln < n_i) {
+            const uint32_t *g = c.misc + 4u + 4u * ln;
+            if (base + n_i <= pr->ireq_cap) pr->ireq[base + ln] = make_uint4(g[0], g[1], g[2], sl | (ln << 24) | (n_i << 27));
+            else sel_push_gap(p, g[0], g[1], g[2], sl * pr->rk);  // (no room: the stretch kernels take them)
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) c.misc[2] = 0;
     }
 }
 
@@ -477,7 +515,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     c.ptab = ptab;
     c.si = le + p.qcap + 2u * SEL_PAD;
     c.req = reinterpret_cast<uint4 *>(c.si + SEL_SI * 64u);
-    c.misc = reinterpret_cast<uint32_t *>(c.req + SEL_REQ);
+    c.misc = reinterpret_cast<uint32_t *>(c.req + SEL_REQ);  // (the slice's stretches for k_sel_stretch: the SEL_REQ entries behind misc's four words)
     c.lane = lane;
     c.has_drop = p.ctg_drop != nullptr;
     c.nreal = c.own_lo = c.own_hi = 0;
@@ -488,6 +526,7 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     if (threadIdx.x == 0) *blk_ticket = nwv;  // (tickets 0 .. nwv - 1: the waves' first slices)
     if (lane == 0) {
         c.misc[0] = 0;
+        c.misc[2] = 0;
         c.misc[1] = 0xFFFFFFFFu;  // this wave's region of global memory, once it has needed one (kept in LDS: a loop-carried scalar
                                   // for a path one slice in 10^5 takes cost every slice a wait -- the compiler's phi of it)
     }
@@ -606,6 +645,357 @@ __global__ __launch_bounds__(1024) void k_bs_select(const BsSelParams p)
     }
 }
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// The candidate-free stretches between two candidates of one slice: sketched one wave per slice (round 6): k_sel_stretch
+// ---------------------------------------------------------------------------------------------------------------
+// A stretch of n = w + a k-mers (all of one run: their bases are consecutive) has a + 1 windows, and with a < w every one of
+// them holds the stretch's middle [a, w): window j = k-mers [j, a) of the front part, the middle, and [w, w + j) of the back part.
+// So the windows' arg-mins are those of a sliding window of a + 1 entries over
+//     X = front part (a entries) | M = the rightmost minimum of the middle | back part (a entries),
+// window j = min(suffix minimum of X[j .. a], prefix minimum of X[a + 1 .. a + j]), the right one of equals (btllib rescans with
+// <=): two scans over a + 1 <= 64 SEL_INL_R entries, a lane holding SEL_INL_R consecutive ones.  Stretches with more windows are taken in
+// pieces that overlap by one window, a piece after the first leaving out the arg-min of the window it shares with the piece before
+// it (the rule of sel_push_gap / k_gap_fix).  The hashes: a lane rolls over ceil(n / 64) consecutive k-mers from the direct formula
+// at its first one.  The stretch's minimizers become entries of the slice's own row, between the candidate in front of the stretch
+// and the one behind it: k_gap_fix / k_gap_post / the placing blocks of k_emit never see the stretch.  This is what lets the
+// filter's threshold come down (fewer candidates per window, e^-c of them followed by a stretch).
+struct InlBest {
+    uint64_t h;
+    uint32_t id;  // k-mer of the piece (~0: none)
+};
+// what the lane CTRL names holds (DPP; lanes without a source: "none")
+template <int CTRL, int ROWS>
+__device__ __forceinline__ InlBest inl_dpp(const InlBest v)
+{
+    InlBest o;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)v.h, CTRL, ROWS, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(v.h >> 32), CTRL, ROWS, 0xf, false);
+    o.h = ((uint64_t)hi << 32) | lo;
+    o.id = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v.id, CTRL, ROWS, 0xf, false);
+    return o;
+}
+// Inclusive scan over the lanes, from lane 0 up, of "the smaller hash, the RIGHT one of equals".  OWN_LEFT = false: the lanes hold
+// the segments in order (what comes from a lower lane lies to the left: it wins only with a smaller hash); OWN_LEFT = true: the
+// lanes hold them in REVERSE order (what comes from a lower lane lies to the right: it wins unless the own hash is smaller).
+template <bool OWN_LEFT>
+__device__ __forceinline__ InlBest inl_scan(InlBest v)
+{
+#define MXG_INL_STEP(CTRL, ROWS)                                                   \
+    {                                                                              \
+        const InlBest g = inl_dpp<CTRL, ROWS>(v);                                  \
+        const bool take = OWN_LEFT ? (g.id != 0xFFFFFFFFu && !(v.h < g.h)) : (g.h < v.h); \
+        if (take) v = g;                                                           \
+    }
+    MXG_INL_STEP(0x111, 0xf)  // row_shr:1
+    MXG_INL_STEP(0x112, 0xf)  // row_shr:2
+    MXG_INL_STEP(0x114, 0xf)  // row_shr:4
+    MXG_INL_STEP(0x118, 0xf)  // row_shr:8
+    MXG_INL_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1 and 3
+    MXG_INL_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2 and 3
+#undef MXG_INL_STEP
+    return v;
+}
+__device__ __forceinline__ InlBest inl_lane(const InlBest v, const int src_lane)
+{
+    InlBest o;
+    o.h = __shfl(v.h, src_lane);
+    o.id = __shfl(v.id, src_lane);
+    return o;
+}
+
+// all 64 lanes of one wave; X: 2 amax + 1 words of LDS, tmp: cap_t entries
+// -> entries written to tmp (0: none; ~0: more than cap_t, the stretch goes to k_gap_fix)
+__device__ __forceinline__ uint32_t stretch_sketch(const SelStretchParams &p, const uint4 *byte_tab, const uint4 *rtab, uint64_t *X, uint4 *tmp,
+                                                   const uint32_t cap_t, const uint32_t cg, const uint32_t k_from, const uint32_t k_to,
+                                                   const uint64_t b_from, const bool drop0)
+{
+    const uint32_t lane = threadIdx.x & 63u, w = p.w, amax = p.amax;
+    const uint32_t *__restrict__ packed = p.packed;
+    const uint32_t a_tot = k_to - k_from + 1u - w;
+    uint32_t m = 0;
+    for (uint32_t lo = 0;;) {
+        const uint32_t a = min(a_tot - lo, amax), n = w + a;
+        // ---- exact hashes: front and back part into X, the middle's minimum in registers
+        const uint32_t L = (n + 63u) >> 6;
+        const uint32_t j0 = lane * L, jn = j0 < n ? min(L, n - j0) : 0u;  // the lane's k-mers [j0, j0 + jn)
+        uint64_t mh = ~0ull;
+        uint32_t mj = 0xFFFFFFFFu;
+        // (no branches: every k-mer is stored -- the middle's into a slot nobody reads -- and every k-mer is compared)
+        auto take = [&](const uint32_t jj, const uint64_t h) {
+            const bool mid = jj >= a && jj < w;
+            const uint32_t slot = jj < a ? jj : (mid ? 2u * a + 1u : jj - w + a + 1u);
+            X[slot] = h;
+            const bool better = mid && h <= mh;
+            mh = better ? h : mh;
+            mj = better ? jj : mj;
+        };
+        const uint64_t bl = b_from + lo + j0;  // first base of the lane's first k-mer
+        H2 st = {0u, 0u, 0u, 0u};
+        // 32 rolls at a time from five words requested together (the lane's first k-mer from the first three: init_direct's
+        // formula at k = 32); roll r takes k-mer r to k-mer r + 1: base r leaves, base r + 32 comes in.  Nothing is read behind
+        // the word of the lane's last base.
+        for (uint32_t q = 0; q < L; q += 32u) {  // (wave-uniform; q = 0 also when L = 1)
+            const uint32_t rolls = q + 1u < jn && !(p.ablate & 1u) ? min(32u, jn - 1u - q) : 0u;
+            const uint64_t bq = bl + q;
+            const uint32_t *pw = packed + (bq >> 4);
+            const uint32_t last = jn ? (uint32_t)(((bq + 31u + rolls) >> 4) - (bq >> 4)) : 0u;  // word of the last base needed (>= 1 when jn)
+            uint32_t wd[5] = {0u, 0u, 0u, 0u, 0u};
+            if (jn && (q == 0u || rolls)) {
+                const Words3 v = *reinterpret_cast<const Words3 *>(pw);  // (last >= 1; word 2 exists: the k-mer's bases 32 .. reach it or the pad does)
+                wd[0] = v.w0; wd[1] = v.w1; wd[2] = last >= 2u ? v.w2 : 0u;
+                if (last >= 3u) wd[3] = pw[3];
+                if (last >= 4u) wd[4] = pw[4];
+            }
+            const uint32_t sh = ((uint32_t)bq & 15u) * 2u;
+            if (q == 0u && jn && !(p.ablate & 2u)) {
+                const uint32_t lo16 = __builtin_amdgcn_alignbit(wd[1], wd[0], sh), hi16 = __builtin_amdgcn_alignbit(wd[2], wd[1], sh);
+                uint32_t flo = 0, fhi = 0, tlo = 0, thi = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < 8u; ++u) {
+                    const uint4 e = byte_tab[((u < 4u ? lo16 : hi16) >> (8u * (u & 3u))) & 255u];
+                    srol4(flo, fhi);
+                    sror4(tlo, thi);
+                    flo ^= e.x; fhi ^= e.y; tlo ^= e.z; thi ^= e.w;
+                }
+                srol_var(tlo, thi, 28u);
+                st = {flo, fhi, tlo, thi};
+                take(j0, canonical<MXG_VARIANT_V2_SUM>(st));
+            }
+#pragma unroll
+            for (uint32_t half = 0; half < 2u; ++half) {
+                const uint32_t out16 = __builtin_amdgcn_alignbit(wd[half + 1u], wd[half], sh);
+                const uint32_t in16 = __builtin_amdgcn_alignbit(wd[half + 3u], wd[half + 2u], sh);
+#pragma unroll
+                for (uint32_t t = 0; t < 16u; ++t) {
+                    if (16u * half + t < rolls) {
+                        const uint32_t o = (out16 >> (2u * t)) & 3u, in = (in16 >> (2u * t)) & 3u;
+                        nt_step(st, rtab[o * 4u + in]);
+                        take(j0 + q + 16u * half + t + 1u, canonical<MXG_VARIANT_V2_SUM>(st));
+                    }
+                }
+            }
+        }
+        // the middle's minimum, the rightmost of equals (lanes hold rising k-mers): X[a]
+        InlBest M = inl_scan<false>(InlBest{mh, mj});  // (a lane without a middle k-mer: {~0, none}, never "smaller")
+        M.h = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(M.h >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)M.h, 63);
+        M.id = (uint32_t)__builtin_amdgcn_readlane((int)M.id, 63);
+        if (lane == 0) X[a] = M.h;
+        __builtin_amdgcn_wave_barrier();
+        if (p.ablate & 4u) return M.id == 12345u ? 1u : 0u;
+        // ---- the windows: lane holds windows j = R lane + r
+        const uint32_t R = (a + 64u) >> 6;  // ceil((a + 1) / 64) <= SEL_INL_R
+        InlBest sa[SEL_INL_R], pc[SEL_INL_R];
+        {   // suffix minima of X[j .. a]: a smaller hash on the left wins, an equal one does not
+            InlBest run{~0ull, 0xFFFFFFFFu};
+#pragma unroll
+            for (int r = (int)SEL_INL_R - 1; r >= 0; --r) {
+                const uint32_t j = lane * R + (uint32_t)r;
+                if ((uint32_t)r < R && j <= a) {
+                    const uint64_t x = X[j];
+                    if (run.id == 0xFFFFFFFFu || x < run.h) run = InlBest{x, j < a ? j : M.id};
+                }
+                sa[r] = run;
+            }
+            // the lanes' minima in reverse lane order, scanned from lane 0 up = over the lanes to the right; then one lane on
+            // (the lanes strictly to the right) and back into place
+            const InlBest rev = inl_scan<true>(inl_lane(run, 63 - (int)lane));
+            const InlBest carry = inl_lane(inl_dpp<0x138, 0xf>(rev), 63 - (int)lane);  // (wave_shr:1)
+#pragma unroll
+            for (uint32_t r = 0; r < SEL_INL_R; ++r)
+                if (carry.id != 0xFFFFFFFFu && !(sa[r].id != 0xFFFFFFFFu && sa[r].h < carry.h)) sa[r] = carry;
+        }
+        {   // prefix minima of X[a + 1 .. a + j] (window j holds j k-mers of the back part): the right one of equals wins
+            InlBest run{~0ull, 0xFFFFFFFFu};
+            InlBest own[SEL_INL_R];
+#pragma unroll
+            for (uint32_t r = 0; r < SEL_INL_R; ++r) {
+                const uint32_t j = lane * R + r;
+                if (r < R && j >= 1u && j <= a) {
+                    const uint64_t x = X[a + j];
+                    if (run.id == 0xFFFFFFFFu || x <= run.h) run = InlBest{x, w + j - 1u};
+                }
+                own[r] = run;
+            }
+            const InlBest carry = inl_dpp<0x138, 0xf>(inl_scan<false>(run));  // (the lanes strictly to the left)
+#pragma unroll
+            for (uint32_t r = 0; r < SEL_INL_R; ++r) {
+                pc[r] = own[r];
+                if (carry.id != 0xFFFFFFFFu && (own[r].id == 0xFFFFFFFFu || carry.h < own[r].h)) pc[r] = carry;
+            }
+        }
+        // ---- the windows' arg-mins, every one once, in order
+        uint32_t ids[SEL_INL_R];
+        uint64_t hs[SEL_INL_R];
+#pragma unroll
+        for (uint32_t r = 0; r < SEL_INL_R; ++r) {
+            const bool back = pc[r].id != 0xFFFFFFFFu && !(sa[r].id != 0xFFFFFFFFu && sa[r].h < pc[r].h);
+            ids[r] = back ? pc[r].id : sa[r].id;
+            hs[r] = back ? pc[r].h : sa[r].h;
+        }
+        // the window in front of the lane's first one: the last window of the lane before (all of whose windows exist)
+        uint32_t last = ids[0];
+#pragma unroll
+        for (uint32_t r = 1; r < SEL_INL_R; ++r)
+            if (r < R) last = ids[r];
+        uint32_t prev = (uint32_t)__shfl((int)last, (int)lane - 1);
+        if (lane == 0) prev = 0xFFFFFFFFu;
+        uint32_t cnt = 0;
+        bool em[SEL_INL_R];
+#pragma unroll
+        for (uint32_t r = 0; r < SEL_INL_R; ++r) {
+            const uint32_t j = lane * R + r;
+            // (btllib never reports 2^64 - 1; a piece after the first: its first window belongs to the piece before it)
+            // (the dropped arg-min stays `prev`: the windows behind the first that share it do not report it either)
+            em[r] = r < R && j <= a && ids[r] != prev && hs[r] != ~0ull && !(j == 0u && (lo != 0u || drop0));
+            if (r < R && j <= a) prev = ids[r];
+            cnt += em[r] ? 1u : 0u;
+        }
+        const uint32_t incl = wave_inclusive_dpp(cnt);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (m + tot > cap_t) return 0xFFFFFFFFu;
+        uint32_t at = m + incl - cnt;
+#pragma unroll
+        for (uint32_t r = 0; r < SEL_INL_R; ++r)
+            if (em[r]) tmp[at++] = make_uint4((uint32_t)hs[r], (uint32_t)(hs[r] >> 32), k_from + lo + ids[r], cg);
+        m += tot;
+        __builtin_amdgcn_wave_barrier();  // (X is reused by the next piece)
+        if (lo + a >= a_tot) break;
+        lo += a;
+    }
+    return m;
+}
+
+}  // namespace
+
+// One wave per slice that has stretches: the wave that meets a slice's first request takes them all, the last one first (the row's
+// entries behind a stretch's place move up by the stretch's minimizers), and adds what it put in to the slice's counts.  A stretch's
+// place in the row: behind the entries with a smaller (contig, k-mer) -- the row is in that order.  What this kernel does not take
+// (k-mers of more than one run: invalid bases inside; more than SEL_INL_PIECES pieces; more than SEL_INL_TMP minimizers; a full
+// row) goes on to k_gap_fix.
+constexpr uint32_t SST_WAVES = 4;
+__global__ __launch_bounds__(SST_WAVES * 64, 5) void k_sel_stretch(const SelStretchParams p)
+{
+    __shared__ uint4 byte_tab[256];
+    __shared__ uint4 rtab[16];
+    __shared__ uint64_t Xs[SST_WAVES][2 * 64 * SEL_INL_R];
+    __shared__ uint4 tmps[SST_WAVES][SEL_INL_TMP];
+    const uint32_t n_req = min(p.ctrl[15], p.ireq_cap);
+    if (blockIdx.x * SST_WAVES >= n_req) return;
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) byte_tab[i] = p.byte_tab[i];
+    if (threadIdx.x < 16u) rtab[threadIdx.x] = p.tab.e[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint64_t *X = Xs[wv];
+    uint4 *tmp = tmps[wv];
+    // The requests are handed out one by one: a wave's time goes with what its slices hold, and a launch that deals them out in
+    // advance waits for the unluckiest wave.  64 ticket counters, each on a line of its own, each for every 64th request (adds to
+    // one line are served one after the other, ~10 ns each: ONE counter for 5120 waves and 8000 requests took 130 us).
+    // Everything a request needs is asked for in as few dependent round trips as there are: the slice's requests (whatever
+    // their number: eight entries), then run table and row.
+    uint32_t *const ticket = p.tickets + ((blockIdx.x * SST_WAVES + wv) & 63u) * 32u;
+    for (;;) {
+        uint32_t r = 0;
+        if (lane == 0) r = atomicAdd(ticket, 1u);
+        r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r) * 64u + ((blockIdx.x * SST_WAVES + wv) & 63u);
+        if (r >= n_req) break;
+        const uint4 mine = p.ireq[r + (lane & 7u)];  // (the array has eight entries to spare)
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine.w);
+        if ((w0 >> 24) & 7u) continue;  // (not the slice's first request)
+        if (p.ablate & 8u) continue;
+        const uint32_t n_i = min(w0 >> 27, SEL_REQ), sl = w0 & 0xFFFFFFu;
+        const bool has = lane < n_i;
+        const uint64_t my_key = has ? (((uint64_t)mine.x << 32) | mine.y) + 1ull : 0ull;  // (+ 1: 0 = taken / no request)
+        uint4 *row = p.cs + (size_t)sl * p.rk;
+        uint32_t n_cur = p.cnt[sl];
+        // lane q < n_i: the run of request q's first k-mer
+        uint64_t my_b = 0;
+        bool my_ok = false;
+        if (has) {
+            uint32_t lo = p.ctg_run0[mine.x], hi = p.ctg_run0[mine.x + 1u];
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (p.runs[mid].kidx0 <= mine.y) lo = mid; else hi = mid;
+            }
+            const Run run = p.runs[lo];
+            my_ok = mine.z < run.kidx0 + run.n_kmers && mine.z - mine.y + 1u >= p.w && mine.z - mine.y + 1u - p.w <= p.amax * SEL_INL_PIECES;
+            my_b = run.base_off + (mine.y - run.kidx0);
+        }
+        // the row as the slice kernel left it (rows of up to 128 entries stay in registers: they are moved from there)
+        n_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_cur);
+        uint4 e0 = make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu), e1 = e0;
+        if (lane < n_cur) e0 = row[lane];
+        if (lane + 64u < n_cur) e1 = row[lane + 64u];
+        const bool in_regs = n_cur <= 128u && n_i == 1u;
+        uint32_t added = 0;
+        uint64_t left = my_key;
+        for (uint32_t it = 0; it < n_i; ++it) {
+            // the request with the largest key among those left
+            uint64_t best = left;
+#pragma unroll
+            for (uint32_t d = 1; d < 8u; d <<= 1) {
+                const uint64_t o = __shfl_xor(best, (int)d);
+                best = o > best ? o : best;
+            }
+            best = __shfl(best, 0);
+            const uint64_t holder = __ballot(left == best && best != 0ull);
+            const int src = __builtin_ctzll(holder);
+            if ((int)lane == src) left = 0ull;
+            const uint32_t cg = (uint32_t)__shfl((int)mine.x, src), k_from = (uint32_t)__shfl((int)mine.y, src), k_to = (uint32_t)__shfl((int)mine.z, src);
+            const uint64_t b_from = __shfl(my_b, src);
+            const bool ok = __shfl((int)my_ok, src) != 0;
+            const bool drop0 = k_from == 0u && p.ctg_drop && p.ctg_drop[cg];  // a piece of a record that starts with the halo of the shard before it (k_gap_fix)
+            // the stretch's place: behind the row's entries in front of it (what later stretches of the slice put in lies behind it)
+            const uint64_t key = ((uint64_t)cg << 32) | k_from;
+            uint32_t below = ((((uint64_t)e0.w << 32) | e0.z) < key ? 1u : 0u) + ((((uint64_t)e1.w << 32) | e1.z) < key ? 1u : 0u);
+            for (uint32_t e = lane + 128u; e < n_cur - added; e += 64u) {
+                const uint4 q = row[e];
+                below += ((((uint64_t)q.w << 32) | q.z) < key) ? 1u : 0u;
+            }
+            uint32_t m = ok ? stretch_sketch(p, byte_tab, rtab, X, tmp, SEL_INL_TMP, cg, k_from, k_to, b_from, drop0) : 0xFFFFFFFFu;
+            if (m != 0xFFFFFFFFu && n_cur + m > p.rk) m = 0xFFFFFFFFu;
+            if (m == 0xFFFFFFFFu) {
+                if (lane == 0) push_gap(p.gaps, p.gap_cap, p.ctrl, p.gap_nmax, p.w, cg, k_from, k_to, sl * p.rk);
+                continue;
+            }
+            if (m == 0) continue;
+            const uint32_t at = wave_sum_u32(below);
+            if (in_regs) {
+                if (lane >= at && lane < n_cur) row[lane + m] = e0;
+                if (lane + 64u >= at && lane + 64u < n_cur) row[lane + 64u + m] = e1;
+            } else {
+                for (uint32_t hi = n_cur; hi > at;) {  // from the top, 64 entries at a time: what a pass writes lies above what is still to be read
+                    const uint32_t lo_ = hi > at + 64u ? hi - 64u : at;
+                    const uint32_t x = lo_ + lane;
+                    if (x < hi) {
+                        const volatile uint64_t *sp = reinterpret_cast<const volatile uint64_t *>(row + x);
+                        const uint64_t v0 = sp[0], v1 = sp[1];
+                        row[x + m] = make_uint4((uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32));
+                    }
+                    hi = lo_;
+                }
+            }
+            for (uint32_t t = lane; t < m; t += 64u) row[at + t] = tmp[t];
+            if (it + 1u < n_i) __threadfence_block();  // (a slice's next stretch: the wave's other lanes read what these wrote)
+            n_cur += m;
+            added += m;
+        }
+        if (added && lane == 0) {
+            p.cnt[sl] = n_cur;
+            atomicAdd(&p.sup[(sl >> SUP_SHIFT) * SUP_STRIDE], added);
+        }
+    }
+}
+
+int launch_sel_stretch(mxg_handle *h, const SelStretchParams &p, hipStream_t st)
+{
+    // (the requests are counted on the device: a grid for the i.i.d. expectation's order of magnitude, every wave walks on)
+    hipLaunchKernelGGL(k_sel_stretch, dim3(1280), dim3(SST_WAVES * 64), 0, st, p);
+    MXG_HIP(h, hipGetLastError());
+    return MXG_OK;
+}
+
 size_t bs_select_lds(uint32_t qcap, uint32_t waves) { return (size_t)2048 * 16 + (size_t)waves * sel_wave_lds(qcap) + 16; }  // (+ the block's ticket counter)
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -651,6 +1041,12 @@ uint32_t bs_select_halo(const Assembly *a, uint32_t S, uint32_t w)
     return H;
 }
 
+uint32_t bs_select_inline_amax(uint32_t w)
+{
+    if (w < 16u) return 0u;
+    return std::min<uint32_t>(64u * SEL_INL_R - 1u, w - 1u);
+}
+
 BsSelGeom bs_select_geom(uint32_t S, uint32_t H, uint32_t w, double frac, uint32_t n_strips, uint32_t qcap_force, uint32_t rk_force)
 {
     BsSelGeom g{};
@@ -692,6 +1088,8 @@ int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hi
         const int dev = h->device;
         if (dev < 0 || dev >= MXG_MAX_DEVICES || !attr_set[dev]) {
             const void *fns[] = {reinterpret_cast<const void *>(&k_bs_select<12, 10>), reinterpret_cast<const void *>(&k_bs_select<8, 6>),
+                                 reinterpret_cast<const void *>(&k_bs_select<16, 13>), reinterpret_cast<const void *>(&k_bs_select<16, 15>),
+                                 reinterpret_cast<const void *>(&k_bs_select<20, 16>),
                                  reinterpret_cast<const void *>(&k_bs_select<8, 0>),
                                  reinterpret_cast<const void *>(&k_bs_select<12, 0>), reinterpret_cast<const void *>(&k_bs_select<16, 0>),
                                  reinterpret_cast<const void *>(&k_bs_select<20, 0>), reinterpret_cast<const void *>(&k_bs_select<36, 0>)};
@@ -701,6 +1099,9 @@ int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hi
     }
     if (p.S == 320u) hipLaunchKernelGGL((k_bs_select<12, 10>), grid, block, g.lds, st, p);
     else if (p.S == 192u) hipLaunchKernelGGL((k_bs_select<8, 6>), grid, block, g.lds, st, p);
+    else if (p.S == 416u) hipLaunchKernelGGL((k_bs_select<16, 13>), grid, block, g.lds, st, p);
+    else if (p.S == 480u) hipLaunchKernelGGL((k_bs_select<16, 15>), grid, block, g.lds, st, p);
+    else if (p.S == 512u) hipLaunchKernelGGL((k_bs_select<20, 16>), grid, block, g.lds, st, p);
     else if (nwc <= 8) hipLaunchKernelGGL((k_bs_select<8, 0>), grid, block, g.lds, st, p);
     else if (nwc <= 12) hipLaunchKernelGGL((k_bs_select<12, 0>), grid, block, g.lds, st, p);
     else if (nwc <= 16) hipLaunchKernelGGL((k_bs_select<16, 0>), grid, block, g.lds, st, p);

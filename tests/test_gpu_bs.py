@@ -19,7 +19,7 @@ from tests.test_gpu_scale_paths import _check, _records
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUTE_KNOBS = ("MXG_GAP_POOL", "MXG_BS", "MXG_BS_SELECT", "MXG_SEL_QCAP", "MXG_SEL_RK", "MXG_GAP_WHOLE", "MXG_GAP_DEV_CAP", "MXG_SPARSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S", "MXG_DEV_GAPS")
+ROUTE_KNOBS = ("MXG_GAP_POOL", "MXG_BS", "MXG_BS_SELECT", "MXG_SEL_QCAP", "MXG_SEL_RK", "MXG_GAP_WHOLE", "MXG_GAP_DEV_CAP", "MXG_SPARSE_BATCH_KMERS", "MXG_WAVE_CAP", "MXG_SPARSE_S", "MXG_DEV_GAPS", "MXG_SEL_INLINE")
 
 
 @pytest.fixture
@@ -123,6 +123,27 @@ def test_select_stretch_ends_behind_the_slice(oracle, env):
     for c in (2, 10):
         st = _check(oracle, recs, 32, 1000, cand_per_window=c)
         assert st["select_slices"] > 0
+
+
+@pytest.mark.parametrize("dev_gaps", ["0", "1"])
+def test_stretches_are_sketched_behind_the_slice_kernel(oracle, env, dev_gaps):
+    """few candidates per window on plain random sequence: hundreds of candidate-free stretches just over a window long, between two
+    candidates of a slice, at a contig's start and end, reaching past the slice's strips -- k_sel_stretch sketches them one wave per
+    slice and puts their minimizers into the slice's row (several stretches in one slice: the last one first); with a window of
+    2500 and 3 candidates a stretch is taken in pieces; MXG_SEL_INLINE=0: the same sketch with every stretch through k_gap_fix"""
+    rng = random.Random(77)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    recs = [("a", rnd(700000)), ("b", rnd(1500)), ("c", rnd(1031)), ("d", rnd(300000)), ("n_inside", rnd(40000) + "N" + rnd(50000) + "NNNN" + rnd(800)),
+            ("e", rnd(2200)), ("f", rnd(450000))]
+    env["MXG_SPARSE_S"] = "320"
+    env["MXG_DEV_GAPS"] = dev_gaps
+    for w, c in ((1000, 4), (1000, 7), (300, 3), (2500, 3), (64, 2)):
+        st = _check(oracle, recs, 32, w, cand_per_window=c)
+        assert st["select_slices"] > 0 and st["deferred_stretches"] == 0, (w, c)
+        assert st["slice_stretches"] > 5, (w, c, st["slice_stretches"])
+    env["MXG_SEL_INLINE"] = "0"
+    st = _check(oracle, recs, 32, 1000, cand_per_window=4)
+    assert st["slice_stretches"] == 0
 
 
 def test_low_complexity_stretches_stay_on_the_device(oracle, env):
