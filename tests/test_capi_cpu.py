@@ -34,7 +34,7 @@ def test_struct_sizes_match_header():
     capi, _ = _lib()
     # mxg_config: 6*u32 + ptr + u32 + 5*u32 (with natural alignment) ; mxg_stats layout is mirrored field by field
     assert C.sizeof(capi.Config) == 56
-    assert C.sizeof(capi.Stats) == 8 + 8 * 8 + 3 * 8 + 2 * 8 + 8 * 8 + 5 * 8
+    assert C.sizeof(capi.Stats) == 8 + 8 * 8 + 3 * 8 + 2 * 8 + 8 * 8 + 6 * 8
 
 
 def test_py_repr_double_matches_python():
