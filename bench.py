@@ -832,7 +832,7 @@ def main():
             sel = s2.get("select_slices", 0) > 0   # k_bs_select ran (its time is booked where the other route books count + reorder)
             ker = {"k_hash_bs" if bs else "k_hash_sparse": s2["ms_hash"] / nk,
                    ("k_bs_select" if sel else "k_bs_count+k_bs_reorder_w") if bs else "k_reorder_w": s2["ms_reorder"] / nk,
-                   "k_gap_fix+k_gap_post" if sel else "k_resolve+k_gap_fix+k_gap_post": s2["ms_resolve_kernel"] / nk,
+                   "k_sel_stretch+k_gap_fix+k_gap_post" if sel else "k_resolve+k_gap_fix+k_gap_post": s2["ms_resolve_kernel"] / nk,
                    "k_emit": s2["ms_emit"] / nk, "join (k_pj_* / k_insert+k_flags)": s2["ms_join"] / nk,
                    "k_vertices+k_adjacency": s2["ms_vertices"] / nk, "k_edge_flags+k_edges": s2["ms_edges"] / nk}
             tot = sum(ker.values()) or 1.0
@@ -872,7 +872,7 @@ def main():
             alg = {"filter": ALG_BYTES_PER_BASE_HASH * bases_total, "emit": 16.0 * mx, "join": 18.0 * mx, "graph": 36.0 * mx}
             groups = [("k_hash_bs" if bs else "k_hash_sparse", "filter", ("k_hash_bs", "k_hash_sparse")),
                       (("k_bs_select" if sel else "k_bs_count+k_bs_reorder_w") if bs else "k_reorder_w", None, ("k_bs_select", "k_bs_count", "k_bs_reorder_w", "k_reorder")),
-                      ("k_gap_fix+k_gap_post" if sel else "k_resolve+k_gap_fix+k_gap_post", None, ("k_resolve", "k_gap_fix", "k_gap_post")),
+                      ("k_sel_stretch+k_gap_fix+k_gap_post" if sel else "k_resolve+k_gap_fix+k_gap_post", None, ("k_resolve", "k_sel_stretch", "k_gap_fix", "k_gap_post")),
                       ("k_emit", "emit", ("k_emit",)),
                       ("join (k_pj_* / k_insert+k_flags)", "join", ("k_pj", "k_flags", "k_insert")),
                       ("k_vertices+k_adjacency", "graph", ("k_vertices", "k_adjacency", "k_block_prefix", "k_edge_flags", "k_edges")),

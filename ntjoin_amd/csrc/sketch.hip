@@ -1848,7 +1848,9 @@ static uint32_t choose_sparse_S(const mxg_handle *h, uint64_t total_kmers)
     // the k = 32 route's slice kernel wants w k-mers in a few strips (sketch_bs.h: SEL_MAX_H), whatever the input's size
     const bool sel_route = h->cfg.k == 32 && h->cfg.variant == MXG_VARIANT_V2_SUM && knob_u64(h, "MXG_BS", 1) != 0 &&
                            knob_u64(h, "MXG_BS_SELECT", 1) != 0;
-    if (sel_route && h->cfg.w > 64 * SEL_MAX_H) return 320;
+    // (352 at eight candidates per window: ~186 raw candidates per slice = three rounds of 64 lanes in the slice kernel's hash and
+    // decision phases, nearly full; tools/sweep_cS.sh, round 6: 2.60 / 2.58 / 2.68 ms per step at S = 320 / 352 / 384)
+    if (sel_route && h->cfg.w > 64 * SEL_MAX_H) return knob_u64(h, "MXG_SEL_INLINE", 1) ? 352 : 320;
     const uint64_t lanes = 1024ull * 64;  // SIMDs x lanes
     // small inputs: keep at least ~4 waves per SIMD in flight
     uint64_t S = (total_kmers + lanes * 4 - 1) / (lanes * 4);
@@ -2701,6 +2703,13 @@ struct Driver {
         // (the next assembly's filter may start here; MXG_STAGGER=2, an experiment: behind this batch's emit instead, below)
         const bool late = knob_u64(h, "MXG_STAGGER", 1) == 2;
         if (h->ev_sel_done[slot] && !late) MXG_HIP(h, hipEventRecord(h->ev_sel_done[slot], st));
+        h->stat_sel_slices += b.n_slices;
+        const bool dev = io && io->dev_gaps;
+        if (timing && !fine) {  // the rest of the batch (stretches, emit) as one span
+            if ((rc = ev_end()) != MXG_OK || (rc = ev_begin(0, false, 1)) != MXG_OK) return rc;
+        }
+        if ((rc = ev_next(3)) != MXG_OK) return rc;
+        // (booked with the stretch kernels: the slice kernel's span is its own)
         if (bp.inl_amax) {
             SelStretchParams sp{};
             sp.packed = bp.packed;
@@ -2725,12 +2734,6 @@ struct Driver {
             sp.gap_nmax = bp.gap_nmax;
             if ((rc = launch_sel_stretch(h, sp, st)) != MXG_OK) return rc;
         }
-        h->stat_sel_slices += b.n_slices;
-        const bool dev = io && io->dev_gaps;
-        if (timing && !fine) {  // the rest of the batch (stretches, emit) as one span
-            if ((rc = ev_end()) != MXG_OK || (rc = ev_begin(0, false, 1)) != MXG_OK) return rc;
-        }
-        if ((rc = ev_next(3)) != MXG_OK) return rc;
         if (dev && (rc = enqueue_dev_gaps(a, T, ctrl_host)) != MXG_OK) return rc;
         if (defer_emit && io && !io->wait && !io->base_in && !io->base_out) {
             // the emit is held back (flush_emit): the caller enqueues it behind the NEXT assembly's slice kernel -- enqueued here it
@@ -3175,8 +3178,14 @@ static SparsePlan sparse_plan(const mxg_handle *h, const Assembly *a)
     // measured on MI355X (3 Gbp + 3 Gbp, w=1000, batches of 512 Mi k-mers): 941 / 985 / 945 / 897 Gbp/s at c = 8 / 10 / 12 / 14
     // (w = 500, configs[3], S = 192: 1256 / 1313 / 1342 / 1259 Gbp/s at c = 9 / 10 / 11 / 12 -- candidates are twice as dense as at
     // w = 1000, so are the stretches at a given c, and the stretch kernels' share grows: one candidate more per window pays)
+    // round 6, k = 32 route: the stretches between candidates are sketched by k_sel_stretch right behind the slice kernel (one wave
+    // per slice that has any), so a stretch costs a few us of one wave and c = 8 pays (tools/sweep_cS.sh: 2.74 / 2.62 / 2.60 / 3.05 ms
+    // per step at c = 10 / 8 / 7 / 6 on 3 Gbp + 3 Gbp, w = 1000; configs[3], w = 500: 1421 / 1468 / 1540 / 1579 / 1578 Gbp/s at
+    // c = 11 / 10 / 9 / 8 / 7)
+    const bool inl_route = h->cfg.k == 32 && h->cfg.variant == MXG_VARIANT_V2_SUM && knob_u64(h, "MXG_BS", 1) != 0 &&
+                           knob_u64(h, "MXG_BS_SELECT", 1) != 0 && knob_u64(h, "MXG_SEL_INLINE", 1) != 0;
     const uint32_t c = h->cfg.cand_per_window ? h->cfg.cand_per_window
-                                              : (sp.dev_gaps ? (uint32_t)env_u64(h, "MXG_DEV_CAND", h->cfg.w < 700 ? 11 : 10) : 18u);
+                                              : (sp.dev_gaps ? (uint32_t)env_u64(h, "MXG_DEV_CAND", inl_route ? 8 : (h->cfg.w < 700 ? 11 : 10)) : 18u);
     sp.frac = (double)c / (double)h->cfg.w;
     // even: the threshold then falls on the top 31-bit ring of the hash, which is all the sparse kernel rolls
     sp.tau_hi = std::max(2u, (uint32_t)std::min<double>(4294967294.0, sp.frac * 4294967296.0) & ~1u);

@@ -1088,6 +1088,8 @@ int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hi
         const int dev = h->device;
         if (dev < 0 || dev >= MXG_MAX_DEVICES || !attr_set[dev]) {
             const void *fns[] = {reinterpret_cast<const void *>(&k_bs_select<12, 10>), reinterpret_cast<const void *>(&k_bs_select<8, 6>),
+                                 reinterpret_cast<const void *>(&k_bs_select<8, 5>), reinterpret_cast<const void *>(&k_bs_select<8, 7>),
+                                 reinterpret_cast<const void *>(&k_bs_select<12, 11>), reinterpret_cast<const void *>(&k_bs_select<16, 12>),
                                  reinterpret_cast<const void *>(&k_bs_select<16, 13>), reinterpret_cast<const void *>(&k_bs_select<16, 15>),
                                  reinterpret_cast<const void *>(&k_bs_select<20, 16>),
                                  reinterpret_cast<const void *>(&k_bs_select<8, 0>),
@@ -1099,6 +1101,10 @@ int launch_bs_select(mxg_handle *h, const BsSelParams &p, const BsSelGeom &g, hi
     }
     if (p.S == 320u) hipLaunchKernelGGL((k_bs_select<12, 10>), grid, block, g.lds, st, p);
     else if (p.S == 192u) hipLaunchKernelGGL((k_bs_select<8, 6>), grid, block, g.lds, st, p);
+    else if (p.S == 160u) hipLaunchKernelGGL((k_bs_select<8, 5>), grid, block, g.lds, st, p);
+    else if (p.S == 224u) hipLaunchKernelGGL((k_bs_select<8, 7>), grid, block, g.lds, st, p);
+    else if (p.S == 352u) hipLaunchKernelGGL((k_bs_select<12, 11>), grid, block, g.lds, st, p);
+    else if (p.S == 384u) hipLaunchKernelGGL((k_bs_select<16, 12>), grid, block, g.lds, st, p);
     else if (p.S == 416u) hipLaunchKernelGGL((k_bs_select<16, 13>), grid, block, g.lds, st, p);
     else if (p.S == 480u) hipLaunchKernelGGL((k_bs_select<16, 15>), grid, block, g.lds, st, p);
     else if (p.S == 512u) hipLaunchKernelGGL((k_bs_select<20, 16>), grid, block, g.lds, st, p);
