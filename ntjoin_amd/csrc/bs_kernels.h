@@ -42,10 +42,14 @@ __global__ __launch_bounds__(256) void k_hash_bs(const uint32_t *__restrict__ pa
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
     const uint32_t stride = gridDim.x * 4u, c0 = c_lo + wave, voff256 = lane * 256u, voff128 = lane * 128u;
+    // the transposes' stage 16 goes through LDS (gen/bs_gen.py: swap16_lds): a few KB per wave, the lane's own eight bytes of a slot
+    // at 8 lane + 4 (lane / 16) -- the 32 lanes of one LDS cycle on 32 different banks
+    __shared__ uint32_t bs_lds[4 * (HASH_BS_LDS_PER_WAVE / 4) + 4];
+    const uint32_t vlds = (uint32_t)(uintptr_t)bs_lds + (threadIdx.x >> 6) * (uint32_t)HASH_BS_LDS_PER_WAVE + lane * 8u + (lane >> 4) * 4u;
     asm volatile(HASH_BS_ASM
                  :
                  : [t] "s"(packed), [p] "s"(tail), [hd] "s"(head), [o] "s"(OUT), [c0] "s"(c0), [n] "s"(c_hi), [stride] "s"(stride), [tt] "s"(tt), [ctail] "s"(c_tail),
-                   [voff256] "v"(voff256), [voff128] "v"(voff128)
+                   [voff256] "v"(voff256), [voff128] "v"(voff128), [vlds] "v"(vlds)
                  : HASH_BS_CLOBBERS);
 }
 

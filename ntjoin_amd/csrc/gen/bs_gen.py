@@ -133,6 +133,12 @@ def to_asm(ins):
         regs = f"v[{d}:{d + n - 1}]" if n > 1 else f"v{d}"
         suffix = {4: 'dwordx4', 3: 'dwordx3', 1: 'dword'}[n]
         return f"global_store_{suffix} %[voff128], {regs}, {sp(ins[2])} offset:{ins[3]}"
+    if op == 'dsw16':    # low half of a register -> LDS; the lane's address is operand %[vlds]
+        return f"ds_write_b16 %[vlds], {a[0]} offset:{ins[2]}"
+    if op == 'dsw16hi':  # high half
+        return f"ds_write_b16_d16_hi %[vlds], {a[0]} offset:{ins[2]}"
+    if op == 'dsr32':
+        return f"ds_read_b32 {a[0]}, %[vlds] offset:{ins[2]}"
     if op == 'waitcnt':
         return f"s_waitcnt {ins[1]}"
     if op == 'comment':
@@ -153,6 +159,9 @@ def to_asm(ins):
 # The block stays below 256 registers = two waves per SIMD, which is what the grid is sized for anyway (an odd number of
 # waves per SIMD issues slower than an even one).
 # ---------------------------------------------------------------------------------------------------------------
+LDS_SLOTS = 8              # pairs of the LDS stage in flight per wave (slots are reused in order)
+LDS_SLOT = 528             # bytes per slot: 64 lanes x 8 bytes + 4 bytes per 16 lanes (lane address = 8 lane + 4 (lane / 16): the
+                           # 32 lanes of a read then hit 32 different banks)
 B0 = 8                     # first VGPR of the block (the compiler keeps v0..v7)
 W0 = B0                    # 64 registers
 G0 = W0 + 64               # 31 groups of 4: FP[i], RP[i], bank 2, bank 3
@@ -191,11 +200,13 @@ SEND = S_HD + 2
 
 
 class Gen:
-    def __init__(self, k=32, b_planes=B_PLANES, ablate=()):
+    def __init__(self, k=32, b_planes=B_PLANES, ablate=(), lds16=()):
         """ablate (timing experiments only, tools/bs_ablate.sh -- the results are wrong on purpose): 'loads' = no vector loads in the
         chunk loop (every chunk works on the first one's words) and no waits for them, 'stores' = no result stores"""
         assert k == 32, "strips of 32 k-mers: k = 32 only (other k: k_hash_sparse)"
         self.ablate = set(ablate)
+        self.lds16 = set(lds16) if not isinstance(lds16, bool) else ({'in', 'out'} if lds16 else set())
+        self.lds_slot = 0
         self.k = k
         self.b = b_planes
         self.ins = []
@@ -389,6 +400,25 @@ class Gen:
             for (x, y), t_ in zip(grp_, tmp):
                 e('xor', x, x, t_)
 
+    def swap16_lds(self, pairs):
+        """the stage j = 16 of a transpose (rows k, k + 16 exchange x's high with y's low half) through LDS: no VALU at all.
+        A pair has 8 bytes per lane, [x.lo][y.lo][x.hi][y.hi], written half by half (ds_write_b16 / ds_write_b16_d16_hi) and read
+        back as the two new words.  In registers the stage is lshr, bitop3, xor, SIXTEEN v_add_u32 (the left shift; v_lshlrev_b32
+        is slow class) and xor per pair: 20 of the 8 520 instructions of a chunk x 48 pairs.  The LDS operations of one wave are
+        carried out in order, so the slots are reused without waiting; the caller waits (lgkmcnt) before it uses the registers.
+        Measured on MI355X (round 6, profiles/r06/filter_lds16_ab.txt): 7 576 VALU + 288 LDS operations per chunk run as long as the
+        8 520 VALU of the register version (470-500 us per 3 Gbp launch either way), so the shipped kernel keeps the registers."""
+        e = self.e
+        for (x, y) in pairs:
+            o = LDS_SLOT * (self.lds_slot % LDS_SLOTS)
+            self.lds_slot += 1
+            e('dsw16', x, o)
+            e('dsw16', y, o + 2)
+            e('dsw16hi', x, o + 4)
+            e('dsw16hi', y, o + 6)
+            e('dsr32', x, o)
+            e('dsr32', y, o + 4)
+
     @staticmethod
     def stage_pairs(regs, j):
         return [(regs[k], regs[k + j]) for k in range(32) if not k & j]
@@ -418,10 +448,15 @@ class Gen:
         p16 = [self.stage_pairs(self.RAW[h_], 16) for h_ in (0, 1)]
         for k in range(0, 16, 2):
             e('waitcnt', f'vmcnt({8 - k // 2 if k < 14 else 0})')
-            self.swap_pairs(p16[0][k:k + 2] + p16[1][k:k + 2], 16, S_M16)
+            if 'in' in self.lds16:
+                self.swap16_lds(p16[0][k:k + 2] + p16[1][k:k + 2])
+            else:
+                self.swap_pairs(p16[0][k:k + 2] + p16[1][k:k + 2], 16, S_M16)
         for be in (0, 1):
             self.even_bits(self.QL[be], pa, be)
             self.even_bits(self.QH[be], pb, be)
+        if 'in' in self.lds16:
+            e('waitcnt', 'lgkmcnt(0)')
         for j, sm in ((8, S_M8), (4, S_M4), (2, S_M2), (1, S_M1)):
             self.swap_pairs(self.stage_pairs(self.RAW[0], j) + self.stage_pairs(self.RAW[1], j), j, sm)
 
@@ -434,6 +469,10 @@ class Gen:
         pool = self.temp_pool()
         for j, sm in ((16, S_M16), (8, S_M8), (4, S_M4), (2, S_M2), (1, S_M1)):
             pairs = self.stage_pairs(self.M, j)
+            if j == 16 and 'out' in self.lds16:  # (new_a = [b.lo : a.lo], new_b = [b.hi : a.hi]: the same exchange)
+                self.swap16_lds(pairs)
+                e('waitcnt', 'lgkmcnt(0)')
+                continue
             for i in range(0, len(pairs), width):
                 grp_ = pairs[i:i + width]
                 used = set()
@@ -571,6 +610,7 @@ class VM:
         self.sr = {S_CM + i: (0xFFFFFFFF if (tt >> i) & 1 else 0) for i in range(B_PLANES)}
         self.sr.update({S_M16: 0x0000FFFF, S_M8: 0x00FF00FF, S_M4: 0x0F0F0F0F, S_M2: 0x33333333, S_M1: 0x55555555})
         self.out = np.zeros(2048 + 1, dtype=np.uint32)  # word index + 1 (slot 0 of lane 0 lies in front of the chunk)
+        self.lds = {}  # byte offset of a half word (lane address left out: every lane has its own bytes) -> uint16[64]
 
     def V(self, x):
         if isinstance(x, int):
@@ -643,6 +683,13 @@ class VM:
                 lanes = np.arange(64)
                 for j in range(n):
                     self.out[1 + base + 32 * lanes + ins[3] // 4 + j] = self.vr[f"v{d + j}"]
+            elif op == 'dsw16':
+                self.lds[ins[2]] = (self.V(ins[1]) & U(0xFFFF)).astype(np.uint16)
+            elif op == 'dsw16hi':
+                self.lds[ins[2]] = (self.V(ins[1]) >> U(16)).astype(np.uint16)
+            elif op == 'dsr32':
+                assert ins[2] % 4 == 0
+                self.vr[ins[1]] = self.lds[ins[2]].astype(U) | (self.lds[ins[2] + 2].astype(U) << U(16))
             elif op in ('waitcnt', 'comment'):
                 pass
             else:
@@ -694,17 +741,18 @@ def out_position(c, t, lane, s):
     return c * CHUNK + (32 * lane + s - 1) * 32 + t
 
 
-def emit_inc(path, k, ablate=()):
-    g = Gen(k, ablate=ablate)
+def emit_inc(path, k, ablate=(), lds16=()):
+    g = Gen(k, ablate=ablate, lds16=lds16)
     lines = g.asm()
     n_valu = sum(1 for i in g.ins if i[0] in ('xor', 'and', 'or', 'mov', 'bitop3', 'add', 'lshr'))
     with open(path, 'w') as fh:
         fh.write(f"// GENERATED by gen/bs_gen.py (k = {k}, {B_PLANES} sum planes): the bit-sliced ring filter, chunk loop included.\n")
         fh.write(f"// {n_valu} VALU per chunk of 65 536 base positions per wave, all of them full-rate (see gen/bs_gen.py).  Do not edit.\n")
-        fh.write("// operands: [t] [p] [hd] [o] SGPR pairs (packed bases, padded copies of the last / first chunk, OUT), [c0] [n] [stride] [tt] [ctail] SGPRs, [voff256] VGPR = lane * 256, [voff128] = lane * 128\n")
+        fh.write("// operands: [t] [p] [hd] [o] SGPR pairs (packed bases, padded copies of the last / first chunk, OUT), [c0] [n] [stride] [tt] [ctail] SGPRs, [voff256] VGPR = lane * 256, [voff128] = lane * 128, [vlds] = the lane's LDS address (HASH_BS_LDS_PER_WAVE bytes per wave: 8 lane + 4 (lane / 16))\n")
         fh.write(f"#define HASH_BS_VGPR_END {VEND}\n")
         fh.write(f"#define HASH_BS_VALU_PER_CHUNK {n_valu}\n")
         fh.write(f"#define HASH_BS_PLANES {B_PLANES}\n")
+        fh.write(f"#define HASH_BS_LDS_PER_WAVE {LDS_SLOTS * LDS_SLOT if g.lds16 else 0}\n")
         fh.write("#define HASH_BS_ASM \\\n")
         for ln in lines:
             fh.write(f'    "{ln}\\n" \\\n')
@@ -718,6 +766,7 @@ if __name__ == '__main__':
     ap.add_argument('-k', type=int, default=32)
     ap.add_argument('-o', default='hash_bs_k32.inc')
     ap.add_argument('--ablate', default='', help="comma-separated: loads, stores (timing experiments: tools/bs_ablate.sh)")
+    ap.add_argument('--lds16', default='', help="which transposes' stage 16 goes through LDS instead of registers: in, out, in,out (round 6: 944 VALU instructions fewer per chunk for 288 LDS operations, and no faster -- profiles/r06/filter_lds16_ab.txt)")
     a = ap.parse_args()
-    n, nv = emit_inc(a.o, a.k, tuple(x for x in a.ablate.split(',') if x))
+    n, nv = emit_inc(a.o, a.k, tuple(x for x in a.ablate.split(',') if x), lds16=tuple(x for x in a.lds16.split(',') if x))
     print(f"{a.o}: {n} lines, {nv} VALU per chunk", file=sys.stderr)

@@ -19,11 +19,11 @@ sys.path.insert(0, os.path.join(REPO, "ntjoin_amd", "csrc", "gen"))
 import bs_gen as G  # noqa: E402
 
 
-def _vm_chunk(seed, tt, c, n_chunks=3):
+def _vm_chunk(seed, tt, c, n_chunks=3, **gen_kw):
     rng = np.random.default_rng(seed)
     codes = rng.integers(0, 4, n_chunks * G.CHUNK).astype(np.uint8)
     packed = G.pack_chunks(codes, n_chunks)
-    g = G.Gen(32)
+    g = G.Gen(32, **gen_kw)
     g.chunk()
     c_next = min(c + 1, n_chunks - 1)
     vm = G.VM(packed, tt, c, c_next)
@@ -61,6 +61,16 @@ def test_vm_matches_reference_bits(seed, tt, c):
         assert abs(dens - expect) < 0.15 * expect + 2e-4
 
 
+@pytest.mark.parametrize("lds16", [("in",), ("out",), ("in", "out")])
+def test_vm_with_the_transposes_stage_16_through_lds(lds16):
+    """the generator's variant that exchanges half words through LDS (measured in round 6 and not shipped: profiles/r06/
+    filter_lds16_ab.txt) computes the same bitmap"""
+    _vm_chunk(5, 131, 1, lds16=lds16)
+    g = G.Gen(32, lds16=lds16)
+    g.chunk()
+    assert sum(1 for i in g.ins if i[0] in ("dsw16", "dsw16hi", "dsr32")) == 6 * 16 * (2 * ("in" in lds16) + ("out" in lds16))
+
+
 def test_instruction_classes_and_banks():
     """only instructions of the class that issues at full rate on gfx950 (profiles/ubench/README.md), and three-register
     v_bitop3 operands in three different register banks"""
@@ -69,7 +79,8 @@ def test_instruction_classes_and_banks():
     ops = {i[0] for i in g.ins}
     valu = {"xor", "and", "or", "mov", "bitop3", "add", "lshr"}
     # besides them: loads, waits and the marker where the results of the chunk before are stored -- nothing of the slow class
-    assert ops - valu <= {"gload4", "gload2", "waitcnt", "comment", "prev_stores"}
+    # (... and the LDS stores / loads of the transposes' stage 16: they are not VALU instructions)
+    assert ops - valu <= {"gload4", "gload2", "waitcnt", "comment", "prev_stores", "dsw16", "dsw16hi", "dsr32"}
     assert {i[0] for i in g.store_ins} == {"gstore1", "gstore3", "gstore4"}
     g.check_banks()
     n_valu = sum(1 for i in g.ins if i[0] in valu)
