@@ -437,26 +437,58 @@ def repeat_rich_side_run(cand):
             "what": "bench.py --workload repeats / --workload configs2 --mbp 1000, 10 steps each in processes of their own (never `value`)"}
 
 
+def scaling_fields(wl, W, world, value, bases_total):
+    """N > 1: what one GPU does on the SAME workload (the committed line of `bench.py --workload <wl>` under profiles/, with the commit
+    it was measured at) and value / (N x that).  The default workload differs with N (BASELINE.json names configs[2] for one and two
+    GPUs, configs[3] for four, configs[4] for eight), so value(N) / value(1) of two default lines is not an efficiency; this is."""
+    for rnd in sorted((d for d in os.listdir(os.path.join(REPO, "profiles")) if d.startswith("r0")), reverse=True):
+        path = os.path.join(REPO, "profiles", rnd, f"bench_{wl}.json")
+        if not os.path.exists(path):
+            continue
+        try:
+            one = json.loads([ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1])
+        except Exception:
+            continue
+        c = one.get("config", {})
+        if one.get("n_gpus") != 1 or c.get("w") != W or abs(c.get("bases_per_step", 0) - bases_total) > 0.05 * bases_total:
+            continue  # (another size of the workload)
+        v1 = float(one["value"])
+        return {"one_gpu_same_workload": {"value": v1, "unit": "Gbp/s", "ms_per_step": one.get("ms_per_step"), "from": f"profiles/{rnd}/bench_{wl}.json",
+                                          "kernel_sources_digest": one.get("kernel_sources_digest"), "bases_per_step": c.get("bases_per_step")},
+                "efficiency": round(value / (world * v1), 4),
+                "efficiency_is": f"value / ({world} x one_gpu_same_workload.value): same workload, same sizes, one GPU (committed line; not measured in this run)"}
+    return {"one_gpu_same_workload": None, "efficiency": None,
+            "efficiency_is": f"no committed one-GPU line of workload {wl} under profiles/: run `python bench.py --workload {wl}` on one GPU"}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks here -- one process per GPU, the environment torchrun
     would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT on 127.0.0.1 with a free port) -- hand rank 0's
-    stdout through (its last line is the JSON line), drop the other ranks' stdout, keep everybody's stderr, and end with a
-    non-zero status as soon as any rank does (the others are then stopped: a rank waiting in a collective for a dead one would
-    hang the run).  The driver's own `python -m torch.distributed.run ... bench.py --gpus N` takes the other branch (WORLD_SIZE set)."""
+    stdout through (its last line is the JSON line), drop the other ranks' stdout, and end with a non-zero status as soon as any
+    rank does (the others are then stopped: a rank waiting in a collective for a dead one would hang the run) OR when the run
+    outlives its wall-clock budget (MXG_BENCH_BUDGET_S, default 900 s: a rank stuck inside a collective -- a link that never
+    comes up, a peer that spins -- keeps every status at "running"): the process groups are then stopped and every rank's last
+    stderr lines are printed, so that the one lease a multi-GPU run gets ends with a diagnosis instead of the driver's timeout.
+    Every rank's stderr goes through a file of its own (shown in full for rank 0 at the end, as a tail for the others).
+    The driver's own `python -m torch.distributed.run ... bench.py --gpus N` takes the other branch (WORLD_SIZE set)."""
     import signal
     import socket
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    budget = float(os.environ.get("MXG_BENCH_BUDGET_S", "900"))
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MXG_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "1")
+        errs.append(tempfile.TemporaryFile(mode="w+b"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL, start_new_session=True))
-    rc = 0
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=errs[r], start_new_session=True))
+    rc, why = 0, None
+    t_start = time.perf_counter()
     try:
         live = set(range(n))
         while live:
@@ -466,7 +498,11 @@ def launch_ranks(n):
                     live.discard(r)
                     if c != 0 and rc == 0:
                         rc = c if c > 0 else 1
-                        print(f"bench.py: rank {r} ended with status {c}; stopping the other ranks", file=sys.stderr, flush=True)
+                        why = f"rank {r} ended with status {c}; stopping the other ranks"
+            if rc == 0 and live and time.perf_counter() - t_start > budget:
+                rc = 124
+                why = (f"ranks {sorted(live)} still running after {budget:g} s (MXG_BENCH_BUDGET_S): stuck in a collective or before the "
+                       "rendezvous; stopping every rank")
             if rc:
                 break
             time.sleep(0.05)
@@ -482,6 +518,19 @@ def launch_ranks(n):
                 p.wait(timeout=20)
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, signal.SIGKILL)
+        if why:
+            print(f"bench.py: {why}", file=sys.stderr, flush=True)
+        for r, f in enumerate(errs):
+            f.seek(0)
+            text = f.read().decode("utf-8", "replace")
+            f.close()
+            if not text.strip():
+                continue
+            lines = text.rstrip("\n").splitlines()
+            if rc and (r != 0 or len(lines) > 40):
+                lines = ["..."] + lines[-15:] if len(lines) > 15 else lines
+            if rc or r == 0:
+                print("\n".join(f"[rank {r}] {ln}" for ln in lines), file=sys.stderr, flush=True)
     return rc
 
 
@@ -532,10 +581,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         backend = os.environ.get("MXG_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo only for the one-GPU test
+        # (a collective that does not complete within this ends the rank with an error instead of the default ten minutes)
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get("MXG_BENCH_COLLECTIVE_TIMEOUT_S", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
     from ntjoin_amd import synth
     from ntjoin_amd.engine import MxEngine
@@ -569,8 +621,10 @@ def main():
     eng = MxEngine(k=K, w=W, device=local_rank, timing=True, cand_per_window=args.cand,
                    stream=xstream.cuda_stream if xstream is not None else None)
     bases_job = sum(int(a[2][:, 2].sum()) for a in asms)
-    m_rank = 2e-6 * bases_job / (W + 1) / world  # minimizers per rank, millions (density 2/(w+1))
-    graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("partitioned" if m_rank * (0.14 * world - 0.2) > 0.39 else "union")
+    # the graph route of N > 1: MXG_BENCH_GRAPH names it; else both are tried in the warm-up (two steps each behind a first one that
+    # sets the exchange up) and the faster one -- the same on every rank: the times are max-reduced -- runs the timed steps
+    graph_mode = os.environ.get("MXG_BENCH_GRAPH") or ("measure" if multi else "union")
+    route_trial = None
     if repeats:
         for (name, weight, *_), recs in zip(asms, (ref_recs, tgt_recs)):
             eng.add_records(name, weight, [(f"r{i}", synth.to_ascii5(c)) for i, c in enumerate(recs)])
@@ -584,8 +638,18 @@ def main():
     torch.cuda.synchronize()
     union = None
 
+    n_calls = [0]
+
     def step(e=eng):
         nonlocal union
+        n_calls[0] += 1
+        if multi and n_calls[0] == 2:  # testing: a rank that dies / hangs while its peers wait for it inside the step's collectives
+            if os.environ.get("MXG_BENCH_DIE_IN_STEP") == str(rank):
+                time.sleep(1.0)
+                os._exit(3)
+            if os.environ.get("MXG_BENCH_HANG_RANK") == str(rank):
+                print(f"bench.py: rank {rank} told to hang (MXG_BENCH_HANG_RANK)", file=sys.stderr, flush=True)
+                time.sleep(3600.0)
         if not multi and os.environ.get("MXG_BENCH_FUSED") == "1":
             e.sketch_graph()  # sketches and graph stage in one call with one host sync (measured: no faster)
             return
@@ -605,6 +669,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if graph_mode == "measure":
+        route_trial = {}
+        unions = {}
+        for mode in ("union", "partitioned"):
+            graph_mode, union = mode, None
+            step()                      # (the first step of a route: sizes exchanged, slots laid out)
+            step()
+            fence()
+            t_r = time.perf_counter()
+            step()
+            step()
+            fence()
+            t_mode = torch.tensor([(time.perf_counter() - t_r) / 2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t_mode, op=dist.ReduceOp.MAX)
+            route_trial[mode] = round(float(t_mode[0]) * 1e3, 4)
+            unions[mode] = union
+        graph_mode = min(route_trial, key=route_trial.get)
+        union = unions[graph_mode]
+        for m_, u_ in unions.items():
+            if m_ != graph_mode and u_ is not None:
+                u_.close()
+        del unions
     cold = None
     for i in range(args.warmup):
         if i == 0 and not multi:  # the first pass of a fresh handle (what a one-shot CLI run pays): no candidate counts yet
@@ -654,7 +740,10 @@ def main():
                      "distinct_devices": len({tuple(int(v) for v in d.tolist()) for d in devs}),
                      "launched_by": "bench.py itself (python bench.py --gpus N)" if os.environ.get("MXG_BENCH_SELF_LAUNCHED") == "1"
                                     else "an external launcher (torch.distributed.run)",
-                     "graph_route": graph_mode}
+                     "graph_route": graph_mode,
+                     "graph_route_chosen_by": ("MXG_BENCH_GRAPH" if os.environ.get("MXG_BENCH_GRAPH") else
+                                               {"ms_per_step_in_the_warm_up": route_trial, "rule": "the faster of two warm-up steps per route (max over ranks)"}),
+                     "collective_timeout_s": float(os.environ.get("MXG_BENCH_COLLECTIVE_TIMEOUT_S", "120"))}
 
     st = eng.stats()
     if union is not None and graph_mode == "partitioned":
@@ -711,6 +800,7 @@ def main():
                                        ("graph stage partitioned by hash range (RCCL all-to-all)" if graph_mode == "partitioned"
                                         else "RCCL all-gather of sketches, graph of the union on every rank"))},
             "distributed": dist_info,
+            **(scaling_fields(wl, W, world, value, bases_total) if world > 1 else {}),
             "kernel_sources_digest": kernel_sources_digest(),
             "knobs_in_force": eng.knobs(),  # MXG_* environment switches the handle read and found set ("" = library defaults)
             "resident_input": "2-bit packed bases (0.25 B/bp) as handed over through mxg_add_assembly_packed_device*; every step reads them as they are",

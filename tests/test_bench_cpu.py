@@ -51,3 +51,28 @@ def test_committed_profiles_are_readable():
         assert pj["per_slice"]["valu"] > 0 and pj["per_slice"]["salu"] > 0 and pj["slices_per_launch"] > 0
         m = bench.select_valu_model(0.5, pj["slices_per_launch"])
         assert m is not None and ("stale" in m or 0 < m["frac_of_issue_bound"] < 1.5)
+
+
+def test_scaling_fields_quote_the_same_workload_on_one_gpu():
+    """the N-GPU line's efficiency = value / (N x the committed one-GPU line of the SAME workload and size); another size: no figure"""
+    sys.path.insert(0, REPO)
+    import bench
+    f = bench.scaling_fields("configs2", 1000, 2, 3000.0, 5993199554.0)
+    one = f["one_gpu_same_workload"]
+    assert one and one["from"].startswith("profiles/r0") and one["from"].endswith("bench_configs2.json") and one["value"] > 1000
+    assert abs(f["efficiency"] - 3000.0 / (2 * one["value"])) < 1e-3
+    g = bench.scaling_fields("configs2", 1000, 2, 30.0, 1.0e7)   # (a test-sized run: no committed line of that size)
+    assert g["efficiency"] is None and g["one_gpu_same_workload"] is None and "python bench.py --workload configs2" in g["efficiency_is"]
+
+
+def test_own_launcher_stops_a_run_that_outlives_its_budget(tmp_path):
+    """the launcher's wall-clock budget, without a GPU: a stand-in rank program that sleeps; rc 124, the ranks named, their stderr shown"""
+    sys.path.insert(0, REPO)
+    import bench
+    prog = tmp_path / "sleeper.py"
+    prog.write_text("import os, sys, time\nprint('rank', os.environ['RANK'], 'sleeping', file=sys.stderr, flush=True)\ntime.sleep(600)\n")
+    code = ("import sys, os\nsys.path.insert(0, %r)\nimport bench\nbench.__file__ = %r\nsys.argv = ['bench.py']\n"
+            "os.environ['MXG_BENCH_BUDGET_S'] = '3'\nsys.exit(bench.launch_ranks(2))\n") % (REPO, str(prog))
+    out = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 124, out.stderr[-2000:]
+    assert "still running after 3 s" in out.stderr and "[rank 1] rank 1 sleeping" in out.stderr and "[rank 0] rank 0 sleeping" in out.stderr

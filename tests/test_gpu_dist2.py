@@ -123,6 +123,50 @@ def test_bench_own_ranks_fail_loudly():
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
+def _bench2(extra_env, timeout=600, extra_args=()):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MXG_BENCH_BACKEND="gloo", MXG_BENCH_ONE_DEVICE="1")
+    env.update(extra_env)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mbp", "5",
+           "--no-cpu-baseline", "--no-end-to-end"] + list(extra_args)
+    import time
+    t0 = time.perf_counter()
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+    return out, time.perf_counter() - t0
+
+
+def test_bench_rank_that_dies_inside_a_step():
+    """rank 1 exits while rank 0 waits for it in the step's collectives: the run ends non-zero, at once, with rank 1's status"""
+    out, dt = _bench2({"MXG_BENCH_DIE_IN_STEP": "1", "MXG_BENCH_BUDGET_S": "300"})
+    assert out.returncode == 3, out.stderr[-2000:]
+    assert dt < 200 and "rank 1 ended with status 3" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_rank_that_hangs_runs_into_the_budget():
+    """rank 1 never enters the collective its peer waits in: every status stays "running" -- the wall-clock budget ends the run,
+    names the ranks and shows their last stderr lines (the collective's own timeout, 120 s by default, is the second line of
+    defence: set longer than the budget here so that the budget is what ends the run)"""
+    out, dt = _bench2({"MXG_BENCH_HANG_RANK": "1", "MXG_BENCH_BUDGET_S": "45", "MXG_BENCH_COLLECTIVE_TIMEOUT_S": "600"})
+    assert out.returncode == 124, out.stderr[-2000:]
+    assert dt < 120
+    assert "still running after 45 s" in out.stderr and "[rank 1] bench.py: rank 1 told to hang" in out.stderr
+
+
+def test_bench_line_of_two_ranks_carries_route_trial_and_efficiency_fields():
+    import json
+    out, _ = _bench2({})
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    di = d["distributed"]
+    assert di["graph_route"] in ("union", "partitioned")
+    trial = di["graph_route_chosen_by"]["ms_per_step_in_the_warm_up"]
+    assert set(trial) == {"union", "partitioned"} and di["graph_route"] == min(trial, key=trial.get)
+    assert di["collective_timeout_s"] == 120.0
+    # (5 Mbp is no size a committed one-GPU line exists for: the fields are there and say so)
+    assert "efficiency" in d and "one_gpu_same_workload" in d and "efficiency_is" in d
+
+
 @pytest.mark.parametrize("world,split", [(3, True), (2, False)])
 def test_run_dist_ranks_on_one_gpu(tmp_path, world, split):
     """the torchrun-able FASTA driver with several ranks (gloo, one GPU): with --split the shards are equal base ranges
