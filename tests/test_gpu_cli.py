@@ -383,3 +383,65 @@ def test_make_j_concurrent_indexlr_instances_and_log_time(tmp_path):
     assert [p.wait() for p in procs] == [0] * 6
     for i in range(6):
         assert filecmp.cmp(str(tmp_path / f"c{i}.tsv"), os.path.join(GOLDEN, "cases", meta["name"], asms[i % len(asms)]["tsv"]), shallow=False)
+
+
+def test_mxgraph_back_to_back_and_a_gpu_job_right_behind_the_parent(tmp_path):
+    """`mxgraph` at genome scale (MXG_TEST_E2E_MBP, default 1000 Mbp per assembly: the worker holds ~5 GB of HBM + its pinned buffers
+    when the parent returns): two runs back to back and, the instant the first parent is back, a third GPU process (an `indexlr` of
+    the same reference) -- while the first run's worker is still handing its memory back to the driver.  No failure, no OOM, and
+    every run's outputs are the same bytes; the attached run (MXG_NO_DETACH=1) writes them too."""
+    import hashlib
+    import time
+    import numpy as np
+    from ntjoin_amd import capi, synth
+    mbp = float(os.environ.get("MXG_TEST_E2E_MBP", "1000"))
+    w = 1000
+    lib = capi.load()
+    fas = []
+    for i, (name, seed) in enumerate((("ref.fa", 5), ("tgt.fa", 6))):
+        lens = np.full(12 if i == 0 else 4000, int(mbp * 1e6) // (12 if i == 0 else 4000), dtype=np.uint64)
+        segs, n_words, _ = synth.reference_segments(lens)
+        words = synth.fill_device(segs, n_words, seed).cpu().numpy().view(np.uint32)
+        fa = str(tmp_path / name)
+        rs, rl = np.ascontiguousarray(segs[:, 0]), np.ascontiguousarray(segs[:, 2])
+        assert lib.mxg_synth_write_fasta(fa.encode(), words.ctypes.data, rs.ctypes.data, rl.ctypes.data, len(rl), b"c", 80, 16) == 0
+        del words
+        fas.append(fa)
+    import torch
+    torch.cuda.empty_cache()
+    exe, ilr = os.path.join(BIN_DIR, "mxgraph"), os.path.join(BIN_DIR, "indexlr")
+
+    def run(prefix, env=None):
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "-k32", f"-w{w}", "-t8", "-p", str(tmp_path / prefix), "-s", fas[1], "-l", "1", "-r", "2", fas[0]],
+                           env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return time.perf_counter() - t0
+
+    def digest(prefix):
+        out = []
+        for f in [str(tmp_path / (prefix + ".mx.dot"))] + [f"{fa}.k32.w{w}.tsv" for fa in fas]:
+            hsh = hashlib.sha256()
+            with open(f, "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 24), b""):
+                    hsh.update(blk)
+            out.append(hsh.hexdigest())
+        return out
+
+    t_first = run("a")
+    # the instant the parent is back: another GPU process, and the second run right behind it
+    third = subprocess.Popen([ilr, "--long", "--pos", "-k32", f"-w{w}", "-t8", "-o", str(tmp_path / "third.tsv"), fas[0]], stderr=subprocess.PIPE)
+    d_a = digest("a")
+    t_second = run("b")
+    assert third.wait(timeout=900) == 0, third.stderr.read()[-2000:]
+    d_b = digest("b")
+    assert d_a == d_b
+    t_attached = run("c", {"MXG_NO_DETACH": "1"})
+    assert digest("c") == d_a
+    # the third process's sketch of the reference = the reference's TSV without the sequence column's absence mattering: same line count
+    with open(tmp_path / "third.tsv", "rb") as fh:
+        n_third = sum(1 for _ in fh)
+    with open(f"{fas[0]}.k32.w{w}.tsv", "rb") as fh:
+        n_ref = sum(1 for _ in fh)
+    assert n_third == n_ref == 12
+    print(f"mxgraph at {mbp:g} + {mbp:g} Mbp: detached {t_first:.2f} s, again {t_second:.2f} s, attached {t_attached:.2f} s")
