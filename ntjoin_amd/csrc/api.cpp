@@ -146,6 +146,7 @@ static int commit(mxg_handle *h, Assembly *a, int rc)
         return rc;
     }
     h->asms.push_back(a);
+    if (prewarm_assembly(h, a) != MXG_OK) h->err.clear();  // (what cannot be prepared now is reported by the sketch that needs it)
     h->graph.valid = false;
     h->pj_overflowed = false;
     h->pj_cap1_P1 = 0;

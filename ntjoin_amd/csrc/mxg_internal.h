@@ -365,6 +365,7 @@ struct XchgPackReq {  // mxg_sketch_pack: where the sketches go once they exist 
 int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_graph = false, const XchgPackReq *xp = nullptr);
 int sketch_finish(mxg_handle *h);
 int upload_packed(mxg_handle *h, Assembly *a);
+int prewarm_assembly(mxg_handle *h, Assembly *a);  // tables, output arrays, the filter's bitmap: when the assembly is added
 int sync_sketch_to_host(mxg_handle *h, Assembly *a);
 int write_sketch_bin(mxg_handle *h, Assembly *a, const char *path);  // host_io.cpp
 int load_sketch_bin(mxg_handle *h, Assembly *a, const char *path, std::vector<uint64_t> &hash, std::vector<uint32_t> &pos,

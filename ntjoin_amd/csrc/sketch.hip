@@ -35,6 +35,7 @@
 //                  dense path counts and scans with k_count_n / k_scan_sums)
 //   k_merge        merge of the (small) gap sketch into the batch sketch by (record,pos)
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -3078,8 +3079,19 @@ int upload_packed(mxg_handle *h, Assembly *a)
     return MXG_OK;
 }
 
+// (diagnostics, MXG_DEBUG_COLD=1: host milliseconds between marks -- where a fresh handle's first step goes)
+static void cold_mark_g(const mxg_handle *h, const char *what)
+{
+    static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    if (!knob_set(h, "MXG_DEBUG_COLD")) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[mxg]   . %s: %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
+}
+
 static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
 {
+    cold_mark_g(h, "(prepare_sketch begins)");
     if (!a->has_bases) return set_err(h, MXG_EINVAL, "assembly '%s' has no bases to sketch", a->name.c_str());
     MXG_HIP(h, hipSetDevice(h->device));
     const uint32_t w = h->cfg.w;
@@ -3100,8 +3112,10 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
         *empty = true;
         return MXG_OK;
     }
+    cold_mark_g(h, "upload_packed");
     int rc = prepare_tables(h, a);
     if (rc != MXG_OK) return rc;
+    cold_mark_g(h, "prepare_tables");
     if (!h->d_init_tab.p) {
         std::vector<uint4> it;
         make_init_tab(h->cfg.k, it);
@@ -3135,7 +3149,22 @@ static int prepare_sketch(mxg_handle *h, Assembly *a, Tables &T, bool *empty)
     MXG_HIP(h, a->d_pos.ensure(cap * 4));
     MXG_HIP(h, a->d_rec.ensure(cap * 4));
     MXG_HIP(h, a->d_fwd.ensure(cap));
+    cold_mark_g(h, "init table + output arrays");
     return MXG_OK;
+}
+
+// What a sketch needs of an assembly besides its bases, made when the assembly is ADDED (api.cpp: commit) instead of inside its
+// first sketch: run / strip / contig tables in HBM (nine small uploads, the strip -> run table built on the stream), the output
+// arrays, the filter's bitmap.  A fresh handle's first step spent 1.2 ms of host time on them at 3 Gbp + 3 Gbp before and between
+// its enqueues (MXG_DEBUG_COLD=1), 45 % on top of the step.  Failures are left for the sketch to report.
+int prewarm_assembly(mxg_handle *h, Assembly *a)
+{
+    if (!a->has_bases || a->runs.empty() || !a->d_packed || knob_set(h, "MXG_NO_PREWARM")) return MXG_OK;
+    Tables T;
+    bool empty = false;
+    int rc = prepare_sketch(h, a, T, &empty);
+    if (rc == MXG_OK && !empty && bs_possible(h, a) && knob_u64(h, "MXG_BS", 1) != 0) rc = bs_prepare(h, a);
+    return rc;
 }
 
 // Sparse path: expected c candidates per window; it pays while candidates are a small fraction of k-mers.
@@ -3330,8 +3359,10 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         // tables with short runs between invalid bases take count -> reorder -> resolve behind the same bitmap
         bool use_bs = bs_env && bs_possible(h, list[i]);
         bool sel_ok = use_bs && bs_select && (attempt == 0 || list[i]->sel_again);
+        cold_mark_g(h, "(enqueue_asm begins)");
         if (use_bs) {
             if ((rc = bs_prepare(h, list[i])) != MXG_OK) return rc;
+            cold_mark_g(h, "bs_prepare");
             use_bs = list[i]->bs_ready;
             Assembly *a = list[i];
             if (use_bs && sel_ok && (a->sel_H_S != a->S_sparse || a->sel_H_w != h->cfg.w)) {
@@ -3368,6 +3399,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
             }
             if (sel_ok) break;
         }
+        cold_mark_g(h, "halo + batch geometry");
         if (gs.empty() || (chain_modes && gs.size() > 1) || items.size() + gs.size() >= PINNED_SLOTS - 1) return MXG_OK;
         sel_ok = sel_ok && use_bs;
         hipEvent_t ev_hash = nullptr;
@@ -3478,15 +3510,25 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         q_hi[i] = items.size();
         return MXG_OK;
     };
+    const bool dbg_cold = knob_set(h, "MXG_DEBUG_COLD");  // (diagnostics: where the host's time goes before and between the enqueues)
+    auto t_cold = std::chrono::steady_clock::now();
+    auto cold_mark = [&](const char *what, size_t i) {
+        if (!dbg_cold) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mxg] sketch_assemblies: %s %zu: %.3f ms\n", what, i, std::chrono::duration<double, std::milli>(now - t_cold).count());
+        t_cold = now;
+    };
     for (size_t i = 0; i < n; ++i) {
         item0[i] = items.size();
         bool empty = false;
         if ((rc = prepare_sketch(h, list[i], tabs[i], &empty)) != MXG_OK) return rc;
+        cold_mark("prepare_sketch", i);
         if (empty) {
             state[i] = 2;
             continue;
         }
         if ((rc = enqueue_asm(i, 0)) != MXG_OK) return rc;
+        cold_mark("enqueue_asm", i);
         if (state[i] == 1) ++n_enq;
     }
     for (Driver *od : drvs)  // (the last assembly's emit, held back for an assembly that did not come)
