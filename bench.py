@@ -449,6 +449,54 @@ def repeat_rich_side_run(cand):
             "what": "bench.py --workload repeats / --workload configs2 --mbp 1000, 10 steps each in processes of their own (never `value`)"}
 
 
+def other_k_run(w=1000, mbp=1000.0, steps=10, warmup=3):
+    """`bench.py --other-k`: the routes the headline does not take, on 1 Gbp + 1 Gbp of the configs[2] genome -- k = 24 (no
+    bit-sliced filter: the rolling-hash kernel k_hash_sparse -> k_reorder_w -> k_resolve) and k = 32 with the `min(fwd, rev)`
+    variant (the same kernels; reference ntJoin:33,36: k and w are the user's variables).  One JSON object; never `value`."""
+    import torch
+    from ntjoin_amd.engine import MxEngine
+    torch.cuda.set_device(0)
+    cfg, asms, _ = workload_tables("configs2", mbp, w, seed=1)
+    bases = sum(int(a[2][:, 2].sum()) for a in asms)
+    out = {}
+    for tag, k, variant in (("k24", 24, None), ("k32_min_variant", 32, "v1")):
+        kw = {"variant": variant} if variant else {}
+        eng = MxEngine(k=k, w=w, device=0, timing=True, **kw)
+        keep = [add_rank_share(eng, name, weight, segs, cfg["seed"], sub_seed, sub, 0, 1, 0)[0] for name, weight, segs, _, sub, sub_seed in asms]
+        for _ in range(warmup):
+            eng.sketch(-2)
+            eng.build_graph()
+        eng.reset_timers()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.sketch(-2)
+            eng.build_graph()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = eng.stats()
+        out[tag] = {"k": k, "variant": "min(fwd, rev) (v1)" if variant else "fwd + rev (v2)", "value": round(bases * steps / dt / 1e9, 2), "unit": "Gbp/s",
+                    "ms_per_step": round(dt / steps * 1e3, 4), "minimizers": int(st["minimizers"]), "vertices": int(st["vertices"]), "edges": int(st["edges"]),
+                    "bit_sliced_filter_ran": bool(st["bs_filter_bases"]), "hash_kernel_ms_per_step": round(st["ms_hash"] / steps, 4),
+                    "hash_kernel_frac_of_hbm_roof": round(ALG_BYTES_PER_BASE_HASH * st["hash_kernel_bases"] / max(st["ms_hash"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+                    "batches_redone": int(st["batches_redone"])}
+        eng.close()
+        del keep
+        torch.cuda.empty_cache()
+    out["workload"] = f"configs[2] genome at {mbp / 1000:g} Gbp + {mbp / 1000:g} Gbp, w={w}, weights 2/1, {steps} steps each"
+    out["what"] = "the rolling-hash route (k_hash_sparse -> k_reorder_w -> k_resolve -> k_emit) + the graph stage, in a process of its own; never `value`"
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def other_k_side_run():
+    try:
+        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--other-k"], capture_output=True, text=True, timeout=600)
+        return json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:  # (a side measurement: the headline does not depend on it)
+        return {"error": repr(e)[:200]}
+
+
 def scaling_fields(wl, W, world, value, bases_total):
     """N > 1: what one GPU does on the SAME workload (the committed line of `bench.py --workload <wl>` under profiles/, with the commit
     it was measured at) and value / (N x that).  The default workload differs with N (BASELINE.json names configs[2] for one and two
@@ -565,7 +613,10 @@ def main():
                     help="with --gpus N on ONE GPU and one process: play every rank's share of the N-GPU workload in turn (real sizes, real "
                          "kernels, no collective) and print the per-rank kernel times, the bytes each rank would send and the step time "
                          "they predict -- a prediction to hold the first real N-GPU run against, never a measurement of it")
+    ap.add_argument("--other-k", action="store_true", help="only the side measurement of the routes the headline does not take (k = 24, the min variant)")
     args = ap.parse_args()
+    if args.other_k:
+        return other_k_run()
     if args.dry:
         return dry_run(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1061,6 +1112,7 @@ def main():
                 shutil.rmtree(td, ignore_errors=True)
         if not multi and args.workload == "auto" and not args.no_repeats and not args.mbp:
             out["repeat_rich"] = repeat_rich_side_run(args.cand)
+            out["other_k"] = other_k_side_run()
         result_line = json.dumps(out)
     if multi:
         dist.barrier()

@@ -161,7 +161,11 @@ def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs /root/reference (build container only)")
     subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle")])
-    install_igraph_standin()
+    if os.environ.get("MXG_GOLDEN_REAL_IGRAPH") == "1":  # a box that has python-igraph: the real container (tests/golden/real_igraph/README.md)
+        import igraph  # noqa: F401
+        print("make_golden.py: python-igraph", igraph.__version__, "is the reference's container", file=sys.stderr)
+    else:
+        install_igraph_standin()
     fasta_dir = os.path.join(HERE, "fasta")
     os.makedirs(fasta_dir, exist_ok=True)
     # the reference's own expected outputs for this path (data files its tests hold)
