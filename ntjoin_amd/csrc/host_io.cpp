@@ -915,19 +915,10 @@ bool put_parallel(int fd, uint64_t off, const char *const *data, const size_t *l
     for (uint32_t t = 0; t < n_parts; ++t) at[t + 1] = at[t] + len[t];
     const uint64_t total = at[n_parts] - off;
     if (!total) return true;
-    static const uint64_t page = (uint64_t)sysconf(_SC_PAGESIZE);
-    const uint64_t map_lo = off / page * page;
-    char *m = static_cast<char *>(MAP_FAILED);
-    // (measured on the GPU boxes' /tmp: the mapping is SLOWER there, 1.2-1.35 s against 0.8-0.9 s of pwrite for 1.9 GB of outputs --
-    // write faults on a shared file mapping are no cheaper than the inode lock; it stays an option: MXG_MMAP_OUT=1)
-    if (getenv("MXG_MMAP_OUT") && ftruncate(fd, (off_t)at[n_parts]) == 0)
-        m = static_cast<char *>(mmap(nullptr, at[n_parts] - map_lo, PROT_WRITE, MAP_SHARED, fd, (off_t)map_lo));
+    // (a shared mapping of the file filled by the workers was measured on the GPU boxes' /tmp and dropped: 1.2-1.35 s against
+    // 0.8-0.9 s of pwrite for 1.9 GB of outputs -- write faults on a shared file mapping are no cheaper than the inode lock)
     std::atomic<bool> good{true};
     auto put = [&](uint32_t t) {
-        if (m != MAP_FAILED) {
-            memcpy(m + (at[t] - map_lo), data[t], len[t]);
-            return;
-        }
         size_t done = 0;
         while (done < len[t]) {
             const ssize_t wr = pwrite(fd, data[t] + done, len[t] - done, (off_t)(at[t] + done));
@@ -944,7 +935,6 @@ bool put_parallel(int fd, uint64_t off, const char *const *data, const size_t *l
         put(0);
         for (auto &x : th) x.join();
     }
-    if (m != MAP_FAILED && munmap(m, at[n_parts] - map_lo) != 0) good = false;
     return good;
 }
 

@@ -220,8 +220,8 @@ __global__ __launch_bounds__(256) void k_hash_sparse(const SparseParams p)
     const uint32_t S = p.S;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     __shared__ uint32_t wtot[4];
-    // Block g works on the 256-strip tiles g, g + gridDim.x, ...; by default the grid has one block per tile.  (MXG_HASH_BPC=n
-    // launches n blocks per CU that share the tiles: a residency cap by grid size instead of by unused LDS.  Measured at
+    // Block g works on the 256-strip tiles g, g + gridDim.x, ...; the grid has one block per tile.  (Round 2 tried n persistent
+    // blocks per CU that share the tiles: a residency cap by grid size instead of by unused LDS.  Measured at
     // 3 Gbp: 1231 Gbp/s against 1304 -- with the CU's LDS free, the other stream's kernels move in beside the hash kernel
     // and both run slower than one after the other.)
 #pragma unroll 1
@@ -2381,16 +2381,9 @@ struct Driver {
     }
     // Enqueue one batch completely (hash -> order -> resolve+count -> speculative emit at out.n); the last kernel writes
     // the control block to `ctrl_host` (PINNED host memory); NO host sync.  *n_cap_out = capacity the candidate arrays were sized for.
-    // grid of the hash kernel: one block per tile of 256 strips, or (MXG_HASH_BPC=n, an experiment: see the kernel) about n
-    // blocks per CU with an equal number of tiles each
-    uint32_t sparse_grid(uint32_t n_tiles, uint64_t nk) const
-    {
-        (void)nk;
-        const uint64_t bpc = env_u64(h, "MXG_HASH_BPC", 0);
-        if (bpc == 0 || n_tiles <= 256 * bpc) return n_tiles;
-        const uint32_t rounds = (uint32_t)std::max<uint64_t>(1, (n_tiles + 128 * bpc) / (256 * bpc));  // nearest
-        return (n_tiles + rounds - 1) / rounds;
-    }
+    // grid of the hash kernel: one block per tile of 256 strips (a few persistent blocks per CU with an equal number of tiles each
+    // were an experiment of round 2, measured and dropped)
+    uint32_t sparse_grid(uint32_t n_tiles, uint64_t) const { return n_tiles; }
     // stretches sketched on the device, one block each (results wait in their regions for k_gap_post): reads SC_GAPS / ctrl[1]
     int enqueue_dev_gaps(Assembly *a, const Tables &T, const uint32_t *ctrl_host)
     {
@@ -2506,8 +2499,8 @@ struct Driver {
         // reorder geometry (needed first: the k = 32 route's reorder kernel exists in the one-wave-per-slice form only)
         const uint32_t queue_cap = sp.wave_cap <= 8192 ? sp.wave_cap : 0;
         const size_t q_lds = (size_t)queue_cap * 4;
-        // slices per block (MXG_REORDER_G): the block's byte table is loaded once for all of them
-        const uint32_t r_g = (uint32_t)std::max<uint64_t>(1, env_u64(h, "MXG_REORDER_G", 1));
+        // slices per block of k_reorder: one (two to four, the block's byte table loaded once for all of them, measured slower in round 2)
+        const uint32_t r_g = 1;
         const uint32_t r_grid = (g.n_waves + r_g - 1) / r_g;
         // one wave per slice + position tables when the queues of a block fit beside the 32 KB of tables
         const size_t w_lds = (size_t)2048 * 16 + (size_t)RW_WAVES * queue_cap * 4;

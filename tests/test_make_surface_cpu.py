@@ -75,3 +75,30 @@ def test_log_time_wraps_the_sketch_recipe(tmp_path):
     os.remove(tmp_path / "a.fa.k32.w100.tsv.time")
     subprocess.check_call(["make", "-f", MK, "a.fa.k32.w100.tsv", "k=32", "w=100", "mx_engine=indexlr"], cwd=tmp_path, env=env)
     assert not (tmp_path / "a.fa.k32.w100.tsv.time").exists()
+
+
+def test_readme_lists_every_environment_knob_the_library_reads():
+    """every MXG_* name the sources under ntjoin_amd/csrc read from the environment has a line in README.md's knob table, and the
+    table names nothing that no source (library, Python package, bench.py, tests, tools) reads any more"""
+    import re
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(here, "ntjoin_amd", "csrc")
+    read = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".cpp", ".hip", ".h")):
+            read |= set(re.findall(r'"(MXG_[A-Z0-9_]+)"', open(os.path.join(csrc, f), encoding="utf-8").read()))
+    readme = open(os.path.join(here, "README.md"), encoding="utf-8").read()
+    named = set(re.findall(r"MXG_[A-Z0-9_]+", readme))
+    assert not (read - named), f"knobs the library reads that README.md does not name: {sorted(read - named)}"
+    elsewhere = set()
+    for d, _, files in os.walk(here):
+        if any(part in d for part in (".git", "gpurun_out", "profiles", "__pycache__")):
+            continue
+        for f in files:
+            if f.endswith((".py", ".sh", ".h", "ntJoin-mx")) or f == "ntJoin-mx":
+                try:
+                    elsewhere |= set(re.findall(r"MXG_[A-Z0-9_]+", open(os.path.join(d, f), encoding="utf-8").read()))
+                except (OSError, UnicodeDecodeError):
+                    pass
+    stale = {n for n in named - read - elsewhere if n != "MXG_X"}   # (MXG_X: the placeholder of tools/abenv.sh's usage line)
+    assert not stale, f"README.md names knobs nothing reads: {sorted(stale)}"

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-5 PMC passes over bench.py at a workload (default configs[2]: 3 Gbp + 3 Gbp) on the GPU box: one rocprofv3 run per counter
+# PMC passes over bench.py at a workload (default configs[2]: 3 Gbp + 3 Gbp) on the GPU box: one rocprofv3 run per counter
 # group (--pmc with --kernel-trace only), kernels of the two streams kept apart (MXG_ONE_STREAM=1) so that a kernel's counters are its
 # own.  Per-kernel averages per launch (+ the launches' average duration) -> gpurun_out/<name>/pmc_by_kernel.json.
-#   usage: tools/pmc_r05.sh name [bench args]
+#   usage: tools/pmc_round.sh name [bench args]
 name=${1:-pmc}; shift
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/$name
