@@ -78,7 +78,7 @@ struct SelStretchParams {
     uint32_t *tickets;           // 64 counters, 32 words apart, zero: request 64 t + c is handed out by ticket t of counter c
     uint4 *gaps;
     uint32_t gap_cap, gap_nmax;
-    uint32_t ablate;             // (profiling only, MXG_SST_ABLATE: 1 no rolls, 2 no first hash, 4 no window scans, 8 nothing per request)
+    uint32_t ablate;             // (profiling only, MXG_SST_ABLATE: 1 no rolls, 2 no first hash, 4 no window scans, 8 nothing per request, 32 no row update)
 };
 // the longest piece the window w allows (sketch_bs.hip: stretch_sketch); 0: no stretch is taken this way
 uint32_t bs_select_inline_amax(uint32_t w);

@@ -959,7 +959,7 @@ __global__ __launch_bounds__(SST_WAVES * 64, 5) void k_sel_stretch(const SelStre
                 if (lane == 0) push_gap(p.gaps, p.gap_cap, p.ctrl, p.gap_nmax, p.w, cg, k_from, k_to, sl * p.rk);
                 continue;
             }
-            if (m == 0) continue;
+            if (m == 0 || (p.ablate & 32u)) continue;  // (32, profiling: the stretch sketched, its row left alone)
             const uint32_t at = wave_sum_u32(below);
             if (in_regs) {
                 if (lane >= at && lane < n_cur) row[lane + m] = e0;
