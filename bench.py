@@ -134,7 +134,8 @@ def valu_model(bases_per_launch, avg_ms):
                      "static (generated code: ntjoin_amd/csrc/gen/bs_gen.py), the launch time is this run's"}
 
 
-SELECT_ISSUE_CYCLES = 4.0  # what a wave64 VALU instruction of k_bs_select's mix (compares, shifts, selects, DPP, SDWA) occupies its SIMD
+SELECT_ISSUE_CYCLES = 3.49  # what a wave64 VALU instruction of k_bs_select's mix (47 % slow class: compares, address arithmetic, SDWA) occupies its
+                            # SIMD at four waves per SIMD: MEASURED, profiles/r06/select_issue_ubench.txt (profiles/ubench/select_mix.hip; 4.0 assumed until round 5)
                            # for: the instruction classes measured one at a time in profiles/ubench/README.md -- anything outside the
                            # filter's full-rate class keeps the stream at ~4 cycles per instruction
 ALG_BYTES_PER_MINIMIZER_TUPLE = 16.0  # the (hash, pos, record) tuple a selected minimizer is written as
@@ -173,14 +174,18 @@ def select_valu_model(launch_ms, slices_per_launch):
     per = pj["per_slice"]
     bound_ms = per["valu"] * slices_per_launch / SIMDS * SELECT_ISSUE_CYCLES / CLOCK_HZ * 1e3
     return {"kernel": "k_bs_select", "wave64_instr_per_slice": per, "slices_per_launch": int(slices_per_launch),
-            "cycles_per_valu_instr_measured": pj.get("cycles_per_valu_instr"), "lds_bank_conflict_cycles_per_slice": pj.get("lds_bank_conflict_cycles_per_slice"),
+            "cycles_per_valu_instr_measured": SELECT_ISSUE_CYCLES,
+            "cycles_per_valu_instr_measured_by": "profiles/r06/select_issue_ubench.txt: the kernel's VALU opcode mix as a register-only loop at four waves per SIMD "
+                                                 "(3.49; fast class alone 2.39, slow class alone 4.09)",
+            "wave_cycles_per_valu_instr_in_the_pmc_pass": pj.get("cycles_per_valu_instr"), "lds_bank_conflict_cycles_per_slice": pj.get("lds_bank_conflict_cycles_per_slice"),
             "wait_any_frac_of_wave_cycles": pj.get("wait_any_frac"), "waves_per_simd": pj.get("waves_per_simd"),
             "valu_issue_bound_ms": round(bound_ms, 4), "avg_launch_ms": round(launch_ms, 4),
             "frac_of_issue_bound": round(bound_ms / launch_ms, 4) if launch_ms > 0 else None,
             "source": f"profiles/{PROFILE_ROUND}/configs2_select_pmc.json (commit {pj.get('commit', '?')})",
             "gpu_cycles_per_valu_instr_per_simd_in_the_pmc_pass": pj.get("gpu_cycles_per_valu_instr_per_simd"),
             "model": f"VALU instructions per slice x slices / {SIMDS} SIMDs x {SELECT_ISSUE_CYCLES:g} cycles / {CLOCK_HZ / 1e9:g} GHz: the kernel's "
-                     "instruction mix issues at 4 cycles per wave64 instruction (profiles/ubench), not at the 2 of the filter's fast-class stream"}
+                     "instruction mix (47 % slow class) issues at 3.49 cycles per wave64 instruction, measured (select_issue_ubench.txt), not at the 2.4 "
+                     "of the filter's fast-class stream"}
 
 
 def workload_tables(name, mbp, w, seed=1):
