@@ -46,7 +46,7 @@ sys.path.insert(0, REPO)
 
 K = 32
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r05"   # profiles/<round>/: the committed rocprofv3 summaries static figures are quoted from
+PROFILE_ROUND = "r06"   # profiles/<round>/: the committed rocprofv3 summaries static figures are quoted from
 ALG_BYTES_PER_BASE_HASH = 0.25   # hash kernel: one 2-bit packed base read per base
 ALG_BYTES_PER_MINIMIZER = 70.0   # whole path: sketch tuple + uniqueness + intersection + edge build
 
