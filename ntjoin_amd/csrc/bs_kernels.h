@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void k_hash_bs(const uint32_t *__restrict__ pa
     asm volatile(HASH_BS_ASM
                  :
                  : [t] "s"(packed), [p] "s"(tail), [hd] "s"(head), [o] "s"(OUT), [c0] "s"(c0), [n] "s"(c_hi), [stride] "s"(stride), [tt] "s"(tt), [ctail] "s"(c_tail),
-                   [voff256] "v"(voff256), [voff128] "v"(voff128), [vlds] "v"(vlds)
+                   [voff256] "v"(voff256), [voff128] "v"(voff128), [vlds] "v"(vlds),
+                   [vco0] "v"(lane * 16u), [vco1] "v"(lane * 16u + 4096u), [vco2] "v"(lane * 16u + 8192u), [vco3] "v"(lane * 16u + 12288u)  // (gen/bs_gen.py --ablate coalesced only)
                  : HASH_BS_CLOBBERS);
 }
 

@@ -123,6 +123,9 @@ def to_asm(ins):
         return f"v_lshrrev_b32 {a[0]}, {a[2]}, {a[1]}"
     if op == 'gload4':  # first dst register, base SGPR pair, byte offset; the lane's offset (lane * 256) is operand %[voff256]
         d = int(ins[1][1:])
+        if COALESCED_ABLATION:  # (timing only, wrong words: the 64 lanes of a load read 1 KB in a row -- 8 cache lines instead of 64)
+            k = ins[3] // 16
+            return f"global_load_dwordx4 v[{d}:{d + 3}], %[vco{k // 4}], {sp(ins[2])} offset:{1024 * (k % 4)}"
         return f"global_load_dwordx4 v[{d}:{d + 3}], %[voff256], {sp(ins[2])} offset:{ins[3]}"
     if op == 'gload2':  # the two words in front of the lane's 64: base pair = the chunk's words - 8 bytes
         d = int(ins[1][1:])
@@ -159,6 +162,7 @@ def to_asm(ins):
 # The block stays below 256 registers = two waves per SIMD, which is what the grid is sized for anyway (an odd number of
 # waves per SIMD issues slower than an even one).
 # ---------------------------------------------------------------------------------------------------------------
+COALESCED_ABLATION = False  # --ablate coalesced (tools/bs_bench.hip timing only)
 LDS_SLOTS = 8              # pairs of the LDS stage in flight per wave (slots are reused in order)
 LDS_SLOT = 528             # bytes per slot: 64 lanes x 8 bytes + 4 bytes per 16 lanes (lane address = 8 lane + 4 (lane / 16): the
                            # 32 lanes of a read then hit 32 different banks)
@@ -765,8 +769,9 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('-k', type=int, default=32)
     ap.add_argument('-o', default='hash_bs_k32.inc')
-    ap.add_argument('--ablate', default='', help="comma-separated: loads, stores (timing experiments: tools/bs_ablate.sh)")
+    ap.add_argument('--ablate', default='', help="comma-separated: loads, stores, coalesced (timing experiments: tools/bs_ablate.sh; coalesced = every load's 64 lanes read 1 KB in a row, wrong words)")
     ap.add_argument('--lds16', default='', help="which transposes' stage 16 goes through LDS instead of registers: in, out, in,out (round 6: 944 VALU instructions fewer per chunk for 288 LDS operations, and no faster -- profiles/r06/filter_lds16_ab.txt)")
     a = ap.parse_args()
+    COALESCED_ABLATION = 'coalesced' in a.ablate.split(',')
     n, nv = emit_inc(a.o, a.k, tuple(x for x in a.ablate.split(',') if x), lds16=tuple(x for x in a.lds16.split(',') if x))
     print(f"{a.o}: {n} lines, {nv} VALU per chunk", file=sys.stderr)
