@@ -718,8 +718,11 @@ def main():
             if os.environ.get("MXG_BENCH_HANG_RANK") == str(rank):
                 print(f"bench.py: rank {rank} told to hang (MXG_BENCH_HANG_RANK)", file=sys.stderr, flush=True)
                 time.sleep(3600.0)
-        if not multi and os.environ.get("MXG_BENCH_FUSED") == "1":
-            e.sketch_graph()  # sketches and graph stage in one call with one host sync (measured: no faster)
+        if not multi and os.environ.get("MXG_BENCH_FUSED", "1") != "0":
+            # mxg_sketch_graph: every assembly's sketch and the graph stage in ONE call with one host sync (the graph stage is enqueued
+            # behind the sketches with the counts read on the device); round 6: 1.3 % faster than the two calls (2.57-2.60 against
+            # 2.60-2.63 ms on one box, interleaved), no faster in round 3.  MXG_BENCH_FUSED=0: mxg_sketch(ALL) + mxg_build_graph
+            e.sketch_graph()
             return
         if multi and graph_mode != "partitioned":
             # sketch -> pack -> all-gather -> unpack -> graph of the union, one host sync per step in steady state
@@ -871,6 +874,9 @@ def main():
             **(scaling_fields(wl, W, world, value, bases_total) if world > 1 else {}),
             "kernel_sources_digest": kernel_sources_digest(),
             "knobs_in_force": eng.knobs(),  # MXG_* environment switches the handle read and found set ("" = library defaults)
+            "step_is": ("mxg_sketch_graph(h): every assembly's sketch + the graph stage in one call, one host sync"
+                        if (not multi and os.environ.get("MXG_BENCH_FUSED", "1") != "0") else
+                        ("mxg_sketch(h, MXG_SKETCH_ALL) + mxg_build_graph(h): two calls, two host syncs" if not multi else "sketch + exchange + graph (see distributed)")),
             "resident_input": "2-bit packed bases (0.25 B/bp) as handed over through mxg_add_assembly_packed_device*; every step reads them as they are",
             "step_ms_min_max": [round(min(step_times) * 1e3, 4), round(max(step_times) * 1e3, 4)],
             "roofline": None,  # (filled below: the dominant kernel of the step)
