@@ -552,6 +552,15 @@ int mxg_sketch_graph(mxg_handle *h)
             all_bases = all_bases && a->has_bases;
             if (a->has_bases) todo.push_back(a);
         }
+        // an assembly that takes several batches (more k-mers than one launch of the slice kernel counts: 3600 Mi) cannot keep the graph
+        // stage enqueued behind it -- the one-call mode would send it through the synchronous route (configs[4]: 56 ms per step instead
+        // of 19).  Such handles get the two calls in one: every batch of every assembly through the streams, then the graph stage.
+        bool several = false;
+        for (auto *a : todo) several = several || a->total_kmers > knob_u64(h, "MXG_SEL_BATCH_KMERS", 3600ull << 20);
+        if (all_bases && several) {
+            int rc = sketch_assemblies(h, todo.data(), todo.size());
+            return rc != MXG_OK ? rc : build_graph(h);
+        }
         if (!all_bases) {  // some assembly came as a sketch (TSV, arrays): sketch what has bases, then the ordinary graph stage
             if (!todo.empty()) {
                 int rc = sketch_assemblies(h, todo.data(), todo.size());

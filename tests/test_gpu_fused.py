@@ -128,3 +128,31 @@ def test_fused_with_an_assembly_from_tsv():
         g1, g2 = e1.get_graph(), e2.get_graph()
         for key in g1:
             assert np.array_equal(np.asarray(g1[key]), np.asarray(g2[key])), key
+
+
+def test_fused_call_on_assemblies_of_several_batches():
+    """an assembly with more k-mers than one launch of the slice kernel takes (MXG_SEL_BATCH_KMERS; configs[4]'s 20 Gbp at the
+    default) cannot keep the graph stage enqueued behind it: mxg_sketch_graph then runs every batch of every assembly through
+    the streams and the graph stage behind them -- the same result as the two calls, not the synchronous route (round 6: the
+    bench line of configs[4] took 56 ms per step through it instead of 19)"""
+    from ntjoin_amd import synth
+    from ntjoin_amd.engine import MxEngine
+    ref, tgt = synth.config2(seed=5, n_bases=12_000_000)
+    saved = os.environ.get("MXG_SEL_BATCH_KMERS")
+    os.environ["MXG_SEL_BATCH_KMERS"] = "3000000"
+    try:
+        with MxEngine(k=32, w=1000) as e1, MxEngine(k=32, w=1000) as e2:
+            for e in (e1, e2):
+                _packed(e, "ref", 2.0, ref)
+                _packed(e, "tgt", 1.0, tgt)
+            e1.sketch_graph()
+            e1.sketch_graph()
+            e2.sketch(-2)
+            e2.build_graph()
+            _same(e1, e2, 2)
+            assert e1.stats()["sync_assemblies"] == 0 and e1.stats()["select_slices"] > 0
+    finally:
+        if saved is None:
+            os.environ.pop("MXG_SEL_BATCH_KMERS", None)
+        else:
+            os.environ["MXG_SEL_BATCH_KMERS"] = saved
