@@ -133,6 +133,10 @@ def to_asm(ins):
     if op in ('gstore4', 'gstore3', 'gstore1'):  # first data register, base SGPR pair, byte offset; lane * 128: %[voff128]
         d = int(ins[1][1:])
         n = int(op[-1])
+        if COSTORES_ABLATION and op != 'gstore1':  # (timing only, wrong places: a store's 64 lanes write 1 KB in a row)
+            q = ins[3] // 16
+            regs_ = f"v[{d}:{d + n - 1}]"
+            return f"global_store_{ {4: 'dwordx4', 3: 'dwordx3'}[n]} %[vco{q // 4}], {regs_}, {sp(S_OC + 2)} offset:{1024 * (q % 4)}"
         regs = f"v[{d}:{d + n - 1}]" if n > 1 else f"v{d}"
         suffix = {4: 'dwordx4', 3: 'dwordx3', 1: 'dword'}[n]
         return f"global_store_{suffix} %[voff128], {regs}, {sp(ins[2])} offset:{ins[3]}"
@@ -163,6 +167,7 @@ def to_asm(ins):
 # waves per SIMD issues slower than an even one).
 # ---------------------------------------------------------------------------------------------------------------
 COALESCED_ABLATION = False  # --ablate coalesced (tools/bs_bench.hip timing only)
+COSTORES_ABLATION = False   # --ablate costores (likewise, the result stores)
 LDS_SLOTS = 8              # pairs of the LDS stage in flight per wave (slots are reused in order)
 LDS_SLOT = 528             # bytes per slot: 64 lanes x 8 bytes + 4 bytes per 16 lanes (lane address = 8 lane + 4 (lane / 16): the
                            # 32 lanes of a read then hit 32 different banks)
@@ -773,5 +778,6 @@ if __name__ == '__main__':
     ap.add_argument('--lds16', default='', help="which transposes' stage 16 goes through LDS instead of registers: in, out, in,out (round 6: 944 VALU instructions fewer per chunk for 288 LDS operations, and no faster -- profiles/r06/filter_lds16_ab.txt)")
     a = ap.parse_args()
     COALESCED_ABLATION = 'coalesced' in a.ablate.split(',')
+    COSTORES_ABLATION = 'costores' in a.ablate.split(',')
     n, nv = emit_inc(a.o, a.k, tuple(x for x in a.ablate.split(',') if x), lds16=tuple(x for x in a.lds16.split(',') if x))
     print(f"{a.o}: {n} lines, {nv} VALU per chunk", file=sys.stderr)
