@@ -51,6 +51,7 @@ included) and (2) executed by a numpy model (class VM): tests/test_bs_gen_cpu.py
 formula, so renaming, truth tables and address arithmetic are checked without a GPU.
 """
 import argparse
+import os
 import sys
 
 import numpy as np
@@ -112,24 +113,29 @@ def to_asm(ins):
     op = ins[0]
     a = [fmt_src(x) for x in ins[1:]]
     if op in ('xor', 'and', 'or'):
-        return f"v_{op}_b32 {a[0]}, {a[1]}, {a[2]}"
+        return f"v_{op}_b32{E64} {a[0]}, {a[1]}, {a[2]}"
     if op == 'mov':
-        return f"v_mov_b32 {a[0]}, {a[1]}"
+        return f"v_mov_b32{E64} {a[0]}, {a[1]}"
     if op == 'bitop3':
         return f"v_bitop3_b32 {a[0]}, {a[1]}, {a[2]}, {a[3]} bitop3:{hex(ins[5])}"
+    if op == 'perm':  # v_perm_b32: byte i of dst = byte sel[i] of {src0 (4..7), src1 (0..3)}; the selector in an SGPR
+        return f"v_perm_b32 {a[0]}, {a[1]}, {a[2]}, {a[3]}"
     if op == 'add':
-        return f"v_add_u32 {a[0]}, {a[1]}, {a[2]}"
+        return f"v_add_u32{E64} {a[0]}, {a[1]}, {a[2]}"
     if op == 'lshr':
-        return f"v_lshrrev_b32 {a[0]}, {a[2]}, {a[1]}"
+        return f"v_lshrrev_b32{E64} {a[0]}, {a[2]}, {a[1]}"
+    if op in ('gload4', 'gload2') and LDSLOADS_ABLATION:  # (timing only: the words land in LDS -- and stay there -- instead of the registers)
+        k = ins[3] // 16 if op == 'gload4' else 16
+        return f"s_add_u32 m0, s{S_LB}, {1024 * k}\nglobal_load_lds_{'dwordx4' if op == 'gload4' else 'dword'} %[voff256], {sp(ins[2])} offset:{ins[3]}"
     if op == 'gload4':  # first dst register, base SGPR pair, byte offset; the lane's offset (lane * 256) is operand %[voff256]
         d = int(ins[1][1:])
         if COALESCED_ABLATION:  # (timing only, wrong words: the 64 lanes of a load read 1 KB in a row -- 8 cache lines instead of 64)
             k = ins[3] // 16
             return f"global_load_dwordx4 v[{d}:{d + 3}], %[vco{k // 4}], {sp(ins[2])} offset:{1024 * (k % 4)}"
-        return f"global_load_dwordx4 v[{d}:{d + 3}], %[voff256], {sp(ins[2])} offset:{ins[3]}"
+        return f"global_load_dwordx4 v[{d}:{d + 3}], %[voff256], {sp(ins[2])} offset:{ins[3]}{LOAD_MOD}"
     if op == 'gload2':  # the two words in front of the lane's 64: base pair = the chunk's words - 8 bytes
         d = int(ins[1][1:])
-        return f"global_load_dwordx2 v[{d}:{d + 1}], %[voff256], {sp(ins[2])} offset:{ins[3]}"
+        return f"global_load_dwordx2 v[{d}:{d + 1}], %[voff256], {sp(ins[2])} offset:{ins[3]}{LOAD_MOD}"
     if op in ('gstore4', 'gstore3', 'gstore1'):  # first data register, base SGPR pair, byte offset; lane * 128: %[voff128]
         d = int(ins[1][1:])
         n = int(op[-1])
@@ -139,7 +145,7 @@ def to_asm(ins):
             return f"global_store_{ {4: 'dwordx4', 3: 'dwordx3'}[n]} %[vco{q // 4}], {regs_}, {sp(S_OC + 2)} offset:{1024 * (q % 4)}"
         regs = f"v[{d}:{d + n - 1}]" if n > 1 else f"v{d}"
         suffix = {4: 'dwordx4', 3: 'dwordx3', 1: 'dword'}[n]
-        return f"global_store_{suffix} %[voff128], {regs}, {sp(ins[2])} offset:{ins[3]}"
+        return f"global_store_{suffix} %[voff128], {regs}, {sp(ins[2])} offset:{ins[3]}{STORE_MOD}"
     if op == 'dsw16':    # low half of a register -> LDS; the lane's address is operand %[vlds]
         return f"ds_write_b16 %[vlds], {a[0]} offset:{ins[2]}"
     if op == 'dsw16hi':  # high half
@@ -166,6 +172,10 @@ def to_asm(ins):
 # The block stays below 256 registers = two waves per SIMD, which is what the grid is sized for anyway (an odd number of
 # waves per SIMD issues slower than an even one).
 # ---------------------------------------------------------------------------------------------------------------
+E64 = "_e64" if os.environ.get("BS_E64") == "1" else ""   # experiment: the two-source instructions in their 8-byte encoding (same work, larger code)
+LOAD_MOD = os.environ.get("BS_LOAD_MOD", "")    # cache-policy bits of the loads / stores (experiments: " nt", " sc1", ...)
+STORE_MOD = os.environ.get("BS_STORE_MOD", "")
+LDSLOADS_ABLATION = False   # --ablate ldsloads (timing only: LDS-direct loads, nothing reads the LDS)
 COALESCED_ABLATION = False  # --ablate coalesced (tools/bs_bench.hip timing only)
 COSTORES_ABLATION = False   # --ablate costores (likewise, the result stores)
 LDS_SLOTS = 8              # pairs of the LDS stage in flight per wave (slots are reused in order)
@@ -205,16 +215,21 @@ S_TMP = S0 + 26     # pair
 S_CM = S0 + 28      # B_PLANES compare masks
 S_M16, S_M8, S_M4, S_M2, S_M1 = (S0 + 28 + B_PLANES + i for i in range(5))  # the transpose's select masks
 S_HD = (S_M1 + 2) & ~1   # pair (even register): the padded copy of chunk 0's words
-SEND = S_HD + 2
+S_PA = S_HD + 2      # v_perm_b32 selectors of the transposes' stage 16: [y.lo : x.lo] and [y.hi : x.hi] of (src0 = y, src1 = x)
+S_PB = S_HD + 3
+SEND = S_HD + 4
+S_LB = SEND         # (--ablate ldsloads only: the wave's LDS base)
 
 
 class Gen:
-    def __init__(self, k=32, b_planes=B_PLANES, ablate=(), lds16=()):
+    def __init__(self, k=32, b_planes=B_PLANES, ablate=(), lds16=(), perm16=()):
         """ablate (timing experiments only, tools/bs_ablate.sh -- the results are wrong on purpose): 'loads' = no vector loads in the
         chunk loop (every chunk works on the first one's words) and no waits for them, 'stores' = no result stores"""
         assert k == 32, "strips of 32 k-mers: k = 32 only (other k: k_hash_sparse)"
         self.ablate = set(ablate)
         self.lds16 = set(lds16) if not isinstance(lds16, bool) else ({'in', 'out'} if lds16 else set())
+        self.perm16 = set(perm16)
+        self.warm_pairs = 'nowarmpairs' not in self.ablate
         self.lds_slot = 0
         self.k = k
         self.b = b_planes
@@ -277,8 +292,10 @@ class Gen:
         ra = mA[sa] if sa else None
         rb = mB[sb] if sb else None
         if first:
-            assert ra is None
-            e('mov', dst, rb if rb else 0)
+            if ra is not None and rb is not None:
+                e('xor', dst, ra, rb)
+            else:
+                e('mov', dst, ra or rb or 0)
             self.neg[dst] = c
             return
         self.neg[dst] ^= c
@@ -289,15 +306,17 @@ class Gen:
         else:
             e('bitop3', dst, dst, ra, rb, 0x96)
 
-    def o_stream(self, t):
-        """A[0], A[1] <- the two bit planes of the outgoing base of step t: W[t] moved up by one slot, bit t of Q at the bottom"""
+    def o_stream(self, t, dst=None):
+        """dst[0], dst[1] (default: A) <- the two bit planes of the outgoing base of step t: W[t] moved up by one slot, bit t of
+        Q at the bottom"""
         e = self.e
         tt = self.tt3(lambda a, b2, c: a | (b2 & c))
+        dst = dst or self.A
         for be in (0, 1):
             if t % 16 == 0:
                 e('mov', self.Qr[be], (self.QL if t == 0 else self.QH)[be])
-            e('add', self.A[be], self.W[(t, be)], self.W[(t, be)])
-            e('bitop3', self.A[be], self.A[be], self.Qr[be], 1, tt)
+            e('add', dst[be], self.W[(t, be)], self.W[(t, be)])
+            e('bitop3', dst[be], dst[be], self.Qr[be], 1, tt)
             if t % 16 != 15:
                 e('lshr', self.Qr[be], self.Qr[be], 1)
 
@@ -311,15 +330,30 @@ class Gen:
         self.planes_in()
         e('prev_stores')
         # ---- warm-up: steps n = 0..31: the slot's own strip, i.e. the o-stream (W shifted up by one slot)
-        for n in range(32):
+        # Two steps per pass over the ring: a roll has room for two masks (the productive steps' outgoing and incoming base),
+        # the warm-up has no outgoing base, so steps n and n + 1 share one instruction per plane (masks of n in the A set,
+        # of n + 1 in the B set, which nothing else uses before the first productive step).  The first pair writes the ring
+        # (dst = m1 ^ m2), the others add to it.
+        n = 0
+        while n < 32:
+            if not self.warm_pairs:
+                self.o_stream(n)
+                m1 = self.masks(A)
+                for r in range(31):
+                    self.plane_update(FP[r], None, None, self.fi[(r + n + 1) % 31], m1, first=(n == 0))
+                for r in range(31):
+                    self.plane_update(RP[r], None, None, self.ri[(r - n) % 31], m1, first=(n == 0))
+                n += 1
+                continue
             self.o_stream(n)
-            mB = self.masks(A)
+            m1 = self.masks(A)
+            self.o_stream(n + 1, B)
+            m2 = self.masks(B)
             for r in range(31):
-                jf = (r + n + 1) % 31
-                self.plane_update(FP[r], None, None, self.fi[jf], mB, first=(n == 0))
+                self.plane_update(FP[r], self.fi[(r + n + 1) % 31], m1, self.fi[(r + n + 2) % 31], m2, first=(n == 0))
             for r in range(31):
-                jr = (r - n) % 31
-                self.plane_update(RP[r], None, None, self.ri[jr], mB, first=(n == 0))
+                self.plane_update(RP[r], self.ri[(r - n) % 31], m1, self.ri[(r - n - 1) % 31], m2, first=(n == 0))
+            n += 2
         # ---- productive steps t = 0..31 (n = 32 + t): test the k-mer, then roll
         s, cy, le, ones = self.s, self.cy, self.le, self.ones
         for t in range(32):
@@ -428,6 +462,23 @@ class Gen:
             e('dsr32', x, o)
             e('dsr32', y, o + 4)
 
+    def swap16_perm(self, pairs, width=8):
+        """the stage j = 16 of a transpose as byte permutes: x' = [y.lo : x.lo], y' = [y.hi : x.hi] -- two v_perm_b32 and a move per
+        pair instead of lshr, bitop3, xor, SIXTEEN v_add_u32 and xor.  v_perm_b32 is not of the fast class (profiles/ubench), but
+        three instructions stand for twenty."""
+        e = self.e
+        pool = self.temp_pool()
+        for i in range(0, len(pairs), width):
+            grp_ = pairs[i:i + width]
+            used = set()
+            tmp = [self.pick(pool, used, set()) for _ in grp_]
+            for (x, y), t_ in zip(grp_, tmp):
+                e('perm', t_, y, x, f"s{S_PB}")
+            for (x, y), t_ in zip(grp_, tmp):
+                e('perm', x, y, x, f"s{S_PA}")
+            for (x, y), t_ in zip(grp_, tmp):
+                e('mov', y, t_)
+
     @staticmethod
     def stage_pairs(regs, j):
         return [(regs[k], regs[k + j]) for k in range(32) if not k & j]
@@ -459,6 +510,8 @@ class Gen:
             e('waitcnt', f'vmcnt({8 - k // 2 if k < 14 else 0})')
             if 'in' in self.lds16:
                 self.swap16_lds(p16[0][k:k + 2] + p16[1][k:k + 2])
+            elif 'in' in self.perm16:
+                self.swap16_perm(p16[0][k:k + 2] + p16[1][k:k + 2])
             else:
                 self.swap_pairs(p16[0][k:k + 2] + p16[1][k:k + 2], 16, S_M16)
         for be in (0, 1):
@@ -481,6 +534,9 @@ class Gen:
             if j == 16 and 'out' in self.lds16:  # (new_a = [b.lo : a.lo], new_b = [b.hi : a.hi]: the same exchange)
                 self.swap16_lds(pairs)
                 e('waitcnt', 'lgkmcnt(0)')
+                continue
+            if j == 16 and 'out' in self.perm16:
+                self.swap16_perm(pairs)
                 continue
             for i in range(0, len(pairs), width):
                 grp_ = pairs[i:i + width]
@@ -565,16 +621,21 @@ class Gen:
         for i in range(self.b):  # compare masks: Cm_i = all ones iff bit i of the threshold is set
             A(f"s_bfe_u32 s{S_TMP}, s{S_TT}, {hex((1 << 16) | i)}")
             A(f"s_sub_u32 s{S_CM + i}, 0, s{S_TMP}")
-        for sm, val in ((S_M16, 0x0000FFFF), (S_M8, 0x00FF00FF), (S_M4, 0x0F0F0F0F), (S_M2, 0x33333333), (S_M1, 0x55555555)):
+        for sm, val in ((S_M16, 0x0000FFFF), (S_M8, 0x00FF00FF), (S_M4, 0x0F0F0F0F), (S_M2, 0x33333333), (S_M1, 0x55555555),
+                        (S_PA, 0x05040100), (S_PB, 0x07060302)):
             A(f"s_mov_b32 s{sm}, {hex(val)}")
         A(f"s_cmp_ge_u32 s{S_C}, s{S_N}")
         A("s_cbranch_scc1 L_bs_end_%=")
         # prologue: the first chunk's words
+        if LDSLOADS_ABLATION:
+            A(f"v_readfirstlane_b32 s{S_LB}, %[vlds]")
         A(f"s_mov_b32 s{S_TMP}, s{S_C}")
         self.next_pointers(L, S_TMP)
         for k in range(16):
-            A(to_asm(('gload4', f"v{W0 + 4 * k}", S_TN, 16 * k)))
-        A(to_asm(('gload2', self.Qr[0], S_TQ, 0)))
+            for piece in to_asm(('gload4', f"v{W0 + 4 * k}", S_TN, 16 * k)).split("\n"):
+                A(piece)
+        for piece in to_asm(('gload2', self.Qr[0], S_TQ, 0)).split("\n"):
+            A(piece)
         A("L_bs_loop_%=:")
         self.address_setup(L)
         for ins in body:
@@ -589,6 +650,8 @@ class Gen:
                 self.out_pointers(L)
             elif ins[0] in ('gload4', 'gload2', 'waitcnt') and 'loads' in self.ablate:
                 continue
+            elif ins[0] == 'waitcnt' and 'vmcnt' in ins[1] and 'waits' in self.ablate:  # (the loads stay, nothing waits for them)
+                continue
             elif ins[0] != 'comment':
                 for piece in to_asm(ins).split("\n"):
                     A(piece)
@@ -602,7 +665,7 @@ class Gen:
         return L
 
     def clobbers(self):
-        return [f"v{i}" for i in range(B0, VEND)] + [f"s{i}" for i in range(S0, SEND)] + ["vcc", "scc", "memory"]
+        return [f"v{i}" for i in range(B0, VEND)] + [f"s{i}" for i in range(S0, SEND)] + ["vcc", "scc", "memory"] + (["m0", f"s{S_LB}"] if LDSLOADS_ABLATION else [])
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -617,7 +680,8 @@ class VM:
         self.c, self.cn = c, c_next
         self.vr = {}
         self.sr = {S_CM + i: (0xFFFFFFFF if (tt >> i) & 1 else 0) for i in range(B_PLANES)}
-        self.sr.update({S_M16: 0x0000FFFF, S_M8: 0x00FF00FF, S_M4: 0x0F0F0F0F, S_M2: 0x33333333, S_M1: 0x55555555})
+        self.sr.update({S_M16: 0x0000FFFF, S_M8: 0x00FF00FF, S_M4: 0x0F0F0F0F, S_M2: 0x33333333, S_M1: 0x55555555,
+                        S_PA: 0x05040100, S_PB: 0x07060302})
         self.out = np.zeros(2048 + 1, dtype=np.uint32)  # word index + 1 (slot 0 of lane 0 lies in front of the chunk)
         self.lds = {}  # byte offset of a half word (lane address left out: every lane has its own bytes) -> uint16[64]
 
@@ -670,6 +734,15 @@ class VM:
                 for idx in range(8):
                     if (tt >> idx) & 1:
                         r |= (a if idx & 4 else ~a) & (b if idx & 2 else ~b) & (c if idx & 1 else ~c)
+                self.vr[ins[1]] = r
+            elif op == 'perm':
+                both = (self.V(ins[2]).astype(np.uint64) << np.uint64(32)) | self.V(ins[3]).astype(np.uint64)
+                sel = int(self.V(ins[4])[0]) if not isinstance(self.V(ins[4]), int) else self.V(ins[4])
+                r = np.zeros(64, dtype=U)
+                for i in range(4):
+                    q = (sel >> (8 * i)) & 0xFF
+                    assert q < 8
+                    r |= ((both >> np.uint64(8 * q)) & np.uint64(0xFF)).astype(U) << U(8 * i)
                 self.vr[ins[1]] = r
             elif op == 'add':
                 self.vr[ins[1]] = (self.V(ins[2]) + self.V(ins[3])).astype(U)
@@ -750,10 +823,10 @@ def out_position(c, t, lane, s):
     return c * CHUNK + (32 * lane + s - 1) * 32 + t
 
 
-def emit_inc(path, k, ablate=(), lds16=()):
-    g = Gen(k, ablate=ablate, lds16=lds16)
+def emit_inc(path, k, ablate=(), lds16=(), perm16=()):
+    g = Gen(k, ablate=ablate, lds16=lds16, perm16=perm16)
     lines = g.asm()
-    n_valu = sum(1 for i in g.ins if i[0] in ('xor', 'and', 'or', 'mov', 'bitop3', 'add', 'lshr'))
+    n_valu = sum(1 for i in g.ins if i[0] in ('xor', 'and', 'or', 'mov', 'bitop3', 'add', 'lshr', 'perm'))
     with open(path, 'w') as fh:
         fh.write(f"// GENERATED by gen/bs_gen.py (k = {k}, {B_PLANES} sum planes): the bit-sliced ring filter, chunk loop included.\n")
         fh.write(f"// {n_valu} VALU per chunk of 65 536 base positions per wave, all of them full-rate (see gen/bs_gen.py).  Do not edit.\n")
@@ -761,7 +834,7 @@ def emit_inc(path, k, ablate=(), lds16=()):
         fh.write(f"#define HASH_BS_VGPR_END {VEND}\n")
         fh.write(f"#define HASH_BS_VALU_PER_CHUNK {n_valu}\n")
         fh.write(f"#define HASH_BS_PLANES {B_PLANES}\n")
-        fh.write(f"#define HASH_BS_LDS_PER_WAVE {LDS_SLOTS * LDS_SLOT if g.lds16 else 0}\n")
+        fh.write(f"#define HASH_BS_LDS_PER_WAVE {18 * 1024 if LDSLOADS_ABLATION else LDS_SLOTS * LDS_SLOT if g.lds16 else 0}\n")
         fh.write("#define HASH_BS_ASM \\\n")
         for ln in lines:
             fh.write(f'    "{ln}\\n" \\\n')
@@ -775,9 +848,12 @@ if __name__ == '__main__':
     ap.add_argument('-k', type=int, default=32)
     ap.add_argument('-o', default='hash_bs_k32.inc')
     ap.add_argument('--ablate', default='', help="comma-separated: loads, stores, coalesced (timing experiments: tools/bs_ablate.sh; coalesced = every load's 64 lanes read 1 KB in a row, wrong words)")
+    ap.add_argument('--perm16', default='', help="which transposes' stage 16 is two v_perm_b32 and a move per pair instead of twenty fast-class instructions: in, out, in,out")
     ap.add_argument('--lds16', default='', help="which transposes' stage 16 goes through LDS instead of registers: in, out, in,out (round 6: 944 VALU instructions fewer per chunk for 288 LDS operations, and no faster -- profiles/r06/filter_lds16_ab.txt)")
     a = ap.parse_args()
     COALESCED_ABLATION = 'coalesced' in a.ablate.split(',')
+    LDSLOADS_ABLATION = 'ldsloads' in a.ablate.split(',')
     COSTORES_ABLATION = 'costores' in a.ablate.split(',')
-    n, nv = emit_inc(a.o, a.k, tuple(x for x in a.ablate.split(',') if x), lds16=tuple(x for x in a.lds16.split(',') if x))
+    n, nv = emit_inc(a.o, a.k, tuple(x for x in a.ablate.split(',') if x), lds16=tuple(x for x in a.lds16.split(',') if x),
+                     perm16=tuple(x for x in a.perm16.split(',') if x))
     print(f"{a.o}: {n} lines, {nv} VALU per chunk", file=sys.stderr)

@@ -61,6 +61,14 @@ def test_vm_matches_reference_bits(seed, tt, c):
         assert abs(dens - expect) < 0.15 * expect + 2e-4
 
 
+@pytest.mark.parametrize("kw", [{"perm16": ("in", "out")}, {"perm16": ("out",)}, {"ablate": ("nowarmpairs",)}])
+def test_vm_with_other_generator_options(kw):
+    """generator options that were measured and not shipped (stage 16 of the transposes as v_perm_b32: 800 instructions fewer
+    and slower, profiles/r06/filter_lds16_ab.txt) or that the shipped stream replaced (one warm-up step per pass over the ring)
+    still produce the same bitmap"""
+    _vm_chunk(7, 164, 1, **kw)
+
+
 @pytest.mark.parametrize("lds16", [("in",), ("out",), ("in", "out")])
 def test_vm_with_the_transposes_stage_16_through_lds(lds16):
     """the generator's variant that exchanges half words through LDS (measured in round 6 and not shipped: profiles/r06/

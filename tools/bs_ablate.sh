@@ -6,11 +6,11 @@
 cd "$(dirname "$0")/.."
 mbp=${1:-3000}
 mkdir -p tools/bin /tmp/bs_abl
-for v in full loads stores loads,stores; do
+for v in ${VARIANTS:-full loads stores loads,stores}; do
   name=$(echo $v | tr ',' '_')
   abl=$v; [ "$v" = full ] && abl=""
   python ntjoin_amd/csrc/gen/bs_gen.py -o /tmp/bs_abl/hash_$name.inc --ablate "$abl" 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ntjoin_amd/csrc -I /tmp/bs_abl -DHASH_BS_INC_FILE="\"hash_$name.inc\"" tools/bs_bench.hip -o /tmp/bs_abl/bench_$name 2>/dev/null || { echo "build of $name failed"; continue; }
   echo "== variant: $( [ "$v" = full ] && echo 'the shipped kernel' || echo "without its $v" )"
-  /tmp/bs_abl/bench_$name $mbp | grep -v MISMATCH
+  /tmp/bs_abl/bench_$name $mbp 164 $PROBE | grep -v MISMATCH
 done

@@ -38,6 +38,16 @@ static bool ref_bit(const std::vector<uint32_t> &w, uint64_t p, uint32_t tt, int
     return St <= tt || St >= (1u << b) - 2u;
 }
 
+// one wave that sleeps `iters` times 127 x 64 shader clocks and reports how long that took on the constant 100 MHz counter: the
+// shader clock while the filter runs beside it (s_sleep counts shader clocks whatever else the SIMD does)
+__global__ void k_clock_probe(uint64_t *out, uint32_t iters)
+{
+    const uint64_t w0 = wall_clock64();
+    for (uint32_t i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(127);
+    const uint64_t w1 = wall_clock64();
+    if (threadIdx.x == 0) out[blockIdx.x] = w1 - w0;
+}
+
 int main(int argc, char **argv)
 {
     const double mbp = argc > 1 ? atof(argv[1]) : 3000.0;
@@ -84,6 +94,29 @@ int main(int argc, char **argv)
     }
     printf("verify: %s (%llu candidates in 4 chunks)\n", bad ? "FAILED" : "ok", (unsigned long long)total);
     const double kmers = (double)n_chunks * 65536.0;
+    if (argc > 3) {  // bs_bench Mbp tt probe: the shader clock with and without the filter running
+        hipStream_t s2;
+        CK(hipStreamCreate(&s2));
+        uint64_t *dW, hW[8];
+        CK(hipMalloc(&dW, sizeof(hW)));
+        const uint32_t iters = 1500;
+        for (int with : {0, 1, 0, 1}) {
+            CK(hipDeviceSynchronize());
+            hipLaunchKernelGGL(k_clock_probe, dim3(8), dim3(64), 0, s2, dW, iters);
+            if (with)
+                for (int r = 0; r < 12; ++r)
+                    hipLaunchKernelGGL(mxg::k_hash_bs, dim3(512), dim3(256), 0, 0, dp, dHead, dTail, dO, 0u, n_chunks, tt, n_chunks - 1);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(hW, dW, sizeof(hW), hipMemcpyDeviceToHost));
+            double lo = 1e30, hi = 0;
+            for (uint64_t v : hW) {
+                const double mhz = (double)iters * 127.0 * 64.0 / ((double)v / 100.0);  // clocks per us
+                lo = mhz < lo ? mhz : lo;
+                hi = mhz > hi ? mhz : hi;
+            }
+            printf("shader clock %s: %.0f - %.0f MHz over %.2f ms (8 probe waves)\n", with ? "with the filter running" : "on an idle GPU        ", lo, hi, (double)hW[0] / 100e3);
+        }
+    }
     for (int blocks : {256, 512, 768, 1024}) {
         hipLaunchKernelGGL(mxg::k_hash_bs, dim3(blocks), dim3(256), 0, 0, dp, dHead, dTail, dO, 0u, n_chunks, tt, n_chunks - 1);
         CK(hipDeviceSynchronize());
