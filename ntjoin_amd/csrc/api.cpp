@@ -103,6 +103,8 @@ void mxg_destroy(mxg_handle *h)
     h->asms.clear();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (hipEvent_t e : h->ev_part)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_bs) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_sel_done)
@@ -532,6 +534,34 @@ int mxg_sketch_pack(mxg_handle *h, void *d_slot, uint64_t head_bytes, const uint
     }
 }
 
+int mxg_sketch_pack_parts(mxg_handle *h, void *const *d_parts, const uint64_t *caps)
+{
+    if (!h || !d_parts || !caps) return MXG_EINVAL;
+    if (!h->pend_list.empty()) return set_err(h, MXG_EINVAL, "mxg_sketch_pack_parts: the previous call was not finished (mxg_sketch_finish)");
+    try {
+        std::vector<Assembly *> todo;
+        for (auto *a : h->asms) {
+            if (!a->has_bases) return set_err(h, MXG_EINVAL, "mxg_sketch_pack_parts: assembly '%s' has no bases", a->name.c_str());
+            if (!d_parts[todo.size()]) return MXG_EINVAL;
+            todo.push_back(a);
+        }
+        if (todo.empty()) return set_err(h, MXG_EINVAL, "mxg_sketch_pack_parts: no assemblies");
+        XchgPackReq xp{nullptr, 0, caps, d_parts};
+        return sketch_assemblies(h, todo.data(), todo.size(), false, &xp);
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_sketch_pack_parts");
+    }
+}
+
+int mxg_part_packed_wait(mxg_handle *h, int assembly, void *stream)
+{
+    if (!h || assembly < 0 || (size_t)assembly >= h->asms.size() || assembly >= MXG_MAX_ASSEMBLIES) return MXG_EINVAL;
+    if (!h->ev_part[assembly]) return set_err(h, MXG_EINVAL, "mxg_part_packed_wait: no mxg_sketch_pack_parts before");
+    MXG_HIP(h, hipSetDevice(h->device));
+    MXG_HIP(h, hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_part[assembly], 0));
+    return MXG_OK;
+}
+
 int mxg_sketch_finish(mxg_handle *h)
 {
     if (!h) return MXG_EINVAL;
@@ -645,6 +675,15 @@ int mxg_xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint
 {
     if (!h || !d_all || !caps || !rec_offsets) return MXG_EINVAL;
     return xchg_unpack_graph(h, d_all, world, slot_bytes, head_bytes, caps, rec_offsets);
+}
+
+int mxg_xchg_unpack_graph_parts(mxg_handle *h, const void *const *d_all_parts, uint32_t world, const uint64_t *caps,
+                                const uint64_t *rec_offsets)
+{
+    if (!h || !d_all_parts || !caps || !rec_offsets) return MXG_EINVAL;
+    for (size_t a = 0; a < h->asms.size(); ++a)
+        if (!d_all_parts[a]) return MXG_EINVAL;
+    return xchg_unpack_graph(h, nullptr, world, 0, 0, caps, rec_offsets, d_all_parts);
 }
 
 int mxg_set_sketch_device(mxg_handle *h, int assembly, const void *d_out_hash, const void *d_pos,

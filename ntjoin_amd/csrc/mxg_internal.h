@@ -221,6 +221,7 @@ struct mxg_handle {
     mxg::DevBuf d_chain;            // pipelined batches: where the next batch of an assembly starts in its sketch (u64 per batch)
     std::vector<hipEvent_t> ev_sync;  // ... and the events by which a batch waits for its predecessor on the other stream
     hipEvent_t ev_join = nullptr;   // ... and the event that joins the second stream into the first
+    hipEvent_t ev_part[MXG_MAX_ASSEMBLIES] = {};  // mxg_sketch_pack_parts: assembly a's part is packed
     mxg::DevBuf dbg_buf;            // (profiling: MXG_BSR_DBG)
     uint32_t dbg_blocks = 0;
     std::vector<hipEvent_t> ev_bs;  // k = 32 route: "the assembly's filter has run" (batches on other streams wait for it)
@@ -361,7 +362,11 @@ struct XchgPackReq {  // mxg_sketch_pack: where the sketches go once they exist 
     void *d_slot;
     uint64_t head_bytes;
     const uint64_t *caps;
+    // mxg_sketch_pack_parts: one buffer per assembly instead, [64 bytes: int64 count | caps[a] entries], packed right behind that
+    // assembly's own k_emit on the stream it ran on, with an event the caller's communication stream can wait for (ev_part)
+    void *const *d_parts = nullptr;
 };
+constexpr uint64_t XCHG_PART_HEAD = 64;
 int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_graph = false, const XchgPackReq *xp = nullptr);
 int sketch_finish(mxg_handle *h);
 int upload_packed(mxg_handle *h, Assembly *a);
@@ -384,7 +389,7 @@ int build_graph(mxg_handle *h, int mode = GRAPH_FULL, const void *d_msgs = nullp
                 const GraphBounds *gb = nullptr);
 int xchg_pack(mxg_handle *h, void *d_slot, uint64_t head_bytes, const uint64_t *caps);
 int xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t slot_bytes, uint64_t head_bytes,
-                      const uint64_t *caps, const uint64_t *rec_offsets);
+                      const uint64_t *caps, const uint64_t *rec_offsets, const void *const *d_all_parts = nullptr);
 int graph_to_host(mxg_handle *h);
 int find_paths(mxg_handle *h, int64_t n_min);  // paths.hip
 // dgraph.hip

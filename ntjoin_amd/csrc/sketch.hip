@@ -3503,6 +3503,23 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         q_hi[i] = items.size();
         return MXG_OK;
     };
+    auto pack_part = [&](size_t i, hipStream_t st, Driver *drv, uint32_t place4) -> int {
+        Assembly *a = list[i];
+        const uint64_t cap = xp->caps[i];
+        const uint64_t out_cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
+        const long long fixed = state[i] == 1 ? -2ll : (state[i] == 2 ? 0ll : -1ll);
+        const uint32_t grid = state[i] == 1 ? (uint32_t)std::max<uint64_t>((cap + 255) / 256, 1) : 1u;
+        unsigned char *part = static_cast<unsigned char *>(xp->d_parts[i]);
+        MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
+        hipLaunchKernelGGL(k_pack_slot_dev, dim3(grid), dim3(256), 0, st, a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(),
+                           a->d_rec.as<uint32_t>(), h->d_nmx.as<uint32_t>() + i,
+                           drv ? drv->sc(SC_CTRL).as<uint32_t>() : h->d_nmx.as<uint32_t>(), out_cap, cap, fixed,
+                           reinterpret_cast<long long *>(part), part + XCHG_PART_HEAD, state[i] == 1 && plans[i].dev_gaps ? 1u : 0u, place4);
+        MXG_HIP(h, hipGetLastError());
+        if (!h->ev_part[i]) MXG_HIP(h, hipEventCreateWithFlags(&h->ev_part[i], hipEventDisableTiming));
+        MXG_HIP(h, hipEventRecord(h->ev_part[i], st));
+        return MXG_OK;
+    };
     const bool dbg_cold = knob_set(h, "MXG_DEBUG_COLD");  // (diagnostics: where the host's time goes before and between the enqueues)
     auto t_cold = std::chrono::steady_clock::now();
     auto cold_mark = [&](const char *what, size_t i) {
@@ -3523,6 +3540,12 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         if ((rc = enqueue_asm(i, 0)) != MXG_OK) return rc;
         cold_mark("enqueue_asm", i);
         if (state[i] == 1) ++n_enq;
+        if (xp && xp->d_parts && state[i] == 1) {
+            // mxg_sketch_pack_parts: this assembly's part right behind its k_emit, on the stream that ran it -- the caller's
+            // all-gather of the part travels while the next assembly is sketched
+            const Item &it = items[q_lo[i]];
+            if ((rc = pack_part(i, drvs[it.slot]->st, drvs[it.slot], it.place4)) != MXG_OK) return rc;
+        }
     }
     for (Driver *od : drvs)  // (the last assembly's emit, held back for an assembly that did not come)
         if ((rc = od->flush_emit(nullptr)) != MXG_OK) return rc;
@@ -3541,7 +3564,9 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
         unsigned char *base = static_cast<unsigned char *>(xp->d_slot);
         uint64_t off = xp->head_bytes;
-        for (size_t i = 0; i < n; ++i) {
+        for (size_t i = 0; xp->d_parts && i < n; ++i)  // (parts: what was enqueued is packed already; the others say 0 / -1)
+            if (state[i] != 1 && (rc = pack_part(i, h->stream, nullptr, 0)) != MXG_OK) return rc;
+        for (size_t i = 0; !xp->d_parts && i < n; ++i) {
             Assembly *a = list[i];
             const uint64_t cap = xp->caps[i];
             const uint64_t out_cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
@@ -4031,7 +4056,7 @@ __global__ __launch_bounds__(256) void k_unpack_slot(const UnpackSlotParams p)
 // returns 1 (nothing usable: some sketch did not fit its slot on some rank, the caller exchanges sizes first) or the
 // result of build_graph
 int xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t slot_bytes, uint64_t head_bytes,
-                      const uint64_t *caps, const uint64_t *rec_offsets)
+                      const uint64_t *caps, const uint64_t *rec_offsets, const void *const *d_all_parts)
 {
     if (world == 0 || world > 64) return set_err(h, MXG_ELIMIT, "world size must be 1..64");
     const size_t A = h->asms.size();
@@ -4052,12 +4077,12 @@ int xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t
         MXG_HIP(h, a->d_pos.ensure(std::max<uint64_t>(bound * 4, 16)));
         MXG_HIP(h, a->d_rec.ensure(std::max<uint64_t>(bound * 4, 16)));
         UnpackSlotParams up;
-        up.all = static_cast<const unsigned char *>(d_all);
-        up.slot_bytes = slot_bytes;
-        up.region_off = off;
+        up.all = static_cast<const unsigned char *>(d_all_parts ? d_all_parts[ai] : d_all);
+        up.slot_bytes = d_all_parts ? XCHG_PART_HEAD + 16 * caps[ai] : slot_bytes;
+        up.region_off = d_all_parts ? XCHG_PART_HEAD : off;
         up.cap = caps[ai];
         up.world = world;
-        up.a = (uint32_t)ai;
+        up.a = d_all_parts ? 0u : (uint32_t)ai;
         for (uint32_t r = 0; r < world; ++r) up.rec_off[r] = (uint32_t)rec_offsets[ai * world + r];
         up.hash = a->d_hash.as<uint64_t>();
         up.pos = a->d_pos.as<uint32_t>();

@@ -205,8 +205,50 @@ def _allgather_union_graph(eng, k, w, device, union, group, stream):
                     "rec_off_flat": np.concatenate([np.concatenate([[0], np.cumsum(metas[:, a, 1])[:-1]]) for a in range(A)]).astype(np.uint64),
                     "send": torch.zeros(slot, dtype=torch.uint8, device=dev),
                     "recv": torch.empty(world * slot, dtype=torch.uint8, device=dev)}
+    if overlap_exchange():
+        # one buffer per assembly (64-byte header + its region): assembly a's all-gather is issued on a stream of its own as soon
+        # as a's sketch is packed, and travels while assembly a + 1 is sketched (sketch_union_graph)
+        union._slots["send_parts"] = [torch.zeros(PART_HEAD + 16 * c, dtype=torch.uint8, device=dev) for c in caps]
+        union._slots["recv_parts"] = [torch.empty(world * (PART_HEAD + 16 * c), dtype=torch.uint8, device=dev) for c in caps]
+        if getattr(union, "_comm", None) is None:
+            union._comm = torch.cuda.Stream(device=dev)
     union.build_graph()
     return union
+
+
+PART_HEAD = 64  # bytes in front of an assembly's region in its own exchange buffer (XCHG_PART_HEAD in the library)
+
+
+def overlap_exchange():
+    """MXG_XCHG_OVERLAP=0: the steady-state exchange as ONE all-gather behind every sketch (the round-5 path) instead of one per
+    assembly overlapped with the next assembly's sketch"""
+    return os.environ.get("MXG_XCHG_OVERLAP", "1") != "0"
+
+
+def _sketch_union_graph_overlapped(eng, union, group, stream):
+    """steady state, exchange overlapped with compute: every assembly's sketch is enqueued on `stream` (the library's two
+    streams behind it) and packed into its own buffer right behind its last kernel; the communication stream waits for that
+    event only and carries the all-gather of assembly a while assembly a + 1 is still being sketched.  `stream` then waits
+    for the collectives, unpacks and builds the graph of the union: one host sync per step, as before."""
+    sl = union._slots
+    A = eng.n_assemblies
+    comm = union._comm
+    works = []
+    with torch.cuda.stream(stream):
+        eng.sketch_pack_parts([t.data_ptr() for t in sl["send_parts"]], sl["caps"])
+    for a in range(A):
+        eng.part_packed_wait(a, comm.cuda_stream)
+        with torch.cuda.stream(comm):
+            works.append(dist.all_gather_into_tensor(sl["recv_parts"][a], sl["send_parts"][a], group=group, async_op=True))
+    with torch.cuda.stream(stream):
+        for wk in works:
+            wk.wait()                       # (nccl: `stream` waits for the collective; gloo: the host does)
+        stream.wait_stream(comm)
+        ok = union.xchg_unpack_graph_parts([t.data_ptr() for t in sl["recv_parts"]], dist.get_world_size(group), sl["caps"],
+                                           sl["rec_off_flat"])
+    comm.wait_stream(stream)                # (the next step's collectives must not overwrite what this unpack reads)
+    eng.sketch_finish()
+    return ok
 
 
 def sketch_union_graph(eng, k, w, device, union=None, group=None, stream=None):
@@ -216,6 +258,11 @@ def sketch_union_graph(eng, k, w, device, union=None, group=None, stream=None):
     (mxg_sketch_pack), then ONE all-gather, then mxg_xchg_unpack_graph, whose sync is the step's only one."""
     if stream is not None and union is not None and getattr(union, "_slots", None) is not None:
         sl = union._slots
+        if "send_parts" in sl:
+            if _sketch_union_graph_overlapped(eng, union, group, stream):
+                return union
+            union._slots = None
+            return allgather_union_graph(eng, k, w, device, union, group=group, stream=stream)
         with torch.cuda.stream(stream):
             eng.sketch_pack(sl["send"].data_ptr(), sl["head"], sl["caps"])
             dist.all_gather_into_tensor(sl["recv"], sl["send"], group=group)

@@ -133,6 +133,8 @@ def main():
                 os.write(1, b"graph too small to mean anything\n")
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    sl = getattr(union, "_slots", None)
+    os.write(1, f"EXCHANGE rank {rank}: {'none' if sl is None else 'per-assembly' if 'send_parts' in sl else 'one all-gather'}\n".encode())
     union.close()
     owner.close()
     eng.close()

@@ -34,6 +34,21 @@ def test_union_graph_world_size(world, stream, slot_pct):
     assert out.stdout.count("DIST2 OK") == world, out.stdout[-3000:]
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_union_exchange_per_assembly_and_as_one_gather(overlap):
+    """the steady-state exchange of the union route both ways: one all-gather per assembly, issued on a communication stream as
+    soon as that assembly's sketch is packed (mxg_sketch_pack_parts; the default), and ONE all-gather behind every sketch
+    (MXG_XCHG_OVERLAP=0) -- the same graph as a single handle either way, and the worker says which one its last steps took"""
+    env = dict(os.environ, MXG_TEST_STREAM="1", MXG_XCHG_OVERLAP=overlap)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "tests", "_dist2_worker.py")]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("DIST2 OK") == 2, out.stdout[-3000:]
+    assert out.stdout.count("EXCHANGE rank") == 2
+    assert out.stdout.count("per-assembly" if overlap == "1" else "one all-gather") == 2, out.stdout[-3000:]
+
+
 @pytest.mark.parametrize("world,config3", [(4, "1"), (4, "0"), (8, "0"), (8, "1")])
 def test_four_and_eight_ranks_on_one_gpu(world, config3):
     """rank counts of BASELINE configs[3] (4 GPUs: target + 3 references, w=500, weights 1/2/2/2) and configs[4] (8 GPUs), at
