@@ -374,6 +374,8 @@ def dry_run(args):
     cfg, asms, label = workload_tables(wl, mbp, W, seed=1)
     bases_job = sum(int(a[2][:, 2].sum()) for a in asms)
     ranks = []
+    parts = [[] for _ in asms]   # per assembly: every rank's sketch (host arrays), for the union route's graph stage
+    rec_ids = None
     for r in range(N):
         eng = MxEngine(k=K, w=W, device=0, timing=True, timing_fine=True, cand_per_window=args.cand)
         keep = [add_rank_share(eng, name, weight, segs, cfg["seed"], sub_seed, sub, r, N, 0)[0] for name, weight, segs, _, sub, sub_seed in asms]
@@ -403,11 +405,20 @@ def dry_run(args):
         except Exception:
             pass
         m = int(st["minimizers"])
+        per_asm = []
+        for a in range(len(asms)):
+            sk = eng.get_sketch(a)
+            per_asm.append(len(sk["out_hash"]))
+            parts[a].append((sk["out_hash"].copy(), sk["pos"].copy(), sk["record"].copy()))
+            if r == 0:
+                rec_ids = (rec_ids or []) + [sk["record_ids"]]
         shared = int(frac * m)
         out_frac = (N - 1) / N
         sent = {"items": int(16 * m * out_frac), "verdicts": int(8 * m * out_frac), "adjacency_messages": int(2 * 16 * shared * out_frac)}  # one message to each end point's owner
         per_link = sum(sent.values()) / (N - 1)
-        ranks.append({"rank": r, "bases": int(st["bases"]), "minimizers": m, "sketch_ms": round(t_sk, 3), "graph_stage_on_own_minimizers_ms": round(t_gr, 3),
+        ranks.append({"rank": r, "bases": int(st["bases"]), "minimizers": m, "minimizers_by_assembly": per_asm,
+                      "bases_by_assembly": [int(a_[2][:, 2].sum()) // N for a_ in asms],   # (equal base ranges of every assembly)
+                      "sketch_ms": round(t_sk, 3), "graph_stage_on_own_minimizers_ms": round(t_gr, 3),
                       "kernel_ms_per_step": {"filter": round(st["ms_hash"] / args.steps, 3), "select (or count+reorder)": round(st["ms_reorder"] / args.steps, 3),
                                              "stretches (+resolve)": round(st["ms_resolve_kernel"] / args.steps, 3), "emit": round(st["ms_emit"] / args.steps, 3),
                                              "join": round(st["ms_join"] / args.steps, 3), "vertices": round(st["ms_vertices"] / args.steps, 3),
@@ -416,14 +427,58 @@ def dry_run(args):
         eng.close()
         del keep
         torch.cuda.empty_cache()
-    step_ms = max(x["sketch_ms"] + x["graph_stage_on_own_minimizers_ms"] + x["exchange_ms_at_link_rate"] for x in ranks) + 6 * 0.03
+    part_ms = max(x["sketch_ms"] + x["graph_stage_on_own_minimizers_ms"] + x["exchange_ms_at_link_rate"] for x in ranks) + 6 * 0.03
+    # ---- the union route (ntjoin_amd/dist.py sketch_union_graph): every rank's sketch to every rank, the graph of the union on
+    # every rank.  Its graph stage is measured on the real union of the ranks' sketches; an assembly's part is its fixed slot
+    # (MXG_XCHG_SLOT_PCT above the largest share), all-gathered over N - 1 links at once (one part per link and direction).
+    un = MxEngine(k=K, w=W, device=0, timing=True)
+    for a, (name, weight, *_rest) in enumerate(asms):
+        un.add_minimizers(name, weight, np.concatenate([p_[0] for p_ in parts[a]]), np.concatenate([p_[1] for p_ in parts[a]]),
+                          np.concatenate([p_[2] for p_ in parts[a]]), rec_ids[a])
+    for _ in range(max(args.warmup, 1)):
+        un.build_graph()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        un.build_graph()
+    torch.cuda.synchronize()
+    t_union_graph = (time.perf_counter() - t2) / args.steps * 1e3
+    ug = un.get_graph()
+    union_counts = {"vertices": int(len(ug["vertex_hash"])), "edges": int(len(ug["edge_u"]))}
+    un.close()
+    del parts
+    pct = int(os.environ.get("MXG_XCHG_SLOT_PCT", "110"))
+    link = XGMI_LINK_GBS * 1e9
+    part_bytes = [64 + 16 * ((max(x["minimizers_by_assembly"][a] for x in ranks) * pct // 100 + 64 + 7) // 8 * 8) for a in range(len(asms))]
+    gather_ms = [b / link * 1e3 + 0.03 for b in part_bytes]   # (+ one collective's latency)
+    unpack_ms = sum(16.0 * N * (b - 64) / 16 / 3.0e12 * 1e3 for b in part_bytes)  # the unpack kernels move 16 B in + 16 B out per entry at ~3 TB/s
+    union_one, union_ovl = 0.0, 0.0
+    for x in ranks:
+        tot_b = max(sum(x["bases_by_assembly"]), 1)
+        s_a = [x["sketch_ms"] * b / tot_b for b in x["bases_by_assembly"]]   # the assemblies one behind the other
+        t, c = 0.0, 0.0
+        for a in range(len(asms)):
+            t += s_a[a]
+            c = max(c, t) + gather_ms[a]        # part a travels as soon as it is packed and the part before it has gone
+        union_ovl = max(union_ovl, c)
+        union_one = max(union_one, x["sketch_ms"] + sum(part_bytes) / link * 1e3 + 0.03)
+    union_ovl += unpack_ms + t_union_graph
+    union_one += unpack_ms + t_union_graph
+    routes = {"partitioned (exchange behind the sketches, as built)": round(part_ms, 3),
+              "union, one all-gather behind the sketches (MXG_XCHG_OVERLAP=0)": round(union_one, 3),
+              "union, one all-gather per assembly beside the next assembly's sketch (as built)": round(union_ovl, 3)}
+    step_ms = min(routes.values())   # bench.py --gpus N tries the routes in its warm-up and times the faster one
     out = {"metric": f"PREDICTION of Gbp/s minimizer-sketch+graph-build (k=32,w={W}) on {N} GPUs, from one GPU playing every rank in turn",
            "value": round(bases_job / (step_ms * 1e-3) / 1e9, 2), "unit": "Gbp/s", "n_gpus": N, "dry": True, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(step_ms, 3), "higher_is_better": True, "data": "synthetic", "dtype": "u64",
            "config": {"workload": label + f", rank shares of 1/{N} of every assembly's bases", "bases_per_step": int(bases_job)},
-           "model": "step = max over ranks of (sketch stage + exchange bytes / (N-1) links at "
+           "model": "partitioned: step = max over ranks of (sketch stage + exchange bytes / (N-1) links at "
                     f"{XGMI_LINK_GBS:g} GB/s per link and direction + graph stage on as many minimizers as the rank owns) + 6 collectives x 30 us; "
-                    "the five host syncs of the exact partitioned exchange are inside the measured stages' own syncs or not modelled",
+                    "the five host syncs of the exact partitioned exchange are inside the measured stages' own syncs or not modelled.  "
+                    "union: an assembly's part = its fixed slot (16 B per entry, MXG_XCHG_SLOT_PCT above the largest share) to every peer over its own link; "
+                    "per assembly: ready when its sketch ends (sketch stage split by bases), gone one part-time + 30 us later, never before the part in front of it; "
+                    "then unpack + the graph stage MEASURED on the union of the ranks' sketches.  value = the fastest route (bench.py --gpus N measures the routes and takes the faster)",
+           "routes_ms_per_step": routes, "union_graph_stage_ms": round(t_union_graph, 3), "union_part_bytes": part_bytes, "union_graph": union_counts,
            "ranks": ranks}
     print(json.dumps(out), flush=True)
     return 0

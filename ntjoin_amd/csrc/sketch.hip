@@ -3428,7 +3428,9 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 // kernel takes 0.64 ms instead of 0.44 -- neither kernel's time says anything about the kernel any more; at
                 // 1 Gbp + 1 Gbp, where the tails weigh more, running free is 6 % faster and stays.  (MXG_STAGGER=0: never)
                 hipEvent_t behind = nullptr;
-                if (stagger && !one_stream && last_sel_slot >= 0 && drvs[last_sel_slot] != &drv && list[i]->total_kmers >= (1ull << 31))
+                // (mxg_sketch_pack_parts: always -- the assembly before this one must END first, its part travels beside this filter)
+                if (stagger && !one_stream && last_sel_slot >= 0 && drvs[last_sel_slot] != &drv &&
+                    (list[i]->total_kmers >= (1ull << 31) || (xp && xp->d_parts)))
                     behind = h->ev_sel_done[last_sel_slot];
                 if (sel_ok && (rc = drv.clear_sel_ctrl(bgs[b])) != MXG_OK) return rc;
                 if ((rc = bs_edges(h, list[i], drv.st)) != MXG_OK) return rc;  // (the two blocks that copy the edge chunks need not wait)
