@@ -1,5 +1,5 @@
 #!/bin/bash
-# Where the filter's time goes beyond its issue bound (k_hash_bs: 8520 full-rate VALU instructions per chunk, 2 cycles each at best):
+# Where the filter's time goes beyond its issue bound (k_hash_bs: 7840 full-rate VALU instructions per chunk, 2 cycles each at best):
 # the same generated instruction stream with its vector loads removed, its stores removed, both removed -- timing variants of
 # gen/bs_gen.py (--ablate; results wrong on purpose), each built into tools/bs_bench.hip and run at 3 Gbp with 1, 2, 3 and 4 blocks per CU.
 #   tools/bs_ablate.sh [Mbp]   (GPU box)   -> stdout; profiles/ubench/bs_ablate_r05.txt is a committed run
