@@ -127,6 +127,16 @@ def to_asm(ins):
     if op in ('gload4', 'gload2') and LDSLOADS_ABLATION:  # (timing only: the words land in LDS -- and stay there -- instead of the registers)
         k = ins[3] // 16 if op == 'gload4' else 16
         return f"s_add_u32 m0, s{S_LB}, {1024 * k}\nglobal_load_lds_{'dwordx4' if op == 'gload4' else 'dword'} %[voff256], {sp(ins[2])} offset:{ins[3]}"
+    if MUBUF and op in ('gload4', 'gload2'):  # (experiment: buffer instructions on a resource based at the words - 8 bytes)
+        d = int(ins[1][1:])
+        n = 4 if op == 'gload4' else 2
+        return f"buffer_load_dwordx{n} v[{d}:{d + n - 1}], %[voff256], s[{S_RL}:{S_RL + 3}], 0 offen offset:{ins[3] + 8 if op == 'gload4' else 0}"
+    if MUBUF and op in ('gstore4', 'gstore3', 'gstore1'):  # (resource based at OUT - 4 bytes)
+        d = int(ins[1][1:])
+        n = int(op[-1])
+        regs = f"v[{d}:{d + n - 1}]" if n > 1 else f"v{d}"
+        suffix = {4: 'dwordx4', 3: 'dwordx3', 1: 'dword'}[n]
+        return f"buffer_store_{suffix} {regs}, %[voff128], s[{S_RS}:{S_RS + 3}], 0 offen offset:{ins[3] + (0 if ins[2] == S_OC else 4)}"
     if op == 'gload4':  # first dst register, base SGPR pair, byte offset; the lane's offset (lane * 256) is operand %[voff256]
         d = int(ins[1][1:])
         if COALESCED_ABLATION:  # (timing only, wrong words: the 64 lanes of a load read 1 KB in a row -- 8 cache lines instead of 64)
@@ -173,6 +183,7 @@ def to_asm(ins):
 # waves per SIMD issues slower than an even one).
 # ---------------------------------------------------------------------------------------------------------------
 E64 = "_e64" if os.environ.get("BS_E64") == "1" else ""   # experiment: the two-source instructions in their 8-byte encoding (same work, larger code)
+MUBUF = os.environ.get("BS_MUBUF") == "1"   # experiment: buffer_load / buffer_store instead of global_load / global_store
 LOAD_MOD = os.environ.get("BS_LOAD_MOD", "")    # cache-policy bits of the loads / stores (experiments: " nt", " sc1", ...)
 STORE_MOD = os.environ.get("BS_STORE_MOD", "")
 LDSLOADS_ABLATION = False   # --ablate ldsloads (timing only: LDS-direct loads, nothing reads the LDS)
@@ -219,6 +230,8 @@ S_PA = S_HD + 2      # v_perm_b32 selectors of the transposes' stage 16: [y.lo :
 S_PB = S_HD + 3
 SEND = S_HD + 4
 S_LB = SEND         # (--ablate ldsloads only: the wave's LDS base)
+S_RL = 88           # (BS_MUBUF only: buffer resources of the loads and of the stores, four SGPRs each)
+S_RS = 92
 
 
 class Gen:
@@ -580,6 +593,9 @@ class Gen:
         L(f"s_cselect_b64 {sp(S_TN)}, {sp(S_HD)}, {sp(S_TN)}")
         L(f"s_add_u32 s{S_TQ}, s{S_TN}, -8")
         L(f"s_addc_u32 s{S_TQ + 1}, s{S_TN + 1}, -1")
+        if MUBUF:
+            L(f"s_mov_b32 s{S_RL}, s{S_TQ}")
+            L(f"s_and_b32 s{S_RL + 1}, s{S_TQ + 1}, 0xffff")
 
     def address_setup(self, lines):
         """SALU at the top of the loop: the NEXT chunk's words (the last chunk of a wave asks for its own words again)"""
@@ -599,6 +615,9 @@ class Gen:
         L(f"s_addc_u32 s{d + 1}, s{d + 1}, s{S_O + 1}")
         L(f"s_add_u32 s{S_OC}, s{d}, -4")
         L(f"s_addc_u32 s{S_OC + 1}, s{d + 1}, -1")
+        if MUBUF:
+            L(f"s_mov_b32 s{S_RS}, s{S_OC}")
+            L(f"s_and_b32 s{S_RS + 1}, s{S_OC + 1}, 0xffff")
 
     def asm(self):
         """the inline-asm text.  Operands: %[t] %[p] %[hd] %[o] (SGPR pairs: packed bases, padded copies of the last and of the first
@@ -618,6 +637,10 @@ class Gen:
         A(f"s_mov_b64 {sp(S_O)}, %[o]")
         A(f"s_mov_b32 s{S_CTAIL}, %[ctail]")
         A(f"s_mov_b32 s{S_FIRST}, 1")
+        if MUBUF:
+            for r_ in (S_RL, S_RS):
+                A(f"s_mov_b32 s{r_ + 2}, -1")
+                A(f"s_mov_b32 s{r_ + 3}, 0x00020000")
         for i in range(self.b):  # compare masks: Cm_i = all ones iff bit i of the threshold is set
             A(f"s_bfe_u32 s{S_TMP}, s{S_TT}, {hex((1 << 16) | i)}")
             A(f"s_sub_u32 s{S_CM + i}, 0, s{S_TMP}")
@@ -665,7 +688,7 @@ class Gen:
         return L
 
     def clobbers(self):
-        return [f"v{i}" for i in range(B0, VEND)] + [f"s{i}" for i in range(S0, SEND)] + ["vcc", "scc", "memory"] + (["m0", f"s{S_LB}"] if LDSLOADS_ABLATION else [])
+        return [f"v{i}" for i in range(B0, VEND)] + [f"s{i}" for i in range(S0, SEND)] + ["vcc", "scc", "memory"] + (["m0", f"s{S_LB}"] if LDSLOADS_ABLATION else []) + ([f"s{i}" for i in range(S_RL, S_RS + 4)] if MUBUF else [])
 
 
 # ---------------------------------------------------------------------------------------------------------------
