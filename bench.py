@@ -449,9 +449,11 @@ def dry_run(args):
     del parts
     pct = int(os.environ.get("MXG_XCHG_SLOT_PCT", "110"))
     link = XGMI_LINK_GBS * 1e9
-    part_bytes = [64 + 16 * ((max(x["minimizers_by_assembly"][a] for x in ranks) * pct // 100 + 64 + 7) // 8 * 8) for a in range(len(asms))]
+    slot_caps = [(max(x["minimizers_by_assembly"][a] for x in ranks) * pct // 100 + 64 + 7) // 8 * 8 for a in range(len(asms))]
+    part_bytes = [64 + 12 * c + 4 * ((len(rec_ids[a]) + 3) // 4 * 4) for a, c in enumerate(slot_caps)]   # (ntjoin_amd/dist.py part_bytes)
+    one_slot_bytes = 64 + 16 * sum(slot_caps)   # (the single gather's slot: 16 B per entry, record column included)
     gather_ms = [b / link * 1e3 + 0.03 for b in part_bytes]   # (+ one collective's latency)
-    unpack_ms = sum(16.0 * N * (b - 64) / 16 / 3.0e12 * 1e3 for b in part_bytes)  # the unpack kernels move 16 B in + 16 B out per entry at ~3 TB/s
+    unpack_ms = sum(28.0 * N * (b - 64) / 12 / 3.0e12 * 1e3 for b in part_bytes)  # the unpack kernels move 12 B in + 16 B out per entry at ~3 TB/s
     union_one, union_ovl = 0.0, 0.0
     for x in ranks:
         tot_b = max(sum(x["bases_by_assembly"]), 1)
@@ -461,7 +463,7 @@ def dry_run(args):
             t += s_a[a]
             c = max(c, t) + gather_ms[a]        # part a travels as soon as it is packed and the part before it has gone
         union_ovl = max(union_ovl, c)
-        union_one = max(union_one, x["sketch_ms"] + sum(part_bytes) / link * 1e3 + 0.03)
+        union_one = max(union_one, x["sketch_ms"] + one_slot_bytes / link * 1e3 + 0.03)
     union_ovl += unpack_ms + t_union_graph
     union_one += unpack_ms + t_union_graph
     routes = {"partitioned (exchange behind the sketches, as built)": round(part_ms, 3),
@@ -475,7 +477,7 @@ def dry_run(args):
            "model": "partitioned: step = max over ranks of (sketch stage + exchange bytes / (N-1) links at "
                     f"{XGMI_LINK_GBS:g} GB/s per link and direction + graph stage on as many minimizers as the rank owns) + 6 collectives x 30 us; "
                     "the five host syncs of the exact partitioned exchange are inside the measured stages' own syncs or not modelled.  "
-                    "union: an assembly's part = its fixed slot (16 B per entry, MXG_XCHG_SLOT_PCT above the largest share) to every peer over its own link; "
+                    "union: an assembly's part = its fixed slot (12 B per entry + 4 B per record, MXG_XCHG_SLOT_PCT above the largest share) to every peer over its own link; "
                     "per assembly: ready when its sketch ends (sketch stage split by bases), gone one part-time + 30 us later, never before the part in front of it; "
                     "then unpack + the graph stage MEASURED on the union of the ranks' sketches.  value = the fastest route (bench.py --gpus N measures the routes and takes the faster)",
            "routes_ms_per_step": routes, "union_graph_stage_ms": round(t_union_graph, 3), "union_part_bytes": part_bytes, "union_graph": union_counts,

@@ -277,17 +277,20 @@ int mxg_sketch_finish(mxg_handle *h);
 int mxg_xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t slot_bytes, uint64_t head_bytes,
                           const uint64_t *caps, const uint64_t *rec_offsets);
 /* The same exchange with ONE BUFFER PER ASSEMBLY, so that an assembly's sketch can travel while the next assembly is still
-   being sketched: part a = [64 bytes: int64 count (-1: does not fit) | caps[a] entries as mxg_pack_sketch_device lays them
-   out].  mxg_sketch_pack_parts enqueues every assembly's sketch and packs each part right behind that assembly's own last
+   being sketched -- and with 12 bytes per minimizer instead of 16: part a = [64 bytes: int64 count (-1: does not fit), int64
+   records | caps[a] hashes (u64) | caps[a] positions (u32) | rcaps[a] x u32: the first entry of every record of the sender
+   (entries are in (record, position) order: the record column is a step function of the entry index, the receiver finds an
+   entry's record by bisection)]; caps[a] a multiple of 8, rcaps[a] even and at least the sender's number of records;
+   64 + 12 caps[a] + 4 rcaps[a] bytes.  mxg_sketch_pack_parts enqueues every assembly's sketch and packs each part right behind that assembly's own last
    kernel; mxg_part_packed_wait(h, a, stream) makes `stream` (a hipStream_t: the caller's communication stream) wait for part
    a -- the caller then issues the all-gather of part a on it, one collective per assembly.  mxg_xchg_unpack_graph_parts on
    the union's handle takes the gathered parts (d_all_parts[a] = world parts of assembly a, rank after rank) once the
    handle's stream has been made to wait for the collectives; returns as mxg_xchg_unpack_graph.  mxg_sketch_finish as
    above.  No counterpart in the reference (single process). */
-int mxg_sketch_pack_parts(mxg_handle *h, void *const *d_parts, const uint64_t *caps);
+int mxg_sketch_pack_parts(mxg_handle *h, void *const *d_parts, const uint64_t *caps, const uint64_t *rcaps);
 int mxg_part_packed_wait(mxg_handle *h, int assembly, void *stream);
 int mxg_xchg_unpack_graph_parts(mxg_handle *h, const void *const *d_all_parts, uint32_t world, const uint64_t *caps,
-                                const uint64_t *rec_offsets);
+                                const uint64_t *rcaps, const uint64_t *rec_offsets);
 /* indexlr TSV: `id \t out_hash[:pos][:+|-][:kmer] ( out_hash...)* \n`, one line per record, input order.
    path "-" = stdout. */
 int mxg_write_tsv(mxg_handle *h, int assembly, const char *path, int with_pos, int with_strand,

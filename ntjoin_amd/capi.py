@@ -132,9 +132,9 @@ def load():
     L.mxg_sketch_pack.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.mxg_sketch_finish.argtypes = [vp]
     L.mxg_xchg_unpack_graph.argtypes = [vp, vp, C.c_uint32, u64, u64, C.POINTER(u64), C.POINTER(u64)]
-    L.mxg_sketch_pack_parts.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.mxg_sketch_pack_parts.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.mxg_part_packed_wait.argtypes = [vp, C.c_int, vp]
-    L.mxg_xchg_unpack_graph_parts.argtypes = [vp, C.POINTER(vp), C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
+    L.mxg_xchg_unpack_graph_parts.argtypes = [vp, C.POINTER(vp), C.c_uint32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mxg_shard_range.argtypes = [C.POINTER(u64), u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
     L.mxg_assembly_shard.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(u64)]
     L.mxg_add_assembly_buffers.argtypes = [vp, cp, C.c_double, vp, C.POINTER(u64), C.POINTER(cp), u64]

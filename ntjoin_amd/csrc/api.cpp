@@ -534,9 +534,9 @@ int mxg_sketch_pack(mxg_handle *h, void *d_slot, uint64_t head_bytes, const uint
     }
 }
 
-int mxg_sketch_pack_parts(mxg_handle *h, void *const *d_parts, const uint64_t *caps)
+int mxg_sketch_pack_parts(mxg_handle *h, void *const *d_parts, const uint64_t *caps, const uint64_t *rcaps)
 {
-    if (!h || !d_parts || !caps) return MXG_EINVAL;
+    if (!h || !d_parts || !caps || !rcaps) return MXG_EINVAL;
     if (!h->pend_list.empty()) return set_err(h, MXG_EINVAL, "mxg_sketch_pack_parts: the previous call was not finished (mxg_sketch_finish)");
     try {
         std::vector<Assembly *> todo;
@@ -546,7 +546,7 @@ int mxg_sketch_pack_parts(mxg_handle *h, void *const *d_parts, const uint64_t *c
             todo.push_back(a);
         }
         if (todo.empty()) return set_err(h, MXG_EINVAL, "mxg_sketch_pack_parts: no assemblies");
-        XchgPackReq xp{nullptr, 0, caps, d_parts};
+        XchgPackReq xp{nullptr, 0, caps, d_parts, rcaps};
         return sketch_assemblies(h, todo.data(), todo.size(), false, &xp);
     } catch (const std::bad_alloc &) {
         return set_err(h, MXG_ENOMEM, "out of host memory in mxg_sketch_pack_parts");
@@ -678,12 +678,12 @@ int mxg_xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint
 }
 
 int mxg_xchg_unpack_graph_parts(mxg_handle *h, const void *const *d_all_parts, uint32_t world, const uint64_t *caps,
-                                const uint64_t *rec_offsets)
+                                const uint64_t *rcaps, const uint64_t *rec_offsets)
 {
-    if (!h || !d_all_parts || !caps || !rec_offsets) return MXG_EINVAL;
+    if (!h || !d_all_parts || !caps || !rcaps || !rec_offsets) return MXG_EINVAL;
     for (size_t a = 0; a < h->asms.size(); ++a)
-        if (!d_all_parts[a]) return MXG_EINVAL;
-    return xchg_unpack_graph(h, nullptr, world, 0, 0, caps, rec_offsets, d_all_parts);
+        if (!d_all_parts[a] || caps[a] % 8 || rcaps[a] % 2) return MXG_EINVAL;  // (parts lie side by side: 8-byte columns)
+    return xchg_unpack_graph(h, nullptr, world, 0, 0, caps, rec_offsets, d_all_parts, rcaps);
 }
 
 int mxg_set_sketch_device(mxg_handle *h, int assembly, const void *d_out_hash, const void *d_pos,

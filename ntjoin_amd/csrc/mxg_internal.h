@@ -362,9 +362,11 @@ struct XchgPackReq {  // mxg_sketch_pack: where the sketches go once they exist 
     void *d_slot;
     uint64_t head_bytes;
     const uint64_t *caps;
-    // mxg_sketch_pack_parts: one buffer per assembly instead, [64 bytes: int64 count | caps[a] entries], packed right behind that
+    // mxg_sketch_pack_parts: one buffer per assembly instead, [64 bytes: int64 count, int64 records | caps[a] hashes | caps[a]
+    // positions | rcaps[a] first entries of the records], packed right behind that
     // assembly's own k_emit on the stream it ran on, with an event the caller's communication stream can wait for (ev_part)
     void *const *d_parts = nullptr;
+    const uint64_t *rcaps = nullptr;  // ... and room for this many records' first entries behind the 12 bytes per entry
 };
 constexpr uint64_t XCHG_PART_HEAD = 64;
 int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_graph = false, const XchgPackReq *xp = nullptr);
@@ -389,7 +391,8 @@ int build_graph(mxg_handle *h, int mode = GRAPH_FULL, const void *d_msgs = nullp
                 const GraphBounds *gb = nullptr);
 int xchg_pack(mxg_handle *h, void *d_slot, uint64_t head_bytes, const uint64_t *caps);
 int xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t slot_bytes, uint64_t head_bytes,
-                      const uint64_t *caps, const uint64_t *rec_offsets, const void *const *d_all_parts = nullptr);
+                      const uint64_t *caps, const uint64_t *rec_offsets, const void *const *d_all_parts = nullptr,
+                      const uint64_t *rcaps = nullptr);
 int graph_to_host(mxg_handle *h);
 int find_paths(mxg_handle *h, int64_t n_min);  // paths.hip
 // dgraph.hip

@@ -3278,6 +3278,62 @@ __global__ __launch_bounds__(256) void k_pack_slot_dev(const uint64_t *__restric
     reinterpret_cast<uint32_t *>(region + 12 * cap)[i] = rec[i];
 }
 
+// mxg_sketch_pack_parts' kernels.  A part carries 12 bytes per minimizer, not 16: hash | pos | the first entry of every RECORD.
+// The entries are in (record, position) order, so the record column is a step function of the entry index: 4 bytes per record
+// travel instead of 4 per minimizer, and the receiver finds an entry's record by bisection (k_unpack_part).  Same predicate as
+// k_pack_slot_dev; header word 1 = the sender's number of records.
+__global__ __launch_bounds__(256) void k_pack_part_dev(const uint64_t *__restrict__ hash, const uint32_t *__restrict__ pos,
+                                                       const uint32_t *__restrict__ rec, const uint32_t *__restrict__ n_ptr,
+                                                       const uint32_t *__restrict__ ctrl, uint64_t out_cap, uint64_t cap,
+                                                       long long fixed, long long *header, unsigned char *__restrict__ region,
+                                                       uint32_t n_rec, uint32_t rcap, uint32_t dev_gaps, uint32_t place4)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (fixed != -2) {
+        if (i == 0) {
+            header[0] = fixed;
+            header[1] = 0;
+        }
+        return;
+    }
+    const uint64_t n = *n_ptr;
+    const bool ok = ctrl[0] == 0 && ctrl[6] == 0 && ctrl[13] == 0 && (dev_gaps ? (ctrl[11] == 0 && ctrl[1] <= place4) : ctrl[1] == 0) && (ctrl[4] | ctrl[5]) != 0 &&
+                    n <= cap && n <= out_cap && n_rec <= rcap;
+    if (i == 0) {
+        header[0] = ok ? (long long)n : -1ll;
+        header[1] = n_rec;
+    }
+    if (!ok || i >= n) return;
+    reinterpret_cast<uint64_t *>(region)[i] = hash[i];
+    reinterpret_cast<uint32_t *>(region + 8 * cap)[i] = pos[i];
+    const uint32_t r = rec[i];
+    if ((i == 0 || rec[i - 1] != r) && r < n_rec) reinterpret_cast<uint32_t *>(region + 12 * cap)[r] = (uint32_t)i;
+}
+
+// starts[r] = min(starts[r .. n_rec), n): a record without an entry takes the next record's first entry (one block)
+__global__ __launch_bounds__(1024) void k_part_starts(const long long *__restrict__ header, uint32_t *__restrict__ starts, uint32_t n_rec)
+{
+    const long long n = header[0];
+    if (n < 0) return;
+    __shared__ uint32_t smin[1024];
+    const uint32_t per = (n_rec + 1023u) / 1024u, lo = min(threadIdx.x * per, n_rec), hi = min(lo + per, n_rec);
+    uint32_t m = 0xFFFFFFFFu;
+    for (uint32_t q = lo; q < hi; ++q) m = min(m, starts[q]);
+    smin[threadIdx.x] = m;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {  // suffix minimum over the threads' chunks
+        const uint32_t v = threadIdx.x + off < 1024u ? smin[threadIdx.x + off] : 0xFFFFFFFFu;
+        __syncthreads();
+        smin[threadIdx.x] = min(smin[threadIdx.x], v);
+        __syncthreads();
+    }
+    uint32_t carry = min(threadIdx.x + 1u < 1024u ? smin[threadIdx.x + 1u] : 0xFFFFFFFFu, (uint32_t)n);
+    for (uint32_t q = hi; q-- > lo;) {
+        carry = min(carry, starts[q]);
+        starts[q] = carry;
+    }
+}
+
 // Every assembly is cut into batches of whole records (SPARSE_BATCH_KMERS) and EVERY batch of EVERY assembly is enqueued
 // completely -- hash -> order -> resolve (-> stretches on the device) -> emit -- alternating between the handle's two
 // streams with their own scratch, before the host waits once for both streams.  A batch starts in the assembly's sketch
@@ -3512,11 +3568,17 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         const long long fixed = state[i] == 1 ? -2ll : (state[i] == 2 ? 0ll : -1ll);
         const uint32_t grid = state[i] == 1 ? (uint32_t)std::max<uint64_t>((cap + 255) / 256, 1) : 1u;
         unsigned char *part = static_cast<unsigned char *>(xp->d_parts[i]);
+        const uint64_t rcap = xp->rcaps[i], n_rec = a->recs.size();
+        uint32_t *starts = reinterpret_cast<uint32_t *>(part + XCHG_PART_HEAD + 12 * cap);
         MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
-        hipLaunchKernelGGL(k_pack_slot_dev, dim3(grid), dim3(256), 0, st, a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(),
+        if (state[i] == 1 && n_rec <= rcap && n_rec) MXG_HIP(h, hipMemsetAsync(starts, 0xFF, 4 * n_rec, st));
+        hipLaunchKernelGGL(k_pack_part_dev, dim3(grid), dim3(256), 0, st, a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(),
                            a->d_rec.as<uint32_t>(), h->d_nmx.as<uint32_t>() + i,
                            drv ? drv->sc(SC_CTRL).as<uint32_t>() : h->d_nmx.as<uint32_t>(), out_cap, cap, fixed,
-                           reinterpret_cast<long long *>(part), part + XCHG_PART_HEAD, state[i] == 1 && plans[i].dev_gaps ? 1u : 0u, place4);
+                           reinterpret_cast<long long *>(part), part + XCHG_PART_HEAD, (uint32_t)std::min<uint64_t>(n_rec, 0xFFFFFFFFu),
+                           (uint32_t)std::min<uint64_t>(rcap, 0xFFFFFFFFu), state[i] == 1 && plans[i].dev_gaps ? 1u : 0u, place4);
+        if (state[i] == 1 && n_rec <= rcap && n_rec)
+            hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, st, reinterpret_cast<const long long *>(part), starts, (uint32_t)n_rec);
         MXG_HIP(h, hipGetLastError());
         if (!h->ev_part[i]) MXG_HIP(h, hipEventCreateWithFlags(&h->ev_part[i], hipEventDisableTiming));
         MXG_HIP(h, hipEventRecord(h->ev_part[i], st));
@@ -4055,10 +4117,58 @@ __global__ __launch_bounds__(256) void k_unpack_slot(const UnpackSlotParams p)
     p.rec[o] = reinterpret_cast<const uint32_t *>(reg + 12 * p.cap)[i] + p.rec_off[r];
 }
 
+// the same out of parts (k_pack_part_dev): 12 bytes per entry, the record found by bisection in the sender's table of first entries
+struct UnpackPartParams {
+    const unsigned char *all;  // world parts of ONE assembly
+    uint64_t part_bytes, cap, rcap;
+    uint32_t world;
+    uint32_t rec_off[64];
+    uint64_t *hash;
+    uint32_t *pos, *rec;
+    uint32_t *n_dev, *host_total;
+};
+
+__global__ __launch_bounds__(256) void k_unpack_part(const UnpackPartParams p)
+{
+    const uint32_t r = blockIdx.y;
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    uint64_t start = 0, total = 0;
+    bool bad = false;
+    long long mine = 0, my_recs = 0;
+    for (uint32_t q = 0; q < p.world; ++q) {
+        const long long *hd = reinterpret_cast<const long long *>(p.all + (size_t)q * p.part_bytes);
+        const long long c = hd[0];
+        bad = bad || c < 0 || (uint64_t)c > p.cap || (c > 0 && (hd[1] <= 0 || (uint64_t)hd[1] > p.rcap));
+        if (q < r) start += (uint64_t)max(c, 0ll);
+        if (q == r) {
+            mine = c;
+            my_recs = hd[1];
+        }
+        total += (uint64_t)max(c, 0ll);
+    }
+    if (r == 0 && i == 0) {
+        *p.n_dev = bad ? 0u : (uint32_t)total;
+        *p.host_total = bad ? 0xFFFFFFFFu : (uint32_t)total;
+    }
+    if (bad || (long long)i >= mine) return;
+    const unsigned char *reg = p.all + (size_t)r * p.part_bytes + XCHG_PART_HEAD;
+    const uint32_t *starts = reinterpret_cast<const uint32_t *>(reg + 12 * p.cap);
+    uint32_t lo = 0, hi = (uint32_t)my_recs;  // the last record whose first entry is <= i (records without entries share the next one's)
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (starts[mid] <= (uint32_t)i) lo = mid + 1;
+        else hi = mid;
+    }
+    const uint64_t o = start + i;
+    p.hash[o] = reinterpret_cast<const uint64_t *>(reg)[i];
+    p.pos[o] = reinterpret_cast<const uint32_t *>(reg + 8 * p.cap)[i];
+    p.rec[o] = (lo ? lo - 1u : 0u) + p.rec_off[r];
+}
+
 // returns 1 (nothing usable: some sketch did not fit its slot on some rank, the caller exchanges sizes first) or the
 // result of build_graph
 int xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t slot_bytes, uint64_t head_bytes,
-                      const uint64_t *caps, const uint64_t *rec_offsets, const void *const *d_all_parts)
+                      const uint64_t *caps, const uint64_t *rec_offsets, const void *const *d_all_parts, const uint64_t *rcaps)
 {
     if (world == 0 || world > 64) return set_err(h, MXG_ELIMIT, "world size must be 1..64");
     const size_t A = h->asms.size();
@@ -4078,22 +4188,39 @@ int xchg_unpack_graph(mxg_handle *h, const void *d_all, uint32_t world, uint64_t
         MXG_HIP(h, a->d_hash.ensure(std::max<uint64_t>(bound * 8, 16)));
         MXG_HIP(h, a->d_pos.ensure(std::max<uint64_t>(bound * 4, 16)));
         MXG_HIP(h, a->d_rec.ensure(std::max<uint64_t>(bound * 4, 16)));
+        h->pinned_ctrl[16 * ai] = 0xFFFFFFFFu;
+        if (d_all_parts) {
+            UnpackPartParams pp;
+            pp.all = static_cast<const unsigned char *>(d_all_parts[ai]);
+            pp.cap = caps[ai];
+            pp.rcap = rcaps[ai];
+            pp.part_bytes = XCHG_PART_HEAD + 12 * caps[ai] + 4 * rcaps[ai];
+            pp.world = world;
+            for (uint32_t r = 0; r < world; ++r) pp.rec_off[r] = (uint32_t)rec_offsets[ai * world + r];
+            pp.hash = a->d_hash.as<uint64_t>();
+            pp.pos = a->d_pos.as<uint32_t>();
+            pp.rec = a->d_rec.as<uint32_t>();
+            pp.n_dev = h->d_nmx.as<uint32_t>() + ai;
+            pp.host_total = h->pinned_ctrl + 16 * ai;
+            hipLaunchKernelGGL(k_unpack_part, dim3((uint32_t)std::max<uint64_t>((caps[ai] + 255) / 256, 1), world), dim3(256), 0,
+                               h->stream, pp);
+        }
         UnpackSlotParams up;
-        up.all = static_cast<const unsigned char *>(d_all_parts ? d_all_parts[ai] : d_all);
-        up.slot_bytes = d_all_parts ? XCHG_PART_HEAD + 16 * caps[ai] : slot_bytes;
-        up.region_off = d_all_parts ? XCHG_PART_HEAD : off;
+        up.all = static_cast<const unsigned char *>(d_all);
+        up.slot_bytes = slot_bytes;
+        up.region_off = off;
         up.cap = caps[ai];
         up.world = world;
-        up.a = d_all_parts ? 0u : (uint32_t)ai;
+        up.a = (uint32_t)ai;
         for (uint32_t r = 0; r < world; ++r) up.rec_off[r] = (uint32_t)rec_offsets[ai * world + r];
         up.hash = a->d_hash.as<uint64_t>();
         up.pos = a->d_pos.as<uint32_t>();
         up.rec = a->d_rec.as<uint32_t>();
         up.n_dev = h->d_nmx.as<uint32_t>() + ai;
         up.host_total = h->pinned_ctrl + 16 * ai;
-        h->pinned_ctrl[16 * ai] = 0xFFFFFFFFu;
-        hipLaunchKernelGGL(k_unpack_slot, dim3((uint32_t)std::max<uint64_t>((caps[ai] + 255) / 256, 1), world), dim3(256), 0,
-                           h->stream, up);
+        if (!d_all_parts)
+            hipLaunchKernelGGL(k_unpack_slot, dim3((uint32_t)std::max<uint64_t>((caps[ai] + 255) / 256, 1), world), dim3(256), 0,
+                               h->stream, up);
         off += 16 * caps[ai];
         gb.n_bound[ai] = bound;
         gb.n_ptr[ai] = h->d_nmx.as<uint32_t>() + ai;

@@ -209,8 +209,11 @@ def _allgather_union_graph(eng, k, w, device, union, group, stream):
     if overlap_exchange():
         # one buffer per assembly (64-byte header + its region): assembly a's all-gather is issued on a stream of its own as soon
         # as a's sketch is packed, and travels while assembly a + 1 is sketched (sketch_union_graph)
-        union._slots["send_parts"] = [torch.zeros(PART_HEAD + 16 * c, dtype=torch.uint8, device=dev) for c in caps]
-        union._slots["recv_parts"] = [torch.empty(world * (PART_HEAD + 16 * c), dtype=torch.uint8, device=dev) for c in caps]
+        # (12 bytes per minimizer: hash + position; the record column travels as the first entry of every record, mxg_sketch_pack_parts)
+        rcaps = [(max(int(metas[:, a, 1].max()), eng.n_records(a), 1) + 3) // 4 * 4 for a in range(A)]
+        union._slots["rcaps"] = rcaps
+        union._slots["send_parts"] = [torch.zeros(part_bytes(c, rc), dtype=torch.uint8, device=dev) for c, rc in zip(caps, rcaps)]
+        union._slots["recv_parts"] = [torch.empty(world * part_bytes(c, rc), dtype=torch.uint8, device=dev) for c, rc in zip(caps, rcaps)]
         if getattr(union, "_comm", None) is None:
             union._comm = torch.cuda.Stream(device=dev)
     union.build_graph()
@@ -218,6 +221,11 @@ def _allgather_union_graph(eng, k, w, device, union, group, stream):
 
 
 PART_HEAD = 64  # bytes in front of an assembly's region in its own exchange buffer (XCHG_PART_HEAD in the library)
+
+
+def part_bytes(cap, rcap):
+    """an assembly's exchange buffer: header, `cap` hashes and positions, the first entry of each of `rcap` records"""
+    return PART_HEAD + 12 * int(cap) + 4 * int(rcap)
 
 
 def overlap_exchange():
@@ -236,7 +244,7 @@ def _sketch_union_graph_overlapped(eng, union, group, stream):
     comm = union._comm
     works = []
     with torch.cuda.stream(stream):
-        eng.sketch_pack_parts([t.data_ptr() for t in sl["send_parts"]], sl["caps"])
+        eng.sketch_pack_parts([t.data_ptr() for t in sl["send_parts"]], sl["caps"], sl["rcaps"])
     for a in range(A):
         eng.part_packed_wait(a, comm.cuda_stream)
         with torch.cuda.stream(comm):
@@ -246,7 +254,7 @@ def _sketch_union_graph_overlapped(eng, union, group, stream):
             wk.wait()                       # (nccl: `stream` waits for the collective; gloo: the host does)
         stream.wait_stream(comm)
         ok = union.xchg_unpack_graph_parts([t.data_ptr() for t in sl["recv_parts"]], dist.get_world_size(group), sl["caps"],
-                                           sl["rec_off_flat"])
+                                           sl["rcaps"], sl["rec_off_flat"])
     comm.wait_stream(stream)                # (the next step's collectives must not overwrite what this unpack reads)
     eng.sketch_finish()
     return ok

@@ -108,25 +108,29 @@ class MxEngine:
         return self._check(self._lib.mxg_sketch_pack(self._h, C.c_void_p(int(d_slot)), int(head_bytes),
                                                      cc.ctypes.data_as(C.POINTER(C.c_uint64))))
 
-    def sketch_pack_parts(self, d_parts, caps):
-        """sketch every assembly; each one's sketch is packed into its own buffer (d_parts[a]: 64-byte header + 16 * caps[a] bytes)
-        right behind its last kernel -- part_packed_wait(a, stream) then lets a communication stream send it while the next
-        assembly is sketched (finish with sketch_finish)"""
+    def sketch_pack_parts(self, d_parts, caps, rcaps):
+        """sketch every assembly; each one's sketch is packed into its own buffer (d_parts[a]: 64-byte header + 12 * caps[a] bytes of
+        hashes and positions + 4 * rcaps[a] bytes: the records' first entries) right behind its last kernel --
+        part_packed_wait(a, stream) then lets a communication stream send it while the next assembly is sketched (finish with
+        sketch_finish)"""
         cc = np.ascontiguousarray(caps, dtype=np.uint64)
+        rc_ = np.ascontiguousarray(rcaps, dtype=np.uint64)
         pp = (C.c_void_p * len(d_parts))(*[int(x) for x in d_parts])
-        return self._check(self._lib.mxg_sketch_pack_parts(self._h, pp, cc.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return self._check(self._lib.mxg_sketch_pack_parts(self._h, pp, cc.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                           rc_.ctypes.data_as(C.POINTER(C.c_uint64))))
 
     def part_packed_wait(self, a, stream):
         """make `stream` (a raw hipStream_t) wait until assembly a's part is packed"""
         return self._check(self._lib.mxg_part_packed_wait(self._h, int(a), C.c_void_p(int(stream))))
 
-    def xchg_unpack_graph_parts(self, d_all_parts, world, caps, rec_offsets):
+    def xchg_unpack_graph_parts(self, d_all_parts, world, caps, rcaps, rec_offsets):
         """-> False when some rank's sketch did not fit its part (nothing usable), True: sketches unpacked + graph built"""
         cc = np.ascontiguousarray(caps, dtype=np.uint64)
+        rc_ = np.ascontiguousarray(rcaps, dtype=np.uint64)
         ro = np.ascontiguousarray(rec_offsets, dtype=np.uint64)
         pp = (C.c_void_p * len(d_all_parts))(*[int(x) for x in d_all_parts])
         rc = self._lib.mxg_xchg_unpack_graph_parts(self._h, pp, int(world), cc.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                                   ro.ctypes.data_as(C.POINTER(C.c_uint64)))
+                                                   rc_.ctypes.data_as(C.POINTER(C.c_uint64)), ro.ctypes.data_as(C.POINTER(C.c_uint64)))
         if rc == 1:
             return False
         self._check(rc)
