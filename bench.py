@@ -428,6 +428,18 @@ def dry_run(args):
         del keep
         torch.cuda.empty_cache()
     part_ms = max(x["sketch_ms"] + x["graph_stage_on_own_minimizers_ms"] + x["exchange_ms_at_link_rate"] for x in ranks) + 6 * 0.03
+    # ... and as built since round 6: every assembly's items (16 B per minimizer to its hash's owner) leave in an all-to-all of their own
+    # when that assembly's sketch ends, never before the assembly in front of it; verdicts and adjacency messages behind all of them
+    part_ovl = 0.0
+    for x in ranks:
+        tot_b = max(sum(x["bases_by_assembly"]), 1)
+        t, c = 0.0, 0.0
+        for a in range(len(asms)):
+            t += x["sketch_ms"] * x["bases_by_assembly"][a] / tot_b
+            items_a = 16 * x["minimizers_by_assembly"][a] * (N - 1) / N / (N - 1)          # bytes per link
+            c = max(c, t) + items_a / (XGMI_LINK_GBS * 1e9) * 1e3 + 0.03
+        rest = (x["bytes_sent_per_step"]["verdicts"] + x["bytes_sent_per_step"]["adjacency_messages"]) / (N - 1) / (XGMI_LINK_GBS * 1e9) * 1e3
+        part_ovl = max(part_ovl, c + rest + x["graph_stage_on_own_minimizers_ms"] + 5 * 0.03)
     # ---- the union route (ntjoin_amd/dist.py sketch_union_graph): every rank's sketch to every rank, the graph of the union on
     # every rank.  Its graph stage is measured on the real union of the ranks' sketches; an assembly's part is its fixed slot
     # (MXG_XCHG_SLOT_PCT above the largest share), all-gathered over N - 1 links at once (one part per link and direction).
@@ -466,7 +478,8 @@ def dry_run(args):
         union_one = max(union_one, x["sketch_ms"] + one_slot_bytes / link * 1e3 + 0.03)
     union_ovl += unpack_ms + t_union_graph
     union_one += unpack_ms + t_union_graph
-    routes = {"partitioned (exchange behind the sketches, as built)": round(part_ms, 3),
+    routes = {"partitioned, every exchange behind the sketches (MXG_XCHG_OVERLAP=0)": round(part_ms, 3),
+              "partitioned, an assembly's items beside the next assembly's sketch (as built)": round(part_ovl, 3),
               "union, one all-gather behind the sketches (MXG_XCHG_OVERLAP=0)": round(union_one, 3),
               "union, one all-gather per assembly beside the next assembly's sketch (as built)": round(union_ovl, 3)}
     step_ms = min(routes.values())   # bench.py --gpus N tries the routes in its warm-up and times the faster one
@@ -476,7 +489,7 @@ def dry_run(args):
            "config": {"workload": label + f", rank shares of 1/{N} of every assembly's bases", "bases_per_step": int(bases_job)},
            "model": "partitioned: step = max over ranks of (sketch stage + exchange bytes / (N-1) links at "
                     f"{XGMI_LINK_GBS:g} GB/s per link and direction + graph stage on as many minimizers as the rank owns) + 6 collectives x 30 us; "
-                    "the five host syncs of the exact partitioned exchange are inside the measured stages' own syncs or not modelled.  "
+                    "the five host syncs of the exact partitioned exchange are inside the measured stages' own syncs or not modelled; as built, an assembly's items leave when its sketch ends (sketch stage split by bases), one all-to-all per assembly, verdicts and messages behind them.  "
                     "union: an assembly's part = its fixed slot (12 B per entry + 4 B per record, MXG_XCHG_SLOT_PCT above the largest share) to every peer over its own link; "
                     "per assembly: ready when its sketch ends (sketch stage split by bases), gone one part-time + 30 us later, never before the part in front of it; "
                     "then unpack + the graph stage MEASURED on the union of the ranks' sketches.  value = the fastest route (bench.py --gpus N measures the routes and takes the faster)",
@@ -785,10 +798,12 @@ def main():
             # sketch -> pack -> all-gather -> unpack -> graph of the union, one host sync per step in steady state
             union = sketch_union_graph(e, K, W, local_rank, union, stream=xstream)
             return
-        e.sketch(-2)  # MXG_SKETCH_ALL: every assembly enqueued back to back
         if multi:
-            union = partitioned_graph(e, K, W, local_rank, union, stream=xstream)   # this rank's part of the graph
+            # this rank's part of the graph; the call sketches too: in steady state every assembly's items leave for their owners
+            # while the next assembly is still being sketched (ntjoin_amd/dist.py: _partitioned_slots, sketch_inside)
+            union = partitioned_graph(e, K, W, local_rank, union, stream=xstream, sketch=True)
         else:
+            e.sketch(-2)  # MXG_SKETCH_ALL: every assembly enqueued back to back
             e.build_graph()
 
     def fence():
@@ -926,7 +941,15 @@ def main():
                                         f"each 1/{world} of every assembly's bases (records cut at the range borders travel as pieces "
                                         "with a w-k-mer halo), ") +
                                        ("graph stage partitioned by hash range (RCCL all-to-all)" if graph_mode == "partitioned"
-                                        else "RCCL all-gather of sketches, graph of the union on every rank"))},
+                                        else "RCCL all-gather of sketches, graph of the union on every rank")),
+                       "exchange": (None if not multi else
+                                    ("every assembly's items leave in an all-to-all of their own while the next assembly is sketched"
+                                     if graph_mode == "partitioned" and union is not None and getattr(union, "_slots", None) is not None
+                                     and getattr(union, "_comm", None) is not None and not getattr(union, "_no_overlap", False)
+                                     else "items behind the sketches") if graph_mode == "partitioned" else
+                                    ("one all-gather per assembly beside the next assembly's sketch, 12 B per minimizer"
+                                     if union is not None and getattr(union, "_slots", None) and "send_parts" in union._slots
+                                     else "one all-gather behind the sketches, 16 B per minimizer"))},
             "distributed": dist_info,
             **(scaling_fields(wl, W, world, value, bases_total) if world > 1 else {}),
             "kernel_sources_digest": kernel_sources_digest(),

@@ -398,11 +398,21 @@ int mxg_dg_last_shared(mxg_handle *h, const void *d_ret, void *d_out);
 int mxg_dg_set_ghosts(mxg_handle *h, const void *d_all, uint32_t world, uint32_t rank);
 int mxg_dg_edges(mxg_handle *h, const void *d_msgs, uint64_t n_msgs, uint64_t *n_vertices, uint64_t *n_edges);
 /* Steady state of the same exchange with FIXED-CAPACITY SLOTS: once one exact step has shown the sizes, every (source,
-   destination) pair gets a slot = 64-byte header (u64 count per assembly, <= 8 assemblies) + cap[a] 16-byte items per
-   assembly; the all-to-alls then have equal splits and the receivers read the counts on the device: no size exchange,
-   no host sync before mxg_dg_edges_slots.  A count above its capacity sets *overflow there: repeat the step the exact
-   way.  Message slots: 64-byte header (word 0 = count) + max_msgs 16-byte messages.  mxg_dg_pack_slots clears the
-   headers when called for assembly 0 (pack the assemblies in order), mxg_dg_pack_msg_slots at its start. */
+   destination, assembly) triple gets a slot = 64-byte header (word 0 = the count) + cap[a] 16-byte items (<= 8 assemblies);
+   the all-to-alls then have equal splits and the receivers read the counts on the device: no size exchange, no host sync
+   before mxg_dg_edges_slots.  A count above its capacity sets *overflow there: repeat the step the exact way.  The item
+   buffer is ASSEMBLY-MAJOR: assembly a's `world` slots lie side by side at byte offset sum over a' < a of
+   world * (64 + 16 cap[a']), so that one all-to-all per assembly carries them (the verdict buffers stay [world][sum cap]).
+   Message slots: 64-byte header (word 0 = count) + max_msgs 16-byte messages.  mxg_dg_pack_slots clears its assembly's
+   headers, mxg_dg_pack_msg_slots all of them at its start.
+   mxg_sketch_dg_pack_slots = mxg_sketch(h, MXG_SKETCH_ALL) + mxg_dg_pack_slots for every assembly WITHOUT the host sync in
+   between: the sketches are enqueued, every assembly's items are packed right behind its own last kernel with the count
+   read on the device (rec_offsets[a] = that assembly's record index shift), and mxg_part_packed_wait(h, a, stream) lets the
+   caller's communication stream send assembly a's slots while the next assembly is still being sketched.  A sketch that did
+   not end the common way reaches every destination as a count far above any capacity (overflow: all ranks repeat the step the
+   exact way).  After the caller's sync on the handle's stream: mxg_sketch_finish.  No counterpart in the reference. */
+int mxg_sketch_dg_pack_slots(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const uint32_t *rec_offsets,
+                             void *d_send);
 int mxg_dg_pack_slots(mxg_handle *h, int assembly, uint32_t rec_offset, uint32_t world, uint32_t n_asm, const uint32_t *cap,
                       void *d_send);
 int mxg_dg_owner_slots(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv, void *d_n_vertices);

@@ -14,7 +14,7 @@ ABI_VERSION = 2
 
 SYMBOLS = [
     "mxg_abi_version", "mxg_create", "mxg_destroy", "mxg_last_error",
-    "mxg_add_assembly_fasta", "mxg_add_assembly_fasta_shard", "mxg_add_assembly_fasta_split", "mxg_assembly_continues", "mxg_xchg_pack", "mxg_xchg_unpack_graph", "mxg_sketch_pack", "mxg_sketch_pack_parts", "mxg_part_packed_wait", "mxg_xchg_unpack_graph_parts", "mxg_sketch_finish", "mxg_shard_range", "mxg_assembly_shard",
+    "mxg_add_assembly_fasta", "mxg_add_assembly_fasta_shard", "mxg_add_assembly_fasta_split", "mxg_assembly_continues", "mxg_xchg_pack", "mxg_xchg_unpack_graph", "mxg_sketch_pack", "mxg_sketch_pack_parts", "mxg_sketch_dg_pack_slots", "mxg_part_packed_wait", "mxg_xchg_unpack_graph_parts", "mxg_sketch_finish", "mxg_shard_range", "mxg_assembly_shard",
     "mxg_add_assembly_buffers", "mxg_add_assembly_packed_device",
     "mxg_add_assembly_tsv", "mxg_add_assembly_bin", "mxg_write_sketch_bin", "mxg_add_assembly_minimizers", "mxg_num_assemblies", "mxg_assembly_name",
     "mxg_record_id", "mxg_record_length", "mxg_num_records", "mxg_assembly_weight",
@@ -134,6 +134,7 @@ def load():
     L.mxg_xchg_unpack_graph.argtypes = [vp, vp, C.c_uint32, u64, u64, C.POINTER(u64), C.POINTER(u64)]
     L.mxg_sketch_pack_parts.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.mxg_part_packed_wait.argtypes = [vp, C.c_int, vp]
+    L.mxg_sketch_dg_pack_slots.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), vp]
     L.mxg_xchg_unpack_graph_parts.argtypes = [vp, C.POINTER(vp), C.c_uint32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mxg_shard_range.argtypes = [C.POINTER(u64), u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
     L.mxg_assembly_shard.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(u64)]

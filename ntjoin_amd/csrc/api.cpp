@@ -553,10 +553,30 @@ int mxg_sketch_pack_parts(mxg_handle *h, void *const *d_parts, const uint64_t *c
     }
 }
 
+int mxg_sketch_dg_pack_slots(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const uint32_t *rec_offsets, void *d_send)
+{
+    if (!h || !cap || !rec_offsets || !d_send) return MXG_EINVAL;
+    if (n_asm != h->asms.size()) return set_err(h, MXG_EINVAL, "mxg_sketch_dg_pack_slots: the handle has %zu assemblies", h->asms.size());
+    if (!h->pend_list.empty()) return set_err(h, MXG_EINVAL, "mxg_sketch_dg_pack_slots: the previous call was not finished (mxg_sketch_finish)");
+    try {
+        std::vector<Assembly *> todo;
+        for (auto *a : h->asms) {
+            if (!a->has_bases) return set_err(h, MXG_EINVAL, "mxg_sketch_dg_pack_slots: assembly '%s' has no bases", a->name.c_str());
+            todo.push_back(a);
+        }
+        if (todo.empty()) return set_err(h, MXG_EINVAL, "mxg_sketch_dg_pack_slots: no assemblies");
+        DgPackReq rq{world, n_asm, cap, rec_offsets, d_send};
+        XchgPackReq xp{nullptr, 0, nullptr, nullptr, nullptr, &rq};
+        return sketch_assemblies(h, todo.data(), todo.size(), false, &xp);
+    } catch (const std::bad_alloc &) {
+        return set_err(h, MXG_ENOMEM, "out of host memory in mxg_sketch_dg_pack_slots");
+    }
+}
+
 int mxg_part_packed_wait(mxg_handle *h, int assembly, void *stream)
 {
     if (!h || assembly < 0 || (size_t)assembly >= h->asms.size() || assembly >= MXG_MAX_ASSEMBLIES) return MXG_EINVAL;
-    if (!h->ev_part[assembly]) return set_err(h, MXG_EINVAL, "mxg_part_packed_wait: no mxg_sketch_pack_parts before");
+    if (!h->ev_part[assembly]) return set_err(h, MXG_EINVAL, "mxg_part_packed_wait: no mxg_sketch_pack_parts / mxg_sketch_dg_pack_slots before");
     MXG_HIP(h, hipSetDevice(h->device));
     MXG_HIP(h, hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_part[assembly], 0));
     return MXG_OK;

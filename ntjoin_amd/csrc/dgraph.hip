@@ -570,16 +570,20 @@ int dg_pack_msgs(mxg_handle *h, Assembly *a, uint32_t assembly, uint32_t world, 
 
 // ------------------------------------------------------------------------------------------------------
 // Steady state: fixed-capacity slots.  Once the sizes of one exact exchange are known, every (source, destination) pair
-// gets a slot of fixed capacity (header of counts + one region per assembly); the all-to-alls then have equal splits
-// (no size exchange), and the receivers read the counts from the headers ON THE DEVICE (no host sync until the stage's
-// last kernel).  A count above its capacity raises an overflow word and the caller repeats the step the exact way.
+// gets a slot of fixed capacity PER ASSEMBLY (64-byte header: the count + cap[a] items); the all-to-alls then have equal
+// splits (no size exchange), and the receivers read the counts from the headers ON THE DEVICE (no host sync until the
+// stage's last kernel).  A count above its capacity raises an overflow word and the caller repeats the step the exact way.
+// The buffer is ASSEMBLY-MAJOR (round 6): assembly a's slots for all `world` destinations lie side by side, so ONE all-to-all
+// per assembly carries them -- and can leave as soon as that assembly is sketched, while the next one still is (dg_pack_slots_dev).
 // ------------------------------------------------------------------------------------------------------
 struct DgSlots {
     uint32_t world, n_asm;
-    uint32_t cap[8];   // items per assembly and slot
-    uint32_t off[8];   // first item of assembly a inside a slot's item area
-    uint32_t items;    // items per slot
-    uint64_t stride;   // bytes per slot: 64 (header: u64 count per assembly) + 16 * items
+    uint32_t cap[8];      // items per assembly and slot
+    uint32_t off[8];      // first verdict of assembly a inside a destination's verdict area (the verdict buffers are [world][items])
+    uint32_t items;       // items per destination, all assemblies
+    uint64_t abase[8];    // byte offset of assembly a's `world` slots
+    uint64_t astride[8];  // bytes per slot of assembly a: 64 (header: word 0 = count) + 16 * cap[a]
+    uint64_t total;       // bytes of the whole buffer
 };
 
 static int dg_layout(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, DgSlots *L)
@@ -594,21 +598,63 @@ static int dg_layout(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32
         off += L->cap[a];
     }
     L->items = off;
-    L->stride = 64 + (uint64_t)off * 16;
+    uint64_t at = 0;
+    for (uint32_t a = 0; a < 8; ++a) {
+        L->abase[a] = at;
+        L->astride[a] = 64 + (uint64_t)L->cap[a] * 16;
+        if (a < n_asm) at += (uint64_t)world * L->astride[a];
+    }
+    L->total = at;
     return MXG_OK;
 }
 
-__device__ __forceinline__ const unsigned long long *slot_hdr(const unsigned char *buf, const DgSlots &L, uint32_t s)
+// the slot of assembly a for destination / from source s (its first word = the count, its items 64 bytes further)
+__device__ __forceinline__ const unsigned char *slot_at(const unsigned char *buf, const DgSlots &L, uint32_t a, uint32_t s)
 {
-    return reinterpret_cast<const unsigned long long *>(buf + (size_t)s * L.stride);
+    return buf + L.abase[a] + (size_t)s * L.astride[a];
 }
+__device__ __forceinline__ unsigned long long slot_count(const unsigned char *buf, const DgSlots &L, uint32_t a, uint32_t s)
+{
+    return *reinterpret_cast<const unsigned long long *>(slot_at(buf, L, a, s));
+}
+// a sender whose sketch was not usable (dg_pack_slots_dev) says so with a count no slot can hold: overflow like any count above
+// the capacity, but NOTHING in the slot is an item then (a count that merely exceeds the capacity leaves `cap` good items)
+constexpr unsigned long long DG_SLOT_INVALID = 1ull << 40;
+__device__ __forceinline__ uint32_t slot_items(unsigned long long raw, uint32_t cap)
+{
+    return raw >= DG_SLOT_INVALID ? 0u : (uint32_t)min(raw, (unsigned long long)cap);
+}
+
+// mxg_sketch_dg_pack_slots: the sketch may still be in flight on the stream -- its length is read on the device and the batch's
+// control words say whether it ended the common way (the predicate of k_pack_slot_dev, sketch.hip).  mode 0: n is the host's.
+struct DgDevN {
+    uint32_t mode;  // 0: host count; 1: count + predicate on the device; 2: the host knows the sketch is not usable
+    const uint32_t *n_ptr, *ctrl;
+    uint64_t out_cap;
+    uint32_t dev_gaps, place4;
+};
 
 __global__ __launch_bounds__(256) void k_dg_pack_slots(const uint64_t *__restrict__ hash, const uint32_t *__restrict__ pos,
                                                        const uint32_t *__restrict__ rec, uint64_t n, uint32_t a, uint32_t rec_off,
-                                                       const DgSlots L, unsigned char *send, uint32_t *perm)
+                                                       const DgSlots L, unsigned char *send, uint32_t *perm, const DgDevN dv)
 {
     __shared__ uint32_t lh[64], lcur[64];
     __shared__ unsigned long long lbase[64];
+    if (dv.mode) {  // (block-uniform)
+        bool ok = dv.mode == 1;
+        if (ok) {
+            const uint32_t *ctrl = dv.ctrl;
+            n = *dv.n_ptr;
+            ok = ctrl[0] == 0 && ctrl[6] == 0 && ctrl[13] == 0 && (dv.dev_gaps ? (ctrl[11] == 0 && ctrl[1] <= dv.place4) : ctrl[1] == 0) &&
+                 (ctrl[4] | ctrl[5]) != 0 && n <= dv.out_cap;
+        }
+        if (!ok) {  // every destination sees a count far above any capacity: all ranks repeat the step the exact way
+            if (blockIdx.x == 0 && threadIdx.x < L.world)
+                atomicAdd(reinterpret_cast<unsigned long long *>(send + L.abase[a] + (size_t)threadIdx.x * L.astride[a]), DG_SLOT_INVALID);
+            return;
+        }
+        if ((uint64_t)blockIdx.x * DG_IPB >= n) return;
+    }
     if (threadIdx.x < 64) lh[threadIdx.x] = lcur[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t i0 = (uint64_t)blockIdx.x * DG_IPB;
@@ -619,7 +665,7 @@ __global__ __launch_bounds__(256) void k_dg_pack_slots(const uint64_t *__restric
     }
     __syncthreads();
     if (threadIdx.x < L.world && lh[threadIdx.x])  // the header word of the destination's slot is the bucket's cursor
-        lbase[threadIdx.x] = atomicAdd(reinterpret_cast<unsigned long long *>(send + (size_t)threadIdx.x * L.stride) + a,
+        lbase[threadIdx.x] = atomicAdd(reinterpret_cast<unsigned long long *>(send + L.abase[a] + (size_t)threadIdx.x * L.astride[a]),
                                        (unsigned long long)lh[threadIdx.x]);
     __syncthreads();
     for (uint32_t it = 0; it < DG_IPB / 256; ++it) {
@@ -631,7 +677,7 @@ __global__ __launch_bounds__(256) void k_dg_pack_slots(const uint64_t *__restric
         if (in) {
             const uint64_t idx = lbase[d] + sl;
             if (idx < L.cap[a]) {
-                reinterpret_cast<uint4 *>(send + (size_t)d * L.stride + 64)[L.off[a] + idx] =
+                reinterpret_cast<uint4 *>(send + L.abase[a] + (size_t)d * L.astride[a] + 64)[idx] =
                     make_uint4((uint32_t)h, (uint32_t)(h >> 32), pos[i], rec[i] + rec_off);
                 perm[i] = d * L.items + L.off[a] + (uint32_t)idx;
             } else {
@@ -647,20 +693,21 @@ __global__ __launch_bounds__(256) void k_dg_slots_to_soa(const unsigned char *__
 {
     const uint32_t cap = L.cap[a];
     const uint64_t o = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (o >= (uint64_t)L.world * cap) return;
-    const uint32_t src = (uint32_t)(o / cap), idx = (uint32_t)(o % cap);
+    const bool any = o < (uint64_t)L.world * cap;
+    if (!any && o != 0) return;  // (thread 0 reads the headers whatever the capacity: a slot without room can still say "overflow")
+    const uint32_t src = any ? (uint32_t)(o / cap) : 0u, idx = any ? (uint32_t)(o % cap) : 0u;
     uint32_t before = 0, mine = 0, total = 0;
     for (uint32_t s = 0; s < L.world; ++s) {
-        const unsigned long long raw = slot_hdr(recv, L, s)[a];
+        const unsigned long long raw = slot_count(recv, L, a, s);
         if (raw > cap && o == 0) *ovf = 1;
-        const uint32_t c = (uint32_t)min(raw, (unsigned long long)cap);
+        const uint32_t c = slot_items(raw, cap);
         if (s < src) before += c;
         if (s == src) mine = c;
         total += c;
     }
     if (o == 0) n_out[a] = total;
-    if (idx >= mine) return;
-    const uint4 it = reinterpret_cast<const uint4 *>(recv + (size_t)src * L.stride + 64)[L.off[a] + idx];
+    if (!any || idx >= mine) return;
+    const uint4 it = reinterpret_cast<const uint4 *>(slot_at(recv, L, a, src) + 64)[idx];
     const uint32_t t = before + idx;
     hash[t] = ((uint64_t)it.y << 32) | it.x;
     pos[t] = it.z;
@@ -678,7 +725,7 @@ __global__ __launch_bounds__(256) void k_dg_slot_results(const uint8_t *__restri
     const uint32_t src = (uint32_t)(o / cap), idx = (uint32_t)(o % cap);
     uint32_t before = 0, mine = 0;
     for (uint32_t s = 0; s <= src; ++s) {
-        const uint32_t c = (uint32_t)min(slot_hdr(recv, L, s)[a], (unsigned long long)cap);
+        const uint32_t c = slot_items(slot_count(recv, L, a, s), cap);
         if (s < src) before += c; else mine = c;
     }
     if (idx >= mine) return;
@@ -749,15 +796,39 @@ int dg_pack_slots(mxg_handle *h, Assembly *a, uint32_t ai, uint32_t rec_offset, 
     DgSlots L;
     int rc = dg_layout(h, world, n_asm, cap, &L);
     if (rc != MXG_OK) return rc;
+    if (ai >= n_asm) return MXG_EINVAL;
     MXG_HIP(h, a->d_perm.ensure(std::max<uint64_t>(a->n_mx * 4, 16)));
-    if (ai == 0)  // the slot headers are the buckets' cursors: cleared here, on the stream the packing kernels run on
-        MXG_HIP(h, hipMemset2DAsync(d_send, L.stride, 0, 64, world, h->stream));
+    // the slot headers are the buckets' cursors: this assembly's are cleared here, on the stream the packing kernel runs on
+    MXG_HIP(h, hipMemset2DAsync(static_cast<unsigned char *>(d_send) + L.abase[ai], L.astride[ai], 0, 64, world, h->stream));
     if (a->n_mx)
         hipLaunchKernelGGL(k_dg_pack_slots, dim3((uint32_t)((a->n_mx + DG_IPB - 1) / DG_IPB)), dim3(256), 0, h->stream,
                            a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(), a->d_rec.as<uint32_t>(), a->n_mx, ai, rec_offset, L,
-                           static_cast<unsigned char *>(d_send), a->d_perm.as<uint32_t>());
+                           static_cast<unsigned char *>(d_send), a->d_perm.as<uint32_t>(), DgDevN{0, nullptr, nullptr, 0, 0, 0});
     MXG_HIP(h, hipGetLastError());
     if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));
+    return MXG_OK;
+}
+
+// the same behind a sketch that is still in flight on `st` (sketch_assemblies, mxg_sketch_dg_pack_slots): the count is read on the
+// device (n_ptr; ctrl = the batch's control words), the grid covers what the output arrays hold.  mode 2: the host already knows
+// that the sketch did not go through the one-batch pipeline; mode 0 with n = 0: an assembly without k-mers.
+int dg_pack_slots_dev(mxg_handle *h, Assembly *a, uint32_t ai, const DgPackReq &rq, hipStream_t st, uint32_t mode, const uint32_t *n_ptr,
+                      const uint32_t *ctrl, uint64_t out_cap, uint32_t dev_gaps, uint32_t place4)
+{
+    DgSlots L;
+    int rc = dg_layout(h, rq.world, rq.n_asm, rq.cap, &L);
+    if (rc != MXG_OK) return rc;
+    if (ai >= rq.n_asm) return MXG_EINVAL;
+    unsigned char *send = static_cast<unsigned char *>(rq.d_send);
+    MXG_HIP(h, hipMemset2DAsync(send + L.abase[ai], L.astride[ai], 0, 64, rq.world, st));
+    if (mode == 1) MXG_HIP(h, a->d_perm.ensure(std::max<uint64_t>(out_cap * 4, 16)));
+    const uint64_t bound = mode == 1 ? out_cap : 0;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>((bound + DG_IPB - 1) / DG_IPB, 1);
+    if (mode != 0)
+        hipLaunchKernelGGL(k_dg_pack_slots, dim3(grid), dim3(256), 0, st, a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(),
+                           a->d_rec.as<uint32_t>(), (uint64_t)0, ai, rq.rec_off[ai], L, send, a->d_perm.as<uint32_t>(),
+                           DgDevN{mode, n_ptr, ctrl, out_cap, dev_gaps, place4});
+    MXG_HIP(h, hipGetLastError());
     return MXG_OK;
 }
 
@@ -780,8 +851,7 @@ int dg_owner_slots(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t
         MXG_HIP(h, a->d_hash.ensure(std::max<uint64_t>(bound * 8, 16)));
         MXG_HIP(h, a->d_pos.ensure(std::max<uint64_t>(bound * 4, 16)));
         MXG_HIP(h, a->d_rec.ensure(std::max<uint64_t>(bound * 4, 16)));
-        if (bound)
-            hipLaunchKernelGGL(k_dg_slots_to_soa, dim3((uint32_t)((bound + 255) / 256)), dim3(256), 0, h->stream,
+        hipLaunchKernelGGL(k_dg_slots_to_soa, dim3((uint32_t)std::max<uint64_t>((bound + 255) / 256, 1)), dim3(256), 0, h->stream,
                                static_cast<const unsigned char *>(d_recv), L, ai, a->d_hash.as<uint64_t>(), a->d_pos.as<uint32_t>(),
                                a->d_rec.as<uint32_t>(), h->d_nmx.as<uint32_t>(), ovf);
         a->n_mx = bound;  // an upper bound until mxg_dg_edges_slots reads the counts back

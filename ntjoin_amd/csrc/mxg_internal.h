@@ -367,6 +367,15 @@ struct XchgPackReq {  // mxg_sketch_pack: where the sketches go once they exist 
     // assembly's own k_emit on the stream it ran on, with an event the caller's communication stream can wait for (ev_part)
     void *const *d_parts = nullptr;
     const uint64_t *rcaps = nullptr;  // ... and room for this many records' first entries behind the 12 bytes per entry
+    // mxg_sketch_dg_pack_slots: instead, every assembly's minimizers into the item slots of the partitioned graph stage (dgraph.hip),
+    // right behind that assembly's k_emit, with the same per-assembly event
+    const struct DgPackReq *dg = nullptr;
+};
+struct DgPackReq {
+    uint32_t world, n_asm;
+    const uint32_t *cap;      // items per (destination, assembly) slot
+    const uint32_t *rec_off;  // record index shift per assembly
+    void *d_send;
 };
 constexpr uint64_t XCHG_PART_HEAD = 64;
 int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_graph = false, const XchgPackReq *xp = nullptr);
@@ -409,6 +418,8 @@ int dg_pack_msgs(mxg_handle *h, Assembly *a, uint32_t assembly, uint32_t world, 
                  void *d_send);
 int dg_pack_slots(mxg_handle *h, Assembly *a, uint32_t ai, uint32_t rec_offset, uint32_t world, uint32_t n_asm, const uint32_t *cap,
                   void *d_send);
+int dg_pack_slots_dev(mxg_handle *h, Assembly *a, uint32_t ai, const DgPackReq &rq, hipStream_t st, uint32_t mode, const uint32_t *n_ptr,
+                      const uint32_t *ctrl, uint64_t out_cap, uint32_t dev_gaps, uint32_t place4);
 int dg_owner_slots(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv, void *d_nv);
 int dg_slot_results(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv, const void *d_gbase,
                     void *d_out);

@@ -3486,7 +3486,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
                 hipEvent_t behind = nullptr;
                 // (mxg_sketch_pack_parts: always -- the assembly before this one must END first, its part travels beside this filter)
                 if (stagger && !one_stream && last_sel_slot >= 0 && drvs[last_sel_slot] != &drv &&
-                    (list[i]->total_kmers >= (1ull << 31) || (xp && xp->d_parts)))
+                    (list[i]->total_kmers >= (1ull << 31) || (xp && (xp->d_parts || xp->dg))))
                     behind = h->ev_sel_done[last_sel_slot];
                 if (sel_ok && (rc = drv.clear_sel_ctrl(bgs[b])) != MXG_OK) return rc;
                 if ((rc = bs_edges(h, list[i], drv.st)) != MXG_OK) return rc;  // (the two blocks that copy the edge chunks need not wait)
@@ -3563,6 +3563,17 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
     };
     auto pack_part = [&](size_t i, hipStream_t st, Driver *drv, uint32_t place4) -> int {
         Assembly *a = list[i];
+        if (xp->dg) {  // the partitioned graph stage's item slots instead of an exchange part
+            const uint64_t oc = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
+            MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
+            const int rcd = dg_pack_slots_dev(h, a, (uint32_t)i, *xp->dg, st, state[i] == 1 ? 1u : (state[i] == 2 ? 0u : 2u),
+                                              h->d_nmx.as<uint32_t>() + i, drv ? drv->sc(SC_CTRL).as<uint32_t>() : nullptr, oc,
+                                              state[i] == 1 && plans[i].dev_gaps ? 1u : 0u, place4);
+            if (rcd != MXG_OK) return rcd;
+            if (!h->ev_part[i]) MXG_HIP(h, hipEventCreateWithFlags(&h->ev_part[i], hipEventDisableTiming));
+            MXG_HIP(h, hipEventRecord(h->ev_part[i], st));
+            return MXG_OK;
+        }
         const uint64_t cap = xp->caps[i];
         const uint64_t out_cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});
         const long long fixed = state[i] == 1 ? -2ll : (state[i] == 2 ? 0ll : -1ll);
@@ -3604,7 +3615,7 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         if ((rc = enqueue_asm(i, 0)) != MXG_OK) return rc;
         cold_mark("enqueue_asm", i);
         if (state[i] == 1) ++n_enq;
-        if (xp && xp->d_parts && state[i] == 1) {
+        if (xp && (xp->d_parts || xp->dg) && state[i] == 1) {
             // mxg_sketch_pack_parts: this assembly's part right behind its k_emit, on the stream that ran it -- the caller's
             // all-gather of the part travels while the next assembly is sketched
             const Item &it = items[q_lo[i]];
@@ -3628,9 +3639,9 @@ int sketch_assemblies(mxg_handle *h, Assembly *const *list, size_t n, bool fuse_
         MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4));
         unsigned char *base = static_cast<unsigned char *>(xp->d_slot);
         uint64_t off = xp->head_bytes;
-        for (size_t i = 0; xp->d_parts && i < n; ++i)  // (parts: what was enqueued is packed already; the others say 0 / -1)
+        for (size_t i = 0; (xp->d_parts || xp->dg) && i < n; ++i)  // (parts: what was enqueued is packed already; the others say 0 / -1)
             if (state[i] != 1 && (rc = pack_part(i, h->stream, nullptr, 0)) != MXG_OK) return rc;
-        for (size_t i = 0; !xp->d_parts && i < n; ++i) {
+        for (size_t i = 0; !xp->d_parts && !xp->dg && i < n; ++i) {
             Assembly *a = list[i];
             const uint64_t cap = xp->caps[i];
             const uint64_t out_cap = std::min<uint64_t>({a->d_hash.bytes / 8, a->d_pos.bytes / 4, a->d_rec.bytes / 4, a->d_fwd.bytes});

@@ -378,7 +378,7 @@ def _grow(cache, key, n_bytes, dev):
     return t
 
 
-def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
+def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None, sketch=False):
     """The graph stage without replication: every minimizer goes to the rank that owns its hash (all-to-all), the owner
     decides uniqueness / intersection for its hashes and numbers its vertices, the verdicts come back, the adjacency of
     this rank's records goes to the owners of the end points, and every owner emits its edges.  Work and memory per rank
@@ -393,7 +393,15 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
     from .engine import MxEngine
     if stream is not None and torch.cuda.current_stream() != stream:
         with torch.cuda.stream(stream):
-            return partitioned_graph(eng, k, w, device, owner, group, stream)
+            return partitioned_graph(eng, k, w, device, owner, group, stream, sketch)
+    # sketch=True: the call sketches `eng`'s assemblies itself -- in steady state (fixed slots, MXG_XCHG_OVERLAP != 0, a stream) every
+    # assembly's items are packed on the device right behind its sketch and its all-to-all leaves while the next assembly is sketched
+    sketched = not sketch
+    overlap = (sketch and stream is not None and overlap_exchange() and owner is not None and getattr(owner, "_slots", None) is not None
+               and os.environ.get("MXG_DG_EXACT") != "1" and not getattr(owner, "_no_overlap", False))
+    if sketch and not overlap:
+        eng.sketch(-2)
+        sketched = True
     lib, A = eng._lib, eng.n_assemblies
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = torch.device("cuda", device)
@@ -430,9 +438,12 @@ def partitioned_graph(eng, k, w, device, owner=None, group=None, stream=None):
                      "bases": torch.zeros(world + 1, dtype=torch.int32, device=dev)}
     buf, st = owner._buf, owner._st
     if getattr(owner, "_slots", None) is not None and os.environ.get("MXG_DG_EXACT") != "1":
-        if _partitioned_slots(eng, owner, A, world, rank, dev, group, stream):
+        if _partitioned_slots(eng, owner, A, world, rank, dev, group, stream, sketch_inside=not sketched):
             return owner
         owner._slots = None                  # a slot was too small somewhere: this step the exact way, new capacities
+        if not sketched:                     # ... or a sketch could not be packed on the device (an assembly that does not take the
+            owner._no_overlap = True         # one-batch route would say so every step): from now on behind the sketches
+        sketched = True                      # (the sketches are complete: mxg_sketch_finish redid what did not travel)
     prof = getattr(owner, "_prof", None)     # tools: owner._prof = {} collects host seconds per section
     import time as _time
     t_last = [_time.perf_counter()]
@@ -567,27 +578,59 @@ def _ghosts(eng, owner, lib, A, world, rank, dev, ret_in, group, own):
         eng._check(rc)
 
 
-def _partitioned_slots(eng, owner, A, world, rank, dev, group, stream):
-    """one step of the partitioned graph stage with fixed-capacity slots: 4 all-to-all / all-gather collectives with equal
+def _partitioned_slots(eng, owner, A, world, rank, dev, group, stream, sketch_inside=False):
+    """one step of the partitioned graph stage with fixed-capacity slots: all-to-all / all-gather collectives with equal
     splits, counts read on the device, ONE host sync (the owner's last kernel) + the agreement on overflow.  False: a
-    slot overflowed on some rank (all ranks return False together)."""
+    slot overflowed on some rank (all ranks return False together).  The item slots are assembly-major -- assembly a's
+    slots for all destinations side by side -- and travel in one all-to-all per assembly.  sketch_inside: `eng` has not been
+    sketched yet; its sketches are enqueued here, every assembly's items are packed on the device right behind its last kernel
+    (mxg_sketch_dg_pack_slots) and its all-to-all is issued on a communication stream that waits for that event only: the
+    reference's items travel while the target is being sketched."""
     import ctypes as C
     lib, sl, st, buf = eng._lib, owner._slots, owner._st, owner._buf
     caps, items, M = sl["caps"], sl["items"], sl["M"]
     capp = caps.ctypes.data_as(C.POINTER(C.c_uint32))
     cur = torch.cuda.current_stream()
-    stride, mstride = 64 + 16 * items, 64 + 16 * M
+    mstride = 64 + 16 * M
+    astride = [64 + 16 * int(c) for c in caps[:A]]
+    abase = np.concatenate([[0], np.cumsum([world * x for x in astride])]).astype(np.int64)
+    total = int(abase[A])
 
     def chk(e, rc):
         if rc < 0:
             e._check(rc)
 
-    send = _grow(buf, "s_send", world * stride, dev)[:world * stride]
-    recv = _grow(buf, "s_recv", world * stride, dev)[:world * stride]
-    for a in range(A):
-        chk(eng, lib.mxg_dg_pack_slots(eng._h, a, owner._rec_off[a], world, A, capp, C.c_void_p(send.data_ptr())))
+    send = _grow(buf, "s_send", total, dev)[:total]
+    recv = _grow(buf, "s_recv", total, dev)[:total]
+    part = lambda t, a: t[int(abase[a]):int(abase[a + 1])].view(world, astride[a])  # noqa: E731  (assembly a's slots, one per rank)
     own = stream is None                                                      # handles on their own streams: a collective's
-    dist.all_to_all_single(recv.view(world, stride), send.view(world, stride), group=group)
+    if sketch_inside:
+        comm = getattr(owner, "_comm", None)
+        if comm is None:
+            comm = owner._comm = torch.cuda.Stream(device=dev)
+        comm.wait_stream(cur)                                                 # (the last step's owner kernels have read `recv`)
+        roff = np.ascontiguousarray(owner._rec_off, dtype=np.uint32)
+        chk(eng, lib.mxg_sketch_dg_pack_slots(eng._h, world, A, capp, roff.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(send.data_ptr())))
+        works = []
+        for a in range(A):
+            chk(eng, lib.mxg_part_packed_wait(eng._h, a, C.c_void_p(comm.cuda_stream)))
+            with torch.cuda.stream(comm):
+                works.append(dist.all_to_all_single(part(recv, a), part(send, a), group=group, async_op=True))
+        for wk in works:
+            wk.wait()
+        cur.wait_stream(comm)
+        # a sender whose sketch could not be packed on the device marked ALL its slots (a count no slot can hold): every rank sees that
+        # in what it received, so all leave together -- before this rank's own verdict lookup runs over an index it never wrote
+        worst = torch.stack([part(recv, a)[:, :8].contiguous().view(torch.int64).max() for a in range(A)]).max()
+        invalid = int(worst.item()) >= (1 << 40)                              # (the sync: the sketches are complete, the items have arrived)
+        eng.sketch_finish()
+        if invalid:
+            return False
+    else:
+        for a in range(A):
+            chk(eng, lib.mxg_dg_pack_slots(eng._h, a, owner._rec_off[a], world, A, capp, C.c_void_p(send.data_ptr())))
+        for a in range(A):
+            dist.all_to_all_single(part(recv, a), part(send, a), group=group)
     if own:                                                                   # result must be complete before a handle reads it
         cur.synchronize()
     chk(owner, lib.mxg_dg_owner_slots(owner._h, world, A, capp, C.c_void_p(recv.data_ptr()), C.c_void_p(st["nv"].data_ptr())))

@@ -30,6 +30,24 @@ def records(seed, n, genome=90000):
     return out
 
 
+def records_np(seed, n, genome):
+    """the same construction with numpy (sizes at which the sketches take the one-batch device route: Mbp per rank)"""
+    import numpy as np
+    base = np.random.default_rng(0).integers(0, 4, genome).astype(np.uint8)
+    rng = np.random.default_rng(seed)
+    cuts = np.sort(rng.choice(np.arange(2000, genome - 2000), n - 1, replace=False)).tolist()
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+    for r, (lo, hi) in enumerate(zip([0] + cuts, cuts + [genome])):
+        s_ = base[lo:hi].copy()
+        at = rng.integers(0, len(s_), len(s_) // 300)
+        s_[at] = rng.integers(0, 4, len(at))
+        if r % 3 == 1:
+            s_ = (3 - s_[::-1]).astype(np.uint8)
+        out.append((f"s{seed}_{r}", acgt[s_].tobytes().decode()))
+    return out
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
@@ -40,6 +58,9 @@ def main():
         w = 500
         asms = [("ref1", 2.0, records(11, 17, 700000)), ("ref2", 2.0, records(12, 13, 700000)), ("ref3", 2.0, records(13, 19, 700000)),
                 ("tgt", 1.0, records(14, 41, 700000))]
+    if os.environ.get("MXG_TEST_CONFIG3") == "2":   # configs[2]'s shape at 6 Mbp per assembly: every rank's sketches are packed on the device
+        w = 1000
+        asms = [("refA", 2.0, records_np(1, 9, 6_000_000)), ("refB", 1.5, records_np(2, 7, 6_000_000)), ("tgt", 1.0, records_np(3, 11, 6_000_000))]
     use_stream = os.environ.get("MXG_TEST_STREAM") == "1"
     xs = torch.cuda.Stream() if use_stream else None
     kw = {"cand_per_window": int(os.environ["MXG_TEST_CAND"])} if os.environ.get("MXG_TEST_CAND") else {}
@@ -60,9 +81,13 @@ def main():
     # the same graph, distributed by hash range: every rank ends up with its own vertices and edges
     owner = None
     for _step in range(3):                       # exact exchange, then twice with the fixed-capacity slots
-        eng.sketch(-2)
-        owner = partitioned_graph(eng, k, w, 0, owner, stream=xs)
+        if os.environ.get("MXG_TEST_DG_SKETCH", "1") == "1":   # the call sketches too (on a stream and with slots: every assembly's
+            owner = partitioned_graph(eng, k, w, 0, owner, stream=xs, sketch=True)   # items leave while the next one is sketched)
+        else:
+            eng.sketch(-2)
+            owner = partitioned_graph(eng, k, w, 0, owner, stream=xs)
     os.write(1, f"slots in use: {owner._slots is not None}\n".encode())
+    os.write(1, f"ITEMS rank {rank}: {'behind the sketches' if getattr(owner, '_comm', None) is None or getattr(owner, '_no_overlap', False) else 'beside the sketches'}\n".encode())
     partitioned_totals(owner)
     pg = owner.get_graph()
     part = {"base": owner.dg["base"], "vhash": pg["vertex_hash"].tolist(),

@@ -34,6 +34,31 @@ def test_union_graph_world_size(world, stream, slot_pct):
     assert out.stdout.count("DIST2 OK") == world, out.stdout[-3000:]
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_both_overlapped_exchanges_at_a_size_where_they_really_run(world):
+    """6 Mbp per assembly, w = 1000: every rank's sketches end the common way, so the union's per-assembly all-gathers (12 bytes
+    per minimizer) and the partitioned route's per-assembly item all-to-alls are what the later steps take (the worker says so) --
+    same graph as a single handle holding every record"""
+    env = dict(os.environ, MXG_TEST_STREAM="1", MXG_TEST_CONFIG3="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "tests", "_dist2_worker.py")]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("DIST2 OK") == world, out.stdout[-3000:]
+    assert out.stdout.count("beside the sketches") == world and out.stdout.count("per-assembly") == world, out.stdout[-3000:]
+
+
+def test_partitioned_graph_behind_sketches_of_the_callers_own():
+    """the two-call form of the partitioned route (mxg_sketch, then partitioned_graph): the default of the other tests is the
+    one call that sketches too and lets every assembly's items leave while the next assembly is sketched"""
+    env = dict(os.environ, MXG_TEST_STREAM="1", MXG_TEST_DG_SKETCH="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "tests", "_dist2_worker.py")]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("DIST2 OK") == 2, out.stdout[-3000:]
+
+
 @pytest.mark.parametrize("overlap", ["1", "0"])
 def test_union_exchange_per_assembly_and_as_one_gather(overlap):
     """the steady-state exchange of the union route both ways: one all-gather per assembly, issued on a communication stream as
@@ -91,13 +116,14 @@ def test_bench_two_ranks_on_one_gpu(mode):
     env = dict(os.environ, MXG_BENCH_BACKEND="gloo", MXG_BENCH_ONE_DEVICE="1", MXG_BENCH_GRAPH=mode)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--mbp", "5"]
+           "--mbp", "50"]   # (large enough for the sketches to be packed on the device: the overlapped exchanges really run)
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0   # N=2: configs[2] shared between the ranks
-    assert d["config"]["bases_per_step"] > 0.95 * 2 * 5e6       # the whole job's 5 Mbp + ~5 Mbp
+    assert d["config"]["bases_per_step"] > 0.95 * 2 * 50e6      # the whole job's 50 Mbp + ~50 Mbp
+    assert ("while the next assembly is sketched" in d["config"]["exchange"]) if mode == "partitioned" else ("per assembly" in d["config"]["exchange"])
     assert d["config"]["vertices"] > 0 and d["config"]["edges"] > 0
     assert ("partitioned" in d["config"]["parallelism"]) == (mode == "partitioned")
     _BENCH_COUNTS[mode] = (d["config"]["vertices"], d["config"]["edges"])
