@@ -376,8 +376,24 @@ def dry_run(args):
     ranks = []
     parts = [[] for _ in asms]   # per assembly: every rank's sketch (host arrays), for the union route's graph stage
     rec_ids = None
+    # the partitioned route's graph stage is timed through its REAL code path (ntjoin_amd/dist.py partitioned_graph: the rank's packing /
+    # verdict / message kernels and the owner's kernels, on as many minimizers as the rank owns) with the collectives of ONE rank: copies
+    import torch.distributed as tdist
+    from ntjoin_amd.dist import partitioned_graph
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def _copy(out, inp, *a, **k):
+        out.view(-1)[:inp.numel()].copy_(inp.reshape(-1))
+        return _Done()
+    loop = {"get_world_size": lambda group=None: 1, "get_rank": lambda group=None: 0, "all_to_all_single": _copy,
+            "all_gather_into_tensor": _copy, "all_reduce": lambda t, *a, **k: _Done()}
+    saved = {k_: getattr(tdist, k_) for k_ in loop}
+    xs = torch.cuda.Stream()
     for r in range(N):
-        eng = MxEngine(k=K, w=W, device=0, timing=True, timing_fine=True, cand_per_window=args.cand)
+        eng = MxEngine(k=K, w=W, device=0, timing=True, timing_fine=True, cand_per_window=args.cand, stream=xs.cuda_stream)
         keep = [add_rank_share(eng, name, weight, segs, cfg["seed"], sub_seed, sub, r, N, 0)[0] for name, weight, segs, _, sub, sub_seed in asms]
         eng.global_records = True
         for _ in range(max(args.warmup, 1)):
@@ -396,6 +412,23 @@ def dry_run(args):
         torch.cuda.synchronize()
         t_gr = (time.perf_counter() - t1) / args.steps * 1e3
         st = eng.stats()
+        for k_, f_ in loop.items():
+            setattr(tdist, k_, f_)
+        try:
+            owner = None
+            for _ in range(3):                      # the exact exchange, then the fixed slots
+                owner = partitioned_graph(eng, K, W, 0, owner, stream=xs)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                owner = partitioned_graph(eng, K, W, 0, owner, stream=xs)
+            torch.cuda.synchronize()
+            t_dg = (time.perf_counter() - t3) / args.steps * 1e3
+            dg_slots = getattr(owner, "_slots", None) is not None
+            owner.close()
+        finally:
+            for k_, f_ in saved.items():
+                setattr(tdist, k_, f_)
         # shared minimizers on this rank: the job's vertex count x assemblies / minimizers, from the committed one-GPU run of the
         # same workload when there is one (a rank's own two shares are different stretches of the genome: its own graph says nothing)
         frac = 0.75
@@ -419,6 +452,7 @@ def dry_run(args):
         ranks.append({"rank": r, "bases": int(st["bases"]), "minimizers": m, "minimizers_by_assembly": per_asm,
                       "bases_by_assembly": [int(a_[2][:, 2].sum()) // N for a_ in asms],   # (equal base ranges of every assembly)
                       "sketch_ms": round(t_sk, 3), "graph_stage_on_own_minimizers_ms": round(t_gr, 3),
+                      "partitioned_graph_stage_ms": round(t_dg, 3), "partitioned_graph_stage_with_fixed_slots": dg_slots,
                       "kernel_ms_per_step": {"filter": round(st["ms_hash"] / args.steps, 3), "select (or count+reorder)": round(st["ms_reorder"] / args.steps, 3),
                                              "stretches (+resolve)": round(st["ms_resolve_kernel"] / args.steps, 3), "emit": round(st["ms_emit"] / args.steps, 3),
                                              "join": round(st["ms_join"] / args.steps, 3), "vertices": round(st["ms_vertices"] / args.steps, 3),
@@ -427,7 +461,7 @@ def dry_run(args):
         eng.close()
         del keep
         torch.cuda.empty_cache()
-    part_ms = max(x["sketch_ms"] + x["graph_stage_on_own_minimizers_ms"] + x["exchange_ms_at_link_rate"] for x in ranks) + 6 * 0.03
+    part_ms = max(x["sketch_ms"] + x["partitioned_graph_stage_ms"] + x["exchange_ms_at_link_rate"] for x in ranks) + 6 * 0.03
     # ... and as built since round 6: every assembly's items (16 B per minimizer to its hash's owner) leave in an all-to-all of their own
     # when that assembly's sketch ends, never before the assembly in front of it; verdicts and adjacency messages behind all of them
     part_ovl = 0.0
@@ -439,7 +473,7 @@ def dry_run(args):
             items_a = 16 * x["minimizers_by_assembly"][a] * (N - 1) / N / (N - 1)          # bytes per link
             c = max(c, t) + items_a / (XGMI_LINK_GBS * 1e9) * 1e3 + 0.03
         rest = (x["bytes_sent_per_step"]["verdicts"] + x["bytes_sent_per_step"]["adjacency_messages"]) / (N - 1) / (XGMI_LINK_GBS * 1e9) * 1e3
-        part_ovl = max(part_ovl, c + rest + x["graph_stage_on_own_minimizers_ms"] + 5 * 0.03)
+        part_ovl = max(part_ovl, c + rest + x["partitioned_graph_stage_ms"] + 5 * 0.03)
     # ---- the union route (ntjoin_amd/dist.py sketch_union_graph): every rank's sketch to every rank, the graph of the union on
     # every rank.  Its graph stage is measured on the real union of the ranks' sketches; an assembly's part is its fixed slot
     # (MXG_XCHG_SLOT_PCT above the largest share), all-gathered over N - 1 links at once (one part per link and direction).
@@ -488,7 +522,8 @@ def dry_run(args):
            "ms_per_step": round(step_ms, 3), "higher_is_better": True, "data": "synthetic", "dtype": "u64",
            "config": {"workload": label + f", rank shares of 1/{N} of every assembly's bases", "bases_per_step": int(bases_job)},
            "model": "partitioned: step = max over ranks of (sketch stage + exchange bytes / (N-1) links at "
-                    f"{XGMI_LINK_GBS:g} GB/s per link and direction + graph stage on as many minimizers as the rank owns) + 6 collectives x 30 us; "
+                    f"{XGMI_LINK_GBS:g} GB/s per link and direction + the route's own graph stage -- partitioned_graph() timed on one rank whose collectives are copies: the rank's packing, "
+                    "verdict and message kernels and the owner's kernels on as many minimizers as the rank owns; until round 6 the model took the one-GPU graph stage here, 3-4 x less) + 6 collectives x 30 us; "
                     "the five host syncs of the exact partitioned exchange are inside the measured stages' own syncs or not modelled; as built, an assembly's items leave when its sketch ends (sketch stage split by bases), one all-to-all per assembly, verdicts and messages behind them.  "
                     "union: an assembly's part = its fixed slot (12 B per entry + 4 B per record, MXG_XCHG_SLOT_PCT above the largest share) to every peer over its own link; "
                     "per assembly: ready when its sketch ends (sketch stage split by bases), gone one part-time + 30 us later, never before the part in front of it; "

@@ -717,10 +717,15 @@ __global__ __launch_bounds__(256) void k_dg_slots_to_soa(const unsigned char *__
 // the verdicts of assembly a's items, written where the items sat: out[src][off[a] + idx]
 __global__ __launch_bounds__(256) void k_dg_slot_results(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ ivid,
                                                          const unsigned char *__restrict__ recv, const DgSlots L, uint32_t a,
-                                                         const uint32_t *__restrict__ gbase_ptr, unsigned long long *out)
+                                                         const uint32_t *__restrict__ gbase_ptr, unsigned long long *out,
+                                                         const uint64_t *__restrict__ pj_fail, uint32_t *ovf)
 {
     const uint32_t cap = L.cap[a];
     const uint64_t o = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    // the owner's LDS join gave up (a key of huge multiplicity): flags and vertex ids mean nothing -- every item leaves as "no
+    // vertex", so that no message is built on them, and the step is reported as overflowed (all ranks repeat it the exact way)
+    const bool failed = *pj_fail != 0;
+    if (failed && o == 0) *ovf = 1;
     if (o >= (uint64_t)L.world * cap) return;
     const uint32_t src = (uint32_t)(o / cap), idx = (uint32_t)(o % cap);
     uint32_t before = 0, mine = 0;
@@ -729,8 +734,8 @@ __global__ __launch_bounds__(256) void k_dg_slot_results(const uint8_t *__restri
         if (s < src) before += c; else mine = c;
     }
     if (idx >= mine) return;
-    const uint32_t t = before + idx, v = ivid[t];
-    out[(size_t)src * L.items + L.off[a] + idx] = ((unsigned long long)(v == DG_NONE ? DG_NONE : v + *gbase_ptr) << 8) | flags[t];
+    const uint32_t t = before + idx, v = failed ? DG_NONE : ivid[t];
+    out[(size_t)src * L.items + L.off[a] + idx] = ((unsigned long long)(v == DG_NONE ? DG_NONE : v + *gbase_ptr) << 8) | (failed ? 0u : flags[t]);
 }
 
 // adjacency messages into slots of M messages per destination (header word 0 = count)
@@ -843,7 +848,7 @@ int dg_owner_slots(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t
     if (n_asm != h->asms.size()) return set_err(h, MXG_EINVAL, "slots: the owner handle has %zu assemblies", h->asms.size());
     MXG_HIP(h, h->d_nmx.ensure(MXG_MAX_ASSEMBLIES * 4 + 16));
     uint32_t *ovf = h->d_nmx.as<uint32_t>() + MXG_MAX_ASSEMBLIES;  // the word after the counts
-    MXG_HIP(h, hipMemsetAsync(ovf, 0, 4, h->stream));
+    MXG_HIP(h, hipMemsetAsync(ovf, 0, 16, h->stream));              // (... and the join's "failed" word behind it)
     GraphBounds gb;
     for (uint32_t ai = 0; ai < n_asm; ++ai) {
         Assembly *a = h->asms[ai];
@@ -885,7 +890,8 @@ int dg_slot_results(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_
         }
         hipLaunchKernelGGL(k_dg_slot_results, dim3((uint32_t)((bound + 255) / 256)), dim3(256), 0, h->stream,
                            a->d_flags.as<uint8_t>(), a->d_ivid.as<uint32_t>(), static_cast<const unsigned char *>(d_recv), L, ai,
-                           static_cast<const uint32_t *>(d_gbase), static_cast<unsigned long long *>(d_out));
+                           static_cast<const uint32_t *>(d_gbase), static_cast<unsigned long long *>(d_out), dg_pj_fail_word(h),
+                           h->d_nmx.as<uint32_t>() + MXG_MAX_ASSEMBLIES);
     }
     MXG_HIP(h, hipGetLastError());
     if (h->own_stream) MXG_HIP(h, hipStreamSynchronize(h->stream));
@@ -958,9 +964,10 @@ int dg_edges_slots(mxg_handle *h, const void *d_recv, uint32_t world, uint32_t M
     }
     int rc = build_graph(h, GRAPH_DG_EDGES_APPLIED);
     if (rc != MXG_OK) return rc;
-    uint32_t back[MXG_MAX_ASSEMBLIES + 1];
+    uint32_t back[MXG_MAX_ASSEMBLIES + 4];
     MXG_HIP(h, hipMemcpy(back, h->d_nmx.p, sizeof back, hipMemcpyDeviceToHost));
     for (uint32_t ai = 0; ai < A; ++ai) h->asms[ai]->n_mx = back[ai];  // the real item counts
+    if (back[MXG_MAX_ASSEMBLIES + 2] | back[MXG_MAX_ASSEMBLIES + 3]) h->dg_pj_off = true;  // (the LDS join failed: reported as overflow above)
     if (n_vertices) *n_vertices = g.nv;
     if (n_edges) *n_edges = g.ne;
     if (overflow) *overflow = back[MXG_MAX_ASSEMBLIES];

@@ -883,6 +883,7 @@ struct VertexPjParams {
     uint64_t *vhash;
     uint32_t *vpos, *vrec, *fv, *frec;  // [A][nvs]
     uint32_t nvs;
+    uint32_t *ivid[MXG_MAX_ASSEMBLIES];  // (owner of a partitioned graph stage: item -> vertex id, NONE32 for an item that is no vertex)
 };
 
 __global__ __launch_bounds__(256) void k_vertices_pj(const VertexPjParams p)
@@ -920,6 +921,7 @@ __global__ __launch_bounds__(256) void k_vertices_pj(const VertexPjParams p)
     }
     __syncthreads();
     const uint32_t r = sh_before + block_exclusive_256(f ? 1u : 0u, sh);
+    if (in && p.ivid[a]) p.ivid[a][i] = f ? (a ? v0 : r) : 0xFFFFFFFFu;
     if (!f) return;
     const uint32_t v = a ? v0 : r;
     if (!a) p.vhash[v] = hsh;
@@ -1184,7 +1186,10 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
     // reference that of a minimizer of the same assembly: < 2^29)
     uint64_t n_max = 0;
     for (uint32_t a = 0; a < A; ++a) n_max = std::max(n_max, n_of[a]);
-    const bool pj = mode == GRAPH_FULL && !global_table && (P1 == 0 || two_level) && P <= PJ_MAX_P &&
+    // (the owner's half of the partitioned graph stage takes the LDS join too when it runs over fixed slots -- gb: the counts on the
+    // device, nobody waits for the host before the verdicts leave -- and says "failed" through a DEVICE word: dg_pj_fail_word)
+    const bool dg_pj = mode == GRAPH_DG_VERTICES && gb != nullptr && !h->dg_pj_off;
+    const bool pj = (mode == GRAPH_FULL || dg_pj) && !global_table && (P1 == 0 || two_level) && P <= PJ_MAX_P &&
                     n_max < (1ull << 29) && !(join_env && !strcmp(join_env, "global"));
     const uint32_t pj_force_fail = knob_u64(h, "MXG_PJ_FORCE_FAIL", 0) ? 1u : 0u;
 
@@ -1242,6 +1247,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
     if (!h->pinned_gctl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_gctl, CTL_WORDS * 8));
     uint64_t *const hctl = h->pinned_gctl;
     memset(hctl, 0, CTL_WORDS * 8);
+    uint64_t *const pj_fail = mode == GRAPH_DG_VERTICES ? dg_pj_fail_word(h) : hctl + CTL_PJ_FAIL;  // (cleared by dg_owner_slots)
     if (nvs > 0 && (uint64_t)A * nvs >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "graph too large for 32-bit item indices");
     const size_t anv = (size_t)A * nvs;
     const uint32_t n_items = (uint32_t)anv;
@@ -1270,16 +1276,16 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         if (pipe_blocks && rows2 <= 256) {
             const uint32_t nblk = (uint32_t)std::min<uint64_t>(pipe_blocks, (uint64_t)P1 * P);
             if (A <= 16)
-                hipLaunchKernelGGL(k_pj_join_pipe<true>, dim3(nblk), dim3(256), 0, h->stream, recs2, M, P, P1 * P, hctl + CTL_PJ_FAIL,
+                hipLaunchKernelGGL(k_pj_join_pipe<true>, dim3(nblk), dim3(256), 0, h->stream, recs2, M, P, P1 * P, pj_fail,
                                    pj_force_fail, cursor, cap1, rows2, as_all);
             else
-                hipLaunchKernelGGL(k_pj_join_pipe<false>, dim3(nblk), dim3(256), 0, h->stream, recs2, M, P, P1 * P, hctl + CTL_PJ_FAIL,
+                hipLaunchKernelGGL(k_pj_join_pipe<false>, dim3(nblk), dim3(256), 0, h->stream, recs2, M, P, P1 * P, pj_fail,
                                    pj_force_fail, cursor, cap1, rows2, as_all);
         } else if (A <= 16)
-            hipLaunchKernelGGL(k_pj_join<true>, dim3(P1 * P), dim3(256), 0, h->stream, recs2, M, P, 0u, hctl + CTL_PJ_FAIL, pj_force_fail,
+            hipLaunchKernelGGL(k_pj_join<true>, dim3(P1 * P), dim3(256), 0, h->stream, recs2, M, P, 0u, pj_fail, pj_force_fail,
                                cursor, cap1, rows2, as_all);
         else
-            hipLaunchKernelGGL(k_pj_join<false>, dim3(P1 * P), dim3(256), 0, h->stream, recs2, M, P, 0u, hctl + CTL_PJ_FAIL, pj_force_fail,
+            hipLaunchKernelGGL(k_pj_join<false>, dim3(P1 * P), dim3(256), 0, h->stream, recs2, M, P, 0u, pj_fail, pj_force_fail,
                                cursor, cap1, rows2, as_all);
         hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, cnt, fsup, pj_mask0);
     } else if (nb && !resume && pj) {
@@ -1291,10 +1297,10 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
         hipLaunchKernelGGL(k_pj_bucket, dim3(n_rows), dim3(PJ_BT), (size_t)P * 8, h->stream, as_all, nb, P - 1, M, recs, fsup,
                            n_fsup + n_esup);
         if (A <= 16)
-            hipLaunchKernelGGL(k_pj_join<true>, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, hctl + CTL_PJ_FAIL, pj_force_fail, nullptr,
+            hipLaunchKernelGGL(k_pj_join<true>, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, pj_fail, pj_force_fail, nullptr,
                                0u, 0u, as_all);
         else
-            hipLaunchKernelGGL(k_pj_join<false>, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, hctl + CTL_PJ_FAIL, pj_force_fail, nullptr,
+            hipLaunchKernelGGL(k_pj_join<false>, dim3(P), dim3(256), 0, h->stream, recs, M, P, n_rows, pj_fail, pj_force_fail, nullptr,
                                0u, 0u, as_all);
         hipLaunchKernelGGL(k_flags_pj, dim3(nb), dim3(256), 0, h->stream, as_all, cnt, fsup, pj_mask0);
     } else if (nb && !resume) {
@@ -1319,6 +1325,11 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
             for (uint32_t a = 0; a < MXG_MAX_ASSEMBLIES; ++a) {
                 vp.pos[a] = a < A ? h->asms[a]->d_pos.as<uint32_t>() : nullptr;
                 vp.rec[a] = a < A ? h->asms[a]->d_rec.as<uint32_t>() : nullptr;
+                vp.ivid[a] = nullptr;
+                if (a < A && mode == GRAPH_DG_VERTICES) {
+                    MXG_HIP(h, h->asms[a]->d_ivid.ensure((size_t)n_of[a] * 4 + 16));
+                    vp.ivid[a] = h->asms[a]->d_ivid.as<uint32_t>();
+                }
             }
             vp.cnt = cnt;
             vp.sup = fsup;

@@ -244,6 +244,7 @@ struct mxg_handle {
     uint64_t pj_cap1_need = 0;   // cursors reported them (a key of large multiplicity skews the partitions)
     uint64_t pj_learnt_sig = 0;  // the sketches (count and sizes) the three fields around this one were learnt on
     bool pj_overflowed = false;  // graph stage: the partitioned join overflowed once (build_graph then starts with the global table)
+    bool dg_pj_off = false;      // owner of a partitioned graph stage: the LDS join failed once over the slots (global table from then on)
     uint64_t stat_retries = 0;   // assemblies enqueued a second time (their batches did not all end the common way)
     uint64_t stat_deferred = 0;  // candidate-free stretches the device route handed to the host
     uint64_t stat_batches_redone = 0, stat_sync_assemblies = 0;  // batches that did not end the common way / assemblies redone whole
@@ -421,6 +422,8 @@ int dg_pack_slots(mxg_handle *h, Assembly *a, uint32_t ai, uint32_t rec_offset, 
 int dg_pack_slots_dev(mxg_handle *h, Assembly *a, uint32_t ai, const DgPackReq &rq, hipStream_t st, uint32_t mode, const uint32_t *n_ptr,
                       const uint32_t *ctrl, uint64_t out_cap, uint32_t dev_gaps, uint32_t place4);
 int dg_owner_slots(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv, void *d_nv);
+// the words behind the per-assembly counts of d_nmx: [MXG_MAX_ASSEMBLIES] = a slot overflowed, then (8-byte aligned) "the owner's LDS join failed"
+inline uint64_t *dg_pj_fail_word(mxg_handle *h) { return reinterpret_cast<uint64_t *>(h->d_nmx.as<unsigned char>() + 4 * MXG_MAX_ASSEMBLIES + 8); }
 int dg_slot_results(mxg_handle *h, uint32_t world, uint32_t n_asm, const uint32_t *cap, const void *d_recv, const void *d_gbase,
                     void *d_out);
 int dg_pack_msg_slots(mxg_handle *h, uint32_t world, uint32_t M, const void *d_ret, const void *d_bases, void *d_send);

@@ -48,6 +48,19 @@ def test_both_overlapped_exchanges_at_a_size_where_they_really_run(world):
     assert out.stdout.count("beside the sketches") == world and out.stdout.count("per-assembly") == world, out.stdout[-3000:]
 
 
+def test_owner_falls_back_when_its_lds_join_fails():
+    """the owner's half of the partitioned route joins in LDS partitions when it runs over the fixed slots; a partition that
+    overflows (forced here: MXG_PJ_FORCE_FAIL) is reported through a device word -- every verdict of that step leaves as "no
+    vertex", the step counts as overflowed on every rank and is repeated the exact way (global table), and the handle stays with
+    the global table: same graph as a single handle"""
+    env = dict(os.environ, MXG_TEST_STREAM="1", MXG_TEST_CONFIG3="2", MXG_PJ_FORCE_FAIL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "tests", "_dist2_worker.py")]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("DIST2 OK") == 2, out.stdout[-3000:]
+
+
 def test_partitioned_graph_behind_sketches_of_the_callers_own():
     """the two-call form of the partitioned route (mxg_sketch, then partitioned_graph): the default of the other tests is the
     one call that sketches too and lets every assembly's items leave while the next assembly is sketched"""
