@@ -32,7 +32,7 @@ constexpr uint32_t BS_OUT_PAD = 4;          // words in front of OUT[0] (slot 0 
 
 // The filter.  Blocks of 256 threads = one wave per SIMD; the grid is sized for TWO waves per SIMD (an even number of waves
 // per SIMD issues at 2.05 cycles per instruction, an odd one at 2.5-2.7: profiles/ubench), every wave takes the chunks
-// c0, c0 + stride, ...  The body is generated (gen/bs_gen.py) and owns v8..v247 and s36..s82; the few values around it
+// c0, c0 + stride, ...  The body is generated (gen/bs_gen.py) and owns v8..v247 and s36..s87; the few values around it
 // stay in v0..v7.  `head` / `tail` = the padded copies of chunk 0's / chunk c_tail's words (the address of their word 0: two
 // more words lie in front of it).
 __global__ __launch_bounds__(256) void k_hash_bs(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ head,
