@@ -371,10 +371,14 @@ XGMI_LINK_GBS = 153.0 * 0.5   # one xGMI link, one direction (MI355X_MICROARCH.m
 
 def dry_run(args):
     """bench.py --gpus N --dry on one GPU: rank r = 0..N-1 of the N-GPU workload one after the other, each at its real share
-    (configs[4] for N = 8: 1/8 of the bases of both assemblies = 5 Gbp per rank), sketch stage timed for real; the exchange is
-    priced from the counts (16 B per minimizer to its hash's owner, 8 B verdict back, 16 B per adjacency message to each end
-    point's owner; (N-1)/N of it leaves the rank, spread over N-1 links); the owner's graph work is taken as the graph stage on
-    this rank's own minimizers (the same number of keys and records, not the same keys)."""
+    (configs[4] for N = 8: 1/8 of the bases of both assemblies = 5 Gbp per rank), sketch stage timed for real; the exchanges are
+    priced from the counts at the link rate (partitioned: 16 B per minimizer to its hash's owner, 8 B verdict back, 16 B per
+    adjacency message to each end point's owner, (N-1)/N of it leaves the rank, spread over N-1 links; union: the fixed part of
+    12 B per minimizer + 4 B per record to every peer over its own link).  The graph stages are TIMED through the code the real run
+    takes: the partitioned route's partitioned_graph() on the rank's own minimizers with its collectives replaced by copies (the
+    same number of keys and records as the rank would own, not the same keys), the union route's graph stage on the real union of
+    the ranks' sketches.  Both routes as built (an assembly's exchange beside the next assembly's sketch) and with every exchange
+    behind the sketches; value = the fastest, as the real run picks by measurement."""
     import torch
     from ntjoin_amd.engine import MxEngine
     N = args.gpus
