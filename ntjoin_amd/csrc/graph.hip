@@ -1247,7 +1247,7 @@ static int build_graph_impl(mxg_handle *h, int mode, const void *d_msgs, uint64_
     if (!h->pinned_gctl) MXG_HIP(h, hipHostMalloc((void **)&h->pinned_gctl, CTL_WORDS * 8));
     uint64_t *const hctl = h->pinned_gctl;
     memset(hctl, 0, CTL_WORDS * 8);
-    uint64_t *const pj_fail = mode == GRAPH_DG_VERTICES ? dg_pj_fail_word(h) : hctl + CTL_PJ_FAIL;  // (cleared by dg_owner_slots)
+    uint64_t *const pj_fail = dg_pj ? dg_pj_fail_word(h) : hctl + CTL_PJ_FAIL;  // (the device word: cleared by dg_owner_slots)
     if (nvs > 0 && (uint64_t)A * nvs >= (1ull << 32)) return set_err(h, MXG_ELIMIT, "graph too large for 32-bit item indices");
     const size_t anv = (size_t)A * nvs;
     const uint32_t n_items = (uint32_t)anv;

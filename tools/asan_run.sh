@@ -18,4 +18,7 @@ export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1:verify_asan_
 # about this library's memory, and nothing of it without the sanitizer.  The thread that registers the pieces is covered by the tsan run.)
 [ "$kind" = asan ] && export MXG_PIN_MALLOC=1
 export TSAN_OPTIONS=${TSAN_OPTIONS:-"suppressions=$root/tools/tsan.supp:halt_on_error=0:exitcode=66:report_signal_unsafe=0:second_deadlock_stack=1"}
+# (tests that use torch for device buffers: torch.cuda's lazy init dlopens libcaffe2_nvrtc.so by its bare name, and under the
+# preloaded sanitizer runtime -- whose dlopen interceptor is the caller then -- torch's own RUNPATH no longer applies)
+export LD_LIBRARY_PATH=$(python -c "import importlib.util, os; print(os.path.join(os.path.dirname(importlib.util.find_spec('torch').origin), 'lib'))"):$LD_LIBRARY_PATH
 cd "$root" && LD_PRELOAD=$rt python -m pytest "$@"
