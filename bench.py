@@ -330,7 +330,7 @@ def end_to_end(asms_host, w, td, threads):
     one = os.path.join(REPO, "ntjoin_amd", "bin", "mxgraph")
     # (every cold process is one sample of a noisy quantity -- one run in five or so loses 30-70 ms to the first kernels of the process:
     # each leg runs twice, the line carries both times and quotes the faster one)
-    t_one_all, phases, same = [], None, True
+    t_one_all, phases, same, phases_all = [], None, True, []
     for _rep in range(2):
         for t in tsvs + [os.path.join(td, "one.mx.dot")]:
             if os.path.exists(t):
@@ -340,8 +340,10 @@ def end_to_end(asms_host, w, td, threads):
         pr = subprocess.run([one, "-v", f"-k{K}", f"-w{w}", f"-t{threads}", "-p", os.path.join(td, "one"), "-s", fas[-1], "-l", "1",
                              "-r", " ".join(["2"] * (len(fas) - 1))] + fas[:-1], check=True, stderr=subprocess.PIPE, text=True)
         t_one_all.append(time.perf_counter() - t2)
+        ph = next((ln.split("mxgraph: ", 1)[1] for ln in pr.stderr.splitlines() if "device + handle" in ln), None)
+        phases_all.append(ph)
         if t_one_all[-1] == min(t_one_all):
-            phases = next((ln.split("mxgraph: ", 1)[1] for ln in pr.stderr.splitlines() if "device + handle" in ln), None)
+            phases = ph
         same = same and all(open(t, "rb").read(1 << 16) == two[t] for t in tsvs) and os.path.getsize(os.path.join(td, "one.mx.dot")) == dot_size
     t_one = min(t_one_all)
     # ... and the same once more with the worker attached (MXG_NO_DETACH=1): `mxgraph` does its work in a child and the parent
@@ -361,7 +363,7 @@ def end_to_end(asms_host, w, td, threads):
     t_attached = min(t_att_all)
     bases = sum(int(l.sum()) for _, _, l in asms_host)
     return {"bases": bases, "fasta_bytes": sizes, "t_sketch_cli": t_sketch, "t_graph_cli": t_graph, "t_one_process": t_one, "t_attached": t_attached,
-            "t_one_all": t_one_all, "t_attached_all": t_att_all,
+            "t_one_all": t_one_all, "t_attached_all": t_att_all, "phases_all": phases_all,
             "one_process_same_outputs": bool(same), "one_process_phases": phases,
             "tsv_bytes": sum(os.path.getsize(t) for t in tsvs), "dot_bytes": os.path.getsize(os.path.join(td, "out.mx.dot"))}
 
@@ -1239,7 +1241,7 @@ def main():
                     "route": "ntjoin_amd/bin/mxgraph (= `ntJoin-mx mxgraph`): FASTA -> TSVs + .mx.dot in one GPU process, cold (HIP init included); "
                              "the command forks: a worker does everything, the parent returns when every output is written and closed",
                     "seconds": round(e2e["t_one_process"], 3), "clock_stops": "when the parent returns (outputs closed; the worker's release of its HBM is not on it)",
-                    "seconds_of_every_run": [round(x, 3) for x in e2e["t_one_all"]],
+                    "seconds_of_every_run": [round(x, 3) for x in e2e["t_one_all"]], "phases_of_every_run": e2e["phases_all"],
                     "samples": "each leg twice, every run a cold process; `seconds` / `seconds_until_worker_exit` = the faster run, every run's time beside it",
                     "seconds_until_worker_exit": round(e2e["t_attached"], 3),
                     "seconds_until_worker_exit_of_every_run": [round(x, 3) for x in e2e["t_attached_all"]],
