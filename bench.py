@@ -1234,7 +1234,7 @@ def main():
                         csum = np.cumsum(lens.astype(np.int64))
                         n = min(int(np.searchsorted(csum, args.e2e_mbp * 1e6, side="left")) + 1, len(lens))
                         sample.append((words, starts[:n], lens[:n]))
-                e2e = end_to_end(sample, W, td, min(n_cores(), 8))
+                e2e = end_to_end(sample, W, td, int(os.environ.get("MXG_BENCH_E2E_THREADS", min(n_cores(), 8))))
                 t_all = e2e["t_sketch_cli"] + e2e["t_graph_cli"]
                 out["end_to_end"] = {
                     "value": round(e2e["bases"] / e2e["t_one_process"] / 1e9, 4), "unit": "Gbp/s",
@@ -1254,7 +1254,7 @@ def main():
                                 "(HIP init included): `indexlr` per assembly, then `python -m ntjoin_amd.run`" % W,
                     "bases": int(e2e["bases"]), "fasta_bytes": int(e2e["fasta_bytes"]), "tsv_bytes": int(e2e["tsv_bytes"]),
                     "dot_bytes": int(e2e["dot_bytes"]), "seconds_indexlr": round(e2e["t_sketch_cli"], 3),
-                    "seconds_graph": round(e2e["t_graph_cli"], 3), "threads": min(n_cores(), 8),
+                    "seconds_graph": round(e2e["t_graph_cli"], 3), "threads": int(os.environ.get("MXG_BENCH_E2E_THREADS", min(n_cores(), 8))),
                     "settle_s_before_each_route": E2E_SETTLE_S}
             finally:
                 shutil.rmtree(td, ignore_errors=True)
