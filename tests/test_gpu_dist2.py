@@ -329,3 +329,25 @@ def test_partitioned_graph_with_records_cut_between_ranks(tmp_path, world):
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("SPLIT OK") == world, out.stdout[-3000:]
+
+
+def test_bench_dry_run_prices_both_routes():
+    """`bench.py --gpus 2 --dry` (one GPU plays every rank in turn): one JSON line that times the sketch stage, the partitioned route's
+    own graph stage (partitioned_graph with copies for collectives) and the union's graph stage on the real union, prices the links,
+    and quotes the fastest of the four route variants -- small enough to run in seconds, so the shape of the line is what is checked"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry", "--steps", "2", "--warmup", "1", "--mbp", "50"]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["dry"] is True and d["n_gpus"] == 2 and d["value"] > 0
+    routes = d["routes_ms_per_step"]
+    assert len(routes) == 4 and abs(min(routes.values()) - d["ms_per_step"]) < 1e-6
+    assert d["union_graph"]["vertices"] > 1000 and d["union_graph"]["edges"] > 1000
+    for r in d["ranks"]:
+        assert r["partitioned_graph_stage_with_fixed_slots"] is True
+        assert r["partitioned_graph_stage_ms"] > 0 and r["sketch_ms"] > 0 and sum(r["minimizers_by_assembly"]) == r["minimizers"]
+    # 12 bytes per minimizer + 4 per record + the header, 10 % above the largest share
+    m0 = max(r["minimizers_by_assembly"][0] for r in d["ranks"])
+    assert 12 * m0 < d["union_part_bytes"][0] < 12 * m0 * 1.2 + 4096
