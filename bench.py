@@ -371,6 +371,16 @@ def end_to_end(asms_host, w, td, threads):
 XGMI_LINK_GBS = 153.0 * 0.5   # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, both directions)
 
 
+def exchange_beside_sketches(sketch_ms, send_ms):
+    """when the last of the per-assembly exchanges ends: assembly a is sketched behind assembly a - 1 (sketch_ms[a] each), its exchange
+    (send_ms[a]) starts when its sketch has ended AND the exchange of the assembly in front of it has (one communication stream)"""
+    t = c = 0.0
+    for s_a, x_a in zip(sketch_ms, send_ms):
+        t += s_a
+        c = max(c, t) + x_a
+    return c
+
+
 def dry_run(args):
     """bench.py --gpus N --dry on one GPU: rank r = 0..N-1 of the N-GPU workload one after the other, each at its real share
     (configs[4] for N = 8: 1/8 of the bases of both assemblies = 5 Gbp per rank), sketch stage timed for real; the exchanges are
@@ -486,11 +496,9 @@ def dry_run(args):
     part_ovl = 0.0
     for x in ranks:
         tot_b = max(sum(x["bases_by_assembly"]), 1)
-        t, c = 0.0, 0.0
-        for a in range(len(asms)):
-            t += x["sketch_ms"] * x["bases_by_assembly"][a] / tot_b
-            items_a = 16 * x["minimizers_by_assembly"][a] * (N - 1) / N / (N - 1)          # bytes per link
-            c = max(c, t) + items_a / (XGMI_LINK_GBS * 1e9) * 1e3 + 0.03
+        s_a = [x["sketch_ms"] * b / tot_b for b in x["bases_by_assembly"]]
+        items_ms = [16 * m_a * (N - 1) / N / (N - 1) / (XGMI_LINK_GBS * 1e9) * 1e3 + 0.03 for m_a in x["minimizers_by_assembly"]]  # (bytes per link)
+        c = exchange_beside_sketches(s_a, items_ms)
         rest = (x["bytes_sent_per_step"]["verdicts"] + x["bytes_sent_per_step"]["adjacency_messages"]) / (N - 1) / (XGMI_LINK_GBS * 1e9) * 1e3
         part_ovl = max(part_ovl, c + rest + x["partitioned_graph_stage_ms"] + 5 * 0.03)
     # ---- the union route (ntjoin_amd/dist.py sketch_union_graph): every rank's sketch to every rank, the graph of the union on
@@ -523,11 +531,7 @@ def dry_run(args):
     for x in ranks:
         tot_b = max(sum(x["bases_by_assembly"]), 1)
         s_a = [x["sketch_ms"] * b / tot_b for b in x["bases_by_assembly"]]   # the assemblies one behind the other
-        t, c = 0.0, 0.0
-        for a in range(len(asms)):
-            t += s_a[a]
-            c = max(c, t) + gather_ms[a]        # part a travels as soon as it is packed and the part before it has gone
-        union_ovl = max(union_ovl, c)
+        union_ovl = max(union_ovl, exchange_beside_sketches(s_a, gather_ms))  # part a travels as soon as it is packed and the part before it has gone
         union_one = max(union_one, x["sketch_ms"] + one_slot_bytes / link * 1e3 + 0.03)
     union_ovl += unpack_ms + t_union_graph
     union_one += unpack_ms + t_union_graph

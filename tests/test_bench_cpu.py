@@ -76,3 +76,18 @@ def test_own_launcher_stops_a_run_that_outlives_its_budget(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=_clean_env(), capture_output=True, text=True, timeout=120)
     assert out.returncode == 124, out.stderr[-2000:]
     assert "still running after 3 s" in out.stderr and "[rank 1] rank 1 sleeping" in out.stderr and "[rank 0] rank 0 sleeping" in out.stderr
+
+
+def test_exchange_beside_sketches_timeline():
+    """the dry run's model of an exchange per assembly on one communication stream: an exchange starts when its assembly is sketched
+    and the exchange in front of it has ended"""
+    import bench
+    f = bench.exchange_beside_sketches
+    assert f([1.0, 1.0], [0.5, 0.5]) == 2.5                 # each hides under the next sketch; the last one is exposed
+    assert f([1.0, 1.0], [3.0, 0.5]) == 4.5                 # the first is still travelling when the second is ready
+    assert f([0.5, 0.5, 0.5, 0.5], [0.2] * 4) == 2.2        # four assemblies: only the last exchange shows
+    assert f([1.0], [0.7]) == 1.7 and f([], []) == 0.0
+    # never better than everything behind the sketches, never worse than that either
+    import itertools
+    for sk, se in itertools.product([[0.3, 0.9, 0.1], [1.0, 1.0, 1.0]], [[0.5, 0.1, 0.8], [2.0, 2.0, 2.0]]):
+        assert max(sum(sk) + se[-1], sk[0] + sum(se)) - 1e-12 <= f(sk, se) <= sum(sk) + sum(se) + 1e-12
